@@ -1,0 +1,98 @@
+"""ctypes binding of libhyperseg_hip.so (include/hyperseg_hip.h).
+
+The library is the product: importing this module without the built .so raises, and every
+wrapper refuses non-CUDA / non-fp32 / non-contiguous tensors instead of falling back to anything.
+PyTorch is used only for device memory and the current HIP stream.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libhyperseg_hip.so')
+
+ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
+PAD_MODES = {'zeros': 0, 'reflect': 1, 'replicate': 2, 'circular': 3}
+PREV_NONE, PREV_SAME, PREV_BILINEAR = 0, 1, 2
+
+_STATUS = {-1: 'bad argument', -2: 'feature map does not tile into the weight grid (H % fh or W % fw != 0)',
+           -3: 'unsupported shape', -4: 'tile does not fit the LDS'}
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+class StageInputC(C.Structure):
+    _fields_ = [('skip', C.c_void_p), ('prev', C.c_void_p),
+                ('batch', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
+                ('c_skip', C.c_int32), ('c_prev', C.c_int32),
+                ('Hp', C.c_int32), ('Wp', C.c_int32),
+                ('coords', C.c_int32), ('prev_mode', C.c_int32)]
+
+
+class EpilogueC(C.Structure):
+    _fields_ = [('scale', C.c_void_p), ('shift', C.c_void_p), ('act', C.c_int32)]
+
+
+def _load():
+    if not os.path.exists(_LIB_PATH):
+        raise HipLibraryError(
+            f'{_LIB_PATH} is missing: build it with `python -m hyperseg_amd.build` (hipcc, gfx950). '
+            'hyperseg_amd has no fallback path.')
+    lib = C.CDLL(_LIB_PATH)
+    i32, i64, vp = C.c_int32, C.c_int64, C.c_void_p
+    sig = {
+        'hs_version': ([], C.c_int),
+        'hs_build_info': ([], C.c_char_p),
+        'hs_signal2weights_fwd': ([vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i64, vp], C.c_int),
+        'hs_bank_pack_fwd': ([vp, i32, i32, i32, i32, i32, vp, i32, vp, i64, vp], C.c_int),
+        'hs_bn_fold_fwd': ([vp, vp, vp, vp, C.c_float, i32, vp, vp, vp], C.c_int),
+        'hs_patch_conv_fwd': ([C.POINTER(StageInputC), i32, i32, vp, i64, i32, i32, i32, i32, i32,
+                               C.POINTER(EpilogueC), vp, vp], C.c_int),
+        'hs_patch_ir_fwd': ([C.POINTER(StageInputC), i32, i32, vp, i64, i32, i32, C.POINTER(EpilogueC),
+                             C.POINTER(EpilogueC), C.POINTER(EpilogueC), i32, vp, vp], C.c_int),
+        'hs_ir_row_map': ([i32, i32, i32, C.POINTER(i32)], C.c_int),
+        'hs_upsample_bilinear_fwd': ([vp, i32, i32, i32, i32, i32, i32, vp, vp], C.c_int),
+        'hs_stage_input_fwd': ([C.POINTER(StageInputC), vp, vp], C.c_int),
+    }
+    for name, (argtypes, restype) in sig.items():
+        fn = getattr(lib, name)          # AttributeError here = the .so does not match the header
+        fn.argtypes, fn.restype = argtypes, restype
+    if lib.hs_version() != 1:
+        raise HipLibraryError(f'ABI mismatch: library reports version {lib.hs_version()}, binding expects 1')
+    return lib
+
+
+lib = _load()
+EXPORTS = ['hs_version', 'hs_build_info', 'hs_signal2weights_fwd', 'hs_bank_pack_fwd', 'hs_bn_fold_fwd',
+           'hs_patch_conv_fwd', 'hs_patch_ir_fwd', 'hs_ir_row_map', 'hs_upsample_bilinear_fwd',
+           'hs_stage_input_fwd']
+
+
+def check(status, what):
+    if status == 0:
+        return
+    if status < 0:
+        raise HipLibraryError(f'{what}: {_STATUS.get(status, status)}')
+    raise HipLibraryError(f'{what}: HIP launch failed with hipError_t {status}')
+
+
+def dev_ptr(t, name='tensor', dtype=torch.float32):
+    """Device pointer of a tensor the kernels can consume as-is; raises otherwise (no silent copies)."""
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f'{name} must be a torch.Tensor')
+    if not t.is_cuda:
+        raise HipLibraryError(f'{name} is on {t.device}: the HyperSeg decoder path runs on an MI355X only '
+                              '(hyperseg_amd has no CPU fallback)')
+    if t.dtype != dtype:
+        raise HipLibraryError(f'{name} must be {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise HipLibraryError(f'{name} must be contiguous')
+    return t.data_ptr()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,122 @@
+// Shared device helpers of the HyperSeg decoder kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "hyperseg_hip.h"
+
+namespace hs {
+
+constexpr int kWave = 64;   // CDNA wavefront
+
+// Device-side copy of hs_stage_input with derived constants.
+struct StageIn {
+    const float* __restrict__ skip;
+    const float* __restrict__ prev;
+    int B, H, W, c_skip, c_prev, Hp, Wp, coords, prev_mode;
+    float step_x, step_y;     // linspace steps 2/(W-1), 2/(H-1)
+    float scale_y, scale_x;   // Hp/H, Wp/W (bilinear source scale, align_corners=False)
+    __host__ __device__ int cin() const { return 2 * coords + c_skip + c_prev; }
+};
+
+// torch.linspace(-1, 1, n)[i]: symmetric evaluation (start + step*i below the midpoint,
+// end - step*(n-1-i) above it), as ATen's linspace kernel does.
+__device__ __forceinline__ float linspace_pm1(int i, int n, float step) {
+    if (n == 1) return -1.0f;
+    return (i < n / 2) ? (-1.0f + step * (float)i) : (1.0f - step * (float)(n - 1 - i));
+}
+
+// Index map of F.pad for one axis.  Returns -1 for "zero" (HS_PAD_ZEROS outside the image).
+__device__ __forceinline__ int pad_index(int i, int n, int mode) {
+    if (i >= 0 && i < n) return i;
+    switch (mode) {
+        case HS_PAD_REFLECT:   i = (i < 0) ? -i : 2 * (n - 1) - i; return i;
+        case HS_PAD_REPLICATE: return (i < 0) ? 0 : n - 1;
+        case HS_PAD_CIRCULAR:  i %= n; return (i < 0) ? i + n : i;
+        default:               return -1;
+    }
+}
+
+// Bilinear taps of F.interpolate(mode='bilinear', align_corners=False) for one axis.
+struct Tap { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Tap bilinear_tap(int dst, float scale, int in_size) {
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    src = src < 0.0f ? 0.0f : src;
+    int i0 = (int)src;
+    i0 = i0 > in_size - 1 ? in_size - 1 : i0;
+    Tap t;
+    t.i0 = i0;
+    t.i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+    t.l1 = src - (float)i0;
+    t.l0 = 1.0f - t.l1;
+    return t;
+}
+
+// Precomputed per-position sampling state of a stage input: everything that does not depend
+// on the channel.  (y, x) are in-image coordinates (already mapped through pad_index).
+struct StagePos {
+    int y, x;             // -1 in either => zero padding
+    Tap ty, tx;           // only valid for prev_mode == HS_PREV_BILINEAR
+};
+
+__device__ __forceinline__ StagePos stage_pos(const StageIn& s, int y, int x) {
+    StagePos p;
+    p.y = y; p.x = x;
+    if (s.prev_mode == HS_PREV_BILINEAR && y >= 0 && x >= 0) {
+        p.ty = bilinear_tap(y, s.scale_y, s.Hp);
+        p.tx = bilinear_tap(x, s.scale_x, s.Wp);
+    }
+    return p;
+}
+
+// Value of stage-input channel c of batch b at a sampled position.
+__device__ __forceinline__ float stage_value(const StageIn& s, int b, int c, const StagePos& p) {
+    if (p.y < 0 || p.x < 0) return 0.0f;
+    if (s.coords) {
+        if (c == 0) return linspace_pm1(p.x, s.W, s.step_x);
+        if (c == 1) return linspace_pm1(p.y, s.H, s.step_y);
+        c -= 2;
+    }
+    if (c < s.c_skip)
+        return s.skip[(((size_t)b * s.c_skip + c) * s.H + p.y) * s.W + p.x];
+    c -= s.c_skip;
+    const float* base = s.prev + ((size_t)b * s.c_prev + c) * s.Hp * s.Wp;
+    if (s.prev_mode == HS_PREV_SAME) return base[(size_t)p.y * s.Wp + p.x];
+    const float* r0 = base + (size_t)p.ty.i0 * s.Wp;
+    const float* r1 = base + (size_t)p.ty.i1 * s.Wp;
+    float top = p.tx.l0 * r0[p.tx.i0] + p.tx.l1 * r0[p.tx.i1];
+    float bot = p.tx.l0 * r1[p.tx.i0] + p.tx.l1 * r1[p.tx.i1];
+    return p.ty.l0 * top + p.ty.l1 * bot;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == HS_ACT_RELU)  return fmaxf(v, 0.0f);
+    if (act == HS_ACT_RELU6) return fminf(fmaxf(v, 0.0f), 6.0f);
+    return v;
+}
+
+// ---- host side ---------------------------------------------------------------------------
+inline int make_stage(const hs_stage_input* in, StageIn* out) {
+    if (!in || (!in->skip && in->c_skip > 0)) return HS_ERR_BAD_ARG;
+    if (in->batch <= 0 || in->H <= 0 || in->W <= 0 || in->c_skip < 0 || in->c_prev < 0) return HS_ERR_BAD_ARG;
+    if (in->c_prev > 0 && (in->prev == nullptr || in->prev_mode == HS_PREV_NONE)) return HS_ERR_BAD_ARG;
+    if (in->c_prev > 0 && (in->Hp <= 0 || in->Wp <= 0)) return HS_ERR_BAD_ARG;
+    if (in->prev_mode == HS_PREV_SAME && in->c_prev > 0 && (in->Hp != in->H || in->Wp != in->W)) return HS_ERR_BAD_ARG;
+    out->skip = in->skip; out->prev = in->prev;
+    out->B = in->batch; out->H = in->H; out->W = in->W;
+    out->c_skip = in->c_skip; out->c_prev = in->c_prev;
+    out->Hp = in->c_prev > 0 ? in->Hp : 1; out->Wp = in->c_prev > 0 ? in->Wp : 1;
+    out->coords = in->coords ? 1 : 0;
+    out->prev_mode = in->c_prev > 0 ? in->prev_mode : HS_PREV_NONE;
+    out->step_x = in->W > 1 ? 2.0f / (float)(in->W - 1) : 0.0f;
+    out->step_y = in->H > 1 ? 2.0f / (float)(in->H - 1) : 0.0f;
+    out->scale_y = (float)out->Hp / (float)in->H;
+    out->scale_x = (float)out->Wp / (float)in->W;
+    return HS_OK;
+}
+
+inline int launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? HS_OK : (int)e;
+}
+
+}  // namespace hs

@@ -1,0 +1,202 @@
+// Op A / Op B: dynamic patch-wise k x k convolution with a fused stage-input prologue
+// (coords + skip + bilinear-resized previous level, image-level padding) and a fused
+// BatchNorm-affine + activation epilogue.  One workgroup = one tile of one patch:
+//   1. the patch's filter bank (contiguous ld floats in HBM) is staged in LDS once,
+//   2. the input tile (with halo) is generated into LDS through the prologue,
+//   3. each thread produces outputs (o, pixel) with pixel fastest, so LDS reads of the tile are
+//      conflict-free and the weight reads are broadcasts; stores are row-contiguous.
+// These levels (k=1 levels 0-2 of HyperSeg-M/S, and every v0_1 conv) are bound by the bank read:
+// bytes/patch = hp*4, FLOPs/patch = 2*hp*ph*pw.
+#include "hs_common.h"
+
+namespace hs {
+
+struct ConvArgs {
+    StageIn in;
+    int fh, fw, ph, pw;
+    const float* __restrict__ bank;
+    long ld;
+    int cout, k, pad, pad_mode, groups, cin_g, cout_g;
+    const float* __restrict__ scale;
+    const float* __restrict__ shift;
+    int act;
+    float* __restrict__ y;
+    int TH, TW, tiles_y, tiles_x;   // output tile and tiles per patch
+    int w_stride;                   // LDS row stride of the staged bank (odd => conflict-free)
+};
+
+constexpr int CONV_THREADS = 256;
+
+__global__ __launch_bounds__(CONV_THREADS)
+void patch_conv_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    int blk = blockIdx.x;
+    const int tx_i = blk % a.tiles_x; blk /= a.tiles_x;
+    const int ty_i = blk % a.tiles_y; blk /= a.tiles_y;
+    const int patch = blk;                       // (b*fh + i)*fw + j
+    const int j = patch % a.fw, i = (patch / a.fw) % a.fh, b = patch / (a.fw * a.fh);
+
+    const int cin = a.in.cin();
+    const int kk = a.k * a.k;
+    const int wrow = a.cin_g * kk;               // weights per output channel
+    const int y0 = i * a.ph + ty_i * a.TH, x0 = j * a.pw + tx_i * a.TW;
+    const int th = min(a.TH, (i + 1) * a.ph - y0), tw = min(a.TW, (j + 1) * a.pw - x0);
+    const int HH = a.TH + 2 * a.pad, HW = a.TW + 2 * a.pad, tpos = HH * HW;
+
+    float* wl = lds;                                       // [cout][w_stride]
+    float* xl = lds + (size_t)a.cout * a.w_stride;         // [cin][tpos]
+
+    // 1. filter bank -> LDS (coalesced; rows re-strided to an odd stride)
+    const float* wp = a.bank + (size_t)patch * a.ld;
+    const int hp = a.cout * wrow;
+    for (int e = tid; e < hp; e += CONV_THREADS) {
+        const int o = e / wrow, r = e - o * wrow;
+        wl[o * a.w_stride + r] = wp[e];
+    }
+    // 2. input tile with halo through the fused prologue
+    for (int pos = tid; pos < tpos; pos += CONV_THREADS) {
+        const int u = pos / HW, v = pos - u * HW;
+        const int yy = pad_index(y0 + u - a.pad, a.in.H, a.pad_mode);
+        const int xx = pad_index(x0 + v - a.pad, a.in.W, a.pad_mode);
+        const StagePos sp = stage_pos(a.in, yy, xx);
+        for (int c = 0; c < cin; ++c) xl[c * tpos + pos] = stage_value(a.in, b, c, sp);
+    }
+    __syncthreads();
+
+    // 3. outputs
+    const int npix = a.TH * a.TW;
+    const int total = a.cout * npix;
+    for (int idx = tid; idx < total; idx += CONV_THREADS) {
+        const int o = idx / npix, pix = idx - o * npix;
+        const int u = pix / a.TW, v = pix - u * a.TW;
+        if (u >= th || v >= tw) continue;
+        const int g = o / a.cout_g;
+        const float* wr = wl + o * a.w_stride;
+        const float* xr = xl + (size_t)g * a.cin_g * tpos + u * HW + v;
+        float acc = 0.0f;
+        if (a.k == 1) {
+            for (int c = 0; c < a.cin_g; ++c) acc = fmaf(wr[c], xr[c * tpos], acc);
+        } else {
+            for (int c = 0; c < a.cin_g; ++c)
+                for (int ky = 0; ky < a.k; ++ky)
+                    for (int kx = 0; kx < a.k; ++kx)
+                        acc = fmaf(wr[(c * a.k + ky) * a.k + kx], xr[c * tpos + ky * HW + kx], acc);
+        }
+        if (a.scale) acc = fmaf(acc, a.scale[o], a.shift[o]);
+        acc = apply_act(acc, a.act);
+        a.y[(((size_t)b * a.cout + o) * a.in.H + (y0 + u)) * a.in.W + (x0 + v)] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ void stage_input_kernel(StageIn s, float* __restrict__ y) {
+    const size_t n = (size_t)s.B * s.cin() * s.H * s.W;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const int x = e % s.W; size_t r = e / s.W;
+        const int yy = r % s.H; r /= s.H;
+        const int c = r % s.cin(); const int b = r / s.cin();
+        y[e] = stage_value(s, b, c, stage_pos(s, yy, x));
+    }
+}
+
+// Bilinear resize (align_corners=False).  One thread = 4 consecutive output pixels of a row.
+__global__ __launch_bounds__(256)
+void upsample_bilinear_kernel(const float* __restrict__ x, int planes, int Hi, int Wi, int Ho, int Wo,
+                              float scale_y, float scale_x, float* __restrict__ y) {
+    const int wq = (Wo + 3) / 4;
+    const size_t n = (size_t)planes * Ho * wq;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const int q = e % wq; size_t r = e / wq;
+        const int yo = r % Ho; const size_t pl = r / Ho;
+        const Tap ty = bilinear_tap(yo, scale_y, Hi);
+        const float* r0 = x + (pl * Hi + ty.i0) * Wi;
+        const float* r1 = x + (pl * Hi + ty.i1) * Wi;
+        float out[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int xo = 4 * q + t;
+            const Tap tx = bilinear_tap(xo < Wo ? xo : Wo - 1, scale_x, Wi);
+            const float top = tx.l0 * r0[tx.i0] + tx.l1 * r0[tx.i1];
+            const float bot = tx.l0 * r1[tx.i0] + tx.l1 * r1[tx.i1];
+            out[t] = ty.l0 * top + ty.l1 * bot;
+        }
+        float* dst = y + (pl * Ho + yo) * Wo + 4 * q;
+        if ((Wo & 3) == 0) {
+            *reinterpret_cast<float4*>(dst) = make_float4(out[0], out[1], out[2], out[3]);
+        } else {
+            for (int t = 0; t < 4 && 4 * q + t < Wo; ++t) dst[t] = out[t];
+        }
+    }
+}
+
+}  // namespace hs
+
+using namespace hs;
+
+extern "C" int hs_patch_conv_fwd(const hs_stage_input* in, int32_t fh, int32_t fw, const float* bank, int64_t ld,
+                                 int32_t c_out, int32_t k, int32_t pad, int32_t pad_mode, int32_t groups,
+                                 const hs_epilogue* ep, float* y, void* stream) {
+    ConvArgs a;
+    int st = make_stage(in, &a.in);
+    if (st != HS_OK) return st;
+    if (!bank || !y || fh <= 0 || fw <= 0 || c_out <= 0 || k <= 0 || groups <= 0 || pad < 0) return HS_ERR_BAD_ARG;
+    if (2 * pad != k - 1) return HS_ERR_UNSUPPORTED;         // "same" convolutions only (every reference config)
+    if (pad_mode < HS_PAD_ZEROS || pad_mode > HS_PAD_CIRCULAR) return HS_ERR_BAD_ARG;
+    if (in->H % fh != 0 || in->W % fw != 0) return HS_ERR_NOT_DIVISIBLE;
+    const int cin = a.in.cin();
+    if (cin % groups != 0 || c_out % groups != 0) return HS_ERR_BAD_ARG;
+    if (pad_mode == HS_PAD_REFLECT && (pad >= in->H || pad >= in->W)) return HS_ERR_BAD_ARG;
+    a.fh = fh; a.fw = fw; a.ph = in->H / fh; a.pw = in->W / fw;
+    a.bank = bank; a.ld = ld;
+    a.cout = c_out; a.k = k; a.pad = pad; a.pad_mode = pad_mode; a.groups = groups;
+    a.cin_g = cin / groups; a.cout_g = c_out / groups;
+    if (ld < (int64_t)c_out * a.cin_g * k * k) return HS_ERR_BAD_ARG;
+    a.scale = ep ? ep->scale : nullptr; a.shift = ep ? ep->shift : nullptr; a.act = ep ? ep->act : HS_ACT_NONE;
+    if (a.scale && !a.shift) return HS_ERR_BAD_ARG;
+    a.y = y;
+    const int wrow = a.cin_g * k * k;
+    a.w_stride = wrow | 1;
+    // tile: whole patch if it fits the LDS budget, otherwise split (rows first, then columns)
+    const size_t budget = 96 * 1024;
+    const size_t wbytes = (size_t)c_out * a.w_stride * sizeof(float);
+    if (wbytes + (size_t)cin * (1 + 2 * pad) * (1 + 2 * pad) * sizeof(float) > 150 * 1024) return HS_ERR_LDS;
+    a.TW = a.pw > 64 ? 64 : a.pw;
+    a.TH = a.ph > 64 ? 64 : a.ph;
+    auto tile_bytes = [&](int th, int tw) { return wbytes + (size_t)cin * (th + 2 * pad) * (tw + 2 * pad) * sizeof(float); };
+    while (tile_bytes(a.TH, a.TW) > budget && (a.TH > 1 || a.TW > 1)) {
+        if (a.TH >= a.TW && a.TH > 1) a.TH = (a.TH + 1) / 2; else a.TW = (a.TW + 1) / 2;
+    }
+    a.tiles_y = (a.ph + a.TH - 1) / a.TH;
+    a.tiles_x = (a.pw + a.TW - 1) / a.TW;
+    const size_t lds = tile_bytes(a.TH, a.TW);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)patch_conv_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    const long blocks = (long)in->batch * fh * fw * a.tiles_y * a.tiles_x;
+    hipLaunchKernelGGL(patch_conv_kernel, dim3((unsigned)blocks), dim3(CONV_THREADS), lds, (hipStream_t)stream, a);
+    return launch_status();
+}
+
+extern "C" int hs_stage_input_fwd(const hs_stage_input* in, float* y, void* stream) {
+    StageIn s;
+    int st = make_stage(in, &s);
+    if (st != HS_OK) return st;
+    if (!y) return HS_ERR_BAD_ARG;
+    const size_t n = (size_t)s.B * s.cin() * s.H * s.W;
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
+    hipLaunchKernelGGL(stage_input_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s, y);
+    return launch_status();
+}
+
+extern "C" int hs_upsample_bilinear_fwd(const float* x, int32_t batch, int32_t channels, int32_t Hi, int32_t Wi,
+                                        int32_t Ho, int32_t Wo, float* y, void* stream) {
+    if (!x || !y || batch <= 0 || channels <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return HS_ERR_BAD_ARG;
+    const size_t n = (size_t)batch * channels * Ho * ((Wo + 3) / 4);
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256);
+    hipLaunchKernelGGL(upsample_bilinear_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       x, batch * channels, Hi, Wi, Ho, Wo, (float)Hi / (float)Ho, (float)Wi / (float)Wo, y);
+    return launch_status();
+}

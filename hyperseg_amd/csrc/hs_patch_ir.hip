@@ -1,0 +1,203 @@
+// Op C: the fused per-patch inverted residual of HyperSeg's k=3 decoder levels
+// (hyperseg_v1_0.py:328-376) -- the dominant kernel of the decoder (85 % of its FLOPs at
+// HyperSeg-M).  One workgroup = one (<=16x16)-pixel tile of one patch, one launch per level:
+//
+//   prologue   every thread owns ONE position of the (TH+2)x(TW+2) reflect-halo tile and builds
+//              its CIN-channel input column in REGISTERS straight from HBM (coords analytic, skip
+//              gather, previous level bilinear 2x) -- the concatenated / padded / unfolded input
+//              of the reference never exists.
+//   pw1        h1[h][pos] = relu6(bn1(sum_c W1[h][c] * T[c])): the patch's weights are uniform
+//              over the workgroup, so they arrive through the SCALAR cache (s_load) as SGPR
+//              operands of v_fmac -- no LDS traffic and no VGPRs for weights.  h1 goes to LDS
+//              in chunks of HC hidden channels (double-buffered, one barrier per chunk).
+//   dw + pw3   every thread owns ONE output pixel: 9 LDS reads of h1 per hidden channel,
+//              depthwise 3x3 + bn2 + relu6 in registers, then COUT FMAs into register
+//              accumulators with W3T[h][:] again as scalar operands.
+//   epilogue   bn3 (+ residual) and one store per (o, pixel); rows are contiguous.
+//
+// Hidden activations (hid x 324 floats per patch at HyperSeg-M level 4) never leave the CU.
+// Algorithmic HBM bytes per patch: bank (ld*4) + input tile + output tile.
+#include "hs_common.h"
+
+namespace hs {
+
+constexpr int IR_MAX_TILE = 16;                       // output tile edge
+constexpr int IR_HC = 16;                             // hidden channels per LDS chunk
+constexpr int IR_MAX_THREADS = 384;                   // >= 18*18 positions, multiple of 64
+
+struct IrArgs {
+    StageIn in;
+    int fh, fw, ph, pw;
+    const float* __restrict__ bank;
+    long ld;
+    int cin, hid, cout;
+    const float* __restrict__ s1; const float* __restrict__ b1;
+    const float* __restrict__ s2; const float* __restrict__ b2;
+    const float* __restrict__ s3; const float* __restrict__ b3;
+    float* __restrict__ y;
+    int TH, TW, tiles_y, tiles_x, residual;
+};
+
+__device__ __forceinline__ float relu6f(float v) { return fminf(fmaxf(v, 0.0f), 6.0f); }
+
+template <int CIN, int COUT, bool EXACT>
+__global__ __launch_bounds__(IR_MAX_THREADS)
+void patch_ir_kernel(IrArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x [IR_HC][npos]
+    const int tid = threadIdx.x;
+    int blk = blockIdx.x;
+    const int tx_i = blk % a.tiles_x; blk /= a.tiles_x;
+    const int ty_i = blk % a.tiles_y; blk /= a.tiles_y;
+    const int patch = blk;
+    const int j = patch % a.fw, i = (patch / a.fw) % a.fh, b = patch / (a.fw * a.fh);
+    const int cin = EXACT ? CIN : a.cin;
+    const int cout = EXACT ? COUT : a.cout;
+    const int hid = a.hid;
+
+    const int y0 = i * a.ph + ty_i * a.TH, x0 = j * a.pw + tx_i * a.TW;
+    const int th = min(a.TH, (i + 1) * a.ph - y0), tw = min(a.TW, (j + 1) * a.pw - x0);
+    const int HW = a.TW + 2, npos = (a.TH + 2) * HW, npix = a.TH * a.TW;
+
+    // ---- prologue: this thread's input column ------------------------------------------------
+    const bool has_pos = tid < npos;
+    float T[CIN];
+    {
+        const int pu = tid / HW, pv = tid - pu * HW;
+        const int yy = pad_index(y0 + pu - 1, a.in.H, HS_PAD_REFLECT);
+        const int xx = pad_index(x0 + pv - 1, a.in.W, HS_PAD_REFLECT);
+        const bool live = has_pos && pu < th + 2 && pv < tw + 2;
+        const StagePos sp = stage_pos(a.in, live ? yy : -1, live ? xx : -1);
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) T[c] = (EXACT || c < cin) ? stage_value(a.in, b, c, sp) : 0.0f;
+    }
+    const bool has_pix = tid < npix;
+    const int u = tid / a.TW, v = tid - u * a.TW;
+    const int dw_off = u * HW + v;
+
+    const float* __restrict__ wp = a.bank + (size_t)patch * a.ld;   // uniform -> scalar loads
+    const float* __restrict__ w1 = wp;
+    const float* __restrict__ kd = wp + (size_t)cin * hid;
+    const float* __restrict__ w3t = kd + (size_t)9 * hid;
+
+    float out[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) out[o] = 0.0f;
+
+    auto pw1_chunk = [&](int h0, float* buf) {
+        if (!has_pos) return;
+        const int hc = min(IR_HC, hid - h0);
+        for (int hh = 0; hh < hc; ++hh) {
+            const int h = h0 + hh;
+            const float* __restrict__ wr = w1 + (size_t)h * cin;
+            float acc = 0.0f;
+#pragma unroll
+            for (int c = 0; c < CIN; ++c)
+                if (EXACT || c < cin) acc = fmaf(wr[c], T[c], acc);
+            buf[hh * npos + tid] = relu6f(fmaf(acc, a.s1[h], a.b1[h]));
+        }
+    };
+    auto dw_pw3_chunk = [&](int h0, const float* buf) {
+        if (!has_pix) return;
+        const int hc = min(IR_HC, hid - h0);
+        for (int hh = 0; hh < hc; ++hh) {
+            const int h = h0 + hh;
+            const float* __restrict__ kr = kd + (size_t)h * 9;
+            const float* t = buf + hh * npos + dw_off;
+            float d = 0.0f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) d = fmaf(kr[ky * 3 + kx], t[ky * HW + kx], d);
+            d = relu6f(fmaf(d, a.s2[h], a.b2[h]));
+            const float* __restrict__ w3r = w3t + (size_t)h * cout;
+#pragma unroll
+            for (int o = 0; o < COUT; ++o)
+                if (EXACT || o < cout) out[o] = fmaf(w3r[o], d, out[o]);
+        }
+    };
+
+    float* buf0 = lds;
+    float* buf1 = lds + IR_HC * npos;
+    pw1_chunk(0, buf0);
+    __syncthreads();
+    int cur = 0;
+    for (int h0 = 0; h0 < hid; h0 += IR_HC) {
+        float* bc = cur ? buf1 : buf0;
+        float* bn = cur ? buf0 : buf1;
+        if (h0 + IR_HC < hid) pw1_chunk(h0 + IR_HC, bn);
+        dw_pw3_chunk(h0, bc);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue --------------------------------------------------------------------------
+    if (has_pix && u < th && v < tw) {
+        const int yy = y0 + u, xx = x0 + v;
+        StagePos sp;
+        if (a.residual) sp = stage_pos(a.in, yy, xx);
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) {
+            if (EXACT || o < cout) {
+                float r = fmaf(out[o], a.s3[o], a.b3[o]);
+                if (a.residual) r += stage_value(a.in, b, o, sp);
+                a.y[(((size_t)b * cout + o) * a.in.H + yy) * a.in.W + xx] = r;
+            }
+        }
+    }
+}
+
+template <int CIN, int COUT, bool EXACT>
+static int launch_ir(const IrArgs& a, int threads, size_t lds, long blocks, hipStream_t stream) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)patch_ir_kernel<CIN, COUT, EXACT>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL((patch_ir_kernel<CIN, COUT, EXACT>), dim3((unsigned)blocks), dim3(threads), lds, stream, a);
+    return launch_status();
+}
+
+}  // namespace hs
+
+using namespace hs;
+
+extern "C" int hs_patch_ir_fwd(const hs_stage_input* in, int32_t fh, int32_t fw, const float* bank, int64_t ld,
+                               int32_t hidden, int32_t c_out, const hs_epilogue* bn1, const hs_epilogue* bn2,
+                               const hs_epilogue* bn3, int32_t residual, float* y, void* stream) {
+    IrArgs a;
+    int st = make_stage(in, &a.in);
+    if (st != HS_OK) return st;
+    if (!bank || !y || !bn1 || !bn2 || !bn3 || fh <= 0 || fw <= 0 || hidden <= 0 || c_out <= 0) return HS_ERR_BAD_ARG;
+    if (!bn1->scale || !bn1->shift || !bn2->scale || !bn2->shift || !bn3->scale || !bn3->shift) return HS_ERR_BAD_ARG;
+    if (in->H % fh != 0 || in->W % fw != 0) return HS_ERR_NOT_DIVISIBLE;
+    if (in->H < 2 || in->W < 2) return HS_ERR_BAD_ARG;           // reflect padding by 1 needs >= 2 pixels
+    a.fh = fh; a.fw = fw; a.ph = in->H / fh; a.pw = in->W / fw;
+    a.bank = bank; a.ld = ld;
+    a.cin = a.in.cin(); a.hid = hidden; a.cout = c_out;
+    if (ld < (int64_t)a.cin * hidden + 9 * hidden + (int64_t)hidden * c_out) return HS_ERR_BAD_ARG;
+    a.s1 = bn1->scale; a.b1 = bn1->shift; a.s2 = bn2->scale; a.b2 = bn2->shift; a.s3 = bn3->scale; a.b3 = bn3->shift;
+    a.y = y;
+    if (residual && a.cin != c_out) return HS_ERR_BAD_ARG;        // use_res_connect (hyperseg_v1_0.py:295)
+    a.residual = residual ? 1 : 0;
+    a.TH = a.ph > IR_MAX_TILE ? IR_MAX_TILE : a.ph;
+    a.TW = a.pw > IR_MAX_TILE ? IR_MAX_TILE : a.pw;
+    a.tiles_y = (a.ph + a.TH - 1) / a.TH;
+    a.tiles_x = (a.pw + a.TW - 1) / a.TW;
+    const int npos = (a.TH + 2) * (a.TW + 2);
+    const int threads = ((npos + kWave - 1) / kWave) * kWave;
+    const size_t lds = (size_t)2 * IR_HC * npos * sizeof(float);
+    const long blocks = (long)in->batch * fh * fw * a.tiles_y * a.tiles_x;
+    hipStream_t s = (hipStream_t)stream;
+#define HS_IR_CASE(CI, CO) if (a.cin == CI && c_out == CO) return launch_ir<CI, CO, true>(a, threads, lds, blocks, s);
+    HS_IR_CASE(24, 16)   // HyperSeg-M / CamVid-S level 3
+    HS_IR_CASE(34, 19)   // HyperSeg-M level 4 (Cityscapes, 19 classes)
+    HS_IR_CASE(14, 8)    // HyperSeg-S level 3
+    HS_IR_CASE(26, 19)   // HyperSeg-S level 4
+    HS_IR_CASE(22, 12)   // CamVid-S level 4 (12 classes)
+#undef HS_IR_CASE
+    if (a.cin <= 16 && c_out <= 16) return launch_ir<16, 16, false>(a, threads, lds, blocks, s);
+    if (a.cin <= 32 && c_out <= 32) return launch_ir<32, 32, false>(a, threads, lds, blocks, s);
+    if (a.cin <= 64 && c_out <= 32) return launch_ir<64, 32, false>(a, threads, lds, blocks, s);
+    if (a.cin <= 128 && c_out <= 64) return launch_ir<128, 64, false>(a, threads, lds, blocks, s);
+    return HS_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,244 @@
+"""Tensor-level entry points of the HIP decoder kernels (thin wrappers over the C ABI).
+
+Vocabulary: a *bank* is the patch-major per-patch filter bank
+``bank[p, m]`` (p = (b*fh + i)*fw + j); a *stage input* is the lazy channel concatenation
+[coords | skip | resized previous level] that the reference materialises with torch.cat
+(hyperseg_v1_0.py:231-240) and the kernels generate on the fly.
+"""
+import ctypes as C
+
+import torch
+
+from . import _hip
+from ._hip import ACT_NONE, ACT_RELU, ACT_RELU6, PAD_MODES  # noqa: F401  (re-exported)
+
+BN_EPS_DEFAULT = 1e-5
+
+
+def _round_up(n, m):
+    return (n + m - 1) // m * m
+
+
+class StageInput:
+    """Lazy ``cat([coords(2)?, skip, resize(prev)?], dim=1)`` consumed by the stage kernels' prologue."""
+
+    def __init__(self, skip, prev=None, coords=False):
+        if skip.dim() != 4:
+            raise ValueError('skip must be (B, C, H, W)')
+        if prev is not None and (prev.dim() != 4 or prev.shape[0] != skip.shape[0]):
+            raise ValueError('prev must be (B, C, h, w) with the same batch as skip')
+        self.skip, self.prev, self.coords = skip, prev, bool(coords)
+
+    @property
+    def channels(self):
+        return 2 * self.coords + self.skip.shape[1] + (self.prev.shape[1] if self.prev is not None else 0)
+
+    @property
+    def shape(self):
+        b, _, h, w = self.skip.shape
+        return torch.Size((b, self.channels, h, w))
+
+    @property
+    def device(self):
+        return self.skip.device
+
+    def c_struct(self):
+        b, cs, h, w = self.skip.shape
+        st = _hip.StageInputC()
+        st.skip = _hip.dev_ptr(self.skip, 'stage input (skip)')
+        st.batch, st.H, st.W, st.c_skip = b, h, w, cs
+        st.coords = int(self.coords)
+        if self.prev is not None:
+            st.prev = _hip.dev_ptr(self.prev, 'stage input (prev)')
+            st.c_prev, st.Hp, st.Wp = self.prev.shape[1], self.prev.shape[2], self.prev.shape[3]
+            st.prev_mode = _hip.PREV_SAME if self.prev.shape[2:] == self.skip.shape[2:] else _hip.PREV_BILINEAR
+        else:
+            st.prev, st.c_prev, st.Hp, st.Wp, st.prev_mode = None, 0, 0, 0, _hip.PREV_NONE
+        return st
+
+    def materialize(self):
+        """The concatenated tensor itself (diagnostics / modules that cannot consume a lazy input)."""
+        st = self.c_struct()
+        y = torch.empty(self.shape, device=self.device, dtype=torch.float32)
+        _hip.check(_hip.lib.hs_stage_input_fwd(C.byref(st), y.data_ptr(), _hip.stream_ptr()), 'hs_stage_input_fwd')
+        return y
+
+
+def _channel_view(t, name):
+    """(device pointer, channels of the underlying buffer) of a (B, C, h, w) tensor that is contiguous
+    or a channel-range view ``base[:, a:b]`` of a contiguous tensor (what MetaSequential passes)."""
+    if t.dim() != 4:
+        raise ValueError(f'{name} must be 4-D (B, C, h, w), got {tuple(t.shape)}')
+    if not t.is_cuda or t.dtype != torch.float32:
+        _hip.dev_ptr(t, name)          # raises with the proper message
+    b, c, h, w = t.shape
+    sb, sc, sh, sw = t.stride()
+    plane = h * w
+    ok = (sw == 1 or w == 1) and (sh == w or h == 1) and (sc == plane or c == 1) and \
+         (b == 1 or (sb % plane == 0 and sb // plane >= c))
+    if not ok:
+        t = t.contiguous()
+        return t, t.data_ptr(), c
+    return t, t.data_ptr(), (sb // plane if b > 1 else c)
+
+
+def as_stage(x):
+    return x if isinstance(x, StageInput) else StageInput(x)
+
+
+def _epilogue(scale=None, shift=None, act=ACT_NONE):
+    ep = _hip.EpilogueC()
+    ep.scale = _hip.dev_ptr(scale, 'epilogue scale') if scale is not None else None
+    ep.shift = _hip.dev_ptr(shift, 'epilogue shift') if shift is not None else None
+    ep.act = int(act)
+    return ep
+
+
+def ir_row_map(cin, hidden, c_out, device):
+    """int32 row map of hs_patch_ir_fwd's bank order (W1 | K | W3 transposed) -> natural reference rows."""
+    rows = _hip.lib.hs_ir_row_map(cin, hidden, c_out, None)
+    buf = (C.c_int32 * rows)()
+    _hip.lib.hs_ir_row_map(cin, hidden, c_out, buf)
+    return torch.tensor(list(buf), dtype=torch.int32, device=device)
+
+
+def signal2weights(signal, wsw_t, signal_index, signal_channels, groups, rows, row_src=None, out=None):
+    """Grouped 1x1 conv of the signal slice -> patch-major bank (B*fh*fw, ld).  ``wsw_t`` is the
+    Conv2d weight transposed to (Cs/G, Wc).  Replaces signal2weights(...)[:, :hp] + permute copy."""
+    b, c_view, fh, fw = signal.shape
+    if signal_index + signal_channels > c_view:
+        raise ValueError(f'signal slice [{signal_index}, {signal_index + signal_channels}) exceeds the '
+                         f'{c_view} channels handed to the module')
+    signal, sig_ptr, c_signal = _channel_view(signal, 'signal')
+    wc = wsw_t.shape[1]
+    ld = _round_up(rows, 4)
+    if out is None:
+        out = torch.empty(b * fh * fw, ld, device=signal.device, dtype=torch.float32)
+    st = _hip.lib.hs_signal2weights_fwd(
+        sig_ptr, b, c_signal, fh, fw, signal_index, signal_channels, groups,
+        _hip.dev_ptr(wsw_t, 'wsw_t'), wc, _hip.dev_ptr(row_src, 'row_src', torch.int32), rows,
+        _hip.dev_ptr(out, 'bank'), out.stride(0), _hip.stream_ptr())
+    _hip.check(st, 'hs_signal2weights_fwd')
+    return out
+
+
+def bank_pack(w, ch_offset, rows, row_src=None, out=None):
+    """(B, hp_total, fh, fw) channel-major weights -> patch-major bank (B*fh*fw, ld)."""
+    b, c_view, fh, fw = w.shape
+    if row_src is None and ch_offset + rows > c_view:
+        raise ValueError(f'weight has {c_view} channels, the module needs {ch_offset + rows}')
+    w, w_ptr, hp_total = _channel_view(w, 'weight')
+    ld = _round_up(rows, 4)
+    if out is None:
+        out = torch.empty(b * fh * fw, ld, device=w.device, dtype=torch.float32)
+    st = _hip.lib.hs_bank_pack_fwd(w_ptr, b, hp_total, fh, fw, ch_offset,
+                                   _hip.dev_ptr(row_src, 'row_src', torch.int32), rows,
+                                   _hip.dev_ptr(out, 'bank'), out.stride(0), _hip.stream_ptr())
+    _hip.check(st, 'hs_bank_pack_fwd')
+    return out
+
+
+def bn_fold(gamma, beta, mean, var, eps=BN_EPS_DEFAULT):
+    n = mean.numel()
+    out = torch.empty(2, n, device=mean.device, dtype=torch.float32)
+    st = _hip.lib.hs_bn_fold_fwd(_hip.dev_ptr(gamma, 'bn weight'), _hip.dev_ptr(beta, 'bn bias'),
+                                 _hip.dev_ptr(mean, 'bn running_mean'), _hip.dev_ptr(var, 'bn running_var'),
+                                 float(eps), n, out[0].data_ptr(), out[1].data_ptr(), _hip.stream_ptr())
+    _hip.check(st, 'hs_bn_fold_fwd')
+    return out[0], out[1]
+
+
+def _bank_ptr(bank):
+    """A bank is any 2-D fp32 CUDA tensor whose rows are contiguous (row stride = ld)."""
+    if bank.dim() != 2 or bank.stride(1) != 1 and bank.shape[1] != 1:
+        raise ValueError('bank must be 2-D (patches, rows) with contiguous rows')
+    if not bank.is_cuda or bank.dtype != torch.float32:
+        _hip.dev_ptr(bank, 'bank')
+    return bank.data_ptr(), bank.stride(0)
+
+
+def patch_conv(x, grid, bank, c_out, k=1, padding=0, padding_mode='reflect', groups=1,
+               scale=None, shift=None, act=ACT_NONE):
+    """Op A / Op B with fused prologue (x may be a StageInput) and BN-affine + activation epilogue."""
+    stage = as_stage(x)
+    fh, fw = grid
+    b, _, h, w = stage.shape
+    st_in = stage.c_struct()
+    ep = _epilogue(scale, shift, act)
+    y = torch.empty(b, c_out, h, w, device=stage.device, dtype=torch.float32)
+    bank_ptr, ld = _bank_ptr(bank)
+    st = _hip.lib.hs_patch_conv_fwd(C.byref(st_in), fh, fw, bank_ptr, ld, c_out, k,
+                                    padding, PAD_MODES[padding_mode], groups, C.byref(ep), y.data_ptr(),
+                                    _hip.stream_ptr())
+    _hip.check(st, 'hs_patch_conv_fwd')
+    return y
+
+
+def patch_ir(x, grid, bank, hidden, c_out, bn1, bn2, bn3, residual=False):
+    """Op C: fused per-patch inverted residual.  bn* are (scale, shift) pairs; bank in "ir" row order."""
+    stage = as_stage(x)
+    fh, fw = grid
+    b, _, h, w = stage.shape
+    st_in = stage.c_struct()
+    e1, e2, e3 = _epilogue(*bn1), _epilogue(*bn2), _epilogue(*bn3)
+    y = torch.empty(b, c_out, h, w, device=stage.device, dtype=torch.float32)
+    bank_ptr, ld = _bank_ptr(bank)
+    st = _hip.lib.hs_patch_ir_fwd(C.byref(st_in), fh, fw, bank_ptr, ld, hidden, c_out,
+                                  C.byref(e1), C.byref(e2), C.byref(e3), int(bool(residual)), y.data_ptr(),
+                                  _hip.stream_ptr())
+    _hip.check(st, 'hs_patch_ir_fwd')
+    return y
+
+
+def upsample_bilinear(x, size):
+    """F.interpolate(x, size, mode='bilinear', align_corners=False)."""
+    b, c, hi, wi = x.shape
+    ho, wo = size
+    y = torch.empty(b, c, ho, wo, device=x.device, dtype=torch.float32)
+    st = _hip.lib.hs_upsample_bilinear_fwd(_hip.dev_ptr(x, 'x'), b, c, hi, wi, ho, wo, y.data_ptr(),
+                                           _hip.stream_ptr())
+    _hip.check(st, 'hs_upsample_bilinear_fwd')
+    return y
+
+
+# ------------------------------------------------------------------------------------------
+# small caches keyed on parameter versions (host-side only; nothing is hidden from autograd
+# because this path is inference-only: modules raise in training mode)
+# ------------------------------------------------------------------------------------------
+def _key(*tensors):
+    return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
+
+
+class FoldedBN:
+    """Per-module cache of the folded (scale, shift) of an eval-mode nn.BatchNorm2d."""
+
+    def __init__(self):
+        self._k, self._v = None, None
+
+    def get(self, bn):
+        if bn.training or not bn.track_running_stats:
+            raise NotImplementedError('hyperseg_amd: the HIP decoder path is inference-only in this build '
+                                      '(BatchNorm in training mode needs the backward kernels)')
+        ts = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        k = _key(*ts)
+        if k != self._k:
+            with torch.no_grad():
+                self._v = bn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
+            self._k = k
+        return self._v
+
+
+class TransposedS2W:
+    """Per-module cache of the signal2weights Conv2d weight transposed to (Cs/G, Wc)."""
+
+    def __init__(self):
+        self._k, self._v = None, None
+
+    def get(self, conv):
+        w = conv.weight
+        k = _key(w)
+        if k != self._k:
+            with torch.no_grad():
+                self._v = w.detach().reshape(w.shape[0], w.shape[1]).t().contiguous()
+            self._k = k
+        return self._v

@@ -1,0 +1,527 @@
+"""HyperSeg v1.0 on the MI355X decoder path -- drop-in for hyperseg/models/hyperseg_v1_0.py.
+
+Same class names, constructor arguments, ``forward(x, s)`` signatures, ``hyper_params`` bookkeeping
+and state-dict keys as the reference (HyperSeg-M Cityscapes and HyperSeg-S/L CamVid configs), so
+reference checkpoints load with ``strict=True``.  What differs is what runs:
+
+* the encoder (:mod:`.backbones.efficientnet`) and the context head (:class:`WeightMapper`) are
+  stock PyTorch-ROCm;
+* every decoder level is ONE fused HIP launch (plus one bank-producing launch): the stage input
+  ``cat(coords, skip, bilinear2x(prev))`` is generated inside the kernel's prologue, the per-patch
+  filter bank is produced patch-major by ``hs_signal2weights_fwd`` and consumed immediately, and
+  BatchNorm + ReLU/ReLU6 live in the epilogue (reference: hyperseg_v1_0.py:221-253, 328-376,
+  486-498: ~11-21 ATen kernels per level).
+
+Quirks kept on purpose: ``signal_index`` is 0 for every level (D-1), the
+signal reaches the modules through MetaSequential's clamped slice (D-2), ``weight_groups`` lists are
+consumed by ``pop(0)`` (D-3), coordinate buffers exist for checkpoint compatibility but the values
+are generated analytically (D-11).
+"""
+import numbers
+from functools import partial
+from itertools import groupby
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.modules.utils import _pair
+
+from .. import functional as HF
+from .layers.meta_conv import MetaConv2d, _require_inference
+from .layers.meta_sequential import MetaSequential
+
+
+def next_multiply(x, base):
+    return type(x)(np.ceil(x / base) * base)
+
+
+class _SignalToWeights:
+    """Mixin for the modules that own a ``signal2weights`` grouped 1x1 conv (hyperseg_v1_0.py:315-326,
+    473-484, 529-541).  ``_bank(s, rows, row_src)`` runs the conv as one HIP launch that writes the
+    patch-major bank directly; ``apply_signal2weights`` keeps the reference's tensor-returning form."""
+
+    def _init_s2w_state(self):
+        self.signal_channels = None
+        self.signal_index = None
+        self.signal2weights = None
+        self._s2w_t = HF.TransposedS2W()
+
+    def _make_signal2weights(self, signal_channels, signal_index, groups, weight_channels):
+        self.signal_channels = signal_channels
+        self.signal_index = signal_index
+        self.signal2weights = nn.Conv2d(signal_channels, weight_channels, 1, bias=False, groups=groups)
+
+    def _bank(self, s, rows, row_src=None):
+        conv = self.signal2weights
+        if conv is None:
+            # no hypernetwork head: ``s`` already holds the weights (B, hp, fh, fw)
+            return HF.bank_pack(s, 0, rows, row_src)
+        _require_inference(s, conv.weight)
+        return HF.signal2weights(s, self._s2w_t.get(conv), self.signal_index, self.signal_channels,
+                                 conv.groups, rows, row_src)
+
+    def apply_signal2weights(self, s):
+        """(B, hp, fh, fw) weights in the reference's channel-major layout (diagnostics / API parity)."""
+        if self.signal2weights is None:
+            return s
+        b, _, fh, fw = s.shape
+        hp = int(self.hyper_params)
+        bank = self._bank(s, hp)
+        return bank[:, :hp].reshape(b, fh, fw, hp).permute(0, 3, 1, 2)
+
+
+class HyperPatchNoPadding(nn.Module, _SignalToWeights):
+    """k=1 dynamic patch-wise conv fed by the signal (hyperseg_v1_0.py:455-498) -> Op A."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, dilation=1, groups=1):
+        super(HyperPatchNoPadding, self).__init__()
+        if in_channels % groups != 0:
+            raise ValueError('in_channels must be divisible by groups')
+        if out_channels % groups != 0:
+            raise ValueError('out_channels must be divisible by groups')
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = _pair(kernel_size)
+        self.stride = _pair(stride)
+        self.dilation = _pair(dilation)
+        self.groups = groups
+        self.hyper_params = int(np.prod((out_channels, in_channels // groups) + self.kernel_size))
+        self._init_s2w_state()
+
+    def init_signal2weights(self, signal_channels, signal_index=0, groups=1):
+        self._make_signal2weights(signal_channels, signal_index, groups, next_multiply(self.hyper_params, groups))
+
+    def forward_fused(self, x, s, scale=None, shift=None, act=HF.ACT_NONE):
+        if self.kernel_size != (1, 1) or self.stride != (1, 1) or self.dilation != (1, 1):
+            raise NotImplementedError('HyperPatchNoPadding: only the k=1, stride 1 form the reference builds '
+                                      '(padding == 0 <=> kernel_size == 1, hyperseg_v1_0.py:748-750)')
+        fh, fw = s.shape[-2:]
+        bank = self._bank(s, self.hyper_params)
+        return HF.patch_conv(x, (fh, fw), bank, self.out_channels, 1, 0, 'zeros', self.groups, scale, shift, act)
+
+    def forward(self, x, s):
+        return self.forward_fused(x, s)
+
+
+class HyperPatch(nn.Module, _SignalToWeights):
+    """Dynamic patch-wise block with image-level padding fed by the signal (hyperseg_v1_0.py:501-557)."""
+
+    def __init__(self, module: nn.Module, padding=0, padding_mode='reflect'):
+        super(HyperPatch, self).__init__()
+        valid_padding_modes = {'zeros', 'reflect', 'replicate', 'circular'}
+        if padding_mode not in valid_padding_modes:
+            raise ValueError(
+                f"padding_mode must be one of {valid_padding_modes}, but got padding_mode='{padding_mode}'")
+        self.hyper_module = module
+        self.padding = _pair(padding)
+        self.padding_mode = padding_mode
+        self._init_s2w_state()
+
+    @property
+    def hyper_params(self):
+        return self.hyper_module.hyper_params
+
+    def init_signal2weights(self, signal_channels, signal_index=0, groups=1):
+        # NB: no next_multiply here in the reference (hyperseg_v1_0.py:532-535)
+        self._make_signal2weights(signal_channels, signal_index, groups, self.hyper_params)
+
+    def forward_fused(self, x, s, scale=None, shift=None, act=HF.ACT_NONE):
+        conv = self.hyper_module
+        if not isinstance(conv, MetaConv2d):
+            raise NotImplementedError('hyperseg_amd.HyperPatch has a HIP kernel only for a wrapped MetaConv2d')
+        k, inner_pad = conv._check_supported()
+        if inner_pad != 0 or self.padding[0] != self.padding[1]:
+            raise NotImplementedError('HyperPatch expects the wrapped conv to be unpadded')
+        fh, fw = s.shape[-2:]
+        bank = self._bank(s, conv.hyper_params)
+        return HF.patch_conv(x, (fh, fw), bank, conv.out_channels, k, self.padding[0], self.padding_mode,
+                             conv.groups, scale, shift, act)
+
+    def forward(self, x, s):
+        return self.forward_fused(x, s)
+
+
+class HyperPatchConv2d(HyperPatch):
+    """forward(x (B,C,H,W), s (B,Cs,fh,fw)) -> (B,Cout,H,W) (hyperseg_v1_0.py:560-725)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 padding_mode='reflect'):
+        conv = MetaConv2d(in_channels, out_channels, kernel_size, stride, 0, dilation, groups)
+        super(HyperPatchConv2d, self).__init__(conv, padding, padding_mode)
+
+    @property
+    def in_channels(self):
+        return self.hyper_module.in_channels
+
+    @property
+    def out_channels(self):
+        return self.hyper_module.out_channels
+
+    @property
+    def kernel_size(self):
+        return self.hyper_module.kernel_size
+
+    @property
+    def groups(self):
+        return self.hyper_module.groups
+
+
+class HyperPatchInvertedResidual(nn.Module, _SignalToWeights):
+    """Per-patch MobileNetV2 block on a reflect halo tile (hyperseg_v1_0.py:281-376) -> Op C, one launch."""
+
+    def __init__(self, in_nc, out_nc, kernel_size=3, stride=1, expand_ratio=1, norm_layer=nn.BatchNorm2d,
+                 act_layer=nn.ReLU6(inplace=True), padding_mode='reflect'):
+        super(HyperPatchInvertedResidual, self).__init__()
+        self.stride = stride
+        assert stride in [1, 2]
+        self.padding_mode = padding_mode
+        self.padding = (1, 1)
+        self.in_nc = in_nc
+        self.out_nc = out_nc
+        self.kernel_size = _pair(kernel_size)
+        self.hidden_dim = int(round(in_nc * expand_ratio))
+        self.use_res_connect = self.stride == 1 and in_nc == out_nc
+        self.act_layer = act_layer
+        self.bn1 = norm_layer(self.hidden_dim)
+        self.bn2 = norm_layer(self.hidden_dim)
+        self.bn3 = norm_layer(self.out_nc)
+
+        # flat weight ranges: pw1 | dw | pw3
+        self._ranges = [0, in_nc * self.hidden_dim]
+        self._ranges.append(self._ranges[-1] + int(np.prod((self.hidden_dim,) + self.kernel_size)))
+        self._ranges.append(self._ranges[-1] + self.hidden_dim * out_nc)
+        self.hyper_params = self._ranges[-1]
+        self._init_s2w_state()
+        self._folded = [HF.FoldedBN(), HF.FoldedBN(), HF.FoldedBN()]
+        self._row_src = None
+
+    def init_signal2weights(self, signal_channels, signal_index=0, groups=1):
+        self._make_signal2weights(signal_channels, signal_index, groups, next_multiply(self.hyper_params, groups))
+
+    def _check_supported(self):
+        if self.kernel_size != (3, 3) or self.stride != 1 or self.padding_mode != 'reflect' or \
+                not isinstance(self.act_layer, nn.ReLU6) or \
+                not all(isinstance(b, nn.BatchNorm2d) for b in (self.bn1, self.bn2, self.bn3)):
+            raise NotImplementedError('hs_patch_ir_fwd implements the block every reference config builds: '
+                                      '3x3 depthwise, stride 1, reflect halo, BatchNorm2d, ReLU6')
+
+    def _rows(self, device):
+        if self._row_src is None or self._row_src.device != device:
+            self._row_src = HF.ir_row_map(self.in_nc, self.hidden_dim, self.out_nc, device)
+        return self._row_src
+
+    def _run(self, x, s, residual):
+        self._check_supported()
+        stage = HF.as_stage(x)
+        if stage.channels != self.in_nc:
+            raise ValueError(f'expected {self.in_nc} input channels, got {stage.channels}')
+        fh, fw = s.shape[-2:]
+        bank = self._bank(s, self.hyper_params, self._rows(stage.device))
+        bns = [f.get(bn) for f, bn in zip(self._folded, (self.bn1, self.bn2, self.bn3))]
+        return HF.patch_ir(stage, (fh, fw), bank, self.hidden_dim, self.out_nc, *bns, residual=residual)
+
+    def conv(self, x, s):
+        return self._run(x, s, False)
+
+    def forward(self, x, s):
+        return self._run(x, s, self.use_res_connect)
+
+
+def make_hyper_patch_conv2d_block(in_nc, out_nc, kernel_size=3, stride=1, padding=None, dilation=1, groups=1,
+                                  padding_mode='reflect', norm_layer=nn.BatchNorm2d, act_layer=nn.ReLU(True),
+                                  dropout=None):
+    """[HyperPatchNoPadding | HyperPatchConv2d, norm, act, Dropout?] (hyperseg_v1_0.py:728-760)."""
+    assert dropout is None or isinstance(dropout, float)
+    padding = kernel_size // 2 if padding is None else padding
+    if padding == 0:
+        layers = [HyperPatchNoPadding(in_nc, out_nc, kernel_size, stride, dilation, groups)]
+    else:
+        layers = [HyperPatchConv2d(in_nc, out_nc, kernel_size, stride, padding, dilation, groups, padding_mode)]
+    if norm_layer is not None:
+        layers.append(norm_layer(out_nc))
+    if act_layer is not None:
+        layers.append(act_layer)
+    if dropout is not None:
+        layers.append(nn.Dropout(dropout))
+    return MetaSequential(*layers)
+
+
+_HYPER_TYPES = (HyperPatchConv2d, HyperPatchNoPadding, HyperPatchInvertedResidual)
+
+
+def get_hyper_params(model):
+    """hyper_params of every signal-fed module, depth first (hyperseg_v1_0.py:256-266)."""
+    found = []
+    for _, m in model.named_children():
+        if isinstance(m, _HYPER_TYPES):
+            found.append(m.hyper_params)
+        else:
+            found.extend(get_hyper_params(m))
+    return found
+
+
+def init_signal2weights(model, signal_features, signal_index=0, weight_groups=1):
+    """Hands every signal-fed module its share of signal channels and its group count, depth first.
+
+    Faithful to hyperseg_v1_0.py:269-278 including its quirk: the running ``signal_index`` advances
+    only across DIRECT children of one container and is not propagated back out of a recursion, so
+    with one hyper-module per level every level reads signal channels starting at 0 (Appendix D-1)."""
+    for _, m in model.named_children():
+        if isinstance(m, _HYPER_TYPES):
+            nc = signal_features.pop(0)
+            g = weight_groups.pop(0) if isinstance(weight_groups, list) else weight_groups
+            m.init_signal2weights(nc, signal_index, g)
+            signal_index += nc
+        else:
+            init_signal2weights(m, signal_features, signal_index, weight_groups)
+
+
+def divide_feature(in_feature, out_features, min_unit=8):
+    """Split ``in_feature`` channels between consumers in proportion to ``out_features``, in multiples
+    of ``min_unit``; equal consumers get equal shares and the group with the smallest total takes the
+    remainder.  Must reproduce hyperseg_v1_0.py:763-810 exactly (checkpoint shapes depend on it)."""
+    assert in_feature % min_unit == 0, f'in_feature ({in_feature}) must be divisible by min_unit ({min_unit})'
+    units = in_feature // min_unit
+    order = np.argsort(out_features)
+    sorted_vals = np.array(out_features)[order]
+    groups = [(val, order[list(idx)]) for val, idx in groupby(range(len(order)), lambda i: sorted_vals[i])]
+    groups.sort(key=lambda g: g[0] * len(g[1]), reverse=True)
+    ratio = float(units) / sum(out_features)
+    share = [len(members) for _, members in groups]          # one unit per consumer to start with
+    left = units - sum(share)
+    for gi, (val, members) in enumerate(groups):
+        if gi == len(groups) - 1:
+            share[-1] += left
+            break
+        n = len(members)
+        want = max(val * n * ratio, n)
+        want = want // n * n - n                             # float floor-division, as the reference
+        want = min(want, left)
+        share[gi] += want
+        left -= want
+        if left == 0:
+            break
+    out = np.zeros(len(out_features), dtype=int)
+    for gi, (_, members) in enumerate(groups):
+        for m in members:
+            out[m] = share[gi] // len(members) * min_unit
+    return out
+
+
+class MultiScaleDecoder(nn.Module):
+    """Dynamic multi-scale decoder (hyperseg_v1_0.py:94-253).  ``forward(x, s)``: x = list of feature
+    maps fine -> coarse including the input image, s = signal (B, Cs, H/32, W/32)."""
+
+    def __init__(self, feat_channels, signal_channels, num_classes=3, kernel_sizes=3, level_layers=1,
+                 level_channels=None, norm_layer=nn.BatchNorm2d, act_layer=nn.ReLU6(inplace=True), out_kernel_size=1,
+                 expand_ratio=1, groups=1, weight_groups=1, with_out_fc=False, dropout=None, coords_res=None):
+        super(MultiScaleDecoder, self).__init__()
+        n = len(level_channels)
+        if isinstance(kernel_sizes, numbers.Number):
+            kernel_sizes = (kernel_sizes,) * n
+        if isinstance(level_layers, numbers.Number):
+            level_layers = (level_layers,) * n
+        if isinstance(expand_ratio, numbers.Number):
+            expand_ratio = (expand_ratio,) * n
+        assert len(kernel_sizes) == n, f'kernel_sizes ({len(kernel_sizes)}) must be of size {n}'
+        assert len(level_layers) == n, f'level_layers ({len(level_layers)}) must be of size {n}'
+        assert len(expand_ratio) == n, f'expand_ratio ({len(expand_ratio)}) must be of size {n}'
+        if isinstance(groups, (list, tuple)):
+            assert len(groups) == n, f'groups ({len(groups)}) must be of size {n}'
+        self.level_layers = level_layers
+        self.levels = n
+        self.layer_params = []
+        feat_channels = feat_channels[::-1]          # coarse -> fine
+        self.coords_cache = {}
+        self.weight_groups = weight_groups
+
+        prev_channels = 0
+        for level in range(self.levels):
+            curr_ngf = feat_channels[level]
+            curr_out_ngf = curr_ngf if level_channels is None else level_channels[level]
+            prev_channels += curr_ngf
+            curr_layers = []
+            k = kernel_sizes[level]
+            for layer in range(self.level_layers[level]):
+                if (not with_out_fc) and level == self.levels - 1 and layer == self.level_layers[level] - 1:
+                    curr_out_ngf = num_classes
+                if k > 1:
+                    curr_layers.append(HyperPatchInvertedResidual(
+                        prev_channels + 2, curr_out_ngf, k, expand_ratio=expand_ratio[level],
+                        norm_layer=norm_layer, act_layer=act_layer))
+                else:
+                    group = groups[level] if isinstance(groups, (list, tuple)) else groups
+                    curr_layers.append(make_hyper_patch_conv2d_block(prev_channels + 2, curr_out_ngf, k, groups=group))
+                prev_channels = curr_out_ngf
+            self.add_module(f'level_{level}', MetaSequential(*curr_layers))
+
+        if with_out_fc:
+            out_fc_layers = [nn.Dropout2d(dropout, True)] if dropout is not None else []
+            out_fc_layers.append(
+                HyperPatchConv2d(prev_channels, num_classes, out_kernel_size, padding=out_kernel_size // 2))
+            self.out_fc = MetaSequential(*out_fc_layers)
+        else:
+            self.out_fc = None
+
+        # per-level hyper-parameter bookkeeping
+        self.hyper_params = 0
+        self._ranges = [0]
+        self.param_groups = []
+        for level in range(self.levels):
+            lp = getattr(self, f'level_{level}').hyper_params
+            self.hyper_params += lp
+            self._ranges.append(self.hyper_params)
+            self.param_groups.append(lp)
+        if with_out_fc:
+            self.hyper_params += self.out_fc.hyper_params
+            self.param_groups.append(self.out_fc.hyper_params)
+        self._ranges.append(self.hyper_params)
+
+        # coordinate buffers: kept so reference checkpoints load strictly; the kernels generate the
+        # same values analytically and never read them
+        if coords_res is not None:
+            for res in coords_res:
+                for i in range(self.levels):
+                    h, w = res[0] // 2 ** i, res[1] // 2 ** i
+                    self.register_buffer(f'coord{h}_{w}', self.cache_image_coordinates(h, w))
+
+        hyper_params = get_hyper_params(self)
+        min_unit = max(weight_groups) if isinstance(weight_groups, (list, tuple)) else weight_groups
+        signal_features = divide_feature(signal_channels, hyper_params, min_unit=min_unit)
+        init_signal2weights(self, list(signal_features), weight_groups=weight_groups)
+        self.hyper_params = sum(hyper_params)
+
+    def cache_image_coordinates(self, h, w):
+        x = torch.linspace(-1, 1, steps=w)
+        y = torch.linspace(-1, 1, steps=h)
+        return torch.stack([x.view(1, w).expand(h, w), y.view(h, 1).expand(h, w)], dim=0).unsqueeze(0).contiguous()
+
+    def get_image_coordinates(self, b, h, w, device):
+        cache = f'coord{h}_{w}'
+        if hasattr(self, cache):
+            return getattr(self, cache).expand(b, -1, -1, -1)
+        return self.cache_image_coordinates(h, w).to(device).expand(b, -1, -1, -1)
+
+    def forward(self, x, s):
+        p = None
+        for level in range(self.levels):
+            level_layers = getattr(self, f'level_{level}')
+            # cat(coords, skip, bilinear(p)) is never built: the stage kernel's prologue generates it
+            stage = HF.StageInput(x[-level - 1], p, coords=True)
+            p = level_layers(stage, s)
+        if self.out_fc is not None:
+            p = self.out_fc(p, s)
+        if p.shape[2:] != x[0].shape[2:]:
+            p = HF.upsample_bilinear(p, x[0].shape[2:])
+        return p
+
+
+class WeightMapper(nn.Module):
+    """Context head (hyperseg_v1_0.py:379-448): 1x1 reduce, (levels-1) stride-2 2x2 convs down, global
+    average at the bottom, 1x1 merges + nearest 2x up, concat -> signal.  Stock PyTorch-ROCm."""
+
+    def __init__(self, in_channels, out_channels, levels=3, bias=False, min_unit=4, weight_groups=1):
+        super(WeightMapper, self).__init__()
+        assert levels > 0, 'levels must be greater than zero'
+        assert in_channels % 2 == 0, 'in_channels must be divisible by 2'
+        if isinstance(weight_groups, (list, tuple)):
+            assert len(weight_groups) == len(out_channels), \
+                f'groups ({len(weight_groups)}) must be of size {len(out_channels)}'
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.levels = levels
+        self.bias = bias
+        self.weight_groups = weight_groups
+        half = in_channels // 2
+
+        def block(cin, k, stride):
+            return nn.Sequential(nn.Conv2d(cin, half, kernel_size=k, stride=stride, bias=bias),
+                                 nn.BatchNorm2d(half), nn.ReLU(inplace=True))
+
+        self.down_blocks = nn.ModuleList()
+        self.up_blocks = nn.ModuleList()
+        self.in_conv = block(in_channels, 1, 1)
+        for _ in range(levels - 1):
+            self.down_blocks.append(block(half, 2, 2))
+            self.up_blocks.append(block(in_channels, 1, 1))
+        self.upsample = nn.UpsamplingNearest2d(scale_factor=2)
+
+    def forward(self, x):
+        feat = [self.in_conv(x)]
+        for down in self.down_blocks:
+            feat.append(down(feat[-1]))
+        x = feat[-1]
+        if x.shape[-2:] != (1, 1):
+            x = F.adaptive_avg_pool2d(x, 1).expand_as(x)      # == avg pool + nearest resize back
+        for level in range(self.levels - 2, -1, -1):
+            x = self.upsample(self.up_blocks[level](torch.cat((feat.pop(), x), dim=1)))
+        return torch.cat((feat.pop(), x), dim=1)
+
+
+class HyperGen(nn.Module):
+    """backbone -> context head -> dynamic decoder (hyperseg_v1_0.py:12-91)."""
+
+    def __init__(self, backbone, weight_mapper, in_nc=3, num_classes=3, kernel_sizes=3, level_layers=1,
+                 level_channels=None, expand_ratio=1, groups=1, weight_groups=1, inference_hflip=False,
+                 inference_gather='mean', with_out_fc=False, decoder_groups=1, decoder_dropout=None, coords_res=None):
+        super(HyperGen, self).__init__()
+        self.inference_hflip = inference_hflip
+        self.inference_gather = inference_gather
+        self.backbone = backbone()
+        feat_channels = [in_nc] + self.backbone.feat_channels[:-1]
+        self.decoder = MultiScaleDecoder(feat_channels, self.backbone.feat_channels[-1], num_classes, kernel_sizes,
+                                         level_layers, level_channels, with_out_fc=with_out_fc, out_kernel_size=1,
+                                         expand_ratio=expand_ratio, groups=decoder_groups,
+                                         weight_groups=list(weight_groups) if isinstance(weight_groups, (list, tuple))
+                                         else weight_groups,
+                                         dropout=decoder_dropout, coords_res=coords_res)
+        self.weight_mapper = weight_mapper(self.backbone.feat_channels[-1], self.decoder.param_groups)
+
+    @property
+    def hyper_params(self):
+        return self.decoder.hyper_params
+
+    def process_single_tensor(self, x, hflip=False):
+        x = torch.flip(x, [-1]) if hflip else x
+        features = self.backbone(x)
+        signal = self.weight_mapper(features[-1])
+        pyramid = [t.contiguous() for t in [x] + features[:-1]]
+        y = self.decoder(pyramid, signal.contiguous())
+        return torch.flip(y, [-1]) if hflip else y
+
+    def gather_results(self, x, y=None):
+        assert x is not None
+        if y is None:
+            return x
+        return (x + y) * 0.5 if self.inference_gather == 'mean' else torch.max(x, y)
+
+    def forward(self, x):
+        assert isinstance(x, (list, tuple, torch.Tensor)), 'x must be of type list, tuple, or tensor'
+        if isinstance(x, torch.Tensor):
+            return self.process_single_tensor(x)
+        out_res = x[0].shape[2:]          # the first pyramid level sets the output resolution
+        out = None
+        for p in x:
+            if self.inference_hflip:
+                p = torch.max(self.process_single_tensor(p), self.process_single_tensor(p, hflip=True))
+            else:
+                p = self.process_single_tensor(p)
+            if p.shape[2:] != out_res:
+                p = HF.upsample_bilinear(p.contiguous(), out_res)
+            out = self.gather_results(p, out)
+        return out
+
+
+def hyperseg_efficientnet(model_name, pretrained=False, out_feat_scale=0.25, levels=3, weights_path=None, **kwargs):
+    """Config-file factory with the reference's signature (hyperseg_v1_0.py:813-827)."""
+    from .backbones.efficientnet import efficientnet
+
+    weight_mapper = partial(WeightMapper, levels=levels)
+    backbone = partial(efficientnet, model_name, pretrained=pretrained, out_feat_scale=out_feat_scale, head=None,
+                       return_features=True)
+    model = HyperGen(backbone, weight_mapper, **kwargs)
+    if weights_path is not None:
+        checkpoint = torch.load(weights_path, map_location='cpu', weights_only=False)
+        model.load_state_dict(checkpoint['state_dict'], strict=True)
+    return model

@@ -1,0 +1,109 @@
+"""MetaPatch / MetaPatchConv2d -- drop-in for hyperseg/models/layers/meta_patch.py:9-257.
+
+The reference pads the whole image, unfolds it into halo tiles, folds the batch of tiles into conv
+groups and folds the result back (lines 35-57: six memory passes around one small conv).  Here:
+one ``hs_bank_pack_fwd`` launch turns the (B, hp, fh, fw) weight tensor into a patch-major bank and
+one ``hs_patch_conv_fwd`` launch does padding + gather + conv (+ BN + activation when called from a
+MetaSequential) with the tile living in LDS.
+"""
+import torch
+import torch.nn as nn
+from torch.nn.modules.utils import _pair
+
+from ... import functional as HF
+from .meta_conv import MetaConv2d, _require_inference
+from .meta_sequential import MetaSequential
+
+
+class MetaPatch(nn.Module):
+    """Dynamic patch-wise wrapper.  Only a wrapped :class:`MetaConv2d` has a HIP kernel; any other
+    wrapped module raises (the reference's generic unfold/fold route is not reproduced)."""
+
+    def __init__(self, module: nn.Module, padding=0, padding_mode='reflect'):
+        super(MetaPatch, self).__init__()
+        valid_padding_modes = {'zeros', 'reflect', 'replicate', 'circular'}
+        if padding_mode not in valid_padding_modes:
+            raise ValueError(
+                f"padding_mode must be one of {valid_padding_modes}, but got padding_mode='{padding_mode}'")
+        self.hyper_module = module
+        self.padding = _pair(padding)
+        self.padding_mode = padding_mode
+
+    @property
+    def hyper_params(self):
+        return self.hyper_module.hyper_params
+
+    def forward_fused(self, x, weight, scale=None, shift=None, act=HF.ACT_NONE):
+        conv = self.hyper_module
+        if not isinstance(conv, MetaConv2d):
+            raise NotImplementedError('hyperseg_amd.MetaPatch has a HIP kernel only for a wrapped MetaConv2d')
+        _require_inference(x if isinstance(x, torch.Tensor) else x.skip, weight)
+        k, inner_pad = conv._check_supported()
+        if inner_pad != 0 or self.padding[0] != self.padding[1]:
+            raise NotImplementedError('MetaPatch expects the wrapped conv to be unpadded (meta_patch.py:190-193)')
+        if weight.dim() != 4 or weight.shape[1] < conv.hyper_params:
+            raise ValueError(f'weight must be (B, >={conv.hyper_params}, fh, fw), got {tuple(weight.shape)}')
+        fh, fw = weight.shape[-2:]
+        h, w = x.shape[-2:]
+        if h % fh != 0 or w % fw != 0:
+            raise ValueError(f'input {h}x{w} does not tile into the {fh}x{fw} weight grid')
+        bank = HF.bank_pack(weight, 0, conv.hyper_params)
+        return HF.patch_conv(x, (fh, fw), bank, conv.out_channels, k, self.padding[0], self.padding_mode,
+                             conv.groups, scale, shift, act)
+
+    def forward(self, x, weight):
+        return self.forward_fused(x, weight)
+
+
+class MetaPatchConv2d(MetaPatch):
+    """Patch-wise dynamic 2D convolution: every cell of the (fh, fw) weight grid has its own filters.
+    forward(x (B,C,H,W), weight (B,hp,fh,fw)) -> (B,Cout,H,W)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 padding_mode='reflect'):
+        conv = MetaConv2d(in_channels, out_channels, kernel_size, stride, 0, dilation, groups)
+        super(MetaPatchConv2d, self).__init__(conv, padding, padding_mode)
+
+    @property
+    def in_channels(self):
+        return self.hyper_module.in_channels
+
+    @property
+    def out_channels(self):
+        return self.hyper_module.out_channels
+
+    @property
+    def kernel_size(self):
+        return self.hyper_module.kernel_size
+
+    @property
+    def groups(self):
+        return self.hyper_module.groups
+
+    def __repr__(self):
+        m = self.hyper_module
+        s = f'{self.__class__.__name__}({m.in_channels}, {m.out_channels}, kernel_size={m.kernel_size}, ' \
+            f'stride={m.stride}'
+        if self.padding != (0, 0):
+            s += f', padding={self.padding}'
+        if m.groups != 1:
+            s += f', groups={m.groups}'
+        if self.padding_mode != 'zeros':
+            s += f', padding_mode={self.padding_mode}'
+        return s + ')'
+
+
+def make_meta_patch_conv2d_block(in_nc, out_nc, kernel_size=3, stride=1, padding=None, dilation=1, groups=1,
+                                 padding_mode='reflect', norm_layer=nn.BatchNorm2d, act_layer=nn.ReLU(True),
+                                 dropout=None):
+    """[MetaPatchConv2d, norm, act, Dropout?] in a MetaSequential (meta_patch.py:228-257)."""
+    assert dropout is None or isinstance(dropout, float)
+    padding = kernel_size // 2 if padding is None else padding
+    layers = [MetaPatchConv2d(in_nc, out_nc, kernel_size, stride, padding, dilation, groups, padding_mode)]
+    if norm_layer is not None:
+        layers.append(norm_layer(out_nc))
+    if act_layer is not None:
+        layers.append(act_layer)
+    if dropout is not None:
+        layers.append(nn.Dropout(dropout))
+    return MetaSequential(*layers)

@@ -1,0 +1,73 @@
+"""MetaSequential -- drop-in for hyperseg/models/layers/meta_sequential.py:5-40.
+
+Same container semantics (children with ``hyper_params`` consume a channel range of ``w`` or the
+next entry of a weight list; plain children get ``module(x)``), plus one thing the reference
+cannot do: when a dynamic convolution is followed by an eval-mode BatchNorm2d and/or ReLU/ReLU6
+(the blocks built by make_*_patch_conv2d_block), the three are executed as ONE HIP launch through
+the child's ``forward_fused`` (BN folded to scale/shift, activation in the epilogue).
+The channel slice is passed as a view -- the reference's ``.contiguous()`` copy (line 35) is gone.
+"""
+import torch
+import torch.nn as nn
+
+from ... import functional as HF
+
+
+def _act_code(m):
+    if isinstance(m, nn.ReLU6):
+        return HF.ACT_RELU6
+    if isinstance(m, nn.ReLU):
+        return HF.ACT_RELU
+    return None
+
+
+class MetaSequential(nn.Sequential):
+    def __init__(self, *args):
+        super(MetaSequential, self).__init__(*args)
+        self.hyper_params = 0
+        self._ranges = [0]
+        self._folded = {}
+        for module in self:
+            if hasattr(module, 'hyper_params'):
+                self.hyper_params += module.hyper_params
+            self._ranges.append(self.hyper_params)
+
+    def _fold(self, idx, bn):
+        cache = self._folded.get(idx)
+        if cache is None:
+            cache = self._folded[idx] = HF.FoldedBN()
+        return cache.get(bn)
+
+    def forward(self, x, w):
+        mods = list(self)
+        n = len(mods)
+        w_count = 0
+        i = 0
+        while i < n:
+            module = mods[i]
+            if self._ranges[i] < self._ranges[i + 1]:
+                if isinstance(w, (list, tuple)):
+                    wi = w[w_count]
+                else:
+                    wi = w[:, self._ranges[i]:self._ranges[i + 1]]     # clamped view, no copy
+                w_count += 1
+                if hasattr(module, 'forward_fused'):
+                    j = i + 1
+                    scale = shift = None
+                    act = HF.ACT_NONE
+                    if j < n and isinstance(mods[j], nn.BatchNorm2d) and not mods[j].training:
+                        scale, shift = self._fold(j, mods[j])
+                        j += 1
+                    if j < n and _act_code(mods[j]) is not None:
+                        act = _act_code(mods[j])
+                        j += 1
+                    x = module.forward_fused(x, wi, scale, shift, act)
+                    i = j
+                    continue
+                x = module(x, wi)
+            else:
+                if isinstance(x, HF.StageInput):
+                    x = x.materialize()
+                x = module(x)
+            i += 1
+        return x

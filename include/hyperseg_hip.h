@@ -1,0 +1,140 @@
+/*
+ * hyperseg_hip.h -- C ABI of libhyperseg_hip.so: the MI355X (gfx950) kernels of the HyperSeg
+ * decoder hot path (dynamic patch-wise convolution + inter-stage glue).
+ *
+ * The reference (YuvalNirkin/hyperseg) has no FFI layer: its boundary for this path is the
+ * nn.Module API of hyperseg/models/layers/{meta_sequential,meta_conv,meta_patch}.py and the
+ * HyperPatch* classes of hyperseg/models/hyperseg_v*.py.  The host-side mirror of that API
+ * lives in hyperseg_amd/models/ and binds exactly these entry points with ctypes
+ * (hyperseg_amd/_hip.py); INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - All tensors are fp32, NCHW, contiguous, device pointers BORROWED for the duration of the
+ *    call; the library allocates nothing, keeps no global mutable state, never synchronises the
+ *    device, and enqueues on the caller's stream (hipStream_t passed as void*).  Re-entrant.
+ *  - Every function returns 0 on success, a negative hs_status on rejected arguments (nothing
+ *    enqueued), or a positive hipError_t if the launch itself failed.
+ *  - "grid" = the (fh, fw) weight grid; a level of resolution (H, W) has patches of
+ *    ph = H/fh by pw = W/fw pixels; patch (b, i, j) has linear index p = (b*fh + i)*fw + j.
+ *  - A *bank* is the per-patch filter bank in PATCH-MAJOR layout: bank[p*ld + m], m < rows.
+ *    Row order is chosen by the producer (hs_signal2weights_fwd / hs_bank_pack_fwd) through a
+ *    row map; the consumers document the order they expect.
+ *  - A *stage input* is the channel concatenation the reference builds with torch.cat
+ *    (hyperseg_v1_0.py:231-240): [2 coord channels | skip feature | previous level output,
+ *    optionally bilinearly resized]; it is generated on the fly, never materialised.
+ */
+#ifndef HYPERSEG_HIP_H
+#define HYPERSEG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HS_ABI_VERSION 1
+
+typedef enum {
+    HS_OK = 0,
+    HS_ERR_BAD_ARG = -1,       /* null pointer / non-positive size / inconsistent shapes */
+    HS_ERR_NOT_DIVISIBLE = -2, /* H % fh != 0 or W % fw != 0 (hyperseg_v1_0.py:490-494 view error) */
+    HS_ERR_UNSUPPORTED = -3,   /* shape outside what the kernels were instantiated for */
+    HS_ERR_LDS = -4            /* tile does not fit the 160 KiB LDS */
+} hs_status;
+
+typedef enum { HS_ACT_NONE = 0, HS_ACT_RELU = 1, HS_ACT_RELU6 = 2 } hs_act;
+typedef enum { HS_PAD_ZEROS = 0, HS_PAD_REFLECT = 1, HS_PAD_REPLICATE = 2, HS_PAD_CIRCULAR = 3 } hs_pad_mode;
+typedef enum { HS_PREV_NONE = 0, HS_PREV_SAME = 1, HS_PREV_BILINEAR = 2 } hs_prev_mode;
+
+/* Stage input: replaces F.interpolate + 2x torch.cat + get_image_coordinates
+ * (hyperseg_v1_0.py:203-240; v0_1: hyperseg_v0_1.py:186-198, 240-246). */
+typedef struct {
+    const float* skip;   /* (B, c_skip, H, W) */
+    const float* prev;   /* (B, c_prev, Hp, Wp) or NULL */
+    int32_t batch, H, W;
+    int32_t c_skip, c_prev;
+    int32_t Hp, Wp;      /* resolution of prev; bilinear (align_corners=False) to (H, W) if prev_mode == 2 */
+    int32_t coords;      /* 1: prepend x in [-1,1] over W (ch 0) and y over H (ch 1), linspace endpoints inclusive */
+    int32_t prev_mode;   /* hs_prev_mode */
+} hs_stage_input;
+
+/* Per-channel affine applied after a convolution: y = act(conv * scale + shift).  Inference
+ * BatchNorm folded by hs_bn_fold_fwd; scale == NULL means identity. */
+typedef struct {
+    const float* scale;
+    const float* shift;
+    int32_t act;         /* hs_act */
+} hs_epilogue;
+
+/* ABI version / build info (sanity check for the ctypes binding). */
+int hs_version(void);
+const char* hs_build_info(void);
+
+/* a9: "hypernetwork head emits per-patch weights" -- grouped 1x1 conv, bias-free.
+ * Replaces signal2weights(...)[:, :hp] (hyperseg_v1_0.py:479-484, 321-326;
+ * hyperseg_v1_0_unify.py:302-309) AND the permute/reshape copy that follows it.
+ *   bank[p*ld + m] = sum_k wsw_t[k*wc + n] * signal[b, signal_index + g(n)*cs_g + k, i, j],
+ *   n = row_src ? row_src[m] : m  (n < 0 -> 0.0f),  g(n) = n / (wc / groups).
+ * wsw_t is the Conv2d weight (wc, cs_g, 1, 1) TRANSPOSED to (cs_g, wc) (done once by the host). */
+int hs_signal2weights_fwd(const float* signal, int32_t batch, int32_t c_signal, int32_t fh, int32_t fw,
+                          int32_t signal_index, int32_t signal_channels, int32_t groups,
+                          const float* wsw_t, int32_t wc,
+                          const int32_t* row_src, int32_t rows,
+                          float* bank, int64_t ld, void* stream);
+
+/* Re-layout of a reference-layout weight tensor (B, hp_total, fh, fw) (channel-major, as
+ * MetaPatch.forward / HyperPatchInvertedResidual receive it: meta_patch.py:49,
+ * hyperseg_v1_0_unify.py:335-349) into a patch-major bank:
+ *   bank[p*ld + m] = w[b, ch_offset + (row_src ? row_src[m] : m), i, j]  (row < 0 -> 0.0f). */
+int hs_bank_pack_fwd(const float* w, int32_t batch, int32_t hp_total, int32_t fh, int32_t fw,
+                     int32_t ch_offset, const int32_t* row_src, int32_t rows,
+                     float* bank, int64_t ld, void* stream);
+
+/* Inference BatchNorm folding: scale = gamma / sqrt(var + eps), shift = beta - mean * scale,
+ * for n channels (nn.BatchNorm2d eval semantics; eps 1e-5 in every reference module). */
+int hs_bn_fold_fwd(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                   int32_t n, float* scale, float* shift, void* stream);
+
+/* Op A / Op B: dynamic patch-wise k x k convolution with image-level padding, stride 1,
+ * dilation 1.  Replaces MetaPatch.forward + MetaConv2d.forward (meta_patch.py:35-57,
+ * meta_conv.py:163-186), HyperPatchNoPadding.forward (hyperseg_v1_0.py:486-498) and
+ * HyperPatch.forward (hyperseg_v1_0.py:543-557), plus the BatchNorm/activation modules that
+ * follow them in make_*_patch_conv2d_block.  With fh = fw = 1 it is MetaConv2d itself.
+ * Bank row order (natural): m = ((o*cin_g + c)*k + ky)*k + kx, cin_g = cin/groups.
+ *   y[b,o,y,x] = act(scale[o] * sum W[m] * in_pad[b, grp(o)*cin_g + c, y+ky-pad, x+kx-pad] + shift[o]) */
+int hs_patch_conv_fwd(const hs_stage_input* in, int32_t fh, int32_t fw,
+                      const float* bank, int64_t ld,
+                      int32_t c_out, int32_t k, int32_t pad, int32_t pad_mode, int32_t groups,
+                      const hs_epilogue* ep, float* y, void* stream);
+
+/* Op C: fused per-patch inverted residual of hyperseg_v1_0.py:328-376 (and its unify twin
+ * hyperseg_v1_0_unify.py:330-389): reflect halo tile -> pw1 -> BN1 -> ReLU6 -> dw3x3 ->
+ * BN2 -> ReLU6 -> pw3 -> BN3 (+ the stage input itself if residual != 0, which requires
+ * cin == c_out: use_res_connect, hyperseg_v1_0.py:295, 372-376), one launch, hidden activations
+ * never leave the CU.  Bank row order ("ir" order, build it with hs_ir_row_map):
+ *   [0, cin*hid)               W1[h][c]        (natural)
+ *   [cin*hid, +9*hid)          K[h][ky][kx]    (natural)
+ *   [.., +hid*c_out)           W3T[h][o]       (TRANSPOSED: natural index is o*hid + h)
+ * bn1/bn2/bn3 are folded scale/shift pairs (activation fields ignored). */
+int hs_patch_ir_fwd(const hs_stage_input* in, int32_t fh, int32_t fw,
+                    const float* bank, int64_t ld, int32_t hidden, int32_t c_out,
+                    const hs_epilogue* bn1, const hs_epilogue* bn2, const hs_epilogue* bn3,
+                    int32_t residual, float* y, void* stream);
+
+/* Fills row_src[rows] for hs_patch_ir_fwd's bank order; returns rows = cin*hid + 9*hid + hid*c_out.
+ * Host function (no GPU work). */
+int hs_ir_row_map(int32_t cin, int32_t hidden, int32_t c_out, int32_t* row_src);
+
+/* Final logits resize: F.interpolate(p, size, mode='bilinear', align_corners=False)
+ * (hyperseg_v1_0.py:250-251).  x (B,C,Hi,Wi) -> y (B,C,Ho,Wo). */
+int hs_upsample_bilinear_fwd(const float* x, int32_t batch, int32_t channels, int32_t Hi, int32_t Wi,
+                             int32_t Ho, int32_t Wo, float* y, void* stream);
+
+/* Materialises a stage input (B, 2*coords + c_skip + c_prev, H, W); test/diagnostic twin of the
+ * fused prologue (the product path never calls it). */
+int hs_stage_input_fwd(const hs_stage_input* in, float* y, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYPERSEG_HIP_H */

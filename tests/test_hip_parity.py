@@ -1,0 +1,285 @@
+"""Parity of the HIP path (through the C ABI and the nn.Module mirror) against the reference-made
+golden fixtures and the CPU oracle.  Needs an MI355X: run with ``-m gpu``.
+
+Tolerances: the north star asks for <= 1e-3 relative fp32 and argmax-identical masks.  Everything
+here is held to REL_TOL = 2e-5 (tensor-scale relative; observed ~1e-6) -- fp32 sums are re-associated,
+so bit equality is not expected -- and masks must agree wherever the reference's own top-2 margin
+exceeds MARGIN = 1e-4 (the minimum margin over 0.5 M pixels is ~1 ulp, see make_golden.py).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import bn_of, rel_err, sub
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 2e-5
+NORTH_STAR_TOL = 1e-3
+MARGIN = 1e-4
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail('these tests need the MI355X (torch.cuda.is_available() is False)')
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def HF(dev):
+    import hyperseg_amd.functional as hf
+    return hf
+
+
+@pytest.fixture(scope='module')
+def O():
+    from oracle import hyperseg_oracle
+    return hyperseg_oracle
+
+
+def load_bn(bn, p, prefix):
+    with torch.no_grad():
+        for k in ('weight', 'bias', 'running_mean', 'running_var'):
+            getattr(bn, k).copy_(p[f'{prefix}.{k}'])
+
+
+def cmp(y, ref, tol=REL_TOL, what=''):
+    assert tuple(y.shape) == tuple(ref.shape), (what, y.shape, ref.shape)
+    e = rel_err(y.cpu(), ref)
+    assert e < tol, f'{what}: relative error {e:.3e} >= {tol}'
+    return e
+
+
+# ------------------------------------------------------------------------------ raw kernels
+def test_stage_input_and_upsample(HF, O, dev):
+    g = torch.Generator().manual_seed(0)
+    for (b, cs, cp, h, w, mode) in [(2, 3, 4, 8, 12, 'bilinear'), (1, 5, 0, 7, 9, 'none'), (2, 2, 3, 6, 10, 'same'),
+                                    (1, 1, 2, 1, 4, 'bilinear'), (1, 4, 19, 64, 32, 'bilinear')]:
+        skip = torch.randn(b, cs, h, w, generator=g)
+        prev = None
+        if mode == 'bilinear':
+            prev = torch.randn(b, cp, max(h // 2, 1), max(w // 2, 1), generator=g)
+        elif mode == 'same':
+            prev = torch.randn(b, cp, h, w, generator=g)
+        ref = O.stage_input(skip, prev)
+        st = HF.StageInput(skip.to(dev), prev.to(dev) if prev is not None else None, coords=True)
+        cmp(st.materialize(), ref, what=f'stage_input {mode}')
+    for (shape, size) in [((2, 3, 5, 7), (10, 14)), ((1, 19, 16, 32), (32, 64)), ((1, 2, 6, 5), (9, 11)),
+                          ((1, 1, 4, 4), (4, 4))]:
+        x = torch.randn(*shape, generator=g)
+        ref = torch.nn.functional.interpolate(x, size, mode='bilinear', align_corners=False)
+        cmp(HF.upsample_bilinear(x.to(dev), size), ref, what=f'upsample {shape}->{size}')
+
+
+def test_bn_fold(HF, O, dev):
+    gen = torch.Generator().manual_seed(1)
+    bn = O.synth_bn(gen, 37)
+    scale, shift = HF.bn_fold(*(bn[k].to(dev) for k in ('weight', 'bias', 'running_mean', 'running_var')))
+    x = torch.randn(2, 37, 3, 3, generator=gen)
+    cmp(x.to(dev) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1), O.bn_eval(x, bn), what='bn_fold')
+
+
+def test_signal2weights_and_bank_pack(HF, O, dev):
+    g = torch.Generator().manual_seed(2)
+    cases = [dict(b=2, c=24, fh=3, fw=4, idx=3, cs=16, grp=4, hp=35),       # next_multiply padding, 2 batches
+             dict(b=1, c=64, fh=4, fw=8, idx=0, cs=64, grp=16, hp=1000),    # many groups per wave
+             dict(b=1, c=1280, fh=16, fw=32, idx=0, cs=416, grp=32, hp=5248),   # HyperSeg-M level 0
+             dict(b=3, c=10, fh=5, fw=7, idx=2, cs=8, grp=1, hp=9)]         # ragged patch count (105 % 16 != 0)
+    for c in cases:
+        rows = O.next_multiply(c['hp'], c['grp'])
+        wsw = torch.randn(rows, c['cs'] // c['grp'], 1, 1, generator=g)
+        s = torch.randn(c['b'], c['c'], c['fh'], c['fw'], generator=g).clamp(min=0)
+        ref = O.signal2weights(s, wsw, c['idx'], c['cs'], c['grp'], c['hp'])          # (B, hp, fh, fw)
+        ref_bank = ref.permute(0, 2, 3, 1).reshape(-1, c['hp'])
+        wsw_t = wsw.reshape(rows, -1).t().contiguous().to(dev)
+        bank = HF.signal2weights(s.to(dev), wsw_t, c['idx'], c['cs'], c['grp'], c['hp'])
+        cmp(bank[:, :c['hp']], ref_bank, what=f's2w {c}')
+        # row map: reversed order with a zero row
+        perm = torch.arange(c['hp'] - 1, -1, -1, dtype=torch.int32)
+        perm[0] = -1
+        bank2 = HF.signal2weights(s.to(dev), wsw_t, c['idx'], c['cs'], c['grp'], c['hp'], perm.to(dev))
+        want = ref_bank.flip(1).clone()
+        want[:, 0] = 0
+        cmp(bank2[:, :c['hp']], want, what='s2w row map')
+        # bank_pack of the reference-layout tensor gives the same bank
+        packed = HF.bank_pack(ref.contiguous().to(dev), 0, c['hp'])
+        assert torch.equal(packed[:, :c['hp']].cpu(), ref_bank)
+        packed = HF.bank_pack(ref.contiguous().to(dev), 0, c['hp'], perm.to(dev))
+        assert torch.equal(packed[:, :c['hp']].cpu(), want)
+
+
+def test_ir_row_map(HF, dev):
+    m = HF.ir_row_map(3, 4, 2, dev).cpu().tolist()
+    r2 = 3 * 4 + 9 * 4
+    assert m[:r2] == list(range(r2))
+    assert m[r2:] == [r2 + o * 4 + h for h in range(4) for o in range(2)]
+
+
+# ------------------------------------------------------------------------------ module mirror vs golden
+def test_meta_conv2d(golden, dev):
+    from hyperseg_amd.models.layers.meta_conv import MetaConv2d
+    m = MetaConv2d(3, 3, 3, padding=1, groups=3)
+    x = torch.ones(4, 3, 64, 64)
+    x[0::2] = 0
+    w = torch.ones(4, m.hyper_params)
+    w[0::2] = 0
+    with torch.no_grad():
+        assert float(m(x.to(dev), w.to(dev)).max()) == 9.0 == float(golden('meta_conv_known_answer')['out_max'])
+    g = golden('meta_conv2d')
+    for i in range(int(g['n'])):
+        cin, cout, k, pad, groups = [int(v) for v in g[f'{i}.cfg']]
+        m = MetaConv2d(cin, cout, k, padding=pad, groups=groups, padding_mode=str(g[f'{i}.mode']))
+        if 2 * pad != k - 1:
+            with pytest.raises(Exception):     # "valid" convs are not instantiated by any reference config
+                m(g[f'{i}.x'].to(dev), g[f'{i}.w'].to(dev))
+            continue
+        with torch.no_grad():
+            cmp(m(g[f'{i}.x'].to(dev), g[f'{i}.w'].to(dev)), g[f'{i}.y'], what=f'meta_conv2d {i}')
+
+
+def test_meta_patch_conv2d(golden, dev):
+    from hyperseg_amd.models.layers.meta_patch import MetaPatchConv2d, make_meta_patch_conv2d_block
+    g = golden('meta_patch_conv2d')
+    with torch.no_grad():
+        for i in range(int(g['n'])):
+            cin, cout, k, groups = [int(v) for v in g[f'{i}.cfg']]
+            m = MetaPatchConv2d(cin, cout, k, padding=k // 2, groups=groups)
+            cmp(m(g[f'{i}.x'].to(dev), g[f'{i}.w'].to(dev)), g[f'{i}.y'], what=f'meta_patch {i}')
+        blk = make_meta_patch_conv2d_block(6, 5, 1).eval()
+        load_bn(blk[1], sub(g, 'blk.p.'), '1')
+        blk = blk.to(dev)
+        cmp(blk(g['blk.x'].to(dev), g['blk.w'].to(dev)), g['blk.y'], what='meta_patch block (fused BN+ReLU)')
+        # meta_patch.py main(): x 2x10x256x256, w ones 2xhpx8x8 -> torch.Size([2, 20, 256, 256])
+        m = MetaPatchConv2d(10, 20, 3, padding=1)
+        y = m(torch.rand(2, 10, 256, 256, device=dev), torch.ones(2, m.hyper_params, 8, 8, device=dev))
+        assert y.shape == torch.Size([2, 20, 256, 256])
+
+
+def test_meta_sequential(golden, dev):
+    from hyperseg_amd.models.layers.meta_patch import MetaPatchConv2d
+    from hyperseg_amd.models.layers.meta_sequential import MetaSequential
+    g = golden('meta_sequential')
+    seq = MetaSequential(MetaPatchConv2d(4, 6, 1), torch.nn.ReLU(), MetaPatchConv2d(6, 3, 3, padding=1)).eval().to(dev)
+    hp0, hp1 = [int(v) for v in g['hp']]
+    assert seq._ranges == [int(v) for v in g['ranges']] and seq.hyper_params == hp0 + hp1
+    x, w = g['x'].to(dev), g['w'].to(dev)
+    with torch.no_grad():
+        cmp(seq(x, w), g['y_tensor'], what='tensor weights')
+        cmp(seq(x, [w[:, :hp0].contiguous(), w[:, hp0:].contiguous()]), g['y_list'], what='list weights')
+        w_long = torch.cat([w, torch.randn(2, 5, 3, 2, device=dev)], dim=1)
+        cmp(seq(x, w_long), g['y_long'], what='clamped slice')
+
+
+def test_hyper_patch_v1(golden, dev):
+    from hyperseg_amd.models import hyperseg_v1_0 as M
+    g = golden('hyper_patch_v1')
+    with torch.no_grad():
+        cin, cout, cs, idx, grp, hp = [int(v) for v in g['np.cfg']]
+        m = M.HyperPatchNoPadding(cin, cout, 1)
+        m.init_signal2weights(cs, idx, grp)
+        assert m.hyper_params == hp and tuple(m.signal2weights.weight.shape) == tuple(g['np.w_s2w'].shape)
+        m.signal2weights.weight.copy_(g['np.w_s2w'])
+        m = m.to(dev)
+        cmp(m.apply_signal2weights(g['np.s'].to(dev)), g['np.wt'], what='apply_signal2weights')
+        cmp(m(g['np.x'].to(dev), g['np.s'].to(dev)), g['np.y'], what='HyperPatchNoPadding')
+
+        cin, cout, cs, idx, grp, hp = [int(v) for v in g['pc.cfg']]
+        m = M.HyperPatchConv2d(cin, cout, 3, padding=1)
+        m.init_signal2weights(cs, idx, grp)
+        m.signal2weights.weight.copy_(g['pc.w_s2w'])
+        m = m.to(dev)
+        cmp(m(g['pc.x'].to(dev), g['pc.s'].to(dev)), g['pc.y'], what='HyperPatchConv2d')
+
+        cin, cout, cs, idx, grp, hp = [int(v) for v in g['blk.cfg']]
+        blk = M.make_hyper_patch_conv2d_block(cin, cout, 1).eval()
+        blk[0].init_signal2weights(cs, idx, grp)
+        p = sub(g, 'blk.p.')
+        missing, unexpected = blk.load_state_dict(p, strict=False)
+        assert not unexpected and all('num_batches' in k for k in missing)
+        blk = blk.to(dev)
+        cmp(blk(g['blk.x'].to(dev), g['blk.s'].to(dev)), g['blk.y'], what='hyper patch block, clamped signal slice')
+
+
+def test_inverted_residual_v1(golden, dev):
+    from hyperseg_amd.models import hyperseg_v1_0 as M
+    g = golden('inverted_residual_v1')
+    with torch.no_grad():
+        for i in range(int(g['n'])):
+            cin, cout, hid, cs, idx, grp, hp = [int(v) for v in g[f'{i}.cfg']]
+            m = M.HyperPatchInvertedResidual(cin, cout, 3, expand_ratio=hid / cin).eval()
+            assert m.hidden_dim == hid and m.hyper_params == hp
+            m.init_signal2weights(cs, idx, grp)
+            missing, unexpected = m.load_state_dict(sub(g, f'{i}.p.'), strict=False)
+            assert not unexpected and all('num_batches' in k for k in missing)
+            m = m.to(dev)
+            cmp(m(g[f'{i}.x'].to(dev), g[f'{i}.s'].to(dev)), g[f'{i}.y'], what=f'IR v1 case {i}')
+
+
+def test_tiny_decoder_v1_0(golden, dev):
+    from hyperseg_amd.models import hyperseg_v1_0 as M
+    from test_oracle_golden import TINY
+    g = golden('decoder_t_v1_0')
+    c = TINY['t_v1_0']
+    d = M.MultiScaleDecoder(c['feat'], c['signal'], c['num_classes'], c['kernel_sizes'], 1, c['level_channels'],
+                            expand_ratio=c['expand_ratio'], weight_groups=list(c['weight_groups'])).eval()
+    assert d.param_groups == [int(v) for v in g['hyper_params']]
+    missing, unexpected = d.load_state_dict(sub(g, 'p.'), strict=False)
+    assert not unexpected and all('num_batches' in k for k in missing)
+    d = d.to(dev)
+    with torch.no_grad():
+        y = d([g[f'x{i}'].to(dev) for i in range(6)], g['s'].to(dev))
+    cmp(y, g['y'], what='tiny v1_0 decoder')
+    assert bool((y.argmax(1).cpu() == g['y'].argmax(1)).all())
+
+
+# ------------------------------------------------------------------------------ full BASELINE shapes
+def build_decoder(name, O):
+    from hyperseg_amd.models import hyperseg_v1_0 as M
+    c = O.CONFIGS[name]
+    assert c['variant'] == 'v1_0'
+    d = M.MultiScaleDecoder(c['feat'], c['signal'], c['num_classes'], c['kernel_sizes'], 1, c['level_channels'],
+                            expand_ratio=c['expand_ratio'], weight_groups=list(c['weight_groups'])).eval()
+    params = O.synth_decoder_params(O.config_plan(name), seed=0)
+    missing, unexpected = d.load_state_dict(params, strict=False)
+    assert not unexpected and all('num_batches' in k for k in missing)
+    return d
+
+
+@pytest.mark.parametrize('name', ['M', 'Sc'])
+def test_full_config_v1_0(golden, O, dev, name):
+    """HyperSeg-M 1024x512 / CamVid-S 768x576 decoder on the seeded synthetic workload of SURVEY 8(d):
+    vs the oracle on the full tensor, vs the reference's own sampled logits and masks."""
+    g = golden('decoder_full_configs')
+    d = build_decoder(name, O).to(dev)
+    x, s = O.synth_decoder_inputs(name, batch=1, seed=0)
+    with torch.no_grad():
+        y = d([t.to(dev) for t in x], s.to(dev)).cpu()
+    ref, levels = O.run_config(name, batch=1, seed=0, return_levels=True)
+    e = cmp(y, ref, tol=REL_TOL, what=f'{name} logits vs oracle')
+    assert e < NORTH_STAR_TOL
+    top2 = ref.topk(2, dim=1).values
+    margin = top2[:, 0] - top2[:, 1]
+    flips = (y.argmax(1) != ref.argmax(1))
+    assert int((flips & (margin > MARGIN)).sum()) == 0
+    assert int(flips.sum()) <= int((margin <= MARGIN).sum())
+    # against the reference itself (fixture): strided logits + masks
+    ys = y[:, :, 3::37, 5::41]
+    assert float((ys - g[f'{name}.logits_sample']).abs().max()) < REL_TOL * float(g[f'{name}.logits_absmax'])
+    ok = g[f'{name}.margin_sample'] > MARGIN
+    assert bool((ys.argmax(1).to(torch.uint8)[ok] == g[f'{name}.mask_sample'][ok]).all())
+
+
+def test_errors_are_loud(HF, dev):
+    from hyperseg_amd._hip import HipLibraryError
+    from hyperseg_amd.models.layers.meta_patch import MetaPatchConv2d
+    m = MetaPatchConv2d(4, 4, 1)
+    with torch.no_grad():
+        with pytest.raises(HipLibraryError):
+            m(torch.randn(1, 4, 8, 8), torch.randn(1, 16, 2, 2))                      # CPU tensors
+        with pytest.raises(ValueError):
+            m(torch.randn(1, 4, 9, 8, device=dev), torch.randn(1, 16, 2, 2, device=dev))   # 9 % 2 != 0
+        with pytest.raises(ValueError):
+            m(torch.randn(1, 4, 8, 8, device=dev), torch.randn(1, 15, 2, 2, device=dev))   # too few weights
+    with pytest.raises(NotImplementedError):
+        m(torch.randn(1, 4, 8, 8, device=dev, requires_grad=True), torch.randn(1, 16, 2, 2, device=dev))
