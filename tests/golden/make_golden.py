@@ -329,6 +329,46 @@ def gen_decoders():
     save('decoder_full_configs', **arrs)
 
 
+# ------------------------------------------------------------------------------ whole models (boundary)
+MODEL_KW = {
+    'M': dict(mod='v1_0', name='efficientnet-b1', num_classes=19, kw=dict(
+        levels=2, out_feat_scale=[1., .25, .25, .25, .25], kernel_sizes=[1, 1, 1, 3, 3],
+        level_channels=[64, 32, 16, 16, 16], expand_ratio=2, with_out_fc=False, decoder_dropout=None,
+        weight_groups=[32, 16, 8, 16, 4], decoder_groups=1, inference_hflip=True,
+        coords_res=[(512, 512), (512, 1024)])),
+}
+
+
+def gen_models():
+    """HyperGen end to end with name-keyed weights (tests/util_weights.py): pins the stock-PyTorch encoder,
+    the context head and the factory kwargs of the build to the reference."""
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    from util_weights import fill_by_name
+    mods = {'v1_0': v1, 'unify': vu, 'v0_1': v0}
+    for tag, spec in MODEL_KW.items():
+        kw = {k: (list(v) if isinstance(v, list) else v) for k, v in spec['kw'].items()}
+        model = mods[spec['mod']].hyperseg_efficientnet(spec['name'], False, num_classes=spec['num_classes'], **kw)
+        fill_by_name(model.eval(), seed=11)
+        x = torch.rand(1, 3, 128, 256, generator=torch.Generator().manual_seed(12))
+        feats = model.backbone(x)
+        sig = model.weight_mapper(feats[-1])
+        y = model(x)
+        keys = [k for k in model.state_dict() if 'num_batches' not in k]
+        save(f'model_{tag}', x=x, y=y[:, :, 1::5, 2::7].contiguous(), y_absmax=y.abs().max(),
+             y_shape=np.array(y.shape), signal=sig[:, ::13].contiguous(),
+             feat_absmax=np.array([float(f.abs().max()) for f in feats]),
+             n_keys=len(keys), key_hash=np.array([hash_str(' '.join(keys))]),
+             shape_hash=np.array([hash_str(' '.join(str(tuple(model.state_dict()[k].shape)) for k in keys))]),
+             mask=y.argmax(1)[:, 1::5, 2::7].to(torch.uint8),
+             margin=(y.topk(2, dim=1).values[:, 0] - y.topk(2, dim=1).values[:, 1])[:, 1::5, 2::7].contiguous())
+        print(tag, tuple(y.shape), 'absmax', float(y.abs().max()), 'signal absmax', float(sig.abs().max()))
+
+
+def hash_str(s):
+    import hashlib
+    return int.from_bytes(hashlib.sha256(s.encode()).digest()[:7], 'little')
+
+
 if __name__ == '__main__':
     gen_meta_conv()
     gen_meta_patch()
@@ -338,3 +378,4 @@ if __name__ == '__main__':
     gen_ir_v0()
     gen_divide_feature()
     gen_decoders()
+    gen_models()
