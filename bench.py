@@ -69,8 +69,12 @@ def decoder_algorithmic(model, h, w, batch=1):
 
 
 def cpu_baseline(model_cpu, size, budget_s=20.0):
-    """CPU 'port' baseline: stock encoder + context head on CPU, oracle decoder; bounded sample."""
+    """CPU 'port' baseline on this box's host cores: stock encoder + context head on CPU, then the reference's
+    ATen op sequence for the decoder (oracle/cpu_port.py, pinned to the oracle).  The thread count is chosen by a
+    one-frame calibration over {8, 16, 32, 64, all} (more threads than that only slows these small ops down) and
+    reported as `cores`; bounded sample of ~budget_s seconds."""
     from oracle import hyperseg_oracle as O
+    from oracle import cpu_port as P
     plan = O.config_plan('M')
     params = {k: v for k, v in model_cpu.decoder.state_dict().items()}
     x = torch.rand(1, 3, *size)
@@ -81,18 +85,28 @@ def cpu_baseline(model_cpu, size, budget_s=20.0):
         feats = model_cpu.backbone(x)
         s = model_cpu.weight_mapper(feats[-1])
         t1 = time.perf_counter()
-        O.decoder_v1_0(plan, params, [x] + feats[:-1], s)
+        P.decoder_v1_0(plan, params, [x] + feats[:-1], s)
         return t1 - t0, time.perf_counter() - t1
+    ncpu = os.cpu_count() or 1
     with torch.no_grad():
-        frame()                                   # warm-up
+        best = None
+        for nt in sorted({min(n, ncpu) for n in (8, 16, 32, 64, ncpu)}):
+            torch.set_num_threads(nt)
+            frame()
+            t = sum(frame())
+            if best is None or t < best[0]:
+                best = (t, nt)
+        torch.set_num_threads(best[1])
+        frame()
         t_start, enc, dec, n = time.perf_counter(), 0.0, 0.0, 0
-        while n < 3 or (time.perf_counter() - t_start < budget_s and n < 50):
+        while n < 3 or (time.perf_counter() - t_start < budget_s and n < 200):
             e, d = frame()
             enc, dec, n = enc + e, dec + d, n + 1
     total = enc + dec
-    return {'value': round(n / total, 3), 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'{n} frames of HyperSeg-M 1024x512 bs1 ({total:.1f} s): stock encoder+context head on CPU '
-                      f'+ oracle decoder', 'decoder_ms': round(1e3 * dec / n, 2), 'encoder_ms': round(1e3 * enc / n, 2)}
+    return {'value': round(n / total, 3), 'unit': 'frames/s', 'cores': best[1], 'kind': 'port',
+            'sample': f'{n} frames of HyperSeg-M 1024x512 bs1 ({total:.1f} s) on {best[1]} of {ncpu} host threads: '
+                      f'stock encoder + context head on CPU + oracle/cpu_port.py decoder',
+            'decoder_ms': round(1e3 * dec / n, 2), 'encoder_ms': round(1e3 * enc / n, 2)}
 
 
 def main():

@@ -169,3 +169,13 @@ def test_upsample_and_coords_match_torch():
     x = torch.randn(1, 2, 5, 6, generator=g)
     for mode in ('reflect', 'replicate', 'circular'):
         assert torch.equal(O.pad2d(x, (1, 1), mode), torch.nn.functional.pad(x, (1, 1, 1, 1), mode=mode))
+
+
+def test_cpu_port_matches_oracle():
+    """oracle/cpu_port.py (the timed CPU baseline of bench.py) computes what the oracle computes."""
+    from oracle import cpu_port as P
+    for name, size in (('M', (128, 256)), ('Sc', (96, 64))):
+        plan = O.config_plan(name)
+        params = O.synth_decoder_params(plan, seed=3)
+        x, s = O.synth_decoder_inputs(name, batch=2, seed=3, size=size)
+        assert rel_err(P.decoder_v1_0(plan, params, x, s), O.decoder_v1_0(plan, params, x, s)) < TOL
