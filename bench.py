@@ -223,7 +223,7 @@ def main():
     # ---- instrumented eager pass: per-launch durations of the decoder kernels -----------------
     out = None
     if rank == 0:
-        names = ['signal2weights', 'bank_pack', 'patch_conv', 'patch_ir', 'upsample_bilinear']
+        names = ['signal2weights', 'signal2weights_multi', 'bank_pack', 'patch_conv', 'patch_ir', 'upsample_bilinear']
         orig = {n: getattr(HF, n) for n in names}
         recs, counter = {}, [0]
 
@@ -287,6 +287,8 @@ def main():
                     li += 1
             li = 0
             for l in launches:
+                if l['kernel'] == 'hs_signal2weights_multi_fwd':
+                    per[l['idx']] = sum(lv['bank_bytes'] for lv in levels)
                 if l['kernel'] == 'hs_signal2weights_fwd':
                     per[l['idx']] = levels[li]['bank_bytes']
                     li += 1

@@ -90,6 +90,154 @@ void patch_conv_kernel(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Op A fast path (k = 1, whole patch per workgroup): the levels where a patch is 1..16 pixels and the
+// launch is nothing but "read the bank once".  The bank is copied to LDS with 16-byte loads (all of a
+// thread's loads in flight together), the (c, pixel) elements of the stage input are spread over all
+// 256 threads, and when a patch has fewer than 256 outputs the dot products are split SPLIT ways across
+// adjacent lanes and reduced with DPP shuffles, so level 0 (64 outputs of length 82) still uses 4 waves.
+// ------------------------------------------------------------------------------------------
+struct Conv1Args {
+    StageIn in;
+    int fh, fw, ph, pw;
+    const float* __restrict__ bank;
+    long ld;
+    int cout, groups, cin_g, cout_g;
+    const float* __restrict__ scale;
+    const float* __restrict__ shift;
+    int act;
+    float* __restrict__ y;
+    int split;        // power of two <= 64: lanes cooperating on one output
+};
+
+__global__ __launch_bounds__(CONV_THREADS)
+void patch_conv1x1_kernel(Conv1Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int patch = blockIdx.x;
+    const int j = patch % a.fw, i = (patch / a.fw) % a.fh, b = patch / (a.fw * a.fh);
+    const int cin = a.in.cin();
+    const int npix = a.ph * a.pw;
+    const int hp = a.cout * a.cin_g;
+    const int hp4 = (hp + 3) & ~3;
+    float* wl = lds;                 // [cout][cin_g], natural order
+    float* xl = lds + hp4;           // [cin][npix]
+
+    // 1. bank -> LDS, 16-byte loads, up to 8 in flight per thread
+    {
+        const float4* __restrict__ src = reinterpret_cast<const float4*>(a.bank + (size_t)patch * a.ld);
+        float4* dst = reinterpret_cast<float4*>(wl);
+        const int n4 = hp4 >> 2;                      // ld is a multiple of 4 and >= hp: the tail read stays in-row
+        for (int e0 = tid; e0 < n4; e0 += 8 * CONV_THREADS) {
+            float4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int e = e0 + q * CONV_THREADS;
+                if (e < n4) v[q] = src[e];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int e = e0 + q * CONV_THREADS;
+                if (e < n4) dst[e] = v[q];
+            }
+        }
+    }
+    // 2. stage input elements (c, pixel), pixel fastest
+    {
+        const int y0 = i * a.ph, x0 = j * a.pw;
+        const int total = cin * npix;
+        for (int e0 = tid; e0 < total; e0 += 4 * CONV_THREADS) {
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = e0 + q * CONV_THREADS;
+                if (e < total) {
+                    const int c = e / npix, pix = e - c * npix;
+                    const int u = pix / a.pw, vv = pix - u * a.pw;
+                    v[q] = stage_value(a.in, b, c, stage_pos(a.in, y0 + u, x0 + vv));
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = e0 + q * CONV_THREADS;
+                if (e < total) xl[e] = v[q];
+            }
+        }
+    }
+    __syncthreads();
+
+    // 3. outputs: SPLIT adjacent lanes share one (o, pixel)
+    const int split = a.split;
+    const int part = tid & (split - 1);
+    const int per_pass = CONV_THREADS / split;
+    const int total = a.cout * npix;
+    for (int base = 0; base < total; base += per_pass) {
+        const int idx = base + tid / split;
+        const bool live = idx < total;
+        const int o = live ? idx / npix : 0, pix = live ? idx - o * npix : 0;
+        const int g = o / a.cout_g;
+        const float* wr = wl + o * a.cin_g;
+        const float* xr = xl + (size_t)g * a.cin_g * npix + pix;
+        float acc = 0.0f;
+        for (int c = part; c < a.cin_g; c += split) acc = fmaf(wr[c], xr[c * npix], acc);
+        for (int m = split >> 1; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+        if (live && part == 0) {
+            if (a.scale) acc = fmaf(acc, a.scale[o], a.shift[o]);
+            acc = apply_act(acc, a.act);
+            const int u = pix / a.pw, v = pix - u * a.pw;
+            a.y[(((size_t)b * a.cout + o) * a.in.H + (i * a.ph + u)) * a.in.W + (j * a.pw + v)] = acc;
+        }
+    }
+}
+
+// Exact 2x bilinear upsample (align_corners=False): taps are {0.25, 0.75} with edge clamping.  One thread =
+// 2 output rows x 4 output columns from a 3 x 4 input neighbourhood: two 16-byte stores per 12 cached loads.
+__global__ __launch_bounds__(256)
+void upsample2x_kernel(const float* __restrict__ x, int planes, int Hi, int Wi, float* __restrict__ y) {
+    const int wq = Wi >> 1;                 // pairs of input columns
+    const size_t n = (size_t)planes * Hi * wq;
+    const int Wo = 2 * Wi;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const int q = e % wq; size_t r = e / wq;
+        const int yi = r % Hi; const size_t pl = r / Hi;
+        const int xi = 2 * q;
+        const int xm = xi > 0 ? xi - 1 : 0, xp = xi + 2 < Wi ? xi + 2 : Wi - 1;
+        const int ym = yi > 0 ? yi - 1 : 0, yp = yi + 1 < Hi ? yi + 1 : Hi - 1;
+        const float* base = x + pl * Hi * Wi;
+        float in[3][4];
+        const int ys[3] = {ym, yi, yp};
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+            const float* row = base + (size_t)ys[rr] * Wi;
+            in[rr][0] = row[xm]; in[rr][1] = row[xi]; in[rr][2] = row[xi + 1]; in[rr][3] = row[xp];
+        }
+        // horizontal pass, same operation order as ATen: l0*a + l1*b with (l0, l1) = (0.25, 0.75) / (0.75, 0.25)
+        float hz[3][4];
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+            hz[rr][0] = 0.25f * in[rr][0] + 0.75f * in[rr][1];
+            hz[rr][1] = 0.75f * in[rr][1] + 0.25f * in[rr][2];
+            hz[rr][2] = 0.25f * in[rr][1] + 0.75f * in[rr][2];
+            hz[rr][3] = 0.75f * in[rr][2] + 0.25f * in[rr][3];
+        }
+        // ATen clamps the SOURCE index at 0 (lambda = 0 there): first output row/col equal the edge sample
+        if (xi == 0) {
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr) hz[rr][0] = 1.0f * in[rr][1] + 0.0f * in[rr][2];
+        }
+        float4 o0, o1;
+        float* t0 = &o0.x; float* t1 = &o1.x;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            t0[c] = (yi == 0) ? (1.0f * hz[1][c] + 0.0f * hz[2][c]) : (0.25f * hz[0][c] + 0.75f * hz[1][c]);
+            t1[c] = 0.75f * hz[1][c] + 0.25f * hz[2][c];
+        }
+        float* dst = y + (pl * 2 * Hi + 2 * yi) * Wo + 4 * q;
+        *reinterpret_cast<float4*>(dst) = o0;
+        *reinterpret_cast<float4*>(dst + Wo) = o1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 __global__ void stage_input_kernel(StageIn s, float* __restrict__ y) {
     const size_t n = (size_t)s.B * s.cin() * s.H * s.W;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
@@ -155,6 +303,28 @@ extern "C" int hs_patch_conv_fwd(const hs_stage_input* in, int32_t fh, int32_t f
     a.scale = ep ? ep->scale : nullptr; a.shift = ep ? ep->shift : nullptr; a.act = ep ? ep->act : HS_ACT_NONE;
     if (a.scale && !a.shift) return HS_ERR_BAD_ARG;
     a.y = y;
+    if (k == 1) {
+        const size_t hp4 = ((size_t)c_out * a.cin_g + 3) & ~(size_t)3;
+        const size_t lds1 = (hp4 + (size_t)cin * a.ph * a.pw) * sizeof(float);
+        if (lds1 <= 96 * 1024 && (ld & 3) == 0 && a.ph * a.pw <= 4096) {
+            Conv1Args f;
+            f.in = a.in; f.fh = fh; f.fw = fw; f.ph = a.ph; f.pw = a.pw; f.bank = bank; f.ld = ld;
+            f.cout = c_out; f.groups = groups; f.cin_g = a.cin_g; f.cout_g = a.cout_g;
+            f.scale = a.scale; f.shift = a.shift; f.act = a.act; f.y = y;
+            const int outs = c_out * a.ph * a.pw;
+            int split = 1;
+            while (split < 64 && outs * split * 2 <= CONV_THREADS && split * 2 <= a.cin_g) split *= 2;
+            f.split = split;
+            if (lds1 > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute((const void*)patch_conv1x1_kernel,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+                if (e != hipSuccess) return (int)e;
+            }
+            hipLaunchKernelGGL(patch_conv1x1_kernel, dim3((unsigned)((long)in->batch * fh * fw)), dim3(CONV_THREADS),
+                               lds1, (hipStream_t)stream, f);
+            return launch_status();
+        }
+    }
     const int wrow = a.cin_g * k * k;
     a.w_stride = wrow | 1;
     // tile: whole patch if it fits the LDS budget, otherwise split (rows first, then columns)
@@ -194,6 +364,13 @@ extern "C" int hs_stage_input_fwd(const hs_stage_input* in, float* y, void* stre
 extern "C" int hs_upsample_bilinear_fwd(const float* x, int32_t batch, int32_t channels, int32_t Hi, int32_t Wi,
                                         int32_t Ho, int32_t Wo, float* y, void* stream) {
     if (!x || !y || batch <= 0 || channels <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return HS_ERR_BAD_ARG;
+    if (Ho == 2 * Hi && Wo == 2 * Wi && (Wi & 1) == 0) {
+        const size_t n2 = (size_t)batch * channels * Hi * (Wi / 2);
+        const unsigned blocks2 = (unsigned)((n2 + 255) / 256 > 8192 ? 8192 : (n2 + 255) / 256);
+        hipLaunchKernelGGL(upsample2x_kernel, dim3(blocks2), dim3(256), 0, (hipStream_t)stream,
+                           x, batch * channels, Hi, Wi, y);
+        return launch_status();
+    }
     const size_t n = (size_t)batch * channels * Ho * ((Wo + 3) / 4);
     const unsigned blocks = (unsigned)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256);
     hipLaunchKernelGGL(upsample_bilinear_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,

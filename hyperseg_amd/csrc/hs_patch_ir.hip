@@ -40,7 +40,10 @@ struct IrArgs {
 
 __device__ __forceinline__ float relu6f(float v) { return fminf(fmaxf(v, 0.0f), 6.0f); }
 
-template <int CIN, int COUT, bool EXACT>
+// EXACT instantiations are the decoder's fused form: coords + CSKIP skip channels + (CIN-2-CSKIP) channels of
+// the previous level resized bilinearly.  Their prologue issues every HBM load of the column (CSKIP skip loads +
+// 4 taps x CPREV) before the first use, so the ~1 us HBM latency is paid once per tile instead of once per channel.
+template <int CIN, int CSKIP, int COUT, bool EXACT>
 __global__ __launch_bounds__(IR_MAX_THREADS)
 void patch_ir_kernel(IrArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x [IR_HC][npos]
@@ -63,12 +66,37 @@ void patch_ir_kernel(IrArgs a) {
     float T[CIN];
     {
         const int pu = tid / HW, pv = tid - pu * HW;
-        const int yy = pad_index(y0 + pu - 1, a.in.H, HS_PAD_REFLECT);
-        const int xx = pad_index(x0 + pv - 1, a.in.W, HS_PAD_REFLECT);
         const bool live = has_pos && pu < th + 2 && pv < tw + 2;
-        const StagePos sp = stage_pos(a.in, live ? yy : -1, live ? xx : -1);
+        int yy = pad_index(y0 + pu - 1, a.in.H, HS_PAD_REFLECT);
+        int xx = pad_index(x0 + pv - 1, a.in.W, HS_PAD_REFLECT);
+        if constexpr (EXACT) {
+            constexpr int CPREV = CIN - 2 - CSKIP;
+            yy = live ? yy : 0; xx = live ? xx : 0;          // dead lanes read a valid address, result unused
+            T[0] = linspace_pm1(xx, a.in.W, a.in.step_x);
+            T[1] = linspace_pm1(yy, a.in.H, a.in.step_y);
+            const size_t plane = (size_t)a.in.H * a.in.W;
+            const float* __restrict__ sp = a.in.skip + (size_t)b * CSKIP * plane + (size_t)yy * a.in.W + xx;
 #pragma unroll
-        for (int c = 0; c < CIN; ++c) T[c] = (EXACT || c < cin) ? stage_value(a.in, b, c, sp) : 0.0f;
+            for (int c = 0; c < CSKIP; ++c) T[2 + c] = sp[c * plane];
+            const Tap ty = bilinear_tap(yy, a.in.scale_y, a.in.Hp), tx = bilinear_tap(xx, a.in.scale_x, a.in.Wp);
+            const size_t pplane = (size_t)a.in.Hp * a.in.Wp;
+            const float* __restrict__ pp = a.in.prev + (size_t)b * CPREV * pplane;
+            const int o00 = ty.i0 * a.in.Wp + tx.i0, o01 = ty.i0 * a.in.Wp + tx.i1;
+            const int o10 = ty.i1 * a.in.Wp + tx.i0, o11 = ty.i1 * a.in.Wp + tx.i1;
+            float v00[CPREV], v01[CPREV], v10[CPREV], v11[CPREV];
+#pragma unroll
+            for (int c = 0; c < CPREV; ++c) {
+                const float* __restrict__ q = pp + c * pplane;
+                v00[c] = q[o00]; v01[c] = q[o01]; v10[c] = q[o10]; v11[c] = q[o11];
+            }
+#pragma unroll
+            for (int c = 0; c < CPREV; ++c)
+                T[2 + CSKIP + c] = ty.l0 * (tx.l0 * v00[c] + tx.l1 * v01[c]) + ty.l1 * (tx.l0 * v10[c] + tx.l1 * v11[c]);
+        } else {
+            const StagePos sp = stage_pos(a.in, live ? yy : -1, live ? xx : -1);
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) T[c] = (c < cin) ? stage_value(a.in, b, c, sp) : 0.0f;
+        }
     }
     const bool has_pix = tid < npix;
     const int u = tid / a.TW, v = tid - u * a.TW;
@@ -146,14 +174,14 @@ void patch_ir_kernel(IrArgs a) {
     }
 }
 
-template <int CIN, int COUT, bool EXACT>
+template <int CIN, int CSKIP, int COUT, bool EXACT>
 static int launch_ir(const IrArgs& a, int threads, size_t lds, long blocks, hipStream_t stream) {
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)patch_ir_kernel<CIN, COUT, EXACT>,
+        hipError_t e = hipFuncSetAttribute((const void*)patch_ir_kernel<CIN, CSKIP, COUT, EXACT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL((patch_ir_kernel<CIN, COUT, EXACT>), dim3((unsigned)blocks), dim3(threads), lds, stream, a);
+    hipLaunchKernelGGL((patch_ir_kernel<CIN, CSKIP, COUT, EXACT>), dim3((unsigned)blocks), dim3(threads), lds, stream, a);
     return launch_status();
 }
 
@@ -188,16 +216,18 @@ extern "C" int hs_patch_ir_fwd(const hs_stage_input* in, int32_t fh, int32_t fw,
     const size_t lds = (size_t)2 * IR_HC * npos * sizeof(float);
     const long blocks = (long)in->batch * fh * fw * a.tiles_y * a.tiles_x;
     hipStream_t s = (hipStream_t)stream;
-#define HS_IR_CASE(CI, CO) if (a.cin == CI && c_out == CO) return launch_ir<CI, CO, true>(a, threads, lds, blocks, s);
-    HS_IR_CASE(24, 16)   // HyperSeg-M / CamVid-S level 3
-    HS_IR_CASE(34, 19)   // HyperSeg-M level 4 (Cityscapes, 19 classes)
-    HS_IR_CASE(14, 8)    // HyperSeg-S level 3
-    HS_IR_CASE(26, 19)   // HyperSeg-S level 4
-    HS_IR_CASE(22, 12)   // CamVid-S level 4 (12 classes)
+    const bool fused_form = in->coords && a.in.prev_mode == HS_PREV_BILINEAR && !a.residual;
+#define HS_IR_CASE(CI, CS, CO) \
+    if (fused_form && a.cin == CI && in->c_skip == CS && c_out == CO) return launch_ir<CI, CS, CO, true>(a, threads, lds, blocks, s);
+    HS_IR_CASE(24, 6, 16)    // HyperSeg-M / CamVid-S level 3
+    HS_IR_CASE(34, 16, 19)   // HyperSeg-M level 4 (Cityscapes, 19 classes)
+    HS_IR_CASE(14, 4, 8)     // HyperSeg-S level 3
+    HS_IR_CASE(26, 16, 19)   // HyperSeg-S level 4
+    HS_IR_CASE(22, 4, 12)    // CamVid-S level 4 (12 classes)
 #undef HS_IR_CASE
-    if (a.cin <= 16 && c_out <= 16) return launch_ir<16, 16, false>(a, threads, lds, blocks, s);
-    if (a.cin <= 32 && c_out <= 32) return launch_ir<32, 32, false>(a, threads, lds, blocks, s);
-    if (a.cin <= 64 && c_out <= 32) return launch_ir<64, 32, false>(a, threads, lds, blocks, s);
-    if (a.cin <= 128 && c_out <= 64) return launch_ir<128, 64, false>(a, threads, lds, blocks, s);
+    if (a.cin <= 16 && c_out <= 16) return launch_ir<16, 0, 16, false>(a, threads, lds, blocks, s);
+    if (a.cin <= 32 && c_out <= 32) return launch_ir<32, 0, 32, false>(a, threads, lds, blocks, s);
+    if (a.cin <= 64 && c_out <= 32) return launch_ir<64, 0, 32, false>(a, threads, lds, blocks, s);
+    if (a.cin <= 128 && c_out <= 64) return launch_ir<128, 0, 64, false>(a, threads, lds, blocks, s);
     return HS_ERR_UNSUPPORTED;
 }

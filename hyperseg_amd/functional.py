@@ -122,6 +122,48 @@ def signal2weights(signal, wsw_t, signal_index, signal_channels, groups, rows, r
     return out
 
 
+class BankRef:
+    """A bank that already exists (produced by :func:`signal2weights_multi` for a whole decoder).  It stands in
+    for the signal / weight tensor on its way through MetaSequential to the module that consumes it."""
+
+    def __init__(self, bank, batch, rows, grid):
+        self.bank, self.rows, self.grid = bank, rows, tuple(grid)
+        self.shape = torch.Size((batch, rows) + self.grid)
+        self.requires_grad = False
+
+    def __getitem__(self, _):
+        return self            # MetaSequential's channel slice is a no-op on a finished bank
+
+    def dim(self):
+        return 4
+
+
+def signal2weights_multi(signal, layers):
+    """All signal2weights layers of a decoder in ONE launch.  ``layers``: list of dicts with wsw_t, signal_index,
+    signal_channels, groups, rows, row_src (or None).  Returns one BankRef per layer (views of one buffer)."""
+    b, c_view, fh, fw = signal.shape
+    signal, sig_ptr, c_signal = _channel_view(signal, 'signal')
+    p = b * fh * fw
+    lds = [_round_up(l['rows'], 4) for l in layers]
+    buf = torch.empty(p * sum(lds), device=signal.device, dtype=torch.float32)
+    arr = (_hip.S2wLayerC * len(layers))()
+    refs, off = [], 0
+    for i, (l, ld) in enumerate(zip(layers, lds)):
+        if l['signal_index'] + l['signal_channels'] > c_view:
+            raise ValueError('signal slice out of range')
+        bank = buf[off:off + p * ld].view(p, ld)
+        off += p * ld
+        a = arr[i]
+        a.signal_index, a.signal_channels, a.groups = l['signal_index'], l['signal_channels'], l['groups']
+        a.wsw_t, a.wc = _hip.dev_ptr(l['wsw_t'], 'wsw_t'), l['wsw_t'].shape[1]
+        a.row_src = _hip.dev_ptr(l.get('row_src'), 'row_src', torch.int32)
+        a.rows, a.bank, a.ld = l['rows'], bank.data_ptr(), ld
+        refs.append(BankRef(bank, b, l['rows'], (fh, fw)))
+    st = _hip.lib.hs_signal2weights_multi_fwd(sig_ptr, b, c_signal, fh, fw, arr, len(layers), _hip.stream_ptr())
+    _hip.check(st, 'hs_signal2weights_multi_fwd')
+    return refs
+
+
 def bank_pack(w, ch_offset, rows, row_src=None, out=None):
     """(B, hp_total, fh, fw) channel-major weights -> patch-major bank (B*fh*fw, ld)."""
     b, c_view, fh, fw = w.shape

@@ -52,7 +52,17 @@ class _SignalToWeights:
         self.signal_index = signal_index
         self.signal2weights = nn.Conv2d(signal_channels, weight_channels, 1, bias=False, groups=groups)
 
+    def _s2w_layer(self, rows, row_src=None):
+        """Descriptor of this module's signal2weights for the decoder-wide single launch."""
+        conv = self.signal2weights
+        return dict(wsw_t=self._s2w_t.get(conv), signal_index=self.signal_index,
+                    signal_channels=self.signal_channels, groups=conv.groups, rows=rows, row_src=row_src)
+
     def _bank(self, s, rows, row_src=None):
+        if isinstance(s, HF.BankRef):
+            if s.rows != rows:
+                raise ValueError(f'bank has {s.rows} rows, module needs {rows}')
+            return s.bank
         conv = self.signal2weights
         if conv is None:
             # no hypernetwork head: ``s`` already holds the weights (B, hp, fh, fw)
@@ -92,6 +102,9 @@ class HyperPatchNoPadding(nn.Module, _SignalToWeights):
     def init_signal2weights(self, signal_channels, signal_index=0, groups=1):
         self._make_signal2weights(signal_channels, signal_index, groups, next_multiply(self.hyper_params, groups))
 
+    def s2w_layer(self, device):
+        return self._s2w_layer(self.hyper_params)
+
     def forward_fused(self, x, s, scale=None, shift=None, act=HF.ACT_NONE):
         if self.kernel_size != (1, 1) or self.stride != (1, 1) or self.dilation != (1, 1):
             raise NotImplementedError('HyperPatchNoPadding: only the k=1, stride 1 form the reference builds '
@@ -125,6 +138,9 @@ class HyperPatch(nn.Module, _SignalToWeights):
     def init_signal2weights(self, signal_channels, signal_index=0, groups=1):
         # NB: no next_multiply here in the reference (hyperseg_v1_0.py:532-535)
         self._make_signal2weights(signal_channels, signal_index, groups, self.hyper_params)
+
+    def s2w_layer(self, device):
+        return self._s2w_layer(self.hyper_params)
 
     def forward_fused(self, x, s, scale=None, shift=None, act=HF.ACT_NONE):
         conv = self.hyper_module
@@ -210,6 +226,9 @@ class HyperPatchInvertedResidual(nn.Module, _SignalToWeights):
         if self._row_src is None or self._row_src.device != device:
             self._row_src = HF.ir_row_map(self.in_nc, self.hidden_dim, self.out_nc, device)
         return self._row_src
+
+    def s2w_layer(self, device):
+        return self._s2w_layer(self.hyper_params, self._rows(device))
 
     def _run(self, x, s, residual):
         self._check_supported()
@@ -403,15 +422,41 @@ class MultiScaleDecoder(nn.Module):
             return getattr(self, cache).expand(b, -1, -1, -1)
         return self.cache_image_coordinates(h, w).to(device).expand(b, -1, -1, -1)
 
+    def _hyper_modules(self):
+        """Signal-fed modules per top-level child, in the order MetaSequential consumes weight-list entries."""
+        if getattr(self, '_hyper_cache', None) is None:
+            def collect(m):
+                out = []
+                for _, c in m.named_children():
+                    out.extend([c] if isinstance(c, _HYPER_TYPES) else collect(c))
+                return out
+            self._hyper_cache = [collect(getattr(self, f'level_{l}')) for l in range(self.levels)]
+            self._hyper_cache.append(collect(self.out_fc) if self.out_fc is not None else [])
+        return self._hyper_cache
+
     def forward(self, x, s):
+        # every level's filter bank in ONE launch (the banks only depend on the signal)
+        groups = self._hyper_modules()
+        flat = [m for g in groups for m in g]
+        _require_inference(s, *[m.signal2weights.weight for m in flat])
+        for m in flat:
+            # the reference hands each module s[:, 0:hyper_params] (MetaSequential's clamped slice, Appendix D-2)
+            if m.signal_index + m.signal_channels > min(int(m.hyper_params), s.shape[1]):
+                raise ValueError('signal slice of a decoder level exceeds what MetaSequential would hand to it')
+        sig = s
+        refs = HF.signal2weights_multi(sig, [m.s2w_layer(s.device) for m in flat])
+        banks, k = [], 0
+        for g in groups:
+            banks.append(refs[k:k + len(g)])
+            k += len(g)
         p = None
         for level in range(self.levels):
             level_layers = getattr(self, f'level_{level}')
             # cat(coords, skip, bilinear(p)) is never built: the stage kernel's prologue generates it
             stage = HF.StageInput(x[-level - 1], p, coords=True)
-            p = level_layers(stage, s)
+            p = level_layers(stage, banks[level])
         if self.out_fc is not None:
-            p = self.out_fc(p, s)
+            p = self.out_fc(p, banks[-1])
         if p.shape[2:] != x[0].shape[2:]:
             p = HF.upsample_bilinear(p, x[0].shape[2:])
         return p

@@ -82,6 +82,20 @@ int hs_signal2weights_fwd(const float* signal, int32_t batch, int32_t c_signal, 
                           const int32_t* row_src, int32_t rows,
                           float* bank, int64_t ld, void* stream);
 
+/* The same for up to 8 signal2weights layers (all levels of a decoder) in ONE launch: every layer reads its own
+ * slice of the same signal and writes its own bank. */
+typedef struct {
+    int32_t signal_index, signal_channels, groups;
+    const float* wsw_t;        /* (signal_channels/groups, wc) */
+    int32_t wc;
+    const int32_t* row_src;    /* NULL = identity */
+    int32_t rows;
+    float* bank;
+    int64_t ld;
+} hs_s2w_layer;
+int hs_signal2weights_multi_fwd(const float* signal, int32_t batch, int32_t c_signal, int32_t fh, int32_t fw,
+                                const hs_s2w_layer* layers, int32_t n_layers, void* stream);
+
 /* Re-layout of a reference-layout weight tensor (B, hp_total, fh, fw) (channel-major, as
  * MetaPatch.forward / HyperPatchInvertedResidual receive it: meta_patch.py:49,
  * hyperseg_v1_0_unify.py:335-349) into a patch-major bank:

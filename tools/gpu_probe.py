@@ -28,7 +28,7 @@ def main():
 
     # per-launch timing: wrap the functional entry points
     records = {}
-    names = ['signal2weights', 'bank_pack', 'patch_conv', 'patch_ir', 'upsample_bilinear']
+    names = ['signal2weights', 'signal2weights_multi', 'bank_pack', 'patch_conv', 'patch_ir', 'upsample_bilinear']
     orig = {n: getattr(HF, n) for n in names}
     counter = [0]
 
