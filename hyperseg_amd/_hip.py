@@ -37,7 +37,7 @@ class EpilogueC(C.Structure):
 
 class S2wLayerC(C.Structure):
     _fields_ = [('signal_index', C.c_int32), ('signal_channels', C.c_int32), ('groups', C.c_int32),
-                ('wsw_t', C.c_void_p), ('wc', C.c_int32), ('row_src', C.c_void_p), ('rows', C.c_int32),
+                ('wsw_t', C.c_void_p), ('wc', C.c_int32), ('rows', C.c_int32),
                 ('bank', C.c_void_p), ('ld', C.c_int64)]
 
 
@@ -51,15 +51,14 @@ def _load():
     sig = {
         'hs_version': ([], C.c_int),
         'hs_build_info': ([], C.c_char_p),
-        'hs_signal2weights_fwd': ([vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i64, vp], C.c_int),
+        'hs_signal2weights_fwd': ([vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp, i64, vp], C.c_int),
         'hs_signal2weights_multi_fwd': ([vp, i32, i32, i32, i32, C.POINTER(S2wLayerC), i32, vp], C.c_int),
-        'hs_bank_pack_fwd': ([vp, i32, i32, i32, i32, i32, vp, i32, vp, i64, vp], C.c_int),
+        'hs_bank_pack_fwd': ([vp, i32, i32, i32, i32, i32, i32, vp, i64, vp], C.c_int),
         'hs_bn_fold_fwd': ([vp, vp, vp, vp, C.c_float, i32, vp, vp, vp], C.c_int),
         'hs_patch_conv_fwd': ([C.POINTER(StageInputC), i32, i32, vp, i64, i32, i32, i32, i32, i32,
                                C.POINTER(EpilogueC), vp, vp], C.c_int),
         'hs_patch_ir_fwd': ([C.POINTER(StageInputC), i32, i32, vp, i64, i32, i32, C.POINTER(EpilogueC),
                              C.POINTER(EpilogueC), C.POINTER(EpilogueC), i32, vp, vp], C.c_int),
-        'hs_ir_row_map': ([i32, i32, i32, C.POINTER(i32)], C.c_int),
         'hs_upsample_bilinear_fwd': ([vp, i32, i32, i32, i32, i32, i32, vp, vp], C.c_int),
         'hs_stage_input_fwd': ([C.POINTER(StageInputC), vp, vp], C.c_int),
     }
@@ -73,7 +72,7 @@ def _load():
 
 lib = _load()
 EXPORTS = ['hs_version', 'hs_build_info', 'hs_signal2weights_fwd', 'hs_signal2weights_multi_fwd', 'hs_bank_pack_fwd', 'hs_bn_fold_fwd',
-           'hs_patch_conv_fwd', 'hs_patch_ir_fwd', 'hs_ir_row_map', 'hs_upsample_bilinear_fwd',
+           'hs_patch_conv_fwd', 'hs_patch_ir_fwd', 'hs_upsample_bilinear_fwd',
            'hs_stage_input_fwd']
 
 

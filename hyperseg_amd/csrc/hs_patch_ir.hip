@@ -11,8 +11,8 @@
 //              operands of v_fmac -- no LDS traffic and no VGPRs for weights.  h1 goes to LDS
 //              in chunks of HC hidden channels (double-buffered, one barrier per chunk).
 //   dw + pw3   every thread owns ONE output pixel: 9 LDS reads of h1 per hidden channel,
-//              depthwise 3x3 + bn2 + relu6 in registers, then COUT FMAs into register
-//              accumulators with W3T[h][:] again as scalar operands.
+//              depthwise 3x3 + bn2 + relu6 in registers, then COUT x chunk FMAs into register
+//              accumulators with W3[o][chunk] again as scalar operands (natural bank order).
 //   epilogue   bn3 (+ residual) and one store per (o, pixel); rows are contiguous.
 //
 // Hidden activations (hid x 324 floats per patch at HyperSeg-M level 4) never leave the CU.
@@ -105,7 +105,7 @@ void patch_ir_kernel(IrArgs a) {
     const float* __restrict__ wp = a.bank + (size_t)patch * a.ld;   // uniform -> scalar loads
     const float* __restrict__ w1 = wp;
     const float* __restrict__ kd = wp + (size_t)cin * hid;
-    const float* __restrict__ w3t = kd + (size_t)9 * hid;
+    const float* __restrict__ w3 = kd + (size_t)9 * hid;
 
     float out[COUT];
 #pragma unroll
@@ -127,20 +127,31 @@ void patch_ir_kernel(IrArgs a) {
     auto dw_pw3_chunk = [&](int h0, const float* buf) {
         if (!has_pix) return;
         const int hc = min(IR_HC, hid - h0);
-        for (int hh = 0; hh < hc; ++hh) {
-            const int h = h0 + hh;
-            const float* __restrict__ kr = kd + (size_t)h * 9;
-            const float* t = buf + hh * npos + dw_off;
-            float d = 0.0f;
+        float h2c[IR_HC];                       // depthwise outputs of the chunk for this pixel
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+        for (int hh = 0; hh < IR_HC; ++hh) {
+            h2c[hh] = 0.0f;
+            if (hh < hc) {
+                const int h = h0 + hh;
+                const float* __restrict__ kr = kd + (size_t)h * 9;
+                const float* t = buf + hh * npos + dw_off;
+                float d = 0.0f;
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) d = fmaf(kr[ky * 3 + kx], t[ky * HW + kx], d);
-            d = relu6f(fmaf(d, a.s2[h], a.b2[h]));
-            const float* __restrict__ w3r = w3t + (size_t)h * cout;
+                for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int o = 0; o < COUT; ++o)
-                if (EXACT || o < cout) out[o] = fmaf(w3r[o], d, out[o]);
+                    for (int kx = 0; kx < 3; ++kx) d = fmaf(kr[ky * 3 + kx], t[ky * HW + kx], d);
+                h2c[hh] = relu6f(fmaf(d, a.s2[h], a.b2[h]));
+            }
+        }
+        // pw3 in the natural bank order W3[o][h]: a contiguous run of the chunk's weights per output channel
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) {
+            if (EXACT || o < cout) {
+                const float* __restrict__ w3r = w3 + (size_t)o * hid + h0;
+#pragma unroll
+                for (int hh = 0; hh < IR_HC; ++hh)
+                    if (hh < hc) out[o] = fmaf(w3r[hh], h2c[hh], out[o]);
+            }
         }
     };
 

@@ -10,25 +10,30 @@
 namespace hs {
 
 // ------------------------------------------------------------------------------------------
-// signal2weights, all levels of a decoder in ONE launch.  Block = 256 threads = (2 adjacent bank
-// rows per thread) x 16 patches of one layer.  The signal slice of the 16 patches is staged once in
-// LDS as [channel][patch] so that one ds_read_b128 feeds 4 patches x 2 rows = 8 FMAs; the
-// (transposed) Conv2d weight is read coalesced from L2, 8 k-steps of loads in flight at a time
-// (the grid is only ~4 waves per CU, so latency has to be covered inside the wave).
+// signal2weights, all levels of a decoder in ONE launch, on the f32 MATRIX cores.
+//
+// Per layer and group this is a dense GEMM  bank[p, n] = sum_k S[p, k] * Wsw[n, k]  (M = rows of the group,
+// N = patches, K = Cs/G = 7..80) -- exactly the case the north star reserves MFMA for.  One wave owns a strip of
+// 32 bank rows (two 16x16 tiles sharing the signal operand) and walks 16-patch tiles with
+// v_mfma_f32_16x16x4_f32 (exact fp32: a k-ordered fma chain, bit-compatible with the VALU form):
+//   A[i = row][k]     lane l holds Wsw_t[k0 + (l>>4)][n0 + (l&15)]      64-byte coalesced runs, L2 resident
+//   B[k][j = patch]   lane l holds S[b, idx + g*K + k0 + (l>>4), ij]    16 consecutive patches = 64 bytes
+//   D[i][j]           lane l holds rows n0 + 4*(l>>4) + {0..3} of patch p0 + (l&15) -> one 16-byte store
+// No LDS, no scalar-cache traffic; operand loads are independent of the accumulator chain so they stream.
 // ------------------------------------------------------------------------------------------
-constexpr int S2W_TP = 16;     // patches per block
-constexpr int S2W_THREADS = 256;
-constexpr int S2W_ROWS = 2 * S2W_THREADS;
-constexpr int S2W_KU = 8;      // k-steps per load batch
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int S2W_THREADS = 256;          // 4 waves
+constexpr int S2W_STRIP = 32;             // bank rows per wave-task (2 MFMA row tiles)
+constexpr int S2W_PT = 8;                 // 16-patch tiles per wave-task
 constexpr int S2W_MAX_LAYERS = 8;
 
 struct S2wLayer {
     const float* __restrict__ wsw_t;
-    const int* __restrict__ row_src;
     float* __restrict__ bank;
     long ld;
-    int signal_index, signal_channels, cs_g, rows_per_group, wc, rows;
-    int block_begin;           // first blockIdx.x of this layer
+    int signal_index, cs_g, rows_per_group, wc, rows;
+    int strips_per_group, strip_begin;     // strips of this layer start at blockIdx.x == strip_begin
 };
 struct S2wArgs {
     const float* __restrict__ signal;
@@ -38,105 +43,76 @@ struct S2wArgs {
 
 __global__ __launch_bounds__(S2W_THREADS)
 void signal2weights_kernel(S2wArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float s_lds[];   // [signal_channels][16]
-    const int tid = threadIdx.x;
-    const int p0 = blockIdx.y * S2W_TP;
+    // layer descriptor through the kernarg segment with a uniform index -> scalar loads, no register copies
+    const __attribute__((address_space(4))) S2wArgs* ka =
+        (const __attribute__((address_space(4))) S2wArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     int li = 0;
-#pragma unroll
-    for (int q = 1; q < S2W_MAX_LAYERS; ++q)
-        if (q < a.n_layers && (int)blockIdx.x >= a.layer[q].block_begin) li = q;
-    const S2wLayer& L = a.layer[li];
-    const int signal_channels = L.signal_channels, cs_g = L.cs_g, wc = L.wc, rows = L.rows;
+    for (int q = 1; q < ka->n_layers; ++q)
+        if ((int)blockIdx.x >= ka->layer[q].strip_begin) li = q;
+    const float* __restrict__ wsw_t = ka->layer[li].wsw_t;
+    float* __restrict__ bank = ka->layer[li].bank;
+    const long ld = ka->layer[li].ld;
+    const int signal_index = ka->layer[li].signal_index, cs_g = ka->layer[li].cs_g;
+    const int rpg = ka->layer[li].rows_per_group, wc = ka->layer[li].wc, rows = ka->layer[li].rows;
+    const int spg = ka->layer[li].strips_per_group;
+    const int strip = (int)blockIdx.x - ka->layer[li].strip_begin;
+    const int grid_sz = ka->grid_sz, n_patches = ka->n_patches, c_signal = ka->c_signal;
+    const float* __restrict__ signal = ka->signal;
 
-    // stage signal[b, signal_index + c, ij] for the block's 16 patches, patch index fastest
-    {
-        const int t = tid % S2W_TP;
-        const int p = p0 + t;
-        const bool ok = p < a.n_patches;
-        const int bb = ok ? p / a.grid_sz : 0, ij = ok ? p - bb * a.grid_sz : 0;
-        const float* __restrict__ src = a.signal + ((size_t)bb * a.c_signal + L.signal_index) * a.grid_sz + ij;
-        constexpr int CSTEP = S2W_THREADS / S2W_TP;     // 16 channels per pass
-        for (int c0 = tid / S2W_TP; c0 < signal_channels; c0 += 4 * CSTEP) {
-            float v[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c = c0 + q * CSTEP;
-                v[q] = (ok && c < signal_channels) ? src[(size_t)c * a.grid_sz] : 0.0f;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c = c0 + q * CSTEP;
-                if (c < signal_channels) s_lds[c * S2W_TP + t] = v[q];
-            }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = strip / spg;
+    const int r0 = (strip - g * spg) * S2W_STRIP;            // first row of the strip inside the group
+    const int n0 = g * rpg + r0;                             // natural row index
+    const int lrow = lane & 15, lk = lane >> 4;
+
+    // per-lane row validity of the two A tiles
+    const bool a0_ok = (r0 + lrow) < rpg;
+    const bool a1_ok = (r0 + 16 + lrow) < rpg;
+    // clamped row addresses: masked lanes still read inside the (cs_g, wc) array
+    const float* __restrict__ wa0 = wsw_t + min(n0 + lrow, wc - 1);        // + k*wc
+    const float* __restrict__ wa1 = wsw_t + min(n0 + 16 + lrow, wc - 1);
+    const int ksteps = (cs_g + 3) >> 2;
+    const size_t sig_base = (size_t)(signal_index + g * cs_g) * grid_sz;
+
+    const int tile0 = (blockIdx.y * 4 + wave) * S2W_PT;
+    for (int t = 0; t < S2W_PT; ++t) {
+        const int p0 = (tile0 + t) * 16;
+        if (p0 >= n_patches) break;
+        const int p = p0 + lrow;
+        const bool p_ok = p < n_patches;
+        const int bb = p_ok ? p / grid_sz : 0, ij = p_ok ? p - bb * grid_sz : 0;
+        const float* __restrict__ sb = signal + (size_t)bb * c_signal * grid_sz + sig_base + ij;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int ks = 0; ks < ksteps; ++ks) {
+            const int k = ks * 4 + lk;
+            const bool k_ok = k < cs_g;
+            const int kc = k_ok ? k : 0;
+            const float w0 = wa0[(size_t)kc * wc], w1 = wa1[(size_t)kc * wc];
+            const float sv = sb[(size_t)kc * grid_sz];
+            const float fa0 = (k_ok && a0_ok) ? w0 : 0.0f;
+            const float fa1 = (k_ok && a1_ok) ? w1 : 0.0f;
+            const float fb = (k_ok && p_ok) ? sv : 0.0f;
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0, fb, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1, fb, acc1, 0, 0, 0);
         }
-    }
-    __syncthreads();
-
-    const int m0 = ((int)blockIdx.x - L.block_begin) * S2W_ROWS + 2 * tid;
-    if (m0 >= rows) return;
-    const bool has1 = (m0 + 1) < rows;
-    const int n0 = L.row_src ? L.row_src[m0] : m0;
-    const int n1 = has1 ? (L.row_src ? L.row_src[m0 + 1] : m0 + 1) : -1;
-    const int g0 = n0 >= 0 ? n0 / L.rows_per_group : 0;
-    const int g1 = n1 >= 0 ? n1 / L.rows_per_group : g0;
-    const bool same = (g0 == g1);
-
-    float acc0[S2W_TP], acc1[S2W_TP];
+        if (!p_ok) continue;
+        // D: this lane holds rows (tile row 4*lk + r) of patch p
+        float* __restrict__ dst = bank + (size_t)p * ld + n0 + 4 * lk;
+        const int rr0 = r0 + 4 * lk;                          // row inside the group of acc0[0]
 #pragma unroll
-    for (int t = 0; t < S2W_TP; ++t) { acc0[t] = 0.0f; acc1[t] = 0.0f; }
-
-    const float4* s0 = reinterpret_cast<const float4*>(s_lds + (size_t)g0 * cs_g * S2W_TP);
-    const float4* s1 = reinterpret_cast<const float4*>(s_lds + (size_t)g1 * cs_g * S2W_TP);
-    const float* __restrict__ w0p = L.wsw_t + (n0 >= 0 ? n0 : 0);
-    const float* __restrict__ w1p = L.wsw_t + (n1 >= 0 ? n1 : 0);
-    for (int k0 = 0; k0 < cs_g; k0 += S2W_KU) {
-        float w0[S2W_KU], w1[S2W_KU];
+        for (int half = 0; half < 2; ++half) {
+            const f32x4 v = half ? acc1 : acc0;
+            const int rg = rr0 + 16 * half;                    // row in group
+            const int n = n0 + 4 * lk + 16 * half;             // natural row
+            float* d = dst + 16 * half;
+            if (rg + 3 < rpg && n + 3 < rows && ((((size_t)p * ld + n) & 3) == 0)) {
+                *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
 #pragma unroll
-        for (int q = 0; q < S2W_KU; ++q) {               // 16 independent L2 loads in flight
-            const int k = k0 + q;
-            const int kc = k < cs_g ? k : cs_g - 1;
-            const float a0 = w0p[(size_t)kc * wc], a1 = w1p[(size_t)kc * wc];
-            w0[q] = (n0 >= 0 && k < cs_g) ? a0 : 0.0f;
-            w1[q] = (n1 >= 0 && k < cs_g) ? a1 : 0.0f;
-        }
-#pragma unroll
-        for (int q = 0; q < S2W_KU; ++q) {
-            const int k = (k0 + q) < cs_g ? (k0 + q) : cs_g - 1;
-            float4 v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = s0[k * 4 + r];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc0[4 * r + 0] = fmaf(w0[q], v[r].x, acc0[4 * r + 0]);
-                acc0[4 * r + 1] = fmaf(w0[q], v[r].y, acc0[4 * r + 1]);
-                acc0[4 * r + 2] = fmaf(w0[q], v[r].z, acc0[4 * r + 2]);
-                acc0[4 * r + 3] = fmaf(w0[q], v[r].w, acc0[4 * r + 3]);
+                for (int r = 0; r < 4; ++r)
+                    if (rg + r < rpg && n + r < rows) d[r] = v[r];
             }
-            if (!same) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = s1[k * 4 + r];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc1[4 * r + 0] = fmaf(w1[q], v[r].x, acc1[4 * r + 0]);
-                acc1[4 * r + 1] = fmaf(w1[q], v[r].y, acc1[4 * r + 1]);
-                acc1[4 * r + 2] = fmaf(w1[q], v[r].z, acc1[4 * r + 2]);
-                acc1[4 * r + 3] = fmaf(w1[q], v[r].w, acc1[4 * r + 3]);
-            }
-        }
-    }
-    // bank rows m0, m0+1 of 16 patches: 8-byte stores, consecutive lanes -> consecutive rows
-    const bool vec = has1 && ((L.ld & 1) == 0);
-#pragma unroll
-    for (int t = 0; t < S2W_TP; ++t) {
-        const int p = p0 + t;
-        if (p >= a.n_patches) break;
-        float* dst = L.bank + (size_t)p * L.ld + m0;
-        if (vec) {
-            *reinterpret_cast<float2*>(dst) = make_float2(acc0[t], acc1[t]);
-        } else {
-            dst[0] = acc0[t];
-            if (has1) dst[1] = acc1[t];
         }
     }
 }
@@ -146,7 +122,7 @@ void signal2weights_kernel(S2wArgs a) {
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
 void bank_pack_kernel(const float* __restrict__ w, int hp_total, int grid_sz, int ch_offset,
-                      const int* __restrict__ row_src, int rows, float* __restrict__ bank, long ld) {
+                      int rows, float* __restrict__ bank, long ld) {
     __shared__ float tile[32][33];
     const int b = blockIdx.z;
     const int m_base = blockIdx.x * 32, q_base = blockIdx.y * 32;   // q = i*fw + j
@@ -154,10 +130,7 @@ void bank_pack_kernel(const float* __restrict__ w, int hp_total, int grid_sz, in
     for (int r = ty; r < 32; r += 8) {
         const int m = m_base + r, q = q_base + tx;
         float v = 0.0f;
-        if (m < rows && q < grid_sz) {
-            const int n = row_src ? row_src[m] : m;
-            if (n >= 0) v = w[((size_t)b * hp_total + ch_offset + n) * grid_sz + q];
-        }
+        if (m < rows && q < grid_sz) v = w[((size_t)b * hp_total + ch_offset + m) * grid_sz + q];
         tile[r][tx] = v;
     }
     __syncthreads();
@@ -188,53 +161,45 @@ extern "C" int hs_signal2weights_multi_fwd(const float* signal, int32_t batch, i
     if (batch <= 0 || fh <= 0 || fw <= 0) return HS_ERR_BAD_ARG;
     S2wArgs a;
     a.signal = signal; a.c_signal = c_signal; a.grid_sz = fh * fw; a.n_patches = batch * fh * fw; a.n_layers = n_layers;
-    int blocks = 0;
-    size_t lds = 0;
+    int strips = 0;
     for (int i = 0; i < n_layers; ++i) {
         const hs_s2w_layer& l = layers[i];
-        if (!l.wsw_t || !l.bank || l.groups <= 0 || l.rows <= 0 || l.wc <= 0 || l.ld < l.rows) return HS_ERR_BAD_ARG;
+        if (!l.wsw_t || !l.bank || l.groups <= 0 || l.rows <= 0 || l.wc <= 0 || l.ld < l.rows || l.rows > l.wc) return HS_ERR_BAD_ARG;
         if (l.signal_index < 0 || l.signal_channels <= 0 || l.signal_index + l.signal_channels > c_signal) return HS_ERR_BAD_ARG;
         if (l.signal_channels % l.groups != 0 || l.wc % l.groups != 0) return HS_ERR_BAD_ARG;
         S2wLayer& d = a.layer[i];
-        d.wsw_t = l.wsw_t; d.row_src = l.row_src; d.bank = l.bank; d.ld = (long)l.ld;
-        d.signal_index = l.signal_index; d.signal_channels = l.signal_channels;
+        d.wsw_t = l.wsw_t; d.bank = l.bank; d.ld = (long)l.ld;
+        d.signal_index = l.signal_index;
         d.cs_g = l.signal_channels / l.groups; d.rows_per_group = l.wc / l.groups; d.wc = l.wc; d.rows = l.rows;
-        d.block_begin = blocks;
-        blocks += (l.rows + S2W_ROWS - 1) / S2W_ROWS;
-        const size_t need = (size_t)l.signal_channels * S2W_TP * sizeof(float);
-        lds = need > lds ? need : lds;
+        d.strips_per_group = (d.rows_per_group + S2W_STRIP - 1) / S2W_STRIP;
+        d.strip_begin = strips;
+        strips += d.strips_per_group * l.groups;
     }
-    for (int i = n_layers; i < S2W_MAX_LAYERS; ++i) { a.layer[i] = a.layer[0]; a.layer[i].block_begin = 0x7fffffff; }
-    if (lds > 160 * 1024) return HS_ERR_LDS;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)signal2weights_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-    }
-    dim3 grid(blocks, (a.n_patches + S2W_TP - 1) / S2W_TP);
-    hipLaunchKernelGGL(signal2weights_kernel, grid, dim3(S2W_THREADS), lds, (hipStream_t)stream, a);
+    for (int i = n_layers; i < S2W_MAX_LAYERS; ++i) { a.layer[i] = a.layer[0]; a.layer[i].strip_begin = 0x7fffffff; }
+    const int tiles = (a.n_patches + 15) / 16;
+    dim3 grid(strips, (tiles + 4 * S2W_PT - 1) / (4 * S2W_PT));
+    hipLaunchKernelGGL(signal2weights_kernel, grid, dim3(S2W_THREADS), 0, (hipStream_t)stream, a);
     return launch_status();
 }
 
 extern "C" int hs_signal2weights_fwd(const float* signal, int32_t batch, int32_t c_signal, int32_t fh, int32_t fw,
                                      int32_t signal_index, int32_t signal_channels, int32_t groups,
-                                     const float* wsw_t, int32_t wc, const int32_t* row_src, int32_t rows,
+                                     const float* wsw_t, int32_t wc, int32_t rows,
                                      float* bank, int64_t ld, void* stream) {
     hs_s2w_layer l;
     l.signal_index = signal_index; l.signal_channels = signal_channels; l.groups = groups;
-    l.wsw_t = wsw_t; l.wc = wc; l.row_src = row_src; l.rows = rows; l.bank = bank; l.ld = ld;
+    l.wsw_t = wsw_t; l.wc = wc; l.rows = rows; l.bank = bank; l.ld = ld;
     return hs_signal2weights_multi_fwd(signal, batch, c_signal, fh, fw, &l, 1, stream);
 }
 
 extern "C" int hs_bank_pack_fwd(const float* w, int32_t batch, int32_t hp_total, int32_t fh, int32_t fw,
-                                int32_t ch_offset, const int32_t* row_src, int32_t rows,
-                                float* bank, int64_t ld, void* stream) {
+                                int32_t ch_offset, int32_t rows, float* bank, int64_t ld, void* stream) {
     if (!w || !bank || batch <= 0 || fh <= 0 || fw <= 0 || rows <= 0 || ld < rows || ch_offset < 0) return HS_ERR_BAD_ARG;
-    if (!row_src && ch_offset + rows > hp_total) return HS_ERR_BAD_ARG;
+    if (ch_offset + rows > hp_total) return HS_ERR_BAD_ARG;
     const int grid_sz = fh * fw;
     dim3 grid((rows + 31) / 32, (grid_sz + 31) / 32, batch);
     hipLaunchKernelGGL(bank_pack_kernel, grid, dim3(256), 0, (hipStream_t)stream,
-                       w, hp_total, grid_sz, ch_offset, row_src, rows, bank, (long)ld);
+                       w, hp_total, grid_sz, ch_offset, rows, bank, (long)ld);
     return launch_status();
 }
 
@@ -244,18 +209,6 @@ extern "C" int hs_bn_fold_fwd(const float* gamma, const float* beta, const float
     hipLaunchKernelGGL(bn_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        gamma, beta, mean, var, eps, n, scale, shift);
     return launch_status();
-}
-
-extern "C" int hs_ir_row_map(int32_t cin, int32_t hidden, int32_t c_out, int32_t* row_src) {
-    if (cin <= 0 || hidden <= 0 || c_out <= 0) return HS_ERR_BAD_ARG;
-    const int r2 = cin * hidden + 9 * hidden;
-    const int rows = r2 + hidden * c_out;
-    if (row_src) {
-        for (int m = 0; m < r2; ++m) row_src[m] = m;
-        for (int h = 0; h < hidden; ++h)
-            for (int o = 0; o < c_out; ++o) row_src[r2 + h * c_out + o] = r2 + o * hidden + h;
-    }
-    return rows;
 }
 
 extern "C" int hs_version(void) { return HS_ABI_VERSION; }

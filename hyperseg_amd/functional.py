@@ -94,15 +94,7 @@ def _epilogue(scale=None, shift=None, act=ACT_NONE):
     return ep
 
 
-def ir_row_map(cin, hidden, c_out, device):
-    """int32 row map of hs_patch_ir_fwd's bank order (W1 | K | W3 transposed) -> natural reference rows."""
-    rows = _hip.lib.hs_ir_row_map(cin, hidden, c_out, None)
-    buf = (C.c_int32 * rows)()
-    _hip.lib.hs_ir_row_map(cin, hidden, c_out, buf)
-    return torch.tensor(list(buf), dtype=torch.int32, device=device)
-
-
-def signal2weights(signal, wsw_t, signal_index, signal_channels, groups, rows, row_src=None, out=None):
+def signal2weights(signal, wsw_t, signal_index, signal_channels, groups, rows, out=None):
     """Grouped 1x1 conv of the signal slice -> patch-major bank (B*fh*fw, ld).  ``wsw_t`` is the
     Conv2d weight transposed to (Cs/G, Wc).  Replaces signal2weights(...)[:, :hp] + permute copy."""
     b, c_view, fh, fw = signal.shape
@@ -116,7 +108,7 @@ def signal2weights(signal, wsw_t, signal_index, signal_channels, groups, rows, r
         out = torch.empty(b * fh * fw, ld, device=signal.device, dtype=torch.float32)
     st = _hip.lib.hs_signal2weights_fwd(
         sig_ptr, b, c_signal, fh, fw, signal_index, signal_channels, groups,
-        _hip.dev_ptr(wsw_t, 'wsw_t'), wc, _hip.dev_ptr(row_src, 'row_src', torch.int32), rows,
+        _hip.dev_ptr(wsw_t, 'wsw_t'), wc, rows,
         _hip.dev_ptr(out, 'bank'), out.stride(0), _hip.stream_ptr())
     _hip.check(st, 'hs_signal2weights_fwd')
     return out
@@ -140,7 +132,7 @@ class BankRef:
 
 def signal2weights_multi(signal, layers):
     """All signal2weights layers of a decoder in ONE launch.  ``layers``: list of dicts with wsw_t, signal_index,
-    signal_channels, groups, rows, row_src (or None).  Returns one BankRef per layer (views of one buffer)."""
+    signal_channels, groups, rows.  Returns one BankRef per layer (views of one buffer)."""
     b, c_view, fh, fw = signal.shape
     signal, sig_ptr, c_signal = _channel_view(signal, 'signal')
     p = b * fh * fw
@@ -156,7 +148,6 @@ def signal2weights_multi(signal, layers):
         a = arr[i]
         a.signal_index, a.signal_channels, a.groups = l['signal_index'], l['signal_channels'], l['groups']
         a.wsw_t, a.wc = _hip.dev_ptr(l['wsw_t'], 'wsw_t'), l['wsw_t'].shape[1]
-        a.row_src = _hip.dev_ptr(l.get('row_src'), 'row_src', torch.int32)
         a.rows, a.bank, a.ld = l['rows'], bank.data_ptr(), ld
         refs.append(BankRef(bank, b, l['rows'], (fh, fw)))
     st = _hip.lib.hs_signal2weights_multi_fwd(sig_ptr, b, c_signal, fh, fw, arr, len(layers), _hip.stream_ptr())
@@ -164,17 +155,16 @@ def signal2weights_multi(signal, layers):
     return refs
 
 
-def bank_pack(w, ch_offset, rows, row_src=None, out=None):
+def bank_pack(w, ch_offset, rows, out=None):
     """(B, hp_total, fh, fw) channel-major weights -> patch-major bank (B*fh*fw, ld)."""
     b, c_view, fh, fw = w.shape
-    if row_src is None and ch_offset + rows > c_view:
+    if ch_offset + rows > c_view:
         raise ValueError(f'weight has {c_view} channels, the module needs {ch_offset + rows}')
     w, w_ptr, hp_total = _channel_view(w, 'weight')
     ld = _round_up(rows, 4)
     if out is None:
         out = torch.empty(b * fh * fw, ld, device=w.device, dtype=torch.float32)
-    st = _hip.lib.hs_bank_pack_fwd(w_ptr, b, hp_total, fh, fw, ch_offset,
-                                   _hip.dev_ptr(row_src, 'row_src', torch.int32), rows,
+    st = _hip.lib.hs_bank_pack_fwd(w_ptr, b, hp_total, fh, fw, ch_offset, rows,
                                    _hip.dev_ptr(out, 'bank'), out.stride(0), _hip.stream_ptr())
     _hip.check(st, 'hs_bank_pack_fwd')
     return out
@@ -217,7 +207,7 @@ def patch_conv(x, grid, bank, c_out, k=1, padding=0, padding_mode='reflect', gro
 
 
 def patch_ir(x, grid, bank, hidden, c_out, bn1, bn2, bn3, residual=False):
-    """Op C: fused per-patch inverted residual.  bn* are (scale, shift) pairs; bank in "ir" row order."""
+    """Op C: fused per-patch inverted residual.  bn* are (scale, shift) pairs; bank rows in the reference's flat order."""
     stage = as_stage(x)
     fh, fw = grid
     b, _, h, w = stage.shape

@@ -38,7 +38,7 @@ def next_multiply(x, base):
 
 class _SignalToWeights:
     """Mixin for the modules that own a ``signal2weights`` grouped 1x1 conv (hyperseg_v1_0.py:315-326,
-    473-484, 529-541).  ``_bank(s, rows, row_src)`` runs the conv as one HIP launch that writes the
+    473-484, 529-541).  ``_bank(s, rows)`` runs the conv as one HIP launch that writes the
     patch-major bank directly; ``apply_signal2weights`` keeps the reference's tensor-returning form."""
 
     def _init_s2w_state(self):
@@ -52,13 +52,13 @@ class _SignalToWeights:
         self.signal_index = signal_index
         self.signal2weights = nn.Conv2d(signal_channels, weight_channels, 1, bias=False, groups=groups)
 
-    def _s2w_layer(self, rows, row_src=None):
+    def _s2w_layer(self, rows):
         """Descriptor of this module's signal2weights for the decoder-wide single launch."""
         conv = self.signal2weights
         return dict(wsw_t=self._s2w_t.get(conv), signal_index=self.signal_index,
-                    signal_channels=self.signal_channels, groups=conv.groups, rows=rows, row_src=row_src)
+                    signal_channels=self.signal_channels, groups=conv.groups, rows=rows)
 
-    def _bank(self, s, rows, row_src=None):
+    def _bank(self, s, rows):
         if isinstance(s, HF.BankRef):
             if s.rows != rows:
                 raise ValueError(f'bank has {s.rows} rows, module needs {rows}')
@@ -66,10 +66,10 @@ class _SignalToWeights:
         conv = self.signal2weights
         if conv is None:
             # no hypernetwork head: ``s`` already holds the weights (B, hp, fh, fw)
-            return HF.bank_pack(s, 0, rows, row_src)
+            return HF.bank_pack(s, 0, rows)
         _require_inference(s, conv.weight)
         return HF.signal2weights(s, self._s2w_t.get(conv), self.signal_index, self.signal_channels,
-                                 conv.groups, rows, row_src)
+                                 conv.groups, rows)
 
     def apply_signal2weights(self, s):
         """(B, hp, fh, fw) weights in the reference's channel-major layout (diagnostics / API parity)."""
@@ -210,7 +210,6 @@ class HyperPatchInvertedResidual(nn.Module, _SignalToWeights):
         self.hyper_params = self._ranges[-1]
         self._init_s2w_state()
         self._folded = [HF.FoldedBN(), HF.FoldedBN(), HF.FoldedBN()]
-        self._row_src = None
 
     def init_signal2weights(self, signal_channels, signal_index=0, groups=1):
         self._make_signal2weights(signal_channels, signal_index, groups, next_multiply(self.hyper_params, groups))
@@ -222,13 +221,8 @@ class HyperPatchInvertedResidual(nn.Module, _SignalToWeights):
             raise NotImplementedError('hs_patch_ir_fwd implements the block every reference config builds: '
                                       '3x3 depthwise, stride 1, reflect halo, BatchNorm2d, ReLU6')
 
-    def _rows(self, device):
-        if self._row_src is None or self._row_src.device != device:
-            self._row_src = HF.ir_row_map(self.in_nc, self.hidden_dim, self.out_nc, device)
-        return self._row_src
-
     def s2w_layer(self, device):
-        return self._s2w_layer(self.hyper_params, self._rows(device))
+        return self._s2w_layer(self.hyper_params)
 
     def _run(self, x, s, residual):
         self._check_supported()
@@ -236,7 +230,7 @@ class HyperPatchInvertedResidual(nn.Module, _SignalToWeights):
         if stage.channels != self.in_nc:
             raise ValueError(f'expected {self.in_nc} input channels, got {stage.channels}')
         fh, fw = s.shape[-2:]
-        bank = self._bank(s, self.hyper_params, self._rows(stage.device))
+        bank = self._bank(s, self.hyper_params)
         bns = [f.get(bn) for f, bn in zip(self._folded, (self.bn1, self.bn2, self.bn3))]
         return HF.patch_ir(stage, (fh, fw), bank, self.hidden_dim, self.out_nc, *bns, residual=residual)
 

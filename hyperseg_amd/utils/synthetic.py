@@ -30,7 +30,9 @@ def tensor_for(key, shape, seed=0):
 
 def fill_by_name(module, seed=0):
     sd = module.state_dict()
-    new = {k: (tensor_for(k, tuple(v.shape), seed).to(v.dtype) if v.dtype.is_floating_point else v)
-           for k, v in sd.items()}
+    # cached coordinate buffers (decoder.coord{h}_{w}) keep their constructed linspace values: they are data the
+    # constructor defines, not weights (the HIP path regenerates them analytically, Appendix D-11)
+    new = {k: (tensor_for(k, tuple(v.shape), seed).to(v.dtype)
+               if v.dtype.is_floating_point and '.coord' not in k else v) for k, v in sd.items()}
     module.load_state_dict(new, strict=True)
     return module

@@ -73,13 +73,12 @@ const char* hs_build_info(void);
 /* a9: "hypernetwork head emits per-patch weights" -- grouped 1x1 conv, bias-free.
  * Replaces signal2weights(...)[:, :hp] (hyperseg_v1_0.py:479-484, 321-326;
  * hyperseg_v1_0_unify.py:302-309) AND the permute/reshape copy that follows it.
- *   bank[p*ld + m] = sum_k wsw_t[k*wc + n] * signal[b, signal_index + g(n)*cs_g + k, i, j],
- *   n = row_src ? row_src[m] : m  (n < 0 -> 0.0f),  g(n) = n / (wc / groups).
+ *   bank[p*ld + n] = sum_k wsw_t[k*wc + n] * signal[b, signal_index + g(n)*cs_g + k, i, j],
+ *   n < rows <= wc,  g(n) = n / (wc / groups).  Runs on the f32 matrix cores (v_mfma_f32_16x16x4_f32).
  * wsw_t is the Conv2d weight (wc, cs_g, 1, 1) TRANSPOSED to (cs_g, wc) (done once by the host). */
 int hs_signal2weights_fwd(const float* signal, int32_t batch, int32_t c_signal, int32_t fh, int32_t fw,
                           int32_t signal_index, int32_t signal_channels, int32_t groups,
-                          const float* wsw_t, int32_t wc,
-                          const int32_t* row_src, int32_t rows,
+                          const float* wsw_t, int32_t wc, int32_t rows,
                           float* bank, int64_t ld, void* stream);
 
 /* The same for up to 8 signal2weights layers (all levels of a decoder) in ONE launch: every layer reads its own
@@ -88,7 +87,6 @@ typedef struct {
     int32_t signal_index, signal_channels, groups;
     const float* wsw_t;        /* (signal_channels/groups, wc) */
     int32_t wc;
-    const int32_t* row_src;    /* NULL = identity */
     int32_t rows;
     float* bank;
     int64_t ld;
@@ -99,10 +97,9 @@ int hs_signal2weights_multi_fwd(const float* signal, int32_t batch, int32_t c_si
 /* Re-layout of a reference-layout weight tensor (B, hp_total, fh, fw) (channel-major, as
  * MetaPatch.forward / HyperPatchInvertedResidual receive it: meta_patch.py:49,
  * hyperseg_v1_0_unify.py:335-349) into a patch-major bank:
- *   bank[p*ld + m] = w[b, ch_offset + (row_src ? row_src[m] : m), i, j]  (row < 0 -> 0.0f). */
+ *   bank[p*ld + m] = w[b, ch_offset + m, i, j]. */
 int hs_bank_pack_fwd(const float* w, int32_t batch, int32_t hp_total, int32_t fh, int32_t fw,
-                     int32_t ch_offset, const int32_t* row_src, int32_t rows,
-                     float* bank, int64_t ld, void* stream);
+                     int32_t ch_offset, int32_t rows, float* bank, int64_t ld, void* stream);
 
 /* Inference BatchNorm folding: scale = gamma / sqrt(var + eps), shift = beta - mean * scale,
  * for n channels (nn.BatchNorm2d eval semantics; eps 1e-5 in every reference module). */
@@ -125,19 +122,15 @@ int hs_patch_conv_fwd(const hs_stage_input* in, int32_t fh, int32_t fw,
  * hyperseg_v1_0_unify.py:330-389): reflect halo tile -> pw1 -> BN1 -> ReLU6 -> dw3x3 ->
  * BN2 -> ReLU6 -> pw3 -> BN3 (+ the stage input itself if residual != 0, which requires
  * cin == c_out: use_res_connect, hyperseg_v1_0.py:295, 372-376), one launch, hidden activations
- * never leave the CU.  Bank row order ("ir" order, build it with hs_ir_row_map):
- *   [0, cin*hid)               W1[h][c]        (natural)
- *   [cin*hid, +9*hid)          K[h][ky][kx]    (natural)
- *   [.., +hid*c_out)           W3T[h][o]       (TRANSPOSED: natural index is o*hid + h)
+ * never leave the CU.  Bank rows in the reference's flat order (hyperseg_v1_0.py:302-309):
+ *   [0, cin*hid)               W1[h][c]
+ *   [cin*hid, +9*hid)          K[h][ky][kx]
+ *   [.., +hid*c_out)           W3[o][h]
  * bn1/bn2/bn3 are folded scale/shift pairs (activation fields ignored). */
 int hs_patch_ir_fwd(const hs_stage_input* in, int32_t fh, int32_t fw,
                     const float* bank, int64_t ld, int32_t hidden, int32_t c_out,
                     const hs_epilogue* bn1, const hs_epilogue* bn2, const hs_epilogue* bn3,
                     int32_t residual, float* y, void* stream);
-
-/* Fills row_src[rows] for hs_patch_ir_fwd's bank order; returns rows = cin*hid + 9*hid + hid*c_out.
- * Host function (no GPU work). */
-int hs_ir_row_map(int32_t cin, int32_t hidden, int32_t c_out, int32_t* row_src);
 
 /* Final logits resize: F.interpolate(p, size, mode='bilinear', align_corners=False)
  * (hyperseg_v1_0.py:250-251).  x (B,C,Hi,Wi) -> y (B,C,Ho,Wo). */

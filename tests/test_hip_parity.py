@@ -95,28 +95,36 @@ def test_signal2weights_and_bank_pack(HF, O, dev):
         wsw_t = wsw.reshape(rows, -1).t().contiguous().to(dev)
         bank = HF.signal2weights(s.to(dev), wsw_t, c['idx'], c['cs'], c['grp'], c['hp'])
         cmp(bank[:, :c['hp']], ref_bank, what=f's2w {c}')
-        # row map: reversed order with a zero row
-        perm = torch.arange(c['hp'] - 1, -1, -1, dtype=torch.int32)
-        perm[0] = -1
-        bank2 = HF.signal2weights(s.to(dev), wsw_t, c['idx'], c['cs'], c['grp'], c['hp'], perm.to(dev))
-        want = ref_bank.flip(1).clone()
-        want[:, 0] = 0
-        cmp(bank2[:, :c['hp']], want, what='s2w row map')
-        # bank_pack of the reference-layout tensor gives the same bank
+        # pad columns [hp, ld) are never read by the consumers; rows beyond hp (next_multiply padding) are not stored
+        # bank_pack of the reference-layout tensor gives the same bank, also from a channel-range view
         packed = HF.bank_pack(ref.contiguous().to(dev), 0, c['hp'])
         assert torch.equal(packed[:, :c['hp']].cpu(), ref_bank)
-        packed = HF.bank_pack(ref.contiguous().to(dev), 0, c['hp'], perm.to(dev))
-        assert torch.equal(packed[:, :c['hp']].cpu(), want)
+        if c['hp'] > 8:
+            big = torch.cat([torch.zeros_like(ref[:, :3]), ref, torch.ones_like(ref[:, :2])], dim=1).to(dev)
+            packed = HF.bank_pack(big[:, 3:3 + c['hp']], 0, c['hp'])
+            assert torch.equal(packed[:, :c['hp']].cpu(), ref_bank)
+            packed = HF.bank_pack(big, 3, c['hp'])
+            assert torch.equal(packed[:, :c['hp']].cpu(), ref_bank)
 
 
-def test_ir_row_map(HF, dev):
-    m = HF.ir_row_map(3, 4, 2, dev).cpu().tolist()
-    r2 = 3 * 4 + 9 * 4
-    assert m[:r2] == list(range(r2))
-    assert m[r2:] == [r2 + o * 4 + h for h in range(4) for o in range(2)]
+def test_signal2weights_multi(HF, O, dev):
+    """All five HyperSeg-M levels in one launch == five oracle convolutions (rows/group 164, 188, 88, 147, 1054:
+    partial MFMA tiles, unaligned groups (147), K = 13, 14, 16, 12, 80)."""
+    plan = O.config_plan('M')
+    params = O.synth_decoder_params(plan, seed=5)
+    _, s = O.synth_decoder_inputs('M', batch=1, seed=5)
+    layers, refs = [], []
+    for l, (lv, sw) in enumerate(zip(plan['levels'], plan['s2w'])):
+        key = f'level_{l}.0.0.signal2weights.weight' if lv['k'] == 1 else f'level_{l}.0.signal2weights.weight'
+        w = params[key]
+        layers.append(dict(wsw_t=w.reshape(w.shape[0], -1).t().contiguous().to(dev), signal_index=sw['signal_index'],
+                           signal_channels=sw['signal_channels'], groups=sw['groups'], rows=lv['hp']))
+        refs.append(O.signal2weights(s, w, sw['signal_index'], sw['signal_channels'], sw['groups'], lv['hp']))
+    out = HF.signal2weights_multi(s.to(dev), layers)
+    for ref, o, lv in zip(refs, out, plan['levels']):
+        cmp(o.bank[:, :lv['hp']], ref.permute(0, 2, 3, 1).reshape(-1, lv['hp']), what=f's2w multi level hp={lv["hp"]}')
 
 
-# ------------------------------------------------------------------------------ module mirror vs golden
 def test_meta_conv2d(golden, dev):
     from hyperseg_amd.models.layers.meta_conv import MetaConv2d
     m = MetaConv2d(3, 3, 3, padding=1, groups=3)

@@ -30,3 +30,9 @@ pyr = [x] + fc[:-1]
 ref = O.decoder_v1_0(plan, params, pyr, sc)
 y = mg.decoder([t.cuda().contiguous() for t in pyr], sc.cuda().contiguous()).cpu()
 print('decoder on identical inputs: absmax', float(ref.abs().max()), 'rel err', float((y-ref).abs().max()/ref.abs().max()))
+import numpy as np
+g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests/golden/model_M.npz'))
+yfull = mg(x.cuda()).cpu()
+print('whole model vs golden sample: abs err', float((yfull[:, :, 1::5, 2::7] - torch.from_numpy(g['y'])).abs().max()), 'absmax', float(g['y_absmax']))
+print('whole model vs (cpu feats + oracle):', float((yfull - ref).abs().max()))
+print('oracle(ref) vs golden sample:', float((ref[:, :, 1::5, 2::7] - torch.from_numpy(g['y'])).abs().max()))
