@@ -196,6 +196,10 @@ static int launch_ir(const IrArgs& a, int threads, size_t lds, long blocks, hipS
     return launch_status();
 }
 
+int try_launch_ir_mfma(const StageIn& in, int fh, int fw, const float* bank, long ld, int cin, int c_skip, int hid,
+                       int c_out, const float* s1, const float* b1, const float* s2, const float* b2,
+                       const float* s3, const float* b3, float* y, hipStream_t stream);   // hs_patch_ir_mfma.hip
+
 }  // namespace hs
 
 using namespace hs;
@@ -228,6 +232,12 @@ extern "C" int hs_patch_ir_fwd(const hs_stage_input* in, int32_t fh, int32_t fw,
     const long blocks = (long)in->batch * fh * fw * a.tiles_y * a.tiles_x;
     hipStream_t s = (hipStream_t)stream;
     const bool fused_form = in->coords && a.in.prev_mode == HS_PREV_BILINEAR && !a.residual;
+    if (fused_form) {
+        // the decoder's own shapes run on the matrix cores; anything else falls through to the generic kernel
+        const int st_m = try_launch_ir_mfma(a.in, fh, fw, bank, (long)ld, a.cin, in->c_skip, hidden, c_out,
+                                            a.s1, a.b1, a.s2, a.b2, a.s3, a.b3, y, s);
+        if (st_m != 1) return st_m;
+    }
 #define HS_IR_CASE(CI, CS, CO) \
     if (fused_form && a.cin == CI && in->c_skip == CS && c_out == CO) return launch_ir<CI, CS, CO, true>(a, threads, lds, blocks, s);
     HS_IR_CASE(24, 6, 16)    // HyperSeg-M / CamVid-S level 3

@@ -25,7 +25,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int S2W_THREADS = 256;          // 4 waves
 constexpr int S2W_STRIP = 32;             // bank rows per wave-task (2 MFMA row tiles)
-constexpr int S2W_PT = 8;                 // 16-patch tiles per wave-task
+constexpr int S2W_PT = 2;                 // 16-patch tiles per wave-task
 constexpr int S2W_MAX_LAYERS = 8;
 
 struct S2wLayer {
@@ -40,6 +40,76 @@ struct S2wArgs {
     int c_signal, grid_sz, n_patches, n_layers;
     S2wLayer layer[S2W_MAX_LAYERS];
 };
+
+// One wave-task: a 32-row strip x S2W_PT 16-patch tiles, K padded to 4*KS.  Every operand load of the task is
+// issued before the first MFMA (A: 2*KS registers, B: S2W_PT*KS registers), so the L2 latency is paid once per
+// task and hidden across the ~8 waves per SIMD the grid provides.
+template <int KS>
+__device__ __forceinline__ void s2w_task(const float* __restrict__ wsw_t, const float* __restrict__ signal,
+                                         float* __restrict__ bank, long ld, int cs_g, int rpg, int wc, int rows,
+                                         int r0, int n0, size_t sig_base, int c_signal, int grid_sz, int n_patches,
+                                         int tile0, int lane, float* __restrict__ stage) {
+    const int lrow = lane & 15, lk = lane >> 4;
+    const bool a0_ok = (r0 + lrow) < rpg, a1_ok = (r0 + 16 + lrow) < rpg;
+    // 32-bit element offsets from the uniform base pointers (saddr + voffset addressing: one VGPR per load);
+    // masked lanes are clamped so that they still read inside the arrays
+    const unsigned na0 = (unsigned)min(n0 + lrow, wc - 1), na1 = (unsigned)min(n0 + 16 + lrow, wc - 1);
+    float a0[KS], a1[KS], bv[S2W_PT][KS];
+    bool p_ok[S2W_PT];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const unsigned kc = (unsigned)min(ks * 4 + lk, cs_g - 1);
+        a0[ks] = wsw_t[kc * (unsigned)wc + na0];
+        a1[ks] = wsw_t[kc * (unsigned)wc + na1];
+    }
+#pragma unroll
+    for (int t = 0; t < S2W_PT; ++t) {
+        const int p = (tile0 + t) * 16 + lrow;
+        p_ok[t] = p < n_patches;
+        const int pc = p_ok[t] ? p : 0;
+        const int bb = pc / grid_sz, ij = pc - bb * grid_sz;
+        const unsigned sb = (unsigned)((size_t)bb * c_signal * grid_sz + sig_base + ij);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const unsigned kc = (unsigned)min(ks * 4 + lk, cs_g - 1);
+            bv[t][ks] = signal[sb + kc * (unsigned)grid_sz];
+        }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const bool k_ok = (ks * 4 + lk) < cs_g;
+        a0[ks] = (k_ok && a0_ok) ? a0[ks] : 0.0f;
+        a1[ks] = (k_ok && a1_ok) ? a1[ks] : 0.0f;
+    }
+#pragma unroll
+    for (int t = 0; t < S2W_PT; ++t) {
+        if ((tile0 + t) * 16 >= n_patches) break;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bool k_ok = (ks * 4 + lk) < cs_g;
+            const float fb = (k_ok && p_ok[t]) ? bv[t][ks] : 0.0f;
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[ks], fb, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[ks], fb, acc1, 0, 0, 0);
+        }
+        // D (lane l: rows 4*lk + r of patch lrow) -> wave-private LDS [patch][row] -> 128-byte row runs: each store
+        // instruction writes two patches x 32 consecutive bank rows, whatever the alignment of the group start
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            stage[lrow * 33 + 4 * lk + r] = acc0[r];
+            stage[lrow * 33 + 16 + 4 * lk + r] = acc1[r];
+        }
+        const int row = lane & 31;
+        const bool row_ok = (r0 + row) < rpg && (n0 + row) < rows;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int pl = 2 * q + (lane >> 5);
+            const int p = (tile0 + t) * 16 + pl;
+            const float v = stage[pl * 33 + row];
+            if (row_ok && p < n_patches) bank[(size_t)p * ld + n0 + row] = v;
+        }
+    }
+}
 
 __global__ __launch_bounds__(S2W_THREADS)
 void signal2weights_kernel(S2wArgs a) {
@@ -63,58 +133,20 @@ void signal2weights_kernel(S2wArgs a) {
     const int g = strip / spg;
     const int r0 = (strip - g * spg) * S2W_STRIP;            // first row of the strip inside the group
     const int n0 = g * rpg + r0;                             // natural row index
-    const int lrow = lane & 15, lk = lane >> 4;
-
-    // per-lane row validity of the two A tiles
-    const bool a0_ok = (r0 + lrow) < rpg;
-    const bool a1_ok = (r0 + 16 + lrow) < rpg;
-    // clamped row addresses: masked lanes still read inside the (cs_g, wc) array
-    const float* __restrict__ wa0 = wsw_t + min(n0 + lrow, wc - 1);        // + k*wc
-    const float* __restrict__ wa1 = wsw_t + min(n0 + 16 + lrow, wc - 1);
-    const int ksteps = (cs_g + 3) >> 2;
     const size_t sig_base = (size_t)(signal_index + g * cs_g) * grid_sz;
-
     const int tile0 = (blockIdx.y * 4 + wave) * S2W_PT;
-    for (int t = 0; t < S2W_PT; ++t) {
-        const int p0 = (tile0 + t) * 16;
-        if (p0 >= n_patches) break;
-        const int p = p0 + lrow;
-        const bool p_ok = p < n_patches;
-        const int bb = p_ok ? p / grid_sz : 0, ij = p_ok ? p - bb * grid_sz : 0;
-        const float* __restrict__ sb = signal + (size_t)bb * c_signal * grid_sz + sig_base + ij;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int ks = 0; ks < ksteps; ++ks) {
-            const int k = ks * 4 + lk;
-            const bool k_ok = k < cs_g;
-            const int kc = k_ok ? k : 0;
-            const float w0 = wa0[(size_t)kc * wc], w1 = wa1[(size_t)kc * wc];
-            const float sv = sb[(size_t)kc * grid_sz];
-            const float fa0 = (k_ok && a0_ok) ? w0 : 0.0f;
-            const float fa1 = (k_ok && a1_ok) ? w1 : 0.0f;
-            const float fb = (k_ok && p_ok) ? sv : 0.0f;
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0, fb, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1, fb, acc1, 0, 0, 0);
-        }
-        if (!p_ok) continue;
-        // D: this lane holds rows (tile row 4*lk + r) of patch p
-        float* __restrict__ dst = bank + (size_t)p * ld + n0 + 4 * lk;
-        const int rr0 = r0 + 4 * lk;                          // row inside the group of acc0[0]
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const f32x4 v = half ? acc1 : acc0;
-            const int rg = rr0 + 16 * half;                    // row in group
-            const int n = n0 + 4 * lk + 16 * half;             // natural row
-            float* d = dst + 16 * half;
-            if (rg + 3 < rpg && n + 3 < rows && ((((size_t)p * ld + n) & 3) == 0)) {
-                *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (rg + r < rpg && n + r < rows) d[r] = v[r];
-            }
-        }
-    }
+    if (tile0 * 16 >= n_patches) return;
+    const int ksteps = (cs_g + 3) >> 2;
+    __shared__ float stage_all[4 * 16 * 33];
+    float* stage = stage_all + wave * (16 * 33);
+#define HS_S2W_CASE(KS) s2w_task<KS>(wsw_t, signal, bank, ld, cs_g, rpg, wc, rows, r0, n0, sig_base, c_signal, \
+                                     grid_sz, n_patches, tile0, lane, stage)
+    if (ksteps <= 2) HS_S2W_CASE(2);
+    else if (ksteps <= 4) HS_S2W_CASE(4);
+    else if (ksteps <= 8) HS_S2W_CASE(8);
+    else if (ksteps <= 12) HS_S2W_CASE(12);
+    else HS_S2W_CASE(20);                                    // K <= 80; larger K is rejected by the host wrapper
+#undef HS_S2W_CASE
 }
 
 // ------------------------------------------------------------------------------------------
@@ -159,6 +191,7 @@ extern "C" int hs_signal2weights_multi_fwd(const float* signal, int32_t batch, i
                                            const hs_s2w_layer* layers, int32_t n_layers, void* stream) {
     if (!signal || !layers || n_layers <= 0 || n_layers > S2W_MAX_LAYERS) return HS_ERR_BAD_ARG;
     if (batch <= 0 || fh <= 0 || fw <= 0) return HS_ERR_BAD_ARG;
+    if ((size_t)batch * c_signal * fh * fw >= (1ull << 31)) return HS_ERR_UNSUPPORTED;     // 32-bit element offsets
     S2wArgs a;
     a.signal = signal; a.c_signal = c_signal; a.grid_sz = fh * fw; a.n_patches = batch * fh * fw; a.n_layers = n_layers;
     int strips = 0;
@@ -167,6 +200,7 @@ extern "C" int hs_signal2weights_multi_fwd(const float* signal, int32_t batch, i
         if (!l.wsw_t || !l.bank || l.groups <= 0 || l.rows <= 0 || l.wc <= 0 || l.ld < l.rows || l.rows > l.wc) return HS_ERR_BAD_ARG;
         if (l.signal_index < 0 || l.signal_channels <= 0 || l.signal_index + l.signal_channels > c_signal) return HS_ERR_BAD_ARG;
         if (l.signal_channels % l.groups != 0 || l.wc % l.groups != 0) return HS_ERR_BAD_ARG;
+        if (l.signal_channels / l.groups > 80) return HS_ERR_UNSUPPORTED;   // K-step register buckets stop at 20
         S2wLayer& d = a.layer[i];
         d.wsw_t = l.wsw_t; d.bank = l.bank; d.ld = (long)l.ld;
         d.signal_index = l.signal_index;
