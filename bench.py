@@ -167,11 +167,10 @@ def main():
 
     comm = None
     if world > 1 and args.gather != 'none':
-        shape = y.shape if args.gather == 'logits' else (y.shape[0], y.shape[2], y.shape[3])
+        from hyperseg_amd.distributed import LogitsGatherer
+        shape = tuple(y.shape) if args.gather == 'logits' else (y.shape[0], y.shape[2], y.shape[3])
         dtype = torch.float32 if args.gather == 'logits' else torch.uint8
-        send = [torch.empty(shape, dtype=dtype, device=dev) for _ in range(2)]
-        recv = [torch.empty((world,) + tuple(shape), dtype=dtype, device=dev) for _ in range(2)]
-        comm = dict(send=send, recv=recv, work=[None, None])
+        comm = LogitsGatherer(world, shape, dtype, dev)
 
     def step(i):
         nonlocal y
@@ -180,22 +179,12 @@ def main():
         else:
             y = model(x)
         if comm is not None:
-            k = i & 1
-            if comm['work'][k] is not None:
-                comm['work'][k].wait()                 # buffer pair k is free again
-            if args.gather == 'logits':
-                comm['send'][k].copy_(y)
-            else:
-                comm['send'][k].copy_(y.argmax(1))
             # RCCL all-gather over xGMI on RCCL's own stream: overlaps the next frame's compute
-            comm['work'][k] = dist.all_gather_into_tensor(comm['recv'][k], comm['send'][k], async_op=True)
+            comm.submit(i, y if args.gather == 'logits' else y.argmax(1).to(torch.uint8))
 
     def drain():
         if comm is not None:
-            for k in (0, 1):
-                if comm['work'][k] is not None:
-                    comm['work'][k].wait()
-                    comm['work'][k] = None
+            comm.drain()
 
     def fence():
         torch.cuda.synchronize()

@@ -18,6 +18,19 @@ MODELS = {
              "with_out_fc=False, decoder_dropout=None, weight_groups=[64, 32, 32, 16, 8], decoder_groups=1, "
              "inference_hflip=True, coords_res=[(576, 576), (576, 768)])",
         num_classes=12, size=(576, 768), batch=1),
+    # configs/train/cityscapes_efficientnet_b1_hyperseg-s.py:36-40
+    'hyperseg-s': dict(
+        arch="hyperseg.models.hyperseg_v1_0_unify.hyperseg_efficientnet('efficientnet-b1', False, levels=2, "
+             "out_feat_scale=[1., .166, .2, .25, .4], kernel_sizes=[1, 1, 1, 3, 3], level_channels=[32, 16, 8, 8, 8], "
+             "expand_ratio=2, with_out_fc=False, decoder_dropout=None, weight_groups=[32, 16, 8, 16, 4], "
+             "decoder_groups=1, inference_hflip=True, unify_level=4, coords_res=[(768, 768), (768, 1536)])",
+        num_classes=19, size=(768, 1536), batch=1),
+    # configs/train/vocsbd_efficientnet_b3_hyperseg-l.py:32-34
+    'hyperseg-l': dict(
+        arch="hyperseg.models.hyperseg_v0_1.hyperseg_efficientnet('efficientnet-b3', False, levels=3, "
+             "kernel_sizes=(1, 1, 3, 3, 3, 3), expand_ratio=2, inference_hflip=True, with_out_fc=False, "
+             "decoder_dropout=None, weight_groups=16)",
+        num_classes=21, size=(512, 512), batch=32),
 }
 
 

@@ -122,46 +122,45 @@ void patch_conv1x1_kernel(Conv1Args a) {
     float* wl = lds;                 // [cout][cin_g], natural order
     float* xl = lds + hp4;           // [cin][npix]
 
-    // 1. bank -> LDS, 16-byte loads, up to 8 in flight per thread
-    {
-        const float4* __restrict__ src = reinterpret_cast<const float4*>(a.bank + (size_t)patch * a.ld);
-        float4* dst = reinterpret_cast<float4*>(wl);
-        const int n4 = hp4 >> 2;                      // ld is a multiple of 4 and >= hp: the tail read stays in-row
-        for (int e0 = tid; e0 < n4; e0 += 8 * CONV_THREADS) {
-            float4 v[8];
+    // 1+2. all HBM loads of the workgroup in flight together: the bank (16-byte loads, up to 8 per thread) AND the
+    //      stage-input elements (c, pixel); only then the LDS stores.  One memory round trip per workgroup.
+    const float4* __restrict__ src = reinterpret_cast<const float4*>(a.bank + (size_t)patch * a.ld);
+    float4* dst = reinterpret_cast<float4*>(wl);
+    const int n4 = hp4 >> 2;                          // ld is a multiple of 4 and >= hp: the tail read stays in-row
+    const int y0 = i * a.ph, x0 = j * a.pw;
+    const int total_x = cin * npix;
+    float4 wv[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int e = e0 + q * CONV_THREADS;
-                if (e < n4) v[q] = src[e];
-            }
+    for (int q = 0; q < 8; ++q) {
+        const int e = tid + q * CONV_THREADS;
+        if (e < n4) wv[q] = src[e];
+    }
+    float xv[4];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int e = e0 + q * CONV_THREADS;
-                if (e < n4) dst[e] = v[q];
-            }
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + q * CONV_THREADS;
+        if (e < total_x) {
+            const int c = e / npix, pix = e - c * npix;
+            const int u = pix / a.pw, vv = pix - u * a.pw;
+            xv[q] = stage_value(a.in, b, c, stage_pos(a.in, y0 + u, x0 + vv));
         }
     }
-    // 2. stage input elements (c, pixel), pixel fastest
-    {
-        const int y0 = i * a.ph, x0 = j * a.pw;
-        const int total = cin * npix;
-        for (int e0 = tid; e0 < total; e0 += 4 * CONV_THREADS) {
-            float v[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int e = e0 + q * CONV_THREADS;
-                if (e < total) {
-                    const int c = e / npix, pix = e - c * npix;
-                    const int u = pix / a.pw, vv = pix - u * a.pw;
-                    v[q] = stage_value(a.in, b, c, stage_pos(a.in, y0 + u, x0 + vv));
-                }
-            }
+    for (int q = 0; q < 8; ++q) {
+        const int e = tid + q * CONV_THREADS;
+        if (e < n4) dst[e] = wv[q];
+    }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int e = e0 + q * CONV_THREADS;
-                if (e < total) xl[e] = v[q];
-            }
-        }
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + q * CONV_THREADS;
+        if (e < total_x) xl[e] = xv[q];
+    }
+    // remainders of very large banks / tiles (not reached by the decoder's own shapes)
+    for (int e = tid + 8 * CONV_THREADS; e < n4; e += CONV_THREADS) dst[e] = src[e];
+    for (int e = tid + 4 * CONV_THREADS; e < total_x; e += CONV_THREADS) {
+        const int c = e / npix, pix = e - c * npix;
+        const int u = pix / a.pw, vv = pix - u * a.pw;
+        xl[e] = stage_value(a.in, b, c, stage_pos(a.in, y0 + u, x0 + vv));
     }
     __syncthreads();
 
@@ -306,7 +305,7 @@ extern "C" int hs_patch_conv_fwd(const hs_stage_input* in, int32_t fh, int32_t f
     if (k == 1) {
         const size_t hp4 = ((size_t)c_out * a.cin_g + 3) & ~(size_t)3;
         const size_t lds1 = (hp4 + (size_t)cin * a.ph * a.pw) * sizeof(float);
-        if (lds1 <= 96 * 1024 && (ld & 3) == 0 && a.ph * a.pw <= 4096) {
+        if (lds1 <= 96 * 1024 && (ld & 3) == 0 && ((uintptr_t)bank & 15) == 0 && a.ph * a.pw <= 4096) {
             Conv1Args f;
             f.in = a.in; f.fh = fh; f.fw = fw; f.ph = a.ph; f.pw = a.pw; f.bank = bank; f.ld = ld;
             f.cout = c_out; f.groups = groups; f.cin_g = a.cin_g; f.cout_g = a.cout_g;

@@ -37,7 +37,7 @@ struct S2wLayer {
 };
 struct S2wArgs {
     const float* __restrict__ signal;
-    int c_signal, grid_sz, n_patches, n_layers;
+    int c_signal, grid_sz, n_patches, n_layers, n_strips;
     S2wLayer layer[S2W_MAX_LAYERS];
 };
 
@@ -116,16 +116,18 @@ void signal2weights_kernel(S2wArgs a) {
     // layer descriptor through the kernarg segment with a uniform index -> scalar loads, no register copies
     const __attribute__((address_space(4))) S2wArgs* ka =
         (const __attribute__((address_space(4))) S2wArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    const int vstrip = (int)blockIdx.x;
+    if (vstrip >= ka->n_strips) return;
     int li = 0;
     for (int q = 1; q < ka->n_layers; ++q)
-        if ((int)blockIdx.x >= ka->layer[q].strip_begin) li = q;
+        if (vstrip >= ka->layer[q].strip_begin) li = q;
     const float* __restrict__ wsw_t = ka->layer[li].wsw_t;
     float* __restrict__ bank = ka->layer[li].bank;
     const long ld = ka->layer[li].ld;
     const int signal_index = ka->layer[li].signal_index, cs_g = ka->layer[li].cs_g;
     const int rpg = ka->layer[li].rows_per_group, wc = ka->layer[li].wc, rows = ka->layer[li].rows;
     const int spg = ka->layer[li].strips_per_group;
-    const int strip = (int)blockIdx.x - ka->layer[li].strip_begin;
+    const int strip = vstrip - ka->layer[li].strip_begin;
     const int grid_sz = ka->grid_sz, n_patches = ka->n_patches, c_signal = ka->c_signal;
     const float* __restrict__ signal = ka->signal;
 
@@ -194,9 +196,19 @@ extern "C" int hs_signal2weights_multi_fwd(const float* signal, int32_t batch, i
     if ((size_t)batch * c_signal * fh * fw >= (1ull << 31)) return HS_ERR_UNSUPPORTED;     // 32-bit element offsets
     S2wArgs a;
     a.signal = signal; a.c_signal = c_signal; a.grid_sz = fh * fw; a.n_patches = batch * fh * fw; a.n_layers = n_layers;
+    // heaviest layers (largest K) first, so the long wave-tasks do not form the tail of the launch
+    int order[S2W_MAX_LAYERS];
+    for (int i = 0; i < n_layers; ++i) order[i] = i;
+    for (int i = 1; i < n_layers; ++i)
+        for (int q = i; q > 0; --q) {
+            const hs_s2w_layer &x = layers[order[q]], &y = layers[order[q - 1]];
+            if (x.groups > 0 && y.groups > 0 && x.signal_channels / x.groups > y.signal_channels / y.groups) {
+                const int t = order[q]; order[q] = order[q - 1]; order[q - 1] = t;
+            } else break;
+        }
     int strips = 0;
     for (int i = 0; i < n_layers; ++i) {
-        const hs_s2w_layer& l = layers[i];
+        const hs_s2w_layer& l = layers[order[i]];
         if (!l.wsw_t || !l.bank || l.groups <= 0 || l.rows <= 0 || l.wc <= 0 || l.ld < l.rows || l.rows > l.wc) return HS_ERR_BAD_ARG;
         if (l.signal_index < 0 || l.signal_channels <= 0 || l.signal_index + l.signal_channels > c_signal) return HS_ERR_BAD_ARG;
         if (l.signal_channels % l.groups != 0 || l.wc % l.groups != 0) return HS_ERR_BAD_ARG;
@@ -210,6 +222,7 @@ extern "C" int hs_signal2weights_multi_fwd(const float* signal, int32_t batch, i
         strips += d.strips_per_group * l.groups;
     }
     for (int i = n_layers; i < S2W_MAX_LAYERS; ++i) { a.layer[i] = a.layer[0]; a.layer[i].strip_begin = 0x7fffffff; }
+    a.n_strips = strips;
     const int tiles = (a.n_patches + 15) / 16;
     dim3 grid(strips, (tiles + 4 * S2W_PT - 1) / (4 * S2W_PT));
     hipLaunchKernelGGL(signal2weights_kernel, grid, dim3(S2W_THREADS), 0, (hipStream_t)stream, a);

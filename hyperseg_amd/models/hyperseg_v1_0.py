@@ -48,9 +48,9 @@ class _SignalToWeights:
         self._s2w_t = HF.TransposedS2W()
 
     def _make_signal2weights(self, signal_channels, signal_index, groups, weight_channels):
-        self.signal_channels = signal_channels
-        self.signal_index = signal_index
-        self.signal2weights = nn.Conv2d(signal_channels, weight_channels, 1, bias=False, groups=groups)
+        self.signal_channels = int(signal_channels)
+        self.signal_index = int(signal_index)
+        self.signal2weights = nn.Conv2d(int(signal_channels), int(weight_channels), 1, bias=False, groups=int(groups))
 
     def _s2w_layer(self, rows):
         """Descriptor of this module's signal2weights for the decoder-wide single launch."""

@@ -1,0 +1,237 @@
+"""HyperSeg v1.0 "unify" on the MI355X decoder path -- drop-in for hyperseg/models/hyperseg_v1_0_unify.py
+(HyperSeg-S Cityscapes 1536x768: configs/train/cityscapes_efficientnet_b1_hyperseg-s.py:10, 36-40).
+
+Differences to v1_0, as in the reference: the ``signal2weights`` convolutions live in :class:`WeightLayer` modules
+(``decoder.weight_blocks.{i}``), levels >= ``unify_level - 1`` share ONE weight layer whose output is channel-sliced
+per level (hyperseg_v1_0_unify.py:172-178, 242-249), and the level modules receive weights, not the signal.
+Here every weight layer of the decoder runs in one ``hs_signal2weights_multi_fwd`` launch and the shared bank is
+consumed in place through row-range views (no slice copies).
+"""
+import numbers
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from .. import functional as HF
+from .hyperseg_v1_0 import (HyperPatch, HyperPatchConv2d, HyperPatchInvertedResidual, HyperPatchNoPadding,  # noqa: F401
+                            WeightMapper, _SignalToWeights, divide_feature, make_hyper_patch_conv2d_block,
+                            next_multiply)
+from .layers.meta_conv import _require_inference
+from .layers.meta_sequential import MetaSequential
+
+
+class WeightLayer(nn.Module, _SignalToWeights):
+    """signal -> weights of one level (or of all unified levels): hyperseg_v1_0_unify.py:287-309."""
+
+    def __init__(self, target_params):
+        super(WeightLayer, self).__init__()
+        self.target_params = target_params
+        self._init_s2w_state()
+
+    @property
+    def hyper_params(self):
+        return self.target_params
+
+    def init_signal2weights(self, signal_channels, signal_index=0, groups=1):
+        self._make_signal2weights(signal_channels, signal_index, groups, next_multiply(self.target_params, groups))
+
+    def s2w_layer(self, device):
+        return self._s2w_layer(self.target_params)
+
+    def forward(self, s):
+        return self.apply_signal2weights(s)
+
+
+def get_hyper_params(model):
+    found = []
+    for _, m in model.named_children():
+        if isinstance(m, WeightLayer):
+            found.append(m.target_params)
+        else:
+            found.extend(get_hyper_params(m))
+    return found
+
+
+def init_signal2weights(model, signal_features, signal_index=0, weight_groups=1):
+    """Same traversal as v1_0 but over WeightLayer modules, which are siblings in one ModuleList: here the
+    running signal offset DOES accumulate (0 / 576 / 704 / 768 for HyperSeg-S)."""
+    for _, m in model.named_children():
+        if isinstance(m, WeightLayer):
+            nc = signal_features.pop(0)
+            g = weight_groups.pop(0) if isinstance(weight_groups, list) else weight_groups
+            m.init_signal2weights(nc, signal_index, g)
+            signal_index += nc
+        else:
+            init_signal2weights(m, signal_features, signal_index, weight_groups)
+
+
+class MultiScaleDecoder(nn.Module):
+    """hyperseg_v1_0_unify.py:96-259."""
+
+    def __init__(self, feat_channels, signal_channels, num_classes=3, kernel_sizes=3, level_layers=1,
+                 level_channels=None, norm_layer=nn.BatchNorm2d, act_layer=nn.ReLU6(inplace=True), out_kernel_size=1,
+                 expand_ratio=1, groups=1, weight_groups=1, with_out_fc=False, dropout=None,
+                 coords_res=None, unify_level=None):
+        super(MultiScaleDecoder, self).__init__()
+        n = len(level_channels)
+        if isinstance(kernel_sizes, numbers.Number):
+            kernel_sizes = (kernel_sizes,) * n
+        if isinstance(level_layers, numbers.Number):
+            level_layers = (level_layers,) * n
+        if isinstance(expand_ratio, numbers.Number):
+            expand_ratio = (expand_ratio,) * n
+        assert len(kernel_sizes) == n and len(level_layers) == n and len(expand_ratio) == n
+        self.level_layers = level_layers
+        self.levels = n
+        self.unify_level = unify_level
+        self.layer_params = []
+        feat_channels = feat_channels[::-1]
+        self.coords_cache = {}
+        self.weight_groups = weight_groups
+        self.level_blocks = nn.ModuleList()
+        self.weight_blocks = nn.ModuleList()
+        self._ranges = [0]
+
+        prev_channels = 0
+        for level in range(self.levels):
+            curr_ngf = feat_channels[level]
+            curr_out_ngf = curr_ngf if level_channels is None else level_channels[level]
+            prev_channels += curr_ngf
+            curr_layers = []
+            k = kernel_sizes[level]
+            for layer in range(self.level_layers[level]):
+                if (not with_out_fc) and level == self.levels - 1 and layer == self.level_layers[level] - 1:
+                    curr_out_ngf = num_classes
+                if k > 1:
+                    curr_layers.append(HyperPatchInvertedResidual(
+                        prev_channels + 2, curr_out_ngf, k, expand_ratio=expand_ratio[level],
+                        norm_layer=norm_layer, act_layer=act_layer))
+                else:
+                    group = groups[level] if isinstance(groups, (list, tuple)) else groups
+                    curr_layers.append(make_hyper_patch_conv2d_block(prev_channels + 2, curr_out_ngf, k, groups=group))
+                prev_channels = curr_out_ngf
+            self.level_blocks.append(MetaSequential(*curr_layers))
+            if level < (unify_level - 1):
+                self.weight_blocks.append(WeightLayer(self.level_blocks[-1].hyper_params))
+            else:
+                self._ranges.append(self._ranges[-1] + self.level_blocks[-1].hyper_params)
+                if level == self.levels - 1:
+                    total = sum(b.hyper_params for b in self.level_blocks[unify_level - 1:])
+                    self.weight_blocks.append(WeightLayer(total))
+
+        if with_out_fc:
+            out_fc_layers = [nn.Dropout2d(dropout, True)] if dropout is not None else []
+            out_fc_layers.append(
+                HyperPatchConv2d(prev_channels, num_classes, out_kernel_size, padding=out_kernel_size // 2))
+            self.out_fc = MetaSequential(*out_fc_layers)
+        else:
+            self.out_fc = None
+
+        if coords_res is not None:
+            for res in coords_res:
+                for i in range(self.levels):
+                    h, w = res[0] // 2 ** i, res[1] // 2 ** i
+                    self.register_buffer(f'coord{h}_{w}', self.cache_image_coordinates(h, w))
+
+        self.param_groups = get_hyper_params(self)
+        min_unit = max(weight_groups) if isinstance(weight_groups, (list, tuple)) else weight_groups
+        signal_features = divide_feature(signal_channels, self.param_groups, min_unit=min_unit)
+        init_signal2weights(self, list(signal_features), weight_groups=weight_groups)
+        self.hyper_params = sum(self.param_groups)
+
+    def cache_image_coordinates(self, h, w):
+        x = torch.linspace(-1, 1, steps=w)
+        y = torch.linspace(-1, 1, steps=h)
+        return torch.stack([x.view(1, w).expand(h, w), y.view(h, 1).expand(h, w)], dim=0).unsqueeze(0).contiguous()
+
+    def forward(self, x, s):
+        if self.out_fc is not None:
+            raise NotImplementedError('with_out_fc=True: the reference itself feeds the raw signal to out_fc here '
+                                      '(hyperseg_v1_0_unify.py:252-253); no config uses it')
+        wl = list(self.weight_blocks)
+        _require_inference(s, *[m.signal2weights.weight for m in wl])
+        refs = HF.signal2weights_multi(s, [m.s2w_layer(s.device) for m in wl])      # every weight layer, one launch
+        ul = self.unify_level
+        p = None
+        for level in range(self.levels):
+            stage = HF.StageInput(x[-level - 1], p, coords=True)
+            if level < ul - 1:
+                w = refs[level]
+            else:
+                i = level - ul + 1
+                shared = refs[ul - 1]
+                r0, r1 = self._ranges[i], self._ranges[i + 1]
+                # rows [r0, r1) of the shared bank, consumed in place (reference: w[:, r0:r1] + .contiguous())
+                w = HF.BankRef(shared.bank[:, r0:r1], shared.shape[0], r1 - r0, shared.grid)
+            p = self.level_blocks[level](stage, [w])
+        if p.shape[2:] != x[0].shape[2:]:
+            p = HF.upsample_bilinear(p, x[0].shape[2:])
+        return p
+
+
+class HyperGen(nn.Module):
+    """hyperseg_v1_0_unify.py:12-93."""
+
+    def __init__(self, backbone, weight_mapper, in_nc=3, num_classes=3, kernel_sizes=3, level_layers=1,
+                 level_channels=None, expand_ratio=1, groups=1, weight_groups=1, inference_hflip=False,
+                 inference_gather='mean', with_out_fc=False, decoder_groups=1, decoder_dropout=None, coords_res=None,
+                 unify_level=None):
+        super(HyperGen, self).__init__()
+        self.inference_hflip = inference_hflip
+        self.inference_gather = inference_gather
+        self.backbone = backbone()
+        feat_channels = [in_nc] + self.backbone.feat_channels[:-1]
+        wg = list(weight_groups) if isinstance(weight_groups, (list, tuple)) else weight_groups
+        self.decoder = MultiScaleDecoder(feat_channels, self.backbone.feat_channels[-1], num_classes, kernel_sizes,
+                                         level_layers, level_channels, with_out_fc=with_out_fc, out_kernel_size=1,
+                                         expand_ratio=expand_ratio, groups=decoder_groups, weight_groups=wg,
+                                         dropout=decoder_dropout, coords_res=coords_res, unify_level=unify_level)
+        self.weight_mapper = weight_mapper(self.backbone.feat_channels[-1], self.decoder.param_groups)
+
+    @property
+    def hyper_params(self):
+        return self.decoder.hyper_params
+
+    def process_single_tensor(self, x, hflip=False):
+        x = torch.flip(x, [-1]) if hflip else x
+        features = self.backbone(x)
+        signal = self.weight_mapper(features[-1])
+        y = self.decoder([t.contiguous() for t in [x] + features[:-1]], signal.contiguous())
+        return torch.flip(y, [-1]) if hflip else y
+
+    def gather_results(self, x, y=None):
+        assert x is not None
+        if y is None:
+            return x
+        return (x + y) * 0.5 if self.inference_gather == 'mean' else torch.max(x, y)
+
+    def forward(self, x):
+        assert isinstance(x, (list, tuple, torch.Tensor)), 'x must be of type list, tuple, or tensor'
+        if isinstance(x, torch.Tensor):
+            return self.process_single_tensor(x)
+        out_res = x[0].shape[2:]
+        out = None
+        for p in x:
+            if self.inference_hflip:
+                p = torch.max(self.process_single_tensor(p), self.process_single_tensor(p, hflip=True))
+            else:
+                p = self.process_single_tensor(p)
+            if p.shape[2:] != out_res:
+                p = HF.upsample_bilinear(p.contiguous(), out_res)
+            out = self.gather_results(p, out)
+        return out
+
+
+def hyperseg_efficientnet(model_name, pretrained=False, out_feat_scale=0.25, levels=3, weights_path=None, **kwargs):
+    """Config-file factory (hyperseg_v1_0_unify.py:654-668)."""
+    from .backbones.efficientnet import efficientnet
+
+    weight_mapper = partial(WeightMapper, levels=levels)
+    backbone = partial(efficientnet, model_name, pretrained=pretrained, out_feat_scale=out_feat_scale, head=None,
+                       return_features=True)
+    model = HyperGen(backbone, weight_mapper, **kwargs)
+    if weights_path is not None:
+        checkpoint = torch.load(weights_path, map_location='cpu', weights_only=False)
+        model.load_state_dict(checkpoint['state_dict'], strict=True)
+    return model

@@ -336,6 +336,14 @@ MODEL_KW = {
         level_channels=[64, 32, 16, 16, 16], expand_ratio=2, with_out_fc=False, decoder_dropout=None,
         weight_groups=[32, 16, 8, 16, 4], decoder_groups=1, inference_hflip=True,
         coords_res=[(512, 512), (512, 1024)])),
+    'S': dict(mod='unify', name='efficientnet-b1', num_classes=19, kw=dict(
+        levels=2, out_feat_scale=[1., .166, .2, .25, .4], kernel_sizes=[1, 1, 1, 3, 3],
+        level_channels=[32, 16, 8, 8, 8], expand_ratio=2, with_out_fc=False, decoder_dropout=None,
+        weight_groups=[32, 16, 8, 16, 4], decoder_groups=1, inference_hflip=True, unify_level=4,
+        coords_res=[(768, 768), (768, 1536)])),
+    'L': dict(mod='v0_1', name='efficientnet-b3', num_classes=21, kw=dict(
+        levels=3, kernel_sizes=(1, 1, 3, 3, 3, 3), expand_ratio=2, inference_hflip=True, with_out_fc=False,
+        decoder_dropout=None, weight_groups=16)),
 }
 
 
@@ -352,6 +360,8 @@ def gen_models():
         x = torch.rand(1, 3, 128, 256, generator=torch.Generator().manual_seed(12))
         feats = model.backbone(x)
         sig = model.weight_mapper(feats[-1])
+        if isinstance(sig, (list, tuple)):          # v0_1: list of per-level weight tensors
+            sig = torch.cat([t[:, ::97] for t in sig], dim=1)
         y = model(x)
         keys = [k for k in model.state_dict() if 'num_batches' not in k]
         save(f'model_{tag}', x=x, y=y[:, :, 1::5, 2::7].contiguous(), y_absmax=y.abs().max(),

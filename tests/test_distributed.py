@@ -1,0 +1,61 @@
+"""N > 1 path of bench.py's batch-sharded inference harness, world_size 2 on CPU with the gloo backend: the
+double-buffered async all_gather_into_tensor of per-rank results (the logits of the rank's frames), overlapped with
+the "next frame", must deliver every rank's frames to every rank in rank order.  The GPU run uses the same code
+with backend "nccl" (= RCCL over xGMI)."""
+import os
+import socket
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # spawned workers re-import this file
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from hyperseg_amd.distributed import LogitsGatherer, shard_frames
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, steps, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        shape = (1, 3, 4, 5)
+        g = LogitsGatherer(world, shape, torch.float32, torch.device('cpu'))
+        ok = True
+        frames = shard_frames(steps * world, rank, world)
+        assert frames == list(range(rank, steps * world, world))
+        for i, f in enumerate(frames):
+            y = torch.full(shape, float(f))                  # stands for the logits of global frame f
+            prev = g.submit(i, y)                            # starts the gather of frame i, returns a finished one
+            if prev is not None:
+                step, out = prev
+                want = torch.tensor([float(step * world + r) for r in range(world)]).view(world, 1, 1, 1, 1)
+                ok &= bool(torch.equal(out, want.expand(world, *shape)))
+        for step, out in g.drain():
+            want = torch.tensor([float(step * world + r) for r in range(world)]).view(world, 1, 1, 1, 1)
+            ok &= bool(torch.equal(out, want.expand(world, *shape)))
+        q.put((rank, ok, g.completed))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('steps', [1, 5])
+def test_batch_sharded_gather_gloo(steps):
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=90) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True, steps), (1, True, steps)]

@@ -241,29 +241,80 @@ def test_tiny_decoder_v1_0(golden, dev):
     assert bool((y.argmax(1).cpu() == g['y'].argmax(1)).all())
 
 
+def test_inverted_residual_unify_and_v0(golden, dev):
+    """unify flavour (weights arrive directly) and the v0_1 block (three image-level patch convs, Op D)."""
+    from hyperseg_amd.models import hyperseg_v1_0_unify as U
+    from hyperseg_amd.models import hyperseg_v0_1 as V0
+    g = golden('inverted_residual_v1')
+    cin, cout, hid = [int(v) for v in g['u.cfg']]
+    with torch.no_grad():
+        m = U.HyperPatchInvertedResidual(cin, cout, 3, expand_ratio=hid / cin).eval()
+        missing, unexpected = m.load_state_dict(sub(g, 'u.p.'), strict=False)
+        assert not unexpected and all('num_batches' in k for k in missing)
+        cmp(m.to(dev)(g['u.x'].to(dev), g['u.wt'].to(dev)), g['u.y'], what='unify IR')
+        g0 = golden('inverted_residual_v0')
+        for i in range(int(g0['n'])):
+            cin, cout, hid = [int(v) for v in g0[f'{i}.cfg']]
+            m = V0.HyperPatchInvertedResidual(cin, cout, 3, expand_ratio=2).eval()
+            missing, unexpected = m.load_state_dict(sub(g0, f'{i}.p.'), strict=False)
+            assert not unexpected and all('num_batches' in k for k in missing)
+            cmp(m.to(dev)(g0[f'{i}.x'].to(dev), g0[f'{i}.wt'].to(dev)), g0[f'{i}.y'], what=f'v0_1 IR case {i}')
+
+
+def make_decoder(c):
+    if c['variant'] == 'v1_0':
+        from hyperseg_amd.models import hyperseg_v1_0 as M
+        return M.MultiScaleDecoder(c['feat'], c['signal'], c['num_classes'], c['kernel_sizes'], 1, c['level_channels'],
+                                   expand_ratio=c['expand_ratio'], weight_groups=list(c['weight_groups'])).eval()
+    if c['variant'] == 'unify':
+        from hyperseg_amd.models import hyperseg_v1_0_unify as U
+        return U.MultiScaleDecoder(c['feat'], c['signal'], c['num_classes'], c['kernel_sizes'], 1, c['level_channels'],
+                                   expand_ratio=c['expand_ratio'], weight_groups=list(c['weight_groups']),
+                                   unify_level=c['unify_level']).eval()
+    from hyperseg_amd.models import hyperseg_v0_1 as V0
+    return V0.MultiScaleDecoder(c['feat'], 3, c['num_classes'], c['kernel_sizes'], 1, expand_ratio=c['expand_ratio']).eval()
+
+
+@pytest.mark.parametrize('name', ['t_unify', 't_v0_1'])
+def test_tiny_decoder_other_variants(golden, dev, name):
+    from test_oracle_golden import TINY
+    g = golden('decoder_' + name)
+    c = TINY[name]
+    d = make_decoder(c)
+    missing, unexpected = d.load_state_dict(sub(g, 'p.'), strict=False)
+    assert not unexpected and all('num_batches' in k for k in missing)
+    d = d.to(dev)
+    x = [g[f'x{i}'].to(dev) for i in range(6)]
+    w = [g[f'w{i}'].to(dev) for i in range(6)] if c['variant'] == 'v0_1' else g['s'].to(dev)
+    with torch.no_grad():
+        y = d(x, w)
+    cmp(y, g['y'], what=name)
+    assert bool((y.argmax(1).cpu() == g['y'].argmax(1)).all())
+
+
 # ------------------------------------------------------------------------------ full BASELINE shapes
 def build_decoder(name, O):
-    from hyperseg_amd.models import hyperseg_v1_0 as M
     c = O.CONFIGS[name]
-    assert c['variant'] == 'v1_0'
-    d = M.MultiScaleDecoder(c['feat'], c['signal'], c['num_classes'], c['kernel_sizes'], 1, c['level_channels'],
-                            expand_ratio=c['expand_ratio'], weight_groups=list(c['weight_groups'])).eval()
+    d = make_decoder(c)
     params = O.synth_decoder_params(O.config_plan(name), seed=0)
     missing, unexpected = d.load_state_dict(params, strict=False)
     assert not unexpected and all('num_batches' in k for k in missing)
     return d
 
 
-@pytest.mark.parametrize('name', ['M', 'Sc'])
-def test_full_config_v1_0(golden, O, dev, name):
-    """HyperSeg-M 1024x512 / CamVid-S 768x576 decoder on the seeded synthetic workload of SURVEY 8(d):
-    vs the oracle on the full tensor, vs the reference's own sampled logits and masks."""
+@pytest.mark.parametrize('name', ['M', 'Sc', 'S', 'L'])
+def test_full_config(golden, O, dev, name):
+    """HyperSeg-M 1024x512 / CamVid-S 768x576 / HyperSeg-S 1536x768 (unify) / HyperSeg-L 512x512 bs2 (v0_1)
+    decoders on the seeded synthetic workload of SURVEY 8(d): vs the oracle on the full tensor, vs the
+    reference's own sampled logits and masks."""
     g = golden('decoder_full_configs')
+    batch = int(g[f'{name}.batch'])
     d = build_decoder(name, O).to(dev)
-    x, s = O.synth_decoder_inputs(name, batch=1, seed=0)
+    x, s = O.synth_decoder_inputs(name, batch=batch, seed=0)
+    s = [t.to(dev) for t in s] if isinstance(s, list) else s.to(dev)
     with torch.no_grad():
-        y = d([t.to(dev) for t in x], s.to(dev)).cpu()
-    ref, levels = O.run_config(name, batch=1, seed=0, return_levels=True)
+        y = d([t.to(dev) for t in x], s).cpu()
+    ref, levels = O.run_config(name, batch=batch, seed=0, return_levels=True)
     e = cmp(y, ref, tol=REL_TOL, what=f'{name} logits vs oracle')
     assert e < NORTH_STAR_TOL
     top2 = ref.topk(2, dim=1).values

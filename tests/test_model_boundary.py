@@ -20,6 +20,35 @@ def model_m():
     return fill_by_name(configs.build('hyperseg-m').eval(), seed=11)
 
 
+MODELS = {'M': 'hyperseg-m', 'S': 'hyperseg-s', 'L': 'hyperseg-l'}
+
+
+@pytest.mark.parametrize('tag', ['S', 'L'])
+def test_state_dict_and_context_head_other_variants(golden, tag):
+    """unify (HyperSeg-S) and v0_1 (HyperSeg-L): key/shape hashes + encoder/context-head numerics on CPU."""
+    from hyperseg_amd import configs
+    g = golden(f'model_{tag}')
+    m = fill_by_name(configs.build(MODELS[tag]).eval(), seed=11)
+    sd = m.state_dict()
+    keys = [k for k in sd if 'num_batches' not in k]
+    assert len(keys) == int(g['n_keys'])
+    assert _h(' '.join(keys)) == int(g['key_hash'][0])
+    assert _h(' '.join(str(tuple(sd[k].shape)) for k in keys)) == int(g['shape_hash'][0])
+    with torch.no_grad():
+        feats = m.backbone(g['x'])
+        sig = m.weight_mapper(feats[-1])
+    if isinstance(sig, (list, tuple)):          # v0_1: the "signal" is the list of per-level weight tensors
+        sig = torch.cat([t[:, ::97] for t in sig], dim=1)
+    assert rel_err(sig[:, ::13], g['signal']) < 1e-4
+    if tag == 'S':
+        assert [(w.signal_index, w.signal_channels) for w in m.decoder.weight_blocks] == \
+               [(0, 576), (576, 128), (704, 64), (768, 512)]
+        assert tuple(sd['decoder.weight_blocks.3.signal2weights.weight'].shape) == (3680, 32, 1, 1)
+    else:
+        assert tuple(sd['weight_mapper.out_conv.conv_1.weight'].shape) == (4496, 17, 1, 1)
+        assert m.decoder.param_groups == [9408, 4488, 6624, 1716, 992, 902]
+
+
 def test_state_dict_contract(golden, model_m):
     g = golden('model_M')
     sd = model_m.state_dict()
@@ -64,6 +93,22 @@ def test_decoder_refuses_cpu(model_m):
     from hyperseg_amd._hip import HipLibraryError
     with torch.no_grad(), pytest.raises(HipLibraryError):
         model_m(torch.rand(1, 3, 64, 64))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', ['S', 'L'])
+def test_model_end_to_end_other_variants(golden, tag):
+    from hyperseg_amd import configs
+    g = golden(f'model_{tag}')
+    dev = torch.device('cuda:0')
+    m = fill_by_name(configs.build(MODELS[tag]).eval(), seed=11).to(dev)
+    with torch.no_grad():
+        y = m(g['x'].to(dev)).cpu()
+    assert list(y.shape) == [int(v) for v in g['y_shape']]
+    ys = y[:, :, 1::5, 2::7]
+    assert float((ys - g['y']).abs().max()) < 1e-3 * float(g['y_absmax'])
+    ok = g['margin'] > 1e-3 * float(g['y_absmax'])
+    assert bool((ys.argmax(1).to(torch.uint8)[ok] == g['mask'][ok]).all())
 
 
 @pytest.mark.gpu
