@@ -9,7 +9,8 @@ import os
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libhyperseg_hip.so')
+_LIB_PATH = os.environ.get('HS_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib',
+                                                         'libhyperseg_hip.so')   # HS_HIP_LIB: dev override
 
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
 PAD_MODES = {'zeros': 0, 'reflect': 1, 'replicate': 2, 'circular': 3}

@@ -129,21 +129,20 @@ void patch_conv1x1_kernel(Conv1Args a) {
     const int n4 = hp4 >> 2;                          // ld is a multiple of 4 and >= hp: the tail read stays in-row
     const int y0 = i * a.ph, x0 = j * a.pw;
     const int total_x = cin * npix;
+    // unconditional loads from clamped indices: conditionally-written register arrays end up in scratch memory
     float4 wv[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int e = tid + q * CONV_THREADS;
-        if (e < n4) wv[q] = src[e];
+        wv[q] = src[e < n4 ? e : n4 - 1];
     }
     float xv[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int e = tid + q * CONV_THREADS;
-        if (e < total_x) {
-            const int c = e / npix, pix = e - c * npix;
-            const int u = pix / a.pw, vv = pix - u * a.pw;
-            xv[q] = stage_value(a.in, b, c, stage_pos(a.in, y0 + u, x0 + vv));
-        }
+        const int e = min(tid + q * CONV_THREADS, total_x - 1);
+        const int c = e / npix, pix = e - c * npix;
+        const int u = pix / a.pw, vv = pix - u * a.pw;
+        xv[q] = stage_value(a.in, b, c, stage_pos(a.in, y0 + u, x0 + vv));
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {

@@ -20,6 +20,10 @@
 // LDS: max(T tile, h1 + h2) = 48 KB at HyperSeg-M level 4 -> 3 workgroups / CU; hidden activations never leave the CU.
 #include "hs_common.h"
 
+#ifndef HS_IRM_ABLATE
+#define HS_IRM_ABLATE 0     // dev-only timing ablations (tools/ablate_ir.py): 1 no prologue loads, 2 no pw1 MFMA,
+#endif                      // 4 no dw math, 8 no pw3 MFMA, 16 no per-chunk operand loads.  0 = the product kernel.
+
 namespace hs {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -46,11 +50,15 @@ template <int TILE> struct IrmGeom {
     static constexpr int NP1 = NT1 * 16;
     static constexpr int J1 = (NT1 + 3) / 4;                    // position tiles per wave
     static constexpr int RS = (HW + 3) & ~3;                    // h1 row stride (floats), 16-byte aligned rows
-    static constexpr int H1P = HW * RS;                         // h1 plane per hidden channel
+    // h1 plane per hidden channel, padded to == 4 (mod 8) floats: the two D-row groups (lk = 0, 1) of a half-wave
+    // then write banks 16 apart (an unpadded 360 makes all four row groups collide: 4-way conflicts on every store)
+    static constexpr int H1P = ((HW * RS + 7) & ~7) + 4;
     static constexpr int NPIX = TILE * TILE;
     static constexpr int NT3 = NPIX / 16;                       // pixel tiles (pw3 N)
     static constexpr int J3 = (NT3 + 3) / 4;
-    static constexpr int H2S = NPIX + 16;                       // h2 row stride: == 16 (mod 32) -> conflict-free B reads
+    static constexpr int RS2 = TILE + 4;                        // h2 pixel-row stride: 16-byte rows, b128 stores of
+                                                                // 8 consecutive rows fall on 8 distinct bank quads
+    static constexpr int H2S = ((TILE * RS2 + 31) & ~31) + 16;  // h2 plane: == 16 (mod 32) -> conflict-free B reads
 };
 
 __device__ __forceinline__ float relu6m(float v) { return fminf(fmaxf(v, 0.0f), 6.0f); }
@@ -66,6 +74,9 @@ void patch_ir_mfma_kernel(IrMfmaArgs a) {
     float* T = lds;                                   // [KS1*4][NP1]            (prologue only)
     float* h1 = lds;                                  // [16][H1P]               (aliases T)
     float* h2 = lds + 16 * G::H1P;                    // [16][H2S]
+    constexpr int TILE_FLOATS = (KS1 * 4 * G::NP1 > 16 * G::H1P + 16 * G::H2S) ? KS1 * 4 * G::NP1
+                                                                               : 16 * G::H1P + 16 * G::H2S;
+    float* wl = lds + TILE_FLOATS;                    // the patch's whole filter bank (rows in reference order)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, lk = lane >> 4;
@@ -77,9 +88,28 @@ void patch_ir_mfma_kernel(IrMfmaArgs a) {
     const int y0 = i * a.ph + ty_i * TILE, x0 = j * a.pw + tx_i * TILE;
     const int hid = a.hid;
     const float* __restrict__ wp = a.bank + (size_t)patch * a.ld;
-    const float* __restrict__ w1 = wp;
-    const float* __restrict__ kd = wp + (size_t)CIN * hid;
-    const float* __restrict__ w3 = kd + (size_t)9 * hid;
+    const int nw = CIN * hid + 9 * hid + hid * COUT;           // bank rows of this block
+    const int nw4 = (nw + 3) >> 2;
+    float* bnl = wl + nw4 * 4;                                  // [s1 | b1 | s2 | b2] x hid, [s3 | b3] x COUT
+    const float* w1 = wl;                                       // LDS copies (filled below)
+    const float* kd = wl + CIN * hid;
+    const float* w3 = kd + 9 * hid;
+
+    // The bank is read from HBM exactly once, as 16-byte loads issued BEFORE the prologue's gathers, so the (cold)
+    // HBM latency of weights and inputs is paid once and together; every later operand fetch is an LDS read.
+    constexpr int WQ = 6;                                       // float4 per thread: covers banks up to 6144 floats
+    float4 wreg[WQ];
+    const bool w_vec = (((size_t)wp) & 15) == 0;
+    {
+        // unconditional loads from a clamped index keep wreg in registers (ld is a multiple of 4 >= rows, so the
+        // last float4 of the bank stays inside this patch's row)
+        const float4* __restrict__ src = reinterpret_cast<const float4*>(w_vec ? wp : a.bank);
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) {
+            const int e = tid + q * IRM_THREADS;
+            wreg[q] = src[e < nw4 ? e : nw4 - 1];
+        }
+    }
 
     // ---- prologue: stage-input columns -> LDS --------------------------------------------------
     {
@@ -97,7 +127,7 @@ void patch_ir_mfma_kernel(IrMfmaArgs a) {
             col[1] = linspace_pm1(yy, a.in.H, a.in.step_y);
             const float* __restrict__ sp = skb + (size_t)yy * a.in.W + xx;
 #pragma unroll
-            for (int c = 0; c < CSKIP; ++c) col[2 + c] = sp[c * plane];
+            for (int c = 0; c < CSKIP; ++c) col[2 + c] = (HS_IRM_ABLATE & 1) ? (float)(c + pos) : sp[c * plane];
             const Tap ty = bilinear_tap(yy, a.in.scale_y, a.in.Hp), tx = bilinear_tap(xx, a.in.scale_x, a.in.Wp);
             const int o00 = ty.i0 * a.in.Wp + tx.i0, o01 = ty.i0 * a.in.Wp + tx.i1;
             const int o10 = ty.i1 * a.in.Wp + tx.i0, o11 = ty.i1 * a.in.Wp + tx.i1;
@@ -105,7 +135,8 @@ void patch_ir_mfma_kernel(IrMfmaArgs a) {
 #pragma unroll
             for (int c = 0; c < CPREV; ++c) {
                 const float* __restrict__ q = pvb + c * pplane;
-                v00[c] = q[o00]; v01[c] = q[o01]; v10[c] = q[o10]; v11[c] = q[o11];
+                if (HS_IRM_ABLATE & 1) { v00[c] = v01[c] = v10[c] = v11[c] = (float)(o00 + c); }
+                else { v00[c] = q[o00]; v01[c] = q[o01]; v10[c] = q[o10]; v11[c] = q[o11]; }
             }
 #pragma unroll
             for (int c = 0; c < CPREV; ++c)
@@ -116,6 +147,21 @@ void patch_ir_mfma_kernel(IrMfmaArgs a) {
             for (int c = 0; c < KS1 * 4; ++c) T[c * G::NP1 + pos] = live ? col[c] : 0.0f;
         }
     }
+    if (w_vec) {
+        float4* dst = reinterpret_cast<float4*>(wl);
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) {
+            const int e = tid + q * IRM_THREADS;
+            if (e < nw4) dst[e] = wreg[q];
+        }
+        for (int e = tid + WQ * IRM_THREADS; e < nw4; e += IRM_THREADS) dst[e] = reinterpret_cast<const float4*>(wp)[e];
+    } else {
+        for (int e = tid; e < nw; e += IRM_THREADS) wl[e] = wp[e];
+    }
+    for (int e = tid; e < hid; e += IRM_THREADS) {
+        bnl[e] = a.s1[e]; bnl[hid + e] = a.b1[e]; bnl[2 * hid + e] = a.s2[e]; bnl[3 * hid + e] = a.b2[e];
+    }
+    if (tid < COUT) { bnl[4 * hid + tid] = a.s3[tid]; bnl[4 * hid + COUT + tid] = a.b3[tid]; }
     __syncthreads();
 
     // ---- B fragments of this wave's position tiles, kept in registers for the whole kernel ------
@@ -133,6 +179,12 @@ void patch_ir_mfma_kernel(IrMfmaArgs a) {
     }
     __syncthreads();                                   // T is dead: h1 / h2 may now overwrite it
 
+    int h2off[G::J3];                                  // LDS offset of this lane's pixel inside an h2 plane
+#pragma unroll
+    for (int jt = 0; jt < G::J3; ++jt) {
+        const int pix = (wave + 4 * jt) * 16 + lrow;
+        h2off[jt] = (pix / TILE) * G::RS2 + (pix % TILE);
+    }
     f32x4 acc3[MT3][G::J3];
 #pragma unroll
     for (int m = 0; m < MT3; ++m)
@@ -146,12 +198,12 @@ void patch_ir_mfma_kernel(IrMfmaArgs a) {
     const int nchunks = (hid + 15) >> 4;
     for (int ch = 0; ch < nchunks; ++ch) {
         const int h0 = ch * 16;
-        // operands of this chunk (independent vector loads, issued together)
-        float af[KS1];
+        // per-chunk operands: LDS reads of the staged bank (A fragments are distributed over the lanes)
+        float af[KS1];             // pw1 A fragments   W1[h0 + lrow][4*ks + lk]
         {
             const int h = h0 + lrow;
             const bool hok = h < hid;
-            const float* __restrict__ wr = w1 + (size_t)(hok ? h : 0) * CIN;
+            const float* wr = w1 + (hok ? h : 0) * CIN;
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks) {
                 const int k = ks * 4 + lk;
@@ -159,30 +211,30 @@ void patch_ir_mfma_kernel(IrMfmaArgs a) {
                 af[ks] = (hok && k < CIN) ? v : 0.0f;
             }
         }
-        float sc1[4], sh1[4];
+        float sc1[4], sh1[4];      // bn1 rows of this lane's 4 D rows
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int h = h0 + 4 * lk + r;
-            const int hc = h < hid ? h : 0;
-            sc1[r] = a.s1[hc]; sh1[r] = a.b1[hc];
+            const int hr = h0 + 4 * lk + r;
+            const int hc = hr < hid ? hr : 0;
+            sc1[r] = bnl[hc]; sh1[r] = bnl[hid + hc];
         }
-        float k9[9], sc2, sh2;
+        float k9[9], sc2, sh2;     // depthwise weights + bn2 of this thread's dw channel
         {
             const int h = h0 + dw_hh;
             const int hc = h < hid ? h : 0;
 #pragma unroll
-            for (int q = 0; q < 9; ++q) k9[q] = kd[(size_t)hc * 9 + q];
-            sc2 = a.s2[hc]; sh2 = a.b2[hc];
+            for (int q = 0; q < 9; ++q) k9[q] = kd[hc * 9 + q];
+            sc2 = bnl[2 * hid + hc]; sh2 = bnl[3 * hid + hc];
         }
-        float a3[MT3][4];
+        float a3[MT3][4];          // pw3 A fragments   W3[16*m + lrow][h0 + 4*ks + lk]
 #pragma unroll
         for (int m = 0; m < MT3; ++m) {
-            const int o = m * 16 + lrow;
-            const bool ook = o < COUT;
+            const int oc = m * 16 + lrow;
+            const bool ook = oc < COUT;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int h = h0 + ks * 4 + lk;
-                const float v = w3[(size_t)(ook ? o : 0) * hid + (h < hid ? h : 0)];
+                const float v = w3[(ook ? oc : 0) * hid + (h < hid ? h : 0)];
                 a3[m][ks] = (ook && h < hid) ? v : 0.0f;
             }
         }
@@ -193,8 +245,10 @@ void patch_ir_mfma_kernel(IrMfmaArgs a) {
             if (wave + 4 * jt < G::NT1) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < KS1; ++ks)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks], bf[jt][ks], acc, 0, 0, 0);
+                for (int ks = 0; ks < KS1; ++ks) {
+                    if (HS_IRM_ABLATE & 2) acc[ks & 3] += af[ks] * bf[jt][ks];
+                    else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks], bf[jt][ks], acc, 0, 0, 0);
+                }
                 if (h1off[jt] >= 0) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
@@ -222,10 +276,11 @@ void patch_ir_mfma_kernel(IrMfmaArgs a) {
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) d = fmaf(k9[ky * 3 + kx], rowv[ky][v + kx], d);
+                    for (int kx = 0; kx < 3; ++kx)
+                        if (!(HS_IRM_ABLATE & 4) || (ky == 1 && kx == 1)) d = fmaf(k9[ky * 3 + kx], rowv[ky][v + kx], d);
                 o[v] = relu6m(fmaf(d, sc2, sh2));
             }
-            float* dst = h2 + dw_hh * G::H2S + dw_u * TILE;
+            float* dst = h2 + dw_hh * G::H2S + dw_u * G::RS2;
 #pragma unroll
             for (int q = 0; q < TILE / 4; ++q)
                 *reinterpret_cast<float4*>(dst + 4 * q) = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
@@ -240,10 +295,12 @@ void patch_ir_mfma_kernel(IrMfmaArgs a) {
                 for (int jt = 0; jt < G::J3; ++jt) {
                     const int nt = wave + 4 * jt;
                     if (nt < G::NT3) {
-                        const float bv = h2[(ks * 4 + lk) * G::H2S + nt * 16 + lrow];
+                        const float bv = h2[(ks * 4 + lk) * G::H2S + h2off[jt]];
 #pragma unroll
-                        for (int m = 0; m < MT3; ++m)
-                            acc3[m][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[m][ks], bv, acc3[m][jt], 0, 0, 0);
+                        for (int m = 0; m < MT3; ++m) {
+                            if (HS_IRM_ABLATE & 8) acc3[m][jt][ks] += a3[m][ks] * bv;
+                            else acc3[m][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[m][ks], bv, acc3[m][jt], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -259,7 +316,7 @@ void patch_ir_mfma_kernel(IrMfmaArgs a) {
         for (int r = 0; r < 4; ++r) {
             const int o = m * 16 + 4 * lk + r;
             if (o < COUT) {
-                const float sc = a.s3[o], sh = a.b3[o];
+                const float sc = bnl[4 * hid + o], sh = bnl[4 * hid + COUT + o];
 #pragma unroll
                 for (int jt = 0; jt < G::J3; ++jt) {
                     const int nt = wave + 4 * jt;
@@ -280,8 +337,15 @@ static int launch_irm(const IrMfmaArgs& a, long blocks, hipStream_t stream) {
     constexpr int KS1 = (CIN + 3) / 4;
     constexpr size_t t_floats = (size_t)KS1 * 4 * G::NP1;
     constexpr size_t h_floats = (size_t)16 * G::H1P + (size_t)16 * G::H2S;
-    constexpr size_t lds = (t_floats > h_floats ? t_floats : h_floats) * sizeof(float);
-    static_assert(lds <= 64 * 1024, "tile does not fit the default dynamic LDS limit");
+    const size_t nw = (size_t)CIN * a.hid + 9 * (size_t)a.hid + (size_t)a.hid * COUT;
+    const size_t lds = ((t_floats > h_floats ? t_floats : h_floats) + ((nw + 3) & ~(size_t)3) + 4 * (size_t)a.hid + 2 * COUT) *
+                       sizeof(float);
+    if (lds > 160 * 1024) return HS_ERR_LDS;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)patch_ir_mfma_kernel<CIN, CSKIP, COUT, TILE>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
     hipLaunchKernelGGL((patch_ir_mfma_kernel<CIN, CSKIP, COUT, TILE>), dim3((unsigned)blocks), dim3(IRM_THREADS), lds, stream, a);
     return launch_status();
 }

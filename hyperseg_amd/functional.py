@@ -155,6 +155,20 @@ def signal2weights_multi(signal, layers):
     return refs
 
 
+class SideStream:
+    """A second HIP stream per device for work that is independent of the decoder's level-to-level chain (the banks
+    of the late levels): forked from / joined to the current stream with events, so it is captured as a parallel
+    branch when the forward runs under HIP-graph capture."""
+    _streams = {}
+
+    @classmethod
+    def get(cls, device):
+        key = (device.type, device.index)
+        if key not in cls._streams:
+            cls._streams[key] = torch.cuda.Stream(device=device)
+        return cls._streams[key]
+
+
 def bank_pack(w, ch_offset, rows, out=None):
     """(B, hp_total, fh, fw) channel-major weights -> patch-major bank (B*fh*fw, ld)."""
     b, c_view, fh, fw = w.shape

@@ -437,8 +437,28 @@ class MultiScaleDecoder(nn.Module):
             # the reference hands each module s[:, 0:hyper_params] (MetaSequential's clamped slice, Appendix D-2)
             if m.signal_index + m.signal_channels > min(int(m.hyper_params), s.shape[1]):
                 raise ValueError('signal slice of a decoder level exceeds what MetaSequential would hand to it')
-        sig = s
-        refs = HF.signal2weights_multi(sig, [m.s2w_layer(s.device) for m in flat])
+        # The banks depend on the signal only.  The light k=1 levels' banks are produced on the current stream; the
+        # heavy k=3 levels' banks (80 % of the signal2weights work) on a side stream, overlapping the k=1 levels.
+        n_early = sum(len(g) for l, g in enumerate(groups)
+                      if l < self.levels and all(not isinstance(m, HyperPatchInvertedResidual) for m in g)
+                      and all(all(not isinstance(q, HyperPatchInvertedResidual) for q in groups[e]) for e in range(l)))
+        layers = [m.s2w_layer(s.device) for m in flat]
+        side = join_level = None
+        if 0 < n_early < len(flat) and s.is_cuda:
+            main = torch.cuda.current_stream()
+            side = HF.SideStream.get(s.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                late = HF.signal2weights_multi(s, layers[n_early:])
+            refs = HF.signal2weights_multi(s, layers[:n_early]) + late
+            cnt = 0
+            for l, g in enumerate(groups):
+                cnt += len(g)
+                if cnt > n_early:
+                    join_level = l
+                    break
+        else:
+            refs = HF.signal2weights_multi(s, layers)
         banks, k = [], 0
         for g in groups:
             banks.append(refs[k:k + len(g)])
@@ -446,9 +466,14 @@ class MultiScaleDecoder(nn.Module):
         p = None
         for level in range(self.levels):
             level_layers = getattr(self, f'level_{level}')
+            if side is not None and level == join_level:
+                torch.cuda.current_stream().wait_stream(side)
+                side = None
             # cat(coords, skip, bilinear(p)) is never built: the stage kernel's prologue generates it
             stage = HF.StageInput(x[-level - 1], p, coords=True)
             p = level_layers(stage, banks[level])
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         if self.out_fc is not None:
             p = self.out_fc(p, banks[-1])
         if p.shape[2:] != x[0].shape[2:]:
