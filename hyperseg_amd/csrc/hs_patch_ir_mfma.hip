@@ -24,6 +24,19 @@
 #define HS_IRM_ABLATE 0     // dev-only timing ablations (tools/ablate_ir.py): 1 no prologue loads, 2 no pw1 MFMA,
 #endif                      // 4 no dw math, 8 no pw3 MFMA, 16 no per-chunk operand loads.  0 = the product kernel.
 
+#ifndef HS_IRM_TIMING
+#define HS_IRM_TIMING 0     // dev-only: per-phase s_memtime stamps of wave 0 of every workgroup (tools/ablate_ir.py)
+#endif
+#if HS_IRM_TIMING
+__device__ long long hs_irm_stamps[4096 * 24];
+#define HS_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) hs_irm_stamps[blockIdx.x * 24 + (k)] = __builtin_readcyclecounter(); } while (0)
+extern "C" int hs_debug_read_stamps(long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hs_irm_stamps), sizeof(long long) * n);
+}
+#else
+#define HS_STAMP(k) do {} while (0)
+#endif
+
 namespace hs {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -53,6 +66,8 @@ template <int TILE> struct IrmGeom {
     // h1 plane per hidden channel, padded to == 4 (mod 8) floats: the two D-row groups (lk = 0, 1) of a half-wave
     // then write banks 16 apart (an unpadded 360 makes all four row groups collide: 4-way conflicts on every store)
     static constexpr int H1P = ((HW * RS + 7) & ~7) + 4;
+    static constexpr int PW = TILE / 2 + 2;                     // low-res window edge of the previous level (exact 2x)
+    static constexpr int PPL = PW * PW;
     static constexpr int NPIX = TILE * TILE;
     static constexpr int NT3 = NPIX / 16;                       // pixel tiles (pw3 N)
     static constexpr int J3 = (NT3 + 3) / 4;
@@ -95,6 +110,24 @@ void patch_ir_mfma_kernel(IrMfmaArgs a) {
     const float* kd = wl + CIN * hid;
     const float* w3 = kd + 9 * hid;
 
+    HS_STAMP(0);
+    // low-res window of the previous level: rows [ly0, ly0+PW) x cols [lx0, lx0+PW) (indices clamped at the image
+    // border) -- every bilinear tap of the halo tile, reflected positions included, falls inside it
+    float* pl = bnl + ((4 * hid + 2 * COUT + 3) & ~3);         // [CPREV][PW*PW]
+    const int ly0 = (y0 >> 1) - 1, lx0 = (x0 >> 1) - 1;
+    constexpr int PQ = (CPREV * G::PPL + IRM_THREADS - 1) / IRM_THREADS;
+    float preg[PQ];
+    {
+        const float* __restrict__ pvb = a.in.prev + (size_t)b * CPREV * a.in.Hp * a.in.Wp;
+#pragma unroll
+        for (int q = 0; q < PQ; ++q) {
+            const int e = min(tid + q * IRM_THREADS, CPREV * G::PPL - 1);
+            const int c = e / G::PPL, rq = e - c * G::PPL;
+            const int r = rq / G::PW, qq = rq - r * G::PW;
+            const int yy = min(max(ly0 + r, 0), a.in.Hp - 1), xx = min(max(lx0 + qq, 0), a.in.Wp - 1);
+            preg[q] = pvb[((size_t)c * a.in.Hp + yy) * a.in.Wp + xx];
+        }
+    }
     // The bank is read from HBM exactly once, as 16-byte loads issued BEFORE the prologue's gathers, so the (cold)
     // HBM latency of weights and inputs is paid once and together; every later operand fetch is an LDS read.
     constexpr int WQ = 6;                                       // float4 per thread: covers banks up to 6144 floats
@@ -110,42 +143,30 @@ void patch_ir_mfma_kernel(IrMfmaArgs a) {
             wreg[q] = src[e < nw4 ? e : nw4 - 1];
         }
     }
-
-    // ---- prologue: stage-input columns -> LDS --------------------------------------------------
+    // the skip-feature gathers of BOTH position passes are issued now as well: together with the window and the bank
+    // this is the workgroup's ONLY exposed HBM round trip
+    constexpr int NPASS = (G::NP1 + IRM_THREADS - 1) / IRM_THREADS;
+    float skv[NPASS][CSKIP];
     {
         const size_t plane = (size_t)a.in.H * a.in.W;
-        const size_t pplane = (size_t)a.in.Hp * a.in.Wp;
         const float* __restrict__ skb = a.in.skip + (size_t)b * CSKIP * plane;
-        const float* __restrict__ pvb = a.in.prev + (size_t)b * CPREV * pplane;
-        for (int pos = tid; pos < G::NP1; pos += IRM_THREADS) {
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int pos = tid + ps * IRM_THREADS;
             const bool live = pos < G::NPOS;
             const int pu = live ? pos / G::HW : 0, pv = live ? pos - pu * G::HW : 0;
             const int yy = pad_index(y0 + pu - 1, a.in.H, HS_PAD_REFLECT);
             const int xx = pad_index(x0 + pv - 1, a.in.W, HS_PAD_REFLECT);
-            float col[KS1 * 4];
-            col[0] = linspace_pm1(xx, a.in.W, a.in.step_x);
-            col[1] = linspace_pm1(yy, a.in.H, a.in.step_y);
             const float* __restrict__ sp = skb + (size_t)yy * a.in.W + xx;
 #pragma unroll
-            for (int c = 0; c < CSKIP; ++c) col[2 + c] = (HS_IRM_ABLATE & 1) ? (float)(c + pos) : sp[c * plane];
-            const Tap ty = bilinear_tap(yy, a.in.scale_y, a.in.Hp), tx = bilinear_tap(xx, a.in.scale_x, a.in.Wp);
-            const int o00 = ty.i0 * a.in.Wp + tx.i0, o01 = ty.i0 * a.in.Wp + tx.i1;
-            const int o10 = ty.i1 * a.in.Wp + tx.i0, o11 = ty.i1 * a.in.Wp + tx.i1;
-            float v00[CPREV], v01[CPREV], v10[CPREV], v11[CPREV];
-#pragma unroll
-            for (int c = 0; c < CPREV; ++c) {
-                const float* __restrict__ q = pvb + c * pplane;
-                if (HS_IRM_ABLATE & 1) { v00[c] = v01[c] = v10[c] = v11[c] = (float)(o00 + c); }
-                else { v00[c] = q[o00]; v01[c] = q[o01]; v10[c] = q[o10]; v11[c] = q[o11]; }
-            }
-#pragma unroll
-            for (int c = 0; c < CPREV; ++c)
-                col[2 + CSKIP + c] = ty.l0 * (tx.l0 * v00[c] + tx.l1 * v01[c]) + ty.l1 * (tx.l0 * v10[c] + tx.l1 * v11[c]);
-#pragma unroll
-            for (int c = CIN; c < KS1 * 4; ++c) col[c] = 0.0f;
-#pragma unroll
-            for (int c = 0; c < KS1 * 4; ++c) T[c * G::NP1 + pos] = live ? col[c] : 0.0f;
+            for (int c = 0; c < CSKIP; ++c) skv[ps][c] = sp[c * plane];
         }
+    }
+
+#pragma unroll
+    for (int q = 0; q < PQ; ++q) {
+        const int e = tid + q * IRM_THREADS;
+        if (e < CPREV * G::PPL) pl[e] = preg[q];
     }
     if (w_vec) {
         float4* dst = reinterpret_cast<float4*>(wl);
@@ -158,12 +179,43 @@ void patch_ir_mfma_kernel(IrMfmaArgs a) {
     } else {
         for (int e = tid; e < nw; e += IRM_THREADS) wl[e] = wp[e];
     }
+    __syncthreads();
+    // ---- prologue: stage-input columns -> LDS --------------------------------------------------
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int pos = tid + ps * IRM_THREADS;
+        if (pos < G::NP1) {
+            const bool live = pos < G::NPOS;
+            const int pu = live ? pos / G::HW : 0, pv = live ? pos - pu * G::HW : 0;
+            const int yy = pad_index(y0 + pu - 1, a.in.H, HS_PAD_REFLECT);
+            const int xx = pad_index(x0 + pv - 1, a.in.W, HS_PAD_REFLECT);
+            float col[KS1 * 4];
+            col[0] = linspace_pm1(xx, a.in.W, a.in.step_x);
+            col[1] = linspace_pm1(yy, a.in.H, a.in.step_y);
+#pragma unroll
+            for (int c = 0; c < CSKIP; ++c) col[2 + c] = skv[ps][c];
+            const Tap ty = bilinear_tap(yy, a.in.scale_y, a.in.Hp), tx = bilinear_tap(xx, a.in.scale_x, a.in.Wp);
+            // bilinear taps from the LDS window (tap indices are already clamped to the image by bilinear_tap)
+            const int r0 = ty.i0 - ly0, r1 = ty.i1 - ly0, q0 = tx.i0 - lx0, q1 = tx.i1 - lx0;
+            const int o00 = r0 * G::PW + q0, o01 = r0 * G::PW + q1, o10 = r1 * G::PW + q0, o11 = r1 * G::PW + q1;
+#pragma unroll
+            for (int c = 0; c < CPREV; ++c) {
+                const float* q = pl + c * G::PPL;
+                col[2 + CSKIP + c] = ty.l0 * (tx.l0 * q[o00] + tx.l1 * q[o01]) + ty.l1 * (tx.l0 * q[o10] + tx.l1 * q[o11]);
+            }
+#pragma unroll
+            for (int c = CIN; c < KS1 * 4; ++c) col[c] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < KS1 * 4; ++c) T[c * G::NP1 + pos] = live ? col[c] : 0.0f;
+        }
+    }
     for (int e = tid; e < hid; e += IRM_THREADS) {
         bnl[e] = a.s1[e]; bnl[hid + e] = a.b1[e]; bnl[2 * hid + e] = a.s2[e]; bnl[3 * hid + e] = a.b2[e];
     }
     if (tid < COUT) { bnl[4 * hid + tid] = a.s3[tid]; bnl[4 * hid + COUT + tid] = a.b3[tid]; }
     __syncthreads();
 
+    HS_STAMP(2);
     // ---- B fragments of this wave's position tiles, kept in registers for the whole kernel ------
     float bf[G::J1][KS1];
     int h1off[G::J1];                                  // LDS offset (pu*RS + pv) of this lane's position, -1 if none
@@ -178,6 +230,7 @@ void patch_ir_mfma_kernel(IrMfmaArgs a) {
         h1off[jt] = (ok && pos < G::NPOS) ? pu * G::RS + pv : -1;
     }
     __syncthreads();                                   // T is dead: h1 / h2 may now overwrite it
+    HS_STAMP(3);
 
     int h2off[G::J3];                                  // LDS offset of this lane's pixel inside an h2 plane
 #pragma unroll
@@ -239,6 +292,7 @@ void patch_ir_mfma_kernel(IrMfmaArgs a) {
             }
         }
 
+        HS_STAMP(4 + 4 * (ch < 4 ? ch : 4));
         // ---- pw1: h1[16][pos] = relu6(bn1(W1 chunk . T)) ---------------------------------------
 #pragma unroll
         for (int jt = 0; jt < G::J1; ++jt) {
@@ -256,7 +310,9 @@ void patch_ir_mfma_kernel(IrMfmaArgs a) {
                 }
             }
         }
+        HS_STAMP(5 + 4 * (ch < 4 ? ch : 4));
         __syncthreads();
+        HS_STAMP(6 + 4 * (ch < 4 ? ch : 4));
 
         // ---- dw 3x3 + bn2 + relu6: thread = (hidden channel, output row) ------------------------
         if (dw_on) {
@@ -286,6 +342,7 @@ void patch_ir_mfma_kernel(IrMfmaArgs a) {
                 *reinterpret_cast<float4*>(dst + 4 * q) = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
         }
         __syncthreads();
+        HS_STAMP(7 + 4 * (ch < 4 ? ch : 4));
 
         // ---- pw3: acc3 += W3[:, chunk] . h2 ------------------------------------------------------
 #pragma unroll
@@ -309,6 +366,7 @@ void patch_ir_mfma_kernel(IrMfmaArgs a) {
         // and the next dw writes h2 only after the next chunk's first barrier, which every wave reaches after pw3.
     }
 
+    HS_STAMP(22);
     // ---- epilogue: bn3 + store -----------------------------------------------------------------
 #pragma unroll
     for (int m = 0; m < MT3; ++m) {
@@ -329,6 +387,7 @@ void patch_ir_mfma_kernel(IrMfmaArgs a) {
             }
         }
     }
+    HS_STAMP(23);
 }
 
 template <int CIN, int CSKIP, int COUT, int TILE>
@@ -338,8 +397,9 @@ static int launch_irm(const IrMfmaArgs& a, long blocks, hipStream_t stream) {
     constexpr size_t t_floats = (size_t)KS1 * 4 * G::NP1;
     constexpr size_t h_floats = (size_t)16 * G::H1P + (size_t)16 * G::H2S;
     const size_t nw = (size_t)CIN * a.hid + 9 * (size_t)a.hid + (size_t)a.hid * COUT;
-    const size_t lds = ((t_floats > h_floats ? t_floats : h_floats) + ((nw + 3) & ~(size_t)3) + 4 * (size_t)a.hid + 2 * COUT) *
-                       sizeof(float);
+    constexpr size_t cprev = CIN - 2 - CSKIP;
+    const size_t lds = ((t_floats > h_floats ? t_floats : h_floats) + ((nw + 3) & ~(size_t)3) +
+                        ((4 * (size_t)a.hid + 2 * COUT + 3) & ~(size_t)3) + cprev * G::PPL) * sizeof(float);
     if (lds > 160 * 1024) return HS_ERR_LDS;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)patch_ir_mfma_kernel<CIN, CSKIP, COUT, TILE>,
@@ -363,6 +423,7 @@ int try_launch_ir_mfma(const StageIn& in, int fh, int fw, const float* bank, lon
     if (a.ph % 16 == 0 && a.pw % 16 == 0) tile = 16;
     else if (a.ph % 8 == 0 && a.pw % 8 == 0) tile = 8;
     if (!tile) return 1;
+    if (in.Hp * 2 != in.H || in.Wp * 2 != in.W) return 1;      // the LDS window assumes the exact 2x pyramid
     a.tiles_y = a.ph / tile; a.tiles_x = a.pw / tile;
     const long blocks = (long)in.B * fh * fw * a.tiles_y * a.tiles_x;
 #define HS_IRM_CASE(CI, CS, CO) \
