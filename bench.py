@@ -247,13 +247,37 @@ def main():
         torch.cuda.synchronize()
         for n in names:
             setattr(HF, n, orig[n])
+        # an empty event pair on a busy stream is not 0: calibrate that overhead and report both
+        cal = []
+        for _ in range(50):
+            torch.cuda._sleep(200_000)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); e1.record()
+            cal.append((e0, e1))
+        torch.cuda.synchronize()
+        cal = sorted(a.elapsed_time(b) * 1e3 for a, b in cal)
+        ev_overhead = cal[len(cal) // 2]
         launches = []
         for (i, n), evs in sorted(recs.items()):
             ts = [a.elapsed_time(b) * 1e3 for a, b in evs]
-            launches.append(dict(idx=i, kernel='hs_' + n + '_fwd', avg_us=round(sum(ts) / len(ts), 2)))
+            avg = sum(ts) / len(ts)
+            launches.append(dict(idx=i, kernel='hs_' + n + '_fwd', avg_us=round(max(avg - ev_overhead, 0.0), 2),
+                                 raw_event_us=round(avg, 2)))
         dec_us = sum(a.elapsed_time(b) for a, b in dec_evs) * 1e3 / len(dec_evs)
 
         alg_bytes, levels = decoder_algorithmic(model, h, w, spec['batch'])
+
+        def pmc_traffic(kernel_substr):
+            """HBM bytes per launch from the committed PMC passes (profiles/round1_pmc_hbm.json: separate rocprofv3 --pmc
+            FETCH_SIZE / WRITE_SIZE runs of tools/prof_decoder.py; KB units; gfx950 FETCH_SIZE x2 correction)."""
+            try:
+                doc = json.load(open(os.path.join(REPO, 'profiles', 'round1_pmc_hbm.json')))
+                for k, v in doc['kernels'].items():
+                    if kernel_substr in k:
+                        return int((2 * v['FETCH_SIZE_KB_avg_per_launch'] + v['WRITE_SIZE_KB_avg_per_launch']) * 1024)
+            except (OSError, KeyError, ValueError):
+                pass
+            return None
         ir = [l for l in launches if l['kernel'] == 'hs_patch_ir_fwd']
         dom = max(launches, key=lambda l: l['avg_us'])
         lv4 = levels[-1]
@@ -264,7 +288,8 @@ def main():
             # the kernel's binding roof: fp32 FLOPs (8.0 us at peak) > HBM bytes (3.6 us at peak)
             roof = {'bound': 'mfma', 'kernel': 'hs_patch_ir_fwd (level 4: 34->68->19 ch, 16x16 patches)',
                     'achieved': round(flops / t_s / 1e12, 3), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(flops / t_s / 1e12 / FP32_PEAK_TFLOPS, 4), 'traffic': None,
+                    'frac': round(flops / t_s / 1e12 / FP32_PEAK_TFLOPS, 4),
+                    'traffic': pmc_traffic('patch_ir_mfma_kernel<34, 16, 19, 16>'),
                     'avg_launch_us': dom['avg_us'], 'algorithmic_flops': flops, 'algorithmic_bytes': kbytes,
                     'hbm_frac': round(kbytes / t_s / 1e9 / HBM_PEAK_GBS, 4),
                     'note': 'fp32 math: f32 vector peak == f32-input MFMA dense peak (157.3 TF/s)'}
@@ -303,7 +328,8 @@ def main():
                        'parallelism': f'batch-sharded x{world}' + (f', RCCL all_gather of {args.gather}'
                                                                    if comm is not None else '')},
             'roofline': roof,
-            'decoder': {'us_per_frame_eager': round(dec_us, 1), 'algorithmic_bytes': alg_bytes,
+            'decoder': {'us_per_frame_eager': round(dec_us, 1), 'event_pair_overhead_us': round(ev_overhead, 2),
+                        'algorithmic_bytes': alg_bytes,
                         'hbm_frac_of_8TBs': round(alg_bytes / (dec_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                         'launches': launches},
         }

@@ -6,6 +6,7 @@ Vocabulary: a *bank* is the patch-major per-patch filter b
 (hyperseg_v1_0.py:231-240) and the kernels generate on the fly.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -13,6 +14,9 @@ from . import _hip
 from ._hip import ACT_NONE, ACT_RELU, ACT_RELU6, PAD_MODES  # noqa: F401  (re-exported)
 
 BN_EPS_DEFAULT = 1e-5
+# Late-level banks on a second stream: saves ~14 us of decoder time in isolation, but a forked/joined capture makes
+# the whole-model HIP-graph replay 0.37 ms SLOWER on ROCm 7.2 (measured: 3.62 -> 3.99 ms/frame), so it is off by default.
+USE_SIDE_STREAM = os.environ.get('HS_SIDE_STREAM', '0') == '1'
 
 
 def _round_up(n, m):

@@ -444,7 +444,7 @@ class MultiScaleDecoder(nn.Module):
                       and all(all(not isinstance(q, HyperPatchInvertedResidual) for q in groups[e]) for e in range(l)))
         layers = [m.s2w_layer(s.device) for m in flat]
         side = join_level = None
-        if 0 < n_early < len(flat) and s.is_cuda:
+        if 0 < n_early < len(flat) and s.is_cuda and HF.USE_SIDE_STREAM:
             main = torch.cuda.current_stream()
             side = HF.SideStream.get(s.device)
             side.wait_stream(main)
