@@ -12,7 +12,7 @@ import torch
 _LIB_PATH = os.environ.get('HS_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib',
                                                          'libhyperseg_hip.so')   # HS_HIP_LIB: dev override
 
-ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SWISH = 0, 1, 2, 3
 PAD_MODES = {'zeros': 0, 'reflect': 1, 'replicate': 2, 'circular': 3}
 PREV_NONE, PREV_SAME, PREV_BILINEAR = 0, 1, 2
 
@@ -62,6 +62,7 @@ def _load():
                              C.POINTER(EpilogueC), C.POINTER(EpilogueC), i32, vp, vp], C.c_int),
         'hs_upsample_bilinear_fwd': ([vp, i32, i32, i32, i32, i32, i32, vp, vp], C.c_int),
         'hs_stage_input_fwd': ([C.POINTER(StageInputC), vp, vp], C.c_int),
+        'hs_depthwise_conv_fwd': ([vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp], C.c_int),
     }
     for name, (argtypes, restype) in sig.items():
         fn = getattr(lib, name)          # AttributeError here = the .so does not match the header
@@ -74,7 +75,7 @@ def _load():
 lib = _load()
 EXPORTS = ['hs_version', 'hs_build_info', 'hs_signal2weights_fwd', 'hs_signal2weights_multi_fwd', 'hs_bank_pack_fwd', 'hs_bn_fold_fwd',
            'hs_patch_conv_fwd', 'hs_patch_ir_fwd', 'hs_upsample_bilinear_fwd',
-           'hs_stage_input_fwd']
+           'hs_stage_input_fwd', 'hs_depthwise_conv_fwd']
 
 
 def check(status, what):

@@ -240,6 +240,22 @@ def patch_ir(x, grid, bank, hidden, c_out, bn1, bn2, bn3, residual=False):
     return y
 
 
+def depthwise_conv_bn_act(x, weight, stride, pad_top, pad_left, out_size, scale=None, shift=None, act=0):
+    """Depthwise conv (k 3|5, stride 1|2, TF-"SAME" zero padding given as top/left offsets) + affine + activation
+    (3 = swish) in one launch.  Encoder-side helper, opt-in (utils/inference.py)."""
+    b, c, h, w = x.shape
+    k = weight.shape[-1]
+    ho, wo = out_size
+    y = torch.empty(b, c, ho, wo, device=x.device, dtype=torch.float32)
+    st = _hip.lib.hs_depthwise_conv_fwd(_hip.dev_ptr(x, 'x'), b, c, h, w, _hip.dev_ptr(weight, 'weight'), k, stride,
+                                        pad_top, pad_left, ho, wo,
+                                        _hip.dev_ptr(scale, 'scale') if scale is not None else None,
+                                        _hip.dev_ptr(shift, 'shift') if shift is not None else None, int(act),
+                                        y.data_ptr(), _hip.stream_ptr())
+    _hip.check(st, 'hs_depthwise_conv_fwd')
+    return y
+
+
 def upsample_bilinear(x, size):
     """F.interpolate(x, size, mode='bilinear', align_corners=False)."""
     b, c, hi, wi = x.shape

@@ -95,12 +95,16 @@ class MBConvBlock(nn.Module):
         self._se_expand = SamePadConv2d(squeezed, mid, 1, image_size=1)
         self._project_conv = SamePadConv2d(mid, out_f, 1, image_size=_out_size(image_size, stride), bias=False)
         self._bn2 = bn(out_f)
+        self._fused_dw = None       # set by utils.inference.prepare_for_inference(fused_depthwise=True)
 
     def forward(self, inputs, drop_connect_rate=None):
         x = inputs
         if self.expand != 1:
             x = F.silu(self._bn0(self._expand_conv(x)))
-        x = F.silu(self._bn1(self._depthwise_conv(x)))
+        if self._fused_dw is not None and x.is_cuda and not self.training:
+            x = self._fused_dw(x)                       # depthwise + BN + swish: one HIP launch
+        else:
+            x = F.silu(self._bn1(self._depthwise_conv(x)))
         gate = self._se_expand(F.silu(self._se_reduce(F.adaptive_avg_pool2d(x, 1))))
         x = torch.sigmoid(gate) * x
         x = self._bn2(self._project_conv(x))

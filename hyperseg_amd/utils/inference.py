@@ -45,15 +45,55 @@ def _fold_sequential(seq):
     return n
 
 
-def prepare_for_inference(model, fold_bn=True, channels_last=False):
-    """In-place; returns the number of BatchNorms folded.  ``model`` is a HyperGen in eval mode."""
+class FusedDepthwiseBNSwish(nn.Module):
+    """depthwise conv + eval BatchNorm + swish of one MBConv block as ONE ``hs_depthwise_conv_fwd`` launch
+    (MIOpen has no tuned fp32 depthwise solver on ROCm 7.2: Winograd-per-group / naive kernels, ~half of the frame).
+    Holds the folded BN affine as non-persistent buffers; the filter stays the block's own ``_depthwise_conv.weight``."""
+
+    def __init__(self, conv, bn):
+        super().__init__()
+        with torch.no_grad():
+            scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+            shift = bn.bias - bn.running_mean * scale
+        self.register_buffer('scale', scale.detach().clone(), persistent=False)
+        self.register_buffer('shift', shift.detach().clone(), persistent=False)
+        self._conv = [conv]                      # not registered twice
+        self.k, self.stride = conv.kernel_size[0], conv.stride[0]
+        if conv._pad is not None:                # asymmetric TF-"SAME": (left, right, top, bottom)
+            self.pad_l, self.pad_t = conv._pad[0], conv._pad[2]
+            self.pad_w, self.pad_h = conv._pad[0] + conv._pad[1], conv._pad[2] + conv._pad[3]
+        else:
+            self.pad_t, self.pad_l = conv.padding
+            self.pad_h, self.pad_w = 2 * conv.padding[0], 2 * conv.padding[1]
+
+    def forward(self, x):
+        from .. import functional as HF
+        h, w = x.shape[-2:]
+        ho = (h + self.pad_h - self.k) // self.stride + 1
+        wo = (w + self.pad_w - self.k) // self.stride + 1
+        return HF.depthwise_conv_bn_act(x.contiguous(), self._conv[0].weight, self.stride, self.pad_t, self.pad_l,
+                                        (ho, wo), self.scale, self.shift, act=3)
+
+
+def prepare_for_inference(model, fold_bn=True, channels_last=False, fused_depthwise=False):
+    """In-place; returns the number of BatchNorms folded.  ``model`` is a HyperGen in eval mode.
+    ``fused_depthwise`` swaps each MBConv block's depthwise conv + BN + swish for the fused HIP kernel (do it BEFORE
+    ``fold_bn`` touches those BatchNorms: handled here)."""
     assert not model.training, 'call model.eval() first'
     folded = 0
+    if fused_depthwise:
+        for blk in model.backbone._blocks:
+            conv = blk._depthwise_conv
+            if conv.kernel_size[0] in (3, 5) and conv.stride[0] in (1, 2) and isinstance(blk._bn1, nn.BatchNorm2d):
+                blk._fused_dw = FusedDepthwiseBNSwish(conv, blk._bn1)
     if fold_bn:
         bb = model.backbone
         folded += _fold_pairs(bb, [('_conv_stem', '_bn0'), ('_conv_head', '_bn1')])
         for blk in bb._blocks:
-            folded += _fold_pairs(blk, [('_expand_conv', '_bn0'), ('_depthwise_conv', '_bn1'), ('_project_conv', '_bn2')])
+            pairs = [('_expand_conv', '_bn0'), ('_project_conv', '_bn2')]
+            if blk._fused_dw is None:
+                pairs.append(('_depthwise_conv', '_bn1'))
+            folded += _fold_pairs(blk, pairs)
         for m in list(bb.children()) + list(model.weight_mapper.modules()):
             if isinstance(m, nn.Sequential):
                 folded += _fold_sequential(m)

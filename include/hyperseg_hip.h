@@ -137,6 +137,16 @@ int hs_patch_ir_fwd(const hs_stage_input* in, int32_t fh, int32_t fw,
 int hs_upsample_bilinear_fwd(const float* x, int32_t batch, int32_t channels, int32_t Hi, int32_t Wi,
                              int32_t Ho, int32_t Wo, float* y, void* stream);
 
+/* Encoder-side helper ("next" row of SURVEY.md section 8f; opt-in via hyperseg_amd.utils.inference): depthwise k x k
+ * convolution (k in {3,5}, stride in {1,2}) with arbitrary top/left zero padding (TF-"SAME"), + per-channel affine
+ * (folded BatchNorm) + activation (hs_act, or 3 = swish) in one launch.  x (B,C,H,W), w (C,1,k,k) -> y (B,C,Ho,Wo).
+ * Replaces F.pad + F.conv2d(groups=C) + BatchNorm2d + swish of the reference's MBConvBlock
+ * (hyperseg/models/backbones/efficientnet.py:59-66, 101-103). */
+int hs_depthwise_conv_fwd(const float* x, int32_t batch, int32_t channels, int32_t H, int32_t W,
+                          const float* w, int32_t k, int32_t stride, int32_t pad_t, int32_t pad_l,
+                          int32_t Ho, int32_t Wo, const float* scale, const float* shift, int32_t act,
+                          float* y, void* stream);
+
 /* Materialises a stage input (B, 2*coords + c_skip + c_prev, H, W); test/diagnostic twin of the
  * fused prologue (the product path never calls it). */
 int hs_stage_input_fwd(const hs_stage_input* in, float* y, void* stream);

@@ -12,7 +12,7 @@ ref = None
 for variant in sys.argv[1:] or ['plain', 'fold', 'cl', 'foldcl', 'foldbench']:
     torch.backends.cudnn.benchmark = 'bench' in variant
     m = fill_by_name(configs.build('hyperseg-m').eval(), seed=0)
-    n = prepare_for_inference(m, fold_bn='fold' in variant, channels_last='cl' in variant)
+    n = prepare_for_inference(m, fold_bn='fold' in variant, channels_last='cl' in variant, fused_depthwise='dw' in variant)
     m = m.to(dev)
     x = x0.contiguous(memory_format=torch.channels_last) if 'cl' in variant else x0
     s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
