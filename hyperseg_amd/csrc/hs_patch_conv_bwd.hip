@@ -1,0 +1,164 @@
+// Backward of the dynamic patch-wise convolution (Op A / Op B), fp32.  The reference defines no backward (autograd
+// differentiates F.pad / unfold / grouped conv2d / fold: SURVEY.md Appendix E); these are the two adjoints stated there:
+//
+//   per-patch weight gradient (BASELINE config 5's "per-patch weight-grad kernel")
+//     dBank[p, ((o*cin_g + c)*k + ky)*k + kx] = sum_{(y,x) in patch p} dY[b,o,y,x] * Xpad[b, grp(o)*cin_g + c, y+ky-pad, x+kx-pad]
+//   input gradient
+//     dX[b,c,y,x] = sum over every PADDED coordinate (yp,xp) that the padding maps onto (y,x), every tap (ky,kx) and every
+//                   output channel o of c's group:  W_{patch(y',x')}[o,c,ky,kx] * dY[b,o,y',x'],  (y',x') = (yp-ky+pad, xp-kx+pad)
+//     -- the weights are those of the patch that owns the OUTPUT pixel, and reflect / replicate / circular padding
+//     folds the halo gradients back onto their source pixels (adjoint of F.pad).
+// Both kernels are straightforward (correctness first; forward is the tuned path): bwd_weight is one workgroup per patch
+// with the patch's dY and padded X tiles in LDS, bwd_input one thread per input element.
+#include "hs_common.h"
+
+namespace hs {
+
+struct ConvBwdArgs {
+    const float* __restrict__ x;       // (B, cin, H, W)
+    const float* __restrict__ dy;      // (B, cout, H, W)
+    const float* __restrict__ bank;    // (P, ld)
+    float* __restrict__ dx;            // (B, cin, H, W)
+    float* __restrict__ dbank;         // (P, ld)
+    long ld;
+    int B, H, W, fh, fw, ph, pw, cin, cout, k, pad, pad_mode, groups, cin_g, cout_g;
+};
+
+// number of padded coordinates (in [-pad, n+pad)) that map onto index i, and the q-th of them
+__device__ __forceinline__ int pad_aliases(int i, int n, int pad, int mode, int* out) {
+    int cnt = 0;
+    out[cnt++] = i;
+    if (pad == 0 || mode == HS_PAD_ZEROS) return cnt;
+    for (int p = -pad; p < 0; ++p)
+        if (pad_index(p, n, mode) == i) out[cnt++] = p;
+    for (int p = n; p < n + pad; ++p)
+        if (pad_index(p, n, mode) == i) out[cnt++] = p;
+    return cnt;
+}
+
+__global__ __launch_bounds__(256)
+void patch_conv_bwd_input_kernel(ConvBwdArgs a) {
+    const size_t total = (size_t)a.B * a.cin * a.H * a.W;
+    const int kk = a.k * a.k;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int x = e % a.W; size_t r = e / a.W;
+        const int y = r % a.H; r /= a.H;
+        const int c = r % a.cin; const int b = r / a.cin;
+        const int g = c / a.cin_g, cl = c - g * a.cin_g;
+        int ys[8], xs[8];
+        const int ny = pad_aliases(y, a.H, a.pad, a.pad_mode, ys);
+        const int nx = pad_aliases(x, a.W, a.pad, a.pad_mode, xs);
+        float acc = 0.0f;
+        for (int iy = 0; iy < ny; ++iy)
+            for (int ky = 0; ky < a.k; ++ky) {
+                const int yo = ys[iy] - ky + a.pad;
+                if (yo < 0 || yo >= a.H) continue;
+                for (int ix = 0; ix < nx; ++ix)
+                    for (int kx = 0; kx < a.k; ++kx) {
+                        const int xo = xs[ix] - kx + a.pad;
+                        if (xo < 0 || xo >= a.W) continue;
+                        const int p = (b * a.fh + yo / a.ph) * a.fw + xo / a.pw;
+                        const float* __restrict__ wp = a.bank + (size_t)p * a.ld + (size_t)cl * kk + ky * a.k + kx;
+                        const float* __restrict__ dyp = a.dy + (((size_t)b * a.cout + g * a.cout_g) * a.H + yo) * a.W + xo;
+                        for (int o = 0; o < a.cout_g; ++o)
+                            acc = fmaf(wp[(size_t)(g * a.cout_g + o) * a.cin_g * kk], dyp[(size_t)o * a.H * a.W], acc);
+                    }
+            }
+        a.dx[e] = acc;
+    }
+}
+
+// One workgroup per patch; LDS: dY tile [cout][ph*pw] and padded X tile [cin][(ph+2pad)*(pw+2pad)]; every thread owns
+// bank rows n = tid, tid+256, ... and reduces over the patch's pixels.
+__global__ __launch_bounds__(256)
+void patch_conv_bwd_weight_kernel(ConvBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int patch = blockIdx.x;
+    const int j = patch % a.fw, i = (patch / a.fw) % a.fh, b = patch / (a.fw * a.fh);
+    const int npix = a.ph * a.pw;
+    const int HH = a.ph + 2 * a.pad, HW = a.pw + 2 * a.pad, tpos = HH * HW;
+    float* dyl = lds;                         // [cout][npix]
+    float* xl = lds + (size_t)a.cout * npix;  // [cin][tpos]
+    const int y0 = i * a.ph, x0 = j * a.pw;
+    for (int e = threadIdx.x; e < a.cout * npix; e += blockDim.x) {
+        const int o = e / npix, pix = e - o * npix;
+        const int u = pix / a.pw, v = pix - u * a.pw;
+        dyl[e] = a.dy[(((size_t)b * a.cout + o) * a.H + y0 + u) * a.W + x0 + v];
+    }
+    for (int e = threadIdx.x; e < a.cin * tpos; e += blockDim.x) {
+        const int c = e / tpos, pos = e - c * tpos;
+        const int u = pos / HW, v = pos - u * HW;
+        const int yy = pad_index(y0 + u - a.pad, a.H, a.pad_mode), xx = pad_index(x0 + v - a.pad, a.W, a.pad_mode);
+        xl[e] = (yy >= 0 && xx >= 0) ? a.x[(((size_t)b * a.cin + c) * a.H + yy) * a.W + xx] : 0.0f;
+    }
+    __syncthreads();
+    const int kk = a.k * a.k;
+    const int rows = a.cout * a.cin_g * kk;
+    for (int n = threadIdx.x; n < rows; n += blockDim.x) {
+        const int kx = n % a.k; int r = n / a.k;
+        const int ky = r % a.k; r /= a.k;
+        const int cl = r % a.cin_g; const int o = r / a.cin_g;
+        const int c = (o / a.cout_g) * a.cin_g + cl;
+        const float* dr = dyl + (size_t)o * npix;
+        const float* xr = xl + (size_t)c * tpos + ky * HW + kx;
+        float acc = 0.0f;
+        for (int u = 0; u < a.ph; ++u)
+            for (int v = 0; v < a.pw; ++v) acc = fmaf(dr[u * a.pw + v], xr[u * HW + v], acc);
+        a.dbank[(size_t)patch * a.ld + n] = acc;
+    }
+}
+
+}  // namespace hs
+
+using namespace hs;
+
+static int fill_bwd(ConvBwdArgs& a, const float* x, const float* dy, const float* bank, int64_t ld, int32_t batch,
+                    int32_t c_in, int32_t H, int32_t W, int32_t fh, int32_t fw, int32_t c_out, int32_t k, int32_t pad,
+                    int32_t pad_mode, int32_t groups) {
+    if (!dy || batch <= 0 || c_in <= 0 || c_out <= 0 || H <= 0 || W <= 0 || fh <= 0 || fw <= 0 || k <= 0 || groups <= 0)
+        return HS_ERR_BAD_ARG;
+    if (2 * pad != k - 1) return HS_ERR_UNSUPPORTED;
+    if (pad > 3) return HS_ERR_UNSUPPORTED;
+    if (H % fh != 0 || W % fw != 0) return HS_ERR_NOT_DIVISIBLE;
+    if (c_in % groups != 0 || c_out % groups != 0) return HS_ERR_BAD_ARG;
+    if (pad_mode < HS_PAD_ZEROS || pad_mode > HS_PAD_CIRCULAR) return HS_ERR_BAD_ARG;
+    a.x = x; a.dy = dy; a.bank = bank; a.ld = (long)ld;
+    a.B = batch; a.H = H; a.W = W; a.fh = fh; a.fw = fw; a.ph = H / fh; a.pw = W / fw;
+    a.cin = c_in; a.cout = c_out; a.k = k; a.pad = pad; a.pad_mode = pad_mode; a.groups = groups;
+    a.cin_g = c_in / groups; a.cout_g = c_out / groups;
+    if (ld < (int64_t)c_out * a.cin_g * k * k) return HS_ERR_BAD_ARG;
+    return HS_OK;
+}
+
+extern "C" int hs_patch_conv_bwd_input(const float* dy, const float* bank, int64_t ld, int32_t batch, int32_t c_in,
+                                       int32_t H, int32_t W, int32_t fh, int32_t fw, int32_t c_out, int32_t k, int32_t pad,
+                                       int32_t pad_mode, int32_t groups, float* dx, void* stream) {
+    ConvBwdArgs a;
+    int st = fill_bwd(a, nullptr, dy, bank, ld, batch, c_in, H, W, fh, fw, c_out, k, pad, pad_mode, groups);
+    if (st != HS_OK) return st;
+    if (!bank || !dx) return HS_ERR_BAD_ARG;
+    a.dx = dx; a.dbank = nullptr;
+    const size_t total = (size_t)batch * c_in * H * W;
+    const unsigned blocks = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    hipLaunchKernelGGL(patch_conv_bwd_input_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return launch_status();
+}
+
+extern "C" int hs_patch_conv_bwd_weight(const float* x, const float* dy, int32_t batch, int32_t c_in, int32_t H, int32_t W,
+                                        int32_t fh, int32_t fw, int32_t c_out, int32_t k, int32_t pad, int32_t pad_mode,
+                                        int32_t groups, float* dbank, int64_t ld, void* stream) {
+    ConvBwdArgs a;
+    int st = fill_bwd(a, x, dy, nullptr, ld, batch, c_in, H, W, fh, fw, c_out, k, pad, pad_mode, groups);
+    if (st != HS_OK) return st;
+    if (!x || !dbank) return HS_ERR_BAD_ARG;
+    a.dx = nullptr; a.dbank = dbank;
+    const size_t lds = ((size_t)c_out * a.ph * a.pw + (size_t)c_in * (a.ph + 2 * pad) * (a.pw + 2 * pad)) * sizeof(float);
+    if (lds > 160 * 1024) return HS_ERR_LDS;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)patch_conv_bwd_weight_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(patch_conv_bwd_weight_kernel, dim3((unsigned)(batch * fh * fw)), dim3(256), lds, (hipStream_t)stream, a);
+    return launch_status();
+}

@@ -28,7 +28,8 @@ import torch.nn.functional as F
 from torch.nn.modules.utils import _pair
 
 from .. import functional as HF
-from .layers.meta_conv import MetaConv2d, _require_inference
+from .. import autograd as HA
+from .layers.meta_conv import MetaConv2d, _apply_epilogue, _require_inference
 from .layers.meta_sequential import MetaSequential
 
 
@@ -71,6 +72,20 @@ class _SignalToWeights:
         return HF.signal2weights(s, self._s2w_t.get(conv), self.signal_index, self.signal_channels,
                                  conv.groups, rows)
 
+    def _weights_train(self, s):
+        """Differentiable reference-layout weights (B, hp, fh, fw): the grouped 1x1 conv as a stock op (training)."""
+        hp = int(self.hyper_params)
+        if isinstance(s, HF.BankRef):
+            raise RuntimeError('a precomputed bank cannot carry gradients')
+        if self.signal2weights is None:
+            return s[:, :hp]
+        return self.signal2weights(s[:, self.signal_index:self.signal_index + self.signal_channels])[:, :hp]
+
+    def _train_mode(self, x, s):
+        probe = [x.skip, x.prev] if isinstance(x, HF.StageInput) else [x]
+        params = [self.signal2weights.weight] if self.signal2weights is not None else []
+        return not isinstance(s, HF.BankRef) and HA.needs_grad(s, *probe, *params)
+
     def apply_signal2weights(self, s):
         """(B, hp, fh, fw) weights in the reference's channel-major layout (diagnostics / API parity)."""
         if self.signal2weights is None:
@@ -109,6 +124,11 @@ class HyperPatchNoPadding(nn.Module, _SignalToWeights):
         if self.kernel_size != (1, 1) or self.stride != (1, 1) or self.dilation != (1, 1):
             raise NotImplementedError('HyperPatchNoPadding: only the k=1, stride 1 form the reference builds '
                                       '(padding == 0 <=> kernel_size == 1, hyperseg_v1_0.py:748-750)')
+        if self._train_mode(x, s):
+            xt = HA.materialize_stage(x) if isinstance(x, HF.StageInput) else x
+            y = HA.patch_conv_train(xt, self._weights_train(s), self.out_channels, 1, 0, 'zeros', self.groups,
+                                    self.hyper_params)
+            return _apply_epilogue(y, scale, shift, act)
         fh, fw = s.shape[-2:]
         bank = self._bank(s, self.hyper_params)
         return HF.patch_conv(x, (fh, fw), bank, self.out_channels, 1, 0, 'zeros', self.groups, scale, shift, act)
@@ -149,6 +169,11 @@ class HyperPatch(nn.Module, _SignalToWeights):
         k, inner_pad = conv._check_supported()
         if inner_pad != 0 or self.padding[0] != self.padding[1]:
             raise NotImplementedError('HyperPatch expects the wrapped conv to be unpadded')
+        if self._train_mode(x, s):
+            xt = HA.materialize_stage(x) if isinstance(x, HF.StageInput) else x
+            y = HA.patch_conv_train(xt, self._weights_train(s), conv.out_channels, k, self.padding[0],
+                                    self.padding_mode, conv.groups, conv.hyper_params)
+            return _apply_epilogue(y, scale, shift, act)
         fh, fw = s.shape[-2:]
         bank = self._bank(s, conv.hyper_params)
         return HF.patch_conv(x, (fh, fw), bank, conv.out_channels, k, self.padding[0], self.padding_mode,
@@ -224,8 +249,36 @@ class HyperPatchInvertedResidual(nn.Module, _SignalToWeights):
     def s2w_layer(self, device):
         return self._s2w_layer(self.hyper_params)
 
+    def _run_train(self, x, s, residual):
+        """Training / gradient path (hyperseg_v1_0.py:328-376 semantics incl. BN1 statistics over the duplicated halo
+        pixels, Appendix D-4): the halo tiles are laid side by side as one "tiled image", on which pw1 is a k=1 patch
+        conv, the depthwise 3x3 a zero-padded k=3 patch conv whose tile interiors are kept, pw3 a k=1 patch conv on the
+        re-assembled image -- three HIP convolutions with HIP backward kernels; BatchNorm / ReLU6 / gather are stock."""
+        xt = HA.materialize_stage(x) if isinstance(x, HF.StageInput) else x
+        w = self._weights_train(s)
+        b, c, h, wd = xt.shape
+        fh, fw = w.shape[-2:]
+        ph, pw = h // fh, wd // fw
+        r1, r2, r3 = self._ranges[1], self._ranges[2], self._ranges[3]
+        bank = HA.BankPack.apply(w, r3)
+        xp = F.pad(xt, (1, 1, 1, 1), mode='reflect')
+        tiles = xp.unfold(2, ph + 2, ph).unfold(3, pw + 2, pw)                     # B C fh fw ph+2 pw+2
+        tiled = tiles.permute(0, 1, 2, 4, 3, 5).reshape(b, c, fh * (ph + 2), fw * (pw + 2))
+        grid = (fh, fw)
+        y = HA.PatchConv.apply(tiled, bank[:, :r1], grid, self.hidden_dim, 1, 0, 'zeros', 1)
+        y = self.act_layer(self.bn1(y))
+        y = HA.PatchConv.apply(y, bank[:, r1:r2], grid, self.hidden_dim, 3, 1, 'zeros', self.hidden_dim)
+        y = y.reshape(b, self.hidden_dim, fh, ph + 2, fw, pw + 2)[:, :, :, 1:-1, :, 1:-1].reshape(b, self.hidden_dim, h, wd)
+        y = self.act_layer(self.bn2(y))
+        y = HA.PatchConv.apply(y, bank[:, r2:r3], grid, self.out_nc, 1, 0, 'zeros', 1)
+        y = self.bn3(y)
+        return xt + y if residual else y
+
     def _run(self, x, s, residual):
         self._check_supported()
+        bn_params = [self.bn1.weight, self.bn2.weight, self.bn3.weight]
+        if self._train_mode(x, s) or self.bn1.training or HA.needs_grad(*bn_params):
+            return self._run_train(x, s, residual)
         stage = HF.as_stage(x)
         if stage.channels != self.in_nc:
             raise ValueError(f'expected {self.in_nc} input channels, got {stage.channels}')
@@ -428,11 +481,23 @@ class MultiScaleDecoder(nn.Module):
             self._hyper_cache.append(collect(self.out_fc) if self.out_fc is not None else [])
         return self._hyper_cache
 
+    def _forward_autograd(self, x, s):
+        """Training / gradient path: same modules, per-module weight generation, everything through autograd."""
+        p = None
+        for level in range(self.levels):
+            p = getattr(self, f'level_{level}')(HF.StageInput(x[-level - 1], p, coords=True), s)
+        if self.out_fc is not None:
+            p = self.out_fc(p, s)
+        if p.shape[2:] != x[0].shape[2:]:
+            p = F.interpolate(p, x[0].shape[2:], mode='bilinear', align_corners=False)
+        return p
+
     def forward(self, x, s):
+        if self.training or HA.needs_grad(s, *x, *self.parameters()):
+            return self._forward_autograd(x, s)
         # every level's filter bank in ONE launch (the banks only depend on the signal)
         groups = self._hyper_modules()
         flat = [m for g in groups for m in g]
-        _require_inference(s, *[m.signal2weights.weight for m in flat])
         for m in flat:
             # the reference hands each module s[:, 0:hyper_params] (MetaSequential's clamped slice, Appendix D-2)
             if m.signal_index + m.signal_channels > min(int(m.hyper_params), s.shape[1]):

@@ -12,7 +12,9 @@ from functools import partial
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
+from .. import autograd as HA
 from .. import functional as HF
 from .hyperseg_v1_0 import (HyperPatch, HyperPatchConv2d, HyperPatchInvertedResidual, HyperPatchNoPadding,  # noqa: F401
                             WeightMapper, _SignalToWeights, divide_feature, make_hyper_patch_conv2d_block,
@@ -145,12 +147,31 @@ class MultiScaleDecoder(nn.Module):
         y = torch.linspace(-1, 1, steps=h)
         return torch.stack([x.view(1, w).expand(h, w), y.view(h, 1).expand(h, w)], dim=0).unsqueeze(0).contiguous()
 
+    def _forward_autograd(self, x, s):
+        """Training / gradient path: weight layers as stock grouped 1x1 convs, levels through hyperseg_amd.autograd."""
+        ul = self.unify_level
+        p, w = None, None
+        for level in range(self.levels):
+            stage = HF.StageInput(x[-level - 1], p, coords=True)
+            wb = self.weight_blocks[min(level, ul - 1)]
+            if level <= ul - 1:
+                w = wb._weights_train(s)
+            if level < ul - 1:
+                p = self.level_blocks[level](stage, w)
+            else:
+                i = level - ul + 1
+                p = self.level_blocks[level](stage, w[:, self._ranges[i]:self._ranges[i + 1]])
+        if p.shape[2:] != x[0].shape[2:]:
+            p = F.interpolate(p, x[0].shape[2:], mode='bilinear', align_corners=False)
+        return p
+
     def forward(self, x, s):
         if self.out_fc is not None:
             raise NotImplementedError('with_out_fc=True: the reference itself feeds the raw signal to out_fc here '
                                       '(hyperseg_v1_0_unify.py:252-253); no config uses it')
+        if self.training or HA.needs_grad(s, *x, *self.parameters()):
+            return self._forward_autograd(x, s)
         wl = list(self.weight_blocks)
-        _require_inference(s, *[m.signal2weights.weight for m in wl])
         refs = HF.signal2weights_multi(s, [m.s2w_layer(s.device) for m in wl])      # every weight layer, one launch
         ul = self.unify_level
         p = None

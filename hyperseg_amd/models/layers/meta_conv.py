@@ -15,8 +15,19 @@ from .meta_sequential import MetaSequential
 
 def _require_inference(*tensors):
     if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors):
-        raise NotImplementedError('hyperseg_amd: this build of the HIP decoder path is inference-only; '
-                                  'run under torch.no_grad() (backward kernels: SURVEY.md section 7 step 6)')
+        raise NotImplementedError('hyperseg_amd: this entry point is the fused inference path; gradients flow through '
+                                  'hyperseg_amd.autograd (module forward in training mode)')
+
+
+def _apply_epilogue(y, scale, shift, act):
+    """Epilogue with stock ops (training path: the autograd kernels have no fused epilogue)."""
+    if scale is not None:
+        y = y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    if act == HF.ACT_RELU:
+        y = torch.relu(y)
+    elif act == HF.ACT_RELU6:
+        y = torch.clamp(y, 0.0, 6.0)
+    return y
 
 
 class MetaConv2d(nn.Module):
@@ -49,11 +60,15 @@ class MetaConv2d(nn.Module):
         return kh, self.padding[0]
 
     def forward_fused(self, x, w, scale=None, shift=None, act=HF.ACT_NONE):
-        _require_inference(x if isinstance(x, torch.Tensor) else x.skip, w)
         k, pad = self._check_supported()
         assert x.shape[0] == w.shape[0]
         if w.dim() != 2 or w.shape[1] != self.hyper_params:
             raise ValueError(f'w must be (B, {self.hyper_params}), got {tuple(w.shape)}')
+        from ... import autograd as HA
+        if HA.needs_grad(x if isinstance(x, torch.Tensor) else x.skip, w):
+            xt = HA.materialize_stage(x) if isinstance(x, HF.StageInput) else x
+            y = HA.PatchConv.apply(xt, w, (1, 1), self.out_channels, k, pad, self.padding_mode, self.groups)
+            return _apply_epilogue(y, scale, shift, act)
         if w.stride(1) != 1 and w.shape[1] != 1:
             w = w.contiguous()
         return HF.patch_conv(x, (1, 1), w, self.out_channels, k, pad, self.padding_mode, self.groups,

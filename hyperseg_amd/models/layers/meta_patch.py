@@ -11,7 +11,7 @@ import torch.nn as nn
 from torch.nn.modules.utils import _pair
 
 from ... import functional as HF
-from .meta_conv import MetaConv2d, _require_inference
+from .meta_conv import MetaConv2d, _apply_epilogue
 from .meta_sequential import MetaSequential
 
 
@@ -37,7 +37,6 @@ class MetaPatch(nn.Module):
         conv = self.hyper_module
         if not isinstance(conv, MetaConv2d):
             raise NotImplementedError('hyperseg_amd.MetaPatch has a HIP kernel only for a wrapped MetaConv2d')
-        _require_inference(x if isinstance(x, torch.Tensor) else x.skip, weight)
         k, inner_pad = conv._check_supported()
         if inner_pad != 0 or self.padding[0] != self.padding[1]:
             raise NotImplementedError('MetaPatch expects the wrapped conv to be unpadded (meta_patch.py:190-193)')
@@ -47,6 +46,14 @@ class MetaPatch(nn.Module):
         h, w = x.shape[-2:]
         if h % fh != 0 or w % fw != 0:
             raise ValueError(f'input {h}x{w} does not tile into the {fh}x{fw} weight grid')
+        from ... import autograd as HA
+        probe = [x.skip, x.prev] if isinstance(x, HF.StageInput) else [x]
+        if HA.needs_grad(weight, *probe):
+            # training: HIP forward + HIP backward kernels through autograd, stock glue around them
+            xt = HA.materialize_stage(x) if isinstance(x, HF.StageInput) else x
+            y = HA.patch_conv_train(xt, weight, conv.out_channels, k, self.padding[0], self.padding_mode, conv.groups,
+                                    conv.hyper_params)
+            return _apply_epilogue(y, scale, shift, act)
         bank = HF.bank_pack(weight, 0, conv.hyper_params)
         return HF.patch_conv(x, (fh, fw), bank, conv.out_channels, k, self.padding[0], self.padding_mode,
                              conv.groups, scale, shift, act)

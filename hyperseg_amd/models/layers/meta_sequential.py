@@ -55,7 +55,9 @@ class MetaSequential(nn.Sequential):
                     j = i + 1
                     scale = shift = None
                     act = HF.ACT_NONE
-                    if j < n and isinstance(mods[j], nn.BatchNorm2d) and not mods[j].training:
+                    grad = torch.is_grad_enabled() and mods[j].weight is not None and mods[j].weight.requires_grad \
+                        if j < n and isinstance(mods[j], nn.BatchNorm2d) else False
+                    if j < n and isinstance(mods[j], nn.BatchNorm2d) and not mods[j].training and not grad:
                         scale, shift = self._fold(j, mods[j])
                         j += 1
                     if j < n and _act_code(mods[j]) is not None:

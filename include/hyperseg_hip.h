@@ -137,6 +137,19 @@ int hs_patch_ir_fwd(const hs_stage_input* in, int32_t fh, int32_t fw,
 int hs_upsample_bilinear_fwd(const float* x, int32_t batch, int32_t channels, int32_t Hi, int32_t Wi,
                              int32_t Ho, int32_t Wo, float* y, void* stream);
 
+/* Backward of hs_patch_conv_fwd (plain input x, no fused prologue / epilogue), fp32 -- SURVEY.md Appendix E.
+ * The reference has no backward of its own (autograd over F.pad/unfold/grouped conv2d/fold: meta_patch.py:35-57);
+ * these are the adjoints the training path (BASELINE config 5) needs:
+ *   hs_patch_conv_bwd_weight: dbank[p, n] = sum over the patch's pixels of dy * padded x  ("per-patch weight-grad kernel")
+ *   hs_patch_conv_bwd_input : dx = transposed patch-wise correlation of dy with each output pixel's own patch filters,
+ *                             halo gradients folded back through the padding (adjoint of F.pad). */
+int hs_patch_conv_bwd_input(const float* dy, const float* bank, int64_t ld, int32_t batch, int32_t c_in,
+                            int32_t H, int32_t W, int32_t fh, int32_t fw, int32_t c_out, int32_t k, int32_t pad,
+                            int32_t pad_mode, int32_t groups, float* dx, void* stream);
+int hs_patch_conv_bwd_weight(const float* x, const float* dy, int32_t batch, int32_t c_in, int32_t H, int32_t W,
+                             int32_t fh, int32_t fw, int32_t c_out, int32_t k, int32_t pad, int32_t pad_mode,
+                             int32_t groups, float* dbank, int64_t ld, void* stream);
+
 /* Encoder-side helper ("next" row of SURVEY.md section 8f; opt-in via hyperseg_amd.utils.inference): depthwise k x k
  * convolution (k in {3,5}, stride in {1,2}) with arbitrary top/left zero padding (TF-"SAME"), + per-channel affine
  * (folded BatchNorm) + activation (hs_act, or 3 = swish) in one launch.  x (B,C,H,W), w (C,1,k,k) -> y (B,C,Ho,Wo).

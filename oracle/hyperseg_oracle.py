@@ -474,9 +474,12 @@ def _bn(params, prefix):
 # a8: the three decoders.  ``params`` uses the reference's state-dict key names (Appendix C),
 # without the leading "decoder." prefix.
 # --------------------------------------------------------------------------------------
-def decoder_v1_0(plan, params, x, s, return_levels=False):
-    """MultiScaleDecoder.forward of hyperseg_v1_0.py:221-253.  x: list fine->coarse incl. image."""
-    p, outs = None, []
+def decoder_v1_0(plan, params, x, s, return_levels=False, training=False):
+    """MultiScaleDecoder.forward of hyperseg_v1_0.py:221-253.  x: list fine->coarse incl. image.
+    ``training=True``: BatchNorm with batch statistics (BN1 of the inverted residual over the duplicated halo pixels,
+    Appendix D-4); returns (logits, new_running_stats) -- everything is plain torch, so autograd of this function is
+    the oracle for the backward kernels (checked against the reference's own gradients in the train_* fixtures)."""
+    p, outs, stats = None, [], {}
     for l, lv in enumerate(plan['levels']):
         inp = stage_input(x[-l - 1], p)
         sw = plan['s2w'][l]
@@ -484,15 +487,26 @@ def decoder_v1_0(plan, params, x, s, return_levels=False):
             wt = signal2weights(s, params[f'level_{l}.0.0.signal2weights.weight'], sw['signal_index'],
                                 sw['signal_channels'], sw['groups'], lv['hp'])
             y = patch_conv_k1(inp, wt, lv['cout'])
-            p = act(bn_eval(y, _bn(params, f'level_{l}.0.1')), ACT_RELU)
+            if training:
+                y, m, v = bn_train(y, _bn(params, f'level_{l}.0.1'))
+                stats[f'level_{l}.0.1.running_mean'], stats[f'level_{l}.0.1.running_var'] = m, v
+            else:
+                y = bn_eval(y, _bn(params, f'level_{l}.0.1'))
+            p = act(y, ACT_RELU)
         else:
             wt = signal2weights(s, params[f'level_{l}.0.signal2weights.weight'], sw['signal_index'],
                                 sw['signal_channels'], sw['groups'], lv['hp'])
             p = patch_inverted_residual_v1(inp, wt, lv['hidden'], lv['cout'], _bn(params, f'level_{l}.0.bn1'),
-                                           _bn(params, f'level_{l}.0.bn2'), _bn(params, f'level_{l}.0.bn3'))
+                                           _bn(params, f'level_{l}.0.bn2'), _bn(params, f'level_{l}.0.bn3'),
+                                           training=training)
+            if training:
+                p, st = p
+                stats.update({f'level_{l}.0.{k}': v for k, v in st.items()})
         outs.append(p)
     if p.shape[-2:] != x[0].shape[-2:]:
         p = upsample_bilinear(p, x[0].shape[-2:])
+    if training:
+        return p, stats
     return (p, outs) if return_levels else p
 
 

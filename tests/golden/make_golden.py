@@ -329,6 +329,41 @@ def gen_decoders():
     save('decoder_full_configs', **arrs)
 
 
+# ------------------------------------------------------------------------------ training step (config 5 contract)
+def gen_train():
+    """Train-mode forward + backward of the tiny decoders in the REFERENCE: loss = sum(y * R); gradients w.r.t. every
+    pyramid input, the signal / weights, signal2weights.weight, BN gamma/beta; BN running stats after the step."""
+    for name, cfg in TINY.items():
+        O.CONFIGS[name] = cfg
+        plan = O.config_plan(name)
+        params = O.synth_decoder_params(plan, seed=9)
+        dec = ref_decoder(cfg)
+        load_params(dec, params)
+        dec.train()
+        x, sw = O.synth_decoder_inputs(name, batch=2, seed=9)
+        with torch.enable_grad():
+            x = [t.clone().requires_grad_(True) for t in x]
+            sw = [t.clone().requires_grad_(True) for t in sw] if isinstance(sw, list) else sw.clone().requires_grad_(True)
+            y = dec(x, sw)
+            r = torch.randn(y.shape, generator=torch.Generator().manual_seed(10))
+            (y * r).sum().backward()
+        arrs = {f'x{i}': t.detach() for i, t in enumerate(x)}
+        arrs.update({f'gx{i}': (t.grad if t.grad is not None else torch.zeros_like(t)) for i, t in enumerate(x)})
+        if isinstance(sw, list):
+            arrs.update({f'w{i}': t.detach() for i, t in enumerate(sw)})
+            arrs.update({f'gw{i}': t.grad for i, t in enumerate(sw)})
+        else:
+            arrs['s'] = sw.detach()
+            arrs['gs'] = sw.grad
+        arrs.update({'p.' + k: v for k, v in params.items()})
+        arrs.update({'g.' + k: v.grad for k, v in dec.named_parameters() if v.grad is not None})
+        arrs.update({'after.' + k: v for k, v in dec.state_dict().items() if 'running_' in k})
+        arrs['y'] = y.detach()
+        arrs['r'] = r
+        save('train_' + name, **arrs)
+        print(name, 'train y absmax', float(y.abs().max()), 'n grads', sum(1 for k in arrs if k.startswith('g.')))
+
+
 # ------------------------------------------------------------------------------ whole models (boundary)
 MODEL_KW = {
     'M': dict(mod='v1_0', name='efficientnet-b1', num_classes=19, kw=dict(
@@ -388,4 +423,5 @@ if __name__ == '__main__':
     gen_ir_v0()
     gen_divide_feature()
     gen_decoders()
+    gen_train()
     gen_models()

@@ -1,0 +1,108 @@
+"""Training path on the GPU (BASELINE config 5 contract): HIP forward + HIP backward kernels through
+hyperseg_amd.autograd, against (i) autograd of the CPU oracle for the raw patch convolution and (ii) the REFERENCE's
+own train-mode outputs, gradients and BatchNorm running statistics (fixtures train_t_*.npz, loss = sum(y * r))."""
+import pytest
+import torch
+
+from conftest import rel_err, sub
+from test_oracle_golden import TINY
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4      # sums over up to ~6e5 pixels; observed ~1e-6
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail('needs the MI355X')
+    return torch.device('cuda:0')
+
+
+@pytest.mark.parametrize('case', [
+    dict(cin=5, cout=7, k=1, groups=1, mode='zeros', b=2, grid=(3, 4), patch=(2, 4)),
+    dict(cin=6, cout=4, k=3, groups=1, mode='reflect', b=2, grid=(3, 4), patch=(4, 2)),
+    dict(cin=6, cout=6, k=3, groups=6, mode='reflect', b=1, grid=(2, 3), patch=(8, 8)),
+    dict(cin=4, cout=6, k=3, groups=2, mode='zeros', b=1, grid=(4, 2), patch=(2, 2)),
+    dict(cin=4, cout=4, k=3, groups=4, mode='replicate', b=2, grid=(2, 2), patch=(3, 5)),
+    dict(cin=3, cout=2, k=5, groups=1, mode='circular', b=1, grid=(1, 2), patch=(6, 4)),
+    dict(cin=8, cout=8, k=1, groups=4, mode='zeros', b=2, grid=(2, 2), patch=(16, 16)),
+])
+def test_patch_conv_gradients_vs_oracle(dev, case):
+    from oracle import hyperseg_oracle as O
+    from hyperseg_amd.models.layers.meta_patch import MetaPatchConv2d
+    c = case
+    g = torch.Generator().manual_seed(17)
+    h, w = c['grid'][0] * c['patch'][0], c['grid'][1] * c['patch'][1]
+    m = MetaPatchConv2d(c['cin'], c['cout'], c['k'], padding=c['k'] // 2, groups=c['groups'], padding_mode=c['mode'])
+    x = torch.randn(c['b'], c['cin'], h, w, generator=g)
+    wt = torch.randn(c['b'], m.hyper_params + 3, *c['grid'], generator=g)      # 3 unused trailing channels
+    r = torch.randn(c['b'], c['cout'], h, w, generator=g)
+    xo, wo = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    yo = O.meta_patch_conv2d(xo, wo[:, :m.hyper_params], c['cout'], c['k'], c['k'] // 2, c['mode'], c['groups'])
+    (yo * r).sum().backward()
+    xg, wg = x.to(dev).requires_grad_(True), wt.to(dev).requires_grad_(True)
+    yg = m(xg, wg)
+    (yg * r.to(dev)).sum().backward()
+    assert rel_err(yg.detach().cpu(), yo.detach()) < TOL
+    assert rel_err(xg.grad.cpu(), xo.grad) < TOL
+    assert rel_err(wg.grad.cpu(), wo.grad) < TOL
+    assert float(wg.grad[:, m.hyper_params:].abs().max()) == 0.0
+
+
+def make_decoder(c):
+    from test_hip_parity import make_decoder as mk
+    return mk(c)
+
+
+@pytest.mark.parametrize('name', ['t_v1_0', 't_unify', 't_v0_1'])
+def test_train_step_vs_reference(golden, dev, name):
+    g = golden('train_' + name)
+    c = TINY[name]
+    d = make_decoder(c)
+    missing, unexpected = d.load_state_dict(sub(g, 'p.'), strict=False)
+    assert not unexpected and all('num_batches' in k for k in missing)
+    d = d.to(dev).train()
+    x = [g[f'x{i}'].to(dev).requires_grad_(True) for i in range(6)]
+    if c['variant'] == 'v0_1':
+        w = [g[f'w{i}'].to(dev).requires_grad_(True) for i in range(6)]
+    else:
+        w = g['s'].to(dev).requires_grad_(True)
+    y = d(x, w)
+    assert rel_err(y.detach().cpu(), g['y']) < TOL
+    (y * g['r'].to(dev)).sum().backward()
+    first = 0 if c['variant'] == 'v0_1' else 1        # 5-level decoders never read the image itself
+    for i in range(first, 6):
+        assert rel_err(x[i].grad.cpu(), g[f'gx{i}']) < TOL, f'grad of pyramid input {i}'
+    if c['variant'] == 'v0_1':
+        for i in range(6):
+            assert rel_err(w[i].grad.cpu(), g[f'gw{i}']) < TOL, f'grad of level weights {i}'
+    else:
+        assert rel_err(w.grad.cpu(), g['gs']) < TOL, 'grad of the signal'
+    named = dict(d.named_parameters())
+    grads = sub(g, 'g.')
+    assert set(grads) == {k for k, v in named.items() if v.grad is not None}
+    for k, v in grads.items():
+        assert rel_err(named[k].grad.cpu(), v) < TOL, k
+    sd = d.state_dict()
+    for k, v in sub(g, 'after.').items():
+        assert rel_err(sd[k].cpu(), v) < TOL, k
+
+
+def test_optimizer_step_runs(dev):
+    """forward + loss + backward + Adam step of the CamVid-S-shaped decoder at a small crop (config 5 plumbing)."""
+    from oracle import hyperseg_oracle as O
+    from test_hip_parity import build_decoder
+    d = build_decoder('Sc', O).to(dev).train()
+    x, s = O.synth_decoder_inputs('Sc', batch=2, seed=3, size=(96, 96))
+    x = [t.to(dev) for t in x]
+    s = s.to(dev).requires_grad_(True)
+    opt = torch.optim.Adam(d.parameters(), lr=1e-3, betas=(0.5, 0.999))
+    target = torch.randint(0, 12, (2, 96, 96), device=dev)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = torch.nn.functional.cross_entropy(d(x, s), target)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0]

@@ -179,3 +179,26 @@ def test_cpu_port_matches_oracle():
         params = O.synth_decoder_params(plan, seed=3)
         x, s = O.synth_decoder_inputs(name, batch=2, seed=3, size=size)
         assert rel_err(P.decoder_v1_0(plan, params, x, s), O.decoder_v1_0(plan, params, x, s)) < TOL
+
+
+def test_train_step_oracle_vs_reference(golden):
+    """Train-mode forward + autograd of the oracle == the reference's own train-mode forward, gradients and updated
+    BatchNorm running statistics (fixture train_t_v1_0: loss = sum(y * r))."""
+    g = golden('train_t_v1_0')
+    c = TINY['t_v1_0']
+    plan = O.decoder_plan(c['variant'], c['feat'], c['signal'], c['num_classes'], c['kernel_sizes'],
+                          c['level_channels'], c['expand_ratio'], c['weight_groups'])
+    params = {k: v.clone().requires_grad_(v.dtype.is_floating_point and 'running' not in k) for k, v in sub(g, 'p.').items()}
+    x = [g[f'x{i}'].clone().requires_grad_(True) for i in range(6)]
+    s = g['s'].clone().requires_grad_(True)
+    y, stats = O.decoder_v1_0(plan, params, x, s, training=True)
+    assert rel_err(y.detach(), g['y']) < 1e-5
+    (y * g['r']).sum().backward()
+    for i in range(1, 6):                       # x[0] (the image) only sets the output size in a 5-level decoder
+        assert rel_err(x[i].grad, g[f'gx{i}']) < 1e-4, i
+    assert x[0].grad is None and float(g['gx0'].abs().max()) == 0.0
+    assert rel_err(s.grad, g['gs']) < 1e-4
+    for k, v in sub(g, 'g.').items():
+        assert rel_err(params[k].grad, v) < 1e-4, k
+    for k, v in sub(g, 'after.').items():
+        assert rel_err(stats[k], v) < 1e-5, k
