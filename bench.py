@@ -117,6 +117,8 @@ def main():
     ap.add_argument('--gather', default='logits', choices=['logits', 'masks', 'none'],
                     help='what the N>1 all-gather moves (north star: logits)')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of HIP graph replay')
+    ap.add_argument('--stock-encoder', action='store_true',
+                    help='leave the encoder entirely on stock PyTorch-ROCm/MIOpen (no fused depthwise HIP kernel)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
     args = ap.parse_args()
@@ -141,11 +143,16 @@ def main():
 
     spec = configs.MODELS[MODEL]
     h, w = spec['size']
+    from hyperseg_amd.utils.inference import prepare_for_inference
     model = fill_by_name(configs.build(MODEL).eval(), seed=0)       # synthetic, non-denormal, same on every rank
     cpu_model = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import copy
         cpu_model = copy.deepcopy(model)
+    # inference preparation of the encoder: depthwise conv + BN + swish of every MBConv block as one
+    # HIP launch (MIOpen's fp32 depthwise path costs half of the frame); everything else of the encoder is stock PyTorch
+    if not args.stock_encoder:
+        prepare_for_inference(model, fold_bn=False, fused_depthwise=True)
     model = model.to(dev)
     torch.manual_seed(1234 + rank)
     x = torch.rand(spec['batch'], 3, h, w, device=dev)              # resident synthetic frame
@@ -323,7 +330,9 @@ def main():
             'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'HyperSeg-M / EfficientNet-B1 / 1024x512 bs=1 per GPU, whole model forward '
-                                   '(stock PyTorch-ROCm encoder + context head, HIP decoder), resident input',
+                                   '(PyTorch-ROCm encoder + context head, HIP decoder), resident input',
+                       'encoder': 'stock PyTorch-ROCm / MIOpen' if args.stock_encoder else
+                                  'stock PyTorch-ROCm except depthwise conv+BN+swish = hs_depthwise_conv_fwd (23 launches)',
                        'launch': 'eager' if args.no_graph else 'hipGraph replay',
                        'parallelism': f'batch-sharded x{world}' + (f', RCCL all_gather of {args.gather}'
                                                                    if comm is not None else '')},

@@ -19,6 +19,7 @@
 //   epilogue  BN3, 64-byte row runs to HBM.
 // LDS: max(T tile, h1 + h2) = 48 KB at HyperSeg-M level 4 -> 3 workgroups / CU; hidden activations never leave the CU.
 #include "hs_common.h"
+#include <cstdlib>
 
 #ifndef HS_IRM_ABLATE
 #define HS_IRM_ABLATE 0     // dev-only timing ablations (tools/ablate_ir.py): 1 no prologue loads, 2 no pw1 MFMA,
@@ -28,8 +29,8 @@
 #define HS_IRM_TIMING 0     // dev-only: per-phase s_memtime stamps of wave 0 of every workgroup (tools/ablate_ir.py)
 #endif
 #if HS_IRM_TIMING
-__device__ long long hs_irm_stamps[4096 * 24];
-#define HS_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) hs_irm_stamps[blockIdx.x * 24 + (k)] = __builtin_readcyclecounter(); } while (0)
+__device__ long long hs_irm_stamps[4096 * 32];
+#define HS_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) hs_irm_stamps[blockIdx.x * 32 + (k)] = __builtin_readcyclecounter(); } while (0)
 extern "C" int hs_debug_read_stamps(long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hs_irm_stamps), sizeof(long long) * n);
 }
@@ -163,6 +164,30 @@ void patch_ir_mfma_kernel(IrMfmaArgs a) {
         }
     }
 
+    // folded BatchNorm rows (4*hid + 2*COUT floats), also part of the single up-front load batch
+    float bnreg[2];
+    {
+        const int nb = 4 * hid + 2 * COUT;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = min(tid + q * IRM_THREADS, nb - 1);
+            const float* __restrict__ srcp;
+            int off;
+            if (e < hid) { srcp = a.s1; off = e; }
+            else if (e < 2 * hid) { srcp = a.b1; off = e - hid; }
+            else if (e < 3 * hid) { srcp = a.s2; off = e - 2 * hid; }
+            else if (e < 4 * hid) { srcp = a.b2; off = e - 3 * hid; }
+            else if (e < 4 * hid + COUT) { srcp = a.s3; off = e - 4 * hid; }
+            else { srcp = a.b3; off = e - 4 * hid - COUT; }
+            bnreg[q] = srcp[off];
+        }
+    }
+    HS_STAMP(24);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int e = tid + q * IRM_THREADS;
+        if (e < 4 * hid + 2 * COUT) bnl[e] = bnreg[q];
+    }
 #pragma unroll
     for (int q = 0; q < PQ; ++q) {
         const int e = tid + q * IRM_THREADS;
@@ -179,7 +204,9 @@ void patch_ir_mfma_kernel(IrMfmaArgs a) {
     } else {
         for (int e = tid; e < nw; e += IRM_THREADS) wl[e] = wp[e];
     }
+    HS_STAMP(25);
     __syncthreads();
+    HS_STAMP(26);
     // ---- prologue: stage-input columns -> LDS --------------------------------------------------
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
@@ -209,10 +236,7 @@ void patch_ir_mfma_kernel(IrMfmaArgs a) {
             for (int c = 0; c < KS1 * 4; ++c) T[c * G::NP1 + pos] = live ? col[c] : 0.0f;
         }
     }
-    for (int e = tid; e < hid; e += IRM_THREADS) {
-        bnl[e] = a.s1[e]; bnl[hid + e] = a.b1[e]; bnl[2 * hid + e] = a.s2[e]; bnl[3 * hid + e] = a.b2[e];
-    }
-    if (tid < COUT) { bnl[4 * hid + tid] = a.s3[tid]; bnl[4 * hid + COUT + tid] = a.b3[tid]; }
+    HS_STAMP(27);
     __syncthreads();
 
     HS_STAMP(2);
@@ -422,6 +446,10 @@ int try_launch_ir_mfma(const StageIn& in, int fh, int fw, const float* bank, lon
     int tile = 0;
     if (a.ph % 16 == 0 && a.pw % 16 == 0) tile = 16;
     else if (a.ph % 8 == 0 && a.pw % 8 == 0) tile = 8;
+    {   // dev knob (read once): HS_IRM_TILE=8 forces 8x8 tiles on 16x16 patches
+        static const int forced = [] { const char* e = getenv("HS_IRM_TILE"); return e ? atoi(e) : 0; }();
+        if (forced == 8 && tile == 16) tile = 8;
+    }
     if (!tile) return 1;
     if (in.Hp * 2 != in.H || in.Wp * 2 != in.W) return 1;      // the LDS window assumes the exact 2x pyramid
     a.tiles_y = a.ph / tile; a.tiles_x = a.pw / tile;

@@ -340,5 +340,6 @@ def test_errors_are_loud(HF, dev):
             m(torch.randn(1, 4, 9, 8, device=dev), torch.randn(1, 16, 2, 2, device=dev))   # 9 % 2 != 0
         with pytest.raises(ValueError):
             m(torch.randn(1, 4, 8, 8, device=dev), torch.randn(1, 15, 2, 2, device=dev))   # too few weights
-    with pytest.raises(NotImplementedError):
-        m(torch.randn(1, 4, 8, 8, device=dev, requires_grad=True), torch.randn(1, 16, 2, 2, device=dev))
+    # gradients are supported through hyperseg_amd.autograd (tests/test_hip_training.py)
+    y = m(torch.randn(1, 4, 8, 8, device=dev, requires_grad=True), torch.randn(1, 16, 2, 2, device=dev))
+    assert y.requires_grad and y.grad_fn is not None

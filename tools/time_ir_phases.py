@@ -28,11 +28,11 @@ else:
     for _ in range(5):
         d(x, s)
     torch.cuda.synchronize()
-    n = 512 * 24
+    n = 512 * 32
     buf = (ctypes.c_longlong * n)()
     hip.lib.hs_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
     assert hip.lib.hs_debug_read_stamps(buf, n) == 0
-    st = np.array(buf, dtype=np.int64).reshape(512, 24)      # the LAST IR launch (level 4) overwrote level 3's stamps
+    st = np.array(buf, dtype=np.int64).reshape(512, 32)      # the LAST IR launch (level 4) overwrote level 3's stamps
     names = ['start->loads issued', 'prologue gathers+T', 'bank->LDS+barrier', 'Bfrag+barrier']
     d0 = st[:, 1:4] - st[:, 0:3]
     print('blocks: first start %d, last end %d cycles span (100 MHz ticks?)' % (0, int(st[:, 23].max() - st[:, 0].min())))
@@ -40,8 +40,11 @@ else:
     for i, nm in enumerate(['bank loads issued', 'prologue gathers -> T in LDS', 'bank -> LDS + barrier', 'B frags + barrier']):
         if i == 0:
             print('%-32s %8.0f' % (nm, np.median(st[:, 1] - st[:, 0])))
-    print('%-32s %8.0f' % ('prologue (stamp0->1) [incl. gathers]', np.median(st[:, 1] - st[:, 0])))
-    print('%-32s %8.0f' % ('bank->LDS + barrier (1->2)', np.median(st[:, 2] - st[:, 1])))
+    print('%-32s %8.0f' % ('all loads issued (0->24)', np.median(st[:, 24] - st[:, 0])))
+    print('%-32s %8.0f' % ('wait + LDS stores (24->25)', np.median(st[:, 25] - st[:, 24])))
+    print('%-32s %8.0f' % ('barrier (25->26)', np.median(st[:, 26] - st[:, 25])))
+    print('%-32s %8.0f' % ('position passes (26->27)', np.median(st[:, 27] - st[:, 26])))
+    print('%-32s %8.0f' % ('barrier (27->2)', np.median(st[:, 2] - st[:, 27])))
     print('%-32s %8.0f' % ('B frags + barrier (2->3)', np.median(st[:, 3] - st[:, 2])))
     for ch in range(5):
         b = 4 + 4 * ch
