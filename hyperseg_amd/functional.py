@@ -240,20 +240,47 @@ def patch_ir(x, grid, bank, hidden, c_out, bn1, bn2, bn3, residual=False):
     return y
 
 
-def depthwise_conv_bn_act(x, weight, stride, pad_top, pad_left, out_size, scale=None, shift=None, act=0):
+def depthwise_conv_bn_act(x, weight, stride, pad_top, pad_left, out_size, scale=None, shift=None, act=0, pool=False):
     """Depthwise conv (k 3|5, stride 1|2, TF-"SAME" zero padding given as top/left offsets) + affine + activation
-    (3 = swish) in one launch.  Encoder-side helper, opt-in (utils/inference.py)."""
+    (3 = swish) in one launch.  ``pool=True`` also returns the per-workgroup partial sums of the outputs (B*C, nblk)
+    for :func:`se_gate`.  Encoder-side helper, opt-in (utils/inference.py)."""
     b, c, h, w = x.shape
     k = weight.shape[-1]
     ho, wo = out_size
     y = torch.empty(b, c, ho, wo, device=x.device, dtype=torch.float32)
+    partial = None
+    if pool:
+        partial = torch.empty(b * c, _hip.lib.hs_depthwise_pool_blocks(ho, wo), device=x.device, dtype=torch.float32)
     st = _hip.lib.hs_depthwise_conv_fwd(_hip.dev_ptr(x, 'x'), b, c, h, w, _hip.dev_ptr(weight, 'weight'), k, stride,
                                         pad_top, pad_left, ho, wo,
                                         _hip.dev_ptr(scale, 'scale') if scale is not None else None,
                                         _hip.dev_ptr(shift, 'shift') if shift is not None else None, int(act),
-                                        y.data_ptr(), _hip.stream_ptr())
+                                        y.data_ptr(), partial.data_ptr() if pool else None, _hip.stream_ptr())
     _hip.check(st, 'hs_depthwise_conv_fwd')
-    return y
+    return (y, partial) if pool else y
+
+
+def se_gate(partial, batch, hw, w_reduce, b_reduce, w_expand, b_expand, w_proj=None):
+    """Squeeze-excite gate from pooled partial sums; with ``w_proj`` (Cout, C[,1,1]) returns the project weights
+    scaled by the gate, (B, Cout, C, 1, 1); otherwise the gate (B, C)."""
+    c = partial.shape[0] // batch
+    csq = w_reduce.shape[0]
+    dev = partial.device
+    gate = w_scaled = None
+    cout = 0
+    if w_proj is not None:
+        cout = w_proj.shape[0]
+        w_scaled = torch.empty(batch, cout, c, 1, 1, device=dev, dtype=torch.float32)
+    else:
+        gate = torch.empty(batch, c, device=dev, dtype=torch.float32)
+    st = _hip.lib.hs_se_gate_fwd(_hip.dev_ptr(partial, 'partial'), batch, c, partial.shape[1], 1.0 / float(hw),
+                                 _hip.dev_ptr(w_reduce, 'w_reduce'), _hip.dev_ptr(b_reduce, 'b_reduce'), csq,
+                                 _hip.dev_ptr(w_expand, 'w_expand'), _hip.dev_ptr(b_expand, 'b_expand'),
+                                 gate.data_ptr() if gate is not None else None,
+                                 _hip.dev_ptr(w_proj, 'w_proj') if w_proj is not None else None, cout,
+                                 w_scaled.data_ptr() if w_scaled is not None else None, _hip.stream_ptr())
+    _hip.check(st, 'hs_se_gate_fwd')
+    return w_scaled if w_proj is not None else gate
 
 
 def upsample_bilinear(x, size):

@@ -102,12 +102,13 @@ class MBConvBlock(nn.Module):
         if self.expand != 1:
             x = F.silu(self._bn0(self._expand_conv(x)))
         if self._fused_dw is not None and x.is_cuda and not self.training:
-            x = self._fused_dw(x)                       # depthwise + BN + swish: one HIP launch
+            # depthwise + BN + swish (+ SE pooling) in one HIP launch, SE gate folded into the project weights
+            x = self._fused_dw(x, self)
         else:
             x = F.silu(self._bn1(self._depthwise_conv(x)))
-        gate = self._se_expand(F.silu(self._se_reduce(F.adaptive_avg_pool2d(x, 1))))
-        x = torch.sigmoid(gate) * x
-        x = self._bn2(self._project_conv(x))
+            gate = self._se_expand(F.silu(self._se_reduce(F.adaptive_avg_pool2d(x, 1))))
+            x = self._project_conv(torch.sigmoid(gate) * x)
+        x = self._bn2(x)
         if self.stride == 1 and self.in_f == self.out_f:
             if drop_connect_rate and self.training:      # stochastic depth
                 keep = 1.0 - drop_connect_rate

@@ -66,13 +66,23 @@ class FusedDepthwiseBNSwish(nn.Module):
             self.pad_t, self.pad_l = conv.padding
             self.pad_h, self.pad_w = 2 * conv.padding[0], 2 * conv.padding[1]
 
-    def forward(self, x):
+    def forward(self, x, blk):
+        """x -> project_conv(SE(swish(bn1(depthwise(x))))) of MBConv block ``blk`` (before its bn2)."""
+        import torch.nn.functional as F
         from .. import functional as HF
+        b = x.shape[0]
         h, w = x.shape[-2:]
         ho = (h + self.pad_h - self.k) // self.stride + 1
         wo = (w + self.pad_w - self.k) // self.stride + 1
-        return HF.depthwise_conv_bn_act(x.contiguous(), self._conv[0].weight, self.stride, self.pad_t, self.pad_l,
-                                        (ho, wo), self.scale, self.shift, act=3)
+        y, partial = HF.depthwise_conv_bn_act(x.contiguous(), self._conv[0].weight, self.stride, self.pad_t, self.pad_l,
+                                              (ho, wo), self.scale, self.shift, act=3, pool=True)
+        red, exp, proj = blk._se_reduce, blk._se_expand, blk._project_conv
+        if b == 1:
+            # gate folded into the 1x1 project weights: no elementwise pass over the activation
+            wp = HF.se_gate(partial, 1, ho * wo, red.weight, red.bias, exp.weight, exp.bias, w_proj=proj.weight)
+            return F.conv2d(y, wp[0])
+        gate = HF.se_gate(partial, b, ho * wo, red.weight, red.bias, exp.weight, exp.bias)
+        return proj(y * gate[:, :, None, None])
 
 
 def prepare_for_inference(model, fold_bn=True, channels_last=False, fused_depthwise=False):

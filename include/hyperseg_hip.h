@@ -158,7 +158,15 @@ int hs_patch_conv_bwd_weight(const float* x, const float* dy, int32_t batch, int
 int hs_depthwise_conv_fwd(const float* x, int32_t batch, int32_t channels, int32_t H, int32_t W,
                           const float* w, int32_t k, int32_t stride, int32_t pad_t, int32_t pad_l,
                           int32_t Ho, int32_t Wo, const float* scale, const float* shift, int32_t act,
-                          float* y, void* stream);
+                          float* y, float* pool_partial, void* stream);
+/* pool_partial (optional): (B*C, hs_depthwise_pool_blocks(Ho, Wo)) per-workgroup sums of the outputs, the squeeze-excite
+ * pooling for free.  hs_se_gate_fwd turns them into the SE gate (pool -> 1x1 reduce + swish -> 1x1 expand -> sigmoid;
+ * efficientnet.py:106-111) and, if w_proj is given, folds the gate into the block's project convolution weights:
+ * w_scaled[b, o, c] = w_proj[o, c] * gate[b, c]. */
+int hs_depthwise_pool_blocks(int32_t Ho, int32_t Wo);
+int hs_se_gate_fwd(const float* partial, int32_t batch, int32_t channels, int32_t nblk, float inv_hw,
+                   const float* w_reduce, const float* b_reduce, int32_t c_squeezed, const float* w_expand,
+                   const float* b_expand, float* gate, const float* w_proj, int32_t c_out, float* w_scaled, void* stream);
 
 /* Materialises a stage input (B, 2*coords + c_skip + c_prev, H, W); test/diagnostic twin of the
  * fused prologue (the product path never calls it). */
