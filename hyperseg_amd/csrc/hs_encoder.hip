@@ -88,40 +88,104 @@ void depthwise_conv_kernel(const float* __restrict__ x, const float* __restrict_
 // convolution, w_scaled[b, o, c] = w_proj[o, c] * gate[b, c]: scaling ~1e5 weights replaces a full elementwise pass over
 // the (up to 100 MB) activation.  Replaces adaptive_avg_pool2d + 2 convs + swish + sigmoid + mul
 // (hyperseg/models/backbones/efficientnet.py:106-111).
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(1024)
 void se_gate_kernel(const float* __restrict__ partial, int nblk, float inv_hw, const float* __restrict__ w1,
                     const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2, int C, int Csq,
-                    float* __restrict__ gate, const float* __restrict__ w_proj, int Cout, float* __restrict__ w_scaled) {
+                    float* __restrict__ gate) {
     extern __shared__ float sm[];            // pooled[C] | z[Csq] | gate[C]
     float* pooled = sm; float* z = sm + C; float* g = z + Csq;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    for (int c = tid; c < C; c += blockDim.x) {
-        const float* __restrict__ p = partial + ((size_t)b * C + c) * nblk;
-        float t = 0.0f;
-        for (int i = 0; i < nblk; ++i) t += p[i];
-        pooled[c] = t * inv_hw;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
+    // 1. pooled[c] = mean: one wave per channel, 4 channels' loads in flight per step (few waves, so ILP hides latency)
+    if (nblk <= 16) {
+        // few partials per plane (late, small feature maps with many channels): one thread per channel, all of its
+        // partials loaded at once -- a wave-per-channel walk would pay one memory round trip per 4 channels
+        for (int c = tid; c < C; c += blockDim.x) {
+            const float* __restrict__ p = partial + ((size_t)b * C + c) * nblk;
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = p[i < nblk ? i : nblk - 1];
+            float t = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (i < nblk) t += v[i];
+            pooled[c] = t * inv_hw;
+        }
+    } else {
+        for (int c0 = wave * 4; c0 < C; c0 += nwave * 4) {
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = c0 + q < C ? c0 + q : C - 1;
+                const float* __restrict__ p = partial + ((size_t)b * C + c) * nblk;
+                float t = 0.0f;
+                for (int i = lane; i < nblk; i += 64) t += p[i];
+                v[q] = t;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float t = v[q];
+                for (int m = 32; m > 0; m >>= 1) t += __shfl_xor(t, m, 64);
+                if (lane == 0 && c0 + q < C) pooled[c0 + q] = t * inv_hw;
+            }
+        }
     }
     __syncthreads();
-    for (int j = tid >> 6; j < Csq; j += (int)(blockDim.x >> 6)) {       // one wave per squeezed channel
-        const float* __restrict__ wr = w1 + (size_t)j * C;
-        float t = 0.0f;
-        for (int c = tid & 63; c < C; c += 64) t = fmaf(wr[c], pooled[c], t);
-        for (int m = 32; m > 0; m >>= 1) t += __shfl_xor(t, m, 64);
-        if ((tid & 63) == 0) { t += b1[j]; z[j] = t / (1.0f + expf(-t)); }
+    // 2. z = swish(W1 pooled + b1): one wave per squeezed channel, two channels in flight per step
+    for (int j0 = wave * 2; j0 < Csq; j0 += nwave * 2) {
+        float t[2] = {0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int j = j0 + q < Csq ? j0 + q : Csq - 1;
+            const float* __restrict__ wr = w1 + (size_t)j * C;
+            for (int c0 = lane; c0 < C; c0 += 64 * 8) {             // 8 independent loads in flight per lane
+                float wv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) wv[u] = wr[min(c0 + 64 * u, C - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (c0 + 64 * u < C) t[q] = fmaf(wv[u], pooled[c0 + 64 * u], t[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float u = t[q];
+            for (int m = 32; m > 0; m >>= 1) u += __shfl_xor(u, m, 64);
+            if (lane == 0 && j0 + q < Csq) { u += b1[j0 + q]; z[j0 + q] = u / (1.0f + expf(-u)); }
+        }
     }
     __syncthreads();
+    // 3. gate = sigmoid(W2 z + b2)
     for (int c = tid; c < C; c += blockDim.x) {
-        const float* __restrict__ wr = w2 + (size_t)c * Csq;
-        float t = b2[c];
-        for (int j = 0; j < Csq; ++j) t = fmaf(wr[j], z[j], t);
+        float t = b2[c];                       // w2 is the expand weight TRANSPOSED to (Csq, C): coalesced over c
+        for (int j0 = 0; j0 < Csq; j0 += 8) {  // 8 independent loads in flight per thread
+            float wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wv[u] = w2[(size_t)min(j0 + u, Csq - 1) * C + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (j0 + u < Csq) t = fmaf(wv[u], z[j0 + u], t);
+        }
         const float gv = 1.0f / (1.0f + expf(-t));
         g[c] = gv;
-        if (gate) gate[(size_t)b * C + c] = gv;
+        gate[(size_t)b * C + c] = gv;
     }
-    if (!w_proj) return;
-    __syncthreads();
-    const size_t n = (size_t)Cout * C;
-    for (size_t e = tid; e < n; e += blockDim.x) w_scaled[(size_t)b * n + e] = w_proj[e] * g[e % C];
+}
+
+// w_scaled[b, o, c] = w_proj[o, c] * gate[b, c]  (the SE gate folded into the 1x1 project convolution)
+__global__ __launch_bounds__(256)
+void scale_weights_kernel(const float* __restrict__ w_proj, const float* __restrict__ gate, int C, size_t n,
+                          float* __restrict__ w_scaled) {
+    const int b = blockIdx.y;
+    const size_t e0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (e0 >= n) return;
+    const float* __restrict__ g = gate + (size_t)b * C;
+    if (e0 + 3 < n && (C & 3) == 0) {       // rows are multiples of 4 long: a float4 never straddles two rows
+        const float4 w = *reinterpret_cast<const float4*>(w_proj + e0);
+        const float4 gv = *reinterpret_cast<const float4*>(g + (e0 % C));
+        *reinterpret_cast<float4*>(w_scaled + (size_t)b * n + e0) = make_float4(w.x * gv.x, w.y * gv.y, w.z * gv.z, w.w * gv.w);
+    } else {
+        for (size_t e = e0; e < n && e < e0 + 4; ++e) w_scaled[(size_t)b * n + e] = w_proj[e] * g[e % C];
+    }
 }
 
 }  // namespace hs
@@ -160,12 +224,17 @@ extern "C" int hs_se_gate_fwd(const float* partial, int32_t batch, int32_t chann
                               const float* w_reduce, const float* b_reduce, int32_t c_squeezed, const float* w_expand,
                               const float* b_expand, float* gate, const float* w_proj, int32_t c_out, float* w_scaled,
                               void* stream) {
-    if (!partial || !w_reduce || !b_reduce || !w_expand || !b_expand || batch <= 0 || channels <= 0 || nblk <= 0 ||
+    if (!partial || !w_reduce || !b_reduce || !w_expand || !b_expand || !gate || batch <= 0 || channels <= 0 || nblk <= 0 ||
         c_squeezed <= 0) return HS_ERR_BAD_ARG;
-    if ((w_proj != nullptr) != (w_scaled != nullptr) || (w_proj && c_out <= 0) || (!gate && !w_proj)) return HS_ERR_BAD_ARG;
+    if ((w_proj != nullptr) != (w_scaled != nullptr) || (w_proj && c_out <= 0)) return HS_ERR_BAD_ARG;
     const size_t lds = (size_t)(2 * channels + c_squeezed) * sizeof(float);
     if (lds > 64 * 1024) return HS_ERR_LDS;
-    hipLaunchKernelGGL(se_gate_kernel, dim3(batch), dim3(256), lds, (hipStream_t)stream, partial, nblk, inv_hw, w_reduce,
-                       b_reduce, w_expand, b_expand, channels, c_squeezed, gate, w_proj, c_out, w_scaled);
+    hipLaunchKernelGGL(se_gate_kernel, dim3(batch), dim3(1024), lds, (hipStream_t)stream, partial, nblk, inv_hw, w_reduce,
+                       b_reduce, w_expand, b_expand, channels, c_squeezed, gate);
+    int st = launch_status();
+    if (st != HS_OK || !w_proj) return st;
+    const size_t n = (size_t)c_out * channels;
+    hipLaunchKernelGGL(scale_weights_kernel, dim3((unsigned)((n / 4 + 255) / 256 + 1), batch), dim3(256), 0,
+                       (hipStream_t)stream, w_proj, gate, channels, n, w_scaled);
     return launch_status();
 }

@@ -266,17 +266,16 @@ def se_gate(partial, batch, hw, w_reduce, b_reduce, w_expand, b_expand, w_proj=N
     c = partial.shape[0] // batch
     csq = w_reduce.shape[0]
     dev = partial.device
-    gate = w_scaled = None
+    w_scaled = None
     cout = 0
+    gate = torch.empty(batch, c, device=dev, dtype=torch.float32)
     if w_proj is not None:
         cout = w_proj.shape[0]
         w_scaled = torch.empty(batch, cout, c, 1, 1, device=dev, dtype=torch.float32)
-    else:
-        gate = torch.empty(batch, c, device=dev, dtype=torch.float32)
     st = _hip.lib.hs_se_gate_fwd(_hip.dev_ptr(partial, 'partial'), batch, c, partial.shape[1], 1.0 / float(hw),
                                  _hip.dev_ptr(w_reduce, 'w_reduce'), _hip.dev_ptr(b_reduce, 'b_reduce'), csq,
                                  _hip.dev_ptr(w_expand, 'w_expand'), _hip.dev_ptr(b_expand, 'b_expand'),
-                                 gate.data_ptr() if gate is not None else None,
+                                 gate.data_ptr(),
                                  _hip.dev_ptr(w_proj, 'w_proj') if w_proj is not None else None, cout,
                                  w_scaled.data_ptr() if w_scaled is not None else None, _hip.stream_ptr())
     _hip.check(st, 'hs_se_gate_fwd')

@@ -58,6 +58,7 @@ class FusedDepthwiseBNSwish(nn.Module):
         self.register_buffer('scale', scale.detach().clone(), persistent=False)
         self.register_buffer('shift', shift.detach().clone(), persistent=False)
         self._conv = [conv]                      # not registered twice
+        self._exp_t = None                       # (Csq, C) transposed SE expand weight, built on first use
         self.k, self.stride = conv.kernel_size[0], conv.stride[0]
         if conv._pad is not None:                # asymmetric TF-"SAME": (left, right, top, bottom)
             self.pad_l, self.pad_t = conv._pad[0], conv._pad[2]
@@ -77,11 +78,13 @@ class FusedDepthwiseBNSwish(nn.Module):
         y, partial = HF.depthwise_conv_bn_act(x.contiguous(), self._conv[0].weight, self.stride, self.pad_t, self.pad_l,
                                               (ho, wo), self.scale, self.shift, act=3, pool=True)
         red, exp, proj = blk._se_reduce, blk._se_expand, blk._project_conv
+        if self._exp_t is None or self._exp_t.device != x.device:
+            self._exp_t = exp.weight.detach().flatten(1).t().contiguous()
         if b == 1:
             # gate folded into the 1x1 project weights: no elementwise pass over the activation
-            wp = HF.se_gate(partial, 1, ho * wo, red.weight, red.bias, exp.weight, exp.bias, w_proj=proj.weight)
+            wp = HF.se_gate(partial, 1, ho * wo, red.weight, red.bias, self._exp_t, exp.bias, w_proj=proj.weight)
             return F.conv2d(y, wp[0])
-        gate = HF.se_gate(partial, b, ho * wo, red.weight, red.bias, exp.weight, exp.bias)
+        gate = HF.se_gate(partial, b, ho * wo, red.weight, red.bias, self._exp_t, exp.bias)
         return proj(y * gate[:, :, None, None])
 
 

@@ -162,7 +162,8 @@ int hs_depthwise_conv_fwd(const float* x, int32_t batch, int32_t channels, int32
 /* pool_partial (optional): (B*C, hs_depthwise_pool_blocks(Ho, Wo)) per-workgroup sums of the outputs, the squeeze-excite
  * pooling for free.  hs_se_gate_fwd turns them into the SE gate (pool -> 1x1 reduce + swish -> 1x1 expand -> sigmoid;
  * efficientnet.py:106-111) and, if w_proj is given, folds the gate into the block's project convolution weights:
- * w_scaled[b, o, c] = w_proj[o, c] * gate[b, c]. */
+ * w_scaled[b, o, c] = w_proj[o, c] * gate[b, c].  w_reduce is (c_squeezed, channels); w_expand is passed TRANSPOSED,
+ * (c_squeezed, channels), so that both are read coalesced. */
 int hs_depthwise_pool_blocks(int32_t Ho, int32_t Wo);
 int hs_se_gate_fwd(const float* partial, int32_t batch, int32_t channels, int32_t nblk, float inv_hw,
                    const float* w_reduce, const float* b_reduce, int32_t c_squeezed, const float* w_expand,

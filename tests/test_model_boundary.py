@@ -144,7 +144,7 @@ def test_inference_prep_matches_stock_encoder(batch):
     assert len([m for m in fused.backbone.modules() if isinstance(m, torch.nn.BatchNorm2d)]) == n_bn
     assert list(fused.state_dict()) == list(stock.state_dict())          # checkpoints still round-trip
     stock, fused = stock.to(dev), fused.to(dev)
-    x = torch.rand(batch, 3, 160, 224, device=dev)
+    x = torch.rand(batch, 3, 128, 192, device=dev)
     with torch.no_grad():
         fs, ff = stock.backbone(x), fused.backbone(x)
         for a, b in zip(fs, ff):
