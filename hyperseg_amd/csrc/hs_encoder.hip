@@ -238,3 +238,99 @@ extern "C" int hs_se_gate_fwd(const float* partial, int32_t batch, int32_t chann
                        (hipStream_t)stream, w_proj, gate, channels, n, w_scaled);
     return launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// 1x1 convolution as an fp32 MFMA GEMM with everything around it fused: y[b,o,p] = act(scale[o] * sum_c W[o,c] *
+// (gate[b,c] * x[b,c,p]) + shift[o]) + residual[b,o,p].  One launch replaces {SE multiply, conv, BatchNorm, swish,
+// skip add} of an MBConv block (efficientnet.py:101-103, 110-124).  NCHW: pixels are the contiguous GEMM dimension, so
+// the B operand (x) is read in 64-byte runs and D is stored in 64-byte runs; no LDS -- x tiles are re-read by the
+// ceil(Cout/32) workgroups of a pixel strip through L1/L2.  Wave tile 32 (o) x 64 (p), v_mfma_f32_16x16x4_f32.
+// ---------------------------------------------------------------------------------------------------------------
+namespace hs {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__global__ __launch_bounds__(256)
+void pointwise_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ gate,
+                           const float* __restrict__ scale, const float* __restrict__ shift,
+                           const float* __restrict__ residual, float* __restrict__ y, int Cin, int Cout, int P, int act) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lrow = lane & 15, lk = lane >> 4;
+    const int b = blockIdx.z;
+    const int o0 = blockIdx.y * 32;
+    const int p0 = (blockIdx.x * 4 + wave) * 64;
+    if (p0 >= P) return;
+    const float* __restrict__ xb = x + (size_t)b * Cin * P;
+    const float* __restrict__ gb = gate ? gate + (size_t)b * Cin : nullptr;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // clamped per-lane rows / pixels (masked lanes read valid addresses; their products are zeroed)
+    int orow[2]; bool ook[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) { const int o = o0 + 16 * m + lrow; ook[m] = o < Cout; orow[m] = ook[m] ? o : Cout - 1; }
+    int pcol[4]; bool pok[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) { const int p = p0 + 16 * n + lrow; pok[n] = p < P; pcol[n] = pok[n] ? p : P - 1; }
+    constexpr int KU = 4;                                   // k-steps per load batch
+    for (int k0 = 0; k0 < Cin; k0 += 4 * KU) {
+        float av[KU][2], bv[KU][4];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int k = k0 + 4 * u + lk;
+            const bool kok = k < Cin;
+            const int kc = kok ? k : Cin - 1;
+            const float g = gb ? gb[kc] : 1.0f;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const float t = w[(size_t)orow[m] * Cin + kc];
+                av[u][m] = (kok && ook[m]) ? t : 0.0f;
+            }
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const float t = xb[(size_t)kc * P + pcol[n]];
+                bv[u][n] = (kok && pok[n]) ? t * g : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < KU; ++u)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][m], bv[u][n], acc[m][n], 0, 0, 0);
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = o0 + 16 * m + 4 * lk + r;
+            if (o >= Cout) continue;
+            const float sc = scale ? scale[o] : 1.0f, sh = shift ? shift[o] : 0.0f;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                if (!pok[n]) continue;
+                float v = fmaf(acc[m][n][r], sc, sh);
+                if (act == 3) v = v / (1.0f + expf(-v));
+                else v = apply_act(v, act);
+                const size_t idx = ((size_t)b * Cout + o) * P + pcol[n];
+                if (residual) v += residual[idx];
+                y[idx] = v;
+            }
+        }
+}
+
+}  // namespace hs
+
+extern "C" int hs_pointwise_conv_fwd(const float* x, int32_t batch, int32_t c_in, int32_t pixels, const float* w,
+                                     int32_t c_out, const float* gate, const float* scale, const float* shift, int32_t act,
+                                     const float* residual, float* y, void* stream) {
+    if (!x || !w || !y || batch <= 0 || c_in <= 0 || c_out <= 0 || pixels <= 0 || (scale && !shift)) return HS_ERR_BAD_ARG;
+    if (batch > 65535 || (c_out + 31) / 32 > 65535) return HS_ERR_UNSUPPORTED;
+    dim3 grid((pixels + 255) / 256, (c_out + 31) / 32, batch);
+    hipLaunchKernelGGL(hs::pointwise_conv_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w, gate, scale, shift,
+                       residual, y, c_in, c_out, pixels, act);
+    return hs::launch_status();
+}

@@ -260,6 +260,19 @@ def depthwise_conv_bn_act(x, weight, stride, pad_top, pad_left, out_size, scale=
     return (y, partial) if pool else y
 
 
+def pointwise_conv(x, weight, gate=None, scale=None, shift=None, act=0, residual=None):
+    """1x1 conv (fp32 MFMA GEMM) + optional input gate (B,Cin) + affine + activation (3 = swish) + residual, one launch."""
+    b, cin, h, w = x.shape
+    cout = weight.shape[0]
+    y = torch.empty(b, cout, h, w, device=x.device, dtype=torch.float32)
+    opt = lambda t, n: _hip.dev_ptr(t, n) if t is not None else None   # noqa: E731
+    st = _hip.lib.hs_pointwise_conv_fwd(_hip.dev_ptr(x, 'x'), b, cin, h * w, _hip.dev_ptr(weight, 'weight'), cout,
+                                        opt(gate, 'gate'), opt(scale, 'scale'), opt(shift, 'shift'), int(act),
+                                        opt(residual, 'residual'), y.data_ptr(), _hip.stream_ptr())
+    _hip.check(st, 'hs_pointwise_conv_fwd')
+    return y
+
+
 def se_gate(partial, batch, hw, w_reduce, b_reduce, w_expand, b_expand, w_proj=None):
     """Squeeze-excite gate from pooled partial sums; with ``w_proj`` (Cout, C[,1,1]) returns the project weights
     scaled by the gate, (B, Cout, C, 1, 1); otherwise the gate (B, C)."""

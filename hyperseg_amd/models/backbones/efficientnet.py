@@ -98,17 +98,14 @@ class MBConvBlock(nn.Module):
         self._fused_dw = None       # set by utils.inference.prepare_for_inference(fused_depthwise=True)
 
     def forward(self, inputs, drop_connect_rate=None):
+        if self._fused_dw is not None and inputs.is_cuda and not self.training:
+            return self._fused_dw(inputs, self)         # the whole block in 4 HIP launches (utils/inference.py)
         x = inputs
         if self.expand != 1:
             x = F.silu(self._bn0(self._expand_conv(x)))
-        if self._fused_dw is not None and x.is_cuda and not self.training:
-            # depthwise + BN + swish (+ SE pooling) in one HIP launch, SE gate folded into the project weights
-            x = self._fused_dw(x, self)
-        else:
-            x = F.silu(self._bn1(self._depthwise_conv(x)))
-            gate = self._se_expand(F.silu(self._se_reduce(F.adaptive_avg_pool2d(x, 1))))
-            x = self._project_conv(torch.sigmoid(gate) * x)
-        x = self._bn2(x)
+        x = F.silu(self._bn1(self._depthwise_conv(x)))
+        gate = self._se_expand(F.silu(self._se_reduce(F.adaptive_avg_pool2d(x, 1))))
+        x = self._bn2(self._project_conv(torch.sigmoid(gate) * x))
         if self.stride == 1 and self.in_f == self.out_f:
             if drop_connect_rate and self.training:      # stochastic depth
                 keep = 1.0 - drop_connect_rate
@@ -174,6 +171,7 @@ class EfficientNet(nn.Module):
         self._avg_pooling = nn.AdaptiveAvgPool2d(1)
         self._dropout = nn.Dropout(dropout)
         self._fc = head(head_nc, num_classes) if head is not None else None
+        self._fused_head, self._fused_fc = None, None      # set by utils.inference.prepare_for_inference
 
     def extract_features_list(self, inputs):
         x = F.silu(self._bn0(self._conv_stem(inputs)))
@@ -184,8 +182,12 @@ class EfficientNet(nn.Module):
             x = block(x, drop_connect_rate=rate)
             if self._res_feat_mask[idx]:
                 fc = getattr(self, f'_feat_fc_{len(feats)}', None) if self.out_feat_scale is not None else None
-                feats.append(x if fc is None else fc(x))
-        x = F.silu(self._bn1(self._conv_head(x)))
+                fused = self._fused_fc is not None and x.is_cuda and not self.training and str(len(feats)) in self._fused_fc
+                feats.append(self._fused_fc[str(len(feats))](x) if fused else (x if fc is None else fc(x)))
+        if self._fused_head is not None and x.is_cuda and not self.training:
+            x = self._fused_head(x)
+        else:
+            x = F.silu(self._bn1(self._conv_head(x)))
         if self.pool:
             x = self._avg_pooling(x).flatten(1)
         x = self._dropout(x)

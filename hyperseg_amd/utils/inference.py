@@ -45,20 +45,44 @@ def _fold_sequential(seq):
     return n
 
 
-class FusedDepthwiseBNSwish(nn.Module):
-    """depthwise conv + eval BatchNorm + swish of one MBConv block as ONE ``hs_depthwise_conv_fwd`` launch
-    (MIOpen has no tuned fp32 depthwise solver on ROCm 7.2: Winograd-per-group / naive kernels, ~half of the frame).
-    Holds the folded BN affine as non-persistent buffers; the filter stays the block's own ``_depthwise_conv.weight``."""
+def _bn_affine(bn):
+    with torch.no_grad():
+        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        shift = bn.bias - bn.running_mean * scale
+    return scale.detach().clone(), shift.detach().clone()
 
-    def __init__(self, conv, bn):
+
+class FusedPointwise(nn.Module):
+    """1x1 conv + eval BatchNorm (+ activation) as one ``hs_pointwise_conv_fwd`` launch.  The conv stays where it is in
+    the model (weights are read through a reference); only the folded BN affine lives here (non-persistent buffers)."""
+
+    def __init__(self, conv, bn, act=0):
         super().__init__()
-        with torch.no_grad():
-            scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
-            shift = bn.bias - bn.running_mean * scale
-        self.register_buffer('scale', scale.detach().clone(), persistent=False)
-        self.register_buffer('shift', shift.detach().clone(), persistent=False)
-        self._conv = [conv]                      # not registered twice
-        self._exp_t = None                       # (Csq, C) transposed SE expand weight, built on first use
+        assert conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.groups == 1 and conv.bias is None
+        scale, shift = _bn_affine(bn)
+        self.register_buffer('scale', scale, persistent=False)
+        self.register_buffer('shift', shift, persistent=False)
+        self._conv = [conv]
+        self.act = act
+
+    def forward(self, x, gate=None, residual=None):
+        from .. import functional as HF
+        return HF.pointwise_conv(x.contiguous(), self._conv[0].weight, gate, self.scale, self.shift, self.act, residual)
+
+
+class FusedMBConv(nn.Module):
+    """A whole MBConv block in 4 HIP launches: [1x1 expand + BN + swish] -> [depthwise + BN + swish + SE pooling] ->
+    [SE gate] -> [gate * 1x1 project + BN + skip add]  (stock: 15 launches; MIOpen has no tuned fp32 depthwise solver on
+    ROCm 7.2 -- Winograd-per-group / naive kernels cost half of the frame).  Filters stay the block's own parameters."""
+
+    def __init__(self, blk):
+        super().__init__()
+        conv = blk._depthwise_conv
+        self.expand = FusedPointwise(blk._expand_conv, blk._bn0, act=3) if blk.expand != 1 else None
+        self.project = FusedPointwise(blk._project_conv, blk._bn2, act=0)
+        scale, shift = _bn_affine(blk._bn1)
+        self.register_buffer('scale', scale, persistent=False)
+        self.register_buffer('shift', shift, persistent=False)
         self.k, self.stride = conv.kernel_size[0], conv.stride[0]
         if conv._pad is not None:                # asymmetric TF-"SAME": (left, right, top, bottom)
             self.pad_l, self.pad_t = conv._pad[0], conv._pad[2]
@@ -66,49 +90,55 @@ class FusedDepthwiseBNSwish(nn.Module):
         else:
             self.pad_t, self.pad_l = conv.padding
             self.pad_h, self.pad_w = 2 * conv.padding[0], 2 * conv.padding[1]
+        self.skip = blk.stride == 1 and blk.in_f == blk.out_f
+        self._exp_t = None                       # (Csq, C) transposed SE expand weight, built on first use
 
-    def forward(self, x, blk):
-        """x -> project_conv(SE(swish(bn1(depthwise(x))))) of MBConv block ``blk`` (before its bn2)."""
-        import torch.nn.functional as F
+    def forward(self, inputs, blk):
         from .. import functional as HF
-        b = x.shape[0]
-        h, w = x.shape[-2:]
+        x = inputs.contiguous()
+        if self.expand is not None:
+            x = self.expand(x)
+        b, _, h, w = x.shape
         ho = (h + self.pad_h - self.k) // self.stride + 1
         wo = (w + self.pad_w - self.k) // self.stride + 1
-        y, partial = HF.depthwise_conv_bn_act(x.contiguous(), self._conv[0].weight, self.stride, self.pad_t, self.pad_l,
+        y, partial = HF.depthwise_conv_bn_act(x, blk._depthwise_conv.weight, self.stride, self.pad_t, self.pad_l,
                                               (ho, wo), self.scale, self.shift, act=3, pool=True)
-        red, exp, proj = blk._se_reduce, blk._se_expand, blk._project_conv
+        red, exp = blk._se_reduce, blk._se_expand
         if self._exp_t is None or self._exp_t.device != x.device:
             self._exp_t = exp.weight.detach().flatten(1).t().contiguous()
-        if b == 1:
-            # gate folded into the 1x1 project weights: no elementwise pass over the activation
-            wp = HF.se_gate(partial, 1, ho * wo, red.weight, red.bias, self._exp_t, exp.bias, w_proj=proj.weight)
-            return F.conv2d(y, wp[0])
         gate = HF.se_gate(partial, b, ho * wo, red.weight, red.bias, self._exp_t, exp.bias)
-        return proj(y * gate[:, :, None, None])
+        return self.project(y, gate=gate, residual=inputs.contiguous() if self.skip else None)
 
 
 def prepare_for_inference(model, fold_bn=True, channels_last=False, fused_depthwise=False):
+    # fused_depthwise: historical name -- it now fuses every MBConv block end to end (4 launches), the head and the
+    # feature reducers
     """In-place; returns the number of BatchNorms folded.  ``model`` is a HyperGen in eval mode.
     ``fused_depthwise`` swaps each MBConv block's depthwise conv + BN + swish for the fused HIP kernel (do it BEFORE
     ``fold_bn`` touches those BatchNorms: handled here)."""
     assert not model.training, 'call model.eval() first'
     folded = 0
     if fused_depthwise:
-        for blk in model.backbone._blocks:
+        bb = model.backbone
+        for blk in bb._blocks:
             conv = blk._depthwise_conv
             if conv.kernel_size[0] in (3, 5) and conv.stride[0] in (1, 2) and isinstance(blk._bn1, nn.BatchNorm2d):
-                blk._fused_dw = FusedDepthwiseBNSwish(conv, blk._bn1)
+                blk._fused_dw = FusedMBConv(blk)
+        bb._fused_head = FusedPointwise(bb._conv_head, bb._bn1, act=3)
+        bb._fused_fc = nn.ModuleDict()
+        for i in range(len(bb.feat_channels) - 1):
+            fc = getattr(bb, f'_feat_fc_{i}', None)
+            if isinstance(fc, nn.Sequential):
+                bb._fused_fc[str(i)] = FusedPointwise(fc[0], fc[1], act=0)
     if fold_bn:
         bb = model.backbone
-        folded += _fold_pairs(bb, [('_conv_stem', '_bn0'), ('_conv_head', '_bn1')])
+        folded += _fold_pairs(bb, [('_conv_stem', '_bn0')] + ([] if getattr(bb, '_fused_head', None) is not None else [('_conv_head', '_bn1')]))
         for blk in bb._blocks:
-            pairs = [('_expand_conv', '_bn0'), ('_project_conv', '_bn2')]
             if blk._fused_dw is None:
-                pairs.append(('_depthwise_conv', '_bn1'))
-            folded += _fold_pairs(blk, pairs)
-        for m in list(bb.children()) + list(model.weight_mapper.modules()):
-            if isinstance(m, nn.Sequential):
+                folded += _fold_pairs(blk, [('_expand_conv', '_bn0'), ('_project_conv', '_bn2'), ('_depthwise_conv', '_bn1')])
+        fused_fc = getattr(bb, '_fused_fc', None)
+        for name, m in list(bb.named_children()) + list(model.weight_mapper.named_modules()):
+            if isinstance(m, nn.Sequential) and not (fused_fc is not None and name.startswith('_feat_fc_')):
                 folded += _fold_sequential(m)
     if channels_last:
         model.backbone.to(memory_format=torch.channels_last)

@@ -169,6 +169,14 @@ int hs_se_gate_fwd(const float* partial, int32_t batch, int32_t channels, int32_
                    const float* w_reduce, const float* b_reduce, int32_t c_squeezed, const float* w_expand,
                    const float* b_expand, float* gate, const float* w_proj, int32_t c_out, float* w_scaled, void* stream);
 
+/* Encoder-side helper: 1x1 convolution as an fp32 MFMA GEMM with its surroundings fused,
+ *   y[b,o,p] = act(scale[o] * sum_c w[o,c] * (gate[b,c] * x[b,c,p]) + shift[o]) + residual[b,o,p]
+ * (gate, scale/shift, residual optional; act = hs_act or 3 = swish).  x (B,Cin,P), w (Cout,Cin), y (B,Cout,P), P = H*W.
+ * Replaces {SE multiply, 1x1 conv, BatchNorm2d, swish, skip add} of an MBConv block (efficientnet.py:101-103, 110-124). */
+int hs_pointwise_conv_fwd(const float* x, int32_t batch, int32_t c_in, int32_t pixels, const float* w, int32_t c_out,
+                          const float* gate, const float* scale, const float* shift, int32_t act, const float* residual,
+                          float* y, void* stream);
+
 /* Materialises a stage input (B, 2*coords + c_skip + c_prev, H, W); test/diagnostic twin of the
  * fused prologue (the product path never calls it). */
 int hs_stage_input_fwd(const hs_stage_input* in, float* y, void* stream);
