@@ -334,3 +334,37 @@ extern "C" int hs_pointwise_conv_fwd(const float* x, int32_t batch, int32_t c_in
                        residual, y, c_in, c_out, pixels, act);
     return hs::launch_status();
 }
+
+// y = act(scale[c] * x + shift[c]) + residual, elementwise over (B, C, P); y may alias x.  Used after the stock
+// (rocBLAS) 1x1 convolutions of the encoder where K is large: one launch instead of BatchNorm + swish (+ skip add).
+namespace hs {
+__global__ __launch_bounds__(256)
+void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                       const float* __restrict__ residual, float* __restrict__ y, int C, int P, size_t n4, int act) {
+    const int pq = P >> 2;                     // P % 4 == 0 (checked by the host)
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)((e / pq) % C);
+        const float sc = scale[c], sh = shift[c];
+        const float4 v = reinterpret_cast<const float4*>(x)[e];
+        float o[4] = {fmaf(v.x, sc, sh), fmaf(v.y, sc, sh), fmaf(v.z, sc, sh), fmaf(v.w, sc, sh)};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[t] = act == 3 ? o[t] / (1.0f + expf(-o[t])) : apply_act(o[t], act);
+        if (residual) {
+            const float4 r = reinterpret_cast<const float4*>(residual)[e];
+            o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+        }
+        reinterpret_cast<float4*>(y)[e] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+}  // namespace hs
+
+extern "C" int hs_affine_act_fwd(const float* x, int32_t batch, int32_t channels, int32_t pixels, const float* scale,
+                                 const float* shift, int32_t act, const float* residual, float* y, void* stream) {
+    if (!x || !y || !scale || !shift || batch <= 0 || channels <= 0 || pixels <= 0) return HS_ERR_BAD_ARG;
+    if (pixels & 3) return HS_ERR_UNSUPPORTED;
+    const size_t n4 = (size_t)batch * channels * pixels / 4;
+    const unsigned blocks = (unsigned)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256);
+    hipLaunchKernelGGL(hs::affine_act_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, scale, shift, residual, y,
+                       channels, pixels, n4, act);
+    return hs::launch_status();
+}

@@ -273,6 +273,17 @@ def pointwise_conv(x, weight, gate=None, scale=None, shift=None, act=0, residual
     return y
 
 
+def affine_act_(x, scale, shift, act=0, residual=None):
+    """In place: x = act(scale[c]*x + shift[c]) + residual  (folded BN + activation + skip add, one launch)."""
+    b, c, h, w = x.shape
+    st = _hip.lib.hs_affine_act_fwd(_hip.dev_ptr(x, 'x'), b, c, h * w, _hip.dev_ptr(scale, 'scale'),
+                                    _hip.dev_ptr(shift, 'shift'), int(act),
+                                    _hip.dev_ptr(residual, 'residual') if residual is not None else None, x.data_ptr(),
+                                    _hip.stream_ptr())
+    _hip.check(st, 'hs_affine_act_fwd')
+    return x
+
+
 def se_gate(partial, batch, hw, w_reduce, b_reduce, w_expand, b_expand, w_proj=None):
     """Squeeze-excite gate from pooled partial sums; with ``w_proj`` (Cout, C[,1,1]) returns the project weights
     scaled by the gate, (B, Cout, C, 1, 1); otherwise the gate (B, C)."""

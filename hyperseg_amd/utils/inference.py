@@ -65,9 +65,30 @@ class FusedPointwise(nn.Module):
         self._conv = [conv]
         self.act = act
 
-    def forward(self, x, gate=None, residual=None):
+    def uses_mfma(self, x):
+        """Small-K, many-pixel layers run as one fused MFMA GEMM; large-K layers keep the stock (rocBLAS) GEMM."""
+        return x.shape[1] <= 96 and x.shape[2] * x.shape[3] >= 8192
+
+    def forward(self, x, gate=None, residual=None, w_scaled=None):
+        """``gate`` (B, Cin): SE gate applied to the input (MFMA path), or ``w_scaled`` (Cout, Cin, 1, 1): the conv
+        weights with the gate already folded in (stock-GEMM path, batch 1).  The stock GEMM is followed by ONE fused
+        BatchNorm + activation + skip-add launch."""
+        import torch.nn.functional as F
         from .. import functional as HF
-        return HF.pointwise_conv(x.contiguous(), self._conv[0].weight, gate, self.scale, self.shift, self.act, residual)
+        conv = self._conv[0]
+        x = x.contiguous()
+        b, cin, h, w = x.shape
+        if self.uses_mfma(x) and w_scaled is None:
+            return HF.pointwise_conv(x, conv.weight, gate, self.scale, self.shift, self.act, residual)
+        if (h * w) % 4 != 0:
+            raise NotImplementedError('feature maps with H*W % 4 != 0')
+        if w_scaled is not None:
+            y = F.conv2d(x, w_scaled)
+        elif gate is None:
+            y = F.conv2d(x, conv.weight)
+        else:
+            y = F.conv2d(x * gate[:, :, None, None], conv.weight)
+        return HF.affine_act_(y, self.scale, self.shift, self.act, residual)
 
 
 class FusedMBConv(nn.Module):
@@ -106,8 +127,13 @@ class FusedMBConv(nn.Module):
         red, exp = blk._se_reduce, blk._se_expand
         if self._exp_t is None or self._exp_t.device != x.device:
             self._exp_t = exp.weight.detach().flatten(1).t().contiguous()
+        skip = inputs.contiguous() if self.skip else None
+        if b == 1 and not self.project.uses_mfma(y):
+            # large K: gate folded into the project weights (tiny kernel) instead of an elementwise pass over y
+            wp = HF.se_gate(partial, 1, ho * wo, red.weight, red.bias, self._exp_t, exp.bias, w_proj=blk._project_conv.weight)
+            return self.project(y, residual=skip, w_scaled=wp[0])
         gate = HF.se_gate(partial, b, ho * wo, red.weight, red.bias, self._exp_t, exp.bias)
-        return self.project(y, gate=gate, residual=inputs.contiguous() if self.skip else None)
+        return self.project(y, gate=gate, residual=skip)
 
 
 def prepare_for_inference(model, fold_bn=True, channels_last=False, fused_depthwise=False):

@@ -177,6 +177,11 @@ int hs_pointwise_conv_fwd(const float* x, int32_t batch, int32_t c_in, int32_t p
                           const float* gate, const float* scale, const float* shift, int32_t act, const float* residual,
                           float* y, void* stream);
 
+/* y = act(scale[c]*x + shift[c]) + residual over (B, C, P), P % 4 == 0, y may alias x: folded BatchNorm + swish (+ skip
+ * add) after a stock 1x1 convolution in one launch. */
+int hs_affine_act_fwd(const float* x, int32_t batch, int32_t channels, int32_t pixels, const float* scale,
+                      const float* shift, int32_t act, const float* residual, float* y, void* stream);
+
 /* Materialises a stage input (B, 2*coords + c_skip + c_prev, H, W); test/diagnostic twin of the
  * fused prologue (the product path never calls it). */
 int hs_stage_input_fwd(const hs_stage_input* in, float* y, void* stream);
