@@ -1,0 +1,77 @@
+"""Pieces shared by the three HyperSeg model variants of this package (v1_0, v1_0_unify, v0_1): the HyperGen wrapper
+logic (single tensor / pyramid + h-flip inference), per-level argument normalisation, coordinate buffers."""
+import numbers
+
+import torch
+import torch.nn as nn
+
+from .. import functional as HF
+
+
+def per_level(value, n, name):
+    """Broadcast a scalar hyper-parameter to ``n`` levels, or check a sequence's length."""
+    if isinstance(value, numbers.Number):
+        return (value,) * n
+    if len(value) != n:
+        raise AssertionError(f'{name} ({len(value)}) must be of size {n}')
+    return tuple(value)
+
+
+def coordinate_grid(h, w, device=None):
+    """(1, 2, h, w): channel 0 = x in [-1, 1] over W, channel 1 = y over H, endpoints inclusive.  Same values as the
+    reference's cached buffers; the HIP kernels regenerate them analytically."""
+    xs = torch.linspace(-1, 1, steps=w, device=device).view(1, w).expand(h, w)
+    ys = torch.linspace(-1, 1, steps=h, device=device).view(h, 1).expand(h, w)
+    return torch.stack([xs, ys], dim=0).unsqueeze(0).contiguous()
+
+
+def register_coordinate_buffers(module, coords_res, levels):
+    """``coord{h}_{w}`` buffers for every resolution of every listed pyramid -- kept only so that reference checkpoints
+    load with strict=True."""
+    for res in coords_res or ():
+        for i in range(levels):
+            h, w = res[0] // 2 ** i, res[1] // 2 ** i
+            module.register_buffer(f'coord{h}_{w}', coordinate_grid(h, w))
+
+
+class HyperGenBase(nn.Module):
+    """backbone -> context head -> dynamic decoder, with the reference's list-input (image pyramid) and horizontal-flip
+    inference modes (hyperseg_v1_0.py:52-91).  Subclasses create ``backbone``, ``decoder`` and ``weight_mapper``."""
+
+    inference_hflip = False
+    inference_gather = 'mean'
+
+    @property
+    def hyper_params(self):
+        return self.decoder.hyper_params
+
+    def process_single_tensor(self, x, hflip=False):
+        if hflip:
+            x = torch.flip(x, [-1])
+        features = self.backbone(x)
+        head_out = self.weight_mapper(features[-1])
+        if isinstance(head_out, torch.Tensor):
+            head_out = head_out.contiguous()
+        y = self.decoder([t.contiguous() for t in [x] + features[:-1]], head_out)
+        return torch.flip(y, [-1]) if hflip else y
+
+    def gather_results(self, x, y=None):
+        assert x is not None
+        if y is None:
+            return x
+        return (x + y) * 0.5 if self.inference_gather == 'mean' else torch.max(x, y)
+
+    def forward(self, x):
+        if isinstance(x, torch.Tensor):
+            return self.process_single_tensor(x)
+        assert isinstance(x, (list, tuple)), 'x must be of type list, tuple, or tensor'
+        out_res = x[0].shape[2:]          # the first pyramid level sets the output resolution
+        merged = None
+        for level in x:
+            y = self.process_single_tensor(level)
+            if self.inference_hflip:
+                y = torch.max(y, self.process_single_tensor(level, hflip=True))
+            if y.shape[2:] != out_res:
+                y = HF.upsample_bilinear(y.contiguous(), out_res)
+            merged = self.gather_results(y, merged)
+        return merged

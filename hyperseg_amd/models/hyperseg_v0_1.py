@@ -17,6 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import functional as HF
+from ._common import HyperGenBase, coordinate_grid, per_level
 from .layers.meta_patch import MetaPatchConv2d, make_meta_patch_conv2d_block
 from .layers.meta_sequential import MetaSequential
 
@@ -26,11 +27,8 @@ def next_multiply(x, base):
 
 
 def get_image_coordinates(b, h, w, device):
-    """(b, 2, h, w): channel 0 = x in [-1, 1], channel 1 = y (hyperseg_v0_1.py:240-246).  Kept for API parity; the
-    decoder generates the same values inside the stage kernels."""
-    x = torch.linspace(-1, 1, steps=w, device=device)
-    y = torch.linspace(-1, 1, steps=h, device=device)
-    return torch.stack([x.view(1, w).expand(h, w), y.view(h, 1).expand(h, w)], dim=0).repeat(b, 1, 1, 1)
+    """(b, 2, h, w) coordinate channels (hyperseg_v0_1.py:240-246); API parity -- the kernels generate them in place."""
+    return coordinate_grid(h, w, device).repeat(b, 1, 1, 1)
 
 
 class HyperPatchInvertedResidual(nn.Module):
@@ -72,54 +70,39 @@ class MultiScaleDecoder(nn.Module):
                  act_layer=nn.ReLU6(inplace=True), out_kernel_size=1, expand_ratio=1, with_out_fc=False, dropout=None):
         super(MultiScaleDecoder, self).__init__()
         n = len(feat_channels)
-        if isinstance(kernel_sizes, int):
-            kernel_sizes = (kernel_sizes,) * n
-        if isinstance(level_layers, int):
-            level_layers = (level_layers,) * n
-        assert len(kernel_sizes) == n, f'kernel_sizes ({len(kernel_sizes)}) must be of size {n}'
-        assert len(level_layers) == n, f'level_layers ({len(level_layers)}) must be of size {n}'
-        self.level_layers = level_layers
-        self.levels = len(level_layers)
+        kernel_sizes = per_level(kernel_sizes, n, 'kernel_sizes')
+        level_layers = per_level(level_layers, n, 'level_layers')
+        self.level_layers, self.levels = level_layers, n
         self.layer_params = []
-        feat_channels = feat_channels[::-1]
+        coarse_to_fine = feat_channels[::-1]
 
-        prev_channels = 0
-        for level in range(self.levels):
-            curr_ngf = feat_channels[level]
-            prev_channels += curr_ngf
-            curr_layers = []
-            k = kernel_sizes[level]
-            for layer in range(self.level_layers[level]):
-                if (not with_out_fc) and level == self.levels - 1 and layer == self.level_layers[level] - 1:
-                    curr_ngf = num_classes
+        carried = 0                                   # channels handed up from the coarser level
+        for lvl, (skip_nc, k, depth) in enumerate(zip(coarse_to_fine, kernel_sizes, level_layers)):
+            width, carried = skip_nc, carried + skip_nc
+            blocks = []
+            for j in range(depth):
+                if not with_out_fc and lvl == n - 1 and j == depth - 1:
+                    width = num_classes               # the very last layer emits the logits
                 if k > 1:
-                    curr_layers.append(HyperPatchInvertedResidual(
-                        prev_channels + 2, curr_ngf, k, expand_ratio=expand_ratio, norm_layer=norm_layer,
-                        act_layer=act_layer))
+                    blocks.append(HyperPatchInvertedResidual(carried + 2, width, k, expand_ratio=expand_ratio,
+                                                             norm_layer=norm_layer, act_layer=act_layer))
                 else:
-                    curr_layers.append(make_meta_patch_conv2d_block(prev_channels + 2, curr_ngf, k))
-                prev_channels = curr_ngf
-            self.add_module(f'level_{level}', MetaSequential(*curr_layers))
+                    blocks.append(make_meta_patch_conv2d_block(carried + 2, width, k))
+                carried = width
+            self.add_module(f'level_{lvl}', MetaSequential(*blocks))
 
+        self.out_fc = None
         if with_out_fc:
-            out_fc_layers = [nn.Dropout2d(dropout, True)] if dropout is not None else []
-            out_fc_layers.append(
-                MetaPatchConv2d(prev_channels, num_classes, out_kernel_size, padding=out_kernel_size // 2))
-            self.out_fc = MetaSequential(*out_fc_layers)
-        else:
-            self.out_fc = None
+            tail = [] if dropout is None else [nn.Dropout2d(dropout, True)]
+            tail.append(MetaPatchConv2d(carried, num_classes, out_kernel_size, padding=out_kernel_size // 2))
+            self.out_fc = MetaSequential(*tail)
 
-        self.hyper_params = 0
-        self._ranges = [0]
-        self.param_groups = []
-        for level in range(self.levels):
-            lp = getattr(self, f'level_{level}').hyper_params
-            self.hyper_params += lp
-            self._ranges.append(self.hyper_params)
-            self.param_groups.append(lp)
-        if with_out_fc:
-            self.hyper_params += self.out_fc.hyper_params
+        # bookkeeping the context head sizes itself from
+        self.param_groups = [getattr(self, f'level_{lvl}').hyper_params for lvl in range(n)]
+        if self.out_fc is not None:
             self.param_groups.append(self.out_fc.hyper_params)
+        self._ranges = [0] + list(np.cumsum(self.param_groups))
+        self.hyper_params = int(self._ranges[-1])
         self._ranges.append(self.hyper_params)
 
     def forward(self, x, w):
@@ -168,19 +151,16 @@ class Conv2dMulti(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
                  bias=True, padding_mode='zeros', min_unit=8):
         super(Conv2dMulti, self).__init__()
-        self.in_channels = in_channels
-        self.out_channels = out_channels
-        self.bias = bias
-        self._ranges = [0]
-        parts = divide_feature_legacy(in_channels, out_channels, min_unit)
-        for i, out_nc in enumerate(out_channels):
-            self._ranges.append(self._ranges[-1] + int(parts[i]))
-            self.add_module(f'conv_{i}', nn.Conv2d(int(parts[i]), int(out_nc), kernel_size, stride, padding, dilation,
-                                                   groups, bias, padding_mode))
+        self.in_channels, self.out_channels, self.bias = in_channels, out_channels, bias
+        widths = [int(v) for v in divide_feature_legacy(in_channels, out_channels, min_unit)]
+        self._ranges = [0] + [int(v) for v in np.cumsum(widths)]
+        for i, (cin, cout) in enumerate(zip(widths, out_channels)):
+            self.add_module(f'conv_{i}', nn.Conv2d(cin, int(cout), kernel_size, stride, padding, dilation, groups, bias,
+                                                   padding_mode))
 
     def forward(self, x):
-        return [getattr(self, f'conv_{i}')(x[:, self._ranges[i]:self._ranges[i + 1]])
-                for i in range(len(self.out_channels))]
+        lo, hi = self._ranges[:-1], self._ranges[1:]
+        return [getattr(self, f'conv_{i}')(x[:, a:b]) for i, (a, b) in enumerate(zip(lo, hi))]
 
     def extra_repr(self):
         return f'in_channels={self.in_channels}, out_channels={self.out_channels}, bias={self.bias}'
@@ -193,96 +173,54 @@ class WeightMapper(nn.Module):
     def __init__(self, in_channels, out_channels, levels=2, bias=False, min_unit=8, down_groups=1, flat_groups=1,
                  weight_groups=1, avg_pool=False):
         super(WeightMapper, self).__init__()
-        assert levels > 0, 'levels must be greater than zero'
-        self.in_channels = in_channels
-        self.out_channels = out_channels
-        self.levels = levels
-        self.bias = bias
-        self.avg_pool = avg_pool
-        self.down_groups = down_groups
-        self.flat_groups = flat_groups
-        self.weight_groups = weight_groups
-        min_unit = max(min_unit, weight_groups)
-        for level in range(self.levels - 1):
-            self.add_module(f'down_{level}', nn.Sequential(
-                nn.Conv2d(in_channels, in_channels, kernel_size=2, stride=2, bias=bias, groups=down_groups),
-                nn.BatchNorm2d(in_channels), nn.ReLU(inplace=True)))
-            self.add_module(f'up_{level}', nn.UpsamplingNearest2d(scale_factor=2))
-            flat = [nn.Conv2d(in_channels * 2, in_channels, kernel_size=1, bias=bias, groups=flat_groups),
-                    nn.BatchNorm2d(in_channels)]
-            if level > 0:
-                flat.append(nn.ReLU(inplace=True))
-            self.add_module(f'flat_{level}', nn.Sequential(*flat))
+        if levels <= 0:
+            raise AssertionError('levels must be greater than zero')
+        self.in_channels, self.out_channels, self.levels, self.bias = in_channels, out_channels, levels, bias
+        self.avg_pool, self.down_groups, self.flat_groups, self.weight_groups = avg_pool, down_groups, flat_groups, weight_groups
+        nc = in_channels
+        for i in range(levels - 1):
+            down = nn.Sequential(nn.Conv2d(nc, nc, 2, 2, bias=bias, groups=down_groups), nn.BatchNorm2d(nc), nn.ReLU(True))
+            merge = [nn.Conv2d(2 * nc, nc, 1, bias=bias, groups=flat_groups), nn.BatchNorm2d(nc)]
+            if i > 0:
+                merge.append(nn.ReLU(True))          # the top merge feeds out_conv un-activated
+            self.add_module(f'down_{i}', down)
+            self.add_module(f'up_{i}', nn.UpsamplingNearest2d(scale_factor=2))
+            self.add_module(f'flat_{i}', nn.Sequential(*merge))
         padded = [next_multiply(c, weight_groups) for c in out_channels]
-        self.out_conv = Conv2dMulti(in_channels, padded, 1, bias=bias, min_unit=min_unit, groups=weight_groups)
+        self.out_conv = Conv2dMulti(nc, padded, 1, bias=bias, min_unit=max(min_unit, weight_groups), groups=weight_groups)
 
     def forward(self, x):
-        if self.levels <= 1:
-            return self.out_conv(x)
-        feat = [x]
-        for level in range(self.levels - 1):
-            feat.append(getattr(self, f'down_{level}')(feat[-1]))
-        if self.avg_pool and feat[-1].shape[-2:] != (1, 1):
-            feat[-1] = F.adaptive_avg_pool2d(feat[-1], 1).expand_as(feat[-1])
-        for level in range(self.levels - 2, -1, -1):
-            up = getattr(self, f'up_{level}')(feat.pop())
-            feat[-1] = getattr(self, f'flat_{level}')(torch.cat((feat[-1], up), dim=1))
-        w = self.out_conv(feat[-1])
-        if self.weight_groups > 1:
-            w = [wi[:, :oc] for wi, oc in zip(w, self.out_channels)]
-        return w
+        pyramid = [x]
+        for i in range(self.levels - 1):
+            pyramid.append(getattr(self, f'down_{i}')(pyramid[-1]))
+        if self.avg_pool and self.levels > 1 and pyramid[-1].shape[-2:] != (1, 1):
+            pyramid[-1] = F.adaptive_avg_pool2d(pyramid[-1], 1).expand_as(pyramid[-1])
+        while len(pyramid) > 1:
+            i = len(pyramid) - 2
+            coarse = getattr(self, f'up_{i}')(pyramid.pop())
+            pyramid[-1] = getattr(self, f'flat_{i}')(torch.cat((pyramid[-1], coarse), dim=1))
+        banks = self.out_conv(pyramid[0])
+        if self.weight_groups > 1:                    # drop the rows added to round up to the group count
+            banks = [t[:, :rows] for t, rows in zip(banks, self.out_channels)]
+        return banks
 
     def extra_repr(self):
         return f'in_channels={self.in_channels}, out_channels={self.out_channels}, bias={self.bias}'
 
 
-class HyperGen(nn.Module):
-    """hyperseg_v0_1.py:11-88."""
+class HyperGen(HyperGenBase):
+    """hyperseg_v0_1.py:11-88; the context head returns a LIST of per-level weight tensors.  Inference modes in HyperGenBase."""
 
     def __init__(self, backbone, weight_mapper, in_nc=3, num_classes=3, kernel_sizes=3, level_layers=1, expand_ratio=1,
                  groups=1, inference_hflip=False, inference_gather='mean', with_out_fc=False, decoder_dropout=None):
         super(HyperGen, self).__init__()
-        self.inference_hflip = inference_hflip
-        self.inference_gather = inference_gather
+        self.inference_hflip, self.inference_gather = inference_hflip, inference_gather
         self.backbone = backbone()
-        feat_channels = [in_nc] + self.backbone.feat_channels[:-1]
-        self.decoder = MultiScaleDecoder(feat_channels, 3, num_classes, kernel_sizes, level_layers,
+        taps = self.backbone.feat_channels
+        self.decoder = MultiScaleDecoder([in_nc] + taps[:-1], 3, num_classes, kernel_sizes, level_layers,
                                          with_out_fc=with_out_fc, out_kernel_size=1, expand_ratio=expand_ratio,
                                          dropout=decoder_dropout)
-        self.weight_mapper = weight_mapper(self.backbone.feat_channels[-1], self.decoder.param_groups)
-
-    @property
-    def hyper_params(self):
-        return self.decoder.hyper_params
-
-    def process_single_tensor(self, x, hflip=False):
-        x = torch.flip(x, [-1]) if hflip else x
-        features = self.backbone(x)
-        weights = self.weight_mapper(features[-1])
-        y = self.decoder([t.contiguous() for t in [x] + features[:-1]], weights)
-        return torch.flip(y, [-1]) if hflip else y
-
-    def gather_results(self, x, y=None):
-        assert x is not None
-        if y is None:
-            return x
-        return (x + y) * 0.5 if self.inference_gather == 'mean' else torch.max(x, y)
-
-    def forward(self, x):
-        assert isinstance(x, (list, tuple, torch.Tensor)), 'x must be of type list, tuple, or tensor'
-        if isinstance(x, torch.Tensor):
-            return self.process_single_tensor(x)
-        out_res = x[0].shape[2:]
-        out = None
-        for p in x:
-            if self.inference_hflip:
-                p = torch.max(self.process_single_tensor(p), self.process_single_tensor(p, hflip=True))
-            else:
-                p = self.process_single_tensor(p)
-            if p.shape[2:] != out_res:
-                p = HF.upsample_bilinear(p.contiguous(), out_res)
-            out = self.gather_results(p, out)
-        return out
+        self.weight_mapper = weight_mapper(taps[-1], self.decoder.param_groups)
 
 
 def hyperseg_efficientnet(model_name, pretrained=False, levels=3, down_groups=1, flat_groups=1, weight_groups=1,

@@ -29,6 +29,7 @@ from torch.nn.modules.utils import _pair
 
 from .. import functional as HF
 from .. import autograd as HA
+from ._common import HyperGenBase, coordinate_grid, per_level, register_coordinate_buffers
 from .layers.meta_conv import MetaConv2d, _apply_epilogue, _require_inference
 from .layers.meta_sequential import MetaSequential
 
@@ -384,17 +385,11 @@ class MultiScaleDecoder(nn.Module):
                  expand_ratio=1, groups=1, weight_groups=1, with_out_fc=False, dropout=None, coords_res=None):
         super(MultiScaleDecoder, self).__init__()
         n = len(level_channels)
-        if isinstance(kernel_sizes, numbers.Number):
-            kernel_sizes = (kernel_sizes,) * n
-        if isinstance(level_layers, numbers.Number):
-            level_layers = (level_layers,) * n
-        if isinstance(expand_ratio, numbers.Number):
-            expand_ratio = (expand_ratio,) * n
-        assert len(kernel_sizes) == n, f'kernel_sizes ({len(kernel_sizes)}) must be of size {n}'
-        assert len(level_layers) == n, f'level_layers ({len(level_layers)}) must be of size {n}'
-        assert len(expand_ratio) == n, f'expand_ratio ({len(expand_ratio)}) must be of size {n}'
+        kernel_sizes = per_level(kernel_sizes, n, 'kernel_sizes')
+        level_layers = per_level(level_layers, n, 'level_layers')
+        expand_ratio = per_level(expand_ratio, n, 'expand_ratio')
         if isinstance(groups, (list, tuple)):
-            assert len(groups) == n, f'groups ({len(groups)}) must be of size {n}'
+            per_level(groups, n, 'groups')
         self.level_layers = level_layers
         self.levels = n
         self.layer_params = []
@@ -444,13 +439,7 @@ class MultiScaleDecoder(nn.Module):
             self.param_groups.append(self.out_fc.hyper_params)
         self._ranges.append(self.hyper_params)
 
-        # coordinate buffers: kept so reference checkpoints load strictly; the kernels generate the
-        # same values analytically and never read them
-        if coords_res is not None:
-            for res in coords_res:
-                for i in range(self.levels):
-                    h, w = res[0] // 2 ** i, res[1] // 2 ** i
-                    self.register_buffer(f'coord{h}_{w}', self.cache_image_coordinates(h, w))
+        register_coordinate_buffers(self, coords_res, self.levels)      # checkpoint compatibility only
 
         hyper_params = get_hyper_params(self)
         min_unit = max(weight_groups) if isinstance(weight_groups, (list, tuple)) else weight_groups
@@ -459,15 +448,12 @@ class MultiScaleDecoder(nn.Module):
         self.hyper_params = sum(hyper_params)
 
     def cache_image_coordinates(self, h, w):
-        x = torch.linspace(-1, 1, steps=w)
-        y = torch.linspace(-1, 1, steps=h)
-        return torch.stack([x.view(1, w).expand(h, w), y.view(h, 1).expand(h, w)], dim=0).unsqueeze(0).contiguous()
+        return coordinate_grid(h, w)
 
     def get_image_coordinates(self, b, h, w, device):
-        cache = f'coord{h}_{w}'
-        if hasattr(self, cache):
-            return getattr(self, cache).expand(b, -1, -1, -1)
-        return self.cache_image_coordinates(h, w).to(device).expand(b, -1, -1, -1)
+        buf = getattr(self, f'coord{h}_{w}', None)
+        grid = buf if buf is not None else coordinate_grid(h, w, device)
+        return grid.expand(b, -1, -1, -1)
 
     def _hyper_modules(self):
         """Signal-fed modules per top-level child, in the order MetaSequential consumes weight-list entries."""
@@ -588,58 +574,22 @@ class WeightMapper(nn.Module):
         return torch.cat((feat.pop(), x), dim=1)
 
 
-class HyperGen(nn.Module):
-    """backbone -> context head -> dynamic decoder (hyperseg_v1_0.py:12-91)."""
+class HyperGen(HyperGenBase):
+    """backbone -> context head -> dynamic decoder (hyperseg_v1_0.py:12-91); inference modes in HyperGenBase."""
 
     def __init__(self, backbone, weight_mapper, in_nc=3, num_classes=3, kernel_sizes=3, level_layers=1,
                  level_channels=None, expand_ratio=1, groups=1, weight_groups=1, inference_hflip=False,
                  inference_gather='mean', with_out_fc=False, decoder_groups=1, decoder_dropout=None, coords_res=None):
         super(HyperGen, self).__init__()
-        self.inference_hflip = inference_hflip
-        self.inference_gather = inference_gather
+        self.inference_hflip, self.inference_gather = inference_hflip, inference_gather
         self.backbone = backbone()
-        feat_channels = [in_nc] + self.backbone.feat_channels[:-1]
-        self.decoder = MultiScaleDecoder(feat_channels, self.backbone.feat_channels[-1], num_classes, kernel_sizes,
-                                         level_layers, level_channels, with_out_fc=with_out_fc, out_kernel_size=1,
-                                         expand_ratio=expand_ratio, groups=decoder_groups,
-                                         weight_groups=list(weight_groups) if isinstance(weight_groups, (list, tuple))
-                                         else weight_groups,
+        taps = self.backbone.feat_channels
+        wg = list(weight_groups) if isinstance(weight_groups, (list, tuple)) else weight_groups   # the decoder pops from it
+        self.decoder = MultiScaleDecoder([in_nc] + taps[:-1], taps[-1], num_classes, kernel_sizes, level_layers,
+                                         level_channels, with_out_fc=with_out_fc, out_kernel_size=1,
+                                         expand_ratio=expand_ratio, groups=decoder_groups, weight_groups=wg,
                                          dropout=decoder_dropout, coords_res=coords_res)
-        self.weight_mapper = weight_mapper(self.backbone.feat_channels[-1], self.decoder.param_groups)
-
-    @property
-    def hyper_params(self):
-        return self.decoder.hyper_params
-
-    def process_single_tensor(self, x, hflip=False):
-        x = torch.flip(x, [-1]) if hflip else x
-        features = self.backbone(x)
-        signal = self.weight_mapper(features[-1])
-        pyramid = [t.contiguous() for t in [x] + features[:-1]]
-        y = self.decoder(pyramid, signal.contiguous())
-        return torch.flip(y, [-1]) if hflip else y
-
-    def gather_results(self, x, y=None):
-        assert x is not None
-        if y is None:
-            return x
-        return (x + y) * 0.5 if self.inference_gather == 'mean' else torch.max(x, y)
-
-    def forward(self, x):
-        assert isinstance(x, (list, tuple, torch.Tensor)), 'x must be of type list, tuple, or tensor'
-        if isinstance(x, torch.Tensor):
-            return self.process_single_tensor(x)
-        out_res = x[0].shape[2:]          # the first pyramid level sets the output resolution
-        out = None
-        for p in x:
-            if self.inference_hflip:
-                p = torch.max(self.process_single_tensor(p), self.process_single_tensor(p, hflip=True))
-            else:
-                p = self.process_single_tensor(p)
-            if p.shape[2:] != out_res:
-                p = HF.upsample_bilinear(p.contiguous(), out_res)
-            out = self.gather_results(p, out)
-        return out
+        self.weight_mapper = weight_mapper(taps[-1], self.decoder.param_groups)
 
 
 def hyperseg_efficientnet(model_name, pretrained=False, out_feat_scale=0.25, levels=3, weights_path=None, **kwargs):

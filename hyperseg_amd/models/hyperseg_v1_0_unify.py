@@ -7,7 +7,6 @@ per level (hyperseg_v1_0_unify.py:172-178, 242-249), and the level modules recei
 Here every weight layer of the decoder runs in one ``hs_signal2weights_multi_fwd`` launch and the shared bank is
 consumed in place through row-range views (no slice copies).
 """
-import numbers
 from functools import partial
 
 import torch
@@ -16,6 +15,7 @@ import torch.nn.functional as F
 
 from .. import autograd as HA
 from .. import functional as HF
+from ._common import HyperGenBase, coordinate_grid, per_level, register_coordinate_buffers
 from .hyperseg_v1_0 import (HyperPatch, HyperPatchConv2d, HyperPatchInvertedResidual, HyperPatchNoPadding,  # noqa: F401
                             WeightMapper, _SignalToWeights, divide_feature, make_hyper_patch_conv2d_block,
                             next_multiply)
@@ -77,13 +77,9 @@ class MultiScaleDecoder(nn.Module):
                  coords_res=None, unify_level=None):
         super(MultiScaleDecoder, self).__init__()
         n = len(level_channels)
-        if isinstance(kernel_sizes, numbers.Number):
-            kernel_sizes = (kernel_sizes,) * n
-        if isinstance(level_layers, numbers.Number):
-            level_layers = (level_layers,) * n
-        if isinstance(expand_ratio, numbers.Number):
-            expand_ratio = (expand_ratio,) * n
-        assert len(kernel_sizes) == n and len(level_layers) == n and len(expand_ratio) == n
+        kernel_sizes = per_level(kernel_sizes, n, 'kernel_sizes')
+        level_layers = per_level(level_layers, n, 'level_layers')
+        expand_ratio = per_level(expand_ratio, n, 'expand_ratio')
         self.level_layers = level_layers
         self.levels = n
         self.unify_level = unify_level
@@ -130,11 +126,7 @@ class MultiScaleDecoder(nn.Module):
         else:
             self.out_fc = None
 
-        if coords_res is not None:
-            for res in coords_res:
-                for i in range(self.levels):
-                    h, w = res[0] // 2 ** i, res[1] // 2 ** i
-                    self.register_buffer(f'coord{h}_{w}', self.cache_image_coordinates(h, w))
+        register_coordinate_buffers(self, coords_res, self.levels)      # checkpoint compatibility only
 
         self.param_groups = get_hyper_params(self)
         min_unit = max(weight_groups) if isinstance(weight_groups, (list, tuple)) else weight_groups
@@ -143,9 +135,7 @@ class MultiScaleDecoder(nn.Module):
         self.hyper_params = sum(self.param_groups)
 
     def cache_image_coordinates(self, h, w):
-        x = torch.linspace(-1, 1, steps=w)
-        y = torch.linspace(-1, 1, steps=h)
-        return torch.stack([x.view(1, w).expand(h, w), y.view(h, 1).expand(h, w)], dim=0).unsqueeze(0).contiguous()
+        return coordinate_grid(h, w)
 
     def _forward_autograd(self, x, s):
         """Training / gradient path: weight layers as stock grouped 1x1 convs, levels through hyperseg_amd.autograd."""
@@ -191,57 +181,23 @@ class MultiScaleDecoder(nn.Module):
         return p
 
 
-class HyperGen(nn.Module):
-    """hyperseg_v1_0_unify.py:12-93."""
+class HyperGen(HyperGenBase):
+    """hyperseg_v1_0_unify.py:12-93; inference modes in HyperGenBase."""
 
     def __init__(self, backbone, weight_mapper, in_nc=3, num_classes=3, kernel_sizes=3, level_layers=1,
                  level_channels=None, expand_ratio=1, groups=1, weight_groups=1, inference_hflip=False,
                  inference_gather='mean', with_out_fc=False, decoder_groups=1, decoder_dropout=None, coords_res=None,
                  unify_level=None):
         super(HyperGen, self).__init__()
-        self.inference_hflip = inference_hflip
-        self.inference_gather = inference_gather
+        self.inference_hflip, self.inference_gather = inference_hflip, inference_gather
         self.backbone = backbone()
-        feat_channels = [in_nc] + self.backbone.feat_channels[:-1]
+        taps = self.backbone.feat_channels
         wg = list(weight_groups) if isinstance(weight_groups, (list, tuple)) else weight_groups
-        self.decoder = MultiScaleDecoder(feat_channels, self.backbone.feat_channels[-1], num_classes, kernel_sizes,
-                                         level_layers, level_channels, with_out_fc=with_out_fc, out_kernel_size=1,
+        self.decoder = MultiScaleDecoder([in_nc] + taps[:-1], taps[-1], num_classes, kernel_sizes, level_layers,
+                                         level_channels, with_out_fc=with_out_fc, out_kernel_size=1,
                                          expand_ratio=expand_ratio, groups=decoder_groups, weight_groups=wg,
                                          dropout=decoder_dropout, coords_res=coords_res, unify_level=unify_level)
-        self.weight_mapper = weight_mapper(self.backbone.feat_channels[-1], self.decoder.param_groups)
-
-    @property
-    def hyper_params(self):
-        return self.decoder.hyper_params
-
-    def process_single_tensor(self, x, hflip=False):
-        x = torch.flip(x, [-1]) if hflip else x
-        features = self.backbone(x)
-        signal = self.weight_mapper(features[-1])
-        y = self.decoder([t.contiguous() for t in [x] + features[:-1]], signal.contiguous())
-        return torch.flip(y, [-1]) if hflip else y
-
-    def gather_results(self, x, y=None):
-        assert x is not None
-        if y is None:
-            return x
-        return (x + y) * 0.5 if self.inference_gather == 'mean' else torch.max(x, y)
-
-    def forward(self, x):
-        assert isinstance(x, (list, tuple, torch.Tensor)), 'x must be of type list, tuple, or tensor'
-        if isinstance(x, torch.Tensor):
-            return self.process_single_tensor(x)
-        out_res = x[0].shape[2:]
-        out = None
-        for p in x:
-            if self.inference_hflip:
-                p = torch.max(self.process_single_tensor(p), self.process_single_tensor(p, hflip=True))
-            else:
-                p = self.process_single_tensor(p)
-            if p.shape[2:] != out_res:
-                p = HF.upsample_bilinear(p.contiguous(), out_res)
-            out = self.gather_results(p, out)
-        return out
+        self.weight_mapper = weight_mapper(taps[-1], self.decoder.param_groups)
 
 
 def hyperseg_efficientnet(model_name, pretrained=False, out_feat_scale=0.25, levels=3, weights_path=None, **kwargs):

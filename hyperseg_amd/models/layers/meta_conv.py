@@ -4,7 +4,6 @@ The reference folds the batch into conv groups (``F.conv2d(groups=B*g)``, lines 
 per-sample dynamic convolution is simply the patch-wise kernel with a 1x1 weight grid: the (B, hp)
 weight matrix already IS a patch-major bank, so there is no re-layout at all.
 """
-import numpy as np
 import torch
 import torch.nn as nn
 from torch.nn.modules.utils import _pair
@@ -17,6 +16,26 @@ def _require_inference(*tensors):
     if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors):
         raise NotImplementedError('hyperseg_amd: this entry point is the fused inference path; gradients flow through '
                                   'hyperseg_amd.autograd (module forward in training mode)')
+
+
+PADDING_MODES = ('zeros', 'reflect', 'replicate', 'circular')
+
+
+def check_padding_mode(mode):
+    """Same ValueError the reference raises (meta_conv.py:149-151, meta_patch.py:21-24)."""
+    if mode not in PADDING_MODES:
+        raise ValueError(f"padding_mode must be one of {set(PADDING_MODES)}, but got padding_mode='{mode}'")
+    return mode
+
+
+def assemble_block(conv, out_nc, norm_layer, act_layer, dropout):
+    """conv -> norm -> activation -> dropout, each optional, as one MetaSequential (the layout of the reference's
+    ``make_meta_*_block`` factories; MetaSequential fuses conv + eval-BN + ReLU/ReLU6 into one launch)."""
+    if not (dropout is None or isinstance(dropout, float)):
+        raise AssertionError('dropout must be None or a float')
+    tail = [norm_layer(out_nc) if norm_layer is not None else None, act_layer,
+            nn.Dropout(dropout) if dropout is not None else None]
+    return MetaSequential(conv, *[m for m in tail if m is not None])
 
 
 def _apply_epilogue(y, scale, shift, act):
@@ -34,23 +53,15 @@ class MetaConv2d(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
                  padding_mode='zeros'):
         super(MetaConv2d, self).__init__()
-        if in_channels % groups != 0:
-            raise ValueError('in_channels must be divisible by groups')
-        if out_channels % groups != 0:
-            raise ValueError('out_channels must be divisible by groups')
-        valid_padding_modes = {'zeros', 'reflect', 'replicate', 'circular'}
-        if padding_mode not in valid_padding_modes:
-            raise ValueError(
-                f"padding_mode must be one of {valid_padding_modes}, but got padding_mode='{padding_mode}'")
-        self.in_channels = in_channels
-        self.out_channels = out_channels
-        self.kernel_size = _pair(kernel_size)
-        self.stride = _pair(stride)
-        self.padding = _pair(padding)
-        self.dilation = _pair(dilation)
-        self.groups = groups
-        self.padding_mode = padding_mode
-        self.hyper_params = int(np.prod((out_channels, in_channels // groups) + self.kernel_size))
+        for name, nc in (('in_channels', in_channels), ('out_channels', out_channels)):
+            if nc % groups:
+                raise ValueError(f'{name} must be divisible by groups')
+        self.padding_mode = check_padding_mode(padding_mode)
+        self.in_channels, self.out_channels, self.groups = in_channels, out_channels, groups
+        self.kernel_size, self.stride = _pair(kernel_size), _pair(stride)
+        self.padding, self.dilation = _pair(padding), _pair(dilation)
+        # rows of the weight vector one sample needs: Cout x Cin/groups x kh x kw
+        self.hyper_params = out_channels * (in_channels // groups) * self.kernel_size[0] * self.kernel_size[1]
 
     def _check_supported(self):
         kh, kw = self.kernel_size
@@ -78,29 +89,16 @@ class MetaConv2d(nn.Module):
         return self.forward_fused(x, w)
 
     def extra_repr(self):
-        s = ('{in_channels}, {out_channels}, kernel_size={kernel_size}'
-             ', stride={stride}')
-        if self.padding != (0,) * len(self.padding):
-            s += ', padding={padding}'
-        if self.dilation != (1,) * len(self.dilation):
-            s += ', dilation={dilation}'
-        if self.groups != 1:
-            s += ', groups={groups}'
-        if self.padding_mode != 'zeros':
-            s += ', padding_mode={padding_mode}'
-        return s.format(**self.__dict__)
+        parts = [str(self.in_channels), str(self.out_channels), f'kernel_size={self.kernel_size}', f'stride={self.stride}']
+        for name, default in (('padding', (0, 0)), ('dilation', (1, 1)), ('groups', 1), ('padding_mode', 'zeros')):
+            if getattr(self, name) != default:
+                parts.append(f'{name}={getattr(self, name)}')
+        return ', '.join(parts)
 
 
 def make_meta_conv2d_block(in_nc, out_nc, kernel_size=3, stride=1, padding=None, dilation=1, groups=1,
                            padding_mode='reflect', norm_layer=nn.BatchNorm2d, act_layer=nn.ReLU(True), dropout=None):
     """[MetaConv2d, norm, act, Dropout?] in a MetaSequential (meta_conv.py:202-230)."""
-    assert dropout is None or isinstance(dropout, float)
-    padding = kernel_size // 2 if padding is None else padding
-    layers = [MetaConv2d(in_nc, out_nc, kernel_size, stride, padding, dilation, groups, padding_mode)]
-    if norm_layer is not None:
-        layers.append(norm_layer(out_nc))
-    if act_layer is not None:
-        layers.append(act_layer)
-    if dropout is not None:
-        layers.append(nn.Dropout(dropout))
-    return MetaSequential(*layers)
+    pad = kernel_size // 2 if padding is None else padding
+    conv = MetaConv2d(in_nc, out_nc, kernel_size, stride, pad, dilation, groups, padding_mode)
+    return assemble_block(conv, out_nc, norm_layer, act_layer, dropout)

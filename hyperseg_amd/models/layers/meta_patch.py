@@ -11,8 +11,7 @@ import torch.nn as nn
 from torch.nn.modules.utils import _pair
 
 from ... import functional as HF
-from .meta_conv import MetaConv2d, _apply_epilogue
-from .meta_sequential import MetaSequential
+from .meta_conv import MetaConv2d, _apply_epilogue, assemble_block, check_padding_mode
 
 
 class MetaPatch(nn.Module):
@@ -21,13 +20,8 @@ class MetaPatch(nn.Module):
 
     def __init__(self, module: nn.Module, padding=0, padding_mode='reflect'):
         super(MetaPatch, self).__init__()
-        valid_padding_modes = {'zeros', 'reflect', 'replicate', 'circular'}
-        if padding_mode not in valid_padding_modes:
-            raise ValueError(
-                f"padding_mode must be one of {valid_padding_modes}, but got padding_mode='{padding_mode}'")
         self.hyper_module = module
-        self.padding = _pair(padding)
-        self.padding_mode = padding_mode
+        self.padding, self.padding_mode = _pair(padding), check_padding_mode(padding_mode)
 
     @property
     def hyper_params(self):
@@ -71,46 +65,28 @@ class MetaPatchConv2d(MetaPatch):
         conv = MetaConv2d(in_channels, out_channels, kernel_size, stride, 0, dilation, groups)
         super(MetaPatchConv2d, self).__init__(conv, padding, padding_mode)
 
-    @property
-    def in_channels(self):
-        return self.hyper_module.in_channels
-
-    @property
-    def out_channels(self):
-        return self.hyper_module.out_channels
-
-    @property
-    def kernel_size(self):
-        return self.hyper_module.kernel_size
-
-    @property
-    def groups(self):
-        return self.hyper_module.groups
+    # the wrapped conv's attributes, exposed the way the reference's subclass stores them
+    in_channels = property(lambda self: self.hyper_module.in_channels)
+    out_channels = property(lambda self: self.hyper_module.out_channels)
+    kernel_size = property(lambda self: self.hyper_module.kernel_size)
+    groups = property(lambda self: self.hyper_module.groups)
 
     def __repr__(self):
         m = self.hyper_module
-        s = f'{self.__class__.__name__}({m.in_channels}, {m.out_channels}, kernel_size={m.kernel_size}, ' \
-            f'stride={m.stride}'
+        parts = [str(m.in_channels), str(m.out_channels), f'kernel_size={m.kernel_size}', f'stride={m.stride}']
         if self.padding != (0, 0):
-            s += f', padding={self.padding}'
+            parts.append(f'padding={self.padding}')
         if m.groups != 1:
-            s += f', groups={m.groups}'
+            parts.append(f'groups={m.groups}')
         if self.padding_mode != 'zeros':
-            s += f', padding_mode={self.padding_mode}'
-        return s + ')'
+            parts.append(f'padding_mode={self.padding_mode}')
+        return f"{type(self).__name__}({', '.join(parts)})"
 
 
 def make_meta_patch_conv2d_block(in_nc, out_nc, kernel_size=3, stride=1, padding=None, dilation=1, groups=1,
                                  padding_mode='reflect', norm_layer=nn.BatchNorm2d, act_layer=nn.ReLU(True),
                                  dropout=None):
     """[MetaPatchConv2d, norm, act, Dropout?] in a MetaSequential (meta_patch.py:228-257)."""
-    assert dropout is None or isinstance(dropout, float)
-    padding = kernel_size // 2 if padding is None else padding
-    layers = [MetaPatchConv2d(in_nc, out_nc, kernel_size, stride, padding, dilation, groups, padding_mode)]
-    if norm_layer is not None:
-        layers.append(norm_layer(out_nc))
-    if act_layer is not None:
-        layers.append(act_layer)
-    if dropout is not None:
-        layers.append(nn.Dropout(dropout))
-    return MetaSequential(*layers)
+    pad = kernel_size // 2 if padding is None else padding
+    conv = MetaPatchConv2d(in_nc, out_nc, kernel_size, stride, pad, dilation, groups, padding_mode)
+    return assemble_block(conv, out_nc, norm_layer, act_layer, dropout)
