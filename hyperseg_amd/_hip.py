@@ -64,11 +64,11 @@ def _load():
         'hs_stage_input_fwd': ([C.POINTER(StageInputC), vp, vp], C.c_int),
         'hs_patch_conv_bwd_input': ([vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp], C.c_int),
         'hs_patch_conv_bwd_weight': ([vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, vp], C.c_int),
-        'hs_depthwise_conv_fwd': ([vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp], C.c_int),
+        'hs_depthwise_conv_fwd': ([vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp], C.c_int),
         'hs_pointwise_conv_fwd': ([vp, i32, i32, i32, vp, i32, vp, vp, vp, i32, vp, vp, vp], C.c_int),
         'hs_affine_act_fwd': ([vp, i32, i32, i32, vp, vp, i32, vp, vp, vp], C.c_int),
         'hs_depthwise_pool_blocks': ([i32, i32], C.c_int),
-        'hs_se_gate_fwd': ([vp, i32, i32, i32, C.c_float, vp, vp, i32, vp, vp, vp, vp, i32, vp, vp], C.c_int),
+        'hs_se_gate_fwd': ([vp, i32, i32, i32, C.c_float, vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp], C.c_int),
     }
     for name, (argtypes, restype) in sig.items():
         fn = getattr(lib, name)          # AttributeError here = the .so does not match the header

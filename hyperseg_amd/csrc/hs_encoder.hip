@@ -18,9 +18,14 @@ template <int K, int S>
 __global__ __launch_bounds__(256)
 void depthwise_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
                            const float* __restrict__ shift, float* __restrict__ y, int C, int H, int W, int Ho, int Wo,
-                           int pad_t, int pad_l, int act, float* __restrict__ pool_partial) {
+                           int pad_t, int pad_l, int act, float* __restrict__ pool_partial,
+                           const float* __restrict__ in_scale, const float* __restrict__ in_shift) {
     const int plane = blockIdx.y;                        // b*C + c
     const int c = plane % C;
+    // optional prologue: the taps are swish(in_scale[c] * x + in_shift[c]) -- the BatchNorm + swish of the 1x1 expand
+    // convolution that produced x, applied on load so that the raw GEMM output needs no elementwise pass of its own
+    const bool pre = in_scale != nullptr;
+    const float isc = pre ? in_scale[c] : 1.0f, ish = pre ? in_shift[c] : 0.0f;
     const int wq = (Wo + 3) >> 2;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = q < Ho * wq;
@@ -42,7 +47,8 @@ void depthwise_conv_kernel(const float* __restrict__ x, const float* __restrict_
         for (int j = 0; j < NCOL; ++j) {
             const int xi = xi0 + j;
             const bool ok = row_ok && xi >= 0 && xi < W;
-            const float t = row[ok ? xi : 0];
+            float t = row[ok ? xi : 0];
+            if (pre) { t = fmaf(t, isc, ish); t = t / (1.0f + expf(-t)); }
             v[j] = ok ? t : 0.0f;
         }
 #pragma unroll
@@ -83,108 +89,89 @@ void depthwise_conv_kernel(const float* __restrict__ x, const float* __restrict_
     }
 }
 
-// Squeeze-excite gate of one MBConv block from the pooled partial sums: pooled -> 1x1 reduce + swish -> 1x1 expand ->
-// sigmoid, one workgroup per batch element.  With w_proj != NULL the gate is folded into the block's project
-// convolution, w_scaled[b, o, c] = w_proj[o, c] * gate[b, c]: scaling ~1e5 weights replaces a full elementwise pass over
-// the (up to 100 MB) activation.  Replaces adaptive_avg_pool2d + 2 convs + swish + sigmoid + mul
-// (hyperseg/models/backbones/efficientnet.py:106-111).
-__global__ __launch_bounds__(1024)
-void se_gate_kernel(const float* __restrict__ partial, int nblk, float inv_hw, const float* __restrict__ w1,
-                    const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2, int C, int Csq,
-                    float* __restrict__ gate) {
-    extern __shared__ float sm[];            // pooled[C] | z[Csq] | gate[C]
-    float* pooled = sm; float* z = sm + C; float* g = z + Csq;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
-    // 1. pooled[c] = mean: one wave per channel, 4 channels' loads in flight per step (few waves, so ILP hides latency)
-    if (nblk <= 16) {
-        // few partials per plane (late, small feature maps with many channels): one thread per channel, all of its
-        // partials loaded at once -- a wave-per-channel walk would pay one memory round trip per 4 channels
-        for (int c = tid; c < C; c += blockDim.x) {
-            const float* __restrict__ p = partial + ((size_t)b * C + c) * nblk;
-            float v[16];
+// Squeeze-excite gate of one MBConv block from the pooled partial sums, as TWO multi-workgroup launches that each
+// make a single trip to memory (the first version was one workgroup walking pool -> reduce -> expand serially: three
+// dependent load phases and up to 1.2 MB of weights through one CU, 14 us per block):
+//
+//   se_squeeze_kernel  grid (Csq, B): z[b,j] = swish(b1[j] + (1/HW) * sum_{c,i} w1[j,c] * partial[b,c,i])
+//       the average pool and the 1x1 reduce conv are one dot product over the flattened (c, i) partials -- the w1 gather
+//       index depends only on the element index, so partials and weights are all in flight together.
+//   se_excite_kernel   grid (ceil(C/64), B, ceil(Cout/64)): gate[b,c] = sigmoid(b2[c] + sum_j w2t[j,c] * z[b,j]) for a
+//       strip of 64 channels (4 waves each take a quarter of j), then w_scaled[b,o,c] = w_proj[o,c] * gate[b,c]
+//       (* out_scale[o]) for 64 rows of the strip: the gate (and optionally the project conv's BatchNorm scale) folded
+//       into the project weights -- scaling ~1e5 weights replaces an elementwise pass over the activation.
+// Replaces adaptive_avg_pool2d + 2 convs + swish + sigmoid + mul (hyperseg/models/backbones/efficientnet.py:106-111).
+__global__ __launch_bounds__(256)
+void se_squeeze_kernel(const float* __restrict__ partial, int nblk, float inv_hw, const float* __restrict__ w1,
+                       const float* __restrict__ b1, int C, int Csq, float* __restrict__ z) {
+    const int j = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int n = C * nblk;
+    const float* __restrict__ p = partial + (size_t)b * n;
+    const float* __restrict__ wr = w1 + (size_t)j * C;
+    float acc = 0.0f;
+    for (int e0 = tid; e0 < n; e0 += 256 * 8) {
+        float pv[8], wv[8];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = p[i < nblk ? i : nblk - 1];
-            float t = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if (i < nblk) t += v[i];
-            pooled[c] = t * inv_hw;
+        for (int u = 0; u < 8; ++u) {
+            const int e = min(e0 + 256 * u, n - 1);
+            pv[u] = p[e];
+            wv[u] = wr[e / nblk];
         }
-    } else {
-        for (int c0 = wave * 4; c0 < C; c0 += nwave * 4) {
-            float v[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c = c0 + q < C ? c0 + q : C - 1;
-                const float* __restrict__ p = partial + ((size_t)b * C + c) * nblk;
-                float t = 0.0f;
-                for (int i = lane; i < nblk; i += 64) t += p[i];
-                v[q] = t;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float t = v[q];
-                for (int m = 32; m > 0; m >>= 1) t += __shfl_xor(t, m, 64);
-                if (lane == 0 && c0 + q < C) pooled[c0 + q] = t * inv_hw;
-            }
-        }
+        for (int u = 0; u < 8; ++u)
+            if (e0 + 256 * u < n) acc = fmaf(pv[u], wv[u], acc);
     }
+    __shared__ float ws[4];
+    for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    if ((tid & 63) == 0) ws[tid >> 6] = acc;
     __syncthreads();
-    // 2. z = swish(W1 pooled + b1): one wave per squeezed channel, two channels in flight per step
-    for (int j0 = wave * 2; j0 < Csq; j0 += nwave * 2) {
-        float t[2] = {0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int j = j0 + q < Csq ? j0 + q : Csq - 1;
-            const float* __restrict__ wr = w1 + (size_t)j * C;
-            for (int c0 = lane; c0 < C; c0 += 64 * 8) {             // 8 independent loads in flight per lane
-                float wv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) wv[u] = wr[min(c0 + 64 * u, C - 1)];
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (c0 + 64 * u < C) t[q] = fmaf(wv[u], pooled[c0 + 64 * u], t[q]);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            float u = t[q];
-            for (int m = 32; m > 0; m >>= 1) u += __shfl_xor(u, m, 64);
-            if (lane == 0 && j0 + q < Csq) { u += b1[j0 + q]; z[j0 + q] = u / (1.0f + expf(-u)); }
-        }
-    }
-    __syncthreads();
-    // 3. gate = sigmoid(W2 z + b2)
-    for (int c = tid; c < C; c += blockDim.x) {
-        float t = b2[c];                       // w2 is the expand weight TRANSPOSED to (Csq, C): coalesced over c
-        for (int j0 = 0; j0 < Csq; j0 += 8) {  // 8 independent loads in flight per thread
-            float wv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) wv[u] = w2[(size_t)min(j0 + u, Csq - 1) * C + c];
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (j0 + u < Csq) t = fmaf(wv[u], z[j0 + u], t);
-        }
-        const float gv = 1.0f / (1.0f + expf(-t));
-        g[c] = gv;
-        gate[(size_t)b * C + c] = gv;
+    if (tid == 0) {
+        const float t = fmaf((ws[0] + ws[1]) + (ws[2] + ws[3]), inv_hw, b1[j]);
+        z[(size_t)b * Csq + j] = t / (1.0f + expf(-t));
     }
 }
 
-// w_scaled[b, o, c] = w_proj[o, c] * gate[b, c]  (the SE gate folded into the 1x1 project convolution)
 __global__ __launch_bounds__(256)
-void scale_weights_kernel(const float* __restrict__ w_proj, const float* __restrict__ gate, int C, size_t n,
-                          float* __restrict__ w_scaled) {
-    const int b = blockIdx.y;
-    const size_t e0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (e0 >= n) return;
-    const float* __restrict__ g = gate + (size_t)b * C;
-    if (e0 + 3 < n && (C & 3) == 0) {       // rows are multiples of 4 long: a float4 never straddles two rows
-        const float4 w = *reinterpret_cast<const float4*>(w_proj + e0);
-        const float4 gv = *reinterpret_cast<const float4*>(g + (e0 % C));
-        *reinterpret_cast<float4*>(w_scaled + (size_t)b * n + e0) = make_float4(w.x * gv.x, w.y * gv.y, w.z * gv.z, w.w * gv.w);
-    } else {
-        for (size_t e = e0; e < n && e < e0 + 4; ++e) w_scaled[(size_t)b * n + e] = w_proj[e] * g[e % C];
+void se_excite_kernel(const float* __restrict__ z, const float* __restrict__ w2t, const float* __restrict__ b2, int C,
+                      int Csq, float* __restrict__ gate, const float* __restrict__ w_proj, int Cout,
+                      const float* __restrict__ out_scale, float* __restrict__ w_scaled) {
+    const int b = blockIdx.y, tid = threadIdx.x, col = tid & 63, part = tid >> 6;
+    const int c = blockIdx.x * 64 + col, cc = min(c, C - 1);
+    const int o0 = blockIdx.z * 64 + part * 16;
+    // project-weight rows of this thread: issued before the gate so that both sets of loads share one round trip
+    float wp[16];
+    if (w_proj) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wp[r] = w_proj[(size_t)min(o0 + r, Cout - 1) * C + cc];
+    }
+    const int jq = (Csq + 3) >> 2, j0 = part * jq, j1 = min(j0 + jq, Csq);
+    const float* __restrict__ zb = z + (size_t)b * Csq;
+    float acc = 0.0f;
+    for (int jb = j0; jb < j1; jb += 8) {
+        float wv[8], zv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = min(jb + u, Csq - 1);
+            wv[u] = w2t[(size_t)j * C + cc];
+            zv[u] = zb[j];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (jb + u < j1) acc = fmaf(wv[u], zv[u], acc);
+    }
+    __shared__ float red[4][64];
+    red[part][col] = acc;
+    __syncthreads();
+    const float t = ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) + b2[cc];
+    const float g = 1.0f / (1.0f + expf(-t));
+    if (blockIdx.z == 0 && part == 0 && c < C) gate[(size_t)b * C + c] = g;
+    if (w_proj && c < C) {
+        float* __restrict__ dst = w_scaled + (size_t)b * Cout * C + c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = o0 + r;
+            if (o < Cout) dst[(size_t)o * C] = wp[r] * g * (out_scale ? out_scale[o] : 1.0f);
+        }
     }
 }
 
@@ -195,7 +182,9 @@ using namespace hs;
 extern "C" int hs_depthwise_conv_fwd(const float* x, int32_t batch, int32_t channels, int32_t H, int32_t W,
                                      const float* w, int32_t k, int32_t stride, int32_t pad_t, int32_t pad_l,
                                      int32_t Ho, int32_t Wo, const float* scale, const float* shift, int32_t act,
-                                     float* y, float* pool_partial, void* stream) {
+                                     float* y, float* pool_partial, const float* in_scale, const float* in_shift,
+                                     void* stream) {
+    if ((in_scale != nullptr) != (in_shift != nullptr)) return HS_ERR_BAD_ARG;
     if (!x || !w || !y || batch <= 0 || channels <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return HS_ERR_BAD_ARG;
     if (pad_t < 0 || pad_l < 0 || (scale && !shift)) return HS_ERR_BAD_ARG;
     if ((long)batch * channels > 65535) return HS_ERR_UNSUPPORTED;
@@ -204,7 +193,7 @@ extern "C" int hs_depthwise_conv_fwd(const float* x, int32_t batch, int32_t chan
     dim3 grid((quads + threads - 1) / threads, batch * channels);
     hipStream_t s = (hipStream_t)stream;
 #define HS_DW(KK, SS) hipLaunchKernelGGL((depthwise_conv_kernel<KK, SS>), grid, dim3(threads), 0, s, x, w, scale, shift, y, \
-                                         channels, H, W, Ho, Wo, pad_t, pad_l, act, pool_partial)
+                                         channels, H, W, Ho, Wo, pad_t, pad_l, act, pool_partial, in_scale, in_shift)
     if (k == 3 && stride == 1) HS_DW(3, 1);
     else if (k == 3 && stride == 2) HS_DW(3, 2);
     else if (k == 5 && stride == 1) HS_DW(5, 1);
@@ -222,20 +211,20 @@ extern "C" int hs_depthwise_pool_blocks(int32_t Ho, int32_t Wo) {
 
 extern "C" int hs_se_gate_fwd(const float* partial, int32_t batch, int32_t channels, int32_t nblk, float inv_hw,
                               const float* w_reduce, const float* b_reduce, int32_t c_squeezed, const float* w_expand,
-                              const float* b_expand, float* gate, const float* w_proj, int32_t c_out, float* w_scaled,
-                              void* stream) {
-    if (!partial || !w_reduce || !b_reduce || !w_expand || !b_expand || !gate || batch <= 0 || channels <= 0 || nblk <= 0 ||
-        c_squeezed <= 0) return HS_ERR_BAD_ARG;
-    if ((w_proj != nullptr) != (w_scaled != nullptr) || (w_proj && c_out <= 0)) return HS_ERR_BAD_ARG;
-    const size_t lds = (size_t)(2 * channels + c_squeezed) * sizeof(float);
-    if (lds > 64 * 1024) return HS_ERR_LDS;
-    hipLaunchKernelGGL(se_gate_kernel, dim3(batch), dim3(1024), lds, (hipStream_t)stream, partial, nblk, inv_hw, w_reduce,
-                       b_reduce, w_expand, b_expand, channels, c_squeezed, gate);
+                              const float* b_expand, float* squeezed, float* gate, const float* w_proj, int32_t c_out,
+                              const float* out_scale, float* w_scaled, void* stream) {
+    if (!partial || !w_reduce || !b_reduce || !w_expand || !b_expand || !squeezed || !gate || batch <= 0 || channels <= 0 ||
+        nblk <= 0 || c_squeezed <= 0) return HS_ERR_BAD_ARG;
+    if ((w_proj != nullptr) != (w_scaled != nullptr) || (w_proj && c_out <= 0) || (out_scale && !w_proj)) return HS_ERR_BAD_ARG;
+    if (batch > 65535 || c_squeezed > 65535) return HS_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(se_squeeze_kernel, dim3(c_squeezed, batch), dim3(256), 0, s, partial, nblk, inv_hw, w_reduce,
+                       b_reduce, channels, c_squeezed, squeezed);
     int st = launch_status();
-    if (st != HS_OK || !w_proj) return st;
-    const size_t n = (size_t)c_out * channels;
-    hipLaunchKernelGGL(scale_weights_kernel, dim3((unsigned)((n / 4 + 255) / 256 + 1), batch), dim3(256), 0,
-                       (hipStream_t)stream, w_proj, gate, channels, n, w_scaled);
+    if (st != HS_OK) return st;
+    const int row_groups = w_proj ? (c_out + 63) / 64 : 1;
+    hipLaunchKernelGGL(se_excite_kernel, dim3((channels + 63) / 64, batch, row_groups), dim3(256), 0, s, squeezed, w_expand,
+                       b_expand, channels, c_squeezed, gate, w_proj, c_out, out_scale, w_scaled);
     return launch_status();
 }
 
@@ -344,7 +333,7 @@ void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ sc
     const int pq = P >> 2;                     // P % 4 == 0 (checked by the host)
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)((e / pq) % C);
-        const float sc = scale[c], sh = shift[c];
+        const float sc = scale ? scale[c] : 1.0f, sh = shift[c];
         const float4 v = reinterpret_cast<const float4*>(x)[e];
         float o[4] = {fmaf(v.x, sc, sh), fmaf(v.y, sc, sh), fmaf(v.z, sc, sh), fmaf(v.w, sc, sh)};
 #pragma unroll
@@ -360,7 +349,7 @@ void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ sc
 
 extern "C" int hs_affine_act_fwd(const float* x, int32_t batch, int32_t channels, int32_t pixels, const float* scale,
                                  const float* shift, int32_t act, const float* residual, float* y, void* stream) {
-    if (!x || !y || !scale || !shift || batch <= 0 || channels <= 0 || pixels <= 0) return HS_ERR_BAD_ARG;
+    if (!x || !y || !shift || batch <= 0 || channels <= 0 || pixels <= 0) return HS_ERR_BAD_ARG;
     if (pixels & 3) return HS_ERR_UNSUPPORTED;
     const size_t n4 = (size_t)batch * channels * pixels / 4;
     const unsigned blocks = (unsigned)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256);

@@ -240,10 +240,12 @@ def patch_ir(x, grid, bank, hidden, c_out, bn1, bn2, bn3, residual=False):
     return y
 
 
-def depthwise_conv_bn_act(x, weight, stride, pad_top, pad_left, out_size, scale=None, shift=None, act=0, pool=False):
+def depthwise_conv_bn_act(x, weight, stride, pad_top, pad_left, out_size, scale=None, shift=None, act=0, pool=False,
+                          in_scale=None, in_shift=None):
     """Depthwise conv (k 3|5, stride 1|2, TF-"SAME" zero padding given as top/left offsets) + affine + activation
     (3 = swish) in one launch.  ``pool=True`` also returns the per-workgroup partial sums of the outputs (B*C, nblk)
-    for :func:`se_gate`.  Encoder-side helper, opt-in (utils/inference.py)."""
+    for :func:`se_gate`.  ``in_scale``/``in_shift`` (C): the taps are swish(in_scale*x + in_shift) -- x is then the RAW
+    output of the 1x1 expand GEMM.  Encoder-side helper, opt-in (utils/inference.py)."""
     b, c, h, w = x.shape
     k = weight.shape[-1]
     ho, wo = out_size
@@ -255,7 +257,10 @@ def depthwise_conv_bn_act(x, weight, stride, pad_top, pad_left, out_size, scale=
                                         pad_top, pad_left, ho, wo,
                                         _hip.dev_ptr(scale, 'scale') if scale is not None else None,
                                         _hip.dev_ptr(shift, 'shift') if shift is not None else None, int(act),
-                                        y.data_ptr(), partial.data_ptr() if pool else None, _hip.stream_ptr())
+                                        y.data_ptr(), partial.data_ptr() if pool else None,
+                                        _hip.dev_ptr(in_scale, 'in_scale') if in_scale is not None else None,
+                                        _hip.dev_ptr(in_shift, 'in_shift') if in_shift is not None else None,
+                                        _hip.stream_ptr())
     _hip.check(st, 'hs_depthwise_conv_fwd')
     return (y, partial) if pool else y
 
@@ -274,9 +279,11 @@ def pointwise_conv(x, weight, gate=None, scale=None, shift=None, act=0, residual
 
 
 def affine_act_(x, scale, shift, act=0, residual=None):
-    """In place: x = act(scale[c]*x + shift[c]) + residual  (folded BN + activation + skip add, one launch)."""
+    """In place: x = act(scale[c]*x + shift[c]) + residual  (folded BN + activation + skip add, one launch);
+    ``scale=None`` means 1."""
     b, c, h, w = x.shape
-    st = _hip.lib.hs_affine_act_fwd(_hip.dev_ptr(x, 'x'), b, c, h * w, _hip.dev_ptr(scale, 'scale'),
+    st = _hip.lib.hs_affine_act_fwd(_hip.dev_ptr(x, 'x'), b, c, h * w,
+                                    _hip.dev_ptr(scale, 'scale') if scale is not None else None,
                                     _hip.dev_ptr(shift, 'shift'), int(act),
                                     _hip.dev_ptr(residual, 'residual') if residual is not None else None, x.data_ptr(),
                                     _hip.stream_ptr())
@@ -284,23 +291,28 @@ def affine_act_(x, scale, shift, act=0, residual=None):
     return x
 
 
-def se_gate(partial, batch, hw, w_reduce, b_reduce, w_expand, b_expand, w_proj=None):
-    """Squeeze-excite gate from pooled partial sums; with ``w_proj`` (Cout, C[,1,1]) returns the project weights
-    scaled by the gate, (B, Cout, C, 1, 1); otherwise the gate (B, C)."""
+def se_gate(partial, batch, hw, w_reduce, b_reduce, w_expand, b_expand, w_proj=None, out_scale=None):
+    """Squeeze-excite gate from pooled partial sums (two launches); with ``w_proj`` (Cout, C[,1,1]) returns the project
+    weights scaled by the gate (and by ``out_scale`` (Cout), the project conv's folded BN scale), (B, Cout, C, 1, 1);
+    otherwise the gate (B, C)."""
     c = partial.shape[0] // batch
     csq = w_reduce.shape[0]
     dev = partial.device
     w_scaled = None
     cout = 0
-    gate = torch.empty(batch, c, device=dev, dtype=torch.float32)
+    work = torch.empty(batch, c + csq, device=dev, dtype=torch.float32)      # gate | squeezed activations
+    gate, squeezed = work[:, :c], work[:, c:]
+    if batch > 1:
+        gate, squeezed = torch.empty(batch, c, device=dev), torch.empty(batch, csq, device=dev)
     if w_proj is not None:
         cout = w_proj.shape[0]
         w_scaled = torch.empty(batch, cout, c, 1, 1, device=dev, dtype=torch.float32)
     st = _hip.lib.hs_se_gate_fwd(_hip.dev_ptr(partial, 'partial'), batch, c, partial.shape[1], 1.0 / float(hw),
                                  _hip.dev_ptr(w_reduce, 'w_reduce'), _hip.dev_ptr(b_reduce, 'b_reduce'), csq,
                                  _hip.dev_ptr(w_expand, 'w_expand'), _hip.dev_ptr(b_expand, 'b_expand'),
-                                 gate.data_ptr(),
+                                 squeezed.data_ptr(), gate.data_ptr(),
                                  _hip.dev_ptr(w_proj, 'w_proj') if w_proj is not None else None, cout,
+                                 _hip.dev_ptr(out_scale, 'out_scale') if out_scale is not None else None,
                                  w_scaled.data_ptr() if w_scaled is not None else None, _hip.stream_ptr())
     _hip.check(st, 'hs_se_gate_fwd')
     return w_scaled if w_proj is not None else gate

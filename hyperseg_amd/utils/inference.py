@@ -65,26 +65,39 @@ class FusedPointwise(nn.Module):
         self._conv = [conv]
         self.act = act
 
+    @property
+    def conv(self):
+        return self._conv[0]
+
+    @torch.no_grad()
+    def absorb_input_offset(self, offset):
+        """The input arrives as x - offset (a per-channel constant its producer did not add, see FusedMBConv): a 1x1
+        conv is linear, so the missing term is a constant per output channel -- fold it into the BN shift."""
+        w = self.conv.weight.detach().flatten(1).to(offset.device)
+        self.shift.add_(self.scale * (w @ offset))
+
     def uses_mfma(self, x):
         """Small-K, many-pixel layers run as one fused MFMA GEMM; large-K layers keep the stock (rocBLAS) GEMM."""
         return x.shape[1] <= 96 and x.shape[2] * x.shape[3] >= 8192
 
-    def forward(self, x, gate=None, residual=None, w_scaled=None):
-        """``gate`` (B, Cin): SE gate applied to the input (MFMA path), or ``w_scaled`` (Cout, Cin, 1, 1): the conv
-        weights with the gate already folded in (stock-GEMM path, batch 1).  The stock GEMM is followed by ONE fused
+    def raw(self, x):
+        """The bare GEMM (batch 1): W (Cout, Cin) @ x (Cin, HW); BN + activation are left to the consumer."""
+        _, cin, h, w = x.shape
+        return torch.mm(self.conv.weight.view(-1, cin), x.view(cin, h * w)).view(1, -1, h, w)
+
+    def forward(self, x, gate=None, residual=None):
+        """``gate`` (B, Cin): SE gate applied to the input.  Non-MFMA shapes: stock GEMM followed by ONE fused
         BatchNorm + activation + skip-add launch."""
         import torch.nn.functional as F
         from .. import functional as HF
-        conv = self._conv[0]
+        conv = self.conv
         x = x.contiguous()
         b, cin, h, w = x.shape
-        if self.uses_mfma(x) and w_scaled is None:
+        if self.uses_mfma(x):
             return HF.pointwise_conv(x, conv.weight, gate, self.scale, self.shift, self.act, residual)
         if (h * w) % 4 != 0:
             raise NotImplementedError('feature maps with H*W % 4 != 0')
-        if w_scaled is not None:
-            y = F.conv2d(x, w_scaled)
-        elif gate is None:
+        if gate is None:
             y = F.conv2d(x, conv.weight)
         else:
             y = F.conv2d(x * gate[:, :, None, None], conv.weight)
@@ -92,11 +105,22 @@ class FusedPointwise(nn.Module):
 
 
 class FusedMBConv(nn.Module):
-    """A whole MBConv block in 4 HIP launches: [1x1 expand + BN + swish] -> [depthwise + BN + swish + SE pooling] ->
-    [SE gate] -> [gate * 1x1 project + BN + skip add]  (stock: 15 launches; MIOpen has no tuned fp32 depthwise solver on
-    ROCm 7.2 -- Winograd-per-group / naive kernels cost half of the frame).  Filters stay the block's own parameters."""
+    """A whole MBConv block in 5 launches (stock: 15; MIOpen has no tuned fp32 depthwise solver on ROCm 7.2 -- its
+    Winograd-per-group / naive kernels cost half of the frame).  Filters stay the block's own parameters.
 
-    def __init__(self, blk):
+    Early blocks (few channels, many pixels; any batch):
+        [1x1 expand + BN + swish: MFMA] -> [depthwise + BN + swish + SE pooling] -> [SE squeeze] -> [SE excite] ->
+        [gate * 1x1 project + BN + skip: MFMA]
+    Late blocks (many channels, few pixels; batch 1): the 1x1 convs are plain library GEMMs with NOTHING after them --
+        [expand GEMM, raw] -> [depthwise: BN0 + swish applied to the taps on load, + BN1 + swish + SE pooling] ->
+        [SE squeeze] -> [SE excite + gate and BN2 scale folded into the project weights] ->
+        [project GEMM, accumulating onto the skip tensor in place (beta = 1)]
+      The BN2 shift is a per-channel constant; when every consumer of the block's output is a 1x1 conv (the next block's
+      expand, the feature reducer, the head) it is not added at all: the block stores ``y - out_offset`` and the consumers
+      fold ``W @ out_offset`` into their own BN shift (``absorb_input_offset``), exactly, offline.
+    """
+
+    def __init__(self, blk, in_offset=None, defer_shift=False):
         super().__init__()
         conv = blk._depthwise_conv
         self.expand = FusedPointwise(blk._expand_conv, blk._bn0, act=3) if blk.expand != 1 else None
@@ -113,27 +137,91 @@ class FusedMBConv(nn.Module):
             self.pad_h, self.pad_w = 2 * conv.padding[0], 2 * conv.padding[1]
         self.skip = blk.stride == 1 and blk.in_f == blk.out_f
         self._exp_t = None                       # (Csq, C) transposed SE expand weight, built on first use
+        # constant-offset bookkeeping (see the class docstring)
+        if in_offset is not None:
+            assert self.expand is not None, 'a depthwise conv cannot consume an offset tensor (zero padding)'
+            self.expand.absorb_input_offset(in_offset)
+        with torch.no_grad():
+            carried = self.project.shift.clone()
+            if self.skip and in_offset is not None:
+                carried += in_offset.to(carried.device)          # the skip tensor is short of in_offset as well
+            self.defer_shift = bool(defer_shift)
+            self.out_offset = carried.clone() if defer_shift else None
+            self.project.shift.copy_(torch.zeros_like(carried) if defer_shift else carried)
 
     def forward(self, inputs, blk):
         from .. import functional as HF
         x = inputs.contiguous()
+        b = x.shape[0]
+        lean = b == 1                             # library GEMMs with nothing around them
+        in_scale = in_shift = None
         if self.expand is not None:
-            x = self.expand(x)
-        b, _, h, w = x.shape
+            if lean and not self.expand.uses_mfma(x):
+                in_scale, in_shift = self.expand.scale, self.expand.shift
+                x = self.expand.raw(x)
+            else:
+                x = self.expand(x)
+        _, _, h, w = x.shape
         ho = (h + self.pad_h - self.k) // self.stride + 1
         wo = (w + self.pad_w - self.k) // self.stride + 1
         y, partial = HF.depthwise_conv_bn_act(x, blk._depthwise_conv.weight, self.stride, self.pad_t, self.pad_l,
-                                              (ho, wo), self.scale, self.shift, act=3, pool=True)
+                                              (ho, wo), self.scale, self.shift, act=3, pool=True,
+                                              in_scale=in_scale, in_shift=in_shift)
         red, exp = blk._se_reduce, blk._se_expand
         if self._exp_t is None or self._exp_t.device != x.device:
             self._exp_t = exp.weight.detach().flatten(1).t().contiguous()
         skip = inputs.contiguous() if self.skip else None
-        if b == 1 and not self.project.uses_mfma(y):
-            # large K: gate folded into the project weights (tiny kernel) instead of an elementwise pass over y
-            wp = HF.se_gate(partial, 1, ho * wo, red.weight, red.bias, self._exp_t, exp.bias, w_proj=blk._project_conv.weight)
-            return self.project(y, residual=skip, w_scaled=wp[0])
+        proj = self.project
+        if lean and not proj.uses_mfma(y):
+            # gate (and BN2 scale) folded into the project weights by the SE kernel: ~1e5 weights instead of a pass over y
+            wp = HF.se_gate(partial, 1, ho * wo, red.weight, red.bias, self._exp_t, exp.bias,
+                            w_proj=proj.conv.weight, out_scale=proj.scale)
+            cmid = y.shape[1]
+            w2d, y2d = wp.view(-1, cmid), y.view(cmid, ho * wo)
+            if self.defer_shift:
+                if skip is None:
+                    return torch.mm(w2d, y2d).view(1, -1, ho, wo)
+                skip.view(-1, ho * wo).addmm_(w2d, y2d)          # in place: the block input has no other consumer
+                return skip
+            out = torch.mm(w2d, y2d).view(1, -1, ho, wo)
+            return HF.affine_act_(out, None, proj.shift, 0, skip)
         gate = HF.se_gate(partial, b, ho * wo, red.weight, red.bias, self._exp_t, exp.bias)
-        return self.project(y, gate=gate, residual=skip)
+        return proj(y, gate=gate, residual=skip)
+
+
+def _fuse_backbone(bb):
+    """Swap every MBConv block, the head conv and the feature reducers of an EfficientNet for their fused forms, threading
+    the deferred-BN-shift offsets (FusedMBConv docstring) from producer to consumers."""
+    blocks = list(bb._blocks)
+    offset, tap = None, 0
+    bb._fused_fc = nn.ModuleDict()
+    for idx, blk in enumerate(blocks):
+        conv = blk._depthwise_conv
+        ok = conv.kernel_size[0] in (3, 5) and conv.stride[0] in (1, 2) and isinstance(blk._bn1, nn.BatchNorm2d)
+        tapped = bb._res_feat_mask[idx]
+        fc = getattr(bb, f'_feat_fc_{tap}', None) if (tapped and bb.out_feat_scale is not None) else None
+        if ok:
+            nxt = blocks[idx + 1] if idx + 1 < len(blocks) else None
+            nxt_ok = nxt is None or (nxt.expand != 1 and nxt._depthwise_conv.kernel_size[0] in (3, 5)
+                                     and isinstance(nxt._bn1, nn.BatchNorm2d))
+            # every consumer of the output must be a 1x1 conv we control: next block's expand (or the head), the reducer
+            defer = nxt_ok and (not tapped or isinstance(fc, nn.Sequential))
+            blk._fused_dw = FusedMBConv(blk, in_offset=offset, defer_shift=defer)
+            offset = blk._fused_dw.out_offset
+        else:
+            assert offset is None
+        if tapped:
+            if isinstance(fc, nn.Sequential):
+                fused = FusedPointwise(fc[0], fc[1], act=0)
+                if offset is not None:
+                    fused.absorb_input_offset(offset)
+                bb._fused_fc[str(tap)] = fused
+            else:
+                assert offset is None
+            tap += 1
+    bb._fused_head = FusedPointwise(bb._conv_head, bb._bn1, act=3)
+    if offset is not None:
+        bb._fused_head.absorb_input_offset(offset)
 
 
 def prepare_for_inference(model, fold_bn=True, channels_last=False, fused_depthwise=False):
@@ -145,17 +233,7 @@ def prepare_for_inference(model, fold_bn=True, channels_last=False, fused_depthw
     assert not model.training, 'call model.eval() first'
     folded = 0
     if fused_depthwise:
-        bb = model.backbone
-        for blk in bb._blocks:
-            conv = blk._depthwise_conv
-            if conv.kernel_size[0] in (3, 5) and conv.stride[0] in (1, 2) and isinstance(blk._bn1, nn.BatchNorm2d):
-                blk._fused_dw = FusedMBConv(blk)
-        bb._fused_head = FusedPointwise(bb._conv_head, bb._bn1, act=3)
-        bb._fused_fc = nn.ModuleDict()
-        for i in range(len(bb.feat_channels) - 1):
-            fc = getattr(bb, f'_feat_fc_{i}', None)
-            if isinstance(fc, nn.Sequential):
-                bb._fused_fc[str(i)] = FusedPointwise(fc[0], fc[1], act=0)
+        _fuse_backbone(model.backbone)
     if fold_bn:
         bb = model.backbone
         folded += _fold_pairs(bb, [('_conv_stem', '_bn0')] + ([] if getattr(bb, '_fused_head', None) is not None else [('_conv_head', '_bn1')]))

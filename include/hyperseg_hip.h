@@ -158,16 +158,21 @@ int hs_patch_conv_bwd_weight(const float* x, const float* dy, int32_t batch, int
 int hs_depthwise_conv_fwd(const float* x, int32_t batch, int32_t channels, int32_t H, int32_t W,
                           const float* w, int32_t k, int32_t stride, int32_t pad_t, int32_t pad_l,
                           int32_t Ho, int32_t Wo, const float* scale, const float* shift, int32_t act,
-                          float* y, float* pool_partial, void* stream);
-/* pool_partial (optional): (B*C, hs_depthwise_pool_blocks(Ho, Wo)) per-workgroup sums of the outputs, the squeeze-excite
+                          float* y, float* pool_partial, const float* in_scale, const float* in_shift, void* stream);
+/* in_scale / in_shift (optional, both or neither, (C)): the taps become swish(in_scale[c]*x + in_shift[c]) -- the folded
+ * BatchNorm + swish of the 1x1 expand convolution that produced x (efficientnet.py:101-103), applied on load so that the
+ * raw GEMM output is consumed directly; zero padding stays zero.
+ * pool_partial (optional): (B*C, hs_depthwise_pool_blocks(Ho, Wo)) per-workgroup sums of the outputs, the squeeze-excite
  * pooling for free.  hs_se_gate_fwd turns them into the SE gate (pool -> 1x1 reduce + swish -> 1x1 expand -> sigmoid;
- * efficientnet.py:106-111) and, if w_proj is given, folds the gate into the block's project convolution weights:
- * w_scaled[b, o, c] = w_proj[o, c] * gate[b, c].  w_reduce is (c_squeezed, channels); w_expand is passed TRANSPOSED,
- * (c_squeezed, channels), so that both are read coalesced. */
+ * efficientnet.py:106-111) in two launches: squeezed (B, c_squeezed) = swish(reduce(pool)), then gate (B, channels); if
+ * w_proj (c_out, channels) is given it also folds the gate -- and, with out_scale (c_out), the project convolution's folded
+ * BatchNorm scale -- into the project weights: w_scaled[b, o, c] = w_proj[o, c] * gate[b, c] * out_scale[o].
+ * w_reduce is (c_squeezed, channels); w_expand is passed TRANSPOSED, (c_squeezed, channels): both are read coalesced. */
 int hs_depthwise_pool_blocks(int32_t Ho, int32_t Wo);
 int hs_se_gate_fwd(const float* partial, int32_t batch, int32_t channels, int32_t nblk, float inv_hw,
                    const float* w_reduce, const float* b_reduce, int32_t c_squeezed, const float* w_expand,
-                   const float* b_expand, float* gate, const float* w_proj, int32_t c_out, float* w_scaled, void* stream);
+                   const float* b_expand, float* squeezed, float* gate, const float* w_proj, int32_t c_out,
+                   const float* out_scale, float* w_scaled, void* stream);
 
 /* Encoder-side helper: 1x1 convolution as an fp32 MFMA GEMM with its surroundings fused,
  *   y[b,o,p] = act(scale[o] * sum_c w[o,c] * (gate[b,c] * x[b,c,p]) + shift[o]) + residual[b,o,p]

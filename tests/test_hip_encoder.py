@@ -1,0 +1,122 @@
+"""Encoder-side helper kernels (opt-in through utils.inference.prepare_for_inference) against
+plain fp32 PyTorch on the CPU: depthwise conv + BN + swish (+ input affine prologue, + SE pooling), the two-launch SE gate
+(+ weight folding), the MFMA 1x1 conv, the affine epilogue, and the whole prepared encoder against the stock one at a
+resolution where both the MFMA and the library-GEMM routes are taken.  Needs an MI355X: ``-m gpu``.
+Tolerance: 2e-5 of the tensor scale (fp32 sums re-associated)."""
+import copy
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 2e-5
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail('these tests need the MI355X (torch.cuda.is_available() is False)')
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def HF(dev):
+    from hyperseg_amd import functional
+    return functional
+
+
+def swish(t):
+    return t * torch.sigmoid(t)
+
+
+@pytest.mark.parametrize('k,stride,h,w,pre', [(3, 1, 16, 32, False), (3, 2, 33, 47, False), (5, 1, 16, 32, True),
+                                              (5, 2, 64, 128, True), (3, 1, 7, 9, True), (5, 1, 130, 70, False)])
+def test_depthwise_conv(HF, dev, k, stride, h, w, pre):
+    g = torch.Generator().manual_seed(k * 100 + stride * 10 + h)
+    b, c = 2, 13
+    x = torch.randn(b, c, h, w, generator=g)
+    wt = torch.randn(c, 1, k, k, generator=g) * 0.3
+    scale, shift = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1
+    isc, ish = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1
+    # TF-"SAME" for this input size: total = max((ceil(n/s)-1)*s + k - n, 0), extra pixel at the bottom/right
+    ho, wo = -(-h // stride), -(-w // stride)
+    ph, pw = max((ho - 1) * stride + k - h, 0), max((wo - 1) * stride + k - w, 0)
+    xin = swish(x * isc.view(1, -1, 1, 1) + ish.view(1, -1, 1, 1)) if pre else x
+    ref = F.conv2d(F.pad(xin, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2)), wt, stride=stride, groups=c)
+    ref = swish(ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    y, partial = HF.depthwise_conv_bn_act(x.to(dev), wt.to(dev), stride, ph // 2, pw // 2, (ho, wo), scale.to(dev),
+                                          shift.to(dev), act=3, pool=True,
+                                          in_scale=isc.to(dev) if pre else None, in_shift=ish.to(dev) if pre else None)
+    assert rel_err(y.cpu(), ref) < REL_TOL
+    pooled = partial.cpu().sum(1).view(b, c) / (ho * wo)
+    assert rel_err(pooled, ref.mean((2, 3))) < REL_TOL
+
+
+@pytest.mark.parametrize('c,csq,nblk,cout', [(32, 8, 128, 16), (96, 4, 32, 24), (240, 10, 8, 40), (672, 28, 2, 112),
+                                             (1152, 48, 1, 320), (1920, 80, 1, 320), (50, 3, 5, 7)])
+@pytest.mark.parametrize('batch', [1, 2])
+def test_se_gate(HF, dev, c, csq, nblk, cout, batch):
+    g = torch.Generator().manual_seed(c + csq)
+    hw = 77.0
+    partial = torch.randn(batch * c, nblk, generator=g)
+    w1, b1 = torch.randn(csq, c, generator=g) / c ** 0.5, torch.randn(csq, generator=g) * 0.1
+    w2, b2 = torch.randn(c, csq, generator=g) / csq ** 0.5, torch.randn(c, generator=g) * 0.1
+    wp, osc = torch.randn(cout, c, generator=g), torch.rand(cout, generator=g) + 0.5
+    pooled = partial.sum(1).view(batch, c) / hw
+    gate_ref = torch.sigmoid(swish(pooled @ w1.t() + b1) @ w2.t() + b2)
+    args = [t.to(dev) for t in (partial, w1, b1, w2.t().contiguous(), b2)]
+    gate = HF.se_gate(args[0], batch, hw, *args[1:])
+    assert rel_err(gate.cpu(), gate_ref) < REL_TOL
+    ws = HF.se_gate(args[0], batch, hw, *args[1:], w_proj=wp.to(dev))
+    assert rel_err(ws.cpu().view(batch, cout, c), wp[None] * gate_ref[:, None, :]) < REL_TOL
+    ws = HF.se_gate(args[0], batch, hw, *args[1:], w_proj=wp.to(dev), out_scale=osc.to(dev))
+    assert rel_err(ws.cpu().view(batch, cout, c), wp[None] * gate_ref[:, None, :] * osc[None, :, None]) < REL_TOL
+
+
+@pytest.mark.parametrize('cin,cout,hw', [(16, 96, (64, 128)), (96, 24, (32, 64)), (32, 16, (16, 20)), (50, 37, (9, 12))])
+def test_pointwise_conv_and_affine(HF, dev, cin, cout, hw):
+    g = torch.Generator().manual_seed(cin * cout)
+    b = 2
+    x = torch.randn(b, cin, *hw, generator=g)
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    gate = torch.rand(b, cin, generator=g)
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    res = torch.randn(b, cout, *hw, generator=g)
+    lin = F.conv2d(x * gate[:, :, None, None], wt) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    y = HF.pointwise_conv(x.to(dev), wt.to(dev), gate.to(dev), scale.to(dev), shift.to(dev), 3, res.to(dev))
+    assert rel_err(y.cpu(), swish(lin) + res) < REL_TOL
+    y = HF.pointwise_conv(x.to(dev), wt.to(dev), None, scale.to(dev), shift.to(dev), 0, None)
+    assert rel_err(y.cpu(), F.conv2d(x, wt) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)) < REL_TOL
+    if (hw[0] * hw[1]) % 4 == 0:
+        t = res.clone().to(dev)
+        HF.affine_act_(t, scale[:cout].to(dev), shift.to(dev), 3, x[:, :1].expand(-1, cout, -1, -1).contiguous().to(dev))
+        ref = swish(res * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)) + x[:, :1]
+        assert rel_err(t.cpu(), ref) < REL_TOL
+        t = res.clone().to(dev)
+        HF.affine_act_(t, None, shift.to(dev), 0, None)
+        assert rel_err(t.cpu(), res + shift.view(1, -1, 1, 1)) < REL_TOL
+
+
+@pytest.mark.parametrize('batch,size', [(1, (256, 512)), (1, (128, 192)), (2, (256, 256))])
+def test_prepared_encoder_matches_stock(dev, batch, size):
+    """Whole prepared model (MFMA early blocks, lean library-GEMM late blocks with deferred BN shifts) == stock model."""
+    from hyperseg_amd import configs
+    from hyperseg_amd.utils.inference import prepare_for_inference
+    from hyperseg_amd.utils.synthetic import fill_by_name
+    stock = fill_by_name(configs.build('hyperseg-m').eval(), seed=7)
+    fused = copy.deepcopy(stock)
+    prepare_for_inference(fused, fold_bn=False, fused_depthwise=True)
+    assert any(b._fused_dw.defer_shift for b in fused.backbone._blocks)
+    stock, fused = stock.to(dev), fused.to(dev)
+    x = torch.rand(batch, 3, *size, device=dev)
+    with torch.no_grad():
+        fs, ff = stock.backbone(x), fused.backbone(x)
+        for a, b in zip(fs, ff):
+            assert rel_err(b.cpu(), a.cpu()) < 5e-5
+        ys, yf = stock(x).cpu(), fused(x).cpu()
+        assert rel_err(yf, ys) < 1e-4
+        # twice: the in-place skip accumulation must not corrupt anything that outlives a forward
+        assert rel_err(fused(x).cpu(), ys) < 1e-4

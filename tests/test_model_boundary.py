@@ -150,3 +150,77 @@ def test_inference_prep_matches_stock_encoder(batch):
         for a, b in zip(fs, ff):
             assert rel_err(b.cpu(), a.cpu()) < 2e-5
         assert rel_err(fused(x).cpu(), stock(x).cpu()) < 1e-4
+
+
+def test_deferred_bn_shift_algebra_cpu(monkeypatch):
+    """Host logic of utils.inference (no GPU): the deferred-BN-shift bookkeeping of the fused MBConv blocks is exact.
+    The HIP entry points are replaced by plain-torch stand-ins of their documented semantics, the fused encoder is
+    walked by hand (the product path refuses CPU tensors) and must reproduce the stock encoder's features."""
+    import copy
+    import torch.nn.functional as F
+    from hyperseg_amd import configs, functional as HF
+    from hyperseg_amd.utils.inference import prepare_for_inference
+
+    def act_of(t, act):
+        return t * torch.sigmoid(t) if act == 3 else (torch.relu(t) if act == 1 else (t.clamp(0, 6) if act == 2 else t))
+
+    def dw(x, weight, stride, pad_top, pad_left, out_size, scale=None, shift=None, act=0, pool=False, in_scale=None,
+           in_shift=None):
+        if in_scale is not None:
+            x = act_of(x * in_scale.view(1, -1, 1, 1) + in_shift.view(1, -1, 1, 1), 3)
+        k = weight.shape[-1]
+        ho, wo = out_size
+        pb, pr = (ho - 1) * stride + k - x.shape[2] - pad_top, (wo - 1) * stride + k - x.shape[3] - pad_left
+        y = F.conv2d(F.pad(x, (pad_left, pr, pad_top, pb)), weight, stride=stride, groups=x.shape[1])
+        y = act_of(y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1), act)
+        return y, y.sum((2, 3)).view(-1, 1)
+
+    def se_gate(partial, batch, hw, w_reduce, b_reduce, w_expand_t, b_expand, w_proj=None, out_scale=None):
+        pooled = partial.sum(1).view(batch, -1) / hw
+        z = act_of(pooled @ w_reduce.flatten(1).t() + b_reduce, 3)
+        gate = torch.sigmoid(z @ w_expand_t + b_expand)
+        if w_proj is None:
+            return gate
+        ws = w_proj.flatten(1)[None] * gate[:, None, :]
+        if out_scale is not None:
+            ws = ws * out_scale[None, :, None]
+        return ws[..., None, None]
+
+    def pointwise(x, weight, gate=None, scale=None, shift=None, act=0, residual=None):
+        if gate is not None:
+            x = x * gate[:, :, None, None]
+        y = act_of(F.conv2d(x, weight) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1), act)
+        return y if residual is None else y + residual
+
+    def affine(x, scale, shift, act=0, residual=None):
+        y = x if scale is None else x * scale.view(1, -1, 1, 1)
+        y = act_of(y + shift.view(1, -1, 1, 1), act)
+        x.copy_(y if residual is None else y + residual)
+        return x
+
+    monkeypatch.setattr(HF, 'depthwise_conv_bn_act', dw)
+    monkeypatch.setattr(HF, 'se_gate', se_gate)
+    monkeypatch.setattr(HF, 'pointwise_conv', pointwise)
+    monkeypatch.setattr(HF, 'affine_act_', affine)
+
+    stock = fill_by_name(configs.build('hyperseg-m').eval(), seed=3)
+    fused = copy.deepcopy(stock)
+    prepare_for_inference(fused, fold_bn=False, fused_depthwise=True)
+    bb = fused.backbone
+    deferred = [b._fused_dw.defer_shift for b in bb._blocks]
+    assert sum(deferred) >= len(deferred) - 3 and not deferred[0]     # block 0 feeds a depthwise conv directly
+    for size, batch in (((128, 256), 1), ((64, 128), 2)):             # 128x256: first blocks take the "MFMA" route
+        x = torch.rand(batch, 3, *size)
+        with torch.no_grad():
+            ref = stock.backbone(x)
+            t = F.silu(bb._bn0(bb._conv_stem(x)))
+            feats = []
+            for idx, blk in enumerate(bb._blocks):
+                t = blk._fused_dw(t, blk)
+                if bb._res_feat_mask[idx]:
+                    key = str(len(feats))
+                    feats.append(bb._fused_fc[key](t) if key in bb._fused_fc else t.clone())
+            feats.append(bb._fused_head(t))
+        assert len(feats) == len(ref)
+        for a, b in zip(ref, feats):
+            assert rel_err(b, a) < 2e-5
