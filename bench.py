@@ -114,6 +114,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--output', default='logits', choices=['logits', 'masks'],
+                    help="what a step produces: fp32 logits (the reference's forward, default) or uint8 argmax masks "
+                         "taken inside the final upsample kernel (HyperGen.segment; test_fps.py:194's epilogue fused)")
     ap.add_argument('--gather', default='logits', choices=['logits', 'masks', 'none'],
                     help='what the N>1 all-gather moves (north star: logits)')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of HIP graph replay')
@@ -161,21 +164,24 @@ def main():
     # ---- build the step (HIP graph of the whole forward) -------------------------------------
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
+    forward = model.segment if args.output == 'masks' else model
+    if args.output == 'masks' and args.gather == 'logits':
+        args.gather = 'masks'
     with torch.cuda.stream(side):
         for _ in range(3):
-            y = model(x)
+            y = forward(x)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = None
     if not args.no_graph:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            y = model(x)
+            y = forward(x)
 
     comm = None
     if world > 1 and args.gather != 'none':
         from hyperseg_amd.distributed import LogitsGatherer
-        shape = tuple(y.shape) if args.gather == 'logits' else (y.shape[0], y.shape[2], y.shape[3])
+        shape = tuple(y.shape) if args.gather == 'logits' else (y.shape[0],) + tuple(y.shape[-2:])
         dtype = torch.float32 if args.gather == 'logits' else torch.uint8
         comm = LogitsGatherer(world, shape, dtype, dev)
 
@@ -184,10 +190,10 @@ def main():
         if graph is not None:
             graph.replay()
         else:
-            y = model(x)
+            y = forward(x)
         if comm is not None:
             # RCCL all-gather over xGMI on RCCL's own stream: overlaps the next frame's compute
-            comm.submit(i, y if args.gather == 'logits' else y.argmax(1).to(torch.uint8))
+            comm.submit(i, y if (args.gather == 'logits' or y.dtype == torch.uint8) else y.argmax(1).to(torch.uint8))
 
     def drain():
         if comm is not None:
@@ -334,7 +340,9 @@ def main():
             'config': {'workload': 'HyperSeg-M / EfficientNet-B1 / 1024x512 bs=1 per GPU, whole model forward '
                                    '(PyTorch-ROCm encoder + context head, HIP decoder), resident input',
                        'encoder': 'stock PyTorch-ROCm / MIOpen' if args.stock_encoder else
-                                  'stock PyTorch-ROCm except depthwise conv+BN+swish = hs_depthwise_conv_fwd (23 launches)',
+                                  'MBConv blocks through hyperseg_amd.utils.inference (hs_depthwise_conv_fwd, hs_se_gate_fwd, '
+                                  'hs_pointwise_conv_fwd / library GEMMs); stem + context head stock PyTorch-ROCm',
+                       'output': 'fp32 logits (B,19,512,1024)' if args.output == 'logits' else 'uint8 argmax masks (B,512,1024)',
                        'launch': 'eager' if args.no_graph else 'hipGraph replay',
                        'parallelism': f'batch-sharded x{world}' + (f', RCCL all_gather of {args.gather}'
                                                                    if comm is not None else '')},

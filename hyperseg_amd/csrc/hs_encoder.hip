@@ -36,26 +36,34 @@ void depthwise_conv_kernel(const float* __restrict__ x, const float* __restrict_
     const float* __restrict__ wc = w + (size_t)c * K * K;          // uniform -> scalar loads
     constexpr int NCOL = 3 * S + K;                                // input columns feeding 4 outputs
     const int xi0 = xo * S - pad_l, yi0 = yo * S - pad_t;
+    // every tap of the K x NCOL window is loaded BEFORE the first use (clamped addresses, masks applied afterwards): a
+    // row-by-row load/fma interleaving exposes one memory round trip per tap row
+    float v[K][NCOL];
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+        const int yi = yi0 + ky;
+        const float* __restrict__ row = xp + (size_t)min(max(yi, 0), H - 1) * W;
+#pragma unroll
+        for (int j = 0; j < NCOL; ++j) v[ky][j] = row[min(max(xi0 + j, 0), W - 1)];
+    }
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ky = 0; ky < K; ++ky) {
         const int yi = yi0 + ky;
         const bool row_ok = yi >= 0 && yi < H;
-        const float* __restrict__ row = xp + (size_t)(row_ok ? yi : 0) * W;
-        float v[NCOL];
 #pragma unroll
         for (int j = 0; j < NCOL; ++j) {
             const int xi = xi0 + j;
             const bool ok = row_ok && xi >= 0 && xi < W;
-            float t = row[ok ? xi : 0];
+            float t = v[ky][j];
             if (pre) { t = fmaf(t, isc, ish); t = t / (1.0f + expf(-t)); }
-            v[j] = ok ? t : 0.0f;
+            v[ky][j] = ok ? t : 0.0f;
         }
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) {
             const float wv = wc[ky * K + kx];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = fmaf(wv, v[t * S + kx], acc[t]);
+            for (int t = 0; t < 4; ++t) acc[t] = fmaf(wv, v[ky][t * S + kx], acc[t]);
         }
     }
     const float sc = scale ? scale[c] : 1.0f, sh = shift ? shift[c] : 0.0f;

@@ -1,0 +1,247 @@
+// Encoder-side helper (opt-in through utils.inference): the first HALF of an MBConv block
+// in one launch,
+//     y = swish(BN1(depthwise_KxK_strideS(zero-pad(swish(BN0(W_e . x))))))      (+ per-tile sums of y for the SE pool)
+// replacing {1x1 expand conv, BatchNorm, swish, F.pad, depthwise conv, BatchNorm, swish, adaptive_avg_pool2d} of
+// hyperseg/models/backbones/efficientnet.py:101-106.  The 6x-expanded activation (50 MB at the first stride-2 block of
+// HyperSeg-M 1024x512: written once and read once = 100 MB of HBM traffic around 0.4 GFLOP) never exists: it lives in LDS
+// one 16-channel chunk of one spatial tile at a time.  Same structure as the decoder's patch_ir_mfma_kernel
+// (hs_patch_ir_mfma.hip) minus the per-patch weights:
+//
+//   workgroup (4 waves) = one OTH x OTW output tile x a range of 16-channel chunks of the hidden dimension
+//   prologue   the input halo tile ((OTH-1)S+K) x ((OTW-1)S+K) x Cin is loaded ONCE, straight into MFMA B fragments in
+//              registers (lane = (position, k)): 64-byte runs, every load of the tile in flight together
+//   per chunk  pw   v_mfma_f32_16x16x4_f32, A = W_e rows of the chunk (per-lane vector loads, L2 resident);
+//                   D -> BN0 -> swish -> LDS h1[16][rows x RS]; positions outside the image are written as exact zeros
+//                   (the depthwise conv pads the ACTIVATION, not the input)
+//              dw   thread = (channel, output row segment): K rows of h1 as ds_read_b128, K*K per-lane taps, BN1, swish,
+//                   16/32-byte row runs to HBM; 16-lane shuffle reduction -> one pool partial per (channel, tile)
+// The depthwise taps accumulate in the same (ky, kx) order as depthwise_conv_kernel, so the two routes differ only by the
+// k-order of the expand GEMM.
+#include "hs_common.h"
+
+namespace hs {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+struct MbxArgs {
+    const float* __restrict__ x; const float* __restrict__ w_e; const float* __restrict__ s0; const float* __restrict__ b0;
+    const float* __restrict__ w_dw; const float* __restrict__ s1; const float* __restrict__ b1;
+    float* __restrict__ y; float* __restrict__ pool;
+    int Cin, Cmid, H, W, Ho, Wo, pad_t, pad_l, tiles_y, tiles_x, chunks_per_wg, ngroups;
+};
+
+template <int K, int S, int OTH, int OTW> struct MbxGeom {
+    static constexpr int IH = (OTH - 1) * S + K, IW = (OTW - 1) * S + K;      // input halo tile
+    static constexpr int NPOS = IH * IW;
+    static constexpr int NT = (NPOS + 15) / 16;                               // position tiles (pw N)
+    static constexpr int J = (NT + 3) / 4;                                    // position tiles per wave
+    static constexpr int RS = (IW + 3) & ~3;                                  // h1 row stride: 16-byte aligned rows
+    static constexpr int H1P = ((IH * RS + 7) & ~7) + 4;                      // plane == 4 (mod 8): see IrmGeom::H1P
+    static constexpr int NSEG = 16 / OTH;                                     // row segments per output row
+    static constexpr int NOUT = OTW / NSEG;                                   // outputs per dw thread
+    static constexpr int NIN = (NOUT - 1) * S + K;                            // h1 values feeding them, per tap row
+    static constexpr int NIN4 = (NIN + 3) & ~3;
+    static_assert(16 % OTH == 0 && OTW % NSEG == 0 && (NOUT * S) % 4 == 0, "tile shape");
+};
+
+__device__ __forceinline__ float swishf(float t) { return t / (1.0f + expf(-t)); }
+
+// two workgroups per CU wherever the B fragments leave room for it (<= 256 registers incl. AGPRs): the per-chunk weight
+// fetch and the two barriers of one workgroup then overlap the other's MFMA / depthwise phases
+template <int K, int S, int OTH, int OTW, int KS>
+__global__ __launch_bounds__(256, (MbxGeom<K, S, OTH, OTW>::J * KS <= 80 ? 2 : 1))
+void mbconv_expand_dw_kernel(MbxArgs a) {
+    using G = MbxGeom<K, S, OTH, OTW>;
+    extern __shared__ __attribute__((aligned(16))) float h1[];                 // [16][H1P]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 15, lk = lane >> 4;
+    int blk = blockIdx.x;
+    const int grp = blk % a.ngroups; blk /= a.ngroups;
+    const int tx = blk % a.tiles_x; blk /= a.tiles_x;
+    const int ty = blk % a.tiles_y;
+    const int b = blk / a.tiles_y;
+    const int oy0 = ty * OTH, ox0 = tx * OTW;
+    const int iy0 = oy0 * S - a.pad_t, ix0 = ox0 * S - a.pad_l;
+    const int Cin = a.Cin, Cmid = a.Cmid;
+    const size_t plane = (size_t)a.H * a.W;
+
+    // ---- prologue: the input halo tile -> B fragments (registers), all loads in flight together ----------------------
+    float bf[G::J][KS];
+    int h1off[G::J];                   // LDS offset of this lane's position (-1: no such position); bit 30: inside the image
+#pragma unroll
+    for (int jt = 0; jt < G::J; ++jt) {
+        const int nt = wave + 4 * jt;
+        const int pos = nt * 16 + lrow;
+        const bool ok = nt < G::NT && pos < G::NPOS;
+        const int pu = ok ? pos / G::IW : 0, pv = ok ? pos - pu * G::IW : 0;
+        const int yy = iy0 + pu, xx = ix0 + pv;
+        const bool in = ok && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+        const float* __restrict__ src = a.x + (size_t)b * Cin * plane + (size_t)(in ? yy : 0) * a.W + (in ? xx : 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int c = ks * 4 + lk;
+            const float v = src[(size_t)(c < Cin ? c : Cin - 1) * plane];
+            bf[jt][ks] = (in && c < Cin) ? v : 0.0f;
+        }
+        h1off[jt] = ok ? ((pu * G::RS + pv) | (in ? (1 << 30) : 0)) : -1;
+    }
+
+    // dw role of this thread: hidden channel hh of the chunk, output row / row segment
+    const int hh = tid >> 4, u = tid & 15;
+    const int drow = u % OTH, dseg = u / OTH;
+    const int oy = oy0 + drow, ox = ox0 + dseg * G::NOUT;
+    const int ntiles = a.tiles_y * a.tiles_x;
+    const int nchunks = (Cmid + 15) >> 4;
+    const int c_begin = grp * a.chunks_per_wg;
+    const int c_end = min(c_begin + a.chunks_per_wg, nchunks);
+
+    for (int ch = c_begin; ch < c_end; ++ch) {
+        const int h0 = ch * 16;
+        // per-chunk operands (weights: L2-resident vector loads, issued together ahead of the MFMAs)
+        float af[KS];                   // A fragments  W_e[h0 + lrow][4*ks + lk]
+        {
+            const int h = h0 + lrow;
+            const bool hok = h < Cmid;
+            const float* __restrict__ wr = a.w_e + (size_t)(hok ? h : 0) * Cin;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int k = ks * 4 + lk;
+                const float v = wr[k < Cin ? k : 0];
+                af[ks] = (hok && k < Cin) ? v : 0.0f;
+            }
+        }
+        float sc0[4], sh0[4];           // BN0 rows of this lane's 4 D rows
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int hr = min(h0 + 4 * lk + r, Cmid - 1);
+            sc0[r] = a.s0[hr]; sh0[r] = a.b0[hr];
+        }
+        const int hd = min(h0 + hh, Cmid - 1);
+        float kd[K * K];
+#pragma unroll
+        for (int q = 0; q < K * K; ++q) kd[q] = a.w_dw[(size_t)hd * K * K + q];
+        const float sc1 = a.s1[hd], sh1 = a.b1[hd];
+
+        // ---- pw: h1[16][pos] = swish(BN0(W_e chunk . x tile)), exact zeros outside the image -------------------------
+#pragma unroll
+        for (int jt = 0; jt < G::J; ++jt) {
+            if (wave + 4 * jt < G::NT) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks], bf[jt][ks], acc, 0, 0, 0);
+                if (h1off[jt] >= 0) {
+                    const bool in = (h1off[jt] >> 30) & 1;
+                    const int off = h1off[jt] & ((1 << 30) - 1);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        h1[(4 * lk + r) * G::H1P + off] = in ? swishf(fmaf(acc[r], sc0[r], sh0[r])) : 0.0f;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- dw K x K stride S + BN1 + swish: thread = (hidden channel, output row segment) --------------------------
+        {
+            const float* hp = h1 + hh * G::H1P + (drow * S) * G::RS + dseg * G::NOUT * S;
+            float o[G::NOUT];
+#pragma unroll
+            for (int v = 0; v < G::NOUT; ++v) o[v] = 0.0f;
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) {
+                float rowv[G::NIN4];
+#pragma unroll
+                for (int q = 0; q < G::NIN4 / 4; ++q) {
+                    const float4 t = *reinterpret_cast<const float4*>(hp + ky * G::RS + 4 * q);
+                    rowv[4 * q] = t.x; rowv[4 * q + 1] = t.y; rowv[4 * q + 2] = t.z; rowv[4 * q + 3] = t.w;
+                }
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                    for (int v = 0; v < G::NOUT; ++v) o[v] = fmaf(kd[ky * K + kx], rowv[v * S + kx], o[v]);
+            }
+            const int h = h0 + hh;
+            float psum = 0.0f;
+            if (h < Cmid && oy < a.Ho) {
+                float* __restrict__ dst = a.y + (((size_t)b * Cmid + h) * a.Ho + oy) * a.Wo + ox;
+#pragma unroll
+                for (int v = 0; v < G::NOUT; ++v) o[v] = swishf(fmaf(o[v], sc1, sh1));
+                if ((a.Wo & 3) == 0 && ox + G::NOUT <= a.Wo) {
+#pragma unroll
+                    for (int q = 0; q < G::NOUT / 4; ++q) {
+                        *reinterpret_cast<float4*>(dst + 4 * q) = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+                        psum += (o[4 * q] + o[4 * q + 1]) + (o[4 * q + 2] + o[4 * q + 3]);
+                    }
+                } else {
+#pragma unroll
+                    for (int v = 0; v < G::NOUT; ++v)
+                        if (ox + v < a.Wo) { dst[v] = o[v]; psum += o[v]; }
+                }
+            }
+            // SE pooling: one partial sum per (channel, tile), reduced over the channel's 16 lanes
+            if (a.pool) {
+                for (int m = 8; m > 0; m >>= 1) psum += __shfl_xor(psum, m, 64);
+                if (u == 0 && h < Cmid) a.pool[((size_t)b * Cmid + h) * ntiles + ty * a.tiles_x + tx] = psum;
+            }
+        }
+        __syncthreads();               // h1 is rewritten by the next chunk's pw
+    }
+}
+
+template <int K, int S, int OTH, int OTW, int KS>
+static int launch_mbx(const MbxArgs& a, int batch, hipStream_t stream) {
+    using G = MbxGeom<K, S, OTH, OTW>;
+    const size_t lds = (size_t)16 * G::H1P * sizeof(float);
+    const size_t blocks = (size_t)batch * a.tiles_y * a.tiles_x * a.ngroups;
+    if (blocks > 0x7fffffffu) return HS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((mbconv_expand_dw_kernel<K, S, OTH, OTW, KS>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    return launch_status();
+}
+
+template <int K, int S, int OTH, int OTW>
+static int dispatch_ks(const MbxArgs& a, int batch, hipStream_t stream) {
+    const int ks = (a.Cin + 3) / 4;
+    if (ks <= 4) return launch_mbx<K, S, OTH, OTW, 4>(a, batch, stream);
+    if (ks <= 6) return launch_mbx<K, S, OTH, OTW, 6>(a, batch, stream);
+    if (ks <= 10) return launch_mbx<K, S, OTH, OTW, 10>(a, batch, stream);
+    if (ks <= 12) return launch_mbx<K, S, OTH, OTW, 12>(a, batch, stream);
+    if (ks <= 20) return launch_mbx<K, S, OTH, OTW, 20>(a, batch, stream);
+    return HS_ERR_UNSUPPORTED;         // wider inputs: the B fragments no longer fit the register file -> unfused route
+}
+
+}  // namespace hs
+
+using namespace hs;
+
+extern "C" int hs_mbconv_tiles(int32_t k, int32_t stride, int32_t Ho, int32_t Wo) {
+    (void)k;
+    const int oth = stride == 1 ? 16 : 8, otw = 16;
+    return ((Ho + oth - 1) / oth) * ((Wo + otw - 1) / otw);
+}
+
+extern "C" int hs_mbconv_expand_dw_fwd(const float* x, int32_t batch, int32_t c_in, int32_t H, int32_t W,
+                                       const float* w_expand, int32_t c_mid, const float* scale0, const float* shift0,
+                                       const float* w_dw, int32_t k, int32_t stride, int32_t pad_t, int32_t pad_l,
+                                       int32_t Ho, int32_t Wo, const float* scale1, const float* shift1, float* y,
+                                       float* pool_partial, void* stream) {
+    if (!x || !w_expand || !scale0 || !shift0 || !w_dw || !scale1 || !shift1 || !y) return HS_ERR_BAD_ARG;
+    if (batch <= 0 || c_in <= 0 || c_mid <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || pad_t < 0 || pad_l < 0)
+        return HS_ERR_BAD_ARG;
+    MbxArgs a;
+    a.x = x; a.w_e = w_expand; a.s0 = scale0; a.b0 = shift0; a.w_dw = w_dw; a.s1 = scale1; a.b1 = shift1;
+    a.y = y; a.pool = pool_partial;
+    a.Cin = c_in; a.Cmid = c_mid; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.pad_t = pad_t; a.pad_l = pad_l;
+    const int oth = stride == 1 ? 16 : 8, otw = 16;
+    a.tiles_y = (Ho + oth - 1) / oth; a.tiles_x = (Wo + otw - 1) / otw;
+    // enough workgroups to fill 256 CUs a few times over, but as few re-loads of the input tile as that allows
+    const int nchunks = (c_mid + 15) / 16;
+    const long tiles = (long)batch * a.tiles_y * a.tiles_x;
+    int cpw = nchunks;
+    while (cpw > 1 && tiles * ((nchunks + cpw - 1) / cpw) < 768) --cpw;
+    a.chunks_per_wg = cpw; a.ngroups = (nchunks + cpw - 1) / cpw;
+    hipStream_t s = (hipStream_t)stream;
+    if (k == 3 && stride == 1) return dispatch_ks<3, 1, 16, 16>(a, batch, s);
+    if (k == 3 && stride == 2) return dispatch_ks<3, 2, 8, 16>(a, batch, s);
+    if (k == 5 && stride == 1) return dispatch_ks<5, 1, 16, 16>(a, batch, s);
+    if (k == 5 && stride == 2) return dispatch_ks<5, 2, 8, 16>(a, batch, s);
+    return HS_ERR_UNSUPPORTED;
+}

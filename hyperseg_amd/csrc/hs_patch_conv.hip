@@ -189,6 +189,40 @@ void patch_conv1x1_kernel(Conv1Args a) {
 
 // Exact 2x bilinear upsample (align_corners=False): taps are {0.25, 0.75} with edge clamping.  One thread =
 // 2 output rows x 4 output columns from a 3 x 4 input neighbourhood: two 16-byte stores per 12 cached loads.
+// up2x_block is shared by the logits kernel and the fused argmax kernel so that both round identically.
+__device__ __forceinline__ void up2x_block(const float* __restrict__ base, int Hi, int Wi, int yi, int q,
+                                           float (&o0)[4], float (&o1)[4]) {
+    const int xi = 2 * q;
+    const int xm = xi > 0 ? xi - 1 : 0, xp = xi + 2 < Wi ? xi + 2 : Wi - 1;
+    const int ym = yi > 0 ? yi - 1 : 0, yp = yi + 1 < Hi ? yi + 1 : Hi - 1;
+    float in[3][4];
+    const int ys[3] = {ym, yi, yp};
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) {
+        const float* row = base + (size_t)ys[rr] * Wi;
+        in[rr][0] = row[xm]; in[rr][1] = row[xi]; in[rr][2] = row[xi + 1]; in[rr][3] = row[xp];
+    }
+    // horizontal pass, same operation order as ATen: l0*a + l1*b with (l0, l1) = (0.25, 0.75) / (0.75, 0.25)
+    float hz[3][4];
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) {
+        hz[rr][0] = 0.25f * in[rr][0] + 0.75f * in[rr][1];
+        hz[rr][1] = 0.75f * in[rr][1] + 0.25f * in[rr][2];
+        hz[rr][2] = 0.25f * in[rr][1] + 0.75f * in[rr][2];
+        hz[rr][3] = 0.75f * in[rr][2] + 0.25f * in[rr][3];
+    }
+    // ATen clamps the SOURCE index at 0 (lambda = 0 there): first output row/col equal the edge sample
+    if (xi == 0) {
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) hz[rr][0] = 1.0f * in[rr][1] + 0.0f * in[rr][2];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        o0[c] = (yi == 0) ? (1.0f * hz[1][c] + 0.0f * hz[2][c]) : (0.25f * hz[0][c] + 0.75f * hz[1][c]);
+        o1[c] = 0.75f * hz[1][c] + 0.25f * hz[2][c];
+    }
+}
+
 __global__ __launch_bounds__(256)
 void upsample2x_kernel(const float* __restrict__ x, int planes, int Hi, int Wi, float* __restrict__ y) {
     const int wq = Wi >> 1;                 // pairs of input columns
@@ -197,42 +231,43 @@ void upsample2x_kernel(const float* __restrict__ x, int planes, int Hi, int Wi, 
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
         const int q = e % wq; size_t r = e / wq;
         const int yi = r % Hi; const size_t pl = r / Hi;
-        const int xi = 2 * q;
-        const int xm = xi > 0 ? xi - 1 : 0, xp = xi + 2 < Wi ? xi + 2 : Wi - 1;
-        const int ym = yi > 0 ? yi - 1 : 0, yp = yi + 1 < Hi ? yi + 1 : Hi - 1;
-        const float* base = x + pl * Hi * Wi;
-        float in[3][4];
-        const int ys[3] = {ym, yi, yp};
-#pragma unroll
-        for (int rr = 0; rr < 3; ++rr) {
-            const float* row = base + (size_t)ys[rr] * Wi;
-            in[rr][0] = row[xm]; in[rr][1] = row[xi]; in[rr][2] = row[xi + 1]; in[rr][3] = row[xp];
-        }
-        // horizontal pass, same operation order as ATen: l0*a + l1*b with (l0, l1) = (0.25, 0.75) / (0.75, 0.25)
-        float hz[3][4];
-#pragma unroll
-        for (int rr = 0; rr < 3; ++rr) {
-            hz[rr][0] = 0.25f * in[rr][0] + 0.75f * in[rr][1];
-            hz[rr][1] = 0.75f * in[rr][1] + 0.25f * in[rr][2];
-            hz[rr][2] = 0.25f * in[rr][1] + 0.75f * in[rr][2];
-            hz[rr][3] = 0.75f * in[rr][2] + 0.25f * in[rr][3];
-        }
-        // ATen clamps the SOURCE index at 0 (lambda = 0 there): first output row/col equal the edge sample
-        if (xi == 0) {
-#pragma unroll
-            for (int rr = 0; rr < 3; ++rr) hz[rr][0] = 1.0f * in[rr][1] + 0.0f * in[rr][2];
-        }
-        float4 o0, o1;
-        float* t0 = &o0.x; float* t1 = &o1.x;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            t0[c] = (yi == 0) ? (1.0f * hz[1][c] + 0.0f * hz[2][c]) : (0.25f * hz[0][c] + 0.75f * hz[1][c]);
-            t1[c] = 0.75f * hz[1][c] + 0.25f * hz[2][c];
-        }
+        float o0[4], o1[4];
+        up2x_block(x + pl * Hi * Wi, Hi, Wi, yi, q, o0, o1);
         float* dst = y + (pl * 2 * Hi + 2 * yi) * Wo + 4 * q;
-        *reinterpret_cast<float4*>(dst) = o0;
-        *reinterpret_cast<float4*>(dst + Wo) = o1;
+        *reinterpret_cast<float4*>(dst) = make_float4(o0[0], o0[1], o0[2], o0[3]);
+        *reinterpret_cast<float4*>(dst + Wo) = make_float4(o1[0], o1[1], o1[2], o1[3]);
     }
+}
+
+// The same upsample with the class argmax taken in registers: uint8 masks instead of logits (M: 0.5 MB written instead
+// of 39.8 MB, and no separate argmax pass re-reading them).  Ties resolve to the lowest class index.  Replaces
+// F.interpolate + pred.argmax(1) (hyperseg_v1_0.py:250-251 + test.py:171 / test_fps.py:194).
+__global__ __launch_bounds__(256)
+void upsample2x_argmax_kernel(const float* __restrict__ x, int B, int C, int Hi, int Wi, uint8_t* __restrict__ mask) {
+    const int wq = Wi >> 1;
+    const size_t n = (size_t)B * Hi * wq;
+    const int Wo = 2 * Wi;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int q = e % wq; size_t r = e / wq;
+    const int yi = r % Hi; const size_t b = r / Hi;
+    const float* __restrict__ xb = x + b * C * Hi * Wi;
+    float best0[4], best1[4];
+    int idx0[4] = {0, 0, 0, 0}, idx1[4] = {0, 0, 0, 0};
+    up2x_block(xb, Hi, Wi, yi, q, best0, best1);
+#pragma unroll 6
+    for (int c = 1; c < C; ++c) {
+        float o0[4], o1[4];
+        up2x_block(xb + (size_t)c * Hi * Wi, Hi, Wi, yi, q, o0, o1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (o0[t] > best0[t]) { best0[t] = o0[t]; idx0[t] = c; }
+            if (o1[t] > best1[t]) { best1[t] = o1[t]; idx1[t] = c; }
+        }
+    }
+    uint8_t* dst = mask + (b * 2 * Hi + 2 * yi) * Wo + 4 * q;
+    *reinterpret_cast<uchar4*>(dst) = make_uchar4(idx0[0], idx0[1], idx0[2], idx0[3]);
+    *reinterpret_cast<uchar4*>(dst + Wo) = make_uchar4(idx1[0], idx1[1], idx1[2], idx1[3]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -246,7 +281,30 @@ __global__ void stage_input_kernel(StageIn s, float* __restrict__ y) {
     }
 }
 
-// Bilinear resize (align_corners=False).  One thread = 4 consecutive output pixels of a row.
+// Bilinear resize (align_corners=False).  One thread = 4 consecutive output pixels of a row; bilinear_row4 is shared by
+// the logits kernel and the fused argmax kernel.
+struct Row4 { Tap ty; Tap tx[4]; };
+__device__ __forceinline__ Row4 row4_taps(int yo, int q, int Hi, int Wi, int Wo, float scale_y, float scale_x) {
+    Row4 t;
+    t.ty = bilinear_tap(yo, scale_y, Hi);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int xo = 4 * q + i;
+        t.tx[i] = bilinear_tap(xo < Wo ? xo : Wo - 1, scale_x, Wi);
+    }
+    return t;
+}
+__device__ __forceinline__ void bilinear_row4(const float* __restrict__ plane, int Wi, const Row4& t, float (&out)[4]) {
+    const float* r0 = plane + (size_t)t.ty.i0 * Wi;
+    const float* r1 = plane + (size_t)t.ty.i1 * Wi;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float top = t.tx[i].l0 * r0[t.tx[i].i0] + t.tx[i].l1 * r0[t.tx[i].i1];
+        const float bot = t.tx[i].l0 * r1[t.tx[i].i0] + t.tx[i].l1 * r1[t.tx[i].i1];
+        out[i] = t.ty.l0 * top + t.ty.l1 * bot;
+    }
+}
+
 __global__ __launch_bounds__(256)
 void upsample_bilinear_kernel(const float* __restrict__ x, int planes, int Hi, int Wi, int Ho, int Wo,
                               float scale_y, float scale_x, float* __restrict__ y) {
@@ -255,24 +313,45 @@ void upsample_bilinear_kernel(const float* __restrict__ x, int planes, int Hi, i
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
         const int q = e % wq; size_t r = e / wq;
         const int yo = r % Ho; const size_t pl = r / Ho;
-        const Tap ty = bilinear_tap(yo, scale_y, Hi);
-        const float* r0 = x + (pl * Hi + ty.i0) * Wi;
-        const float* r1 = x + (pl * Hi + ty.i1) * Wi;
+        const Row4 t = row4_taps(yo, q, Hi, Wi, Wo, scale_y, scale_x);
         float out[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int xo = 4 * q + t;
-            const Tap tx = bilinear_tap(xo < Wo ? xo : Wo - 1, scale_x, Wi);
-            const float top = tx.l0 * r0[tx.i0] + tx.l1 * r0[tx.i1];
-            const float bot = tx.l0 * r1[tx.i0] + tx.l1 * r1[tx.i1];
-            out[t] = ty.l0 * top + ty.l1 * bot;
-        }
+        bilinear_row4(x + pl * Hi * Wi, Wi, t, out);
         float* dst = y + (pl * Ho + yo) * Wo + 4 * q;
         if ((Wo & 3) == 0) {
             *reinterpret_cast<float4*>(dst) = make_float4(out[0], out[1], out[2], out[3]);
         } else {
-            for (int t = 0; t < 4 && 4 * q + t < Wo; ++t) dst[t] = out[t];
+            for (int i = 0; i < 4 && 4 * q + i < Wo; ++i) dst[i] = out[i];
         }
+    }
+}
+
+__global__ __launch_bounds__(256)
+void upsample_argmax_kernel(const float* __restrict__ x, int B, int C, int Hi, int Wi, int Ho, int Wo, float scale_y,
+                            float scale_x, uint8_t* __restrict__ mask) {
+    const int wq = (Wo + 3) / 4;
+    const size_t n = (size_t)B * Ho * wq;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int q = e % wq; size_t r = e / wq;
+    const int yo = r % Ho; const size_t b = r / Ho;
+    const Row4 t = row4_taps(yo, q, Hi, Wi, Wo, scale_y, scale_x);
+    const float* __restrict__ xb = x + b * C * Hi * Wi;
+    float best[4];
+    int idx[4] = {0, 0, 0, 0};
+    bilinear_row4(xb, Wi, t, best);
+#pragma unroll 6
+    for (int c = 1; c < C; ++c) {
+        float o[4];
+        bilinear_row4(xb + (size_t)c * Hi * Wi, Wi, t, o);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (o[i] > best[i]) { best[i] = o[i]; idx[i] = c; }
+    }
+    uint8_t* dst = mask + (b * Ho + yo) * Wo + 4 * q;
+    if ((Wo & 3) == 0) {
+        *reinterpret_cast<uchar4*>(dst) = make_uchar4(idx[0], idx[1], idx[2], idx[3]);
+    } else {
+        for (int i = 0; i < 4 && 4 * q + i < Wo; ++i) dst[i] = (uint8_t)idx[i];
     }
 }
 
@@ -356,6 +435,22 @@ extern "C" int hs_stage_input_fwd(const hs_stage_input* in, float* y, void* stre
     const size_t n = (size_t)s.B * s.cin() * s.H * s.W;
     const unsigned blocks = (unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
     hipLaunchKernelGGL(stage_input_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s, y);
+    return launch_status();
+}
+
+extern "C" int hs_upsample_argmax_fwd(const float* x, int32_t batch, int32_t channels, int32_t Hi, int32_t Wi,
+                                      int32_t Ho, int32_t Wo, uint8_t* mask, void* stream) {
+    if (!x || !mask || batch <= 0 || channels <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return HS_ERR_BAD_ARG;
+    if (channels > 256) return HS_ERR_UNSUPPORTED;           // uint8 class indices
+    if (Ho == 2 * Hi && Wo == 2 * Wi && (Wi & 1) == 0) {
+        const size_t n2 = (size_t)batch * Hi * (Wi / 2);
+        hipLaunchKernelGGL(upsample2x_argmax_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           x, batch, channels, Hi, Wi, mask);
+        return launch_status();
+    }
+    const size_t n = (size_t)batch * Ho * ((Wo + 3) / 4);
+    hipLaunchKernelGGL(upsample_argmax_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, batch, channels, Hi, Wi, Ho, Wo, (float)Hi / (float)Ho, (float)Wi / (float)Wo, mask);
     return launch_status();
 }
 

@@ -265,6 +265,26 @@ def depthwise_conv_bn_act(x, weight, stride, pad_top, pad_left, out_size, scale=
     return (y, partial) if pool else y
 
 
+def mbconv_expand_dw(x, w_expand, scale0, shift0, w_dw, stride, pad_top, pad_left, out_size, scale1, shift1, pool=True):
+    """1x1 expand + BN + swish + depthwise k x k (TF-"SAME" zero padding of the ACTIVATION) + BN + swish in one launch
+    (+ SE pooling partial sums): the expanded tensor never reaches HBM.  x (B,Cin,H,W), w_expand (Cmid,Cin[,1,1]),
+    w_dw (Cmid,1,k,k) -> y (B,Cmid,Ho,Wo)[, partial (B*Cmid, ntiles)].  Encoder-side helper, opt-in."""
+    b, cin, h, w = x.shape
+    cmid, k = w_dw.shape[0], w_dw.shape[-1]
+    ho, wo = out_size
+    y = torch.empty(b, cmid, ho, wo, device=x.device, dtype=torch.float32)
+    partial = None
+    if pool:
+        partial = torch.empty(b * cmid, _hip.lib.hs_mbconv_tiles(k, stride, ho, wo), device=x.device, dtype=torch.float32)
+    st = _hip.lib.hs_mbconv_expand_dw_fwd(_hip.dev_ptr(x, 'x'), b, cin, h, w, _hip.dev_ptr(w_expand, 'w_expand'), cmid,
+                                          _hip.dev_ptr(scale0, 'scale0'), _hip.dev_ptr(shift0, 'shift0'),
+                                          _hip.dev_ptr(w_dw, 'w_dw'), k, stride, pad_top, pad_left, ho, wo,
+                                          _hip.dev_ptr(scale1, 'scale1'), _hip.dev_ptr(shift1, 'shift1'), y.data_ptr(),
+                                          partial.data_ptr() if pool else None, _hip.stream_ptr())
+    _hip.check(st, 'hs_mbconv_expand_dw_fwd')
+    return (y, partial) if pool else y
+
+
 def pointwise_conv(x, weight, gate=None, scale=None, shift=None, act=0, residual=None):
     """1x1 conv (fp32 MFMA GEMM) + optional input gate (B,Cin) + affine + activation (3 = swish) + residual, one launch."""
     b, cin, h, w = x.shape
@@ -327,6 +347,17 @@ def upsample_bilinear(x, size):
                                            _hip.stream_ptr())
     _hip.check(st, 'hs_upsample_bilinear_fwd')
     return y
+
+
+def upsample_argmax(x, size):
+    """``F.interpolate(x, size, 'bilinear', align_corners=False).argmax(1)`` as uint8 masks (B, Ho, Wo), one launch; the
+    upsampled logits never exist in memory.  Bit-identical to ``upsample_bilinear(x, size).argmax(1)``."""
+    b, c, hi, wi = x.shape
+    ho, wo = size
+    mask = torch.empty(b, ho, wo, device=x.device, dtype=torch.uint8)
+    st = _hip.lib.hs_upsample_argmax_fwd(_hip.dev_ptr(x, 'x'), b, c, hi, wi, ho, wo, mask.data_ptr(), _hip.stream_ptr())
+    _hip.check(st, 'hs_upsample_argmax_fwd')
+    return mask
 
 
 # ------------------------------------------------------------------------------------------

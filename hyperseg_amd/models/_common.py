@@ -45,15 +45,25 @@ class HyperGenBase(nn.Module):
     def hyper_params(self):
         return self.decoder.hyper_params
 
-    def process_single_tensor(self, x, hflip=False):
+    def process_single_tensor(self, x, hflip=False, masks=False):
         if hflip:
             x = torch.flip(x, [-1])
         features = self.backbone(x)
         head_out = self.weight_mapper(features[-1])
         if isinstance(head_out, torch.Tensor):
             head_out = head_out.contiguous()
-        y = self.decoder([t.contiguous() for t in [x] + features[:-1]], head_out)
+        pyramid = [t.contiguous() for t in [x] + features[:-1]]
+        y = self.decoder(pyramid, head_out, masks=True) if masks else self.decoder(pyramid, head_out)
         return torch.flip(y, [-1]) if hflip else y
+
+    @torch.no_grad()
+    def segment(self, x):
+        """uint8 class masks (B, H, W) == ``self(x).argmax(1)`` (the reference's test.py:171 / test_fps.py:194 epilogue).
+        For a single tensor in eval mode the argmax is taken inside the final upsample kernel and the full-resolution
+        logits are never written; pyramid / h-flip inference falls back to the logits path."""
+        if isinstance(x, torch.Tensor) and not self.training and not self.inference_hflip:
+            return self.process_single_tensor(x, masks=True)
+        return self(x).argmax(1).to(torch.uint8)
 
     def gather_results(self, x, y=None):
         assert x is not None

@@ -478,8 +478,11 @@ class MultiScaleDecoder(nn.Module):
             p = F.interpolate(p, x[0].shape[2:], mode='bilinear', align_corners=False)
         return p
 
-    def forward(self, x, s):
+    def forward(self, x, s, masks=False):
+        """``masks=True`` (inference only, not in the reference): uint8 argmax masks straight from the final upsample
+        kernel instead of logits."""
         if self.training or HA.needs_grad(s, *x, *self.parameters()):
+            assert not masks, 'masks=True is an inference-only shortcut'
             return self._forward_autograd(x, s)
         # every level's filter bank in ONE launch (the banks only depend on the signal)
         groups = self._hyper_modules()
@@ -527,6 +530,8 @@ class MultiScaleDecoder(nn.Module):
             torch.cuda.current_stream().wait_stream(side)
         if self.out_fc is not None:
             p = self.out_fc(p, banks[-1])
+        if masks:
+            return HF.upsample_argmax(p, x[0].shape[2:])
         if p.shape[2:] != x[0].shape[2:]:
             p = HF.upsample_bilinear(p, x[0].shape[2:])
         return p

@@ -155,11 +155,12 @@ class MultiScaleDecoder(nn.Module):
             p = F.interpolate(p, x[0].shape[2:], mode='bilinear', align_corners=False)
         return p
 
-    def forward(self, x, s):
+    def forward(self, x, s, masks=False):
         if self.out_fc is not None:
             raise NotImplementedError('with_out_fc=True: the reference itself feeds the raw signal to out_fc here '
                                       '(hyperseg_v1_0_unify.py:252-253); no config uses it')
         if self.training or HA.needs_grad(s, *x, *self.parameters()):
+            assert not masks, 'masks=True is an inference-only shortcut'
             return self._forward_autograd(x, s)
         wl = list(self.weight_blocks)
         refs = HF.signal2weights_multi(s, [m.s2w_layer(s.device) for m in wl])      # every weight layer, one launch
@@ -176,6 +177,8 @@ class MultiScaleDecoder(nn.Module):
                 # rows [r0, r1) of the shared bank, consumed in place (reference: w[:, r0:r1] + .contiguous())
                 w = HF.BankRef(shared.bank[:, r0:r1], shared.shape[0], r1 - r0, shared.grid)
             p = self.level_blocks[level](stage, [w])
+        if masks:
+            return HF.upsample_argmax(p, x[0].shape[2:])
         if p.shape[2:] != x[0].shape[2:]:
             p = HF.upsample_bilinear(p, x[0].shape[2:])
         return p

@@ -1,0 +1,64 @@
+"""Train-step counterparts of the reference's training harness for config 5 ("harness counterparts
+(ii)"): the loss, the LR policy and the step that drive the decoder's autograd path.  Plain PyTorch -- the HIP work happens
+inside ``model(x)`` / ``backward()`` through hyperseg_amd.autograd.
+
+* :class:`BootstrappedCrossEntropyLoss` -- hyperseg/losses/bootstrapped_ce_loss.py:8-40: per IMAGE (not per batch), the
+  pixel-wise cross entropy is sorted in descending order; if the (k+1)-th largest loss exceeds ``thresh`` every pixel above
+  ``thresh`` is kept, otherwise the k largest; the image's loss is the mean of what is kept; the batch loss is the mean of
+  the image losses.  ``ignore_index`` pixels contribute a loss of exactly 0 and stay in the ranking.
+* :class:`PolyLR` -- hyperseg/utils/polylr.py:4-22: lr = base_lr * (1 - step/max_step)**power, stepped per batch.
+* :func:`train_step` -- hyperseg/train.py:118-136: forward, resize the prediction to the target if needed, loss,
+  zero_grad / backward / optimizer.step / scheduler.step.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.optim.lr_scheduler import LRScheduler
+
+
+def bootstrapped_cross_entropy(pred, target, k=4096, thresh=0.3, weight=None, ignore_index=-100):
+    """pred (N, C, H, W) logits, target (N, H, W) int64 -> scalar."""
+    total = pred.new_zeros(())
+    for logits, labels in zip(pred, target):
+        per_pixel = F.cross_entropy(logits.flatten(1).t(), labels.flatten(), weight=weight, ignore_index=ignore_index,
+                                    reduction='none')
+        ranked = per_pixel.sort(descending=True).values
+        kept = ranked[ranked > thresh] if ranked[k] > thresh else ranked[:k]
+        total = total + kept.mean()
+    return total / float(pred.shape[0])
+
+
+class BootstrappedCrossEntropyLoss(nn.Module):
+    def __init__(self, k=4096, thresh=0.3, weight=None, ignore_index=-100, reduction='mean'):
+        super().__init__()
+        if reduction != 'mean':
+            raise ValueError("only reduction='mean' is meaningful: the reference stores the argument and always averages")
+        self.k, self.thresh, self.ignore_index = k, thresh, ignore_index
+        self.register_buffer('weight', weight)
+
+    def forward(self, input, target):
+        return bootstrapped_cross_entropy(input, target, self.k, self.thresh, self.weight, self.ignore_index)
+
+
+class PolyLR(LRScheduler):
+    def __init__(self, optimizer, max_epoch, power=0.9, last_epoch=-1):
+        self.max_epoch, self.power = max_epoch, power
+        super().__init__(optimizer, last_epoch)
+
+    def get_lr(self):
+        decay = (1.0 - float(self.last_epoch) / float(self.max_epoch)) ** self.power
+        return [base * decay for base in self.base_lrs]
+
+
+def train_step(model, criterion, optimizer, scheduler, x, target):
+    """One optimisation step; returns (loss, prediction).  ``model`` is any callable producing (N, C, h, w) logits."""
+    pred = model(x)
+    if pred.shape[2:] != target.shape[1:]:
+        pred = F.interpolate(pred, size=target.shape[1:], mode='bilinear')
+    loss = criterion(pred, target)
+    optimizer.zero_grad()
+    loss.backward()
+    optimizer.step()
+    if scheduler is not None:
+        scheduler.step()
+    return loss.detach(), pred.detach()

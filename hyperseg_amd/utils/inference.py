@@ -8,6 +8,8 @@ eval-mode modules that remove launches from the frame (SURVEY.md section 8f rank
 The decoder modules are left untouched (their BatchNorms are folded inside the HIP kernels' epilogues).
 The state dict changes (BN entries disappear), so apply it AFTER loading a checkpoint.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -50,6 +52,10 @@ def _bn_affine(bn):
         scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
         shift = bn.bias - bn.running_mean * scale
     return scale.detach().clone(), shift.detach().clone()
+
+
+# output pixels from which the fused expand + depthwise kernel is used (tools/bench_mbconv.py measures both routes)
+FUSE_EXPAND_MIN_PIXELS = int(os.environ.get('HS_FUSE_EXPAND_MIN_PIXELS', '2048'))
 
 
 class FusedPointwise(nn.Module):
@@ -149,24 +155,34 @@ class FusedMBConv(nn.Module):
             self.out_offset = carried.clone() if defer_shift else None
             self.project.shift.copy_(torch.zeros_like(carried) if defer_shift else carried)
 
+    def fuses_expand(self, x, ho, wo):
+        """[expand + BN + swish + depthwise + BN + swish + pool] as ONE launch (hs_mbconv_expand_dw_fwd): wherever the
+        map is large enough to fill the chip with (tile x channel-chunk) workgroups and Cin fits the register-resident
+        B fragments.  Small late maps keep the library GEMM + depthwise kernel pair."""
+        return self.expand is not None and x.shape[1] <= 80 and ho * wo >= FUSE_EXPAND_MIN_PIXELS
+
     def forward(self, inputs, blk):
         from .. import functional as HF
         x = inputs.contiguous()
-        b = x.shape[0]
-        lean = b == 1                             # library GEMMs with nothing around them
-        in_scale = in_shift = None
-        if self.expand is not None:
-            if lean and not self.expand.uses_mfma(x):
-                in_scale, in_shift = self.expand.scale, self.expand.shift
-                x = self.expand.raw(x)
-            else:
-                x = self.expand(x)
-        _, _, h, w = x.shape
+        b, _, h, w = x.shape
         ho = (h + self.pad_h - self.k) // self.stride + 1
         wo = (w + self.pad_w - self.k) // self.stride + 1
-        y, partial = HF.depthwise_conv_bn_act(x, blk._depthwise_conv.weight, self.stride, self.pad_t, self.pad_l,
-                                              (ho, wo), self.scale, self.shift, act=3, pool=True,
-                                              in_scale=in_scale, in_shift=in_shift)
+        lean = b == 1                             # library GEMMs with nothing around them
+        if self.fuses_expand(x, ho, wo):
+            y, partial = HF.mbconv_expand_dw(x, self.expand.conv.weight, self.expand.scale, self.expand.shift,
+                                             blk._depthwise_conv.weight, self.stride, self.pad_t, self.pad_l, (ho, wo),
+                                             self.scale, self.shift, pool=True)
+        else:
+            in_scale = in_shift = None
+            if self.expand is not None:
+                if lean and not self.expand.uses_mfma(x):
+                    in_scale, in_shift = self.expand.scale, self.expand.shift
+                    x = self.expand.raw(x)
+                else:
+                    x = self.expand(x)
+            y, partial = HF.depthwise_conv_bn_act(x, blk._depthwise_conv.weight, self.stride, self.pad_t, self.pad_l,
+                                                  (ho, wo), self.scale, self.shift, act=3, pool=True,
+                                                  in_scale=in_scale, in_shift=in_shift)
         red, exp = blk._se_reduce, blk._se_expand
         if self._exp_t is None or self._exp_t.device != x.device:
             self._exp_t = exp.weight.detach().flatten(1).t().contiguous()

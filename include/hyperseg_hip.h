@@ -137,6 +137,13 @@ int hs_patch_ir_fwd(const hs_stage_input* in, int32_t fh, int32_t fw,
 int hs_upsample_bilinear_fwd(const float* x, int32_t batch, int32_t channels, int32_t Hi, int32_t Wi,
                              int32_t Ho, int32_t Wo, float* y, void* stream);
 
+/* The same resize with the class argmax taken in registers: mask (B, Ho, Wo) uint8 = argmax_c of the upsampled logits,
+ * bit-identical to argmax over hs_upsample_bilinear_fwd's output (shared arithmetic), ties -> lowest class; channels
+ * <= 256.  Replaces F.interpolate + pred.argmax(1) (hyperseg_v1_0.py:250-251 + test.py:171, test_fps.py:194) for callers
+ * that only need masks: 0.5 MB written instead of 39.8 MB at HyperSeg-M 1024x512. */
+int hs_upsample_argmax_fwd(const float* x, int32_t batch, int32_t channels, int32_t Hi, int32_t Wi,
+                           int32_t Ho, int32_t Wo, uint8_t* mask, void* stream);
+
 /* Backward of hs_patch_conv_fwd (plain input x, no fused prologue / epilogue), fp32 -- SURVEY.md Appendix E.
  * The reference has no backward of its own (autograd over F.pad/unfold/grouped conv2d/fold: meta_patch.py:35-57);
  * these are the adjoints the training path (BASELINE config 5) needs:
@@ -173,6 +180,18 @@ int hs_se_gate_fwd(const float* partial, int32_t batch, int32_t channels, int32_
                    const float* w_reduce, const float* b_reduce, int32_t c_squeezed, const float* w_expand,
                    const float* b_expand, float* squeezed, float* gate, const float* w_proj, int32_t c_out,
                    const float* out_scale, float* w_scaled, void* stream);
+
+/* Encoder-side helper: the first half of an MBConv block in ONE launch,
+ *   y = swish(BN1(depthwise_kxk_stride(zero-pad(swish(BN0(w_expand . x))))))   (+ per-tile sums of y for the SE pool)
+ * x (B,c_in,H,W), w_expand (c_mid,c_in), w_dw (c_mid,1,k,k), scale/shift = folded BatchNorms, y (B,c_mid,Ho,Wo),
+ * pool_partial (optional) (B*c_mid, hs_mbconv_tiles(k, stride, Ho, Wo)).  k in {3,5}, stride in {1,2}, c_in <= 80.
+ * The expanded activation lives in LDS only.  Replaces efficientnet.py:101-106 of the reference's MBConvBlock. */
+int hs_mbconv_tiles(int32_t k, int32_t stride, int32_t Ho, int32_t Wo);
+int hs_mbconv_expand_dw_fwd(const float* x, int32_t batch, int32_t c_in, int32_t H, int32_t W,
+                            const float* w_expand, int32_t c_mid, const float* scale0, const float* shift0,
+                            const float* w_dw, int32_t k, int32_t stride, int32_t pad_t, int32_t pad_l,
+                            int32_t Ho, int32_t Wo, const float* scale1, const float* shift1, float* y,
+                            float* pool_partial, void* stream);
 
 /* Encoder-side helper: 1x1 convolution as an fp32 MFMA GEMM with its surroundings fused,
  *   y[b,o,p] = act(scale[o] * sum_c w[o,c] * (gate[b,c] * x[b,c,p]) + shift[o]) + residual[b,o,p]

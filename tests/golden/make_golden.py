@@ -364,6 +364,60 @@ def gen_train():
         print(name, 'train y absmax', float(y.abs().max()), 'n grads', sum(1 for k in arrs if k.startswith('g.')))
 
 
+def gen_train_step():
+    """TWO optimisation steps of the tiny v1_0 decoder with the REFERENCE's loss / optimiser / LR policy
+    (BootstrappedCrossEntropyLoss(k, thresh, ignore_index=255), Adam(lr=1e-3, betas=(0.5, 0.999)), PolyLR per batch:
+    train.py:118-136, 240-262): losses, learning rates and every parameter / BN buffer after the steps."""
+    from hyperseg.losses.bootstrapped_ce_loss import BootstrappedCrossEntropyLoss
+    from hyperseg.utils.polylr import PolyLR
+    name = 't_v1_0'
+    cfg = TINY[name]
+    O.CONFIGS[name] = cfg
+    plan = O.config_plan(name)
+    params = O.synth_decoder_params(plan, seed=21)
+    dec = ref_decoder(cfg)
+    load_params(dec, params)
+    dec.train()
+    x, s = O.synth_decoder_inputs(name, batch=2, seed=21)
+    g = torch.Generator().manual_seed(22)
+    with torch.no_grad():
+        y0 = dec(x, s)
+    target = torch.randint(0, y0.shape[1], (y0.shape[0],) + tuple(y0.shape[2:]), generator=g)
+    target[torch.rand(target.shape, generator=g) < 0.1] = 255
+    k = y0.shape[2] * y0.shape[3] // 8
+    crit = BootstrappedCrossEntropyLoss(k=k, thresh=0.3, ignore_index=255)
+    start = {kk: v.clone() for kk, v in dec.state_dict().items()}
+    opt = torch.optim.Adam(dec.parameters(), lr=1e-3, betas=(0.5, 0.999))
+    sched = PolyLR(opt, 10, 0.9)
+    losses, lrs = [], []
+    with torch.enable_grad():
+        for it in range(2):
+            pred = dec(x, s)
+            loss = crit(pred, target)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            sched.step()
+            losses.append(float(loss))
+            lrs.append(opt.param_groups[0]['lr'])
+            if it == 0:
+                pred0 = pred.detach().clone()
+    arrs = {f'x{i}': t for i, t in enumerate(x)}
+    arrs['s'] = s
+    arrs['target'] = target
+    arrs['k'] = np.array(k)
+    arrs['pred0'] = pred0
+    arrs['losses'] = np.array(losses, dtype=np.float64)
+    # the other branch of the bootstrap rule (the (k+1)-th loss is below the threshold -> plain top-k)
+    arrs['loss_topk'] = np.array(float(BootstrappedCrossEntropyLoss(k=k, thresh=5.0, ignore_index=255)(pred0, target)))
+    arrs['loss_thresh'] = np.array(float(BootstrappedCrossEntropyLoss(k=k, thresh=0.3, ignore_index=255)(pred0, target)))
+    arrs['lrs'] = np.array(lrs, dtype=np.float64)
+    arrs.update({'start.' + kk: v for kk, v in start.items() if 'num_batches' not in kk})
+    arrs.update({'end.' + kk: v for kk, v in dec.state_dict().items() if 'num_batches' not in kk})
+    save('train_step_t_v1_0', **arrs)
+    print('train_step losses', losses, 'lrs', lrs, 'k', k)
+
+
 # ------------------------------------------------------------------------------ whole models (boundary)
 MODEL_KW = {
     'M': dict(mod='v1_0', name='efficientnet-b1', num_classes=19, kw=dict(
@@ -415,13 +469,9 @@ def hash_str(s):
 
 
 if __name__ == '__main__':
-    gen_meta_conv()
-    gen_meta_patch()
-    gen_meta_sequential()
-    gen_hyper_patch()
-    gen_ir_v1()
-    gen_ir_v0()
-    gen_divide_feature()
-    gen_decoders()
-    gen_train()
-    gen_models()
+    ALL = [gen_meta_conv, gen_meta_patch, gen_meta_sequential, gen_hyper_patch, gen_ir_v1, gen_ir_v0, gen_divide_feature,
+           gen_decoders, gen_train, gen_train_step, gen_models]
+    only = set(sys.argv[1:])            # e.g. "python make_golden.py gen_train_step" regenerates one fixture family
+    for fn in ALL:
+        if not only or fn.__name__ in only:
+            fn()

@@ -55,6 +55,31 @@ def test_depthwise_conv(HF, dev, k, stride, h, w, pre):
     assert rel_err(pooled, ref.mean((2, 3))) < REL_TOL
 
 
+@pytest.mark.parametrize('cin,cmid,k,stride,h,w', [(16, 96, 3, 2, 64, 128), (24, 144, 3, 1, 32, 48), (24, 144, 5, 2, 50, 70),
+                                                   (40, 240, 5, 1, 33, 47), (40, 100, 3, 2, 31, 45), (80, 480, 3, 1, 16, 32),
+                                                   (80, 200, 5, 1, 20, 36), (6, 20, 3, 1, 9, 9), (48, 40, 5, 2, 17, 40)])
+def test_mbconv_expand_dw(HF, dev, cin, cmid, k, stride, h, w):
+    """hs_mbconv_expand_dw_fwd == depthwise(zero-pad(swish(BN0(expand(x))))) -> BN1 -> swish, incl. ragged edge tiles,
+    channel counts that are not multiples of the 16-channel chunk / 4-wide k-step, and the SE pooling partial sums."""
+    g = torch.Generator().manual_seed(cin * 7 + cmid + k + stride)
+    b = 2
+    x = torch.randn(b, cin, h, w, generator=g)
+    we = torch.randn(cmid, cin, 1, 1, generator=g) / cin ** 0.5
+    wd = torch.randn(cmid, 1, k, k, generator=g) * 0.3
+    s0, b0 = torch.rand(cmid, generator=g) + 0.5, torch.randn(cmid, generator=g) * 0.3
+    s1, b1 = torch.rand(cmid, generator=g) + 0.5, torch.randn(cmid, generator=g) * 0.1
+    ho, wo = -(-h // stride), -(-w // stride)
+    ph, pw = max((ho - 1) * stride + k - h, 0), max((wo - 1) * stride + k - w, 0)
+    mid = swish(F.conv2d(x, we) * s0.view(1, -1, 1, 1) + b0.view(1, -1, 1, 1))
+    ref = F.conv2d(F.pad(mid, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2)), wd, stride=stride, groups=cmid)
+    ref = swish(ref * s1.view(1, -1, 1, 1) + b1.view(1, -1, 1, 1))
+    y, partial = HF.mbconv_expand_dw(x.to(dev), we.to(dev), s0.to(dev), b0.to(dev), wd.to(dev), stride, ph // 2, pw // 2,
+                                     (ho, wo), s1.to(dev), b1.to(dev), pool=True)
+    assert rel_err(y.cpu(), ref) < REL_TOL
+    pooled = partial.cpu().sum(1).view(b, cmid) / (ho * wo)
+    assert rel_err(pooled, ref.mean((2, 3))) < REL_TOL
+
+
 @pytest.mark.parametrize('c,csq,nblk,cout', [(32, 8, 128, 16), (96, 4, 32, 24), (240, 10, 8, 40), (672, 28, 2, 112),
                                              (1152, 48, 1, 320), (1920, 80, 1, 320), (50, 3, 5, 7)])
 @pytest.mark.parametrize('batch', [1, 2])

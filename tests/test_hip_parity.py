@@ -343,3 +343,22 @@ def test_errors_are_loud(HF, dev):
     # gradients are supported through hyperseg_amd.autograd (tests/test_hip_training.py)
     y = m(torch.randn(1, 4, 8, 8, device=dev, requires_grad=True), torch.randn(1, 16, 2, 2, device=dev))
     assert y.requires_grad and y.grad_fn is not None
+
+
+@pytest.mark.parametrize('shape,size', [((2, 19, 16, 32), (32, 64)), ((1, 19, 64, 128), (128, 256)), ((1, 7, 9, 13), (18, 26)),
+                                        ((2, 21, 11, 14), (33, 31)), ((1, 5, 12, 20), (12, 20)), ((1, 1, 8, 8), (16, 16)),
+                                        ((1, 256, 4, 6), (8, 12))])
+def test_upsample_argmax(HF, dev, shape, size):
+    """hs_upsample_argmax_fwd == argmax over hs_upsample_bilinear_fwd's logits, bit for bit (shared arithmetic), and ==
+    the reference epilogue F.interpolate(...).argmax(1) wherever the top-2 margin is not a rounding artefact."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g)
+    m = HF.upsample_argmax(x.to(dev), size).cpu()
+    assert m.dtype == torch.uint8 and tuple(m.shape) == (shape[0],) + tuple(size)
+    up = HF.upsample_bilinear(x.to(dev), size).cpu()
+    assert bool((m.long() == up.argmax(1)).all())
+    ref = F.interpolate(x, size, mode='bilinear', align_corners=False)
+    top2 = ref.topk(min(2, shape[1]), dim=1).values
+    clear = (top2[:, 0] - top2[:, -1] > MARGIN) if shape[1] > 1 else torch.ones_like(m, dtype=torch.bool)
+    assert bool((m.long()[clear] == ref.argmax(1)[clear]).all())

@@ -128,6 +128,22 @@ def test_model_m_end_to_end(golden, model_m):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('tag', ['M', 'S', 'L'])
+def test_segment_equals_argmax_of_forward(golden, tag):
+    """HyperGen.segment (argmax fused into the final upsample) == forward(x).argmax(1), bit for bit."""
+    from hyperseg_amd import configs
+    g = golden(f'model_{tag}')
+    dev = torch.device('cuda:0')
+    m = fill_by_name(configs.build(MODELS[tag]).eval(), seed=11).to(dev)
+    x = g['x'].to(dev)
+    with torch.no_grad():
+        masks = m.segment(x)
+        ref = m(x).argmax(1)
+    assert masks.dtype == torch.uint8 and masks.shape == ref.shape
+    assert bool((masks.long() == ref).all())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('batch', [1, 2])
 def test_inference_prep_matches_stock_encoder(batch):
     """prepare_for_inference (fused depthwise + BN + swish + SE kernels, gate folded into the project conv) leaves the
@@ -198,6 +214,11 @@ def test_deferred_bn_shift_algebra_cpu(monkeypatch):
         x.copy_(y if residual is None else y + residual)
         return x
 
+    def expand_dw(x, w_expand, scale0, shift0, w_dw, stride, pad_top, pad_left, out_size, scale1, shift1, pool=True):
+        hmid = pointwise(x, w_expand.view(w_expand.shape[0], -1, 1, 1), None, scale0, shift0, 3)
+        return dw(hmid, w_dw, stride, pad_top, pad_left, out_size, scale1, shift1, act=3, pool=True)
+
+    monkeypatch.setattr(HF, 'mbconv_expand_dw', expand_dw)
     monkeypatch.setattr(HF, 'depthwise_conv_bn_act', dw)
     monkeypatch.setattr(HF, 'se_gate', se_gate)
     monkeypatch.setattr(HF, 'pointwise_conv', pointwise)

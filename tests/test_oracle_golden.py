@@ -202,3 +202,28 @@ def test_train_step_oracle_vs_reference(golden):
         assert rel_err(params[k].grad, v) < 1e-4, k
     for k, v in sub(g, 'after.').items():
         assert rel_err(stats[k], v) < 1e-5, k
+
+
+def test_training_harness_loss_and_lr_vs_reference(golden):
+    """hyperseg_amd.training (bootstrapped CE, PolyLR) against values captured from the reference's own classes
+    (make_golden.gen_train_step): both branches of the bootstrap rule, ignore_index pixels, the per-batch LR decay."""
+    from hyperseg_amd.training import BootstrappedCrossEntropyLoss, PolyLR, bootstrapped_cross_entropy
+    g = golden('train_step_t_v1_0')
+    k = int(g['k'])
+    pred, target = g['pred0'], g['target']
+    assert bool((target == 255).any())
+    a = float(bootstrapped_cross_entropy(pred, target, k, 0.3, ignore_index=255))
+    b = float(BootstrappedCrossEntropyLoss(k=k, thresh=5.0, ignore_index=255)(pred, target))
+    assert abs(a - float(g['loss_thresh'])) < 1e-6 * abs(a) + 1e-7
+    assert abs(b - float(g['loss_topk'])) < 1e-6 * abs(b) + 1e-7
+    assert abs(a - b) > 1e-3                                   # the two branches really differ on this input
+    assert abs(a - float(g['losses'][0])) < 1e-6
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=1e-3, betas=(0.5, 0.999))
+    sched = PolyLR(opt, 10, 0.9)
+    lrs = []
+    for _ in range(2):
+        opt.step()
+        sched.step()
+        lrs.append(opt.param_groups[0]['lr'])
+    assert np.allclose(lrs, g['lrs'].numpy() if hasattr(g['lrs'], 'numpy') else g['lrs'], rtol=1e-12)
