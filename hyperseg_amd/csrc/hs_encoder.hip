@@ -56,7 +56,7 @@ void depthwise_conv_kernel(const float* __restrict__ x, const float* __restrict_
             const int xi = xi0 + j;
             const bool ok = row_ok && xi >= 0 && xi < W;
             float t = v[ky][j];
-            if (pre) { t = fmaf(t, isc, ish); t = t / (1.0f + expf(-t)); }
+            if (pre) t = swishf(fmaf(t, isc, ish));
             v[ky][j] = ok ? t : 0.0f;
         }
 #pragma unroll
@@ -71,7 +71,7 @@ void depthwise_conv_kernel(const float* __restrict__ x, const float* __restrict_
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         float r = fmaf(acc[t], sc, sh);
-        if (act == 3) r = r / (1.0f + expf(-r));                   // swish / SiLU
+        if (act == 3) r = swishf(r);                               // swish / SiLU
         else r = apply_act(r, act);
         o[t] = r;
     }
@@ -135,7 +135,7 @@ void se_squeeze_kernel(const float* __restrict__ partial, int nblk, float inv_hw
     __syncthreads();
     if (tid == 0) {
         const float t = fmaf((ws[0] + ws[1]) + (ws[2] + ws[3]), inv_hw, b1[j]);
-        z[(size_t)b * Csq + j] = t / (1.0f + expf(-t));
+        z[(size_t)b * Csq + j] = swishf(t);
     }
 }
 
@@ -171,7 +171,7 @@ void se_excite_kernel(const float* __restrict__ z, const float* __restrict__ w2t
     red[part][col] = acc;
     __syncthreads();
     const float t = ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) + b2[cc];
-    const float g = 1.0f / (1.0f + expf(-t));
+    const float g = sigmoidf_fast(t);
     if (blockIdx.z == 0 && part == 0 && c < C) gate[(size_t)b * C + c] = g;
     if (w_proj && c < C) {
         float* __restrict__ dst = w_scaled + (size_t)b * Cout * C + c;
@@ -247,6 +247,9 @@ namespace hs {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+// NB = number of 16-channel K batches (fully unrolled, double buffered: the loads of batch i+1 are in flight while the
+// MFMAs of batch i run), NT = 16-pixel tiles per wave (the host shrinks it until the launch has >= 512 workgroups).
+template <int NB, int NT>
 __global__ __launch_bounds__(256)
 void pointwise_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ gate,
                            const float* __restrict__ scale, const float* __restrict__ shift,
@@ -255,49 +258,54 @@ void pointwise_conv_kernel(const float* __restrict__ x, const float* __restrict_
     const int lrow = lane & 15, lk = lane >> 4;
     const int b = blockIdx.z;
     const int o0 = blockIdx.y * 32;
-    const int p0 = (blockIdx.x * 4 + wave) * 64;
+    const int p0 = (blockIdx.x * 4 + wave) * (16 * NT);
     if (p0 >= P) return;
     const float* __restrict__ xb = x + (size_t)b * Cin * P;
     const float* __restrict__ gb = gate ? gate + (size_t)b * Cin : nullptr;
-    f32x4 acc[2][4];
+    f32x4 acc[2][NT];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     // clamped per-lane rows / pixels (masked lanes read valid addresses; their products are zeroed)
     int orow[2]; bool ook[2];
 #pragma unroll
     for (int m = 0; m < 2; ++m) { const int o = o0 + 16 * m + lrow; ook[m] = o < Cout; orow[m] = ook[m] ? o : Cout - 1; }
-    int pcol[4]; bool pok[4];
+    int pcol[NT]; bool pok[NT];
 #pragma unroll
-    for (int n = 0; n < 4; ++n) { const int p = p0 + 16 * n + lrow; pok[n] = p < P; pcol[n] = pok[n] ? p : P - 1; }
-    constexpr int KU = 4;                                   // k-steps per load batch
-    for (int k0 = 0; k0 < Cin; k0 += 4 * KU) {
-        float av[KU][2], bv[KU][4];
+    for (int n = 0; n < NT; ++n) { const int p = p0 + 16 * n + lrow; pok[n] = p < P; pcol[n] = pok[n] ? p : P - 1; }
+    constexpr int KU = 4;                                   // k-steps per batch (16 input channels)
+    float av[2][KU][2], bv[2][KU][NT];
+    auto load_batch = [&](int i, float (&a)[KU][2], float (&bb)[KU][NT]) {
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
-            const int k = k0 + 4 * u + lk;
+            const int k = i * 4 * KU + 4 * u + lk;
             const bool kok = k < Cin;
             const int kc = kok ? k : Cin - 1;
             const float g = gb ? gb[kc] : 1.0f;
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const float t = w[(size_t)orow[m] * Cin + kc];
-                av[u][m] = (kok && ook[m]) ? t : 0.0f;
+                a[u][m] = (kok && ook[m]) ? t : 0.0f;
             }
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
+            for (int n = 0; n < NT; ++n) {
                 const float t = xb[(size_t)kc * P + pcol[n]];
-                bv[u][n] = (kok && pok[n]) ? t * g : 0.0f;
+                bb[u][n] = (kok && pok[n]) ? t * g : 0.0f;
             }
         }
+    };
+    load_batch(0, av[0], bv[0]);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        if (i + 1 < NB) load_batch(i + 1, av[(i + 1) & 1], bv[(i + 1) & 1]);
 #pragma unroll
         for (int u = 0; u < KU; ++u)
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int n = 0; n < 4; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][m], bv[u][n], acc[m][n], 0, 0, 0);
+                for (int n = 0; n < NT; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i & 1][u][m], bv[i & 1][u][n], acc[m][n], 0, 0, 0);
     }
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -307,16 +315,27 @@ void pointwise_conv_kernel(const float* __restrict__ x, const float* __restrict_
             if (o >= Cout) continue;
             const float sc = scale ? scale[o] : 1.0f, sh = shift ? shift[o] : 0.0f;
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
+            for (int n = 0; n < NT; ++n) {
                 if (!pok[n]) continue;
                 float v = fmaf(acc[m][n][r], sc, sh);
-                if (act == 3) v = v / (1.0f + expf(-v));
+                if (act == 3) v = swishf(v);
                 else v = apply_act(v, act);
                 const size_t idx = ((size_t)b * Cout + o) * P + pcol[n];
                 if (residual) v += residual[idx];
                 y[idx] = v;
             }
         }
+}
+
+template <int NB>
+static int launch_pointwise(int nt, dim3 grid, hipStream_t s, const float* x, const float* w, const float* gate,
+                            const float* scale, const float* shift, const float* residual, float* y, int c_in, int c_out,
+                            int pixels, int act) {
+#define HS_PW(NT) hipLaunchKernelGGL((pointwise_conv_kernel<NB, NT>), grid, dim3(256), 0, s, x, w, gate, scale, shift, \
+                                     residual, y, c_in, c_out, pixels, act)
+    if (nt == 4) HS_PW(4); else if (nt == 2) HS_PW(2); else HS_PW(1);
+#undef HS_PW
+    return launch_status();
 }
 
 }  // namespace hs
@@ -326,10 +345,22 @@ extern "C" int hs_pointwise_conv_fwd(const float* x, int32_t batch, int32_t c_in
                                      const float* residual, float* y, void* stream) {
     if (!x || !w || !y || batch <= 0 || c_in <= 0 || c_out <= 0 || pixels <= 0 || (scale && !shift)) return HS_ERR_BAD_ARG;
     if (batch > 65535 || (c_out + 31) / 32 > 65535) return HS_ERR_UNSUPPORTED;
-    dim3 grid((pixels + 255) / 256, (c_out + 31) / 32, batch);
-    hipLaunchKernelGGL(hs::pointwise_conv_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w, gate, scale, shift,
-                       residual, y, c_in, c_out, pixels, act);
-    return hs::launch_status();
+    if (c_in > 128) return HS_ERR_UNSUPPORTED;              // larger K: library GEMM (utils/inference.py routes those)
+    const int mblocks = (c_out + 31) / 32;
+    int nt = 4;
+    while (nt > 1 && (long)((pixels + 64 * nt - 1) / (64 * nt)) * mblocks * batch < 512) nt >>= 1;
+    dim3 grid((pixels + 64 * nt - 1) / (64 * nt), mblocks, batch);
+    hipStream_t s = (hipStream_t)stream;
+    switch ((c_in + 15) / 16) {
+        case 1: return hs::launch_pointwise<1>(nt, grid, s, x, w, gate, scale, shift, residual, y, c_in, c_out, pixels, act);
+        case 2: return hs::launch_pointwise<2>(nt, grid, s, x, w, gate, scale, shift, residual, y, c_in, c_out, pixels, act);
+        case 3: return hs::launch_pointwise<3>(nt, grid, s, x, w, gate, scale, shift, residual, y, c_in, c_out, pixels, act);
+        case 4: return hs::launch_pointwise<4>(nt, grid, s, x, w, gate, scale, shift, residual, y, c_in, c_out, pixels, act);
+        case 5: return hs::launch_pointwise<5>(nt, grid, s, x, w, gate, scale, shift, residual, y, c_in, c_out, pixels, act);
+        case 6: return hs::launch_pointwise<6>(nt, grid, s, x, w, gate, scale, shift, residual, y, c_in, c_out, pixels, act);
+        case 7: return hs::launch_pointwise<7>(nt, grid, s, x, w, gate, scale, shift, residual, y, c_in, c_out, pixels, act);
+        default: return hs::launch_pointwise<8>(nt, grid, s, x, w, gate, scale, shift, residual, y, c_in, c_out, pixels, act);
+    }
 }
 
 // y = act(scale[c] * x + shift[c]) + residual, elementwise over (B, C, P); y may alias x.  Used after the stock
@@ -345,7 +376,7 @@ void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ sc
         const float4 v = reinterpret_cast<const float4*>(x)[e];
         float o[4] = {fmaf(v.x, sc, sh), fmaf(v.y, sc, sh), fmaf(v.z, sc, sh), fmaf(v.w, sc, sh)};
 #pragma unroll
-        for (int t = 0; t < 4; ++t) o[t] = act == 3 ? o[t] / (1.0f + expf(-o[t])) : apply_act(o[t], act);
+        for (int t = 0; t < 4; ++t) o[t] = act == 3 ? swishf(o[t]) : apply_act(o[t], act);
         if (residual) {
             const float4 r = reinterpret_cast<const float4*>(residual)[e];
             o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;

@@ -44,8 +44,6 @@ template <int K, int S, int OTH, int OTW> struct MbxGeom {
     static_assert(16 % OTH == 0 && OTW % NSEG == 0 && (NOUT * S) % 4 == 0, "tile shape");
 };
 
-__device__ __forceinline__ float swishf(float t) { return t / (1.0f + expf(-t)); }
-
 // two workgroups per CU wherever the B fragments leave room for it (<= 256 registers incl. AGPRs): the per-chunk weight
 // fetch and the two barriers of one workgroup then overlap the other's MFMA / depthwise phases
 template <int K, int S, int OTH, int OTW, int KS>
@@ -80,8 +78,10 @@ void mbconv_expand_dw_kernel(MbxArgs a) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int c = ks * 4 + lk;
+            // unconditional load from a clamped (always valid) address, masked by a multiply: a select would let the
+            // compiler predicate every load behind its own exec-mask branch
             const float v = src[(size_t)(c < Cin ? c : Cin - 1) * plane];
-            bf[jt][ks] = (in && c < Cin) ? v : 0.0f;
+            bf[jt][ks] = v * ((in && c < Cin) ? 1.0f : 0.0f);
         }
         h1off[jt] = ok ? ((pu * G::RS + pv) | (in ? (1 << 30) : 0)) : -1;
     }
@@ -133,8 +133,10 @@ void mbconv_expand_dw_kernel(MbxArgs a) {
                     const bool in = (h1off[jt] >> 30) & 1;
                     const int off = h1off[jt] & ((1 << 30) - 1);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        h1[(4 * lk + r) * G::H1P + off] = in ? swishf(fmaf(acc[r], sc0[r], sh0[r])) : 0.0f;
+                    for (int r = 0; r < 4; ++r) {
+                        const float sv = swishf(fmaf(acc[r], sc0[r], sh0[r]));
+                        h1[(4 * lk + r) * G::H1P + off] = in ? sv : 0.0f;
+                    }
                 }
             }
         }

@@ -234,8 +234,11 @@ void upsample2x_kernel(const float* __restrict__ x, int planes, int Hi, int Wi, 
         float o0[4], o1[4];
         up2x_block(x + pl * Hi * Wi, Hi, Wi, yi, q, o0, o1);
         float* dst = y + (pl * 2 * Hi + 2 * yi) * Wo + 4 * q;
-        *reinterpret_cast<float4*>(dst) = make_float4(o0[0], o0[1], o0[2], o0[3]);
-        *reinterpret_cast<float4*>(dst + Wo) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+        // streaming stores: the full-resolution logits (39.8 MB at HyperSeg-M) are written once and not re-read by this
+        // frame -- keep them from evicting the next frame's weights and features from L2 / MALL
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(v4f{o0[0], o0[1], o0[2], o0[3]}, reinterpret_cast<v4f*>(dst));
+        __builtin_nontemporal_store(v4f{o1[0], o1[1], o1[2], o1[3]}, reinterpret_cast<v4f*>(dst + Wo));
     }
 }
 

@@ -56,6 +56,11 @@ def _bn_affine(bn):
 
 # output pixels from which the fused expand + depthwise kernel is used (tools/bench_mbconv.py measures both routes)
 FUSE_EXPAND_MIN_PIXELS = int(os.environ.get('HS_FUSE_EXPAND_MIN_PIXELS', '2048'))
+FUSE_EXPAND_MAX_CIN = int(os.environ.get('HS_FUSE_EXPAND_MAX_CIN', '40'))      # wider inputs: 1 wave / SIMD, slower than GEMM + dw
+
+
+PW_MFMA_MAX_CIN = int(os.environ.get('HS_PW_MFMA_MAX_CIN', '96'))
+PW_MFMA_MIN_PIXELS = int(os.environ.get('HS_PW_MFMA_MIN_PIXELS', '8192'))
 
 
 class FusedPointwise(nn.Module):
@@ -83,8 +88,9 @@ class FusedPointwise(nn.Module):
         self.shift.add_(self.scale * (w @ offset))
 
     def uses_mfma(self, x):
-        """Small-K, many-pixel layers run as one fused MFMA GEMM; large-K layers keep the stock (rocBLAS) GEMM."""
-        return x.shape[1] <= 96 and x.shape[2] * x.shape[3] >= 8192
+        """Small-K, many-pixel layers run as one fused MFMA GEMM; large-K layers keep the library GEMM
+        (tools/bench_mbconv.py times both routes per layer)."""
+        return x.shape[1] <= PW_MFMA_MAX_CIN and x.shape[2] * x.shape[3] >= PW_MFMA_MIN_PIXELS
 
     def raw(self, x):
         """The bare GEMM (batch 1): W (Cout, Cin) @ x (Cin, HW); BN + activation are left to the consumer."""
@@ -159,7 +165,7 @@ class FusedMBConv(nn.Module):
         """[expand + BN + swish + depthwise + BN + swish + pool] as ONE launch (hs_mbconv_expand_dw_fwd): wherever the
         map is large enough to fill the chip with (tile x channel-chunk) workgroups and Cin fits the register-resident
         B fragments.  Small late maps keep the library GEMM + depthwise kernel pair."""
-        return self.expand is not None and x.shape[1] <= 80 and ho * wo >= FUSE_EXPAND_MIN_PIXELS
+        return self.expand is not None and x.shape[1] <= FUSE_EXPAND_MAX_CIN and ho * wo >= FUSE_EXPAND_MIN_PIXELS
 
     def forward(self, inputs, blk):
         from .. import functional as HF

@@ -106,3 +106,41 @@ def test_optimizer_step_runs(dev):
         opt.step()
         losses.append(float(loss))
     assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0]
+
+
+def test_two_optimizer_steps_vs_reference(golden, dev):
+    """hyperseg_amd.training.train_step x 2 on the HIP decoder == the reference's loop (train.py:118-136) run with the
+    reference's BootstrappedCrossEntropyLoss / Adam(betas=(0.5, 0.999)) / PolyLR on the reference decoder
+    (fixture train_step_t_v1_0.npz): losses, learning rates, BN running statistics and parameters after two steps.
+    Adam's first steps move every parameter by ~lr * sign(grad): where a gradient is at rounding-noise level the sign may
+    differ between the two implementations, so parameters are compared element-wise with a 1 % budget for such entries."""
+    from hyperseg_amd.training import BootstrappedCrossEntropyLoss, PolyLR, train_step
+    g = golden('train_step_t_v1_0')
+    d = make_decoder(TINY['t_v1_0'])
+    missing, unexpected = d.load_state_dict(sub(g, 'start.'), strict=False)
+    assert not unexpected and all('num_batches' in k for k in missing)
+    d = d.to(dev).train()
+    x = [g[f'x{i}'].to(dev) for i in range(6)]
+    s, target = g['s'].to(dev), g['target'].to(dev)
+    crit = BootstrappedCrossEntropyLoss(k=int(g['k']), thresh=0.3, ignore_index=255)
+    opt = torch.optim.Adam(d.parameters(), lr=1e-3, betas=(0.5, 0.999))
+    sched = PolyLR(opt, 10, 0.9)
+    losses, lrs = [], []
+    for it in range(2):
+        loss, pred = train_step(lambda inp: d(inp, s), crit, opt, sched, x, target)
+        if it == 0:
+            assert rel_err(pred.cpu(), g['pred0']) < TOL
+        losses.append(float(loss))
+        lrs.append(opt.param_groups[0]['lr'])
+    ref_losses = [float(v) for v in g['losses']]
+    assert abs(losses[0] - ref_losses[0]) < 1e-5 * abs(ref_losses[0])
+    assert abs(losses[1] - ref_losses[1]) < 1e-3 * abs(ref_losses[1])
+    assert all(abs(a - float(b)) < 1e-12 for a, b in zip(lrs, g['lrs']))
+    sd = d.state_dict()
+    for k, v in sub(g, 'end.').items():
+        mine = sd[k].cpu()
+        if 'running_' in k:
+            assert rel_err(mine, v) < 1e-3, k
+        else:
+            close = (mine - v).abs() <= 1e-5 + 1e-4 * v.abs()
+            assert float(close.float().mean()) > 0.99, (k, float(close.float().mean()))

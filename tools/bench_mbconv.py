@@ -78,3 +78,28 @@ for idx, blk in enumerate(bb._blocks):
               f'{err:9.1e} pool {perr:.1e}')
     t = blk(t)
 print(f'sum unfused {tot_a:.1f} us   fused {tot_b:.1f} us')
+
+# ---- every 1x1 convolution of the encoder: library GEMM (torch.mm) vs hs_pointwise_conv_fwd (bare GEMM, no epilogue) ----
+print(f'\n{"blk":>3} {"conv":>7} {"cin":>5} {"cout":>5} {"pixels":>7} {"mm_us":>8} {"mfma_us":>8}')
+t = torch.nn.functional.silu(bb._bn0(bb._conv_stem(x)))
+for idx, blk in enumerate(bb._blocks):
+    f = blk._fused_dw
+    xin = t.contiguous()
+    convs = []
+    if f.expand is not None:
+        convs.append(('expand', blk._expand_conv.weight, xin))
+    hh, ww = xin.shape[2:]
+    ho = (hh + f.pad_h - f.k) // f.stride + 1
+    wo = (ww + f.pad_w - f.k) // f.stride + 1
+    convs.append(('project', blk._project_conv.weight, torch.randn(1, blk._project_conv.in_channels, ho, wo, device=dev)))
+    for name, wt, inp in convs:
+        cin, px = inp.shape[1], inp.shape[2] * inp.shape[3]
+        if cin > 128:
+            ta, _ = timed(lambda: torch.mm(wt.view(-1, cin), inp.view(cin, px)))
+            print(f'{idx:3d} {name:>7} {cin:5d} {wt.shape[0]:5d} {px:7d} {ta:8.2f} {"-":>8}')
+            continue
+        ta, ya = timed(lambda: torch.mm(wt.view(-1, cin), inp.view(cin, px)))
+        tb, yb = timed(lambda: HF.pointwise_conv(inp, wt, None, None, None, 0, None))
+        err = float((ya.view(-1) - yb.view(-1)).abs().max() / ya.abs().max())
+        print(f'{idx:3d} {name:>7} {cin:5d} {wt.shape[0]:5d} {px:7d} {ta:8.2f} {tb:8.2f}   err {err:.1e}')
+    t = blk(t)
