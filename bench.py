@@ -144,6 +144,8 @@ def main():
     from hyperseg_amd.utils.synthetic import fill_by_name
     import hyperseg_amd.functional as HF
 
+    if os.environ.get('HS_BLAS'):                                   # dev knob: 'cublas' (= rocBLAS) | 'cublaslt' (= hipBLASLt)
+        torch.backends.cuda.preferred_blas_library(os.environ['HS_BLAS'])
     spec = configs.MODELS[MODEL]
     h, w = spec['size']
     from hyperseg_amd.utils.inference import prepare_for_inference

@@ -14,7 +14,10 @@
 
 namespace hs {
 
-template <int K, int S>
+// PL >= 0: the left padding is the compile-time constant PL and W % 4 == 0 -- every tap row is then fetched as aligned
+// 16-byte loads (3-4 per row instead of 6-11 dword loads; the kernel is bound by the texture-address path, which spends
+// the same cycles on a 4-byte as on a 16-byte per-lane access).  PL = -1: arbitrary pad_l / W, dword loads.
+template <int K, int S, int PL>
 __global__ __launch_bounds__(256)
 void depthwise_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
                            const float* __restrict__ shift, float* __restrict__ y, int C, int H, int W, int Ho, int Wo,
@@ -39,12 +42,32 @@ void depthwise_conv_kernel(const float* __restrict__ x, const float* __restrict_
     // every tap of the K x NCOL window is loaded BEFORE the first use (clamped addresses, masks applied afterwards): a
     // row-by-row load/fma interleaving exposes one memory round trip per tap row
     float v[K][NCOL];
+    if constexpr (PL >= 0) {
+        constexpr int OFF = (4 - PL % 4) % 4;                      // xi0 = 4*q*S - PL: misalignment of the window start
+        constexpr int NV = (OFF + NCOL + 3) / 4;
+        const int a0 = xi0 - OFF;                                  // multiple of 4
 #pragma unroll
-    for (int ky = 0; ky < K; ++ky) {
-        const int yi = yi0 + ky;
-        const float* __restrict__ row = xp + (size_t)min(max(yi, 0), H - 1) * W;
+        for (int ky = 0; ky < K; ++ky) {
+            const int yi = yi0 + ky;
+            const float* __restrict__ row = xp + (size_t)min(max(yi, 0), H - 1) * W;
+            float win[NV * 4];
 #pragma unroll
-        for (int j = 0; j < NCOL; ++j) v[ky][j] = row[min(max(xi0 + j, 0), W - 1)];
+            for (int i = 0; i < NV; ++i) {
+                const int col = a0 + 4 * i;                        // W % 4 == 0: a quad is entirely inside or outside
+                const float4 t = *reinterpret_cast<const float4*>(row + ((col >= 0 && col < W) ? col : 0));
+                win[4 * i] = t.x; win[4 * i + 1] = t.y; win[4 * i + 2] = t.z; win[4 * i + 3] = t.w;
+            }
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) v[ky][j] = win[OFF + j];
+        }
+    } else {
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const int yi = yi0 + ky;
+            const float* __restrict__ row = xp + (size_t)min(max(yi, 0), H - 1) * W;
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) v[ky][j] = row[min(max(xi0 + j, 0), W - 1)];
+        }
     }
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -200,12 +223,13 @@ extern "C" int hs_depthwise_conv_fwd(const float* x, int32_t batch, int32_t chan
     const int threads = quads >= 256 ? 256 : ((quads + 63) / 64) * 64;
     dim3 grid((quads + threads - 1) / threads, batch * channels);
     hipStream_t s = (hipStream_t)stream;
-#define HS_DW(KK, SS) hipLaunchKernelGGL((depthwise_conv_kernel<KK, SS>), grid, dim3(threads), 0, s, x, w, scale, shift, y, \
-                                         channels, H, W, Ho, Wo, pad_t, pad_l, act, pool_partial, in_scale, in_shift)
-    if (k == 3 && stride == 1) HS_DW(3, 1);
-    else if (k == 3 && stride == 2) HS_DW(3, 2);
-    else if (k == 5 && stride == 1) HS_DW(5, 1);
-    else if (k == 5 && stride == 2) HS_DW(5, 2);
+#define HS_DW(KK, SS, PP) hipLaunchKernelGGL((depthwise_conv_kernel<KK, SS, PP>), grid, dim3(threads), 0, s, x, w, scale, shift, \
+                                             y, channels, H, W, Ho, Wo, pad_t, pad_l, act, pool_partial, in_scale, in_shift)
+    const bool vec = (W & 3) == 0 && (((size_t)x) & 15) == 0;
+    if (k == 3 && stride == 1) { if (vec && pad_l == 1) HS_DW(3, 1, 1); else HS_DW(3, 1, -1); }
+    else if (k == 3 && stride == 2) { if (vec && pad_l == 0) HS_DW(3, 2, 0); else if (vec && pad_l == 1) HS_DW(3, 2, 1); else HS_DW(3, 2, -1); }
+    else if (k == 5 && stride == 1) { if (vec && pad_l == 2) HS_DW(5, 1, 2); else HS_DW(5, 1, -1); }
+    else if (k == 5 && stride == 2) { if (vec && pad_l == 1) HS_DW(5, 2, 1); else if (vec && pad_l == 2) HS_DW(5, 2, 2); else HS_DW(5, 2, -1); }
     else return HS_ERR_UNSUPPORTED;
 #undef HS_DW
     return launch_status();
@@ -394,5 +418,82 @@ extern "C" int hs_affine_act_fwd(const float* x, int32_t batch, int32_t channels
     const unsigned blocks = (unsigned)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256);
     hipLaunchKernelGGL(hs::affine_act_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, scale, shift, residual, y,
                        channels, pixels, n4, act);
+    return hs::launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Stem: dense 3x3 stride-2 convolution of the (3-channel) image + folded BatchNorm + swish in one launch, TF-"SAME" zero
+// padding by (top, left) offsets.  Replaces F.pad (fill + copy) + MIOpen conv + BatchNorm2d + SiLU = 5 launches
+// (efficientnet.py:321-322 of the reference).  One thread = 4 consecutive output pixels x 8 output channels: 27 input
+// values per channel-plane window (81 loads, all in flight), the 8 x 27 weights are workgroup-uniform (scalar loads),
+// 1 KB contiguous per store instruction.
+// ---------------------------------------------------------------------------------------------------------------
+namespace hs {
+template <int CIN>
+__global__ __launch_bounds__(256)
+void stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
+                      const float* __restrict__ shift, float* __restrict__ y, int Cout, int H, int W, int Ho, int Wo,
+                      int pad_t, int pad_l) {
+    constexpr int K = 3, S = 2, NCOL = 3 * S + K, CG = 8;
+    const int wq = (Wo + 3) >> 2;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Ho * wq) return;
+    const int g = blockIdx.y, b = blockIdx.z;
+    const int yo = q / wq, xo = (q - yo * wq) * 4;
+    const int xi0 = xo * S - pad_l, yi0 = yo * S - pad_t;
+    const float* __restrict__ xb = x + (size_t)b * CIN * H * W;
+    float v[CIN][K][NCOL];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c)
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const int yi = yi0 + ky;
+            const bool row_ok = yi >= 0 && yi < H;
+            const float* __restrict__ row = xb + ((size_t)c * H + min(max(yi, 0), H - 1)) * W;
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) {
+                const int xi = xi0 + j;
+                const float t = row[min(max(xi, 0), W - 1)];
+                v[c][ky][j] = t * ((row_ok && xi >= 0 && xi < W) ? 1.0f : 0.0f);
+            }
+        }
+#pragma unroll
+    for (int oc = 0; oc < CG; ++oc) {
+        const int o = min(g * CG + oc, Cout - 1);
+        const float* __restrict__ wo = w + (size_t)o * CIN * K * K;          // workgroup-uniform -> scalar loads
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < CIN; ++c)
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const float wv = wo[(c * K + ky) * K + kx];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = fmaf(wv, v[c][ky][t * S + kx], acc[t]);
+                }
+        if (g * CG + oc < Cout) {
+            const float sc = scale[o], sh = shift[o];
+            float r[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) r[t] = swishf(fmaf(acc[t], sc, sh));
+            float* dst = y + (((size_t)b * Cout + o) * Ho + yo) * Wo + xo;
+            if ((Wo & 3) == 0) *reinterpret_cast<float4*>(dst) = make_float4(r[0], r[1], r[2], r[3]);
+            else for (int t = 0; t < 4 && xo + t < Wo; ++t) dst[t] = r[t];
+        }
+    }
+}
+}  // namespace hs
+
+extern "C" int hs_stem_conv_fwd(const float* x, int32_t batch, int32_t c_in, int32_t H, int32_t W, const float* w,
+                                int32_t c_out, int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo, const float* scale,
+                                const float* shift, float* y, void* stream) {
+    if (!x || !w || !scale || !shift || !y || batch <= 0 || c_out <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 ||
+        pad_t < 0 || pad_l < 0) return HS_ERR_BAD_ARG;
+    if (c_in != 3 || batch > 65535) return HS_ERR_UNSUPPORTED;
+    const int quads = Ho * ((Wo + 3) / 4);
+    dim3 grid((quads + 255) / 256, (c_out + 7) / 8, batch);
+    hipLaunchKernelGGL(hs::stem_conv_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, x, w, scale, shift, y, c_out, H, W,
+                       Ho, Wo, pad_t, pad_l);
     return hs::launch_status();
 }

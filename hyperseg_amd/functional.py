@@ -265,6 +265,19 @@ def depthwise_conv_bn_act(x, weight, stride, pad_top, pad_left, out_size, scale=
     return (y, partial) if pool else y
 
 
+def stem_conv_bn_swish(x, weight, pad_top, pad_left, out_size, scale, shift):
+    """3x3 stride-2 conv of the 3-channel image + folded BN + swish, one launch (encoder stem).  Opt-in helper."""
+    b, cin, h, w = x.shape
+    cout = weight.shape[0]
+    ho, wo = out_size
+    y = torch.empty(b, cout, ho, wo, device=x.device, dtype=torch.float32)
+    st = _hip.lib.hs_stem_conv_fwd(_hip.dev_ptr(x, 'x'), b, cin, h, w, _hip.dev_ptr(weight, 'weight'), cout, pad_top, pad_left,
+                                   ho, wo, _hip.dev_ptr(scale, 'scale'), _hip.dev_ptr(shift, 'shift'), y.data_ptr(),
+                                   _hip.stream_ptr())
+    _hip.check(st, 'hs_stem_conv_fwd')
+    return y
+
+
 def mbconv_expand_dw(x, w_expand, scale0, shift0, w_dw, stride, pad_top, pad_left, out_size, scale1, shift1, pool=True):
     """1x1 expand + BN + swish + depthwise k x k (TF-"SAME" zero padding of the ACTIVATION) + BN + swish in one launch
     (+ SE pooling partial sums): the expanded tensor never reaches HBM.  x (B,Cin,H,W), w_expand (Cmid,Cin[,1,1]),

@@ -171,10 +171,13 @@ class EfficientNet(nn.Module):
         self._avg_pooling = nn.AdaptiveAvgPool2d(1)
         self._dropout = nn.Dropout(dropout)
         self._fc = head(head_nc, num_classes) if head is not None else None
-        self._fused_head, self._fused_fc = None, None      # set by utils.inference.prepare_for_inference
+        self._fused_head, self._fused_fc, self._fused_stem = None, None, None      # set by utils.inference.prepare_for_inference
 
     def extract_features_list(self, inputs):
-        x = F.silu(self._bn0(self._conv_stem(inputs)))
+        if self._fused_stem is not None and inputs.is_cuda and not self.training:
+            x = self._fused_stem(inputs)
+        else:
+            x = F.silu(self._bn0(self._conv_stem(inputs)))
         feats = []
         n = len(self._blocks)
         for idx, block in enumerate(self._blocks):

@@ -566,8 +566,12 @@ class WeightMapper(nn.Module):
             self.down_blocks.append(block(half, 2, 2))
             self.up_blocks.append(block(in_channels, 1, 1))
         self.upsample = nn.UpsamplingNearest2d(scale_factor=2)
+        self._fused = None          # set by utils.inference.prepare_for_inference (single-frame inference route)
 
     def forward(self, x):
+        if self._fused is not None and x.is_cuda and x.shape[0] == 1 and not self.training \
+                and x.shape[2] % 2 ** self.levels == 0 and x.shape[3] % 2 ** self.levels == 0:
+            return self._fused(x.contiguous())
         feat = [self.in_conv(x)]
         for down in self.down_blocks:
             feat.append(down(feat[-1]))

@@ -59,6 +59,9 @@ FUSE_EXPAND_MIN_PIXELS = int(os.environ.get('HS_FUSE_EXPAND_MIN_PIXELS', '2048')
 FUSE_EXPAND_MAX_CIN = int(os.environ.get('HS_FUSE_EXPAND_MAX_CIN', '40'))      # wider inputs: 1 wave / SIMD, slower than GEMM + dw
 
 
+# batch-1 project convs need no epilogue once gate / BN scale are folded into the weights: the bare library GEMM beats
+# hs_pointwise_conv_fwd for every K but the smallest (tools/bench_mbconv.py, second table)
+LEAN_MFMA_MAX_CIN = int(os.environ.get('HS_LEAN_MFMA_MAX_CIN', '16'))
 PW_MFMA_MAX_CIN = int(os.environ.get('HS_PW_MFMA_MAX_CIN', '96'))
 PW_MFMA_MIN_PIXELS = int(os.environ.get('HS_PW_MFMA_MIN_PIXELS', '8192'))
 
@@ -114,6 +117,32 @@ class FusedPointwise(nn.Module):
         else:
             y = F.conv2d(x * gate[:, :, None, None], conv.weight)
         return HF.affine_act_(y, self.scale, self.shift, self.act, residual)
+
+
+class FusedStem(nn.Module):
+    """conv_stem (3x3 stride 2, TF-"SAME") + BN + swish as one ``hs_stem_conv_fwd`` launch (stock: pad fill + pad copy +
+    MIOpen conv + BatchNorm + SiLU)."""
+
+    def __init__(self, conv, bn):
+        super().__init__()
+        assert conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.in_channels == 3 and conv.bias is None
+        scale, shift = _bn_affine(bn)
+        self.register_buffer('scale', scale, persistent=False)
+        self.register_buffer('shift', shift, persistent=False)
+        self._conv = [conv]
+        if conv._pad is not None:
+            self.pad_l, self.pad_t = conv._pad[0], conv._pad[2]
+            self.pad_w, self.pad_h = conv._pad[0] + conv._pad[1], conv._pad[2] + conv._pad[3]
+        else:
+            self.pad_t, self.pad_l = conv.padding
+            self.pad_h, self.pad_w = 2 * conv.padding[0], 2 * conv.padding[1]
+
+    def forward(self, x):
+        from .. import functional as HF
+        x = x.contiguous()
+        h, w = x.shape[2:]
+        ho, wo = (h + self.pad_h - 3) // 2 + 1, (w + self.pad_w - 3) // 2 + 1
+        return HF.stem_conv_bn_swish(x, self._conv[0].weight, self.pad_t, self.pad_l, (ho, wo), self.scale, self.shift)
 
 
 class FusedMBConv(nn.Module):
@@ -194,7 +223,9 @@ class FusedMBConv(nn.Module):
             self._exp_t = exp.weight.detach().flatten(1).t().contiguous()
         skip = inputs.contiguous() if self.skip else None
         proj = self.project
-        if lean and not proj.uses_mfma(y):
+        # deferred shift -> nothing follows the GEMM: the bare library GEMM wins for all but the smallest K; otherwise the
+        # MFMA kernel with its fused epilogue wins wherever it applies (few channels, many pixels)
+        if lean and (y.shape[1] > LEAN_MFMA_MAX_CIN if self.defer_shift else not proj.uses_mfma(y)):
             # gate (and BN2 scale) folded into the project weights by the SE kernel: ~1e5 weights instead of a pass over y
             wp = HF.se_gate(partial, 1, ho * wo, red.weight, red.bias, self._exp_t, exp.bias,
                             w_proj=proj.conv.weight, out_scale=proj.scale)
@@ -209,6 +240,78 @@ class FusedMBConv(nn.Module):
             return HF.affine_act_(out, None, proj.shift, 0, skip)
         gate = HF.se_gate(partial, b, ho * wo, red.weight, red.bias, self._exp_t, exp.bias)
         return proj(y, gate=gate, residual=skip)
+
+
+class FusedContextHead(nn.Module):
+    """The v1_0 context head (WeightMapper, hyperseg_v1_0.py:379-448) for one frame with fewer launches -- same library
+    GEMMs, but every Conv -> BatchNorm -> ReLU is GEMM + ONE affine/ReLU launch, and the concatenations are never built:
+
+      * ``cat(feat, pooled.expand_as(feat))`` in front of a 1x1 conv: the pooled half is constant over the pixels, so its
+        product with the right half of the weights is a per-channel constant -- one mat-vec folded into the BN shift;
+      * the final ``cat(feat0, upsample(u))`` is written in place: the first GEMM's output IS the left half of the
+        signal buffer, the nearest-2x upsample is a broadcast copy into the right half.
+
+    Weights are read through the head's own parameters; folded BN affines are non-persistent buffers."""
+
+    def __init__(self, wm):
+        super().__init__()
+        self._wm = [wm]
+        blocks = [wm.in_conv] + list(wm.down_blocks) + list(wm.up_blocks)
+        for i, blk in enumerate(blocks):
+            assert isinstance(blk[0], nn.Conv2d) and isinstance(blk[1], nn.BatchNorm2d) and isinstance(blk[2], nn.ReLU)
+            assert blk[0].bias is None
+            scale, shift = _bn_affine(blk[1])
+            self.register_buffer(f'scale{i}', scale, persistent=False)
+            self.register_buffer(f'shift{i}', shift, persistent=False)
+        self.n_down = n = len(wm.down_blocks)
+        # deepest merge: BN scale folded into the half of the weights that multiplies the (pixel-constant) pooled vector
+        with torch.no_grad():
+            up = wm.up_blocks[n - 1]
+            half = up[0].out_channels
+            wb = up[0].weight.detach().flatten(1)[:, half:]
+            self.register_buffer('wb_scaled', getattr(self, f'scale{2 * n}')[:, None] * wb, persistent=False)
+
+    def _affine(self, i):
+        return getattr(self, f'scale{i}'), getattr(self, f'shift{i}')
+
+    def forward(self, x):
+        from .. import functional as HF
+        import torch.nn.functional as F
+        wm = self._wm[0]
+        _, cin, h, w = x.shape
+        half = cin // 2
+        n = self.n_down
+        signal = torch.empty(1, cin, h, w, device=x.device, dtype=torch.float32)
+        # feat0 = relu(bn(in_conv(x))), produced directly as the left half of the signal
+        left = signal[:, :half]
+        torch.mm(wm.in_conv[0].weight.view(half, cin), x.view(cin, h * w), out=left.view(half, h * w))
+        HF.affine_act_(left, *self._affine(0), HF.ACT_RELU)
+        feat = [left]
+        for i, down in enumerate(wm.down_blocks):
+            t = F.conv2d(feat[-1], down[0].weight, stride=2)
+            feat.append(HF.affine_act_(t, *self._affine(1 + i), HF.ACT_RELU))
+        t = feat[-1]
+        pooled_const = t.shape[-2:] != (1, 1)            # the bottom is replaced by its global average
+        for level in range(n - 1, -1, -1):
+            up = wm.up_blocks[level]
+            scale, shift = self._affine(1 + n + level)
+            wgt = up[0].weight.view(half, cin)
+            skip = feat.pop()                             # feat[level + 1]
+            sh, sw = skip.shape[-2:]
+            if pooled_const:
+                # right operand is constant over the pixels: W_b @ mean -> per-channel constant in the shift
+                shift = torch.addmv(shift, self.wb_scaled, t.mean((2, 3)).view(half))
+                y = torch.mm(wgt[:, :half], skip.view(half, sh * sw)).view(1, half, sh, sw)
+                pooled_const = False
+            else:
+                y = torch.mm(wgt, torch.cat((skip, t), dim=1).view(cin, sh * sw)).view(1, half, sh, sw)
+            y = HF.affine_act_(y, scale, shift, HF.ACT_RELU)
+            if level > 0:
+                t = wm.upsample(y)
+            else:
+                # nearest 2x upsample straight into the right half of the signal
+                signal[:, half:].view(half, sh, 2, sw, 2).copy_(y.view(half, sh, 1, sw, 1).expand(half, sh, 2, sw, 2))
+        return signal
 
 
 def _fuse_backbone(bb):
@@ -241,6 +344,9 @@ def _fuse_backbone(bb):
             else:
                 assert offset is None
             tap += 1
+    stem = bb._conv_stem
+    if stem.kernel_size == (3, 3) and stem.stride == (2, 2) and stem.in_channels == 3 and isinstance(bb._bn0, nn.BatchNorm2d):
+        bb._fused_stem = FusedStem(stem, bb._bn0)
     bb._fused_head = FusedPointwise(bb._conv_head, bb._bn1, act=3)
     if offset is not None:
         bb._fused_head.absorb_input_offset(offset)
@@ -256,9 +362,12 @@ def prepare_for_inference(model, fold_bn=True, channels_last=False, fused_depthw
     folded = 0
     if fused_depthwise:
         _fuse_backbone(model.backbone)
+        wm = model.weight_mapper
+        if type(wm).__name__ == 'WeightMapper' and hasattr(wm, 'in_conv') and hasattr(wm, 'up_blocks') and wm.levels >= 2:
+            wm._fused = FusedContextHead(wm)
     if fold_bn:
         bb = model.backbone
-        folded += _fold_pairs(bb, [('_conv_stem', '_bn0')] + ([] if getattr(bb, '_fused_head', None) is not None else [('_conv_head', '_bn1')]))
+        folded += _fold_pairs(bb, ([] if getattr(bb, '_fused_stem', None) is not None else [('_conv_stem', '_bn0')]) + ([] if getattr(bb, '_fused_head', None) is not None else [('_conv_head', '_bn1')]))
         for blk in bb._blocks:
             if blk._fused_dw is None:
                 folded += _fold_pairs(blk, [('_expand_conv', '_bn0'), ('_project_conv', '_bn2'), ('_depthwise_conv', '_bn1')])

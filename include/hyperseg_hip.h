@@ -181,6 +181,13 @@ int hs_se_gate_fwd(const float* partial, int32_t batch, int32_t channels, int32_
                    const float* b_expand, float* squeezed, float* gate, const float* w_proj, int32_t c_out,
                    const float* out_scale, float* w_scaled, void* stream);
 
+/* Encoder-side helper: the stem -- dense 3x3 stride-2 convolution of the 3-channel image (zero padding by top/left
+ * offsets, TF-"SAME") + folded BatchNorm + swish in one launch.  x (B,3,H,W), w (c_out,3,3,3) -> y (B,c_out,Ho,Wo).
+ * Replaces F.pad + conv + BatchNorm2d + swish of efficientnet.py:321-322. */
+int hs_stem_conv_fwd(const float* x, int32_t batch, int32_t c_in, int32_t H, int32_t W, const float* w, int32_t c_out,
+                     int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo, const float* scale, const float* shift,
+                     float* y, void* stream);
+
 /* Encoder-side helper: the first half of an MBConv block in ONE launch,
  *   y = swish(BN1(depthwise_kxk_stride(zero-pad(swish(BN0(w_expand . x))))))   (+ per-tile sums of y for the SE pool)
  * x (B,c_in,H,W), w_expand (c_mid,c_in), w_dw (c_mid,1,k,k), scale/shift = folded BatchNorms, y (B,c_mid,Ho,Wo),

@@ -55,6 +55,21 @@ def test_depthwise_conv(HF, dev, k, stride, h, w, pre):
     assert rel_err(pooled, ref.mean((2, 3))) < REL_TOL
 
 
+@pytest.mark.parametrize('h,w,cout,pads', [(64, 128, 32, (0, 0, 1, 1)), (33, 47, 40, (1, 1, 1, 1)), (20, 22, 13, (0, 0, 1, 1)),
+                                           (17, 9, 8, (1, 1, 2, 2))])
+def test_stem_conv(HF, dev, h, w, cout, pads):
+    """hs_stem_conv_fwd == swish(BN(conv3x3/s2(zero-pad(x)))); pads = (top, left, total_h, total_w)."""
+    g = torch.Generator().manual_seed(h * w + cout)
+    pt, pl, ph, pw = pads
+    x = torch.rand(2, 3, h, w, generator=g)
+    wt = torch.randn(cout, 3, 3, 3, generator=g) * 0.3
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(F.pad(x, (pl, pw - pl, pt, ph - pt)), wt, stride=2)
+    ref = swish(ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    y = HF.stem_conv_bn_swish(x.to(dev), wt.to(dev), pt, pl, tuple(ref.shape[2:]), scale.to(dev), shift.to(dev))
+    assert rel_err(y.cpu(), ref) < REL_TOL
+
+
 @pytest.mark.parametrize('cin,cmid,k,stride,h,w', [(16, 96, 3, 2, 64, 128), (24, 144, 3, 1, 32, 48), (24, 144, 5, 2, 50, 70),
                                                    (40, 240, 5, 1, 33, 47), (40, 100, 3, 2, 31, 45), (80, 480, 3, 1, 16, 32),
                                                    (80, 200, 5, 1, 20, 36), (6, 20, 3, 1, 9, 9), (48, 40, 5, 2, 17, 40)])

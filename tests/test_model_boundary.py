@@ -245,3 +245,7 @@ def test_deferred_bn_shift_algebra_cpu(monkeypatch):
         assert len(feats) == len(ref)
         for a, b in zip(ref, feats):
             assert rel_err(b, a) < 2e-5
+        if batch == 1:
+            # the context head without its concatenations (FusedContextHead) == the stock head
+            with torch.no_grad():
+                assert rel_err(fused.weight_mapper._fused(feats[-1].contiguous()), stock.weight_mapper(ref[-1])) < 2e-5

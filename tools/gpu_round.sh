@@ -16,6 +16,14 @@ if [ "$mbx" = mbx ]; then
 fi
 timeout 300 python bench.py > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err
 echo "bench rc=$?"; cat gpurun_out/bench_$tag.json | cut -c1-400
+# extra bench variants: arguments 5.. are "name:ENV1=V1,ENV2=V2" (no spaces); each runs bench.py --no-cpu-baseline
+shift 4 2>/dev/null || shift $#
+for spec in "$@"; do
+  name=${spec%%:*}; envs=${spec#*:}
+  ( IFS=,; for kv in $envs; do export "$kv"; done
+    timeout 200 python bench.py --no-cpu-baseline > gpurun_out/bench_${tag}_$name.json 2> gpurun_out/bench_${tag}_$name.err )
+  echo "variant $name ($envs): $(python -c "import json,sys; d=json.loads(open('gpurun_out/bench_${tag}_$name.json').read() or '{}'); print(d.get('value'), d.get('ms_per_step'))" 2>&1 | tail -1)"
+done
 if [ "$trace" = trace ]; then
   cd /tmp && export TMPDIR=/tmp
   rm -rf /tmp/prof_seq
