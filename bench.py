@@ -144,8 +144,9 @@ def main():
     from hyperseg_amd.utils.synthetic import fill_by_name
     import hyperseg_amd.functional as HF
 
-    if os.environ.get('HS_BLAS'):                                   # dev knob: 'cublas' (= rocBLAS) | 'cublaslt' (= hipBLASLt)
-        torch.backends.cuda.preferred_blas_library(os.environ['HS_BLAS'])
+    # library GEMMs of the encoder's 1x1 convolutions: rocBLAS picks better kernels than hipBLASLt for these skinny fp32
+    # shapes on ROCm 7.2 (953 vs 912 FPS, gpurun round r1h); 'cublas' = rocBLAS, 'cublaslt' = hipBLASLt in torch's naming
+    torch.backends.cuda.preferred_blas_library(os.environ.get('HS_BLAS', 'cublas'))
     spec = configs.MODELS[MODEL]
     h, w = spec['size']
     from hyperseg_amd.utils.inference import prepare_for_inference
@@ -223,6 +224,9 @@ def main():
         elapsed = float(t.item())
     frames = args.steps * spec['batch'] * world
     fps = frames / elapsed
+    if HF.se_gate_timeouts():                                       # the single-launch SE gate's bounded barrier gave up
+        raise RuntimeError('hs_se_gate_fwd: device-scope barrier timed out -- results of this run are invalid '
+                           '(set HS_SE_SINGLE_LAUNCH=0 to use the two-launch route)')
 
     # ---- instrumented eager pass: per-launch durations of the decoder kernels -----------------
     out = None

@@ -132,28 +132,46 @@ void depthwise_conv_kernel(const float* __restrict__ x, const float* __restrict_
 //       (* out_scale[o]) for 64 rows of the strip: the gate (and optionally the project conv's BatchNorm scale) folded
 //       into the project weights -- scaling ~1e5 weights replaces an elementwise pass over the activation.
 // Replaces adaptive_avg_pool2d + 2 convs + swish + sigmoid + mul (hyperseg/models/backbones/efficientnet.py:106-111).
-__global__ __launch_bounds__(256)
-void se_squeeze_kernel(const float* __restrict__ partial, int nblk, float inv_hw, const float* __restrict__ w1,
-                       const float* __restrict__ b1, int C, int Csq, float* __restrict__ z) {
-    const int j = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+// z[b, j] for one squeezed channel j: block-wide dot product over the flattened (channel, partial) index
+__device__ __forceinline__ void se_squeeze_body(int j, int b, const float* __restrict__ partial, int nblk, float inv_hw,
+                                                const float* __restrict__ w1, const float* __restrict__ b1, int C, int Csq,
+                                                float* __restrict__ z, float* ws /* LDS [4] */) {
+    const int tid = threadIdx.x;
     const int n = C * nblk;
     const float* __restrict__ p = partial + (size_t)b * n;
     const float* __restrict__ wr = w1 + (size_t)j * C;
     float acc = 0.0f;
-    for (int e0 = tid; e0 < n; e0 += 256 * 8) {
-        float pv[8], wv[8];
+    if ((nblk & 3) == 0) {
+        // 16-byte loads of the partials: the four elements of a quad belong to the same channel
+        const int n4 = n >> 2, q4 = nblk >> 2;
+        for (int e0 = tid; e0 < n4; e0 += 256 * 8) {
+            float4 pv[8]; float wv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = min(e0 + 256 * u, n - 1);
-            pv[u] = p[e];
-            wv[u] = wr[e / nblk];
+            for (int u = 0; u < 8; ++u) {
+                const int e = min(e0 + 256 * u, n4 - 1);
+                pv[u] = reinterpret_cast<const float4*>(p)[e];
+                wv[u] = wr[e / q4];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e0 + 256 * u < n4) acc = fmaf((pv[u].x + pv[u].y) + (pv[u].z + pv[u].w), wv[u], acc);
         }
+    } else {
+        for (int e0 = tid; e0 < n; e0 += 256 * 8) {
+            float pv[8], wv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (e0 + 256 * u < n) acc = fmaf(pv[u], wv[u], acc);
+            for (int u = 0; u < 8; ++u) {
+                const int e = min(e0 + 256 * u, n - 1);
+                pv[u] = p[e];
+                wv[u] = wr[e / nblk];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e0 + 256 * u < n) acc = fmaf(pv[u], wv[u], acc);
+        }
     }
-    __shared__ float ws[4];
     for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    __syncthreads();                         // ws may still be read by a previous call of this body
     if ((tid & 63) == 0) ws[tid >> 6] = acc;
     __syncthreads();
     if (tid == 0) {
@@ -162,13 +180,15 @@ void se_squeeze_kernel(const float* __restrict__ partial, int nblk, float inv_hw
     }
 }
 
-__global__ __launch_bounds__(256)
-void se_excite_kernel(const float* __restrict__ z, const float* __restrict__ w2t, const float* __restrict__ b2, int C,
-                      int Csq, float* __restrict__ gate, const float* __restrict__ w_proj, int Cout,
-                      const float* __restrict__ out_scale, float* __restrict__ w_scaled) {
-    const int b = blockIdx.y, tid = threadIdx.x, col = tid & 63, part = tid >> 6;
-    const int c = blockIdx.x * 64 + col, cc = min(c, C - 1);
-    const int o0 = blockIdx.z * 64 + part * 16;
+// gate for the 64-channel strip cb (+ scaled project-weight rows of row group rg)
+__device__ __forceinline__ void se_excite_body(int cb, int rg, int b, const float* __restrict__ z,
+                                               const float* __restrict__ w2t, const float* __restrict__ b2, int C, int Csq,
+                                               float* __restrict__ gate, const float* __restrict__ w_proj, int Cout,
+                                               const float* __restrict__ out_scale, float* __restrict__ w_scaled,
+                                               float (*red)[64] /* LDS [4][64] */) {
+    const int tid = threadIdx.x, col = tid & 63, part = tid >> 6;
+    const int c = cb * 64 + col, cc = min(c, C - 1);
+    const int o0 = rg * 64 + part * 16;
     // project-weight rows of this thread: issued before the gate so that both sets of loads share one round trip
     float wp[16];
     if (w_proj) {
@@ -190,12 +210,12 @@ void se_excite_kernel(const float* __restrict__ z, const float* __restrict__ w2t
         for (int u = 0; u < 8; ++u)
             if (jb + u < j1) acc = fmaf(wv[u], zv[u], acc);
     }
-    __shared__ float red[4][64];
+    __syncthreads();                         // red may still be read by a previous call of this body
     red[part][col] = acc;
     __syncthreads();
     const float t = ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) + b2[cc];
     const float g = sigmoidf_fast(t);
-    if (blockIdx.z == 0 && part == 0 && c < C) gate[(size_t)b * C + c] = g;
+    if (rg == 0 && part == 0 && c < C) gate[(size_t)b * C + c] = g;
     if (w_proj && c < C) {
         float* __restrict__ dst = w_scaled + (size_t)b * Cout * C + c;
 #pragma unroll
@@ -204,6 +224,62 @@ void se_excite_kernel(const float* __restrict__ z, const float* __restrict__ w2t
             if (o < Cout) dst[(size_t)o * C] = wp[r] * g * (out_scale ? out_scale[o] : 1.0f);
         }
     }
+}
+
+__global__ __launch_bounds__(256)
+void se_squeeze_kernel(const float* __restrict__ partial, int nblk, float inv_hw, const float* __restrict__ w1,
+                       const float* __restrict__ b1, int C, int Csq, float* __restrict__ z) {
+    __shared__ float ws[4];
+    se_squeeze_body(blockIdx.x, blockIdx.y, partial, nblk, inv_hw, w1, b1, C, Csq, z, ws);
+}
+
+__global__ __launch_bounds__(256)
+void se_excite_kernel(const float* __restrict__ z, const float* __restrict__ w2t, const float* __restrict__ b2, int C,
+                      int Csq, float* __restrict__ gate, const float* __restrict__ w_proj, int Cout,
+                      const float* __restrict__ out_scale, float* __restrict__ w_scaled) {
+    __shared__ float red[4][64];
+    se_excite_body(blockIdx.x, blockIdx.z, blockIdx.y, z, w2t, b2, C, Csq, gate, w_proj, Cout, out_scale, w_scaled, red);
+}
+
+// Both phases in ONE launch for a single frame (batch 1): <= 128 workgroups, all co-resident on the 256 CUs, separated
+// by a device-scope barrier on caller-provided words: sync[0] counts arrivals, sync[2] departures -- the last workgroup to
+// leave resets both, so stream-ordered launches (of any grid size) can share them.  The wait is BOUNDED: a workgroup that
+// does not see the others arrive within ~50 ms raises sync[1] and proceeds, so a scheduling surprise costs a wrong gate
+// (caught by the flag), never a hung GPU.  Saves one launch (~4.5 us of fixed cost) per MBConv block, 23 per frame.
+__global__ __launch_bounds__(256)
+void se_gate_fused_kernel(const float* __restrict__ partial, int nblk, float inv_hw, const float* __restrict__ w1,
+                          const float* __restrict__ b1, int C, int Csq, float* __restrict__ z,
+                          const float* __restrict__ w2t, const float* __restrict__ b2, float* __restrict__ gate,
+                          const float* __restrict__ w_proj, int Cout, const float* __restrict__ out_scale,
+                          float* __restrict__ w_scaled, unsigned* __restrict__ sync) {
+    __shared__ float ws[4];
+    __shared__ float red[4][64];
+    const unsigned G = gridDim.x;
+    for (int j = blockIdx.x; j < Csq; j += G) se_squeeze_body(j, 0, partial, nblk, inv_hw, w1, b1, C, Csq, z, ws);
+    // ---- device-scope barrier ----
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();                                           // release: this workgroup's z values
+        atomicAdd(&sync[0], 1u);
+        int spins = 0;
+        while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < G) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > 250000) { atomicExch(&sync[1], 1u); break; }
+        }
+        __threadfence();                                           // acquire: everybody else's z values
+        // every workgroup increments sync[2] only after it has left the wait above, so whoever brings it to G knows that
+        // nobody reads sync[0] any more
+        if (atomicAdd(&sync[2], 1u) == G - 1u) {
+            __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sync[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence();
+        }
+    }
+    __syncthreads();
+    const int ncb = (C + 63) / 64;
+    const int units = ncb * (w_proj ? (Cout + 63) / 64 : 1);
+    for (int u = blockIdx.x; u < units; u += G)
+        se_excite_body(u % ncb, u / ncb, 0, z, w2t, b2, C, Csq, gate, w_proj, Cout, out_scale, w_scaled, red);
 }
 
 }  // namespace hs
@@ -244,12 +320,20 @@ extern "C" int hs_depthwise_pool_blocks(int32_t Ho, int32_t Wo) {
 extern "C" int hs_se_gate_fwd(const float* partial, int32_t batch, int32_t channels, int32_t nblk, float inv_hw,
                               const float* w_reduce, const float* b_reduce, int32_t c_squeezed, const float* w_expand,
                               const float* b_expand, float* squeezed, float* gate, const float* w_proj, int32_t c_out,
-                              const float* out_scale, float* w_scaled, void* stream) {
+                              const float* out_scale, float* w_scaled, uint32_t* sync, void* stream) {
     if (!partial || !w_reduce || !b_reduce || !w_expand || !b_expand || !squeezed || !gate || batch <= 0 || channels <= 0 ||
         nblk <= 0 || c_squeezed <= 0) return HS_ERR_BAD_ARG;
     if ((w_proj != nullptr) != (w_scaled != nullptr) || (w_proj && c_out <= 0) || (out_scale && !w_proj)) return HS_ERR_BAD_ARG;
     if (batch > 65535 || c_squeezed > 65535) return HS_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
+    if (sync && batch == 1) {
+        const int units = ((channels + 63) / 64) * (w_proj ? (c_out + 63) / 64 : 1);
+        int g = units < 128 ? units : 128;
+        if (g < c_squeezed) g = c_squeezed < 128 ? c_squeezed : 128;
+        hipLaunchKernelGGL(se_gate_fused_kernel, dim3(g), dim3(256), 0, s, partial, nblk, inv_hw, w_reduce, b_reduce, channels,
+                           c_squeezed, squeezed, w_expand, b_expand, gate, w_proj, c_out, out_scale, w_scaled, sync);
+        return launch_status();
+    }
     hipLaunchKernelGGL(se_squeeze_kernel, dim3(c_squeezed, batch), dim3(256), 0, s, partial, nblk, inv_hw, w_reduce,
                        b_reduce, channels, c_squeezed, squeezed);
     int st = launch_status();
@@ -429,15 +513,16 @@ extern "C" int hs_affine_act_fwd(const float* x, int32_t batch, int32_t channels
 // 1 KB contiguous per store instruction.
 // ---------------------------------------------------------------------------------------------------------------
 namespace hs {
-template <int CIN>
+template <int CIN, int PL>
 __global__ __launch_bounds__(256)
 void stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
                       const float* __restrict__ shift, float* __restrict__ y, int Cout, int H, int W, int Ho, int Wo,
                       int pad_t, int pad_l) {
     constexpr int K = 3, S = 2, NCOL = 3 * S + K, CG = 8;
     const int wq = (Wo + 3) >> 2;
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= Ho * wq) return;
+    const int q0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = q0 < Ho * wq;
+    const int q = live ? q0 : 0;                                        // dead lanes shadow quad 0 up to the barrier
     const int g = blockIdx.y, b = blockIdx.z;
     const int yo = q / wq, xo = (q - yo * wq) * 4;
     const int xi0 = xo * S - pad_l, yi0 = yo * S - pad_t;
@@ -450,17 +535,50 @@ void stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, 
             const int yi = yi0 + ky;
             const bool row_ok = yi >= 0 && yi < H;
             const float* __restrict__ row = xb + ((size_t)c * H + min(max(yi, 0), H - 1)) * W;
+            if constexpr (PL >= 0) {                                   // W % 4 == 0: aligned 16-byte loads (see the depthwise kernel)
+                constexpr int OFF = (4 - PL % 4) % 4;
+                constexpr int NV = (OFF + NCOL + 3) / 4;
+                const int a0 = xi0 - OFF;
+                float win[NV * 4];
 #pragma unroll
-            for (int j = 0; j < NCOL; ++j) {
-                const int xi = xi0 + j;
-                const float t = row[min(max(xi, 0), W - 1)];
-                v[c][ky][j] = t * ((row_ok && xi >= 0 && xi < W) ? 1.0f : 0.0f);
+                for (int i = 0; i < NV; ++i) {
+                    const int col = a0 + 4 * i;
+                    const bool ok = row_ok && col >= 0 && col < W;
+                    const float4 t = *reinterpret_cast<const float4*>(row + ((col >= 0 && col < W) ? col : 0));
+                    const float m = ok ? 1.0f : 0.0f;
+                    win[4 * i] = t.x * m; win[4 * i + 1] = t.y * m; win[4 * i + 2] = t.z * m; win[4 * i + 3] = t.w * m;
+                }
+#pragma unroll
+                for (int j = 0; j < NCOL; ++j) v[c][ky][j] = win[OFF + j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < NCOL; ++j) {
+                    const int xi = xi0 + j;
+                    const float t = row[min(max(xi, 0), W - 1)];
+                    v[c][ky][j] = t * ((row_ok && xi >= 0 && xi < W) ? 1.0f : 0.0f);
+                }
             }
         }
+    // the workgroup's 8 x 27 weights, staged in LDS and read back as broadcast ds_read_b128 (all lanes, same address):
+    // as SGPR operands they trickle in through the scalar cache one s_load at a time -- 28 us instead of ~10 for this kernel
+    constexpr int NW = CIN * K * K;                                    // 27
+    constexpr int NWP = (NW + 3) & ~3;                                 // row pitch 28: 16-byte rows
+    __shared__ __attribute__((aligned(16))) float wl[CG * NWP];
+    for (int e = threadIdx.x; e < CG * NWP; e += blockDim.x) {
+        const int oc = e / NWP, r = e - oc * NWP;
+        const int o = min(g * CG + oc, Cout - 1);
+        wl[e] = r < NW ? w[(size_t)o * NW + r] : 0.0f;
+    }
+    __syncthreads();
+    if (!live) return;
 #pragma unroll
     for (int oc = 0; oc < CG; ++oc) {
-        const int o = min(g * CG + oc, Cout - 1);
-        const float* __restrict__ wo = w + (size_t)o * CIN * K * K;          // workgroup-uniform -> scalar loads
+        float wv[NWP];
+#pragma unroll
+        for (int r4 = 0; r4 < NWP / 4; ++r4) {
+            const float4 t = *reinterpret_cast<const float4*>(wl + oc * NWP + 4 * r4);
+            wv[4 * r4] = t.x; wv[4 * r4 + 1] = t.y; wv[4 * r4 + 2] = t.z; wv[4 * r4 + 3] = t.w;
+        }
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < CIN; ++c)
@@ -468,11 +586,11 @@ void stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, 
             for (int ky = 0; ky < K; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < K; ++kx) {
-                    const float wv = wo[(c * K + ky) * K + kx];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[t] = fmaf(wv, v[c][ky][t * S + kx], acc[t]);
+                    for (int t = 0; t < 4; ++t) acc[t] = fmaf(wv[(c * K + ky) * K + kx], v[c][ky][t * S + kx], acc[t]);
                 }
-        if (g * CG + oc < Cout) {
+        const int o = g * CG + oc;
+        if (o < Cout) {
             const float sc = scale[o], sh = shift[o];
             float r[4];
 #pragma unroll
@@ -493,7 +611,10 @@ extern "C" int hs_stem_conv_fwd(const float* x, int32_t batch, int32_t c_in, int
     if (c_in != 3 || batch > 65535) return HS_ERR_UNSUPPORTED;
     const int quads = Ho * ((Wo + 3) / 4);
     dim3 grid((quads + 255) / 256, (c_out + 7) / 8, batch);
-    hipLaunchKernelGGL(hs::stem_conv_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, x, w, scale, shift, y, c_out, H, W,
-                       Ho, Wo, pad_t, pad_l);
+    const bool vec = (W & 3) == 0 && (((size_t)x) & 15) == 0;
+#define HS_STEM(PP) hipLaunchKernelGGL((hs::stem_conv_kernel<3, PP>), grid, dim3(256), 0, (hipStream_t)stream, x, w, scale, shift, \
+                                       y, c_out, H, W, Ho, Wo, pad_t, pad_l)
+    if (vec && pad_l == 0) HS_STEM(0); else if (vec && pad_l == 1) HS_STEM(1); else HS_STEM(-1);
+#undef HS_STEM
     return hs::launch_status();
 }
