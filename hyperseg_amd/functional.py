@@ -324,32 +324,10 @@ def affine_act_(x, scale, shift, act=0, residual=None):
     return x
 
 
-SE_SINGLE_LAUNCH = os.environ.get('HS_SE_SINGLE_LAUNCH', '1') == '1'
-_SE_SYNC = {}
-
-
-def _se_sync_words(device):
-    """(arrivals, timeout flag, departures) of the single-launch SE gate, one triple per device: launches that share it
-    must be stream-ordered (one inference stream per device and process, as everywhere in this package).  It has to exist
-    before a graph capture starts (bench / tests / smoke run eagerly first); a first use inside a capture stays on the
-    two-launch route."""
-    t = _SE_SYNC.get(device.index)
-    if t is None:
-        if torch.cuda.is_current_stream_capturing():
-            return None
-        t = _SE_SYNC[device.index] = torch.zeros(4, dtype=torch.int32, device=device)
-    return t
-
-
-def se_gate_timeouts():
-    """Number of (device, stream) pairs whose single-launch SE barrier ever timed out (must be 0; synchronises)."""
-    return sum(int(t[1].item() != 0) for t in _SE_SYNC.values())
-
-
 def se_gate(partial, batch, hw, w_reduce, b_reduce, w_expand, b_expand, w_proj=None, out_scale=None):
     """Squeeze-excite gate from pooled partial sums; with ``w_proj`` (Cout, C[,1,1]) returns the project weights scaled by
     the gate (and by ``out_scale`` (Cout), the project conv's folded BN scale), (B, Cout, C, 1, 1); otherwise the gate
-    (B, C).  Batch 1: one launch (two phases around a bounded device-scope barrier); otherwise two launches."""
+    (B, C).  Two launches (squeeze, excite)."""
     c = partial.shape[0] // batch
     csq = w_reduce.shape[0]
     dev = partial.device
@@ -362,15 +340,13 @@ def se_gate(partial, batch, hw, w_reduce, b_reduce, w_expand, b_expand, w_proj=N
     if w_proj is not None:
         cout = w_proj.shape[0]
         w_scaled = torch.empty(batch, cout, c, 1, 1, device=dev, dtype=torch.float32)
-    sync = _se_sync_words(dev) if (SE_SINGLE_LAUNCH and batch == 1) else None
     st = _hip.lib.hs_se_gate_fwd(_hip.dev_ptr(partial, 'partial'), batch, c, partial.shape[1], 1.0 / float(hw),
                                  _hip.dev_ptr(w_reduce, 'w_reduce'), _hip.dev_ptr(b_reduce, 'b_reduce'), csq,
                                  _hip.dev_ptr(w_expand, 'w_expand'), _hip.dev_ptr(b_expand, 'b_expand'),
                                  squeezed.data_ptr(), gate.data_ptr(),
                                  _hip.dev_ptr(w_proj, 'w_proj') if w_proj is not None else None, cout,
                                  _hip.dev_ptr(out_scale, 'out_scale') if out_scale is not None else None,
-                                 w_scaled.data_ptr() if w_scaled is not None else None,
-                                 sync.data_ptr() if sync is not None else None, _hip.stream_ptr())
+                                 w_scaled.data_ptr() if w_scaled is not None else None, _hip.stream_ptr())
     _hip.check(st, 'hs_se_gate_fwd')
     return w_scaled if w_proj is not None else gate
 

@@ -62,6 +62,7 @@ FUSE_EXPAND_MAX_CIN = int(os.environ.get('HS_FUSE_EXPAND_MAX_CIN', '40'))      #
 # batch-1 project convs need no epilogue once gate / BN scale are folded into the weights: the bare library GEMM beats
 # hs_pointwise_conv_fwd for every K but the smallest (tools/bench_mbconv.py, second table)
 LEAN_MFMA_MAX_CIN = int(os.environ.get('HS_LEAN_MFMA_MAX_CIN', '16'))
+MM_SPLIT = int(os.environ.get('HS_MM_SPLIT', '1'))
 PW_MFMA_MAX_CIN = int(os.environ.get('HS_PW_MFMA_MAX_CIN', '96'))
 PW_MFMA_MIN_PIXELS = int(os.environ.get('HS_PW_MFMA_MIN_PIXELS', '8192'))
 
@@ -98,7 +99,16 @@ class FusedPointwise(nn.Module):
     def raw(self, x):
         """The bare GEMM (batch 1): W (Cout, Cin) @ x (Cin, HW); BN + activation are left to the consumer."""
         _, cin, h, w = x.shape
-        return torch.mm(self.conv.weight.view(-1, cin), x.view(cin, h * w)).view(1, -1, h, w)
+        wt = self.conv.weight.view(-1, cin)
+        cout = wt.shape[0]
+        if MM_SPLIT > 1 and cout >= 600 and cin <= 128 and h * w >= 2048 and cout % MM_SPLIT == 0:
+            # dev knob: the library's kernel choice for (672 x 2048 x 112) is 3x slower than for (480 x 2048 x 80)
+            out = torch.empty(cout, h * w, device=x.device, dtype=torch.float32)
+            step = cout // MM_SPLIT
+            for i in range(MM_SPLIT):
+                torch.mm(wt[i * step:(i + 1) * step], x.view(cin, h * w), out=out[i * step:(i + 1) * step])
+            return out.view(1, cout, h, w)
+        return torch.mm(wt, x.view(cin, h * w)).view(1, -1, h, w)
 
     def forward(self, x, gate=None, residual=None):
         """``gate`` (B, Cin): SE gate applied to the input.  Non-MFMA shapes: stock GEMM followed by ONE fused

@@ -179,11 +179,8 @@ int hs_depthwise_pool_blocks(int32_t Ho, int32_t Wo);
 int hs_se_gate_fwd(const float* partial, int32_t batch, int32_t channels, int32_t nblk, float inv_hw,
                    const float* w_reduce, const float* b_reduce, int32_t c_squeezed, const float* w_expand,
                    const float* b_expand, float* squeezed, float* gate, const float* w_proj, int32_t c_out,
-                   const float* out_scale, float* w_scaled, uint32_t* sync, void* stream);
-/* sync (optional, batch 1 only): three zero-initialised uint32 in device memory owned by the caller and shared only by
- * stream-ordered launches.  When given, both phases run in ONE launch of <= 128 co-resident workgroups separated by a
- * device-scope barrier (sync[0] arrivals, sync[2] departures; the last workgroup out resets both); the wait is bounded
- * (~50 ms) and a timeout sets sync[1] = 1 instead of hanging.  NULL: two launches. */
+                   const float* out_scale, float* w_scaled, void* stream);
+
 
 /* Encoder-side helper: the stem -- dense 3x3 stride-2 convolution of the 3-channel image (zero padding by top/left
  * offsets, TF-"SAME") + folded BatchNorm + swish in one launch.  x (B,3,H,W), w (c_out,3,3,3) -> y (B,c_out,Ho,Wo).

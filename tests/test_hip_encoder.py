@@ -116,33 +116,6 @@ def test_se_gate(HF, dev, c, csq, nblk, cout, batch):
     assert rel_err(ws.cpu().view(batch, cout, c), wp[None] * gate_ref[:, None, :] * osc[None, :, None]) < REL_TOL
 
 
-def test_se_gate_single_launch_barrier(HF, dev):
-    """The one-launch SE gate (two phases around a bounded device-scope barrier) == the two-launch route, over a sequence
-    of back-to-back calls with different grid sizes sharing the barrier words (self-reset), with no timeout."""
-    g = torch.Generator().manual_seed(5)
-    shapes = [(32, 8, 128, 16), (1920, 80, 1, 320), (96, 4, 256, 24), (672, 28, 2, 112), (1152, 48, 1, 192), (50, 3, 5, 7)]
-    cases = []
-    for c, csq, nblk, cout in shapes:
-        cases.append([t.to(dev) for t in (torch.randn(c, nblk, generator=g), torch.randn(csq, c, generator=g) / c ** 0.5,
-                                          torch.randn(csq, generator=g) * 0.1, torch.randn(csq, c, generator=g) / csq ** 0.5,
-                                          torch.randn(c, generator=g) * 0.1, torch.randn(cout, c, generator=g),
-                                          torch.rand(cout, generator=g) + 0.5)])
-    assert HF.SE_SINGLE_LAUNCH
-    try:
-        HF.SE_SINGLE_LAUNCH = False
-        ref = [HF.se_gate(a[0], 1, 77.0, a[1], a[2], a[3], a[4], w_proj=a[5], out_scale=a[6]).clone() for a in cases]
-        ref_gate = [HF.se_gate(a[0], 1, 77.0, a[1], a[2], a[3], a[4]).clone() for a in cases]
-    finally:
-        HF.SE_SINGLE_LAUNCH = True
-    for _ in range(20):                                       # 240 barriers back to back, no host synchronisation between
-        outs = [HF.se_gate(a[0], 1, 77.0, a[1], a[2], a[3], a[4], w_proj=a[5], out_scale=a[6]) for a in cases]
-        gates = [HF.se_gate(a[0], 1, 77.0, a[1], a[2], a[3], a[4]) for a in cases]
-    torch.cuda.synchronize()
-    assert HF.se_gate_timeouts() == 0
-    for o, r in zip(outs + gates, ref + ref_gate):
-        assert torch.equal(o, r)                              # same arithmetic in both routes: bit-identical
-
-
 @pytest.mark.parametrize('cin,cout,hw', [(16, 96, (64, 128)), (96, 24, (32, 64)), (32, 16, (16, 20)), (50, 37, (9, 12))])
 def test_pointwise_conv_and_affine(HF, dev, cin, cout, hw):
     g = torch.Generator().manual_seed(cin * cout)
