@@ -144,9 +144,7 @@ def main():
     from hyperseg_amd.utils.synthetic import fill_by_name
     import hyperseg_amd.functional as HF
 
-    # library GEMMs of the encoder's 1x1 convolutions: rocBLAS picks better kernels than hipBLASLt for these skinny fp32
-    # shapes on ROCm 7.2 (953 vs 912 FPS, gpurun round r1h); 'cublas' = rocBLAS, 'cublaslt' = hipBLASLt in torch's naming
-    torch.backends.cuda.preferred_blas_library(os.environ.get('HS_BLAS', 'cublas'))
+# (the BLAS behind each bare GEMM is chosen per call in hyperseg_amd.utils.inference.gemm_library)
     spec = configs.MODELS[MODEL]
     h, w = spec['size']
     from hyperseg_amd.utils.inference import prepare_for_inference

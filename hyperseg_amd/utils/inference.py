@@ -8,6 +8,7 @@ eval-mode modules that remove launches from the frame (SURVEY.md section 8f rank
 The decoder modules are left untouched (their BatchNorms are folded inside the HIP kernels' epilogues).
 The state dict changes (BN entries disappear), so apply it AFTER loading a checkpoint.
 """
+import contextlib
 import os
 
 import torch
@@ -62,9 +63,26 @@ FUSE_EXPAND_MAX_CIN = int(os.environ.get('HS_FUSE_EXPAND_MAX_CIN', '40'))      #
 # batch-1 project convs need no epilogue once gate / BN scale are folded into the weights: the bare library GEMM beats
 # hs_pointwise_conv_fwd for every K but the smallest (tools/bench_mbconv.py, second table)
 LEAN_MFMA_MAX_CIN = int(os.environ.get('HS_LEAN_MFMA_MAX_CIN', '16'))
-MM_SPLIT = int(os.environ.get('HS_MM_SPLIT', '1'))
 PW_MFMA_MAX_CIN = int(os.environ.get('HS_PW_MFMA_MAX_CIN', '96'))
 PW_MFMA_MIN_PIXELS = int(os.environ.get('HS_PW_MFMA_MIN_PIXELS', '8192'))
+
+
+@contextlib.contextmanager
+def gemm_library(pixels):
+    """Which BLAS backs the bare fp32 GEMMs of the 1x1 convolutions (ROCm 7.2, measured per layer under graph replay,
+    profiles/round1_frame_sequence*.txt): hipBLASLt for the few-channel / many-pixel project convs of the first stages
+    (24 x 32768 x 144: 9.8 us vs rocBLAS 21.3), rocBLAS for everything at <= 64x128 pixels (672 x 2048 x 112: 9.1 us vs
+    hipBLASLt 19.5).  torch's names: 'cublaslt' = hipBLASLt, 'cublas' = rocBLAS.  The choice is made at call (= capture) time."""
+    want = os.environ.get('HS_BLAS') or ('cublaslt' if pixels >= GEMM_LT_MIN_PIXELS else 'cublas')
+    prev = torch.backends.cuda.preferred_blas_library()
+    torch.backends.cuda.preferred_blas_library(want)
+    try:
+        yield
+    finally:
+        torch.backends.cuda.preferred_blas_library(prev)
+
+
+GEMM_LT_MIN_PIXELS = int(os.environ.get('HS_GEMM_LT_MIN_PIXELS', '16384'))
 
 
 class FusedPointwise(nn.Module):
@@ -99,16 +117,8 @@ class FusedPointwise(nn.Module):
     def raw(self, x):
         """The bare GEMM (batch 1): W (Cout, Cin) @ x (Cin, HW); BN + activation are left to the consumer."""
         _, cin, h, w = x.shape
-        wt = self.conv.weight.view(-1, cin)
-        cout = wt.shape[0]
-        if MM_SPLIT > 1 and cout >= 600 and cin <= 128 and h * w >= 2048 and cout % MM_SPLIT == 0:
-            # dev knob: the library's kernel choice for (672 x 2048 x 112) is 3x slower than for (480 x 2048 x 80)
-            out = torch.empty(cout, h * w, device=x.device, dtype=torch.float32)
-            step = cout // MM_SPLIT
-            for i in range(MM_SPLIT):
-                torch.mm(wt[i * step:(i + 1) * step], x.view(cin, h * w), out=out[i * step:(i + 1) * step])
-            return out.view(1, cout, h, w)
-        return torch.mm(wt, x.view(cin, h * w)).view(1, -1, h, w)
+        with gemm_library(h * w):
+            return torch.mm(self.conv.weight.view(-1, cin), x.view(cin, h * w)).view(1, -1, h, w)
 
     def forward(self, x, gate=None, residual=None):
         """``gate`` (B, Cin): SE gate applied to the input.  Non-MFMA shapes: stock GEMM followed by ONE fused
@@ -241,12 +251,13 @@ class FusedMBConv(nn.Module):
                             w_proj=proj.conv.weight, out_scale=proj.scale)
             cmid = y.shape[1]
             w2d, y2d = wp.view(-1, cmid), y.view(cmid, ho * wo)
-            if self.defer_shift:
-                if skip is None:
-                    return torch.mm(w2d, y2d).view(1, -1, ho, wo)
-                skip.view(-1, ho * wo).addmm_(w2d, y2d)          # in place: the block input has no other consumer
-                return skip
-            out = torch.mm(w2d, y2d).view(1, -1, ho, wo)
+            with gemm_library(ho * wo):
+                if self.defer_shift:
+                    if skip is None:
+                        return torch.mm(w2d, y2d).view(1, -1, ho, wo)
+                    skip.view(-1, ho * wo).addmm_(w2d, y2d)      # in place: the block input has no other consumer
+                    return skip
+                out = torch.mm(w2d, y2d).view(1, -1, ho, wo)
             return HF.affine_act_(out, None, proj.shift, 0, skip)
         gate = HF.se_gate(partial, b, ho * wo, red.weight, red.bias, self._exp_t, exp.bias)
         return proj(y, gate=gate, residual=skip)
@@ -285,6 +296,10 @@ class FusedContextHead(nn.Module):
         return getattr(self, f'scale{i}'), getattr(self, f'shift{i}')
 
     def forward(self, x):
+        with gemm_library(x.shape[2] * x.shape[3]):
+            return self._forward(x)
+
+    def _forward(self, x):
         from .. import functional as HF
         import torch.nn.functional as F
         wm = self._wm[0]

@@ -24,6 +24,14 @@ for spec in "$@"; do
     timeout 200 python bench.py --no-cpu-baseline > gpurun_out/bench_${tag}_$name.json 2> gpurun_out/bench_${tag}_$name.err )
   echo "variant $name ($envs): $(python -c "import json,sys; d=json.loads(open('gpurun_out/bench_${tag}_$name.json').read() or '{}'); print(d.get('value'), d.get('ms_per_step'))" 2>&1 | tail -1)"
 done
+if [ "$mbx" = final ]; then
+  timeout 400 python tools/fps_configs.py > gpurun_out/fps_configs_$tag.jsonl 2> gpurun_out/fps_configs_$tag.err
+  cat gpurun_out/fps_configs_$tag.jsonl
+  ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_bench &&
+    timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- python $R/bench.py --no-cpu-baseline > /tmp/prof_bench.log 2>&1
+    f=$(find /tmp/prof_bench -name '*kernel_stats.csv' | head -1)
+    if [ -n "$f" ]; then cp "$f" $R/gpurun_out/bench_kernel_stats_$tag.csv; tail -1 /tmp/prof_bench.log | cut -c1-200 > $R/gpurun_out/bench_under_rocprof_$tag.json; else echo "no stats"; tail -5 /tmp/prof_bench.log; fi )
+fi
 if [ "$trace" = trace ]; then
   cd /tmp && export TMPDIR=/tmp
   rm -rf /tmp/prof_seq

@@ -9,7 +9,6 @@ from hyperseg_amd.utils.inference import prepare_for_inference
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 variant = sys.argv[2] if len(sys.argv) > 2 else 'plain'
 torch.set_grad_enabled(False)
-torch.backends.cuda.preferred_blas_library(os.environ.get('HS_BLAS', 'cublas'))      # as bench.py
 dev = torch.device('cuda:0')
 m = fill_by_name(configs.build('hyperseg-m').eval(), seed=0)
 prepare_for_inference(m, fold_bn='fold' in variant, fused_depthwise='dw' in variant)
