@@ -22,8 +22,9 @@ __global__ __launch_bounds__(256)
 void depthwise_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
                            const float* __restrict__ shift, float* __restrict__ y, int C, int H, int W, int Ho, int Wo,
                            int pad_t, int pad_l, int act, float* __restrict__ pool_partial,
-                           const float* __restrict__ in_scale, const float* __restrict__ in_shift) {
-    const int plane = blockIdx.y;                        // b*C + c
+                           const float* __restrict__ in_scale, const float* __restrict__ in_shift, int nplanes) {
+    const int plane = blockIdx.y + blockIdx.z * gridDim.y;       // b*C + c (folded over y/z: more than 65535 planes at bs 32)
+    if (plane >= nplanes) return;
     const int c = plane % C;
     // optional prologue: the taps are swish(in_scale[c] * x + in_shift[c]) -- the BatchNorm + swish of the 1x1 expand
     // convolution that produced x, applied on load so that the raw GEMM output needs no elementwise pass of its own
@@ -256,13 +257,15 @@ extern "C" int hs_depthwise_conv_fwd(const float* x, int32_t batch, int32_t chan
     if ((in_scale != nullptr) != (in_shift != nullptr)) return HS_ERR_BAD_ARG;
     if (!x || !w || !y || batch <= 0 || channels <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return HS_ERR_BAD_ARG;
     if (pad_t < 0 || pad_l < 0 || (scale && !shift)) return HS_ERR_BAD_ARG;
-    if ((long)batch * channels > 65535) return HS_ERR_UNSUPPORTED;
+    const long nplanes = (long)batch * channels;
+    if (nplanes > 65535L * 65535L) return HS_ERR_UNSUPPORTED;
     const int quads = Ho * ((Wo + 3) / 4);
     const int threads = quads >= 256 ? 256 : ((quads + 63) / 64) * 64;
-    dim3 grid((quads + threads - 1) / threads, batch * channels);
+    const int gy = nplanes > 65535 ? 32768 : (int)nplanes;
+    dim3 grid((quads + threads - 1) / threads, gy, (unsigned)((nplanes + gy - 1) / gy));
     hipStream_t s = (hipStream_t)stream;
 #define HS_DW(KK, SS, PP) hipLaunchKernelGGL((depthwise_conv_kernel<KK, SS, PP>), grid, dim3(threads), 0, s, x, w, scale, shift, \
-                                             y, channels, H, W, Ho, Wo, pad_t, pad_l, act, pool_partial, in_scale, in_shift)
+                                             y, channels, H, W, Ho, Wo, pad_t, pad_l, act, pool_partial, in_scale, in_shift, (int)nplanes)
     const bool vec = (W & 3) == 0 && (((size_t)x) & 15) == 0;
     if (k == 3 && stride == 1) { if (vec && pad_l == 1) HS_DW(3, 1, 1); else HS_DW(3, 1, -1); }
     else if (k == 3 && stride == 2) { if (vec && pad_l == 0) HS_DW(3, 2, 0); else if (vec && pad_l == 1) HS_DW(3, 2, 1); else HS_DW(3, 2, -1); }

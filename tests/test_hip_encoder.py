@@ -55,6 +55,19 @@ def test_depthwise_conv(HF, dev, k, stride, h, w, pre):
     assert rel_err(pooled, ref.mean((2, 3))) < REL_TOL
 
 
+def test_depthwise_conv_many_planes(HF, dev):
+    """More than 65535 (batch x channel) planes (HyperSeg-L: 32 x 2304): the plane index is folded over grid y/z."""
+    g = torch.Generator().manual_seed(3)
+    b, c, h, w = 2, 40000, 4, 8
+    x = torch.randn(b, c, h, w, generator=g)
+    wt = torch.randn(c, 1, 3, 3, generator=g) * 0.3
+    scale, shift = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1
+    ref = swish(F.conv2d(x, wt, padding=1, groups=c) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    y, partial = HF.depthwise_conv_bn_act(x.to(dev), wt.to(dev), 1, 1, 1, (h, w), scale.to(dev), shift.to(dev), act=3, pool=True)
+    assert rel_err(y.cpu(), ref) < REL_TOL
+    assert rel_err(partial.cpu().sum(1).view(b, c) / (h * w), ref.mean((2, 3))) < REL_TOL
+
+
 @pytest.mark.parametrize('h,w,cout,pads', [(64, 128, 32, (0, 0, 1, 1)), (33, 47, 40, (1, 1, 1, 1)), (20, 22, 13, (0, 0, 1, 1)),
                                            (17, 9, 8, (1, 1, 2, 2))])
 def test_stem_conv(HF, dev, h, w, cout, pads):
