@@ -341,8 +341,9 @@ def main():
             'config': {'workload': 'HyperSeg-M / EfficientNet-B1 / 1024x512 bs=1 per GPU, whole model forward '
                                    '(PyTorch-ROCm encoder + context head, HIP decoder), resident input',
                        'encoder': 'stock PyTorch-ROCm / MIOpen' if args.stock_encoder else
-                                  'MBConv blocks through hyperseg_amd.utils.inference (hs_depthwise_conv_fwd, hs_se_gate_fwd, '
-                                  'hs_pointwise_conv_fwd / library GEMMs); stem + context head stock PyTorch-ROCm',
+                                  'hyperseg_amd.utils.inference.prepare_for_inference: MBConv blocks = hs_mbconv_expand_dw_fwd | '
+                                  'library GEMM + hs_depthwise_conv_fwd, hs_se_gate_fwd, bare library GEMM; hs_stem_conv_fwd; '
+                                  'context head = library GEMMs + hs_affine_act_fwd',
                        'output': 'fp32 logits (B,19,512,1024)' if args.output == 'logits' else 'uint8 argmax masks (B,512,1024)',
                        'launch': 'eager' if args.no_graph else 'hipGraph replay',
                        'parallelism': f'batch-sharded x{world}' + (f', RCCL all_gather of {args.gather}'
