@@ -6,9 +6,10 @@
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one forward of the whole model on one resident synthetic 1024x512 frame per rank:
-stock PyTorch-ROCm encoder + context head, then the HIP decoder (hot path), captured once in a HIP
-graph and replayed.  N > 1 is batch-sharded inference (one process per GPU, weak scaling) with an RCCL
-all-gather of the logits on a side stream, overlapped with the next frame.  Rank 0 prints ONE JSON line.
+encoder + context head (hyperseg_amd.utils.inference.prepare_for_inference; --stock-encoder: plain PyTorch-ROCm), then
+the HIP decoder (hot path), captured once in a HIP graph and replayed.  N > 1 is batch-sharded inference (one process
+per GPU, weak scaling) with an RCCL gather of the logits onto rank 0 (nn.DataParallel's semantics; --collective
+allgather for an all-gather) on RCCL's stream, overlapped with the next frame.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
   roofline      the dominant decoder kernel (hs_patch_ir_fwd at level 4): algorithmic FLOPs (and bytes) per
@@ -22,6 +23,8 @@ import json
 import os
 import sys
 import time
+
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL peer-to-peer needs it on this driver
 
 import torch
 import torch.distributed as dist
@@ -118,7 +121,9 @@ def main():
                     help="what a step produces: fp32 logits (the reference's forward, default) or uint8 argmax masks "
                          "taken inside the final upsample kernel (HyperGen.segment; test_fps.py:194's epilogue fused)")
     ap.add_argument('--gather', default='logits', choices=['logits', 'masks', 'none'],
-                    help='what the N>1 all-gather moves (north star: logits)')
+                    help='what the N>1 collective moves (north star: logits)')
+    ap.add_argument('--collective', default='gather', choices=['gather', 'allgather'],
+                    help='N>1: gather onto rank 0 (nn.DataParallel semantics, default) or all_gather to every rank')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of HIP graph replay')
     ap.add_argument('--stock-encoder', action='store_true',
                     help='leave the encoder entirely on stock PyTorch-ROCm/MIOpen (no fused depthwise HIP kernel)')
@@ -184,7 +189,7 @@ def main():
         from hyperseg_amd.distributed import LogitsGatherer
         shape = tuple(y.shape) if args.gather == 'logits' else (y.shape[0],) + tuple(y.shape[-2:])
         dtype = torch.float32 if args.gather == 'logits' else torch.uint8
-        comm = LogitsGatherer(world, shape, dtype, dev)
+        comm = LogitsGatherer(world, shape, dtype, dev, mode=args.collective)
 
     def step(i):
         nonlocal y
@@ -193,7 +198,7 @@ def main():
         else:
             y = forward(x)
         if comm is not None:
-            # RCCL all-gather over xGMI on RCCL's own stream: overlaps the next frame's compute
+            # RCCL gather over xGMI on RCCL's own stream: overlaps the next frame's compute
             comm.submit(i, y if (args.gather == 'logits' or y.dtype == torch.uint8) else y.argmax(1).to(torch.uint8))
 
     def drain():
@@ -346,7 +351,7 @@ def main():
                                   'context head = library GEMMs + hs_affine_act_fwd',
                        'output': 'fp32 logits (B,19,512,1024)' if args.output == 'logits' else 'uint8 argmax masks (B,512,1024)',
                        'launch': 'eager' if args.no_graph else 'hipGraph replay',
-                       'parallelism': f'batch-sharded x{world}' + (f', RCCL all_gather of {args.gather}'
+                       'parallelism': f'batch-sharded x{world}' + (f', RCCL {args.collective} of {args.gather}'
                                                                    if comm is not None else '')},
             'roofline': roof,
             'decoder': {'us_per_frame_eager': round(dec_us, 1), 'event_pair_overhead_us': round(ev_overhead, 2),
