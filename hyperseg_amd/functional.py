@@ -374,8 +374,8 @@ def upsample_argmax(x, size):
 
 
 # ------------------------------------------------------------------------------------------
-# small caches keyed on parameter versions (host-side only; nothing is hidden from autograd
-# because this path is inference-only: modules raise in training mode)
+# small caches keyed on parameter versions (host-side only; used by the fused inference route --
+# tensors that require grad take the hyperseg_amd.autograd route, which folds nothing)
 # ------------------------------------------------------------------------------------------
 def _key(*tensors):
     return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
@@ -389,8 +389,8 @@ class FoldedBN:
 
     def get(self, bn):
         if bn.training or not bn.track_running_stats:
-            raise NotImplementedError('hyperseg_amd: the HIP decoder path is inference-only in this build '
-                                      '(BatchNorm in training mode needs the backward kernels)')
+            raise NotImplementedError('hyperseg_amd: a train-mode BatchNorm cannot be folded into a kernel epilogue; '
+                                      'the training route (hyperseg_amd.autograd) keeps BatchNorm as a module')
         ts = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
         k = _key(*ts)
         if k != self._k:
