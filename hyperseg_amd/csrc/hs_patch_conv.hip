@@ -245,32 +245,58 @@ void upsample2x_kernel(const float* __restrict__ x, int planes, int Hi, int Wi, 
 // The same upsample with the class argmax taken in registers: uint8 masks instead of logits (M: 0.5 MB written instead
 // of 39.8 MB, and no separate argmax pass re-reading them).  Ties resolve to the lowest class index.  Replaces
 // F.interpolate + pred.argmax(1) (hyperseg_v1_0.py:250-251 + test.py:171 / test_fps.py:194).
+// Four consecutive lanes share one 2x4 output block and split the classes among them (c = sub, sub + 4, ...): with one
+// thread per block the launch is a single wave per SIMD walking 19 dependent load batches; this way it is four waves per
+// SIMD with <= 5 classes (60 loads, one batch) each, combined with two shuffles (larger value wins, lower class on ties).
 __global__ __launch_bounds__(256)
 void upsample2x_argmax_kernel(const float* __restrict__ x, int B, int C, int Hi, int Wi, uint8_t* __restrict__ mask) {
     const int wq = Wi >> 1;
     const size_t n = (size_t)B * Hi * wq;
     const int Wo = 2 * Wi;
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int sub = (int)(t & 3);
+    const size_t e0 = t >> 2;
+    const size_t e = e0 < n ? e0 : n - 1;                    // surplus lanes shadow the last block (shuffles stay convergent)
     const int q = e % wq; size_t r = e / wq;
     const int yi = r % Hi; const size_t b = r / Hi;
     const float* __restrict__ xb = x + b * C * Hi * Wi;
-    float best0[4], best1[4];
-    int idx0[4] = {0, 0, 0, 0}, idx1[4] = {0, 0, 0, 0};
-    up2x_block(xb, Hi, Wi, yi, q, best0, best1);
-#pragma unroll 6
-    for (int c = 1; c < C; ++c) {
-        float o0[4], o1[4];
-        up2x_block(xb + (size_t)c * Hi * Wi, Hi, Wi, yi, q, o0, o1);
+    constexpr float NEG = -3.402823466e38f;
+    float best0[4] = {NEG, NEG, NEG, NEG}, best1[4] = {NEG, NEG, NEG, NEG};
+    int idx0[4] = {sub, sub, sub, sub}, idx1[4] = {sub, sub, sub, sub};
+    for (int c0 = sub; c0 < C; c0 += 20) {
+        float o0[5][4], o1[5][4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            if (o0[t] > best0[t]) { best0[t] = o0[t]; idx0[t] = c; }
-            if (o1[t] > best1[t]) { best1[t] = o1[t]; idx1[t] = c; }
+        for (int u = 0; u < 5; ++u) {                        // 5 classes = 60 loads in flight
+            const int c = min(c0 + 4 * u, C - 1);
+            up2x_block(xb + (size_t)c * Hi * Wi, Hi, Wi, yi, q, o0[u], o1[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int c = c0 + 4 * u;
+            if (c < C) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (o0[u][i] > best0[i]) { best0[i] = o0[u][i]; idx0[i] = c; }
+                    if (o1[u][i] > best1[i]) { best1[i] = o1[u][i]; idx1[i] = c; }
+                }
+            }
         }
     }
-    uint8_t* dst = mask + (b * 2 * Hi + 2 * yi) * Wo + 4 * q;
-    *reinterpret_cast<uchar4*>(dst) = make_uchar4(idx0[0], idx0[1], idx0[2], idx0[3]);
-    *reinterpret_cast<uchar4*>(dst + Wo) = make_uchar4(idx1[0], idx1[1], idx1[2], idx1[3]);
+#pragma unroll
+    for (int m = 1; m <= 2; m <<= 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v0 = __shfl_xor(best0[i], m, 64), v1 = __shfl_xor(best1[i], m, 64);
+            const int j0 = __shfl_xor(idx0[i], m, 64), j1 = __shfl_xor(idx1[i], m, 64);
+            if (v0 > best0[i] || (v0 == best0[i] && j0 < idx0[i])) { best0[i] = v0; idx0[i] = j0; }
+            if (v1 > best1[i] || (v1 == best1[i] && j1 < idx1[i])) { best1[i] = v1; idx1[i] = j1; }
+        }
+    }
+    if (sub == 0 && e0 < n) {
+        uint8_t* dst = mask + (b * 2 * Hi + 2 * yi) * Wo + 4 * q;
+        *reinterpret_cast<uchar4*>(dst) = make_uchar4(idx0[0], idx0[1], idx0[2], idx0[3]);
+        *reinterpret_cast<uchar4*>(dst + Wo) = make_uchar4(idx1[0], idx1[1], idx1[2], idx1[3]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -446,7 +472,7 @@ extern "C" int hs_upsample_argmax_fwd(const float* x, int32_t batch, int32_t cha
     if (!x || !mask || batch <= 0 || channels <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return HS_ERR_BAD_ARG;
     if (channels > 256) return HS_ERR_UNSUPPORTED;           // uint8 class indices
     if (Ho == 2 * Hi && Wo == 2 * Wi && (Wi & 1) == 0) {
-        const size_t n2 = (size_t)batch * Hi * (Wi / 2);
+        const size_t n2 = (size_t)batch * Hi * (Wi / 2) * 4;         // 4 lanes per 2x4 output block
         hipLaunchKernelGGL(upsample2x_argmax_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                            x, batch, channels, Hi, Wi, mask);
         return launch_status();
