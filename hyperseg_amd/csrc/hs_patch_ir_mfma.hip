@@ -19,7 +19,6 @@
 //   epilogue  BN3, 64-byte row runs to HBM.
 // LDS: max(T tile, h1 + h2) = 48 KB at HyperSeg-M level 4 -> 3 workgroups / CU; hidden activations never leave the CU.
 #include "hs_common.h"
-#include <cstdio>
 #include <cstdlib>
 
 #ifndef HS_IRM_ABLATE
@@ -54,7 +53,6 @@ struct IrMfmaArgs {
     const float* __restrict__ s3; const float* __restrict__ b3;
     float* __restrict__ y;
     int tiles_y, tiles_x;
-    int stagger_mode, stagger_sleep;       // dev knob HS_IRM_STAGGER=mode,count (0 = off), see the chunk loop
 };
 
 constexpr int IRM_THREADS = 256;
@@ -274,14 +272,6 @@ void patch_ir_mfma_kernel(IrMfmaArgs a) {
     const int dw_hh = tid >> 4, dw_u = tid & 15;
     const bool dw_on = dw_u < TILE;
 
-    // dev experiment: the two workgroups that share a CU start together and stay in phase (both in their MFMA phase, then
-    // both in their depthwise phase; SQ_WAIT_INST_ANY = 41 %).  HS_IRM_STAGGER delays half of the workgroups by count x 512
-    // cycles in front of the chunk loop: mode 1 = odd workgroups, mode 2 = upper half of the grid.
-    if (a.stagger_sleep > 0) {
-        const bool late = a.stagger_mode == 1 ? (blockIdx.x & 1) != 0 : blockIdx.x >= (gridDim.x >> 1);
-        if (late)
-            for (int i = 0; i < a.stagger_sleep; ++i) __builtin_amdgcn_s_sleep(8);
-    }
     const int nchunks = (hid + 15) >> 4;
     for (int ch = 0; ch < nchunks; ++ch) {
         const int h0 = ch * 16;
@@ -459,15 +449,6 @@ int try_launch_ir_mfma(const StageIn& in, int fh, int fw, const float* bank, lon
     {   // dev knob (read once): HS_IRM_TILE=8 forces 8x8 tiles on 16x16 patches
         static const int forced = [] { const char* e = getenv("HS_IRM_TILE"); return e ? atoi(e) : 0; }();
         if (forced == 8 && tile == 16) tile = 8;
-    }
-    {   // dev knob (read once): HS_IRM_STAGGER=mode,count
-        static const int packed = [] {
-            const char* e = getenv("HS_IRM_STAGGER");
-            int m = 0, c = 0;
-            if (e && sscanf(e, "%d,%d", &m, &c) == 2 && m >= 1 && m <= 2 && c > 0 && c < 64) return m * 256 + c;
-            return 0;
-        }();
-        a.stagger_mode = packed >> 8; a.stagger_sleep = packed & 255;
     }
     if (!tile) return 1;
     if (in.Hp * 2 != in.H || in.Wp * 2 != in.W) return 1;      // the LDS window assumes the exact 2x pyramid
