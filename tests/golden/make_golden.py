@@ -418,6 +418,24 @@ def gen_train_step():
     print('train_step losses', losses, 'lrs', lrs, 'k', k)
 
 
+def gen_confusion_matrix():
+    """The reference's ConfusionMatrix (hyperseg/utils/seg_utils.py:5-36) on seeded label maps incl. ignored targets."""
+    from hyperseg.utils.seg_utils import ConfusionMatrix
+    g = torch.Generator().manual_seed(31)
+    n = 7
+    cm = ConfusionMatrix(n)
+    ts, ps = [], []
+    for _ in range(3):
+        t = torch.randint(0, n, (2, 9, 11), generator=g)
+        t[torch.rand(t.shape, generator=g) < 0.15] = 255
+        p = torch.randint(0, n - 1, (2, 9, 11), generator=g)          # class n-1 never predicted: a zero column
+        cm.update(t.flatten(), p.flatten())
+        ts.append(t)
+        ps.append(p)
+    acc_global, acc, iu = cm.compute()
+    save('confusion_matrix', target=torch.stack(ts), pred=torch.stack(ps), mat=cm.mat, acc_global=acc_global, acc=acc, iu=iu)
+
+
 # ------------------------------------------------------------------------------ whole models (boundary)
 MODEL_KW = {
     'M': dict(mod='v1_0', name='efficientnet-b1', num_classes=19, kw=dict(
@@ -470,7 +488,7 @@ def hash_str(s):
 
 if __name__ == '__main__':
     ALL = [gen_meta_conv, gen_meta_patch, gen_meta_sequential, gen_hyper_patch, gen_ir_v1, gen_ir_v0, gen_divide_feature,
-           gen_decoders, gen_train, gen_train_step, gen_models]
+           gen_decoders, gen_train, gen_train_step, gen_confusion_matrix, gen_models]
     only = set(sys.argv[1:])            # e.g. "python make_golden.py gen_train_step" regenerates one fixture family
     for fn in ALL:
         if not only or fn.__name__ in only:

@@ -144,6 +144,30 @@ def test_segment_equals_argmax_of_forward(golden, tag):
 
 
 @pytest.mark.gpu
+def test_fps_harness_and_bn_removal():
+    """hyperseg_amd.fps (the test_fps.py counterpart) end to end on the GPU, incl. the reference's BN -> identity switch:
+    with every BatchNorm removed the fused decoder kernels must equal the same model with identity-valued BatchNorms."""
+    import copy
+    from hyperseg_amd import configs, fps
+    dev = torch.device('cuda:0')
+    model = fill_by_name(configs.build('hyperseg-m').eval(), seed=4)
+    ident = copy.deepcopy(model)
+    for m in ident.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            with torch.no_grad():
+                m.weight.fill_(1.0); m.bias.zero_(); m.running_mean.zero_(); m.running_var.fill_(1.0 - m.eps)
+    fps.remove_bn(model)
+    assert not any(isinstance(m, torch.nn.BatchNorm2d) for m in model.modules())
+    x = torch.rand(1, 3, 128, 256)
+    with torch.no_grad():
+        a, b = model.to(dev)(x.to(dev)).cpu(), ident.to(dev)(x.to(dev)).cpu()
+    assert rel_err(a, b) < 1e-4
+    batches = fps.synthetic_batches(3, 1, (128, 256), 19, dev)
+    res = fps.measure_fps(model, batches, dev, 19)
+    assert res['frames'] == 3 and res['fps'] > 1.0 and 0.0 <= res['mean_iou'] <= 1.0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('batch', [1, 2])
 def test_inference_prep_matches_stock_encoder(batch):
     """prepare_for_inference (fused depthwise + BN + swish + SE kernels, gate folded into the project conv) leaves the

@@ -227,3 +227,23 @@ def test_training_harness_loss_and_lr_vs_reference(golden):
         sched.step()
         lrs.append(opt.param_groups[0]['lr'])
     assert np.allclose(lrs, g['lrs'].numpy() if hasattr(g['lrs'], 'numpy') else g['lrs'], rtol=1e-12)
+
+
+def test_fps_harness_confusion_matrix_and_plumbing(golden):
+    """hyperseg_amd.fps: ConfusionMatrix against the reference's own class (fixture confusion_matrix.npz, incl. ignored
+    targets and a never-predicted class), remove_bn, and the per-iteration timing loop on a CPU-only box (guarded sync)."""
+    from hyperseg_amd.fps import ConfusionMatrix, measure_fps, remove_bn
+    g = golden('confusion_matrix')
+    cm = ConfusionMatrix(int(g['mat'].shape[0]))
+    for t, p in zip(g['target'], g['pred']):
+        cm.update(t.flatten(), p.flatten())
+    assert torch.equal(cm.mat, g['mat'])
+    acc_global, acc, iu = cm.compute()
+    assert abs(float(acc_global) - float(g['acc_global'])) < 1e-7
+    assert torch.allclose(acc, g['acc'], rtol=0, atol=1e-7) and torch.allclose(iu, g['iu'], rtol=0, atol=1e-7)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 5, 1), torch.nn.BatchNorm2d(5), torch.nn.Sequential(torch.nn.BatchNorm2d(5)))
+    remove_bn(net)
+    assert not any(isinstance(m, torch.nn.BatchNorm2d) for m in net.modules())
+    batches = [(torch.rand(2, 3, 4, 6), torch.randint(0, 5, (2, 4, 6))) for _ in range(3)]
+    res = measure_fps(net.eval(), batches, torch.device('cpu'), 5)
+    assert res['frames'] == 6 and res['pass'] == 1 and res['fps'] > 0 and 0.0 <= res['mean_iou'] <= 1.0
