@@ -300,7 +300,7 @@ class HyperPatchInvertedResidual(nn.Module, _SignalToWeights):
             raise ValueError(f'expected {self.in_nc} input channels, got {stage.channels}')
         fh, fw = s.shape[-2:]
         bank = self._bank(s, self.hyper_params)
-        bns = [self._affine_of(i, bn, s.device) for i, bn in enumerate((self.bn1, self.bn2, self.bn3))]
+        bns = [self._affine_of(i, bn, bank.device) for i, bn in enumerate((self.bn1, self.bn2, self.bn3))]
         return HF.patch_ir(stage, (fh, fw), bank, self.hidden_dim, self.out_nc, *bns, residual=residual)
 
     def conv(self, x, s):
