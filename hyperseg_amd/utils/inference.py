@@ -385,6 +385,9 @@ def prepare_for_inference(model, fold_bn=True, channels_last=False, fused_depthw
     ``fold_bn`` touches those BatchNorms: handled here)."""
     assert not model.training, 'call model.eval() first'
     folded = 0
+    if fused_depthwise and any(getattr(b, '_fused_dw', None) is not None for b in model.backbone._blocks):
+        raise RuntimeError('prepare_for_inference(fused_depthwise=True) was already applied to this model: the deferred '
+                           'BatchNorm shifts would be absorbed twice')
     if fused_depthwise:
         _fuse_backbone(model.backbone)
         wm = model.weight_mapper

@@ -252,6 +252,8 @@ def test_deferred_bn_shift_algebra_cpu(monkeypatch, config):
     stock = fill_by_name(configs.build(config).eval(), seed=3)
     fused = copy.deepcopy(stock)
     prepare_for_inference(fused, fold_bn=False, fused_depthwise=True)
+    with pytest.raises(RuntimeError):                     # not idempotent by design: refuses a second application
+        prepare_for_inference(fused, fold_bn=False, fused_depthwise=True)
     bb = fused.backbone
     deferred = [b._fused_dw.defer_shift for b in bb._blocks]
     assert sum(deferred) >= len(deferred) - 3 and not deferred[0]     # block 0 feeds a depthwise conv directly
