@@ -1,13 +1,19 @@
-"""Inference-time preparation of the STOCK PyTorch parts of a HyperGen model (encoder + context head).
+"""Inference-time preparation of the encoder and the context head of a HyperGen model (the rows
+next to the decoder hot path).  Opt-in: ``prepare_for_inference(model, fused_depthwise=True)`` after ``model.eval()``
+and after loading a checkpoint; modules, parameters and state-dict keys are left untouched -- the fused routes read the
+model's own parameters and keep their folded BatchNorm affines in non-persistent buffers.
 
-Not part of the decoder hot path and not custom kernels: standard, mathematically equivalent transforms of
-eval-mode modules that remove launches from the frame (the encoder is ~90 % of the frame):
-  * fold every eval BatchNorm2d that directly follows a convolution into that convolution (w' = w * g/sqrt(v+eps),
-    b' = beta - mean * g/sqrt(v+eps)); the BN becomes nn.Identity;
-  * optionally switch the encoder to channels_last.
-The decoder modules are left untouched (their BatchNorms are folded inside the HIP kernels' epilogues).
-The state dict changes (BN entries disappear), so apply it AFTER loading a checkpoint.
-"""
+``fused_depthwise=True`` (historical name) switches on, for CUDA tensors in eval mode:
+  * ``FusedStem``        conv_stem + BN + swish                           -> hs_stem_conv_fwd
+  * ``FusedMBConv``      every MBConv block in 4-5 launches               -> hs_mbconv_expand_dw_fwd | library GEMM +
+                         hs_depthwise_conv_fwd, hs_se_gate_fwd, library GEMM (gate / BN folded into its weights,
+                         BN shift deferred to the consumers), see the class docstring
+  * ``FusedPointwise``   feature reducers and the head conv              -> hs_pointwise_conv_fwd | GEMM + hs_affine_act_fwd
+  * ``FusedContextHead`` the v1_0 WeightMapper without its concatenations -> library GEMMs + hs_affine_act_fwd
+``fold_bn=True`` additionally folds the remaining Conv -> BatchNorm pairs of the stock modules into the convolutions
+(that one DOES change the state dict: BN entries turn into identities) and ``channels_last`` switches the stock encoder's
+memory format; neither is used by bench.py.
+DESIGN.md section 6c has the measurements behind every routing threshold below."""
 import contextlib
 import os
 
@@ -65,6 +71,7 @@ FUSE_EXPAND_MAX_CIN = int(os.environ.get('HS_FUSE_EXPAND_MAX_CIN', '40'))      #
 LEAN_MFMA_MAX_CIN = int(os.environ.get('HS_LEAN_MFMA_MAX_CIN', '16'))
 PW_MFMA_MAX_CIN = int(os.environ.get('HS_PW_MFMA_MAX_CIN', '96'))
 PW_MFMA_MIN_PIXELS = int(os.environ.get('HS_PW_MFMA_MIN_PIXELS', '8192'))
+GEMM_LT_MIN_PIXELS = int(os.environ.get('HS_GEMM_LT_MIN_PIXELS', '16384'))       # see gemm_library
 
 
 @contextlib.contextmanager
@@ -80,9 +87,6 @@ def gemm_library(pixels):
         yield
     finally:
         torch.backends.cuda.preferred_blas_library(prev)
-
-
-GEMM_LT_MIN_PIXELS = int(os.environ.get('HS_GEMM_LT_MIN_PIXELS', '16384'))
 
 
 class FusedPointwise(nn.Module):
@@ -378,29 +382,30 @@ def _fuse_backbone(bb):
 
 
 def prepare_for_inference(model, fold_bn=True, channels_last=False, fused_depthwise=False):
-    # fused_depthwise: historical name -- it now fuses every MBConv block end to end (4 launches), the head and the
-    # feature reducers
-    """In-place; returns the number of BatchNorms folded.  ``model`` is a HyperGen in eval mode.
-    ``fused_depthwise`` swaps each MBConv block's depthwise conv + BN + swish for the fused HIP kernel (do it BEFORE
-    ``fold_bn`` touches those BatchNorms: handled here)."""
+    """In place; returns the number of BatchNorms folded by ``fold_bn``.  ``model``: a HyperGen in eval mode (module
+    docstring for what each switch does).  The fused routes are installed first, so ``fold_bn`` only touches the
+    Conv -> BatchNorm pairs that no fused route reads."""
     assert not model.training, 'call model.eval() first'
     folded = 0
     if fused_depthwise and any(getattr(b, '_fused_dw', None) is not None for b in model.backbone._blocks):
         raise RuntimeError('prepare_for_inference(fused_depthwise=True) was already applied to this model: the deferred '
                            'BatchNorm shifts would be absorbed twice')
+    wm = model.weight_mapper
     if fused_depthwise:
         _fuse_backbone(model.backbone)
-        wm = model.weight_mapper
         if type(wm).__name__ == 'WeightMapper' and hasattr(wm, 'in_conv') and hasattr(wm, 'up_blocks') and wm.levels >= 2:
             wm._fused = FusedContextHead(wm)
     if fold_bn:
         bb = model.backbone
-        folded += _fold_pairs(bb, ([] if getattr(bb, '_fused_stem', None) is not None else [('_conv_stem', '_bn0')]) + ([] if getattr(bb, '_fused_head', None) is not None else [('_conv_head', '_bn1')]))
+        pairs = ([] if getattr(bb, '_fused_stem', None) is not None else [('_conv_stem', '_bn0')]) + \
+                ([] if getattr(bb, '_fused_head', None) is not None else [('_conv_head', '_bn1')])
+        folded += _fold_pairs(bb, pairs)
         for blk in bb._blocks:
             if blk._fused_dw is None:
                 folded += _fold_pairs(blk, [('_expand_conv', '_bn0'), ('_project_conv', '_bn2'), ('_depthwise_conv', '_bn1')])
         fused_fc = getattr(bb, '_fused_fc', None)
-        for name, m in list(bb.named_children()) + list(model.weight_mapper.named_modules()):
+        head_mods = [] if getattr(wm, '_fused', None) is not None else list(wm.named_modules())
+        for name, m in list(bb.named_children()) + head_mods:
             if isinstance(m, nn.Sequential) and not (fused_fc is not None and name.startswith('_feat_fc_')):
                 folded += _fold_sequential(m)
     if channels_last:
