@@ -272,11 +272,14 @@ void patch_ir_mfma_kernel(IrMfmaArgs a) {
     const int dw_hh = tid >> 4, dw_u = tid & 15;
     const bool dw_on = dw_u < TILE;
 
-    const int nchunks = (hid + 15) >> 4;
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int h0 = ch * 16;
-        // per-chunk operands: LDS reads of the staged bank (A fragments are distributed over the lanes)
+    // per-chunk operands: LDS reads of the staged bank (A fragments are distributed over the lanes)
+    struct ChunkOps {
         float af[KS1];             // pw1 A fragments   W1[h0 + lrow][4*ks + lk]
+        float sc1[4], sh1[4];      // bn1 rows of this lane's 4 D rows
+        float k9[9], sc2, sh2;     // depthwise weights + bn2 of this thread's dw channel
+        float a3[MT3][4];          // pw3 A fragments   W3[16*m + lrow][h0 + 4*ks + lk]
+    };
+    auto load_ops = [&](int h0, ChunkOps& o) {
         {
             const int h = h0 + lrow;
             const bool hok = h < hid;
@@ -285,25 +288,22 @@ void patch_ir_mfma_kernel(IrMfmaArgs a) {
             for (int ks = 0; ks < KS1; ++ks) {
                 const int k = ks * 4 + lk;
                 const float v = wr[k < CIN ? k : 0];
-                af[ks] = (hok && k < CIN) ? v : 0.0f;
+                o.af[ks] = (hok && k < CIN) ? v : 0.0f;
             }
         }
-        float sc1[4], sh1[4];      // bn1 rows of this lane's 4 D rows
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int hr = h0 + 4 * lk + r;
             const int hc = hr < hid ? hr : 0;
-            sc1[r] = bnl[hc]; sh1[r] = bnl[hid + hc];
+            o.sc1[r] = bnl[hc]; o.sh1[r] = bnl[hid + hc];
         }
-        float k9[9], sc2, sh2;     // depthwise weights + bn2 of this thread's dw channel
         {
             const int h = h0 + dw_hh;
             const int hc = h < hid ? h : 0;
 #pragma unroll
-            for (int q = 0; q < 9; ++q) k9[q] = kd[hc * 9 + q];
-            sc2 = bnl[2 * hid + hc]; sh2 = bnl[3 * hid + hc];
+            for (int q = 0; q < 9; ++q) o.k9[q] = kd[hc * 9 + q];
+            o.sc2 = bnl[2 * hid + hc]; o.sh2 = bnl[3 * hid + hc];
         }
-        float a3[MT3][4];          // pw3 A fragments   W3[16*m + lrow][h0 + 4*ks + lk]
 #pragma unroll
         for (int m = 0; m < MT3; ++m) {
             const int oc = m * 16 + lrow;
@@ -312,9 +312,22 @@ void patch_ir_mfma_kernel(IrMfmaArgs a) {
             for (int ks = 0; ks < 4; ++ks) {
                 const int h = h0 + ks * 4 + lk;
                 const float v = w3[(ook ? oc : 0) * hid + (h < hid ? h : 0)];
-                a3[m][ks] = (ook && h < hid) ? v : 0.0f;
+                o.a3[m][ks] = (ook && h < hid) ? v : 0.0f;
             }
         }
+    };
+
+    const int nchunks = (hid + 15) >> 4;
+    ChunkOps ops;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int h0 = ch * 16;
+        load_ops(h0, ops);
+        const float (&af)[KS1] = ops.af;
+        const float (&sc1)[4] = ops.sc1;
+        const float (&sh1)[4] = ops.sh1;
+        const float (&k9)[9] = ops.k9;
+        const float sc2 = ops.sc2, sh2 = ops.sh2;
+        const float (&a3)[MT3][4] = ops.a3;
 
         HS_STAMP(4 + 4 * (ch < 4 ? ch : 4));
         // ---- pw1: h1[16][pos] = relu6(bn1(W1 chunk . T)) ---------------------------------------
