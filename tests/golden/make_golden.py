@@ -486,9 +486,28 @@ def hash_str(s):
     return int.from_bytes(hashlib.sha256(s.encode()).digest()[:7], 'little')
 
 
+def gen_model_pyramid():
+    """HyperGen's list-input inference mode in the REFERENCE (hyperseg_v1_0.py:70-91): an image pyramid of two scales with
+    horizontal-flip test-time augmentation (max over the flip pair, mean over the scales, coarse scale resized to the first)."""
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    from util_weights import fill_by_name
+    spec = MODEL_KW['M']
+    kw = {k: (list(v) if isinstance(v, list) else v) for k, v in spec['kw'].items()}
+    model = v1.hyperseg_efficientnet(spec['name'], False, num_classes=spec['num_classes'], **kw)
+    fill_by_name(model.eval(), seed=11)
+    assert model.inference_hflip and model.inference_gather == 'mean'
+    g = torch.Generator().manual_seed(13)
+    x0 = torch.rand(1, 3, 128, 256, generator=g)
+    x1 = torch.rand(1, 3, 64, 128, generator=g)
+    y = model([x0, x1])
+    top2 = y.topk(2, dim=1).values
+    save('model_M_pyramid', x0=x0, x1=x1, y=y[:, :, 1::3, 2::5].contiguous(), y_absmax=y.abs().max(), y_shape=np.array(y.shape),
+         mask=y.argmax(1)[:, 1::3, 2::5].to(torch.uint8), margin=(top2[:, 0] - top2[:, 1])[:, 1::3, 2::5].contiguous())
+
+
 if __name__ == '__main__':
     ALL = [gen_meta_conv, gen_meta_patch, gen_meta_sequential, gen_hyper_patch, gen_ir_v1, gen_ir_v0, gen_divide_feature,
-           gen_decoders, gen_train, gen_train_step, gen_confusion_matrix, gen_models]
+           gen_decoders, gen_train, gen_train_step, gen_confusion_matrix, gen_models, gen_model_pyramid]
     only = set(sys.argv[1:])            # e.g. "python make_golden.py gen_train_step" regenerates one fixture family
     for fn in ALL:
         if not only or fn.__name__ in only:

@@ -144,6 +144,30 @@ def test_segment_equals_argmax_of_forward(golden, tag):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('prepared', [False, True])
+def test_pyramid_hflip_inference_vs_reference(golden, prepared):
+    """HyperGen's list-input mode (hyperseg_v1_0.py:70-91): two pyramid scales, horizontal-flip augmentation (max over the
+    flip pair), mean over scales, coarse scale resized to the first -- against the reference's own output
+    (fixture model_M_pyramid.npz), with the stock and with the prepared encoder."""
+    from hyperseg_amd import configs
+    from hyperseg_amd.utils.inference import prepare_for_inference
+    g = golden('model_M_pyramid')
+    dev = torch.device('cuda:0')
+    m = fill_by_name(configs.build('hyperseg-m').eval(), seed=11)
+    assert m.inference_hflip and m.inference_gather == 'mean'
+    if prepared:
+        prepare_for_inference(m, fold_bn=False, fused_depthwise=True)
+    m = m.to(dev)
+    with torch.no_grad():
+        y = m([g['x0'].to(dev), g['x1'].to(dev)]).cpu()
+    assert list(y.shape) == [int(v) for v in g['y_shape']]
+    ys = y[:, :, 1::3, 2::5]
+    assert float((ys - g['y']).abs().max()) < 1e-3 * float(g['y_absmax'])
+    ok = g['margin'] > 1e-2 * float(g['y_absmax'])
+    assert bool((ys.argmax(1).to(torch.uint8)[ok] == g['mask'][ok]).all())
+
+
+@pytest.mark.gpu
 def test_fps_harness_and_bn_removal():
     """hyperseg_amd.fps (the test_fps.py counterpart) end to end on the GPU, incl. the reference's BN -> identity switch:
     with every BatchNorm removed the fused decoder kernels must equal the same model with identity-valued BatchNorms."""
