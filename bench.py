@@ -344,7 +344,7 @@ def main():
             'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'HyperSeg-M / EfficientNet-B1 / 1024x512 bs=1 per GPU, whole model forward '
-                                   '(PyTorch-ROCm encoder + context head, HIP decoder), resident input',
+                                   '(encoder + context head as per "encoder", HIP decoder), resident input',
                        'encoder': 'stock PyTorch-ROCm / MIOpen' if args.stock_encoder else
                                   'hyperseg_amd.utils.inference.prepare_for_inference: MBConv blocks = hs_mbconv_expand_dw_fwd | '
                                   'library GEMM + hs_depthwise_conv_fwd, hs_se_gate_fwd, bare library GEMM; hs_stem_conv_fwd; '
