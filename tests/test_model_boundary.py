@@ -300,3 +300,24 @@ def test_deferred_bn_shift_algebra_cpu(monkeypatch, config):
             # the context head without its concatenations (FusedContextHead) == the stock head
             with torch.no_grad():
                 assert rel_err(fused.weight_mapper._fused(feats[-1].contiguous()), stock.weight_mapper(ref[-1])) < 2e-5
+
+
+def test_c_abi_exports_match_header():
+    """The in-tree shared library loads without a GPU and exports every entry point include/hyperseg_hip.h declares (and the
+    ctypes binding knows exactly that set); no compute call is made."""
+    import ctypes
+    import os
+    import re
+    from conftest import REPO
+    from hyperseg_amd import _hip
+    header = open(os.path.join(REPO, 'include', 'hyperseg_hip.h')).read()
+    header = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
+    declared = set(re.findall(r'\b(hs_[a-z0-9_]+)\s*\(', header))
+    assert len(declared) >= 20
+    lib = ctypes.CDLL(_hip._LIB_PATH)
+    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert not missing, f'declared in the header but not exported by the library: {missing}'
+    assert declared == set(_hip.EXPORTS), sorted(declared ^ set(_hip.EXPORTS))
+    assert lib.hs_version() == 1
+    lib.hs_build_info.restype = ctypes.c_char_p
+    assert b'gfx950' in lib.hs_build_info()
