@@ -26,13 +26,10 @@ else:
         env = dict(os.environ, HS_HIP_LIB=os.path.join(OUT, f'lib{v}.so'))
         code = r'''
 import sys, os, torch
-sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
-from oracle import hyperseg_oracle as O
-from test_hip_parity import build_decoder
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tools"))
+from _workload import decoder_workload
 import hyperseg_amd.functional as HF
-dev = torch.device("cuda:0"); torch.set_grad_enabled(False)
-d = build_decoder("M", O).to(dev)
-x, s = O.synth_decoder_inputs("M", batch=1, seed=0); x = [t.to(dev) for t in x]; s = s.to(dev)
+d, x, s = decoder_workload("M")
 orig = HF.patch_ir; recs = []
 def w(*a, **k):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

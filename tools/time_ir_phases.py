@@ -17,14 +17,11 @@ if sys.argv[1] == 'build':
     print('built', LIB)
 else:
     os.environ['HS_HIP_LIB'] = LIB
-    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    sys.path.insert(0, os.path.join(REPO, 'tools'))
     import ctypes, torch, numpy as np
-    from oracle import hyperseg_oracle as O
-    from test_hip_parity import build_decoder
+    from _workload import decoder_workload
     import hyperseg_amd._hip as hip
-    dev = torch.device('cuda:0'); torch.set_grad_enabled(False)
-    d = build_decoder('M', O).to(dev)
-    x, s = O.synth_decoder_inputs('M', batch=1, seed=0); x = [t.to(dev) for t in x]; s = s.to(dev)
+    d, x, s = decoder_workload('M')
     for _ in range(5):
         d(x, s)
     torch.cuda.synchronize()
