@@ -60,6 +60,9 @@ def _load():
                                C.POINTER(EpilogueC), vp, vp], C.c_int),
         'hs_patch_ir_fwd': ([C.POINTER(StageInputC), i32, i32, vp, i64, i32, i32, C.POINTER(EpilogueC),
                              C.POINTER(EpilogueC), C.POINTER(EpilogueC), i32, vp, vp], C.c_int),
+        'hs_patch_ir_v0_fwd': ([C.POINTER(StageInputC), i32, i32, vp, i64, i32, i32, C.POINTER(EpilogueC),
+                                C.POINTER(EpilogueC), C.POINTER(EpilogueC), vp, vp], C.c_int),
+        'hs_ir_tile_map': ([i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), i32], C.c_int),
         'hs_upsample_bilinear_fwd': ([vp, i32, i32, i32, i32, i32, i32, vp, vp], C.c_int),
         'hs_upsample_argmax_fwd': ([vp, i32, i32, i32, i32, i32, i32, vp, vp], C.c_int),
         'hs_stage_input_fwd': ([C.POINTER(StageInputC), vp, vp], C.c_int),
@@ -84,7 +87,7 @@ def _load():
 
 lib = _load()
 EXPORTS = ['hs_version', 'hs_build_info', 'hs_signal2weights_fwd', 'hs_signal2weights_multi_fwd', 'hs_bank_pack_fwd', 'hs_bn_fold_fwd',
-           'hs_patch_conv_fwd', 'hs_patch_ir_fwd', 'hs_upsample_bilinear_fwd', 'hs_upsample_argmax_fwd',
+           'hs_patch_conv_fwd', 'hs_patch_ir_fwd', 'hs_patch_ir_v0_fwd', 'hs_ir_tile_map', 'hs_upsample_bilinear_fwd', 'hs_upsample_argmax_fwd',
            'hs_stage_input_fwd', 'hs_depthwise_conv_fwd', 'hs_depthwise_pool_blocks', 'hs_stem_conv_fwd', 'hs_mbconv_tiles', 'hs_mbconv_expand_dw_fwd', 'hs_se_gate_fwd', 'hs_pointwise_conv_fwd', 'hs_affine_act_fwd', 'hs_patch_conv_bwd_input',
            'hs_patch_conv_bwd_weight']
 
@@ -113,5 +116,7 @@ def dev_ptr(t, name='tensor', dtype=torch.float32):
     return t.data_ptr()
 
 
-def stream_ptr():
-    return torch.cuda.current_stream().cuda_stream
+def stream_ptr(device=None):
+    """The caller's current HIP stream on ``device`` (default: the current device).  hyperseg_amd.functional enters
+    ``torch.cuda.device(tensor.device)`` around every launch, so 'current' is the device that owns the operands."""
+    return torch.cuda.current_stream(device).cuda_stream

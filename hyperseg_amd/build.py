@@ -15,8 +15,8 @@ REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, 'csrc')
 LIB_DIR = os.path.join(PKG, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libhyperseg_hip.so')
-SOURCES = ['hs_weights.hip', 'hs_patch_conv.hip', 'hs_patch_ir.hip', 'hs_patch_ir_mfma.hip', 'hs_encoder.hip', 'hs_mbconv.hip', 'hs_patch_conv_bwd.hip']
-HEADERS = [os.path.join(CSRC, 'hs_common.h'), os.path.join(REPO, 'include', 'hyperseg_hip.h')]
+SOURCES = ['hs_weights.hip', 'hs_patch_conv.hip', 'hs_patch_ir.hip', 'hs_patch_ir_fused.hip', 'hs_encoder.hip', 'hs_mbconv.hip', 'hs_patch_conv_bwd.hip']
+HEADERS = [os.path.join(CSRC, 'hs_common.h'), os.path.join(CSRC, 'hs_ir_tiles.h'), os.path.join(REPO, 'include', 'hyperseg_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
          '-Wall', '-Wno-unused-function', '-I', os.path.join(REPO, 'include'), '-I', CSRC]
 
@@ -36,14 +36,17 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, extra_flags=()):
-    if not force and not needs_build():
+def build(force=False, verbose=False, extra_flags=(), sources=None, lib_path=None, obj_suffix=''):
+    """``sources`` / ``lib_path`` / ``extra_flags``: dev builds of variant libraries (tools/); the product build takes none."""
+    if sources is None and lib_path is None and not force and not needs_build():
         return LIB_PATH
+    sources = list(sources or SOURCES)
+    lib_path = lib_path or LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     objs = []
     procs = []
-    for s in SOURCES:
-        obj = os.path.join(LIB_DIR, s.replace('.hip', '.o'))
+    for s in sources:
+        obj = os.path.join(LIB_DIR, s.replace('.hip', obj_suffix + '.o'))
         cmd = [_hipcc(), *FLAGS, *extra_flags, '-c', os.path.join(CSRC, s), '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
@@ -55,11 +58,11 @@ def build(force=False, verbose=False, extra_flags=()):
             raise RuntimeError(f'hipcc failed on {s}:\n{out}')
         if verbose and out.strip():
             print(out)
-    cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', LIB_PATH]
+    cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', lib_path]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'link failed:\n{r.stdout}')
-    return LIB_PATH
+    return lib_path
 
 
 if __name__ == '__main__':

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "hyperseg_hip.h"
 
 namespace hs {
@@ -122,6 +123,21 @@ inline int make_stage(const hs_stage_input* in, StageIn* out) {
     out->step_y = in->H > 1 ? 2.0f / (float)(in->H - 1) : 0.0f;
     out->scale_y = (float)out->Hp / (float)in->H;
     out->scale_x = (float)out->Wp / (float)in->W;
+    return HS_OK;
+}
+
+// A kernel that may need more than 64 KiB of dynamic LDS has its ceiling raised to the full 160 KiB ONCE per device
+// (hipFuncSetAttribute is a driver call: not something to repeat on every launch).  `done` is the call site's static
+// per-device bit mask -- write-once, idempotent, so the library stays re-entrant.
+inline int allow_full_lds(const void* kernel, std::atomic<unsigned long long>& done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return HS_OK;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    done.fetch_or(bit, std::memory_order_release);
     return HS_OK;
 }
 

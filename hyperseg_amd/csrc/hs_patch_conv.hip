@@ -422,9 +422,9 @@ extern "C" int hs_patch_conv_fwd(const hs_stage_input* in, int32_t fh, int32_t f
             while (split < 64 && outs * split * 2 <= CONV_THREADS && split * 2 <= a.cin_g) split *= 2;
             f.split = split;
             if (lds1 > 64 * 1024) {
-                hipError_t e = hipFuncSetAttribute((const void*)patch_conv1x1_kernel,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-                if (e != hipSuccess) return (int)e;
+                static std::atomic<unsigned long long> done{0};
+                const int e = allow_full_lds((const void*)patch_conv1x1_kernel, done);
+                if (e != HS_OK) return e;
             }
             hipLaunchKernelGGL(patch_conv1x1_kernel, dim3((unsigned)((long)in->batch * fh * fw)), dim3(CONV_THREADS),
                                lds1, (hipStream_t)stream, f);
@@ -447,9 +447,9 @@ extern "C" int hs_patch_conv_fwd(const hs_stage_input* in, int32_t fh, int32_t f
     a.tiles_x = (a.pw + a.TW - 1) / a.TW;
     const size_t lds = tile_bytes(a.TH, a.TW);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)patch_conv_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
+        static std::atomic<unsigned long long> done{0};
+        const int e = allow_full_lds((const void*)patch_conv_kernel, done);
+        if (e != HS_OK) return e;
     }
     const long blocks = (long)in->batch * fh * fw * a.tiles_y * a.tiles_x;
     hipLaunchKernelGGL(patch_conv_kernel, dim3((unsigned)blocks), dim3(CONV_THREADS), lds, (hipStream_t)stream, a);

@@ -68,43 +68,51 @@ void patch_conv_bwd_input_kernel(ConvBwdArgs a) {
     }
 }
 
-// One workgroup per patch; LDS: dY tile [cout][ph*pw] and padded X tile [cin][(ph+2pad)*(pw+2pad)]; every thread owns
-// bank rows n = tid, tid+256, ... and reduces over the patch's pixels.
+// One workgroup per (patch, block of output channels [o0, o0 + ob)); LDS: the block's dY tile [ob][ph*pw] and the padded
+// X tile of the input channels those outputs read, [nx][(ph+2pad)*(pw+2pad)] (all of cin for groups == 1, whole groups
+// otherwise: the host sizes ob so that the pair fits, so neither the channel count nor the tile size is limited by the
+// 160 KiB of LDS any more); every thread owns bank rows of the block and reduces over the patch's pixels.
 __global__ __launch_bounds__(256)
-void patch_conv_bwd_weight_kernel(ConvBwdArgs a) {
+void patch_conv_bwd_weight_kernel(ConvBwdArgs a, int ob) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int patch = blockIdx.x;
+    const int o0 = blockIdx.y * ob;
+    const int on = min(ob, a.cout - o0);                       // output channels of this block
     const int j = patch % a.fw, i = (patch / a.fw) % a.fh, b = patch / (a.fw * a.fh);
     const int npix = a.ph * a.pw;
     const int HH = a.ph + 2 * a.pad, HW = a.pw + 2 * a.pad, tpos = HH * HW;
-    float* dyl = lds;                         // [cout][npix]
-    float* xl = lds + (size_t)a.cout * npix;  // [cin][tpos]
+    const int c_lo = (o0 / a.cout_g) * a.cin_g;                // first input channel any output of the block reads
+    const int c_hi = ((o0 + on - 1) / a.cout_g + 1) * a.cin_g;
+    const int nx = c_hi - c_lo;
+    float* dyl = lds;                          // [on][npix]
+    float* xl = lds + (size_t)ob * npix;       // [nx][tpos]
     const int y0 = i * a.ph, x0 = j * a.pw;
-    for (int e = threadIdx.x; e < a.cout * npix; e += blockDim.x) {
+    for (int e = threadIdx.x; e < on * npix; e += blockDim.x) {
         const int o = e / npix, pix = e - o * npix;
         const int u = pix / a.pw, v = pix - u * a.pw;
-        dyl[e] = a.dy[(((size_t)b * a.cout + o) * a.H + y0 + u) * a.W + x0 + v];
+        dyl[e] = a.dy[(((size_t)b * a.cout + o0 + o) * a.H + y0 + u) * a.W + x0 + v];
     }
-    for (int e = threadIdx.x; e < a.cin * tpos; e += blockDim.x) {
+    for (int e = threadIdx.x; e < nx * tpos; e += blockDim.x) {
         const int c = e / tpos, pos = e - c * tpos;
         const int u = pos / HW, v = pos - u * HW;
         const int yy = pad_index(y0 + u - a.pad, a.H, a.pad_mode), xx = pad_index(x0 + v - a.pad, a.W, a.pad_mode);
-        xl[e] = (yy >= 0 && xx >= 0) ? a.x[(((size_t)b * a.cin + c) * a.H + yy) * a.W + xx] : 0.0f;
+        xl[e] = (yy >= 0 && xx >= 0) ? a.x[(((size_t)b * a.cin + c_lo + c) * a.H + yy) * a.W + xx] : 0.0f;
     }
     __syncthreads();
     const int kk = a.k * a.k;
-    const int rows = a.cout * a.cin_g * kk;
-    for (int n = threadIdx.x; n < rows; n += blockDim.x) {
-        const int kx = n % a.k; int r = n / a.k;
-        const int ky = r % a.k; r /= a.k;
-        const int cl = r % a.cin_g; const int o = r / a.cin_g;
-        const int c = (o / a.cout_g) * a.cin_g + cl;
-        const float* dr = dyl + (size_t)o * npix;
+    const int wrow = a.cin_g * kk;
+    for (int idx = threadIdx.x; idx < on * wrow; idx += blockDim.x) {
+        const int ol = idx / wrow; int r = idx - ol * wrow;
+        const int kx = r % a.k; r /= a.k;
+        const int ky = r % a.k; const int cl = r / a.k;
+        const int o = o0 + ol;
+        const int c = (o / a.cout_g) * a.cin_g + cl - c_lo;
+        const float* dr = dyl + (size_t)ol * npix;
         const float* xr = xl + (size_t)c * tpos + ky * HW + kx;
         float acc = 0.0f;
         for (int u = 0; u < a.ph; ++u)
             for (int v = 0; v < a.pw; ++v) acc = fmaf(dr[u * a.pw + v], xr[u * HW + v], acc);
-        a.dbank[(size_t)patch * a.ld + n] = acc;
+        a.dbank[(size_t)patch * a.ld + (size_t)o * wrow + (idx - ol * wrow)] = acc;
     }
 }
 
@@ -152,13 +160,35 @@ extern "C" int hs_patch_conv_bwd_weight(const float* x, const float* dy, int32_t
     if (st != HS_OK) return st;
     if (!x || !dbank) return HS_ERR_BAD_ARG;
     a.dx = nullptr; a.dbank = dbank;
-    const size_t lds = ((size_t)c_out * a.ph * a.pw + (size_t)c_in * (a.ph + 2 * pad) * (a.pw + 2 * pad)) * sizeof(float);
-    if (lds > 160 * 1024) return HS_ERR_LDS;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)patch_conv_bwd_weight_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
+    // output-channel block: as many channels (whole groups when the convolution is grouped) as fit beside the X tile
+    const size_t npix = (size_t)a.ph * a.pw, tpos = (size_t)(a.ph + 2 * pad) * (a.pw + 2 * pad);
+    int ob = 0;
+    size_t lds = 0;
+    for (const size_t budget : {(size_t)64 * 1024, (size_t)150 * 1024}) {
+        if (groups == 1) {
+            const size_t xb = (size_t)c_in * tpos * sizeof(float);
+            if (xb + npix * sizeof(float) > budget) continue;
+            ob = (int)((budget - xb) / (npix * sizeof(float)));
+            ob = ob > c_out ? c_out : ob;
+            lds = xb + (size_t)ob * npix * sizeof(float);
+        } else {
+            const size_t per_group = ((size_t)a.cout_g * npix + (size_t)a.cin_g * tpos) * sizeof(float);
+            if (per_group > budget) continue;
+            int gb = (int)(budget / per_group);
+            gb = gb > groups ? groups : gb;
+            ob = gb * a.cout_g;
+            lds = (size_t)gb * per_group;
+        }
+        break;
     }
-    hipLaunchKernelGGL(patch_conv_bwd_weight_kernel, dim3((unsigned)(batch * fh * fw)), dim3(256), lds, (hipStream_t)stream, a);
+    if (ob <= 0) return HS_ERR_LDS;
+    if (lds > 64 * 1024) {
+        static std::atomic<unsigned long long> done{0};
+        const int e = allow_full_lds((const void*)patch_conv_bwd_weight_kernel, done);
+        if (e != HS_OK) return e;
+    }
+    const unsigned nblk = (unsigned)((c_out + ob - 1) / ob);
+    hipLaunchKernelGGL(patch_conv_bwd_weight_kernel, dim3((unsigned)(batch * fh * fw), nblk), dim3(256), lds,
+                       (hipStream_t)stream, a, ob);
     return launch_status();
 }

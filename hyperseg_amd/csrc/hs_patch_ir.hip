@@ -188,17 +188,22 @@ void patch_ir_kernel(IrArgs a) {
 template <int CIN, int CSKIP, int COUT, bool EXACT>
 static int launch_ir(const IrArgs& a, int threads, size_t lds, long blocks, hipStream_t stream) {
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)patch_ir_kernel<CIN, CSKIP, COUT, EXACT>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
+        static std::atomic<unsigned long long> done{0};       // one per instantiation
+        const int e = allow_full_lds((const void*)patch_ir_kernel<CIN, CSKIP, COUT, EXACT>, done);
+        if (e != HS_OK) return e;
     }
     hipLaunchKernelGGL((patch_ir_kernel<CIN, CSKIP, COUT, EXACT>), dim3((unsigned)blocks), dim3(threads), lds, stream, a);
     return launch_status();
 }
 
+#ifdef HS_IR_USE_OLD
 int try_launch_ir_mfma(const StageIn& in, int fh, int fw, const float* bank, long ld, int cin, int c_skip, int hid,
                        int c_out, const float* s1, const float* b1, const float* s2, const float* b2,
-                       const float* s3, const float* b3, float* y, hipStream_t stream);   // hs_patch_ir_mfma.hip
+                       const float* s3, const float* b3, float* y, hipStream_t stream);
+#endif
+int try_launch_ir_fused(int mode, const StageIn& in, int fh, int fw, const float* bank, long ld, int cin, int c_skip,
+                        int hid, int c_out, const float* s1, const float* b1, const float* s2, const float* b2,
+                        const float* s3, const float* b3, float* y, hipStream_t stream);   // hs_patch_ir_fused.hip
 
 }  // namespace hs
 
@@ -234,8 +239,13 @@ extern "C" int hs_patch_ir_fwd(const hs_stage_input* in, int32_t fh, int32_t fw,
     const bool fused_form = in->coords && a.in.prev_mode == HS_PREV_BILINEAR && !a.residual;
     if (fused_form) {
         // the decoder's own shapes run on the matrix cores; anything else falls through to the generic kernel
+#ifdef HS_IR_USE_OLD      /* round-2 A/B build only (tools/build_old_ir.sh): the round-1 kernel */
         const int st_m = try_launch_ir_mfma(a.in, fh, fw, bank, (long)ld, a.cin, in->c_skip, hidden, c_out,
                                             a.s1, a.b1, a.s2, a.b2, a.s3, a.b3, y, s);
+#else
+        const int st_m = try_launch_ir_fused(0, a.in, fh, fw, bank, (long)ld, a.cin, in->c_skip, hidden, c_out,
+                                             a.s1, a.b1, a.s2, a.b2, a.s3, a.b3, y, s);
+#endif
         if (st_m != 1) return st_m;
     }
 #define HS_IR_CASE(CI, CS, CO) \
@@ -251,4 +261,24 @@ extern "C" int hs_patch_ir_fwd(const hs_stage_input* in, int32_t fh, int32_t fw,
     if (a.cin <= 64 && c_out <= 32) return launch_ir<64, 0, 32, false>(a, threads, lds, blocks, s);
     if (a.cin <= 128 && c_out <= 64) return launch_ir<128, 0, 64, false>(a, threads, lds, blocks, s);
     return HS_ERR_UNSUPPORTED;
+}
+
+// Op D, fused form only (the decoder's own shapes); anything else returns HS_ERR_UNSUPPORTED and the caller runs the
+// block as three hs_patch_conv_fwd launches (pw1, depthwise, pw3), which is what the reference's module structure is.
+extern "C" int hs_patch_ir_v0_fwd(const hs_stage_input* in, int32_t fh, int32_t fw, const float* bank, int64_t ld,
+                                  int32_t hidden, int32_t c_out, const hs_epilogue* bn1, const hs_epilogue* bn2,
+                                  const hs_epilogue* bn3, float* y, void* stream) {
+    StageIn si;
+    int st = make_stage(in, &si);
+    if (st != HS_OK) return st;
+    if (!bank || !y || !bn1 || !bn2 || !bn3 || fh <= 0 || fw <= 0 || hidden <= 0 || c_out <= 0) return HS_ERR_BAD_ARG;
+    if (!bn1->scale || !bn1->shift || !bn2->scale || !bn2->shift || !bn3->scale || !bn3->shift) return HS_ERR_BAD_ARG;
+    if (in->H % fh != 0 || in->W % fw != 0) return HS_ERR_NOT_DIVISIBLE;
+    if (in->H < 2 || in->W < 2) return HS_ERR_BAD_ARG;
+    const int cin = si.cin();
+    if (ld < (int64_t)cin * hidden + 9 * hidden + (int64_t)hidden * c_out) return HS_ERR_BAD_ARG;
+    if (!(in->coords && si.prev_mode == HS_PREV_BILINEAR)) return HS_ERR_UNSUPPORTED;
+    const int r = try_launch_ir_fused(1, si, fh, fw, bank, (long)ld, cin, in->c_skip, hidden, c_out, bn1->scale, bn1->shift,
+                                      bn2->scale, bn2->shift, bn3->scale, bn3->shift, y, (hipStream_t)stream);
+    return r == 1 ? HS_ERR_UNSUPPORTED : r;
 }

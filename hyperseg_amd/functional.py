@@ -6,6 +6,7 @@ Vocabulary: a *bank* is the patch-major per-patch filter b
 (hyperseg_v1_0.py:231-240) and the kernels generate on the fly.
 """
 import ctypes as C
+import functools
 import os
 
 import torch
@@ -23,6 +24,28 @@ def _round_up(n, m):
     return (n + m - 1) // m * m
 
 
+def _device_of(a):
+    if isinstance(a, torch.Tensor):
+        return a.device
+    if isinstance(a, (StageInput, BankRef)):
+        return a.device
+    return None
+
+
+def _on_operand_device(fn):
+    """Every launch runs with the HIP device of its first tensor operand current: the stream handed to the library
+    (``torch.cuda.current_stream()``) then belongs to the device that owns the pointers, also when the caller's current
+    device is another one (nn.DataParallel replicas, a model placed on cuda:1 from a cuda:0 context)."""
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        dev = next((d for d in map(_device_of, args) if d is not None), None)
+        if dev is None or dev.type != 'cuda' or dev.index is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+    return wrapper
+
+
 class StageInput:
     """Lazy ``cat([coords(2)?, skip, resize(prev)?], dim=1)`` consumed by the stage kernels' prologue."""
 
@@ -31,6 +54,8 @@ class StageInput:
             raise ValueError('skip must be (B, C, H, W)')
         if prev is not None and (prev.dim() != 4 or prev.shape[0] != skip.shape[0]):
             raise ValueError('prev must be (B, C, h, w) with the same batch as skip')
+        if prev is not None and prev.device != skip.device:
+            raise ValueError(f'stage input spans two devices ({skip.device}, {prev.device})')
         self.skip, self.prev, self.coords = skip, prev, bool(coords)
 
     @property
@@ -64,7 +89,8 @@ class StageInput:
         """The concatenated tensor itself (diagnostics / modules that cannot consume a lazy input)."""
         st = self.c_struct()
         y = torch.empty(self.shape, device=self.device, dtype=torch.float32)
-        _hip.check(_hip.lib.hs_stage_input_fwd(C.byref(st), y.data_ptr(), _hip.stream_ptr()), 'hs_stage_input_fwd')
+        with torch.cuda.device(self.device):
+            _hip.check(_hip.lib.hs_stage_input_fwd(C.byref(st), y.data_ptr(), _hip.stream_ptr()), 'hs_stage_input_fwd')
         return y
 
 
@@ -98,6 +124,7 @@ def _epilogue(scale=None, shift=None, act=ACT_NONE):
     return ep
 
 
+@_on_operand_device
 def signal2weights(signal, wsw_t, signal_index, signal_channels, groups, rows, out=None):
     """Grouped 1x1 conv of the signal slice -> patch-major bank (B*fh*fw, ld).  ``wsw_t`` is the
     Conv2d weight transposed to (Cs/G, Wc).  Replaces signal2weights(...)[:, :hp] + permute copy."""
@@ -119,21 +146,33 @@ def signal2weights(signal, wsw_t, signal_index, signal_channels, groups, rows, o
 
 
 class BankRef:
-    """A bank that already exists (produced by :func:`signal2weights_multi` for a whole decoder).  It stands in
-    for the signal / weight tensor on its way through MetaSequential to the module that consumes it."""
+    """A bank that already exists (produced by :func:`signal2weights_multi` for a whole decoder / context head).  It
+    stands in for the signal / weight tensor on its way through MetaSequential to the module that consumes it:
+    ``ref[:, a:b]`` (MetaSequential's channel range) is the bank's column range [a, b), clamped like a tensor slice."""
 
     def __init__(self, bank, batch, rows, grid):
         self.bank, self.rows, self.grid = bank, rows, tuple(grid)
         self.shape = torch.Size((batch, rows) + self.grid)
         self.requires_grad = False
 
-    def __getitem__(self, _):
-        return self            # MetaSequential's channel slice is a no-op on a finished bank
+    @property
+    def device(self):
+        return self.bank.device
+
+    def __getitem__(self, idx):
+        if not (isinstance(idx, tuple) and len(idx) == 2 and idx[0] == slice(None) and isinstance(idx[1], slice)
+                and idx[1].step in (None, 1)):
+            raise IndexError('a filter bank supports only the channel-range slice ref[:, a:b]')
+        a, b, _ = idx[1].indices(self.rows)
+        if a == 0 and b == self.rows:
+            return self
+        return BankRef(self.bank[:, a:max(a, b)], self.shape[0], max(b - a, 0), self.grid)
 
     def dim(self):
         return 4
 
 
+@_on_operand_device
 def signal2weights_multi(signal, layers):
     """All signal2weights layers of a decoder in ONE launch.  ``layers``: list of dicts with wsw_t, signal_index,
     signal_channels, groups, rows.  Returns one BankRef per layer (views of one buffer)."""
@@ -173,6 +212,7 @@ class SideStream:
         return cls._streams[key]
 
 
+@_on_operand_device
 def bank_pack(w, ch_offset, rows, out=None):
     """(B, hp_total, fh, fw) channel-major weights -> patch-major bank (B*fh*fw, ld)."""
     b, c_view, fh, fw = w.shape
@@ -188,6 +228,7 @@ def bank_pack(w, ch_offset, rows, out=None):
     return out
 
 
+@_on_operand_device
 def bn_fold(gamma, beta, mean, var, eps=BN_EPS_DEFAULT):
     n = mean.numel()
     out = torch.empty(2, n, device=mean.device, dtype=torch.float32)
@@ -207,6 +248,7 @@ def _bank_ptr(bank):
     return bank.data_ptr(), bank.stride(0)
 
 
+@_on_operand_device
 def patch_conv(x, grid, bank, c_out, k=1, padding=0, padding_mode='reflect', groups=1,
                scale=None, shift=None, act=ACT_NONE):
     """Op A / Op B with fused prologue (x may be a StageInput) and BN-affine + activation epilogue."""
@@ -224,6 +266,7 @@ def patch_conv(x, grid, bank, c_out, k=1, padding=0, padding_mode='reflect', gro
     return y
 
 
+@_on_operand_device
 def patch_ir(x, grid, bank, hidden, c_out, bn1, bn2, bn3, residual=False):
     """Op C: fused per-patch inverted residual.  bn* are (scale, shift) pairs; bank rows in the reference's flat order."""
     stage = as_stage(x)
@@ -240,6 +283,37 @@ def patch_ir(x, grid, bank, hidden, c_out, bn1, bn2, bn3, residual=False):
     return y
 
 
+@_on_operand_device
+def patch_ir_v0(x, grid, bank, hidden, c_out, bn1, bn2, bn3):
+    """Op D (hyperseg_v0_1.py:205-237) as one launch; returns None when the shape has no fused instantiation (the caller
+    then runs the block as three patch convolutions)."""
+    stage = as_stage(x)
+    fh, fw = grid
+    b, _, h, w = stage.shape
+    st_in = stage.c_struct()
+    e1, e2, e3 = _epilogue(*bn1), _epilogue(*bn2), _epilogue(*bn3)
+    y = torch.empty(b, c_out, h, w, device=stage.device, dtype=torch.float32)
+    bank_ptr, ld = _bank_ptr(bank)
+    st = _hip.lib.hs_patch_ir_v0_fwd(C.byref(st_in), fh, fw, bank_ptr, ld, hidden, c_out,
+                                     C.byref(e1), C.byref(e2), C.byref(e3), y.data_ptr(), _hip.stream_ptr())
+    if st == -3:
+        return None
+    _hip.check(st, 'hs_patch_ir_v0_fwd')
+    return y
+
+
+def ir_tile_map(reg, mode, pwr):
+    """(n_pixel_tiles, array (n_tiles, 16, 3) of (u, v, live)) -- the fused inverted-residual kernel's tile map
+    (host-side introspection, no GPU needed)."""
+    import numpy as np
+    nt, nt3 = C.c_int32(0), C.c_int32(0)
+    _hip.check(_hip.lib.hs_ir_tile_map(reg, mode, pwr, C.byref(nt), C.byref(nt3), None, 0), 'hs_ir_tile_map')
+    buf = (C.c_int32 * (nt.value * 48))()
+    _hip.check(_hip.lib.hs_ir_tile_map(reg, mode, pwr, C.byref(nt), C.byref(nt3), buf, nt.value * 48), 'hs_ir_tile_map')
+    return nt3.value, np.ctypeslib.as_array(buf).reshape(nt.value, 16, 3).copy()
+
+
+@_on_operand_device
 def depthwise_conv_bn_act(x, weight, stride, pad_top, pad_left, out_size, scale=None, shift=None, act=0, pool=False,
                           in_scale=None, in_shift=None):
     """Depthwise conv (k 3|5, stride 1|2, TF-"SAME" zero padding given as top/left offsets) + affine + activation
@@ -265,6 +339,7 @@ def depthwise_conv_bn_act(x, weight, stride, pad_top, pad_left, out_size, scale=
     return (y, partial) if pool else y
 
 
+@_on_operand_device
 def stem_conv_bn_swish(x, weight, pad_top, pad_left, out_size, scale, shift):
     """3x3 stride-2 conv of the 3-channel image + folded BN + swish, one launch (encoder stem).  Opt-in helper."""
     b, cin, h, w = x.shape
@@ -278,6 +353,7 @@ def stem_conv_bn_swish(x, weight, pad_top, pad_left, out_size, scale, shift):
     return y
 
 
+@_on_operand_device
 def mbconv_expand_dw(x, w_expand, scale0, shift0, w_dw, stride, pad_top, pad_left, out_size, scale1, shift1, pool=True):
     """1x1 expand + BN + swish + depthwise k x k (TF-"SAME" zero padding of the ACTIVATION) + BN + swish in one launch
     (+ SE pooling partial sums): the expanded tensor never reaches HBM.  x (B,Cin,H,W), w_expand (Cmid,Cin[,1,1]),
@@ -298,6 +374,7 @@ def mbconv_expand_dw(x, w_expand, scale0, shift0, w_dw, stride, pad_top, pad_lef
     return (y, partial) if pool else y
 
 
+@_on_operand_device
 def pointwise_conv(x, weight, gate=None, scale=None, shift=None, act=0, residual=None):
     """1x1 conv (fp32 MFMA GEMM) + optional input gate (B,Cin) + affine + activation (3 = swish) + residual, one launch."""
     b, cin, h, w = x.shape
@@ -311,6 +388,7 @@ def pointwise_conv(x, weight, gate=None, scale=None, shift=None, act=0, residual
     return y
 
 
+@_on_operand_device
 def affine_act_(x, scale, shift, act=0, residual=None):
     """In place: x = act(scale[c]*x + shift[c]) + residual  (folded BN + activation + skip add, one launch);
     ``scale=None`` means 1."""
@@ -324,6 +402,7 @@ def affine_act_(x, scale, shift, act=0, residual=None):
     return x
 
 
+@_on_operand_device
 def se_gate(partial, batch, hw, w_reduce, b_reduce, w_expand, b_expand, w_proj=None, out_scale=None):
     """Squeeze-excite gate from pooled partial sums; with ``w_proj`` (Cout, C[,1,1]) returns the project weights scaled by
     the gate (and by ``out_scale`` (Cout), the project conv's folded BN scale), (B, Cout, C, 1, 1); otherwise the gate
@@ -351,6 +430,7 @@ def se_gate(partial, batch, hw, w_reduce, b_reduce, w_expand, b_expand, w_proj=N
     return w_scaled if w_proj is not None else gate
 
 
+@_on_operand_device
 def upsample_bilinear(x, size):
     """F.interpolate(x, size, mode='bilinear', align_corners=False)."""
     b, c, hi, wi = x.shape
@@ -362,6 +442,7 @@ def upsample_bilinear(x, size):
     return y
 
 
+@_on_operand_device
 def upsample_argmax(x, size):
     """``F.interpolate(x, size, 'bilinear', align_corners=False).argmax(1)`` as uint8 masks (B, Ho, Wo), one launch; the
     upsampled logits never exist in memory.  Bit-identical to ``upsample_bilinear(x, size).argmax(1)``."""

@@ -56,7 +56,47 @@ class HyperPatchInvertedResidual(nn.Module):
     def hyper_params(self):
         return self.conv.hyper_params
 
+    def _fused_parts(self):
+        """(pw1, bn1, dw, bn2, pw3, bn3) if the block has exactly the structure hs_patch_ir_v0_fwd implements
+        (expand_ratio != 1, 3x3 depthwise with reflect padding, BatchNorm2d, ReLU6, no residual), else None."""
+        blocks = list(self.conv)
+        if self.use_res_connect or len(blocks) != 3 or any(len(b) < 2 for b in blocks):
+            return None
+        (c1, n1, *r1), (c2, n2, *r2), (c3, n3, *r3) = [list(b) for b in blocks]
+        ok = all(isinstance(c, MetaPatchConv2d) for c in (c1, c2, c3)) and \
+            all(isinstance(n, nn.BatchNorm2d) for n in (n1, n2, n3)) and \
+            len(r1) == 1 and isinstance(r1[0], nn.ReLU6) and len(r2) == 1 and isinstance(r2[0], nn.ReLU6) and not r3 and \
+            c1.kernel_size == (1, 1) and c3.kernel_size == (1, 1) and c1.groups == 1 and c3.groups == 1 and \
+            c2.kernel_size == (3, 3) and c2.groups == c2.in_channels == c2.out_channels and \
+            c2.padding == (1, 1) and c2.padding_mode == 'reflect' and \
+            all(c.hyper_module.stride == (1, 1) and c.hyper_module.dilation == (1, 1) for c in (c1, c2, c3))
+        return (c1, n1, c2, n2, c3, n3) if ok else None
+
+    def _forward_fused(self, x, w):
+        parts = self._fused_parts()
+        if parts is None or not isinstance(x, HF.StageInput):
+            return None
+        c1, n1, c2, n2, c3, n3 = parts
+        from .. import autograd as HA
+        if any(n.training for n in (n1, n2, n3)) or HA.needs_grad(w, x.skip, x.prev, n1.weight, n2.weight, n3.weight):
+            return None
+        hp = int(self.hyper_params)
+        if w.dim() != 4 or w.shape[1] < hp:
+            raise ValueError(f'weight must be (B, >={hp}, fh, fw), got {tuple(w.shape)}')
+        if getattr(self, '_folded', None) is None:
+            self._folded = [HF.FoldedBN(), HF.FoldedBN(), HF.FoldedBN()]
+        bns = [f.get(n) for f, n in zip(self._folded, (n1, n2, n3))]
+        if isinstance(w, HF.BankRef):
+            bank = w.bank
+        else:
+            # the level's weights arrive channel-major (B, hp, fh, fw): one re-layout for the whole block
+            bank = HF.bank_pack(w, 0, hp)
+        return HF.patch_ir_v0(x, tuple(w.shape[-2:]), bank, c1.out_channels, c3.out_channels, *bns)
+
     def forward(self, x, w):
+        y = self._forward_fused(x, w)          # one launch (Op D) for the decoder's shapes
+        if y is not None:
+            return y
         if self.use_res_connect:
             xin = x.materialize() if isinstance(x, HF.StageInput) else x
             return xin + self.conv(xin, w)
@@ -201,10 +241,31 @@ class WeightMapper(nn.Module):
             i = len(pyramid) - 2
             coarse = getattr(self, f'up_{i}')(pyramid.pop())
             pyramid[-1] = getattr(self, f'flat_{i}')(torch.cat((pyramid[-1], coarse), dim=1))
+        banks = self._banks_hip(pyramid[0])
+        if banks is not None:
+            return banks
         banks = self.out_conv(pyramid[0])
         if self.weight_groups > 1:                    # drop the rows added to round up to the group count
             banks = [t[:, :rows] for t, rows in zip(banks, self.out_channels)]
         return banks
+
+    def _banks_hip(self, feat):
+        """Inference: Conv2dMulti + the ``[:, :rows]`` truncation (hyperseg_v0_1.py:323-324, 336-359) as ONE
+        hs_signal2weights_multi_fwd launch that writes every level's bank patch-major (f32 MFMA; the stock grouped
+        1x1 convolutions fall into MIOpen's naive kernel: 36 % of HyperSeg-L's kernel time).  Returns a list of
+        HF.BankRef, or None when the stock path has to run (training, biases, K = Cin/groups > 80)."""
+        from .. import autograd as HA
+        convs = [getattr(self.out_conv, f'conv_{i}') for i in range(len(self.out_channels))]
+        if not feat.is_cuda or self.training or self.bias or HA.needs_grad(feat, *[c.weight for c in convs]):
+            return None
+        if any(c.kernel_size != (1, 1) or c.in_channels // c.groups > 80 for c in convs):
+            return None
+        if getattr(self, '_s2w_t', None) is None:
+            self._s2w_t = [HF.TransposedS2W() for _ in convs]
+        lo = self.out_conv._ranges
+        layers = [dict(wsw_t=t.get(c), signal_index=lo[i], signal_channels=c.in_channels, groups=c.groups,
+                       rows=int(self.out_channels[i])) for i, (c, t) in enumerate(zip(convs, self._s2w_t))]
+        return HF.signal2weights_multi(feat.contiguous(), layers)
 
     def extra_repr(self):
         return f'in_channels={self.in_channels}, out_channels={self.out_channels}, bias={self.bias}'

@@ -48,7 +48,8 @@ class MetaPatch(nn.Module):
             y = HA.patch_conv_train(xt, weight, conv.out_channels, k, self.padding[0], self.padding_mode, conv.groups,
                                     conv.hyper_params)
             return _apply_epilogue(y, scale, shift, act)
-        bank = HF.bank_pack(weight, 0, conv.hyper_params)
+        # a bank the context head already wrote patch-major (HF.BankRef) is consumed as is
+        bank = weight.bank if isinstance(weight, HF.BankRef) else HF.bank_pack(weight, 0, conv.hyper_params)
         return HF.patch_conv(x, (fh, fw), bank, conv.out_channels, k, self.padding[0], self.padding_mode,
                              conv.groups, scale, shift, act)
 

@@ -132,6 +132,26 @@ int hs_patch_ir_fwd(const hs_stage_input* in, int32_t fh, int32_t fw,
                     const hs_epilogue* bn1, const hs_epilogue* bn2, const hs_epilogue* bn3,
                     int32_t residual, float* y, void* stream);
 
+/* Op D: the inverted residual of hyperseg_v0_1.py:205-237 (HyperSeg-L) as ONE launch.  The reference runs it as three
+ * IMAGE-level patch convolutions -- pw1 (MetaPatchConv2d k=1) + BN + ReLU6, depthwise 3x3 with reflect padding of the
+ * hidden activation (MetaPatchConv2d k=3, groups=hidden) + BN + ReLU6, pw3 (k=1) + BN -- so the depthwise taps that
+ * cross a patch border read hidden activations produced with the NEIGHBOURING patch's pw1 weights (unlike Op C, which
+ * applies a patch's own weights to its whole halo tile).  The kernel recomputes that one-pixel ring with the
+ * neighbours' weights instead of exchanging it through HBM.  Bank rows as for hs_patch_ir_fwd (the nested
+ * MetaSequential's cumulative ranges, hyperseg_v0_1.py:226-237: pw1 | depthwise | pw3).  Only the decoder's fused form
+ * (coords + skip + 2x-bilinear previous level) at the instantiated shapes; otherwise HS_ERR_UNSUPPORTED, and the caller
+ * runs the block as three hs_patch_conv_fwd launches. */
+int hs_patch_ir_v0_fwd(const hs_stage_input* in, int32_t fh, int32_t fw,
+                       const float* bank, int64_t ld, int32_t hidden, int32_t c_out,
+                       const hs_epilogue* bn1, const hs_epilogue* bn2, const hs_epilogue* bn3,
+                       float* y, void* stream);
+
+/* Introspection for the tests (host only, no GPU): the matrix-core tile map of the fused inverted-residual kernel for a
+ * region edge `reg` (8|16), mode (0 = Op C, 1 = Op D) and patch edge inside the region `pwr`.  out[(t*16+n)*3 + {0,1,2}]
+ * = halo coordinates (u, v) and liveness of column n of pw1 tile t (csrc/hs_ir_tiles.h). */
+int hs_ir_tile_map(int32_t reg, int32_t mode, int32_t pwr, int32_t* n_tiles, int32_t* n_pixel_tiles,
+                   int32_t* out, int32_t capacity);
+
 /* Final logits resize: F.interpolate(p, size, mode='bilinear', align_corners=False)
  * (hyperseg_v1_0.py:250-251).  x (B,C,Hi,Wi) -> y (B,C,Ho,Wo). */
 int hs_upsample_bilinear_fwd(const float* x, int32_t batch, int32_t channels, int32_t Hi, int32_t Wi,

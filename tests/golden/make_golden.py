@@ -301,7 +301,7 @@ def gen_decoders():
         params = O.synth_decoder_params(plan, seed=0)
         dec = ref_decoder(name)
         load_params(dec, params)
-        batch = 2 if name == 'L' else 1
+        batch = 4 if name == 'L' else 1      # L: the per-GPU shard of BASELINE config 4 (bs 32 over 8 GPUs)
         x, sw = O.synth_decoder_inputs(name, batch=batch, seed=0)
         y = dec(x, sw)
         # NB: the minimum top-2 margin over ~0.5 M pixels is ~1 ulp, so a bit-identical mask cannot

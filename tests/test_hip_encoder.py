@@ -173,3 +173,43 @@ def test_prepared_encoder_matches_stock(dev, batch, size):
         assert rel_err(yf, ys) < 1e-4
         # twice: the in-place skip accumulation must not corrupt anything that outlives a forward
         assert rel_err(fused(x).cpu(), ys) < 1e-4
+
+
+def test_benched_configuration_replay_matches_stock(dev):
+    """The configuration bench.py times -- prepared encoder + context head + HIP decoder at 1024x512, captured in a HIP
+    graph and REPLAYED -- against the eager stock model on the same frame: logits within 1e-4 (tensor-relative) and the
+    argmax identical wherever the stock model's top-2 margin exceeds 1e-4.  (The routing thresholds of the prepared
+    encoder depend on the pixel count, so the small-size tests above do not cover this one.)"""
+    from hyperseg_amd import configs
+    from hyperseg_amd.utils.inference import prepare_for_inference
+    from hyperseg_amd.utils.synthetic import fill_by_name
+    stock = fill_by_name(configs.build('hyperseg-m').eval(), seed=0)
+    fused = copy.deepcopy(stock)
+    prepare_for_inference(fused, fold_bn=False, fused_depthwise=True)
+    stock, fused = stock.to(dev), fused.to(dev)
+    x = torch.rand(1, 3, 512, 1024, device=dev)
+    with torch.no_grad():
+        ys = stock(x)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                fused(x)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            yf = fused(x)
+        for _ in range(3):
+            graph.replay()
+        torch.cuda.synchronize()
+        assert rel_err(yf.cpu(), ys.cpu()) < 1e-4
+        top2 = ys.topk(2, dim=1).values
+        clear = (top2[:, 0] - top2[:, 1]) > 1e-4
+        assert bool((yf.argmax(1)[clear] == ys.argmax(1)[clear]).all())
+        # a second frame through the same graph (the static input buffer is rewritten in place)
+        x2 = torch.rand(1, 3, 512, 1024, device=dev)
+        x.copy_(x2)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert rel_err(yf.cpu(), stock(x2).cpu()) < 1e-4

@@ -304,7 +304,7 @@ def build_decoder(name, O):
 
 @pytest.mark.parametrize('name', ['M', 'Sc', 'S', 'L'])
 def test_full_config(golden, O, dev, name):
-    """HyperSeg-M 1024x512 / CamVid-S 768x576 / HyperSeg-S 1536x768 (unify) / HyperSeg-L 512x512 bs2 (v0_1)
+    """HyperSeg-M 1024x512 / CamVid-S 768x576 / HyperSeg-S 1536x768 (unify) / HyperSeg-L 512x512 bs4 = the per-GPU shard of config 4 (v0_1)
     decoders on the seeded synthetic workload of SURVEY 8(d): vs the oracle on the full tensor, vs the
     reference's own sampled logits and masks."""
     g = golden('decoder_full_configs')
@@ -362,3 +362,97 @@ def test_upsample_argmax(HF, dev, shape, size):
     top2 = ref.topk(min(2, shape[1]), dim=1).values
     clear = (top2[:, 0] - top2[:, -1] > MARGIN) if shape[1] > 1 else torch.ones_like(m, dtype=torch.bool)
     assert bool((m.long()[clear] == ref.argmax(1)[clear]).all())
+
+
+# ------------------------------------------------------------------------------ fused Op D (hs_patch_ir_v0_fwd)
+# (cin = 2 + skip + prev, cout, patch edge, grid): the four inverted-residual levels of HyperSeg-L
+# (hyperseg_v0_1.py:205-237 at 64^2 / 128^2 / 256^2 / 512^2 of a 512x512 input), on small grids
+OP_D_CASES = [
+    dict(skip=12, prev=34, cout=12, patch=4, grid=(4, 6)),      # level 2: 8x8 regions of 2x2 patches
+    dict(skip=8, prev=12, cout=8, patch=8, grid=(2, 4)),        # level 3: 16x16 regions of 2x2 patches
+    dict(skip=6, prev=8, cout=6, patch=16, grid=(2, 3)),        # level 4: region == patch
+    dict(skip=3, prev=6, cout=21, patch=32, grid=(1, 2)),       # level 5: 4 regions per patch
+    dict(skip=6, prev=8, cout=6, patch=16, grid=(1, 1)),        # a single patch: every ring position is a reflection
+]
+
+
+def _op_d_case(c, dev, O, batch=2, seed=5):
+    from hyperseg_amd.models import hyperseg_v0_1 as V0
+    g = torch.Generator().manual_seed(seed + c['patch'])
+    cin = 2 + c['skip'] + c['prev']
+    fh, fw = c['grid']
+    h, w = fh * c['patch'], fw * c['patch']
+    m = V0.HyperPatchInvertedResidual(cin, c['cout'], 3, expand_ratio=2).eval()
+    hid = 2 * cin
+    bns = []
+    with torch.no_grad():
+        for blk in m.conv:
+            bn = blk[1]
+            bn.weight.copy_(torch.rand(bn.num_features, generator=g) + 0.5)
+            bn.bias.copy_(torch.randn(bn.num_features, generator=g) * 0.1)
+            bn.running_mean.copy_(torch.randn(bn.num_features, generator=g) * 0.1)
+            bn.running_var.copy_(torch.rand(bn.num_features, generator=g) * 1.5 + 0.5)
+            bns.append({k: getattr(bn, k).clone() for k in ('weight', 'bias', 'running_mean', 'running_var')})
+    skip = torch.randn(batch, c['skip'], h, w, generator=g)
+    prev = torch.randn(batch, c['prev'], h // 2, w // 2, generator=g)
+    # per-patch weights with the fan-in scaling of a trained hypernetwork head, so that ReLU6 is exercised on both sides
+    hp = m.hyper_params
+    assert hp == cin * hid + 9 * hid + hid * c['cout']
+    wt = torch.randn(batch, hp, fh, fw, generator=g)
+    wt[:, :cin * hid] *= (2.0 / cin) ** 0.5
+    wt[:, cin * hid:cin * hid + 9 * hid] *= (2.0 / 9) ** 0.5
+    wt[:, cin * hid + 9 * hid:] *= (1.0 / hid) ** 0.5
+    ref = O.patch_inverted_residual_v0(O.stage_input(skip, prev), wt, hid, c['cout'], *bns)
+    return m.to(dev), skip, prev, wt, ref
+
+
+@pytest.mark.parametrize('case', OP_D_CASES)
+def test_fused_op_d_vs_oracle(HF, O, dev, case):
+    """The one-launch Op D kernel (neighbour-weight ring recompute) == the oracle's three image-level patch convs, and ==
+    this package's own three-launch route bit-for-bit in structure (same inputs), for every HyperSeg-L level shape."""
+    m, skip, prev, wt, ref = _op_d_case(case, dev, O)
+    with torch.no_grad():
+        stage = HF.StageInput(skip.to(dev), prev.to(dev), coords=True)
+        # the fused launch must be the one that ran: ask the library directly
+        parts = m._fused_parts()
+        assert parts is not None
+        y_fused = m._forward_fused(stage, wt.to(dev))
+        assert y_fused is not None, 'hs_patch_ir_v0_fwd has no instantiation for a HyperSeg-L level shape'
+        cmp(y_fused, ref, what=f'fused Op D {case}')
+        y3 = m.conv(stage, wt.to(dev))                       # the three-launch route (generic kernels)
+        cmp(y3, ref, what=f'three-launch Op D {case}')
+        # the context head's patch-major bank (BankRef) instead of channel-major weights
+        bank = HF.bank_pack(wt.to(dev), 0, m.hyper_params)
+        yb = m(stage, HF.BankRef(bank, wt.shape[0], m.hyper_params, wt.shape[-2:]))
+        assert torch.equal(yb, y_fused)
+
+
+def test_fused_op_d_falls_back_when_regions_do_not_tile(HF, O, dev):
+    """12 x 20 pixels at patch 4 do not tile into 8x8 regions: the module silently takes the three-launch route."""
+    case = dict(skip=12, prev=34, cout=12, patch=4, grid=(3, 5))
+    m, skip, prev, wt, ref = _op_d_case(case, dev, O)
+    with torch.no_grad():
+        stage = HF.StageInput(skip.to(dev), prev.to(dev), coords=True)
+        assert m._forward_fused(stage, wt.to(dev)) is None
+        cmp(m(stage, wt.to(dev)), ref, what='fallback Op D')
+
+
+def test_full_config_l_bs32_properties(O, dev):
+    """BASELINE config 4 at its full batch (HyperSeg-L 512x512, bs 32): frames are independent in eval mode, so the
+    bs-32 decoder output must equal, frame by frame and bit for bit, the outputs of the per-GPU shards (bs 4, the
+    configuration test_full_config[L] pins to the reference), whatever the position of a frame inside its batch."""
+    d = build_decoder('L', O).to(dev)
+    x, w = O.synth_decoder_inputs('L', batch=32, seed=0)
+    x = [t.to(dev) for t in x]
+    w = [t.to(dev) for t in w]
+    with torch.no_grad():
+        y = d(x, w)
+        assert tuple(y.shape) == (32, 21, 512, 512) and bool(torch.isfinite(y).all())
+        for lo in (0, 12, 28):
+            ys = d([t[lo:lo + 4].contiguous() for t in x], [t[lo:lo + 4].contiguous() for t in w])
+            assert torch.equal(ys, y[lo:lo + 4]), f'shard starting at frame {lo}'
+    # the first shard is the fixture configuration of test_full_config[L] (same seed => same first frames? no: the
+    # generator is consumed per tensor, so only the oracle is compared here, on one frame)
+    ref = O.decoder_v0_1(O.config_plan('L'), O.synth_decoder_params(O.config_plan('L'), seed=0),
+                         [t[5:6].cpu() for t in x], [t[5:6].cpu() for t in w])
+    cmp(y[5:6], ref, what='L bs32 frame 5 vs oracle')

@@ -144,3 +144,57 @@ def test_two_optimizer_steps_vs_reference(golden, dev):
         else:
             close = (mine - v).abs() <= 1e-5 + 1e-4 * v.abs()
             assert float(close.float().mean()) > 0.99, (k, float(close.float().mean()))
+
+
+def _train_compare(name, batch, size, dev, seed=3):
+    """Train-mode forward + backward of a full BASELINE decoder through hyperseg_amd.autograd vs autograd of the oracle
+    (whose train-mode gradients are pinned to the reference's by the train_t_* fixtures)."""
+    from oracle import hyperseg_oracle as O
+    from test_hip_parity import build_decoder
+    plan = O.config_plan(name)
+    params = O.synth_decoder_params(plan, seed=0)
+    x, s = O.synth_decoder_inputs(name, batch=batch, seed=seed, size=size)
+    r = torch.randn(batch, O.CONFIGS[name]['num_classes'], *size, generator=torch.Generator().manual_seed(seed + 1))
+    # oracle
+    po = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and 'running' not in k else v.clone())
+          for k, v in params.items()}
+    xo = [t.clone().requires_grad_(True) for t in x]
+    so = s.clone().requires_grad_(True)
+    yo, stats = O.decoder_v1_0(plan, po, xo, so, training=True)
+    (yo * r).sum().backward()
+    # HIP path
+    d = build_decoder(name, O).to(dev).train()
+    xg = [t.to(dev).requires_grad_(True) for t in x]
+    sg = s.to(dev).requires_grad_(True)
+    yg = d(xg, sg)
+    (yg * r.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    assert rel_err(yg.detach().cpu(), yo.detach()) < TOL, 'train-mode logits'
+    assert rel_err(sg.grad.cpu(), so.grad) < TOL, 'grad of the signal'
+    for i in range(1, len(x)):                      # the 5-level decoders never read the image itself
+        assert rel_err(xg[i].grad.cpu(), xo[i].grad) < TOL, f'grad of pyramid input {i}'
+    named = dict(d.named_parameters())
+    n_checked = 0
+    for k, v in po.items():
+        if v.requires_grad and v.grad is not None:
+            assert rel_err(named[k].grad.cpu(), v.grad) < TOL, k
+            n_checked += 1
+    assert n_checked == 23 if name in ('Sc', 'M') else n_checked > 0    # 5 signal2weights.weight + 18 BN affine tensors
+    sd = d.state_dict()
+    for k, v in stats.items():
+        assert rel_err(sd[k].cpu(), v) < TOL, k
+    return float(rel_err(yg.detach().cpu(), yo.detach()))
+
+
+def test_config5_full_workload_fp32(dev):
+    """BASELINE config 5 AT ITS WORKLOAD: the CamVid-S decoder on 576x576 crops, batch 2, train mode (train.py:118-136;
+    configs/train/camvid_efficientnet_b1_hyperseg-s.py:27-38) -- forward, backward (dX, per-patch dW -> signal2weights.weight,
+    d signal, BN gamma/beta) and the updated BN running statistics, full size, against autograd of the oracle."""
+    _train_compare('Sc', 2, (576, 576), dev)
+
+
+def test_train_hyperseg_m_level_shapes(dev):
+    """The Cityscapes-M decoder in train mode on a 256x512 crop (grid 8x16): its level-4 depthwise weight-gradient tile
+    (68 hidden channels x 18x18 halo tiles = 192 KB if staged whole) needs the channel-blocked
+    hs_patch_conv_bwd_weight; round 1 raised 'tile does not fit the LDS' here."""
+    _train_compare('M', 1, (256, 512), dev)
