@@ -46,7 +46,7 @@ def build(force=False, verbose=False, extra_flags=(), sources=None, lib_path=Non
     objs = []
     procs = []
     for s in sources:
-        obj = os.path.join(LIB_DIR, s.replace('.hip', obj_suffix + '.o'))
+        obj = os.path.join(LIB_DIR, os.path.basename(s).replace('.hip', obj_suffix + '.o'))
         cmd = [_hipcc(), *FLAGS, *extra_flags, '-c', os.path.join(CSRC, s), '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)

@@ -7,31 +7,32 @@
 //
 // Per region the block is two small dense GEMMs around a depthwise 3x3,
 //     pw1  [hid x cin] . [cin x halo positions]          pw3  [cout x hid] . [hid x pixels]
-// on v_mfma_f32_16x16x4_f32 (exact fp32: a k-ordered fma chain at the fp32 peak rate).  One workgroup (4 waves) = one
-// REG x REG region; the tile maps (which 16 positions share a filter bank) are in hs_ir_tiles.h.
+// on v_mfma_f32_16x16x4_f32 (exact fp32: a k-ordered fma chain).  One workgroup (4 waves) = one REG x REG region; the
+// tile maps (which 16 positions share a filter bank) are in hs_ir_tiles.h.
 //
 //   prologue   the stage input cat(coords, skip, bilinear2x(prev)) is built DIRECTLY in the layout of the matrix
 //              cores' B operand (lane = (position, channel mod 4)): skip features are gathered from HBM straight into
 //              the fragment registers, the previous level's low-resolution window goes through LDS once and is
 //              sampled with the 4-tap stencil, coordinates are analytic.  The fragments stay in registers for the
 //              whole kernel; all HBM loads of the workgroup are in flight together.
-//   pw1        per owned position tile ceil(cin/4) MFMAs; D -> BN1 -> ReLU6 -> LDS h1[2][16][halo] (double-buffered)
-//   dw         thread = (hidden channel, output row): rows of the halo as ds_read_b128, 9 per-lane weights (of the
+//   pw1        per owned position tile ceil(cin/4) MFMAs; D -> BN1 -> ReLU6 -> LDS h1[16][halo]
+//   dw         thread = (hidden channel, output row [, half row]): halo rows as ds_read_b128, 9 per-lane taps (of the
 //              patch that owns the OUTPUT pixel), -> BN2 -> ReLU6 -> LDS h2[16][pixels]
 //   pw3        per owned pixel tile 4 MFMAs per 16 output channels, accumulators persistent across hidden chunks
 //   epilogue   BN3, row runs to HBM.
-// Hidden channels are processed in chunks of 16, software-pipelined: pw1 of chunk c+1 (matrix pipe) is issued in the
-// same basic block as the depthwise stage of chunk c (VALU + LDS), so the two pipes of a SIMD overlap inside every
-// wave instead of alternating behind barriers:
-//     step c:   { pw1(c+1) -> h1[(c+1)&1]  ||  dw(c): h1[c&1] -> h2 }   barrier   { pw3(c): h2 -> acc }   barrier
-// Filter-bank operands (the A fragments, the depthwise taps, BN rows) are plain vector loads from the bank in HBM/L2
-// issued one phase ahead of their use ("load next after use"); nothing of the bank is staged in LDS, which is what
-// lets h1 be double-buffered inside 80 KB (two workgroups per CU at HyperSeg-M level 4: 69.3 KB).
+// Hidden channels go through in chunks of 16:   dw(c) | barrier | pw3(c), pw1(c+1) | barrier.
+//
+// What bounds it (measured on MI355X, tools/ubench/mfma_valu.hip + profiles/round2_*): the f32-input MFMA executes on the
+// SIMD's vector FMA lanes -- while one is in flight the SIMD issues no other VALU instruction, from this wave or from a
+// co-resident one (38 cycles per MFMA alone, 86 with six v_fma behind it, 119 per wave with two waves per SIMD).  So a
+// SIMD's time is the SUM of its MFMA cycles and its VALU/LDS issue cycles; software-pipelining pw1 under the depthwise
+// stage (built and measured in round 2) bought nothing.  The levers that remain are instruction count and memory
+// latency, hence: no masks or selects behind loads (operand rows past the last channel read finite neighbours and meet a
+// zero BN scale/shift instead), 32-bit offsets from uniform bases, filter-bank operands loaded one stage ahead straight
+// from the bank in HBM/L2 (nothing of the bank is staged in LDS), every prologue load in flight before the first wait.
 // Hidden activations never leave the CU.
 #include "hs_common.h"
 #include "hs_ir_tiles.h"
-#include <type_traits>
-#include <utility>
 
 namespace hs {
 
@@ -52,14 +53,6 @@ struct IrFusedArgs {
 
 constexpr int IRF_THREADS = 256;
 
-// 1 = the mixed {pw1 || depthwise} block is emitted as explicit slices "one MFMA + its share of the depthwise stage's
-// VALU / LDS instructions", pinned with sched_barrier (an in-order wave overlaps its matrix and vector work only if
-// they alternate in program order; left alone, the compiler clusters the MFMAs and runs the depthwise stage after them).
-// 0 = the two stages one after the other (dev A/B).
-#ifndef HS_IRF_INTERLEAVE
-#define HS_IRF_INTERLEAVE 1
-#endif
-
 template <int REG> struct IrfGeom {
     static constexpr int HW = REG + 2;
     static constexpr int RS = (HW + 3) & ~3;                    // h1 row stride (floats): 16-byte aligned rows
@@ -71,65 +64,63 @@ template <int REG> struct IrfGeom {
     static constexpr int PPL = PWIN * PWIN;
     static constexpr int RS2 = REG + 4;                         // h2 pixel-row stride
     static constexpr int H2S = ((REG * RS2 + 31) & ~31) + 16;   // h2 plane: == 16 (mod 32) -> conflict-free B reads
-    static constexpr int H1_FLOATS = 2 * 16 * H1P;
+    static constexpr int H1_FLOATS = 16 * H1P;
     static constexpr int H2_FLOATS = 16 * H2S;
 };
 
 __device__ __forceinline__ float relu6_(float v) { return fminf(fmaxf(v, 0.0f), 6.0f); }
 
-// Compile-time loop: f(std::integral_constant<int, LO>), ..., f(std::integral_constant<int, HI-1>).  The mixed stage's
-// schedule needs every index as a constant expression (register arrays indexed by anything else end up in scratch).
-template <int LO, int... I, typename F>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
-    (f(std::integral_constant<int, LO + I>{}), ...);
-}
-template <int LO, int HI, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (HI > LO) static_for_impl<LO>(std::make_integer_sequence<int, HI - LO>{}, f);
-}
-
 template <int CIN, int CSKIP, int COUT, int REG, int MODE, int PWR>
 __global__ __launch_bounds__(IRF_THREADS, 2)
 void patch_ir_fused_kernel(IrFusedArgs a) {
-    constexpr bool INTERLEAVE = HS_IRF_INTERLEAVE != 0;
     using G = IrfGeom<REG>;
     using TM = IrTiles<REG, MODE, PWR>;
     constexpr int CPREV = CIN - 2 - CSKIP;
     static_assert(CPREV > 0 && CSKIP > 0, "fused form: coords + skip + previous level");
     constexpr int KS1 = (CIN + 3) / 4;
     constexpr int MT3 = (COUT + 15) / 16;
+    constexpr int CP = 16 * MT3;                                // output channels, padded
     constexpr int NT1 = TM::NT1, NT3 = TM::NT3;
     constexpr int J1 = (NT1 + 3) / 4, J3 = NT3 / 4;
     static_assert(NT3 % 4 == 0, "pixel tiles split evenly over the 4 waves");
     constexpr bool P1_UNI = (MODE == 0);        // every pw1 tile uses the region's own patch
     constexpr bool IN_UNI = (PWR == REG);       // every pixel of the region belongs to one patch
-    constexpr int SEGS = REG / PWR;
     // depthwise stage: thread = (hidden channel of the chunk, output row, DWW-pixel run of that row): all 256 threads busy
     constexpr int DWW = REG * REG / 16;                    // 16 (a whole row) or 4 (half a row of an 8x8 region)
     constexpr int NRD = (DWW + 2 + 3) / 4;                 // 16-byte reads per halo row
     constexpr int NKD = (IN_UNI || DWW <= PWR) ? 1 : DWW / PWR;   // tap sets per thread (one per patch under its run)
-    constexpr int NA1 = P1_UNI ? 1 : J1, NA3 = IN_UNI ? 1 : J3;
+    constexpr int NA3 = IN_UNI ? 1 : J3;
 
+    const int hid = a.hid;
+    const int HP = (hid + 15) & ~15;                  // hidden channels, padded to whole chunks
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* h1 = lds;                                  // [2][16][H1P]
+    float* h1 = lds;                                  // [16][H1P]
     float* h2 = lds + G::H1_FLOATS;                   // [16][H2S]
-    float* bnl = h2 + G::H2_FLOATS;                   // [s1 | b1 | s2 | b2] x hid, [s3 | b3] x COUT
+    // folded BatchNorm rows [s1 | b1 | s2 | b2] x HP, [s3 | b3] x CP, ZERO beyond the real channels: a hidden channel
+    // past hid (the tail of the last chunk) gets scale = shift = 0, i.e. h1 = h2 = relu6(0) = 0 whatever its (finite)
+    // operand rows held -- which is why no operand load below needs a mask
+    float* bnl = h2 + G::H2_FLOATS;
     float* pl = lds;                                  // prologue only: [CPREV][PWIN*PWIN], aliases h1
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, lk = lane >> 4;
+    // blocks are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, each with its own L2): give every XCD a
+    // CONTIGUOUS range of regions, so that the halo rows / neighbour banks two adjacent regions share are fetched into
+    // one L2 instead of two.  A pure relabelling (speed only; any placement is correct).
     int blk = blockIdx.x;
+    if ((gridDim.x & 7) == 0) blk = (blk & 7) * (gridDim.x >> 3) + (blk >> 3);
     const int rx = blk % a.regs_x; blk /= a.regs_x;
     const int ry = blk % a.regs_y;
     const int b = blk / a.regs_y;
     const int y0 = ry * REG, x0 = rx * REG;
-    const int hid = a.hid;
     const int H = a.in.H, W = a.in.W;
-    auto owner_of = [&](int yy, int xx) { return (b * a.fh + yy / a.ph) * a.fw + xx / a.pw; };
+    const unsigned plane = (unsigned)H * (unsigned)W;
+    // element offset of a patch's bank (host guarantees patches * ld < 2^30: 32-bit offsets from the uniform base)
+    auto bank_of = [&](int yy, int xx) { return (unsigned)((b * a.fh + yy / a.ph) * a.fw + xx / a.pw) * (unsigned)a.ld; };
     const float* __restrict__ bank = a.bank;
-    const size_t off_kd = (size_t)CIN * hid, off_w3 = off_kd + 9 * (size_t)hid;
+    const unsigned off_kd = (unsigned)CIN * hid, off_w3 = off_kd + 9u * hid;
 
-    // ---- prologue ------------------------------------------------------------------------------------------------
+    // ---- prologue: issue every load, then wait ---------------------------------------------------------------------
     // (1) low-res window of the previous level: rows [ly0, ly0+PWIN) x cols [lx0, lx0+PWIN), clamped at the image border;
     //     every bilinear tap of the halo grid, reflected positions included, falls inside it
     const int ly0 = (y0 >> 1) - 1, lx0 = (x0 >> 1) - 1;
@@ -143,17 +134,19 @@ void patch_ir_fused_kernel(IrFusedArgs a) {
             const int c = e / G::PPL, rq = e - c * G::PPL;
             const int r = rq / G::PWIN, qq = rq - r * G::PWIN;
             const int yy = min(max(ly0 + r, 0), a.in.Hp - 1), xx = min(max(lx0 + qq, 0), a.in.Wp - 1);
-            preg[q] = pvb[((size_t)c * a.in.Hp + yy) * a.in.Wp + xx];
+            preg[q] = pvb[(unsigned)((c * a.in.Hp + yy) * a.in.Wp + xx)];
         }
     }
-    // (2) positions of this wave's pw1 tiles and the skip-feature gathers, straight into the B fragments
+    // (2) positions of this wave's pw1 tiles and the skip-feature gathers, straight into the B fragments.  k-steps whose
+    //     four channels are not all skip features (they also hold coordinates / previous-level channels, merged in (4))
+    //     are gathered FIRST: loads return in order, so (4) then waits for those few only, not for the whole batch.
     float bf[J1][KS1];
     int hoff[J1];                 // LDS offset of this lane's position inside an h1 plane (DUMMY for a dead column)
-    int pyx[J1];                  // image coordinates (yy << 16 | xx) of this lane's position
-    int own1[NA1];                // patch that owns the tile (MODE 1)
+    int pyx[J1];                  // image coordinates (yy << 16 | xx) of this lane's position, -1 for a dead column
+    unsigned ob1[P1_UNI ? 1 : J1];   // bank offset of the patch that owns the tile
     {
-        const size_t plane = (size_t)H * W;
         const float* __restrict__ skb = a.in.skip + (size_t)b * CSKIP * plane;
+        int spo[J1];              // element offset of channel (lk - 2) at this lane's position (lanes lk < 2 never use it)
 #pragma unroll
         for (int jt = 0; jt < J1; ++jt) {
             const int t = wave + 4 * jt;
@@ -166,103 +159,111 @@ void patch_ir_fused_kernel(IrFusedArgs a) {
             if constexpr (!P1_UNI) {
                 int u0, v0;
                 TM::halo(tile_ok ? t : 0, 0, u0, v0);
-                own1[jt] = owner_of(pad_index(y0 + u0 - 1, H, HS_PAD_REFLECT), pad_index(x0 + v0 - 1, W, HS_PAD_REFLECT));
+                ob1[jt] = bank_of(pad_index(y0 + u0 - 1, H, HS_PAD_REFLECT), pad_index(x0 + v0 - 1, W, HS_PAD_REFLECT));
             }
-            const float* __restrict__ sp = skb + (size_t)yy * W + xx;
+            spo[jt] = yy * W + xx + (lk - 2) * (int)plane;
+        }
+        if constexpr (P1_UNI) ob1[0] = bank_of(y0, x0);
 #pragma unroll
-            for (int ks = 0; ks < KS1; ++ks) {
-                const int c = ks * 4 + lk;
-                float val = 0.0f;
-                if (live && c >= 2 && c < 2 + CSKIP) val = sp[(size_t)(c - 2) * plane];
-                bf[jt][ks] = val;
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int jt = 0; jt < J1; ++jt) {
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks) {
+                    const bool pure = ks * 4 >= 2 && ks * 4 + 3 < 2 + CSKIP;       // all four channels are skip features
+                    if (pure == (pass == 1)) {
+                        const int c = ks * 4 + lk;
+                        float val = 0.0f;
+                        if (pyx[jt] >= 0 && c >= 2 && c < 2 + CSKIP) val = (skb + (size_t)(ks * 4) * plane)[spo[jt]];
+                        bf[jt][ks] = val;
+                    }
+                }
             }
         }
-        if constexpr (P1_UNI) own1[0] = owner_of(y0, x0);
     }
-    // (3) folded BatchNorm rows -> LDS
-    {
-        const int nb = 4 * hid + 2 * COUT;
-        for (int e = tid; e < nb; e += IRF_THREADS) {
-            const float* __restrict__ srcp;
-            int off;
-            if (e < hid) { srcp = a.s1; off = e; }
-            else if (e < 2 * hid) { srcp = a.b1; off = e - hid; }
-            else if (e < 3 * hid) { srcp = a.s2; off = e - 2 * hid; }
-            else if (e < 4 * hid) { srcp = a.b2; off = e - 3 * hid; }
-            else if (e < 4 * hid + COUT) { srcp = a.s3; off = e - 4 * hid; }
-            else { srcp = a.b3; off = e - 4 * hid - COUT; }
-            bnl[e] = srcp[off];
+    // (3) folded BatchNorm rows (two per thread cover 4*HP + 2*CP <= 512)
+    const int nbp = 4 * HP + 2 * CP;
+    auto bn_val = [&](int e) -> float {
+        const int seg = e < 4 * HP ? e / HP : 4 + (e - 4 * HP) / CP;
+        const int idx = e < 4 * HP ? e - seg * HP : (e - 4 * HP) - (seg - 4) * CP;
+        const float* src = seg == 0 ? a.s1 : seg == 1 ? a.b1 : seg == 2 ? a.s2 : seg == 3 ? a.b2 : seg == 4 ? a.s3 : a.b3;
+        const int n = seg < 4 ? hid : COUT;
+        float v = 0.0f;
+        if (idx < n) v = src[idx];
+        return v;
+    };
+    float bnreg[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) bnreg[q] = bn_val(min(tid + q * IRF_THREADS, nbp - 1));
+
+    // ---- filter-bank operands: plain loads from the bank, issued one stage ahead of their use ----------------------
+    // pw1 A fragments  W1[h0 + lrow][4*ks + lk] of the tile's owner.  One set serves every tile when the region lies in one
+    // patch (Op C); with per-tile owners (Op D) this is tile 0's set, the others are fetched one tile ahead inside the stage
+    float afa[KS1];
+    float k9[NKD][9];                  // depthwise taps of the owner of this thread's output pixels
+    float a3[NA3][MT3][4];             // pw3 A fragments  W3[16*m + lrow][h0 + 4*ks + lk]
+    const int dw_hh = tid >> 4;
+    const int dw_u = (tid & 15) % REG, dw_c0 = ((tid & 15) / REG) * DWW;
+    unsigned ob3[NA3], obd[NKD];
+#pragma unroll
+    for (int q = 0; q < NA3; ++q) {
+        int row, col;
+        TM::pixel(wave + 4 * q, 0, row, col);
+        ob3[q] = IN_UNI ? bank_of(y0, x0) : bank_of(y0 + row, x0 + col);
+    }
+#pragma unroll
+    for (int q = 0; q < NKD; ++q) obd[q] = IN_UNI ? bank_of(y0, x0) : bank_of(y0 + dw_u, x0 + dw_c0 + q * PWR);
+    // lane parts of the operand offsets; rows past hid / k past cin read the finite floats that follow inside the bank
+    // (host-checked), rows past cout are clamped
+    const unsigned o1 = (unsigned)(lrow * CIN + lk);
+    const unsigned okd = off_kd + (unsigned)(dw_hh * 9);
+    unsigned o3[MT3];
+#pragma unroll
+    for (int m = 0; m < MT3; ++m) o3[m] = off_w3 + (unsigned)(min(m * 16 + lrow, COUT - 1) * hid + lk);
+
+    auto load_a1 = [&](int h0, unsigned ob, float (&dst)[KS1]) {
+        const float* __restrict__ wr = bank + (size_t)(h0 * CIN);
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) dst[ks] = wr[ob + o1 + 4 * ks];
+    };
+    auto load_kd = [&](int h0) {
+#pragma unroll
+        for (int q = 0; q < NKD; ++q) {
+            const float* __restrict__ kr = bank + (size_t)(h0 * 9);
+#pragma unroll
+            for (int e = 0; e < 9; ++e) k9[q][e] = kr[obd[q] + okd + e];
         }
-    }
+    };
+    auto load_a3 = [&](int h0, bool last) {
+#pragma unroll
+        for (int q = 0; q < NA3; ++q) {
+#pragma unroll
+            for (int m = 0; m < MT3; ++m) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    // the last chunk may end inside a k-step: stay inside the row (h2 is zero there)
+                    const int hcol = last ? min(h0 + 4 * ks, hid - 1 - lk) : h0 + 4 * ks;
+                    a3[q][m][ks] = bank[ob3[q] + o3[m] + (unsigned)hcol];
+                }
+            }
+        }
+    };
+    const int nchunks = HP >> 4;
+    load_a1(0, ob1[0], afa);
+    load_kd(0);
+    load_a3(0, nchunks == 1);
+    // every load of the prologue is in flight: now the LDS stores (they wait for the OLDEST loads only)
 #pragma unroll
     for (int q = 0; q < PQ; ++q) {
         const int e = tid + q * IRF_THREADS;
         if (e < CPREV * G::PPL) pl[e] = preg[q];
     }
-
-    // ---- filter-bank operands ("load next after use") ------------------------------------------------------------
-    float afa[NA1][KS1];               // pw1 A fragments  W1[h0 + lrow][4*ks + lk]  of the tile's owner
-    float k9[NKD][9], sc2, sh2;        // depthwise taps (of the owner of the output pixels) + bn2 of this thread's channel
-    float a3[NA3][MT3][4];             // pw3 A fragments  W3[16*m + lrow][h0 + 4*ks + lk]
-    const int dw_hh = tid >> 4;
-    const int dw_u = (tid & 15) % REG, dw_c0 = ((tid & 15) / REG) * DWW;
-    int own3[NA3], ownd[NKD];
 #pragma unroll
-    for (int q = 0; q < NA3; ++q) {
-        int row, col;
-        TM::pixel(wave + 4 * q, 0, row, col);
-        own3[q] = IN_UNI ? owner_of(y0, x0) : owner_of(y0 + row, x0 + col);
+    for (int q = 0; q < 2; ++q) {
+        const int e = tid + q * IRF_THREADS;
+        if (e < nbp) bnl[e] = bnreg[q];
     }
-#pragma unroll
-    for (int q = 0; q < NKD; ++q)
-        ownd[q] = IN_UNI ? owner_of(y0, x0) : owner_of(y0 + dw_u, x0 + dw_c0 + q * PWR);
-
-    auto load_a1 = [&](int h0) {
-        const int h = h0 + lrow;
-        const bool hok = h < hid;
-        const size_t row = (size_t)(hok ? h : 0) * CIN;
-#pragma unroll
-        for (int q = 0; q < NA1; ++q) {
-            const float* __restrict__ wr = bank + (size_t)own1[q] * a.ld + row;
-#pragma unroll
-            for (int ks = 0; ks < KS1; ++ks) {
-                const int k = ks * 4 + lk;
-                const float v = wr[k < CIN ? k : 0];
-                afa[q][ks] = (hok && k < CIN) ? v : 0.0f;
-            }
-        }
-    };
-    auto load_kd = [&](int h0) {
-        const int h = h0 + dw_hh;
-        const int hc = h < hid ? h : 0;
-#pragma unroll
-        for (int q = 0; q < NKD; ++q) {
-            const float* __restrict__ kr = bank + (size_t)ownd[q] * a.ld + off_kd + (size_t)hc * 9;
-#pragma unroll
-            for (int e = 0; e < 9; ++e) k9[q][e] = kr[e];
-        }
-        sc2 = a.s2[hc]; sh2 = a.b2[hc];
-    };
-    auto load_a3 = [&](int h0) {
-#pragma unroll
-        for (int q = 0; q < NA3; ++q) {
-            const float* __restrict__ w3 = bank + (size_t)own3[q] * a.ld + off_w3;
-#pragma unroll
-            for (int m = 0; m < MT3; ++m) {
-                const int oc = m * 16 + lrow;
-                const bool ook = oc < COUT;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const int h = h0 + ks * 4 + lk;
-                    const float v = w3[(size_t)(ook ? oc : 0) * hid + (h < hid ? h : 0)];
-                    a3[q][m][ks] = (ook && h < hid) ? v : 0.0f;
-                }
-            }
-        }
-    };
-    load_a1(0);
-    load_kd(0);
-    load_a3(0);
+    for (int e = tid + 2 * IRF_THREADS; e < nbp; e += IRF_THREADS) bnl[e] = bn_val(e);     // hid > 112: not a decoder shape
     __syncthreads();                                   // window + BN rows are in LDS
 
     // (4) coordinates and the bilinear-resized previous level complete the B fragments
@@ -276,24 +277,27 @@ void patch_ir_fused_kernel(IrFusedArgs a) {
         const float cx = linspace_pm1(xx, W, a.in.step_x), cy = linspace_pm1(yy, H, a.in.step_y);
 #pragma unroll
         for (int ks = 0; ks < KS1; ++ks) {
-            const int c = ks * 4 + lk;
-            float val = bf[jt][ks];
-            if (c < 2) val = (c == 0) ? cx : cy;
-            if (c >= 2 + CSKIP && c < CIN) {
-                const float* q = pl + (c - 2 - CSKIP) * G::PPL;
-                val = ty.l0 * (tx.l0 * q[o00] + tx.l1 * q[o01]) + ty.l1 * (tx.l0 * q[o10] + tx.l1 * q[o11]);
+            const bool pure = ks * 4 >= 2 && ks * 4 + 3 < 2 + CSKIP;   // gathered skip features only: nothing to merge
+            if (!pure) {
+                const int c = ks * 4 + lk;
+                float val = bf[jt][ks];
+                if (c < 2) val = (c == 0) ? cx : cy;
+                if (c >= 2 + CSKIP && c < CIN) {
+                    const float* q = pl + (c - 2 - CSKIP) * G::PPL;
+                    val = ty.l0 * (tx.l0 * q[o00] + tx.l1 * q[o01]) + ty.l1 * (tx.l0 * q[o10] + tx.l1 * q[o11]);
+                }
+                bf[jt][ks] = live ? val : 0.0f;
             }
-            bf[jt][ks] = live ? val : 0.0f;
         }
     }
     int h2off[J3];                                     // LDS offset of this lane's pixel inside an h2 plane
-    int pix3[J3];                                      // (row << 8 | col) of this lane's pixel
+    unsigned yoff[J3];                                 // element offset of output channel 4*lk at this lane's pixel
 #pragma unroll
     for (int jt = 0; jt < J3; ++jt) {
         int row, col;
         TM::pixel(wave + 4 * jt, lrow, row, col);
         h2off[jt] = row * G::RS2 + col;
-        pix3[jt] = (row << 8) | col;
+        yoff[jt] = (unsigned)(4 * lk) * plane + (unsigned)((y0 + row) * W + x0 + col);
     }
     f32x4 acc3[MT3][J3];
 #pragma unroll
@@ -302,33 +306,39 @@ void patch_ir_fused_kernel(IrFusedArgs a) {
         for (int jt = 0; jt < J3; ++jt) acc3[m][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();                                   // the window is dead: h1 may overwrite it
 
-    // ---- stages -------------------------------------------------------------------------------------------------
-    // pw1 of the chunk starting at h0 into h1 buffer hb, then the loads of the FOLLOWING chunk's A fragments
-    auto stage_pw1 = [&](int h0, float* __restrict__ hb) {
-        float sc1[4], sh1[4];
+    // ---- stages ------------------------------------------------------------------------------------------------------
+    // pw1 of the chunk starting at h0 -> h1, then the loads of the FOLLOWING chunk's A fragments
+    auto stage_pw1 = [&](int h0) {
+        const float4 sc1 = *reinterpret_cast<const float4*>(bnl + h0 + 4 * lk);
+        const float4 sh1 = *reinterpret_cast<const float4*>(bnl + HP + h0 + 4 * lk);
+        float at[2][KS1];                              // per-tile owners: this tile's / the next tile's fragments
+        if constexpr (!P1_UNI) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int hr = h0 + 4 * lk + r;
-            const int hc = hr < hid ? hr : 0;
-            sc1[r] = bnl[hc]; sh1[r] = bnl[hid + hc];
+            for (int ks = 0; ks < KS1; ++ks) at[0][ks] = afa[ks];
         }
-        // branch-free on purpose (a dead tile multiplies zeros and stores to the DUMMY slot): the whole stage must stay
-        // in ONE basic block with the depthwise stage for the two to be interleaved
 #pragma unroll
         for (int jt = 0; jt < J1; ++jt) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (!P1_UNI) {
+                if (jt + 1 < J1) load_a1(h0, ob1[jt + 1], at[(jt + 1) & 1]);
+            }
+            if ((NT1 % 4 == 0) || jt < J1 - 1 || wave < NT1 - 4 * (J1 - 1)) {      // uniform: the last round may be short
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < KS1; ++ks)
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afa[P1_UNI ? 0 : jt][ks], bf[jt][ks], acc, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                hb[(4 * lk + r) * G::H1P + hoff[jt]] = relu6_(fmaf(acc[r], sc1[r], sh1[r]));
+                for (int ks = 0; ks < KS1; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(P1_UNI ? afa[ks] : at[jt & 1][ks], bf[jt][ks], acc, 0, 0, 0);
+                float* dst = h1 + (4 * lk) * G::H1P + hoff[jt];
+                dst[0] = relu6_(fmaf(acc[0], sc1.x, sh1.x));
+                dst[G::H1P] = relu6_(fmaf(acc[1], sc1.y, sh1.y));
+                dst[2 * G::H1P] = relu6_(fmaf(acc[2], sc1.z, sh1.z));
+                dst[3 * G::H1P] = relu6_(fmaf(acc[3], sc1.w, sh1.w));
+            }
         }
-        load_a1(h0 + 16 < hid ? h0 + 16 : h0);          // next chunk's rows (the last chunk reloads its own)
+        load_a1(h0 + 16 < HP ? h0 + 16 : h0, ob1[0], afa);
     };
-    // depthwise 3x3 + bn2 + relu6 of one chunk: h1 buffer hb -> h2; then the loads of the next chunk's taps
-    auto stage_dw = [&](int h0, const float* __restrict__ hb) {
-        const float* hp = hb + dw_hh * G::H1P + dw_u * G::RS + dw_c0;
+    // depthwise 3x3 + bn2 + relu6 of one chunk: h1 -> h2; then the loads of the next chunk's taps
+    auto stage_dw = [&](int h0) {
+        const float sc2 = bnl[2 * HP + h0 + dw_hh], sh2 = bnl[3 * HP + h0 + dw_hh];
+        const float* hp = h1 + dw_hh * G::H1P + dw_u * G::RS + dw_c0;
         float o[DWW];
 #pragma unroll
         for (int v = 0; v < DWW; ++v) o[v] = 0.0f;
@@ -352,12 +362,10 @@ void patch_ir_fused_kernel(IrFusedArgs a) {
             *reinterpret_cast<float4*>(dst + 4 * q) =
                 make_float4(relu6_(fmaf(o[4 * q], sc2, sh2)), relu6_(fmaf(o[4 * q + 1], sc2, sh2)),
                             relu6_(fmaf(o[4 * q + 2], sc2, sh2)), relu6_(fmaf(o[4 * q + 3], sc2, sh2)));
-        load_kd(h0 + 16 < hid ? h0 + 16 : h0);
+        load_kd(h0 + 16 < HP ? h0 + 16 : h0);
     };
     // pw3: acc3 += W3[:, chunk] . h2; then the loads of the next chunk's A fragments
-    auto stage_pw3 = [&](int h0, auto full) {
-        // FULL: all 16 channels of the chunk exist (every chunk but possibly the last): no k-step test, one block
-        constexpr bool FULL = decltype(full)::value;
+    auto stage_pw3 = [&](int h0) {
         float bv[4][J3];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
@@ -365,7 +373,7 @@ void patch_ir_fused_kernel(IrFusedArgs a) {
             for (int jt = 0; jt < J3; ++jt) bv[ks][jt] = h2[(ks * 4 + lk) * G::H2S + h2off[jt]];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            if (FULL || h0 + ks * 4 < hid) {           // uniform: skip k-steps past the last hidden channel
+            if (h0 + ks * 4 < hid) {                   // uniform: skip k-steps past the last hidden channel
 #pragma unroll
                 for (int jt = 0; jt < J3; ++jt)
 #pragma unroll
@@ -373,123 +381,35 @@ void patch_ir_fused_kernel(IrFusedArgs a) {
                         acc3[m][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[IN_UNI ? 0 : jt][m][ks], bv[ks][jt], acc3[m][jt], 0, 0, 0);
             }
         }
-        load_a3(h0 + 16 < hid ? h0 + 16 : h0);
-    };
-    // ---- software-pipelined chunk loop ---------------------------------------------------------------------------
-    // The mixed stage: pw1 of chunk h0n -> hbn interleaved with the depthwise stage of chunk h0d: hbc -> h2.
-    // MFMA order: tiles in pairs (two independent accumulator chains: a dependent MFMA needs 40 cycles, the pipe 32);
-    // a tile's BN1/ReLU6/LDS-store epilogue is emitted three MFMAs after its last one.  The depthwise stage is a flat
-    // list of micro-ops (halo-row reads through two row buffers, FMAs, BN2/ReLU6 + stores) spread evenly over the slices.
-    auto stage_mixed = [&](int h0n, float* __restrict__ hbn, int h0d, const float* __restrict__ hbc) {
-        constexpr int NSL = J1 * KS1;                  // slices = MFMAs of the pw1 stage
-        constexpr int NF = DWW * 3;                    // FMAs per halo row
-        constexpr int OP_R1 = NRD, OP_F0 = 2 * NRD, OP_R2 = OP_F0 + NF, OP_F1 = OP_R2 + NRD, OP_F2 = OP_F1 + NF,
-                      OP_FIN = OP_F2 + NF, NOPS = OP_FIN + DWW / 4;
-        float sc1[4], sh1[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int hr = h0n + 4 * lk + r;
-            const int hc = hr < hid ? hr : 0;
-            sc1[r] = bnl[hc]; sh1[r] = bnl[hid + hc];
-        }
-        const float* hp = hbc + dw_hh * G::H1P + dw_u * G::RS + dw_c0;
-        float* dst = h2 + dw_hh * G::H2S + dw_u * G::RS2 + dw_c0;
-        float o[DWW], rowv[2][NRD * 4];
-#pragma unroll
-        for (int v = 0; v < DWW; ++v) o[v] = 0.0f;
-        f32x4 acc[J1];
-#pragma unroll
-        for (int jt = 0; jt < J1; ++jt) acc[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        auto dw_op = [&](auto I_) {
-            constexpr int i = decltype(I_)::value;
-            if constexpr (i < OP_F0 || (i >= OP_R2 && i < OP_F1)) {                 // one 16-byte read of a halo row
-                constexpr int ky = i < OP_R1 ? 0 : (i < OP_F0 ? 1 : 2);
-                constexpr int q = i < OP_R1 ? i : (i < OP_F0 ? i - OP_R1 : i - OP_R2);
-                constexpr int buf = ky == 1 ? 1 : 0;
-                const float4 v4 = *reinterpret_cast<const float4*>(hp + ky * G::RS + 4 * q);
-                rowv[buf][4 * q] = v4.x; rowv[buf][4 * q + 1] = v4.y; rowv[buf][4 * q + 2] = v4.z; rowv[buf][4 * q + 3] = v4.w;
-            } else if constexpr (i < OP_FIN) {                                       // one tap
-                constexpr int ky = i < OP_R2 ? 0 : (i < OP_F2 ? 1 : 2);
-                constexpr int f = i < OP_R2 ? i - OP_F0 : (i < OP_F2 ? i - OP_F1 : i - OP_F2);
-                constexpr int buf = ky == 1 ? 1 : 0;
-                constexpr int v = f / 3, kx = f - 3 * v;
-                o[v] = fmaf(k9[NKD == 1 ? 0 : v / PWR][ky * 3 + kx], rowv[buf][v + kx], o[v]);
-            } else {                                                                 // BN2 + ReLU6 + store of 4 pixels
-                constexpr int q = i - OP_FIN;
-                *reinterpret_cast<float4*>(dst + 4 * q) =
-                    make_float4(relu6_(fmaf(o[4 * q], sc2, sh2)), relu6_(fmaf(o[4 * q + 1], sc2, sh2)),
-                                relu6_(fmaf(o[4 * q + 2], sc2, sh2)), relu6_(fmaf(o[4 * q + 3], sc2, sh2)));
-            }
-        };
-        auto tile_epilogue = [&](auto T_) {
-            constexpr int jt = decltype(T_)::value;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                hbn[(4 * lk + r) * G::H1P + hoff[jt]] = relu6_(fmaf(acc[jt][r], sc1[r], sh1[r]));
-        };
-        constexpr int NPAIR = J1 / 2;
-        static_for<0, NSL>([&](auto M_) {
-            constexpr int m = decltype(M_)::value;
-            // (tile, k-step) of MFMA m
-            constexpr bool paired = m < NPAIR * 2 * KS1;
-            constexpr int pr = m / (2 * KS1), r2 = m - pr * 2 * KS1;
-            constexpr int jt = paired ? 2 * pr + (r2 & 1) : J1 - 1;
-            constexpr int ks = paired ? (r2 >> 1) : m - NPAIR * 2 * KS1;
-            acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afa[P1_UNI ? 0 : jt][ks], bf[jt][ks], acc[jt], 0, 0, 0);
-            // epilogues that fall due in this slice (three MFMAs after the tile's last one)
-            static_for<0, J1>([&](auto T_) {
-                constexpr int t = decltype(T_)::value;
-                constexpr int last = (t < NPAIR * 2) ? (t / 2) * 2 * KS1 + 2 * (KS1 - 1) + (t & 1) : NSL - 1;
-                if constexpr (last + 3 < NSL && m == last + 3) tile_epilogue(T_);
-            });
-            if constexpr (INTERLEAVE) {
-                static_for<m * NOPS / NSL, (m + 1) * NOPS / NSL>(dw_op);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        });
-        // tiles whose epilogue could not be placed three MFMAs later
-        static_for<0, J1>([&](auto T_) {
-            constexpr int t = decltype(T_)::value;
-            constexpr int last = (t < NPAIR * 2) ? (t / 2) * 2 * KS1 + 2 * (KS1 - 1) + (t & 1) : NSL - 1;
-            if constexpr (last + 3 >= NSL) tile_epilogue(T_);
-        });
-        if constexpr (!INTERLEAVE) static_for<0, NOPS>(dw_op);
-        load_a1(h0n + 16 < hid ? h0n + 16 : h0n);
-        load_kd(h0d + 16 < hid ? h0d + 16 : h0d);
+        const int hn = h0 + 16 < HP ? h0 + 16 : h0;
+        load_a3(hn, hn + 16 >= HP);
     };
 
-    const int nchunks = (hid + 15) >> 4;
-    stage_pw1(0, h1);
+    // ---- chunk loop:  dw(c) | barrier | pw3(c), pw1(c+1) | barrier ---------------------------------------------------
+    stage_pw1(0);
     __syncthreads();
-    for (int ch = 0; ch + 1 < nchunks; ++ch) {
-        const int h0 = ch * 16;
-        float* cur = h1 + (ch & 1) * (16 * G::H1P);
-        float* nxt = h1 + ((ch + 1) & 1) * (16 * G::H1P);
-        stage_mixed(h0 + 16, nxt, h0, cur);            // matrix pipe under the VALU / LDS work of the previous chunk
+    for (int h0 = 0; h0 < HP; h0 += 16) {
+        stage_dw(h0);
         __syncthreads();
-        stage_pw3(h0, std::true_type{});
-        __syncthreads();                               // h2 is rewritten by the next depthwise stage
-    }
-    {
-        const int ch = nchunks - 1;
-        stage_dw(ch * 16, h1 + (ch & 1) * (16 * G::H1P));
-        __syncthreads();
-        stage_pw3(ch * 16, std::false_type{});
+        stage_pw3(h0);
+        if (h0 + 16 < HP) {
+            stage_pw1(h0 + 16);                        // h1 is free: every wave finished dw(c) before the barrier above
+            __syncthreads();                           // h1 ready for dw(c+1); h2 no longer read by pw3(c)
+        }
     }
 
-    // ---- epilogue: bn3 + store -----------------------------------------------------------------------------------
+    // ---- epilogue: bn3 + store ---------------------------------------------------------------------------------------
+    float* __restrict__ yb = a.y + (size_t)b * COUT * plane;
 #pragma unroll
     for (int m = 0; m < MT3; ++m) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int o = m * 16 + 4 * lk + r;
             if (o < COUT) {
-                const float sc = bnl[4 * hid + o], sh = bnl[4 * hid + COUT + o];
+                const float sc = bnl[4 * HP + o], sh = bnl[4 * HP + CP + o];
+                float* __restrict__ yo = yb + (size_t)(m * 16 + r) * plane;
 #pragma unroll
-                for (int jt = 0; jt < J3; ++jt) {
-                    const int row = pix3[jt] >> 8, col = pix3[jt] & 0xff;
-                    a.y[(((size_t)b * COUT + o) * H + (y0 + row)) * W + (x0 + col)] = fmaf(acc3[m][jt][r], sc, sh);
-                }
+                for (int jt = 0; jt < J3; ++jt) yo[yoff[jt]] = fmaf(acc3[m][jt][r], sc, sh);
             }
         }
     }
@@ -500,8 +420,11 @@ static int launch_irf(IrFusedArgs& a, hipStream_t stream) {
     using G = IrfGeom<REG>;
     if (a.in.H % REG != 0 || a.in.W % REG != 0) return 1;      // regions must tile the level
     a.regs_y = a.in.H / REG; a.regs_x = a.in.W / REG;
-    const size_t bn_floats = ((size_t)4 * a.hid + 2 * COUT + 3) & ~(size_t)3;
+    const size_t hp = ((size_t)a.hid + 15) & ~(size_t)15;
+    const size_t bn_floats = 4 * hp + 2 * 16 * ((COUT + 15) / 16);
     const size_t lds = ((size_t)G::H1_FLOATS + G::H2_FLOATS + bn_floats) * sizeof(float);
+    // operand rows past the last hidden channel / k past cin are read unmasked: they must stay inside the patch's bank
+    if (16 * CIN + 4 > a.hid * (9 + COUT) || 144 > a.hid * COUT) return 1;
     if (lds > 160 * 1024) return HS_ERR_LDS;
     if (lds > 64 * 1024) {
         static std::atomic<unsigned long long> done{0};       // one per instantiation
@@ -525,6 +448,9 @@ int try_launch_ir_fused(int mode, const StageIn& in, int fh, int fw, const float
     a.s1 = s1; a.b1 = b1; a.s2 = s2; a.b2 = b2; a.s3 = s3; a.b3 = b3; a.y = y;
     if (in.Hp * 2 != in.H || in.Wp * 2 != in.W) return 1;      // the LDS window assumes the exact 2x pyramid
     if (in.H >= 32768 || in.W >= 32768) return 1;              // packed (yy << 16 | xx) positions
+    // 32-bit element offsets from uniform bases
+    if ((size_t)in.B * fh * fw * (size_t)ld >= (1u << 30) || (size_t)in.H * in.W * (size_t)(c_out > c_skip ? c_out : c_skip) >= (1u << 30) ||
+        (size_t)(cin - 2 - c_skip) * in.Hp * in.Wp >= (1u << 30)) return 1;
     if (a.ph != a.pw) return 1;
     const int p = a.ph;
 #define HS_IRF_CASE(CI, CS, CO, REG, MODE, PWR) \

@@ -1,7 +1,8 @@
-"""N > 1 path of bench.py's batch-sharded inference harness, world_size 2 on CPU with the gloo backend: the
-double-buffered async gather onto rank 0 (default; or all_gather_into_tensor) of per-rank results (the logits of the
-rank's frames), overlapped with the "next frame", must deliver every rank's frames in rank order.  The GPU run uses the same code
-with backend "nccl" (= RCCL over xGMI)."""
+"""N > 1 path of bench.py's batch-sharded inference harness, world_size 2 on CPU with the gloo backend: the asynchronous
+all_gather_into_tensor (default, the north star's collective; or gather onto rank 0) of per-rank results (the logits of
+the rank's frames) on a ring of three buffers, overlapped with the "next frame", must deliver every rank's frames in rank
+order, and a returned buffer must stay valid until the next submit.  The GPU run uses the same code with backend "nccl"
+(= RCCL over xGMI)."""
 import os
 import socket
 import sys
@@ -22,7 +23,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, steps, q, mode='gather'):
+def _worker(rank, world, port, steps, q, mode='allgather'):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
@@ -32,26 +33,36 @@ def _worker(rank, world, port, steps, q, mode='gather'):
         ok = True
         frames = shard_frames(steps * world, rank, world)
         assert frames == list(range(rank, steps * world, world))
-        for i, f in enumerate(frames):
-            y = torch.full(shape, float(f))                  # stands for the logits of global frame f
-            prev = g.submit(i, y)                            # starts the gather of frame i, returns a finished one
-            if prev is not None:
-                step, out = prev
-                want = torch.tensor([float(step * world + r) for r in range(world)]).view(world, 1, 1, 1, 1)
-                ok &= (out is not None) == owner
-                if owner:
-                    ok &= bool(torch.equal(out, want.expand(world, *shape)))
-        for step, out in g.drain():
+        seen = []
+
+        def check(item):
+            nonlocal ok
+            step, out = item
+            seen.append(step)
             want = torch.tensor([float(step * world + r) for r in range(world)]).view(world, 1, 1, 1, 1)
             ok &= (out is not None) == owner
             if owner:
                 ok &= bool(torch.equal(out, want.expand(world, *shape)))
+        for i, f in enumerate(frames):
+            y = torch.full(shape, float(f))                  # stands for the logits of global frame f
+            prev = g.submit(i, y)                            # starts the collective of step i, returns step i-2's result
+            ok &= (prev is None) == (i < 2)
+            if prev is not None:
+                # the returned buffer must stay intact until the NEXT submit (it used to be re-targeted by
+                # the very submit that returned it)
+                held = prev[1].clone() if prev[1] is not None else None
+                check(prev)
+                if held is not None:
+                    ok &= bool(torch.equal(prev[1], held))
+        for item in g.drain():
+            check(item)
+        ok &= seen == list(range(steps))
         q.put((rank, ok, g.completed))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('mode', ['gather', 'allgather'])
+@pytest.mark.parametrize('mode', ['allgather', 'gather'])
 @pytest.mark.parametrize('steps', [1, 5])
 def test_batch_sharded_gather_gloo(steps, mode):
     world, port = 2, _free_port()

@@ -1,20 +1,71 @@
 """Dev-only variant builds of the HIP library for on-GPU A/B runs (selected with HS_HIP_LIB=<path>); the product build
-(python -m hyperseg_amd.build) contains none of this.
+(python -m hyperseg_amd.build) contains none of this, and the product sources carry no dev hooks: the 'stamps' variant
+is made by patching a COPY of hs_patch_ir_fused.hip.
     oldir     round-1 Op C kernel (hs_patch_ir_mfma.hip) behind hs_patch_ir_fwd
     nointer   fused inverted-residual kernel with the pw1 / depthwise stages NOT interleaved (HS_IRF_INTERLEAVE=0)
+    stamps    s_memtime stamps of wave 0 of every workgroup at the phase boundaries (tools/ir_phase_times.py reads them)
 """
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hyperseg_amd import build as B
 
+STAMP_DECL = '''
+__device__ long long hs_irf_stamps[2048 * 32];
+#define HS_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 2048) hs_irf_stamps[blockIdx.x * 32 + (k)] = __builtin_readcyclecounter(); } while (0)
+extern "C" int hs_debug_read_stamps(long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hs_irf_stamps), sizeof(long long) * n);
+}
+'''
+
+
+def stamped_source():
+    src = open(os.path.join(B.CSRC, 'hs_patch_ir_fused.hip')).read()
+
+    def after(anchor, code, count=1):
+        nonlocal src
+        assert src.count(anchor) >= 1, anchor
+        src = src.replace(anchor, anchor + code, count)
+
+    def before(anchor, code):
+        nonlocal src
+        assert src.count(anchor) == 1, anchor
+        src = src.replace(anchor, code + anchor)
+    after('namespace hs {\n', STAMP_DECL)
+    after('    const int lrow = lane & 15, lk = lane >> 4;\n', '    HS_STAMP(0);\n')
+    before('    __syncthreads();                                   // window + BN rows are in LDS', '    HS_STAMP(1);\n')
+    after('    __syncthreads();                                   // window + BN rows are in LDS\n', '    HS_STAMP(2);\n')
+    before('    __syncthreads();                                   // the window is dead', '    HS_STAMP(3);\n')
+    after('    stage_pw1(0);\n    __syncthreads();\n', '    HS_STAMP(4);\n')
+    after('        stage_dw(h0);\n', '        HS_STAMP(5 + 4 * (h0 < 48 ? h0 / 16 : 3));\n')
+    after('        stage_dw(h0);\n        HS_STAMP(5 + 4 * (h0 < 48 ? h0 / 16 : 3));\n        __syncthreads();\n',
+          '        HS_STAMP(6 + 4 * (h0 < 48 ? h0 / 16 : 3));\n')
+    after('        stage_pw3(h0);\n', '        HS_STAMP(7 + 4 * (h0 < 48 ? h0 / 16 : 3));\n')
+    after('            __syncthreads();                           // h1 ready for dw(c+1); h2 no longer read by pw3(c)\n',
+          '            HS_STAMP(8 + 4 * (h0 < 48 ? h0 / 16 : 3));\n')
+    # end of the kernel body: the closing brace that precedes launch_irf's template header
+    marker = '\ntemplate <int CIN, int CSKIP, int COUT, int REG, int MODE, int PWR>\nstatic int launch_irf('
+    i = src.index(marker)
+    j = src.rindex('}', 0, i)
+    src = src[:j] + '    HS_STAMP(24);\n' + src[j:]
+    os.makedirs(os.path.join(B.LIB_DIR, 'dev_src'), exist_ok=True)
+    path = os.path.join(B.LIB_DIR, 'dev_src', 'hs_patch_ir_fused_stamps.hip')
+    open(path, 'w').write(src)
+    return path
+
+
 VARIANTS = {
     'oldir': dict(flags=['-DHS_IR_USE_OLD'], extra=['hs_patch_ir_mfma.hip']),
     'nointer': dict(flags=['-DHS_IRF_INTERLEAVE=0'], extra=[]),
+    'stamps': dict(flags=[], extra=[], patch=True),
 }
 
 if __name__ == '__main__':
     for name in (sys.argv[1:] or VARIANTS):
         v = VARIANTS[name]
         path = os.path.join(B.LIB_DIR, f'libhyperseg_hip_{name}.so')
-        print(B.build(force=True, extra_flags=v['flags'], sources=B.SOURCES + v['extra'], lib_path=path, obj_suffix='_' + name))
+        sources = list(B.SOURCES) + v['extra']
+        if v.get('patch'):
+            rel = os.path.relpath(stamped_source(), B.CSRC)
+            sources = [rel if s == 'hs_patch_ir_fused.hip' else s for s in sources]
+        print(B.build(force=True, extra_flags=v['flags'], sources=sources, lib_path=path, obj_suffix='_' + name))

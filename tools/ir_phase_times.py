@@ -1,0 +1,44 @@
+"""Per-phase cycle counts of the fused inverted-residual kernel (dev 'stamps' build: HS_HIP_LIB=.../libhyperseg_hip_stamps.so).
+    HS_HIP_LIB=hyperseg_amd/lib/libhyperseg_hip_stamps.so python tools/ir_phase_times.py [M|S|Sc|L]"""
+import ctypes as C
+import os
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _workload import decoder_workload
+import hyperseg_amd._hip as hip
+
+name = sys.argv[1] if len(sys.argv) > 1 else 'M'
+dec, pyr, head = decoder_workload(name)
+for _ in range(3):
+    dec(pyr, head)
+torch.cuda.synchronize()
+fn = hip.lib.hs_debug_read_stamps
+fn.argtypes, fn.restype = [C.c_void_p, C.c_int], C.c_int
+n = 2048 * 32
+buf = np.zeros(n, dtype=np.int64)
+assert fn(buf.ctypes.data, n) == 0
+st = buf.reshape(2048, 32)
+live = st[:, 24] > 0
+st = st[live]
+print(f'{name}: {live.sum()} workgroups stamped (the LAST inverted-residual launch of the decoder)')
+labels = {0: 'start', 1: 'loads issued + LDS stores', 2: 'barrier (window in LDS)', 3: 'B fragments done', 4: 'pw1(0) + barrier',
+          24: 'epilogue stores issued'}
+for c in range(4):
+    labels[5 + 4 * c] = f'dw[{c}{"+" if c == 3 else ""}]'
+    labels[6 + 4 * c] = 'barrier'
+    labels[7 + 4 * c] = 'pw3'
+    labels[8 + 4 * c] = 'pw1(next) + barrier'
+t0 = st[:, 0].min()
+prev = None
+for k in sorted(labels):
+    col = st[:, k]
+    if (col == 0).all():
+        continue
+    rel = col - st[:, 0]
+    d = (col - st[:, prev]) if prev is not None else rel
+    print(f'  stamp {k:2d} {labels[k]:26s} since start: mean {rel.mean():9.0f}  | phase: mean {d.mean():8.0f} min {d.min():8.0f} max {d.max():8.0f}')
+    prev = k
+print(f'  workgroup start spread: {(st[:, 0] - t0).max()} cycles; total mean {(st[:, 24] - st[:, 0]).mean():.0f}, '
+      f'first start -> last end {st[:, 24].max() - t0}')
