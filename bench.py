@@ -1,26 +1,38 @@
 #!/usr/bin/env python
-"""bench.py -- frames/sec of HyperSeg-M (EfficientNet-B1, 1024x512, bs=1 per GPU) on MI355X.
+"""bench.py -- frames/sec of a BASELINE HyperSeg configuration on MI355X (default: HyperSeg-M, EfficientNet-B1, 1024x512, bs=1).
 
     python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W [--model m|s|sc|l]
 
-A "step" is one forward of the whole model on one resident synthetic 1024x512 frame per rank:
-encoder + context head (hyperseg_amd.utils.inference.prepare_for_inference; --stock-encoder: plain PyTorch-ROCm), then
-the HIP decoder (hot path), captured once in a HIP graph and replayed.  N > 1 is batch-sharded inference (one process
-per GPU, weak scaling) with an RCCL gather of the logits onto rank 0 (nn.DataParallel's semantics; --collective
-allgather for an all-gather) on RCCL's stream, overlapped with the next frame.  Rank 0 prints ONE JSON line.
+A "step" is one forward of the whole model on one resident synthetic batch per rank: encoder + context head
+(hyperseg_amd.utils.inference.prepare_for_inference; --stock-encoder: plain PyTorch-ROCm), then the HIP decoder (hot
+path), captured once in a HIP graph and replayed.  N > 1 is batch-sharded inference, one process per GPU:
+  --model m / s / sc   bs 1 per GPU (weak scaling: BASELINE configs 2, 3);
+  --model l            the bs-32 batch of BASELINE config 4 sharded 32/N frames per GPU (strong scaling);
+the single collective is the north star's RCCL all_gather_into_tensor of every rank's logits (--collective gather: onto
+rank 0 only, nn.DataParallel's semantics; --gather masks: uint8 argmax masks instead), issued asynchronously on RCCL's
+stream over a ring of three buffers, so it overlaps the next step.  Rank 0 prints ONE JSON line.
+
+W warm-up steps, then `--repeats` (default 5) timed regions of EXACTLY K steps each, every region bracketed by a barrier
++ torch.cuda.synchronize() on both sides, MAX over ranks per region; `value` uses the MEDIAN region (all are listed).
 
 Extra objects on the line:
-  roofline      the dominant decoder kernel (hs_patch_ir_fwd at level 4): algorithmic FLOPs (and bytes) per
-                launch / its average duration measured with HIP events on the launch stream over `steps`
-                instrumented eager steps run right after the timed region (a graph replay cannot host events).
-  cpu_baseline  the CPU oracle ("port": stock encoder on CPU + oracle/hyperseg_oracle.py decoder) timed on the
-                host cores of this box on a bounded sample of the same workload (N=1, rank 0 only).
+  roofline      the dominant decoder kernel: algorithmic FLOPs or bytes per launch / its average duration measured with
+                HIP events on the launch stream over instrumented eager passes right after the timed regions (a graph
+                replay cannot host events).  `traffic` is null unless --traffic-dir names rocprofv3 --pmc FETCH_SIZE /
+                WRITE_SIZE passes of THIS command made in the same session (tools/gpu_round.sh does that).
+  parity        the replayed output of the benched configuration vs the eager STOCK-encoder model on the same batch
+                (outside the timed regions): max tensor-relative error, argmax flips where the stock margin > 1e-4.
+  fps_reference_protocol  hyperseg/test_fps.py's protocol (per iteration sync -> H2D of a pinned batch -> eager forward ->
+                sync; hyperseg_amd/fps.py) on the same model, N = 1 only.
+  cpu_baseline  the CPU oracle ("port": stock encoder on CPU + oracle/cpu_port.py decoder) timed on the host cores of
+                this box on a bounded sample of the same workload (N = 1, rank 0, --model m only).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -34,41 +46,239 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy peak 6290
 FP32_PEAK_TFLOPS = 157.3       # f32 vector == f32-input MFMA dense peak
-MODEL = 'hyperseg-m'
+MODELS = {'m': 'hyperseg-m', 's': 'hyperseg-s', 'sc': 'hyperseg-s-camvid', 'l': 'hyperseg-l'}
+LABELS = {'m': 'HyperSeg-M / EfficientNet-B1 / 1024x512', 's': 'HyperSeg-S / EfficientNet-B1 / 1536x768',
+          'sc': 'HyperSeg-S / EfficientNet-B1 / CamVid 768x576', 'l': 'HyperSeg-L / EfficientNet-B3 / 512x512'}
 
 
-def decoder_algorithmic(model, h, w, batch=1):
-    """Algorithmic HBM bytes and FLOPs of the decoder per frame (definition: SURVEY.md section 8d):
-    skips read once, each level output written once and read once at its own resolution, banks read
-    once, final logits written once; intermediates 0 B.  Returns (total_bytes, per_level list)."""
+# --------------------------------------------------------------------------------------------- the timed loop
+class StepLoop:
+    """One rank's step / drain / fence triple.  ``forward()`` produces the rank's output tensor (a graph replay returns
+    the captured static output); ``comm`` is a hyperseg_amd.distributed.LogitsGatherer or None."""
+
+    def __init__(self, forward, comm=None, to_payload=None, world=1, device=None):
+        self.forward, self.comm, self.world = forward, comm, world
+        self.to_payload = to_payload or (lambda y: y)
+        self.device = device
+        self.last = None              # the most recent collected (step, tensor) pair, for checks outside the timing
+        self.cuda = device is not None and device.type == 'cuda'
+
+    def step(self, i):
+        y = self.forward()
+        if self.comm is not None:
+            done = self.comm.submit(i, self.to_payload(y))
+            if done is not None:
+                self.last = done
+        return y
+
+    def drain(self):
+        if self.comm is not None:
+            for done in self.comm.drain():
+                self.last = done
+
+    def fence(self):
+        if self.cuda:
+            torch.cuda.synchronize(self.device)
+        if self.world > 1:
+            dist.barrier()
+            if self.cuda:
+                torch.cuda.synchronize(self.device)
+
+
+def run_timed(loop, steps, warmup, repeats=1):
+    """W untimed steps, then ``repeats`` regions of exactly ``steps`` steps; returns the per-region wall time, MAX over
+    ranks.  Step indices keep increasing across regions (the gatherer's ring is indexed by them)."""
+    i = 0
+    for _ in range(warmup):
+        loop.step(i)
+        i += 1
+    loop.drain()
+    times = []
+    for _ in range(repeats):
+        loop.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loop.step(i)
+            i += 1
+        loop.drain()
+        loop.fence()
+        elapsed = time.perf_counter() - t0
+        if loop.world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=loop.device if loop.cuda else None)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        times.append(elapsed)
+    return times
+
+
+# --------------------------------------------------------------------------------------------- decoder accounting
+def decoder_levels(model, h, w, batch):
+    """Algorithmic HBM bytes and MACs of every decoder level (definition: SURVEY.md section 8d): skips read once, each
+    level output written once and read once at its own resolution, banks read once, intermediates 0 B."""
     dec = model.decoder
     fh, fw = h // 32, w // 32
     p = batch * fh * fw
     feat = [3] + model.backbone.feat_channels[:-1]
-    levels, total = [], 0
-    prev_c = 0
+    levels, prev_c = [], 0
     for l in range(dec.levels):
-        blk = getattr(dec, f'level_{l}')[0]
-        blk = blk[0] if hasattr(blk, '__getitem__') else blk
+        blk = getattr(dec, f'level_{l}', None)
+        if blk is None:
+            blk = dec.level_blocks[l]                       # unify variant
+        blk = blk[0]
+        first = blk[0] if isinstance(blk, torch.nn.Sequential) else blk
         stride = 32 >> l
         hl, wl = h // stride, w // stride
         skip_c = feat[::-1][l]
-        if hasattr(blk, 'hidden_dim'):
-            cin, cout, hid = blk.in_nc, blk.out_nc, blk.hidden_dim
-            ph, pw = hl // fh, wl // fw
-            macs = p * ((ph + 2) * (pw + 2) * cin * hid + ph * pw * (9 * hid + hid * cout))
+        hid = getattr(first, 'hidden_dim', 0)
+        if not hid and hasattr(first, 'conv'):              # v0_1 inverted residual: three blocks
+            c1, c3 = first.conv[0][0], first.conv[-1][0]
+            cin, hid, cout = c1.in_channels, c1.out_channels, c3.out_channels
+        elif hid:
+            cin, cout = first.in_nc, first.out_nc
         else:
-            cin, cout, hid = blk.in_channels, blk.out_channels, 0
+            cin, cout = first.in_channels, first.out_channels
+        if hid:
+            ph, pw = hl // fh, wl // fw
+            halo = (ph + 2) * (pw + 2) if hasattr(first, 'hidden_dim') else ph * pw     # Op C runs pw1 on the halo tile
+            macs = p * (halo * cin * hid + ph * pw * (9 * hid + hid * cout))
+            hp = cin * hid + 9 * hid + hid * cout
+        else:
             macs = batch * hl * wl * cin * cout
-        in_b = 4 * batch * (skip_c * hl * wl + prev_c * (hl // 2) * (wl // 2))
-        bank_b = 4 * p * int(blk.hyper_params)
-        out_b = 4 * batch * cout * hl * wl
-        levels.append(dict(level=l, cin=cin, cout=cout, hidden=hid, macs=macs, in_bytes=in_b, bank_bytes=bank_b,
-                           out_bytes=out_b))
-        total += in_b + bank_b + out_b
+            hp = cin * cout
+        levels.append(dict(level=l, cin=cin, cout=cout, hidden=hid, macs=macs,
+                           in_bytes=4 * batch * (skip_c * hl * wl + prev_c * (hl // 2) * (wl // 2)),
+                           bank_bytes=4 * p * hp, out_bytes=4 * batch * cout * hl * wl))
         prev_c = cout
-    total += 4 * batch * prev_c * ((h // 2) * (w // 2) + h * w)      # final upsample: read low-res, write full-res
+    total = sum(lv['in_bytes'] + lv['bank_bytes'] + lv['out_bytes'] for lv in levels)
+    if (32 >> (dec.levels - 1)) > 1:                       # v1_0 / unify stop at stride 2: final 2x upsample of the logits
+        total += 4 * batch * levels[-1]['cout'] * ((h // 2) * (w // 2) + h * w)
     return total, levels
+
+
+def instrumented_decoder(model, x, n_inst):
+    """Per-launch durations of the decoder's HIP launches: HIP events on the launch stream around every hyperseg_amd
+    functional entry point, n_inst eager decoder passes with the GPU parked so that the host enqueues a whole pass before
+    its first launch starts (device time, not host launch gaps).  Returns (launches, decoder_us, event_overhead_us)."""
+    import hyperseg_amd.functional as HF
+    names = ['signal2weights', 'signal2weights_multi', 'bank_pack', 'patch_conv', 'patch_ir', 'patch_ir_v0', 'upsample_bilinear']
+    orig = {n: getattr(HF, n) for n in names}
+    recs, counter = {}, [0]
+
+    def wrap(n):
+        def f(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig[n](*a, **k)
+            e1.record()
+            recs.setdefault((counter[0], n), []).append((e0, e1))
+            counter[0] += 1
+            return r
+        return f
+    feats = model.backbone(x)
+    try:
+        for n in names:
+            setattr(HF, n, wrap(n))
+        dec_evs = []
+        for _ in range(n_inst):
+            counter[0] = 0
+            head = model.weight_mapper(feats[-1])
+            head = head.contiguous() if isinstance(head, torch.Tensor) else head
+            pyr = [t.contiguous() for t in [x] + feats[:-1]]
+            d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda._sleep(1_000_000)
+            first = counter[0]
+            d0.record()
+            model.decoder(pyr, head)
+            d1.record()
+            dec_evs.append((d0, d1, first))
+        torch.cuda.synchronize()
+    finally:
+        for n in names:
+            setattr(HF, n, orig[n])
+    cal = []
+    for _ in range(50):                      # an empty event pair on a busy stream is not 0: calibrate and report it
+        torch.cuda._sleep(200_000)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); e1.record()
+        cal.append((e0, e1))
+    torch.cuda.synchronize()
+    cal = sorted(a.elapsed_time(b) * 1e3 for a, b in cal)
+    ev_overhead = cal[len(cal) // 2]
+    first_dec = dec_evs[0][2]
+    launches = []
+    for (i, n), evs in sorted(recs.items()):
+        ts = [a.elapsed_time(b) * 1e3 for a, b in evs]
+        avg = sum(ts) / len(ts)
+        launches.append(dict(idx=i, kernel='hs_' + n + '_fwd', in_decoder=i >= first_dec, avg_us=round(avg, 2),
+                             minus_event_overhead_us=round(max(avg - ev_overhead, 0.0), 2)))
+    dec_us = sum(a.elapsed_time(b) for a, b, _ in dec_evs) * 1e3 / len(dec_evs)
+    return launches, dec_us, ev_overhead
+
+
+def roofline_of(launches, levels, h, w, batch, traffic_dir):
+    """The dominant decoder launch against the roof that binds it."""
+    conv = [l for l in launches if l['kernel'] in ('hs_patch_conv_fwd', 'hs_patch_ir_fwd', 'hs_patch_ir_v0_fwd') and l['in_decoder']]
+    per = {}
+    # one launch per level when every level is fused (v1_0 / unify / fused v0_1); otherwise no per-level attribution
+    if len(conv) == len(levels):
+        for l, lv in zip(conv, levels):
+            per[l['idx']] = lv
+    dom = max([l for l in launches if l['in_decoder']], key=lambda l: l['avg_us'])
+    t_s = dom['avg_us'] * 1e-6
+    traffic = pmc_traffic(traffic_dir, dom['kernel'])
+    lv = per.get(dom['idx'])
+    if lv is not None and lv['hidden']:
+        flops = 2.0 * lv['macs']
+        kbytes = lv['in_bytes'] + lv['bank_bytes'] + lv['out_bytes']
+        t_fl, t_by = flops / (FP32_PEAK_TFLOPS * 1e12), kbytes / (HBM_PEAK_GBS * 1e9)
+        if t_fl >= t_by:
+            return {'bound': 'mfma', 'kernel': f"{dom['kernel']} (level {lv['level']}: {lv['cin']}->{lv['hidden']}->{lv['cout']} ch)",
+                    'achieved': round(flops / t_s / 1e12, 3), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(flops / t_s / 1e12 / FP32_PEAK_TFLOPS, 4), 'traffic': traffic,
+                    'avg_launch_us': dom['avg_us'], 'algorithmic_flops': flops, 'algorithmic_bytes': kbytes,
+                    'hbm_frac': round(kbytes / t_s / 1e9 / HBM_PEAK_GBS, 4),
+                    'note': 'fp32 math: f32 vector peak == f32-input MFMA dense peak (157.3 TF/s); the launch needs '
+                            f'{t_fl * 1e6:.1f} us at that peak and {t_by * 1e6:.1f} us at the 8 TB/s HBM peak'}
+    if lv is not None:
+        kbytes = lv['in_bytes'] + lv['bank_bytes'] + lv['out_bytes']
+    elif dom['kernel'] in ('hs_signal2weights_multi_fwd', 'hs_signal2weights_fwd'):
+        kbytes = sum(x['bank_bytes'] for x in levels)
+    elif dom['kernel'] == 'hs_upsample_bilinear_fwd':
+        kbytes = 4 * batch * levels[-1]['cout'] * ((h // 2) * (w // 2) + h * w)
+    else:
+        kbytes = 0
+    return {'bound': 'hbm', 'kernel': dom['kernel'], 'achieved': round(kbytes / t_s / 1e9, 1), 'peak': HBM_PEAK_GBS,
+            'unit': 'GB/s', 'frac': round(kbytes / t_s / 1e9 / HBM_PEAK_GBS, 4), 'traffic': traffic,
+            'avg_launch_us': dom['avg_us'], 'algorithmic_bytes': kbytes}
+
+
+def pmc_traffic(traffic_dir, kernel):
+    """HBM bytes per launch of the dominant kernel from rocprofv3 --pmc passes of THIS command made in the same session
+    (FETCH_SIZE and WRITE_SIZE in separate passes; KB units; FETCH_SIZE doubled: gfx950 tallies 128-B reads at 64 B --
+    MI355X_MICROARCH.md, HBM section).  None when no such passes were handed over: never a stored constant."""
+    if not traffic_dir:
+        return None
+    import csv
+    import glob
+    stem = {'hs_patch_ir_fwd': 'patch_ir_fused_kernel', 'hs_patch_ir_v0_fwd': 'patch_ir_fused_kernel',
+            'hs_patch_conv_fwd': 'patch_conv', 'hs_upsample_bilinear_fwd': 'upsample2x_kernel',
+            'hs_signal2weights_multi_fwd': 'signal2weights_kernel'}.get(kernel)
+    if stem is None:
+        return None
+    acc = {}
+    for f in glob.glob(os.path.join(traffic_dir, '**', '*counter_collection.csv'), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if stem in r['Kernel_Name'] and r['Counter_Name'] in ('FETCH_SIZE', 'WRITE_SIZE'):
+                a = acc.setdefault((r['Kernel_Name'], r['Counter_Name']), [0, 0.0])
+                a[0] += 1
+                a[1] += float(r['Counter_Value'])
+    best = None
+    for (kname, cname), (n, v) in acc.items():          # the instantiation with the most bytes = the dominant level
+        other = acc.get((kname, 'WRITE_SIZE' if cname == 'FETCH_SIZE' else 'FETCH_SIZE'))
+        if cname == 'FETCH_SIZE' and other:
+            tot = int((2 * v / n + other[1] / other[0]) * 1024)
+            best = tot if best is None else max(best, tot)
+    return best
 
 
 def cpu_baseline(model_cpu, size, budget_s=20.0):
@@ -112,23 +322,32 @@ def cpu_baseline(model_cpu, size, budget_s=20.0):
             'decoder_ms': round(1e3 * dec / n, 2), 'encoder_ms': round(1e3 * enc / n, 2)}
 
 
+# --------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--repeats', type=int, default=5, help='timed regions of --steps steps each; value = their median')
+    ap.add_argument('--model', default='m', choices=sorted(MODELS),
+                    help='m: HyperSeg-M 1024x512 bs1/GPU (default, the headline metric); s: HyperSeg-S 1536x768 bs1/GPU; '
+                         'sc: CamVid-S 768x576; l: HyperSeg-L 512x512, global batch 32 sharded over the GPUs')
     ap.add_argument('--output', default='logits', choices=['logits', 'masks'],
                     help="what a step produces: fp32 logits (the reference's forward, default) or uint8 argmax masks "
                          "taken inside the final upsample kernel (HyperGen.segment; test_fps.py:194's epilogue fused)")
-    ap.add_argument('--gather', default='logits', choices=['logits', 'masks', 'none'],
+    ap.add_argument('--gather', default='logits', choices=['logits', 'masks'],
                     help='what the N>1 collective moves (north star: logits)')
-    ap.add_argument('--collective', default='gather', choices=['gather', 'allgather'],
-                    help='N>1: gather onto rank 0 (nn.DataParallel semantics, default) or all_gather to every rank')
+    ap.add_argument('--collective', default='allgather', choices=['allgather', 'gather', 'none'],
+                    help="N>1: all_gather_into_tensor to every rank (default, the north star's collective), gather onto "
+                         "rank 0 (nn.DataParallel semantics), or none")
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of HIP graph replay')
     ap.add_argument('--stock-encoder', action='store_true',
                     help='leave the encoder entirely on stock PyTorch-ROCm/MIOpen (no fused depthwise HIP kernel)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the roofline / parity / protocol passes (timing only)')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
+    ap.add_argument('--traffic-dir', default=None,
+                    help='directory with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (same session)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -146,33 +365,34 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from hyperseg_amd import configs
-    from hyperseg_amd.utils.synthetic import fill_by_name
-    import hyperseg_amd.functional as HF
-
-# (the BLAS behind each bare GEMM is chosen per call in hyperseg_amd.utils.inference.gemm_library)
-    spec = configs.MODELS[MODEL]
-    h, w = spec['size']
+    from hyperseg_amd.distributed import LogitsGatherer, shard_batch
     from hyperseg_amd.utils.inference import prepare_for_inference
-    model = fill_by_name(configs.build(MODEL).eval(), seed=0)       # synthetic, non-denormal, same on every rank
-    cpu_model = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        import copy
-        cpu_model = copy.deepcopy(model)
-    # inference preparation of the encoder: depthwise conv + BN + swish of every MBConv block as one
-    # HIP launch (MIOpen's fp32 depthwise path costs half of the frame); everything else of the encoder is stock PyTorch
+    from hyperseg_amd.utils.synthetic import fill_by_name
+    import copy
+
+    cfg = MODELS[args.model]
+    spec = configs.MODELS[cfg]
+    h, w = spec['size']
+    if args.model == 'l':
+        lo, hi = shard_batch(spec['batch'], rank, world)        # strong scaling: the bs-32 batch split over the ranks
+        batch, global_batch, scaling = hi - lo, spec['batch'], 'strong'
+    else:
+        batch, global_batch, scaling = spec['batch'], spec['batch'] * world, 'weak'
+    model = fill_by_name(configs.build(cfg).eval(), seed=0)       # synthetic, non-denormal, same on every rank
+    stock = copy.deepcopy(model) if rank == 0 and not args.no_extras else None
     if not args.stock_encoder:
         prepare_for_inference(model, fold_bn=False, fused_depthwise=True)
     model = model.to(dev)
     torch.manual_seed(1234 + rank)
-    x = torch.rand(spec['batch'], 3, h, w, device=dev)              # resident synthetic frame
+    x = torch.rand(batch, 3, h, w, device=dev)                    # resident synthetic batch
     torch.set_grad_enabled(False)
 
-    # ---- build the step (HIP graph of the whole forward) -------------------------------------
+    # ---- the step: a HIP graph of the whole forward ---------------------------------------------------------------
+    forward = model.segment if args.output == 'masks' else model
+    if args.output == 'masks':
+        args.gather = 'masks'
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
-    forward = model.segment if args.output == 'masks' else model
-    if args.output == 'masks' and args.gather == 'logits':
-        args.gather = 'masks'
     with torch.cuda.stream(side):
         for _ in range(3):
             y = forward(x)
@@ -184,185 +404,92 @@ def main():
         with torch.cuda.graph(graph):
             y = forward(x)
 
-    comm = None
-    if world > 1 and args.gather != 'none':
-        from hyperseg_amd.distributed import LogitsGatherer
-        shape = tuple(y.shape) if args.gather == 'logits' else (y.shape[0],) + tuple(y.shape[-2:])
-        dtype = torch.float32 if args.gather == 'logits' else torch.uint8
-        comm = LogitsGatherer(world, shape, dtype, dev, mode=args.collective)
-
-    def step(i):
+    def run_forward():
         nonlocal y
         if graph is not None:
             graph.replay()
         else:
             y = forward(x)
-        if comm is not None:
-            # RCCL gather over xGMI on RCCL's own stream: overlaps the next frame's compute
-            comm.submit(i, y if (args.gather == 'logits' or y.dtype == torch.uint8) else y.argmax(1).to(torch.uint8))
+        return y
 
-    def drain():
-        if comm is not None:
-            comm.drain()
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(i)
-    drain()
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    drain()
-    fence()
-    elapsed = time.perf_counter() - t0
+    comm, to_payload = None, None
+    if world > 1 and args.collective != 'none':
+        shape = tuple(y.shape) if args.gather == 'logits' else (y.shape[0],) + tuple(y.shape[-2:])
+        dtype = torch.float32 if args.gather == 'logits' else torch.uint8
+        comm = LogitsGatherer(world, shape, dtype, dev, mode=args.collective)
+        if args.gather == 'masks':
+            to_payload = lambda t: t if t.dtype == torch.uint8 else t.argmax(1).to(torch.uint8)   # noqa: E731
+    loop = StepLoop(run_forward, comm, to_payload, world, dev)
+    times = run_timed(loop, args.steps, args.warmup, max(1, args.repeats))
+    med = statistics.median(times)
+    fps = args.steps * global_batch / med
+    rank_fps = torch.tensor([args.steps * batch / med], dtype=torch.float64, device=dev)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    frames = args.steps * spec['batch'] * world
-    fps = frames / elapsed
+        all_fps = [torch.zeros_like(rank_fps) for _ in range(world)]
+        dist.all_gather(all_fps, rank_fps)
+        per_rank = [round(float(t.item()), 1) for t in all_fps]
+    else:
+        per_rank = [round(float(rank_fps.item()), 1)]
 
-    # ---- instrumented eager pass: per-launch durations of the decoder kernels -----------------
     out = None
     if rank == 0:
-        names = ['signal2weights', 'signal2weights_multi', 'bank_pack', 'patch_conv', 'patch_ir', 'upsample_bilinear']
-        orig = {n: getattr(HF, n) for n in names}
-        recs, counter = {}, [0]
-
-        def wrap(n):
-            def f(*a, **k):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                r = orig[n](*a, **k)
-                e1.record()
-                recs.setdefault((counter[0], n), []).append((e0, e1))
-                counter[0] += 1
-                return r
-            return f
-        for n in names:
-            setattr(HF, n, wrap(n))
-        feats = model.backbone(x)
-        sig = model.weight_mapper(feats[-1]).contiguous()
-        pyr = [t.contiguous() for t in [x] + feats[:-1]]
-        d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n_inst = max(10, min(args.steps, 100))
-        dec_evs = []
-        for _ in range(n_inst):
-            counter[0] = 0
-            d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            # park the GPU for ~0.4 ms so that the host enqueues the whole decoder before the first launch starts:
-            # the events then bracket back-to-back kernels (device time) instead of host launch gaps
-            torch.cuda._sleep(1_000_000)
-            d0.record()
-            model.decoder(pyr, sig)
-            d1.record()
-            dec_evs.append((d0, d1))
-        torch.cuda.synchronize()
-        for n in names:
-            setattr(HF, n, orig[n])
-        # an empty event pair on a busy stream is not 0: calibrate that overhead and report both
-        cal = []
-        for _ in range(50):
-            torch.cuda._sleep(200_000)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); e1.record()
-            cal.append((e0, e1))
-        torch.cuda.synchronize()
-        cal = sorted(a.elapsed_time(b) * 1e3 for a, b in cal)
-        ev_overhead = cal[len(cal) // 2]
-        launches = []
-        for (i, n), evs in sorted(recs.items()):
-            ts = [a.elapsed_time(b) * 1e3 for a, b in evs]
-            avg = sum(ts) / len(ts)
-            # avg_us = raw event-pair time (conservative: includes the ~ev_overhead/2 of event bookkeeping on each side;
-            # rocprofv3's kernel duration lies between avg_us - ev_overhead and avg_us)
-            launches.append(dict(idx=i, kernel='hs_' + n + '_fwd', avg_us=round(avg, 2),
-                                 minus_event_overhead_us=round(max(avg - ev_overhead, 0.0), 2)))
-        dec_us = sum(a.elapsed_time(b) for a, b in dec_evs) * 1e3 / len(dec_evs)
-
-        alg_bytes, levels = decoder_algorithmic(model, h, w, spec['batch'])
-
-        def pmc_traffic(kernel_substr):
-            """HBM bytes per launch from the committed PMC passes (profiles/round1_pmc_hbm.json: separate rocprofv3 --pmc
-            FETCH_SIZE / WRITE_SIZE runs of tools/prof_decoder.py; KB units; gfx950 FETCH_SIZE x2 correction)."""
-            try:
-                doc = json.load(open(os.path.join(REPO, 'profiles', 'round1_pmc_hbm.json')))
-                for k, v in doc['kernels'].items():
-                    if kernel_substr in k:
-                        return int((2 * v['FETCH_SIZE_KB_avg_per_launch'] + v['WRITE_SIZE_KB_avg_per_launch']) * 1024)
-            except (OSError, KeyError, ValueError):
-                pass
-            return None
-        ir = [l for l in launches if l['kernel'] == 'hs_patch_ir_fwd']
-        dom = max(launches, key=lambda l: l['avg_us'])
-        lv4 = levels[-1]
-        if dom['kernel'] == 'hs_patch_ir_fwd' and dom is ir[-1]:
-            flops = 2.0 * lv4['macs']
-            kbytes = lv4['in_bytes'] + lv4['bank_bytes'] + lv4['out_bytes']
-            t_s = dom['avg_us'] * 1e-6
-            # the kernel's binding roof: fp32 FLOPs (8.0 us at peak) > HBM bytes (3.6 us at peak)
-            roof = {'bound': 'mfma', 'kernel': 'hs_patch_ir_fwd (level 4: 34->68->19 ch, 16x16 patches)',
-                    'achieved': round(flops / t_s / 1e12, 3), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(flops / t_s / 1e12 / FP32_PEAK_TFLOPS, 4),
-                    'traffic': pmc_traffic('patch_ir_mfma_kernel<34, 16, 19, 16>'),
-                    'avg_launch_us': dom['avg_us'], 'algorithmic_flops': flops, 'algorithmic_bytes': kbytes,
-                    'hbm_frac': round(kbytes / t_s / 1e9 / HBM_PEAK_GBS, 4),
-                    'note': 'fp32 math: f32 vector peak == f32-input MFMA dense peak (157.3 TF/s)'}
-        else:
-            # some other launch dominates: report it against the HBM roof with its own algorithmic bytes
-            per = {}
-            li = 0
-            for l in launches:
-                if l['kernel'] in ('hs_patch_conv_fwd', 'hs_patch_ir_fwd'):
-                    lv = levels[li]
-                    per[l['idx']] = lv['in_bytes'] + lv['bank_bytes'] + lv['out_bytes']
-                    li += 1
-            li = 0
-            for l in launches:
-                if l['kernel'] == 'hs_signal2weights_multi_fwd':
-                    per[l['idx']] = sum(lv['bank_bytes'] for lv in levels)
-                if l['kernel'] == 'hs_signal2weights_fwd':
-                    per[l['idx']] = levels[li]['bank_bytes']
-                    li += 1
-                if l['kernel'] == 'hs_upsample_bilinear_fwd':
-                    per[l['idx']] = 4 * levels[-1]['cout'] * ((h // 2) * (w // 2) + h * w)
-            kbytes = per.get(dom['idx'], 0)
-            t_s = dom['avg_us'] * 1e-6
-            roof = {'bound': 'hbm', 'kernel': dom['kernel'], 'achieved': round(kbytes / t_s / 1e9, 1),
-                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(kbytes / t_s / 1e9 / HBM_PEAK_GBS, 4),
-                    'traffic': None, 'avg_launch_us': dom['avg_us'], 'algorithmic_bytes': kbytes}
-
         out = {
-            'metric': 'frames/sec @ bs=1 HyperSeg-M 1024x512',
+            'metric': f'frames/sec @ bs={spec["batch"]} {LABELS[args.model].split(" / ")[0]} {w}x{h}',
             'value': round(fps, 2), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': round(1e3 * med / args.steps, 4), 'higher_is_better': True, 'scaling': scaling,
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'HyperSeg-M / EfficientNet-B1 / 1024x512 bs=1 per GPU, whole model forward '
+            'repeats': {'n': len(times), 'ms_per_step': [round(1e3 * t / args.steps, 4) for t in times], 'value_from': 'median'},
+            'config': {'workload': f'{LABELS[args.model]}, batch {batch} per GPU (global {global_batch}), whole model forward '
                                    '(encoder + context head as per "encoder", HIP decoder), resident input',
                        'encoder': 'stock PyTorch-ROCm / MIOpen' if args.stock_encoder else
                                   'hyperseg_amd.utils.inference.prepare_for_inference: MBConv blocks = hs_mbconv_expand_dw_fwd | '
                                   'library GEMM + hs_depthwise_conv_fwd, hs_se_gate_fwd, bare library GEMM; hs_stem_conv_fwd; '
                                   'context head = library GEMMs + hs_affine_act_fwd',
-                       'output': 'fp32 logits (B,19,512,1024)' if args.output == 'logits' else 'uint8 argmax masks (B,512,1024)',
+                       'output': f'fp32 logits {tuple(y.shape)}' if args.output == 'logits' else f'uint8 argmax masks {tuple(y.shape)}',
                        'launch': 'eager' if args.no_graph else 'hipGraph replay',
-                       'parallelism': f'batch-sharded x{world}' + (f', RCCL {args.collective} of {args.gather}'
-                                                                   if comm is not None else '')},
-            'roofline': roof,
-            'decoder': {'us_per_frame_eager': round(dec_us, 1), 'event_pair_overhead_us': round(ev_overhead, 2),
-                        'algorithmic_bytes': alg_bytes,
-                        'hbm_frac_of_8TBs': round(alg_bytes / (dec_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                        'launches': launches},
+                       'parallelism': f'batch-sharded x{world}' + (f', RCCL {args.collective} of {args.gather}' if comm is not None else '')},
+            'per_rank_frames_per_s': per_rank,
+            'collective': None if comm is None else {
+                'op': 'all_gather_into_tensor' if args.collective == 'allgather' else 'gather(dst=0)', 'payload': args.gather,
+                'bytes_sent_per_rank_per_step': comm.bytes_per_step,
+                'bytes_received_per_step': comm.bytes_per_step * world if (args.collective == 'allgather') else comm.bytes_per_step * world,
+                'completed': comm.completed},
         }
-        if cpu_model is not None:
-            out['cpu_baseline'] = cpu_baseline(cpu_model, (h, w), args.cpu_budget)
-        elif world == 1:
-            out['cpu_baseline'] = None
+        if not args.no_extras:
+            # ---- the benched configuration against the eager stock model, outside the timed regions -----------------
+            stock = stock.to(dev)
+            y_bench = run_forward()
+            torch.cuda.synchronize()
+            ys = stock(x)
+            if args.output == 'masks':
+                flips = int((y_bench.long() != ys.argmax(1)).sum())
+                out['parity'] = {'vs': 'eager stock-encoder model, same batch', 'mask_mismatches': flips, 'pixels': int(y_bench.numel())}
+            else:
+                err = float((y_bench.double() - ys.double()).abs().max() / ys.double().abs().max())
+                top2 = ys.topk(2, dim=1).values
+                clear = (top2[:, 0] - top2[:, 1]) > 1e-4
+                flips = int(((y_bench.argmax(1) != ys.argmax(1)) & clear).sum())
+                out['parity'] = {'vs': 'eager stock-encoder model, same batch', 'max_rel_err': err,
+                                 'argmax_flips': flips, 'pixels_with_margin_gt_1e-4': int(clear.sum()), 'pixels': int(clear.numel())}
+            del stock, ys
+            # ---- roofline of the dominant decoder launch -------------------------------------------------------------
+            launches, dec_us, ev_overhead = instrumented_decoder(model, x, max(10, min(args.steps, 50)))
+            alg_bytes, levels = decoder_levels(model, h, w, batch)
+            out['roofline'] = roofline_of(launches, levels, h, w, batch, args.traffic_dir)
+            out['decoder'] = {'us_per_batch_eager': round(dec_us, 1), 'event_pair_overhead_us': round(ev_overhead, 2),
+                              'algorithmic_bytes': alg_bytes,
+                              'hbm_frac_of_8TBs': round(alg_bytes / (dec_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                              'launches': launches}
+            if world == 1:
+                # ---- the reference harness' own protocol (sync + pinned H2D + eager forward per iteration) -------------
+                from hyperseg_amd.fps import measure_fps, synthetic_batches
+                uniq = synthetic_batches(4, batch, (h, w), spec['num_classes'], dev)
+                res = measure_fps(model, [uniq[i % 4] for i in range(max(8, 64 // batch))], dev, spec['num_classes'])
+                out['fps_reference_protocol'] = {'value': round(res['fps'], 1), 'unit': 'frames/s', 'frames': res['frames'],
+                                                 'protocol': 'test_fps.py:163-191: per iteration sync, pinned H2D, eager forward, sync'}
+                out['cpu_baseline'] = None
+                if args.model == 'm' and not args.no_cpu_baseline:
+                    out['cpu_baseline'] = cpu_baseline(fill_by_name(configs.build(cfg).eval(), seed=0), (h, w), args.cpu_budget)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -196,11 +196,6 @@ static int launch_ir(const IrArgs& a, int threads, size_t lds, long blocks, hipS
     return launch_status();
 }
 
-#ifdef HS_IR_USE_OLD
-int try_launch_ir_mfma(const StageIn& in, int fh, int fw, const float* bank, long ld, int cin, int c_skip, int hid,
-                       int c_out, const float* s1, const float* b1, const float* s2, const float* b2,
-                       const float* s3, const float* b3, float* y, hipStream_t stream);
-#endif
 int try_launch_ir_fused(int mode, const StageIn& in, int fh, int fw, const float* bank, long ld, int cin, int c_skip,
                         int hid, int c_out, const float* s1, const float* b1, const float* s2, const float* b2,
                         const float* s3, const float* b3, float* y, hipStream_t stream);   // hs_patch_ir_fused.hip
@@ -239,13 +234,8 @@ extern "C" int hs_patch_ir_fwd(const hs_stage_input* in, int32_t fh, int32_t fw,
     const bool fused_form = in->coords && a.in.prev_mode == HS_PREV_BILINEAR && !a.residual;
     if (fused_form) {
         // the decoder's own shapes run on the matrix cores; anything else falls through to the generic kernel
-#ifdef HS_IR_USE_OLD      /* round-2 A/B build only (tools/build_old_ir.sh): the round-1 kernel */
-        const int st_m = try_launch_ir_mfma(a.in, fh, fw, bank, (long)ld, a.cin, in->c_skip, hidden, c_out,
-                                            a.s1, a.b1, a.s2, a.b2, a.s3, a.b3, y, s);
-#else
         const int st_m = try_launch_ir_fused(0, a.in, fh, fw, bank, (long)ld, a.cin, in->c_skip, hidden, c_out,
                                              a.s1, a.b1, a.s2, a.b2, a.s3, a.b3, y, s);
-#endif
         if (st_m != 1) return st_m;
     }
 #define HS_IR_CASE(CI, CS, CO) \

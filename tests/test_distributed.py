@@ -76,3 +76,64 @@ def test_batch_sharded_gather_gloo(steps, mode):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(0, True, steps), (1, True, steps)]
+
+
+def _bench_worker(rank, world, port, q, mode):
+    """bench.py's own step / drain / fence loop (StepLoop + run_timed), driven with a CPU 'forward' over gloo."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import importlib.util
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        spec = importlib.util.spec_from_file_location('bench_under_test', os.path.join(root, 'bench.py'))
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+        shape = (2, 3, 4, 4)                                   # (frames per rank, classes, h, w)
+        calls = [0]
+
+        def forward():                                         # "logits" that encode (rank, call index)
+            calls[0] += 1
+            return torch.full(shape, float(100 * rank + calls[0]))
+        comm = LogitsGatherer(world, shape, torch.float32, torch.device('cpu'), mode=mode)
+        loop = bench.StepLoop(forward, comm, None, world, torch.device('cpu'))
+        steps, warmup, repeats = 4, 2, 3
+        times = bench.run_timed(loop, steps, warmup, repeats)
+        total = warmup + steps * repeats
+        ok = len(times) == repeats and all(t > 0 for t in times) and calls[0] == total and comm.completed == total
+        owner = mode == 'allgather' or rank == 0
+        step, out = loop.last                                  # the last collected step must be the last one issued
+        ok &= step == total - 1 and (out is not None) == owner
+        if owner:
+            want = torch.tensor([float(100 * r + total) for r in range(world)]).view(world, 1, 1, 1, 1)
+            ok &= bool(torch.equal(out, want.expand(world, *shape)))
+        # every rank reports the same (max-over-ranks) region times
+        t = torch.tensor(times, dtype=torch.float64)
+        ts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(ts, t)
+        ok &= all(bool(torch.equal(ts[0], u)) for u in ts)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('mode', ['allgather', 'gather'])
+def test_bench_step_loop_gloo(mode):
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]
+
+
+def test_shard_batch():
+    from hyperseg_amd.distributed import shard_batch
+    assert [shard_batch(32, r, 8) for r in range(8)] == [(4 * r, 4 * r + 4) for r in range(8)]
+    assert shard_batch(32, 0, 1) == (0, 32)
+    with pytest.raises(ValueError):
+        shard_batch(32, 0, 5)

@@ -146,9 +146,15 @@ def test_two_optimizer_steps_vs_reference(golden, dev):
             assert float(close.float().mean()) > 0.99, (k, float(close.float().mean()))
 
 
-def _train_compare(name, batch, size, dev, seed=3, tol=TOL):
+def rel_l2(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / b.norm().clamp(min=1e-30))
+
+
+def _train_compare(name, batch, size, dev, seed=3, grad_tol=TOL, grad_err=rel_err):
     """Train-mode forward + backward of a full BASELINE decoder through hyperseg_amd.autograd vs autograd of the oracle
-    (whose train-mode gradients are pinned to the reference's by the train_t_* fixtures)."""
+    (whose train-mode gradients are pinned to the reference's by the train_t_* fixtures).  Logits and BatchNorm running
+    statistics are held to TOL in the max norm; gradients to ``grad_tol`` under ``grad_err``."""
     from oracle import hyperseg_oracle as O
     from test_hip_parity import build_decoder
     plan = O.config_plan(name)
@@ -169,30 +175,41 @@ def _train_compare(name, batch, size, dev, seed=3, tol=TOL):
     yg = d(xg, sg)
     (yg * r.to(dev)).sum().backward()
     torch.cuda.synchronize()
-    errs = {'logits': rel_err(yg.detach().cpu(), yo.detach()), 'd signal': rel_err(sg.grad.cpu(), so.grad)}
+    exact = {'logits': rel_err(yg.detach().cpu(), yo.detach())}
+    grads = {'d signal': grad_err(sg.grad.cpu(), so.grad)}
     for i in range(1, len(x)):                      # the 5-level decoders never read the image itself
-        errs[f'd pyramid[{i}]'] = rel_err(xg[i].grad.cpu(), xo[i].grad)
+        grads[f'd pyramid[{i}]'] = grad_err(xg[i].grad.cpu(), xo[i].grad)
     named = dict(d.named_parameters())
     n_checked = 0
     for k, v in po.items():
         if v.requires_grad and v.grad is not None:
-            errs['d ' + k] = rel_err(named[k].grad.cpu(), v.grad)
+            grads['d ' + k] = grad_err(named[k].grad.cpu(), v.grad)
             n_checked += 1
     sd = d.state_dict()
     for k, v in stats.items():
-        errs[k] = rel_err(sd[k].cpu(), v)
-    bad = {k: v for k, v in errs.items() if not v < tol}
-    assert not bad, 'tensor-relative errors above %g: %s\n(all: %s)' % (
-        tol, ', '.join(f'{k}={v:.2e}' for k, v in bad.items()), ', '.join(f'{k}={v:.1e}' for k, v in errs.items()))
+        exact[k] = rel_err(sd[k].cpu(), v)
+    bad = {k: v for k, v in exact.items() if not v < TOL}
+    bad.update({k: v for k, v in grads.items() if not v < grad_tol})
+    assert not bad, 'errors above tolerance (%g max-norm / %g gradients): %s\n(all: %s)' % (
+        TOL, grad_tol, ', '.join(f'{k}={v:.2e}' for k, v in bad.items()),
+        ', '.join(f'{k}={v:.1e}' for k, v in {**exact, **grads}.items()))
     assert n_checked == 23 if name in ('Sc', 'M') else n_checked > 0    # 5 signal2weights.weight + 18 BN affine tensors
-    return float(rel_err(yg.detach().cpu(), yo.detach()))
+    return exact, grads
 
 
 def test_config5_full_workload_fp32(dev):
     """BASELINE config 5 AT ITS WORKLOAD: the CamVid-S decoder on 576x576 crops, batch 2, train mode (train.py:118-136;
     configs/train/camvid_efficientnet_b1_hyperseg-s.py:27-38) -- forward, backward (dX, per-patch dW -> signal2weights.weight,
-    d signal, BN gamma/beta) and the updated BN running statistics, full size, against autograd of the oracle."""
-    _train_compare('Sc', 2, (576, 576), dev)
+    d signal, BN gamma/beta) and the updated BN running statistics, full size, against autograd of the oracle.
+
+    Tolerances.  Logits and running statistics: 1e-4 in the max norm (observed 5e-7).  Gradients: 2e-3 in the relative
+    L2 norm, because at this size the gradient of the decoder is not a continuous function of its inputs at fp32
+    resolution -- ~3e7 ReLU / ReLU6 units, some within one ulp of a kink.  Measured with tools/grad_conditioning.py on
+    the fp64 ORACLE ITSELF: perturbing inputs and parameters by one fp32 ulp (6e-8 relative) moves its gradients by
+    2e-4 .. 8e-4 in relative L2 and by up to 2e-2 in the max norm (a handful of flipped units), while the oracle's fp32
+    and fp64 runs agree to 4e-7 when no unit flips.  No fp32 implementation with a different summation order can be held
+    to 1e-4 max-norm here; the small-crop test below and the train_t_* fixtures keep that bar where it is attainable."""
+    _train_compare('Sc', 2, (576, 576), dev, grad_tol=2e-3, grad_err=rel_l2)
 
 
 def test_train_hyperseg_m_level_shapes(dev):

@@ -1,8 +1,6 @@
 """Dev-only variant builds of the HIP library for on-GPU A/B runs (selected with HS_HIP_LIB=<path>); the product build
 (python -m hyperseg_amd.build) contains none of this, and the product sources carry no dev hooks: the 'stamps' variant
 is made by patching a COPY of hs_patch_ir_fused.hip.
-    oldir     round-1 Op C kernel (hs_patch_ir_mfma.hip) behind hs_patch_ir_fwd
-    nointer   fused inverted-residual kernel with the pw1 / depthwise stages NOT interleaved (HS_IRF_INTERLEAVE=0)
     stamps    s_memtime stamps of wave 0 of every workgroup at the phase boundaries (tools/ir_phase_times.py reads them)
 """
 import os
@@ -55,8 +53,6 @@ def stamped_source():
 
 
 VARIANTS = {
-    'oldir': dict(flags=['-DHS_IR_USE_OLD'], extra=['hs_patch_ir_mfma.hip']),
-    'nointer': dict(flags=['-DHS_IRF_INTERLEAVE=0'], extra=[]),
     'stamps': dict(flags=[], extra=[], patch=True),
 }
 
