@@ -17,6 +17,30 @@ def per_level(value, n, name):
     return tuple(value)
 
 
+def plan_levels(feat_channels, level_channels, kernel_sizes, level_layers, expand_ratio, groups, num_classes,
+                with_out_fc):
+    """Channel bookkeeping of a v1_0-style decoder, separated from module construction: for every level (coarse -> fine)
+    the list of its layers as dicts ``{cin, cout, k, expand, groups}``.  Rules (hyperseg_v1_0.py:139-163): a level's first
+    layer sees everything carried up from the coarser level plus this level's skip feature plus two coordinate channels;
+    a level emits ``level_channels[l]`` (or its skip width) channels, except that the very last layer of the decoder emits
+    the class logits unless a separate output layer follows."""
+    skips = list(feat_channels)[::-1]
+    n = len(skips) if level_channels is None else len(level_channels)
+    plan, carried = [], 0
+    for lvl in range(n):
+        width = skips[lvl] if level_channels is None else level_channels[lvl]
+        carried += skips[lvl]
+        layers = []
+        for j in range(level_layers[lvl]):
+            last_of_decoder = lvl == n - 1 and j == level_layers[lvl] - 1
+            cout = num_classes if (last_of_decoder and not with_out_fc) else width
+            layers.append(dict(cin=carried + 2, cout=cout, k=kernel_sizes[lvl], expand=expand_ratio[lvl],
+                               groups=groups[lvl] if isinstance(groups, (list, tuple)) else groups))
+            carried = cout
+        plan.append(layers)
+    return plan, carried
+
+
 def coordinate_grid(h, w, device=None):
     """(1, 2, h, w): channel 0 = x in [-1, 1] over W, channel 1 = y over H, endpoints inclusive.  Same values as the
     reference's cached buffers; the HIP kernels regenerate them analytically."""

@@ -29,7 +29,7 @@ from torch.nn.modules.utils import _pair
 
 from .. import functional as HF
 from .. import autograd as HA
-from ._common import HyperGenBase, coordinate_grid, per_level, register_coordinate_buffers
+from ._common import HyperGenBase, coordinate_grid, per_level, plan_levels, register_coordinate_buffers
 from .layers.meta_conv import MetaConv2d, _apply_epilogue, _require_inference
 from .layers.meta_sequential import MetaSequential
 
@@ -405,62 +405,44 @@ class MultiScaleDecoder(nn.Module):
         expand_ratio = per_level(expand_ratio, n, 'expand_ratio')
         if isinstance(groups, (list, tuple)):
             per_level(groups, n, 'groups')
-        self.level_layers = level_layers
-        self.levels = n
-        self.layer_params = []
-        feat_channels = feat_channels[::-1]          # coarse -> fine
-        self.coords_cache = {}
+        self.level_layers, self.levels = level_layers, n
+        self.layer_params, self.coords_cache = [], {}
         self.weight_groups = weight_groups
 
-        prev_channels = 0
-        for level in range(self.levels):
-            curr_ngf = feat_channels[level]
-            curr_out_ngf = curr_ngf if level_channels is None else level_channels[level]
-            prev_channels += curr_ngf
-            curr_layers = []
-            k = kernel_sizes[level]
-            for layer in range(self.level_layers[level]):
-                if (not with_out_fc) and level == self.levels - 1 and layer == self.level_layers[level] - 1:
-                    curr_out_ngf = num_classes
-                if k > 1:
-                    curr_layers.append(HyperPatchInvertedResidual(
-                        prev_channels + 2, curr_out_ngf, k, expand_ratio=expand_ratio[level],
-                        norm_layer=norm_layer, act_layer=act_layer))
-                else:
-                    group = groups[level] if isinstance(groups, (list, tuple)) else groups
-                    curr_layers.append(make_hyper_patch_conv2d_block(prev_channels + 2, curr_out_ngf, k, groups=group))
-                prev_channels = curr_out_ngf
-            self.add_module(f'level_{level}', MetaSequential(*curr_layers))
-
+        # modules: one MetaSequential per level, named level_<l> (the state-dict keys reference checkpoints carry)
+        plan, carried = plan_levels(feat_channels, level_channels, kernel_sizes, level_layers, expand_ratio, groups,
+                                    num_classes, with_out_fc)
+        for lvl, layers in enumerate(plan):
+            self.add_module(f'level_{lvl}', MetaSequential(*[self._make_layer(spec, norm_layer, act_layer) for spec in layers]))
+        self.out_fc = None
         if with_out_fc:
-            out_fc_layers = [nn.Dropout2d(dropout, True)] if dropout is not None else []
-            out_fc_layers.append(
-                HyperPatchConv2d(prev_channels, num_classes, out_kernel_size, padding=out_kernel_size // 2))
-            self.out_fc = MetaSequential(*out_fc_layers)
-        else:
-            self.out_fc = None
+            tail = [] if dropout is None else [nn.Dropout2d(dropout, True)]
+            tail.append(HyperPatchConv2d(carried, num_classes, out_kernel_size, padding=out_kernel_size // 2))
+            self.out_fc = MetaSequential(*tail)
 
-        # per-level hyper-parameter bookkeeping
-        self.hyper_params = 0
-        self._ranges = [0]
-        self.param_groups = []
-        for level in range(self.levels):
-            lp = getattr(self, f'level_{level}').hyper_params
-            self.hyper_params += lp
-            self._ranges.append(self.hyper_params)
-            self.param_groups.append(lp)
-        if with_out_fc:
-            self.hyper_params += self.out_fc.hyper_params
+        # what the context head sizes itself from: hyper-parameters per top-level consumer, and their running offsets
+        self.param_groups = [getattr(self, f'level_{lvl}').hyper_params for lvl in range(n)]
+        if self.out_fc is not None:
             self.param_groups.append(self.out_fc.hyper_params)
-        self._ranges.append(self.hyper_params)
+        offsets = np.cumsum([0] + self.param_groups)
+        self._ranges = [int(v) for v in offsets[:n + 1]] + [int(offsets[-1])]
 
-        register_coordinate_buffers(self, coords_res, self.levels)      # checkpoint compatibility only
+        register_coordinate_buffers(self, coords_res, n)      # checkpoint compatibility only
 
-        hyper_params = get_hyper_params(self)
-        min_unit = max(weight_groups) if isinstance(weight_groups, (list, tuple)) else weight_groups
-        signal_features = divide_feature(signal_channels, hyper_params, min_unit=min_unit)
-        init_signal2weights(self, list(signal_features), weight_groups=weight_groups)
-        self.hyper_params = sum(hyper_params)
+        # every signal-fed module gets a share of the signal channels proportional to its parameter count, in units of
+        # the largest group count, and its own grouped 1x1 weight generator
+        per_module = get_hyper_params(self)
+        unit = max(weight_groups) if isinstance(weight_groups, (list, tuple)) else weight_groups
+        shares = divide_feature(signal_channels, per_module, min_unit=unit)
+        init_signal2weights(self, list(shares), weight_groups=weight_groups)
+        self.hyper_params = sum(per_module)
+
+    @staticmethod
+    def _make_layer(spec, norm_layer, act_layer):
+        if spec['k'] > 1:
+            return HyperPatchInvertedResidual(spec['cin'], spec['cout'], spec['k'], expand_ratio=spec['expand'],
+                                              norm_layer=norm_layer, act_layer=act_layer)
+        return make_hyper_patch_conv2d_block(spec['cin'], spec['cout'], spec['k'], groups=spec['groups'])
 
     def cache_image_coordinates(self, h, w):
         return coordinate_grid(h, w)
@@ -501,6 +483,13 @@ class MultiScaleDecoder(nn.Module):
             return self._forward_autograd(x, s)
         # every level's filter bank in ONE launch (the banks only depend on the signal)
         groups = self._hyper_modules()
+        if any(len(g) > 1 for g in groups):
+            # several signal-fed modules inside one level (level_layers > 1; no shipped config): the reference hands the
+            # k-th of them the signal slice that starts at the hyper-parameter count of its predecessors
+            # (meta_sequential.py:35), so their signal_index is relative to that slice -- take the per-module route,
+            # which slices exactly like that, instead of the single launch over the whole signal
+            assert not masks, 'masks=True needs the single-launch route'
+            return self._forward_autograd(x, s)
         flat = [m for g in groups for m in g]
         for m in flat:
             # the reference hands each module s[:, 0:hyper_params] (MetaSequential's clamped slice, Appendix D-2)

@@ -15,7 +15,9 @@ import torch.nn.functional as F
 
 from .. import autograd as HA
 from .. import functional as HF
-from ._common import HyperGenBase, coordinate_grid, per_level, register_coordinate_buffers
+import numpy as np
+
+from ._common import HyperGenBase, coordinate_grid, per_level, plan_levels, register_coordinate_buffers
 from .hyperseg_v1_0 import (HyperPatch, HyperPatchConv2d, HyperPatchInvertedResidual, HyperPatchNoPadding,  # noqa: F401
                             WeightMapper, _SignalToWeights, divide_feature, make_hyper_patch_conv2d_block,
                             next_multiply)
@@ -80,51 +82,27 @@ class MultiScaleDecoder(nn.Module):
         kernel_sizes = per_level(kernel_sizes, n, 'kernel_sizes')
         level_layers = per_level(level_layers, n, 'level_layers')
         expand_ratio = per_level(expand_ratio, n, 'expand_ratio')
-        self.level_layers = level_layers
-        self.levels = n
-        self.unify_level = unify_level
-        self.layer_params = []
-        feat_channels = feat_channels[::-1]
-        self.coords_cache = {}
+        self.level_layers, self.levels, self.unify_level = level_layers, n, unify_level
+        self.layer_params, self.coords_cache = [], {}
         self.weight_groups = weight_groups
-        self.level_blocks = nn.ModuleList()
-        self.weight_blocks = nn.ModuleList()
-        self._ranges = [0]
 
-        prev_channels = 0
-        for level in range(self.levels):
-            curr_ngf = feat_channels[level]
-            curr_out_ngf = curr_ngf if level_channels is None else level_channels[level]
-            prev_channels += curr_ngf
-            curr_layers = []
-            k = kernel_sizes[level]
-            for layer in range(self.level_layers[level]):
-                if (not with_out_fc) and level == self.levels - 1 and layer == self.level_layers[level] - 1:
-                    curr_out_ngf = num_classes
-                if k > 1:
-                    curr_layers.append(HyperPatchInvertedResidual(
-                        prev_channels + 2, curr_out_ngf, k, expand_ratio=expand_ratio[level],
-                        norm_layer=norm_layer, act_layer=act_layer))
-                else:
-                    group = groups[level] if isinstance(groups, (list, tuple)) else groups
-                    curr_layers.append(make_hyper_patch_conv2d_block(prev_channels + 2, curr_out_ngf, k, groups=group))
-                prev_channels = curr_out_ngf
-            self.level_blocks.append(MetaSequential(*curr_layers))
-            if level < (unify_level - 1):
-                self.weight_blocks.append(WeightLayer(self.level_blocks[-1].hyper_params))
-            else:
-                self._ranges.append(self._ranges[-1] + self.level_blocks[-1].hyper_params)
-                if level == self.levels - 1:
-                    total = sum(b.hyper_params for b in self.level_blocks[unify_level - 1:])
-                    self.weight_blocks.append(WeightLayer(total))
+        plan, carried = plan_levels(feat_channels, level_channels, kernel_sizes, level_layers, expand_ratio, groups,
+                                    num_classes, with_out_fc)
+        self.level_blocks = nn.ModuleList(MetaSequential(*[self._make_layer(spec, norm_layer, act_layer) for spec in layers])
+                                          for layers in plan)
+        # weight generators: one per level below the unification point, then ONE for all remaining levels together,
+        # whose output is cut into per-level channel ranges (self._ranges)
+        first_shared = unify_level - 1
+        shared = [b.hyper_params for b in self.level_blocks[first_shared:]]
+        self.weight_blocks = nn.ModuleList([WeightLayer(b.hyper_params) for b in self.level_blocks[:first_shared]]
+                                           + [WeightLayer(sum(shared))])
+        self._ranges = [int(v) for v in np.cumsum([0] + shared)]
 
+        self.out_fc = None
         if with_out_fc:
-            out_fc_layers = [nn.Dropout2d(dropout, True)] if dropout is not None else []
-            out_fc_layers.append(
-                HyperPatchConv2d(prev_channels, num_classes, out_kernel_size, padding=out_kernel_size // 2))
-            self.out_fc = MetaSequential(*out_fc_layers)
-        else:
-            self.out_fc = None
+            tail = [] if dropout is None else [nn.Dropout2d(dropout, True)]
+            tail.append(HyperPatchConv2d(carried, num_classes, out_kernel_size, padding=out_kernel_size // 2))
+            self.out_fc = MetaSequential(*tail)
 
         register_coordinate_buffers(self, coords_res, self.levels)      # checkpoint compatibility only
 
@@ -133,6 +111,13 @@ class MultiScaleDecoder(nn.Module):
         signal_features = divide_feature(signal_channels, self.param_groups, min_unit=min_unit)
         init_signal2weights(self, list(signal_features), weight_groups=weight_groups)
         self.hyper_params = sum(self.param_groups)
+
+    @staticmethod
+    def _make_layer(spec, norm_layer, act_layer):
+        if spec['k'] > 1:
+            return HyperPatchInvertedResidual(spec['cin'], spec['cout'], spec['k'], expand_ratio=spec['expand'],
+                                              norm_layer=norm_layer, act_layer=act_layer)
+        return make_hyper_patch_conv2d_block(spec['cin'], spec['cout'], spec['k'], groups=spec['groups'])
 
     def cache_image_coordinates(self, h, w):
         return coordinate_grid(h, w)
