@@ -27,7 +27,7 @@ def _round_up(n, m):
 def _device_of(a):
     if isinstance(a, torch.Tensor):
         return a.device
-    if isinstance(a, (StageInput, BankRef)):
+    if isinstance(a, (StageInput, BankRef, SignalRef)):
         return a.device
     return None
 
@@ -172,6 +172,37 @@ class BankRef:
         return 4
 
 
+# Levels whose patches are at most this many pixels generate their bank inside the consumer (hs_patch_conv_gen_fwd) instead
+# of reading one that hs_signal2weights_multi_fwd wrote.  OFF by default (0): measured on MI355X (profiles/round2_bank_in_
+# consumer_ab.txt) it removes 2 x 18.4 MB of HBM traffic per HyperSeg-M frame but each fused launch takes 21.8 us against
+# 8.8 us + its ~2 us share of the bank launch -- these levels are latency-, not bandwidth-bound, and the fused kernel
+# serialises weight / signal / input round trips that the two-launch route overlaps across its 512 workgroups.
+# Set HS_BANK_IN_CONSUMER_MAX_PIXELS=64 to switch it on.
+BANK_IN_CONSUMER_MAX_PIXELS = int(os.environ.get('HS_BANK_IN_CONSUMER_MAX_PIXELS', '0'))
+
+
+class SignalRef:
+    """Stands in for a filter bank that is NOT materialised: the signal plus the signal2weights layer that would produce
+    the bank (wsw_t, signal_index, signal_channels, groups, rows).  The consuming module hands both to
+    :func:`patch_conv_gen`, which generates the bank rows it needs in LDS."""
+
+    def __init__(self, signal, layer):
+        self.signal, self.layer = signal, layer
+        b, _, fh, fw = signal.shape
+        self.shape = torch.Size((b, layer['rows'], fh, fw))
+        self.requires_grad = False
+
+    @property
+    def device(self):
+        return self.signal.device
+
+    def __getitem__(self, idx):
+        return self            # MetaSequential's channel range of a level with one signal-fed module: the whole bank
+
+    def dim(self):
+        return 4
+
+
 @_on_operand_device
 def signal2weights_multi(signal, layers):
     """All signal2weights layers of a decoder in ONE launch.  ``layers``: list of dicts with wsw_t, signal_index,
@@ -263,6 +294,31 @@ def patch_conv(x, grid, bank, c_out, k=1, padding=0, padding_mode='reflect', gro
                                     padding, PAD_MODES[padding_mode], groups, C.byref(ep), y.data_ptr(),
                                     _hip.stream_ptr())
     _hip.check(st, 'hs_patch_conv_fwd')
+    return y
+
+
+@_on_operand_device
+def patch_conv_gen(x, sref, c_out, scale=None, shift=None, act=ACT_NONE):
+    """Op A with the bank generated inside the kernel from ``sref`` (a :class:`SignalRef`): signal2weights + k = 1 patch
+    conv + BN affine + activation, one launch, no bank in HBM.  Returns None when the shape is outside what the kernel
+    covers (the caller then materialises the bank)."""
+    stage = as_stage(x)
+    b, _, h, w = stage.shape
+    signal, sig_ptr, c_signal = _channel_view(sref.signal, 'signal')
+    fh, fw = signal.shape[-2:]
+    l = sref.layer
+    lay = _hip.S2wLayerC()
+    lay.signal_index, lay.signal_channels, lay.groups = l['signal_index'], l['signal_channels'], l['groups']
+    lay.wsw_t, lay.wc, lay.rows = _hip.dev_ptr(l['wsw_t'], 'wsw_t'), l['wsw_t'].shape[1], l['rows']
+    lay.bank, lay.ld = None, 0
+    st_in = stage.c_struct()
+    ep = _epilogue(scale, shift, act)
+    y = torch.empty(b, c_out, h, w, device=stage.device, dtype=torch.float32)
+    st = _hip.lib.hs_patch_conv_gen_fwd(C.byref(st_in), fh, fw, sig_ptr, c_signal, C.byref(lay), c_out, C.byref(ep),
+                                        y.data_ptr(), _hip.stream_ptr())
+    if st == -3:
+        return None
+    _hip.check(st, 'hs_patch_conv_gen_fwd')
     return y
 
 

@@ -125,6 +125,12 @@ class HyperPatchNoPadding(nn.Module, _SignalToWeights):
         if self.kernel_size != (1, 1) or self.stride != (1, 1) or self.dilation != (1, 1):
             raise NotImplementedError('HyperPatchNoPadding: only the k=1, stride 1 form the reference builds '
                                       '(padding == 0 <=> kernel_size == 1, hyperseg_v1_0.py:748-750)')
+        if isinstance(s, HF.SignalRef):
+            # the bank is generated inside the consumer; if the kernel does not cover the shape, materialise it after all
+            y = HF.patch_conv_gen(x, s, self.out_channels, scale, shift, act) if self.groups == 1 else None
+            if y is not None:
+                return y
+            s = HF.signal2weights_multi(s.signal, [s.layer])[0]
         if self._train_mode(x, s):
             xt = HA.materialize_stage(x) if isinstance(x, HF.StageInput) else x
             y = HA.patch_conv_train(xt, self._weights_train(s), self.out_channels, 1, 0, 'zeros', self.groups,
@@ -501,6 +507,35 @@ class MultiScaleDecoder(nn.Module):
                       if l < self.levels and all(not isinstance(m, HyperPatchInvertedResidual) for m in g)
                       and all(all(not isinstance(q, HyperPatchInvertedResidual) for q in groups[e]) for e in range(l)))
         layers = [m.s2w_layer(s.device) for m in flat]
+        # coarse k = 1 levels generate their bank inside the consumer: no bank in HBM for them
+        fh, fw = s.shape[-2:]
+        in_consumer = {}
+        for lvl, g in enumerate(groups[:self.levels]):
+            hl, wl = x[-lvl - 1].shape[-2:]
+            if len(g) == 1 and isinstance(g[0], HyperPatchNoPadding) and g[0].groups == 1 and \
+                    hl % fh == 0 and wl % fw == 0 and (hl // fh) * (wl // fw) <= HF.BANK_IN_CONSUMER_MAX_PIXELS and \
+                    g[0].signal_channels // g[0].signal2weights.groups <= 80:
+                in_consumer[id(g[0])] = HF.SignalRef(s, g[0].s2w_layer(s.device))
+        if in_consumer:
+            keep = [i for i, m in enumerate(flat) if id(m) not in in_consumer]
+            made = HF.signal2weights_multi(s, [layers[i] for i in keep]) if keep else []
+            refs = [in_consumer.get(id(m)) for m in flat]
+            for i, r in zip(keep, made):
+                refs[i] = r
+            banks, k = [], 0
+            for g in groups:
+                banks.append(refs[k:k + len(g)])
+                k += len(g)
+            p = None
+            for level in range(self.levels):
+                p = getattr(self, f'level_{level}')(HF.StageInput(x[-level - 1], p, coords=True), banks[level])
+            if self.out_fc is not None:
+                p = self.out_fc(p, banks[-1])
+            if masks:
+                return HF.upsample_argmax(p, x[0].shape[2:])
+            if p.shape[2:] != x[0].shape[2:]:
+                p = HF.upsample_bilinear(p, x[0].shape[2:])
+            return p
         side = join_level = None
         if 0 < n_early < len(flat) and s.is_cuda and HF.USE_SIDE_STREAM:
             main = torch.cuda.current_stream()

@@ -148,8 +148,23 @@ class MultiScaleDecoder(nn.Module):
             assert not masks, 'masks=True is an inference-only shortcut'
             return self._forward_autograd(x, s)
         wl = list(self.weight_blocks)
-        refs = HF.signal2weights_multi(s, [m.s2w_layer(s.device) for m in wl])      # every weight layer, one launch
         ul = self.unify_level
+        layers = [m.s2w_layer(s.device) for m in wl]
+        # coarse k = 1 levels with a weight layer of their own generate their bank inside the consumer; every other
+        # weight layer is produced by one launch
+        fh, fw = s.shape[-2:]
+        refs = [None] * len(wl)
+        for lvl in range(min(ul - 1, self.levels)):
+            mods = [m for m in self.level_blocks[lvl][0].children()] if len(self.level_blocks[lvl]) == 1 and \
+                isinstance(self.level_blocks[lvl][0], MetaSequential) else []
+            hl, wdt = x[-lvl - 1].shape[-2:]
+            if mods and isinstance(mods[0], HyperPatchNoPadding) and mods[0].groups == 1 and \
+                    hl % fh == 0 and wdt % fw == 0 and (hl // fh) * (wdt // fw) <= HF.BANK_IN_CONSUMER_MAX_PIXELS and \
+                    layers[lvl]['signal_channels'] // layers[lvl]['groups'] <= 80:
+                refs[lvl] = HF.SignalRef(s, layers[lvl])
+        keep = [i for i, r in enumerate(refs) if r is None]
+        for i, r in zip(keep, HF.signal2weights_multi(s, [layers[i] for i in keep])):
+            refs[i] = r
         p = None
         for level in range(self.levels):
             stage = HF.StageInput(x[-level - 1], p, coords=True)

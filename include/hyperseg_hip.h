@@ -76,6 +76,7 @@ const char* hs_build_info(void);
  *   bank[p*ld + n] = sum_k wsw_t[k*wc + n] * signal[b, signal_index + g(n)*cs_g + k, i, j],
  *   n < rows <= wc,  g(n) = n / (wc / groups).  Runs on the f32 matrix cores (v_mfma_f32_16x16x4_f32).
  * wsw_t is the Conv2d weight (wc, cs_g, 1, 1) TRANSPOSED to (cs_g, wc) (done once by the host). */
+typedef struct hs_s2w_layer hs_s2w_layer;
 int hs_signal2weights_fwd(const float* signal, int32_t batch, int32_t c_signal, int32_t fh, int32_t fw,
                           int32_t signal_index, int32_t signal_channels, int32_t groups,
                           const float* wsw_t, int32_t wc, int32_t rows,
@@ -83,14 +84,14 @@ int hs_signal2weights_fwd(const float* signal, int32_t batch, int32_t c_signal, 
 
 /* The same for up to 8 signal2weights layers (all levels of a decoder) in ONE launch: every layer reads its own
  * slice of the same signal and writes its own bank. */
-typedef struct {
+struct hs_s2w_layer {
     int32_t signal_index, signal_channels, groups;
     const float* wsw_t;        /* (signal_channels/groups, wc) */
     int32_t wc;
     int32_t rows;
     float* bank;
     int64_t ld;
-} hs_s2w_layer;
+};
 int hs_signal2weights_multi_fwd(const float* signal, int32_t batch, int32_t c_signal, int32_t fh, int32_t fw,
                                 const hs_s2w_layer* layers, int32_t n_layers, void* stream);
 
@@ -117,6 +118,15 @@ int hs_patch_conv_fwd(const hs_stage_input* in, int32_t fh, int32_t fw,
                       const float* bank, int64_t ld,
                       int32_t c_out, int32_t k, int32_t pad, int32_t pad_mode, int32_t groups,
                       const hs_epilogue* ep, float* y, void* stream);
+
+/* Op A with the bank generated inside the consumer: signal2weights (grouped 1x1 conv of the signal, hs_s2w_layer minus its
+ * bank / ld fields, which are ignored) + k = 1 dynamic patch convolution + BatchNorm affine + activation in ONE launch --
+ * HyperPatchNoPadding.forward and the norm / activation modules behind it (hyperseg_v1_0.py:473-498, 728-760; unify:
+ * WeightLayer hyperseg_v1_0_unify.py:287-309 + 483-494).  The filter bank is never written to HBM.  Conv groups == 1,
+ * patches of at most 64 pixels (the coarse levels, where the bank is the level's whole traffic); otherwise
+ * HS_ERR_UNSUPPORTED and the caller uses hs_signal2weights_*_fwd + hs_patch_conv_fwd. */
+int hs_patch_conv_gen_fwd(const hs_stage_input* in, int32_t fh, int32_t fw, const float* signal, int32_t c_signal,
+                          const hs_s2w_layer* layer, int32_t c_out, const hs_epilogue* ep, float* y, void* stream);
 
 /* Op C: fused per-patch inverted residual of hyperseg_v1_0.py:328-376 (and its unify twin
  * hyperseg_v1_0_unify.py:330-389): reflect halo tile -> pw1 -> BN1 -> ReLU6 -> dw3x3 ->

@@ -67,4 +67,6 @@ def test_loaded_model_reproduces_the_logits(tmp_path):
     model = load_model(path, 'hyperseg-m', device=dev)
     x = torch.rand(1, 3, 256, 512, device=dev)
     with torch.no_grad():
-        assert torch.equal(model(x), src.to(dev)(x))
+        a, b = model(x), src.to(dev)(x)
+    # same weights, same kernels; MIOpen may still pick different convolution algorithms for the two instances
+    assert float((a - b).abs().max() / b.abs().max()) < 1e-5

@@ -456,3 +456,69 @@ def test_full_config_l_bs32_properties(O, dev):
     ref = O.decoder_v0_1(O.config_plan('L'), O.synth_decoder_params(O.config_plan('L'), seed=0),
                          [t[5:6].cpu() for t in x], [t[5:6].cpu() for t in w])
     cmp(y[5:6], ref, what='L bs32 frame 5 vs oracle')
+
+
+# ------------------------------------------------------------------------------ bank generated inside the consumer
+GEN_CASES = [
+    # skip, prev, cout, patch, grid, batch, signal channels, groups  (rows padded to a multiple of groups like the reference)
+    dict(skip=80, prev=0, cout=64, patch=1, grid=(4, 8), batch=1, cs=416, groups=32),      # HyperSeg-M level 0: 2 channels / group
+    dict(skip=28, prev=64, cout=32, patch=2, grid=(4, 8), batch=1, cs=224, groups=16),     # level 1, bilinear previous level
+    dict(skip=10, prev=32, cout=16, patch=4, grid=(4, 8), batch=1, cs=128, groups=8),      # level 2
+    dict(skip=10, prev=32, cout=16, patch=4, grid=(3, 5), batch=2, cs=256, groups=32),     # CamVid-S level 2: a channel spans
+                                                                                          # two groups; 30 patches (ragged tile)
+    dict(skip=128, prev=0, cout=32, patch=1, grid=(3, 4), batch=1, cs=576, groups=32),     # HyperSeg-S level 0: K = 18
+    dict(skip=5, prev=0, cout=7, patch=8, grid=(2, 2), batch=1, cs=24, groups=3),          # odd everything, 64-pixel patches
+]
+
+
+@pytest.mark.parametrize('case', GEN_CASES)
+def test_bank_in_consumer_vs_oracle(HF, O, dev, case):
+    """hs_patch_conv_gen_fwd (signal2weights + k=1 patch conv + BN + ReLU, the bank never in HBM) == the oracle's
+    signal2weights -> patch_conv_k1 -> bn -> relu, and == the two-launch HIP route."""
+    c = case
+    g = torch.Generator().manual_seed(3 + c['cs'])
+    fh, fw = c['grid']
+    h, w = fh * c['patch'], fw * c['patch']
+    cin = 2 + c['skip'] + c['prev']
+    hp = c['cout'] * cin
+    wc = -(-hp // c['groups']) * c['groups']
+    sidx = 8
+    s = torch.relu(torch.randn(c['batch'], sidx + c['cs'] + 5, fh, fw, generator=g))
+    wsw = torch.randn(wc, c['cs'] // c['groups'], 1, 1, generator=g) * (c['groups'] / c['cs']) ** 0.5
+    skip = torch.randn(c['batch'], c['skip'], h, w, generator=g)
+    prev = torch.randn(c['batch'], c['prev'], h // 2, w // 2, generator=g) if c['prev'] else None
+    bn = dict(weight=torch.rand(c['cout'], generator=g) + 0.5, bias=torch.randn(c['cout'], generator=g) * 0.1,
+              running_mean=torch.randn(c['cout'], generator=g) * 0.1, running_var=torch.rand(c['cout'], generator=g) + 0.5)
+    wt = O.signal2weights(s, wsw, sidx, c['cs'], c['groups'], hp)
+    ref = O.act(O.bn_eval(O.patch_conv_k1(O.stage_input(skip, prev), wt, c['cout']), bn), O.ACT_RELU)
+    with torch.no_grad():
+        sd, stage = s.to(dev), HF.StageInput(skip.to(dev), prev.to(dev) if prev is not None else None, coords=True)
+        layer = dict(wsw_t=wsw.reshape(wc, -1).t().contiguous().to(dev), signal_index=sidx, signal_channels=c['cs'],
+                     groups=c['groups'], rows=hp)
+        scale, shift = HF.bn_fold(*(bn[k].to(dev) for k in ('weight', 'bias', 'running_mean', 'running_var')))
+        y = HF.patch_conv_gen(stage, HF.SignalRef(sd, layer), c['cout'], scale, shift, HF.ACT_RELU)
+        assert y is not None
+        cmp(y, ref, what=f'bank-in-consumer {c}')
+        bank = HF.signal2weights_multi(sd, [layer])[0].bank
+        y2 = HF.patch_conv(stage, (fh, fw), bank, c['cout'], 1, 0, 'zeros', 1, scale, shift, HF.ACT_RELU)
+        cmp(y, y2.cpu(), what='vs the two-launch route')
+
+
+def test_bank_in_consumer_is_what_the_decoder_runs(HF, O, dev, monkeypatch):
+    """With the (opt-in) fusion on, the HyperSeg-M decoder's levels 0-2 go through hs_patch_conv_gen_fwd and only levels
+    3-4 get a materialised bank; with it off (the default) the output is the same to rounding."""
+    d = build_decoder('M', O).to(dev)
+    x, s = O.synth_decoder_inputs('M', batch=1, seed=0, size=(128, 256))
+    x, s = [t.to(dev) for t in x], s.to(dev)
+    calls = {'gen': 0, 'layers': []}
+    gen, multi = HF.patch_conv_gen, HF.signal2weights_multi
+    monkeypatch.setattr(HF, 'patch_conv_gen', lambda *a, **k: (calls.__setitem__('gen', calls['gen'] + 1), gen(*a, **k))[1])
+    monkeypatch.setattr(HF, 'signal2weights_multi', lambda sig, layers: (calls['layers'].append(len(layers)), multi(sig, layers))[1])
+    monkeypatch.setattr(HF, 'BANK_IN_CONSUMER_MAX_PIXELS', 64)
+    with torch.no_grad():
+        y = d(x, s)
+        assert calls['gen'] == 3 and calls['layers'] == [2]
+        monkeypatch.setattr(HF, 'BANK_IN_CONSUMER_MAX_PIXELS', 0)
+        y0 = d(x, s)
+        assert calls['gen'] == 3 and calls['layers'] == [2, 5]
+    cmp(y, y0.cpu(), what='fused vs materialised banks')
