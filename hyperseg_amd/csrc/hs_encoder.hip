@@ -132,9 +132,12 @@ void depthwise_conv_kernel(const float* __restrict__ x, const float* __restrict_
 //       strip of 64 channels (4 waves each take a quarter of j), then w_scaled[b,o,c] = w_proj[o,c] * gate[b,c]
 //       (* out_scale[o]) for 64 rows of the strip: the gate (and optionally the project conv's BatchNorm scale) folded
 //       into the project weights -- scaling ~1e5 weights replaces an elementwise pass over the activation.
-// (Tried and rejected: both phases in one launch of <= 128 co-resident workgroups around a bounded device-scope barrier.
+// (Tried and rejected: (i) both phases in one launch of <= 128 co-resident workgroups around a bounded device-scope barrier.
 //  Bit-identical, but 9-19 us per call against 9.5-10.5 us for the two launches: the agent-scope fences and cross-XCD
-//  atomics cost more than the ~4.5 us launch they save -- 924 vs 979 frames/s, gpurun round r1i.)
+//  atomics cost more than the ~4.5 us launch they save -- 924 vs 979 frames/s, gpurun round r1i.  (ii) round 2: one launch
+//  in which every excite workgroup re-derives the squeezed vector for itself (no cross-workgroup traffic at all): 6.5-14 us
+//  for the narrow blocks, 30-170 us for the wide ones -- each workgroup then pulls the whole Csq x C reduce weight (up to
+//  221 KB) through dependent L2 round trips; 619 vs 1006 frames/s, gpurun round r2i.)
 // Replaces adaptive_avg_pool2d + 2 convs + swish + sigmoid + mul (hyperseg/models/backbones/efficientnet.py:106-111).
 // z[b, j] for one squeezed channel j: block-wide dot product over the flattened (channel, partial) index
 __device__ __forceinline__ void se_squeeze_body(int j, int b, const float* __restrict__ partial, int nblk, float inv_hw,
