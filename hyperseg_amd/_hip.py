@@ -70,6 +70,9 @@ def _load():
         'hs_stage_input_fwd': ([C.POINTER(StageInputC), vp, vp], C.c_int),
         'hs_patch_conv_bwd_input': ([vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp], C.c_int),
         'hs_patch_conv_bwd_weight': ([vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, vp], C.c_int),
+        'hs_patch_conv_plain_fwd': ([i32, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp], C.c_int),
+        'hs_patch_conv_plain_bwd_in': ([i32, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp], C.c_int),
+        'hs_patch_conv_plain_bwd_w': ([i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, vp], C.c_int),
         'hs_depthwise_conv_fwd': ([vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp], C.c_int),
         'hs_pointwise_conv_fwd': ([vp, i32, i32, i32, vp, i32, vp, vp, vp, i32, vp, vp, vp], C.c_int),
         'hs_affine_act_fwd': ([vp, i32, i32, i32, vp, vp, i32, vp, vp, vp], C.c_int),
@@ -91,7 +94,7 @@ lib = _load()
 EXPORTS = ['hs_version', 'hs_build_info', 'hs_signal2weights_fwd', 'hs_signal2weights_multi_fwd', 'hs_bank_pack_fwd', 'hs_bn_fold_fwd',
            'hs_patch_conv_fwd', 'hs_patch_conv_gen_fwd', 'hs_patch_ir_fwd', 'hs_patch_ir_v0_fwd', 'hs_ir_tile_map', 'hs_upsample_bilinear_fwd', 'hs_upsample_argmax_fwd',
            'hs_stage_input_fwd', 'hs_depthwise_conv_fwd', 'hs_depthwise_pool_blocks', 'hs_stem_conv_fwd', 'hs_mbconv_tiles', 'hs_mbconv_expand_dw_fwd', 'hs_se_gate_fwd', 'hs_pointwise_conv_fwd', 'hs_affine_act_fwd', 'hs_patch_conv_bwd_input',
-           'hs_patch_conv_bwd_weight']
+           'hs_patch_conv_bwd_weight', 'hs_patch_conv_plain_fwd', 'hs_patch_conv_plain_bwd_in', 'hs_patch_conv_plain_bwd_w']
 
 
 def check(status, what):

@@ -19,60 +19,101 @@ def needs_grad(*tensors):
     return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
 
 
+DTYPE_CODES = {torch.float32: 0, torch.bfloat16: 1}       # hs_dtype of include/hyperseg_hip.h
+
+
+def _plain_conv(kind, dtype, a, b, ld, shape, meta, out):
+    """One of the storage-typed training kernels (hs_patch_conv_plain_*): fp32, or bf16 storage + fp32 accumulation."""
+    (fh, fw), c_out, k, pad, mode, groups = meta
+    bsz, c_in, h, w = shape
+    fn = getattr(_hip.lib, 'hs_patch_conv_plain_' + kind)
+    code = DTYPE_CODES[dtype]
+    if kind == 'bwd_w':
+        st = fn(code, _hip.dev_ptr(a, 'x', dtype), _hip.dev_ptr(b, 'dy', dtype), bsz, c_in, h, w, fh, fw, c_out, k, pad,
+                HF.PAD_MODES[mode], groups, out.data_ptr(), ld, _hip.stream_ptr())
+    else:
+        st = fn(code, _hip.dev_ptr(a, 'x' if kind == 'fwd' else 'dy', dtype), b.data_ptr(), ld, bsz, c_in, h, w, fh, fw,
+                c_out, k, pad, HF.PAD_MODES[mode], groups, out.data_ptr(), _hip.stream_ptr())
+    _hip.check(st, 'hs_patch_conv_plain_' + kind)
+    return out
+
+
 class PatchConv(torch.autograd.Function):
-    """y = patch_conv(x, bank): Op A / Op B with plain tensors.  Saves x and the bank; backward launches
-    hs_patch_conv_bwd_input / hs_patch_conv_bwd_weight."""
+    """y = patch_conv(x, bank): Op A / Op B with plain tensors.  Saves x and the bank; backward launches the input- and
+    the per-patch weight-gradient kernels.  fp32 tensors take the fp32 kernels; under ``torch.autocast('cuda',
+    dtype=torch.bfloat16)`` (or with bf16 tensors) activations, bank and gradients are stored as bf16 and every sum is
+    accumulated in fp32 (hs_patch_conv_plain_*: BASELINE config 5)."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.bfloat16)
     def forward(ctx, x, bank, grid, c_out, k, padding, padding_mode, groups):
         x = x.contiguous()
+        if bank.dtype != x.dtype:
+            bank = bank.to(x.dtype)
         if bank.stride(1) != 1:
             bank = bank.contiguous()
-        y = HF.patch_conv(x, grid, bank, c_out, k, padding, padding_mode, groups)
+        meta = (tuple(grid), c_out, k, padding, padding_mode, groups)
+        if x.dtype == torch.float32:
+            y = HF.patch_conv(x, grid, bank, c_out, k, padding, padding_mode, groups)
+        else:
+            with torch.cuda.device(x.device):
+                y = _plain_conv('fwd', x.dtype, x, bank, bank.stride(0), x.shape, meta,
+                                torch.empty(x.shape[0], c_out, x.shape[2], x.shape[3], device=x.device, dtype=x.dtype))
         ctx.save_for_backward(x, bank)
-        ctx.meta = (tuple(grid), c_out, k, padding, padding_mode, groups)
+        ctx.meta = meta
         return y
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, dy):
         x, bank = ctx.saved_tensors
         (fh, fw), c_out, k, pad, mode, groups = ctx.meta
-        dy = dy.contiguous()
+        dy = dy.contiguous().to(x.dtype)
         b, c_in, h, w = x.shape
-        stream = _hip.stream_ptr()
         dx = dbank = None
-        bank_ptr, ld = HF._bank_ptr(bank)
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            st = _hip.lib.hs_patch_conv_bwd_input(_hip.dev_ptr(dy, 'dy'), bank_ptr, ld, b, c_in, h, w, fh, fw, c_out, k,
-                                                  pad, HF.PAD_MODES[mode], groups, dx.data_ptr(), stream)
-            _hip.check(st, 'hs_patch_conv_bwd_input')
-        if ctx.needs_input_grad[1]:
-            rows = c_out * (c_in // groups) * k * k
-            full = torch.zeros(bank.shape[0], bank.shape[1], device=x.device, dtype=torch.float32)
-            st = _hip.lib.hs_patch_conv_bwd_weight(_hip.dev_ptr(x, 'x'), _hip.dev_ptr(dy, 'dy'), b, c_in, h, w, fh, fw,
-                                                   c_out, k, pad, HF.PAD_MODES[mode], groups, full.data_ptr(),
-                                                   full.stride(0), stream)
-            _hip.check(st, 'hs_patch_conv_bwd_weight')
-            dbank = full
-            assert rows <= full.shape[1]
+        with torch.cuda.device(x.device):
+            stream = _hip.stream_ptr()
+            bank_ptr, ld = bank.data_ptr(), bank.stride(0)
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                if x.dtype == torch.float32:
+                    st = _hip.lib.hs_patch_conv_bwd_input(_hip.dev_ptr(dy, 'dy'), bank_ptr, ld, b, c_in, h, w, fh, fw, c_out,
+                                                          k, pad, HF.PAD_MODES[mode], groups, dx.data_ptr(), stream)
+                    _hip.check(st, 'hs_patch_conv_bwd_input')
+                else:
+                    _plain_conv('bwd_in', x.dtype, dy, bank, ld, x.shape, ctx.meta, dx)
+            if ctx.needs_input_grad[1]:
+                rows = c_out * (c_in // groups) * k * k
+                full = torch.zeros(bank.shape[0], bank.shape[1], device=x.device, dtype=x.dtype)
+                assert rows <= full.shape[1]
+                if x.dtype == torch.float32:
+                    st = _hip.lib.hs_patch_conv_bwd_weight(_hip.dev_ptr(x, 'x'), _hip.dev_ptr(dy, 'dy'), b, c_in, h, w, fh, fw,
+                                                           c_out, k, pad, HF.PAD_MODES[mode], groups, full.data_ptr(),
+                                                           full.stride(0), stream)
+                    _hip.check(st, 'hs_patch_conv_bwd_weight')
+                else:
+                    _plain_conv('bwd_w', x.dtype, x, dy, full.stride(0), x.shape, ctx.meta, full)
+                dbank = full
         return dx, dbank, None, None, None, None, None, None
 
 
 class BankPack(torch.autograd.Function):
-    """(B, hp_total, fh, fw) reference-layout weights -> patch-major bank (B*fh*fw, ld); backward is the transpose."""
+    """(B, hp_total, fh, fw) reference-layout weights -> patch-major bank (B*fh*fw, ld); backward is the transpose.
+    The re-layout itself runs in fp32 (a bf16 weight tensor produced under autocast is widened first; PatchConv narrows
+    the bank again), so it adds no rounding of its own."""
 
     @staticmethod
     def forward(ctx, w, rows):
         ctx.shape = tuple(w.shape)
         ctx.rows = rows
-        return HF.bank_pack(w, 0, rows)
+        ctx.dtype = w.dtype
+        return HF.bank_pack(w.float().contiguous() if w.dtype != torch.float32 else w, 0, rows)
 
     @staticmethod
     def backward(ctx, dbank):
         b, c, fh, fw = ctx.shape
-        dw = dbank.new_zeros(ctx.shape)
-        dw[:, :ctx.rows] = dbank[:, :ctx.rows].reshape(b, fh, fw, ctx.rows).permute(0, 3, 1, 2)
+        dw = dbank.new_zeros(ctx.shape, dtype=ctx.dtype)
+        dw[:, :ctx.rows] = dbank[:, :ctx.rows].reshape(b, fh, fw, ctx.rows).permute(0, 3, 1, 2).to(ctx.dtype)
         return dw, None
 
 

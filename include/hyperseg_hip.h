@@ -187,6 +187,22 @@ int hs_patch_conv_bwd_weight(const float* x, const float* dy, int32_t batch, int
                              int32_t fh, int32_t fw, int32_t c_out, int32_t k, int32_t pad, int32_t pad_mode,
                              int32_t groups, float* dbank, int64_t ld, void* stream);
 
+/* Training-path twins with a storage type: HS_DTYPE_F32, or HS_DTYPE_BF16 = bf16 storage (activations, banks, gradients
+ * read and written as bf16: half the HBM bytes) with fp32 accumulation (BASELINE config 5; the reference has no reduced-
+ * precision path: SURVEY 8d).  Plain (B, C, H, W) tensors, no fused prologue / epilogue -- the training route composes the
+ * stage input, BatchNorm and activations with stock differentiable ops (hyperseg_amd/autograd.py).  Same math as
+ * hs_patch_conv_fwd / hs_patch_conv_bwd_input / hs_patch_conv_bwd_weight above. */
+typedef enum { HS_DTYPE_F32 = 0, HS_DTYPE_BF16 = 1 } hs_dtype;
+int hs_patch_conv_plain_fwd(int32_t dtype, const void* x, const void* bank, int64_t ld, int32_t batch, int32_t c_in,
+                            int32_t H, int32_t W, int32_t fh, int32_t fw, int32_t c_out, int32_t k, int32_t pad,
+                            int32_t pad_mode, int32_t groups, void* y, void* stream);
+int hs_patch_conv_plain_bwd_in(int32_t dtype, const void* dy, const void* bank, int64_t ld, int32_t batch, int32_t c_in,
+                               int32_t H, int32_t W, int32_t fh, int32_t fw, int32_t c_out, int32_t k, int32_t pad,
+                               int32_t pad_mode, int32_t groups, void* dx, void* stream);
+int hs_patch_conv_plain_bwd_w(int32_t dtype, const void* x, const void* dy, int32_t batch, int32_t c_in, int32_t H, int32_t W,
+                              int32_t fh, int32_t fw, int32_t c_out, int32_t k, int32_t pad, int32_t pad_mode,
+                              int32_t groups, void* dbank, int64_t ld, void* stream);
+
 /* Encoder-side helper ("next" row of SURVEY.md section 8f; opt-in via hyperseg_amd.utils.inference): depthwise k x k
  * convolution (k in {3,5}, stride in {1,2}) with arbitrary top/left zero padding (TF-"SAME"), + per-channel affine
  * (folded BatchNorm) + activation (hs_act, or 3 = swish) in one launch.  x (B,C,H,W), w (C,1,k,k) -> y (B,C,Ho,Wo).

@@ -1,0 +1,42 @@
+"""Time of one config-5 training step of the decoder (CamVid-S, 576x576 crops, bs 2: forward + loss + backward + Adam)
+through the HIP path, fp32 and bf16 autocast, plus the per-kernel picture under rocprofv3 if wrapped.
+    python tools/train_step_time.py [iters]"""
+import os
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from hyperseg_amd import configs
+from hyperseg_amd.training import BootstrappedCrossEntropyLoss
+from hyperseg_amd.utils.synthetic import fill_by_name
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+dev = torch.device('cuda:0')
+model = fill_by_name(configs.build('hyperseg-s-camvid'), seed=0).to(dev)
+x = torch.rand(2, 3, 576, 576, device=dev)
+with torch.no_grad():
+    model.eval()
+    feats = model.backbone(x)
+    s = model.weight_mapper(feats[-1]).contiguous()
+    pyr = [t.contiguous() for t in [x] + feats[:-1]]
+dec = model.decoder.train()
+target = torch.randint(0, 12, (2, 576, 576), device=dev)
+crit = BootstrappedCrossEntropyLoss(k=4096, thresh=0.3, ignore_index=255)
+opt = torch.optim.Adam(dec.parameters(), lr=1e-3, betas=(0.5, 0.999))
+for mode in ('fp32', 'bf16'):
+    def step():
+        opt.zero_grad()
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=(mode == 'bf16')):
+            pred = dec(pyr, s)
+        loss = crit(pred.float(), target)
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        loss = step()
+    torch.cuda.synchronize()
+    print(f'config-5 decoder training step ({mode}): {(time.perf_counter() - t0) / iters * 1e3:.2f} ms/step, loss {float(loss):.4f}')
