@@ -89,7 +89,24 @@ void patch_ir_fused_kernel(IrFusedArgs a) {
     constexpr int DWW = REG * REG / 16;                    // 16 (a whole row) or 4 (half a row of an 8x8 region)
     constexpr int NRD = (DWW + 2 + 3) / 4;                 // 16-byte reads per halo row
     constexpr int NKD = (IN_UNI || DWW <= PWR) ? 1 : DWW / PWR;   // tap sets per thread (one per patch under its run)
+    constexpr int SEGS = REG / PWR;                        // patches per region edge
     constexpr int NA3 = IN_UNI ? 1 : J3;
+    // pw1 A fragments: ONE set when the region lies in one patch; with per-tile owners (Op D) a set per tile, all fetched
+    // a stage ahead when that fits the register budget, otherwise fetched one tile ahead inside the stage
+    constexpr bool A1_ALL = !P1_UNI && J1 * KS1 <= 32;
+    constexpr int NA1 = P1_UNI ? 1 : (A1_ALL ? J1 : 1);
+    // STAGE: the chunk's filter-bank operands go through LDS -- per chunk the workgroup copies W1[16 rows] (of its own patch
+    // and, for Op D, of the 8 patches around it), the 16 x 9 depthwise taps and W3[:, 16 columns] with COALESCED loads
+    // (4-8 per thread, double-buffered one chunk ahead) and every wave reads its fragments from there.  The direct form
+    // (each lane fetching its own fragment elements from the bank: ~26 scattered 4-byte loads per lane and chunk, ~400
+    // 16..64-byte requests per wave) was bound by the CU's address path: profiles/round2_ir_fused_phase_cycles_*.
+    // Kept for the Op D shapes whose regions span several patches (the 16 neighbour slots would not fit the LDS budget).
+    constexpr bool STAGE = P1_UNI || (MODE == 1 && SEGS == 1);
+    constexpr int NS1 = P1_UNI ? 1 : 9;                     // W1 slots: own patch | 3 x 3 patches around the region's patch
+    constexpr int SIN = P1_UNI ? 0 : 4;                     // slot of the patch the region lies in
+    constexpr int W1F = 16 * CIN, KDF = 144, W3S = 17, W3F = COUT * W3S;
+    constexpr int OPF = STAGE ? ((NS1 * W1F + KDF + W3F + 3) & ~3) : 0;     // floats per staged operand buffer
+    constexpr int NLW = (NS1 * W1F + IRF_THREADS - 1) / IRF_THREADS, NL3 = (COUT * 16 + IRF_THREADS - 1) / IRF_THREADS;
 
     const int hid = a.hid;
     const int HP = (hid + 15) & ~15;                  // hidden channels, padded to whole chunks
@@ -100,6 +117,7 @@ void patch_ir_fused_kernel(IrFusedArgs a) {
     // past hid (the tail of the last chunk) gets scale = shift = 0, i.e. h1 = h2 = relu6(0) = 0 whatever its (finite)
     // operand rows held -- which is why no operand load below needs a mask
     float* bnl = h2 + G::H2_FLOATS;
+    float* opsb = bnl + 4 * HP + 2 * CP;              // STAGE: [2][OPF] staged operands of the current / next chunk
     float* pl = lds;                                  // prologue only: [CPREV][PWIN*PWIN], aliases h1
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -144,6 +162,8 @@ void patch_ir_fused_kernel(IrFusedArgs a) {
     int hoff[J1];                 // LDS offset of this lane's position inside an h1 plane (DUMMY for a dead column)
     int pyx[J1];                  // image coordinates (yy << 16 | xx) of this lane's position, -1 for a dead column
     unsigned ob1[P1_UNI ? 1 : J1];   // bank offset of the patch that owns the tile
+    int s1[P1_UNI ? 1 : J1];         // STAGE: its W1 slot (3 x 3 patches around the region's patch, row-major)
+    const int i0 = y0 / a.ph, j0 = x0 / a.pw;       // the patch the region's first pixel lies in
     {
         const float* __restrict__ skb = a.in.skip + (size_t)b * CSKIP * plane;
         int spo[J1];              // element offset of channel (lk - 2) at this lane's position (lanes lk < 2 never use it)
@@ -159,11 +179,13 @@ void patch_ir_fused_kernel(IrFusedArgs a) {
             if constexpr (!P1_UNI) {
                 int u0, v0;
                 TM::halo(tile_ok ? t : 0, 0, u0, v0);
-                ob1[jt] = bank_of(pad_index(y0 + u0 - 1, H, HS_PAD_REFLECT), pad_index(x0 + v0 - 1, W, HS_PAD_REFLECT));
+                const int oy = pad_index(y0 + u0 - 1, H, HS_PAD_REFLECT), ox = pad_index(x0 + v0 - 1, W, HS_PAD_REFLECT);
+                ob1[jt] = bank_of(oy, ox);
+                s1[jt] = (oy / a.ph - i0 + 1) * 3 + (ox / a.pw - j0 + 1);
             }
             spo[jt] = yy * W + xx + (lk - 2) * (int)plane;
         }
-        if constexpr (P1_UNI) ob1[0] = bank_of(y0, x0);
+        if constexpr (P1_UNI) { ob1[0] = bank_of(y0, x0); s1[0] = 0; }
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
@@ -197,9 +219,9 @@ void patch_ir_fused_kernel(IrFusedArgs a) {
     for (int q = 0; q < 2; ++q) bnreg[q] = bn_val(min(tid + q * IRF_THREADS, nbp - 1));
 
     // ---- filter-bank operands: plain loads from the bank, issued one stage ahead of their use ----------------------
-    // pw1 A fragments  W1[h0 + lrow][4*ks + lk] of the tile's owner.  One set serves every tile when the region lies in one
-    // patch (Op C); with per-tile owners (Op D) this is tile 0's set, the others are fetched one tile ahead inside the stage
-    float afa[KS1];
+    // pw1 A fragments  W1[h0 + lrow][4*ks + lk] of the tile's owner (see NA1 above; in the rolling form afa[0] is tile 0's
+    // set of the next chunk)
+    float afa[NA1][KS1];
     float k9[NKD][9];                  // depthwise taps of the owner of this thread's output pixels
     float a3[NA3][MT3][4];             // pw3 A fragments  W3[16*m + lrow][h0 + 4*ks + lk]
     const int dw_hh = tid >> 4;
@@ -249,9 +271,57 @@ void patch_ir_fused_kernel(IrFusedArgs a) {
         }
     };
     const int nchunks = HP >> 4;
-    load_a1(0, ob1[0], afa);
-    load_kd(0);
-    load_a3(0, nchunks == 1);
+    // STAGE: coalesced copy of one chunk's operands, bank -> registers (ops_load) -> LDS buffer (ops_store)
+    const unsigned nw_1 = off_w3 + (unsigned)hid * COUT - 1;               // last float of a patch's bank
+    auto slot_ob = [&](int slot) {                                       // bank offset of W1 slot `slot`
+        if constexpr (P1_UNI) return ob1[0];
+        const int pi = min(max(i0 + slot / 3 - 1, 0), a.fh - 1), pj = min(max(j0 + slot % 3 - 1, 0), a.fw - 1);
+        return (unsigned)((b * a.fh + pi) * a.fw + pj) * (unsigned)a.ld;
+    };
+    float sw[STAGE ? NLW : 1], sk = 0.0f, s3[STAGE ? NL3 : 1];
+    auto ops_load = [&](int h0) {
+        const unsigned ob_in = slot_ob(SIN);
+#pragma unroll
+        for (int q = 0; q < NLW; ++q) {
+            const int e = min(tid + q * IRF_THREADS, NS1 * W1F - 1);
+            const int slot = e / W1F, r = e - slot * W1F;
+            sw[q] = bank[slot_ob(slot) + (unsigned)(h0 * CIN + r)];
+        }
+        sk = bank[ob_in + off_kd + (unsigned)(h0 * 9 + min(tid, KDF - 1))];
+#pragma unroll
+        for (int q = 0; q < NL3; ++q) {
+            const int e = min(tid + q * IRF_THREADS, COUT * 16 - 1);
+            s3[q] = bank[ob_in + min(off_w3 + (unsigned)((e >> 4) * hid + h0 + (e & 15)), nw_1)];
+        }
+    };
+    auto ops_store = [&](float* __restrict__ buf) {
+#pragma unroll
+        for (int q = 0; q < NLW; ++q) {
+            const int e = tid + q * IRF_THREADS;
+            if (e < NS1 * W1F) buf[e] = sw[q];
+        }
+        if (tid < KDF) buf[NS1 * W1F + tid] = sk;
+#pragma unroll
+        for (int q = 0; q < NL3; ++q) {
+            const int e = tid + q * IRF_THREADS;
+            if (e < COUT * 16) buf[NS1 * W1F + KDF + (e >> 4) * W3S + (e & 15)] = s3[q];
+        }
+    };
+    auto load_a1_stage = [&](int h0) {                // the sets a pw1 stage starts from
+        if constexpr (P1_UNI) load_a1(h0, ob1[0], afa[0]);
+        else if constexpr (A1_ALL) {
+#pragma unroll
+            for (int q = 0; q < J1; ++q) load_a1(h0, ob1[q], afa[q]);
+        } else {
+            load_a1(h0, ob1[0], afa[0]);
+        }
+    };
+    if constexpr (STAGE) ops_load(0);
+    else {
+        load_a1_stage(0);
+        load_kd(0);
+        load_a3(0, nchunks == 1);
+    }
     // every load of the prologue is in flight: now the LDS stores (they wait for the OLDEST loads only)
 #pragma unroll
     for (int q = 0; q < PQ; ++q) {
@@ -264,7 +334,8 @@ void patch_ir_fused_kernel(IrFusedArgs a) {
         if (e < nbp) bnl[e] = bnreg[q];
     }
     for (int e = tid + 2 * IRF_THREADS; e < nbp; e += IRF_THREADS) bnl[e] = bn_val(e);     // hid > 112: not a decoder shape
-    __syncthreads();                                   // window + BN rows are in LDS
+    if constexpr (STAGE) ops_store(opsb);
+    __syncthreads();                                   // window + BN rows (+ chunk 0's operands) are in LDS
 
     // (4) coordinates and the bilinear-resized previous level complete the B fragments
 #pragma unroll
@@ -311,21 +382,31 @@ void patch_ir_fused_kernel(IrFusedArgs a) {
     auto stage_pw1 = [&](int h0) {
         const float4 sc1 = *reinterpret_cast<const float4*>(bnl + h0 + 4 * lk);
         const float4 sh1 = *reinterpret_cast<const float4*>(bnl + HP + h0 + 4 * lk);
-        float at[2][KS1];                              // per-tile owners: this tile's / the next tile's fragments
-        if constexpr (!P1_UNI) {
+        const float* ob = opsb + ((h0 >> 4) & 1) * OPF;          // STAGE: this chunk's operand buffer
+        float at[2][KS1];                              // rolling form: fragments of tiles jt and jt+1
+        if constexpr (!STAGE && !P1_UNI && !A1_ALL) {
 #pragma unroll
-            for (int ks = 0; ks < KS1; ++ks) at[0][ks] = afa[ks];
+            for (int ks = 0; ks < KS1; ++ks) at[0][ks] = afa[0][ks];
+        }
+        if constexpr (STAGE && P1_UNI) {
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) afa[0][ks] = ob[o1 + 4 * ks];
         }
 #pragma unroll
         for (int jt = 0; jt < J1; ++jt) {
-            if constexpr (!P1_UNI) {
+            if constexpr (!STAGE && !P1_UNI && !A1_ALL) {
                 if (jt + 1 < J1) load_a1(h0, ob1[jt + 1], at[(jt + 1) & 1]);
             }
             if ((NT1 % 4 == 0) || jt < J1 - 1 || wave < NT1 - 4 * (J1 - 1)) {      // uniform: the last round may be short
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < KS1; ++ks)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(P1_UNI ? afa[ks] : at[jt & 1][ks], bf[jt][ks], acc, 0, 0, 0);
+                for (int ks = 0; ks < KS1; ++ks) {
+                    float av;
+                    if constexpr (P1_UNI) av = afa[0][ks];
+                    else if constexpr (STAGE) av = ob[s1[jt] * W1F + o1 + 4 * ks];
+                    else av = A1_ALL ? afa[jt][ks] : at[jt & 1][ks];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bf[jt][ks], acc, 0, 0, 0);
+                }
                 float* dst = h1 + (4 * lk) * G::H1P + hoff[jt];
                 dst[0] = relu6_(fmaf(acc[0], sc1.x, sh1.x));
                 dst[G::H1P] = relu6_(fmaf(acc[1], sc1.y, sh1.y));
@@ -333,10 +414,16 @@ void patch_ir_fused_kernel(IrFusedArgs a) {
                 dst[3 * G::H1P] = relu6_(fmaf(acc[3], sc1.w, sh1.w));
             }
         }
-        load_a1(h0 + 16 < HP ? h0 + 16 : h0, ob1[0], afa);
+        if constexpr (!STAGE) load_a1_stage(h0 + 16 < HP ? h0 + 16 : h0);
     };
     // depthwise 3x3 + bn2 + relu6 of one chunk: h1 -> h2; then the loads of the next chunk's taps
     auto stage_dw = [&](int h0) {
+        if constexpr (STAGE) {
+            if (h0 + 16 < HP) ops_load(h0 + 16);       // next chunk's operands: in flight during this stage
+            const float* kb = opsb + ((h0 >> 4) & 1) * OPF + NS1 * W1F + dw_hh * 9;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) k9[0][e] = kb[e];
+        }
         const float sc2 = bnl[2 * HP + h0 + dw_hh], sh2 = bnl[3 * HP + h0 + dw_hh];
         const float* hp = h1 + dw_hh * G::H1P + dw_u * G::RS + dw_c0;
         float o[DWW];
@@ -362,10 +449,21 @@ void patch_ir_fused_kernel(IrFusedArgs a) {
             *reinterpret_cast<float4*>(dst + 4 * q) =
                 make_float4(relu6_(fmaf(o[4 * q], sc2, sh2)), relu6_(fmaf(o[4 * q + 1], sc2, sh2)),
                             relu6_(fmaf(o[4 * q + 2], sc2, sh2)), relu6_(fmaf(o[4 * q + 3], sc2, sh2)));
-        load_kd(h0 + 16 < HP ? h0 + 16 : h0);
+        if constexpr (STAGE) {
+            if (h0 + 16 < HP) ops_store(opsb + (((h0 >> 4) + 1) & 1) * OPF);     // visible after the barrier that follows
+        } else {
+            load_kd(h0 + 16 < HP ? h0 + 16 : h0);
+        }
     };
     // pw3: acc3 += W3[:, chunk] . h2; then the loads of the next chunk's A fragments
     auto stage_pw3 = [&](int h0) {
+        if constexpr (STAGE) {
+            const float* wb = opsb + ((h0 >> 4) & 1) * OPF + NS1 * W1F + KDF + lk;
+#pragma unroll
+            for (int m = 0; m < MT3; ++m)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) a3[0][m][ks] = wb[min(m * 16 + lrow, COUT - 1) * W3S + 4 * ks];
+        }
         float bv[4][J3];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
@@ -381,8 +479,10 @@ void patch_ir_fused_kernel(IrFusedArgs a) {
                         acc3[m][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[IN_UNI ? 0 : jt][m][ks], bv[ks][jt], acc3[m][jt], 0, 0, 0);
             }
         }
-        const int hn = h0 + 16 < HP ? h0 + 16 : h0;
-        load_a3(hn, hn + 16 >= HP);
+        if constexpr (!STAGE) {
+            const int hn = h0 + 16 < HP ? h0 + 16 : h0;
+            load_a3(hn, hn + 16 >= HP);
+        }
     };
 
     // ---- chunk loop:  dw(c) | barrier | pw3(c), pw1(c+1) | barrier ---------------------------------------------------
@@ -422,7 +522,9 @@ static int launch_irf(IrFusedArgs& a, hipStream_t stream) {
     a.regs_y = a.in.H / REG; a.regs_x = a.in.W / REG;
     const size_t hp = ((size_t)a.hid + 15) & ~(size_t)15;
     const size_t bn_floats = 4 * hp + 2 * 16 * ((COUT + 15) / 16);
-    const size_t lds = ((size_t)G::H1_FLOATS + G::H2_FLOATS + bn_floats) * sizeof(float);
+    constexpr bool stage = MODE == 0 || REG == PWR;                            // as the kernel's STAGE
+    constexpr size_t opf = stage ? (((MODE == 0 ? 1 : 9) * 16 * CIN + 144 + COUT * 17 + 3) & ~3) : 0;
+    const size_t lds = ((size_t)G::H1_FLOATS + G::H2_FLOATS + bn_floats + 2 * opf) * sizeof(float);
     // operand rows past the last hidden channel / k past cin are read unmasked: they must stay inside the patch's bank
     if (16 * CIN + 4 > a.hid * (9 + COUT) || 144 > a.hid * COUT) return 1;
     if (lds > 160 * 1024) return HS_ERR_LDS;

@@ -4,13 +4,17 @@ is made by patching a COPY of hs_patch_ir_fused.hip.
     stamps    s_memtime stamps of wave 0 of every workgroup at the phase boundaries (tools/ir_phase_times.py reads them)
 """
 import os
+import re
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hyperseg_amd import build as B
 
 STAMP_DECL = '''
-__device__ long long hs_irf_stamps[2048 * 32];
-#define HS_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 2048) hs_irf_stamps[blockIdx.x * 32 + (k)] = __builtin_readcyclecounter(); } while (0)
+__device__ long long hs_irf_stamps[8192 * 32];
+#define HS_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) { hs_irf_stamps[blockIdx.x * 32 + (k)] = __builtin_readcyclecounter(); \
+    if ((k) == 0) { hs_irf_stamps[blockIdx.x * 32 + 31] = ((long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492); \
+                    hs_irf_stamps[blockIdx.x * 32 + 30] = __builtin_amdgcn_s_memrealtime(); } \
+    if ((k) == 24) hs_irf_stamps[blockIdx.x * 32 + 29] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 extern "C" int hs_debug_read_stamps(long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hs_irf_stamps), sizeof(long long) * n);
 }
@@ -31,8 +35,8 @@ def stamped_source():
         src = src.replace(anchor, code + anchor)
     after('namespace hs {\n', STAMP_DECL)
     after('    const int lrow = lane & 15, lk = lane >> 4;\n', '    HS_STAMP(0);\n')
-    before('    __syncthreads();                                   // window + BN rows are in LDS', '    HS_STAMP(1);\n')
-    after('    __syncthreads();                                   // window + BN rows are in LDS\n', '    HS_STAMP(2);\n')
+    before('    __syncthreads();                                   // window + BN rows', '    HS_STAMP(1);\n')
+    src = re.sub(r'(    __syncthreads\(\); +// window \+ BN rows[^\n]*\n)', r'\1    HS_STAMP(2);\n', src, count=1)
     before('    __syncthreads();                                   // the window is dead', '    HS_STAMP(3);\n')
     after('    stage_pw1(0);\n    __syncthreads();\n', '    HS_STAMP(4);\n')
     after('        stage_dw(h0);\n', '        HS_STAMP(5 + 4 * (h0 < 48 ? h0 / 16 : 3));\n')
@@ -52,8 +56,29 @@ def stamped_source():
     return path
 
 
+def patched_source(name, replacements):
+    src = open(os.path.join(B.CSRC, 'hs_patch_ir_fused.hip')).read()
+    for old, new in replacements:
+        assert src.count(old) == 1, old
+        src = src.replace(old, new)
+    os.makedirs(os.path.join(B.LIB_DIR, 'dev_src'), exist_ok=True)
+    path = os.path.join(B.LIB_DIR, 'dev_src', f'hs_patch_ir_fused_{name}.hip')
+    open(path, 'w').write(src)
+    return path
+
+
+STORE_LINE = '                for (int jt = 0; jt < J3; ++jt) yo[yoff[jt]] = fmaf(acc3[m][jt][r], sc, sh);'
+PATCHES = {
+    # dev experiments on the epilogue of the fused inverted-residual kernel (is HyperSeg-L level 5 store-bound?)
+    'nostore': [(STORE_LINE, '                for (int jt = 0; jt < J3; ++jt) if (o == 0 && jt == 0) yo[yoff[jt]] = fmaf(acc3[m][jt][r], sc, sh);'
+                             ' else asm volatile("" :: "v"(acc3[m][jt][r]));')],
+    'ntstore': [(STORE_LINE, '                for (int jt = 0; jt < J3; ++jt) __builtin_nontemporal_store(fmaf(acc3[m][jt][r], sc, sh), &yo[yoff[jt]]);')],
+}
+
 VARIANTS = {
     'stamps': dict(flags=[], extra=[], patch=True),
+    'nostore': dict(flags=[], extra=[], patch='nostore'),
+    'ntstore': dict(flags=[], extra=[], patch='ntstore'),
 }
 
 if __name__ == '__main__':
@@ -62,6 +87,7 @@ if __name__ == '__main__':
         path = os.path.join(B.LIB_DIR, f'libhyperseg_hip_{name}.so')
         sources = list(B.SOURCES) + v['extra']
         if v.get('patch'):
-            rel = os.path.relpath(stamped_source(), B.CSRC)
+            src_path = stamped_source() if v['patch'] is True else patched_source(v['patch'], PATCHES[v['patch']])
+            rel = os.path.relpath(src_path, B.CSRC)
             sources = [rel if s == 'hs_patch_ir_fused.hip' else s for s in sources]
         print(B.build(force=True, extra_flags=v['flags'], sources=sources, lib_path=path, obj_suffix='_' + name))
