@@ -1,0 +1,46 @@
+// Shared by the two fused inverted-residual kernels (hs_patch_ir_fused.hip: exact f32 matrix cores;
+// hs_patch_ir_split.hip: f16 split products on the f16 matrix cores): launch arguments and the LDS geometry of a region.
+#pragma once
+#include "hs_common.h"
+#include "hs_ir_tiles.h"
+
+namespace hs {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+struct IrFusedArgs {
+    StageIn in;
+    int fh, fw, ph, pw;
+    const float* __restrict__ bank;
+    long ld;
+    int hid;
+    const float* __restrict__ s1; const float* __restrict__ b1;
+    const float* __restrict__ s2; const float* __restrict__ b2;
+    const float* __restrict__ s3; const float* __restrict__ b3;
+    float* __restrict__ y;
+    int regs_y, regs_x;          // regions per image
+};
+
+constexpr int IRF_THREADS = 256;
+
+template <int REG> struct IrfGeom {
+    static constexpr int HW = REG + 2;
+    static constexpr int RS = (HW + 3) & ~3;                    // h1 row stride (floats): 16-byte aligned rows
+    // h1 plane per hidden channel, == 4 (mod 8) floats: the D-row groups of a half-wave then store to banks 16 apart.
+    // The plane's tail [HW*RS, H1P) is padding; its first float is the DUMMY slot dead columns store to.
+    static constexpr int H1P = ((HW * RS + 7) & ~7) + 4;
+    static constexpr int DUMMY = HW * RS;
+    static constexpr int PWIN = REG / 2 + 2;                    // low-res window edge of the previous level (exact 2x)
+    static constexpr int PPL = PWIN * PWIN;
+    static constexpr int RS2 = REG + 4;                         // h2 pixel-row stride
+    static constexpr int H2S = ((REG * RS2 + 31) & ~31) + 16;   // h2 plane: == 16 (mod 32) -> conflict-free B reads
+    static constexpr int H1_FLOATS = 16 * H1P;
+    static constexpr int H2_FLOATS = 16 * H2S;
+};
+
+__device__ __forceinline__ float relu6_(float v) { return fminf(fmaxf(v, 0.0f), 6.0f); }
+
+// hs_patch_ir_split.hip; returns 1 when it has no instantiation for the shape (or the math mode asks for exact f32)
+int try_launch_ir_split(int mode, IrFusedArgs& a, int cin, int c_skip, int c_out, hipStream_t stream);
+
+}  // namespace hs

@@ -31,44 +31,9 @@
 // zero BN scale/shift instead), 32-bit offsets from uniform bases, filter-bank operands loaded one stage ahead straight
 // from the bank in HBM/L2 (nothing of the bank is staged in LDS), every prologue load in flight before the first wait.
 // Hidden activations never leave the CU.
-#include "hs_common.h"
-#include "hs_ir_tiles.h"
+#include "hs_ir_common.h"
 
 namespace hs {
-
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-
-struct IrFusedArgs {
-    StageIn in;
-    int fh, fw, ph, pw;
-    const float* __restrict__ bank;
-    long ld;
-    int hid;
-    const float* __restrict__ s1; const float* __restrict__ b1;
-    const float* __restrict__ s2; const float* __restrict__ b2;
-    const float* __restrict__ s3; const float* __restrict__ b3;
-    float* __restrict__ y;
-    int regs_y, regs_x;          // regions per image
-};
-
-constexpr int IRF_THREADS = 256;
-
-template <int REG> struct IrfGeom {
-    static constexpr int HW = REG + 2;
-    static constexpr int RS = (HW + 3) & ~3;                    // h1 row stride (floats): 16-byte aligned rows
-    // h1 plane per hidden channel, == 4 (mod 8) floats: the D-row groups of a half-wave then store to banks 16 apart.
-    // The plane's tail [HW*RS, H1P) is padding; its first float is the DUMMY slot dead columns store to.
-    static constexpr int H1P = ((HW * RS + 7) & ~7) + 4;
-    static constexpr int DUMMY = HW * RS;
-    static constexpr int PWIN = REG / 2 + 2;                    // low-res window edge of the previous level (exact 2x)
-    static constexpr int PPL = PWIN * PWIN;
-    static constexpr int RS2 = REG + 4;                         // h2 pixel-row stride
-    static constexpr int H2S = ((REG * RS2 + 31) & ~31) + 16;   // h2 plane: == 16 (mod 32) -> conflict-free B reads
-    static constexpr int H1_FLOATS = 16 * H1P;
-    static constexpr int H2_FLOATS = 16 * H2S;
-};
-
-__device__ __forceinline__ float relu6_(float v) { return fminf(fmaxf(v, 0.0f), 6.0f); }
 
 template <int CIN, int CSKIP, int COUT, int REG, int MODE, int PWR>
 __global__ __launch_bounds__(IRF_THREADS, 2)
@@ -555,6 +520,10 @@ int try_launch_ir_fused(int mode, const StageIn& in, int fh, int fw, const float
         (size_t)(cin - 2 - c_skip) * in.Hp * in.Wp >= (1u << 30)) return 1;
     if (a.ph != a.pw) return 1;
     const int p = a.ph;
+    {   // the f16 split form first (unless the math mode asks for exact f32 or it has no instantiation)
+        const int e = try_launch_ir_split(mode, a, cin, c_skip, c_out, stream);
+        if (e != 1) return e;
+    }
 #define HS_IRF_CASE(CI, CS, CO, REG, MODE, PWR) \
     if (cin == CI && c_skip == CS && c_out == CO) return launch_irf<CI, CS, CO, REG, MODE, PWR>(a, stream);
     if (mode == 0) {

@@ -358,6 +358,23 @@ def patch_ir_v0(x, grid, bank, hidden, c_out, bn1, bn2, bn3):
     return y
 
 
+IR_MATH = {'auto': 0, 'f32': 1, 'split': 2}
+
+
+def set_ir_math(mode):
+    """Arithmetic of the fused inverted-residual levels: 'split' (f16 matrix cores on split operands, f32-class), 'f32'
+    (exact f32 matrix cores) or 'auto' (split where it is faster; the default) -- include/hyperseg_hip.h, hs_ir_math.
+    Returns the previous mode's name."""
+    prev = get_ir_math()
+    _hip.check(_hip.lib.hs_set_ir_math(IR_MATH[mode]), 'hs_set_ir_math')
+    return prev
+
+
+def get_ir_math():
+    code = _hip.lib.hs_get_ir_math()
+    return next(k for k, v in IR_MATH.items() if v == code)
+
+
 def ir_tile_map(reg, mode, pwr):
     """(n_pixel_tiles, array (n_tiles, 16, 3) of (u, v, live)) -- the fused inverted-residual kernel's tile map
     (host-side introspection, no GPU needed)."""

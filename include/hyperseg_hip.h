@@ -156,6 +156,23 @@ int hs_patch_ir_v0_fwd(const hs_stage_input* in, int32_t fh, int32_t fw,
                        const hs_epilogue* bn1, const hs_epilogue* bn2, const hs_epilogue* bn3,
                        float* y, void* stream);
 
+/* Arithmetic of the fused inverted-residual levels (hs_patch_ir_fwd / hs_patch_ir_v0_fwd at the instantiated shapes):
+ *   HS_IR_MATH_F32    v_mfma_f32_16x16x4_f32: bit-exact f32 fma chains.
+ *   HS_IR_MATH_SPLIT  f16 matrix cores on split operands: every f32 operand is scaled by a power of two and split into
+ *       two f16 pieces, a product is ah*bh + al*bh + ah*bl accumulated in f32 (csrc/hs_patch_ir_split.hip).  f32-class:
+ *       the measured error of a dot product is BELOW an f32 fmaf chain's (tools/ubench/f16_probe.hip: 1.3e-7 vs 2.2e-7 of
+ *       sum|a||b|).  The scales are taken from the data (per weight row, per 16-position input tile, a running exponent
+ *       per pw3 row), so any overall magnitude is carried; what is not is a dynamic range beyond ~2^18 INSIDE one
+ *       reduction (an input 2^20 above its tile's other channels meeting a weight 2^-20 of its row's maximum).
+ *   HS_IR_MATH_AUTO (default)  SPLIT for the shapes where it is the faster form (16x16-pixel regions of Op C: level 4 of
+ *       HyperSeg-M/S, 28.6 vs 32.5 us on MI355X), F32 for the others.
+ * Process-wide; the environment variable HS_IR_MATH=auto|f32|split sets the initial value.  The reference runs these
+ * layers as fp32 torch convolutions (which cuDNN may run in TF32 there); all modes are held to the same parity tolerance
+ * (tests/test_hip_parity.py). */
+typedef enum { HS_IR_MATH_AUTO = 0, HS_IR_MATH_F32 = 1, HS_IR_MATH_SPLIT = 2 } hs_ir_math;
+int hs_set_ir_math(int32_t mode);
+int hs_get_ir_math(void);
+
 /* Introspection for the tests (host only, no GPU): the matrix-core tile map of the fused inverted-residual kernel for a
  * region edge `reg` (8|16), mode (0 = Op C, 1 = Op D) and patch edge inside the region `pwr`.  out[(t*16+n)*3 + {0,1,2}]
  * = halo coordinates (u, v) and liveness of column n of pw1 tile t (csrc/hs_ir_tiles.h). */

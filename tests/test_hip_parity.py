@@ -38,6 +38,15 @@ def O():
     return hyperseg_oracle
 
 
+@pytest.fixture(params=['split', 'f32', 'auto'])
+def ir_math(request, HF):
+    """Both arithmetic modes of the fused inverted-residual kernels (include/hyperseg_hip.h, hs_ir_math): f16 split
+    products on the f16 matrix cores (the default) and exact f32 -- held to the SAME tolerances."""
+    prev = HF.set_ir_math(request.param)
+    yield request.param
+    HF.set_ir_math(prev)
+
+
 def load_bn(bn, p, prefix):
     with torch.no_grad():
         for k in ('weight', 'bias', 'running_mean', 'running_var'):
@@ -209,7 +218,7 @@ def test_hyper_patch_v1(golden, dev):
         cmp(blk(g['blk.x'].to(dev), g['blk.s'].to(dev)), g['blk.y'], what='hyper patch block, clamped signal slice')
 
 
-def test_inverted_residual_v1(golden, dev):
+def test_inverted_residual_v1(golden, dev, ir_math):
     from hyperseg_amd.models import hyperseg_v1_0 as M
     g = golden('inverted_residual_v1')
     with torch.no_grad():
@@ -224,7 +233,7 @@ def test_inverted_residual_v1(golden, dev):
             cmp(m(g[f'{i}.x'].to(dev), g[f'{i}.s'].to(dev)), g[f'{i}.y'], what=f'IR v1 case {i}')
 
 
-def test_tiny_decoder_v1_0(golden, dev):
+def test_tiny_decoder_v1_0(golden, dev, ir_math):
     from hyperseg_amd.models import hyperseg_v1_0 as M
     from test_oracle_golden import TINY
     g = golden('decoder_t_v1_0')
@@ -241,7 +250,7 @@ def test_tiny_decoder_v1_0(golden, dev):
     assert bool((y.argmax(1).cpu() == g['y'].argmax(1)).all())
 
 
-def test_inverted_residual_unify_and_v0(golden, dev):
+def test_inverted_residual_unify_and_v0(golden, dev, ir_math):
     """unify flavour (weights arrive directly) and the v0_1 block (three image-level patch convs, Op D)."""
     from hyperseg_amd.models import hyperseg_v1_0_unify as U
     from hyperseg_amd.models import hyperseg_v0_1 as V0
@@ -276,7 +285,7 @@ def make_decoder(c):
 
 
 @pytest.mark.parametrize('name', ['t_unify', 't_v0_1'])
-def test_tiny_decoder_other_variants(golden, dev, name):
+def test_tiny_decoder_other_variants(golden, dev, name, ir_math):
     from test_oracle_golden import TINY
     g = golden('decoder_' + name)
     c = TINY[name]
@@ -302,8 +311,11 @@ def build_decoder(name, O):
     return d
 
 
+_FULL_REF = {}
+
+
 @pytest.mark.parametrize('name', ['M', 'Sc', 'S', 'L'])
-def test_full_config(golden, O, dev, name):
+def test_full_config(golden, O, dev, name, ir_math):
     """HyperSeg-M 1024x512 / CamVid-S 768x576 / HyperSeg-S 1536x768 (unify) / HyperSeg-L 512x512 bs4 = the per-GPU shard of config 4 (v0_1)
     decoders on the seeded synthetic workload of SURVEY 8(d): vs the oracle on the full tensor, vs the
     reference's own sampled logits and masks."""
@@ -314,8 +326,10 @@ def test_full_config(golden, O, dev, name):
     s = [t.to(dev) for t in s] if isinstance(s, list) else s.to(dev)
     with torch.no_grad():
         y = d([t.to(dev) for t in x], s).cpu()
-    ref, levels = O.run_config(name, batch=batch, seed=0, return_levels=True)
-    e = cmp(y, ref, tol=REL_TOL, what=f'{name} logits vs oracle')
+    if name not in _FULL_REF:
+        _FULL_REF[name] = O.run_config(name, batch=batch, seed=0)
+    ref = _FULL_REF[name]
+    e = cmp(y, ref, tol=REL_TOL, what=f'{name} logits vs oracle ({ir_math})')
     assert e < NORTH_STAR_TOL
     top2 = ref.topk(2, dim=1).values
     margin = top2[:, 0] - top2[:, 1]
@@ -407,7 +421,7 @@ def _op_d_case(c, dev, O, batch=2, seed=5):
 
 
 @pytest.mark.parametrize('case', OP_D_CASES)
-def test_fused_op_d_vs_oracle(HF, O, dev, case):
+def test_fused_op_d_vs_oracle(HF, O, dev, case, ir_math):
     """The one-launch Op D kernel (neighbour-weight ring recompute) == the oracle's three image-level patch convs, and ==
     this package's own three-launch route bit-for-bit in structure (same inputs), for every HyperSeg-L level shape."""
     m, skip, prev, wt, ref = _op_d_case(case, dev, O)
@@ -456,6 +470,79 @@ def test_full_config_l_bs32_properties(O, dev):
     ref = O.decoder_v0_1(O.config_plan('L'), O.synth_decoder_params(O.config_plan('L'), seed=0),
                          [t[5:6].cpu() for t in x], [t[5:6].cpu() for t in w])
     cmp(y[5:6], ref, what='L bs32 frame 5 vs oracle')
+
+
+# ------------------------------------------------------------------------------ split arithmetic: range and scaling
+def _fold(bn, eps=1e-5):
+    sc = bn['weight'] / torch.sqrt(bn['running_var'] + eps)
+    return sc, bn['bias'] - bn['running_mean'] * sc
+
+
+def _op_c_case(O, cin_parts, cout, hid, patch, grid, seed, in_gain=1.0, w1_gain=1.0, w3_gain=1.0, w3_late_gain=1.0):
+    """A v1_0 inverted residual at a decoder level shape with power-of-two gains on the inputs / weights (the BN that
+    follows is rescaled so that the block computes the same function: ReLU6 stays exercised on both sides)."""
+    skip_c, prev_c = cin_parts
+    cin = 2 + skip_c + prev_c
+    fh, fw = grid
+    h, w = fh * patch, fw * patch
+    g = torch.Generator().manual_seed(seed)
+    skip = torch.randn(1, skip_c, h, w, generator=g) * in_gain
+    prev = torch.randn(1, prev_c, h // 2, w // 2, generator=g) * in_gain
+    wt = torch.randn(1, cin * hid + 9 * hid + hid * cout, fh, fw, generator=g)
+    wt[:, :cin * hid] *= (2.0 / cin) ** 0.5 * w1_gain
+    wt[:, :cin * hid].view(1, hid, cin, fh, fw)[:, :, :2] *= in_gain      # the coordinates do not carry the input gain
+    wt[:, cin * hid:cin * hid + 9 * hid] *= (2.0 / 9) ** 0.5
+    w3 = wt[:, cin * hid + 9 * hid:].view(1, cout, hid, fh, fw)
+    w3 *= (1.0 / hid) ** 0.5 * w3_gain
+    w3[:, :, 32:] *= w3_late_gain                      # hidden chunks 2.. : the rows' running exponents must grow
+    bns = []
+    for n, gain in ((hid, in_gain * w1_gain), (hid, 1.0), (cout, 1.0)):
+        bns.append({'weight': torch.rand(n, generator=g) + 0.5, 'bias': torch.randn(n, generator=g) * 0.1,
+                    'running_mean': torch.randn(n, generator=g) * 0.1 * gain,
+                    'running_var': (torch.rand(n, generator=g) * 1.5 + 0.5) * gain * gain})
+    ref = O.patch_inverted_residual_v1(O.stage_input(skip, prev), wt, hid, cout, *bns)
+    return skip, prev, wt, bns, ref
+
+
+@pytest.mark.parametrize('gains', [dict(), dict(in_gain=2.0 ** 12, w1_gain=2.0 ** -9), dict(in_gain=2.0 ** -20, w1_gain=2.0 ** 14),
+                                   dict(w3_gain=2.0 ** -12, w3_late_gain=2.0 ** 9), dict(in_gain=2.0 ** 16, w3_gain=2.0 ** 20)])
+@pytest.mark.parametrize('shape', [((16, 16), 19, 78, 16, (2, 3)), ((6, 16), 16, 48, 8, (3, 2))])
+def test_split_ir_ranges(HF, O, dev, ir_math, shape, gains):
+    """The f16 split products carry power-of-two scales chosen from the data (per weight row, per position tile, a running
+    exponent per pw3 row): inputs at 2^12 / 2^-20 / 2^30, weights at 2^-9 .. 2^20, and late hidden chunks 512x larger
+    than the first (accumulator rescale) must all come out at f32 accuracy -- and identically in exact-f32 mode.
+    (What the split form cannot carry is a dynamic range beyond ~2^18 INSIDE one reduction -- a weight 2^-20 of its row's
+    maximum meeting an input 2^20 above its tile's: f16's exponent range; include/hyperseg_hip.h, hs_ir_math.)"""
+    cin_parts, cout, hid, patch, grid = shape
+    skip, prev, wt, bns, ref = _op_c_case(O, cin_parts, cout, hid, patch, grid, seed=11, **gains)
+    stage = HF.StageInput(skip.to(dev), prev.to(dev), coords=True)
+    bank = HF.bank_pack(wt.to(dev), 0, wt.shape[1])
+    y = HF.patch_ir(stage, grid, bank, hid, cout, *[tuple(t.to(dev) for t in _fold(b)) for b in bns])
+    assert bool(torch.isfinite(y).all())
+    cmp(y, ref, what=f'Op C {shape} gains {gains} ({ir_math})')
+
+
+def test_split_and_exact_modes_agree_on_flips(HF, O, dev):
+    """HyperSeg-M at 1024x512: the two arithmetic modes give the same mask except where the oracle's own top-2 margin is
+    below MARGIN, and logits within REL_TOL of each other."""
+    d = build_decoder('M', O).to(dev)
+    x, s = O.synth_decoder_inputs('M', batch=1, seed=3)
+    x = [t.to(dev) for t in x]
+    ys = {}
+    with torch.no_grad():
+        for mode in ('split', 'f32'):
+            prev = HF.set_ir_math(mode)
+            try:
+                ys[mode] = d(x, s.to(dev))
+            finally:
+                HF.set_ir_math(prev)
+    assert HF.get_ir_math() == 'auto'                      # the library default
+    e = float((ys['split'] - ys['f32']).abs().max() / ys['f32'].abs().max())
+    assert e < REL_TOL, e
+    top2 = ys['f32'].topk(2, dim=1).values
+    margin = top2[:, 0] - top2[:, 1]
+    flips = ys['split'].argmax(1) != ys['f32'].argmax(1)
+    assert int((flips & (margin > MARGIN)).sum()) == 0
 
 
 # ------------------------------------------------------------------------------ bank generated inside the consumer

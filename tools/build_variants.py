@@ -1,6 +1,6 @@
 """Dev-only variant builds of the HIP library for on-GPU A/B runs (selected with HS_HIP_LIB=<path>); the product build
 (python -m hyperseg_amd.build) contains none of this, and the product sources carry no dev hooks: the 'stamps' variant
-is made by patching a COPY of hs_patch_ir_fused.hip.
+is made by patching a COPY of hs_patch_ir_fused.hip ('stamps_split': of hs_patch_ir_split.hip).
     stamps    s_memtime stamps of wave 0 of every workgroup at the phase boundaries (tools/ir_phase_times.py reads them)
 """
 import os
@@ -21,8 +21,8 @@ extern "C" int hs_debug_read_stamps(long long* out, int n) {
 '''
 
 
-def stamped_source():
-    src = open(os.path.join(B.CSRC, 'hs_patch_ir_fused.hip')).read()
+def stamped_source(fname='hs_patch_ir_fused.hip'):
+    src = open(os.path.join(B.CSRC, fname)).read()
 
     def after(anchor, code, count=1):
         nonlocal src
@@ -35,23 +35,24 @@ def stamped_source():
         src = src.replace(anchor, code + anchor)
     after('namespace hs {\n', STAMP_DECL)
     after('    const int lrow = lane & 15, lk = lane >> 4;\n', '    HS_STAMP(0);\n')
-    before('    __syncthreads();                                   // window + BN rows', '    HS_STAMP(1);\n')
-    src = re.sub(r'(    __syncthreads\(\); +// window \+ BN rows[^\n]*\n)', r'\1    HS_STAMP(2);\n', src, count=1)
-    before('    __syncthreads();                                   // the window is dead', '    HS_STAMP(3);\n')
-    after('    stage_pw1(0);\n    __syncthreads();\n', '    HS_STAMP(4);\n')
+    src, n = re.subn(r'(    __syncthreads\(\); +// window \+ BN rows[^\n]*\n)', r'    HS_STAMP(1);\n\1    HS_STAMP(2);\n', src, count=1)
+    assert n == 1
+    src, n = re.subn(r'(    __syncthreads\(\); +// the window is dead)', r'    HS_STAMP(3);\n\1', src, count=1)
+    assert n == 1
+    src = re.sub(r'(    stage_pw1\(0\);\n    __syncthreads\(\);\n)', r'\1    HS_STAMP(4);\n', src, count=1)
     after('        stage_dw(h0);\n', '        HS_STAMP(5 + 4 * (h0 < 48 ? h0 / 16 : 3));\n')
     after('        stage_dw(h0);\n        HS_STAMP(5 + 4 * (h0 < 48 ? h0 / 16 : 3));\n        __syncthreads();\n',
           '        HS_STAMP(6 + 4 * (h0 < 48 ? h0 / 16 : 3));\n')
     after('        stage_pw3(h0);\n', '        HS_STAMP(7 + 4 * (h0 < 48 ? h0 / 16 : 3));\n')
-    after('            __syncthreads();                           // h1 ready for dw(c+1); h2 no longer read by pw3(c)\n',
-          '            HS_STAMP(8 + 4 * (h0 < 48 ? h0 / 16 : 3));\n')
+    src, n = re.subn(r'(            stage_pw1\(h0 \+ 16\);[^\n]*\n            __syncthreads\(\);[^\n]*\n)',
+                     r'\1            HS_STAMP(8 + 4 * (h0 < 48 ? h0 / 16 : 3));\n', src, count=1)
+    assert n == 1
     # end of the kernel body: the closing brace that precedes launch_irf's template header
-    marker = '\ntemplate <int CIN, int CSKIP, int COUT, int REG, int MODE, int PWR>\nstatic int launch_irf('
-    i = src.index(marker)
+    i = re.search(r'\ntemplate <[^>]*>\nstatic int launch_ir[fs]\(', src).start()
     j = src.rindex('}', 0, i)
     src = src[:j] + '    HS_STAMP(24);\n' + src[j:]
     os.makedirs(os.path.join(B.LIB_DIR, 'dev_src'), exist_ok=True)
-    path = os.path.join(B.LIB_DIR, 'dev_src', 'hs_patch_ir_fused_stamps.hip')
+    path = os.path.join(B.LIB_DIR, 'dev_src', fname.replace('.hip', '_stamps.hip'))
     open(path, 'w').write(src)
     return path
 
@@ -77,6 +78,7 @@ PATCHES = {
 
 VARIANTS = {
     'stamps': dict(flags=[], extra=[], patch=True),
+    'stamps_split': dict(flags=[], extra=[], patch=True, file='hs_patch_ir_split.hip'),
     'nostore': dict(flags=[], extra=[], patch='nostore'),
     'ntstore': dict(flags=[], extra=[], patch='ntstore'),
 }
@@ -87,7 +89,8 @@ if __name__ == '__main__':
         path = os.path.join(B.LIB_DIR, f'libhyperseg_hip_{name}.so')
         sources = list(B.SOURCES) + v['extra']
         if v.get('patch'):
-            src_path = stamped_source() if v['patch'] is True else patched_source(v['patch'], PATCHES[v['patch']])
+            fname = v.get('file', 'hs_patch_ir_fused.hip')
+            src_path = stamped_source(fname) if v['patch'] is True else patched_source(v['patch'], PATCHES[v['patch']])
             rel = os.path.relpath(src_path, B.CSRC)
-            sources = [rel if s == 'hs_patch_ir_fused.hip' else s for s in sources]
+            sources = [rel if s == fname else s for s in sources]
         print(B.build(force=True, extra_flags=v['flags'], sources=sources, lib_path=path, obj_suffix='_' + name))
