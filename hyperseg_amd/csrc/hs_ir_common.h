@@ -43,4 +43,7 @@ __device__ __forceinline__ float relu6_(float v) { return fminf(fmaxf(v, 0.0f), 
 // hs_patch_ir_split.hip; returns 1 when it has no instantiation for the shape (or the math mode asks for exact f32)
 int try_launch_ir_split(int mode, IrFusedArgs& a, int cin, int c_skip, int c_out, hipStream_t stream);
 
+// hs_patch_ir_px.hip: Op D, one lane per pixel, for the narrow HyperSeg-L levels; 1 = no instantiation
+int try_launch_ir_px(IrFusedArgs& a, int cin, int c_skip, int c_out, hipStream_t stream);
+
 }  // namespace hs

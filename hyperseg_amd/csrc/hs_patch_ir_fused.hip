@@ -520,6 +520,10 @@ int try_launch_ir_fused(int mode, const StageIn& in, int fh, int fw, const float
         (size_t)(cin - 2 - c_skip) * in.Hp * in.Wp >= (1u << 30)) return 1;
     if (a.ph != a.pw) return 1;
     const int p = a.ph;
+    if (mode == 1) {   // the narrow Op D levels: one lane per pixel (hs_patch_ir_px.hip)
+        const int e = try_launch_ir_px(a, cin, c_skip, c_out, stream);
+        if (e != 1) return e;
+    }
     {   // the f16 split form first (unless the math mode asks for exact f32 or it has no instantiation)
         const int e = try_launch_ir_split(mode, a, cin, c_skip, c_out, stream);
         if (e != 1) return e;
