@@ -237,7 +237,7 @@ def roofline_of(launches, levels, h, w, batch, traffic_dir):
                     'frac': round(flops / t_s / 1e12 / FP32_PEAK_TFLOPS, 4), 'traffic': traffic,
                     'avg_launch_us': dom['avg_us'], 'algorithmic_flops': flops, 'algorithmic_bytes': kbytes,
                     'hbm_frac': round(kbytes / t_s / 1e9 / HBM_PEAK_GBS, 4),
-                    'note': 'fp32 math: f32 vector peak == f32-input MFMA dense peak (157.3 TF/s); the launch needs '
+                    'note': 'priced against the f32 peak: f32 vector peak == f32-input MFMA dense peak (157.3 TF/s); the launch needs '
                             f'{t_fl * 1e6:.1f} us at that peak and {t_by * 1e6:.1f} us at the 8 TB/s HBM peak'}
     if lv is not None:
         kbytes = lv['in_bytes'] + lv['bank_bytes'] + lv['out_bytes']
@@ -260,7 +260,7 @@ def pmc_traffic(traffic_dir, kernel):
         return None
     import csv
     import glob
-    stem = {'hs_patch_ir_fwd': 'patch_ir_fused_kernel', 'hs_patch_ir_v0_fwd': 'patch_ir_fused_kernel',
+    stem = {'hs_patch_ir_fwd': 'patch_ir_', 'hs_patch_ir_v0_fwd': 'patch_ir_',
             'hs_patch_conv_fwd': 'patch_conv', 'hs_upsample_bilinear_fwd': 'upsample2x_kernel',
             'hs_signal2weights_multi_fwd': 'signal2weights_kernel'}.get(kernel)
     if stem is None:
@@ -447,6 +447,8 @@ def main():
                                   'context head = library GEMMs + hs_affine_act_fwd',
                        'output': f'fp32 logits {tuple(y.shape)}' if args.output == 'logits' else f'uint8 argmax masks {tuple(y.shape)}',
                        'launch': 'eager' if args.no_graph else 'hipGraph replay',
+                       'ir_math': __import__('hyperseg_amd.functional', fromlist=['x']).get_ir_math() + ' (include/hyperseg_hip.h hs_ir_math: f32 storage and accumulation; auto = f16 '
+                                  'split products, f32-class, on the level-4 inverted residual; HS_IR_MATH=f32 for exact f32)',
                        'parallelism': f'batch-sharded x{world}' + (f', RCCL {args.collective} of {args.gather}' if comm is not None else '')},
             'per_rank_frames_per_s': per_rank,
             'collective': None if comm is None else {
