@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 constexpr int ITER = 2000;
 
@@ -37,6 +38,19 @@ __global__ __launch_bounds__(256) void k(float* out, long long* cyc, float s0) {
                 a[4 * q + 2] = fmaf(t.z, x, a[4 * q + 2]); a[4 * q + 3] = fmaf(t.w, x, a[4 * q + 3]);
             }
         }
+    } else if (MODE == 4 || MODE == 5) {   // 16 v_mfma_f32_4x4x1 (MODE 4) / 4 v_mfma_f32_16x16x4 (MODE 5) per iteration, 8 / 4 independent chains
+        f32x4 c[8];
+        for (int i = 0; i < 8; ++i) c[i] = f32x4{a[i], a[i + 1], a[i + 2], a[i + 3]};
+        for (int it = 0; it < ITER; ++it) {
+            if (MODE == 4) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) c[i & 7] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[i], x, c[i & 7], 4, 3, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) c[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], x, c[i], 0, 0, 0);
+            }
+        }
+        for (int i = 0; i < 8; ++i) a[i] += c[i][0] + c[i][1] + c[i][2] + c[i][3];
     } else {                    // 4 ds_read_b128 broadcast + 8 v_pk_fma_f32
         f32x2 p[8];
         for (int i = 0; i < 8; ++i) p[i] = f32x2{a[2 * i], a[2 * i + 1]};
@@ -83,5 +97,7 @@ int main() {
     run<1>("v_pk_fma_f32 x8", out, cyc);
     run<2>("ds_read_b128 bcast x4 + v_fma x16", out, cyc);
     run<3>("ds_read_b128 bcast x4 + v_pk_fma x8", out, cyc);
+    run<4>("v_mfma_f32_4x4x1 x16 (=64 FMA/lane)", out, cyc);
+    run<5>("v_mfma_f32_16x16x4 x4 (=64 FMA/lane)", out, cyc);
     return 0;
 }
