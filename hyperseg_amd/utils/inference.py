@@ -119,10 +119,13 @@ class FusedPointwise(nn.Module):
         return x.shape[1] <= PW_MFMA_MAX_CIN and x.shape[2] * x.shape[3] >= PW_MFMA_MIN_PIXELS
 
     def raw(self, x):
-        """The bare GEMM (batch 1): W (Cout, Cin) @ x (Cin, HW); BN + activation are left to the consumer."""
-        _, cin, h, w = x.shape
+        """The bare GEMM: W (Cout, Cin) @ x (Cin, HW) per frame (a strided-batched GEMM with a shared A for a batch); BN +
+        activation are left to the consumer."""
+        b, cin, h, w = x.shape
         with gemm_library(h * w):
-            return torch.mm(self.conv.weight.view(-1, cin), x.view(cin, h * w)).view(1, -1, h, w)
+            if b == 1:
+                return torch.mm(self.conv.weight.view(-1, cin), x.view(cin, h * w)).view(1, -1, h, w)
+            return torch.matmul(self.conv.weight.view(-1, cin), x.view(b, cin, h * w)).view(b, -1, h, w)
 
     def forward(self, x, gate=None, residual=None):
         """``gate`` (B, Cin): SE gate applied to the input.  Non-MFMA shapes: stock GEMM followed by ONE fused
@@ -226,7 +229,7 @@ class FusedMBConv(nn.Module):
         b, _, h, w = x.shape
         ho = (h + self.pad_h - self.k) // self.stride + 1
         wo = (w + self.pad_w - self.k) // self.stride + 1
-        lean = b == 1                             # library GEMMs with nothing around them
+        lean = True                               # library GEMMs with nothing around them (batched for b > 1)
         if self.fuses_expand(x, ho, wo):
             y, partial = HF.mbconv_expand_dw(x, self.expand.conv.weight, self.expand.scale, self.expand.shift,
                                              blk._depthwise_conv.weight, self.stride, self.pad_t, self.pad_l, (ho, wo),
@@ -251,17 +254,26 @@ class FusedMBConv(nn.Module):
         # MFMA kernel with its fused epilogue wins wherever it applies (few channels, many pixels)
         if lean and (y.shape[1] > LEAN_MFMA_MAX_CIN if self.defer_shift else not proj.uses_mfma(y)):
             # gate (and BN2 scale) folded into the project weights by the SE kernel: ~1e5 weights instead of a pass over y
-            wp = HF.se_gate(partial, 1, ho * wo, red.weight, red.bias, self._exp_t, exp.bias,
+            wp = HF.se_gate(partial, b, ho * wo, red.weight, red.bias, self._exp_t, exp.bias,
                             w_proj=proj.conv.weight, out_scale=proj.scale)
             cmid = y.shape[1]
-            w2d, y2d = wp.view(-1, cmid), y.view(cmid, ho * wo)
             with gemm_library(ho * wo):
-                if self.defer_shift:
-                    if skip is None:
-                        return torch.mm(w2d, y2d).view(1, -1, ho, wo)
-                    skip.view(-1, ho * wo).addmm_(w2d, y2d)      # in place: the block input has no other consumer
-                    return skip
-                out = torch.mm(w2d, y2d).view(1, -1, ho, wo)
+                if b == 1:
+                    w2d, y2d = wp.view(-1, cmid), y.view(cmid, ho * wo)
+                    if self.defer_shift:
+                        if skip is None:
+                            return torch.mm(w2d, y2d).view(1, -1, ho, wo)
+                        skip.view(-1, ho * wo).addmm_(w2d, y2d)      # in place: the block input has no other consumer
+                        return skip
+                    out = torch.mm(w2d, y2d).view(1, -1, ho, wo)
+                else:                             # per-frame gated weights: one strided-batched GEMM
+                    w3d, y3d = wp.view(b, -1, cmid), y.view(b, cmid, ho * wo)
+                    if self.defer_shift:
+                        if skip is None:
+                            return torch.bmm(w3d, y3d).view(b, -1, ho, wo)
+                        skip.view(b, -1, ho * wo).baddbmm_(w3d, y3d)
+                        return skip
+                    out = torch.bmm(w3d, y3d).view(b, -1, ho, wo)
             return HF.affine_act_(out, None, proj.shift, 0, skip)
         gate = HF.se_gate(partial, b, ho * wo, red.weight, red.bias, self._exp_t, exp.bias)
         return proj(y, gate=gate, residual=skip)
