@@ -125,7 +125,8 @@ class FusedPointwise(nn.Module):
         with gemm_library(h * w):
             if b == 1:
                 return torch.mm(self.conv.weight.view(-1, cin), x.view(cin, h * w)).view(1, -1, h, w)
-            return torch.matmul(self.conv.weight.view(-1, cin), x.view(b, cin, h * w)).view(b, -1, h, w)
+            # bmm with the weight expanded over the batch (stride 0): matmul(2-D, 3-D) would go through transposed copies
+            return torch.bmm(self.conv.weight.view(1, -1, cin).expand(b, -1, -1), x.view(b, cin, h * w)).view(b, -1, h, w)
 
     def forward(self, x, gate=None, residual=None):
         """``gate`` (B, Cin): SE gate applied to the input.  Non-MFMA shapes: stock GEMM followed by ONE fused
