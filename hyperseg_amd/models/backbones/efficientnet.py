@@ -79,6 +79,15 @@ class SamePadConv2d(nn.Conv2d):
         return self._conv_forward(x, self.weight, self.bias)
 
 
+def _inference_only(module, x):
+    """CUDA tensor, eval mode, and no gradient can be asked of this call."""
+    if not x.is_cuda or module.training:
+        return False
+    if not torch.is_grad_enabled():
+        return True
+    return not (x.requires_grad or any(p.requires_grad for p in module.parameters()))
+
+
 class MBConvBlock(nn.Module):
     def __init__(self, in_f, out_f, expand, kernel, stride, image_size):
         super().__init__()
@@ -96,9 +105,12 @@ class MBConvBlock(nn.Module):
         self._project_conv = SamePadConv2d(mid, out_f, 1, image_size=_out_size(image_size, stride), bias=False)
         self._bn2 = bn(out_f)
         self._fused_dw = None       # set by utils.inference.prepare_for_inference(fused_depthwise=True)
+        self._fused_active = None   # per forward, set by EfficientNet.extract_features_list: all blocks fused or none
+                                    # (deferred BN shifts chain from block to block)
 
     def forward(self, inputs, drop_connect_rate=None):
-        if self._fused_dw is not None and inputs.is_cuda and not self.training:
+        active = self._fused_active if self._fused_active is not None else _inference_only(self, inputs)
+        if self._fused_dw is not None and active:
             return self._fused_dw(inputs, self)         # the whole block in 4 HIP launches (utils/inference.py)
         x = inputs
         if self.expand != 1:
@@ -173,8 +185,35 @@ class EfficientNet(nn.Module):
         self._fc = head(head_nc, num_classes) if head is not None else None
         self._fused_head, self._fused_fc, self._fused_stem = None, None, None      # set by utils.inference.prepare_for_inference
 
+    def _fused_ok(self, inputs):
+        """The prepared (fused HIP) route is taken for a whole forward or not at all -- its blocks hand deferred BN shifts
+        to one another: CUDA, eval mode, nothing that needs a gradient (the kernels have no backward: an eval-mode
+        backbone under autograd, e.g. a frozen-BN fine-tune, takes the stock route), and every stage's H*W a multiple of
+        4 (16-byte rows in hs_affine_act_fwd / the library-GEMM epilogues; odd pyramid scales fall back)."""
+        if self._fused_stem is None and self._fused_head is None and all(b._fused_dw is None for b in self._blocks):
+            return False
+        if not _inference_only(self, inputs):
+            return False
+        h, w = (inputs.shape[2] + 1) // 2, (inputs.shape[3] + 1) // 2           # stem: stride 2, TF-"SAME"
+        for blk in self._blocks:
+            st = blk._depthwise_conv.stride[0]
+            if (h * w) % 4 != 0:
+                return False
+            h, w = (h + st - 1) // st, (w + st - 1) // st
+        return (h * w) % 4 == 0
+
     def extract_features_list(self, inputs):
-        if self._fused_stem is not None and inputs.is_cuda and not self.training:
+        use = self._fused_ok(inputs)
+        for blk in self._blocks:
+            blk._fused_active = use
+        try:
+            return self._extract_features_list(inputs, use)
+        finally:
+            for blk in self._blocks:
+                blk._fused_active = None
+
+    def _extract_features_list(self, inputs, use):
+        if self._fused_stem is not None and use:
             x = self._fused_stem(inputs)
         else:
             x = F.silu(self._bn0(self._conv_stem(inputs)))
@@ -185,9 +224,9 @@ class EfficientNet(nn.Module):
             x = block(x, drop_connect_rate=rate)
             if self._res_feat_mask[idx]:
                 fc = getattr(self, f'_feat_fc_{len(feats)}', None) if self.out_feat_scale is not None else None
-                fused = self._fused_fc is not None and x.is_cuda and not self.training and str(len(feats)) in self._fused_fc
+                fused = self._fused_fc is not None and use and str(len(feats)) in self._fused_fc
                 feats.append(self._fused_fc[str(len(feats))](x) if fused else (x if fc is None else fc(x)))
-        if self._fused_head is not None and x.is_cuda and not self.training:
+        if self._fused_head is not None and use:
             x = self._fused_head(x)
         else:
             x = F.silu(self._bn1(self._conv_head(x)))

@@ -609,7 +609,9 @@ class WeightMapper(nn.Module):
 
     def forward(self, x):
         if self._fused is not None and x.is_cuda and x.shape[0] == 1 and not self.training \
-                and x.shape[2] % 2 ** self.levels == 0 and x.shape[3] % 2 ** self.levels == 0:
+                and not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))) \
+                and x.shape[2] % 2 ** self.levels == 0 and x.shape[3] % 2 ** self.levels == 0 \
+                and (x.shape[2] * x.shape[3]) % 4 ** self.levels == 0:
             return self._fused(x.contiguous())
         feat = [self.in_conv(x)]
         for down in self.down_blocks:

@@ -394,6 +394,19 @@ def _fuse_backbone(bb):
         bb._fused_head.absorb_input_offset(offset)
 
 
+def _install_fused(model):
+    """(Re)build the fused routes of the encoder and the context head from the model's CURRENT parameters."""
+    bb, wm = model.backbone, model.weight_mapper
+    for blk in bb._blocks:
+        blk._fused_dw = None
+    bb._fused_stem = bb._fused_head = bb._fused_fc = None
+    _fuse_backbone(bb)
+    dev = next(model.parameters()).device
+    bb.to(dev)                                      # new non-persistent buffers follow the model's device
+    if type(wm).__name__ == 'WeightMapper' and hasattr(wm, 'in_conv') and hasattr(wm, 'up_blocks') and wm.levels >= 2:
+        wm._fused = FusedContextHead(wm).to(dev)
+
+
 def prepare_for_inference(model, fold_bn=True, channels_last=False, fused_depthwise=False):
     """In place; returns the number of BatchNorms folded by ``fold_bn``.  ``model``: a HyperGen in eval mode (module
     docstring for what each switch does).  The fused routes are installed first, so ``fold_bn`` only touches the
@@ -405,9 +418,13 @@ def prepare_for_inference(model, fold_bn=True, channels_last=False, fused_depthw
                            'BatchNorm shifts would be absorbed twice')
     wm = model.weight_mapper
     if fused_depthwise:
-        _fuse_backbone(model.backbone)
-        if type(wm).__name__ == 'WeightMapper' and hasattr(wm, 'in_conv') and hasattr(wm, 'up_blocks') and wm.levels >= 2:
-            wm._fused = FusedContextHead(wm)
+        _install_fused(model)
+        if not fold_bn and not getattr(model, '_hs_refresh_hook', None):
+            # the folded BN affines and the deferred-shift chain are derived from the parameters at this moment: rebuild
+            # them whenever a state dict is loaded afterwards (fold_bn rewrites parameters, so there the order is fixed)
+            def _refresh(module, incompatible_keys):
+                _install_fused(module)
+            model._hs_refresh_hook = model.register_load_state_dict_post_hook(_refresh)
     if fold_bn:
         bb = model.backbone
         pairs = ([] if getattr(bb, '_fused_stem', None) is not None else [('_conv_stem', '_bn0')]) + \

@@ -213,3 +213,37 @@ def test_benched_configuration_replay_matches_stock(dev):
         graph.replay()
         torch.cuda.synchronize()
         assert rel_err(yf.cpu(), stock(x2).cpu()) < 1e-4
+
+
+def test_prepared_routes_fall_back_and_refresh(dev):
+    """The three gaps ADVICE r1 listed for the prepared encoder: (1) a size whose deep stages have H*W % 4 != 0 takes the
+    stock route instead of raising; (2) an eval-mode model under autograd takes the stock route, so gradients exist;
+    (3) load_state_dict after prepare_for_inference rebuilds the folded BN affines / deferred-shift chain."""
+    from hyperseg_amd import configs
+    from hyperseg_amd.utils.inference import prepare_for_inference
+    from hyperseg_amd.utils.synthetic import fill_by_name
+    stock = fill_by_name(configs.build('hyperseg-m').eval(), seed=3).to(dev)
+    fused = copy.deepcopy(stock)
+    prepare_for_inference(fused, fold_bn=False, fused_depthwise=True)
+    fused = fused.to(dev)
+    # (1) 480 x 480: the /32 stage is 15 x 15
+    x = torch.rand(1, 3, 480, 480, device=dev)
+    assert not fused.backbone._fused_ok(x)
+    with torch.no_grad():
+        for a, b in zip(stock.backbone(x), fused.backbone(x)):
+            assert torch.equal(a, b)
+        x2 = torch.rand(1, 3, 256, 512, device=dev)
+        assert fused.backbone._fused_ok(x2)
+    # (2) autograd through an eval-mode prepared backbone
+    xg = torch.rand(1, 3, 256, 512, device=dev, requires_grad=True)
+    assert not fused.backbone._fused_ok(xg)
+    feats = fused.backbone(xg)
+    feats[-1].square().mean().backward()
+    assert xg.grad is not None and float(xg.grad.abs().max()) > 0
+    # (3) new weights after preparation
+    other = fill_by_name(configs.build('hyperseg-m').eval(), seed=11).to(dev)
+    fused.load_state_dict(other.state_dict(), strict=True)
+    with torch.no_grad():
+        assert fused.backbone._fused_ok(x2)
+        ys, yf = other(x2), fused(x2)
+    assert rel_err(yf.cpu(), ys.cpu()) < 1e-4
