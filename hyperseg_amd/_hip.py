@@ -58,6 +58,7 @@ def _load():
         'hs_bn_fold_fwd': ([vp, vp, vp, vp, C.c_float, i32, vp, vp, vp], C.c_int),
         'hs_patch_conv_fwd': ([C.POINTER(StageInputC), i32, i32, vp, i64, i32, i32, i32, i32, i32,
                                C.POINTER(EpilogueC), vp, vp], C.c_int),
+        'hs_meta_conv_fwd': ([vp, i32, i32, i32, i32, vp, i64] + [i32] * 13 + [C.POINTER(EpilogueC), vp, vp], C.c_int),
         'hs_patch_conv_gen_fwd': ([C.POINTER(StageInputC), i32, i32, vp, i32, C.POINTER(S2wLayerC), i32,
                                    C.POINTER(EpilogueC), vp, vp], C.c_int),
         'hs_patch_ir_fwd': ([C.POINTER(StageInputC), i32, i32, vp, i64, i32, i32, C.POINTER(EpilogueC),
@@ -94,7 +95,7 @@ def _load():
 
 lib = _load()
 EXPORTS = ['hs_version', 'hs_build_info', 'hs_signal2weights_fwd', 'hs_signal2weights_multi_fwd', 'hs_bank_pack_fwd', 'hs_bn_fold_fwd',
-           'hs_patch_conv_fwd', 'hs_patch_conv_gen_fwd', 'hs_patch_ir_fwd', 'hs_patch_ir_v0_fwd', 'hs_ir_tile_map', 'hs_set_ir_math', 'hs_get_ir_math', 'hs_upsample_bilinear_fwd', 'hs_upsample_argmax_fwd',
+           'hs_patch_conv_fwd', 'hs_meta_conv_fwd', 'hs_patch_conv_gen_fwd', 'hs_patch_ir_fwd', 'hs_patch_ir_v0_fwd', 'hs_ir_tile_map', 'hs_set_ir_math', 'hs_get_ir_math', 'hs_upsample_bilinear_fwd', 'hs_upsample_argmax_fwd',
            'hs_stage_input_fwd', 'hs_depthwise_conv_fwd', 'hs_depthwise_pool_blocks', 'hs_stem_conv_fwd', 'hs_mbconv_tiles', 'hs_mbconv_expand_dw_fwd', 'hs_se_gate_fwd', 'hs_pointwise_conv_fwd', 'hs_affine_act_fwd', 'hs_patch_conv_bwd_input',
            'hs_patch_conv_bwd_weight', 'hs_patch_conv_plain_fwd', 'hs_patch_conv_plain_bwd_in', 'hs_patch_conv_plain_bwd_w']
 

@@ -298,6 +298,34 @@ def patch_conv(x, grid, bank, c_out, k=1, padding=0, padding_mode='reflect', gro
 
 
 @_on_operand_device
+def meta_conv(x, w, c_out, kernel_size, stride=(1, 1), padding=(0, 0), dilation=(1, 1), padding_mode='zeros', groups=1,
+              scale=None, shift=None, act=ACT_NONE):
+    """MetaConv2d.forward for ANY of the reference's arguments (meta_conv.py:141-186): x (B, Cin, H, W), per-sample weights
+    w (B, >= Cout * Cin/groups * kh * kw); non-square kernels, stride, dilation, any padding.  The "same"-padded stride-1
+    case runs faster through :func:`patch_conv` with a (1, 1) grid."""
+    if isinstance(x, StageInput):
+        x = x.materialize()
+    b, cin, h, wd = x.shape
+    (kh, kw), (sh, sw), (ph, pw), (dh, dw) = kernel_size, stride, padding, dilation
+    # zero padding: ph rows / pw columns on both sides.  The other modes: the reference hands (ph, pw, ph, pw) to F.pad, whose
+    # order is (left, right, top, bottom) -- left = top = ph, right = bottom = pw (meta_conv.py:159, 175-176); reproduced.
+    pt, pb, pl, pr = (ph, ph, pw, pw) if padding_mode == 'zeros' else (ph, pw, ph, pw)
+    ho = (h + pt + pb - dh * (kh - 1) - 1) // sh + 1
+    wo = (wd + pl + pr - dw * (kw - 1) - 1) // sw + 1
+    if ho <= 0 or wo <= 0:
+        raise ValueError(f'kernel {kernel_size} (dilation {dilation}) does not fit the padded {h}x{wd} input')
+    if w.dim() != 2 or w.shape[0] != b or w.stride(1) != 1:
+        raise ValueError(f'w must be (B, rows) with contiguous rows, got {tuple(w.shape)}')
+    ep = _epilogue(scale, shift, act)
+    y = torch.empty(b, c_out, ho, wo, device=x.device, dtype=torch.float32)
+    st = _hip.lib.hs_meta_conv_fwd(_hip.dev_ptr(x, 'x'), b, cin, h, wd, _hip.dev_ptr(w, 'w'), w.stride(0), c_out, kh, kw,
+                                   sh, sw, pt, pb, pl, pr, dh, dw, PAD_MODES[padding_mode], groups, C.byref(ep), y.data_ptr(),
+                                   _hip.stream_ptr())
+    _hip.check(st, 'hs_meta_conv_fwd')
+    return y
+
+
+@_on_operand_device
 def patch_conv_gen(x, sref, c_out, scale=None, shift=None, act=ACT_NONE):
     """Op A with the bank generated inside the kernel from ``sref`` (a :class:`SignalRef`): signal2weights + k = 1 patch
     conv + BN affine + activation, one launch, no bank in HBM.  Returns None when the shape is outside what the kernel

@@ -64,18 +64,35 @@ class MetaConv2d(nn.Module):
         self.hyper_params = out_channels * (in_channels // groups) * self.kernel_size[0] * self.kernel_size[1]
 
     def _check_supported(self):
+        """(k, padding) of a square, stride-1, dilation-1 conv -- what the PATCH-wise wrappers (MetaPatch, HyperPatch) can
+        hand to the patch-convolution kernels; anything else raises there, as the patch semantics of a strided conv are
+        not something any reference configuration defines."""
         kh, kw = self.kernel_size
         if kh != kw or self.stride != (1, 1) or self.dilation != (1, 1) or self.padding[0] != self.padding[1]:
-            raise NotImplementedError('hyperseg_amd kernels cover square kernels, stride 1, dilation 1 '
+            raise NotImplementedError('hyperseg_amd patch-wise kernels cover square kernels, stride 1, dilation 1 '
                                       '(everything the reference configs instantiate)')
         return kh, self.padding[0]
 
+    def _same_padded(self):
+        """Square kernel, stride 1, dilation 1, padding (k - 1) / 2: what every reference configuration instantiates and
+        what the LDS-tiled patch-convolution kernels (forward and backward) cover."""
+        kh, kw = self.kernel_size
+        return kh == kw and self.stride == (1, 1) and self.dilation == (1, 1) and \
+            self.padding[0] == self.padding[1] and 2 * self.padding[0] == kh - 1
+
     def forward_fused(self, x, w, scale=None, shift=None, act=HF.ACT_NONE):
-        k, pad = self._check_supported()
         assert x.shape[0] == w.shape[0]
         if w.dim() != 2 or w.shape[1] != self.hyper_params:
             raise ValueError(f'w must be (B, {self.hyper_params}), got {tuple(w.shape)}')
         from ... import autograd as HA
+        if not self._same_padded():
+            # the rest of the reference's argument set (meta_conv.py:141-186): the general kernel, inference only
+            if HA.needs_grad(x if isinstance(x, torch.Tensor) else x.skip, w):
+                raise NotImplementedError('hyperseg_amd: gradients through a MetaConv2d with stride / dilation / non-"same" '
+                                          'padding (hs_meta_conv_fwd has no backward kernel; no reference config trains one)')
+            return HF.meta_conv(x, w if w.stride(1) == 1 else w.contiguous(), self.out_channels, self.kernel_size, self.stride,
+                                self.padding, self.dilation, self.padding_mode, self.groups, scale, shift, act)
+        k, pad = self.kernel_size[0], self.padding[0]
         if HA.needs_grad(x if isinstance(x, torch.Tensor) else x.skip, w):
             xt = HA.materialize_stage(x) if isinstance(x, HF.StageInput) else x
             y = HA.PatchConv.apply(xt, w, (1, 1), self.out_channels, k, pad, self.padding_mode, self.groups)

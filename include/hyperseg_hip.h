@@ -119,6 +119,19 @@ int hs_patch_conv_fwd(const hs_stage_input* in, int32_t fh, int32_t fw,
                       int32_t c_out, int32_t k, int32_t pad, int32_t pad_mode, int32_t groups,
                       const hs_epilogue* ep, float* y, void* stream);
 
+/* MetaConv2d.forward with the reference's FULL argument set (meta_conv.py:141-186): per-sample weights w (B, rows >=
+ * c_out * c_in/groups * kh * kw, row stride ldw; natural order ((o*cin_g + c)*kh + ky)*kw + kx), non-square kernels, stride,
+ * dilation, any padding amounts per side and mode (F.pad semantics for reflect / replicate / circular, zero padding
+ * otherwise), groups; optional BatchNorm affine + activation.  y (B, c_out, Ho, Wo),
+ * Ho = (H + pad_top + pad_bottom - dil_h (kh - 1) - 1) / stride_h + 1.  The four pad amounts are explicit because the
+ * reference pads asymmetrically in its non-zero modes (it hands (ph, pw, ph, pw) to F.pad, i.e. left = top = ph, right =
+ * bottom = pw: meta_conv.py:159, 175-176); the host mirror passes exactly that.  The "same"-padded, stride-1 convolutions
+ * every reference configuration uses run faster through hs_patch_conv_fwd (fh = fw = 1); this one covers the rest. */
+int hs_meta_conv_fwd(const float* x, int32_t batch, int32_t c_in, int32_t H, int32_t W, const float* w, int64_t ldw,
+                     int32_t c_out, int32_t kh, int32_t kw, int32_t stride_h, int32_t stride_w, int32_t pad_top,
+                     int32_t pad_bottom, int32_t pad_left, int32_t pad_right, int32_t dil_h, int32_t dil_w,
+                     int32_t pad_mode, int32_t groups, const hs_epilogue* ep, float* y, void* stream);
+
 /* Op A with the bank generated inside the consumer: signal2weights (grouped 1x1 conv of the signal, hs_s2w_layer minus its
  * bank / ld fields, which are ignored) + k = 1 dynamic patch convolution + BatchNorm affine + activation in ONE launch --
  * HyperPatchNoPadding.forward and the norm / activation modules behind it (hyperseg_v1_0.py:473-498, 728-760; unify:

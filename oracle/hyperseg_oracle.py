@@ -127,17 +127,17 @@ def reflect_index(idx, n):
 
 
 def pad2d(x, pad, mode):
-    """Whole-image padding by ``pad`` = (py, px) with an explicit index gather."""
-    py, px = pad
-    if py == 0 and px == 0:
+    """Whole-image padding with an explicit index gather; ``pad`` = (py, px) on both sides, or (top, bottom, left, right)."""
+    pt, pb, pl, pr = (pad[0], pad[0], pad[1], pad[1]) if len(pad) == 2 else pad
+    if pt == pb == pl == pr == 0:
         return x
     h, w = x.shape[-2:]
     if mode == 'zeros':
-        out = x.new_zeros(x.shape[:-2] + (h + 2 * py, w + 2 * px))
-        out[..., py:py + h, px:px + w] = x
+        out = x.new_zeros(x.shape[:-2] + (h + pt + pb, w + pl + pr))
+        out[..., pt:pt + h, pl:pl + w] = x
         return out
-    ys = torch.arange(-py, h + py)
-    xs = torch.arange(-px, w + px)
+    ys = torch.arange(-pt, h + pb)
+    xs = torch.arange(-pl, w + pr)
     if mode == 'reflect':
         ys, xs = reflect_index(ys, h), reflect_index(xs, w)
     elif mode == 'replicate':
@@ -175,7 +175,11 @@ def signal2weights(s, w_s2w, signal_index, signal_channels, groups, hyper_params
 # --------------------------------------------------------------------------------------
 def meta_conv2d(x, w, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
                 padding_mode='zeros'):
-    """y[b] = conv2d(pad(x[b]), w[b].view(Cout, Cin/g, kh, kw), groups=g)."""
+    """y[b] = conv2d(pad(x[b]), w[b].view(Cout, Cin/g, kh, kw), groups=g)  (meta_conv.py:163-186).
+    Quirk reproduced on purpose: for the non-zero padding modes the reference hands ``padding + padding`` = (ph, pw, ph, pw)
+    to F.pad, whose order is (left, right, top, bottom) -- so W is padded by ph on the left and pw on the right, H by ph at
+    the top and pw at the bottom (meta_conv.py:159, 175-176).  Identical to the intended padding whenever ph == pw, which is
+    what every reference configuration uses; the golden vectors of tests/golden/meta_conv2d_general.npz pin the rest."""
     assert x.shape[0] == w.shape[0]
     kh, kw = (kernel_size, kernel_size) if isinstance(kernel_size, int) else kernel_size
     pad = (padding, padding) if isinstance(padding, int) else tuple(padding)
@@ -184,7 +188,7 @@ def meta_conv2d(x, w, out_channels, kernel_size, stride=1, padding=0, dilation=1
     for b in range(x.shape[0]):
         xb = x[b:b + 1]
         if padding_mode != 'zeros' and any(pad):
-            xb = pad2d(xb, pad, padding_mode)
+            xb = pad2d(xb, (pad[0], pad[1], pad[0], pad[1]), padding_mode)       # (top, bottom, left, right): see above
             p = 0
         else:
             p = pad

@@ -85,6 +85,33 @@ def gen_meta_conv():
     save('meta_conv2d', **arrs)
 
 
+def gen_meta_conv_general():
+    """MetaConv2d outside "same" padding / stride 1 / dilation 1 (meta_conv.py:141-186), incl. the three examples of the
+    reference's own docstring (meta_conv.py:127-131, at a smaller size)."""
+    g = torch.Generator().manual_seed(21)
+    cases = [
+        dict(cin=16, cout=33, k=3, stride=2, padding=0, dilation=1, groups=1, mode='zeros', size=(13, 17)),
+        dict(cin=16, cout=33, k=(3, 5), stride=(2, 1), padding=(4, 2), dilation=1, groups=1, mode='zeros', size=(14, 19)),
+        dict(cin=16, cout=33, k=(3, 5), stride=(2, 1), padding=(4, 2), dilation=(3, 1), groups=1, mode='zeros', size=(15, 21)),
+        dict(cin=4, cout=8, k=3, stride=1, padding=0, dilation=1, groups=1, mode='zeros', size=(9, 11)),        # "valid"
+        dict(cin=6, cout=4, k=3, stride=2, padding=2, dilation=2, groups=2, mode='reflect', size=(10, 12)),
+        dict(cin=5, cout=5, k=(1, 3), stride=(1, 2), padding=(0, 3), dilation=(1, 2), groups=5, mode='replicate', size=(7, 9)),
+        dict(cin=3, cout=6, k=(5, 2), stride=3, padding=(3, 1), dilation=1, groups=3, mode='circular', size=(11, 8)),
+        dict(cin=8, cout=2, k=2, stride=2, padding=0, dilation=1, groups=1, mode='zeros', size=(8, 8)),
+        dict(cin=2, cout=3, k=3, stride=1, padding=2, dilation=1, groups=1, mode='reflect', size=(6, 7)),       # "full"-ish
+    ]
+    arrs = {'n': len(cases)}
+    for i, c in enumerate(cases):
+        m = MetaConv2d(c['cin'], c['cout'], c['k'], stride=c['stride'], padding=c['padding'], dilation=c['dilation'],
+                       groups=c['groups'], padding_mode=c['mode'])
+        x = torch.randn(2, c['cin'], *c['size'], generator=g)
+        w = torch.randn(2, int(m.hyper_params), generator=g)
+        arrs.update({f'{i}.x': x, f'{i}.w': w, f'{i}.y': m(x, w),
+                     f'{i}.cfg': np.array([c['cin'], c['cout'], *m.kernel_size, *m.stride, *m.padding, *m.dilation, c['groups']]),
+                     f'{i}.mode': c['mode']})
+    save('meta_conv2d_general', **arrs)
+
+
 # ------------------------------------------------------------------------------ a3 MetaPatchConv2d
 def gen_meta_patch():
     g = torch.Generator().manual_seed(2)
@@ -506,7 +533,7 @@ def gen_model_pyramid():
 
 
 if __name__ == '__main__':
-    ALL = [gen_meta_conv, gen_meta_patch, gen_meta_sequential, gen_hyper_patch, gen_ir_v1, gen_ir_v0, gen_divide_feature,
+    ALL = [gen_meta_conv, gen_meta_conv_general, gen_meta_patch, gen_meta_sequential, gen_hyper_patch, gen_ir_v1, gen_ir_v0, gen_divide_feature,
            gen_decoders, gen_train, gen_train_step, gen_confusion_matrix, gen_models, gen_model_pyramid]
     only = set(sys.argv[1:])            # e.g. "python make_golden.py gen_train_step" regenerates one fixture family
     for fn in ALL:

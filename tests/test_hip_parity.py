@@ -147,12 +147,19 @@ def test_meta_conv2d(golden, dev):
     for i in range(int(g['n'])):
         cin, cout, k, pad, groups = [int(v) for v in g[f'{i}.cfg']]
         m = MetaConv2d(cin, cout, k, padding=pad, groups=groups, padding_mode=str(g[f'{i}.mode']))
-        if 2 * pad != k - 1:
-            with pytest.raises(Exception):     # "valid" convs are not instantiated by any reference config
-                m(g[f'{i}.x'].to(dev), g[f'{i}.w'].to(dev))
-            continue
-        with torch.no_grad():
+        with torch.no_grad():          # "valid" convs (2 pad != k - 1) take the general kernel
             cmp(m(g[f'{i}.x'].to(dev), g[f'{i}.w'].to(dev)), g[f'{i}.y'], what=f'meta_conv2d {i}')
+    # the rest of the reference's argument set: non-square kernels, stride, dilation, any padding (hs_meta_conv_fwd)
+    g = golden('meta_conv2d_general')
+    for i in range(int(g['n'])):
+        cin, cout, kh, kw, sh, sw, ph, pw, dh, dw, groups = [int(v) for v in g[f'{i}.cfg']]
+        m = MetaConv2d(cin, cout, (kh, kw), stride=(sh, sw), padding=(ph, pw), dilation=(dh, dw), groups=groups,
+                       padding_mode=str(g[f'{i}.mode']))
+        with torch.no_grad():
+            y = m(g[f'{i}.x'].to(dev), g[f'{i}.w'].to(dev))
+        cmp(y, g[f'{i}.y'], what=f'general meta_conv2d {i}')
+    with pytest.raises(NotImplementedError):               # no backward kernel behind the general form
+        m(g[f'{i}.x'].to(dev).requires_grad_(), g[f'{i}.w'].to(dev))
 
 
 def test_meta_patch_conv2d(golden, dev):

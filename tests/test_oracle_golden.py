@@ -30,6 +30,17 @@ def test_meta_conv2d(golden):
         assert rel_err(y, g[f'{i}.y']) < TOL, i
 
 
+def test_meta_conv2d_general(golden):
+    """MetaConv2d with non-square kernels, stride, dilation, any padding (meta_conv.py:141-186): reference-made outputs."""
+    g = golden('meta_conv2d_general')
+    for i in range(int(g['n'])):
+        cin, cout, kh, kw, sh, sw, ph, pw, dh, dw, groups = [int(v) for v in g[f'{i}.cfg']]
+        y = O.meta_conv2d(g[f'{i}.x'], g[f'{i}.w'], cout, (kh, kw), stride=(sh, sw), padding=(ph, pw), dilation=(dh, dw),
+                          groups=groups, padding_mode=str(g[f'{i}.mode']))
+        assert tuple(y.shape) == tuple(g[f'{i}.y'].shape)
+        assert rel_err(y, g[f'{i}.y']) < 1e-5, i
+
+
 def test_meta_patch_conv2d(golden):
     g = golden('meta_patch_conv2d')
     for i in range(int(g['n'])):
