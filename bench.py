@@ -24,6 +24,9 @@ Extra objects on the line:
                 WRITE_SIZE passes of THIS command made in the same session (tools/gpu_round.sh does that).
   parity        the replayed output of the benched configuration vs the eager STOCK-encoder model on the same batch
                 (outside the timed regions): max tensor-relative error, argmax flips where the stock margin > 1e-4.
+  exact_f32     the same step (one timed region) with the fused inverted-residual levels on the exact-f32 matrix cores
+                (hs_set_ir_math('f32')); the headline `value` uses config.ir_math (auto: f16 split products at f32-class
+                accuracy on the level-4 block).  N = 1 only.
   fps_reference_protocol  hyperseg/test_fps.py's protocol (per iteration sync -> H2D of a pinned batch -> eager forward ->
                 sync; hyperseg_amd/fps.py) on the same model, N = 1 only.
   cpu_baseline  the CPU oracle ("port": stock encoder on CPU + oracle/cpu_port.py decoder) timed on the host cores of
@@ -482,6 +485,36 @@ def main():
                               'algorithmic_bytes': alg_bytes,
                               'hbm_frac_of_8TBs': round(alg_bytes / (dec_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                               'launches': launches}
+            if world == 1 and graph is not None:
+                # ---- the same step with the fused inverted-residual levels on the EXACT f32 matrix cores (hs_ir_math) ----
+                import hyperseg_amd.functional as HFm
+                prev_math = HFm.set_ir_math('f32')
+                try:
+                    for _ in range(3):
+                        y2 = forward(x)
+                    torch.cuda.synchronize()
+                    g2 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g2):
+                        y2 = forward(x)
+                    for _ in range(args.warmup):
+                        g2.replay()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(args.steps):
+                        g2.replay()
+                    torch.cuda.synchronize()
+                    el = time.perf_counter() - t0
+                    launches2, _, _ = instrumented_decoder(model, x, max(10, min(args.steps, 50)))
+                    dom2 = max([l for l in launches2 if l['in_decoder']], key=lambda l: l['avg_us'])
+                    out['exact_f32'] = {'value': round(args.steps * batch / el, 2), 'unit': 'frames/s',
+                                        'ms_per_step': round(1e3 * el / args.steps, 4), 'regions': 1,
+                                        'dominant_launch_us': dom2['avg_us'],
+                                        'max_abs_diff_vs_benched': float((y2 - y_bench).abs().max()) if args.output != 'masks' else None,
+                                        'note': 'HS_IR_MATH=f32: v_mfma_f32_16x16x4_f32 everywhere; the headline value uses '
+                                                'config.ir_math'}
+                    del g2
+                finally:
+                    HFm.set_ir_math(prev_math)
             if world == 1:
                 # ---- the reference harness' own protocol (sync + pinned H2D + eager forward per iteration) -------------
                 from hyperseg_amd.fps import measure_fps, synthetic_batches
