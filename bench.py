@@ -21,7 +21,7 @@ Extra objects on the line:
   roofline      the dominant decoder kernel: algorithmic FLOPs or bytes per launch / its average duration measured with
                 HIP events on the launch stream over instrumented eager passes right after the timed regions (a graph
                 replay cannot host events).  `traffic` is null unless --traffic-dir names rocprofv3 --pmc FETCH_SIZE /
-                WRITE_SIZE passes of THIS command made in the same session (tools/gpu_round.sh does that).
+                WRITE_SIZE passes of THIS command made in the same session (tools/gpu_round2.sh does that).
   parity        the replayed output of the benched configuration vs the eager STOCK-encoder model on the same batch
                 (outside the timed regions): max tensor-relative error, argmax flips where the stock margin > 1e-4.
   exact_f32     the same step (one timed region) with the fused inverted-residual levels on the exact-f32 matrix cores

@@ -137,3 +137,40 @@ def test_shard_batch():
     assert shard_batch(32, 0, 1) == (0, 32)
     with pytest.raises(ValueError):
         shard_batch(32, 0, 5)
+
+
+@pytest.mark.gpu
+def test_gatherer_on_the_rccl_path_single_gpu():
+    """The nccl (= RCCL) code path of LogitsGatherer on the one GPU a test box has (world size 1): asynchronous
+    all_gather_into_tensor / gather on RCCL's stream, the returned tensor READ by kernels enqueued after submit (ADVICE r1:
+    nothing exercised the CUDA path), ring slots re-targeted only after their consumer was served."""
+    if not torch.cuda.is_available():
+        pytest.fail('needs the MI355X')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    try:
+        for mode in ('allgather', 'gather'):
+            shape = (2, 19, 32, 64)
+            g = LogitsGatherer(1, shape, torch.float32, dev, mode=mode)
+            sums = []
+            for i in range(7):
+                y = torch.full(shape, float(i), device=dev)
+                y.mul_(1.0)                                   # "compute" of step i on the caller's stream
+                prev = g.submit(i, y)
+                y.fill_(-1.0)                                 # the graph's static output is overwritten by the next replay
+                if prev is not None:
+                    step, out = prev
+                    assert tuple(out.shape) == (1,) + shape
+                    sums.append((step, out.sum()))           # a kernel on the caller's stream reads the collected tensor
+            for step, out in g.drain():
+                sums.append((step, out.sum()))
+            torch.cuda.synchronize()
+            n = float(torch.Size(shape).numel())
+            assert [s for s, _ in sums] == list(range(7))
+            assert [float(v) for _, v in sums] == [n * i for i in range(7)]
+            assert g.completed == 7
+    finally:
+        dist.destroy_process_group()

@@ -28,8 +28,14 @@ except Exception as e:
     print('bench parse failed', e); print(open('gpurun_out/bench_$tag.err').read()[-1500:])
 PY
 if [ "$mode" = full ]; then
+  # HyperSeg-L: HBM traffic of its dominant launch as well
+  rm -rf /tmp/pmc_bench_l; mkdir -p /tmp/pmc_bench_l
+  for c in FETCH_SIZE WRITE_SIZE; do
+    ( cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_bench_l/$c -- python $R/bench.py --model l --no-extras --steps 4 --warmup 2 --repeats 1 --no-graph > /tmp/pmc_bench_l_$c.log 2>&1 )
+  done
   for m in s l sc; do
-    timeout 600 python bench.py --model $m --steps 20 --warmup 5 > gpurun_out/bench_${tag}_$m.json 2> gpurun_out/bench_${tag}_$m.err
+    extra=""; [ "$m" = l ] && extra="--traffic-dir /tmp/pmc_bench_l"
+    timeout 600 python bench.py --model $m --steps 20 --warmup 5 $extra > gpurun_out/bench_${tag}_$m.json 2> gpurun_out/bench_${tag}_$m.err
     python - <<PY
 import json
 try:
@@ -44,3 +50,4 @@ PY
     f=$(find /tmp/prof_bench -name '*kernel_stats.csv' | head -1)
     if [ -n "$f" ]; then cp "$f" $R/gpurun_out/bench_kernel_stats_$tag.csv; python $R/tools/kstats.py "$f" "" 14; else echo "no stats"; tail -5 /tmp/prof_bench.log; fi )
 fi
+cd $R && python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
