@@ -28,9 +28,11 @@
 // SIMD's time is the SUM of its MFMA cycles and its VALU/LDS issue cycles; software-pipelining pw1 under the depthwise
 // stage (built and measured in round 2) bought nothing.  The levers that remain are instruction count and memory
 // latency, hence: no masks or selects behind loads (operand rows past the last channel read finite neighbours and meet a
-// zero BN scale/shift instead), 32-bit offsets from uniform bases, filter-bank operands loaded one stage ahead straight
-// from the bank in HBM/L2 (nothing of the bank is staged in LDS), every prologue load in flight before the first wait.
-// Hidden activations never leave the CU.
+// zero BN scale/shift instead), 32-bit offsets from uniform bases, every prologue load in flight before the first wait,
+// and the chunk's filter-bank operands copied into a double-buffered LDS block with COALESCED loads one stage ahead
+// (STAGE below; regions that span several patches keep the direct per-lane operand loads).
+// Hidden activations never leave the CU.  The same dataflow on the f16 matrix cores (split products): hs_patch_ir_split.hip;
+// one lane per pixel with a broadcast MFMA for HyperSeg-L's narrow levels: hs_patch_ir_px.hip.
 #include "hs_ir_common.h"
 
 namespace hs {

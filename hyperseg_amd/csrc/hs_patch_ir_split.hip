@@ -24,7 +24,7 @@
 // chunk's 16 hidden channels x 3 products = 48 -> two MFMAs:  [ah*bh(0..7) | ah*bh(8..15) | al*bh(0..7) | al*bh(8..15)]
 // and [ah*bl(0..7) | ah*bl(8..15) | 0 | 0] (the zero again on the B side, read from a zeroed LDS block).
 //
-// LDS.  h1 stays f32 ([16][halo], consumed by the depthwise stage on the VALU).  h2 is written by the depthwise stage as
+// LDS.  h1 stays f32 (consumed by the depthwise stage on the VALU; channels interleaved in pairs, see SplitH1).  h2 is written by the depthwise stage as
 // two f16 planes per hidden channel ([piece][channel][pixel], 16-byte stores) and read by pw3 with ds_read_b64_tr_b16,
 // which hands each lane 4 consecutive CHANNELS of its pixel -- the transpose the B fragment needs, in the load.  The
 // chunk's weights are split ONCE per workgroup by the thread that stages them (thread = (row, 16-lane segment): the row
