@@ -46,17 +46,21 @@ template <int CIN, int CSKIP, int COUT, int HID> struct IrPxGeom {
     static constexpr int HQ = (HID + 3) / 4;                        // groups of 4 hidden channels
     static constexpr int OQ = (COUT + 3) / 4;                       // groups of 4 output channels
     static constexpr int HS = 4 * (HQ + 1 + (HQ & 1));              // h1 position stride (floats): granule count odd
+    // halo-row stride: a multiple of 16 granules, so that the lanes of the NEXT pixel row that a ds_read_b128 serves
+    // together with this row's ({0-3, 12-15} of one row with {4-11} of the next) complete the bank permutation
+    static constexpr int HR = HW * HS + 4 * ((16 - (HW * (HS / 4)) % 16) % 16);
     static constexpr int PWIN = REG / 2 + 2, PPL = PWIN * PWIN;
     static constexpr int NRING = 4 * REG + 4;
     static constexpr int NKB1 = (CIN + 15) / 16, NKB3 = (HID + 15) / 16, NKQ = (CIN + 3) / 4;
     static constexpr int F_H1 = 0;
-    static constexpr int F_WIN = F_H1 + NPOS * HS;
+    static constexpr int F_WIN = F_H1 + HW * HR;
     static constexpr int F_XR = F_WIN + ((CPREV * PPL + 3) & ~3);
     static constexpr int F_WA1 = F_XR + NRING * CINP;               // [HQ][NKB1][64]: lane 4t + i <- W1[4g + i][16 kb + t]
     static constexpr int F_WA3 = F_WA1 + HQ * NKB1 * 64;            // [OQ][NKB3][64]: lane 4t + i <- W3[4og + i][16 kb + t]
     static constexpr int F_WR = F_WA3 + OQ * NKB3 * 64;             // [HQ][NKQ][64]: lane 16s + 4t + i <- W1_side s[4g + i][4 kq + t]
     static constexpr int F_KD = F_WR + HQ * NKQ * 64;               // [9 taps][4 HQ]
-    static constexpr int FLOATS = F_KD + 9 * 4 * HQ;
+    static constexpr int F_BN = F_KD + 9 * 4 * HQ;                  // folded BatchNorm rows [s1 | b1 | s2 | b2] x 4 HQ, [s3 | b3] x 4 OQ
+    static constexpr int FLOATS = F_BN + 4 * 4 * HQ + 2 * 4 * OQ;
 };
 
 template <int CBSZ, int ABID>
@@ -78,17 +82,18 @@ template <int CIN, int CSKIP, int COUT, int HID>
 __global__ __launch_bounds__(256)
 void patch_ir_px_kernel(IrFusedArgs a) {
     using G = IrPxGeom<CIN, CSKIP, COUT, HID>;
-    constexpr int REG = G::REG, HW = G::HW, CPREV = G::CPREV, CINP = G::CINP, HQ = G::HQ, OQ = G::OQ, HS = G::HS;
+    constexpr int REG = G::REG, HW = G::HW, CPREV = G::CPREV, CINP = G::CINP, HQ = G::HQ, OQ = G::OQ, HS = G::HS, HR = G::HR;
     constexpr int PWIN = G::PWIN, PPL = G::PPL, NRING = G::NRING, NKB1 = G::NKB1, NKB3 = G::NKB3, NKQ = G::NKQ;
     static_assert(CPREV > 0 && CSKIP > 0, "fused form: coords + skip + previous level");
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* h1 = lds + G::F_H1;            // [position][HS]
+    float* h1 = lds + G::F_H1;            // [halo row][HR] of [halo column][HS]
     float* win = lds + G::F_WIN;          // [CPREV][PWIN * PWIN]
     float* xr = lds + G::F_XR;            // [ring position][CINP]
     float* wa1 = lds + G::F_WA1;
     float* wa3 = lds + G::F_WA3;
     float* wr = lds + G::F_WR;
     float* kdt = lds + G::F_KD;
+    float* bnl = lds + G::F_BN;           // BN rows, zero beyond the real channels (uniform reads: LDS broadcasts)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int blk = blockIdx.x;                 // XCD-contiguous region ranges (as the tiled kernels)
@@ -172,6 +177,16 @@ void patch_ir_px_kernel(IrFusedArgs a) {
         const int tap = e / (4 * HQ), h = e - tap * (4 * HQ);
         gk[q] = h < HID ? own[CIN * HID + h * 9 + tap] : 0.0f;
     }
+    // folded BatchNorm rows (one element per thread: 4 * 4 HQ + 2 * 4 OQ <= 256)
+    constexpr int NBN = 4 * 4 * HQ + 2 * 4 * OQ;
+    static_assert(NBN <= 256, "BN rows: one element per thread");
+    float gbn = 0.0f;
+    if (tid < NBN) {
+        const int seg = tid < 16 * HQ ? tid / (4 * HQ) : 4 + (tid - 16 * HQ) / (4 * OQ);
+        const int idx = tid < 16 * HQ ? tid - seg * (4 * HQ) : (tid - 16 * HQ) - (seg - 4) * (4 * OQ);
+        const float* src = seg == 0 ? a.s1 : seg == 1 ? a.b1 : seg == 2 ? a.s2 : seg == 3 ? a.b2 : seg == 4 ? a.s3 : a.b3;
+        if (idx < (seg < 4 ? HID : COUT)) gbn = src[idx];
+    }
     // (3) skip features of this thread's pixel (and of its ring position)
     const int yy_i = y0 + ty, xx_i = x0 + tx;
     int yy_r = y0, xx_r = x0;
@@ -196,7 +211,8 @@ void patch_ir_px_kernel(IrFusedArgs a) {
     for (int q = 0; q < QR; ++q) { const int e = tid + q * 256; if (e < NR) wr[e] = gr[q]; }
 #pragma unroll
     for (int q = 0; q < QK; ++q) { const int e = tid + q * 256; if (e < NK) kdt[e] = gk[q]; }
-    __syncthreads();                                       // window + filter banks in LDS
+    if (tid < NBN) bnl[tid] = gbn;
+    __syncthreads();                                       // window + filter banks + BN rows in LDS
 
     // input vector of pixel (yy, xx): [x coordinate, y coordinate, skip.., bilinear previous level..]
     auto build_x = [&](int yy, int xx, const float (&sk)[CSKIP], float (&x)[CINP]) {
@@ -231,7 +247,7 @@ void patch_ir_px_kernel(IrFusedArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int h = min(4 * g + r, HID - 1);
-            o[r] = 4 * g + r < HID ? relu6_(fmaf(acc[r], a.s1[h], a.b1[h])) : 0.0f;
+            o[r] = 4 * g + r < HID ? relu6_(fmaf(acc[r], bnl[h], bnl[4 * HQ + h])) : 0.0f;
         }
         *reinterpret_cast<float4*>(dst + 4 * g) = make_float4(o[0], o[1], o[2], o[3]);
     };
@@ -249,7 +265,7 @@ void patch_ir_px_kernel(IrFusedArgs a) {
             if (kb == NKB1 - 1) bcast_chains<4, CIN - 16 * (NKB1 - 1), HQ>(wv, xi + 16 * kb, acc);
             else bcast_chains<4, 16, HQ>(wv, xi + 16 * kb, acc);
         }
-        float* dst = h1 + ((ty + 1) * HW + tx + 1) * HS;
+        float* dst = h1 + (ty + 1) * HR + (tx + 1) * HS;
 #pragma unroll
         for (int g = 0; g < HQ; ++g) store_h1(dst, g, acc[g]);
     }
@@ -265,7 +281,7 @@ void patch_ir_px_kernel(IrFusedArgs a) {
             const float4 t = *reinterpret_cast<const float4*>(xr + lane * CINP + 4 * q);
             xe[4 * q] = t.x; xe[4 * q + 1] = t.y; xe[4 * q + 2] = t.z; xe[4 * q + 3] = t.w;
         }
-        float* dst = h1 + (u * HW + v) * HS;
+        float* dst = h1 + u * HR + v * HS;
 #pragma unroll
         for (int gi = 0; gi < (HQ + 3) / 4; ++gi) {
             const int g = wave + 4 * gi;                   // wave-uniform
@@ -290,7 +306,7 @@ void patch_ir_px_kernel(IrFusedArgs a) {
             float acc = 0.0f;
 #pragma unroll
             for (int c = 0; c < CIN; ++c) acc = fmaf(wrow[c], xc[c], acc);
-            h1[(u * HW + v) * HS + h] = relu6_(fmaf(acc, a.s1[h], a.b1[h]));
+            h1[u * HR + v * HS + h] = relu6_(fmaf(acc, bnl[h], bnl[4 * HQ + h]));
         }
     }
     __syncthreads();                                       // h1 complete
@@ -303,7 +319,7 @@ void patch_ir_px_kernel(IrFusedArgs a) {
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            const float* src = h1 + ((ty + ky) * HW + tx + kx) * HS;
+            const float* src = h1 + (ty + ky) * HR + (tx + kx) * HS;
             const float* kt = kdt + (ky * 3 + kx) * (4 * HQ);
 #pragma unroll
             for (int q = 0; q < HQ; ++q) {
@@ -314,7 +330,7 @@ void patch_ir_px_kernel(IrFusedArgs a) {
             }
         }
 #pragma unroll
-    for (int h = 0; h < HID; ++h) h2[h] = relu6_(fmaf(h2[h], a.s2[h], a.b2[h]));
+    for (int h = 0; h < HID; ++h) h2[h] = relu6_(fmaf(h2[h], bnl[8 * HQ + h], bnl[12 * HQ + h]));
 #pragma unroll
     for (int h = HID; h < 4 * HQ; ++h) h2[h] = 0.0f;
 
@@ -336,7 +352,7 @@ void patch_ir_px_kernel(IrFusedArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int o = 4 * og + r;
-            if (o < COUT) yo[(size_t)o * plane] = fmaf(acc3[og][r], a.s3[o], a.b3[o]);
+            if (o < COUT) yo[(size_t)o * plane] = fmaf(acc3[og][r], bnl[16 * HQ + o], bnl[16 * HQ + 4 * OQ + o]);
         }
 }
 

@@ -12,7 +12,7 @@ for group in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTI
              "SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_WAIT_INST_VMEM SQ_ACTIVE_INST_SCA"; do
   i=$((i+1))
   rm -rf /tmp/pmc_$i
-  timeout 120 rocprofv3 --pmc $group --kernel-trace --output-format csv -d /tmp/pmc_$i -- python $R/tools/prof_decoder.py M 20 > /tmp/pmc_$i.log 2>&1
+  timeout 120 rocprofv3 --pmc $group --kernel-trace --output-format csv -d /tmp/pmc_$i -- python $R/tools/prof_decoder.py ${PMC_CFG:-M} ${PMC_ITERS:-20} > /tmp/pmc_$i.log 2>&1
   f=$(find /tmp/pmc_$i -name '*counter_collection.csv' | head -1)
   if [ -n "$f" ]; then
     python - "$f" > $R/gpurun_out/pmc_${tag}_$i.txt <<'PY'
