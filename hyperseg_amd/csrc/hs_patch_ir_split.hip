@@ -114,8 +114,8 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(v - (float)hi);
 }
 
-template <int CIN, int CSKIP, int COUT, int REG, int MODE, int NW>
-__global__ __launch_bounds__(64 * NW, NW / 2)
+template <int CIN, int CSKIP, int COUT, int REG, int MODE, int NW, int WPS>
+__global__ __launch_bounds__(64 * NW, WPS)
 void patch_ir_split_kernel(IrFusedArgs a) {
     // NW waves per workgroup.  4 everywhere: 8 (half the tiles per wave, 4 waves per SIMD) measured SLOWER, 31.4 vs 28.6 us
     // at HyperSeg-M level 4 -- the kernel is bound by VALU issue slots, and per-thread overheads double with the threads.
@@ -597,7 +597,7 @@ void patch_ir_split_kernel(IrFusedArgs a) {
     }
 }
 
-template <int CIN, int CSKIP, int COUT, int REG, int MODE, int NW>
+template <int CIN, int CSKIP, int COUT, int REG, int MODE, int NW, int WPS>
 static int launch_irs(IrFusedArgs& a, hipStream_t stream) {
     using G = IrfGeom<REG>;
     using OP = SplitOps<CIN, COUT, MODE>;
@@ -614,11 +614,11 @@ static int launch_irs(IrFusedArgs& a, hipStream_t stream) {
     if (lds > 160 * 1024) return HS_ERR_LDS;
     if (lds > 64 * 1024) {
         static std::atomic<unsigned long long> done{0};
-        const int e = allow_full_lds((const void*)patch_ir_split_kernel<CIN, CSKIP, COUT, REG, MODE, NW>, done);
+        const int e = allow_full_lds((const void*)patch_ir_split_kernel<CIN, CSKIP, COUT, REG, MODE, NW, WPS>, done);
         if (e != HS_OK) return e;
     }
     const long blocks = (long)a.in.B * a.regs_y * a.regs_x;
-    hipLaunchKernelGGL((patch_ir_split_kernel<CIN, CSKIP, COUT, REG, MODE, NW>), dim3((unsigned)blocks), dim3(64 * NW),
+    hipLaunchKernelGGL((patch_ir_split_kernel<CIN, CSKIP, COUT, REG, MODE, NW, WPS>), dim3((unsigned)blocks), dim3(64 * NW),
                        lds, stream, a);
     return launch_status();
 }
@@ -643,12 +643,14 @@ int try_launch_ir_split(int mode, IrFusedArgs& a, int cin, int c_skip, int c_out
     const int math = ir_math();
     if (math == 1) return 1;
     const int p = a.ph;
-#define HS_IRS_CASE(CI, CS, CO, REG, MODE) \
-    if (cin == CI && c_skip == CS && c_out == CO) return launch_irs<CI, CS, CO, REG, MODE, 4>(a, stream);
+#define HS_IRS_CASE(CI, CS, CO, REG, MODE) HS_IRS_CASE_W(CI, CS, CO, REG, MODE, 2)
+#define HS_IRS_CASE_W(CI, CS, CO, REG, MODE, WPS) \
+    if (cin == CI && c_skip == CS && c_out == CO) return launch_irs<CI, CS, CO, REG, MODE, 4, WPS>(a, stream);
     if (mode == 0) {
         if (p % 16 == 0) {
             HS_IRS_CASE(34, 16, 19, 16, 0)   // HyperSeg-M level 4
-            HS_IRS_CASE(26, 16, 19, 16, 0)   // HyperSeg-S level 4
+            HS_IRS_CASE(26, 16, 19, 16, 0)   // HyperSeg-S level 4 (a third workgroup per CU -- 168 VGPRs, 30 spilled -- measured
+                                             // slower at 1536x768: 56.8 vs ~50 us)
             HS_IRS_CASE(22, 4, 12, 16, 0)    // CamVid-S level 4
             HS_IRS_CASE(24, 6, 16, 16, 0)
         }
@@ -665,6 +667,7 @@ int try_launch_ir_split(int mode, IrFusedArgs& a, int cin, int c_skip, int c_out
         HS_IRS_CASE(11, 3, 21, 16, 1)
     }
 #undef HS_IRS_CASE
+#undef HS_IRS_CASE_W
     return 1;
 }
 
