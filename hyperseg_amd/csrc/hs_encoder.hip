@@ -17,7 +17,11 @@ namespace hs {
 // PL >= 0: the left padding is the compile-time constant PL and W % 4 == 0 -- every tap row is then fetched as aligned
 // 16-byte loads (3-4 per row instead of 6-11 dword loads; the kernel is bound by the texture-address path, which spends
 // the same cycles on a 4-byte as on a 16-byte per-lane access).  PL = -1: arbitrary pad_l / W, dword loads.
-template <int K, int S, int PL>
+// TILE (only with the BN0 + swish prologue, whole output rows per workgroup): the workgroup's input band goes through LDS
+// ONCE, with the prologue applied once per input element -- on load from L1 every tap of every output re-applied it
+// (K*(3S+K)/4 = 8.75 swishes per output at K = 5: the batch-32 launches of HyperSeg-L were bound by exactly that: 90 us
+// per 5x5 launch) -- zero padding materialised in the tile, tap rows read back as aligned ds_read_b128.
+template <int K, int S, int PL, bool TILE>
 __global__ __launch_bounds__(256)
 void depthwise_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
                            const float* __restrict__ shift, float* __restrict__ y, int C, int H, int W, int Ho, int Wo,
@@ -34,16 +38,47 @@ void depthwise_conv_kernel(const float* __restrict__ x, const float* __restrict_
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = q < Ho * wq;
     float psum = 0.0f;
+    const float* __restrict__ xp = x + (size_t)plane * H * W;
+    extern __shared__ __attribute__((aligned(16))) float dw_tile[];
+    const int tw = ((Wo - 1) * S + K + 3) & ~3;                    // TILE: tile row = input columns [-pad_l, -pad_l + tw)
+    const int yo0 = (int)(blockIdx.x * blockDim.x) / wq;           // TILE: first output row of this workgroup (wq | blockDim.x)
+    if constexpr (TILE) {
+        const int rows_out = (int)blockDim.x / wq, rows_in = (rows_out - 1) * S + K;
+        for (int e = threadIdx.x; e < rows_in * tw; e += blockDim.x) {
+            const int r = e / tw, t = e - r * tw;
+            const int yi = yo0 * S - pad_t + r, xi = t - pad_l;
+            float val = 0.0f;
+            if (yi >= 0 && yi < H && xi >= 0 && xi < W) {
+                val = xp[(size_t)yi * W + xi];
+                if (pre) val = swishf(fmaf(val, isc, ish));
+            }
+            dw_tile[e] = val;
+        }
+        __syncthreads();
+    }
     if (live) {
     const int yo = q / wq, xo = (q - yo * wq) * 4;
-    const float* __restrict__ xp = x + (size_t)plane * H * W;
     const float* __restrict__ wc = w + (size_t)c * K * K;          // uniform -> scalar loads
     constexpr int NCOL = 3 * S + K;                                // input columns feeding 4 outputs
     const int xi0 = xo * S - pad_l, yi0 = yo * S - pad_t;
     // every tap of the K x NCOL window is loaded BEFORE the first use (clamped addresses, masks applied afterwards): a
     // row-by-row load/fma interleaving exposes one memory round trip per tap row
     float v[K][NCOL];
-    if constexpr (PL >= 0) {
+    if constexpr (TILE) {
+        constexpr int NV = (NCOL + 3) / 4;
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const float* row = dw_tile + ((yo - yo0) * S + ky) * tw + xo * S;      // 16-byte aligned: tw, xo multiples of 4
+            float win[NV * 4];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const float4 t = *reinterpret_cast<const float4*>(row + 4 * i);   // tw - xo * S is a multiple of 4 and >= NCOL
+                win[4 * i] = t.x; win[4 * i + 1] = t.y; win[4 * i + 2] = t.z; win[4 * i + 3] = t.w;
+            }
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) v[ky][j] = win[j];
+        }
+    } else if constexpr (PL >= 0) {
         constexpr int OFF = (4 - PL % 4) % 4;                      // xi0 = 4*q*S - PL: misalignment of the window start
         constexpr int NV = (OFF + NCOL + 3) / 4;
         const int a0 = xi0 - OFF;                                  // multiple of 4
@@ -75,13 +110,15 @@ void depthwise_conv_kernel(const float* __restrict__ x, const float* __restrict_
     for (int ky = 0; ky < K; ++ky) {
         const int yi = yi0 + ky;
         const bool row_ok = yi >= 0 && yi < H;
+        if constexpr (!TILE) {
 #pragma unroll
-        for (int j = 0; j < NCOL; ++j) {
-            const int xi = xi0 + j;
-            const bool ok = row_ok && xi >= 0 && xi < W;
-            float t = v[ky][j];
-            if (pre) t = swishf(fmaf(t, isc, ish));
-            v[ky][j] = ok ? t : 0.0f;
+            for (int j = 0; j < NCOL; ++j) {
+                const int xi = xi0 + j;
+                const bool ok = row_ok && xi >= 0 && xi < W;
+                float t = v[ky][j];
+                if (pre) t = swishf(fmaf(t, isc, ish));
+                v[ky][j] = ok ? t : 0.0f;
+            }
         }
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) {
@@ -267,8 +304,24 @@ extern "C" int hs_depthwise_conv_fwd(const float* x, int32_t batch, int32_t chan
     const int gy = nplanes > 65535 ? 32768 : (int)nplanes;
     dim3 grid((quads + threads - 1) / threads, gy, (unsigned)((nplanes + gy - 1) / gy));
     hipStream_t s = (hipStream_t)stream;
-#define HS_DW(KK, SS, PP) hipLaunchKernelGGL((depthwise_conv_kernel<KK, SS, PP>), grid, dim3(threads), 0, s, x, w, scale, shift, \
+#define HS_DW(KK, SS, PP) hipLaunchKernelGGL((depthwise_conv_kernel<KK, SS, PP, false>), grid, dim3(threads), 0, s, x, w, scale, shift, \
                                              y, channels, H, W, Ho, Wo, pad_t, pad_l, act, pool_partial, in_scale, in_shift, (int)nplanes)
+    // the LDS-tiled form: BN0 + swish prologue, whole output rows per workgroup (same thread -> output map, same partials)
+    const int wq = Wo / 4;
+    // Only for batched work (>= 8192 planes) on planes of >= 256 output quads: a batch-1 encoder's launches are latency-bound
+    // and the extra barrier costs more than the taps' swishes (HyperSeg-M: 1009 vs 1020 frames/s with it on everywhere).
+    if (in_scale && nplanes >= 8192 && threads == 256 && (Wo & 3) == 0 && threads % wq == 0 && (k == 3 || k == 5) &&
+        (stride == 1 || stride == 2)) {
+        const int rows_out = threads / wq, rows_in = (rows_out - 1) * stride + k, tw = ((Wo - 1) * stride + k + 3) & ~3;
+        const size_t lds = (size_t)rows_in * tw * sizeof(float);
+        if (lds <= 64 * 1024) {
+#define HS_DWT(KK, SS) hipLaunchKernelGGL((depthwise_conv_kernel<KK, SS, -1, true>), grid, dim3(threads), lds, s, x, w, scale, shift, y, \
+                                          channels, H, W, Ho, Wo, pad_t, pad_l, act, pool_partial, in_scale, in_shift, (int)nplanes)
+            if (k == 3 && stride == 1) HS_DWT(3, 1); else if (k == 3) HS_DWT(3, 2); else if (stride == 1) HS_DWT(5, 1); else HS_DWT(5, 2);
+#undef HS_DWT
+            return launch_status();
+        }
+    }
     const bool vec = (W & 3) == 0 && (((size_t)x) & 15) == 0;
     if (k == 3 && stride == 1) { if (vec && pad_l == 1) HS_DW(3, 1, 1); else HS_DW(3, 1, -1); }
     else if (k == 3 && stride == 2) { if (vec && pad_l == 0) HS_DW(3, 2, 0); else if (vec && pad_l == 1) HS_DW(3, 2, 1); else HS_DW(3, 2, -1); }

@@ -33,7 +33,8 @@ def swish(t):
 
 
 @pytest.mark.parametrize('k,stride,h,w,pre', [(3, 1, 16, 32, False), (3, 2, 33, 47, False), (5, 1, 16, 32, True),
-                                              (5, 2, 64, 128, True), (3, 1, 7, 9, True), (5, 1, 130, 70, False)])
+                                              (5, 2, 64, 128, True), (3, 1, 7, 9, True), (5, 1, 130, 70, False),
+                                              (3, 1, 32, 32, True), (5, 1, 32, 32, True), (3, 2, 64, 64, True), (5, 1, 40, 32, True)])
 def test_depthwise_conv(HF, dev, k, stride, h, w, pre):
     g = torch.Generator().manual_seed(k * 100 + stride * 10 + h)
     b, c = 2, 13
@@ -53,6 +54,27 @@ def test_depthwise_conv(HF, dev, k, stride, h, w, pre):
     assert rel_err(y.cpu(), ref) < REL_TOL
     pooled = partial.cpu().sum(1).view(b, c) / (ho * wo)
     assert rel_err(pooled, ref.mean((2, 3))) < REL_TOL
+
+
+@pytest.mark.parametrize('k,stride,h,w', [(5, 1, 32, 32), (3, 1, 32, 32), (3, 2, 64, 64), (5, 2, 63, 64), (5, 1, 40, 32), (3, 1, 16, 64)])
+def test_depthwise_conv_tiled_batched(HF, dev, k, stride, h, w):
+    """The LDS-tiled form (BN0 + swish prologue applied once per input element; taken for >= 8192 planes of >= 256 output
+    quads, i.e. the batched HyperSeg-L encoder): 8 x 1024 planes, incl. a last workgroup with dead rows (40 x 32)."""
+    g = torch.Generator().manual_seed(k * 100 + stride * 10 + h)
+    b, c = 8, 1024
+    x = torch.randn(b, c, h, w, generator=g)
+    wt = torch.randn(c, 1, k, k, generator=g) * 0.3
+    scale, shift = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1
+    isc, ish = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1
+    ho, wo = -(-h // stride), -(-w // stride)
+    ph, pw = max((ho - 1) * stride + k - h, 0), max((wo - 1) * stride + k - w, 0)
+    xin = swish(x * isc.view(1, -1, 1, 1) + ish.view(1, -1, 1, 1))
+    ref = F.conv2d(F.pad(xin, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2)), wt, stride=stride, groups=c)
+    ref = swish(ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    y, partial = HF.depthwise_conv_bn_act(x.to(dev), wt.to(dev), stride, ph // 2, pw // 2, (ho, wo), scale.to(dev),
+                                          shift.to(dev), act=3, pool=True, in_scale=isc.to(dev), in_shift=ish.to(dev))
+    assert rel_err(y.cpu(), ref) < REL_TOL
+    assert rel_err(partial.cpu().sum(1).view(b, c) / (ho * wo), ref.mean((2, 3))) < REL_TOL
 
 
 def test_depthwise_conv_many_planes(HF, dev):
@@ -231,7 +253,7 @@ def test_prepared_routes_fall_back_and_refresh(dev):
     assert not fused.backbone._fused_ok(x)
     with torch.no_grad():
         for a, b in zip(stock.backbone(x), fused.backbone(x)):
-            assert torch.equal(a, b)
+            assert rel_err(b.cpu(), a.cpu()) < 1e-5           # both run the stock route (MIOpen may pick different solvers per call)
         x2 = torch.rand(1, 3, 256, 512, device=dev)
         assert fused.backbone._fused_ok(x2)
     # (2) autograd through an eval-mode prepared backbone
