@@ -75,12 +75,14 @@ GEMM_LT_MIN_PIXELS = int(os.environ.get('HS_GEMM_LT_MIN_PIXELS', '16384'))      
 
 
 @contextlib.contextmanager
-def gemm_library(pixels):
+def gemm_library(pixels, batch=1):
     """Which BLAS backs the bare fp32 GEMMs of the 1x1 convolutions (ROCm 7.2, measured per layer under graph replay,
     profiles/round1_frame_sequence*.txt): hipBLASLt for the few-channel / many-pixel project convs of the first stages
     (24 x 32768 x 144: 9.8 us vs rocBLAS 21.3), rocBLAS for everything at <= 64x128 pixels (672 x 2048 x 112: 9.1 us vs
-    hipBLASLt 19.5).  torch's names: 'cublaslt' = hipBLASLt, 'cublas' = rocBLAS.  The choice is made at call (= capture) time."""
-    want = os.environ.get('HS_BLAS') or ('cublaslt' if pixels >= GEMM_LT_MIN_PIXELS else 'cublas')
+    hipBLASLt 19.5).  Strided-BATCHED GEMMs (batch > 1): hipBLASLt throughout (HyperSeg-L bs 32: 10.50 ms per batch with
+    hipBLASLt everywhere, 10.77 with the single-frame rule, 11.68 with rocBLAS everywhere; gpurun r3h).
+    torch's names: 'cublaslt' = hipBLASLt, 'cublas' = rocBLAS.  The choice is made at call (= capture) time."""
+    want = os.environ.get('HS_BLAS') or ('cublaslt' if (pixels >= GEMM_LT_MIN_PIXELS or batch > 1) else 'cublas')
     prev = torch.backends.cuda.preferred_blas_library()
     torch.backends.cuda.preferred_blas_library(want)
     try:
@@ -122,7 +124,7 @@ class FusedPointwise(nn.Module):
         """The bare GEMM: W (Cout, Cin) @ x (Cin, HW) per frame (a strided-batched GEMM with a shared A for a batch); BN +
         activation are left to the consumer."""
         b, cin, h, w = x.shape
-        with gemm_library(h * w):
+        with gemm_library(h * w, b):
             if b == 1:
                 return torch.mm(self.conv.weight.view(-1, cin), x.view(cin, h * w)).view(1, -1, h, w)
             # bmm with the weight expanded over the batch (stride 0): matmul(2-D, 3-D) would go through transposed copies
@@ -141,7 +143,8 @@ class FusedPointwise(nn.Module):
         if (h * w) % 4 != 0:
             raise NotImplementedError('feature maps with H*W % 4 != 0')
         if gate is None:
-            y = F.conv2d(x, conv.weight)
+            # batches: one strided-batched GEMM (MIOpen would go NCHW -> NHWC -> implicit GEMM -> NCHW)
+            y = F.conv2d(x, conv.weight) if b == 1 else self.raw(x)
         else:
             y = F.conv2d(x * gate[:, :, None, None], conv.weight)
         return HF.affine_act_(y, self.scale, self.shift, self.act, residual)
@@ -258,7 +261,7 @@ class FusedMBConv(nn.Module):
             wp = HF.se_gate(partial, b, ho * wo, red.weight, red.bias, self._exp_t, exp.bias,
                             w_proj=proj.conv.weight, out_scale=proj.scale)
             cmid = y.shape[1]
-            with gemm_library(ho * wo):
+            with gemm_library(ho * wo, b):
                 if b == 1:
                     w2d, y2d = wp.view(-1, cmid), y.view(cmid, ho * wo)
                     if self.defer_shift:
