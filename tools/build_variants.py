@@ -57,13 +57,13 @@ def stamped_source(fname='hs_patch_ir_fused.hip'):
     return path
 
 
-def patched_source(name, replacements):
-    src = open(os.path.join(B.CSRC, 'hs_patch_ir_fused.hip')).read()
+def patched_source(name, replacements, fname='hs_patch_ir_fused.hip'):
+    src = open(os.path.join(B.CSRC, fname)).read()
     for old, new in replacements:
         assert src.count(old) == 1, old
         src = src.replace(old, new)
     os.makedirs(os.path.join(B.LIB_DIR, 'dev_src'), exist_ok=True)
-    path = os.path.join(B.LIB_DIR, 'dev_src', f'hs_patch_ir_fused_{name}.hip')
+    path = os.path.join(B.LIB_DIR, 'dev_src', fname.replace('.hip', f'_{name}.hip'))
     open(path, 'w').write(src)
     return path
 
@@ -73,6 +73,8 @@ PATCHES = {
     # dev experiments on the epilogue of the fused inverted-residual kernel (is HyperSeg-L level 5 store-bound?)
     'nostore': [(STORE_LINE, '                for (int jt = 0; jt < J3; ++jt) if (o == 0 && jt == 0) yo[yoff[jt]] = fmaf(acc3[m][jt][r], sc, sh);'
                              ' else asm volatile("" :: "v"(acc3[m][jt][r]));')],
+    # occupancy probe of the lane-per-pixel kernel: 28 KB of unused LDS -> 2 workgroups per CU instead of 3 at HyperSeg-L level 5
+    'px2wg': [('    constexpr size_t lds = (size_t)G::FLOATS * sizeof(float);', '    constexpr size_t lds = (size_t)G::FLOATS * sizeof(float) + 28 * 1024;')],
     'ntstore': [(STORE_LINE, '                for (int jt = 0; jt < J3; ++jt) __builtin_nontemporal_store(fmaf(acc3[m][jt][r], sc, sh), &yo[yoff[jt]]);')],
 }
 
@@ -81,6 +83,7 @@ VARIANTS = {
     'stamps_split': dict(flags=[], extra=[], patch=True, file='hs_patch_ir_split.hip'),
     'nostore': dict(flags=[], extra=[], patch='nostore'),
     'ntstore': dict(flags=[], extra=[], patch='ntstore'),
+    'px2wg': dict(flags=[], extra=[], patch='px2wg', file='hs_patch_ir_px.hip'),
 }
 
 if __name__ == '__main__':
@@ -90,7 +93,7 @@ if __name__ == '__main__':
         sources = list(B.SOURCES) + v['extra']
         if v.get('patch'):
             fname = v.get('file', 'hs_patch_ir_fused.hip')
-            src_path = stamped_source(fname) if v['patch'] is True else patched_source(v['patch'], PATCHES[v['patch']])
+            src_path = stamped_source(fname) if v['patch'] is True else patched_source(v['patch'], PATCHES[v['patch']], fname)
             rel = os.path.relpath(src_path, B.CSRC)
             sources = [rel if s == fname else s for s in sources]
         print(B.build(force=True, extra_flags=v['flags'], sources=sources, lib_path=path, obj_suffix='_' + name))
