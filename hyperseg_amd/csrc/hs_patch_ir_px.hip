@@ -34,30 +34,37 @@
 //   dw        thread = pixel, 9 x hid/4 ds_read_b128 of h1, taps as uniform ds_read_b128 (the depthwise stage has no
 //             outer-product structure: vector FMAs) -> BN2 -> ReLU6 in registers
 //   pw3       broadcast MFMAs again (B = the lane's h2) -> BN3 -> cout coalesced stores.
+// The hidden channels go through LDS in CHUNKS of GC groups of 4 (pw1(chunk) -> h1 | barrier | dw(chunk) in registers,
+// pw3 += W3[:, chunk] . h2 | barrier; the lane's input vector and the pw3 accumulators live in registers across chunks):
+// the h1 footprint sets the workgroups per CU, and this kernel is wait-bound -- 2 -> 3 -> 4 workgroups per CU measured
+// 565 -> 470 -> 447 us at level 5, and 277 (1) -> 169 (2) -> 121 us (4) at level 4.
 // Exact f32 (the f32 matrix cores compute fma chains).
 #include "hs_ir_common.h"
+#include <type_traits>
+#include <utility>
 
 namespace hs {
 
-template <int CIN, int CSKIP, int COUT, int HID> struct IrPxGeom {
+template <int CIN, int CSKIP, int COUT, int HID, int GC> struct IrPxGeom {
     static constexpr int REG = 16, HW = 18, NPOS = HW * HW;
     static constexpr int CPREV = CIN - 2 - CSKIP;
     static constexpr int CINP = (CIN + 3) & ~3;
     static constexpr int HQ = (HID + 3) / 4;                        // groups of 4 hidden channels
     static constexpr int OQ = (COUT + 3) / 4;                       // groups of 4 output channels
-    static constexpr int HS = 4 * (HQ + 1 + (HQ & 1));              // h1 position stride (floats): granule count odd
+    static constexpr int NCH = (HQ + GC - 1) / GC;                  // the hidden channels go through LDS in chunks of GC groups
+    static constexpr int HS = 4 * (GC + 1 + (GC & 1));              // h1 position stride (floats): granule count odd
     // halo-row stride: a multiple of 16 granules, so that the lanes of the NEXT pixel row that a ds_read_b128 serves
     // together with this row's ({0-3, 12-15} of one row with {4-11} of the next) complete the bank permutation
     static constexpr int HR = HW * HS + 4 * ((16 - (HW * (HS / 4)) % 16) % 16);
     static constexpr int PWIN = REG / 2 + 2, PPL = PWIN * PWIN;
     static constexpr int NRING = 4 * REG + 4;
-    static constexpr int NKB1 = (CIN + 15) / 16, NKB3 = (HID + 15) / 16, NKQ = (CIN + 3) / 4;
+    static constexpr int NKB1 = (CIN + 15) / 16, NKBC = (4 * GC + 15) / 16, NKQ = (CIN + 3) / 4;
     static constexpr int F_H1 = 0;
     static constexpr int F_WIN = F_H1 + HW * HR;
     static constexpr int F_XR = F_WIN + ((CPREV * PPL + 3) & ~3);
     static constexpr int F_WA1 = F_XR + NRING * CINP;               // [HQ][NKB1][64]: lane 4t + i <- W1[4g + i][16 kb + t]
-    static constexpr int F_WA3 = F_WA1 + HQ * NKB1 * 64;            // [OQ][NKB3][64]: lane 4t + i <- W3[4og + i][16 kb + t]
-    static constexpr int F_WR = F_WA3 + OQ * NKB3 * 64;             // [HQ][NKQ][64]: lane 16s + 4t + i <- W1_side s[4g + i][4 kq + t]
+    static constexpr int F_WA3 = F_WA1 + HQ * NKB1 * 64;            // [NCH][OQ][NKBC][64]: lane 4t + i <- W3[4og + i][4 GC c + 16 kb + t]
+    static constexpr int F_WR = F_WA3 + NCH * OQ * NKBC * 64;             // [HQ][NKQ][64]: lane 16s + 4t + i <- W1_side s[4g + i][4 kq + t]
     static constexpr int F_KD = F_WR + HQ * NKQ * 64;               // [9 taps][4 HQ]
     static constexpr int F_BN = F_KD + 9 * 4 * HQ;                  // folded BatchNorm rows [s1 | b1 | s2 | b2] x 4 HQ, [s3 | b3] x 4 OQ
     static constexpr int FLOATS = F_BN + 4 * 4 * HQ + 2 * 4 * OQ;
@@ -78,15 +85,22 @@ __device__ __forceinline__ void bcast_chains(const float (&wv)[NG], const float*
     }
 }
 
-template <int CIN, int CSKIP, int COUT, int HID>
+template <typename F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+template <int CIN, int CSKIP, int COUT, int HID, int GC>
 __global__ __launch_bounds__(256)
 void patch_ir_px_kernel(IrFusedArgs a) {
-    using G = IrPxGeom<CIN, CSKIP, COUT, HID>;
+    using G = IrPxGeom<CIN, CSKIP, COUT, HID, GC>;
     constexpr int REG = G::REG, HW = G::HW, CPREV = G::CPREV, CINP = G::CINP, HQ = G::HQ, OQ = G::OQ, HS = G::HS, HR = G::HR;
-    constexpr int PWIN = G::PWIN, PPL = G::PPL, NRING = G::NRING, NKB1 = G::NKB1, NKB3 = G::NKB3, NKQ = G::NKQ;
+    constexpr int PWIN = G::PWIN, PPL = G::PPL, NRING = G::NRING, NKB1 = G::NKB1, NKBC = G::NKBC, NKQ = G::NKQ, NCH = G::NCH;
     static_assert(CPREV > 0 && CSKIP > 0, "fused form: coords + skip + previous level");
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* h1 = lds + G::F_H1;            // [halo row][HR] of [halo column][HS]
+    float* h1 = lds + G::F_H1;            // [halo row][HR] of [halo column][HS]: the current chunk's hidden channels
     float* win = lds + G::F_WIN;          // [CPREV][PWIN * PWIN]
     float* xr = lds + G::F_XR;            // [ring position][CINP]
     float* wa1 = lds + G::F_WA1;
@@ -144,7 +158,7 @@ void patch_ir_px_kernel(IrFusedArgs a) {
         }
     }
     // (2) the filter banks, straight into the lane order of the broadcast MFMA's A operand (zero beyond the real channels)
-    constexpr int N1 = HQ * NKB1 * 64, N3 = OQ * NKB3 * 64, NR = HQ * NKQ * 64, NK = 9 * 4 * HQ;
+    constexpr int N1 = HQ * NKB1 * 64, N3 = NCH * OQ * NKBC * 64, NR = HQ * NKQ * 64, NK = 9 * 4 * HQ;
     constexpr int Q1 = (N1 + 255) / 256, Q3 = (N3 + 255) / 256, QR = (NR + 255) / 256;
     constexpr int QK = (NK + 255) / 256;
     float g1[Q1], g3[Q3], gr[QR], gk[QK];
@@ -158,9 +172,9 @@ void patch_ir_px_kernel(IrFusedArgs a) {
 #pragma unroll
     for (int q = 0; q < Q3; ++q) {
         const int e = min(tid + q * 256, N3 - 1);
-        const int ln = e & 63, gk_ = e >> 6, og = gk_ / NKB3, kb = gk_ - og * NKB3;
-        const int o = 4 * og + (ln & 3), h = 16 * kb + (ln >> 2);
-        g3[q] = (o < COUT && h < HID) ? own[CIN * HID + 9 * HID + o * HID + h] : 0.0f;
+        const int ln = e & 63, gk_ = e >> 6, kb = gk_ % NKBC, og = (gk_ / NKBC) % OQ, c = gk_ / (NKBC * OQ);
+        const int o = 4 * og + (ln & 3), hl = 16 * kb + (ln >> 2), h = 4 * GC * c + hl;
+        g3[q] = (o < COUT && hl < 4 * GC && h < HID) ? own[CIN * HID + 9 * HID + o * HID + h] : 0.0f;
     }
 #pragma unroll
     for (int q = 0; q < QR; ++q) {
@@ -241,111 +255,128 @@ void patch_ir_px_kernel(IrFusedArgs a) {
             *reinterpret_cast<float4*>(xr + tid * CINP + 4 * q) = make_float4(xq[4 * q], xq[4 * q + 1], xq[4 * q + 2], xq[4 * q + 3]);
     }
 
-    // BN1 + ReLU6 of one group of 4 hidden channels of this lane's position -> h1
-    auto store_h1 = [&](float* dst, int g, const f32x4& acc) {              // g is wave-uniform: scalar BN loads
+    __syncthreads();                                       // ring inputs in LDS
+    // this lane's edge position (the 64 lanes of a wave <-> the 64 edge positions) and its input vector
+    int ue, ve;
+    ring_uv(lane, ue, ve);
+    float xe[CINP];
+#pragma unroll
+    for (int q = 0; q < CINP / 4; ++q) {
+        const float4 t = *reinterpret_cast<const float4*>(xr + lane * CINP + 4 * q);
+        xe[4 * q] = t.x; xe[4 * q + 1] = t.y; xe[4 * q + 2] = t.z; xe[4 * q + 3] = t.w;
+    }
+    // BN1 + ReLU6 of hidden group g (wave-uniform) -> slot j of the chunk at this lane's position
+    auto store_h1 = [&](float* dst, int j, int g, const f32x4& acc) {
         float o[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int h = min(4 * g + r, HID - 1);
             o[r] = 4 * g + r < HID ? relu6_(fmaf(acc[r], bnl[h], bnl[4 * HQ + h])) : 0.0f;
         }
-        *reinterpret_cast<float4*>(dst + 4 * g) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(dst + 4 * j) = make_float4(o[0], o[1], o[2], o[3]);
     };
 
-    // ---- pw1, interior: D[4 channels of group g][this lane's pixel] += W1[4g.., k] * x[k] ----------------------------
-    {
-        f32x4 acc[HQ];
-#pragma unroll
-        for (int g = 0; g < HQ; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kb = 0; kb < NKB1; ++kb) {
-            float wv[HQ];
-#pragma unroll
-            for (int g = 0; g < HQ; ++g) wv[g] = wa1[(g * NKB1 + kb) * 64 + lane];
-            if (kb == NKB1 - 1) bcast_chains<4, CIN - 16 * (NKB1 - 1), HQ>(wv, xi + 16 * kb, acc);
-            else bcast_chains<4, 16, HQ>(wv, xi + 16 * kb, acc);
-        }
-        float* dst = h1 + (ty + 1) * HR + (tx + 1) * HS;
-#pragma unroll
-        for (int g = 0; g < HQ; ++g) store_h1(dst, g, acc[g]);
-    }
-    __syncthreads();                                       // ring inputs in LDS
-    // ---- pw1, ring.  Edges: lane = edge position (16 per side); wave w takes the channel groups w, w + 4, ..;
-    //      CBSZ = 2: the 4 blocks of a side share the A block ABID of their own 16 lanes = that side's owner ----------
-    {
-        int u, v;
-        ring_uv(lane, u, v);
-        float xe[CINP];
-#pragma unroll
-        for (int q = 0; q < CINP / 4; ++q) {
-            const float4 t = *reinterpret_cast<const float4*>(xr + lane * CINP + 4 * q);
-            xe[4 * q] = t.x; xe[4 * q + 1] = t.y; xe[4 * q + 2] = t.z; xe[4 * q + 3] = t.w;
-        }
-        float* dst = h1 + u * HR + v * HS;
-#pragma unroll
-        for (int gi = 0; gi < (HQ + 3) / 4; ++gi) {
-            const int g = wave + 4 * gi;                   // wave-uniform
-            if (g < HQ) {
-                f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-                for (int kq = 0; kq < NKQ; ++kq) {
-                    const float wv[1] = {wr[(g * NKQ + kq) * 64 + lane]};
-                    if (kq == NKQ - 1) bcast_chains<2, CIN - 4 * (NKQ - 1), 1>(wv, xe + 4 * kq, acc);
-                    else bcast_chains<2, 4, 1>(wv, xe + 4 * kq, acc);
-                }
-                store_h1(dst, g, acc[0]);
-            }
-        }
-        // corners: thread = (corner, hidden channel), plain FMAs
-        if (tid < 4 * HID) {
-            const int cr = tid / HID, h = tid - cr * HID;
-            ring_uv(64 + cr, u, v);
-            const float* __restrict__ wrow = (cr == 0 ? patch_bank(it, jl) : cr == 1 ? patch_bank(it, jr)
-                                              : cr == 2 ? patch_bank(ib, jl) : patch_bank(ib, jr)) + h * CIN;
-            const float* xc = xr + (64 + cr) * CINP;
-            float acc = 0.0f;
-#pragma unroll
-            for (int c = 0; c < CIN; ++c) acc = fmaf(wrow[c], xc[c], acc);
-            h1[u * HR + v * HS + h] = relu6_(fmaf(acc, bnl[h], bnl[4 * HQ + h]));
-        }
-    }
-    __syncthreads();                                       // h1 complete
-
-    // ---- depthwise 3x3 + BN2 + ReLU6 in this thread's registers ------------------------------------------------------
-    float h2[4 * HQ];
-#pragma unroll
-    for (int h = 0; h < 4 * HQ; ++h) h2[h] = 0.0f;
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const float* src = h1 + (ty + ky) * HR + (tx + kx) * HS;
-            const float* kt = kdt + (ky * 3 + kx) * (4 * HQ);
-#pragma unroll
-            for (int q = 0; q < HQ; ++q) {
-                const float4 t = *reinterpret_cast<const float4*>(src + 4 * q);
-                const float4 k4 = *reinterpret_cast<const float4*>(kt + 4 * q);       // uniform address: one broadcast read
-                h2[4 * q] = fmaf(k4.x, t.x, h2[4 * q]); h2[4 * q + 1] = fmaf(k4.y, t.y, h2[4 * q + 1]);
-                h2[4 * q + 2] = fmaf(k4.z, t.z, h2[4 * q + 2]); h2[4 * q + 3] = fmaf(k4.w, t.w, h2[4 * q + 3]);
-            }
-        }
-#pragma unroll
-    for (int h = 0; h < HID; ++h) h2[h] = relu6_(fmaf(h2[h], bnl[8 * HQ + h], bnl[12 * HQ + h]));
-#pragma unroll
-    for (int h = HID; h < 4 * HQ; ++h) h2[h] = 0.0f;
-
-    // ---- pw3: D[4 output channels of group og][this lane's pixel] += W3[4og.., h] * h2[h]; BN3; stores -------------
     f32x4 acc3[OQ];
 #pragma unroll
     for (int og = 0; og < OQ; ++og) acc3[og] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- chunks of GC hidden groups:  pw1(chunk) -> h1 | barrier | dw(chunk) in registers, pw3 += W3[:, chunk] . h2 | barrier
+    static_for<NCH>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        constexpr int NGC = c == NCH - 1 ? HQ - GC * (NCH - 1) : GC;                         // groups of this chunk
+        constexpr int CHC = 4 * GC * c + 4 * NGC <= HID ? 4 * NGC : HID - 4 * GC * c;        // its real channels
+        if constexpr (c > 0) __syncthreads();              // every wave finished the previous chunk's depthwise reads
+        // pw1, interior: D[4 channels of group g][this lane's pixel] += W1[4g.., k] * x[k]
+        {
+            f32x4 acc[NGC];
 #pragma unroll
-    for (int kb = 0; kb < NKB3; ++kb) {
-        float wv[OQ];
+            for (int j = 0; j < NGC; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int og = 0; og < OQ; ++og) wv[og] = wa3[(og * NKB3 + kb) * 64 + lane];
-        if (kb == NKB3 - 1) bcast_chains<4, HID - 16 * (NKB3 - 1), OQ>(wv, h2 + 16 * kb, acc3);
-        else bcast_chains<4, 16, OQ>(wv, h2 + 16 * kb, acc3);
-    }
+            for (int kb = 0; kb < NKB1; ++kb) {
+                float wv[NGC];
+#pragma unroll
+                for (int j = 0; j < NGC; ++j) wv[j] = wa1[((GC * c + j) * NKB1 + kb) * 64 + lane];
+                if (kb == NKB1 - 1) bcast_chains<4, CIN - 16 * (NKB1 - 1), NGC>(wv, xi + 16 * kb, acc);
+                else bcast_chains<4, 16, NGC>(wv, xi + 16 * kb, acc);
+            }
+            float* dst = h1 + (ty + 1) * HR + (tx + 1) * HS;
+#pragma unroll
+            for (int j = 0; j < NGC; ++j) store_h1(dst, j, GC * c + j, acc[j]);
+        }
+        // pw1, ring.  Edges: lane = edge position (16 per side); wave w takes the chunk's groups w, w + 4, ..; CBSZ = 2: the
+        // 4 blocks of a side share the A block ABID of their own 16 lanes = that side's owner
+        {
+            float* dst = h1 + ue * HR + ve * HS;
+#pragma unroll
+            for (int ji = 0; ji < (NGC + 3) / 4; ++ji) {
+                const int j = wave + 4 * ji;               // wave-uniform
+                if (j < NGC) {
+                    const int g = GC * c + j;
+                    f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                    for (int kq = 0; kq < NKQ; ++kq) {
+                        const float wv[1] = {wr[(g * NKQ + kq) * 64 + lane]};
+                        if (kq == NKQ - 1) bcast_chains<2, CIN - 4 * (NKQ - 1), 1>(wv, xe + 4 * kq, acc);
+                        else bcast_chains<2, 4, 1>(wv, xe + 4 * kq, acc);
+                    }
+                    store_h1(dst, j, g, acc[0]);
+                }
+            }
+            // corners: thread = (corner, channel of the chunk), plain FMAs, weights straight from the owner's bank
+            if (tid < 4 * 4 * NGC) {
+                const int cr = tid / (4 * NGC), hl = tid - cr * (4 * NGC), h = 4 * GC * c + hl;
+                int u, v;
+                ring_uv(64 + cr, u, v);
+                float val = 0.0f;
+                if (h < HID) {
+                    const float* __restrict__ wrow = (cr == 0 ? patch_bank(it, jl) : cr == 1 ? patch_bank(it, jr)
+                                                      : cr == 2 ? patch_bank(ib, jl) : patch_bank(ib, jr)) + h * CIN;
+                    const float* xc = xr + (64 + cr) * CINP;
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < CIN; ++k) acc = fmaf(wrow[k], xc[k], acc);
+                    val = relu6_(fmaf(acc, bnl[h], bnl[4 * HQ + h]));
+                }
+                h1[u * HR + v * HS + hl] = val;
+            }
+        }
+        __syncthreads();                                   // the chunk's h1 is complete
+
+        // depthwise 3x3 + BN2 + ReLU6 of the chunk in this thread's registers
+        float h2[16 * NKBC];
+#pragma unroll
+        for (int h = 0; h < 16 * NKBC; ++h) h2[h] = 0.0f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float* src = h1 + (ty + ky) * HR + (tx + kx) * HS;
+                const float* kt = kdt + (ky * 3 + kx) * (4 * HQ) + 4 * GC * c;
+#pragma unroll
+                for (int q = 0; q < NGC; ++q) {
+                    const float4 t = *reinterpret_cast<const float4*>(src + 4 * q);
+                    const float4 k4 = *reinterpret_cast<const float4*>(kt + 4 * q);   // uniform address: one broadcast read
+                    h2[4 * q] = fmaf(k4.x, t.x, h2[4 * q]); h2[4 * q + 1] = fmaf(k4.y, t.y, h2[4 * q + 1]);
+                    h2[4 * q + 2] = fmaf(k4.z, t.z, h2[4 * q + 2]); h2[4 * q + 3] = fmaf(k4.w, t.w, h2[4 * q + 3]);
+                }
+            }
+#pragma unroll
+        for (int hl = 0; hl < CHC; ++hl) h2[hl] = relu6_(fmaf(h2[hl], bnl[8 * HQ + 4 * GC * c + hl], bnl[12 * HQ + 4 * GC * c + hl]));
+#pragma unroll
+        for (int hl = CHC; hl < 4 * NGC; ++hl) h2[hl] = 0.0f;
+
+        // pw3: D[4 output channels of group og][this lane's pixel] += W3[4og.., chunk] * h2
+        constexpr int NKBR = (CHC + 15) / 16;              // 16-channel blocks with real channels
+#pragma unroll
+        for (int kb = 0; kb < NKBR; ++kb) {
+            float wv[OQ];
+#pragma unroll
+            for (int og = 0; og < OQ; ++og) wv[og] = wa3[((c * OQ + og) * NKBC + kb) * 64 + lane];
+            if (kb == NKBR - 1) bcast_chains<4, CHC - 16 * (NKBR - 1), OQ>(wv, h2 + 16 * kb, acc3);
+            else bcast_chains<4, 16, OQ>(wv, h2 + 16 * kb, acc3);
+        }
+    });
+
     float* __restrict__ yo = a.y + (size_t)b * COUT * plane + (size_t)yy_i * W + xx_i;
 #pragma unroll
     for (int og = 0; og < OQ; ++og)
@@ -356,30 +387,32 @@ void patch_ir_px_kernel(IrFusedArgs a) {
         }
 }
 
-template <int CIN, int CSKIP, int COUT, int HID>
+template <int CIN, int CSKIP, int COUT, int HID, int GC>
 static int launch_irp(IrFusedArgs& a, hipStream_t stream) {
-    using G = IrPxGeom<CIN, CSKIP, COUT, HID>;
+    using G = IrPxGeom<CIN, CSKIP, COUT, HID, GC>;
     if (a.hid != HID || a.in.H % 16 != 0 || a.in.W % 16 != 0) return 1;
     a.regs_y = a.in.H / 16; a.regs_x = a.in.W / 16;
     constexpr size_t lds = (size_t)G::FLOATS * sizeof(float);
     static_assert(lds <= 160 * 1024, "LDS");
     if (lds > 64 * 1024) {
         static std::atomic<unsigned long long> done{0};
-        const int e = allow_full_lds((const void*)patch_ir_px_kernel<CIN, CSKIP, COUT, HID>, done);
+        const int e = allow_full_lds((const void*)patch_ir_px_kernel<CIN, CSKIP, COUT, HID, GC>, done);
         if (e != HS_OK) return e;
     }
     const long blocks = (long)a.in.B * a.regs_y * a.regs_x;
-    hipLaunchKernelGGL((patch_ir_px_kernel<CIN, CSKIP, COUT, HID>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((patch_ir_px_kernel<CIN, CSKIP, COUT, HID, GC>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
     return launch_status();
 }
 
 // Op D levels with narrow channels and patch edges that are multiples of 16 pixels; 1 = no instantiation
 int try_launch_ir_px(IrFusedArgs& a, int cin, int c_skip, int c_out, hipStream_t stream) {
     if (a.ph != a.pw || a.ph % 16 != 0) return 1;
-#define HS_IRP_CASE(CI, CS, CO, HID) \
-    if (cin == CI && c_skip == CS && c_out == CO && a.hid == HID) return launch_irp<CI, CS, CO, HID>(a, stream);
-    HS_IRP_CASE(11, 3, 21, 22)       // HyperSeg-L level 5 (PASCAL VOC: 21 classes)
-    HS_IRP_CASE(16, 6, 6, 32)        // HyperSeg-L level 4
+// GC = hidden groups per LDS chunk: sets the h1 footprint and with it the workgroups per CU (level 5: 3 chunks of 8 channels,
+// 35 KB -> 4 per CU; level 4: 4 chunks of 8, 40 KB -> 4 per CU; one chunk would be 53 / 71 KB -> 3 / 2 per CU)
+#define HS_IRP_CASE(CI, CS, CO, HID, GC) \
+    if (cin == CI && c_skip == CS && c_out == CO && a.hid == HID) return launch_irp<CI, CS, CO, HID, GC>(a, stream);
+    HS_IRP_CASE(11, 3, 21, 22, 2)    // HyperSeg-L level 5 (PASCAL VOC: 21 classes)
+    HS_IRP_CASE(16, 6, 6, 32, 2)     // HyperSeg-L level 4
 #undef HS_IRP_CASE
     return 1;
 }
