@@ -30,7 +30,7 @@ from torch.nn.modules.utils import _pair
 from .. import functional as HF
 from .. import autograd as HA
 from ._common import HyperGenBase, coordinate_grid, per_level, plan_levels, register_coordinate_buffers
-from .layers.meta_conv import MetaConv2d, _apply_epilogue, _require_inference
+from .layers.meta_conv import MetaConv2d, _apply_epilogue, _require_inference, assemble_block, check_padding_mode
 from .layers.meta_sequential import MetaSequential
 
 
@@ -101,18 +101,14 @@ class HyperPatchNoPadding(nn.Module, _SignalToWeights):
     """k=1 dynamic patch-wise conv fed by the signal (hyperseg_v1_0.py:455-498) -> Op A."""
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, dilation=1, groups=1):
-        super(HyperPatchNoPadding, self).__init__()
-        if in_channels % groups != 0:
-            raise ValueError('in_channels must be divisible by groups')
-        if out_channels % groups != 0:
-            raise ValueError('out_channels must be divisible by groups')
-        self.in_channels = in_channels
-        self.out_channels = out_channels
-        self.kernel_size = _pair(kernel_size)
-        self.stride = _pair(stride)
-        self.dilation = _pair(dilation)
-        self.groups = groups
-        self.hyper_params = int(np.prod((out_channels, in_channels // groups) + self.kernel_size))
+        super().__init__()
+        for name, nc in (('in_channels', in_channels), ('out_channels', out_channels)):
+            if nc % groups:
+                raise ValueError(f'{name} must be divisible by groups')       # the reference's messages (:458-461)
+        self.in_channels, self.out_channels, self.groups = in_channels, out_channels, groups
+        self.kernel_size, self.stride, self.dilation = _pair(kernel_size), _pair(stride), _pair(dilation)
+        kh, kw = self.kernel_size
+        self.hyper_params = out_channels * (in_channels // groups) * kh * kw   # filter-bank rows of one patch
         self._init_s2w_state()
 
     def init_signal2weights(self, signal_channels, signal_index=0, groups=1):
@@ -148,14 +144,9 @@ class HyperPatch(nn.Module, _SignalToWeights):
     """Dynamic patch-wise block with image-level padding fed by the signal (hyperseg_v1_0.py:501-557)."""
 
     def __init__(self, module: nn.Module, padding=0, padding_mode='reflect'):
-        super(HyperPatch, self).__init__()
-        valid_padding_modes = {'zeros', 'reflect', 'replicate', 'circular'}
-        if padding_mode not in valid_padding_modes:
-            raise ValueError(
-                f"padding_mode must be one of {valid_padding_modes}, but got padding_mode='{padding_mode}'")
-        self.hyper_module = module
-        self.padding = _pair(padding)
-        self.padding_mode = padding_mode
+        super().__init__()
+        self.padding_mode = check_padding_mode(padding_mode)                 # same ValueError text as the reference (:506-510)
+        self.hyper_module, self.padding = module, _pair(padding)
         self._init_s2w_state()
 
     @property
@@ -220,25 +211,19 @@ class HyperPatchInvertedResidual(nn.Module, _SignalToWeights):
 
     def __init__(self, in_nc, out_nc, kernel_size=3, stride=1, expand_ratio=1, norm_layer=nn.BatchNorm2d,
                  act_layer=nn.ReLU6(inplace=True), padding_mode='reflect'):
-        super(HyperPatchInvertedResidual, self).__init__()
-        self.stride = stride
-        assert stride in [1, 2]
-        self.padding_mode = padding_mode
-        self.padding = (1, 1)
-        self.in_nc = in_nc
-        self.out_nc = out_nc
-        self.kernel_size = _pair(kernel_size)
-        self.hidden_dim = int(round(in_nc * expand_ratio))
-        self.use_res_connect = self.stride == 1 and in_nc == out_nc
+        super().__init__()
+        assert stride in (1, 2)
+        hidden = int(round(in_nc * expand_ratio))
+        self.in_nc, self.out_nc, self.hidden_dim, self.stride = in_nc, out_nc, hidden, stride
+        self.kernel_size, self.padding, self.padding_mode = _pair(kernel_size), (1, 1), padding_mode
+        self.use_res_connect = stride == 1 and in_nc == out_nc
         self.act_layer = act_layer
-        self.bn1 = norm_layer(self.hidden_dim)
-        self.bn2 = norm_layer(self.hidden_dim)
-        self.bn3 = norm_layer(self.out_nc)
-
-        # flat weight ranges: pw1 | dw | pw3
-        self._ranges = [0, in_nc * self.hidden_dim]
-        self._ranges.append(self._ranges[-1] + int(np.prod((self.hidden_dim,) + self.kernel_size)))
-        self._ranges.append(self._ranges[-1] + self.hidden_dim * out_nc)
+        # state-dict keys bn1 / bn2 / bn3 (Appendix C)
+        self.bn1, self.bn2, self.bn3 = norm_layer(hidden), norm_layer(hidden), norm_layer(out_nc)
+        # rows of the patch's filter bank: pw1 [hidden x in_nc] | depthwise [hidden x kh x kw] | pw3 [out_nc x hidden]
+        kh, kw = self.kernel_size
+        sizes = (in_nc * hidden, hidden * kh * kw, hidden * out_nc)
+        self._ranges = [0, sizes[0], sizes[0] + sizes[1], sum(sizes)]
         self.hyper_params = self._ranges[-1]
         self._init_s2w_state()
         self._folded = [HF.FoldedBN(), HF.FoldedBN(), HF.FoldedBN()]
@@ -320,19 +305,10 @@ def make_hyper_patch_conv2d_block(in_nc, out_nc, kernel_size=3, stride=1, paddin
                                   padding_mode='reflect', norm_layer=nn.BatchNorm2d, act_layer=nn.ReLU(True),
                                   dropout=None):
     """[HyperPatchNoPadding | HyperPatchConv2d, norm, act, Dropout?] (hyperseg_v1_0.py:728-760)."""
-    assert dropout is None or isinstance(dropout, float)
-    padding = kernel_size // 2 if padding is None else padding
-    if padding == 0:
-        layers = [HyperPatchNoPadding(in_nc, out_nc, kernel_size, stride, dilation, groups)]
-    else:
-        layers = [HyperPatchConv2d(in_nc, out_nc, kernel_size, stride, padding, dilation, groups, padding_mode)]
-    if norm_layer is not None:
-        layers.append(norm_layer(out_nc))
-    if act_layer is not None:
-        layers.append(act_layer)
-    if dropout is not None:
-        layers.append(nn.Dropout(dropout))
-    return MetaSequential(*layers)
+    pad = kernel_size // 2 if padding is None else padding
+    conv = (HyperPatchNoPadding(in_nc, out_nc, kernel_size, stride, dilation, groups) if pad == 0 else
+            HyperPatchConv2d(in_nc, out_nc, kernel_size, stride, pad, dilation, groups, padding_mode))
+    return assemble_block(conv, out_nc, norm_layer, act_layer, dropout)
 
 
 _HYPER_TYPES = (HyperPatchConv2d, HyperPatchNoPadding, HyperPatchInvertedResidual)
@@ -581,17 +557,13 @@ class WeightMapper(nn.Module):
     average at the bottom, 1x1 merges + nearest 2x up, concat -> signal.  Stock PyTorch-ROCm."""
 
     def __init__(self, in_channels, out_channels, levels=3, bias=False, min_unit=4, weight_groups=1):
-        super(WeightMapper, self).__init__()
+        super().__init__()
         assert levels > 0, 'levels must be greater than zero'
         assert in_channels % 2 == 0, 'in_channels must be divisible by 2'
         if isinstance(weight_groups, (list, tuple)):
-            assert len(weight_groups) == len(out_channels), \
-                f'groups ({len(weight_groups)}) must be of size {len(out_channels)}'
-        self.in_channels = in_channels
-        self.out_channels = out_channels
-        self.levels = levels
-        self.bias = bias
-        self.weight_groups = weight_groups
+            assert len(weight_groups) == len(out_channels), f'groups ({len(weight_groups)}) must be of size {len(out_channels)}'
+        self.in_channels, self.out_channels, self.levels = in_channels, out_channels, levels
+        self.bias, self.weight_groups = bias, weight_groups
         half = in_channels // 2
 
         def block(cin, k, stride):
