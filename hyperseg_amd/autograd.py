@@ -7,7 +7,6 @@ around it in TRAINING mode (stage-input concatenation, BatchNorm with batch stat
 ``signal2weights`` convolution) stays stock PyTorch so that autograd composes the whole decoder.  Inference never comes
 through this module: it uses the fused kernels (one launch per level).
 """
-import ctypes as C
 
 import torch
 

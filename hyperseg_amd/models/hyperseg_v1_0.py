@@ -17,7 +17,6 @@ signal reaches the modules through MetaSequential's clamped slice (D-2), ``weigh
 consumed by ``pop(0)`` (D-3), coordinate buffers exist for checkpoint compatibility but the values
 are generated analytically (D-11).
 """
-import numbers
 from functools import partial
 from itertools import groupby
 

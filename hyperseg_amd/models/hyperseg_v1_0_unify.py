@@ -21,7 +21,6 @@ from ._common import HyperGenBase, coordinate_grid, per_level, plan_levels, regi
 from .hyperseg_v1_0 import (HyperPatch, HyperPatchConv2d, HyperPatchInvertedResidual, HyperPatchNoPadding,  # noqa: F401
                             WeightMapper, _SignalToWeights, divide_feature, make_hyper_patch_conv2d_block,
                             next_multiply)
-from .layers.meta_conv import _require_inference
 from .layers.meta_sequential import MetaSequential
 
 

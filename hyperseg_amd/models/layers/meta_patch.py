@@ -6,7 +6,6 @@ one ``hs_bank_pack_fwd`` launch turns the (B, hp, fh, fw) weight tensor into a p
 one ``hs_patch_conv_fwd`` launch does padding + gather + conv (+ BN + activation when called from a
 MetaSequential) with the tile living in LDS.
 """
-import torch
 import torch.nn as nn
 from torch.nn.modules.utils import _pair
 

@@ -10,7 +10,6 @@ inside ``model(x)`` / ``backward()`` through hyperseg_amd.autograd.
 * :func:`train_step` -- hyperseg/train.py:118-136: forward, resize the prediction to the target if needed, loss,
   zero_grad / backward / optimizer.step / scheduler.step.
 """
-import torch
 import torch.nn as nn
 import torch.nn.functional as F
 from torch.optim.lr_scheduler import LRScheduler

@@ -8,7 +8,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from hyperseg_amd import configs, functional as HF
 from hyperseg_amd.utils.synthetic import fill_by_name
-from hyperseg_amd.utils import inference
 from hyperseg_amd.utils.inference import prepare_for_inference
 
 REP = 20
