@@ -27,6 +27,8 @@ Extra objects on the line:
   exact_f32     the same step (one timed region) with the fused inverted-residual levels on the exact-f32 matrix cores
                 (hs_set_ir_math('f32')); the headline `value` uses config.ir_math (auto: f16 split products at f32-class
                 accuracy on the level-4 block).  N = 1 only.
+  two_frames_in_flight  serving-style side number (never `value`): two requests of the benched batch in flight, one HIP
+                graph each on its own stream.  N = 1 only.
   fps_reference_protocol  hyperseg/test_fps.py's protocol (per iteration sync -> H2D of a pinned batch -> eager forward ->
                 sync; hyperseg_amd/fps.py) on the same model, N = 1 only.
   cpu_baseline  the CPU oracle ("port": stock encoder on CPU + oracle/cpu_port.py decoder) timed on the host cores of
@@ -326,6 +328,43 @@ def cpu_baseline(model_cpu, size, budget_s=20.0):
 
 
 # --------------------------------------------------------------------------------------------- main
+def two_in_flight(forward, x, y_ref, steps, warmup, batch):
+    """A serving-style side number, never ``value``: two independent requests of the benched batch in flight.  Each is a
+    HIP graph of the same forward, captured and replayed on ITS OWN stream (own capture stream => own library workspaces,
+    own graph memory pool; no fork/join inside a graph), launched alternately.  The bs-1 frame is a chain of ~200
+    latency-bound launches that each fill a fraction of the 256 CUs, so a second chain overlaps almost for free; the
+    per-request latency is the single-stream ``ms_per_step`` or worse.  Outputs are compared with the single-stream run."""
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    xs = [x, x.clone()]
+    graphs, outs = [], []
+    for s, xi in zip(streams, xs):
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            forward(xi)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            yi = forward(xi)
+        graphs.append(g)
+        outs.append(yi)
+
+    def run(n):
+        for i in range(n):
+            with torch.cuda.stream(streams[i & 1]):
+                graphs[i & 1].replay()
+
+    run(2 * max(1, warmup))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    diff = max(float((o.float() - y_ref.float()).abs().max()) for o in outs)
+    return {'value': round(steps * batch / el, 2), 'unit': 'frames/s', 'ms_per_step': round(1e3 * el / steps, 4),
+            'max_abs_diff_vs_benched': diff,
+            'note': 'NOT the headline: 2 requests in flight on 2 streams (one HIP graph each); value above = 1 in flight'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -515,6 +554,12 @@ def main():
                     del g2
                 finally:
                     HFm.set_ir_math(prev_math)
+            if world == 1 and graph is not None:
+                try:                                  # a side number must never cost the line
+                    out['two_frames_in_flight'] = two_in_flight(forward, x, y_bench, args.steps, args.warmup, batch)
+                except Exception as e:                # noqa: BLE001
+                    out['two_frames_in_flight'] = {'error': f'{type(e).__name__}: {e}'[:300]}
+                    torch.cuda.synchronize()
             if world == 1:
                 # ---- the reference harness' own protocol (sync + pinned H2D + eager forward per iteration) -------------
                 from hyperseg_amd.fps import measure_fps, synthetic_batches
