@@ -567,6 +567,18 @@ def main():
                 res = measure_fps(model, [uniq[i % 4] for i in range(max(8, 64 // batch))], dev, spec['num_classes'])
                 out['fps_reference_protocol'] = {'value': round(res['fps'], 1), 'unit': 'frames/s', 'frames': res['frames'],
                                                  'protocol': 'test_fps.py:163-191: per iteration sync, pinned H2D, eager forward, sync'}
+                try:                                  # the same protocol with one HIP-graph replay per frame (GraphedModel)
+                    from hyperseg_amd.utils.inference import GraphedModel
+                    res_g = measure_fps(GraphedModel(model), [uniq[i % 4] for i in range(max(8, 64 // batch))], dev,
+                                        spec['num_classes'])
+                    out['fps_reference_protocol']['graphed'] = {
+                        'value': round(res_g['fps'], 1), 'unit': 'frames/s', 'mean_iou_equal_to_eager':
+                        abs(res_g['mean_iou'] - res['mean_iou']) < 1e-6,
+                        'protocol': 'as above with forward = H2D into the static input + one HIP-graph replay '
+                                    '(hyperseg_amd.utils.inference.GraphedModel)'}
+                except Exception as e:                # noqa: BLE001
+                    out['fps_reference_protocol']['graphed'] = {'error': f'{type(e).__name__}: {e}'[:300]}
+                    torch.cuda.synchronize()
                 out['cpu_baseline'] = None
                 if args.model == 'm' and not args.no_cpu_baseline:
                     out['cpu_baseline'] = cpu_baseline(fill_by_name(configs.build(cfg).eval(), seed=0), (h, w), args.cpu_budget)

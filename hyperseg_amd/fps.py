@@ -10,10 +10,11 @@ Reproduces the reference's protocol on synthetic frames (no dataset, checkpoint 
   * ``pred.argmax(1)`` masks feeding a confusion matrix (:194; hyperseg/utils/seg_utils.py:5-36) -> global accuracy, mIoU.
 ``torch.cuda.synchronize()`` is guarded so that the plumbing also runs on a CPU-only box (with a CPU-capable model).
 
-    python -m hyperseg_amd.fps --config hyperseg-m --iterations 200 [--prepare] [--remove-bn] [--batch-size 1]
+    python -m hyperseg_amd.fps --config hyperseg-m --iterations 200 [--prepare] [--graph] [--remove-bn] [--batch-size 1]
 
-``bench.py`` is the judged benchmark (resident input, HIP-graph replay); this harness includes the H2D copy and eager
-launch overheads exactly like the reference's, so its number is lower."""
+``bench.py`` is the judged benchmark (resident input, HIP-graph replay); this harness includes the H2D copy and the
+per-frame synchronisation exactly like the reference's, and by default its eager launches too, so its number is lower.
+``--graph`` keeps the protocol but makes the forward one HIP-graph replay (``utils.inference.GraphedModel``)."""
 import argparse
 import json
 import time
@@ -78,7 +79,12 @@ def measure_fps(model, batches, device, num_classes, passes=2):
             target = target.to(device)
             _sync(device)
             t0 = time.perf_counter()
-            x = [t.to(device, non_blocking=True) for t in inp] if isinstance(inp, (list, tuple)) else inp.to(device, non_blocking=True)
+            if isinstance(inp, (list, tuple)):
+                x = [t.to(device, non_blocking=True) for t in inp]
+            elif getattr(model, 'accepts_host_input', False):
+                x = inp                          # GraphedModel: the H2D copy lands in the graph's static input buffer
+            else:
+                x = inp.to(device, non_blocking=True)
             pred = model(x)
             _sync(device)
             total_time += time.perf_counter() - t0
@@ -109,6 +115,8 @@ def main(argv=None):
     ap.add_argument('--batch-size', type=int, default=None)
     ap.add_argument('--remove-bn', action='store_true', help="the reference's BN -> identity switch (changes the logits)")
     ap.add_argument('--prepare', action='store_true', help='hyperseg_amd.utils.inference.prepare_for_inference (fused encoder)')
+    ap.add_argument('--graph', action='store_true', help='replay one HIP graph per frame (utils.inference.GraphedModel) '
+                                                         'instead of launching eagerly; same protocol otherwise')
     ap.add_argument('--cpu-only', action='store_true')
     args = ap.parse_args(argv)
 
@@ -128,12 +136,16 @@ def main(argv=None):
         from .utils.inference import prepare_for_inference
         prepare_for_inference(model, fold_bn=False, fused_depthwise=True)
     model = model.to(device)
+    if args.graph and device.type == 'cuda':
+        from .utils.inference import GraphedModel
+        model = GraphedModel(model)
     bs = args.batch_size or spec['batch']
     uniq = synthetic_batches(min(args.distinct, args.iterations), bs, spec['size'], spec['num_classes'], device)
     batches = [uniq[i % len(uniq)] for i in range(args.iterations)]
     res = measure_fps(model, batches, device, spec['num_classes'])
     res.update(config=args.config, batch_size=bs, size=list(spec['size']), device=str(device), remove_bn=args.remove_bn,
-               prepared=bool(args.prepare and not args.remove_bn), protocol='test_fps.py: per-iteration sync + H2D + eager forward')
+               prepared=bool(args.prepare and not args.remove_bn), graph=bool(args.graph and device.type == 'cuda'),
+               protocol='test_fps.py: per-iteration sync + H2D + ' + ('HIP-graph replay' if args.graph else 'eager forward'))
     print(json.dumps(res))
     return res
 

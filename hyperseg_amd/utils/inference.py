@@ -445,3 +445,78 @@ def prepare_for_inference(model, fold_bn=True, channels_last=False, fused_depthw
         model.backbone.to(memory_format=torch.channels_last)
         model.weight_mapper.to(memory_format=torch.channels_last)
     return folded
+
+
+class GraphedModel(nn.Module):
+    """Serving wrapper: ONE HIP-graph replay per forward instead of ~200 eager launches (HyperSeg-M: the eager launch
+    path costs 2.7 ms of host time per frame, the replay 0.98 ms of GPU time).  The reference has no counterpart -- its
+    FPS harness launches eagerly (hyperseg/test_fps.py:173-188); ``hyperseg_amd.fps --graph`` runs that harness' protocol
+    through this wrapper.
+
+    ``forward(x)``: ``x`` a single tensor, on the device or in (pinned) host memory -- it is copied into the graph's
+    static input buffer on the current stream, so the host-to-device copy IS the staging copy.  One graph is captured per
+    (shape, dtype) on first use (``warmup`` eager forwards on a side stream first: library handles, workspaces and the
+    lazily built buffers of the fused routes must exist before capture).  The returned tensor is the graph's static output:
+    valid until the next forward of the same shape (``clone_output=True`` hands out copies).  Anything the graph cannot
+    serve takes the wrapped model's eager path: list inputs (pyramids), training mode, inputs or parameters that need a
+    gradient, CPU models.  Parameters are read through their storage, so in-place updates are seen; ``load_state_dict``
+    on the wrapped model (which rebuilds the fused routes' folded buffers) and ``reset()`` drop the captured graphs."""
+
+    def __init__(self, model, masks=False, warmup=3, clone_output=False, max_graphs=8):
+        super().__init__()
+        self.model = model
+        self.masks, self.warmup, self.clone_output, self.max_graphs = bool(masks), int(warmup), bool(clone_output), int(max_graphs)
+        self._graphs = {}                      # (shape, dtype, device) -> (graph, static_in, static_out)
+        self._hook = model.register_load_state_dict_post_hook(lambda module, incompatible: self.reset())
+
+    def reset(self):
+        self._graphs.clear()
+
+    def _eager(self, x):
+        return self.model.segment(x) if self.masks else self.model(x)
+
+    def _graphable(self, x):
+        if not isinstance(x, torch.Tensor) or self.model.training or x.requires_grad:
+            return False
+        p = next(self.model.parameters(), None)
+        if p is None or not p.is_cuda:
+            return False
+        return not (torch.is_grad_enabled() and any(q.requires_grad for q in self.model.parameters()))
+
+    def _capture(self, key, x, device):
+        if len(self._graphs) >= self.max_graphs:
+            self._graphs.pop(next(iter(self._graphs)))           # oldest shape goes
+        with torch.cuda.device(device), torch.no_grad():
+            static_in = torch.empty(x.shape, dtype=x.dtype, device=device)
+            static_in.copy_(x)
+            main = torch.cuda.current_stream(device)
+            side = torch.cuda.Stream(device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for _ in range(max(1, self.warmup)):
+                    self._eager(static_in)
+            main.wait_stream(side)
+            torch.cuda.synchronize(device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = self._eager(static_in)
+        self._graphs[key] = (graph, static_in, static_out)
+        return self._graphs[key]
+
+    accepts_host_input = True                  # hyperseg_amd.fps.measure_fps hands the pinned host batch over as it is
+
+    def forward(self, x):
+        p = next(self.model.parameters(), None)
+        if not self._graphable(x):
+            if isinstance(x, torch.Tensor) and p is not None and x.device != p.device:
+                x = x.to(p.device, non_blocking=True)
+            return self._eager(x)
+        device = p.device
+        key = (tuple(x.shape), x.dtype, device)
+        entry = self._graphs.get(key)
+        if entry is None:
+            entry = self._capture(key, x, device)
+        graph, static_in, static_out = entry
+        static_in.copy_(x, non_blocking=True)
+        graph.replay()
+        return static_out.clone() if self.clone_output else static_out

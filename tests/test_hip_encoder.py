@@ -269,3 +269,40 @@ def test_prepared_routes_fall_back_and_refresh(dev):
         assert fused.backbone._fused_ok(x2)
         ys, yf = other(x2), fused(x2)
     assert rel_err(yf.cpu(), ys.cpu()) < 1e-4
+
+
+def test_graphed_model_serves_like_eager(dev):
+    """utils.inference.GraphedModel: one HIP-graph replay per forward.  Same logits as the eager prepared model for
+    device and pinned-host inputs, a second input shape gets its own graph, masks == argmax of the logits, a
+    load_state_dict on the wrapped model drops the captured graphs, and what a graph cannot serve runs eagerly."""
+    from hyperseg_amd import configs
+    from hyperseg_amd.utils.inference import GraphedModel, prepare_for_inference
+    from hyperseg_amd.utils.synthetic import fill_by_name
+    model = fill_by_name(configs.build('hyperseg-m').eval(), seed=5)
+    prepare_for_inference(model, fold_bn=False, fused_depthwise=True)
+    model = model.to(dev)
+    served = GraphedModel(model, clone_output=True)
+    with torch.no_grad():
+        xs = [torch.rand(1, 3, 256, 512, device=dev), torch.rand(1, 3, 256, 512).pin_memory(),
+              torch.rand(1, 3, 128, 256, device=dev), torch.rand(1, 3, 256, 512, device=dev)]
+        for x in xs:
+            y = served(x)
+            assert rel_err(y.cpu(), model(x.to(dev)).cpu()) < 1e-5
+        assert len(served._graphs) == 2
+        masks = GraphedModel(model, masks=True)(xs[0])
+        ref = model(xs[0])
+        top2 = ref.topk(2, dim=1).values
+        clear = (top2[:, 0] - top2[:, 1]) > 1e-4
+        assert masks.dtype == torch.uint8 and bool((masks.long()[clear] == ref.argmax(1)[clear]).all())
+        # pyramids are served eagerly
+        pyr = [xs[0], xs[2]]
+        assert rel_err(served(pyr).cpu(), model(pyr).cpu()) < 1e-5
+        # new weights: the graphs are dropped and re-captured against the rebuilt fused routes
+        other = fill_by_name(configs.build('hyperseg-m').eval(), seed=6).to(dev)
+        model.load_state_dict(other.state_dict(), strict=True)
+        assert len(served._graphs) == 0
+        assert rel_err(served(xs[0]).cpu(), other(xs[0]).cpu()) < 1e-4
+    # under autograd the wrapper steps aside
+    xg = torch.rand(1, 3, 128, 256, device=dev, requires_grad=True)
+    served(xg).mean().backward()
+    assert xg.grad is not None
