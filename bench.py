@@ -332,8 +332,10 @@ def two_in_flight(forward, x, y_ref, steps, warmup, batch):
     """A serving-style side number, never ``value``: two independent requests of the benched batch in flight.  Each is a
     HIP graph of the same forward, captured and replayed on ITS OWN stream (own capture stream => own library workspaces,
     own graph memory pool; no fork/join inside a graph), launched alternately.  The bs-1 frame is a chain of ~200
-    latency-bound launches that each fill a fraction of the 256 CUs, so a second chain overlaps almost for free; the
-    per-request latency is the single-stream ``ms_per_step`` or worse.  Outputs are compared with the single-stream run."""
+    latency-bound launches that each fill a fraction of the 256 CUs, so a second chain COULD overlap almost for free.
+    Measured (round 2, ROCm 7.2): it does not -- 1026 vs 1018 frames/s at HyperSeg-M, graph replays issued from two streams
+    execute back to back -- so the number documents that there is nothing to gain this way.  Outputs are compared with the
+    single-stream run."""
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     xs = [x, x.clone()]
     graphs, outs = [], []
