@@ -1,6 +1,6 @@
 """Time of one config-5 training step of the decoder (CamVid-S, 576x576 crops, bs 2: forward + loss + backward + Adam)
 through the HIP path, fp32 and bf16 autocast, plus the per-kernel picture under rocprofv3 if wrapped.
-    python tools/train_step_time.py [iters]"""
+    python tools/train_step_time.py [iters] [fp32|bf16]"""
 import os
 import sys
 import time
@@ -23,7 +23,8 @@ dec = model.decoder.train()
 target = torch.randint(0, 12, (2, 576, 576), device=dev)
 crit = BootstrappedCrossEntropyLoss(k=4096, thresh=0.3, ignore_index=255)
 opt = torch.optim.Adam(dec.parameters(), lr=1e-3, betas=(0.5, 0.999))
-for mode in ('fp32', 'bf16'):
+modes = (sys.argv[2],) if len(sys.argv) > 2 else ('fp32', 'bf16')
+for mode in modes:
     def step():
         opt.zero_grad()
         with torch.autocast('cuda', dtype=torch.bfloat16, enabled=(mode == 'bf16')):
