@@ -234,11 +234,15 @@ __device__ __forceinline__ void se_excite_body(int cb, int rg, int b, const floa
     const int c = cb * 64 + col, cc = min(c, C - 1);
     const int o0 = rg * 64 + part * 16;
     // project-weight rows of this thread: issued before the gate so that both sets of loads share one round trip
-    float wp[16];
+    float wp[16], osc[16];
     if (w_proj) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) wp[r] = w_proj[(size_t)min(o0 + r, Cout - 1) * C + cc];
+        for (int r = 0; r < 16; ++r) {
+            wp[r] = w_proj[(size_t)min(o0 + r, Cout - 1) * C + cc];
+            osc[r] = out_scale ? out_scale[min(o0 + r, Cout - 1)] : 1.0f;     // with the rows: not one round trip per store
+        }
     }
+    const float b2v = b2[cc];
     const int jq = (Csq + 3) >> 2, j0 = part * jq, j1 = min(j0 + jq, Csq);
     const float* __restrict__ zb = z + (size_t)b * Csq;
     float acc = 0.0f;
@@ -257,7 +261,7 @@ __device__ __forceinline__ void se_excite_body(int cb, int rg, int b, const floa
     __syncthreads();                         // red may still be read by a previous call of this body
     red[part][col] = acc;
     __syncthreads();
-    const float t = ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) + b2[cc];
+    const float t = ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) + b2v;
     const float g = sigmoidf_fast(t);
     if (rg == 0 && part == 0 && c < C) gate[(size_t)b * C + c] = g;
     if (w_proj && c < C) {
@@ -265,7 +269,7 @@ __device__ __forceinline__ void se_excite_body(int cb, int rg, int b, const floa
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int o = o0 + r;
-            if (o < Cout) dst[(size_t)o * C] = wp[r] * g * (out_scale ? out_scale[o] : 1.0f);
+            if (o < Cout) dst[(size_t)o * C] = wp[r] * g * osc[r];
         }
     }
 }
@@ -283,6 +287,143 @@ void se_excite_kernel(const float* __restrict__ z, const float* __restrict__ w2t
                       const float* __restrict__ out_scale, float* __restrict__ w_scaled) {
     __shared__ float red[4][64];
     se_excite_body(blockIdx.x, blockIdx.z, blockIdx.y, z, w2t, b2, C, Csq, gate, w_proj, Cout, out_scale, w_scaled, red);
+}
+
+// The whole gate in ONE launch, for the blocks whose reduce weights are small enough that every excite workgroup can
+// re-derive the squeezed vector for itself (C <= 768, Csq <= 32: 16 of EfficientNet-B1's 23 blocks).  Same grid as
+// se_excite_kernel.  Rejected variant (ii) above walked the reduce rows one block-wide reduction at a time; here every
+// global load of the workgroup -- partial sums, the whole reduce weight (<= 84 KB), this strip's expand column and project
+// rows -- is issued before the first use (one memory round trip), a wave owns whole reduce rows (no block-wide reductions in
+// the squeeze), and only two barriers separate the phases: a dependent launch in a replayed graph costs 1.6-2.2 us on this
+// box (profiles/round2_graph_launch_floor.txt) while the squeeze launch it removes took 4.6 us.
+constexpr int SEF_MAX_C = 768, SEF_MAX_CSQ = 32, SEF_MAX_UNITS = 2048;
+__global__ __launch_bounds__(256)
+void se_gate_fused_kernel(const float* __restrict__ partial, int nblk, float inv_hw, const float* __restrict__ w1,
+                          const float* __restrict__ b1, const float* __restrict__ w2t, const float* __restrict__ b2, int C,
+                          int Csq, float* __restrict__ z_out, float* __restrict__ gate, const float* __restrict__ w_proj,
+                          int Cout, const float* __restrict__ out_scale, float* __restrict__ w_scaled) {
+    __shared__ __attribute__((aligned(16))) float mean_c[SEF_MAX_C];
+    __shared__ float se_part[SEF_MAX_UNITS + SEF_MAX_C];     // per-channel runs of partial sums, one pad word per channel
+    __shared__ float zs[SEF_MAX_CSQ];
+    __shared__ float red[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cb = blockIdx.x, b = blockIdx.y, rg = blockIdx.z;
+    const int c = cb * 64 + lane, cc = min(c, C - 1);
+    const int o0 = rg * 64 + wave * 16;
+    // ---- every global load of this workgroup, issued up front (the partial sums first: the two-way branch on their
+    // vector width makes the compiler drain the load queue where its arms join)
+    const bool vec = (nblk & 3) == 0;
+    const int qn = vec ? nblk >> 2 : nblk, units = C * qn;                          // <= SEF_MAX_UNITS
+    const float* __restrict__ pb = partial + (size_t)b * C * nblk;
+    float4 pv[8];
+    if (vec) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pv[k] = reinterpret_cast<const float4*>(pb)[min(tid + 256 * k, units - 1)];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pv[k] = make_float4(pb[min(tid + 256 * k, units - 1)], 0.0f, 0.0f, 0.0f);
+    }
+    float wp[16], osc[16];
+    if (w_proj) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            wp[r] = w_proj[(size_t)min(o0 + r, Cout - 1) * C + cc];
+            osc[r] = out_scale ? out_scale[min(o0 + r, Cout - 1)] : 1.0f;
+        }
+    }
+    const int jq = (Csq + 3) >> 2, j0 = wave * jq, j1 = min(j0 + jq, Csq);          // jq <= 8
+    float w2v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w2v[u] = w2t[(size_t)min(j0 + u, Csq - 1) * C + cc];
+    const float b2v = b2[cc];
+    const int c4 = C >> 2;                                                          // C % 4 == 0, c4 <= 192
+    float4 w1v[8][3];
+    float b1v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int j = min(wave + 4 * r, Csq - 1);
+        b1v[r] = b1[j];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            w1v[r][u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (4 * r < Csq && 64 * u < c4)                                         // uniform: rows / columns that exist
+                w1v[r][u] = reinterpret_cast<const float4*>(w1 + (size_t)j * C)[min(lane + 64 * u, c4 - 1)];
+        }
+    }
+    // ---- phase A: channel means
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int e = tid + 256 * k;
+        if (e < units) {
+            const int ch = e / qn;
+            se_part[ch * (qn + 1) + (e - ch * qn)] = (pv[k].x + pv[k].y) + (pv[k].z + pv[k].w);
+        }
+    }
+    __syncthreads();
+    for (int ch = tid; ch < C; ch += 256) {
+        const float* run = se_part + ch * (qn + 1);
+        float t = 0.0f;
+        for (int i = 0; i < qn; ++i) t += run[i];
+        mean_c[ch] = t * inv_hw;
+    }
+    __syncthreads();
+    // ---- phase B: squeezed activations, wave w owns rows w, w + 4, ...; the wave reductions of four rows run together
+    // (a __shfl_xor is an LDS-crossbar round trip: one row at a time would serialise 48 of them)
+    float4 mv[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int k = lane + 64 * u;
+        mv[u] = *reinterpret_cast<const float4*>(mean_c + 4 * min(k, c4 - 1));
+        if (k >= c4) mv[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+#pragma unroll
+    for (int r0 = 0; r0 < 8; r0 += 4) {
+        if (4 * r0 < Csq) {                                                         // uniform
+            float acc4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float a = 0.0f;
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    a = fmaf(w1v[r0 + q][u].x, mv[u].x, a); a = fmaf(w1v[r0 + q][u].y, mv[u].y, a);
+                    a = fmaf(w1v[r0 + q][u].z, mv[u].z, a); a = fmaf(w1v[r0 + q][u].w, mv[u].w, a);
+                }
+                acc4[q] = a;
+            }
+#pragma unroll
+            for (int mk = 32; mk > 0; mk >>= 1) {
+                float t4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) t4[q] = __shfl_xor(acc4[q], mk, 64);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc4[q] += t4[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = wave + 4 * (r0 + q);
+                if (lane == 0 && j < Csq) zs[j] = swishf(acc4[q] + b1v[r0 + q]);
+            }
+        }
+    }
+    __syncthreads();
+    if (z_out && cb == 0 && rg == 0 && tid < Csq) z_out[(size_t)b * Csq + tid] = zs[tid];
+    // ---- phase C: the strip's gate (each wave a quarter of the squeezed channels), then the scaled project rows
+    float acc = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (j0 + u < j1) acc = fmaf(w2v[u], zs[j0 + u], acc);
+    red[wave][lane] = acc;
+    __syncthreads();
+    const float g = sigmoidf_fast(((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) + b2v);
+    if (rg == 0 && wave == 0 && c < C) gate[(size_t)b * C + c] = g;
+    if (w_proj && c < C) {
+        float* __restrict__ dst = w_scaled + (size_t)b * Cout * C + c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = o0 + r;
+            if (o < Cout) dst[(size_t)o * C] = wp[r] * g * osc[r];
+        }
+    }
 }
 
 }  // namespace hs
@@ -347,11 +488,18 @@ extern "C" int hs_se_gate_fwd(const float* partial, int32_t batch, int32_t chann
     if ((w_proj != nullptr) != (w_scaled != nullptr) || (w_proj && c_out <= 0) || (out_scale && !w_proj)) return HS_ERR_BAD_ARG;
     if (batch > 65535 || c_squeezed > 65535) return HS_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
+    const int row_groups = w_proj ? (c_out + 63) / 64 : 1;
+    const long units = (long)channels * ((nblk & 3) == 0 ? nblk >> 2 : nblk);
+    if ((channels & 3) == 0 && channels <= SEF_MAX_C && c_squeezed <= SEF_MAX_CSQ && units <= SEF_MAX_UNITS) {
+        hipLaunchKernelGGL(se_gate_fused_kernel, dim3((channels + 63) / 64, batch, row_groups), dim3(256), 0, s, partial, nblk,
+                           inv_hw, w_reduce, b_reduce, w_expand, b_expand, channels, c_squeezed, squeezed, gate, w_proj, c_out,
+                           out_scale, w_scaled);
+        return launch_status();
+    }
     hipLaunchKernelGGL(se_squeeze_kernel, dim3(c_squeezed, batch), dim3(256), 0, s, partial, nblk, inv_hw, w_reduce,
                        b_reduce, channels, c_squeezed, squeezed);
     int st = launch_status();
     if (st != HS_OK) return st;
-    const int row_groups = w_proj ? (c_out + 63) / 64 : 1;
     hipLaunchKernelGGL(se_excite_kernel, dim3((channels + 63) / 64, batch, row_groups), dim3(256), 0, s, squeezed, w_expand,
                        b_expand, channels, c_squeezed, gate, w_proj, c_out, out_scale, w_scaled);
     return launch_status();
