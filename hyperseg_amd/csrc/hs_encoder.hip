@@ -32,8 +32,14 @@ void depthwise_conv_kernel(const float* __restrict__ x, const float* __restrict_
     const int c = plane % C;
     // optional prologue: the taps are swish(in_scale[c] * x + in_shift[c]) -- the BatchNorm + swish of the 1x1 expand
     // convolution that produced x, applied on load so that the raw GEMM output needs no elementwise pass of its own
+    // (fetched AFTER the taps have been requested in the untiled form: the compiler issues a scalar load where the source
+    // has it and drains the scalar queue before the next address computation -- at the top of the kernel these two cost a
+    // memory round trip before the first tap load went out; tools/isa_phases.py)
     const bool pre = in_scale != nullptr;
-    const float isc = pre ? in_scale[c] : 1.0f, ish = pre ? in_shift[c] : 0.0f;
+    float isc = 1.0f, ish = 0.0f;
+    if constexpr (TILE) {
+        if (pre) { isc = in_scale[c]; ish = in_shift[c]; }
+    }
     const int wq = (Wo + 3) >> 2;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = q < Ho * wq;
@@ -104,6 +110,9 @@ void depthwise_conv_kernel(const float* __restrict__ x, const float* __restrict_
 #pragma unroll
             for (int j = 0; j < NCOL; ++j) v[ky][j] = row[min(max(xi0 + j, 0), W - 1)];
         }
+    }
+    if constexpr (!TILE) {
+        if (pre) { isc = in_scale[c]; ish = in_shift[c]; }
     }
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -551,20 +560,45 @@ void pointwise_conv_kernel(const float* __restrict__ x, const float* __restrict_
             const int k = i * 4 * KU + 4 * u + lk;
             const bool kok = k < Cin;
             const int kc = kok ? k : Cin - 1;
-            const float g = gb ? gb[kc] : 1.0f;
+            // unconditional loads from clamped addresses, masked by a multiply: with selects the compiler put the loads
+            // behind exec-mask branches and waited for each (tools/isa_phases.py: 3 of 72 loads in flight at the first wait)
+            const float g = (gb ? gb[kc] : 1.0f) * (kok ? 1.0f : 0.0f);
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const float t = w[(size_t)orow[m] * Cin + kc];
-                a[u][m] = (kok && ook[m]) ? t : 0.0f;
-            }
+            for (int m = 0; m < 2; ++m) a[u][m] = w[(size_t)orow[m] * Cin + kc] * (ook[m] ? 1.0f : 0.0f);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const float t = xb[(size_t)kc * P + pcol[n]];
-                bb[u][n] = (kok && pok[n]) ? t * g : 0.0f;
-            }
+            for (int n = 0; n < NT; ++n) bb[u][n] = xb[(size_t)kc * P + pcol[n]] * g;
         }
     };
     load_batch(0, av[0], bv[0]);
+    // epilogue operands, requested with the first batch: BN rows of this lane's 8 output rows and, for a skip block, the
+    // residual values of its 8 x NT outputs (one load per output in the store loop meant one round trip per output)
+    float scv[2][4], shv[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = min(o0 + 16 * m + 4 * lk + r, Cout - 1);
+            scv[m][r] = scale ? scale[o] : 1.0f;
+            shv[m][r] = shift ? shift[o] : 0.0f;
+        }
+    float rv[2][4][NT];
+    if (residual) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = min(o0 + 16 * m + 4 * lk + r, Cout - 1);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) rv[m][r][n] = residual[((size_t)b * Cout + o) * P + pcol[n]];
+            }
+    } else {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) rv[m][r][n] = 0.0f;
+    }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         if (i + 1 < NB) load_batch(i + 1, av[(i + 1) & 1], bv[(i + 1) & 1]);
@@ -582,16 +616,14 @@ void pointwise_conv_kernel(const float* __restrict__ x, const float* __restrict_
         for (int r = 0; r < 4; ++r) {
             const int o = o0 + 16 * m + 4 * lk + r;
             if (o >= Cout) continue;
-            const float sc = scale ? scale[o] : 1.0f, sh = shift ? shift[o] : 0.0f;
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 if (!pok[n]) continue;
-                float v = fmaf(acc[m][n][r], sc, sh);
+                float v = fmaf(acc[m][n][r], scv[m][r], shv[m][r]);
                 if (act == 3) v = swishf(v);
                 else v = apply_act(v, act);
-                const size_t idx = ((size_t)b * Cout + o) * P + pcol[n];
-                if (residual) v += residual[idx];
-                y[idx] = v;
+                v += rv[m][r][n];
+                y[((size_t)b * Cout + o) * P + pcol[n]] = v;
             }
         }
 }

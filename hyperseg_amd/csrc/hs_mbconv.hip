@@ -66,6 +66,7 @@ void mbconv_expand_dw_kernel(MbxArgs a) {
     // ---- prologue: the input halo tile -> B fragments (registers), all loads in flight together ----------------------
     float bf[G::J][KS];
     int h1off[G::J];                   // LDS offset of this lane's position (-1: no such position); bit 30: inside the image
+    unsigned inmask = 0;
 #pragma unroll
     for (int jt = 0; jt < G::J; ++jt) {
         const int nt = wave + 4 * jt;
@@ -75,14 +76,15 @@ void mbconv_expand_dw_kernel(MbxArgs a) {
         const int yy = iy0 + pu, xx = ix0 + pv;
         const bool in = ok && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
         const float* __restrict__ src = a.x + (size_t)b * Cin * plane + (size_t)(in ? yy : 0) * a.W + (in ? xx : 0);
+        // unconditional loads from clamped (always valid) addresses; the masks are applied in a second pass below so that
+        // no load of the tile waits for an earlier one (a use between the loads made the compiler drain the first 8 of
+        // them before issuing the rest: two memory round trips instead of one; tools/isa_phases.py)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int c = ks * 4 + lk;
-            // unconditional load from a clamped (always valid) address, masked by a multiply: a select would let the
-            // compiler predicate every load behind its own exec-mask branch
-            const float v = src[(size_t)(c < Cin ? c : Cin - 1) * plane];
-            bf[jt][ks] = v * ((in && c < Cin) ? 1.0f : 0.0f);
+            bf[jt][ks] = src[(size_t)(c < Cin ? c : Cin - 1) * plane];
         }
+        inmask |= (in ? 1u : 0u) << jt;
         h1off[jt] = ok ? ((pu * G::RS + pv) | (in ? (1 << 30) : 0)) : -1;
     }
 
@@ -95,32 +97,51 @@ void mbconv_expand_dw_kernel(MbxArgs a) {
     const int c_begin = grp * a.chunks_per_wg;
     const int c_end = min(c_begin + a.chunks_per_wg, nchunks);
 
-    for (int ch = c_begin; ch < c_end; ++ch) {
+    // Per-chunk operands (weights: L2-resident vector loads).  Every load is unconditional from a clamped address and all
+    // of them are issued before the first use (masks applied afterwards by a multiply): with selects the compiler put each
+    // A-fragment load behind its own exec-mask branch and waited for it -- four serialised L2 round trips per chunk
+    // (tools/isa_phases.py).  The first chunk's GEMM operands are requested together with the input tile, the next chunk's
+    // at the end of the current one (ahead of its closing barrier).
+    float af[KS];                       // A fragments  W_e[h0 + lrow][4*ks + lk]
+    float sc0[4], sh0[4];               // BN0 rows of this lane's 4 D rows
+    float kd[K * K], sc1, sh1;          // depthwise taps and BN1 of this thread's hidden channel
+    auto fetch_pw = [&](int ch) {       // what the expand GEMM of chunk ch needs
         const int h0 = ch * 16;
-        // per-chunk operands (weights: L2-resident vector loads, issued together ahead of the MFMAs)
-        float af[KS];                   // A fragments  W_e[h0 + lrow][4*ks + lk]
-        {
-            const int h = h0 + lrow;
-            const bool hok = h < Cmid;
-            const float* __restrict__ wr = a.w_e + (size_t)(hok ? h : 0) * Cin;
+        const float* __restrict__ wr = a.w_e + (size_t)min(h0 + lrow, Cmid - 1) * Cin;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int k = ks * 4 + lk;
-                const float v = wr[k < Cin ? k : 0];
-                af[ks] = (hok && k < Cin) ? v : 0.0f;
-            }
-        }
-        float sc0[4], sh0[4];           // BN0 rows of this lane's 4 D rows
+        for (int ks = 0; ks < KS; ++ks) af[ks] = wr[min(ks * 4 + lk, Cin - 1)];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int hr = min(h0 + 4 * lk + r, Cmid - 1);
             sc0[r] = a.s0[hr]; sh0[r] = a.b0[hr];
         }
-        const int hd = min(h0 + hh, Cmid - 1);
-        float kd[K * K];
+    };
+    auto fetch_dw = [&](int ch) {       // what its depthwise stage needs: in flight during the GEMM
+        const int hd = min(ch * 16 + hh, Cmid - 1);
 #pragma unroll
         for (int q = 0; q < K * K; ++q) kd[q] = a.w_dw[(size_t)hd * K * K + q];
-        const float sc1 = a.s1[hd], sh1 = a.b1[hd];
+        sc1 = a.s1[hd]; sh1 = a.b1[hd];
+    };
+    // (the 5x5 instances with a large input tile are within a few registers of the 256 the two-workgroups-per-CU bound
+    // allows: they fetch at the top of the chunk instead -- still one round trip, not overlapped with the tile's)
+    constexpr bool HOIST = !(K == 5 && G::J * KS > 40);
+    if constexpr (HOIST) fetch_pw(min(c_begin, nchunks - 1));
+#pragma unroll
+    for (int jt = 0; jt < G::J; ++jt) {
+        const bool in = (inmask >> jt) & 1u;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) bf[jt][ks] *= (in && ks * 4 + lk < Cin) ? 1.0f : 0.0f;   // a multiply, not a select:
+    }                                                                                             // no exec-mask branches
+
+    for (int ch = c_begin; ch < c_end; ++ch) {
+        const int h0 = ch * 16;
+        if constexpr (!HOIST) fetch_pw(ch);
+        fetch_dw(ch);
+        {
+            const bool hok = h0 + lrow < Cmid;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) af[ks] *= (hok && ks * 4 + lk < Cin) ? 1.0f : 0.0f;
+        }
 
         // ---- pw: h1[16][pos] = swish(BN0(W_e chunk . x tile)), exact zeros outside the image -------------------------
 #pragma unroll
@@ -184,6 +205,9 @@ void mbconv_expand_dw_kernel(MbxArgs a) {
                 for (int m = 8; m > 0; m >>= 1) psum += __shfl_xor(psum, m, 64);
                 if (u == 0 && h < Cmid) a.pool[((size_t)b * Cmid + h) * ntiles + ty * a.tiles_x + tx] = psum;
             }
+        }
+        if constexpr (HOIST) {
+            if (ch + 1 < c_end) fetch_pw(ch + 1);
         }
         __syncthreads();               // h1 is rewritten by the next chunk's pw
     }

@@ -124,36 +124,104 @@ void patch_conv1x1_kernel(Conv1Args a) {
 
     // 1+2. all HBM loads of the workgroup in flight together: the bank (16-byte loads, up to 8 per thread) AND the
     //      stage-input elements (c, pixel); only then the LDS stores.  One memory round trip per workgroup.
-    const float4* __restrict__ src = reinterpret_cast<const float4*>(a.bank + (size_t)patch * a.ld);
-    float4* dst = reinterpret_cast<float4*>(wl);
+    // (a clang vector type, not HIP's float4 struct: struct copies are memcpys, and an array of them stays in scratch memory
+    // once a scheduling barrier sits between the copy in and the copy out)
+    typedef float bank4 __attribute__((ext_vector_type(4)));
+    const bank4* __restrict__ src = reinterpret_cast<const bank4*>(a.bank + (size_t)patch * a.ld);
+    bank4* dst = reinterpret_cast<bank4*>(wl);
     const int n4 = hp4 >> 2;                          // ld is a multiple of 4 and >= hp: the tail read stays in-row
     const int y0 = i * a.ph, x0 = j * a.pw;
     const int total_x = cin * npix;
-    // unconditional loads from clamped indices: conditionally-written register arrays end up in scratch memory
-    float4 wv[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int e = tid + q * CONV_THREADS;
-        wv[q] = src[e < n4 ? e : n4 - 1];
-    }
+    // Stage-input elements without a branch around any load: stage_value() picks coordinate / skip / previous-level by
+    // channel, lanes of one wave differ in that, and every arm's loads were waited for where the arms join (6 serialised
+    // round trips, only 4 of the 38 loads in flight at the first wait; tools/isa_phases.py).  Here the skip sample and the
+    // previous level's taps are BOTH requested from clamped channels (wave-uniform branches only), the unused one is
+    // multiplied by 0 and the value is their sum -- same operations in the same order as stage_value() otherwise.
     float xv[4];
+    bank4 wv[8];
+    float sc_first = 1.0f, sh_first = 0.0f;
+    {
+        const StageIn& s = a.in;
+        // pass 1: indices only
+        int cc[4], yy[4], xx[4];
+        float cv[4], ms[4], mp[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int e = min(tid + q * CONV_THREADS, total_x - 1);
-        const int c = e / npix, pix = e - c * npix;
-        const int u = pix / a.pw, vv = pix - u * a.pw;
-        xv[q] = stage_value(a.in, b, c, stage_pos(a.in, y0 + u, x0 + vv));
-    }
+        for (int q = 0; q < 4; ++q) {
+            const int e = min(tid + q * CONV_THREADS, total_x - 1);
+            int c = e / npix;
+            const int pix = e - c * npix;
+            const int u = pix / a.pw, vv = pix - u * a.pw;
+            yy[q] = y0 + u; xx[q] = x0 + vv;
+            cv[q] = 0.0f;
+            bool is_coord = false;
+            if (s.coords) {                                             // uniform
+                is_coord = c < 2;
+                cv[q] = c == 0 ? linspace_pm1(xx[q], s.W, s.step_x) : (c == 1 ? linspace_pm1(yy[q], s.H, s.step_y) : 0.0f);
+                c -= 2;
+            }
+            ms[q] = (!is_coord && c < s.c_skip) ? 1.0f : 0.0f;
+            mp[q] = (!is_coord && c >= s.c_skip) ? 1.0f : 0.0f;
+            cc[q] = c;
+        }
+        // pass 2: the loads, four per wave-uniform arm, nothing used inside an arm
+        float sk[4] = {0.0f, 0.0f, 0.0f, 0.0f}, pt[4][4];
+        float ly0[4], ly1[4], lx0[4], lx1[4];       // bilinear weights (plain arrays: a select between Tap structs went
+                                                    // through scratch memory)
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int e = tid + q * CONV_THREADS;
-        if (e < n4) dst[e] = wv[q];
-    }
+        for (int q = 0; q < 4; ++q) pt[q][0] = pt[q][1] = pt[q][2] = pt[q][3] = 0.0f;
+        if (s.c_skip > 0) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int e = tid + q * CONV_THREADS;
-        if (e < total_x) xl[e] = xv[q];
+            for (int q = 0; q < 4; ++q)
+                sk[q] = s.skip[(((size_t)b * s.c_skip + min(max(cc[q], 0), s.c_skip - 1)) * s.H + yy[q]) * s.W + xx[q]];
+        }
+        // a same-resolution previous level is the bilinear form with both taps on the pixel and weights (1, 0): one arm
+        const bool bilinear = s.prev_mode != HS_PREV_SAME;
+        if (s.c_prev > 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cp = min(max(cc[q] - s.c_skip, 0), s.c_prev - 1);
+                const float* base = s.prev + ((size_t)b * s.c_prev + cp) * s.Hp * s.Wp;
+                const Tap by = bilinear_tap(yy[q], s.scale_y, s.Hp), bx = bilinear_tap(xx[q], s.scale_x, s.Wp);
+                const int y0i = bilinear ? by.i0 : yy[q], y1i = bilinear ? by.i1 : yy[q];
+                const int x0i = bilinear ? bx.i0 : xx[q], x1i = bilinear ? bx.i1 : xx[q];
+                ly0[q] = bilinear ? by.l0 : 1.0f; ly1[q] = bilinear ? by.l1 : 0.0f;
+                lx0[q] = bilinear ? bx.l0 : 1.0f; lx1[q] = bilinear ? bx.l1 : 0.0f;
+                const float* r0 = base + (size_t)y0i * s.Wp;
+                const float* r1 = base + (size_t)y1i * s.Wp;
+                pt[q][0] = r0[x0i]; pt[q][1] = r0[x1i]; pt[q][2] = r1[x0i]; pt[q][3] = r1[x1i];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { ly0[q] = ly1[q] = lx0[q] = lx1[q] = 0.0f; }
+        }
+        // BN rows of this thread's first output (the only one at the decoder's shapes), with everything else
+        if (a.scale) {
+            const int o_first = min((tid / a.split) / npix, a.cout - 1);
+            sc_first = a.scale[o_first]; sh_first = a.shift[o_first];
+        }
+        // the bank, requested behind the taps (32 registers: kept out of the index arithmetic above)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = tid + q * CONV_THREADS;
+            wv[q] = src[e < n4 ? e : n4 - 1];
+        }
+        __builtin_amdgcn_sched_barrier(0);      // every load above is issued before the first use below
+        // pass 3: masks and the value
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float top = lx0[q] * (pt[q][0] * mp[q]) + lx1[q] * (pt[q][1] * mp[q]);
+            const float bot = lx0[q] * (pt[q][2] * mp[q]) + lx1[q] * (pt[q][3] * mp[q]);
+            const float pv = ly0[q] * top + ly1[q] * bot;
+            xv[q] = (sk[q] * ms[q] + pv) + cv[q];
+        }
     }
+    // Unconditional LDS stores to the same clamped indices (surplus lanes rewrite the last element with the value they
+    // loaded from it): behind an `if (e < n4)` the compiler SINKS each load into its store's branch and waits for it there --
+    // five serialised round trips for the bank (tools/isa_phases.py) instead of the single one this kernel is built around.
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dst[min(tid + q * CONV_THREADS, n4 - 1)] = wv[q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xl[min(tid + q * CONV_THREADS, total_x - 1)] = xv[q];
     // remainders of very large banks / tiles (not reached by the decoder's own shapes)
     for (int e = tid + 8 * CONV_THREADS; e < n4; e += CONV_THREADS) dst[e] = src[e];
     for (int e = tid + 4 * CONV_THREADS; e < total_x; e += CONV_THREADS) {
@@ -179,7 +247,10 @@ void patch_conv1x1_kernel(Conv1Args a) {
         for (int c = part; c < a.cin_g; c += split) acc = fmaf(wr[c], xr[c * npix], acc);
         for (int m = split >> 1; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
         if (live && part == 0) {
-            if (a.scale) acc = fmaf(acc, a.scale[o], a.shift[o]);
+            if (a.scale) {
+                if (base == 0) acc = fmaf(acc, sc_first, sh_first);       // requested with the bank: no round trip here
+                else acc = fmaf(acc, a.scale[o], a.shift[o]);
+            }
             acc = apply_act(acc, a.act);
             const int u = pix / a.pw, v = pix - u * a.pw;
             a.y[(((size_t)b * a.cout + o) * a.in.H + (i * a.ph + u)) * a.in.W + (j * a.pw + v)] = acc;
