@@ -100,6 +100,26 @@ __device__ __forceinline__ float sigmoidf_fast(float t) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * -1.44269504088896341f));
 }
 
+// Sums across lanes on the DPP data path (no LDS crossbar: a __shfl_xor is a ds_bpermute_b32, ~150 cycles of latency each,
+// and a 6-step butterfly of them is ~0.4 us in a kernel whose whole budget is 2-4 us).  rowsum16: every lane of a row of 16
+// gets the row's total (xor 1, xor 2, half-mirror, mirror: the same pairs from both sides, so all 16 results are
+// bit-identical); wave_sum64: the four row totals combined through v_readlane, identical in all 64 lanes.
+__device__ __forceinline__ float rowsum16(float v) {
+    int x = __float_as_int(v);
+    auto step = [&](int moved) { x = __float_as_int(__int_as_float(x) + __int_as_float(moved)); };
+    step(__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false));      // quad_perm [1,0,3,2]
+    step(__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false));      // quad_perm [2,3,0,1]
+    step(__builtin_amdgcn_update_dpp(x, x, 0x141, 0xf, 0xf, false));     // row_half_mirror
+    step(__builtin_amdgcn_update_dpp(x, x, 0x140, 0xf, 0xf, false));     // row_mirror
+    return __int_as_float(x);
+}
+__device__ __forceinline__ float wave_sum64(float v) {
+    const int x = __float_as_int(rowsum16(v));
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(x, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(x, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(x, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(x, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == HS_ACT_RELU)  return fmaxf(v, 0.0f);
     if (act == HS_ACT_RELU6) return fminf(fmaxf(v, 0.0f), 6.0f);

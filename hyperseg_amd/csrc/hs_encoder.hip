@@ -156,7 +156,7 @@ void depthwise_conv_kernel(const float* __restrict__ x, const float* __restrict_
     // squeeze-excite pooling: deterministic per-workgroup partial sums of the outputs (summed by hs_se_gate_fwd)
     if (pool_partial) {
         __shared__ float wsum[4];
-        for (int m = 32; m > 0; m >>= 1) psum += __shfl_xor(psum, m, 64);
+        psum = wave_sum64(psum);
         if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = psum;
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -223,7 +223,7 @@ __device__ __forceinline__ void se_squeeze_body(int j, int b, const float* __res
                 if (e0 + 256 * u < n) acc = fmaf(pv[u], wv[u], acc);
         }
     }
-    for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    acc = wave_sum64(acc);
     __syncthreads();                         // ws may still be read by a previous call of this body
     if ((tid & 63) == 0) ws[tid >> 6] = acc;
     __syncthreads();
@@ -376,8 +376,7 @@ void se_gate_fused_kernel(const float* __restrict__ partial, int nblk, float inv
         mean_c[ch] = t * inv_hw;
     }
     __syncthreads();
-    // ---- phase B: squeezed activations, wave w owns rows w, w + 4, ...; the wave reductions of four rows run together
-    // (a __shfl_xor is an LDS-crossbar round trip: one row at a time would serialise 48 of them)
+    // ---- phase B: squeezed activations, wave w owns rows w, w + 4, ...; sums over the wave on the DPP path
     float4 mv[3];
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
@@ -386,32 +385,17 @@ void se_gate_fused_kernel(const float* __restrict__ partial, int nblk, float inv
         if (k >= c4) mv[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
 #pragma unroll
-    for (int r0 = 0; r0 < 8; r0 += 4) {
-        if (4 * r0 < Csq) {                                                         // uniform
-            float acc4[4];
+    for (int r = 0; r < 8; ++r) {
+        if (4 * r < Csq) {                                                          // uniform
+            float a = 0.0f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float a = 0.0f;
-#pragma unroll
-                for (int u = 0; u < 3; ++u) {
-                    a = fmaf(w1v[r0 + q][u].x, mv[u].x, a); a = fmaf(w1v[r0 + q][u].y, mv[u].y, a);
-                    a = fmaf(w1v[r0 + q][u].z, mv[u].z, a); a = fmaf(w1v[r0 + q][u].w, mv[u].w, a);
-                }
-                acc4[q] = a;
+            for (int u = 0; u < 3; ++u) {
+                a = fmaf(w1v[r][u].x, mv[u].x, a); a = fmaf(w1v[r][u].y, mv[u].y, a);
+                a = fmaf(w1v[r][u].z, mv[u].z, a); a = fmaf(w1v[r][u].w, mv[u].w, a);
             }
-#pragma unroll
-            for (int mk = 32; mk > 0; mk >>= 1) {
-                float t4[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) t4[q] = __shfl_xor(acc4[q], mk, 64);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc4[q] += t4[q];
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int j = wave + 4 * (r0 + q);
-                if (lane == 0 && j < Csq) zs[j] = swishf(acc4[q] + b1v[r0 + q]);
-            }
+            a = wave_sum64(a);
+            const int j = wave + 4 * r;
+            if (lane == 0 && j < Csq) zs[j] = swishf(a + b1v[r]);
         }
     }
     __syncthreads();

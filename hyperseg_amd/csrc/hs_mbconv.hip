@@ -202,7 +202,7 @@ void mbconv_expand_dw_kernel(MbxArgs a) {
             }
             // SE pooling: one partial sum per (channel, tile), reduced over the channel's 16 lanes
             if (a.pool) {
-                for (int m = 8; m > 0; m >>= 1) psum += __shfl_xor(psum, m, 64);
+                psum = rowsum16(psum);         // the channel's 16 lanes are one DPP row
                 if (u == 0 && h < Cmid) a.pool[((size_t)b * Cmid + h) * ntiles + ty * a.tiles_x + tx] = psum;
             }
         }

@@ -235,8 +235,7 @@ void patch_ir_split_kernel(IrFusedArgs a) {
         const int idx = e < 4 * HP ? e - seg * HP : (e - 4 * HP) - (seg - 4) * CP;
         const float* src = seg == 0 ? a.s1 : seg == 1 ? a.b1 : seg == 2 ? a.s2 : seg == 3 ? a.b2 : seg == 4 ? a.s3 : a.b3;
         const int n = seg < 4 ? hid : COUT;
-        float v = 0.0f;
-        if (idx < n) v = src[idx];
+        const float v = src[min(idx, n - 1)] * (idx < n ? 1.0f : 0.0f);     // no branch around the load (it was waited for)
         return (seg == 2 || seg == 3) ? v * H2_SCALE : v;
     };
     float bnreg[2];
