@@ -507,7 +507,7 @@ def affine_act_(x, scale, shift, act=0, residual=None):
 def se_gate(partial, batch, hw, w_reduce, b_reduce, w_expand, b_expand, w_proj=None, out_scale=None):
     """Squeeze-excite gate from pooled partial sums; with ``w_proj`` (Cout, C[,1,1]) returns the project weights scaled by
     the gate (and by ``out_scale`` (Cout), the project conv's folded BN scale), (B, Cout, C, 1, 1); otherwise the gate
-    (B, C).  Two launches (squeeze, excite)."""
+    (B, C).  One launch for blocks with small reduce weights (C <= 768, Csq <= 32), else two (squeeze, excite)."""
     c = partial.shape[0] // batch
     csq = w_reduce.shape[0]
     dev = partial.device

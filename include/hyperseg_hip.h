@@ -247,7 +247,8 @@ int hs_depthwise_conv_fwd(const float* x, int32_t batch, int32_t channels, int32
  * raw GEMM output is consumed directly; zero padding stays zero.
  * pool_partial (optional): (B*C, hs_depthwise_pool_blocks(Ho, Wo)) per-workgroup sums of the outputs, the squeeze-excite
  * pooling for free.  hs_se_gate_fwd turns them into the SE gate (pool -> 1x1 reduce + swish -> 1x1 expand -> sigmoid;
- * efficientnet.py:106-111) in two launches: squeezed (B, c_squeezed) = swish(reduce(pool)), then gate (B, channels); if
+ * efficientnet.py:106-111): squeezed (B, c_squeezed) = swish(reduce(pool)), then gate (B, channels) -- one launch when the
+ * reduce weights are small (channels <= 768, c_squeezed <= 32: every workgroup re-derives the squeezed vector), two otherwise; if
  * w_proj (c_out, channels) is given it also folds the gate -- and, with out_scale (c_out), the project convolution's folded
  * BatchNorm scale -- into the project weights: w_scaled[b, o, c] = w_proj[o, c] * gate[b, c] * out_scale[o].
  * w_reduce is (c_squeezed, channels); w_expand is passed TRANSPOSED, (c_squeezed, channels): both are read coalesced. */
