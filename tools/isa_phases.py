@@ -5,7 +5,7 @@ how many vector loads are issued before the first vmcnt wait, how many loads are
 each: typically a select the compiler turned into an exec-masked load), and how many ds_bpermute (wave shuffles) are immediately waited for (serialised LDS-crossbar
 round trips).  A dependent launch in a replayed graph costs 1.6-2.2 us on an MI355X (profiles/round2_graph_launch_floor.txt);
 the small encoder/decoder kernels take 4.6-9 us, and the difference is exactly these chains.
-    python tools/isa_phases.py hs_encoder.hip [kernel-name-substring]"""
+    python tools/isa_phases.py hs_encoder.hip|/abs/path/to/source.hip [kernel-name-substring]"""
 import os
 import re
 import subprocess
@@ -19,7 +19,7 @@ def assembly(src):
     out = os.path.join(tempfile.gettempdir(), 'hs_isa_' + os.path.basename(src).replace('.hip', '.s'))
     flags = [f for f in B.FLAGS if f != '-fPIC']
     cmd = [B._hipcc(), *flags, '-S', '--cuda-device-only', '-I', os.path.join(os.path.dirname(B.CSRC), '..', 'include'),
-           '-I', B.CSRC, os.path.join(B.CSRC, src), '-o', out]
+           '-I', B.CSRC, src if os.path.isabs(src) else os.path.join(B.CSRC, src), '-o', out]
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
     return open(out).read().splitlines()
 
