@@ -2,6 +2,7 @@
 (python -m hyperseg_amd.build) contains none of this, and the product sources carry no dev hooks: the 'stamps' variant
 is made by patching a COPY of hs_patch_ir_fused.hip ('stamps_split': of hs_patch_ir_split.hip).
     stamps    s_memtime stamps of wave 0 of every workgroup at the phase boundaries (tools/ir_phase_times.py reads them)
+    kpreload  the whole library with -amdgpu-kernarg-preload-count=16 (not yet measured)
 """
 import os
 import re
@@ -84,6 +85,9 @@ VARIANTS = {
     'nostore': dict(flags=[], extra=[], patch='nostore'),
     'ntstore': dict(flags=[], extra=[], patch='ntstore'),
     'px2wg': dict(flags=[], extra=[], patch='px2wg', file='hs_patch_ir_px.hip'),
+    # untried: gfx950 can preload the first kernel arguments into SGPRs at wave launch -- one scalar
+    # round trip less at the top of every kernel.  A/B with HS_HIP_LIB=hyperseg_amd/lib/libhyperseg_hip_kpreload.so
+    'kpreload': dict(flags=['-mllvm', '-amdgpu-kernarg-preload-count=16'], extra=[], patch=None),
 }
 
 if __name__ == '__main__':
