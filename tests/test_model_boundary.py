@@ -95,6 +95,36 @@ def test_decoder_refuses_cpu(model_m):
         model_m(torch.rand(1, 3, 64, 64))
 
 
+def test_graphed_model_host_logic(model_m):
+    """utils.inference.GraphedModel off the GPU: nothing on a CPU model is graphable, so every call is handed to the wrapped
+    model unchanged (which, without a GPU, fails loudly in the decoder -- no CPU fallback); the harness hook, the graph
+    table and reset() behave; state-dict keys are the wrapped model's under ``model.``."""
+    from hyperseg_amd._hip import HipLibraryError
+    from hyperseg_amd.fps import measure_fps, synthetic_batches
+    from hyperseg_amd.utils.inference import GraphedModel
+    served = GraphedModel(model_m, clone_output=True)
+    x = torch.rand(1, 3, 64, 64)
+    assert served.accepts_host_input and not served._graphable(x) and not served._graphable([x, x])
+    with torch.no_grad(), pytest.raises(HipLibraryError):
+        served(x)
+    assert served._graphs == {}
+    assert set(served.state_dict()) == {'model.' + k for k in model_m.state_dict()}
+    served._graphs['stale'] = None
+    model_m.load_state_dict(model_m.state_dict())               # the post-hook drops captured graphs
+    assert served._graphs == {}
+    # measure_fps hands a wrapper that accepts host input the (pinned) host batch itself
+    seen = []
+
+    class Probe(torch.nn.Module):
+        accepts_host_input = True
+
+        def forward(self, t):
+            seen.append(t.device.type)
+            return torch.zeros(t.shape[0], 3, *t.shape[-2:])
+    res = measure_fps(Probe(), synthetic_batches(2, 1, (8, 8), 3, torch.device('cpu')), torch.device('cpu'), 3, passes=1)
+    assert seen == ['cpu', 'cpu'] and res['frames'] == 2
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('tag', ['S', 'L'])
 def test_model_end_to_end_other_variants(golden, tag):
