@@ -76,6 +76,10 @@ PATCHES = {
                              ' else asm volatile("" :: "v"(acc3[m][jt][r]));')],
     # occupancy probe of the lane-per-pixel kernel: 28 KB of unused LDS -> 2 workgroups per CU instead of 3 at HyperSeg-L level 5
     'px2wg': [('    constexpr size_t lds = (size_t)G::FLOATS * sizeof(float);', '    constexpr size_t lds = (size_t)G::FLOATS * sizeof(float) + 28 * 1024;')],
+    # the LDS-tiled depthwise form (BN0 + swish once per input element) at batch 1: only the 5x5 launches / every launch that
+    # qualifies.  The late 5x5 launches are vector-ALU bound (40 swishes per thread on the taps, ~5 waves per SIMD): DESIGN 7.1
+    'dwtile_k5': [('    if (in_scale && nplanes >= 8192 && threads == 256', '    if (in_scale && (nplanes >= 8192 || k == 5) && threads == 256')],
+    'dwtile_all': [('    if (in_scale && nplanes >= 8192 && threads == 256', '    if (in_scale && nplanes >= 1 && threads == 256')],
     'ntstore': [(STORE_LINE, '                for (int jt = 0; jt < J3; ++jt) __builtin_nontemporal_store(fmaf(acc3[m][jt][r], sc, sh), &yo[yoff[jt]]);')],
 }
 
@@ -87,6 +91,8 @@ VARIANTS = {
     'px2wg': dict(flags=[], extra=[], patch='px2wg', file='hs_patch_ir_px.hip'),
     # untried: gfx950 can preload the first kernel arguments into SGPRs at wave launch -- one scalar
     # round trip less at the top of every kernel.  A/B with HS_HIP_LIB=hyperseg_amd/lib/libhyperseg_hip_kpreload.so
+    'dwtile_k5': dict(flags=[], extra=[], patch='dwtile_k5', file='hs_encoder.hip'),
+    'dwtile_all': dict(flags=[], extra=[], patch='dwtile_all', file='hs_encoder.hip'),
     'kpreload': dict(flags=['-mllvm', '-amdgpu-kernarg-preload-count=16'], extra=[], patch=None),
 }
 
