@@ -79,6 +79,7 @@ PATCHES = {
     # the LDS-tiled depthwise form (BN0 + swish once per input element) at batch 1: only the 5x5 launches / every launch that
     # qualifies.  The late 5x5 launches are vector-ALU bound (40 swishes per thread on the taps, ~5 waves per SIMD): DESIGN 7.1
     'dwtile_k5': [('    if (in_scale && nplanes >= 8192 && threads == 256', '    if (in_scale && (nplanes >= 8192 || k == 5) && threads == 256')],
+    'dwtile_k5_128': [('    if (in_scale && nplanes >= 8192 && threads == 256', '    if (in_scale && (nplanes >= 8192 || k == 5) && threads >= 128')],
     'dwtile_all': [('    if (in_scale && nplanes >= 8192 && threads == 256', '    if (in_scale && nplanes >= 1 && threads == 256')],
     'ntstore': [(STORE_LINE, '                for (int jt = 0; jt < J3; ++jt) __builtin_nontemporal_store(fmaf(acc3[m][jt][r], sc, sh), &yo[yoff[jt]]);')],
 }
@@ -92,6 +93,7 @@ VARIANTS = {
     # untried: gfx950 can preload the first kernel arguments into SGPRs at wave launch -- one scalar
     # round trip less at the top of every kernel.  A/B with HS_HIP_LIB=hyperseg_amd/lib/libhyperseg_hip_kpreload.so
     'dwtile_k5': dict(flags=[], extra=[], patch='dwtile_k5', file='hs_encoder.hip'),
+    'dwtile_k5_128': dict(flags=[], extra=[], patch='dwtile_k5_128', file='hs_encoder.hip'),   # + the 16x32 maps (128 threads)
     'dwtile_all': dict(flags=[], extra=[], patch='dwtile_all', file='hs_encoder.hip'),
     'kpreload': dict(flags=['-mllvm', '-amdgpu-kernarg-preload-count=16'], extra=[], patch=None),
 }
