@@ -7,6 +7,8 @@ cannot do: when a dynamic convolution is followed by an eval-mode BatchNorm2d an
 the child's ``forward_fused`` (BN folded to scale/shift, activation in the epilogue).
 The channel slice is passed as a view -- the reference's ``.contiguous()`` copy (line 35) is gone.
 """
+from itertools import accumulate
+
 import torch
 import torch.nn as nn
 
@@ -23,14 +25,13 @@ def _act_code(m):
 
 class MetaSequential(nn.Sequential):
     def __init__(self, *args):
-        super(MetaSequential, self).__init__(*args)
-        self.hyper_params = 0
-        self._ranges = [0]
+        super().__init__(*args)
+        # child i consumes channels [_ranges[i], _ranges[i + 1]) of a weight tensor (or the next entry of a weight list);
+        # the container advertises the total, so containers nest (the reference's contract, meta_sequential.py:10-17)
+        counts = [getattr(m, 'hyper_params', 0) for m in self]
+        self._ranges = [0] + list(accumulate(counts))
+        self.hyper_params = self._ranges[-1]
         self._folded = {}
-        for module in self:
-            if hasattr(module, 'hyper_params'):
-                self.hyper_params += module.hyper_params
-            self._ranges.append(self.hyper_params)
 
     def _fold(self, idx, bn):
         cache = self._folded.get(idx)
