@@ -3,7 +3,7 @@ matrix cores with split operands).  Not part of the product library.
 
     python tools/gemm_split_kernel_probe.py --build        # hipcc -> hyperseg_amd/lib/libhs_dev_gemm.so (no GPU needed)
     python tools/gemm_split_kernel_probe.py --emulate      # CPU emulation of the kernel's arithmetic vs float64 (no GPU needed)
-    python tools/gemm_split_kernel_probe.py                # on an MI355X: accuracy vs float64 and time vs torch.mm per shape
+    python tools/gemm_split_kernel_probe.py [--only 0,3,9] # on an MI355X: accuracy vs float64 and time vs torch.mm per shape
 
 Shapes: the lean-route GEMMs of HyperSeg-M's prepared encoder at 1024x512 (M = Cout, K = Cin, N = pixels)."""
 import ctypes as C
@@ -98,7 +98,8 @@ def main():
     lib.hs_dev_gemm_split.argtypes = [C.c_void_p] * 6 + [C.c_int32] * 8 + [C.c_void_p]
     dev = torch.device('cuda:0')
     g = torch.Generator().manual_seed(0)
-    for m, k, n in SHAPES:
+    only = [int(v) for v in sys.argv[sys.argv.index('--only') + 1].split(',')] if '--only' in sys.argv else range(len(SHAPES))
+    for m, k, n in [SHAPES[i] for i in only]:
         nwv, ks, kp = plan(k)
         mt = 8 if m >= 128 else (4 if m >= 64 else 2)
         w = (torch.randn(m, k, generator=g) / k ** 0.5).to(dev)
