@@ -57,6 +57,30 @@ def plan(k):
     return best[2], best[3], best[2] * best[3] * 32
 
 
+def plan_v1(k):
+    """v1: (nwv, ks, Kp) with nwv in {2, 4, 8} waves, the fewest k-steps per wave (ks <= 5: K <= 1280)."""
+    steps = -(-k // 32)
+    nwv = 2
+    while nwv < 8 and nwv < steps:
+        nwv *= 2
+    ks = -(-steps // nwv)
+    return (nwv, ks, nwv * ks * 32) if ks <= 5 else None
+
+
+def fragment_order(hi, lo, inv):
+    """(M, Kp) f16 pieces -> [RT][KST][piece][lane = lrow + 16 kg][8] halfs (GemmArgsV1), rows padded to 16 RT."""
+    m, kp = hi.shape
+    rt = -(-m // 16)
+    pad = 16 * rt - m
+    if pad:
+        hi, lo = torch.nn.functional.pad(hi, (0, 0, 0, pad)), torch.nn.functional.pad(lo, (0, 0, 0, pad))
+        inv = torch.nn.functional.pad(inv, (0, pad), value=1.0)
+
+    def sw(t):          # [RT][16 lrow][KST][4 kg][8 j] -> [RT][KST][kg][lrow][j]
+        return t.view(rt, 16, kp // 32, 4, 8).permute(0, 2, 3, 1, 4)
+    return torch.stack([sw(hi), sw(lo)], dim=2).contiguous(), inv.contiguous()
+
+
 def emulate(w, x, gate):
     """The kernel's arithmetic on the CPU (f32 accumulation emulated in f64 of exactly representable f16 products)."""
     m, k = w.shape
@@ -96,6 +120,8 @@ def main():
     lib = C.CDLL(LIB)
     lib.hs_dev_gemm_split.restype = C.c_int
     lib.hs_dev_gemm_split.argtypes = [C.c_void_p] * 6 + [C.c_int32] * 8 + [C.c_void_p]
+    lib.hs_dev_gemm_split_v1.restype = C.c_int
+    lib.hs_dev_gemm_split_v1.argtypes = [C.c_void_p] * 5 + [C.c_int32] * 7 + [C.c_void_p]
     dev = torch.device('cuda:0')
     g = torch.Generator().manual_seed(0)
     only = [int(v) for v in sys.argv[sys.argv.index('--only') + 1].split(',')] if '--only' in sys.argv else range(len(SHAPES))
@@ -145,10 +171,30 @@ def main():
                 gr.replay()
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) / (reps * inner) * 1e6
-        t_split = timed(run)
+        t_split = timed(run) if '--v1-only' not in sys.argv else float('nan')
         t_mm = timed(lambda: torch.mm(wg, x, out=y2))
         print(f'M {m:5d} K {k:5d} N {n:5d}  plan nwv {nwv} ks {ks} mt {mt}:  split {t_split:6.2f} us (err {e_split:.1e}, beta path {e_beta:.1e})'
-              f'   torch.mm {t_mm:6.2f} us (err {e_f32:.1e})')
+              f'   torch.mm {t_mm:6.2f} us (err {e_f32:.1e})', flush=True)
+        p1 = plan_v1(k)
+        if p1 is None:
+            continue
+        nwv1, ks1, kp1 = p1
+        hi1, lo1, inv1 = presplit(w, kp1)
+        wsw, inv1 = fragment_order(hi1, lo1, inv1)
+        y1 = torch.zeros(1, m, n, device=dev)
+
+        def run1(beta=0):
+            st = lib.hs_dev_gemm_split_v1(wsw.data_ptr(), inv1.data_ptr(), gate.data_ptr(), x.data_ptr(), y1.data_ptr(),
+                                          1, m, k, kp1, n, beta, nwv1, torch.cuda.current_stream().cuda_stream)
+            assert st == 0, st
+        run1()
+        torch.cuda.synchronize()
+        e1 = float((y1[0].double() - ref).abs().max() / ref.abs().max())
+        run1(1)
+        torch.cuda.synchronize()
+        e1b = float((y1[0].double() - 2 * ref).abs().max() / ref.abs().max())
+        t1 = timed(run1)
+        print(f'{"":24s}v1 plan nwv {nwv1} ks {ks1}:          split {t1:6.2f} us (err {e1:.1e}, beta path {e1b:.1e})', flush=True)
 
 
 if __name__ == '__main__':
