@@ -531,6 +531,66 @@ def se_gate(partial, batch, hw, w_reduce, b_reduce, w_expand, b_expand, w_proj=N
     return w_scaled if w_proj is not None else gate
 
 
+class SplitWeights:
+    """A static 1x1-conv weight prepared for ``hs_gemm_split_fwd``: f16 hi / lo pieces of the power-of-two row-scaled weight in
+    MFMA-fragment order + the inverse row scales (include/hyperseg_hip.h)."""
+    __slots__ = ('frag', 'inv', 'c_out', 'c_in', 'kp')
+
+    def __init__(self, frag, inv, c_out, c_in, kp):
+        self.frag, self.inv, self.c_out, self.c_in, self.kp = frag, inv, c_out, c_in, kp
+
+
+@torch.no_grad()
+def gemm_split_weights(w, row_scale=None):
+    """``w`` (Cout, Cin[, 1, 1]) f32 -> SplitWeights, or None when the kernel does not cover Cin (> 1280).  ``row_scale``
+    (Cout): folded into the rows first (a BatchNorm scale).  Torch tensor ops only; runs once per weight."""
+    w = w.detach().flatten(1).float()
+    m, k = w.shape
+    kp = _hip.lib.hs_gemm_split_kp(k)
+    if kp < 0:
+        return None
+    if row_scale is not None:
+        w = w * row_scale.detach().float()[:, None]
+    # 2^(141 - eb), eb = biased exponent of the row maximum clamped to [27, 254]: row * scale < 2^15 (gs_exp_of / gs_scale_of)
+    eb = (w.abs().amax(1).contiguous().view(torch.int32) >> 23).clamp(27, 254)
+    one = torch.ones(m, device=w.device)
+    ws = w * torch.ldexp(one, 141 - eb)[:, None]
+    hi = ws.half()
+    lo = (ws - hi.float()).half()
+    rt = -(-m // 16)
+    pad = (0, kp - k, 0, 16 * rt - m)
+    hi, lo = torch.nn.functional.pad(hi, pad), torch.nn.functional.pad(lo, pad)
+    inv = torch.nn.functional.pad(torch.ldexp(one, eb - 141), (0, 16 * rt - m), value=1.0)
+
+    def fragment_order(t):      # [RT][16 rows][KST][4 kgroups][8] -> [RT][KST][kgroup][row][8]: lane = row + 16 * kgroup
+        return t.view(rt, 16, kp // 32, 4, 8).permute(0, 2, 3, 1, 4)
+    frag = torch.stack([fragment_order(hi), fragment_order(lo)], dim=2).contiguous()
+    return SplitWeights(frag, inv.contiguous(), m, k, kp)
+
+
+@_on_operand_device
+def gemm_split(sw, x, gate=None, out=None, accumulate=False):
+    """y (B, Cout, H, W) (= | +=) W @ (gate[:, :, None] * x) per frame on the f16 matrix cores with split operands
+    (hs_gemm_split_fwd).  ``out``: written (or accumulated onto, ``accumulate=True``) in place."""
+    b, cin, h, w = x.shape
+    if cin != sw.c_in:
+        raise ValueError(f'input has {cin} channels, the weight {sw.c_in}')
+    if accumulate and out is None:
+        raise ValueError('accumulate=True needs out')
+    if out is None:
+        out = torch.empty(b, sw.c_out, h, w, device=x.device, dtype=torch.float32)
+    elif tuple(out.shape) != (b, sw.c_out, h, w):
+        raise ValueError(f'out has shape {tuple(out.shape)}, expected {(b, sw.c_out, h, w)}')
+    if gate is not None and tuple(gate.shape) != (b, cin):
+        raise ValueError(f'gate has shape {tuple(gate.shape)}, expected {(b, cin)}')
+    st = _hip.lib.hs_gemm_split_fwd(_hip.dev_ptr(sw.frag, 'w_frag', torch.float16), _hip.dev_ptr(sw.inv, 'w_inv'),
+                                    _hip.dev_ptr(gate, 'gate') if gate is not None else None, _hip.dev_ptr(x, 'x'),
+                                    _hip.dev_ptr(out, 'out'), b, sw.c_out, cin, sw.kp, h * w, 1 if accumulate else 0,
+                                    _hip.stream_ptr())
+    _hip.check(st, 'hs_gemm_split_fwd')
+    return out
+
+
 @_on_operand_device
 def upsample_bilinear(x, size):
     """F.interpolate(x, size, mode='bilinear', align_corners=False)."""

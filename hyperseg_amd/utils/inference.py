@@ -10,6 +10,10 @@ model's own parameters and keep their folded BatchNorm affines in non-persistent
                          BN shift deferred to the consumers), see the class docstring
   * ``FusedPointwise``   feature reducers and the head conv              -> hs_pointwise_conv_fwd | GEMM + hs_affine_act_fwd
   * ``FusedContextHead`` the v1_0 WeightMapper without its concatenations -> library GEMMs + hs_affine_act_fwd
+``split_gemm=True`` (with ``fused_depthwise``; OFF by default and not used by bench.py: the kernel was measured as a dev probe
+at the end of round 2, profiles/round2_dev_gemm_split_probe.txt, its wiring here is untested on a GPU) sends the MBConv
+blocks' expand / project 1x1 convolutions and the GEMM-routed reducers through ``hs_gemm_split_fwd`` (f16 matrix cores, split
+operands, SE gate applied inside) instead of the library f32 GEMM.
 ``fold_bn=True`` additionally folds the remaining Conv -> BatchNorm pairs of the stock modules into the convolutions
 (that one DOES change the state dict: BN entries turn into identities) and ``channels_last`` switches the stock encoder's
 memory format; neither is used by bench.py.
@@ -103,10 +107,21 @@ class FusedPointwise(nn.Module):
         self.register_buffer('shift', shift, persistent=False)
         self._conv = [conv]
         self.act = act
+        self.split_gemm = False          # prepare_for_inference(split_gemm=True): hs_gemm_split_fwd instead of the library GEMM
+        self._split = {}                 # (with BN scale, device) -> functional.SplitWeights | None (Cin not covered)
 
     @property
     def conv(self):
         return self._conv[0]
+
+    def split_weights(self, with_scale, device):
+        """The conv weight prepared for hs_gemm_split_fwd (built once per FusedPointwise, i.e. again after every
+        load_state_dict -- _install_fused recreates these modules); ``with_scale``: BN scale folded into the rows."""
+        key = (bool(with_scale), device)
+        if key not in self._split:
+            from .. import functional as HF
+            self._split[key] = HF.gemm_split_weights(self.conv.weight, self.scale if with_scale else None)
+        return self._split[key]
 
     @torch.no_grad()
     def absorb_input_offset(self, offset):
@@ -124,6 +139,11 @@ class FusedPointwise(nn.Module):
         """The bare GEMM: W (Cout, Cin) @ x (Cin, HW) per frame (a strided-batched GEMM with a shared A for a batch); BN +
         activation are left to the consumer."""
         b, cin, h, w = x.shape
+        if self.split_gemm and x.is_cuda:
+            sw = self.split_weights(False, x.device)
+            if sw is not None:
+                from .. import functional as HF
+                return HF.gemm_split(sw, x.contiguous())
         with gemm_library(h * w, b):
             if b == 1:
                 return torch.mm(self.conv.weight.view(-1, cin), x.view(cin, h * w)).view(1, -1, h, w)
@@ -142,6 +162,9 @@ class FusedPointwise(nn.Module):
             return HF.pointwise_conv(x, conv.weight, gate, self.scale, self.shift, self.act, residual)
         if (h * w) % 4 != 0:
             raise NotImplementedError('feature maps with H*W % 4 != 0')
+        sw = self.split_weights(False, x.device) if self.split_gemm else None
+        if sw is not None:
+            return HF.affine_act_(HF.gemm_split(sw, x, gate=gate), self.scale, self.shift, self.act, residual)
         if gate is None:
             # batches: one strided-batched GEMM (MIOpen would go NCHW -> NHWC -> implicit GEMM -> NCHW)
             y = F.conv2d(x, conv.weight) if b == 1 else self.raw(x)
@@ -257,6 +280,16 @@ class FusedMBConv(nn.Module):
         # deferred shift -> nothing follows the GEMM: the bare library GEMM wins for all but the smallest K; otherwise the
         # MFMA kernel with its fused epilogue wins wherever it applies (few channels, many pixels)
         if lean and (y.shape[1] > LEAN_MFMA_MAX_CIN if self.defer_shift else not proj.uses_mfma(y)):
+            sw = proj.split_weights(True, y.device) if proj.split_gemm else None
+            if sw is not None:
+                # our own GEMM (f16 matrix cores, split operands): the BN2 scale is folded into the static split weights, the
+                # gate multiplies the rows of y on load -- no per-frame copy of the project weights is written
+                gate = HF.se_gate(partial, b, ho * wo, red.weight, red.bias, self._exp_t, exp.bias)
+                if self.defer_shift:
+                    if skip is None:
+                        return HF.gemm_split(sw, y, gate=gate)
+                    return HF.gemm_split(sw, y, gate=gate, out=skip, accumulate=True)   # in place: no other consumer
+                return HF.affine_act_(HF.gemm_split(sw, y, gate=gate), None, proj.shift, 0, skip)
             # gate (and BN2 scale) folded into the project weights by the SE kernel: ~1e5 weights instead of a pass over y
             wp = HF.se_gate(partial, b, ho * wo, red.weight, red.bias, self._exp_t, exp.bias,
                             w_proj=proj.conv.weight, out_scale=proj.scale)
@@ -408,9 +441,12 @@ def _install_fused(model):
     bb.to(dev)                                      # new non-persistent buffers follow the model's device
     if type(wm).__name__ == 'WeightMapper' and hasattr(wm, 'in_conv') and hasattr(wm, 'up_blocks') and wm.levels >= 2:
         wm._fused = FusedContextHead(wm).to(dev)
+    for m in bb.modules():                          # opt-in (NOT measured inside the model yet): our GEMM for the 1x1 convs
+        if isinstance(m, FusedPointwise):
+            m.split_gemm = bool(getattr(model, '_hs_split_gemm', False))
 
 
-def prepare_for_inference(model, fold_bn=True, channels_last=False, fused_depthwise=False):
+def prepare_for_inference(model, fold_bn=True, channels_last=False, fused_depthwise=False, split_gemm=False):
     """In place; returns the number of BatchNorms folded by ``fold_bn``.  ``model``: a HyperGen in eval mode (module
     docstring for what each switch does).  The fused routes are installed first, so ``fold_bn`` only touches the
     Conv -> BatchNorm pairs that no fused route reads."""
@@ -421,6 +457,7 @@ def prepare_for_inference(model, fold_bn=True, channels_last=False, fused_depthw
                            'BatchNorm shifts would be absorbed twice')
     wm = model.weight_mapper
     if fused_depthwise:
+        model._hs_split_gemm = bool(split_gemm)
         _install_fused(model)
         if not fold_bn and not getattr(model, '_hs_refresh_hook', None):
             # the folded BN affines and the deferred-shift chain are derived from the parameters at this moment: rebuild

@@ -1,0 +1,85 @@
+"""hs_gemm_split_fwd (opt-in encoder GEMM on the f16 matrix cores, include/hyperseg_hip.h).  The host side (weight split,
+fragment order, plan) is checked on the CPU; the GPU tests are OPT-IN (HS_TEST_SPLIT_GEMM=1) until the route has had its first
+validated GPU run inside the model -- the kernel itself was measured as a dev probe (profiles/round2_dev_gemm_split_probe.txt)."""
+import os
+
+import pytest
+import torch
+
+from conftest import rel_err
+
+opt_in = pytest.mark.skipif(os.environ.get('HS_TEST_SPLIT_GEMM') != '1', reason='opt-in: HS_TEST_SPLIT_GEMM=1')
+
+
+def test_split_weights_host_side():
+    from hyperseg_amd import functional as HF
+    from hyperseg_amd._hip import lib
+    # plan: Cin rounded up to (2 | 4 | 8 waves) x (<= 5 k-steps) x 32; beyond 1280 the kernel declines
+    assert [lib.hs_gemm_split_kp(k) for k in (1, 32, 80, 112, 192, 240, 480, 672, 1152, 1280)] == \
+        [64, 64, 128, 128, 256, 256, 512, 768, 1280, 1280]
+    assert lib.hs_gemm_split_kp(1281) < 0 and lib.hs_gemm_split_kp(1920) < 0 and lib.hs_gemm_split_kp(0) < 0
+    g = torch.Generator().manual_seed(0)
+    for m, k in ((40, 240), (19, 80), (112, 672)):
+        w = torch.randn(m, k, 1, 1, generator=g) * torch.logspace(-3, 3, m).view(m, 1, 1, 1)      # rows of very different size
+        scale = torch.rand(m, generator=g) + 0.5
+        sw = HF.gemm_split_weights(w, scale)
+        assert (sw.c_out, sw.c_in, sw.kp) == (m, k, lib.hs_gemm_split_kp(k))
+        rt, kst = -(-m // 16), sw.kp // 32
+        assert tuple(sw.frag.shape) == (rt, kst, 2, 4, 16, 8) and sw.frag.dtype == torch.float16 and sw.inv.numel() == 16 * rt
+        # back from fragment order: lane = row % 16 + 16 * kgroup holds w[16 R + row % 16][32 S + 8 kgroup + j]
+        back = sw.frag.permute(2, 0, 4, 1, 3, 5).reshape(2, 16 * rt, sw.kp).float()
+        ref = (w.flatten(1) * scale[:, None])
+        rebuilt = (back[0].double() + back[1].double()) * sw.inv.double()[:, None]
+        assert float(back[:, m:].abs().max() if 16 * rt > m else 0.0) == 0.0 and float(back[:, :, k:].abs().max()) == 0.0
+        err = (rebuilt[:m, :k] - ref.double()).abs().amax(1) / ref.abs().amax(1).double()
+        assert float(err.max()) < 2.0 ** -21                     # two f16 pieces of a row scaled to < 2^15
+        assert float((back[0].abs().amax(1)[:m]).max()) < 2.0 ** 15
+    assert HF.gemm_split_weights(torch.randn(8, 1920)) is None
+    with pytest.raises(Exception):
+        HF.gemm_split(HF.gemm_split_weights(torch.randn(8, 64)), torch.rand(1, 64, 4, 4))       # CPU tensors: no fallback
+
+
+@opt_in
+@pytest.mark.gpu
+@pytest.mark.parametrize('m,k,hw,batch', [(40, 240, (64, 128), 1), (80, 480, (32, 64), 2), (112, 672, (32, 64), 1), (192, 1152, (16, 32), 1),
+                                          (320, 1152, (16, 32), 2), (480, 80, (32, 64), 1), (19, 33, (5, 7), 1), (1280, 320, (16, 32), 1)])
+def test_gemm_split_vs_float64(m, k, hw, batch):
+    from hyperseg_amd import functional as HF
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(m + k)
+    w = (torch.randn(m, k, generator=g) / k ** 0.5).to(dev)
+    x = (torch.randn(batch, k, *hw, generator=g) * torch.rand(1, k, 1, 1, generator=g) * 4).to(dev)
+    gate = torch.rand(batch, k, generator=g).to(dev)
+    scale = (torch.rand(m, generator=g) + 0.5).to(dev)
+    sw = HF.gemm_split_weights(w, scale)
+    ref = torch.einsum('ok,bkn->bon', (w * scale[:, None]).double(), (x.flatten(2) * gate[:, :, None]).double()).view(batch, m, *hw)
+    y = HF.gemm_split(sw, x, gate=gate)
+    assert rel_err(y.double().cpu(), ref.cpu()) < 2e-6
+    y0 = HF.gemm_split(HF.gemm_split_weights(w), x)
+    ref0 = torch.einsum('ok,bkn->bon', w.double(), x.flatten(2).double()).view(batch, m, *hw)
+    assert rel_err(y0.double().cpu(), ref0.cpu()) < 2e-6
+    acc = torch.ones_like(y)
+    assert HF.gemm_split(sw, x, gate=gate, out=acc, accumulate=True) is acc
+    assert rel_err(acc.double().cpu(), (ref + 1).cpu()) < 2e-6
+
+
+@opt_in
+@pytest.mark.gpu
+@pytest.mark.parametrize('batch,size', [(1, (256, 512)), (2, (256, 256)), (1, (512, 1024))])
+def test_prepared_model_with_split_gemm(batch, size):
+    import copy
+    from hyperseg_amd import configs
+    from hyperseg_amd.utils.inference import prepare_for_inference
+    from hyperseg_amd.utils.synthetic import fill_by_name
+    dev = torch.device('cuda:0')
+    stock = fill_by_name(configs.build('hyperseg-m').eval(), seed=9)
+    fused = copy.deepcopy(stock)
+    prepare_for_inference(fused, fold_bn=False, fused_depthwise=True, split_gemm=True)
+    stock, fused = stock.to(dev), fused.to(dev)
+    x = torch.rand(batch, 3, *size, device=dev)
+    with torch.no_grad():
+        for a, b in zip(stock.backbone(x), fused.backbone(x)):
+            assert rel_err(b.cpu(), a.cpu()) < 5e-5
+        ys = stock(x).cpu()
+        assert rel_err(fused(x).cpu(), ys) < 1e-4
+        assert rel_err(fused(x).cpu(), ys) < 1e-4          # twice: the in-place skip accumulation
