@@ -139,7 +139,7 @@ class FusedPointwise(nn.Module):
         """The bare GEMM: W (Cout, Cin) @ x (Cin, HW) per frame (a strided-batched GEMM with a shared A for a batch); BN +
         activation are left to the consumer."""
         b, cin, h, w = x.shape
-        if self.split_gemm and x.is_cuda:
+        if self.split_gemm:
             sw = self.split_weights(False, x.device)
             if sw is not None:
                 from .. import functional as HF

@@ -246,11 +246,14 @@ def test_inference_prep_matches_stock_encoder(batch):
         assert rel_err(fused(x).cpu(), stock(x).cpu()) < 1e-4
 
 
-@pytest.mark.parametrize('config', ['hyperseg-m', 'hyperseg-s', 'hyperseg-l'])
-def test_deferred_bn_shift_algebra_cpu(monkeypatch, config):
+@pytest.mark.parametrize('config,split', [('hyperseg-m', False), ('hyperseg-s', False), ('hyperseg-l', False),
+                                          ('hyperseg-m', True), ('hyperseg-l', True)])
+def test_deferred_bn_shift_algebra_cpu(monkeypatch, config, split):
     """Host logic of utils.inference (no GPU): the deferred-BN-shift bookkeeping of the fused MBConv blocks is exact.
     The HIP entry points are replaced by plain-torch stand-ins of their documented semantics, the fused encoder is
-    walked by hand (the product path refuses CPU tensors) and must reproduce the stock encoder's features."""
+    walked by hand (the product path refuses CPU tensors) and must reproduce the stock encoder's features.
+    ``split``: the opt-in hs_gemm_split_fwd route -- the REAL host-side weight preparation (row scaling, f16 pieces, fragment
+    order) feeds a stand-in that rebuilds W from it, so both the wiring and the preparation are exercised."""
     import copy
     import torch.nn.functional as F
     from hyperseg_amd import configs, functional as HF
@@ -297,6 +300,22 @@ def test_deferred_bn_shift_algebra_cpu(monkeypatch, config):
         hmid = pointwise(x, w_expand.view(w_expand.shape[0], -1, 1, 1), None, scale0, shift0, 3)
         return dw(hmid, w_dw, stride, pad_top, pad_left, out_size, scale1, shift1, act=3, pool=True)
 
+    used = {'n': 0, 'gated': 0, 'accumulated': 0}
+
+    def gemm_split(sw, x, gate=None, out=None, accumulate=False):
+        rt = sw.frag.shape[0]
+        back = sw.frag.permute(2, 0, 4, 1, 3, 5).reshape(2, 16 * rt, sw.kp).float()        # [piece][row][k]
+        w = ((back[0] + back[1]) * sw.inv[:, None])[:sw.c_out, :sw.c_in]
+        y = F.conv2d(x if gate is None else x * gate[:, :, None, None], w[:, :, None, None])
+        used['n'] += 1
+        used['gated'] += gate is not None
+        used['accumulated'] += bool(accumulate)
+        if out is None:
+            return y
+        assert out.shape == y.shape
+        return out.add_(y) if accumulate else out.copy_(y)
+
+    monkeypatch.setattr(HF, 'gemm_split', gemm_split)
     monkeypatch.setattr(HF, 'mbconv_expand_dw', expand_dw)
     monkeypatch.setattr(HF, 'depthwise_conv_bn_act', dw)
     monkeypatch.setattr(HF, 'se_gate', se_gate)
@@ -305,7 +324,7 @@ def test_deferred_bn_shift_algebra_cpu(monkeypatch, config):
 
     stock = fill_by_name(configs.build(config).eval(), seed=3)
     fused = copy.deepcopy(stock)
-    prepare_for_inference(fused, fold_bn=False, fused_depthwise=True)
+    prepare_for_inference(fused, fold_bn=False, fused_depthwise=True, split_gemm=split)
     with pytest.raises(RuntimeError):                     # not idempotent by design: refuses a second application
         prepare_for_inference(fused, fold_bn=False, fused_depthwise=True)
     bb = fused.backbone
@@ -326,6 +345,8 @@ def test_deferred_bn_shift_algebra_cpu(monkeypatch, config):
         assert len(feats) == len(ref)
         for a, b in zip(ref, feats):
             assert rel_err(b, a) < 2e-5
+        # the opt-in route is taken (or not at all): expand, gated project and in-place skip accumulation all go through it
+        assert (used['n'] > 20 and used['gated'] > 10 and used['accumulated'] > 5) if split else used['n'] == 0
         if batch == 1 and getattr(fused.weight_mapper, '_fused', None) is not None:
             # the context head without its concatenations (FusedContextHead) == the stock head
             with torch.no_grad():
