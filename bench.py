@@ -387,6 +387,9 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of HIP graph replay')
     ap.add_argument('--stock-encoder', action='store_true',
                     help='leave the encoder entirely on stock PyTorch-ROCm/MIOpen (no fused depthwise HIP kernel)')
+    ap.add_argument('--split-gemm', action='store_true',
+                    help="opt-in, not validated inside the model yet: the encoder's 1x1 convolutions through hs_gemm_split_fwd "
+                         '(prepare_for_inference(split_gemm=True)); the default run does not use it')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the roofline / parity / protocol passes (timing only)')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
@@ -425,7 +428,7 @@ def main():
     model = fill_by_name(configs.build(cfg).eval(), seed=0)       # synthetic, non-denormal, same on every rank
     stock = copy.deepcopy(model) if rank == 0 and not args.no_extras else None
     if not args.stock_encoder:
-        prepare_for_inference(model, fold_bn=False, fused_depthwise=True)
+        prepare_for_inference(model, fold_bn=False, fused_depthwise=True, split_gemm=args.split_gemm)
     model = model.to(dev)
     torch.manual_seed(1234 + rank)
     x = torch.rand(batch, 3, h, w, device=dev)                    # resident synthetic batch
@@ -488,7 +491,8 @@ def main():
                        'encoder': 'stock PyTorch-ROCm / MIOpen' if args.stock_encoder else
                                   'hyperseg_amd.utils.inference.prepare_for_inference: MBConv blocks = hs_mbconv_expand_dw_fwd | '
                                   'library GEMM + hs_depthwise_conv_fwd, hs_se_gate_fwd, bare library GEMM; hs_stem_conv_fwd; '
-                                  'context head = library GEMMs + hs_affine_act_fwd',
+                                  'context head = library GEMMs + hs_affine_act_fwd' +
+                                  ('; --split-gemm: 1x1 convolutions through hs_gemm_split_fwd' if args.split_gemm else ''),
                        'output': f'fp32 logits {tuple(y.shape)}' if args.output == 'logits' else f'uint8 argmax masks {tuple(y.shape)}',
                        'launch': 'eager' if args.no_graph else 'hipGraph replay',
                        'ir_math': __import__('hyperseg_amd.functional', fromlist=['x']).get_ir_math() + ' (include/hyperseg_hip.h hs_ir_math: f32 storage and accumulation; auto = f16 '
