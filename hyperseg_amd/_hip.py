@@ -85,7 +85,7 @@ def _load():
         'hs_mbconv_expand_dw_fwd': ([vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp], C.c_int),
         'hs_se_gate_fwd': ([vp, i32, i32, i32, C.c_float, vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp], C.c_int),
         'hs_gemm_split_kp': ([i32], C.c_int),
-        'hs_gemm_split_fwd': ([vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], C.c_int),
+        'hs_gemm_split_fwd': ([vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp], C.c_int),
     }
     for name, (argtypes, restype) in sig.items():
         fn = getattr(lib, name)          # AttributeError here = the .so does not match the header

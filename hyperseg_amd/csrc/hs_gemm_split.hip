@@ -2,7 +2,8 @@
 // kernel below was measured as a dev probe at the end of round 2, profiles/round2_dev_gemm_split_probe.txt, its wiring into
 // the prepared encoder is new): a 1x1 convolution as a GEMM on the f16 matrix cores with split operands,
 //
-//     Y[b][m][n] (= | +=)  sum_k W[m][k] * gate[b][k] * X[b][k][n]         f32 in, f32 out, f32 accumulation
+//     Y[b][m][n] = act(sum_k W[m][k] * gate[b][k] * X[b][k][n] + shift[m]) + R[b][m][n]       f32 in / out / accumulation
+//     (gate, shift, R optional; R may be Y itself: the in-place skip accumulation of FusedMBConv)
 //
 // replacing the library f32 GEMMs of the MBConv blocks' expand / project convolutions (efficientnet.py:101, 115) and the
 // weight-scaling half of the SE gate (the gate multiplies X's rows on load here, so no per-frame copy of W is written).
@@ -15,9 +16,9 @@
 //   lanes), applies the gate, scales each PIXEL's column by a power of two to < 2^15 (a column scale only scales that column
 //   of D: undone on the lane's own accumulators) and splits it into hi / lo.  Three products per k-step (lo*hi, hi*lo, hi*hi):
 //   error 1.6-2.9e-7 of the f64 product at the encoder's shapes, below the library f32 GEMM's 4.5e-7-1.2e-6.
-// * the waves' partial tiles meet in LDS, are summed in wave order (deterministic), scaled by w_inv[row], optionally added
-//   to Y (the in-place skip accumulation of FusedMBConv) and stored as 128-byte runs; the tail's operands are requested
-//   before the barrier.
+// * the waves' partial tiles meet in LDS, are summed in wave order (deterministic), scaled by w_inv[row], get the BatchNorm
+//   shift, the activation and the residual, and are stored as 128-byte runs; the tail's operands are requested before the
+//   barrier.  (The probed dev kernel had only the accumulate-onto-Y tail; shift / activation / separate residual are new.)
 #include "hs_common.h"
 
 namespace hs {
@@ -33,8 +34,11 @@ __device__ __forceinline__ float gs_inv_scale_of(int eb) { return __int_as_float
 struct GemmSplitArgs {
     const _Float16* __restrict__ wf;       // [RT][KST][2][64][8] halfs, RT = ceil(M / 16), KST = Kp / 32
     const float* __restrict__ w_inv;       // [16 RT]
-    const float* __restrict__ gate; const float* __restrict__ x; float* __restrict__ y;
-    int M, K, KST, N, accumulate;
+    const float* __restrict__ gate; const float* __restrict__ x;
+    const float* shift;                    // [M] or null
+    const float* residual;                 // (B, M, N) or null; may alias y
+    float* y;
+    int M, K, KST, N, act;
 };
 
 template <int KS>
@@ -46,7 +50,8 @@ void gemm_split_kernel(GemmSplitArgs a) {
     const int n0 = blockIdx.x * 32, r0 = blockIdx.y * 2, b = blockIdx.z;
     const float* __restrict__ xb = a.x + (size_t)b * a.K * a.N;
     const float* __restrict__ gb = a.gate ? a.gate + (size_t)b * a.K : nullptr;
-    float* __restrict__ yb = a.y + (size_t)b * a.M * a.N;
+    float* yb = a.y + (size_t)b * a.M * a.N;
+    const float* rb = a.residual ? a.residual + (size_t)b * a.M * a.N : nullptr;
     const int rt_max = (a.M + 15) >> 4;
 
     // ---- every load of this wave: X (two strips) with the gate, A fragments of row tile 0, the tail's operands
@@ -76,13 +81,14 @@ void gemm_split_kernel(GemmSplitArgs a) {
     };
     load_a(0);                                                          // tile 1 follows once the f32 strips are split (registers)
     constexpr int TE = 8;                                               // tail elements per thread: 1024 / nthr <= 8
-    float wi[TE], yo[TE];
+    float wi[TE], sh[TE], yo[TE];
 #pragma unroll
     for (int i = 0; i < TE; ++i) {
         const int e = tid + i * nthr;
         const int row = min(16 * r0 + (e >> 5), a.M - 1), col = min(n0 + (e & 31), a.N - 1);
         wi[i] = a.w_inv[min(16 * r0 + (e >> 5), 16 * rt_max - 1)];
-        yo[i] = a.accumulate ? yb[(size_t)row * a.N + col] : 0.0f;
+        sh[i] = a.shift ? a.shift[row] : 0.0f;
+        yo[i] = rb ? rb[(size_t)row * a.N + col] : 0.0f;
     }
 
     // ---- per-pixel scale and split of the two strips
@@ -135,7 +141,11 @@ void gemm_split_kernel(GemmSplitArgs a) {
             const int row = 16 * r0 + (e >> 5), col = n0 + (e & 31);
             float t = 0.0f;
             for (int w = 0; w < nwv; ++w) t += gs_red[w * 1024 + e];
-            if (row < a.M && col < a.N) yb[(size_t)row * a.N + col] = yo[i] + t * wi[i];
+            if (row < a.M && col < a.N) {
+                float v = fmaf(t, wi[i], sh[i]);
+                v = a.act == 3 ? swishf(v) : apply_act(v, a.act);
+                yb[(size_t)row * a.N + col] = v + yo[i];
+            }
         }
     }
 }
@@ -159,15 +169,16 @@ extern "C" int hs_gemm_split_kp(int32_t c_in) {
     return nwv * ks * 32;
 }
 
-extern "C" int hs_gemm_split_fwd(const void* w_frag, const float* w_inv, const float* gate, const float* x, float* y,
-                                 int32_t batch, int32_t c_out, int32_t c_in, int32_t kp, int32_t pixels, int32_t accumulate,
-                                 void* stream) {
+extern "C" int hs_gemm_split_fwd(const void* w_frag, const float* w_inv, const float* gate, const float* x,
+                                 const float* shift, int32_t act, const float* residual, float* y,
+                                 int32_t batch, int32_t c_out, int32_t c_in, int32_t kp, int32_t pixels, void* stream) {
     if (!w_frag || !w_inv || !x || !y || batch <= 0 || c_out <= 0 || c_in <= 0 || pixels <= 0) return HS_ERR_BAD_ARG;
+    if (act < 0 || act > 3) return HS_ERR_BAD_ARG;
     int nwv, ks;
     if (!gemm_split_plan(c_in, nwv, ks)) return HS_ERR_UNSUPPORTED;
     if (kp != nwv * ks * 32) return HS_ERR_BAD_ARG;
     if (batch > 65535 || (c_out + 31) / 32 > 65535) return HS_ERR_UNSUPPORTED;
-    GemmSplitArgs a{(const _Float16*)w_frag, w_inv, gate, x, y, c_out, c_in, kp / 32, pixels, accumulate};
+    GemmSplitArgs a{(const _Float16*)w_frag, w_inv, gate, x, shift, residual, y, c_out, c_in, kp / 32, pixels, act};
     dim3 grid((pixels + 31) / 32, ((c_out + 15) / 16 + 1) / 2, batch);
     const size_t lds = (size_t)nwv * 1024 * sizeof(float);
     hipStream_t s = (hipStream_t)stream;

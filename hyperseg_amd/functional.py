@@ -569,24 +569,29 @@ def gemm_split_weights(w, row_scale=None):
 
 
 @_on_operand_device
-def gemm_split(sw, x, gate=None, out=None, accumulate=False):
-    """y (B, Cout, H, W) (= | +=) W @ (gate[:, :, None] * x) per frame on the f16 matrix cores with split operands
-    (hs_gemm_split_fwd).  ``out``: written (or accumulated onto, ``accumulate=True``) in place."""
+def gemm_split(sw, x, gate=None, shift=None, act=ACT_NONE, residual=None, out=None):
+    """y (B, Cout, H, W) = act(W @ (gate[:, :, None] * x) + shift[:, None]) + residual per frame, on the f16 matrix cores with
+    split operands (hs_gemm_split_fwd).  ``out``: written in place; ``residual`` may be ``out`` itself (accumulation onto a
+    skip tensor).  ``act``: ACT_* or 3 = swish."""
     b, cin, h, w = x.shape
     if cin != sw.c_in:
         raise ValueError(f'input has {cin} channels, the weight {sw.c_in}')
-    if accumulate and out is None:
-        raise ValueError('accumulate=True needs out')
+    shape = (b, sw.c_out, h, w)
     if out is None:
-        out = torch.empty(b, sw.c_out, h, w, device=x.device, dtype=torch.float32)
-    elif tuple(out.shape) != (b, sw.c_out, h, w):
-        raise ValueError(f'out has shape {tuple(out.shape)}, expected {(b, sw.c_out, h, w)}')
+        out = torch.empty(shape, device=x.device, dtype=torch.float32)
+    elif tuple(out.shape) != shape:
+        raise ValueError(f'out has shape {tuple(out.shape)}, expected {shape}')
+    if residual is not None and tuple(residual.shape) != shape:
+        raise ValueError(f'residual has shape {tuple(residual.shape)}, expected {shape}')
     if gate is not None and tuple(gate.shape) != (b, cin):
         raise ValueError(f'gate has shape {tuple(gate.shape)}, expected {(b, cin)}')
+    if shift is not None and shift.numel() != sw.c_out:
+        raise ValueError(f'shift has {shift.numel()} entries, expected {sw.c_out}')
     st = _hip.lib.hs_gemm_split_fwd(_hip.dev_ptr(sw.frag, 'w_frag', torch.float16), _hip.dev_ptr(sw.inv, 'w_inv'),
                                     _hip.dev_ptr(gate, 'gate') if gate is not None else None, _hip.dev_ptr(x, 'x'),
-                                    _hip.dev_ptr(out, 'out'), b, sw.c_out, cin, sw.kp, h * w, 1 if accumulate else 0,
-                                    _hip.stream_ptr())
+                                    _hip.dev_ptr(shift, 'shift') if shift is not None else None, int(act),
+                                    _hip.dev_ptr(residual, 'residual') if residual is not None else None,
+                                    _hip.dev_ptr(out, 'out'), b, sw.c_out, cin, sw.kp, h * w, _hip.stream_ptr())
     _hip.check(st, 'hs_gemm_split_fwd')
     return out
 

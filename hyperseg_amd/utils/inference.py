@@ -162,9 +162,9 @@ class FusedPointwise(nn.Module):
             return HF.pointwise_conv(x, conv.weight, gate, self.scale, self.shift, self.act, residual)
         if (h * w) % 4 != 0:
             raise NotImplementedError('feature maps with H*W % 4 != 0')
-        sw = self.split_weights(False, x.device) if self.split_gemm else None
-        if sw is not None:
-            return HF.affine_act_(HF.gemm_split(sw, x, gate=gate), self.scale, self.shift, self.act, residual)
+        sw = self.split_weights(True, x.device) if self.split_gemm else None
+        if sw is not None:       # BN scale folded into the split weights; shift, activation and skip add in the GEMM's tail
+            return HF.gemm_split(sw, x, gate=gate, shift=self.shift, act=self.act, residual=residual)
         if gate is None:
             # batches: one strided-batched GEMM (MIOpen would go NCHW -> NHWC -> implicit GEMM -> NCHW)
             y = F.conv2d(x, conv.weight) if b == 1 else self.raw(x)
@@ -288,8 +288,8 @@ class FusedMBConv(nn.Module):
                 if self.defer_shift:
                     if skip is None:
                         return HF.gemm_split(sw, y, gate=gate)
-                    return HF.gemm_split(sw, y, gate=gate, out=skip, accumulate=True)   # in place: no other consumer
-                return HF.affine_act_(HF.gemm_split(sw, y, gate=gate), None, proj.shift, 0, skip)
+                    return HF.gemm_split(sw, y, gate=gate, residual=skip, out=skip)     # in place: no other consumer
+                return HF.gemm_split(sw, y, gate=gate, shift=proj.shift, residual=skip)
             # gate (and BN2 scale) folded into the project weights by the SE kernel: ~1e5 weights instead of a pass over y
             wp = HF.se_gate(partial, b, ho * wo, red.weight, red.bias, self._exp_t, exp.bias,
                             w_proj=proj.conv.weight, out_scale=proj.scale)

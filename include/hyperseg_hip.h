@@ -293,7 +293,9 @@ int hs_affine_act_fwd(const float* x, int32_t batch, int32_t channels, int32_t p
 
 /* Encoder-side helper (opt-in: prepare_for_inference(split_gemm=True); off by default): a 1x1 convolution as a GEMM on the
  * f16 matrix cores with split operands, f32 storage and accumulation,
- *   y[b,o,p] (= | +=, `accumulate`)  sum_c w[o,c] * gate[b,c] * x[b,c,p]       x (B,Cin,P), gate (B,Cin) or NULL, y (B,Cout,P)
+ *   y[b,o,p] = act(sum_c w[o,c] * gate[b,c] * x[b,c,p] + shift[o]) + residual[b,o,p]
+ * x (B,Cin,P), y (B,Cout,P); gate (B,Cin), shift (Cout), residual (B,Cout,P) optional, residual may be y itself (in-place
+ * accumulation onto a skip tensor); act = hs_act or 3 = swish.
  * w_frag / w_inv: the STATIC weight split once on the host into two f16 pieces of every row scaled by a power of two to
  * < 2^15, in MFMA-fragment order [ceil(Cout/16)][kp/32][piece][64 lanes][8] (lane = row % 16 + 16 * kgroup holds
  * w[16 R + row % 16][32 S + 8 kgroup + j]), and the inverse row scales padded to a multiple of 16 rows
@@ -301,8 +303,9 @@ int hs_affine_act_fwd(const float* x, int32_t batch, int32_t channels, int32_t p
  * K split, or HS_ERR_UNSUPPORTED for Cin > 1280.  Replaces the library GEMM of an MBConv block's expand / project convolution
  * (efficientnet.py:101, 115) and, through `gate`, the SE multiply (:110-111). */
 int hs_gemm_split_kp(int32_t c_in);
-int hs_gemm_split_fwd(const void* w_frag, const float* w_inv, const float* gate, const float* x, float* y,
-                      int32_t batch, int32_t c_out, int32_t c_in, int32_t kp, int32_t pixels, int32_t accumulate, void* stream);
+int hs_gemm_split_fwd(const void* w_frag, const float* w_inv, const float* gate, const float* x, const float* shift,
+                      int32_t act, const float* residual, float* y, int32_t batch, int32_t c_out, int32_t c_in, int32_t kp,
+                      int32_t pixels, void* stream);
 
 /* Materialises a stage input (B, 2*coords + c_skip + c_prev, H, W); test/diagnostic twin of the
  * fused prologue (the product path never calls it). */

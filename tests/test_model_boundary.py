@@ -302,18 +302,23 @@ def test_deferred_bn_shift_algebra_cpu(monkeypatch, config, split):
 
     used = {'n': 0, 'gated': 0, 'accumulated': 0}
 
-    def gemm_split(sw, x, gate=None, out=None, accumulate=False):
+    def gemm_split(sw, x, gate=None, shift=None, act=0, residual=None, out=None):
         rt = sw.frag.shape[0]
         back = sw.frag.permute(2, 0, 4, 1, 3, 5).reshape(2, 16 * rt, sw.kp).float()        # [piece][row][k]
         w = ((back[0] + back[1]) * sw.inv[:, None])[:sw.c_out, :sw.c_in]
         y = F.conv2d(x if gate is None else x * gate[:, :, None, None], w[:, :, None, None])
+        if shift is not None:
+            y = y + shift.view(1, -1, 1, 1)
+        y = act_of(y, act)
+        if residual is not None:
+            y = y + residual
         used['n'] += 1
         used['gated'] += gate is not None
-        used['accumulated'] += bool(accumulate)
+        used['accumulated'] += residual is not None and residual is out
         if out is None:
             return y
         assert out.shape == y.shape
-        return out.add_(y) if accumulate else out.copy_(y)
+        return out.copy_(y)
 
     monkeypatch.setattr(HF, 'gemm_split', gemm_split)
     monkeypatch.setattr(HF, 'mbconv_expand_dw', expand_dw)

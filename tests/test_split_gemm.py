@@ -59,8 +59,14 @@ def test_gemm_split_vs_float64(m, k, hw, batch):
     ref0 = torch.einsum('ok,bkn->bon', w.double(), x.flatten(2).double()).view(batch, m, *hw)
     assert rel_err(y0.double().cpu(), ref0.cpu()) < 2e-6
     acc = torch.ones_like(y)
-    assert HF.gemm_split(sw, x, gate=gate, out=acc, accumulate=True) is acc
+    assert HF.gemm_split(sw, x, gate=gate, residual=acc, out=acc) is acc                   # in place onto a skip tensor
     assert rel_err(acc.double().cpu(), (ref + 1).cpu()) < 2e-6
+    shift = torch.randn(m, generator=g).to(dev)
+    res = torch.randn(batch, m, *hw, generator=g).to(dev)
+    for act, fn in ((0, lambda t: t), (1, torch.relu), (2, lambda t: t.clamp(0, 6)), (3, lambda t: t * torch.sigmoid(t))):
+        ya = HF.gemm_split(sw, x, gate=gate, shift=shift, act=act, residual=res)
+        want = fn(ref + shift.double().view(1, -1, 1, 1)) + res.double()
+        assert rel_err(ya.double().cpu(), want.cpu()) < (2e-5 if act == 3 else 2e-6)       # swish: the fast exp2 / rcp form
 
 
 @opt_in
