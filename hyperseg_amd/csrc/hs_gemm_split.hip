@@ -80,7 +80,8 @@ void gemm_split_kernel(GemmSplitArgs a) {
         }
     };
     load_a(0);                                                          // tile 1 follows once the f32 strips are split (registers)
-    constexpr int TE = 8;                                               // tail elements per thread: 1024 / nthr <= 8
+    constexpr int TE = KS == 1 ? 8 : 2;                                 // tail elements per thread, 1024 / nthr: more than one
+                                                                        // k-step per wave only occurs with 8 waves (gemm_split_plan)
     float wi[TE], sh[TE], yo[TE];
 #pragma unroll
     for (int i = 0; i < TE; ++i) {
@@ -176,7 +177,7 @@ extern "C" int hs_gemm_split_fwd(const void* w_frag, const float* w_inv, const f
     if (act < 0 || act > 3) return HS_ERR_BAD_ARG;
     int nwv, ks;
     if (!gemm_split_plan(c_in, nwv, ks)) return HS_ERR_UNSUPPORTED;
-    if (kp != nwv * ks * 32) return HS_ERR_BAD_ARG;
+    if (kp != nwv * ks * 32 || (ks > 1 && nwv != 8)) return HS_ERR_BAD_ARG;
     if (batch > 65535 || (c_out + 31) / 32 > 65535) return HS_ERR_UNSUPPORTED;
     GemmSplitArgs a{(const _Float16*)w_frag, w_inv, gate, x, shift, residual, y, c_out, c_in, kp / 32, pixels, act};
     dim3 grid((pixels + 31) / 32, ((c_out + 15) / 16 + 1) / 2, batch);
