@@ -3,7 +3,7 @@ how many scalar-load round trips precede the first vector memory load, which of 
 how many vector loads are issued before the first vmcnt wait, how many loads are issued only after the first barrier
 (a second memory round trip), how many vector loads are waited for (vmcnt(0)) right after being issued (one round trip
 each: typically a select the compiler turned into an exec-masked load), and how many ds_bpermute (wave shuffles) are immediately waited for (serialised LDS-crossbar
-round trips).  A dependent launch in a replayed graph costs 1.6-2.2 us on an MI355X (profiles/round2_graph_launch_floor.txt);
+round trips); plus VGPRs, spills and scratch bytes from the metadata note (an array that ends up in scratch shows here).  A dependent launch in a replayed graph costs 1.6-2.2 us on an MI355X (profiles/round2_graph_launch_floor.txt);
 the small encoder/decoder kernels take 4.6-9 us, and the difference is exactly these chains.
     python tools/isa_phases.py hs_encoder.hip|/abs/path/to/source.hip [kernel-name-substring]"""
 import os
@@ -37,6 +37,21 @@ def kernels(lines):
                 name = None
 
 
+def resources(lines):
+    """{kernel: (vgprs, spilled vgprs, scratch bytes per lane)} from the metadata note at the end of the assembly."""
+    out, name, cur = {}, None, {}
+    for ln in lines:
+        t = ln.strip()
+        if t.startswith('.name:'):
+            name, cur = t.split()[-1], {}
+        for key in ('.vgpr_count:', '.vgpr_spill_count:', '.private_segment_fixed_size:'):
+            if name and t.startswith(key):
+                cur[key] = int(t.split()[-1])
+                if len(cur) == 3:
+                    out[name] = (cur['.vgpr_count:'], cur['.vgpr_spill_count:'], cur['.private_segment_fixed_size:'])
+    return out
+
+
 def demangle(n):
     try:
         return subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-cxxfilt', n], capture_output=True, text=True).stdout.strip().split('(')[0]
@@ -68,10 +83,14 @@ def analyse(body):
 
 if __name__ == '__main__':
     flt = sys.argv[2] if len(sys.argv) > 2 else ''
-    for name, body in kernels(assembly(sys.argv[1])):
+    asm = assembly(sys.argv[1])
+    res = resources(asm)
+    for name, body in kernels(asm):
         d = demangle(name)
         if flt in d:
             a = analyse(body)
+            v, sp, scr = res.get(name, (-1, -1, -1))
             print(f"{d[:90]:90s} s-trips {a['scalar_round_trips_before_first_vector_load']} (data {a['data_s_loads_before_it']})  "
                   f"vloads {a['vector_loads_up_front']}/{a['vector_loads']} up front, {a['vector_loads_after_first_barrier']} after barrier  "
-                  f"serial shfl {a['serialised_shuffles']}  serial loads {a['serialised_loads']}  instr {a['instructions']}")
+                  f"serial shfl {a['serialised_shuffles']}  serial loads {a['serialised_loads']}  instr {a['instructions']}  "
+                  f"vgpr {v}" + (f" SPILLS {sp}" if sp else '') + (f" scratch {scr} B" if scr else ''))
