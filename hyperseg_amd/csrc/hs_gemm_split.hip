@@ -118,6 +118,7 @@ void gemm_split_kernel(GemmSplitArgs a) {
             }
     }
     load_a(1);
+    __builtin_amdgcn_sched_barrier(0);                                  // tile 1's fragments go out before tile 0's first MFMA
     // ---- products; D element r of this lane = row 4 kg + r of the tile, column lrow of the strip
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
