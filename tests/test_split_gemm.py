@@ -39,6 +39,46 @@ def test_split_weights_host_side():
         HF.gemm_split(HF.gemm_split_weights(torch.randn(8, 64)), torch.rand(1, 64, 4, 4))       # CPU tensors: no fallback
 
 
+@pytest.mark.parametrize('m,k', [(40, 240), (112, 672), (192, 1152), (480, 80)])
+def test_split_arithmetic_emulated(m, k):
+    """The kernel's arithmetic restated with torch on the CPU from the REAL weight preparation: per wave K slice, the gated
+    input column of every pixel is scaled by a power of two to < 2^15 and split into two f16 pieces; three f16 x f16 products
+    (exact in f32) accumulate; column and row scales are undone at the end.  Against the float64 product the result must be at
+    least as close as a plain f32 matmul (the claim DESIGN section 7.2 makes; the GPU probe measured 1.6-2.9e-7)."""
+    from hyperseg_amd import functional as HF
+    g = torch.Generator().manual_seed(m * k)
+    n = 96
+    w = torch.randn(m, k, generator=g) / k ** 0.5
+    x = torch.randn(k, n, generator=g) * torch.rand(k, 1, generator=g) * 4
+    gate = torch.rand(k, generator=g)
+    sw = HF.gemm_split_weights(w)
+    rt = sw.frag.shape[0]
+    back = sw.frag.permute(2, 0, 4, 1, 3, 5).reshape(2, 16 * rt, sw.kp)                    # [piece][row][k], f16
+    steps = sw.kp // 32
+    nwv = 2
+    while nwv < 8 and nwv < steps:
+        nwv *= 2
+    ks = steps // nwv
+    assert nwv * ks * 32 == sw.kp
+    xg = torch.nn.functional.pad(x * gate[:, None], (0, 0, 0, sw.kp - k))
+    y = torch.zeros(16 * rt, n)
+    for wave in range(nwv):
+        sl = slice(wave * ks * 32, (wave + 1) * ks * 32)
+        eb = (xg[sl].abs().amax(0).contiguous().view(torch.int32) >> 23).clamp(27, 254)
+        sc, inv = torch.ldexp(torch.ones(n), 141 - eb), torch.ldexp(torch.ones(n), eb - 141)
+        xs = xg[sl] * sc[None, :]
+        bh = xs.half()
+        bl = (xs - bh.float()).half()
+        ah, al = back[0][:, sl].double(), back[1][:, sl].double()
+        part = al @ bh.double() + ah @ bl.double() + ah @ bh.double()                     # products of f16 pairs: exact
+        y += part.float() * inv[None, :]
+    y = (y * sw.inv[:, None])[:m]
+    ref = w.double() @ (x.double() * gate.double()[:, None])
+    err_split = float((y.double() - ref).abs().max() / ref.abs().max())
+    err_f32 = float(((w @ (x * gate[:, None])).double() - ref).abs().max() / ref.abs().max())
+    assert err_split < 5e-7 and err_split < 2 * err_f32 + 1e-7
+
+
 @opt_in
 @pytest.mark.gpu
 @pytest.mark.parametrize('m,k,hw,batch', [(40, 240, (64, 128), 1), (80, 480, (32, 64), 2), (112, 672, (32, 64), 1), (192, 1152, (16, 32), 1),
