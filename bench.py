@@ -387,9 +387,11 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of HIP graph replay')
     ap.add_argument('--stock-encoder', action='store_true',
                     help='leave the encoder entirely on stock PyTorch-ROCm/MIOpen (no fused depthwise HIP kernel)')
-    ap.add_argument('--split-gemm', action='store_true',
-                    help="opt-in, not validated inside the model yet: the encoder's 1x1 convolutions through hs_gemm_split_fwd "
-                         '(prepare_for_inference(split_gemm=True)); the default run does not use it')
+    ap.add_argument('--library-gemm', dest='split_gemm', action='store_false',
+                    help="the encoder's 1x1 convolutions through the library f32 GEMM instead of hs_gemm_split_fwd (the default since "
+                         'round 3: parity-green inside the model and 8 %% faster, profiles/round3_first_visit.txt)')
+    ap.add_argument('--split-gemm', dest='split_gemm', action='store_true', help='(default) 1x1 convolutions through hs_gemm_split_fwd')
+    ap.set_defaults(split_gemm=True)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the roofline / parity / protocol passes (timing only)')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
@@ -490,9 +492,10 @@ def main():
                                    '(encoder + context head as per "encoder", HIP decoder), resident input',
                        'encoder': 'stock PyTorch-ROCm / MIOpen' if args.stock_encoder else
                                   'hyperseg_amd.utils.inference.prepare_for_inference: MBConv blocks = hs_mbconv_expand_dw_fwd | '
-                                  'library GEMM + hs_depthwise_conv_fwd, hs_se_gate_fwd, bare library GEMM; hs_stem_conv_fwd; '
-                                  'context head = library GEMMs + hs_affine_act_fwd' +
-                                  ('; --split-gemm: 1x1 convolutions through hs_gemm_split_fwd' if args.split_gemm else ''),
+                                  '1x1 GEMM + hs_depthwise_conv_fwd, hs_se_gate_fwd, 1x1 GEMM; hs_stem_conv_fwd; '
+                                  'context head = library GEMMs + hs_affine_act_fwd; 1x1 GEMMs of the MBConv blocks = ' +
+                                  ('hs_gemm_split_fwd (f16 matrix cores, split operands, f32 accumulation)' if args.split_gemm
+                                   else 'library f32 GEMM (--library-gemm)'),
                        'output': f'fp32 logits {tuple(y.shape)}' if args.output == 'logits' else f'uint8 argmax masks {tuple(y.shape)}',
                        'launch': 'eager' if args.no_graph else 'hipGraph replay',
                        'ir_math': __import__('hyperseg_amd.functional', fromlist=['x']).get_ir_math() + ' (include/hyperseg_hip.h hs_ir_math: f32 storage and accumulation; auto = f16 '

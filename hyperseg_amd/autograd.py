@@ -46,6 +46,9 @@ class PatchConv(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.bfloat16)
     def forward(ctx, x, bank, grid, c_out, k, padding, padding_mode, groups):
+        if x.dtype not in DTYPE_CODES:
+            raise NotImplementedError(f'PatchConv: dtype {x.dtype} is not supported (supported: '
+                                      f'{", ".join(str(d) for d in DTYPE_CODES)})')
         x = x.contiguous()
         if bank.dtype != x.dtype:
             bank = bank.to(x.dtype)
@@ -96,6 +99,15 @@ class PatchConv(torch.autograd.Function):
         return dx, dbank, None, None, None, None, None, None
 
 
+def patch_conv_apply(*args):
+    """``PatchConv.apply`` behind the one check its ``custom_fwd`` cannot make (autocast is already off inside it)."""
+    if torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') != torch.bfloat16:
+        # custom_fwd(cast_inputs=bfloat16) would silently force bf16 under autocast(float16): there is no fp16 storage type
+        raise NotImplementedError(f"patch conv under torch.autocast('cuda', dtype={torch.get_autocast_dtype('cuda')}): only "
+                                  'torch.bfloat16 autocast is supported (fp32 without autocast)')
+    return PatchConv.apply(*args)
+
+
 class BankPack(torch.autograd.Function):
     """(B, hp_total, fh, fw) reference-layout weights -> patch-major bank (B*fh*fw, ld); backward is the transpose.
     The re-layout itself runs in fp32 (a bf16 weight tensor produced under autocast is widened first; PatchConv narrows
@@ -120,7 +132,7 @@ def patch_conv_train(x, weight, c_out, k, padding, padding_mode, groups, hp):
     """Differentiable MetaPatchConv2d core: ``weight`` is the reference-layout tensor (B, >=hp, fh, fw)."""
     fh, fw = weight.shape[-2:]
     bank = BankPack.apply(weight, hp)
-    return PatchConv.apply(x, bank, (fh, fw), c_out, k, padding, padding_mode, groups)
+    return patch_conv_apply(x, bank, (fh, fw), c_out, k, padding, padding_mode, groups)
 
 
 def materialize_stage(stage):

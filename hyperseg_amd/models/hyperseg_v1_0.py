@@ -271,12 +271,12 @@ class HyperPatchInvertedResidual(nn.Module, _SignalToWeights):
         tiles = xp.unfold(2, ph + 2, ph).unfold(3, pw + 2, pw)                     # B C fh fw ph+2 pw+2
         tiled = tiles.permute(0, 1, 2, 4, 3, 5).reshape(b, c, fh * (ph + 2), fw * (pw + 2))
         grid = (fh, fw)
-        y = HA.PatchConv.apply(tiled, bank[:, :r1], grid, self.hidden_dim, 1, 0, 'zeros', 1)
+        y = HA.patch_conv_apply(tiled, bank[:, :r1], grid, self.hidden_dim, 1, 0, 'zeros', 1)
         y = self.act_layer(self.bn1(y))
-        y = HA.PatchConv.apply(y, bank[:, r1:r2], grid, self.hidden_dim, 3, 1, 'zeros', self.hidden_dim)
+        y = HA.patch_conv_apply(y, bank[:, r1:r2], grid, self.hidden_dim, 3, 1, 'zeros', self.hidden_dim)
         y = y.reshape(b, self.hidden_dim, fh, ph + 2, fw, pw + 2)[:, :, :, 1:-1, :, 1:-1].reshape(b, self.hidden_dim, h, wd)
         y = self.act_layer(self.bn2(y))
-        y = HA.PatchConv.apply(y, bank[:, r2:r3], grid, self.out_nc, 1, 0, 'zeros', 1)
+        y = HA.patch_conv_apply(y, bank[:, r2:r3], grid, self.out_nc, 1, 0, 'zeros', 1)
         y = self.bn3(y)
         return xt + y if residual else y
 
@@ -513,7 +513,7 @@ class MultiScaleDecoder(nn.Module):
             return p
         side = join_level = None
         if 0 < n_early < len(flat) and s.is_cuda and HF.USE_SIDE_STREAM:
-            main = torch.cuda.current_stream()
+            main = torch.cuda.current_stream(s.device)      # the MODEL's device, not the caller's current one
             side = HF.SideStream.get(s.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
@@ -535,13 +535,13 @@ class MultiScaleDecoder(nn.Module):
         for level in range(self.levels):
             level_layers = getattr(self, f'level_{level}')
             if side is not None and level == join_level:
-                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.current_stream(s.device).wait_stream(side)
                 side = None
             # cat(coords, skip, bilinear(p)) is never built: the stage kernel's prologue generates it
             stage = HF.StageInput(x[-level - 1], p, coords=True)
             p = level_layers(stage, banks[level])
         if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.current_stream(s.device).wait_stream(side)
         if self.out_fc is not None:
             p = self.out_fc(p, banks[-1])
         if masks:

@@ -95,7 +95,7 @@ class MetaConv2d(nn.Module):
         k, pad = self.kernel_size[0], self.padding[0]
         if HA.needs_grad(x if isinstance(x, torch.Tensor) else x.skip, w):
             xt = HA.materialize_stage(x) if isinstance(x, HF.StageInput) else x
-            y = HA.PatchConv.apply(xt, w, (1, 1), self.out_channels, k, pad, self.padding_mode, self.groups)
+            y = HA.patch_conv_apply(xt, w, (1, 1), self.out_channels, k, pad, self.padding_mode, self.groups)
             return _apply_epilogue(y, scale, shift, act)
         if w.stride(1) != 1 and w.shape[1] != 1:
             w = w.contiguous()

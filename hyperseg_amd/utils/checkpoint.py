@@ -57,17 +57,17 @@ def get_arch(obj, *args, eval_partial=True, **kwargs):
     return f"{func}({','.join(parts)})".replace(' ', '')
 
 
-def load_model(model_path, name='', device=None, arch=None, return_checkpoint=False, train=False):
+def load_model(model_path, name='', device=None, arch=None, return_checkpoint=False, train=False, trusted=False):
     """Model from a checkpoint: ``obj_factory(checkpoint['arch'])`` + ``load_state_dict`` (strict), eval mode unless
-    ``train`` (utils.py:147-181)."""
+    ``train`` (utils.py:147-181).  The file is read with ``torch.load(weights_only=True)``: tensors, containers and plain
+    Python scalars / strings only.  A checkpoint that pickles other objects (an optimizer or scheduler state saved by an
+    old torch, say) is refused with the unpickler's own message unless the caller vouches for the file with
+    ``trusted=True`` -- a full pickle load executes code from the file, so it is never taken silently."""
     if model_path is None:
         raise AssertionError(f'{name} model must be specified!')
     if not os.path.exists(model_path):
         raise AssertionError(f"Couldn't find {name} model in path: {model_path}")
-    try:
-        checkpoint = torch.load(model_path, map_location='cpu', weights_only=True)
-    except Exception:                                        # optimizer / scheduler states pickled by older torch versions
-        checkpoint = torch.load(model_path, map_location='cpu', weights_only=False)
+    checkpoint = torch.load(model_path, map_location='cpu', weights_only=not trusted)
     if arch is None and 'arch' not in checkpoint:
         raise AssertionError(f"Couldn't determine {name} model architecture!")
     arch = checkpoint['arch'] if arch is None else arch

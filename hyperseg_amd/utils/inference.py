@@ -10,10 +10,10 @@ model's own parameters and keep their folded BatchNorm affines in non-persistent
                          BN shift deferred to the consumers), see the class docstring
   * ``FusedPointwise``   feature reducers and the head conv              -> hs_pointwise_conv_fwd | GEMM + hs_affine_act_fwd
   * ``FusedContextHead`` the v1_0 WeightMapper without its concatenations -> library GEMMs + hs_affine_act_fwd
-``split_gemm=True`` (with ``fused_depthwise``; OFF by default and not used by bench.py: the kernel was measured as a dev probe
-at the end of round 2, profiles/round2_dev_gemm_split_probe.txt, its wiring here is untested on a GPU) sends the MBConv
-blocks' expand / project 1x1 convolutions and the GEMM-routed reducers through ``hs_gemm_split_fwd`` (f16 matrix cores, split
-operands, SE gate applied inside) instead of the library f32 GEMM.
+``split_gemm=True`` (with ``fused_depthwise``; what bench.py runs since round 3: whole-model parity on the GPU in
+tests/test_split_gemm.py and test_benched_configuration_replay_matches_stock, 1091 -> 1179 frames/s at HyperSeg-M) sends the
+MBConv blocks' expand / project 1x1 convolutions and the GEMM-routed reducers through ``hs_gemm_split_fwd`` (f16 matrix cores,
+split operands, SE gate applied inside) instead of the library f32 GEMM.
 ``fold_bn=True`` additionally folds the remaining Conv -> BatchNorm pairs of the stock modules into the convolutions
 (that one DOES change the state dict: BN entries turn into identities) and ``channels_last`` switches the stock encoder's
 memory format; neither is used by bench.py.
@@ -117,11 +117,14 @@ class FusedPointwise(nn.Module):
     def split_weights(self, with_scale, device):
         """The conv weight prepared for hs_gemm_split_fwd (built once per FusedPointwise, i.e. again after every
         load_state_dict -- _install_fused recreates these modules); ``with_scale``: BN scale folded into the rows."""
-        key = (bool(with_scale), device)
-        if key not in self._split:
-            from .. import functional as HF
-            self._split[key] = HF.gemm_split_weights(self.conv.weight, self.scale if with_scale else None)
-        return self._split[key]
+        from .. import functional as HF
+        srcs = (self.conv.weight, self.scale) if with_scale else (self.conv.weight,)
+        key, ver = (bool(with_scale), device), HF._key(*srcs)       # in-place updates of the weight / BN scale are seen
+        hit = self._split.get(key)
+        if hit is None or hit[0] != ver:
+            hit = (ver, HF.gemm_split_weights(self.conv.weight, self.scale if with_scale else None))
+            self._split[key] = hit
+        return hit[1]
 
     @torch.no_grad()
     def absorb_input_offset(self, offset):
@@ -554,6 +557,7 @@ class GraphedModel(nn.Module):
         if entry is None:
             entry = self._capture(key, x, device)
         graph, static_in, static_out = entry
-        static_in.copy_(x, non_blocking=True)
-        graph.replay()
-        return static_out.clone() if self.clone_output else static_out
+        with torch.cuda.device(device):        # the replay and the input copy go to the MODEL's device and its current stream
+            static_in.copy_(x, non_blocking=True)
+            graph.replay()
+            return static_out.clone() if self.clone_output else static_out

@@ -57,6 +57,24 @@ def test_checkpoint_round_trip_cpu(tmp_path, name):
     assert list(remove_data_parallel_from_state_dict({'module.a.b': 1, 'c': 2})) == ['a.b', 'c']
 
 
+class _Marker:                      # a class the safe unpickler has never heard of
+    pass
+
+
+def test_load_model_never_unpickles_silently(tmp_path):
+    """a checkpoint that needs the full pickle loader (an arbitrary object inside) is REFUSED by default -- no silent
+    retry with weights_only=False -- and loads only when the caller vouches for the file (trusted=True)."""
+    import pickle
+    spec = configs.MODELS['hyperseg-m']
+    arch = get_arch(spec['arch'], num_classes=spec['num_classes'])
+    src = obj_factory(arch).eval()
+    path = str(tmp_path / 'with_object.pth')
+    torch.save({'state_dict': src.state_dict(), 'arch': arch, 'extra': _Marker()}, path)
+    with pytest.raises(pickle.UnpicklingError):
+        load_model(path, 'test')
+    assert type(load_model(path, 'test', trusted=True)) is type(src)
+
+
 @pytest.mark.gpu
 def test_loaded_model_reproduces_the_logits(tmp_path):
     dev = torch.device('cuda:0')

@@ -197,8 +197,9 @@ def test_prepared_encoder_matches_stock(dev, batch, size):
         assert rel_err(fused(x).cpu(), ys) < 1e-4
 
 
-def test_benched_configuration_replay_matches_stock(dev):
-    """The configuration bench.py times -- prepared encoder + context head + HIP decoder at 1024x512, captured in a HIP
+@pytest.mark.parametrize('split_gemm', [True, False], ids=['split_gemm', 'library_gemm'])
+def test_benched_configuration_replay_matches_stock(dev, split_gemm):
+    """The configuration bench.py times (split_gemm=True: its default since round 3; False: --library-gemm) -- prepared encoder + context head + HIP decoder at 1024x512, captured in a HIP
     graph and REPLAYED -- against the eager stock model on the same frame: logits within 1e-4 (tensor-relative) and the
     argmax identical wherever the stock model's top-2 margin exceeds 1e-4.  (The routing thresholds of the prepared
     encoder depend on the pixel count, so the small-size tests above do not cover this one.)"""
@@ -207,7 +208,7 @@ def test_benched_configuration_replay_matches_stock(dev):
     from hyperseg_amd.utils.synthetic import fill_by_name
     stock = fill_by_name(configs.build('hyperseg-m').eval(), seed=0)
     fused = copy.deepcopy(stock)
-    prepare_for_inference(fused, fold_bn=False, fused_depthwise=True)
+    prepare_for_inference(fused, fold_bn=False, fused_depthwise=True, split_gemm=split_gemm)
     stock, fused = stock.to(dev), fused.to(dev)
     x = torch.rand(1, 3, 512, 1024, device=dev)
     with torch.no_grad():

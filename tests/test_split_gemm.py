@@ -1,15 +1,10 @@
-"""hs_gemm_split_fwd (opt-in encoder GEMM on the f16 matrix cores, include/hyperseg_hip.h).  The host side (weight split,
-fragment order, plan) is checked on the CPU; the GPU tests are OPT-IN (HS_TEST_SPLIT_GEMM=1) until the route has had its first
-validated GPU run inside the model -- the kernel itself was measured as a dev probe (profiles/round2_dev_gemm_split_probe.txt)."""
-import os
-
+"""hs_gemm_split_fwd (the encoder's 1x1 convolutions on the f16 matrix cores, include/hyperseg_hip.h).  The host side (weight
+split, fragment order, plan) is checked on the CPU; the GPU tests run under plain ``-m gpu`` since round 3 (first GPU visit r5a:
+16 passed; bench.py 1091 -> 1179 frames/s with the route on, profiles/round3_first_visit.txt)."""
 import pytest
 import torch
 
 from conftest import rel_err
-
-opt_in = pytest.mark.skipif(os.environ.get('HS_TEST_SPLIT_GEMM') != '1', reason='opt-in: HS_TEST_SPLIT_GEMM=1')
-
 
 def test_split_weights_host_side():
     from hyperseg_amd import functional as HF
@@ -79,7 +74,6 @@ def test_split_arithmetic_emulated(m, k):
     assert err_split < 5e-7 and err_split < 2 * err_f32 + 1e-7
 
 
-@opt_in
 @pytest.mark.gpu
 @pytest.mark.parametrize('m,k,hw,batch', [(40, 240, (64, 128), 1), (80, 480, (32, 64), 2), (112, 672, (32, 64), 1), (192, 1152, (16, 32), 1),
                                           (320, 1152, (16, 32), 2), (480, 80, (32, 64), 1), (19, 33, (5, 7), 1), (1280, 320, (16, 32), 1)])
@@ -109,7 +103,6 @@ def test_gemm_split_vs_float64(m, k, hw, batch):
         assert rel_err(ya.double().cpu(), want.cpu()) < (2e-5 if act == 3 else 2e-6)       # swish: the fast exp2 / rcp form
 
 
-@opt_in
 @pytest.mark.gpu
 @pytest.mark.parametrize('batch,size', [(1, (256, 512)), (2, (256, 256)), (1, (512, 1024))])
 def test_prepared_model_with_split_gemm(batch, size):
