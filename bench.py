@@ -25,7 +25,7 @@ Extra objects on the line:
   parity        the replayed output of the benched configuration vs the eager STOCK-encoder model on the same batch
                 (outside the timed regions): max tensor-relative error, argmax flips where the stock margin > 1e-4.
   exact_f32     the same step (one timed region) with the fused inverted-residual levels on the exact-f32 matrix cores
-                (hs_set_ir_math('f32')); the headline `value` uses config.ir_math (auto: f16 split products at f32-class
+                (hs_ir_math = f32); the headline `value` uses config.ir_math (auto: f16 split products at f32-class
                 accuracy on the level-4 block).  N = 1 only.
   two_frames_in_flight  serving-style side number (never `value`): two requests of the benched batch in flight, one HIP
                 graph each on its own stream.  N = 1 only.
@@ -392,6 +392,9 @@ def main():
                          'round 3: parity-green inside the model and 8 %% faster, profiles/round3_first_visit.txt)')
     ap.add_argument('--split-gemm', dest='split_gemm', action='store_true', help='(default) 1x1 convolutions through hs_gemm_split_fwd')
     ap.set_defaults(split_gemm=True)
+    ap.add_argument('--ir-math', choices=['auto', 'f32', 'split'], default='auto',
+                    help='arithmetic of the fused inverted-residual decoder levels (include/hyperseg_hip.h hs_ir_math); the '
+                         'exact_f32 object re-times the step with f32')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the roofline / parity / protocol passes (timing only)')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
@@ -430,7 +433,10 @@ def main():
     model = fill_by_name(configs.build(cfg).eval(), seed=0)       # synthetic, non-denormal, same on every rank
     stock = copy.deepcopy(model) if rank == 0 and not args.no_extras else None
     if not args.stock_encoder:
-        prepare_for_inference(model, fold_bn=False, fused_depthwise=True, split_gemm=args.split_gemm)
+        prepare_for_inference(model, fold_bn=False, fused_depthwise=True, split_gemm=args.split_gemm, ir_math=args.ir_math)
+    else:
+        from hyperseg_amd.utils.inference import set_ir_math
+        set_ir_math(model, args.ir_math)
     model = model.to(dev)
     torch.manual_seed(1234 + rank)
     x = torch.rand(batch, 3, h, w, device=dev)                    # resident synthetic batch
@@ -498,7 +504,7 @@ def main():
                                    else 'library f32 GEMM (--library-gemm)'),
                        'output': f'fp32 logits {tuple(y.shape)}' if args.output == 'logits' else f'uint8 argmax masks {tuple(y.shape)}',
                        'launch': 'eager' if args.no_graph else 'hipGraph replay',
-                       'ir_math': __import__('hyperseg_amd.functional', fromlist=['x']).get_ir_math() + ' (include/hyperseg_hip.h hs_ir_math: f32 storage and accumulation; auto = f16 '
+                       'ir_math': __import__('hyperseg_amd.functional', fromlist=['x']).get_ir_math(args.ir_math) + ' (include/hyperseg_hip.h hs_ir_math: f32 storage and accumulation; auto = f16 '
                                   'split products, f32-class, on the level-4 inverted residual; HS_IR_MATH=f32 for exact f32)',
                        'parallelism': f'batch-sharded x{world}' + (f', RCCL {args.collective} of {args.gather}' if comm is not None else '')},
             'per_rank_frames_per_s': per_rank,

@@ -1,5 +1,5 @@
-// Shared by the two fused inverted-residual kernels (hs_patch_ir_fused.hip: exact f32 matrix cores;
-// hs_patch_ir_split.hip: f16 split products on the f16 matrix cores): launch arguments and the LDS geometry of a region.
+// Shared by the fused inverted-residual kernels (hs_patch_ir_fused.hip, hs_patch_ir_px.hip: exact f32 matrix cores;
+// hs_patch_irc.hip: Op C as f16 split products on the f16 matrix cores): launch arguments and the LDS geometry of a region.
 #pragma once
 #include "hs_common.h"
 #include "hs_ir_tiles.h"
@@ -39,9 +39,6 @@ template <int REG> struct IrfGeom {
 };
 
 __device__ __forceinline__ float relu6_(float v) { return fminf(fmaxf(v, 0.0f), 6.0f); }
-
-// hs_patch_ir_split.hip; returns 1 when it has no instantiation for the shape (or the math mode asks for exact f32)
-int try_launch_ir_split(int mode, IrFusedArgs& a, int cin, int c_skip, int c_out, hipStream_t stream);
 
 // hs_patch_ir_px.hip: Op D, one lane per pixel, for the narrow HyperSeg-L levels; 1 = no instantiation
 int try_launch_ir_px(IrFusedArgs& a, int cin, int c_skip, int c_out, hipStream_t stream);

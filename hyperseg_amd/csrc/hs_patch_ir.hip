@@ -199,6 +199,9 @@ static int launch_ir(const IrArgs& a, int threads, size_t lds, long blocks, hipS
 int try_launch_ir_fused(int mode, const StageIn& in, int fh, int fw, const float* bank, long ld, int cin, int c_skip,
                         int hid, int c_out, const float* s1, const float* b1, const float* s2, const float* b2,
                         const float* s3, const float* b3, float* y, hipStream_t stream);   // hs_patch_ir_fused.hip
+int try_launch_irc(const StageIn& in, int fh, int fw, const float* bank, long ld, int hid, int c_out,
+                   const float* s1, const float* b1, const float* s2, const float* b2, const float* s3, const float* b3,
+                   float* y, hipStream_t stream);                                           // hs_patch_irc.hip
 
 }  // namespace hs
 
@@ -206,7 +209,8 @@ using namespace hs;
 
 extern "C" int hs_patch_ir_fwd(const hs_stage_input* in, int32_t fh, int32_t fw, const float* bank, int64_t ld,
                                int32_t hidden, int32_t c_out, const hs_epilogue* bn1, const hs_epilogue* bn2,
-                               const hs_epilogue* bn3, int32_t residual, float* y, void* stream) {
+                               const hs_epilogue* bn3, int32_t residual, int32_t math, float* y, void* stream) {
+    if (math < HS_IR_MATH_AUTO || math > HS_IR_MATH_SPLIT) return HS_ERR_BAD_ARG;
     IrArgs a;
     int st = make_stage(in, &a.in);
     if (st != HS_OK) return st;
@@ -232,8 +236,13 @@ extern "C" int hs_patch_ir_fwd(const hs_stage_input* in, int32_t fh, int32_t fw,
     const long blocks = (long)in->batch * fh * fw * a.tiles_y * a.tiles_x;
     hipStream_t s = (hipStream_t)stream;
     const bool fused_form = in->coords && a.in.prev_mode == HS_PREV_BILINEAR && !a.residual;
+    if (fused_form && math != HS_IR_MATH_F32) {
+        // f16 matrix cores on split operands: any channel counts up to 16 + 16 -> 32 on patches >= 8 x 16 pixels
+        const int st_c = try_launch_irc(a.in, fh, fw, bank, (long)ld, hidden, c_out, a.s1, a.b1, a.s2, a.b2, a.s3, a.b3, y, s);
+        if (st_c != 1) return st_c;
+    }
     if (fused_form) {
-        // the decoder's own shapes run on the matrix cores; anything else falls through to the generic kernel
+        // exact f32 matrix cores at the decoder's own shapes; anything else falls through to the generic kernel
         const int st_m = try_launch_ir_fused(0, a.in, fh, fw, bank, (long)ld, a.cin, in->c_skip, hidden, c_out,
                                              a.s1, a.b1, a.s2, a.b2, a.s3, a.b3, y, s);
         if (st_m != 1) return st_m;
@@ -253,11 +262,37 @@ extern "C" int hs_patch_ir_fwd(const hs_stage_input* in, int32_t fh, int32_t fw,
     return HS_ERR_UNSUPPORTED;
 }
 
+// Which kernel hs_patch_ir_fwd would run (host only): the same dispatch with nothing launched.
+extern "C" int hs_patch_ir_route(const hs_stage_input* in, int32_t fh, int32_t fw, int32_t hidden, int32_t c_out,
+                                 int32_t residual, int32_t math) {
+    if (math < HS_IR_MATH_AUTO || math > HS_IR_MATH_SPLIT) return HS_ERR_BAD_ARG;
+    hs_stage_input probe = *in;
+    static const float dummy = 0.0f;                             // make_stage only checks that the pointers exist
+    if (probe.c_skip > 0 && !probe.skip) probe.skip = &dummy;
+    if (probe.c_prev > 0 && !probe.prev) probe.prev = &dummy;
+    StageIn si;
+    const int st = make_stage(&probe, &si);
+    if (st != HS_OK) return st;
+    if (fh <= 0 || fw <= 0 || hidden <= 0 || c_out <= 0) return HS_ERR_BAD_ARG;
+    if (in->H % fh != 0 || in->W % fw != 0) return HS_ERR_NOT_DIVISIBLE;
+    const int cin = si.cin();
+    const long ld = (((long)cin * hidden + 9L * hidden + (long)hidden * c_out) + 3) & ~3L;
+    const bool fused_form = in->coords && si.prev_mode == HS_PREV_BILINEAR && !residual;
+    if (fused_form && math != HS_IR_MATH_F32 &&
+        try_launch_irc(si, fh, fw, &dummy, ld, hidden, c_out, &dummy, &dummy, &dummy, &dummy, &dummy, &dummy, nullptr, nullptr) == HS_OK)
+        return HS_IR_ROUTE_SPLIT_MFMA;
+    if (fused_form && try_launch_ir_fused(0, si, fh, fw, &dummy, ld, cin, in->c_skip, hidden, c_out, &dummy, &dummy, &dummy, &dummy,
+                                          &dummy, &dummy, nullptr, nullptr) == HS_OK)
+        return HS_IR_ROUTE_F32_MFMA;
+    return HS_IR_ROUTE_GENERIC;
+}
+
 // Op D, fused form only (the decoder's own shapes); anything else returns HS_ERR_UNSUPPORTED and the caller runs the
 // block as three hs_patch_conv_fwd launches (pw1, depthwise, pw3), which is what the reference's module structure is.
 extern "C" int hs_patch_ir_v0_fwd(const hs_stage_input* in, int32_t fh, int32_t fw, const float* bank, int64_t ld,
                                   int32_t hidden, int32_t c_out, const hs_epilogue* bn1, const hs_epilogue* bn2,
-                                  const hs_epilogue* bn3, float* y, void* stream) {
+                                  const hs_epilogue* bn3, int32_t math, float* y, void* stream) {
+    if (math < HS_IR_MATH_AUTO || math > HS_IR_MATH_SPLIT) return HS_ERR_BAD_ARG;   // Op D: every mode runs the exact-f32 kernels
     StageIn si;
     int st = make_stage(in, &si);
     if (st != HS_OK) return st;

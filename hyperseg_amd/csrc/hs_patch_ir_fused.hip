@@ -495,6 +495,7 @@ static int launch_irf(IrFusedArgs& a, hipStream_t stream) {
     // operand rows past the last hidden channel / k past cin are read unmasked: they must stay inside the patch's bank
     if (16 * CIN + 4 > a.hid * (9 + COUT) || 144 > a.hid * COUT) return 1;
     if (lds > 160 * 1024) return HS_ERR_LDS;
+    if (a.y == nullptr) return HS_OK;                         // route query (hs_patch_ir_route): the shape is covered, nothing is launched
     if (lds > 64 * 1024) {
         static std::atomic<unsigned long long> done{0};       // one per instantiation
         const int e = allow_full_lds((const void*)patch_ir_fused_kernel<CIN, CSKIP, COUT, REG, MODE, PWR>, done);
@@ -524,10 +525,6 @@ int try_launch_ir_fused(int mode, const StageIn& in, int fh, int fw, const float
     const int p = a.ph;
     if (mode == 1) {   // the narrow Op D levels: one lane per pixel (hs_patch_ir_px.hip)
         const int e = try_launch_ir_px(a, cin, c_skip, c_out, stream);
-        if (e != 1) return e;
-    }
-    {   // the f16 split form first (unless the math mode asks for exact f32 or it has no instantiation)
-        const int e = try_launch_ir_split(mode, a, cin, c_skip, c_out, stream);
         if (e != 1) return e;
     }
 #define HS_IRF_CASE(CI, CS, CO, REG, MODE, PWR) \

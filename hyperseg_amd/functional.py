@@ -351,8 +351,9 @@ def patch_conv_gen(x, sref, c_out, scale=None, shift=None, act=ACT_NONE):
 
 
 @_on_operand_device
-def patch_ir(x, grid, bank, hidden, c_out, bn1, bn2, bn3, residual=False):
-    """Op C: fused per-patch inverted residual.  bn* are (scale, shift) pairs; bank rows in the reference's flat order."""
+def patch_ir(x, grid, bank, hidden, c_out, bn1, bn2, bn3, residual=False, math=None):
+    """Op C: fused per-patch inverted residual.  bn* are (scale, shift) pairs; bank rows in the reference's flat order.
+    ``math``: 'f32' | 'split' | 'auto' (include/hyperseg_hip.h, hs_ir_math); None = :func:`get_ir_math`."""
     stage = as_stage(x)
     fh, fw = grid
     b, _, h, w = stage.shape
@@ -361,16 +362,16 @@ def patch_ir(x, grid, bank, hidden, c_out, bn1, bn2, bn3, residual=False):
     y = torch.empty(b, c_out, h, w, device=stage.device, dtype=torch.float32)
     bank_ptr, ld = _bank_ptr(bank)
     st = _hip.lib.hs_patch_ir_fwd(C.byref(st_in), fh, fw, bank_ptr, ld, hidden, c_out,
-                                  C.byref(e1), C.byref(e2), C.byref(e3), int(bool(residual)), y.data_ptr(),
-                                  _hip.stream_ptr())
+                                  C.byref(e1), C.byref(e2), C.byref(e3), int(bool(residual)), ir_math_code(math),
+                                  y.data_ptr(), _hip.stream_ptr())
     _hip.check(st, 'hs_patch_ir_fwd')
     return y
 
 
 @_on_operand_device
-def patch_ir_v0(x, grid, bank, hidden, c_out, bn1, bn2, bn3):
+def patch_ir_v0(x, grid, bank, hidden, c_out, bn1, bn2, bn3, math=None):
     """Op D (hyperseg_v0_1.py:205-237) as one launch; returns None when the shape has no fused instantiation (the caller
-    then runs the block as three patch convolutions)."""
+    then runs the block as three patch convolutions).  ``math`` as for :func:`patch_ir` (Op D has the exact-f32 form only)."""
     stage = as_stage(x)
     fh, fw = grid
     b, _, h, w = stage.shape
@@ -379,7 +380,7 @@ def patch_ir_v0(x, grid, bank, hidden, c_out, bn1, bn2, bn3):
     y = torch.empty(b, c_out, h, w, device=stage.device, dtype=torch.float32)
     bank_ptr, ld = _bank_ptr(bank)
     st = _hip.lib.hs_patch_ir_v0_fwd(C.byref(st_in), fh, fw, bank_ptr, ld, hidden, c_out,
-                                     C.byref(e1), C.byref(e2), C.byref(e3), y.data_ptr(), _hip.stream_ptr())
+                                     C.byref(e1), C.byref(e2), C.byref(e3), ir_math_code(math), y.data_ptr(), _hip.stream_ptr())
     if st == -3:
         return None
     _hip.check(st, 'hs_patch_ir_v0_fwd')
@@ -387,20 +388,52 @@ def patch_ir_v0(x, grid, bank, hidden, c_out, bn1, bn2, bn3):
 
 
 IR_MATH = {'auto': 0, 'f32': 1, 'split': 2}
+# Arithmetic of the fused inverted-residual levels (include/hyperseg_hip.h, hs_ir_math) is an ARGUMENT of every launch: the
+# library keeps no mode.  Who chooses: (1) the ``math`` argument / the calling module's ``ir_math`` attribute (the nn.Module
+# mirror defaults to 'f32', the reference's arithmetic; ``prepare_for_inference(ir_math='auto')`` opts a model into the
+# f16-split form for serving), unless (2) an override is set here -- ``set_ir_math`` (tests, A/B runs) or the environment
+# variable HS_IR_MATH at import time.
+_ir_math_override = os.environ.get('HS_IR_MATH') or None
+if _ir_math_override is not None and _ir_math_override not in IR_MATH:
+    raise ValueError(f'HS_IR_MATH={_ir_math_override!r}: expected one of {sorted(IR_MATH)}')
+DEFAULT_IR_MATH = 'f32'
 
 
 def set_ir_math(mode):
-    """Arithmetic of the fused inverted-residual levels: 'split' (f16 matrix cores on split operands, f32-class), 'f32'
-    (exact f32 matrix cores) or 'auto' (split where it is faster; the default) -- include/hyperseg_hip.h, hs_ir_math.
-    Returns the previous mode's name."""
-    prev = get_ir_math()
-    _hip.check(_hip.lib.hs_set_ir_math(IR_MATH[mode]), 'hs_set_ir_math')
+    """Process-wide OVERRIDE of the math mode every fused inverted-residual launch is asked for ('split' | 'f32' | 'auto'),
+    or None to hand the choice back to the modules.  A Python-side switch for tests and A/B runs -- the C library itself is
+    stateless.  Returns the previous override."""
+    global _ir_math_override
+    if mode is not None and mode not in IR_MATH:
+        raise ValueError(f'ir math {mode!r}: expected one of {sorted(IR_MATH)} or None')
+    prev, _ir_math_override = _ir_math_override, mode
     return prev
 
 
-def get_ir_math():
-    code = _hip.lib.hs_get_ir_math()
-    return next(k for k, v in IR_MATH.items() if v == code)
+def get_ir_math(requested=None):
+    """The mode a launch uses: the override if one is set, else ``requested`` (a module's attribute), else the default."""
+    return _ir_math_override or requested or DEFAULT_IR_MATH
+
+
+def ir_math_code(requested=None):
+    return IR_MATH[get_ir_math(requested)]
+
+
+IR_ROUTES = {0: 'generic', 1: 'f32_mfma', 2: 'split_mfma'}
+
+
+def patch_ir_route(shape, c_skip, c_prev, grid, hidden, c_out, math=None, residual=False, coords=True):
+    """Which kernel ``patch_ir`` would run for a stage of ``shape`` = (B, H, W) with ``c_skip`` skip and ``c_prev`` half-resolution
+    previous-level channels: 'split_mfma' | 'f32_mfma' | 'generic' (include/hyperseg_hip.h, hs_patch_ir_route).  Host only."""
+    b, h, w = shape
+    si = _hip.StageInputC()
+    si.skip, si.prev, si.batch, si.H, si.W = None, None, b, h, w
+    si.c_skip, si.c_prev, si.Hp, si.Wp = c_skip, c_prev, h // 2, w // 2
+    si.coords, si.prev_mode = int(bool(coords)), (2 if c_prev > 0 else 0)      # HS_PREV_BILINEAR: the half-resolution previous level
+    r = _hip.lib.hs_patch_ir_route(C.byref(si), grid[0], grid[1], hidden, c_out, int(bool(residual)), ir_math_code(math))
+    if r < 0:
+        _hip.check(r, 'hs_patch_ir_route')
+    return IR_ROUTES[r]
 
 
 def ir_tile_map(reg, mode, pwr):

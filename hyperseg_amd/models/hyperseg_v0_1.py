@@ -91,7 +91,8 @@ class HyperPatchInvertedResidual(nn.Module):
         else:
             # the level's weights arrive channel-major (B, hp, fh, fw): one re-layout for the whole block
             bank = HF.bank_pack(w, 0, hp)
-        return HF.patch_ir_v0(x, tuple(w.shape[-2:]), bank, c1.out_channels, c3.out_channels, *bns)
+        return HF.patch_ir_v0(x, tuple(w.shape[-2:]), bank, c1.out_channels, c3.out_channels, *bns,
+                              math=getattr(self, 'ir_math', None))
 
     def forward(self, x, w):
         y = self._forward_fused(x, w)          # one launch (Op D) for the decoder's shapes

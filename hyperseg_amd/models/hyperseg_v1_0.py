@@ -291,7 +291,8 @@ class HyperPatchInvertedResidual(nn.Module, _SignalToWeights):
         fh, fw = s.shape[-2:]
         bank = self._bank(s, self.hyper_params)
         bns = [self._affine_of(i, bn, bank.device) for i, bn in enumerate((self.bn1, self.bn2, self.bn3))]
-        return HF.patch_ir(stage, (fh, fw), bank, self.hidden_dim, self.out_nc, *bns, residual=residual)
+        return HF.patch_ir(stage, (fh, fw), bank, self.hidden_dim, self.out_nc, *bns, residual=residual,
+                           math=getattr(self, 'ir_math', None))
 
     def conv(self, x, s):
         return self._run(x, s, False)

@@ -444,17 +444,35 @@ def _install_fused(model):
     bb.to(dev)                                      # new non-persistent buffers follow the model's device
     if type(wm).__name__ == 'WeightMapper' and hasattr(wm, 'in_conv') and hasattr(wm, 'up_blocks') and wm.levels >= 2:
         wm._fused = FusedContextHead(wm).to(dev)
-    for m in bb.modules():                          # opt-in (NOT measured inside the model yet): our GEMM for the 1x1 convs
+    for m in bb.modules():                          # prepare_for_inference(split_gemm=...): our GEMM for the 1x1 convs
         if isinstance(m, FusedPointwise):
             m.split_gemm = bool(getattr(model, '_hs_split_gemm', False))
 
 
-def prepare_for_inference(model, fold_bn=True, channels_last=False, fused_depthwise=False, split_gemm=False):
+def set_ir_math(model, mode):
+    """Arithmetic of the decoder's fused inverted-residual levels (include/hyperseg_hip.h, hs_ir_math): sets the ``ir_math``
+    attribute every such module hands to its launches -- 'f32' (the module default: exact f32 matrix cores), 'split' or
+    'auto' (f16 matrix cores on split operands, f32-class, where that form exists).  Returns the number of modules touched."""
+    from .. import functional as HF
+    if mode not in HF.IR_MATH:
+        raise ValueError(f'ir math {mode!r}: expected one of {sorted(HF.IR_MATH)}')
+    n = 0
+    for m in model.modules():
+        if type(m).__name__ == 'HyperPatchInvertedResidual':
+            m.ir_math = mode
+            n += 1
+    return n
+
+
+def prepare_for_inference(model, fold_bn=True, channels_last=False, fused_depthwise=False, split_gemm=False, ir_math='auto'):
     """In place; returns the number of BatchNorms folded by ``fold_bn``.  ``model``: a HyperGen in eval mode (module
     docstring for what each switch does).  The fused routes are installed first, so ``fold_bn`` only touches the
-    Conv -> BatchNorm pairs that no fused route reads."""
+    Conv -> BatchNorm pairs that no fused route reads.  ``ir_math``: :func:`set_ir_math` for the decoder ('auto' = the
+    f16-split inverted residual wherever it exists -- what serving and bench.py run; None leaves the modules' 'f32')."""
     assert not model.training, 'call model.eval() first'
     folded = 0
+    if ir_math is not None:
+        set_ir_math(model, ir_math)
     if fused_depthwise and any(getattr(b, '_fused_dw', None) is not None for b in model.backbone._blocks):
         raise RuntimeError('prepare_for_inference(fused_depthwise=True) was already applied to this model: the deferred '
                            'BatchNorm shifts would be absorbed twice')

@@ -153,7 +153,7 @@ int hs_patch_conv_gen_fwd(const hs_stage_input* in, int32_t fh, int32_t fw, cons
 int hs_patch_ir_fwd(const hs_stage_input* in, int32_t fh, int32_t fw,
                     const float* bank, int64_t ld, int32_t hidden, int32_t c_out,
                     const hs_epilogue* bn1, const hs_epilogue* bn2, const hs_epilogue* bn3,
-                    int32_t residual, float* y, void* stream);
+                    int32_t residual, int32_t math /* hs_ir_math, below */, float* y, void* stream);
 
 /* Op D: the inverted residual of hyperseg_v0_1.py:205-237 (HyperSeg-L) as ONE launch.  The reference runs it as three
  * IMAGE-level patch convolutions -- pw1 (MetaPatchConv2d k=1) + BN + ReLU6, depthwise 3x3 with reflect padding of the
@@ -167,24 +167,31 @@ int hs_patch_ir_fwd(const hs_stage_input* in, int32_t fh, int32_t fw,
 int hs_patch_ir_v0_fwd(const hs_stage_input* in, int32_t fh, int32_t fw,
                        const float* bank, int64_t ld, int32_t hidden, int32_t c_out,
                        const hs_epilogue* bn1, const hs_epilogue* bn2, const hs_epilogue* bn3,
-                       float* y, void* stream);
+                       int32_t math /* hs_ir_math */, float* y, void* stream);
 
-/* Arithmetic of the fused inverted-residual levels (hs_patch_ir_fwd / hs_patch_ir_v0_fwd at the instantiated shapes):
- *   HS_IR_MATH_F32    v_mfma_f32_16x16x4_f32: bit-exact f32 fma chains.
- *   HS_IR_MATH_SPLIT  f16 matrix cores on split operands: every f32 operand is scaled by a power of two and split into
- *       two f16 pieces, a product is ah*bh + al*bh + ah*bl accumulated in f32 (csrc/hs_patch_ir_split.hip).  f32-class:
- *       the measured error of a dot product is BELOW an f32 fmaf chain's (tools/ubench/f16_probe.hip: 1.3e-7 vs 2.2e-7 of
- *       sum|a||b|).  The scales are taken from the data (per weight row, per 16-position input tile, a running exponent
- *       per pw3 row), so any overall magnitude is carried; what is not is a dynamic range beyond ~2^18 INSIDE one
- *       reduction (an input 2^20 above its tile's other channels meeting a weight 2^-20 of its row's maximum).
- *   HS_IR_MATH_AUTO (default)  SPLIT for the shapes where it is the faster form (16x16-pixel regions of Op C: level 4 of
- *       HyperSeg-M/S, 28.6 vs 32.5 us on MI355X), F32 for the others.
- * Process-wide; the environment variable HS_IR_MATH=auto|f32|split sets the initial value.  The reference runs these
- * layers as fp32 torch convolutions (which cuDNN may run in TF32 there); all modes are held to the same parity tolerance
- * (tests/test_hip_parity.py). */
+/* Arithmetic of the fused inverted-residual levels -- the `math` ARGUMENT of hs_patch_ir_fwd / hs_patch_ir_v0_fwd (chosen by
+ * the caller per launch: the library keeps no mode, or any other mutable state, of its own):
+ *   HS_IR_MATH_F32    v_mfma_f32_16x16x4_f32: bit-exact f32 fma chains (csrc/hs_patch_ir_fused.hip, hs_patch_ir_px.hip).
+ *   HS_IR_MATH_SPLIT  f16 matrix cores on split operands wherever that form exists (Op C on patches >= 8 rows x 16 columns,
+ *       <= 16 skip and <= 16 previous-level channels: csrc/hs_patch_irc.hip): every f32 operand is scaled by a power of two
+ *       and split into two f16 pieces, a product is ah*bh + al*bh + ah*bl accumulated in f32.  f32-class: the measured
+ *       error of a dot product is BELOW an f32 fmaf chain's (tools/ubench/f16_probe.hip: 1.3e-7 vs 2.2e-7 of sum|a||b|).
+ *       The scales are taken from the data (the exact maximum of every weight row, of every halo position's input column),
+ *       so any overall magnitude is carried; what is not is a dynamic range beyond ~2^18 INSIDE one reduction (an input
+ *       2^20 above its position's other channels meeting a weight 2^-20 of its row's maximum).
+ *   HS_IR_MATH_AUTO   SPLIT where it is the faster form, F32 elsewhere (today the two coincide with SPLIT's coverage).
+ * The reference runs these layers as fp32 torch convolutions (which cuDNN may run in TF32 there); all modes are held to the
+ * same parity tolerance (tests/test_hip_parity.py).  The nn.Module mirror defaults to F32; serving / bench.py opt into AUTO
+ * (hyperseg_amd.utils.inference.prepare_for_inference(ir_math='auto')). */
 typedef enum { HS_IR_MATH_AUTO = 0, HS_IR_MATH_F32 = 1, HS_IR_MATH_SPLIT = 2 } hs_ir_math;
-int hs_set_ir_math(int32_t mode);
-int hs_get_ir_math(void);
+
+/* Which kernel hs_patch_ir_fwd would run for a call of this shape (host only: nothing is launched, pointers in `in` may be
+ * null): the generic kernel (vector ALU, any channel counts), the exact-f32 matrix-core kernel (the decoder's own shapes) or
+ * the f16-split matrix-core kernel (any channel split up to 16 + 16 -> 32 on patches >= 8 x 16).  Negative = error code.
+ * For callers that want to know what a configuration gets before they run it, and for the tests that pin the coverage. */
+typedef enum { HS_IR_ROUTE_GENERIC = 0, HS_IR_ROUTE_F32_MFMA = 1, HS_IR_ROUTE_SPLIT_MFMA = 2 } hs_ir_route;
+int hs_patch_ir_route(const hs_stage_input* in, int32_t fh, int32_t fw, int32_t hidden, int32_t c_out,
+                      int32_t residual, int32_t math);
 
 /* Introspection for the tests (host only, no GPU): the matrix-core tile map of the fused inverted-residual kernel for a
  * region edge `reg` (8|16), mode (0 = Op C, 1 = Op D) and patch edge inside the region `pwr`.  out[(t*16+n)*3 + {0,1,2}]

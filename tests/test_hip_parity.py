@@ -40,8 +40,9 @@ def O():
 
 @pytest.fixture(params=['split', 'f32', 'auto'])
 def ir_math(request, HF):
-    """Both arithmetic modes of the fused inverted-residual kernels (include/hyperseg_hip.h, hs_ir_math): f16 split
-    products on the f16 matrix cores (the default) and exact f32 -- held to the SAME tolerances."""
+    """All arithmetic modes of the fused inverted-residual kernels (include/hyperseg_hip.h, hs_ir_math; the mode is an argument
+    of every launch, forced here through the Python-side override): f16 split products on the f16 matrix cores, exact f32,
+    and auto -- held to the SAME tolerances."""
     prev = HF.set_ir_math(request.param)
     yield request.param
     HF.set_ir_math(prev)
@@ -491,7 +492,8 @@ def _op_c_case(O, cin_parts, cout, hid, patch, grid, seed, in_gain=1.0, w1_gain=
     skip_c, prev_c = cin_parts
     cin = 2 + skip_c + prev_c
     fh, fw = grid
-    h, w = fh * patch, fw * patch
+    ph, pw = patch if isinstance(patch, tuple) else (patch, patch)
+    h, w = fh * ph, fw * pw
     g = torch.Generator().manual_seed(seed)
     skip = torch.randn(1, skip_c, h, w, generator=g) * in_gain
     prev = torch.randn(1, prev_c, h // 2, w // 2, generator=g) * in_gain
@@ -529,6 +531,33 @@ def test_split_ir_ranges(HF, O, dev, ir_math, shape, gains):
     cmp(y, ref, what=f'Op C {shape} gains {gains} ({ir_math})')
 
 
+# (skip, prev) channels, classes, hidden, patch (rows, cols), grid -- none of them a BASELINE level shape
+GENERIC_OP_C = [((3, 16), 20, 42, (32, 32), (2, 2)),      # CamVid-L's 6th level (configs/train/camvid_efficientnet_b1_hyperseg-l.py:35-38), 20 classes
+                ((5, 7), 9, 30, (16, 16), (2, 3)),        # odd channel counts everywhere: cin = 14 .. padded K slots, odd bank columns
+                ((4, 8), 8, 28, (8, 16), (3, 2)),         # 8-row patches: the 16 x 8 region form
+                ((16, 8), 19, 52, (16, 32), (2, 2)),      # HyperSeg-S level 4's channels on 16 x 32 patches (two regions per patch, side by side)
+                ((6, 16), 16, 48, (16, 16), (3, 3)),      # level-3 channels on 16 x 16 patches
+                ((16, 16), 32, 96, (16, 16), (2, 2))]     # the largest shape the kernel takes: 16 + 16 -> 96 -> 32
+
+
+@pytest.mark.parametrize('shape', GENERIC_OP_C)
+def test_op_c_generic_shapes_on_the_matrix_cores(HF, O, dev, shape):
+    """dispatch is by RANGES (c_skip <= 16, c_prev <= 16, c_out <= 32, hid <= 96, patches >= 8 x 16), not by a
+    table of BASELINE triples -- any such level gets the f16-split matrix-core kernel (hs_patch_irc.hip), says so through
+    hs_patch_ir_route, and matches the oracle at the same tolerance."""
+    cin_parts, cout, hid, patch, grid = shape
+    skip, prev, wt, bns, ref = _op_c_case(O, cin_parts, cout, hid, patch, grid, seed=23)
+    b, _, h, w = skip.shape
+    assert HF.patch_ir_route((b, h, w), cin_parts[0], cin_parts[1], grid, hid, cout, math='auto') == 'split_mfma'
+    stage = HF.StageInput(skip.to(dev), prev.to(dev), coords=True)
+    bank = HF.bank_pack(wt.to(dev), 0, wt.shape[1])
+    bnf = [tuple(t.to(dev) for t in _fold(bb)) for bb in bns]
+    y = HF.patch_ir(stage, grid, bank, hid, cout, *bnf, math='split')
+    cmp(y, ref, what=f'Op C generic {shape} (split)')
+    y32 = HF.patch_ir(stage, grid, bank, hid, cout, *bnf, math='f32')           # generic vector-ALU kernel for most of these
+    cmp(y32, ref, what=f'Op C generic {shape} (f32)')
+
+
 def test_split_and_exact_modes_agree_on_flips(HF, O, dev):
     """HyperSeg-M at 1024x512: the two arithmetic modes give the same mask except where the oracle's own top-2 margin is
     below MARGIN, and logits within REL_TOL of each other."""
@@ -543,7 +572,7 @@ def test_split_and_exact_modes_agree_on_flips(HF, O, dev):
                 ys[mode] = d(x, s.to(dev))
             finally:
                 HF.set_ir_math(prev)
-    assert HF.get_ir_math() == 'auto'                      # the library default
+    assert HF.get_ir_math() == HF.DEFAULT_IR_MATH == 'f32'  # no override left behind; the modules' default is the exact form
     e = float((ys['split'] - ys['f32']).abs().max() / ys['f32'].abs().max())
     assert e < REL_TOL, e
     top2 = ys['f32'].topk(2, dim=1).values

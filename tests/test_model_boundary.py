@@ -358,6 +358,28 @@ def test_deferred_bn_shift_algebra_cpu(monkeypatch, config, split):
                 assert rel_err(fused.weight_mapper._fused(feats[-1].contiguous()), stock.weight_mapper(ref[-1])) < 2e-5
 
 
+def test_patch_ir_routes():
+    """hs_patch_ir_route (host only): which kernel a fused inverted-residual level gets.  The f16-split matrix-core kernel is
+    chosen by RANGES of channel counts, so every BASELINE level 4, CamVid-L's 6-level model (20-class variant included) and odd
+    shapes all get it; level-3 shapes (8 x 8 patches) keep the exact-f32 matrix-core kernel; 'f32' math never takes the split
+    form; beyond 16 + 16 channels the generic kernel is what is left -- and the query says so instead of hiding it."""
+    from hyperseg_amd import functional as HF
+    cases = {'M level 4': (((1, 256, 512), 16, 16, (16, 32), 68, 19), 'split_mfma', 'f32_mfma'),
+             'S level 4': (((1, 384, 768), 16, 8, (24, 48), 52, 19), 'split_mfma', 'f32_mfma'),
+             'CamVid-S level 4': (((1, 288, 384), 4, 16, (18, 24), 44, 12), 'split_mfma', 'f32_mfma'),
+             'M level 3': (((1, 128, 256), 6, 16, (16, 32), 48, 16), 'f32_mfma', 'f32_mfma'),
+             'CamVid-L level 5, 20 classes': (((1, 768, 1024), 3, 16, (24, 32), 42, 20), 'split_mfma', 'generic'),
+             'CamVid-L level 4': (((1, 384, 512), 4, 16, (24, 32), 44, 16), 'split_mfma', 'generic'),
+             'odd channel counts': (((1, 64, 96), 5, 7, (4, 6), 30, 9), 'split_mfma', 'generic'),
+             '20 skip channels': (((1, 64, 64), 20, 16, (4, 4), 76, 19), 'generic', 'generic')}
+    for name, (args, auto, f32) in cases.items():
+        assert HF.patch_ir_route(*args, math='auto') == auto, name
+        assert HF.patch_ir_route(*args, math='split') == auto, name
+        assert HF.patch_ir_route(*args, math='f32') == f32, name
+    with pytest.raises(Exception):
+        HF.patch_ir_route((1, 100, 100), 4, 4, (3, 3), 16, 8)              # 100 % 3 != 0
+
+
 def test_c_abi_exports_match_header():
     """The in-tree shared library loads without a GPU and exports every entry point include/hyperseg_hip.h declares (and the
     ctypes binding knows exactly that set); no compute call is made."""

@@ -1,6 +1,6 @@
 """Dev-only variant builds of the HIP library for on-GPU A/B runs (selected with HS_HIP_LIB=<path>); the product build
 (python -m hyperseg_amd.build) contains none of this, and the product sources carry no dev hooks: the 'stamps' variant
-is made by patching a COPY of hs_patch_ir_fused.hip ('stamps_split': of hs_patch_ir_split.hip).
+is made by patching a COPY of hs_patch_ir_fused.hip ('stamps_irc': of hs_patch_irc.hip, whose '// @stamp' comments mark the phases).
     stamps    s_memtime stamps of wave 0 of every workgroup at the phase boundaries (tools/ir_phase_times.py reads them)
     kpreload  the whole library with -amdgpu-kernarg-preload-count=16 (not yet measured)
 """
@@ -58,6 +58,18 @@ def stamped_source(fname='hs_patch_ir_fused.hip'):
     return path
 
 
+def stamped_irc_source():
+    """hs_patch_irc.hip carries '// @stamp <expr>' comments at its phase boundaries: the dev build turns them into stamps."""
+    src = open(os.path.join(B.CSRC, 'hs_patch_irc.hip')).read()
+    src = src.replace('namespace hs {\n', 'namespace hs {\n' + STAMP_DECL, 1)
+    src, n = re.subn(r'// @stamp ([^\n]+)\n', r'HS_STAMP(\1);\n', src)
+    assert n >= 12, n
+    os.makedirs(os.path.join(B.LIB_DIR, 'dev_src'), exist_ok=True)
+    path = os.path.join(B.LIB_DIR, 'dev_src', 'hs_patch_irc_stamps.hip')
+    open(path, 'w').write(src)
+    return path
+
+
 def patched_source(name, replacements, fname='hs_patch_ir_fused.hip'):
     src = open(os.path.join(B.CSRC, fname)).read()
     for old, new in replacements:
@@ -86,7 +98,7 @@ PATCHES = {
 
 VARIANTS = {
     'stamps': dict(flags=[], extra=[], patch=True),
-    'stamps_split': dict(flags=[], extra=[], patch=True, file='hs_patch_ir_split.hip'),
+    'stamps_irc': dict(flags=[], extra=[], patch='irc', file='hs_patch_irc.hip'),
     'nostore': dict(flags=[], extra=[], patch='nostore'),
     'ntstore': dict(flags=[], extra=[], patch='ntstore'),
     'px2wg': dict(flags=[], extra=[], patch='px2wg', file='hs_patch_ir_px.hip'),
@@ -105,7 +117,8 @@ if __name__ == '__main__':
         sources = list(B.SOURCES) + v['extra']
         if v.get('patch'):
             fname = v.get('file', 'hs_patch_ir_fused.hip')
-            src_path = stamped_source(fname) if v['patch'] is True else patched_source(v['patch'], PATCHES[v['patch']], fname)
+            src_path = stamped_irc_source() if v['patch'] == 'irc' else stamped_source(fname) if v['patch'] is True else \
+                patched_source(v['patch'], PATCHES[v['patch']], fname)
             rel = os.path.relpath(src_path, B.CSRC)
             sources = [rel if s == fname else s for s in sources]
         print(B.build(force=True, extra_flags=v['flags'], sources=sources, lib_path=path, obj_suffix='_' + name))

@@ -1,5 +1,6 @@
-"""Per-phase cycle counts of the fused inverted-residual kernel (dev 'stamps' build: HS_HIP_LIB=.../libhyperseg_hip_stamps.so).
-    HS_HIP_LIB=hyperseg_amd/lib/libhyperseg_hip_stamps.so python tools/ir_phase_times.py [M|S|Sc|L]"""
+"""Per-phase cycle counts of the fused inverted-residual kernels (dev builds of tools/build_variants.py):
+    HS_IR_MATH=auto HS_HIP_LIB=hyperseg_amd/lib/libhyperseg_hip_stamps_irc.so python tools/ir_phase_times.py [M|S|Sc]     (hs_patch_irc.hip)
+    HS_STAMP_LABELS=fused HS_HIP_LIB=hyperseg_amd/lib/libhyperseg_hip_stamps.so python tools/ir_phase_times.py [M|S|Sc|L]  (hs_patch_ir_fused.hip)"""
 import ctypes as C
 import os
 import sys
@@ -23,13 +24,23 @@ st = buf.reshape(8192, 32)
 live = st[:, 24] > 0
 st = st[live]
 print(f'{name}: {live.sum()} workgroups stamped (the LAST inverted-residual launch of the decoder)')
-labels = {0: 'start', 1: 'loads issued + LDS stores', 2: 'barrier (window in LDS)', 3: 'B fragments done', 4: 'pw1(0) + barrier',
-          24: 'epilogue stores issued'}
-for c in range(4):
-    labels[5 + 4 * c] = f'dw[{c}{"+" if c == 3 else ""}]'
-    labels[6 + 4 * c] = 'barrier'
-    labels[7 + 4 * c] = 'pw3'
-    labels[8 + 4 * c] = 'pw1(next) + barrier'
+if os.environ.get('HS_STAMP_LABELS', 'irc') == 'irc':          # hs_patch_irc.hip ('stamps_irc' build)
+    labels = {0: 'start', 1: 'every load issued, BN rows stored', 2: 'barrier (DMA landed)', 3: 'bank split LDS -> LDS', 4: 'barrier',
+              5: 'tiles + tap tables -> scratch', 6: 'barrier', 7: 'B fragments built', 8: 'barrier', 9: 'pw1(0) + barrier',
+              24: 'epilogue stores issued'}
+    for c in range(3):
+        labels[10 + 4 * c] = f'dw[{c}{"+" if c == 2 else ""}]'
+        labels[11 + 4 * c] = 'barrier'
+        labels[12 + 4 * c] = 'pw3'
+        labels[13 + 4 * c] = 'pw1(next) + barrier'
+else:                                                          # hs_patch_ir_fused.hip ('stamps' build)
+    labels = {0: 'start', 1: 'loads issued + LDS stores', 2: 'barrier (window in LDS)', 3: 'B fragments done', 4: 'pw1(0) + barrier',
+              24: 'epilogue stores issued'}
+    for c in range(4):
+        labels[5 + 4 * c] = f'dw[{c}{"+" if c == 3 else ""}]'
+        labels[6 + 4 * c] = 'barrier'
+        labels[7 + 4 * c] = 'pw3'
+        labels[8 + 4 * c] = 'pw1(next) + barrier'
 t0 = st[:, 0].min()
 prev = None
 for k in sorted(labels):
