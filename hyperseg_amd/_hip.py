@@ -39,7 +39,7 @@ class EpilogueC(C.Structure):
 class S2wLayerC(C.Structure):
     _fields_ = [('signal_index', C.c_int32), ('signal_channels', C.c_int32), ('groups', C.c_int32),
                 ('wsw_t', C.c_void_p), ('wc', C.c_int32), ('rows', C.c_int32),
-                ('bank', C.c_void_p), ('ld', C.c_int64)]
+                ('bank', C.c_void_p), ('ld', C.c_int64), ('wsw_blk', C.c_void_p)]
 
 
 def _load():
@@ -54,6 +54,8 @@ def _load():
         'hs_build_info': ([], C.c_char_p),
         'hs_signal2weights_fwd': ([vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp, i64, vp], C.c_int),
         'hs_signal2weights_multi_fwd': ([vp, i32, i32, i32, i32, C.POINTER(S2wLayerC), i32, vp], C.c_int),
+        'hs_s2w_pack_floats': ([i32, i32, i32], C.c_int64),
+        'hs_s2w_pack_fwd': ([vp, i32, i32, i32, vp, vp], C.c_int),
         'hs_bank_pack_fwd': ([vp, i32, i32, i32, i32, i32, i32, vp, i64, vp], C.c_int),
         'hs_bn_fold_fwd': ([vp, vp, vp, vp, C.c_float, i32, vp, vp, vp], C.c_int),
         'hs_patch_conv_fwd': ([C.POINTER(StageInputC), i32, i32, vp, i64, i32, i32, i32, i32, i32,
@@ -95,7 +97,7 @@ def _load():
 
 
 lib = _load()
-EXPORTS = ['hs_version', 'hs_build_info', 'hs_signal2weights_fwd', 'hs_signal2weights_multi_fwd', 'hs_bank_pack_fwd', 'hs_bn_fold_fwd',
+EXPORTS = ['hs_version', 'hs_build_info', 'hs_signal2weights_fwd', 'hs_signal2weights_multi_fwd', 'hs_s2w_pack_floats', 'hs_s2w_pack_fwd', 'hs_bank_pack_fwd', 'hs_bn_fold_fwd',
            'hs_patch_conv_fwd', 'hs_meta_conv_fwd', 'hs_patch_conv_gen_fwd', 'hs_patch_ir_fwd', 'hs_patch_ir_v0_fwd', 'hs_patch_ir_route', 'hs_ir_tile_map', 'hs_upsample_bilinear_fwd', 'hs_upsample_argmax_fwd',
            'hs_stage_input_fwd', 'hs_depthwise_conv_fwd', 'hs_depthwise_pool_blocks', 'hs_stem_conv_fwd', 'hs_mbconv_tiles', 'hs_mbconv_expand_dw_fwd', 'hs_se_gate_fwd', 'hs_pointwise_conv_fwd', 'hs_affine_act_fwd', 'hs_gemm_split_kp', 'hs_gemm_split_fwd', 'hs_patch_conv_bwd_input',
            'hs_patch_conv_bwd_weight', 'hs_patch_conv_plain_fwd', 'hs_patch_conv_plain_bwd_in', 'hs_patch_conv_plain_bwd_w']

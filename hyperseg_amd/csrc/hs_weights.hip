@@ -152,6 +152,128 @@ void signal2weights_kernel(S2wArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// signal2weights, blocked form (round 3): the same GEMMs with both operands staged through LDS by DMA.
+//
+// Round 2's kernel above gives every wave its own 32-row x 32-patch task and lets it fetch its operands itself: 4 KS
+// per-lane dword gathers per wave (80 at K = 80), every wave of a workgroup re-reading the same weights -- 19-21 us for 4 us of
+// matrix-core work (profiles/round2_bench_kernel_stats.csv), ~1.3 resident waves per SIMD.  Here a workgroup owns a 64-row x
+// 64-patch block of one (layer, group):
+//   A  the conv weight, re-laid ONCE per parameter version by hs_s2w_pack_fwd into the exact LDS image of the blocks
+//      ([group][row block][k-step][row tile][k mod 4][16 rows], zero-padded): one linear DMA stream, 16 bytes per lane;
+//   B  the signal (B, C, fh, fw): per k-step one DMA instruction, lane = (patch tile, k mod 4, 4 consecutive patches) reading
+//      16 bytes -- the LDS image [k-step][patch tile][k mod 4][16 patches] makes every fragment read one conflict-free ds_read_b32;
+//   K  in fills of S2B_KC k-steps (20 KB of LDS per workgroup: 8 workgroups per CU), accumulators live across fills;
+//   D  through LDS ([patch][64 rows]) so that a store instruction writes one patch's 64 consecutive bank rows (256 bytes).
+// Same arithmetic as the direct form: v_mfma_f32_16x16x4_f32, k ascending -- bit-identical banks (tests/test_hip_parity.py).
+// ------------------------------------------------------------------------------------------
+constexpr int S2B_ROWS = 64, S2B_PATCHES = 64, S2B_KC = 10;
+
+struct S2bLayer {
+    const float* __restrict__ blk;          // packed weights (hs_s2w_pack_fwd)
+    float* __restrict__ bank;
+    long ld;
+    int signal_index, cs_g, rpg, rows, ks, rb, groups;
+    int wg_begin;                           // first workgroup of the layer
+};
+struct S2bArgs {
+    const float* __restrict__ signal;
+    int c_signal, grid_sz, n_patches, n_layers, pb, n_wg;
+    unsigned m_grid, m_pb;                  // magic multipliers: / grid_sz, / pb
+    S2bLayer layer[S2W_MAX_LAYERS];
+};
+
+__device__ __forceinline__ unsigned s2b_div(unsigned x, unsigned m) { return m ? __umulhi(x, m) : x; }
+static inline unsigned s2b_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / d + 1); }
+
+__global__ __launch_bounds__(256)
+void signal2weights_blocked_kernel(S2bArgs a) {
+    const __attribute__((address_space(4))) S2bArgs* ka =
+        (const __attribute__((address_space(4))) S2bArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    const int wg = (int)blockIdx.x;
+    int li = 0;
+    for (int q = 1; q < ka->n_layers; ++q)
+        if (wg >= ka->layer[q].wg_begin) li = q;
+    const float* __restrict__ blk = ka->layer[li].blk;
+    float* __restrict__ bank = ka->layer[li].bank;
+    const long ld = ka->layer[li].ld;
+    const int signal_index = ka->layer[li].signal_index, cs_g = ka->layer[li].cs_g, rpg = ka->layer[li].rpg;
+    const int rows = ka->layer[li].rows, KS = ka->layer[li].ks, RB = ka->layer[li].rb;
+    const int grid_sz = ka->grid_sz, n_patches = ka->n_patches, c_signal = ka->c_signal, PB = ka->pb;
+    const float* __restrict__ signal = ka->signal;
+    const int local = wg - ka->layer[li].wg_begin;
+    const int grb = (int)s2b_div((unsigned)local, ka->m_pb), pb = local - grb * PB;      // patch block fastest: neighbours share A
+    const int g = grb / RB, rb = grb - g * RB;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __shared__ __attribute__((aligned(16))) float lds[2 * S2B_KC * 256];                 // A fill | B fill; the output block aliases both
+    float* A = lds;
+    float* Bm = lds + S2B_KC * 256;
+    static_assert(S2B_PATCHES * (S2B_ROWS + 1) <= 2 * S2B_KC * 256, "the output block fits the operand fills");
+
+    // B source of this lane: (patch tile, k mod 4, 4 consecutive patches)
+    const int pt = lane >> 4, kq = (lane >> 2) & 3, j4 = lane & 3;
+    const int p4 = min(pb * S2B_PATCHES + 16 * pt + 4 * j4, n_patches - 4);                // whole 16-byte groups stay inside the signal
+    const int bb = (int)s2b_div((unsigned)p4, ka->m_grid), ij = p4 - bb * grid_sz;
+    const unsigned sig0 = (unsigned)((bb * c_signal + signal_index + g * cs_g) * grid_sz + ij);
+    const float* ablk = blk + (size_t)((g * RB + rb) * KS) * 256;
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < KS; k0 += S2B_KC) {
+        const int kn = min(S2B_KC, KS - k0);
+        if (k0 > 0) __syncthreads();                                                       // the previous fill has been consumed
+        for (int c = wave; c < kn; c += 4) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ablk + (size_t)(k0 + c) * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void*)(A + c * 256), 16, 0, 0);
+            const unsigned k = (unsigned)min(4 * (k0 + c) + kq, cs_g - 1);                 // k past the group reads a finite neighbour: A is zero there
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(signal + sig0 + k * (unsigned)grid_sz),
+                                             (__attribute__((address_space(3))) void*)(Bm + c * 256), 16, 0, 0);
+        }
+        __syncthreads();                                                                   // both fills have landed
+        for (int c = 0; c < kn; ++c) {
+            const float av = A[c * 256 + wave * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Bm[c * 256 + t * 64 + lane], acc[t], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                                                       // operands dead: the output block takes their place
+    {
+        const int j = lane & 15, q4 = lane >> 4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lds[(16 * t + j) * (S2B_ROWS + 1) + 16 * wave + 4 * q4 + r] = acc[t][r];
+    }
+    __syncthreads();
+    const int r0 = rb * S2B_ROWS, n0 = g * rpg + r0;
+    const bool row_ok = (r0 + lane) < rpg && (n0 + lane) < rows;
+#pragma unroll 4
+    for (int q = 0; q < 16; ++q) {
+        const int pl = wave * 16 + q, p = pb * S2B_PATCHES + pl;
+        const float v = lds[pl * (S2B_ROWS + 1) + lane];
+        if (row_ok && p < n_patches) bank[(size_t)p * ld + n0 + lane] = v;
+    }
+}
+
+// hs_s2w_pack_fwd: (cs_g, wc) transposed conv weight -> the blocked kernel's LDS images, zero-padded
+__global__ void s2w_pack_kernel(const float* __restrict__ wsw_t, int cs_g, int wc, int groups, int rb_n, int ks_n,
+                                float* __restrict__ out, long total) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int i = (int)(e & 15), kq = (int)((e >> 4) & 3), rt = (int)((e >> 6) & 3);
+    const long blkid = e >> 8;
+    const int ks = (int)(blkid % ks_n);
+    const long grb = blkid / ks_n;
+    const int rb = (int)(grb % rb_n), g = (int)(grb / rb_n);
+    const int rpg = wc / groups;
+    const int r = rb * S2B_ROWS + rt * 16 + i, k = 4 * ks + kq;
+    out[e] = (r < rpg && k < cs_g) ? wsw_t[(size_t)k * wc + (size_t)g * rpg + r] : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------
 // bank_pack: (B, hp_total, fh, fw) channel-major -> patch-major, 32x32 LDS transpose tiles.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
@@ -189,6 +311,53 @@ __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __r
 
 using namespace hs;
 
+// floats of a layer's packed image
+static long s2b_floats(int cs_g, int wc, int groups) {
+    const int rpg = wc / groups;
+    return (long)groups * ((rpg + S2B_ROWS - 1) / S2B_ROWS) * ((cs_g + 3) / 4) * 256;
+}
+
+extern "C" int64_t hs_s2w_pack_floats(int32_t signal_channels, int32_t groups, int32_t wc) {
+    if (signal_channels <= 0 || groups <= 0 || wc <= 0 || signal_channels % groups != 0 || wc % groups != 0) return HS_ERR_BAD_ARG;
+    return s2b_floats(signal_channels / groups, wc, groups);
+}
+
+extern "C" int hs_s2w_pack_fwd(const float* wsw_t, int32_t signal_channels, int32_t groups, int32_t wc, float* out, void* stream) {
+    if (!wsw_t || !out) return HS_ERR_BAD_ARG;
+    const int64_t n = hs_s2w_pack_floats(signal_channels, groups, wc);
+    if (n < 0) return (int)n;
+    const int cs_g = signal_channels / groups, rpg = wc / groups;
+    hipLaunchKernelGGL(s2w_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wsw_t, cs_g, wc, groups,
+                       (rpg + S2B_ROWS - 1) / S2B_ROWS, (cs_g + 3) / 4, out, (long)n);
+    return launch_status();
+}
+
+// The blocked form: every layer brought its packed weights, patches come in whole 16-byte groups.  1 = not applicable.
+static int launch_s2w_blocked(const float* signal, int batch, int c_signal, int fh, int fw, const hs_s2w_layer* layers,
+                              const int* order, int n_layers, hipStream_t stream) {
+    const int grid_sz = fh * fw, n_patches = batch * grid_sz;
+    if ((grid_sz & 3) != 0 || n_patches < 4) return 1;
+    S2bArgs a;
+    a.signal = signal; a.c_signal = c_signal; a.grid_sz = grid_sz; a.n_patches = n_patches; a.n_layers = n_layers;
+    a.pb = (n_patches + S2B_PATCHES - 1) / S2B_PATCHES;
+    a.m_grid = s2b_magic((unsigned)grid_sz); a.m_pb = s2b_magic((unsigned)a.pb);
+    int wgs = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        const hs_s2w_layer& l = layers[order[i]];
+        if (!l.wsw_blk) return 1;
+        S2bLayer& d = a.layer[i];
+        d.blk = l.wsw_blk; d.bank = l.bank; d.ld = (long)l.ld; d.signal_index = l.signal_index;
+        d.cs_g = l.signal_channels / l.groups; d.rpg = l.wc / l.groups; d.rows = l.rows; d.groups = l.groups;
+        d.ks = (d.cs_g + 3) / 4; d.rb = (d.rpg + S2B_ROWS - 1) / S2B_ROWS;
+        d.wg_begin = wgs;
+        wgs += l.groups * d.rb * a.pb;
+    }
+    for (int i = n_layers; i < S2W_MAX_LAYERS; ++i) { a.layer[i] = a.layer[0]; a.layer[i].wg_begin = 0x7fffffff; }
+    a.n_wg = wgs;
+    hipLaunchKernelGGL(signal2weights_blocked_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, a);
+    return launch_status();
+}
+
 extern "C" int hs_signal2weights_multi_fwd(const float* signal, int32_t batch, int32_t c_signal, int32_t fh, int32_t fw,
                                            const hs_s2w_layer* layers, int32_t n_layers, void* stream) {
     if (!signal || !layers || n_layers <= 0 || n_layers > S2W_MAX_LAYERS) return HS_ERR_BAD_ARG;
@@ -221,6 +390,10 @@ extern "C" int hs_signal2weights_multi_fwd(const float* signal, int32_t batch, i
         d.strip_begin = strips;
         strips += d.strips_per_group * l.groups;
     }
+    {
+        const int st = launch_s2w_blocked(signal, batch, c_signal, fh, fw, layers, order, n_layers, (hipStream_t)stream);
+        if (st != 1) return st;
+    }
     for (int i = n_layers; i < S2W_MAX_LAYERS; ++i) { a.layer[i] = a.layer[0]; a.layer[i].strip_begin = 0x7fffffff; }
     a.n_strips = strips;
     const int tiles = (a.n_patches + 15) / 16;
@@ -235,7 +408,7 @@ extern "C" int hs_signal2weights_fwd(const float* signal, int32_t batch, int32_t
                                      float* bank, int64_t ld, void* stream) {
     hs_s2w_layer l;
     l.signal_index = signal_index; l.signal_channels = signal_channels; l.groups = groups;
-    l.wsw_t = wsw_t; l.wc = wc; l.rows = rows; l.bank = bank; l.ld = ld;
+    l.wsw_t = wsw_t; l.wc = wc; l.rows = rows; l.bank = bank; l.ld = ld; l.wsw_blk = nullptr;
     return hs_signal2weights_multi_fwd(signal, batch, c_signal, fh, fw, &l, 1, stream);
 }
 

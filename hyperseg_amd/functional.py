@@ -203,6 +203,33 @@ class SignalRef:
         return 4
 
 
+_S2W_BLK = {}        # (wsw_t data_ptr, version, shape, channels, groups) -> (weakref to wsw_t, packed operand image of the blocked kernel)
+
+
+@_on_operand_device
+def s2w_packed(wsw_t, signal_channels, groups):
+    """The transposed signal2weights weight re-laid for ``hs_signal2weights_multi_fwd``'s blocked form (hs_s2w_pack_fwd), built
+    once per parameter version (the transposed tensor itself is cached per module by version, so its address is the key)."""
+    import weakref
+    key = (wsw_t.data_ptr(), wsw_t._version, tuple(wsw_t.shape), signal_channels, groups, wsw_t.device)
+    ent = _S2W_BLK.get(key)
+    hit = ent[1] if ent is not None and ent[0]() is wsw_t else None       # the address alone could be a dead tensor's, reused
+    if hit is None:
+        for k in [k for k, (r, _) in _S2W_BLK.items() if r() is None]:      # sources that died take their images with them
+            del _S2W_BLK[k]
+        n = _hip.lib.hs_s2w_pack_floats(signal_channels, groups, wsw_t.shape[1])
+        if n < 0:
+            _hip.check(int(n), 'hs_s2w_pack_floats')
+        hit = torch.empty(n, device=wsw_t.device, dtype=torch.float32)
+        _hip.check(_hip.lib.hs_s2w_pack_fwd(_hip.dev_ptr(wsw_t, 'wsw_t'), signal_channels, groups, wsw_t.shape[1], hit.data_ptr(),
+                                            _hip.stream_ptr()), 'hs_s2w_pack_fwd')
+        _S2W_BLK[key] = (weakref.ref(wsw_t), hit)
+    return hit
+
+
+S2W_BLOCKED = os.environ.get('HS_S2W_BLOCKED', '1') == '1'     # dev A/B switch: 0 = the direct (round-2) kernel
+
+
 @_on_operand_device
 def signal2weights_multi(signal, layers):
     """All signal2weights layers of a decoder in ONE launch.  ``layers``: list of dicts with wsw_t, signal_index,
@@ -223,6 +250,7 @@ def signal2weights_multi(signal, layers):
         a.signal_index, a.signal_channels, a.groups = l['signal_index'], l['signal_channels'], l['groups']
         a.wsw_t, a.wc = _hip.dev_ptr(l['wsw_t'], 'wsw_t'), l['wsw_t'].shape[1]
         a.rows, a.bank, a.ld = l['rows'], bank.data_ptr(), ld
+        a.wsw_blk = s2w_packed(l['wsw_t'], l['signal_channels'], l['groups']).data_ptr() if S2W_BLOCKED else None
         refs.append(BankRef(bank, b, l['rows'], (fh, fw)))
     st = _hip.lib.hs_signal2weights_multi_fwd(sig_ptr, b, c_signal, fh, fw, arr, len(layers), _hip.stream_ptr())
     _hip.check(st, 'hs_signal2weights_multi_fwd')

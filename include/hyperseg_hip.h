@@ -91,7 +91,14 @@ struct hs_s2w_layer {
     int32_t rows;
     float* bank;
     int64_t ld;
+    const float* wsw_blk;      /* optional: the same weight packed by hs_s2w_pack_fwd (hs_s2w_pack_floats floats).  When EVERY
+                                * layer brings one and fh * fw is a multiple of 4, the launch takes the blocked form: operands
+                                * staged through LDS by DMA, 64-row x 64-patch blocks; results are bit-identical. */
 };
+/* Packs the transposed conv weight of one signal2weights layer into the blocked kernel's operand images (once per parameter
+ * version; wsw_t as above).  hs_s2w_pack_floats = the size of `out` in floats. */
+int64_t hs_s2w_pack_floats(int32_t signal_channels, int32_t groups, int32_t wc);
+int hs_s2w_pack_fwd(const float* wsw_t, int32_t signal_channels, int32_t groups, int32_t wc, float* out, void* stream);
 int hs_signal2weights_multi_fwd(const float* signal, int32_t batch, int32_t c_signal, int32_t fh, int32_t fw,
                                 const hs_s2w_layer* layers, int32_t n_layers, void* stream);
 
