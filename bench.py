@@ -51,6 +51,7 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy peak 6290
 FP32_PEAK_TFLOPS = 157.3       # f32 vector == f32-input MFMA dense peak
+F16_PEAK_TFLOPS = 2500.0       # dense f16 / bf16 MFMA peak (MI355X_MICROARCH.md)
 MODELS = {'m': 'hyperseg-m', 's': 'hyperseg-s', 'sc': 'hyperseg-s-camvid', 'l': 'hyperseg-l'}
 LABELS = {'m': 'HyperSeg-M / EfficientNet-B1 / 1024x512', 's': 'HyperSeg-S / EfficientNet-B1 / 1536x768',
           'sc': 'HyperSeg-S / EfficientNet-B1 / CamVid 768x576', 'l': 'HyperSeg-L / EfficientNet-B3 / 512x512'}
@@ -61,15 +62,16 @@ class StepLoop:
     """One rank's step / drain / fence triple.  ``forward()`` produces the rank's output tensor (a graph replay returns
     the captured static output); ``comm`` is a hyperseg_amd.distributed.LogitsGatherer or None."""
 
-    def __init__(self, forward, comm=None, to_payload=None, world=1, device=None):
+    def __init__(self, forward, comm=None, to_payload=None, world=1, device=None, forward_takes_step=False):
         self.forward, self.comm, self.world = forward, comm, world
+        self.forward_takes_step = forward_takes_step      # forward(i): one HIP graph per ring slot (zero-copy collective)
         self.to_payload = to_payload or (lambda y: y)
         self.device = device
         self.last = None              # the most recent collected (step, tensor) pair, for checks outside the timing
         self.cuda = device is not None and device.type == 'cuda'
 
     def step(self, i):
-        y = self.forward()
+        y = self.forward(i) if self.forward_takes_step else self.forward()
         if self.comm is not None:
             done = self.comm.submit(i, self.to_payload(y))
             if done is not None:
@@ -150,7 +152,11 @@ def decoder_levels(model, h, w, batch):
         else:
             macs = batch * hl * wl * cin * cout
             hp = cin * cout
-        levels.append(dict(level=l, cin=cin, cout=cout, hidden=hid, macs=macs,
+        route = None
+        if hid and hasattr(first, 'hidden_dim'):            # Op C: which kernel the level gets under the module's math mode
+            import hyperseg_amd.functional as HF
+            route = HF.patch_ir_route((batch, hl, wl), skip_c, prev_c, (fh, fw), hid, cout, math=getattr(first, 'ir_math', None))
+        levels.append(dict(level=l, cin=cin, cout=cout, hidden=hid, macs=macs, route=route,
                            in_bytes=4 * batch * (skip_c * hl * wl + prev_c * (hl // 2) * (wl // 2)),
                            bank_bytes=4 * p * hp, out_bytes=4 * batch * cout * hl * wl))
         prev_c = cout
@@ -236,6 +242,21 @@ def roofline_of(launches, levels, h, w, batch, traffic_dir):
         flops = 2.0 * lv['macs']
         kbytes = lv['in_bytes'] + lv['bank_bytes'] + lv['out_bytes']
         t_fl, t_by = flops / (FP32_PEAK_TFLOPS * 1e12), kbytes / (HBM_PEAK_GBS * 1e9)
+        if lv.get('route') == 'split_mfma':
+            # The f16-split kernel issues 3 f16 products per f32 product on v_mfma_f32_16x16x32_f16: its matrix-core roof is
+            # 3 x flops at the f16 peak, which the launch's HBM time exceeds -- the roof that binds it is HBM.
+            t_f16 = 3.0 * flops / (F16_PEAK_TFLOPS * 1e12)
+            if t_by >= t_f16:
+                return {'bound': 'hbm', 'kernel': f"{dom['kernel']} (level {lv['level']}: {lv['cin']}->{lv['hidden']}->{lv['cout']} ch, "
+                                                  'f16-split matrix-core form hs_patch_irc.hip)',
+                        'achieved': round(kbytes / t_s / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                        'frac': round(kbytes / t_s / 1e9 / HBM_PEAK_GBS, 4), 'traffic': traffic, 'avg_launch_us': dom['avg_us'],
+                        'algorithmic_bytes': kbytes, 'algorithmic_flops': flops,
+                        'f32_mfma_frac': round(flops / t_s / 1e12 / FP32_PEAK_TFLOPS, 4),
+                        'f16_mfma_frac': round(3.0 * flops / t_s / 1e12 / F16_PEAK_TFLOPS, 4),
+                        'note': f'roofs of this launch: HBM {t_by * 1e6:.1f} us at 8 TB/s (binding), f16 matrix cores {t_f16 * 1e6:.1f} us '
+                                f'(3 products per f32 product), f32 matrix cores {t_fl * 1e6:.1f} us (what the exact-f32 form would '
+                                'need; reported as f32_mfma_frac for comparison with rounds 1-2)'}
         if t_fl >= t_by:
             return {'bound': 'mfma', 'kernel': f"{dom['kernel']} (level {lv['level']}: {lv['cin']}->{lv['hidden']}->{lv['cout']} ch)",
                     'achieved': round(flops / t_s / 1e12, 3), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -381,9 +402,11 @@ def main():
                          "taken inside the final upsample kernel (HyperGen.segment; test_fps.py:194's epilogue fused)")
     ap.add_argument('--gather', default='logits', choices=['logits', 'masks'],
                     help='what the N>1 collective moves (north star: logits)')
-    ap.add_argument('--collective', default='allgather', choices=['allgather', 'gather', 'none'],
-                    help="N>1: all_gather_into_tensor to every rank (default, the north star's collective), gather onto "
-                         "rank 0 (nn.DataParallel semantics), or none")
+    ap.add_argument('--collective', default=None, choices=['allgather', 'direct', 'gather', 'none'],
+                    help="N>1: the all-gather of every rank's logits.  'direct' (default): RCCL grouped point-to-point sends / receives, "
+                         "all pairs -- every shard crosses exactly one xGMI link; 'allgather': RCCL all_gather_into_tensor (its ring moves "
+                         "N-1 shards through every link); 'gather': onto rank 0 (nn.DataParallel semantics); 'none'.  Given explicitly at N=1 it runs the collective on a "
+                         "one-rank group and reports its per-step overhead ('collective.overhead_pct')")
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of HIP graph replay')
     ap.add_argument('--stock-encoder', action='store_true',
                     help='leave the encoder entirely on stock PyTorch-ROCm/MIOpen (no fused depthwise HIP kernel)')
@@ -401,6 +424,11 @@ def main():
     ap.add_argument('--traffic-dir', default=None,
                     help='directory with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (same session)')
     args = ap.parse_args()
+    # The ONE JSON line goes to the process' real stdout; everything else that writes to fd 1 (RCCL prints a version banner there
+    # when its first communicator comes up, MIOpen may chat) is sent to stderr, so that the line is the only thing a reader sees.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -412,8 +440,16 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs an MI355X'
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
-    if world > 1:
+    collective_probe = world == 1 and args.collective not in (None, 'none')      # N=1: measure the collective's own cost
+    if args.collective is None:
+        args.collective = 'direct' if world > 1 else 'none'
+    if world > 1 or collective_probe:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if collective_probe:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(('127.0.0.1', 0))
+                os.environ.setdefault('MASTER_PORT', str(sk.getsockname()[1]))
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from hyperseg_amd import configs
@@ -467,14 +503,40 @@ def main():
             y = forward(x)
         return y
 
-    comm, to_payload = None, None
-    if world > 1 and args.collective != 'none':
+    comm, to_payload, zero_copy = None, None, False
+    if (world > 1 or collective_probe) and args.collective != 'none':
         shape = tuple(y.shape) if args.gather == 'logits' else (y.shape[0],) + tuple(y.shape[-2:])
         dtype = torch.float32 if args.gather == 'logits' else torch.uint8
         comm = LogitsGatherer(world, shape, dtype, dev, mode=args.collective)
         if args.gather == 'masks':
             to_payload = lambda t: t if t.dtype == torch.uint8 else t.argmax(1).to(torch.uint8)   # noqa: E731
-    loop = StepLoop(run_forward, comm, to_payload, world, dev)
+    base_ms = None
+    if collective_probe:                                  # the same step without the collective, for the overhead figure
+        base = run_timed(StepLoop(run_forward, None, None, world, dev), args.steps, args.warmup, max(1, args.repeats))
+        base_ms = 1e3 * statistics.median(base) / args.steps
+    graphs = None
+    if comm is not None and graph is not None and args.gather == 'logits' and args.collective in ('allgather', 'direct') \
+            and hasattr(model.decoder, 'forward') and args.output != 'masks':
+        # zero copy: one HIP graph per ring slot, the decoder's last kernel writing the logits straight into the slot the
+        # collective sends from (LogitsGatherer.slot; VERDICT r2 #9: submit used to copy 39.8 MB per step)
+        from hyperseg_amd.distributed import RING
+        graphs = []
+        for k in range(RING):
+            model.decoder.output_buffer = comm.slot(k)
+            gk = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gk):
+                yk = forward(x)
+            graphs.append((gk, yk))
+        model.decoder.output_buffer = None
+        zero_copy = all(yk.data_ptr() == comm.slot(k).data_ptr() for k, (_, yk) in enumerate(graphs))
+        if not zero_copy:
+            graphs = None
+
+    def run_forward_slot(i):
+        gk, yk = graphs[i % len(graphs)]
+        gk.replay()
+        return yk
+    loop = StepLoop(run_forward_slot if graphs else run_forward, comm, to_payload, world, dev, forward_takes_step=bool(graphs))
     times = run_timed(loop, args.steps, args.warmup, max(1, args.repeats))
     med = statistics.median(times)
     fps = args.steps * global_batch / med
@@ -509,7 +571,11 @@ def main():
                        'parallelism': f'batch-sharded x{world}' + (f', RCCL {args.collective} of {args.gather}' if comm is not None else '')},
             'per_rank_frames_per_s': per_rank,
             'collective': None if comm is None else {
-                'op': 'all_gather_into_tensor' if args.collective == 'allgather' else 'gather(dst=0)', 'payload': args.gather,
+                'op': {'allgather': 'all_gather_into_tensor', 'direct': 'batch_isend_irecv, all pairs (one shard per link and direction)',
+                       'gather': 'gather(dst=0)'}[args.collective], 'payload': args.gather,
+                'zero_copy': zero_copy, 'copies_into_the_ring': comm.copies,
+                'ms_per_step_without': None if base_ms is None else round(base_ms, 4),
+                'overhead_pct': None if base_ms is None else round(100.0 * (1e3 * med / args.steps - base_ms) / base_ms, 2),
                 'bytes_sent_per_rank_per_step': comm.bytes_per_step,
                 'bytes_received_per_step': comm.bytes_per_step * world if (args.collective == 'allgather') else comm.bytes_per_step * world,
                 'completed': comm.completed},
@@ -597,8 +663,9 @@ def main():
                 out['cpu_baseline'] = None
                 if args.model == 'm' and not args.no_cpu_baseline:
                     out['cpu_baseline'] = cpu_baseline(fill_by_name(configs.build(cfg).eval(), seed=0), (h, w), args.cpu_budget)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
+    if dist.is_available() and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -243,9 +243,20 @@ void patch_conv1x1_kernel(Conv1Args a) {
         const int g = o / a.cout_g;
         const float* wr = wl + o * a.cin_g;
         const float* xr = xl + (size_t)g * a.cin_g * npix + pix;
-        float acc = 0.0f;
-        for (int c = part; c < a.cin_g; c += split) acc = fmaf(wr[c], xr[c * npix], acc);
-        for (int m = split >> 1; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+        // four independent partial sums: the LDS reads of four steps are in flight together (a single dependent chain paid the
+        // LDS latency once per channel: ~1.5 us of the launch at level 0); lanes of a split group then combine on the DPP path
+        float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
+        int c = part;
+        for (; c + 3 * split < a.cin_g; c += 4 * split) {
+            const float w0 = wr[c], w1 = wr[c + split], w2 = wr[c + 2 * split], w3 = wr[c + 3 * split];
+            const float x0 = xr[c * npix], x1 = xr[(c + split) * npix], x2 = xr[(c + 2 * split) * npix], x3 = xr[(c + 3 * split) * npix];
+            acc0 = fmaf(w0, x0, acc0); acc1 = fmaf(w1, x1, acc1); acc2 = fmaf(w2, x2, acc2); acc3 = fmaf(w3, x3, acc3);
+        }
+        for (; c < a.cin_g; c += split) acc0 = fmaf(wr[c], xr[c * npix], acc0);
+        float acc = (acc0 + acc1) + (acc2 + acc3);
+        if (split >= 2) acc += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0xB1, 0xf, 0xf, false));   // lane ^ 1
+        if (split >= 4) acc += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x4E, 0xf, 0xf, false));   // lane ^ 2
+        for (int m = split >> 1; m >= 4; m >>= 1) acc += __shfl_xor(acc, m, 64);
         if (live && part == 0) {
             if (a.scale) {
                 if (base == 0) acc = fmaf(acc, sc_first, sh_first);       // requested with the bank: no round trip here

@@ -29,10 +29,18 @@ def shard_batch(batch, rank, world):
 class LogitsGatherer:
     """Asynchronous collection of one tensor per rank and step over a ring of three send/receive buffers.
 
-    ``mode='allgather'`` (default, the north star's collective): ``all_gather_into_tensor`` -- every rank ends up with
-    every rank's result.  ``mode='gather'``: every rank sends to ``dst`` only (nn.DataParallel's semantics,
-    test_fps.py:155-156); on point-to-point xGMI that is one transfer per peer link and only ``dst`` pays the inbound
-    bandwidth.
+    ``mode='allgather'`` (default, the north star's collective): RCCL ``all_gather_into_tensor`` -- every rank ends up with
+    every rank's result.  On point-to-point xGMI RCCL's ring moves (world - 1) shards through EVERY link per step: at 8 ranks x
+    ~1100 frames/s x 39.8 MB that is ~300 GB/s per link against ~153 GB/s.  ``mode='direct'``: the all-pairs
+    schedule -- one grouped batch of RCCL point-to-point sends / receives (``batch_isend_irecv``: a single ncclGroup), every
+    shard crossing exactly ONE link, the one between its producer and its consumer: 7 x 39.8 MB in, 7 x out per GPU and step,
+    each of the 7 links carrying one shard each way.  ``mode='gather'``: every rank sends to ``dst`` only (nn.DataParallel's
+    semantics, test_fps.py:155-156).
+
+    Zero-copy: the slot a rank's own result belongs in is part of the receive buffer (``slot(step)``: rows [rank] of ring entry
+    step % 3).  A producer that writes there -- bench.py captures one HIP graph per ring entry with the decoder's
+    ``output_buffer`` pointing at it -- hands ``submit`` that very tensor and no copy is made (allgather then runs in place,
+    NCCL's sendbuff == recvbuff + rank * count form); any other tensor is copied in first, as in rounds 1-2.
 
     ``submit(i, y)`` starts the collective of step i and returns ``(i-2, collected)`` -- the result of the collective
     issued two steps earlier, now complete -- or None during the first two steps.  The returned (world, *shape) tensor
@@ -41,25 +49,35 @@ class LogitsGatherer:
     next submit may read it safely.  Ranks that own no result (gather mode, rank != dst) get ``collected = None``."""
 
     def __init__(self, world, shape, dtype, device, mode='allgather', dst=0):
-        if mode not in ('gather', 'allgather'):
+        if mode not in ('gather', 'allgather', 'direct'):
             raise ValueError(mode)
         self.world, self.mode, self.dst = world, mode, dst
         self.rank = dist.get_rank()
         self.shape = tuple(shape)
         self.bytes_per_step = int(torch.empty((), dtype=dtype).element_size()) * int(torch.Size(shape).numel())
-        self.send = [torch.empty(shape, dtype=dtype, device=device) for _ in range(RING)]
         self.recv = [None] * RING
-        if mode == 'allgather' or self.rank == dst:
+        if mode in ('allgather', 'direct') or self.rank == dst:
             self.recv = [torch.empty((world * shape[0],) + tuple(shape[1:]), dtype=dtype, device=device)
                          for _ in range(RING)]
+        if mode in ('allgather', 'direct'):
+            # the rank's own rows of the receive buffer ARE its send buffer
+            self.send = [r.view((world,) + self.shape)[self.rank] for r in self.recv]
+        else:
+            self.send = [torch.empty(shape, dtype=dtype, device=device) for _ in range(RING)]
         self.work = [None] * RING
         self.step_of = [None] * RING
         self.completed = 0
+        self.copies = 0                          # submits that had to copy their payload into the slot
+
+    def slot(self, step):
+        """Where the result of ``step`` should be produced to be sent without a copy."""
+        return self.send[step % RING]
 
     def _finish(self, k):
         if self.work[k] is None:
             return None
-        self.work[k].wait()
+        for w in self.work[k]:
+            w.wait()
         self.work[k] = None
         self.completed += 1
         out = self.recv[k].view((self.world,) + self.shape) if self.recv[k] is not None else None
@@ -70,13 +88,23 @@ class LogitsGatherer:
         if self.work[k] is not None:                 # a caller that skipped steps: never overwrite a live slot
             self._finish(k)
         done = self._finish((step - 2) % RING) if step >= 2 else None
-        self.send[k].copy_(y)
+        if not (y.data_ptr() == self.send[k].data_ptr() and tuple(y.shape) == self.shape):
+            self.send[k].copy_(y)
+            self.copies += 1
         self.step_of[k] = step
         if self.mode == 'allgather':
-            self.work[k] = dist.all_gather_into_tensor(self.recv[k], self.send[k], async_op=True)
+            self.work[k] = [dist.all_gather_into_tensor(self.recv[k], self.send[k], async_op=True)]
+        elif self.mode == 'direct':
+            rows = self.recv[k].view((self.world,) + self.shape)
+            ops = []
+            for d in range(1, self.world):           # peer at distance d: every rank sends "forward" and receives "backward"
+                to, frm = (self.rank + d) % self.world, (self.rank - d) % self.world
+                ops.append(dist.P2POp(dist.isend, self.send[k], to))
+                ops.append(dist.P2POp(dist.irecv, rows[frm], frm))
+            self.work[k] = dist.batch_isend_irecv(ops) if ops else []
         else:
             parts = list(self.recv[k].view((self.world,) + self.shape).unbind(0)) if self.rank == self.dst else None
-            self.work[k] = dist.gather(self.send[k], gather_list=parts, dst=self.dst, async_op=True)
+            self.work[k] = [dist.gather(self.send[k], gather_list=parts, dst=self.dst, async_op=True)]
         return done
 
     def drain(self):

@@ -658,11 +658,15 @@ def gemm_split(sw, x, gate=None, shift=None, act=ACT_NONE, residual=None, out=No
 
 
 @_on_operand_device
-def upsample_bilinear(x, size):
-    """F.interpolate(x, size, mode='bilinear', align_corners=False)."""
+def upsample_bilinear(x, size, out=None):
+    """F.interpolate(x, size, mode='bilinear', align_corners=False).  ``out``: a contiguous (B, C, *size) f32 tensor on x's device
+    to write into (a collective's send slot: hyperseg_amd.distributed.LogitsGatherer.slot); ignored if it does not fit."""
     b, c, hi, wi = x.shape
     ho, wo = size
-    y = torch.empty(b, c, ho, wo, device=x.device, dtype=torch.float32)
+    if out is not None and tuple(out.shape) == (b, c, ho, wo) and out.dtype == torch.float32 and out.device == x.device and out.is_contiguous():
+        y = out
+    else:
+        y = torch.empty(b, c, ho, wo, device=x.device, dtype=torch.float32)
     st = _hip.lib.hs_upsample_bilinear_fwd(_hip.dev_ptr(x, 'x'), b, c, hi, wi, ho, wo, y.data_ptr(),
                                            _hip.stream_ptr())
     _hip.check(st, 'hs_upsample_bilinear_fwd')

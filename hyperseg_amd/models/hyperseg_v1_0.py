@@ -510,7 +510,7 @@ class MultiScaleDecoder(nn.Module):
             if masks:
                 return HF.upsample_argmax(p, x[0].shape[2:])
             if p.shape[2:] != x[0].shape[2:]:
-                p = HF.upsample_bilinear(p, x[0].shape[2:])
+                p = HF.upsample_bilinear(p, x[0].shape[2:], out=getattr(self, 'output_buffer', None))
             return p
         side = join_level = None
         if 0 < n_early < len(flat) and s.is_cuda and HF.USE_SIDE_STREAM:
@@ -548,7 +548,7 @@ class MultiScaleDecoder(nn.Module):
         if masks:
             return HF.upsample_argmax(p, x[0].shape[2:])
         if p.shape[2:] != x[0].shape[2:]:
-            p = HF.upsample_bilinear(p, x[0].shape[2:])
+            p = HF.upsample_bilinear(p, x[0].shape[2:], out=getattr(self, 'output_buffer', None))
         return p
 
 

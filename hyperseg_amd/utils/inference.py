@@ -348,8 +348,22 @@ class FusedContextHead(nn.Module):
             wb = up[0].weight.detach().flatten(1)[:, half:]
             self.register_buffer('wb_scaled', getattr(self, f'scale{2 * n}')[:, None] * wb, persistent=False)
 
+        self.split_gemm = False          # prepare_for_inference(split_gemm=True): the 1x1 convolutions through hs_gemm_split_fwd
+        self._split = {}                 # name -> (key of the sources, SplitWeights | None)
+
     def _affine(self, i):
         return getattr(self, f'scale{i}'), getattr(self, f'shift{i}')
+
+    def _split_weights(self, name, weight, scale):
+        """``weight`` (Cout, K) with the BN ``scale`` folded into its rows, prepared for hs_gemm_split_fwd (None when K is outside
+        what the kernel covers); rebuilt when the conv weight or the BN scale change in place (functional._key)."""
+        from .. import functional as HF
+        key = HF._key(weight, scale)
+        hit = self._split.get(name)
+        if hit is None or hit[0] != key:
+            hit = (key, HF.gemm_split_weights(weight, scale))
+            self._split[name] = hit
+        return hit[1]
 
     def forward(self, x):
         with gemm_library(x.shape[2] * x.shape[3]):
@@ -365,8 +379,12 @@ class FusedContextHead(nn.Module):
         signal = torch.empty(1, cin, h, w, device=x.device, dtype=torch.float32)
         # feat0 = relu(bn(in_conv(x))), produced directly as the left half of the signal
         left = signal[:, :half]
-        torch.mm(wm.in_conv[0].weight.view(half, cin), x.view(cin, h * w), out=left.view(half, h * w))
-        HF.affine_act_(left, *self._affine(0), HF.ACT_RELU)
+        sw_in = self._split_weights('in', wm.in_conv[0].weight.view(half, cin), self.scale0) if self.split_gemm and (h * w) % 4 == 0 else None
+        if sw_in is not None:            # Conv -> BN -> ReLU in ONE launch: BN scale in the split weights, shift + ReLU in the GEMM's tail
+            HF.gemm_split(sw_in, x.contiguous(), shift=self.shift0, act=HF.ACT_RELU, out=left)
+        else:
+            torch.mm(wm.in_conv[0].weight.view(half, cin), x.view(cin, h * w), out=left.view(half, h * w))
+            HF.affine_act_(left, *self._affine(0), HF.ACT_RELU)
         feat = [left]
         for i, down in enumerate(wm.down_blocks):
             t = F.conv2d(feat[-1], down[0].weight, stride=2)
@@ -382,11 +400,15 @@ class FusedContextHead(nn.Module):
             if pooled_const:
                 # right operand is constant over the pixels: W_b @ mean -> per-channel constant in the shift
                 shift = torch.addmv(shift, self.wb_scaled, t.mean((2, 3)).view(half))
-                y = torch.mm(wgt[:, :half], skip.view(half, sh * sw)).view(1, half, sh, sw)
+                sw_up = self._split_weights(f'up{level}', wgt[:, :half], scale) if self.split_gemm and (sh * sw) % 4 == 0 else None
+                if sw_up is not None:
+                    y = HF.gemm_split(sw_up, skip.contiguous(), shift=shift, act=HF.ACT_RELU)
+                else:
+                    y = HF.affine_act_(torch.mm(wgt[:, :half], skip.view(half, sh * sw)).view(1, half, sh, sw), scale, shift, HF.ACT_RELU)
                 pooled_const = False
             else:
                 y = torch.mm(wgt, torch.cat((skip, t), dim=1).view(cin, sh * sw)).view(1, half, sh, sw)
-            y = HF.affine_act_(y, scale, shift, HF.ACT_RELU)
+                y = HF.affine_act_(y, scale, shift, HF.ACT_RELU)
             if level > 0:
                 t = wm.upsample(y)
             else:
@@ -444,6 +466,7 @@ def _install_fused(model):
     bb.to(dev)                                      # new non-persistent buffers follow the model's device
     if type(wm).__name__ == 'WeightMapper' and hasattr(wm, 'in_conv') and hasattr(wm, 'up_blocks') and wm.levels >= 2:
         wm._fused = FusedContextHead(wm).to(dev)
+        wm._fused.split_gemm = bool(getattr(model, '_hs_split_gemm', False))
     for m in bb.modules():                          # prepare_for_inference(split_gemm=...): our GEMM for the 1x1 convs
         if isinstance(m, FusedPointwise):
             m.split_gemm = bool(getattr(model, '_hs_split_gemm', False))

@@ -23,13 +23,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, steps, q, mode='allgather'):
+def _worker(rank, world, port, steps, q, mode='allgather', zero_copy=False):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         shape = (1, 3, 4, 5)
         g = LogitsGatherer(world, shape, torch.float32, torch.device('cpu'), mode=mode)
-        owner = mode == 'allgather' or rank == 0
+        owner = mode in ('allgather', 'direct') or rank == 0
         ok = True
         frames = shard_frames(steps * world, rank, world)
         assert frames == list(range(rank, steps * world, world))
@@ -44,7 +44,11 @@ def _worker(rank, world, port, steps, q, mode='allgather'):
             if owner:
                 ok &= bool(torch.equal(out, want.expand(world, *shape)))
         for i, f in enumerate(frames):
-            y = torch.full(shape, float(f))                  # stands for the logits of global frame f
+            if zero_copy:                                    # the producer writes straight into the ring slot: no copy in submit
+                y = g.slot(i)
+                y.fill_(float(f))
+            else:
+                y = torch.full(shape, float(f))              # stands for the logits of global frame f
             prev = g.submit(i, y)                            # starts the collective of step i, returns step i-2's result
             ok &= (prev is None) == (i < 2)
             if prev is not None:
@@ -57,25 +61,29 @@ def _worker(rank, world, port, steps, q, mode='allgather'):
         for item in g.drain():
             check(item)
         ok &= seen == list(range(steps))
+        ok &= g.copies == (0 if zero_copy else steps)
         q.put((rank, ok, g.completed))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('mode', ['allgather', 'gather'])
+@pytest.mark.parametrize('mode,world,zero_copy', [('allgather', 2, False), ('gather', 2, False), ('direct', 2, False), ('direct', 3, True),
+                                                  ('allgather', 2, True)])
 @pytest.mark.parametrize('steps', [1, 5])
-def test_batch_sharded_gather_gloo(steps, mode):
-    world, port = 2, _free_port()
+def test_batch_sharded_gather_gloo(steps, mode, world, zero_copy):
+    """allgather / gather-to-0 / direct all-pairs (grouped point-to-point sends and receives: every shard crosses one link), with
+    the payload copied into the ring slot or produced there (zero copy): ordering, ownership and buffer lifetime."""
+    port = _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, steps, q, mode)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, steps, q, mode, zero_copy)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=90) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert res == [(0, True, steps), (1, True, steps)]
+    assert res == [(r, True, steps) for r in range(world)]
 
 
 def _bench_worker(rank, world, port, q, mode):
@@ -100,7 +108,7 @@ def _bench_worker(rank, world, port, q, mode):
         times = bench.run_timed(loop, steps, warmup, repeats)
         total = warmup + steps * repeats
         ok = len(times) == repeats and all(t > 0 for t in times) and calls[0] == total and comm.completed == total
-        owner = mode == 'allgather' or rank == 0
+        owner = mode in ('allgather', 'direct') or rank == 0
         step, out = loop.last                                  # the last collected step must be the last one issued
         ok &= step == total - 1 and (out is not None) == owner
         if owner:
@@ -116,7 +124,7 @@ def _bench_worker(rank, world, port, q, mode):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('mode', ['allgather', 'gather'])
+@pytest.mark.parametrize('mode', ['allgather', 'gather', 'direct'])
 def test_bench_step_loop_gloo(mode):
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')
@@ -152,15 +160,20 @@ def test_gatherer_on_the_rccl_path_single_gpu():
     torch.cuda.set_device(dev)
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
     try:
-        for mode in ('allgather', 'gather'):
+        for mode in ('allgather', 'gather', 'direct'):
             shape = (2, 19, 32, 64)
             g = LogitsGatherer(1, shape, torch.float32, dev, mode=mode)
             sums = []
             for i in range(7):
-                y = torch.full(shape, float(i), device=dev)
-                y.mul_(1.0)                                   # "compute" of step i on the caller's stream
-                prev = g.submit(i, y)
-                y.fill_(-1.0)                                 # the graph's static output is overwritten by the next replay
+                if mode != 'gather' and i % 2:               # odd steps: produced in the ring slot itself (zero copy)
+                    y = g.slot(i)
+                    y.fill_(float(i))
+                    prev = g.submit(i, y)
+                else:
+                    y = torch.full(shape, float(i), device=dev)
+                    y.mul_(1.0)                               # "compute" of step i on the caller's stream
+                    prev = g.submit(i, y)
+                    y.fill_(-1.0)                             # the graph's static output is overwritten by the next replay
                 if prev is not None:
                     step, out = prev
                     assert tuple(out.shape) == (1,) + shape
@@ -171,6 +184,6 @@ def test_gatherer_on_the_rccl_path_single_gpu():
             n = float(torch.Size(shape).numel())
             assert [s for s, _ in sums] == list(range(7))
             assert [float(v) for _, v in sums] == [n * i for i in range(7)]
-            assert g.completed == 7
+            assert g.completed == 7 and g.copies == (7 if mode == 'gather' else 4)
     finally:
         dist.destroy_process_group()
