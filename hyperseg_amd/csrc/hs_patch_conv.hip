@@ -109,14 +109,20 @@ struct Conv1Args {
     int split;        // power of two <= 64: lanes cooperating on one output
 };
 
+// PWL >= 0: square patches of edge 2^PWL (the decoder's levels 0-2 are 1, 2 and 4 pixels; the launch's split is then a compile-time
+// value too): the index arithmetic -- e -> (channel, pixel), pixel -> (row, column), output -> (o, pixel) -- is shifts and masks
+// instead of run-time integer divisions, which were a third of this kernel's ~970 vector instructions per wave
+// (profiles/round3_pmc_k1_and_s2w.txt).  PWL = -1: any patch size.
+template <int PWL>
 __global__ __launch_bounds__(CONV_THREADS)
 void patch_conv1x1_kernel(Conv1Args a) {
+    const int ph_ = PWL >= 0 ? (1 << PWL) : a.ph, pw_ = PWL >= 0 ? (1 << PWL) : a.pw;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int patch = blockIdx.x;
-    const int j = patch % a.fw, i = (patch / a.fw) % a.fh, b = patch / (a.fw * a.fh);
+    const int pib = patch / a.fw, j = patch - pib * a.fw, b = pib / a.fh, i = pib - b * a.fh;
     const int cin = a.in.cin();
-    const int npix = a.ph * a.pw;
+    const int npix = ph_ * pw_;
     const int hp = a.cout * a.cin_g;
     const int hp4 = (hp + 3) & ~3;
     float* wl = lds;                 // [cout][cin_g], natural order
@@ -130,7 +136,7 @@ void patch_conv1x1_kernel(Conv1Args a) {
     const bank4* __restrict__ src = reinterpret_cast<const bank4*>(a.bank + (size_t)patch * a.ld);
     bank4* dst = reinterpret_cast<bank4*>(wl);
     const int n4 = hp4 >> 2;                          // ld is a multiple of 4 and >= hp: the tail read stays in-row
-    const int y0 = i * a.ph, x0 = j * a.pw;
+    const int y0 = i * ph_, x0 = j * pw_;
     const int total_x = cin * npix;
     // Stage-input elements without a branch around any load: stage_value() picks coordinate / skip / previous-level by
     // channel, lanes of one wave differ in that, and every arm's loads were waited for where the arms join (6 serialised
@@ -150,7 +156,7 @@ void patch_conv1x1_kernel(Conv1Args a) {
             const int e = min(tid + q * CONV_THREADS, total_x - 1);
             int c = e / npix;
             const int pix = e - c * npix;
-            const int u = pix / a.pw, vv = pix - u * a.pw;
+            const int u = pix / pw_, vv = pix - u * pw_;
             yy[q] = y0 + u; xx[q] = x0 + vv;
             cv[q] = 0.0f;
             bool is_coord = false;
@@ -226,7 +232,7 @@ void patch_conv1x1_kernel(Conv1Args a) {
     for (int e = tid + 8 * CONV_THREADS; e < n4; e += CONV_THREADS) dst[e] = src[e];
     for (int e = tid + 4 * CONV_THREADS; e < total_x; e += CONV_THREADS) {
         const int c = e / npix, pix = e - c * npix;
-        const int u = pix / a.pw, vv = pix - u * a.pw;
+        const int u = pix / pw_, vv = pix - u * pw_;
         xl[e] = stage_value(a.in, b, c, stage_pos(a.in, y0 + u, x0 + vv));
     }
     __syncthreads();
@@ -263,8 +269,8 @@ void patch_conv1x1_kernel(Conv1Args a) {
                 else acc = fmaf(acc, a.scale[o], a.shift[o]);
             }
             acc = apply_act(acc, a.act);
-            const int u = pix / a.pw, v = pix - u * a.pw;
-            a.y[(((size_t)b * a.cout + o) * a.in.H + (i * a.ph + u)) * a.in.W + (j * a.pw + v)] = acc;
+            const int u = pix / pw_, v = pix - u * pw_;
+            a.y[(((size_t)b * a.cout + o) * a.in.H + (i * ph_ + u)) * a.in.W + (j * pw_ + v)] = acc;
         }
     }
 }
@@ -503,14 +509,21 @@ extern "C" int hs_patch_conv_fwd(const hs_stage_input* in, int32_t fh, int32_t f
             int split = 1;
             while (split < 64 && outs * split * 2 <= CONV_THREADS && split * 2 <= a.cin_g) split *= 2;
             f.split = split;
-            if (lds1 > 64 * 1024) {
-                static std::atomic<unsigned long long> done{0};
-                const int e = allow_full_lds((const void*)patch_conv1x1_kernel, done);
-                if (e != HS_OK) return e;
-            }
-            hipLaunchKernelGGL(patch_conv1x1_kernel, dim3((unsigned)((long)in->batch * fh * fw)), dim3(CONV_THREADS),
-                               lds1, (hipStream_t)stream, f);
-            return launch_status();
+            const dim3 grid((unsigned)((long)in->batch * fh * fw));
+#define HS_K1_LAUNCH(PWL) do { \
+                if (lds1 > 64 * 1024) { \
+                    static std::atomic<unsigned long long> done{0}; \
+                    const int e = allow_full_lds((const void*)patch_conv1x1_kernel<PWL>, done); \
+                    if (e != HS_OK) return e; \
+                } \
+                hipLaunchKernelGGL(patch_conv1x1_kernel<PWL>, grid, dim3(CONV_THREADS), lds1, (hipStream_t)stream, f); \
+                return launch_status(); } while (0)
+            if (a.ph == a.pw && a.ph == 1) HS_K1_LAUNCH(0);
+            if (a.ph == a.pw && a.ph == 2) HS_K1_LAUNCH(1);
+            if (a.ph == a.pw && a.ph == 4) HS_K1_LAUNCH(2);
+            if (a.ph == a.pw && a.ph == 8) HS_K1_LAUNCH(3);
+            HS_K1_LAUNCH(-1);
+#undef HS_K1_LAUNCH
         }
     }
     const int wrow = a.cin_g * k * k;

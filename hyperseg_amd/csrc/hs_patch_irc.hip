@@ -221,13 +221,14 @@ void patch_irc_kernel(IrcArgs a) {
                                              (__attribute__((address_space(3))) void*)(scr + c * 1024), 16, 0, 0);
         }
     }
-    // (2) skip tile.  Wave w takes channels w, w + NW, ..; lanes 0 .. 59 = (halo row u of a pass of 10 rows, 16-byte segment sg of
-    //     columns x0 - 4 + 4 sg ..): the channel is wave-uniform (scalar base), the per-lane offset is computed once per pass.
-    //     Segments that would leave the image are clamped inside it -- their halo column then comes from the reflected interior
-    //     column (phase 2).
+    // (2) skip tile.  Wave w loads the channels of lane group kg = w (w SPL .. w SPL + SPL - 1); lanes 0 .. 59 = (halo row u of a
+    //     pass of 10 rows, 16-byte segment sg of columns x0 - 4 + 4 sg ..): the channel is wave-uniform (scalar base), the per-lane
+    //     offset is computed once per pass, and a thread ends up with an SPL-channel x 4-column block -- what phase 2 stores as one
+    //     SPL-float vector per halo position.  Segments that would leave the image are clamped inside it: their halo column then
+    //     comes from the reflected interior column (phase 2).
+    static_assert(NW == 4, "wave w <-> lane group kg = w");
     constexpr int SKPASS = (G::HH + 9) / 10;                           // 1 (RH = 8) or 2 (RH = 16) passes of 10 halo rows
-    constexpr int SCH = 4 * SPL, SKQ = SCH / NW;                       // channel slots; loads per thread and pass
-    f32x4 sk4[SKPASS][SKQ];
+    f32x4 sk4[SKPASS][SPL];
     const int sk_ul = lane / 6, sk_sg = lane - 6 * sk_ul;              // row of the pass (0 .. 9 live), segment
     {
         const float* __restrict__ skb = a.in.skip + (size_t)b * cskip * plane;
@@ -238,33 +239,31 @@ void patch_irc_kernel(IrcArgs a) {
             const int yy = pad_index(y0 + u - 1, H, HS_PAD_REFLECT);
             const unsigned off = (__umul24((unsigned)yy, (unsigned)W) + (unsigned)c0) << 2;
 #pragma unroll
-            for (int k = 0; k < SKQ; ++k) {
-                const int ch = wave + NW * k;                          // uniform; no branch around the load: clamp + mask
+            for (int k = 0; k < SPL; ++k) {
+                const int ch = wave * SPL + k;                         // uniform; no branch around the load: clamp + mask
                 const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(skb + (size_t)min(ch, cskip - 1) * plane) + (size_t)off);
                 const float mk = ch < cskip ? 1.0f : 0.0f;
                 sk4[pp][k] = f32x4{v[0] * mk, v[1] * mk, v[2] * mk, v[3] * mk};
             }
         }
     }
-    // (3) low-res window of the previous level: rows [ly0, ly0 + PWH) x cols [lx0, lx0 + PWW), clamped at the border.  A load
-    //     instruction takes PWC channels: lanes = (channel of the set, row r, 16-byte segment of columns x0 / 2 - 4 + 4 s ..).
+    // (3) low-res window of the previous level: rows [ly0, ly0 + PWH) x cols [lx0, lx0 + PWW), clamped at the border.  Wave w loads
+    //     the PPL channels of lane group w, one channel per instruction: lanes 0 .. 4 PWH - 1 = (row r, 16-byte segment of columns
+    //     x0 / 2 - 4 + 4 s ..).
     const int ly0 = (y0 >> 1) - 1, lx0 = (x0 >> 1) - 1;
-    constexpr int PWC = 64 / (4 * PWH);                                // channels per load instruction: 2 (RH = 8), 1 (RH = 16)
-    static_assert(PWC >= 1, "a window channel fits one wave");
-    constexpr int PCH = 4 * PPL, PWQ = (PCH + PWC * NW - 1) / (PWC * NW);
-    f32x4 pw4[PWQ];
-    const int pw_half = min(lane / (4 * PWH), PWC - 1), pw_l = lane - 4 * PWH * pw_half;
-    const int pw_r = min(pw_l >> 2, PWH - 1), pw_s = pw_l & 3;
+    static_assert(4 * PWH <= 64, "a window channel fits one wave");
+    f32x4 pw4[PPL];
+    const int pw_r = min(lane >> 2, PWH - 1), pw_s = lane & 3;
     {
         const float* __restrict__ pvb = a.in.prev + (size_t)b * cprev * a.in.Hp * a.in.Wp;
         const int yy = min(max(ly0 + pw_r, 0), a.in.Hp - 1);
         const int c0 = min(max((x0 >> 1) - 4 + 4 * pw_s, 0), a.in.Wp - 4);
-        const unsigned off = __umul24((unsigned)yy, (unsigned)a.in.Wp) + (unsigned)c0;
-        const unsigned cpl = (unsigned)(a.in.Hp * a.in.Wp);
+        const unsigned off = (__umul24((unsigned)yy, (unsigned)a.in.Wp) + (unsigned)c0) << 2;
+        const size_t cpl = (size_t)a.in.Hp * a.in.Wp;
 #pragma unroll
-        for (int k = 0; k < PWQ; ++k) {
-            const int ch = PWC * (wave + NW * k) + pw_half;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(pvb) + (size_t)((__umul24((unsigned)min(ch, cprev - 1), cpl) + off) << 2));
+        for (int k = 0; k < PPL; ++k) {
+            const int ch = wave * PPL + k;                             // uniform
+            const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(pvb + (size_t)min(ch, cprev - 1) * cpl) + (size_t)off);
             const float mk = ch < cprev ? 1.0f : 0.0f;
             pw4[k] = f32x4{v[0] * mk, v[1] * mk, v[2] * mk, v[3] * mk};
         }
@@ -285,140 +284,92 @@ void patch_irc_kernel(IrcArgs a) {
     // @stamp 2
 
     // ================================================ phase 1: split the bank, LDS -> LDS ==============================
-    // A 16-lane segment takes one matrix ROW at a time; lane l of the segment holds columns 2l, 2l + 1 (and 32 + 2l, 33 + 2l):
-    // the row maximum is a DPP reduction inside the segment.  W1 rows scale to [2^14, 2^15); 1 / scale goes into BN1's scale.
-    constexpr int NSEG = NTHR / 16;                                   // rows in flight per round
-    constexpr int R1 = (96 + NSEG - 1) / NSEG, R3 = (32 + NSEG - 1) / NSEG, TQ = (96 * 9 + NTHR - 1) / NTHR;
-    const int sgi = tid >> 4, seg = tid & 15;
-    // every LDS read of the pass first (rows clamped, not branched around), then the arithmetic: R1 + R3 independent chains
-    float w1v[R1][4], w3v[R3][6], tpv[TQ], s1r[R1], s3r[R3], s2r[TQ];
-    const int c2 = min(32 + 2 * seg, cin - 2);                        // second column pair of the lane (columns 32..), clamped
-#pragma unroll
-    for (int r = 0; r < R1; ++r) {                                    // no branches: rounds past hid re-read the last row
-        const int h = min(sgi + r * NSEG, hid - 1);
-        const float* rp = raw + h * cin;
-        w1v[r][0] = rp[2 * seg]; w1v[r][1] = rp[2 * seg + 1]; w1v[r][2] = rp[c2]; w1v[r][3] = rp[c2 + 1];
-        s1r[r] = raw_s1[h];
-    }
-#pragma unroll
-    for (int r = 0; r < R3; ++r) {
-        const int o = min(sgi + r * NSEG, cout - 1);
-        const float* rp = raw + off_w3 + o * hid;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int hh = min(32 * i + 2 * seg, hid - 2);
-            w3v[r][2 * i] = rp[hh]; w3v[r][2 * i + 1] = rp[hh + 1];
-        }
-        s3r[r] = raw_s3[o];
-    }
-#pragma unroll
-    for (int q = 0; q < TQ; ++q) {
-        const int e = min(tid + q * NTHR, 9 * hid - 1);
-        tpv[q] = raw[off_kd + e];
-        s2r[q] = raw_s2[(unsigned)e / 9u];
-    }
+    // One JOB per thread: a contiguous piece of one matrix row -- a W1 row (cin values) is 2 jobs, a W3 row (hid values) 4 -- so
+    // the 4216 weights of HyperSeg-M's level 4 are 212 jobs of <= 18 values, one pass of the workgroup.  (Round 3a gave a 16-lane
+    // segment a row at a time: 2 useful values per lane and round, the per-row arithmetic repeated in 16 lanes, 500 vector
+    // instructions per wave for what is 16 values per thread.)  The row maximum is the maximum of the job's values combined across
+    // the 2 / 4 neighbouring lanes of the row on the DPP path; every row scales to [2^14, 2^15) and 1 / scale goes into the
+    // BatchNorm scale that follows (s1f, s3f).
     {
-        const unsigned m0e = 2 * seg < cin ? ~0u : 0u, m0o = 2 * seg + 1 < cin ? ~0u : 0u;
-        const bool second = 32 + 2 * seg < cin;                       // columns 32.. : lanes 0, 1 at cin = 34
-        const unsigned m1e = second ? ~0u : 0u, m1o = 32 + 2 * seg + 1 < cin ? ~0u : 0u;
-#pragma unroll
-        for (int r = 0; r < R1; ++r) {
-            {
-                const int h = sgi + r * NSEG;
-                // columns past cin become exact zeros (they read the next row): out of the maximum, and a zero in the pad column
-                const float v0 = __uint_as_float(__float_as_uint(w1v[r][0]) & m0e), v1 = __uint_as_float(__float_as_uint(w1v[r][1]) & m0o);
-                const float v2 = __uint_as_float(__float_as_uint(w1v[r][2]) & m1e), v3 = __uint_as_float(__float_as_uint(w1v[r][3]) & m1o);
-                const unsigned m = max(max(absbits(v0), absbits(v1)), max(absbits(v2), absbits(v3)));
-                const int eb = irc_exp_of(rowmax16_u(m));
-                const float sc = irc_scale_of(eb);
-                unsigned hi0, lo0, hi1, lo1;
-                split2(v0, v1, sc, hi0, lo0);
-                split2(v2, v3, sc, hi1, lo1);
-                if (h < hid) {                                         // uniform per 16-lane segment
-                    unsigned* dh = reinterpret_cast<unsigned*>(w1h + h * cinp);                 // h * cinp is even: 4-byte aligned
-                    unsigned* dl = reinterpret_cast<unsigned*>(w1h + w1_piece + h * cinp);
-                    if (2 * seg < cinp) { dh[seg] = hi0; dl[seg] = lo0; }
-                    if (second) { dh[16 + seg] = hi1; dl[16 + seg] = lo1; }
-                    if (seg == 0) s1f[h] = s1r[r] * irc_inv_scale_of(eb);
-                }
-            }
-        }
-    }
-    // W3: per output row, the maximum over ALL hidden channels; 1 / scale and h2's 2^-12 go into BN3's scale
-#pragma unroll
-    for (int r = 0; r < R3; ++r) {
-        {
-            const int o = sgi + r * NSEG;
-            float wv[6];
+        constexpr int MAXP = 12;                                       // value pairs per job: cin <= 34 -> 9, hid <= 96 -> 12
+        const int ca = (((cin + 1) >> 1) + 1) & ~1, cb = (((hid + 3) >> 2) + 1) & ~1;   // piece lengths (even, rounded up): W1 rows in 2, W3 rows in 4
+        const int j1n = 2 * hid, j3b = (j1n + 3) & ~3, jn = j3b + 4 * cout;
+        for (int job = tid; job < ((jn + 3) & ~3); job += NTHR) {      // whole quads enter together (the DPP steps read neighbours)
+            const bool is1 = job < j1n, is3 = job >= j3b && job < jn;
+            const int row = is1 ? job >> 1 : (job - j3b) >> 2, part = is1 ? job & 1 : (job - j3b) & 3;
+            const int len_row = is1 ? cin : hid, piece = is1 ? ca : cb;
+            const int c_lo = part * piece, cnt = (is1 || is3) ? min(max(len_row - c_lo, 0), piece) : 0;
+            const float* rp = raw + (is1 ? row * cin : off_w3 + row * hid) + c_lo;
+            float v[2 * MAXP];
             unsigned m = 0;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int hh = 32 * i + 2 * seg;
-                wv[2 * i] = hh < hid ? w3v[r][2 * i] : 0.0f;
-                wv[2 * i + 1] = hh + 1 < hid ? w3v[r][2 * i + 1] : 0.0f;
-                m = max(m, max(absbits(wv[2 * i]), absbits(wv[2 * i + 1])));
+            for (int i = 0; i < 2 * MAXP; ++i) {
+                v[i] = i < cnt ? rp[i] : 0.0f;                         // LDS reads; a predicated read costs nothing extra
+                m = max(m, absbits(v[i]));
             }
-            const int eb = irc_exp_of(rowmax16_u(m));
+            m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xf, 0xf, false));          // lane ^ 1: the row's other W1 piece
+            const unsigned m4 = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xf, 0xf, false));   // lane ^ 2: W3 rows span a quad
+            const int eb = irc_exp_of(is1 ? m : m4);
             const float sc = irc_scale_of(eb);
-            if (o < cout) {
-                unsigned* dh = reinterpret_cast<unsigned*>(w3h + o * hidp);
-                unsigned* dl = reinterpret_cast<unsigned*>(w3h + w3_piece + o * hidp);
+            _Float16* dbase = is1 ? w1h + row * cinp + c_lo : w3h + row * hidp + c_lo;      // even half index: 4-byte aligned
+            unsigned* dh = reinterpret_cast<unsigned*>(dbase);
+            unsigned* dl = reinterpret_cast<unsigned*>(dbase + (is1 ? w1_piece : w3_piece));
+            const int npair = (min(cnt, (is1 ? cinp : hidp) - c_lo) + 1) >> 1;     // the pad column of an odd row length is written as zero
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    unsigned hi, lo;
-                    split2(wv[2 * i], wv[2 * i + 1], sc, hi, lo);
-                    if (32 * i + 2 * seg < hidp) { dh[16 * i + seg] = hi; dl[16 * i + seg] = lo; }
-                }
-                if (seg == 0) s3f[o] = s3r[r] * (irc_inv_scale_of(eb) * (1.0f / IRC_H2_SCALE));
+            for (int i = 0; i < MAXP; ++i) {
+                unsigned hi, lo;
+                split2(v[2 * i], v[2 * i + 1], sc, hi, lo);
+                if (i < npair) { dh[i] = hi; dl[i] = lo; }
             }
+            if (is1 && part == 0) s1f[row] = raw_s1[row] * irc_inv_scale_of(eb);
+            if (is3 && part == 0) s3f[row] = raw_s3[row] * (irc_inv_scale_of(eb) * (1.0f / IRC_H2_SCALE));
         }
     }
-#pragma unroll
-    for (int q = 0; q < TQ; ++q) {
-        const int e = tid + q * NTHR;
-        if (e < 9 * hid) taps[e] = tpv[q] * (s2r[q] * IRC_H2_SCALE);
-    }
+    for (int e = tid; e < 9 * hid; e += NTHR) taps[e] = raw[off_kd + e] * (raw_s2[(unsigned)e / 9u] * IRC_H2_SCALE);
     // @stamp 3
     __syncthreads();                                       // the raw bank is dead
     // @stamp 4
 
     // ================================================ phase 2: tiles and tap tables into the scratch ====================
-    {
+    {   // skip tile: the thread's SPL-channel x 4-column block -> one SPL-float vector per halo position of lane group kg = wave
         const bool left = sk_sg == 0, right = sk_sg == 5;
         const bool clamp_l = x0 == 0, clamp_r = x0 + RW == W;           // uniform: the region touches the image border
+        using skv = __attribute__((ext_vector_type(SPL))) float;
 #pragma unroll
         for (int pp = 0; pp < SKPASS; ++pp) {
             const int u = pp * 10 + sk_ul;
             if (sk_ul < 10 && u < G::HH) {
+                float* d = SK + (wave * SKPL + u * HWD + 4 * sk_sg - 3) * SPL;
 #pragma unroll
-                for (int k = 0; k < SKQ; ++k) {
-                    const int ch = wave + NW * k;
-                    f32x4 v = sk4[pp][k];
-                    // halo column 0 is image column x0 - 1 (element 3 of segment 0) or, reflected at the left border, column 1 (element 1
-                    // of the clamped segment); halo column 17 likewise
-                    if (left) v[3] = clamp_l ? v[1] : v[3];
-                    if (right) v[0] = clamp_r ? v[2] : v[0];
-                    float* d = SK + ((ch / SPL) * SKPL + u * HWD + 4 * sk_sg - 3) * SPL + ch % SPL;
+                for (int i = 0; i < 4; ++i) {
+                    const int vv = 4 * sk_sg - 3 + i;
+                    if (vv >= 0 && vv < HWD) {
+                        // halo column 0 is image column x0 - 1 (element 3 of segment 0) or, reflected at the left border, column 1
+                        // (element 1 of the clamped segment); halo column 17 likewise
+                        const int src = (left && clamp_l) ? 1 : (right && clamp_r) ? 2 : i;
+                        if constexpr (SPL == 1) d[i] = src == i ? sk4[pp][0][i] : (src == 1 ? sk4[pp][0][1] : sk4[pp][0][2]);
+                        else {
+                            skv o;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int vv = 4 * sk_sg - 3 + i;
-                        if (vv >= 0 && vv < HWD) d[i * SPL] = v[i];
+                            for (int k = 0; k < SPL; ++k) o[k] = src == i ? sk4[pp][k][i] : (src == 1 ? sk4[pp][k][1] : sk4[pp][k][2]);
+                            *reinterpret_cast<skv*>(d + i * SPL) = o;
+                        }
                     }
                 }
             }
         }
     }
-    if (lane < 4 * PWH * PWC) {
+    if (lane < 4 * PWH) {
+        using pwv = __attribute__((ext_vector_type(PPL))) float;
+        float* d = WN + (wave * WNP + pw_r * PWW + 4 * pw_s - 3) * PPL;
 #pragma unroll
-        for (int k = 0; k < PWQ; ++k) {
-            const int ch = PWC * (wave + NW * k) + pw_half;
-            if (ch < PCH) {
-                float* d = WN + ((ch / PPL) * WNP + pw_r * PWW + 4 * pw_s - 3) * PPL + ch % PPL;
+        for (int i = 0; i < 4; ++i) {
+            const int q = 4 * pw_s - 3 + i;
+            if (q >= 0 && q < PWW) {
+                pwv o;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int q = 4 * pw_s - 3 + i;
-                    if (q >= 0 && q < PWW) d[i * PPL] = pw4[k][i];
-                }
+                for (int k = 0; k < PPL; ++k) o[k] = pw4[k][i];
+                *reinterpret_cast<pwv*>(d + i * PPL) = o;
             }
         }
     }

@@ -166,7 +166,10 @@ void signal2weights_kernel(S2wArgs a) {
 //   D  through LDS ([patch][64 rows]) so that a store instruction writes one patch's 64 consecutive bank rows (256 bytes).
 // Same arithmetic as the direct form: v_mfma_f32_16x16x4_f32, k ascending -- bit-identical banks (tests/test_hip_parity.py).
 // ------------------------------------------------------------------------------------------
-constexpr int S2B_ROWS = 64, S2B_PATCHES = 64, S2B_KC = 10;
+#ifndef HS_S2B_KC
+#define HS_S2B_KC 10
+#endif
+constexpr int S2B_ROWS = 64, S2B_PATCHES = 64, S2B_KC = HS_S2B_KC;      // HS_S2B_KC: dev A/B knob (tools/build_variants.py)
 
 struct S2bLayer {
     const float* __restrict__ blk;          // packed weights (hs_s2w_pack_fwd)
@@ -371,7 +374,11 @@ extern "C" int hs_signal2weights_multi_fwd(const float* signal, int32_t batch, i
     for (int i = 1; i < n_layers; ++i)
         for (int q = i; q > 0; --q) {
             const hs_s2w_layer &x = layers[order[q]], &y = layers[order[q - 1]];
+#ifdef HS_S2B_LIGHT_FIRST
+            if (x.groups > 0 && y.groups > 0 && x.signal_channels / x.groups < y.signal_channels / y.groups) {
+#else
             if (x.groups > 0 && y.groups > 0 && x.signal_channels / x.groups > y.signal_channels / y.groups) {
+#endif
                 const int t = order[q]; order[q] = order[q - 1]; order[q - 1] = t;
             } else break;
         }

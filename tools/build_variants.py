@@ -108,6 +108,9 @@ VARIANTS = {
     'dwtile_k5_128': dict(flags=[], extra=[], patch='dwtile_k5_128', file='hs_encoder.hip'),   # + the 16x32 maps (128 threads)
     'dwtile_all': dict(flags=[], extra=[], patch='dwtile_all', file='hs_encoder.hip'),
     'kpreload': dict(flags=['-mllvm', '-amdgpu-kernarg-preload-count=16'], extra=[], patch=None),
+    's2b_kc20': dict(flags=['-DHS_S2B_KC=20'], extra=[], patch=None),          # blocked signal2weights: one LDS fill for K = 80 (40 KB)
+    's2b_kc5': dict(flags=['-DHS_S2B_KC=5'], extra=[], patch=None),
+    's2b_light_first': dict(flags=['-DHS_S2B_LIGHT_FIRST'], extra=[], patch=None),
 }
 
 if __name__ == '__main__':
