@@ -286,9 +286,9 @@ def pmc_traffic(traffic_dir, kernel):
         return None
     import csv
     import glob
-    stem = {'hs_patch_ir_fwd': 'patch_ir_', 'hs_patch_ir_v0_fwd': 'patch_ir_',
+    stem = {'hs_patch_ir_fwd': 'patch_ir', 'hs_patch_ir_v0_fwd': 'patch_ir',
             'hs_patch_conv_fwd': 'patch_conv', 'hs_upsample_bilinear_fwd': 'upsample2x_kernel',
-            'hs_signal2weights_multi_fwd': 'signal2weights_kernel'}.get(kernel)
+            'hs_signal2weights_multi_fwd': 'signal2weights'}.get(kernel)
     if stem is None:
         return None
     acc = {}

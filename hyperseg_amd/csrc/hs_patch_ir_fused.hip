@@ -31,7 +31,7 @@
 // zero BN scale/shift instead), 32-bit offsets from uniform bases, every prologue load in flight before the first wait,
 // and the chunk's filter-bank operands copied into a double-buffered LDS block with COALESCED loads one stage ahead
 // (STAGE below; regions that span several patches keep the direct per-lane operand loads).
-// Hidden activations never leave the CU.  The same dataflow on the f16 matrix cores (split products): hs_patch_ir_split.hip;
+// Hidden activations never leave the CU.  Op C on the f16 matrix cores (split products): hs_patch_irc.hip;
 // one lane per pixel with a broadcast MFMA for HyperSeg-L's narrow levels: hs_patch_ir_px.hip.
 #include "hs_ir_common.h"
 

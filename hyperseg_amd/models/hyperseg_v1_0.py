@@ -79,7 +79,21 @@ class _SignalToWeights:
             raise RuntimeError('a precomputed bank cannot carry gradients')
         if self.signal2weights is None:
             return s[:, :hp]
-        return self.signal2weights(s[:, self.signal_index:self.signal_index + self.signal_channels])[:, :hp]
+        conv = self.signal2weights
+        sig = s[:, self.signal_index:self.signal_index + self.signal_channels]
+        if s.is_cuda and conv.bias is None:
+            # The grouped 1x1 conv as ONE strided-batched GEMM per direction (rocBLAS / hipBLASLt, forward and both gradients
+            # through autograd): MIOpen runs this shape -- a few hundred pixels, up to 64 groups -- on its naive direct kernel
+            # (naive_conv_ab_nonpacked_*: 0.3 ms of the config-5 step, and far worse under bf16 autocast, which is why bf16
+            # training was SLOWER than fp32 in round 2, profiles/round2_train_step_kernels.txt).  Same sums, same order of
+            # operands; hyperseg_v1_0.py:479-484.
+            b, _, fh, fw = sig.shape
+            g = conv.groups
+            wc, k = conv.weight.shape[0], conv.weight.shape[1]
+            w = conv.weight.view(g, wc // g, k)
+            x = sig.reshape(b, g, k, fh * fw)
+            return torch.einsum('grk,bgkp->bgrp', w, x).reshape(b, wc, fh, fw)[:, :hp]
+        return conv(sig)[:, :hp]
 
     def _train_mode(self, x, s):
         probe = [x.skip, x.prev] if isinstance(x, HF.StageInput) else [x]

@@ -1,7 +1,7 @@
 #!/bin/bash
-# One GPU-box visit of round 2: [tests] -> PMC traffic passes of the bench command -> bench.py (default model, with the
+# The full measurement visit (rounds 2-3): [tests] -> PMC traffic passes of the bench command -> bench.py (default model, with the
 # measured traffic) -> bench.py for the other BASELINE configs -> rocprofv3 kernel stats of the bench command.
-#   gpurun --timeout 1500 -- 'bash tools/gpu_round2.sh <tag> [tests|notests] [full|quick]'
+#   gpurun --timeout 1500 -- 'bash tools/gpu_full_visit.sh <tag> [tests|notests] [full|quick]'
 tag=${1:-x}; tests=${2:-tests}; mode=${3:-full}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; mkdir -p gpurun_out
 export TMPDIR=/tmp

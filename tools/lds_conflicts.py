@@ -48,88 +48,81 @@ def report(name, op, addrs, active=None):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# hs_patch_irc.hip layouts (region RH x 16 pixels, halo (RH + 2) x 18, chunk of 16 hidden channels)
+# hs_patch_irc.hip layouts (region RH x 16 pixels, halo (RH + 2) x 18, chunk of 16 hidden channels, 4 waves)
 # ------------------------------------------------------------------------------------------------------------------
-def irc_geometry(rh=8, cs=18):
+def irc_geometry(rh=16):
     hh, hw = rh + 2, 18
-    ps = hh * cs
-    while ps % 8 != 4:
-        ps += 1
-    return dict(rh=rh, hh=hh, hw=hw, cs=cs, ps=ps)
+    npos = hh * hw
+    ps1 = ((npos - 16 + 63) // 64) * 64 + 16             # IrcGeom::PS1: smallest value >= npos that is == 16 (mod 64)
+    skpl = ((npos + 63) // 64) * 64
+    return dict(rh=rh, hh=hh, hw=hw, npos=npos, cs=hw, ps1=ps1, h2_plane=rh * 16, skpl=skpl)
 
 
-def irc_patterns(rh=8, cs=18, h2ps=None, verbose=True):
-    g = irc_geometry(rh, cs)
-    cs, ps, hw = g['cs'], g['ps'], g['hw']
+def h1_slot(c):
+    return 4 * (c & 3) + (c >> 2)
+
+
+def h2_swz(p):
+    return (p & 3) + 4 * (p >> 3)
+
+
+def irc_patterns(rh=16, verbose=True):
+    """(name, op, cycles, ideal) of every LDS access pattern of the chunk loop and of the B-fragment build."""
+    g = irc_geometry(rh)
+    cs, ps1, hw, npos = g['cs'], g['ps1'], g['hw'], g['npos']
     out = []
-    rep = report if verbose else (lambda n, o, a, act=None: cycles(o, a, act))
-    # pw1 D tile -> h1: lane (n = lane & 15, kg = lane >> 4) writes channel 4 kg + r of halo position t * 16 + n
-    for t in (0, 1, 5):
-        for r in (0,):
+
+    def rec(name, op, addrs, active=None):
+        c, ideal = cycles(op, addrs, active)
+        if verbose:
+            print(f'{name:64s} {op:20s} {c:3d} cycles (conflict-free {ideal}) x{c / ideal:.2f}')
+        out.append((name, op, c, ideal))
+    # pw1 D tile -> h1: lane (n, kg) stores channel 4 kg + r (slot 4 r + kg) of halo position 16 t + n; dead lanes -> the plane's pad
+    for t in (0, 1, 7, (npos + 15) // 16 - 1):
+        for r in (0, 3):
             addrs = []
             for lane in range(64):
                 n, kg = lane & 15, lane >> 4
                 pos = t * 16 + n
-                u, v = divmod(pos, hw)
-                addrs.append(4 * ((4 * kg + r) * ps + u * cs + v))
-            out.append(rep(f'h1 store, tile {t} row {r}', 'ds_write_b32', addrs))
-    # depthwise reads: thread (ch = tid / (2 rh), row = (tid / 2) % rh, half = tid & 1) reads halo rows row + ky, columns 8 half .. + 9
-    for wave in (0, 1):
-        for ky in (0, 1):
-            for piece in range(5 if cs % 4 else 3):
-                addrs = []
-                for lane in range(64):
-                    tid = wave * 64 + lane
-                    ch, row, half = tid // (2 * rh), (tid // 2) % rh, tid & 1
-                    base = ch * ps + (row + ky) * cs + 8 * half
-                    addrs.append(4 * (base + (2 if cs % 4 else 4) * piece))
-                out.append(rep(f'h1 dw read wave {wave} ky {ky} piece {piece}', 'ds_read_b64' if cs % 4 else 'ds_read_b128', addrs))
+                off = (pos // hw) * cs + pos % hw if pos < npos else npos
+                addrs.append(4 * ((4 * r + kg) * ps1 + off))
+            rec(f'pw1 -> h1 store, tile {t}, row {r}', 'ds_write_b32', addrs)
+    # depthwise: lane = half | row_lo << 1 | j << 3 | row_hi << 5, channel wave + 4 j (slot 4 wave + j), rows r (+ 8 for the 2nd item)
+    for wave in (0, 3):
+        for it in range(rh // 8):
+            for ky in (0, 1, 2):
+                for q in range(5):
+                    addrs = []
+                    for lane in range(64):
+                        half, row, j = lane & 1, ((lane >> 1) & 3) | ((lane >> 5) << 2), (lane >> 3) & 3
+                        addrs.append(4 * ((4 * wave + j) * ps1 + (row + 8 * it + ky) * cs + 8 * half + 2 * q))
+                    rec(f'dw h1 read, wave {wave} item {it} ky {ky} piece {q}', 'ds_read_b64', addrs)
+    # depthwise -> h2: 8 halfs (16 bytes) at plane c, row slot (row ^ swz(c)), half
+    for wave in (0, 3):
+        for it in range(rh // 8):
+            addrs = []
+            for lane in range(64):
+                half, row, j = lane & 1, ((lane >> 1) & 3) | ((lane >> 5) << 2), (lane >> 3) & 3
+                c = wave + 4 * j
+                addrs.append(2 * (c * g['h2_plane'] + ((row + 8 * it) ^ h2_swz(c)) * 16 + 8 * half))
+            rec(f'dw -> h2 store, wave {wave} item {it}', 'ds_write_b128', addrs)
+    # pw3 transpose reads: lane i of a 16-lane group supplies the 4-pixel run (i & 3) of plane 8 (lk & 1) + 4 rd + (i >> 2), region row t
+    for t in (0, 5, rh - 1):
+        for rd in (0, 1):
+            addrs = []
+            for lane in range(64):
+                lrow, lk = lane & 15, lane >> 4
+                p = 8 * (lk & 1) + 4 * rd + (lrow >> 2)
+                addrs.append(2 * (p * g['h2_plane'] + 4 * (lrow & 3) + (t ^ h2_swz(p)) * 16))
+            rec(f'pw3 h2 transpose read, row {t} rd {rd}', 'ds_read_b64_tr_b16', addrs)
+    # B-fragment build: SK[kg][pos][4] (one 16-byte read per tile), planes SKPL positions apart
+    for t in (0, 3):
+        addrs = [16 * ((lane >> 4) * g['skpl'] + min(t * 16 + (lane & 15), npos - 1)) for lane in range(64)]
+        rec(f'B build: skip vector read, tile {t}', 'ds_read_b128', addrs)
     return out
 
 
 if __name__ == '__main__':
-    for rh, cs in ((8, 18), (8, 20), (16, 18), (16, 20)):
-        print(f'--- region {rh} x 16, h1 column stride {cs}, plane {irc_geometry(rh, cs)["ps"]}')
-        irc_patterns(rh, cs)
-
-
-def search_dw(rh=8):
-    """Brute force: h1 column stride / plane stride / lane-bit assignment that make the depthwise stage's row reads conflict-free."""
-    import itertools
-    rbits = {8: 3, 16: 4}[rh]
-    best = []
-    for cs in (18, 20, 22, 24, 26, 28):
-        op = 'ds_read_b64' if cs % 4 else 'ds_read_b128'
-        step = 2 if cs % 4 else 4
-        npiece = 5 if cs % 4 else 3
-        for ps in range((rh + 2) * cs, (rh + 2) * cs + 40):
-            if ps % 2:
-                continue
-            for perm in itertools.permutations(range(6)):
-                # lane bit perm[0] -> half, perm[1..rbits] -> row bits, rest -> channel bits (of the wave's channels)
-                if rbits == 4 and False:
-                    continue
-                tot = 0
-                ok = True
-                for ky in (0, 1, 2):
-                    for piece in range(npiece):
-                        addrs = []
-                        for lane in range(64):
-                            half = (lane >> perm[0]) & 1
-                            row = sum(((lane >> perm[1 + i]) & 1) << i for i in range(rbits))
-                            ch = sum(((lane >> perm[1 + rbits + i]) & 1) << i for i in range(6 - 1 - rbits))
-                            addrs.append(4 * (ch * ps + (row + ky) * cs + 8 * half + step * piece))
-                        c, ideal = cycles(op, addrs)
-                        tot += c
-                # stores: pw1 D tile
-                best.append((tot, cs, ps, perm, op))
-            if len(best) > 200000:
-                break
-    best.sort(key=lambda x: (x[0], x[1], x[2]))
-    for b in best[:12]:
-        print(b)
-    return best
-
-
-if __name__ == '__main__' and False:
-    search_dw()
+    for rh in (8, 16):
+        print(f'--- region {rh} x 16: h1 plane {irc_geometry(rh)["ps1"]} floats, row 18')
+        irc_patterns(rh)
