@@ -10,18 +10,23 @@ A "step" is one forward of the whole model on one resident synthetic batch per r
 path), captured once in a HIP graph and replayed.  N > 1 is batch-sharded inference, one process per GPU:
   --model m / s / sc   bs 1 per GPU (weak scaling: BASELINE configs 2, 3);
   --model l            the bs-32 batch of BASELINE config 4 sharded 32/N frames per GPU (strong scaling);
-the single collective is the north star's RCCL all_gather_into_tensor of every rank's logits (--collective gather: onto
-rank 0 only, nn.DataParallel's semantics; --gather masks: uint8 argmax masks instead), issued asynchronously on RCCL's
-stream over a ring of three buffers, so it overlaps the next step.  Rank 0 prints ONE JSON line.
+the single collective is the north star's all-gather of every rank's logits over RCCL / xGMI, asynchronous over a ring of three
+buffers whose slots the decoder's last kernel writes directly (zero copy: one HIP graph per slot), so it overlaps the next step:
+  --collective direct (default at N > 1)  grouped RCCL point-to-point sends / receives, all pairs: one shard per link and direction;
+  --collective allgather                  RCCL all_gather_into_tensor (in place);
+  --collective gather                     onto rank 0 only (nn.DataParallel's semantics);  --gather masks: uint8 argmax masks instead.
+Given explicitly at N = 1 the collective runs on a one-rank group and `collective.overhead_pct` reports its own per-step cost.
+Rank 0 writes ONE JSON line to stdout (everything else that writes to fd 1 -- RCCL's banner -- is sent to stderr).
 
 W warm-up steps, then `--repeats` (default 5) timed regions of EXACTLY K steps each, every region bracketed by a barrier
 + torch.cuda.synchronize() on both sides, MAX over ranks per region; `value` uses the MEDIAN region (all are listed).
 
 Extra objects on the line:
-  roofline      the dominant decoder kernel: algorithmic FLOPs or bytes per launch / its average duration measured with
+  roofline      the dominant decoder kernel against the roof that binds it (the f16-split level 4: HBM; `f32_mfma_frac` beside it for
+                comparison with rounds 1-2): algorithmic FLOPs or bytes per launch / its average duration measured with
                 HIP events on the launch stream over instrumented eager passes right after the timed regions (a graph
                 replay cannot host events).  `traffic` is null unless --traffic-dir names rocprofv3 --pmc FETCH_SIZE /
-                WRITE_SIZE passes of THIS command made in the same session (tools/gpu_round2.sh does that).
+                WRITE_SIZE passes of THIS command made in the same session (tools/gpu_full_visit.sh does that).
   parity        the replayed output of the benched configuration vs the eager STOCK-encoder model on the same batch
                 (outside the timed regions): max tensor-relative error, argmax flips where the stock margin > 1e-4.
   exact_f32     the same step (one timed region) with the fused inverted-residual levels on the exact-f32 matrix cores
