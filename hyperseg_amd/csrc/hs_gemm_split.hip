@@ -1,6 +1,5 @@
-// Encoder-side helper (opt-in: prepare_for_inference(split_gemm=True), OFF by default -- the
-// kernel below was measured as a dev probe at the end of round 2, profiles/round2_dev_gemm_split_probe.txt, its wiring into
-// the prepared encoder is new): a 1x1 convolution as a GEMM on the f16 matrix cores with split operands,
+// Encoder-side helper (prepare_for_inference(split_gemm=True): what bench.py runs since round 3,
+// profiles/round3_first_visit.txt): a 1x1 convolution as a GEMM on the f16 matrix cores with split operands,
 //
 //     Y[b][m][n] = act(sum_k W[m][k] * gate[b][k] * X[b][k][n] + shift[m]) + R[b][m][n]       f32 in / out / accumulation
 //     (gate, shift, R optional; R may be Y itself: the in-place skip accumulation of FusedMBConv)
@@ -41,33 +40,68 @@ struct GemmSplitArgs {
     int M, K, KST, N, act;
 };
 
-template <int KS>
-__global__ __launch_bounds__(512)
+// FAST: K % 8 == 0 and N % 2 == 0 (every encoder / context-head layer): paired pixel loads and vector gate loads, decided at
+// LAUNCH time -- a run-time branch around a load makes the compiler wait for it where the branches join.
+// NS: 16-pixel strips per workgroup.  2 = the 32-pixel block above; 1 = HALF of it, for launches whose 32-pixel grid would leave
+// more than half of the 256 CUs idle (the 16x32 and 32x64 maps): these launches are bound by the instructions ONE CU has to
+// issue for its workgroup (the on-the-fly split is ~2/3 of them), so half the pixels on twice the CUs is the shorter launch.
+#ifndef HS_GS_NARROW_MAX_WG
+#define HS_GS_NARROW_MAX_WG 128
+#endif
+
+template <int KS, int NWV, bool FAST, int NS>
+__global__ __launch_bounds__(64 * NWV)
 void gemm_split_kernel(GemmSplitArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float gs_red[];        // [nwv][32 rows][32 pixels]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwv = nthr >> 6;
+    extern __shared__ __attribute__((aligned(16))) float gs_red[];        // [nwv][32 rows][16 NS pixels]
+    constexpr int nthr = 64 * NWV, nwv = NWV;                              // compile-time: the tail's element count and the reduction unroll
+    constexpr int NP = 16 * NS, NE = 32 * NP;                              // pixels and outputs per workgroup
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, kg = lane >> 4;
-    const int n0 = blockIdx.x * 32, r0 = blockIdx.y * 2, b = blockIdx.z;
+    const int n0 = blockIdx.x * NP, r0 = blockIdx.y * 2, b = blockIdx.z;
     const float* __restrict__ xb = a.x + (size_t)b * a.K * a.N;
     const float* __restrict__ gb = a.gate ? a.gate + (size_t)b * a.K : nullptr;
     float* yb = a.y + (size_t)b * a.M * a.N;
     const float* rb = a.residual ? a.residual + (size_t)b * a.M * a.N : nullptr;
     const int rt_max = (a.M + 15) >> 4;
 
-    // ---- every load of this wave: X (two strips) with the gate, A fragments of row tile 0, the tail's operands
-    int ncol[2];
+    // ---- every load of this wave: X (two strips) with the gate, A fragments of row tile 0, the tail's operands.
+    // Strip t of the 32-pixel block = the pixels of parity t: lane lrow owns pixels n0 + 2 lrow and n0 + 2 lrow + 1, so a k-row's two
+    // values are ONE 8-byte load (round 2: two 4-byte gathers), and the lane group's 8 gate values are two 16-byte loads (round 2:
+    // eight): 50 -> 22 vector-memory instructions per wave at KS = 1 (tools/isa_phases.py) -- these launches are bound by the
+    // per-instruction cost of the CU's address path, not by bytes.  N is even and n0 a multiple of 32, so the pair is aligned.
+    using gs_f32x2 = __attribute__((ext_vector_type(2))) float;
+    const int ncol0 = min(n0 + NS * lrow, a.N - 1), ncol1 = min(n0 + NS * lrow + 1, a.N - 1);
+    float xv[NS][KS][8];
+    float gv[KS][8];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) ncol[t] = min(n0 + 16 * t + lrow, a.N - 1);
-    float xv[2][KS][8];
+    for (int s = 0; s < KS; ++s) {
+        const int k0 = (wave * KS + s) * 32 + 8 * kg;
+        if constexpr (FAST) {
+            // a run of 8 gate values either exists entirely or not at all (K % 8 == 0): clamp the address, mask by a multiply
+            const float* gp = gb ? gb + min(k0, a.K - 8) : a.w_inv;       // w_inv: any valid 32 bytes when there is no gate
+            const gs_f32x4 g0 = *reinterpret_cast<const gs_f32x4*>(gp), g1 = *reinterpret_cast<const gs_f32x4*>(gp + 4);
+            const float mk = k0 < a.K ? 1.0f : 0.0f, one = gb ? 0.0f : mk;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { gv[s][j] = gb ? g0[j] * mk : one; gv[s][4 + j] = gb ? g1[j] * mk : one; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gv[s][j] = (gb ? gb[min(k0 + j, a.K - 1)] : 1.0f) * (k0 + j < a.K ? 1.0f : 0.0f);
+        }
+    }
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = (wave * KS + s) * 32 + 8 * kg + j;
             const int kc = min(k, a.K - 1);
-            const float g = (gb ? gb[kc] : 1.0f) * (k < a.K ? 1.0f : 0.0f);      // clamped address, masked by a multiply
-#pragma unroll
-            for (int t = 0; t < 2; ++t) xv[t][s][j] = xb[(size_t)kc * a.N + ncol[t]] * g;
+            if constexpr (NS == 1) {
+                xv[0][s][j] = xb[(size_t)kc * a.N + ncol0];
+            } else if constexpr (FAST) {
+                const gs_f32x2 v = *reinterpret_cast<const gs_f32x2*>(xb + (size_t)kc * a.N + ncol0);
+                xv[0][s][j] = v[0]; xv[1][s][j] = v[1];
+            } else {
+                xv[0][s][j] = xb[(size_t)kc * a.N + ncol0]; xv[1][s][j] = xb[(size_t)kc * a.N + ncol1];
+            }
         }
     half8 ah[2][KS], al[2][KS];
     auto load_a = [&](int mt) {
@@ -80,42 +114,64 @@ void gemm_split_kernel(GemmSplitArgs a) {
         }
     };
     load_a(0);                                                          // tile 1 follows once the f32 strips are split (registers)
-    constexpr int TE = KS == 1 ? 8 : 2;                                 // tail elements per thread, 1024 / nthr: more than one
-                                                                        // k-step per wave only occurs with 8 waves (gemm_split_plan)
+    constexpr int TE = (NE + nthr - 1) / nthr;                          // tail elements per thread
     float wi[TE], sh[TE], yo[TE];
 #pragma unroll
     for (int i = 0; i < TE; ++i) {
-        const int e = tid + i * nthr;
-        const int row = min(16 * r0 + (e >> 5), a.M - 1), col = min(n0 + (e & 31), a.N - 1);
-        wi[i] = a.w_inv[min(16 * r0 + (e >> 5), 16 * rt_max - 1)];
+        const int e = min(tid + i * nthr, NE - 1);
+        const int row = min(16 * r0 + e / NP, a.M - 1), col = min(n0 + (e & (NP - 1)), a.N - 1);
+        wi[i] = a.w_inv[min(16 * r0 + e / NP, 16 * rt_max - 1)];
         sh[i] = a.shift ? a.shift[row] : 0.0f;
         yo[i] = rb ? rb[(size_t)row * a.N + col] : 0.0f;
     }
 
-    // ---- per-pixel scale and split of the two strips
-    float invb[2];
-    half8 bh[2][KS], bl[2][KS];
+    // ---- per-pixel scale and split of the two strips (2 vector instructions per element: v_fma_mix* converts on the way out)
+    float invb[NS];
+    half8 bh[NS][KS], bl[NS][KS];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        float mx = 0.0f;
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(xv[t][s][j]));
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                         // the pixel's maximum over this wave's K slice
-        const int eb = gs_exp_of(mx);
-        const float sc = gs_scale_of(eb);
-        invb[t] = gs_inv_scale_of(eb);
+    for (int t = 0; t < NS; ++t) {
+        unsigned mx = 0;
 #pragma unroll
         for (int s = 0; s < KS; ++s)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float v = xv[t][s][j] * sc;
-                const _Float16 hi = (_Float16)v;
-                bh[t][s][j] = hi;
-                bl[t][s][j] = (_Float16)(v - (float)hi);
+                xv[t][s][j] *= gv[s][j];
+                mx = max(mx, __float_as_uint(xv[t][s][j]) & 0x7fffffffu);
             }
+        {   // the pixel's maximum over this wave's K slice: lanes lrow, lrow + 16, + 32, + 48 (no LDS round trip)
+            auto r16 = __builtin_amdgcn_permlane16_swap(mx, mx, false, false);
+            mx = max(r16[0], r16[1]);
+            auto r32 = __builtin_amdgcn_permlane32_swap(mx, mx, false, false);
+            mx = max(r32[0], r32[1]);
+        }
+        const int eb = gs_exp_of(__uint_as_float(mx));
+        const float sc = gs_scale_of(eb);
+        invb[t] = gs_inv_scale_of(eb);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if constexpr (FAST) {
+                unsigned hh[4], ll[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+                        "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+                        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+                        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                        : "=&v"(hh[j]), "=&v"(ll[j]) : "v"(xv[t][s][2 * j]), "v"(xv[t][s][2 * j + 1]), "v"(sc));
+                }
+                using gs_u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+                bh[t][s] = __builtin_bit_cast(half8, gs_u32x4{hh[0], hh[1], hh[2], hh[3]});
+                bl[t][s] = __builtin_bit_cast(half8, gs_u32x4{ll[0], ll[1], ll[2], ll[3]});
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = xv[t][s][j] * sc;
+                    const _Float16 hi = (_Float16)v;
+                    bh[t][s][j] = hi;
+                    bl[t][s][j] = (_Float16)(v - (float)hi);
+                }
+            }
+        }
     }
     load_a(1);
     __builtin_amdgcn_sched_barrier(0);                                  // tile 1's fragments go out before tile 0's first MFMA
@@ -123,7 +179,7 @@ void gemm_split_kernel(GemmSplitArgs a) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < NS; ++t) {
             gs_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
@@ -133,16 +189,17 @@ void gemm_split_kernel(GemmSplitArgs a) {
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                gs_red[(wave * 32 + 16 * mt + 4 * kg + r) * 32 + 16 * t + lrow] = acc[r] * invb[t];
+                gs_red[(wave * 32 + 16 * mt + 4 * kg + r) * NP + NS * lrow + t] = acc[r] * invb[t];     // pixel n0 + NS lrow + t
         }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < TE; ++i) {
         const int e = tid + i * nthr;
-        if (e < 1024) {
-            const int row = 16 * r0 + (e >> 5), col = n0 + (e & 31);
+        if (e < NE) {
+            const int row = 16 * r0 + e / NP, col = n0 + (e & (NP - 1));
             float t = 0.0f;
-            for (int w = 0; w < nwv; ++w) t += gs_red[w * 1024 + e];
+#pragma unroll
+            for (int w = 0; w < nwv; ++w) t += gs_red[w * NE + e];
             if (row < a.M && col < a.N) {
                 float v = fmaf(t, wi[i], sh[i]);
                 v = a.act == 3 ? swishf(v) : apply_act(v, a.act);
@@ -182,16 +239,24 @@ extern "C" int hs_gemm_split_fwd(const void* w_frag, const float* w_inv, const f
     if (batch > 65535 || (c_out + 31) / 32 > 65535) return HS_ERR_UNSUPPORTED;
     GemmSplitArgs a{(const _Float16*)w_frag, w_inv, gate, x, shift, residual, y, c_out, c_in, kp / 32, pixels, act};
     dim3 grid((pixels + 31) / 32, ((c_out + 15) / 16 + 1) / 2, batch);
-    const size_t lds = (size_t)nwv * 1024 * sizeof(float);
+    const bool narrow = (size_t)grid.x * grid.y * grid.z <= HS_GS_NARROW_MAX_WG && pixels > 16;
+    if (narrow) grid.x = (pixels + 15) / 16;
+    const size_t lds = (size_t)nwv * (narrow ? 512 : 1024) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
-#define HS_GS(KSV) hipLaunchKernelGGL((gemm_split_kernel<KSV>), grid, dim3(64 * nwv), lds, s, a)
+    // the vector-load / 2-instruction-split form for every K depth: whole frame 0.814 ms against 0.832 (k-steps <= 2 only) and 0.858
+    // (never), same box, interleaved (profiles/round3_gemm_split_latency.txt)
+    const bool fast = (c_in & 7) == 0 && (pixels & 1) == 0 && c_in >= 8;
+#define HS_GS_(KSV, NWV, F) do { if (narrow) hipLaunchKernelGGL((gemm_split_kernel<KSV, NWV, F, 1>), grid, dim3(64 * NWV), lds, s, a); \
+                                 else hipLaunchKernelGGL((gemm_split_kernel<KSV, NWV, F, 2>), grid, dim3(64 * NWV), lds, s, a); } while (0)
+#define HS_GS(KSV, NWV) do { if (fast) HS_GS_(KSV, NWV, true); else HS_GS_(KSV, NWV, false); } while (0)
     switch (ks) {
-        case 1: HS_GS(1); break;
-        case 2: HS_GS(2); break;
-        case 3: HS_GS(3); break;
-        case 4: HS_GS(4); break;
-        default: HS_GS(5); break;
+        case 1: if (nwv == 2) HS_GS(1, 2); else if (nwv == 4) HS_GS(1, 4); else HS_GS(1, 8); break;
+        case 2: HS_GS(2, 8); break;
+        case 3: HS_GS(3, 8); break;
+        case 4: HS_GS(4, 8); break;
+        default: HS_GS(5, 8); break;
     }
 #undef HS_GS
+#undef HS_GS_
     return launch_status();
 }

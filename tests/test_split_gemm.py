@@ -76,7 +76,8 @@ def test_split_arithmetic_emulated(m, k):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('m,k,hw,batch', [(40, 240, (64, 128), 1), (80, 480, (32, 64), 2), (112, 672, (32, 64), 1), (192, 1152, (16, 32), 1),
-                                          (320, 1152, (16, 32), 2), (480, 80, (32, 64), 1), (19, 33, (5, 7), 1), (1280, 320, (16, 32), 1)])
+                                          (320, 1152, (16, 32), 2), (480, 80, (32, 64), 1), (19, 33, (5, 7), 1), (1280, 320, (16, 32), 1),
+                                          (40, 36, (33, 129), 1)])      # odd pixel count on a wide grid: the scalar-load form, 32-pixel blocks
 def test_gemm_split_vs_float64(m, k, hw, batch):
     from hyperseg_amd import functional as HF
     dev = torch.device('cuda:0')

@@ -110,6 +110,10 @@ VARIANTS = {
     'kpreload': dict(flags=['-mllvm', '-amdgpu-kernarg-preload-count=16'], extra=[], patch=None),
     's2b_kc20': dict(flags=['-DHS_S2B_KC=20'], extra=[], patch=None),          # blocked signal2weights: one LDS fill for K = 80 (40 KB)
     's2b_kc5': dict(flags=['-DHS_S2B_KC=5'], extra=[], patch=None),
+    # split GEMM: 16-pixel workgroups when the 32-pixel grid has at most this many workgroups (product: 128)
+    'gs_narrow_0': dict(flags=['-DHS_GS_NARROW_MAX_WG=0'], extra=[], patch=None),
+    'gs_narrow_192': dict(flags=['-DHS_GS_NARROW_MAX_WG=192'], extra=[], patch=None),
+    'gs_narrow_384': dict(flags=['-DHS_GS_NARROW_MAX_WG=384'], extra=[], patch=None),
     's2b_light_first': dict(flags=['-DHS_S2B_LIGHT_FIRST'], extra=[], patch=None),
 }
 

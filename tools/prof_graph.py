@@ -11,7 +11,7 @@ variant = sys.argv[2] if len(sys.argv) > 2 else 'plain'
 torch.set_grad_enabled(False)
 dev = torch.device('cuda:0')
 m = fill_by_name(configs.build('hyperseg-m').eval(), seed=0)
-prepare_for_inference(m, fold_bn='fold' in variant, fused_depthwise='dw' in variant)
+prepare_for_inference(m, fold_bn='fold' in variant, fused_depthwise='dw' in variant, split_gemm='dw' in variant)
 m = m.to(dev)
 x = torch.rand(1, 3, 512, 1024, device=dev)
 s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
