@@ -49,15 +49,22 @@ struct GemmSplitArgs {
 #define HS_GS_NARROW_MAX_WG 128
 #endif
 
-template <int KS, int NWV, bool FAST, int NS>
+// MT: 16-row tiles per workgroup.  2 = the 32-row block above; 4 where that grid would need more than one round of workgroups
+// (M = 640 ... 1920 on the 16x32 map): the split of X is per workgroup, so twice the rows on half the workgroups halves it.
+// A fragments roll through two register slots (tile mt + 2 is requested when tile mt's products have been issued).
+#ifndef HS_GS_TALL_MIN_WG
+#define HS_GS_TALL_MIN_WG 257
+#endif
+
+template <int KS, int NWV, bool FAST, int NS, int MT>
 __global__ __launch_bounds__(64 * NWV)
 void gemm_split_kernel(GemmSplitArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float gs_red[];        // [nwv][32 rows][16 NS pixels]
+    extern __shared__ __attribute__((aligned(16))) float gs_red[];        // [nwv][16 MT rows][16 NS pixels]
     constexpr int nthr = 64 * NWV, nwv = NWV;                              // compile-time: the tail's element count and the reduction unroll
-    constexpr int NP = 16 * NS, NE = 32 * NP;                              // pixels and outputs per workgroup
+    constexpr int NP = 16 * NS, NR = 16 * MT, NE = NR * NP;                // pixels, rows and outputs per workgroup
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, kg = lane >> 4;
-    const int n0 = blockIdx.x * NP, r0 = blockIdx.y * 2, b = blockIdx.z;
+    const int n0 = blockIdx.x * NP, r0 = blockIdx.y * MT, b = blockIdx.z;
     const float* __restrict__ xb = a.x + (size_t)b * a.K * a.N;
     const float* __restrict__ gb = a.gate ? a.gate + (size_t)b * a.K : nullptr;
     float* yb = a.y + (size_t)b * a.M * a.N;
@@ -72,22 +79,6 @@ void gemm_split_kernel(GemmSplitArgs a) {
     using gs_f32x2 = __attribute__((ext_vector_type(2))) float;
     const int ncol0 = min(n0 + NS * lrow, a.N - 1), ncol1 = min(n0 + NS * lrow + 1, a.N - 1);
     float xv[NS][KS][8];
-    float gv[KS][8];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const int k0 = (wave * KS + s) * 32 + 8 * kg;
-        if constexpr (FAST) {
-            // a run of 8 gate values either exists entirely or not at all (K % 8 == 0): clamp the address, mask by a multiply
-            const float* gp = gb ? gb + min(k0, a.K - 8) : a.w_inv;       // w_inv: any valid 32 bytes when there is no gate
-            const gs_f32x4 g0 = *reinterpret_cast<const gs_f32x4*>(gp), g1 = *reinterpret_cast<const gs_f32x4*>(gp + 4);
-            const float mk = k0 < a.K ? 1.0f : 0.0f, one = gb ? 0.0f : mk;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { gv[s][j] = gb ? g0[j] * mk : one; gv[s][4 + j] = gb ? g1[j] * mk : one; }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) gv[s][j] = (gb ? gb[min(k0 + j, a.K - 1)] : 1.0f) * (k0 + j < a.K ? 1.0f : 0.0f);
-        }
-    }
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
@@ -103,28 +94,57 @@ void gemm_split_kernel(GemmSplitArgs a) {
                 xv[0][s][j] = xb[(size_t)kc * a.N + ncol0]; xv[1][s][j] = xb[(size_t)kc * a.N + ncol1];
             }
         }
+    float gv[KS][8];                                                    // raw here; masked after the last load has been issued
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int k0 = (wave * KS + s) * 32 + 8 * kg;
+        if constexpr (FAST) {
+            // a run of 8 gate values either exists entirely or not at all (K % 8 == 0): clamp the address, mask by a multiply
+            const float* gp = gb ? gb + min(k0, a.K - 8) : a.w_inv;       // w_inv: any valid 32 bytes when there is no gate
+            const gs_f32x4 g0 = *reinterpret_cast<const gs_f32x4*>(gp), g1 = *reinterpret_cast<const gs_f32x4*>(gp + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { gv[s][j] = g0[j]; gv[s][4 + j] = g1[j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gv[s][j] = gb ? gb[min(k0 + j, a.K - 1)] : 1.0f;
+        }
+    }
     half8 ah[2][KS], al[2][KS];
-    auto load_a = [&](int mt) {
+    auto load_a = [&](int mt) {                                         // into slot mt & 1
         const int rt = min(r0 + mt, rt_max - 1);                        // clamped: a valid block; its results are not stored
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const _Float16* blk = a.wf + ((size_t)(rt * a.KST + wave * KS + s) * 2) * 512 + lane * 8;
-            ah[mt][s] = *reinterpret_cast<const half8*>(blk);
-            al[mt][s] = *reinterpret_cast<const half8*>(blk + 512);
+            ah[mt & 1][s] = *reinterpret_cast<const half8*>(blk);
+            al[mt & 1][s] = *reinterpret_cast<const half8*>(blk + 512);
         }
     };
     load_a(0);                                                          // tile 1 follows once the f32 strips are split (registers)
     constexpr int TE = (NE + nthr - 1) / nthr;                          // tail elements per thread
     float wi[TE], sh[TE], yo[TE];
+    auto load_tail = [&]() {
 #pragma unroll
-    for (int i = 0; i < TE; ++i) {
-        const int e = min(tid + i * nthr, NE - 1);
-        const int row = min(16 * r0 + e / NP, a.M - 1), col = min(n0 + (e & (NP - 1)), a.N - 1);
-        wi[i] = a.w_inv[min(16 * r0 + e / NP, 16 * rt_max - 1)];
-        sh[i] = a.shift ? a.shift[row] : 0.0f;
-        yo[i] = rb ? rb[(size_t)row * a.N + col] : 0.0f;
-    }
+        for (int i = 0; i < TE; ++i) {
+            const int e = min(tid + i * nthr, NE - 1);
+            const int row = min(16 * r0 + e / NP, a.M - 1), col = min(n0 + (e & (NP - 1)), a.N - 1);
+            wi[i] = a.w_inv[min(16 * r0 + e / NP, 16 * rt_max - 1)];
+            sh[i] = a.shift ? a.shift[row] : 0.0f;
+            yo[i] = rb ? rb[(size_t)row * a.N + col] : 0.0f;
+        }
+    };
+    constexpr bool LATE_TAIL = KS >= 3;                                 // deep K: the f32 strips fill the registers until they are split
+    if constexpr (!LATE_TAIL) load_tail();
 
+    __builtin_amdgcn_sched_barrier(0);                                  // every request above is out before the first wait
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int k0 = (wave * KS + s) * 32 + 8 * kg;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float mk = (FAST ? k0 : k0 + j) < a.K ? 1.0f : 0.0f;
+            gv[s][j] = gb ? gv[s][j] * mk : mk;
+        }
+    }
     // ---- per-pixel scale and split of the two strips (2 vector instructions per element: v_fma_mix* converts on the way out)
     float invb[NS];
     half8 bh[NS][KS], bl[NS][KS];
@@ -174,23 +194,29 @@ void gemm_split_kernel(GemmSplitArgs a) {
         }
     }
     load_a(1);
+    if constexpr (LATE_TAIL) load_tail();
     __builtin_amdgcn_sched_barrier(0);                                  // tile 1's fragments go out before tile 0's first MFMA
     // ---- products; D element r of this lane = row 4 kg + r of the tile, column lrow of the strip
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt) {
+        gs_f32x4 acc[NS];
 #pragma unroll
         for (int t = 0; t < NS; ++t) {
-            gs_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc[t] = gs_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt][s], bh[t][s], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt][s], bl[t][s], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt][s], bh[t][s], acc, 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt & 1][s], bh[t][s], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt & 1][s], bl[t][s], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt & 1][s], bh[t][s], acc[t], 0, 0, 0);
             }
+        }
+        if (mt + 2 < MT) { load_a(mt + 2); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+        for (int t = 0; t < NS; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                gs_red[(wave * 32 + 16 * mt + 4 * kg + r) * NP + NS * lrow + t] = acc[r] * invb[t];     // pixel n0 + NS lrow + t
-        }
+                gs_red[(wave * NR + 16 * mt + 4 * kg + r) * NP + NS * lrow + t] = acc[t][r] * invb[t];  // pixel n0 + NS lrow + t
+    }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < TE; ++i) {
@@ -239,15 +265,19 @@ extern "C" int hs_gemm_split_fwd(const void* w_frag, const float* w_inv, const f
     if (batch > 65535 || (c_out + 31) / 32 > 65535) return HS_ERR_UNSUPPORTED;
     GemmSplitArgs a{(const _Float16*)w_frag, w_inv, gate, x, shift, residual, y, c_out, c_in, kp / 32, pixels, act};
     dim3 grid((pixels + 31) / 32, ((c_out + 15) / 16 + 1) / 2, batch);
-    const bool narrow = (size_t)grid.x * grid.y * grid.z <= HS_GS_NARROW_MAX_WG && pixels > 16;
+    const size_t wgs = (size_t)grid.x * grid.y * grid.z;
+    const bool narrow = wgs <= HS_GS_NARROW_MAX_WG && pixels > 16;
+    const bool tall = wgs >= HS_GS_TALL_MIN_WG && c_out > 32;
     if (narrow) grid.x = (pixels + 15) / 16;
-    const size_t lds = (size_t)nwv * (narrow ? 512 : 1024) * sizeof(float);
+    if (tall) grid.y = ((c_out + 15) / 16 + 3) / 4;
+    const size_t lds = (size_t)nwv * (narrow ? 512 : tall ? 2048 : 1024) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     // the vector-load / 2-instruction-split form for every K depth: whole frame 0.814 ms against 0.832 (k-steps <= 2 only) and 0.858
     // (never), same box, interleaved (profiles/round3_gemm_split_latency.txt)
     const bool fast = (c_in & 7) == 0 && (pixels & 1) == 0 && c_in >= 8;
-#define HS_GS_(KSV, NWV, F) do { if (narrow) hipLaunchKernelGGL((gemm_split_kernel<KSV, NWV, F, 1>), grid, dim3(64 * NWV), lds, s, a); \
-                                 else hipLaunchKernelGGL((gemm_split_kernel<KSV, NWV, F, 2>), grid, dim3(64 * NWV), lds, s, a); } while (0)
+#define HS_GS_(KSV, NWV, F) do { if (narrow) hipLaunchKernelGGL((gemm_split_kernel<KSV, NWV, F, 1, 2>), grid, dim3(64 * NWV), lds, s, a); \
+                                 else if (tall) hipLaunchKernelGGL((gemm_split_kernel<KSV, NWV, F, 2, 4>), grid, dim3(64 * NWV), lds, s, a); \
+                                 else hipLaunchKernelGGL((gemm_split_kernel<KSV, NWV, F, 2, 2>), grid, dim3(64 * NWV), lds, s, a); } while (0)
 #define HS_GS(KSV, NWV) do { if (fast) HS_GS_(KSV, NWV, true); else HS_GS_(KSV, NWV, false); } while (0)
     switch (ks) {
         case 1: if (nwv == 2) HS_GS(1, 2); else if (nwv == 4) HS_GS(1, 4); else HS_GS(1, 8); break;

@@ -114,6 +114,10 @@ VARIANTS = {
     'gs_narrow_0': dict(flags=['-DHS_GS_NARROW_MAX_WG=0'], extra=[], patch=None),
     'gs_narrow_192': dict(flags=['-DHS_GS_NARROW_MAX_WG=192'], extra=[], patch=None),
     'gs_narrow_384': dict(flags=['-DHS_GS_NARROW_MAX_WG=384'], extra=[], patch=None),
+    # split GEMM: 64-row workgroups when the 32-row grid has at least this many workgroups (product: 257)
+    'gs_tall_never': dict(flags=['-DHS_GS_TALL_MIN_WG=100000000'], extra=[], patch=None),
+    'gs_tall_129': dict(flags=['-DHS_GS_TALL_MIN_WG=129'], extra=[], patch=None),
+    'gs_tall_513': dict(flags=['-DHS_GS_TALL_MIN_WG=513'], extra=[], patch=None),
     's2b_light_first': dict(flags=['-DHS_S2B_LIGHT_FIRST'], extra=[], patch=None),
 }
 
