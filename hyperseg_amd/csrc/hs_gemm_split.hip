@@ -38,6 +38,7 @@ struct GemmSplitArgs {
     const float* residual;                 // (B, M, N) or null; may alias y
     float* y;
     int M, K, KST, N, act;
+    int conv_wo;                           // PATCH form: output width (the input map is 2 Ho x 2 Wo), else 0
 };
 
 // FAST: K % 8 == 0 and N % 2 == 0 (every encoder / context-head layer): paired pixel loads and vector gate loads, decided at
@@ -51,12 +52,17 @@ struct GemmSplitArgs {
 
 // MT: 16-row tiles per workgroup.  2 = the 32-row block above; 4 where that grid would need more than one round of workgroups
 // (M = 640 ... 1920 on the 16x32 map): the split of X is per workgroup, so twice the rows on half the workgroups halves it.
-// A fragments roll through two register slots (tile mt + 2 is requested when tile mt's products have been issued).
+// A fragments roll through two register slots (the tile after next is requested when a tile's products have been issued).
 #ifndef HS_GS_TALL_MIN_WG
 #define HS_GS_TALL_MIN_WG 257
 #endif
 
-template <int KS, int NWV, bool FAST, int NS, int MT>
+// NCH: chunks of KS k-steps per wave (K <= 1280 NCH).  Every X request of every chunk is issued up front; a chunk is scaled by
+// its OWN per-pixel power of two, split, multiplied, and its accumulators join the running sum with that scale undone.
+// PATCH: X is read through a 2x2 / stride-2 window -- the GEMM of a Conv2d(C, M, kernel 2, stride 2) on a (C, 2 Ho, 2 Wo) map,
+// k = 4 c + 2 dy + dx (the conv weight's own flatten order), pixel n = oy Wo + ox: the two dx of a (c, dy) are ONE 8-byte load
+// (16 bytes for a lane's two pixels), so the im2col copy of the library path is never written.  No gate in this form.
+template <int KS, int NWV, bool FAST, int NS, int MT, int NCH, bool PATCH>
 __global__ __launch_bounds__(64 * NWV)
 void gemm_split_kernel(GemmSplitArgs a) {
     extern __shared__ __attribute__((aligned(16))) float gs_red[];        // [nwv][16 MT rows][16 NS pixels]
@@ -65,7 +71,7 @@ void gemm_split_kernel(GemmSplitArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, kg = lane >> 4;
     const int n0 = blockIdx.x * NP, r0 = blockIdx.y * MT, b = blockIdx.z;
-    const float* __restrict__ xb = a.x + (size_t)b * a.K * a.N;
+    const float* __restrict__ xb = a.x + (size_t)b * a.K * a.N;           // PATCH: K N = 4 C Ho Wo = the input map's size
     const float* __restrict__ gb = a.gate ? a.gate + (size_t)b * a.K : nullptr;
     float* yb = a.y + (size_t)b * a.M * a.N;
     const float* rb = a.residual ? a.residual + (size_t)b * a.M * a.N : nullptr;
@@ -78,45 +84,75 @@ void gemm_split_kernel(GemmSplitArgs a) {
     // per-instruction cost of the CU's address path, not by bytes.  N is even and n0 a multiple of 32, so the pair is aligned.
     using gs_f32x2 = __attribute__((ext_vector_type(2))) float;
     const int ncol0 = min(n0 + NS * lrow, a.N - 1), ncol1 = min(n0 + NS * lrow + 1, a.N - 1);
-    float xv[NS][KS][8];
+    float xv[NCH][NS][KS][8];
+    if constexpr (PATCH) {
+        const int oy = ncol0 / a.conv_wo, ox = ncol0 - oy * a.conv_wo;     // NS = 2: Wo even, so ncol1 is the next pixel of the row
+        const float* __restrict__ win = xb + (size_t)(2 * oy) * (2 * a.conv_wo) + 2 * ox;
+        const int cmax = (a.K >> 2) - 1;
 #pragma unroll
-    for (int s = 0; s < KS; ++s)
+        for (int c = 0; c < NCH; ++c)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = (wave * KS + s) * 32 + 8 * kg + j;
-            const int kc = min(k, a.K - 1);
-            if constexpr (NS == 1) {
-                xv[0][s][j] = xb[(size_t)kc * a.N + ncol0];
-            } else if constexpr (FAST) {
-                const gs_f32x2 v = *reinterpret_cast<const gs_f32x2*>(xb + (size_t)kc * a.N + ncol0);
-                xv[0][s][j] = v[0]; xv[1][s][j] = v[1];
-            } else {
-                xv[0][s][j] = xb[(size_t)kc * a.N + ncol0]; xv[1][s][j] = xb[(size_t)kc * a.N + ncol1];
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {                              // (channel, dy) = (ch0 + (q >> 1), q & 1)
+                    const int ch = min((((wave * NCH + c) * KS + s) * 32 + 8 * kg) / 4 + (q >> 1), cmax);
+                    const float* src = win + (size_t)ch * (4 * a.N) + (q & 1) * (2 * a.conv_wo);
+                    if constexpr (NS == 1) {
+                        const gs_f32x2 v = *reinterpret_cast<const gs_f32x2*>(src);
+                        xv[c][0][s][2 * q] = v[0]; xv[c][0][s][2 * q + 1] = v[1];
+                    } else {
+                        const gs_f32x4 v = *reinterpret_cast<const gs_f32x4*>(src);
+                        xv[c][0][s][2 * q] = v[0]; xv[c][0][s][2 * q + 1] = v[1];
+                        xv[c][1][s][2 * q] = v[2]; xv[c][1][s][2 * q + 1] = v[3];
+                    }
+                }
+    } else {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = ((wave * NCH + c) * KS + s) * 32 + 8 * kg + j;
+                    const int kc = min(k, a.K - 1);
+                    if constexpr (NS == 1) {
+                        xv[c][0][s][j] = xb[(size_t)kc * a.N + ncol0];
+                    } else if constexpr (FAST) {
+                        const gs_f32x2 v = *reinterpret_cast<const gs_f32x2*>(xb + (size_t)kc * a.N + ncol0);
+                        xv[c][0][s][j] = v[0]; xv[c][1][s][j] = v[1];
+                    } else {
+                        xv[c][0][s][j] = xb[(size_t)kc * a.N + ncol0]; xv[c][1][s][j] = xb[(size_t)kc * a.N + ncol1];
+                    }
+                }
+    }
+    constexpr int NG = PATCH ? 1 : NCH;
+    float gv[NG][KS][8];                                                // raw here; masked after the last load has been issued
+    if constexpr (!PATCH) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int k0 = ((wave * NCH + c) * KS + s) * 32 + 8 * kg;
+                if constexpr (FAST) {
+                    // a run of 8 gate values either exists entirely or not at all (K % 8 == 0): clamp the address, mask by a multiply
+                    const float* gp = gb ? gb + min(k0, a.K - 8) : a.w_inv;   // w_inv: any valid 32 bytes when there is no gate
+                    const gs_f32x4 g0 = *reinterpret_cast<const gs_f32x4*>(gp), g1 = *reinterpret_cast<const gs_f32x4*>(gp + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { gv[c][s][j] = g0[j]; gv[c][s][4 + j] = g1[j]; }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) gv[c][s][j] = gb ? gb[min(k0 + j, a.K - 1)] : 1.0f;
+                }
             }
-        }
-    float gv[KS][8];                                                    // raw here; masked after the last load has been issued
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const int k0 = (wave * KS + s) * 32 + 8 * kg;
-        if constexpr (FAST) {
-            // a run of 8 gate values either exists entirely or not at all (K % 8 == 0): clamp the address, mask by a multiply
-            const float* gp = gb ? gb + min(k0, a.K - 8) : a.w_inv;       // w_inv: any valid 32 bytes when there is no gate
-            const gs_f32x4 g0 = *reinterpret_cast<const gs_f32x4*>(gp), g1 = *reinterpret_cast<const gs_f32x4*>(gp + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { gv[s][j] = g0[j]; gv[s][4 + j] = g1[j]; }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) gv[s][j] = gb ? gb[min(k0 + j, a.K - 1)] : 1.0f;
-        }
     }
     half8 ah[2][KS], al[2][KS];
-    auto load_a = [&](int mt) {                                         // into slot mt & 1
-        const int rt = min(r0 + mt, rt_max - 1);                        // clamped: a valid block; its results are not stored
+    auto load_a = [&](int q) {                                          // q = chunk * MT + row tile, into slot q & 1
+        const int rt = min(r0 + q % MT, rt_max - 1);                    // clamped: a valid block; its results are not stored
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const _Float16* blk = a.wf + ((size_t)(rt * a.KST + wave * KS + s) * 2) * 512 + lane * 8;
-            ah[mt & 1][s] = *reinterpret_cast<const half8*>(blk);
-            al[mt & 1][s] = *reinterpret_cast<const half8*>(blk + 512);
+            const _Float16* blk = a.wf + ((size_t)(rt * a.KST + (wave * NCH + q / MT) * KS + s) * 2) * 512 + lane * 8;
+            ah[q & 1][s] = *reinterpret_cast<const half8*>(blk);
+            al[q & 1][s] = *reinterpret_cast<const half8*>(blk + 512);
         }
     };
     load_a(0);                                                          // tile 1 follows once the f32 strips are split (registers)
@@ -132,90 +168,97 @@ void gemm_split_kernel(GemmSplitArgs a) {
             yo[i] = rb ? rb[(size_t)row * a.N + col] : 0.0f;
         }
     };
-    constexpr bool LATE_TAIL = KS >= 3;                                 // deep K: the f32 strips fill the registers until they are split
+    constexpr bool LATE_TAIL = KS * NCH >= 3;                           // deep K: the f32 strips fill the registers until they are split
     if constexpr (!LATE_TAIL) load_tail();
-
     __builtin_amdgcn_sched_barrier(0);                                  // every request above is out before the first wait
+
+    gs_f32x4 tot[MT][NS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const int k0 = (wave * KS + s) * 32 + 8 * kg;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float mk = (FAST ? k0 : k0 + j) < a.K ? 1.0f : 0.0f;
-            gv[s][j] = gb ? gv[s][j] * mk : mk;
-        }
-    }
-    // ---- per-pixel scale and split of the two strips (2 vector instructions per element: v_fma_mix* converts on the way out)
-    float invb[NS];
-    half8 bh[NS][KS], bl[NS][KS];
-#pragma unroll
-    for (int t = 0; t < NS; ++t) {
-        unsigned mx = 0;
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                xv[t][s][j] *= gv[s][j];
-                mx = max(mx, __float_as_uint(xv[t][s][j]) & 0x7fffffffu);
-            }
-        {   // the pixel's maximum over this wave's K slice: lanes lrow, lrow + 16, + 32, + 48 (no LDS round trip)
-            auto r16 = __builtin_amdgcn_permlane16_swap(mx, mx, false, false);
-            mx = max(r16[0], r16[1]);
-            auto r32 = __builtin_amdgcn_permlane32_swap(mx, mx, false, false);
-            mx = max(r32[0], r32[1]);
-        }
-        const int eb = gs_exp_of(__uint_as_float(mx));
-        const float sc = gs_scale_of(eb);
-        invb[t] = gs_inv_scale_of(eb);
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            if constexpr (FAST) {
-                unsigned hh[4], ll[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
-                        "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
-                        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
-                        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-                        : "=&v"(hh[j]), "=&v"(ll[j]) : "v"(xv[t][s][2 * j]), "v"(xv[t][s][2 * j + 1]), "v"(sc));
-                }
-                using gs_u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-                bh[t][s] = __builtin_bit_cast(half8, gs_u32x4{hh[0], hh[1], hh[2], hh[3]});
-                bl[t][s] = __builtin_bit_cast(half8, gs_u32x4{ll[0], ll[1], ll[2], ll[3]});
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float v = xv[t][s][j] * sc;
-                    const _Float16 hi = (_Float16)v;
-                    bh[t][s][j] = hi;
-                    bl[t][s][j] = (_Float16)(v - (float)hi);
-                }
-            }
-        }
-    }
-    load_a(1);
-    if constexpr (LATE_TAIL) load_tail();
-    __builtin_amdgcn_sched_barrier(0);                                  // tile 1's fragments go out before tile 0's first MFMA
-    // ---- products; D element r of this lane = row 4 kg + r of the tile, column lrow of the strip
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        gs_f32x4 acc[NS];
+    for (int c = 0; c < NCH; ++c) {
+        // ---- per-pixel scale and split of this chunk's strips (2 vector instructions per element: v_fma_mix* converts on the way out)
+        float invb[NS];
+        half8 bh[NS][KS], bl[NS][KS];
 #pragma unroll
         for (int t = 0; t < NS; ++t) {
-            acc[t] = gs_f32x4{0.f, 0.f, 0.f, 0.f};
+            unsigned mx = 0;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt & 1][s], bh[t][s], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt & 1][s], bl[t][s], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt & 1][s], bh[t][s], acc[t], 0, 0, 0);
+                const int k0 = ((wave * NCH + c) * KS + s) * 32 + 8 * kg;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float mk = (FAST || PATCH ? k0 : k0 + j) < a.K ? 1.0f : 0.0f;
+                    float g = mk;
+                    if constexpr (!PATCH) g = gb ? gv[c][s][j] * mk : mk;
+                    xv[c][t][s][j] *= g;
+                    mx = max(mx, __float_as_uint(xv[c][t][s][j]) & 0x7fffffffu);
+                }
+            }
+            {   // the pixel's maximum over this chunk of the wave's K slice: lanes lrow, lrow + 16, + 32, + 48 (no LDS round trip)
+                auto r16 = __builtin_amdgcn_permlane16_swap(mx, mx, false, false);
+                mx = max(r16[0], r16[1]);
+                auto r32 = __builtin_amdgcn_permlane32_swap(mx, mx, false, false);
+                mx = max(r32[0], r32[1]);
+            }
+            const int eb = gs_exp_of(__uint_as_float(mx));
+            const float sc = gs_scale_of(eb);
+            invb[t] = gs_inv_scale_of(eb);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                if constexpr (FAST || PATCH) {
+                    unsigned hh[4], ll[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+                            "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+                            "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+                            "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                            : "=&v"(hh[j]), "=&v"(ll[j]) : "v"(xv[c][t][s][2 * j]), "v"(xv[c][t][s][2 * j + 1]), "v"(sc));
+                    }
+                    using gs_u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+                    bh[t][s] = __builtin_bit_cast(half8, gs_u32x4{hh[0], hh[1], hh[2], hh[3]});
+                    bl[t][s] = __builtin_bit_cast(half8, gs_u32x4{ll[0], ll[1], ll[2], ll[3]});
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float v = xv[c][t][s][j] * sc;
+                        const _Float16 hi = (_Float16)v;
+                        bh[t][s][j] = hi;
+                        bl[t][s][j] = (_Float16)(v - (float)hi);
+                    }
+                }
             }
         }
-        if (mt + 2 < MT) { load_a(mt + 2); __builtin_amdgcn_sched_barrier(0); }
+        if (c == 0) {
+            load_a(1);
+            if constexpr (LATE_TAIL) load_tail();
+        }
+        __builtin_amdgcn_sched_barrier(0);                              // the next tile's fragments go out before this tile's first MFMA
+        // ---- products; D element r of this lane = row 4 kg + r of the tile, column lrow of the strip
 #pragma unroll
-        for (int t = 0; t < NS; ++t)
+        for (int mt = 0; mt < MT; ++mt) {
+            const int q = c * MT + mt;
+            gs_f32x4 acc[NS];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                gs_red[(wave * NR + 16 * mt + 4 * kg + r) * NP + NS * lrow + t] = acc[t][r] * invb[t];  // pixel n0 + NS lrow + t
+            for (int t = 0; t < NS; ++t) {
+                acc[t] = gs_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[q & 1][s], bh[t][s], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[q & 1][s], bl[t][s], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[q & 1][s], bh[t][s], acc[t], 0, 0, 0);
+                }
+            }
+            if (q + 2 < NCH * MT) { load_a(q + 2); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = c == 0 ? acc[t][r] * invb[t] : fmaf(acc[t][r], invb[t], tot[mt][t][r]);
+                    if (c == NCH - 1) gs_red[(wave * NR + 16 * mt + 4 * kg + r) * NP + NS * lrow + t] = v;   // pixel n0 + NS lrow + t
+                    else tot[mt][t][r] = v;
+                }
+            }
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -235,12 +278,15 @@ void gemm_split_kernel(GemmSplitArgs a) {
     }
 }
 
-// waves per workgroup and k-steps per wave for an inner dimension K (the fewest k-steps per wave with 2, 4 or 8 waves)
-static bool gemm_split_plan(int K, int& nwv, int& ks) {
+// waves per workgroup, chunks per wave and k-steps per chunk for an inner dimension K (the fewest k-steps per wave with 2, 4 or
+// 8 waves; more than 5 per wave go in two chunks -- only the PATCH form is instantiated for that)
+static bool gemm_split_plan(int K, int& nwv, int& ks, int& nch) {
     const int steps = (K + 31) / 32;
     nwv = 2;
     while (nwv < 8 && nwv < steps) nwv *= 2;
-    ks = (steps + nwv - 1) / nwv;
+    const int per = (steps + nwv - 1) / nwv;
+    nch = per > 5 ? 2 : 1;
+    ks = (steps + nwv * nch - 1) / (nwv * nch);
     return ks <= 5;
 }
 
@@ -249,9 +295,9 @@ static bool gemm_split_plan(int K, int& nwv, int& ks) {
 using namespace hs;
 
 extern "C" int hs_gemm_split_kp(int32_t c_in) {
-    int nwv, ks;
-    if (c_in <= 0 || !gemm_split_plan(c_in, nwv, ks)) return HS_ERR_UNSUPPORTED;
-    return nwv * ks * 32;
+    int nwv, ks, nch;
+    if (c_in <= 0 || !gemm_split_plan(c_in, nwv, ks, nch)) return HS_ERR_UNSUPPORTED;
+    return nwv * nch * ks * 32;
 }
 
 extern "C" int hs_gemm_split_fwd(const void* w_frag, const float* w_inv, const float* gate, const float* x,
@@ -259,11 +305,11 @@ extern "C" int hs_gemm_split_fwd(const void* w_frag, const float* w_inv, const f
                                  int32_t batch, int32_t c_out, int32_t c_in, int32_t kp, int32_t pixels, void* stream) {
     if (!w_frag || !w_inv || !x || !y || batch <= 0 || c_out <= 0 || c_in <= 0 || pixels <= 0) return HS_ERR_BAD_ARG;
     if (act < 0 || act > 3) return HS_ERR_BAD_ARG;
-    int nwv, ks;
-    if (!gemm_split_plan(c_in, nwv, ks)) return HS_ERR_UNSUPPORTED;
+    int nwv, ks, nch;
+    if (!gemm_split_plan(c_in, nwv, ks, nch) || nch != 1) return HS_ERR_UNSUPPORTED;      // Cin > 1280: the library GEMM
     if (kp != nwv * ks * 32 || (ks > 1 && nwv != 8)) return HS_ERR_BAD_ARG;
     if (batch > 65535 || (c_out + 31) / 32 > 65535) return HS_ERR_UNSUPPORTED;
-    GemmSplitArgs a{(const _Float16*)w_frag, w_inv, gate, x, shift, residual, y, c_out, c_in, kp / 32, pixels, act};
+    GemmSplitArgs a{(const _Float16*)w_frag, w_inv, gate, x, shift, residual, y, c_out, c_in, kp / 32, pixels, act, 0};
     dim3 grid((pixels + 31) / 32, ((c_out + 15) / 16 + 1) / 2, batch);
     const size_t wgs = (size_t)grid.x * grid.y * grid.z;
     const bool narrow = wgs <= HS_GS_NARROW_MAX_WG && pixels > 16;
@@ -273,11 +319,12 @@ extern "C" int hs_gemm_split_fwd(const void* w_frag, const float* w_inv, const f
     const size_t lds = (size_t)nwv * (narrow ? 512 : tall ? 2048 : 1024) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     // the vector-load / 2-instruction-split form for every K depth: whole frame 0.814 ms against 0.832 (k-steps <= 2 only) and 0.858
-    // (never), same box, interleaved (profiles/round3_gemm_split_latency.txt)
+    // (never), same box, interleaved (profiles/round3_gemm_split_policy_ab.txt)
     const bool fast = (c_in & 7) == 0 && (pixels & 1) == 0 && c_in >= 8;
-#define HS_GS_(KSV, NWV, F) do { if (narrow) hipLaunchKernelGGL((gemm_split_kernel<KSV, NWV, F, 1, 2>), grid, dim3(64 * NWV), lds, s, a); \
-                                 else if (tall) hipLaunchKernelGGL((gemm_split_kernel<KSV, NWV, F, 2, 4>), grid, dim3(64 * NWV), lds, s, a); \
-                                 else hipLaunchKernelGGL((gemm_split_kernel<KSV, NWV, F, 2, 2>), grid, dim3(64 * NWV), lds, s, a); } while (0)
+#define HS_GS_(KSV, NWV, F) do { \
+        if (narrow) hipLaunchKernelGGL((gemm_split_kernel<KSV, NWV, F, 1, 2, 1, false>), grid, dim3(64 * NWV), lds, s, a); \
+        else if (tall) hipLaunchKernelGGL((gemm_split_kernel<KSV, NWV, F, 2, 4, 1, false>), grid, dim3(64 * NWV), lds, s, a); \
+        else hipLaunchKernelGGL((gemm_split_kernel<KSV, NWV, F, 2, 2, 1, false>), grid, dim3(64 * NWV), lds, s, a); } while (0)
 #define HS_GS(KSV, NWV) do { if (fast) HS_GS_(KSV, NWV, true); else HS_GS_(KSV, NWV, false); } while (0)
     switch (ks) {
         case 1: if (nwv == 2) HS_GS(1, 2); else if (nwv == 4) HS_GS(1, 4); else HS_GS(1, 8); break;
@@ -288,5 +335,39 @@ extern "C" int hs_gemm_split_fwd(const void* w_frag, const float* w_inv, const f
     }
 #undef HS_GS
 #undef HS_GS_
+    return launch_status();
+}
+
+// Conv2d(c_in, c_out, kernel 2, stride 2, no padding) on x (B, c_in, 2 Ho, 2 Wo) -> y (B, c_out, Ho, Wo) as the same GEMM with
+// K = 4 c_in read through the window (the context head's down blocks, hyperseg_v1_0.py:396-401): w_frag / w_inv from the conv
+// weight flattened to (c_out, 4 c_in), kp = hs_gemm_split_kp(4 c_in).  64 <= c_in <= 640; Wo even.
+extern "C" int hs_gemm_split_conv2x2_fwd(const void* w_frag, const float* w_inv, const float* x, const float* shift, int32_t act,
+                                         float* y, int32_t batch, int32_t c_out, int32_t c_in, int32_t kp, int32_t Ho, int32_t Wo,
+                                         void* stream) {
+    if (!w_frag || !w_inv || !x || !y || batch <= 0 || c_out <= 0 || c_in <= 0 || Ho <= 0 || Wo <= 0) return HS_ERR_BAD_ARG;
+    if (act < 0 || act > 3) return HS_ERR_BAD_ARG;
+    int nwv, ks, nch;
+    if (c_in > (1 << 20) || !gemm_split_plan(4 * c_in, nwv, ks, nch) || nwv != 8 || (Wo & 1) || (c_in & 1)) return HS_ERR_UNSUPPORTED;
+    if (kp != nwv * nch * ks * 32) return HS_ERR_BAD_ARG;
+    if ((((size_t)x) & 15) != 0) return HS_ERR_BAD_ARG;
+    const int pixels = Ho * Wo;
+    if (batch > 65535 || (c_out + 31) / 32 > 65535) return HS_ERR_UNSUPPORTED;
+    GemmSplitArgs a{(const _Float16*)w_frag, w_inv, nullptr, x, shift, nullptr, y, c_out, 4 * c_in, kp / 32, pixels, act, Wo};
+    dim3 grid((pixels + 15) / 16, ((c_out + 15) / 16 + 1) / 2, batch);
+    const size_t lds = (size_t)8 * 512 * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+#define HS_GP(KSV, NCHV) hipLaunchKernelGGL((gemm_split_kernel<KSV, 8, true, 1, 2, NCHV, true>), grid, dim3(512), lds, s, a)
+    switch (ks * 2 + nch - 1) {
+        case 2: HS_GP(1, 1); break;
+        case 4: HS_GP(2, 1); break;
+        case 6: HS_GP(3, 1); break;
+        case 8: HS_GP(4, 1); break;
+        case 10: HS_GP(5, 1); break;
+        case 7: HS_GP(3, 2); break;
+        case 9: HS_GP(4, 2); break;
+        case 11: HS_GP(5, 2); break;
+        default: return HS_ERR_UNSUPPORTED;
+    }
+#undef HS_GP
     return launch_status();
 }

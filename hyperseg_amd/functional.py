@@ -602,12 +602,13 @@ class SplitWeights:
 
 
 @torch.no_grad()
-def gemm_split_weights(w, row_scale=None):
-    """``w`` (Cout, Cin[, 1, 1]) f32 -> SplitWeights, or None when the kernel does not cover Cin (> 1280).  ``row_scale``
+def gemm_split_weights(w, row_scale=None, max_k=1280):
+    """``w`` (Cout, Cin[, 1, 1]) f32 -> SplitWeights, or None when the kernel does not cover Cin (> 1280; the 2x2 / stride-2
+    form of ``gemm_split_conv2x2`` takes K = 4 Cin up to 2560: ``max_k=2560`` with the (Cout, Cin, 2, 2) weight).  ``row_scale``
     (Cout): folded into the rows first (a BatchNorm scale).  Torch tensor ops only; runs once per weight."""
     w = w.detach().flatten(1).float()
     m, k = w.shape
-    kp = _hip.lib.hs_gemm_split_kp(k)
+    kp = _hip.lib.hs_gemm_split_kp(k) if k <= max_k else -1
     if kp < 0:
         return None
     if row_scale is not None:
@@ -654,6 +655,31 @@ def gemm_split(sw, x, gate=None, shift=None, act=ACT_NONE, residual=None, out=No
                                     _hip.dev_ptr(residual, 'residual') if residual is not None else None,
                                     _hip.dev_ptr(out, 'out'), b, sw.c_out, cin, sw.kp, h * w, _hip.stream_ptr())
     _hip.check(st, 'hs_gemm_split_fwd')
+    return out
+
+
+@_on_operand_device
+def gemm_split_conv2x2(sw, x, shift=None, act=ACT_NONE, out=None):
+    """y (B, Cout, H/2, W/2) = act(Conv2d(kernel 2, stride 2)(x) + shift[:, None, None]) on the f16 matrix cores with split
+    operands, the window read on load (hs_gemm_split_conv2x2_fwd; no im2col copy).  ``sw`` = gemm_split_weights(conv.weight
+    (Cout, Cin, 2, 2), scale, max_k=2560)."""
+    b, cin, h, w = x.shape
+    if 4 * cin != sw.c_in:
+        raise ValueError(f'input has {cin} channels, the weight {sw.c_in} / 4')
+    if h % 2 or w % 4:
+        raise ValueError(f'map {h}x{w}: height must be even and width a multiple of 4')
+    shape = (b, sw.c_out, h // 2, w // 2)
+    if out is None:
+        out = torch.empty(shape, device=x.device, dtype=torch.float32)
+    elif tuple(out.shape) != shape:
+        raise ValueError(f'out has shape {tuple(out.shape)}, expected {shape}')
+    if shift is not None and shift.numel() != sw.c_out:
+        raise ValueError(f'shift has {shift.numel()} entries, expected {sw.c_out}')
+    st = _hip.lib.hs_gemm_split_conv2x2_fwd(_hip.dev_ptr(sw.frag, 'w_frag', torch.float16), _hip.dev_ptr(sw.inv, 'w_inv'),
+                                            _hip.dev_ptr(x, 'x'), _hip.dev_ptr(shift, 'shift') if shift is not None else None,
+                                            int(act), _hip.dev_ptr(out, 'out'), b, sw.c_out, cin, sw.kp, h // 2, w // 2,
+                                            _hip.stream_ptr())
+    _hip.check(st, 'hs_gemm_split_conv2x2_fwd')
     return out
 
 

@@ -319,6 +319,9 @@ class FusedMBConv(nn.Module):
         return proj(y, gate=gate, residual=skip)
 
 
+CTX_DOWN_SPLIT = os.environ.get('HS_CTX_DOWN_SPLIT', '1') != '0'      # A/B switch (tools/gpu_ab_env.sh): 0 = F.conv2d + affine for the head's down blocks
+
+
 class FusedContextHead(nn.Module):
     """The v1_0 context head (WeightMapper, hyperseg_v1_0.py:379-448) for one frame with fewer launches -- same library
     GEMMs, but every Conv -> BatchNorm -> ReLU is GEMM + ONE affine/ReLU launch, and the concatenations are never built:
@@ -354,14 +357,14 @@ class FusedContextHead(nn.Module):
     def _affine(self, i):
         return getattr(self, f'scale{i}'), getattr(self, f'shift{i}')
 
-    def _split_weights(self, name, weight, scale):
+    def _split_weights(self, name, weight, scale, max_k=1280):
         """``weight`` (Cout, K) with the BN ``scale`` folded into its rows, prepared for hs_gemm_split_fwd (None when K is outside
         what the kernel covers); rebuilt when the conv weight or the BN scale change in place (functional._key)."""
         from .. import functional as HF
         key = HF._key(weight, scale)
         hit = self._split.get(name)
         if hit is None or hit[0] != key:
-            hit = (key, HF.gemm_split_weights(weight, scale))
+            hit = (key, HF.gemm_split_weights(weight, scale, max_k=max_k))
             self._split[name] = hit
         return hit[1]
 
@@ -387,8 +390,15 @@ class FusedContextHead(nn.Module):
             HF.affine_act_(left, *self._affine(0), HF.ACT_RELU)
         feat = [left]
         for i, down in enumerate(wm.down_blocks):
-            t = F.conv2d(feat[-1], down[0].weight, stride=2)
-            feat.append(HF.affine_act_(t, *self._affine(1 + i), HF.ACT_RELU))
+            src = feat[-1]
+            sw_dn = None
+            if self.split_gemm and CTX_DOWN_SPLIT and src.shape[2] % 2 == 0 and src.shape[3] % 4 == 0 and src.is_contiguous() and src.data_ptr() % 16 == 0:
+                sw_dn = self._split_weights(f'down{i}', down[0].weight, getattr(self, f'scale{1 + i}'), max_k=2560)
+            if sw_dn is not None:        # the 2x2 / stride-2 conv -> BN -> ReLU in ONE launch, the window read on load (no im2col copy)
+                feat.append(HF.gemm_split_conv2x2(sw_dn, src, shift=getattr(self, f'shift{1 + i}'), act=HF.ACT_RELU))
+            else:
+                t = F.conv2d(src, down[0].weight, stride=2)
+                feat.append(HF.affine_act_(t, *self._affine(1 + i), HF.ACT_RELU))
         t = feat[-1]
         pooled_const = t.shape[-2:] != (1, 1)            # the bottom is replaced by its global average
         for level in range(n - 1, -1, -1):

@@ -314,12 +314,19 @@ int hs_affine_act_fwd(const float* x, int32_t batch, int32_t channels, int32_t p
  * < 2^15, in MFMA-fragment order [ceil(Cout/16)][kp/32][piece][64 lanes][8] (lane = row % 16 + 16 * kgroup holds
  * w[16 R + row % 16][32 S + 8 kgroup + j]), and the inverse row scales padded to a multiple of 16 rows
  * (hyperseg_amd.functional.gemm_split_weights builds both).  kp = hs_gemm_split_kp(Cin): Cin rounded up to the workgroup's
- * K split, or HS_ERR_UNSUPPORTED for Cin > 1280.  Replaces the library GEMM of an MBConv block's expand / project convolution
+ * K split (HS_ERR_UNSUPPORTED for Cin > 2560; hs_gemm_split_fwd itself takes Cin <= 1280, the deeper K is the 2x2 form's).  Replaces the library GEMM of an MBConv block's expand / project convolution
  * (efficientnet.py:101, 115) and, through `gate`, the SE multiply (:110-111). */
 int hs_gemm_split_kp(int32_t c_in);
 int hs_gemm_split_fwd(const void* w_frag, const float* w_inv, const float* gate, const float* x, const float* shift,
                       int32_t act, const float* residual, float* y, int32_t batch, int32_t c_out, int32_t c_in, int32_t kp,
                       int32_t pixels, void* stream);
+/* Conv2d(c_in, c_out, kernel 2, stride 2, no padding, no bias) + shift + act with the same arithmetic: x (B,c_in,2Ho,2Wo) ->
+ * y (B,c_out,Ho,Wo), the window read on load (K = 4 c_in, k = 4 c + 2 dy + dx: the conv weight's own flatten order; no im2col
+ * copy).  w_frag / w_inv from the (c_out, 4 c_in) weight, kp = hs_gemm_split_kp(4 c_in); 64 <= c_in <= 640, c_in and Wo even,
+ * x 16-byte aligned, else HS_ERR_UNSUPPORTED.  Replaces F.conv2d + BatchNorm + ReLU of the context head's down blocks
+ * (hyperseg_v1_0.py:396-401). */
+int hs_gemm_split_conv2x2_fwd(const void* w_frag, const float* w_inv, const float* x, const float* shift, int32_t act, float* y,
+                              int32_t batch, int32_t c_out, int32_t c_in, int32_t kp, int32_t Ho, int32_t Wo, void* stream);
 
 /* Materialises a stage input (B, 2*coords + c_skip + c_prev, H, W); test/diagnostic twin of the
  * fused prologue (the product path never calls it). */

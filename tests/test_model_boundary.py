@@ -320,7 +320,16 @@ def test_deferred_bn_shift_algebra_cpu(monkeypatch, config, split):
         assert out.shape == y.shape
         return out.copy_(y)
 
+    def gemm_split_conv2x2(sw, x, shift=None, act=0, out=None):                              # K = 4 Cin in the conv weight's flatten order
+        rt = sw.frag.shape[0]
+        back = sw.frag.permute(2, 0, 4, 1, 3, 5).reshape(2, 16 * rt, sw.kp).float()
+        w = ((back[0] + back[1]) * sw.inv[:, None])[:sw.c_out, :sw.c_in].reshape(sw.c_out, x.shape[1], 2, 2)
+        y = F.conv2d(x, w, stride=2)
+        used['conv2x2'] = used.get('conv2x2', 0) + 1
+        return act_of(y if shift is None else y + shift.view(1, -1, 1, 1), act)
+
     monkeypatch.setattr(HF, 'gemm_split', gemm_split)
+    monkeypatch.setattr(HF, 'gemm_split_conv2x2', gemm_split_conv2x2)
     monkeypatch.setattr(HF, 'mbconv_expand_dw', expand_dw)
     monkeypatch.setattr(HF, 'depthwise_conv_bn_act', dw)
     monkeypatch.setattr(HF, 'se_gate', se_gate)
@@ -356,6 +365,8 @@ def test_deferred_bn_shift_algebra_cpu(monkeypatch, config, split):
             # the context head without its concatenations (FusedContextHead) == the stock head
             with torch.no_grad():
                 assert rel_err(fused.weight_mapper._fused(feats[-1].contiguous()), stock.weight_mapper(ref[-1])) < 2e-5
+            if split and feats[-1].shape[3] % 4 == 0:
+                assert used.get('conv2x2', 0) >= 1              # the head's 2x2 / stride-2 down blocks take the windowed GEMM
 
 
 def test_patch_ir_routes():

@@ -12,7 +12,9 @@ def test_split_weights_host_side():
     # plan: Cin rounded up to (2 | 4 | 8 waves) x (<= 5 k-steps) x 32; beyond 1280 the kernel declines
     assert [lib.hs_gemm_split_kp(k) for k in (1, 32, 80, 112, 192, 240, 480, 672, 1152, 1280)] == \
         [64, 64, 128, 128, 256, 256, 512, 768, 1280, 1280]
-    assert lib.hs_gemm_split_kp(1281) < 0 and lib.hs_gemm_split_kp(1920) < 0 and lib.hs_gemm_split_kp(0) < 0
+    # 1281 ... 2560: two chunks of <= 5 k-steps per wave -- the windowed 2x2 / stride-2 form only (hs_gemm_split_fwd declines)
+    assert [lib.hs_gemm_split_kp(k) for k in (1281, 1600, 1920, 2560)] == [1536, 2048, 2048, 2560]
+    assert lib.hs_gemm_split_kp(2561) < 0 and lib.hs_gemm_split_kp(0) < 0
     g = torch.Generator().manual_seed(0)
     for m, k in ((40, 240), (19, 80), (112, 672)):
         w = torch.randn(m, k, 1, 1, generator=g) * torch.logspace(-3, 3, m).view(m, 1, 1, 1)      # rows of very different size
@@ -30,6 +32,8 @@ def test_split_weights_host_side():
         assert float(err.max()) < 2.0 ** -21                     # two f16 pieces of a row scaled to < 2^15
         assert float((back[0].abs().amax(1)[:m]).max()) < 2.0 ** 15
     assert HF.gemm_split_weights(torch.randn(8, 1920)) is None
+    sw4 = HF.gemm_split_weights(torch.randn(8, 480, 2, 2), max_k=2560)
+    assert (sw4.c_in, sw4.kp) == (1920, 2048) and HF.gemm_split_weights(torch.randn(8, 641, 2, 2), max_k=2560) is None
     with pytest.raises(Exception):
         HF.gemm_split(HF.gemm_split_weights(torch.randn(8, 64)), torch.rand(1, 64, 4, 4))       # CPU tensors: no fallback
 
@@ -102,6 +106,32 @@ def test_gemm_split_vs_float64(m, k, hw, batch):
         ya = HF.gemm_split(sw, x, gate=gate, shift=shift, act=act, residual=res)
         want = fn(ref + shift.double().view(1, -1, 1, 1)) + res.double()
         assert rel_err(ya.double().cpu(), want.cpu()) < (2e-5 if act == 3 else 2e-6)       # swish: the fast exp2 / rcp form
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('m,c,hw,batch', [(640, 640, (16, 32), 1), (96, 64, (8, 8), 2), (130, 250, (6, 12), 1), (320, 320, (32, 64), 1),
+                                          (48, 400, (4, 4), 1)])
+def test_gemm_split_conv2x2_vs_float64(m, c, hw, batch):
+    """Conv2d(c, m, kernel 2, stride 2) + shift + ReLU with the window read on load (the context head's down blocks,
+    hyperseg_v1_0.py:396-401; K = 4 c up to 2560 in two chunks per wave) against the float64 convolution."""
+    import torch.nn.functional as F
+    from hyperseg_amd import functional as HF
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(m + c)
+    w = (torch.randn(m, c, 2, 2, generator=g) / (4 * c) ** 0.5).to(dev)
+    x = (torch.randn(batch, c, *hw, generator=g) * torch.rand(1, c, 1, 1, generator=g) * 4).to(dev)
+    scale = (torch.rand(m, generator=g) + 0.5).to(dev)
+    shift = torch.randn(m, generator=g).to(dev)
+    sw = HF.gemm_split_weights(w, scale, max_k=2560)
+    assert sw is not None and sw.c_in == 4 * c
+    ref = F.conv2d(x.double(), (w * scale.view(-1, 1, 1, 1)).double(), stride=2)
+    y = HF.gemm_split_conv2x2(sw, x)
+    assert y.shape == ref.shape and rel_err(y.double().cpu(), ref.cpu()) < 2e-6
+    ya = HF.gemm_split_conv2x2(sw, x, shift=shift, act=HF.ACT_RELU)
+    assert rel_err(ya.double().cpu(), torch.relu(ref + shift.double().view(1, -1, 1, 1)).cpu()) < 2e-6
+    assert HF.gemm_split_weights(w, scale) is None or 4 * c <= 1280             # the 1x1 form stops at K = 1280
+    with pytest.raises(ValueError):
+        HF.gemm_split_conv2x2(sw, x[:, :, :, :hw[1] - 2].contiguous())          # width must be a multiple of 4
 
 
 @pytest.mark.gpu
