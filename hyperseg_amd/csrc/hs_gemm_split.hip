@@ -39,6 +39,8 @@ struct GemmSplitArgs {
     float* y;
     int M, K, KST, N, act;
     int conv_wo;                           // PATCH form: output width (the input map is 2 Ho x 2 Wo), else 0
+    float* pool_partial;                   // [B][M][gridDim.x] sums of the stored values over the workgroup's 16 pixels, or null
+    int up2_wo;                            // > 0: the N = Ho x up2_wo outputs are stored nearest-2x upsampled, y (B, M, 2 Ho, 2 up2_wo)
 };
 
 // FAST: K % 8 == 0 and N % 2 == 0 (every encoder / context-head layer): paired pixel loads and vector gate loads, decided at
@@ -73,7 +75,7 @@ void gemm_split_kernel(GemmSplitArgs a) {
     const int n0 = blockIdx.x * NP, r0 = blockIdx.y * MT, b = blockIdx.z;
     const float* __restrict__ xb = a.x + (size_t)b * a.K * a.N;           // PATCH: K N = 4 C Ho Wo = the input map's size
     const float* __restrict__ gb = a.gate ? a.gate + (size_t)b * a.K : nullptr;
-    float* yb = a.y + (size_t)b * a.M * a.N;
+    float* yb = a.y + (size_t)b * a.M * a.N * (a.up2_wo > 0 ? 4 : 1);
     const float* rb = a.residual ? a.residual + (size_t)b * a.M * a.N : nullptr;
     const int rt_max = (a.M + 15) >> 4;
 
@@ -269,12 +271,55 @@ void gemm_split_kernel(GemmSplitArgs a) {
             float t = 0.0f;
 #pragma unroll
             for (int w = 0; w < nwv; ++w) t += gs_red[w * NE + e];
-            if (row < a.M && col < a.N) {
-                float v = fmaf(t, wi[i], sh[i]);
-                v = a.act == 3 ? swishf(v) : apply_act(v, a.act);
-                yb[(size_t)row * a.N + col] = v + yo[i];
+            const bool live = row < a.M && col < a.N;
+            float v = fmaf(t, wi[i], sh[i]);
+            v = (a.act == 3 ? swishf(v) : apply_act(v, a.act)) + yo[i];
+            if (live) {
+                if (a.up2_wo > 0) {                                     // pixel (oy, ox) -> the 2x2 block at (2 oy, 2 ox) of a 2 Wo wide map
+                    const int oy = col / a.up2_wo, ox = col - oy * a.up2_wo;
+                    float* dst = yb + (size_t)row * (4 * a.N) + (size_t)(2 * oy) * (2 * a.up2_wo) + 2 * ox;
+                    *reinterpret_cast<gs_f32x2*>(dst) = gs_f32x2{v, v};
+                    *reinterpret_cast<gs_f32x2*>(dst + 2 * a.up2_wo) = gs_f32x2{v, v};
+                } else {
+                    yb[(size_t)row * a.N + col] = v;
+                }
+            }
+            if constexpr (NP == 16) {                                   // 16 consecutive lanes = one output row of this workgroup
+                if (a.pool_partial) {
+                    const float rs = rowsum16(live ? v : 0.0f);
+                    if ((e & 15) == 0 && row < a.M) a.pool_partial[((size_t)b * a.M + row) * gridDim.x + blockIdx.x] = rs;
+                }
             }
         }
+    }
+}
+
+// shift_out[m] = shift[m] + sum_c wb[m][c] * mean[c], mean[c] = inv_p * sum_j partial[c][j]: the context head's deepest merge, where
+// the pooled half of cat(feat, pooled.expand_as(feat)) is constant over the pixels and its product with the right half of the 1x1
+// conv's weights is a per-row constant (hyperseg_v1_0.py:404-409; utils/inference.py FusedContextHead).  16 rows per workgroup.
+__global__ __launch_bounds__(256)
+void pooled_shift_kernel(const float* __restrict__ partial, int nblk, float inv_p, const float* __restrict__ wb,
+                         const float* __restrict__ shift, float* __restrict__ out, int M, int C) {
+    extern __shared__ float ps_mean[];                                  // [C]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < C; c += 256) {
+        float t = 0.0f;
+        for (int j = 0; j < nblk; ++j) t += partial[(size_t)c * nblk + j];
+        ps_mean[c] = t * inv_p;
+    }
+    __syncthreads();
+    const int r0 = 16 * blockIdx.x + 4 * wave;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int c = lane; c < C; c += 64) {
+        const float m = ps_mean[c];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = fmaf(wb[(size_t)min(r0 + i, M - 1) * C + c], m, acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float t = wave_sum64(acc[i]);
+        if (lane == 0 && r0 + i < M) out[r0 + i] = shift[r0 + i] + t;
     }
 }
 
@@ -300,16 +345,16 @@ extern "C" int hs_gemm_split_kp(int32_t c_in) {
     return nwv * nch * ks * 32;
 }
 
-extern "C" int hs_gemm_split_fwd(const void* w_frag, const float* w_inv, const float* gate, const float* x,
-                                 const float* shift, int32_t act, const float* residual, float* y,
-                                 int32_t batch, int32_t c_out, int32_t c_in, int32_t kp, int32_t pixels, void* stream) {
+static int launch_gemm_split_plain(const void* w_frag, const float* w_inv, const float* gate, const float* x, const float* shift,
+                                   int32_t act, const float* residual, float* y, int32_t batch, int32_t c_out, int32_t c_in,
+                                   int32_t kp, int32_t pixels, int up2_wo, void* stream) {
     if (!w_frag || !w_inv || !x || !y || batch <= 0 || c_out <= 0 || c_in <= 0 || pixels <= 0) return HS_ERR_BAD_ARG;
     if (act < 0 || act > 3) return HS_ERR_BAD_ARG;
     int nwv, ks, nch;
     if (!gemm_split_plan(c_in, nwv, ks, nch) || nch != 1) return HS_ERR_UNSUPPORTED;      // Cin > 1280: the library GEMM
     if (kp != nwv * ks * 32 || (ks > 1 && nwv != 8)) return HS_ERR_BAD_ARG;
     if (batch > 65535 || (c_out + 31) / 32 > 65535) return HS_ERR_UNSUPPORTED;
-    GemmSplitArgs a{(const _Float16*)w_frag, w_inv, gate, x, shift, residual, y, c_out, c_in, kp / 32, pixels, act, 0};
+    GemmSplitArgs a{(const _Float16*)w_frag, w_inv, gate, x, shift, residual, y, c_out, c_in, kp / 32, pixels, act, 0, nullptr, up2_wo};
     dim3 grid((pixels + 31) / 32, ((c_out + 15) / 16 + 1) / 2, batch);
     const size_t wgs = (size_t)grid.x * grid.y * grid.z;
     const bool narrow = wgs <= HS_GS_NARROW_MAX_WG && pixels > 16;
@@ -338,12 +383,37 @@ extern "C" int hs_gemm_split_fwd(const void* w_frag, const float* w_inv, const f
     return launch_status();
 }
 
+extern "C" int hs_gemm_split_fwd(const void* w_frag, const float* w_inv, const float* gate, const float* x,
+                                 const float* shift, int32_t act, const float* residual, float* y,
+                                 int32_t batch, int32_t c_out, int32_t c_in, int32_t kp, int32_t pixels, void* stream) {
+    return launch_gemm_split_plain(w_frag, w_inv, gate, x, shift, act, residual, y, batch, c_out, c_in, kp, pixels, 0, stream);
+}
+
+// The same 1x1 convolution with its (B, c_out, Ho, Wo) result stored nearest-2x upsampled, y (B, c_out, 2 Ho, 2 Wo): the context
+// head's last merge writes straight into the right half of the signal (hyperseg_v1_0.py:409-410: upsample + cat never built).
+extern "C" int hs_gemm_split_up2_fwd(const void* w_frag, const float* w_inv, const float* x, const float* shift, int32_t act,
+                                     float* y, int32_t batch, int32_t c_out, int32_t c_in, int32_t kp, int32_t Ho, int32_t Wo,
+                                     void* stream) {
+    if (Ho <= 0 || Wo <= 0 || (((size_t)y) & 7) != 0) return HS_ERR_BAD_ARG;
+    return launch_gemm_split_plain(w_frag, w_inv, nullptr, x, shift, act, nullptr, y, batch, c_out, c_in, kp, Ho * Wo, Wo, stream);
+}
+
+extern "C" int hs_pooled_shift_fwd(const float* partial, int32_t nblk, float inv_pixels, const float* wb, const float* shift,
+                                   float* shift_out, int32_t rows, int32_t channels, void* stream) {
+    if (!partial || !wb || !shift || !shift_out || nblk <= 0 || rows <= 0 || channels <= 0) return HS_ERR_BAD_ARG;
+    if (channels > 8192) return HS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(pooled_shift_kernel, dim3((rows + 15) / 16), dim3(256), (size_t)channels * sizeof(float), (hipStream_t)stream,
+                       partial, nblk, inv_pixels, wb, shift, shift_out, rows, channels);
+    return launch_status();
+}
+
 // Conv2d(c_in, c_out, kernel 2, stride 2, no padding) on x (B, c_in, 2 Ho, 2 Wo) -> y (B, c_out, Ho, Wo) as the same GEMM with
 // K = 4 c_in read through the window (the context head's down blocks, hyperseg_v1_0.py:396-401): w_frag / w_inv from the conv
-// weight flattened to (c_out, 4 c_in), kp = hs_gemm_split_kp(4 c_in).  64 <= c_in <= 640; Wo even.
+// weight flattened to (c_out, 4 c_in), kp = hs_gemm_split_kp(4 c_in).  64 <= c_in <= 640; Wo even.  pool_partial (optional):
+// [B][c_out][ceil(Ho Wo / 16)] sums of y over the 16-pixel blocks, for hs_pooled_shift_fwd (the global average without a launch).
 extern "C" int hs_gemm_split_conv2x2_fwd(const void* w_frag, const float* w_inv, const float* x, const float* shift, int32_t act,
-                                         float* y, int32_t batch, int32_t c_out, int32_t c_in, int32_t kp, int32_t Ho, int32_t Wo,
-                                         void* stream) {
+                                         float* y, float* pool_partial, int32_t batch, int32_t c_out, int32_t c_in, int32_t kp,
+                                         int32_t Ho, int32_t Wo, void* stream) {
     if (!w_frag || !w_inv || !x || !y || batch <= 0 || c_out <= 0 || c_in <= 0 || Ho <= 0 || Wo <= 0) return HS_ERR_BAD_ARG;
     if (act < 0 || act > 3) return HS_ERR_BAD_ARG;
     int nwv, ks, nch;
@@ -352,7 +422,7 @@ extern "C" int hs_gemm_split_conv2x2_fwd(const void* w_frag, const float* w_inv,
     if ((((size_t)x) & 15) != 0) return HS_ERR_BAD_ARG;
     const int pixels = Ho * Wo;
     if (batch > 65535 || (c_out + 31) / 32 > 65535) return HS_ERR_UNSUPPORTED;
-    GemmSplitArgs a{(const _Float16*)w_frag, w_inv, nullptr, x, shift, nullptr, y, c_out, 4 * c_in, kp / 32, pixels, act, Wo};
+    GemmSplitArgs a{(const _Float16*)w_frag, w_inv, nullptr, x, shift, nullptr, y, c_out, 4 * c_in, kp / 32, pixels, act, Wo, pool_partial, 0};
     dim3 grid((pixels + 15) / 16, ((c_out + 15) / 16 + 1) / 2, batch);
     const size_t lds = (size_t)8 * 512 * sizeof(float);
     hipStream_t s = (hipStream_t)stream;

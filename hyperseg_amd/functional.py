@@ -659,10 +659,11 @@ def gemm_split(sw, x, gate=None, shift=None, act=ACT_NONE, residual=None, out=No
 
 
 @_on_operand_device
-def gemm_split_conv2x2(sw, x, shift=None, act=ACT_NONE, out=None):
+def gemm_split_conv2x2(sw, x, shift=None, act=ACT_NONE, out=None, pool_partial=None):
     """y (B, Cout, H/2, W/2) = act(Conv2d(kernel 2, stride 2)(x) + shift[:, None, None]) on the f16 matrix cores with split
     operands, the window read on load (hs_gemm_split_conv2x2_fwd; no im2col copy).  ``sw`` = gemm_split_weights(conv.weight
-    (Cout, Cin, 2, 2), scale, max_k=2560)."""
+    (Cout, Cin, 2, 2), scale, max_k=2560).  ``pool_partial``: a (B, Cout, ceil(H W / 64)) f32 tensor that receives the sums of y
+    over blocks of 16 pixels (``pooled_shift`` turns them into the global average's contribution)."""
     b, cin, h, w = x.shape
     if 4 * cin != sw.c_in:
         raise ValueError(f'input has {cin} channels, the weight {sw.c_in} / 4')
@@ -675,11 +676,51 @@ def gemm_split_conv2x2(sw, x, shift=None, act=ACT_NONE, out=None):
         raise ValueError(f'out has shape {tuple(out.shape)}, expected {shape}')
     if shift is not None and shift.numel() != sw.c_out:
         raise ValueError(f'shift has {shift.numel()} entries, expected {sw.c_out}')
+    nblk = -(-(h // 2) * (w // 2) // 16)
+    if pool_partial is not None and tuple(pool_partial.shape) != (b, sw.c_out, nblk):
+        raise ValueError(f'pool_partial has shape {tuple(pool_partial.shape)}, expected {(b, sw.c_out, nblk)}')
     st = _hip.lib.hs_gemm_split_conv2x2_fwd(_hip.dev_ptr(sw.frag, 'w_frag', torch.float16), _hip.dev_ptr(sw.inv, 'w_inv'),
                                             _hip.dev_ptr(x, 'x'), _hip.dev_ptr(shift, 'shift') if shift is not None else None,
-                                            int(act), _hip.dev_ptr(out, 'out'), b, sw.c_out, cin, sw.kp, h // 2, w // 2,
-                                            _hip.stream_ptr())
+                                            int(act), _hip.dev_ptr(out, 'out'),
+                                            _hip.dev_ptr(pool_partial, 'pool_partial') if pool_partial is not None else None,
+                                            b, sw.c_out, cin, sw.kp, h // 2, w // 2, _hip.stream_ptr())
     _hip.check(st, 'hs_gemm_split_conv2x2_fwd')
+    return out
+
+
+@_on_operand_device
+def gemm_split_up2(sw, x, shift=None, act=ACT_NONE, out=None):
+    """nearest-2x upsample of act(W @ x + shift): (B, Cin, H, W) -> (B, Cout, 2H, 2W), the small map never stored
+    (hs_gemm_split_up2_fwd).  ``out``: e.g. the right half of the context head's signal."""
+    b, cin, h, w = x.shape
+    if cin != sw.c_in:
+        raise ValueError(f'input has {cin} channels, the weight {sw.c_in}')
+    shape = (b, sw.c_out, 2 * h, 2 * w)
+    if out is None:
+        out = torch.empty(shape, device=x.device, dtype=torch.float32)
+    elif tuple(out.shape) != shape:
+        raise ValueError(f'out has shape {tuple(out.shape)}, expected {shape}')
+    if shift is not None and shift.numel() != sw.c_out:
+        raise ValueError(f'shift has {shift.numel()} entries, expected {sw.c_out}')
+    st = _hip.lib.hs_gemm_split_up2_fwd(_hip.dev_ptr(sw.frag, 'w_frag', torch.float16), _hip.dev_ptr(sw.inv, 'w_inv'),
+                                        _hip.dev_ptr(x, 'x'), _hip.dev_ptr(shift, 'shift') if shift is not None else None,
+                                        int(act), _hip.dev_ptr(out, 'out'), b, sw.c_out, cin, sw.kp, h, w, _hip.stream_ptr())
+    _hip.check(st, 'hs_gemm_split_up2_fwd')
+    return out
+
+
+@_on_operand_device
+def pooled_shift(pool_partial, pixels, wb, shift):
+    """shift + wb @ mean, mean = the global average whose 16-pixel block sums ``pool_partial`` (1, C, nblk) holds
+    (hs_pooled_shift_fwd): the pooled half of ``cat(feat, pooled.expand_as(feat))`` in front of a 1x1 conv, as a row constant."""
+    _, c, nblk = pool_partial.shape
+    m = shift.numel()
+    if pool_partial.shape[0] != 1 or tuple(wb.shape) != (m, c):
+        raise ValueError(f'pool_partial {tuple(pool_partial.shape)} / wb {tuple(wb.shape)} / shift {m}: expected (1, C, nblk), (M, C), M')
+    out = torch.empty(m, device=shift.device, dtype=torch.float32)
+    st = _hip.lib.hs_pooled_shift_fwd(_hip.dev_ptr(pool_partial, 'pool_partial'), nblk, 1.0 / pixels, _hip.dev_ptr(wb, 'wb'),
+                                      _hip.dev_ptr(shift, 'shift'), _hip.dev_ptr(out, 'shift_out'), m, c, _hip.stream_ptr())
+    _hip.check(st, 'hs_pooled_shift_fwd')
     return out
 
 

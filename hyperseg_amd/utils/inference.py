@@ -389,13 +389,17 @@ class FusedContextHead(nn.Module):
             torch.mm(wm.in_conv[0].weight.view(half, cin), x.view(cin, h * w), out=left.view(half, h * w))
             HF.affine_act_(left, *self._affine(0), HF.ACT_RELU)
         feat = [left]
+        pool = None
         for i, down in enumerate(wm.down_blocks):
             src = feat[-1]
             sw_dn = None
             if self.split_gemm and CTX_DOWN_SPLIT and src.shape[2] % 2 == 0 and src.shape[3] % 4 == 0 and src.is_contiguous() and src.data_ptr() % 16 == 0:
                 sw_dn = self._split_weights(f'down{i}', down[0].weight, getattr(self, f'scale{1 + i}'), max_k=2560)
             if sw_dn is not None:        # the 2x2 / stride-2 conv -> BN -> ReLU in ONE launch, the window read on load (no im2col copy)
-                feat.append(HF.gemm_split_conv2x2(sw_dn, src, shift=getattr(self, f'shift{1 + i}'), act=HF.ACT_RELU))
+                ho, wo = src.shape[2] // 2, src.shape[3] // 2
+                if i == n - 1 and (ho, wo) != (1, 1):     # the bottom: its global average comes out of the same launch as block sums
+                    pool = torch.empty(1, half, -(-ho * wo // 16), device=x.device, dtype=torch.float32)
+                feat.append(HF.gemm_split_conv2x2(sw_dn, src, shift=getattr(self, f'shift{1 + i}'), act=HF.ACT_RELU, pool_partial=pool))
             else:
                 t = F.conv2d(src, down[0].weight, stride=2)
                 feat.append(HF.affine_act_(t, *self._affine(1 + i), HF.ACT_RELU))
@@ -409,8 +413,15 @@ class FusedContextHead(nn.Module):
             sh, sw = skip.shape[-2:]
             if pooled_const:
                 # right operand is constant over the pixels: W_b @ mean -> per-channel constant in the shift
-                shift = torch.addmv(shift, self.wb_scaled, t.mean((2, 3)).view(half))
+                if pool is not None:
+                    shift = HF.pooled_shift(pool, t.shape[2] * t.shape[3], self.wb_scaled, shift)      # mean + mat-vec, one launch
+                else:
+                    shift = torch.addmv(shift, self.wb_scaled, t.mean((2, 3)).view(half))
                 sw_up = self._split_weights(f'up{level}', wgt[:, :half], scale) if self.split_gemm and (sh * sw) % 4 == 0 else None
+                if sw_up is not None and level == 0:
+                    # ... and the nearest 2x upsample into the right half of the signal is the GEMM's own store
+                    HF.gemm_split_up2(sw_up, skip.contiguous(), shift=shift, act=HF.ACT_RELU, out=signal[:, half:])
+                    return signal
                 if sw_up is not None:
                     y = HF.gemm_split(sw_up, skip.contiguous(), shift=shift, act=HF.ACT_RELU)
                 else:

@@ -323,10 +323,23 @@ int hs_gemm_split_fwd(const void* w_frag, const float* w_inv, const float* gate,
 /* Conv2d(c_in, c_out, kernel 2, stride 2, no padding, no bias) + shift + act with the same arithmetic: x (B,c_in,2Ho,2Wo) ->
  * y (B,c_out,Ho,Wo), the window read on load (K = 4 c_in, k = 4 c + 2 dy + dx: the conv weight's own flatten order; no im2col
  * copy).  w_frag / w_inv from the (c_out, 4 c_in) weight, kp = hs_gemm_split_kp(4 c_in); 64 <= c_in <= 640, c_in and Wo even,
- * x 16-byte aligned, else HS_ERR_UNSUPPORTED.  Replaces F.conv2d + BatchNorm + ReLU of the context head's down blocks
- * (hyperseg_v1_0.py:396-401). */
+ * x 16-byte aligned, else HS_ERR_UNSUPPORTED.  pool_partial (optional): (B, c_out, ceil(Ho Wo / 16)) sums of y over blocks of 16
+ * consecutive pixels -- the global average pool that follows, without a launch of its own (hs_pooled_shift_fwd reads it).
+ * Replaces F.conv2d + BatchNorm + ReLU of the context head's down blocks (hyperseg_v1_0.py:396-401). */
 int hs_gemm_split_conv2x2_fwd(const void* w_frag, const float* w_inv, const float* x, const float* shift, int32_t act, float* y,
-                              int32_t batch, int32_t c_out, int32_t c_in, int32_t kp, int32_t Ho, int32_t Wo, void* stream);
+                              float* pool_partial, int32_t batch, int32_t c_out, int32_t c_in, int32_t kp, int32_t Ho,
+                              int32_t Wo, void* stream);
+/* hs_gemm_split_fwd without gate / residual, its (B,c_out,Ho,Wo) result stored nearest-2x upsampled: y (B,c_out,2Ho,2Wo), 8-byte
+ * aligned.  The context head's last merge writes straight into the right half of the signal (hyperseg_v1_0.py:409-410: neither
+ * the upsampled tensor nor the concatenation is built). */
+int hs_gemm_split_up2_fwd(const void* w_frag, const float* w_inv, const float* x, const float* shift, int32_t act, float* y,
+                          int32_t batch, int32_t c_out, int32_t c_in, int32_t kp, int32_t Ho, int32_t Wo, void* stream);
+/* shift_out[m] = shift[m] + sum_c wb[m][c] * (inv_pixels * sum_j partial[c][j]), partial (channels, nblk) as written by
+ * hs_gemm_split_conv2x2_fwd for ONE frame, wb (rows, channels): where the context head concatenates a feature map with its own
+ * global average (hyperseg_v1_0.py:404-409) the pooled half contributes a per-row constant to the following 1x1 convolution --
+ * this is that constant folded into the BatchNorm shift (mean + mat-vec in one launch).  channels <= 8192. */
+int hs_pooled_shift_fwd(const float* partial, int32_t nblk, float inv_pixels, const float* wb, const float* shift,
+                        float* shift_out, int32_t rows, int32_t channels, void* stream);
 
 /* Materialises a stage input (B, 2*coords + c_skip + c_prev, H, W); test/diagnostic twin of the
  * fused prologue (the product path never calls it). */

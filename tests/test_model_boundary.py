@@ -320,16 +320,35 @@ def test_deferred_bn_shift_algebra_cpu(monkeypatch, config, split):
         assert out.shape == y.shape
         return out.copy_(y)
 
-    def gemm_split_conv2x2(sw, x, shift=None, act=0, out=None):                              # K = 4 Cin in the conv weight's flatten order
+    def weight_of(sw):
         rt = sw.frag.shape[0]
         back = sw.frag.permute(2, 0, 4, 1, 3, 5).reshape(2, 16 * rt, sw.kp).float()
-        w = ((back[0] + back[1]) * sw.inv[:, None])[:sw.c_out, :sw.c_in].reshape(sw.c_out, x.shape[1], 2, 2)
-        y = F.conv2d(x, w, stride=2)
+        return ((back[0] + back[1]) * sw.inv[:, None])[:sw.c_out, :sw.c_in]
+
+    def gemm_split_conv2x2(sw, x, shift=None, act=0, out=None, pool_partial=None):           # K = 4 Cin in the conv weight's flatten order
+        y = F.conv2d(x, weight_of(sw).reshape(sw.c_out, x.shape[1], 2, 2), stride=2)
+        y = act_of(y if shift is None else y + shift.view(1, -1, 1, 1), act)
         used['conv2x2'] = used.get('conv2x2', 0) + 1
-        return act_of(y if shift is None else y + shift.view(1, -1, 1, 1), act)
+        if pool_partial is not None:                                                         # sums over blocks of 16 pixels
+            flat = y.flatten(2)
+            flat = F.pad(flat, (0, pool_partial.shape[2] * 16 - flat.shape[2]))
+            pool_partial.copy_(flat.view(*pool_partial.shape, 16).sum(-1))
+        return y
+
+    def gemm_split_up2(sw, x, shift=None, act=0, out=None):
+        y = F.conv2d(x, weight_of(sw)[:, :, None, None])
+        y = act_of(y if shift is None else y + shift.view(1, -1, 1, 1), act)
+        used['up2'] = used.get('up2', 0) + 1
+        return out.copy_(F.interpolate(y, scale_factor=2, mode='nearest'))
+
+    def pooled_shift(pool_partial, pixels, wb, shift):
+        used['pooled_shift'] = used.get('pooled_shift', 0) + 1
+        return shift + wb @ (pool_partial[0].sum(1) / pixels)
 
     monkeypatch.setattr(HF, 'gemm_split', gemm_split)
     monkeypatch.setattr(HF, 'gemm_split_conv2x2', gemm_split_conv2x2)
+    monkeypatch.setattr(HF, 'gemm_split_up2', gemm_split_up2)
+    monkeypatch.setattr(HF, 'pooled_shift', pooled_shift)
     monkeypatch.setattr(HF, 'mbconv_expand_dw', expand_dw)
     monkeypatch.setattr(HF, 'depthwise_conv_bn_act', dw)
     monkeypatch.setattr(HF, 'se_gate', se_gate)
@@ -366,7 +385,8 @@ def test_deferred_bn_shift_algebra_cpu(monkeypatch, config, split):
             with torch.no_grad():
                 assert rel_err(fused.weight_mapper._fused(feats[-1].contiguous()), stock.weight_mapper(ref[-1])) < 2e-5
             if split and feats[-1].shape[3] % 4 == 0:
-                assert used.get('conv2x2', 0) >= 1              # the head's 2x2 / stride-2 down blocks take the windowed GEMM
+                assert used.get('conv2x2', 0) >= 1              # the head's 2x2 / stride-2 down blocks take the windowed GEMM,
+                assert used.get('pooled_shift', 0) >= 1 and used.get('up2', 0) >= 1     # its pool and its upsample ride along
 
 
 def test_patch_ir_routes():

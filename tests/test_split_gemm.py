@@ -130,8 +130,42 @@ def test_gemm_split_conv2x2_vs_float64(m, c, hw, batch):
     ya = HF.gemm_split_conv2x2(sw, x, shift=shift, act=HF.ACT_RELU)
     assert rel_err(ya.double().cpu(), torch.relu(ref + shift.double().view(1, -1, 1, 1)).cpu()) < 2e-6
     assert HF.gemm_split_weights(w, scale) is None or 4 * c <= 1280             # the 1x1 form stops at K = 1280
+    # the global average of the result rides along as sums over blocks of 16 pixels; folded into a shift by hs_pooled_shift_fwd
+    if batch == 1:
+        p = (hw[0] // 2) * (hw[1] // 2)
+        part = torch.full((1, m, -(-p // 16)), float('nan'), device=dev)
+        yp = HF.gemm_split_conv2x2(sw, x, shift=shift, act=HF.ACT_RELU, pool_partial=part)
+        assert torch.equal(yp, ya)
+        mean = yp.double().mean((2, 3)).view(m)
+        assert rel_err(part.double().sum(2).view(m).cpu() / p, mean.cpu()) < 1e-6
+        wb = torch.randn(24, m, generator=g).to(dev)
+        base = torch.randn(24, generator=g).to(dev)
+        got = HF.pooled_shift(part, p, wb, base)
+        assert rel_err(got.double().cpu(), (base.double() + wb.double() @ mean).cpu()) < 1e-6
     with pytest.raises(ValueError):
         HF.gemm_split_conv2x2(sw, x[:, :, :, :hw[1] - 2].contiguous())          # width must be a multiple of 4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('m,k,hw,batch', [(640, 640, (8, 16), 1), (40, 96, (5, 6), 2), (320, 1152, (16, 32), 1)])
+def test_gemm_split_up2_vs_float64(m, k, hw, batch):
+    """1x1 conv + shift + ReLU stored nearest-2x upsampled (hs_gemm_split_up2_fwd), into a channel slice of a larger tensor."""
+    import torch.nn.functional as F
+    from hyperseg_amd import functional as HF
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(m * k)
+    w = (torch.randn(m, k, generator=g) / k ** 0.5).to(dev)
+    x = torch.randn(batch, k, *hw, generator=g).to(dev)
+    shift = torch.randn(m, generator=g).to(dev)
+    sw = HF.gemm_split_weights(w)
+    ref = F.interpolate(torch.relu(torch.einsum('ok,bkn->bon', w.double(), x.flatten(2).double()).view(batch, m, *hw)
+                                   + shift.double().view(1, -1, 1, 1)), scale_factor=2, mode='nearest')
+    y = HF.gemm_split_up2(sw, x, shift=shift, act=HF.ACT_RELU)
+    assert y.shape == ref.shape and rel_err(y.double().cpu(), ref.cpu()) < 2e-6
+    if batch == 1:
+        big = torch.zeros(1, m + 8, 2 * hw[0], 2 * hw[1], device=dev)
+        HF.gemm_split_up2(sw, x, shift=shift, act=HF.ACT_RELU, out=big[:, 8:])
+        assert torch.equal(big[:, 8:], y) and float(big[:, :8].abs().max()) == 0.0
 
 
 @pytest.mark.gpu
