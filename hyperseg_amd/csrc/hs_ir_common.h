@@ -43,4 +43,11 @@ __device__ __forceinline__ float relu6_(float v) { return fminf(fmaxf(v, 0.0f), 
 // hs_patch_ir_px.hip: Op D, one lane per pixel, for the narrow HyperSeg-L levels; 1 = no instantiation
 int try_launch_ir_px(IrFusedArgs& a, int cin, int c_skip, int c_out, hipStream_t stream);
 
+// hs_patch_ir_d2.hip: Op D for 4 x 4 / 8 x 8-pixel patches in two launches with the hidden map (channels-last) in the caller's
+// workspace; ird_workspace_bytes = 0 and try_launch_ird = 1 when the shape is not covered
+size_t ird_workspace_bytes(const StageIn& si, int fh, int fw, int cin, int hid, int c_out);
+int try_launch_ird(const StageIn& si, int fh, int fw, const float* bank, long ld, int cin, int hid, int c_out,
+                   const float* s1, const float* b1, const float* s2, const float* b2, const float* s3, const float* b3,
+                   float* workspace, size_t workspace_bytes, float* y, hipStream_t stream);
+
 }  // namespace hs

@@ -202,6 +202,10 @@ int try_launch_ir_fused(int mode, const StageIn& in, int fh, int fw, const float
 int try_launch_irc(const StageIn& in, int fh, int fw, const float* bank, long ld, int hid, int c_out,
                    const float* s1, const float* b1, const float* s2, const float* b2, const float* s3, const float* b3,
                    float* y, hipStream_t stream);                                           // hs_patch_irc.hip
+size_t ird_workspace_bytes(const StageIn& si, int fh, int fw, int cin, int hid, int c_out);  // hs_patch_ir_d2.hip
+int try_launch_ird(const StageIn& si, int fh, int fw, const float* bank, long ld, int cin, int hid, int c_out,
+                   const float* s1, const float* b1, const float* s2, const float* b2, const float* s3, const float* b3,
+                   float* workspace, size_t workspace_bytes, float* y, hipStream_t stream);
 
 }  // namespace hs
 
@@ -289,10 +293,24 @@ extern "C" int hs_patch_ir_route(const hs_stage_input* in, int32_t fh, int32_t f
 
 // Op D, fused form only (the decoder's own shapes); anything else returns HS_ERR_UNSUPPORTED and the caller runs the
 // block as three hs_patch_conv_fwd launches (pw1, depthwise, pw3), which is what the reference's module structure is.
+extern "C" int64_t hs_patch_ir_v0_workspace(const hs_stage_input* in, int32_t fh, int32_t fw, int32_t hidden, int32_t c_out) {
+    StageIn si;
+    if (make_stage(in, &si) != HS_OK || fh <= 0 || fw <= 0 || hidden <= 0 || c_out <= 0) return 0;
+    return (int64_t)ird_workspace_bytes(si, fh, fw, si.cin(), hidden, c_out);
+}
+
 extern "C" int hs_patch_ir_v0_fwd(const hs_stage_input* in, int32_t fh, int32_t fw, const float* bank, int64_t ld,
                                   int32_t hidden, int32_t c_out, const hs_epilogue* bn1, const hs_epilogue* bn2,
                                   const hs_epilogue* bn3, int32_t math, float* y, void* stream) {
+    return hs_patch_ir_v0_ws_fwd(in, fh, fw, bank, ld, hidden, c_out, bn1, bn2, bn3, math, nullptr, 0, y, stream);
+}
+
+extern "C" int hs_patch_ir_v0_ws_fwd(const hs_stage_input* in, int32_t fh, int32_t fw, const float* bank, int64_t ld,
+                                     int32_t hidden, int32_t c_out, const hs_epilogue* bn1, const hs_epilogue* bn2,
+                                     const hs_epilogue* bn3, int32_t math, float* workspace, int64_t workspace_bytes, float* y,
+                                     void* stream) {
     if (math < HS_IR_MATH_AUTO || math > HS_IR_MATH_SPLIT) return HS_ERR_BAD_ARG;   // Op D: every mode runs the exact-f32 kernels
+    if (workspace_bytes < 0 || (workspace_bytes > 0 && !workspace)) return HS_ERR_BAD_ARG;
     StageIn si;
     int st = make_stage(in, &si);
     if (st != HS_OK) return st;
@@ -303,6 +321,11 @@ extern "C" int hs_patch_ir_v0_fwd(const hs_stage_input* in, int32_t fh, int32_t 
     const int cin = si.cin();
     if (ld < (int64_t)cin * hidden + 9 * hidden + (int64_t)hidden * c_out) return HS_ERR_BAD_ARG;
     if (!(in->coords && si.prev_mode == HS_PREV_BILINEAR)) return HS_ERR_UNSUPPORTED;
+    if (workspace) {                       // small patches: two launches through the caller's hidden map (hs_patch_ir_d2.hip)
+        const int rd = try_launch_ird(si, fh, fw, bank, (long)ld, cin, hidden, c_out, bn1->scale, bn1->shift, bn2->scale, bn2->shift,
+                                      bn3->scale, bn3->shift, workspace, (size_t)workspace_bytes, y, (hipStream_t)stream);
+        if (rd != 1) return rd;
+    }
     const int r = try_launch_ir_fused(1, si, fh, fw, bank, (long)ld, cin, in->c_skip, hidden, c_out, bn1->scale, bn1->shift,
                                       bn2->scale, bn2->shift, bn3->scale, bn3->shift, y, (hipStream_t)stream);
     return r == 1 ? HS_ERR_UNSUPPORTED : r;

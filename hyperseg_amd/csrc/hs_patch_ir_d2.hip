@@ -1,0 +1,257 @@
+// Op D (hyperseg_v0_1.py:205-237) for the SMALL-PATCH levels of HyperSeg-L -- level 2 (48 -> 96 -> 12 channels on the 64 x 64 map,
+// 4 x 4-pixel patches) and level 3 (22 -> 44 -> 8 on 128 x 128, 8 x 8 patches) -- as the reference states it: three image-level
+// patch convolutions, in TWO launches with the hidden map in HBM between them.
+//
+// Why not one launch: a depthwise tap that crosses a patch edge reads a hidden activation computed with the NEIGHBOUR's W1.  The
+// tiled kernel (hs_patch_ir_fused.hip, MODE 1) recomputes that ring per 16 x 16 region with per-position owner lookups -- at these
+// levels every region spans 4 / 16 patches and its ring 12 / 20 more, W1 is 56-70 % of a bank row, and the launch sits at 6-10 % of
+// its HBM floor (197 / 307 us per bs-32 batch, profiles/round2_decoder_L_kernel_stats.csv).  Writing h1 once costs 50 / 100 MB of
+// the ~350 / 300 MB a batch moves here anyway (the level-2 bank alone is 220 MB: 27 KB of weights for 16 pixels), and both halves
+// become what these levels really are: a stream of small per-patch GEMMs whose N dimension IS the patch --
+//   16 pixels = one 16-column MFMA tile (4 x 4 patches: one tile per patch, 8 x 8: four tiles sharing the A fragments).
+//
+// pass 1  h1 = relu6(bn1(W1[patch] . x)),  x = cat(coords, skip, bilinear2x(prev)) assembled per lane, branch-free (every candidate
+//         load issued, the channel's kind selected afterwards); wave = patch, v_mfma_f32_16x16x4_f32 with A = the bank row's W1
+//         straight from HBM into registers -- each weight is used exactly once per patch, LDS would only add a hop.  A lane fetches
+//         4 consecutive k of its row in one load; MFMA j then multiplies k-set {16 q + 4 kgroup + j}, B is assembled to match.
+//         h1 is stored CHANNELS-LAST (B, H, W, hid rounded up to 16): the lane's four accumulator rows are four consecutive channels
+//         = one 16-byte store, and exactly the unit pass 2 reads.
+// pass 2  h2 = relu6(bn2(dw3x3 reflect (own patch's taps))) for (pixel, 4 channels) per lane -- 9 x 16-byte loads of h1 -- which IS
+//         the B fragment of y = bn3(W3[patch] . h2): 4 MFMAs per 16 hidden channels, A = W3 rows as 16-byte loads.
+// Exact f32.  The hidden map comes from the caller (hs_patch_ir_v0_ws_fwd's workspace): the library owns no global state.
+#include "hs_ir_common.h"
+
+namespace hs {
+
+using d2_f32x4 = __attribute__((ext_vector_type(4))) float;
+using d2_f32x2 = __attribute__((ext_vector_type(2))) float;
+
+struct IrdArgs {
+    StageIn in;
+    const float* __restrict__ bank;
+    long ld;
+    int fh, fw, cin, hid, cout, hidp;
+    const float* __restrict__ s1; const float* __restrict__ b1;
+    const float* __restrict__ s2; const float* __restrict__ b2;
+    const float* __restrict__ s3; const float* __restrict__ b3;
+    float* __restrict__ h1;                // (B, H, W, hidp)
+    float* __restrict__ y;                 // (B, cout, H, W)
+};
+
+// lane n of a 16-pixel tile t of a PW x PW patch -> position inside the patch
+template <int PW> __device__ __forceinline__ void d2_pixel(int t, int n, int& ly, int& lx) {
+    if constexpr (PW == 4) { ly = n >> 2; lx = n & 3; }
+    else { ly = 2 * t + (n >> 3); lx = n & 7; }
+}
+
+// 4 consecutive floats at p (AL = the alignment the host guarantees, in floats)
+template <int AL> __device__ __forceinline__ d2_f32x4 d2_load4(const float* __restrict__ p) {
+    if constexpr (AL == 4) return *reinterpret_cast<const d2_f32x4*>(p);
+    else if constexpr (AL == 2) {
+        const d2_f32x2 lo = *reinterpret_cast<const d2_f32x2*>(p), hi = *reinterpret_cast<const d2_f32x2*>(p + 2);
+        return d2_f32x4{lo[0], lo[1], hi[0], hi[1]};
+    } else return d2_f32x4{p[0], p[1], p[2], p[3]};
+}
+
+// RT 16-row tiles of hidden channels, KQ 16-deep k blocks of input channels; 4 waves = 4 patches next to each other along x
+template <int PW, int RT, int KQ, int AL>
+__global__ __launch_bounds__(256)
+void ird_pw1_kernel(IrdArgs a) {
+    constexpr int NT = PW * PW / 16;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 15, kg = lane >> 4;
+    const int pj = blockIdx.x * 4 + wave, pi = blockIdx.y, b = blockIdx.z;
+    if (pj >= a.fw) return;                                             // no barrier in this kernel: a wave may leave alone
+    const StageIn& s = a.in;
+    const float* __restrict__ w1 = a.bank + (size_t)((b * a.fh + pi) * a.fw + pj) * (size_t)a.ld;
+    const int kq_max = AL == 1 ? a.cin - 1 : a.cin - AL;               // last k a vector piece may start at
+
+    // ---- A fragments of the whole patch: row 16 rt + n, k = 16 q + 4 kg .. + 3 (clamped; the matching B values are zero)
+    d2_f32x4 aw[RT][KQ];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const float* __restrict__ row = w1 + (size_t)min(16 * rt + n, a.hid - 1) * a.cin;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            const int k0 = 16 * q + 4 * kg;
+            if constexpr (AL == 4) aw[rt][q] = d2_load4<4>(row + min(k0, kq_max));
+            else if constexpr (AL == 2) {
+                const d2_f32x2 lo = *reinterpret_cast<const d2_f32x2*>(row + min(k0, kq_max));
+                const d2_f32x2 hi = *reinterpret_cast<const d2_f32x2*>(row + min(k0 + 2, kq_max));
+                aw[rt][q] = d2_f32x4{lo[0], lo[1], hi[0], hi[1]};
+            } else {
+                aw[rt][q] = d2_f32x4{row[min(k0, kq_max)], row[min(k0 + 1, kq_max)], row[min(k0 + 2, kq_max)], row[min(k0 + 3, kq_max)]};
+            }
+        }
+    }
+
+    const int ncoord = 2 * s.coords;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int ly, lx;
+        d2_pixel<PW>(t, n, ly, lx);
+        const int Y = pi * PW + ly, X = pj * PW + lx;
+        const Tap ty = bilinear_tap(Y, s.scale_y, s.Hp), tx = bilinear_tap(X, s.scale_x, s.Wp);
+        const float cx = linspace_pm1(X, s.W, s.step_x), cy = linspace_pm1(Y, s.H, s.step_y);
+        const float* __restrict__ sk = s.skip + (size_t)b * s.c_skip * s.H * s.W + (size_t)Y * s.W + X;
+        const float* __restrict__ pv = s.prev + (size_t)b * s.c_prev * s.Hp * s.Wp;
+        const int o00 = ty.i0 * s.Wp + tx.i0, o01 = ty.i0 * s.Wp + tx.i1, o10 = ty.i1 * s.Wp + tx.i0, o11 = ty.i1 * s.Wp + tx.i1;
+        // every candidate of every k of this lane, requested before the first use
+        float vs[KQ][4], p00[KQ][4], p01[KQ][4], p10[KQ][4], p11[KQ][4];
+#pragma unroll
+        for (int q = 0; q < KQ; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 16 * q + 4 * kg + j;
+                const int cs = min(max(k - ncoord, 0), s.c_skip - 1), cp = min(max(k - ncoord - s.c_skip, 0), s.c_prev - 1);
+                vs[q][j] = sk[(size_t)cs * s.H * s.W];
+                const float* __restrict__ pl = pv + (size_t)cp * s.Hp * s.Wp;
+                p00[q][j] = pl[o00]; p01[q][j] = pl[o01]; p10[q][j] = pl[o10]; p11[q][j] = pl[o11];
+            }
+        d2_f32x4 acc[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = d2_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < KQ; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 16 * q + 4 * kg + j;
+                const float top = tx.l0 * p00[q][j] + tx.l1 * p01[q][j], bot = tx.l0 * p10[q][j] + tx.l1 * p11[q][j];
+                const float up = ty.l0 * top + ty.l1 * bot;              // stage_value's expression (hs_common.h)
+                float v = k < ncoord ? (k == 0 ? cx : cy) : (k - ncoord < s.c_skip ? vs[q][j] : up);
+                v = k < a.cin ? v : 0.0f;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[rt][q][j], v, acc[rt], 0, 0, 0);
+            }
+        // ---- BN1 + ReLU6, channels-last: D row 4 kg + r of tile rt = channel 16 rt + 4 kg + r of pixel n
+        float* __restrict__ dst = a.h1 + ((size_t)(b * s.H + Y) * s.W + X) * a.hidp + 4 * kg;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            d2_f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = min(16 * rt + 4 * kg + r, a.hid - 1);     // BatchNorm rows: L1-resident after the first patch
+                const float v = fminf(fmaxf(fmaf(acc[rt][r], a.s1[c], a.b1[c]), 0.0f), 6.0f);
+                o[r] = 16 * rt + 4 * kg + r < a.hid ? v : 0.0f;
+            }
+            if (16 * rt < a.hidp) *reinterpret_cast<d2_f32x4*>(dst + 16 * rt) = o;
+        }
+    }
+}
+
+// KQ 16-deep blocks of hidden channels (hidp = 16 KQ); cout <= 16.  k block outer (its taps, BN2 rows and W3 quads fetched once),
+// tiles inner (four accumulators at 8 x 8 patches).
+template <int PW, int KQ>
+__global__ __launch_bounds__(256)
+void ird_dw_pw3_kernel(IrdArgs a) {
+    constexpr int NT = PW * PW / 16;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 15, kg = lane >> 4;
+    const int pj = blockIdx.x * 4 + wave, pi = blockIdx.y, b = blockIdx.z;
+    if (pj >= a.fw) return;                                             // no barrier in this kernel: a wave may leave alone
+    const int H = a.in.H, W = a.in.W;
+    const float* __restrict__ wt = a.bank + (size_t)((b * a.fh + pi) * a.fw + pj) * (size_t)a.ld;
+    const float* __restrict__ taps = wt + (size_t)a.cin * a.hid;
+    const float* __restrict__ w3 = taps + 9 * (size_t)a.hid + (size_t)min(n, a.cout - 1) * a.hid;     // this lane's A row
+    const float* __restrict__ hb = a.h1 + (size_t)b * H * W * a.hidp + 4 * kg;
+    // the 3 x 3 neighbourhood of the lane's pixel in every tile (reflect at the image border), as h1 pixel offsets
+    unsigned pos[NT][9];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int ly, lx;
+        d2_pixel<PW>(t, n, ly, lx);
+        const int Y = pi * PW + ly, X = pj * PW + lx;
+        const int ym = Y > 0 ? Y - 1 : 1, yp = Y < H - 1 ? Y + 1 : H - 2, xm = X > 0 ? X - 1 : 1, xp = X < W - 1 ? X + 1 : W - 2;
+        const int ys[3] = {ym, Y, yp}, xs[3] = {xm, X, xp};
+#pragma unroll
+        for (int i = 0; i < 9; ++i) pos[t][i] = (unsigned)(ys[i / 3] * W + xs[i % 3]) * (unsigned)a.hidp;
+    }
+    d2_f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = d2_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+        const int c4 = min(16 * q + 4 * kg, a.hid - 4);                // hid % 4 == 0 (host); beyond it h2 is masked to zero
+        d2_f32x4 tp[9];                                                // taps[c4 .. c4 + 3][ky][kx]: 36 consecutive floats
+#pragma unroll
+        for (int i = 0; i < 9; ++i) tp[i] = *reinterpret_cast<const d2_f32x4*>(taps + 9 * c4 + 4 * i);
+        const d2_f32x4 w3v = *reinterpret_cast<const d2_f32x4*>(w3 + c4);
+        float s2v[4], b2v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s2v[j] = a.s2[c4 + j]; b2v[j] = a.b2[c4 + j]; }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            d2_f32x4 hv[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) hv[i] = *reinterpret_cast<const d2_f32x4*>(hb + pos[t][i] + 16 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float h = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) h = fmaf(tp[(9 * j + i) >> 2][(9 * j + i) & 3], hv[i][j], h);
+                h = fminf(fmaxf(fmaf(h, s2v[j], b2v[j]), 0.0f), 6.0f);
+                h = 16 * q + 4 * kg + j < a.hid ? h : 0.0f;
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3v[j], h, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    float s3v[4], b3v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int o = min(4 * kg + r, a.cout - 1); s3v[r] = a.s3[o]; b3v[r] = a.b3[o]; }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int ly, lx;
+        d2_pixel<PW>(t, n, ly, lx);
+        float* __restrict__ yb = a.y + (size_t)b * a.cout * H * W + (size_t)(pi * PW + ly) * W + pj * PW + lx;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * kg + r < a.cout) yb[(size_t)(4 * kg + r) * H * W] = fmaf(acc[t][r], s3v[r], b3v[r]);
+    }
+}
+
+}  // namespace hs
+
+using namespace hs;
+
+// 0 = launched, 1 = not covered (the caller falls through to the single-launch kernels), else an error code.  Coverage: square
+// patches of 4 or 8 pixels, coords + skip + bilinear prev, cin <= 48 and even, hid <= 96 and % 4 == 0, cout <= 16, no residual
+// (cin != cout), 16-byte aligned bank rows.  workspace: B H W hidp floats (hs_patch_ir_v0_workspace).
+size_t hs::ird_workspace_bytes(const StageIn& si, int fh, int fw, int cin, int hid, int c_out) {
+    if (fh <= 0 || fw <= 0 || si.H % fh || si.W % fw) return 0;
+    const int ph = si.H / fh, pw = si.W / fw;
+    if (ph != pw || (pw != 4 && pw != 8)) return 0;
+    if (!si.coords || si.prev_mode != HS_PREV_BILINEAR || si.c_skip < 1 || si.c_prev < 1) return 0;
+    if (cin > 48 || (cin & 1) || hid > 96 || (hid & 3) || hid < 4 || c_out > 16 || cin == c_out || cin < 2) return 0;
+    if (si.H < 2 || si.W < 2 || fh > 65535 || si.B > 65535) return 0;
+    const int hidp = (hid + 15) & ~15;
+    return (size_t)si.B * si.H * si.W * hidp * sizeof(float);
+}
+
+int hs::try_launch_ird(const StageIn& si, int fh, int fw, const float* bank, long ld, int cin, int hid, int c_out,
+                       const float* s1, const float* b1, const float* s2, const float* b2, const float* s3, const float* b3,
+                       float* workspace, size_t workspace_bytes, float* y, hipStream_t stream) {
+    const size_t need = ird_workspace_bytes(si, fh, fw, cin, hid, c_out);
+    if (need == 0 || !workspace || workspace_bytes < need) return 1;
+    if ((ld & 3) || (((size_t)bank) & 15) || (((size_t)workspace) & 15)) return 1;
+    const int pw = si.W / fw, hidp = (hid + 15) & ~15;
+    IrdArgs a{si, bank, ld, fh, fw, cin, hid, c_out, hidp, s1, b1, s2, b2, s3, b3, workspace, y};
+    const dim3 grid((fw + 3) / 4, fh, si.B), block(256);
+    const int al = (cin & 3) == 0 ? 4 : 2;                              // cin even (hid = expand * cin is a multiple of 4)
+    const bool big = hid > 48 || cin > 32;                              // (RT, KQ) = (6, 3), else (3, 2)
+#define HS_D2A(PWV, RTV, KQV, ALV) hipLaunchKernelGGL((ird_pw1_kernel<PWV, RTV, KQV, ALV>), grid, block, 0, stream, a)
+#define HS_D2B(PWV, RTV, KQV) do { if (al == 4) HS_D2A(PWV, RTV, KQV, 4); else HS_D2A(PWV, RTV, KQV, 2); } while (0)
+    if (pw == 4) { if (big) HS_D2B(4, 6, 3); else HS_D2B(4, 3, 2); }
+    else { if (big) HS_D2B(8, 6, 3); else HS_D2B(8, 3, 2); }
+#undef HS_D2B
+#undef HS_D2A
+    int st = launch_status();
+    if (st != HS_OK) return st;
+#define HS_D2C(PWV, KQV) hipLaunchKernelGGL((ird_dw_pw3_kernel<PWV, KQV>), grid, block, 0, stream, a)
+    const int kq = hidp / 16;
+    if (pw == 4) { switch (kq) { case 1: HS_D2C(4, 1); break; case 2: HS_D2C(4, 2); break; case 3: HS_D2C(4, 3); break; case 4: HS_D2C(4, 4); break;
+                                 case 5: HS_D2C(4, 5); break; default: HS_D2C(4, 6); break; } }
+    else { switch (kq) { case 1: HS_D2C(8, 1); break; case 2: HS_D2C(8, 2); break; case 3: HS_D2C(8, 3); break; case 4: HS_D2C(8, 4); break;
+                         case 5: HS_D2C(8, 5); break; default: HS_D2C(8, 6); break; } }
+#undef HS_D2C
+    return launch_status();
+}

@@ -396,10 +396,15 @@ def patch_ir(x, grid, bank, hidden, c_out, bn1, bn2, bn3, residual=False, math=N
     return y
 
 
+D2_ROUTE = os.environ.get('HS_IR_D2', '1') != '0'      # A/B switch: 0 = small-patch Op D levels on the single-launch tiled kernel
+
+
 @_on_operand_device
 def patch_ir_v0(x, grid, bank, hidden, c_out, bn1, bn2, bn3, math=None):
-    """Op D (hyperseg_v0_1.py:205-237) as one launch; returns None when the shape has no fused instantiation (the caller
-    then runs the block as three patch convolutions).  ``math`` as for :func:`patch_ir` (Op D has the exact-f32 form only)."""
+    """Op D (hyperseg_v0_1.py:205-237) as one launch -- two through a scratch hidden map where patches are 4 x 4 / 8 x 8 pixels
+    (hs_patch_ir_v0_ws_fwd; the scratch is a torch allocation of this call: the caching allocator hands the same block back every
+    step, and under graph capture it belongs to the graph's pool); returns None when the shape has no fused instantiation (the
+    caller then runs the block as three patch convolutions).  ``math`` as for :func:`patch_ir` (Op D has the exact-f32 form only)."""
     stage = as_stage(x)
     fh, fw = grid
     b, _, h, w = stage.shape
@@ -407,11 +412,14 @@ def patch_ir_v0(x, grid, bank, hidden, c_out, bn1, bn2, bn3, math=None):
     e1, e2, e3 = _epilogue(*bn1), _epilogue(*bn2), _epilogue(*bn3)
     y = torch.empty(b, c_out, h, w, device=stage.device, dtype=torch.float32)
     bank_ptr, ld = _bank_ptr(bank)
-    st = _hip.lib.hs_patch_ir_v0_fwd(C.byref(st_in), fh, fw, bank_ptr, ld, hidden, c_out,
-                                     C.byref(e1), C.byref(e2), C.byref(e3), ir_math_code(math), y.data_ptr(), _hip.stream_ptr())
+    need = int(_hip.lib.hs_patch_ir_v0_workspace(C.byref(st_in), fh, fw, hidden, c_out)) if D2_ROUTE else 0
+    ws = torch.empty(need // 4, device=stage.device, dtype=torch.float32) if need > 0 else None
+    st = _hip.lib.hs_patch_ir_v0_ws_fwd(C.byref(st_in), fh, fw, bank_ptr, ld, hidden, c_out, C.byref(e1), C.byref(e2), C.byref(e3),
+                                        ir_math_code(math), ws.data_ptr() if ws is not None else None, need, y.data_ptr(),
+                                        _hip.stream_ptr())
     if st == -3:
         return None
-    _hip.check(st, 'hs_patch_ir_v0_fwd')
+    _hip.check(st, 'hs_patch_ir_v0_ws_fwd')
     return y
 
 

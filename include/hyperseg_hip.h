@@ -175,6 +175,17 @@ int hs_patch_ir_v0_fwd(const hs_stage_input* in, int32_t fh, int32_t fw,
                        const float* bank, int64_t ld, int32_t hidden, int32_t c_out,
                        const hs_epilogue* bn1, const hs_epilogue* bn2, const hs_epilogue* bn3,
                        int32_t math /* hs_ir_math */, float* y, void* stream);
+/* The same operator with a caller-owned workspace: where patches are 4 x 4 or 8 x 8 pixels (HyperSeg-L levels 2 and 3: every 16 x 16
+ * region would span 4-16 patches plus a ring of 12-20 more owners) it runs exactly as the reference states it -- pw1 + BN + ReLU6
+ * written once to the workspace (channels-last, hidden rounded up to 16), then depthwise + BN + ReLU6 + pw3 + BN -- two launches of
+ * per-patch matrix-core GEMMs whose 16-pixel N dimension is the patch (hs_patch_ir_d2.hip).  hs_patch_ir_v0_workspace: the bytes that
+ * form needs for this shape, 0 if the shape is not covered (then, or with workspace = NULL, this call equals hs_patch_ir_v0_fwd).
+ * The workspace is scratch: nothing is kept in it between calls, and the library holds no state of its own. */
+int64_t hs_patch_ir_v0_workspace(const hs_stage_input* in, int32_t fh, int32_t fw, int32_t hidden, int32_t c_out);
+int hs_patch_ir_v0_ws_fwd(const hs_stage_input* in, int32_t fh, int32_t fw,
+                          const float* bank, int64_t ld, int32_t hidden, int32_t c_out,
+                          const hs_epilogue* bn1, const hs_epilogue* bn2, const hs_epilogue* bn3,
+                          int32_t math /* hs_ir_math */, float* workspace, int64_t workspace_bytes, float* y, void* stream);
 
 /* Arithmetic of the fused inverted-residual levels -- the `math` ARGUMENT of hs_patch_ir_fwd / hs_patch_ir_v0_fwd (chosen by
  * the caller per launch: the library keeps no mode, or any other mutable state, of its own):

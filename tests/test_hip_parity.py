@@ -395,6 +395,15 @@ OP_D_CASES = [
     dict(skip=6, prev=8, cout=6, patch=16, grid=(2, 3)),        # level 4: region == patch
     dict(skip=3, prev=6, cout=21, patch=32, grid=(1, 2)),       # level 5: 4 regions per patch
     dict(skip=6, prev=8, cout=6, patch=16, grid=(1, 1)),        # a single patch: every ring position is a reflection
+    # the two-launch form for 4 x 4 / 8 x 8 patches (hs_patch_ir_d2.hip): odd grids (a wave leaves its workgroup early), the level
+    # shapes at grids whose regions would not tile, channel counts off the level shapes, a 1 x 1 grid (reflection everywhere)
+    dict(skip=12, prev=34, cout=12, patch=4, grid=(3, 5)),
+    dict(skip=12, prev=34, cout=12, patch=4, grid=(8, 8)),
+    dict(skip=8, prev=12, cout=8, patch=8, grid=(3, 3)),
+    dict(skip=8, prev=16, cout=8, patch=8, grid=(2, 5)),        # 26 -> 52 channels: 8-byte weight loads, the wide instantiation
+    dict(skip=6, prev=10, cout=3, patch=4, grid=(5, 2)),
+    dict(skip=8, prev=12, cout=8, patch=8, grid=(1, 1)),
+    dict(skip=12, prev=34, cout=16, patch=8, grid=(2, 2)),      # level-2 channels on 8 x 8 patches (the wide instantiation)
 ]
 
 
@@ -450,8 +459,9 @@ def test_fused_op_d_vs_oracle(HF, O, dev, case, ir_math):
 
 
 def test_fused_op_d_falls_back_when_regions_do_not_tile(HF, O, dev):
-    """12 x 20 pixels at patch 4 do not tile into 8x8 regions: the module silently takes the three-launch route."""
-    case = dict(skip=12, prev=34, cout=12, patch=4, grid=(3, 5))
+    """12 x 20 pixels at patch 4 do not tile into 8x8 regions, and 56 input channels are beyond the two-launch form: the module
+    silently takes the three-launch route."""
+    case = dict(skip=20, prev=34, cout=12, patch=4, grid=(3, 5))
     m, skip, prev, wt, ref = _op_d_case(case, dev, O)
     with torch.no_grad():
         stage = HF.StageInput(skip.to(dev), prev.to(dev), coords=True)
