@@ -139,65 +139,132 @@ void ird_pw1_kernel(IrdArgs a) {
     }
 }
 
-// KQ 16-deep blocks of hidden channels (hidp = 16 KQ); cout <= 16.  k block outer (its taps, BN2 rows and W3 quads fetched once),
-// tiles inner (four accumulators at 8 x 8 patches).
+// KQ 16-deep blocks of hidden channels (hidp = 16 KQ); cout <= 16.  Workgroup = the 4 patches of pass 1 = a 4 PW x PW pixel region.
+// Per k block the region's halo (reflect-mapped at the image border) of 16 channels -- 64 contiguous bytes per pixel in the
+// channels-last map -- is staged into LDS by the whole workgroup with fully used loads (the first form had every lane fetch its own
+// nine neighbours: 16 different 64-byte segments per load instruction, 120 16-byte loads per lane, and the L1 return path alone
+// was 26 us of its 76), together with each patch's 144 taps of the block; both double-buffered one block ahead in registers.
+// LDS position stride 20 floats (5 granules: odd) and row pitch == PW (mod 16) positions: the 16 pixels of a tile read 16 distinct
+// granules (tools/lds_conflicts.py model).
+template <int PW> struct IrdP2 {
+    static constexpr int RW = 4 * PW, HWW = RW + 2, HH = PW + 2;
+    static constexpr int ROWP = PW == 4 ? 20 : 40;                       // >= HWW, == PW (mod 16)
+    static constexpr int PS = 20;                                        // floats per position (16 channels + 4 pad)
+    static constexpr int HBUF = HH * ROWP * PS;                          // floats per halo buffer
+    static constexpr int NE = HH * HWW * 4;                              // 16-byte pieces per k block
+    static constexpr int NLD = (NE + 255) / 256;                         // per thread
+    static constexpr int TBUF = 4 * 4 * 36;                              // taps: [wave][kg][36]
+    static constexpr int FLOATS = 2 * HBUF + 2 * TBUF;
+};
+
 template <int PW, int KQ>
 __global__ __launch_bounds__(256)
 void ird_dw_pw3_kernel(IrdArgs a) {
+    using P = IrdP2<PW>;
     constexpr int NT = PW * PW / 16;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    extern __shared__ __attribute__((aligned(16))) float d2_lds[];
+    float* hbuf = d2_lds;                       // [2][HH][ROWP][PS]
+    float* tbuf = d2_lds + 2 * P::HBUF;         // [2][wave][kg][36]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kg = lane >> 4;
     const int pj = blockIdx.x * 4 + wave, pi = blockIdx.y, b = blockIdx.z;
-    if (pj >= a.fw) return;                                             // no barrier in this kernel: a wave may leave alone
+    const bool live = pj < a.fw;                                        // block barriers below: a dead wave stays, its stores do not
     const int H = a.in.H, W = a.in.W;
-    const float* __restrict__ wt = a.bank + (size_t)((b * a.fh + pi) * a.fw + pj) * (size_t)a.ld;
+    const float* __restrict__ wt = a.bank + (size_t)((b * a.fh + pi) * a.fw + min(pj, a.fw - 1)) * (size_t)a.ld;
     const float* __restrict__ taps = wt + (size_t)a.cin * a.hid;
     const float* __restrict__ w3 = taps + 9 * (size_t)a.hid + (size_t)min(n, a.cout - 1) * a.hid;     // this lane's A row
-    const float* __restrict__ hb = a.h1 + (size_t)b * H * W * a.hidp + 4 * kg;
-    // the 3 x 3 neighbourhood of the lane's pixel in every tile (reflect at the image border), as h1 pixel offsets
-    unsigned pos[NT][9];
+    // ---- staging map: piece e = (halo pixel, 16-byte part); the pixel's image position through reflect padding
+    const float* __restrict__ hb = a.h1 + (size_t)b * H * W * a.hidp;
+    unsigned gofs[P::NLD], lofs[P::NLD];
+#pragma unroll
+    for (int i = 0; i < P::NLD; ++i) {
+        const int e = min(tid + 256 * i, P::NE - 1);
+        const int px = e >> 2, part = e & 3, hy = px / P::HWW, hx = px - hy * P::HWW;
+        int Y = pi * PW + hy - 1, X = blockIdx.x * P::RW + hx - 1;
+        Y = Y < 0 ? -Y : (Y > H - 1 ? 2 * (H - 1) - Y : Y);
+        X = X < 0 ? -X : (X > W - 1 ? 2 * (W - 1) - X : X);
+        X = min(max(X, 0), W - 1);                                      // columns of patches beyond the grid (fw % 4 != 0): any pixel
+        gofs[i] = (unsigned)(Y * W + X) * (unsigned)a.hidp + 4 * part;
+        lofs[i] = (hy * P::ROWP + hx) * P::PS + 4 * part;
+    }
+    auto fetch_h = [&](int q, d2_f32x4 (&r)[P::NLD]) {
+#pragma unroll
+        for (int i = 0; i < P::NLD; ++i) r[i] = *reinterpret_cast<const d2_f32x4*>(hb + gofs[i] + 16 * q);
+    };
+    auto store_h = [&](int buf, const d2_f32x4 (&r)[P::NLD]) {
+#pragma unroll
+        for (int i = 0; i < P::NLD; ++i)
+            if (tid + 256 * i < P::NE) *reinterpret_cast<d2_f32x4*>(hbuf + buf * P::HBUF + lofs[i]) = r[i];
+    };
+    // taps of block q for this lane's channel quad: 36 consecutive floats; lane n fetches piece min(n, 8)
+    auto tap_src = [&](int q) { return taps + 9 * min(16 * q + 4 * kg, a.hid - 4) + 4 * min(n, 8); };
+    float* tdst = tbuf + (wave * 4 + kg) * 36 + 4 * min(n, 8);
+
+    // per-block operands that stay in registers: the lane's W3 quad (A fragment) and BatchNorm-2 rows, fetched one block ahead too
+    auto fetch_w = [&](int q, d2_f32x4& w, d2_f32x4& sc, d2_f32x4& sh) {
+        const int c4 = min(16 * q + 4 * kg, a.hid - 4);                // hid % 4 == 0 (host); beyond it h2 is masked to zero
+        w = *reinterpret_cast<const d2_f32x4*>(w3 + c4);
+        sc = d2_f32x4{a.s2[c4], a.s2[c4 + 1], a.s2[c4 + 2], a.s2[c4 + 3]};
+        sh = d2_f32x4{a.b2[c4], a.b2[c4 + 1], a.b2[c4 + 2], a.b2[c4 + 3]};
+    };
+    d2_f32x4 hr[P::NLD], tr, w3n, s2n, b2n;
+    fetch_h(0, hr);
+    tr = *reinterpret_cast<const d2_f32x4*>(tap_src(0));
+    fetch_w(0, w3n, s2n, b2n);
+    // the 3 x 3 neighbourhood of the lane's pixel in every tile, as LDS offsets (halo position = region position + 1)
+    unsigned pos[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         int ly, lx;
         d2_pixel<PW>(t, n, ly, lx);
-        const int Y = pi * PW + ly, X = pj * PW + lx;
-        const int ym = Y > 0 ? Y - 1 : 1, yp = Y < H - 1 ? Y + 1 : H - 2, xm = X > 0 ? X - 1 : 1, xp = X < W - 1 ? X + 1 : W - 2;
-        const int ys[3] = {ym, Y, yp}, xs[3] = {xm, X, xp};
-#pragma unroll
-        for (int i = 0; i < 9; ++i) pos[t][i] = (unsigned)(ys[i / 3] * W + xs[i % 3]) * (unsigned)a.hidp;
+        pos[t] = (ly * P::ROWP + wave * PW + lx) * P::PS + 4 * kg;      // tap (dy, dx) adds (dy ROWP + dx) PS
     }
+    store_h(0, hr);
+    if (n < 9) *reinterpret_cast<d2_f32x4*>(tdst) = tr;
+    __syncthreads();
+
     d2_f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = d2_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
-        const int c4 = min(16 * q + 4 * kg, a.hid - 4);                // hid % 4 == 0 (host); beyond it h2 is masked to zero
-        d2_f32x4 tp[9];                                                // taps[c4 .. c4 + 3][ky][kx]: 36 consecutive floats
+        const d2_f32x4 w3v = w3n, s2v = s2n, b2v = b2n;
+        if (q + 1 < KQ) {                                              // next block's global requests first ...
+            fetch_h(q + 1, hr);
+            tr = *reinterpret_cast<const d2_f32x4*>(tap_src(q + 1));
+            fetch_w(q + 1, w3n, s2n, b2n);
+            __builtin_amdgcn_sched_barrier(0);                         // ... and they stay first (the scheduler sinks them to their use)
+        }
+        const float* hq = hbuf + (q & 1) * P::HBUF;
+        const float* tq = tbuf + (q & 1) * P::TBUF + (wave * 4 + kg) * 36;
+        d2_f32x4 tp[9];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) tp[i] = *reinterpret_cast<const d2_f32x4*>(taps + 9 * c4 + 4 * i);
-        const d2_f32x4 w3v = *reinterpret_cast<const d2_f32x4*>(w3 + c4);
-        float s2v[4], b2v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { s2v[j] = a.s2[c4 + j]; b2v[j] = a.b2[c4 + j]; }
+        for (int i = 0; i < 9; ++i) tp[i] = *reinterpret_cast<const d2_f32x4*>(tq + 4 * i);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             d2_f32x4 hv[9];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) hv[i] = *reinterpret_cast<const d2_f32x4*>(hb + pos[t][i] + 16 * q);
+            for (int i = 0; i < 9; ++i) hv[i] = *reinterpret_cast<const d2_f32x4*>(hq + pos[t] + ((i / 3) * P::ROWP + (i % 3)) * P::PS);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float h = 0.0f;
 #pragma unroll
-                for (int i = 0; i < 9; ++i) h = fmaf(tp[(9 * j + i) >> 2][(9 * j + i) & 3], hv[i][j], h);
+                for (int i = 0; i < 9; ++i) h = fmaf(tp[(9 * j + i) >> 2][(9 * j + i) & 3], hv[i][j], h);   // taps[c][ky][kx]
                 h = fminf(fmaxf(fmaf(h, s2v[j], b2v[j]), 0.0f), 6.0f);
                 h = 16 * q + 4 * kg + j < a.hid ? h : 0.0f;
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3v[j], h, acc[t], 0, 0, 0);
             }
         }
+        if (q + 1 < KQ) {
+            store_h((q + 1) & 1, hr);
+            if (n < 9) *reinterpret_cast<d2_f32x4*>(tdst + ((q + 1) & 1) * P::TBUF) = tr;
+            __syncthreads();                                           // one barrier per block: the other buffer was read a block ago
+        }
     }
     float s3v[4], b3v[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { const int o = min(4 * kg + r, a.cout - 1); s3v[r] = a.s3[o]; b3v[r] = a.b3[o]; }
+    if (!live) return;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         int ly, lx;
@@ -246,7 +313,7 @@ int hs::try_launch_ird(const StageIn& si, int fh, int fw, const float* bank, lon
 #undef HS_D2A
     int st = launch_status();
     if (st != HS_OK) return st;
-#define HS_D2C(PWV, KQV) hipLaunchKernelGGL((ird_dw_pw3_kernel<PWV, KQV>), grid, block, 0, stream, a)
+#define HS_D2C(PWV, KQV) hipLaunchKernelGGL((ird_dw_pw3_kernel<PWV, KQV>), grid, block, IrdP2<PWV>::FLOATS * sizeof(float), stream, a)
     const int kq = hidp / 16;
     if (pw == 4) { switch (kq) { case 1: HS_D2C(4, 1); break; case 2: HS_D2C(4, 2); break; case 3: HS_D2C(4, 3); break; case 4: HS_D2C(4, 4); break;
                                  case 5: HS_D2C(4, 5); break; default: HS_D2C(4, 6); break; } }
