@@ -53,18 +53,27 @@ template <int AL> __device__ __forceinline__ d2_f32x4 d2_load4(const float* __re
     } else return d2_f32x4{p[0], p[1], p[2], p[3]};
 }
 
-// RT 16-row tiles of hidden channels, KQ 16-deep k blocks of input channels; 4 waves = 4 patches next to each other along x
+// RT 16-row tiles of hidden channels, KQ 16-deep k blocks of input channels; 4 waves = 4 patches next to each other along x.
+// The previous level (exactly half the resolution: the host checks) reaches the lanes through LDS: the region's low-resolution window
+// -- PW/2 + 2 rows x 2 PW + 2 columns per channel, clamped at the image border exactly as the bilinear taps clamp -- is staged once
+// by the whole workgroup, and every bilinear corner is a ds_read_b32 (the first form fetched the four corners of every previous-level
+// channel of every pixel from global memory: 60-160 dependent-latency loads per lane at 2 waves per SIMD, 57 / 68 us).
+template <int PW> struct IrdP1 {
+    static constexpr int WROWS = PW / 2 + 2, WCOLS = 2 * PW + 2, WP = WROWS * WCOLS;
+};
+
 template <int PW, int RT, int KQ, int AL>
 __global__ __launch_bounds__(256)
 void ird_pw1_kernel(IrdArgs a) {
+    using P = IrdP1<PW>;
     constexpr int NT = PW * PW / 16;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    extern __shared__ __attribute__((aligned(16))) float d2_win[];        // [c_prev][WROWS][WCOLS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kg = lane >> 4;
     const int pj = blockIdx.x * 4 + wave, pi = blockIdx.y, b = blockIdx.z;
-    if (pj >= a.fw) return;                                             // no barrier in this kernel: a wave may leave alone
     const StageIn& s = a.in;
-    const float* __restrict__ w1 = a.bank + (size_t)((b * a.fh + pi) * a.fw + pj) * (size_t)a.ld;
-    const int kq_max = AL == 1 ? a.cin - 1 : a.cin - AL;               // last k a vector piece may start at
+    const float* __restrict__ w1 = a.bank + (size_t)((b * a.fh + pi) * a.fw + min(pj, a.fw - 1)) * (size_t)a.ld;
+    const int kq_max = a.cin - AL;                                      // last k a vector piece may start at
 
     // ---- A fragments of the whole patch: row 16 rt + n, k = 16 q + 4 kg .. + 3 (clamped; the matching B values are zero)
     d2_f32x4 aw[RT][KQ];
@@ -75,17 +84,58 @@ void ird_pw1_kernel(IrdArgs a) {
         for (int q = 0; q < KQ; ++q) {
             const int k0 = 16 * q + 4 * kg;
             if constexpr (AL == 4) aw[rt][q] = d2_load4<4>(row + min(k0, kq_max));
-            else if constexpr (AL == 2) {
+            else {
                 const d2_f32x2 lo = *reinterpret_cast<const d2_f32x2*>(row + min(k0, kq_max));
                 const d2_f32x2 hi = *reinterpret_cast<const d2_f32x2*>(row + min(k0 + 2, kq_max));
                 aw[rt][q] = d2_f32x4{lo[0], lo[1], hi[0], hi[1]};
-            } else {
-                aw[rt][q] = d2_f32x4{row[min(k0, kq_max)], row[min(k0 + 1, kq_max)], row[min(k0 + 2, kq_max)], row[min(k0 + 3, kq_max)]};
             }
         }
     }
-
+    // ---- the skip values of every tile (the only per-pixel global loads left), then the previous level's window
     const int ncoord = 2 * s.coords;
+    float vs[NT][KQ][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int ly, lx;
+        d2_pixel<PW>(t, n, ly, lx);
+        const float* __restrict__ sk = s.skip + (size_t)b * s.c_skip * s.H * s.W + (size_t)(pi * PW + ly) * s.W + min(pj * PW + lx, s.W - 1);
+#pragma unroll
+        for (int q = 0; q < KQ; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) vs[t][q][j] = sk[(size_t)min(max(16 * q + 4 * kg + j - ncoord, 0), s.c_skip - 1) * s.H * s.W];
+    }
+    const int wy0 = pi * (PW / 2) - 1, wx0 = blockIdx.x * (2 * PW) - 1;
+    {
+        const float* __restrict__ pv = s.prev + (size_t)b * s.c_prev * s.Hp * s.Wp;
+        const int total = s.c_prev * P::WP;
+        for (int base = 0; base < total; base += 1024) {                // 4 requests in flight per thread and round trip
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = min(base + tid + 256 * i, total - 1);
+                const int ch = e / P::WP, r = e - ch * P::WP, wy = r / P::WCOLS, wx = r - wy * P::WCOLS;
+                const int gy = min(max(wy0 + wy, 0), s.Hp - 1), gx = min(max(wx0 + wx, 0), s.Wp - 1);
+                v[i] = pv[((size_t)ch * s.Hp + gy) * s.Wp + gx];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (base + tid + 256 * i < total) d2_win[base + tid + 256 * i] = v[i];
+        }
+    }
+    __syncthreads();
+    if (pj >= a.fw) return;                                             // no barrier below: a wave beyond the grid leaves here
+    constexpr int RTB = NT > 1 ? RT : 1;                                // several tiles: the BatchNorm rows of the lane's channels
+    float s1v[RTB][4], b1v[RTB][4];                                     // 16 rt + 4 kg + r are fetched once (one tile: where they are used)
+    if constexpr (NT > 1) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = min(16 * rt + 4 * kg + r, a.hid - 1);
+                s1v[rt][r] = a.s1[c]; b1v[rt][r] = a.b1[c];
+            }
+    }
+
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         int ly, lx;
@@ -93,21 +143,8 @@ void ird_pw1_kernel(IrdArgs a) {
         const int Y = pi * PW + ly, X = pj * PW + lx;
         const Tap ty = bilinear_tap(Y, s.scale_y, s.Hp), tx = bilinear_tap(X, s.scale_x, s.Wp);
         const float cx = linspace_pm1(X, s.W, s.step_x), cy = linspace_pm1(Y, s.H, s.step_y);
-        const float* __restrict__ sk = s.skip + (size_t)b * s.c_skip * s.H * s.W + (size_t)Y * s.W + X;
-        const float* __restrict__ pv = s.prev + (size_t)b * s.c_prev * s.Hp * s.Wp;
-        const int o00 = ty.i0 * s.Wp + tx.i0, o01 = ty.i0 * s.Wp + tx.i1, o10 = ty.i1 * s.Wp + tx.i0, o11 = ty.i1 * s.Wp + tx.i1;
-        // every candidate of every k of this lane, requested before the first use
-        float vs[KQ][4], p00[KQ][4], p01[KQ][4], p10[KQ][4], p11[KQ][4];
-#pragma unroll
-        for (int q = 0; q < KQ; ++q)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = 16 * q + 4 * kg + j;
-                const int cs = min(max(k - ncoord, 0), s.c_skip - 1), cp = min(max(k - ncoord - s.c_skip, 0), s.c_prev - 1);
-                vs[q][j] = sk[(size_t)cs * s.H * s.W];
-                const float* __restrict__ pl = pv + (size_t)cp * s.Hp * s.Wp;
-                p00[q][j] = pl[o00]; p01[q][j] = pl[o01]; p10[q][j] = pl[o10]; p11[q][j] = pl[o11];
-            }
+        const int r0 = (ty.i0 - wy0) * P::WCOLS - wx0, r1 = (ty.i1 - wy0) * P::WCOLS - wx0;
+        const int o00 = r0 + tx.i0, o01 = r0 + tx.i1, o10 = r1 + tx.i0, o11 = r1 + tx.i1;
         d2_f32x4 acc[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[rt] = d2_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -116,9 +153,10 @@ void ird_pw1_kernel(IrdArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = 16 * q + 4 * kg + j;
-                const float top = tx.l0 * p00[q][j] + tx.l1 * p01[q][j], bot = tx.l0 * p10[q][j] + tx.l1 * p11[q][j];
+                const float* pl = d2_win + min(max(k - ncoord - s.c_skip, 0), s.c_prev - 1) * P::WP;
+                const float top = tx.l0 * pl[o00] + tx.l1 * pl[o01], bot = tx.l0 * pl[o10] + tx.l1 * pl[o11];
                 const float up = ty.l0 * top + ty.l1 * bot;              // stage_value's expression (hs_common.h)
-                float v = k < ncoord ? (k == 0 ? cx : cy) : (k - ncoord < s.c_skip ? vs[q][j] : up);
+                float v = k < ncoord ? (k == 0 ? cx : cy) : (k - ncoord < s.c_skip ? vs[t][q][j] : up);
                 v = k < a.cin ? v : 0.0f;
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[rt][q][j], v, acc[rt], 0, 0, 0);
@@ -130,8 +168,10 @@ void ird_pw1_kernel(IrdArgs a) {
             d2_f32x4 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int c = min(16 * rt + 4 * kg + r, a.hid - 1);     // BatchNorm rows: L1-resident after the first patch
-                const float v = fminf(fmaxf(fmaf(acc[rt][r], a.s1[c], a.b1[c]), 0.0f), 6.0f);
+                float sc, sh;
+                if constexpr (NT > 1) { sc = s1v[rt][r]; sh = b1v[rt][r]; }
+                else { const int c = min(16 * rt + 4 * kg + r, a.hid - 1); sc = a.s1[c]; sh = a.b1[c]; }
+                const float v = fminf(fmaxf(fmaf(acc[rt][r], sc, sh), 0.0f), 6.0f);
                 o[r] = 16 * rt + 4 * kg + r < a.hid ? v : 0.0f;
             }
             if (16 * rt < a.hidp) *reinterpret_cast<d2_f32x4*>(dst + 16 * rt) = o;
@@ -281,7 +321,7 @@ void ird_dw_pw3_kernel(IrdArgs a) {
 using namespace hs;
 
 // 0 = launched, 1 = not covered (the caller falls through to the single-launch kernels), else an error code.  Coverage: square
-// patches of 4 or 8 pixels, coords + skip + bilinear prev, cin <= 48 and even, hid <= 96 and % 4 == 0, cout <= 16, no residual
+// patches of 4 or 8 pixels, coords + skip + bilinear prev at exactly half the resolution, cin <= 48 and even, hid <= 96 and % 4 == 0, cout <= 16, no residual
 // (cin != cout), 16-byte aligned bank rows.  workspace: B H W hidp floats (hs_patch_ir_v0_workspace).
 size_t hs::ird_workspace_bytes(const StageIn& si, int fh, int fw, int cin, int hid, int c_out) {
     if (fh <= 0 || fw <= 0 || si.H % fh || si.W % fw) return 0;
@@ -289,7 +329,7 @@ size_t hs::ird_workspace_bytes(const StageIn& si, int fh, int fw, int cin, int h
     if (ph != pw || (pw != 4 && pw != 8)) return 0;
     if (!si.coords || si.prev_mode != HS_PREV_BILINEAR || si.c_skip < 1 || si.c_prev < 1) return 0;
     if (cin > 48 || (cin & 1) || hid > 96 || (hid & 3) || hid < 4 || c_out > 16 || cin == c_out || cin < 2) return 0;
-    if (si.H < 2 || si.W < 2 || fh > 65535 || si.B > 65535) return 0;
+    if (si.H < 2 || si.W < 2 || fh > 65535 || si.B > 65535 || si.Hp * 2 != si.H || si.Wp * 2 != si.W || si.c_prev > 128) return 0;
     const int hidp = (hid + 15) & ~15;
     return (size_t)si.B * si.H * si.W * hidp * sizeof(float);
 }
@@ -305,7 +345,7 @@ int hs::try_launch_ird(const StageIn& si, int fh, int fw, const float* bank, lon
     const dim3 grid((fw + 3) / 4, fh, si.B), block(256);
     const int al = (cin & 3) == 0 ? 4 : 2;                              // cin even (hid = expand * cin is a multiple of 4)
     const bool big = hid > 48 || cin > 32;                              // (RT, KQ) = (6, 3), else (3, 2)
-#define HS_D2A(PWV, RTV, KQV, ALV) hipLaunchKernelGGL((ird_pw1_kernel<PWV, RTV, KQV, ALV>), grid, block, 0, stream, a)
+#define HS_D2A(PWV, RTV, KQV, ALV) hipLaunchKernelGGL((ird_pw1_kernel<PWV, RTV, KQV, ALV>), grid, block, (size_t)si.c_prev * IrdP1<PWV>::WP * sizeof(float), stream, a)
 #define HS_D2B(PWV, RTV, KQV) do { if (al == 4) HS_D2A(PWV, RTV, KQV, 4); else HS_D2A(PWV, RTV, KQV, 2); } while (0)
     if (pw == 4) { if (big) HS_D2B(4, 6, 3); else HS_D2B(4, 3, 2); }
     else { if (big) HS_D2B(8, 6, 3); else HS_D2B(8, 3, 2); }
