@@ -54,20 +54,31 @@ template <int AL> __device__ __forceinline__ d2_f32x4 d2_load4(const float* __re
 }
 
 // RT 16-row tiles of hidden channels, KQ 16-deep k blocks of input channels; 4 waves = 4 patches next to each other along x.
-// The previous level (exactly half the resolution: the host checks) reaches the lanes through LDS: the region's low-resolution window
-// -- PW/2 + 2 rows x 2 PW + 2 columns per channel, clamped at the image border exactly as the bilinear taps clamp -- is staged once
-// by the whole workgroup, and every bilinear corner is a ds_read_b32 (the first form fetched the four corners of every previous-level
-// channel of every pixel from global memory: 60-160 dependent-latency loads per lane at 2 waves per SIMD, 57 / 68 us).
-template <int PW> struct IrdP1 {
+// The stage input x = cat(coords, skip, bilinear2x(prev)) of the workgroup's 4 PW x PW pixel region is assembled ONCE, cooperatively,
+// into LDS as [pixel][16 KQ channels] -- thread = pixel (x channel group at 4 x 4 patches), the channel index uniform per wave, so
+// each kind of channel is a loop without divergence: skip channels are coalesced global loads (all in flight together), previous-
+// level channels are four ds_read_b32 of the low-resolution window (PW/2 + 2 rows x 2 PW + 2 columns per channel, clamped at the
+// image border exactly as the bilinear taps clamp; the level below is at exactly half the resolution: the host checks) -- and a
+// lane's B fragment is then ONE ds_read_b128 per k block and tile.  (First form: every lane assembled its own 4 KQ values per tile
+// branch-free, i.e. all five candidate loads and the bilinear arithmetic for every k whatever its kind: 2650 instructions per wave at
+// level 3, issue-bound at 52 us; before the window went through LDS the corner loads came from global memory, 68 us.)
+template <int PW, int KQ> struct IrdP1 {
     static constexpr int WROWS = PW / 2 + 2, WCOLS = 2 * PW + 2, WP = WROWS * WCOLS;
+    static constexpr int RW = 4 * PW, NPX = RW * PW, CG = 256 / NPX;     // pixels per region; channel groups per pixel (4 x 4: 4)
+    static constexpr int KP = 16 * KQ, XS = KP + 4;                      // floats per pixel: an odd number of 16-byte granules
+    static constexpr int ROWP = PW == 4 ? 20 : 40;                       // row pitch in pixels, == PW (mod 16): see pass 2
+    static constexpr int XL = PW * ROWP * XS;                            // floats of the assembled region; the window follows
+    static constexpr int MAXS = 16 / CG;                                 // skip channels per thread (c_skip <= 16)
 };
 
 template <int PW, int RT, int KQ, int AL>
 __global__ __launch_bounds__(256)
 void ird_pw1_kernel(IrdArgs a) {
-    using P = IrdP1<PW>;
+    using P = IrdP1<PW, KQ>;
     constexpr int NT = PW * PW / 16;
-    extern __shared__ __attribute__((aligned(16))) float d2_win[];        // [c_prev][WROWS][WCOLS]
+    extern __shared__ __attribute__((aligned(16))) float d2_p1[];
+    float* xl = d2_p1;                                                  // [PW][ROWP][XS]
+    float* win = d2_p1 + P::XL;                                         // [c_prev][WROWS][WCOLS]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kg = lane >> 4;
     const int pj = blockIdx.x * 4 + wave, pi = blockIdx.y, b = blockIdx.z;
@@ -91,19 +102,19 @@ void ird_pw1_kernel(IrdArgs a) {
             }
         }
     }
-    // ---- the skip values of every tile (the only per-pixel global loads left), then the previous level's window
+    // ---- this thread's pixel of the region and channel group; its skip values (all requested now)
     const int ncoord = 2 * s.coords;
-    float vs[NT][KQ][4];
+    const int p = tid % P::NPX, cg = __builtin_amdgcn_readfirstlane(tid / P::NPX);
+    const int ry = p / P::RW, rx = p - ry * P::RW;
+    const int Y = pi * PW + ry, X = min((int)blockIdx.x * P::RW + rx, s.W - 1);     // columns of patches beyond the grid: any pixel
+    float* __restrict__ xp = xl + (ry * P::ROWP + rx) * P::XS;
+    float vs[P::MAXS];
+    {
+        const float* __restrict__ sk = s.skip + (size_t)b * s.c_skip * s.H * s.W + (size_t)Y * s.W + X;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        int ly, lx;
-        d2_pixel<PW>(t, n, ly, lx);
-        const float* __restrict__ sk = s.skip + (size_t)b * s.c_skip * s.H * s.W + (size_t)(pi * PW + ly) * s.W + min(pj * PW + lx, s.W - 1);
-#pragma unroll
-        for (int q = 0; q < KQ; ++q)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) vs[t][q][j] = sk[(size_t)min(max(16 * q + 4 * kg + j - ncoord, 0), s.c_skip - 1) * s.H * s.W];
+        for (int i = 0; i < P::MAXS; ++i) vs[i] = sk[(size_t)min(cg + P::CG * i, s.c_skip - 1) * s.H * s.W];
     }
+    // ---- the previous level's window
     const int wy0 = pi * (PW / 2) - 1, wx0 = blockIdx.x * (2 * PW) - 1;
     {
         const float* __restrict__ pv = s.prev + (size_t)b * s.c_prev * s.Hp * s.Wp;
@@ -119,7 +130,29 @@ void ird_pw1_kernel(IrdArgs a) {
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (base + tid + 256 * i < total) d2_win[base + tid + 256 * i] = v[i];
+                if (base + tid + 256 * i < total) win[base + tid + 256 * i] = v[i];
+        }
+    }
+    // coords, skip and the zero tail do not need the window
+    if (s.coords) {
+        if (cg == 0) xp[0] = linspace_pm1(X, s.W, s.step_x);
+        if (cg == 1 % P::CG) xp[1] = linspace_pm1(Y, s.H, s.step_y);
+    }
+#pragma unroll
+    for (int i = 0; i < P::MAXS; ++i)
+        if (cg + P::CG * i < s.c_skip) xp[ncoord + cg + P::CG * i] = vs[i];
+    for (int c = a.cin + cg; c < P::KP; c += P::CG) xp[c] = 0.0f;
+    __syncthreads();
+    {
+        const Tap ty = bilinear_tap(Y, s.scale_y, s.Hp), tx = bilinear_tap(X, s.scale_x, s.Wp);
+        const int r0 = (ty.i0 - wy0) * P::WCOLS - wx0, r1 = (ty.i1 - wy0) * P::WCOLS - wx0;
+        const int o00 = r0 + tx.i0, o01 = r0 + tx.i1, o10 = r1 + tx.i0, o11 = r1 + tx.i1;
+        float* __restrict__ xq = xp + ncoord + s.c_skip;
+#pragma unroll 4
+        for (int cp = cg; cp < s.c_prev; cp += P::CG) {
+            const float* pl = win + cp * P::WP;
+            const float top = tx.l0 * pl[o00] + tx.l1 * pl[o01], bot = tx.l0 * pl[o10] + tx.l1 * pl[o11];
+            xq[cp] = ty.l0 * top + ty.l1 * bot;                          // stage_value's expression (hs_common.h)
         }
     }
     __syncthreads();
@@ -140,29 +173,21 @@ void ird_pw1_kernel(IrdArgs a) {
     for (int t = 0; t < NT; ++t) {
         int ly, lx;
         d2_pixel<PW>(t, n, ly, lx);
-        const int Y = pi * PW + ly, X = pj * PW + lx;
-        const Tap ty = bilinear_tap(Y, s.scale_y, s.Hp), tx = bilinear_tap(X, s.scale_x, s.Wp);
-        const float cx = linspace_pm1(X, s.W, s.step_x), cy = linspace_pm1(Y, s.H, s.step_y);
-        const int r0 = (ty.i0 - wy0) * P::WCOLS - wx0, r1 = (ty.i1 - wy0) * P::WCOLS - wx0;
-        const int o00 = r0 + tx.i0, o01 = r0 + tx.i1, o10 = r1 + tx.i0, o11 = r1 + tx.i1;
+        const float* __restrict__ xb = xl + (ly * P::ROWP + wave * PW + lx) * P::XS + 4 * kg;
+        d2_f32x4 xv[KQ];
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) xv[q] = *reinterpret_cast<const d2_f32x4*>(xb + 16 * q);
         d2_f32x4 acc[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[rt] = d2_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < KQ; ++q)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = 16 * q + 4 * kg + j;
-                const float* pl = d2_win + min(max(k - ncoord - s.c_skip, 0), s.c_prev - 1) * P::WP;
-                const float top = tx.l0 * pl[o00] + tx.l1 * pl[o01], bot = tx.l0 * pl[o10] + tx.l1 * pl[o11];
-                const float up = ty.l0 * top + ty.l1 * bot;              // stage_value's expression (hs_common.h)
-                float v = k < ncoord ? (k == 0 ? cx : cy) : (k - ncoord < s.c_skip ? vs[t][q][j] : up);
-                v = k < a.cin ? v : 0.0f;
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[rt][q][j], v, acc[rt], 0, 0, 0);
-            }
+                for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[rt][q][j], xv[q][j], acc[rt], 0, 0, 0);
         // ---- BN1 + ReLU6, channels-last: D row 4 kg + r of tile rt = channel 16 rt + 4 kg + r of pixel n
-        float* __restrict__ dst = a.h1 + ((size_t)(b * s.H + Y) * s.W + X) * a.hidp + 4 * kg;
+        float* __restrict__ dst = a.h1 + ((size_t)(b * s.H + pi * PW + ly) * s.W + pj * PW + lx) * a.hidp + 4 * kg;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             d2_f32x4 o;
@@ -329,7 +354,7 @@ size_t hs::ird_workspace_bytes(const StageIn& si, int fh, int fw, int cin, int h
     if (ph != pw || (pw != 4 && pw != 8)) return 0;
     if (!si.coords || si.prev_mode != HS_PREV_BILINEAR || si.c_skip < 1 || si.c_prev < 1) return 0;
     if (cin > 48 || (cin & 1) || hid > 96 || (hid & 3) || hid < 4 || c_out > 16 || cin == c_out || cin < 2) return 0;
-    if (si.H < 2 || si.W < 2 || fh > 65535 || si.B > 65535 || si.Hp * 2 != si.H || si.Wp * 2 != si.W || si.c_prev > 128) return 0;
+    if (si.H < 2 || si.W < 2 || fh > 65535 || si.B > 65535 || si.Hp * 2 != si.H || si.Wp * 2 != si.W || si.c_prev > 64 || si.c_skip > 16) return 0;
     const int hidp = (hid + 15) & ~15;
     return (size_t)si.B * si.H * si.W * hidp * sizeof(float);
 }
@@ -345,7 +370,8 @@ int hs::try_launch_ird(const StageIn& si, int fh, int fw, const float* bank, lon
     const dim3 grid((fw + 3) / 4, fh, si.B), block(256);
     const int al = (cin & 3) == 0 ? 4 : 2;                              // cin even (hid = expand * cin is a multiple of 4)
     const bool big = hid > 48 || cin > 32;                              // (RT, KQ) = (6, 3), else (3, 2)
-#define HS_D2A(PWV, RTV, KQV, ALV) hipLaunchKernelGGL((ird_pw1_kernel<PWV, RTV, KQV, ALV>), grid, block, (size_t)si.c_prev * IrdP1<PWV>::WP * sizeof(float), stream, a)
+#define HS_D2A(PWV, RTV, KQV, ALV) hipLaunchKernelGGL((ird_pw1_kernel<PWV, RTV, KQV, ALV>), grid, block, \
+                                              ((size_t)IrdP1<PWV, KQV>::XL + (size_t)si.c_prev * IrdP1<PWV, KQV>::WP) * sizeof(float), stream, a)
 #define HS_D2B(PWV, RTV, KQV) do { if (al == 4) HS_D2A(PWV, RTV, KQV, 4); else HS_D2A(PWV, RTV, KQV, 2); } while (0)
     if (pw == 4) { if (big) HS_D2B(4, 6, 3); else HS_D2B(4, 3, 2); }
     else { if (big) HS_D2B(8, 6, 3); else HS_D2B(8, 3, 2); }
