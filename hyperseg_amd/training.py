@@ -10,9 +10,27 @@ inside ``model(x)`` / ``backward()`` through hyperseg_amd.autograd.
 * :func:`train_step` -- hyperseg/train.py:118-136: forward, resize the prediction to the target if needed, loss,
   zero_grad / backward / optimizer.step / scheduler.step.
 """
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 from torch.optim.lr_scheduler import LRScheduler
+
+
+def bootstrap_mean_reference(per_pixel, k, thresh):
+    """The reference's own statement (hyperseg/losses/bootstrapped_ce_loss.py:19-25): two host reads and a full sort per image."""
+    ranked = per_pixel.sort(descending=True).values
+    kept = ranked[ranked > thresh] if ranked[k] > thresh else ranked[:k]
+    return kept.mean()
+
+
+def bootstrap_mean_on_device(per_pixel, k, thresh):
+    """The same rule without leaving the device: the reference's ``if ranked[k] > thresh`` is a host read per image, its boolean
+    index a second one, and a full sort of 3e5 losses is 18 merge launches.  Both branches as means, selected by ``where`` -- the
+    gradient reaches the selected branch only, as in the reference (tests/test_oracle_golden.py compares values and gradients)."""
+    top = per_pixel.topk(k + 1, sorted=True).values
+    over = per_pixel > thresh
+    mean_over = (per_pixel * over).sum() / over.sum().clamp(min=1)
+    return torch.where(top[k] > thresh, mean_over, top[:k].mean())
 
 
 def bootstrapped_cross_entropy(pred, target, k=4096, thresh=0.3, weight=None, ignore_index=-100):
@@ -21,9 +39,8 @@ def bootstrapped_cross_entropy(pred, target, k=4096, thresh=0.3, weight=None, ig
     for logits, labels in zip(pred, target):
         per_pixel = F.cross_entropy(logits.flatten(1).t(), labels.flatten(), weight=weight, ignore_index=ignore_index,
                                     reduction='none')
-        ranked = per_pixel.sort(descending=True).values
-        kept = ranked[ranked > thresh] if ranked[k] > thresh else ranked[:k]
-        total = total + kept.mean()
+        on_device = per_pixel.is_cuda and per_pixel.numel() > k            # (numel <= k: the reference raises; so does its restatement)
+        total = total + (bootstrap_mean_on_device if on_device else bootstrap_mean_reference)(per_pixel, k, thresh)
     return total / float(pred.shape[0])
 
 

@@ -229,6 +229,14 @@ def test_training_harness_loss_and_lr_vs_reference(golden):
     assert abs(b - float(g['loss_topk'])) < 1e-6 * abs(b) + 1e-7
     assert abs(a - b) > 1e-3                                   # the two branches really differ on this input
     assert abs(a - float(g['losses'][0])) < 1e-6
+    # the device-resident form of the rule (what a CUDA tensor gets) == the reference's statement, values and gradients, both branches
+    from hyperseg_amd.training import bootstrap_mean_on_device, bootstrap_mean_reference
+    gen = torch.Generator().manual_seed(3)
+    for th in (0.3, 2.5, 5.0):
+        v = (torch.rand(5000, generator=gen) * 6).requires_grad_()
+        r0, r1 = bootstrap_mean_reference(v, 1000, th), bootstrap_mean_on_device(v, 1000, th)
+        g0, g1 = torch.autograd.grad(r0, v)[0], torch.autograd.grad(r1, v)[0]
+        assert abs(float(r0) - float(r1)) < 1e-6 * abs(float(r0)) and torch.allclose(g0, g1, rtol=1e-6, atol=0)
     p = torch.nn.Parameter(torch.zeros(1))
     opt = torch.optim.Adam([p], lr=1e-3, betas=(0.5, 0.999))
     sched = PolyLR(opt, 10, 0.9)
