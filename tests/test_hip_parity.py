@@ -458,6 +458,34 @@ def test_fused_op_d_vs_oracle(HF, O, dev, case, ir_math):
         assert torch.equal(yb, y_fused)
 
 
+@pytest.mark.parametrize('case', [dict(skip=96, prev=0, cout=96, patch=1, grid=(16, 16), batch=4),     # HyperSeg-L level 0 (a bs-4 shard)
+                                  dict(skip=34, prev=96, cout=34, patch=2, grid=(16, 16), batch=4),    # level 1
+                                  dict(skip=10, prev=7, cout=40, patch=2, grid=(17, 33), batch=2),     # odd grid, cin = 19: odd -> the LDS-staged kernel
+                                  dict(skip=20, prev=0, cout=5, patch=1, grid=(32, 35), batch=1),
+                                  dict(skip=6, prev=4, cout=96, patch=1, grid=(40, 30), batch=1)])
+def test_batched_tiny_patches_on_the_matrix_cores(HF, O, dev, case):
+    """Op A, k = 1, >= 1024 patches of 1 or 4 pixels: the weight-stream kernel (hs_patch_conv_k1m.hip) behind hs_patch_conv_fwd,
+    with and without a previous level, BatchNorm + ReLU epilogue, against the oracle's patch_conv_k1 on the stage input."""
+    g = torch.Generator().manual_seed(case['skip'] * 7 + case['cout'])
+    fh, fw = case['grid']
+    h, w = fh * case['patch'], fw * case['patch']
+    bsz = case['batch']
+    skip = torch.randn(bsz, case['skip'], h, w, generator=g)
+    prev = torch.randn(bsz, case['prev'], h // 2, w // 2, generator=g) if case['prev'] else None
+    if prev is not None and (h % 2 or w % 2):
+        pytest.skip('previous level needs an even map')
+    cin = 2 + case['skip'] + case['prev']
+    wt = torch.randn(bsz, case['cout'] * cin, fh, fw, generator=g) * (1.0 / cin) ** 0.5
+    scale, shift = torch.rand(case['cout'], generator=g) + 0.5, torch.randn(case['cout'], generator=g) * 0.1
+    ref = torch.relu(O.patch_conv_k1(O.stage_input(skip, prev), wt, case['cout']) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    stage = HF.StageInput(skip.to(dev), prev.to(dev) if prev is not None else None, coords=True)
+    bank = HF.bank_pack(wt.to(dev), 0, wt.shape[1])
+    y = HF.patch_conv(stage, (fh, fw), bank, case['cout'], scale=scale.to(dev), shift=shift.to(dev), act=HF.ACT_RELU)
+    cmp(y, ref, what=f'batched tiny patches {case}')
+    y0 = HF.patch_conv(stage, (fh, fw), bank, case['cout'])
+    cmp(y0, O.patch_conv_k1(O.stage_input(skip, prev), wt, case['cout']), what=f'batched tiny patches, no epilogue {case}')
+
+
 def test_fused_op_d_falls_back_when_regions_do_not_tile(HF, O, dev):
     """12 x 20 pixels at patch 4 do not tile into 8x8 regions, and 56 input channels are beyond the two-launch form: the module
     silently takes the three-launch route."""
