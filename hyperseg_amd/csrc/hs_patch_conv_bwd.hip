@@ -116,6 +116,161 @@ void patch_conv_bwd_weight_kernel(ConvBwdArgs a, int ob) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// k = 1, groups = 1 on the f32 matrix cores (round 3): the two adjoints of a per-patch 1x1 convolution are per-patch GEMMs over the
+// patch's pixels,   dW[o][c] = sum_px dY[o][px] X[c][px]   (K = pixels)   and   dX[c][px] = sum_o W[o][c] dY[o][px]   (N = pixels),
+// and 7 of the 9 layers of a v1_0 decoder are of this kind.  v_mfma_f32_16x16x4_f32, operands straight from global memory: in NCHW a
+// patch row is contiguous along the pixels, so a lane's four consecutive k (dW) are one 16-byte load -- MFMA j multiplies pixel set
+// {16 s + 4 kgroup + j} of chunk s on both operands.  One workgroup per patch, the 4 waves split the pixel chunks (dW: partial tiles
+// meet in LDS and are summed in wave order: deterministic) or the pixel tiles (dX).  The LDS-staged scalar kernels above stay for
+// everything else (k > 1, groups, patches that are not a multiple of 16 pixels / 4 columns, very wide layers).
+// ---------------------------------------------------------------------------------------------------------------------------------
+using bw_f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// VEC: patches whose rows are whole 4-pixel groups on 16-byte boundaries and whose pixel count is a multiple of 16.  Otherwise (the
+// (ph + 2) x (pw + 2) halo tiles that a train-mode v1_0 inverted residual feeds to its first 1x1 convolution: 18 x 18, 10 x 10) the
+// lane's four pixels are four 4-byte loads with their own row / column, and pixels past the patch contribute zeros.
+template <int MT, int NTI, bool VEC>
+__global__ __launch_bounds__(256)
+void patch_conv_bwd_weight_k1m_kernel(ConvBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[4][MT * NTI][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kg = lane >> 4;
+    const int patch = blockIdx.x;
+    const int pj = patch % a.fw, pi = (patch / a.fw) % a.fh, b = patch / (a.fw * a.fh);
+    const size_t plane = (size_t)a.H * a.W;
+    const float* __restrict__ dyp[MT];
+    const float* __restrict__ xp[NTI];
+    const size_t org = (size_t)(pi * a.ph) * a.W + pj * a.pw;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) dyp[mt] = a.dy + ((size_t)b * a.cout + min(16 * mt + n, a.cout - 1)) * plane + org;
+#pragma unroll
+    for (int nt = 0; nt < NTI; ++nt) xp[nt] = a.x + ((size_t)b * a.cin + min(16 * nt + n, a.cin - 1)) * plane + org;
+    const int npix = a.ph * a.pw, nch = (npix + 15) >> 4;                // chunks of 16 pixels in patch-linear order
+    auto fetch = [&](int s, bw_f32x4 (&av)[MT], bw_f32x4 (&bv)[NTI]) {
+        if constexpr (VEC) {
+            const int l = 16 * s + 4 * kg, u = l / a.pw, v = l - u * a.pw;   // pw % 4 == 0: the lane's 4 pixels are one row segment
+            const size_t off = (size_t)u * a.W + v;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const bw_f32x4*>(dyp[mt] + off);
+#pragma unroll
+            for (int nt = 0; nt < NTI; ++nt) bv[nt] = *reinterpret_cast<const bw_f32x4*>(xp[nt] + off);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int l = 16 * s + 4 * kg + j, lc = min(l, npix - 1), u = lc / a.pw, v = lc - u * a.pw;
+                const size_t off = (size_t)u * a.W + v;
+                const float live = l < npix ? 1.0f : 0.0f;               // clamped address, masked by a multiply (no branch around a load)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) av[mt][j] = dyp[mt][off] * live;
+#pragma unroll
+                for (int nt = 0; nt < NTI; ++nt) bv[nt][j] = xp[nt][off];
+            }
+        }
+    };
+    bw_f32x4 acc[MT][NTI];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTI; ++nt) acc[mt][nt] = bw_f32x4{0.f, 0.f, 0.f, 0.f};
+    auto products = [&](const bw_f32x4 (&av)[MT], const bw_f32x4 (&bv)[NTI]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTI; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][j], bv[nt][j], acc[mt][nt], 0, 0, 0);
+    };
+    bw_f32x4 a0[MT], b0[NTI], a1[MT], b1[NTI];
+    int s = wave;
+    if (s < nch) fetch(s, a0, b0);
+    for (; s + 4 < nch; s += 8) {                                        // two chunks per trip, the next one's operands in flight
+        fetch(s + 4, a1, b1);
+        products(a0, b0);
+        if (s + 8 < nch) fetch(s + 8, a0, b0);
+        products(a1, b1);
+    }
+    if (s < nch) products(a0, b0);
+    // ---- the four partial tiles meet in LDS; element (tile, lane, r) = D row 4 (lane / 16) + r, column lane % 16
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTI; ++nt)
+            *reinterpret_cast<bw_f32x4*>(&red[wave][mt * NTI + nt][4 * lane]) = acc[mt][nt];
+    __syncthreads();
+    float* __restrict__ dst = a.dbank + (size_t)patch * a.ld;
+    for (int e = tid; e < MT * NTI * 256; e += 256) {
+        const int tile = e >> 8, w = e & 255, ln = w >> 2, r = w & 3;
+        const int o = 16 * (tile / NTI) + 4 * (ln >> 4) + r, c = 16 * (tile % NTI) + (ln & 15);
+        if (o < a.cout && c < a.cin)
+            dst[(size_t)o * a.cin + c] = ((red[0][tile][w] + red[1][tile][w]) + red[2][tile][w]) + red[3][tile][w];
+    }
+}
+
+template <int CT, int KQ>
+__global__ __launch_bounds__(256)
+void patch_conv_bwd_input_k1m_kernel(ConvBwdArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kg = lane >> 4;
+    const int patch = blockIdx.x;
+    const int pj = patch % a.fw, pi = (patch / a.fw) % a.fh, b = patch / (a.fw * a.fh);
+    const size_t plane = (size_t)a.H * a.W;
+    // A[i = input channel][k = output channel] = W[o][c]: this patch's bank row, o = 16 q + 4 kg + j, c = 16 ct + n (clamped: the
+    // rows / columns beyond the layer multiply zeros of B or land in rows that are never stored)
+    const float* __restrict__ wp = a.bank + (size_t)patch * a.ld;
+    float aw[CT][KQ][4];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int q = 0; q < KQ; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                aw[ct][q][j] = wp[(size_t)min(16 * q + 4 * kg + j, a.cout - 1) * a.cin + min(16 * ct + n, a.cin - 1)];
+    const size_t org = (size_t)(pi * a.ph) * a.W + pj * a.pw;
+    const float* __restrict__ dyb = a.dy + (size_t)b * a.cout * plane + org;
+    float* __restrict__ dxb = a.dx + (size_t)b * a.cin * plane + org;
+    const int npix = a.ph * a.pw, ntile = (npix + 15) >> 4;
+    auto fetch = [&](int t, float (&bv)[KQ][4], size_t& off) {
+        const int l = min(16 * t + n, npix - 1), u = l / a.pw, v = l - u * a.pw;     // past the patch: a live pixel, not stored
+        off = (size_t)u * a.W + v;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int o = 16 * q + 4 * kg + j;
+                const float val = dyb[(size_t)min(o, a.cout - 1) * plane + off];
+                bv[q][j] = o < a.cout ? val : 0.0f;
+            }
+    };
+    auto tile = [&](int t, const float (&bv)[KQ][4], size_t off) {
+        const bool live = 16 * t + n < npix;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            bw_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < KQ; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[ct][q][j], bv[q][j], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * ct + 4 * kg + r;
+                if (c < a.cin && live) dxb[(size_t)c * plane + off] = acc[r];
+            }
+        }
+    };
+    float b0[KQ][4], b1[KQ][4];
+    size_t o0 = 0, o1 = 0;
+    int t = wave;
+    if (t < ntile) fetch(t, b0, o0);
+    for (; t + 4 < ntile; t += 8) {
+        fetch(t + 4, b1, o1);
+        tile(t, b0, o0);
+        if (t + 8 < ntile) fetch(t + 8, b0, o0);
+        tile(t + 4, b1, o1);
+    }
+    if (t < ntile) tile(t, b0, o0);
+}
+
 }  // namespace hs
 
 using namespace hs;
@@ -146,6 +301,15 @@ extern "C" int hs_patch_conv_bwd_input(const float* dy, const float* bank, int64
     if (st != HS_OK) return st;
     if (!bank || !dx) return HS_ERR_BAD_ARG;
     a.dx = dx; a.dbank = nullptr;
+    if (k == 1 && groups == 1 && a.ph * a.pw >= 16) {
+        const int ct = (c_in + 15) / 16, kq = (c_out + 15) / 16;
+        const dim3 grid((unsigned)(batch * fh * fw));
+#define HS_BI(CTV, KQV) if (ct == CTV && kq == KQV) { \
+            hipLaunchKernelGGL((patch_conv_bwd_input_k1m_kernel<CTV, KQV>), grid, dim3(256), 0, (hipStream_t)stream, a); return launch_status(); }
+        HS_BI(1, 1) HS_BI(1, 2) HS_BI(1, 3) HS_BI(1, 4) HS_BI(2, 1) HS_BI(2, 2) HS_BI(2, 3) HS_BI(2, 4)
+        HS_BI(3, 1) HS_BI(3, 2) HS_BI(3, 3) HS_BI(3, 4) HS_BI(4, 1) HS_BI(4, 2) HS_BI(4, 3) HS_BI(6, 1) HS_BI(6, 2)
+#undef HS_BI
+    }
     const size_t total = (size_t)batch * c_in * H * W;
     const unsigned blocks = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
     hipLaunchKernelGGL(patch_conv_bwd_input_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
@@ -160,6 +324,17 @@ extern "C" int hs_patch_conv_bwd_weight(const float* x, const float* dy, int32_t
     if (st != HS_OK) return st;
     if (!x || !dbank) return HS_ERR_BAD_ARG;
     a.dx = nullptr; a.dbank = dbank;
+    if (k == 1 && groups == 1 && a.ph * a.pw >= 16) {
+        const bool vec = (a.pw & 3) == 0 && ((a.ph * a.pw) & 15) == 0 && (W & 3) == 0 && ((((size_t)x) | ((size_t)dy)) & 15) == 0;
+        const int mt = (c_out + 15) / 16, nt = (c_in + 15) / 16;
+        const dim3 grid((unsigned)(batch * fh * fw));
+#define HS_BW(MTV, NTV) if (mt == MTV && nt == NTV) { \
+            if (vec) hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, true>), grid, dim3(256), 0, (hipStream_t)stream, a); \
+            else hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, false>), grid, dim3(256), 0, (hipStream_t)stream, a); \
+            return launch_status(); }
+        HS_BW(1, 1) HS_BW(1, 2) HS_BW(1, 3) HS_BW(1, 4) HS_BW(2, 1) HS_BW(2, 2) HS_BW(2, 3) HS_BW(2, 4) HS_BW(3, 1) HS_BW(3, 2) HS_BW(4, 1) HS_BW(4, 2)
+#undef HS_BW
+    }
     // output-channel block: as many channels (whole groups when the convolution is grouped) as fit beside the X tile
     const size_t npix = (size_t)a.ph * a.pw, tpos = (size_t)(a.ph + 2 * pad) * (a.pw + 2 * pad);
     int ob = 0;

@@ -24,13 +24,16 @@ def bootstrap_mean_reference(per_pixel, k, thresh):
 
 
 def bootstrap_mean_on_device(per_pixel, k, thresh):
-    """The same rule without leaving the device: the reference's ``if ranked[k] > thresh`` is a host read per image, its boolean
-    index a second one, and a full sort of 3e5 losses is 18 merge launches.  Both branches as means, selected by ``where`` -- the
-    gradient reaches the selected branch only, as in the reference (tests/test_oracle_golden.py compares values and gradients)."""
-    top = per_pixel.topk(k + 1, sorted=True).values
+    """The same rule with ONE host read and, in the common case, no sort: the (k+1)-th largest loss exceeds ``thresh`` exactly when
+    more than k losses do, so the count decides the branch -- the mean of everything above ``thresh`` is a masked sum, and only the
+    other branch needs the k largest (``topk``).  The reference reads the host twice per image (the comparison, then a boolean
+    index) around a full sort of 3e5 losses (18 merge launches, ~0.2 ms per image at config 5).  Values within 1e-6 and gradients
+    equal to the reference statement (tests/test_oracle_golden.py)."""
     over = per_pixel > thresh
-    mean_over = (per_pixel * over).sum() / over.sum().clamp(min=1)
-    return torch.where(top[k] > thresh, mean_over, top[:k].mean())
+    count = over.sum()
+    if int(count) > k:
+        return (per_pixel * over).sum() / count
+    return per_pixel.topk(k, sorted=False).values.mean()
 
 
 def bootstrapped_cross_entropy(pred, target, k=4096, thresh=0.3, weight=None, ignore_index=-100):

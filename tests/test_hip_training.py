@@ -26,6 +26,16 @@ def dev():
     dict(cin=4, cout=4, k=3, groups=4, mode='replicate', b=2, grid=(2, 2), patch=(3, 5)),
     dict(cin=3, cout=2, k=5, groups=1, mode='circular', b=1, grid=(1, 2), patch=(6, 4)),
     dict(cin=8, cout=8, k=1, groups=4, mode='zeros', b=2, grid=(2, 2), patch=(16, 16)),
+    # k = 1, groups = 1, patches of whole 16-pixel chunks: both adjoints on the matrix cores (hs_patch_conv_bwd.hip, *_k1m_kernel)
+    dict(cin=22, cout=44, k=1, groups=1, mode='zeros', b=2, grid=(2, 3), patch=(32, 32)),     # config 5 level 4 pw1
+    dict(cin=44, cout=12, k=1, groups=1, mode='zeros', b=1, grid=(3, 2), patch=(16, 16)),     # pw3: 3 x 1 tiles
+    dict(cin=44, cout=16, k=1, groups=1, mode='zeros', b=2, grid=(2, 2), patch=(8, 8)),       # level 2: 4 chunks, one per wave
+    dict(cin=94, cout=32, k=1, groups=1, mode='zeros', b=1, grid=(2, 2), patch=(4, 4)),       # one chunk: three waves idle; dW stays scalar (6 x 2 tiles)
+    dict(cin=5, cout=3, k=1, groups=1, mode='zeros', b=1, grid=(1, 2), patch=(4, 12)),        # 48 pixels = 3 chunks of 1 1/3 rows
+    dict(cin=17, cout=33, k=1, groups=1, mode='zeros', b=1, grid=(2, 1), patch=(16, 20)),     # odd channel counts, 20 chunks
+    dict(cin=22, cout=44, k=1, groups=1, mode='zeros', b=1, grid=(2, 2), patch=(18, 18)),     # a train-mode Op C halo tile: 324 pixels, scalar loads
+    dict(cin=24, cout=48, k=1, groups=1, mode='zeros', b=2, grid=(1, 3), patch=(10, 10)),
+    dict(cin=6, cout=20, k=1, groups=1, mode='zeros', b=1, grid=(2, 2), patch=(3, 7)),        # 21 pixels: one full chunk and 5 of the next
 ])
 def test_patch_conv_gradients_vs_oracle(dev, case):
     from oracle import hyperseg_oracle as O
