@@ -36,14 +36,26 @@ def bootstrap_mean_on_device(per_pixel, k, thresh):
     return per_pixel.topk(k, sorted=False).values.mean()
 
 
+def bootstrap_mean_capturable(per_pixel, k, thresh):
+    """The rule with NO host read, for a step that is being captured into a HIP graph (GraphedTrainStep): both branches are formed
+    (``topk(k + 1)`` -- on ROCm a full merge sort -- and the masked mean) and ``where`` selects; the gradient reaches the selected
+    branch only, as in the reference."""
+    top = per_pixel.topk(k + 1, sorted=True).values
+    over = per_pixel > thresh
+    mean_over = (per_pixel * over).sum() / over.sum().clamp(min=1)
+    return torch.where(top[k] > thresh, mean_over, top[:k].mean())
+
+
 def bootstrapped_cross_entropy(pred, target, k=4096, thresh=0.3, weight=None, ignore_index=-100):
     """pred (N, C, H, W) logits, target (N, H, W) int64 -> scalar."""
     total = pred.new_zeros(())
+    capturing = pred.is_cuda and torch.cuda.is_current_stream_capturing()
     for logits, labels in zip(pred, target):
         per_pixel = F.cross_entropy(logits.flatten(1).t(), labels.flatten(), weight=weight, ignore_index=ignore_index,
                                     reduction='none')
         on_device = per_pixel.is_cuda and per_pixel.numel() > k            # (numel <= k: the reference raises; so does its restatement)
-        total = total + (bootstrap_mean_on_device if on_device else bootstrap_mean_reference)(per_pixel, k, thresh)
+        fn = bootstrap_mean_capturable if capturing and on_device else bootstrap_mean_on_device if on_device else bootstrap_mean_reference
+        total = total + fn(per_pixel, k, thresh)
     return total / float(pred.shape[0])
 
 
@@ -81,3 +93,77 @@ def train_step(model, criterion, optimizer, scheduler, x, target):
     if scheduler is not None:
         scheduler.step()
     return loss.detach(), pred.detach()
+
+
+def _flat_tensors(obj):
+    if isinstance(obj, torch.Tensor):
+        return [obj]
+    if isinstance(obj, (list, tuple)):
+        return [t for o in obj for t in _flat_tensors(o)]
+    return []
+
+
+class GraphedTrainStep:
+    """forward + loss + backward + optimizer step of a fixed-shape batch as ONE HIP graph (the training-side counterpart of
+    utils.inference.GraphedModel).  An eager config-5 decoder step is ~300 launches whose host side (4.8 ms) is longer than their GPU
+    time (3.4 ms): replaying the captured step removes the difference.
+
+    ``model(*inputs)`` -> logits, ``criterion(logits, target)`` -> scalar.  ``inputs`` (tensors or nested lists of tensors) and
+    ``target`` given here are the STATIC buffers the graph reads: ``step(inputs, target)`` copies new data into them and replays.
+    The optimizer must be capturable (``torch.optim.Adam(..., capturable=True)``: its step count lives on the device); a learning-rate
+    schedule changes ``param_group['lr']`` in place if it is a tensor (``lr=torch.tensor(1e-3, device=...)``).  BatchNorm statistics,
+    parameters and optimizer state are updated by every replay exactly as by an eager step.
+
+    One requirement beyond PyTorch's usual ones (static shapes, warm-up before capture): NO autograd graph of an earlier eager step
+    may still be alive when this object is built -- e.g. a ``loss`` variable that still carries its ``grad_fn``.  Such a graph keeps the
+    parameters' gradient accumulators alive, and those stay bound to the stream of the eager steps; the captured backward would then
+    hop to that (non-capturing) stream and hipStreamEndCapture dies on ROCm 7.2 (bisected in round 3: ``del loss`` is the whole fix).
+    Keep ``loss.detach()`` / ``float(loss)`` instead."""
+
+    def __init__(self, model, criterion, optimizer, inputs, target, warmup=3):
+        self.model, self.criterion, self.optimizer = model, criterion, optimizer
+        self.inputs, self.target = inputs, target
+        dev = target.device
+        if dev.type != 'cuda':
+            raise ValueError('GraphedTrainStep needs CUDA tensors')
+        self._static_in = _flat_tensors(inputs) + [target]
+        if warmup < 1 and not optimizer.state:
+            # the optimizer creates its state (moments, step count) on first use: inside a capture those zero fills become graph nodes
+            # and EVERY replay would reset the moments
+            raise ValueError('GraphedTrainStep: warmup >= 1 is required while the optimizer has no state yet')
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                       # first calls allocate, tune and set kernel attributes: not capturable
+            for _ in range(warmup):
+                self._eager()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        # gradients left by earlier eager steps (the caller's or the warm-up's) would be FREED inside the capture by zero_grad -- blocks
+        # of another stream's pool released while a global-mode capture is open bring hipStreamEndCapture down on ROCm 7.2: drop them now
+        self.optimizer.zero_grad(set_to_none=True)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss, self.pred = self._eager()
+
+    def _eager(self):
+        self.optimizer.zero_grad(set_to_none=True)
+        pred = self.model(*self.inputs) if isinstance(self.inputs, (list, tuple)) else self.model(self.inputs)
+        if pred.shape[2:] != self.target.shape[1:]:
+            pred = F.interpolate(pred, size=self.target.shape[1:], mode='bilinear')
+        loss = self.criterion(pred, self.target)
+        loss.backward()
+        self.optimizer.step()
+        return loss.detach(), pred.detach()
+
+    def step(self, inputs=None, target=None):
+        """Copies ``inputs`` / ``target`` (same structure and shapes; None = keep what is in the static buffers) and replays.
+        Returns the static (loss, prediction) tensors: valid until the next call."""
+        if inputs is not None or target is not None:
+            new = (_flat_tensors(inputs) if inputs is not None else self._static_in[:-1]) + [target if target is not None else self.target]
+            if len(new) != len(self._static_in):
+                raise ValueError('inputs do not match the captured structure')
+            for dst, src in zip(self._static_in, new):
+                if dst is not src:
+                    dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.loss, self.pred

@@ -118,6 +118,50 @@ def test_optimizer_step_runs(dev):
     assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0]
 
 
+def test_graphed_train_step_equals_eager(dev):
+    """hyperseg_amd.training.GraphedTrainStep: three replays of the captured forward + bootstrapped CE + backward + Adam step move
+    the parameters, the BatchNorm statistics and the loss exactly as three eager steps do (same kernels, same order)."""
+    import copy
+    from oracle import hyperseg_oracle as O
+    from test_hip_parity import build_decoder
+    from hyperseg_amd.training import BootstrappedCrossEntropyLoss, GraphedTrainStep
+    d0 = build_decoder('Sc', O).to(dev).train()
+    d1 = copy.deepcopy(d0)
+    x, s = O.synth_decoder_inputs('Sc', batch=2, seed=3, size=(96, 96))
+    x = [t.to(dev) for t in x]
+    s = s.to(dev)
+    target = torch.randint(0, 12, (2, 96, 96), device=dev)
+    crit = BootstrappedCrossEntropyLoss(k=512, thresh=0.3, ignore_index=255)
+    o0 = torch.optim.Adam(d0.parameters(), lr=1e-3, betas=(0.5, 0.999))
+    o1 = torch.optim.Adam(d1.parameters(), lr=torch.tensor(1e-3, device=dev), betas=(0.5, 0.999), capturable=True)
+    with pytest.raises(ValueError):
+        GraphedTrainStep(d1, crit, o1, (x, s), target, warmup=0)       # the optimizer state must exist before the capture
+    gs = GraphedTrainStep(d1, crit, o1, (x, s), target, warmup=2)      # two REAL steps (eager, side stream), then the capture
+    eager = []
+    for _ in range(5):
+        o0.zero_grad()
+        loss = crit(d0(x, s), target)
+        loss.backward()
+        o0.step()
+        eager.append(float(loss))
+    graphed = [float(gs.step()[0]) for _ in range(3)]
+    # capture itself ran nothing: the three replays are steps 3-5
+    assert all(abs(a - b) < 1e-4 * abs(a) for a, b in zip(eager[2:], graphed)), (eager, graphed)
+    assert eager[-1] < eager[0]
+    # Adam moves every parameter by ~lr * sign(grad) per step: where a gradient is at rounding-noise level the sign may differ between
+    # the capturable (device-side bias correction) and the plain optimizer, so parameters get a budget of a few lr, not a relative one
+    sd0, sd1 = d0.state_dict(), d1.state_dict()
+    for k in sd0:
+        if sd0[k].dtype.is_floating_point:
+            diff = (sd1[k] - sd0[k]).abs()
+            if 'running_' in k:
+                assert rel_err(sd1[k].cpu(), sd0[k].cpu()) < 1e-4, k
+            else:
+                assert float(diff.max()) <= 10 * 1e-3 and float(diff.mean()) < 0.5 * 1e-3, (k, float(diff.max()), float(diff.mean()))
+        else:
+            assert torch.equal(sd1[k].cpu(), sd0[k].cpu()), k                # num_batches_tracked: 5 on both sides
+
+
 def test_two_optimizer_steps_vs_reference(golden, dev):
     """hyperseg_amd.training.train_step x 2 on the HIP decoder == the reference's loop (train.py:118-136) run with the
     reference's BootstrappedCrossEntropyLoss / Adam(betas=(0.5, 0.999)) / PolyLR on the reference decoder

@@ -23,8 +23,21 @@ dec = model.decoder.train()
 target = torch.randint(0, 12, (2, 576, 576), device=dev)
 crit = BootstrappedCrossEntropyLoss(k=4096, thresh=0.3, ignore_index=255)
 opt = torch.optim.Adam(dec.parameters(), lr=1e-3, betas=(0.5, 0.999))
-modes = (sys.argv[2],) if len(sys.argv) > 2 else ('fp32', 'bf16')
+modes = sys.argv[2:] if len(sys.argv) > 2 else ('fp32', 'bf16', 'graph')
 for mode in modes:
+    if mode == 'graph':                                     # the fp32 step captured once and replayed (hyperseg_amd.training.GraphedTrainStep)
+        from hyperseg_amd.training import GraphedTrainStep
+        opt_g = torch.optim.Adam(dec.parameters(), lr=torch.tensor(1e-3, device=dev), betas=(0.5, 0.999), capturable=True)
+        gs = GraphedTrainStep(dec, lambda p, t: crit(p.float(), t), opt_g, (pyr, s), target)
+        for _ in range(2):
+            gs.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            loss, _ = gs.step()
+        torch.cuda.synchronize()
+        print(f'config-5 decoder training step (fp32, one HIP graph per step): {(time.perf_counter() - t0) / iters * 1e3:.2f} ms/step, loss {float(loss):.4f}')
+        continue
     def step():
         opt.zero_grad()
         with torch.autocast('cuda', dtype=torch.bfloat16, enabled=(mode == 'bf16')):
@@ -41,3 +54,4 @@ for mode in modes:
         loss = step()
     torch.cuda.synchronize()
     print(f'config-5 decoder training step ({mode}): {(time.perf_counter() - t0) / iters * 1e3:.2f} ms/step, loss {float(loss):.4f}')
+    del loss                                                # a live autograd graph must not outlive the eager modes (GraphedTrainStep docstring)
