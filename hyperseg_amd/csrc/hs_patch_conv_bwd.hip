@@ -24,6 +24,9 @@ struct ConvBwdArgs {
     int B, H, W, fh, fw, ph, pw, cin, cout, k, pad, pad_mode, groups, cin_g, cout_g;
 };
 
+int try_launch_fwd_k1m(const float* x, int batch, int c_in, int H, int W, int fh, int fw, const float* bank, long ld, int c_out,
+                       const float* scale, const float* shift, int act, float* y, hipStream_t stream);
+
 // number of padded coordinates (in [-pad, n+pad)) that map onto index i, and the q-th of them
 __device__ __forceinline__ int pad_aliases(int i, int n, int pad, int mode, int* out) {
     int cnt = 0;
@@ -271,9 +274,100 @@ void patch_conv_bwd_input_k1m_kernel(ConvBwdArgs a) {
     if (t < ntile) tile(t, b0, o0);
 }
 
+// The forward of the same layer on a PLAIN input tensor (what the autograd path calls: no fused stage-input prologue), same structure
+// as the input-gradient kernel with the bank row read untransposed:  y[o][px] = sum_c W[o][c] x[c][px].  a.dy = x (cin channels),
+// a.dx = y (cout channels); BatchNorm affine + activation optional.
+template <int MT, int KQ>
+__global__ __launch_bounds__(256)
+void patch_conv_fwd_k1m_kernel(ConvBwdArgs a, const float* __restrict__ scale, const float* __restrict__ shift, int act) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kg = lane >> 4;
+    const int patch = blockIdx.x;
+    const int pj = patch % a.fw, pi = (patch / a.fw) % a.fh, b = patch / (a.fw * a.fh);
+    const size_t plane = (size_t)a.H * a.W;
+    const float* __restrict__ wp = a.bank + (size_t)patch * a.ld;
+    float aw[MT][KQ][4];                                                // A[i = output channel][k = input channel]
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int q = 0; q < KQ; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                aw[mt][q][j] = wp[(size_t)min(16 * mt + n, a.cout - 1) * a.cin + min(16 * q + 4 * kg + j, a.cin - 1)];
+    float sc[MT][4], sh[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = min(16 * mt + 4 * kg + r, a.cout - 1);
+            sc[mt][r] = scale ? scale[o] : 1.0f; sh[mt][r] = scale ? shift[o] : 0.0f;
+        }
+    const size_t org = (size_t)(pi * a.ph) * a.W + pj * a.pw;
+    const float* __restrict__ xb = a.dy + (size_t)b * a.cin * plane + org;
+    float* __restrict__ yb = a.dx + (size_t)b * a.cout * plane + org;
+    const int npix = a.ph * a.pw, ntile = (npix + 15) >> 4;
+    auto fetch = [&](int t, float (&bv)[KQ][4], size_t& off) {
+        const int l = min(16 * t + n, npix - 1), u = l / a.pw, v = l - u * a.pw;
+        off = (size_t)u * a.W + v;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = 16 * q + 4 * kg + j;
+                const float val = xb[(size_t)min(c, a.cin - 1) * plane + off];
+                bv[q][j] = c < a.cin ? val : 0.0f;
+            }
+    };
+    auto tile = [&](int t, const float (&bv)[KQ][4], size_t off) {
+        const bool live = 16 * t + n < npix;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            bw_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < KQ; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[mt][q][j], bv[q][j], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 16 * mt + 4 * kg + r;
+                if (o < a.cout && live) yb[(size_t)o * plane + off] = apply_act(fmaf(acc[r], sc[mt][r], sh[mt][r]), act);
+            }
+        }
+    };
+    float b0[KQ][4], b1[KQ][4];
+    size_t o0 = 0, o1 = 0;
+    int t = wave;
+    if (t < ntile) fetch(t, b0, o0);
+    for (; t + 4 < ntile; t += 8) {
+        fetch(t + 4, b1, o1);
+        tile(t, b0, o0);
+        if (t + 8 < ntile) fetch(t + 8, b0, o0);
+        tile(t + 4, b1, o1);
+    }
+    if (t < ntile) tile(t, b0, o0);
+}
+
 }  // namespace hs
 
 using namespace hs;
+
+// 0 = launched, 1 = not covered.  Plain input (no coords, no previous level), k = 1, groups = 1, patches of >= 64 pixels.
+int hs::try_launch_fwd_k1m(const float* x, int batch, int c_in, int H, int W, int fh, int fw, const float* bank, long ld, int c_out,
+                           const float* scale, const float* shift, int act, float* y, hipStream_t stream) {
+    if (H % fh || W % fw) return 1;
+    ConvBwdArgs a{};
+    a.dy = x; a.dx = y; a.bank = bank; a.ld = ld; a.B = batch; a.H = H; a.W = W; a.fh = fh; a.fw = fw; a.ph = H / fh; a.pw = W / fw;
+    a.cin = c_in; a.cout = c_out; a.k = 1; a.groups = 1; a.cin_g = c_in; a.cout_g = c_out;
+    if (a.ph * a.pw < 64) return 1;
+    const int mt = (c_out + 15) / 16, kq = (c_in + 15) / 16;
+    const dim3 grid((unsigned)(batch * fh * fw));
+#define HS_FW(MTV, KQV) if (mt == MTV && kq == KQV) { \
+        hipLaunchKernelGGL((patch_conv_fwd_k1m_kernel<MTV, KQV>), grid, dim3(256), 0, stream, a, scale, shift, act); return launch_status(); }
+    HS_FW(1, 1) HS_FW(1, 2) HS_FW(1, 3) HS_FW(1, 4) HS_FW(2, 1) HS_FW(2, 2) HS_FW(2, 3) HS_FW(2, 4)
+    HS_FW(3, 1) HS_FW(3, 2) HS_FW(3, 3) HS_FW(3, 4) HS_FW(4, 1) HS_FW(4, 2) HS_FW(4, 3)
+#undef HS_FW
+    return 1;
+}
 
 static int fill_bwd(ConvBwdArgs& a, const float* x, const float* dy, const float* bank, int64_t ld, int32_t batch,
                     int32_t c_in, int32_t H, int32_t W, int32_t fh, int32_t fw, int32_t c_out, int32_t k, int32_t pad,
