@@ -26,6 +26,8 @@ struct ConvBwdArgs {
 
 int try_launch_fwd_k1m(const float* x, int batch, int c_in, int H, int W, int fh, int fw, const float* bank, long ld, int c_out,
                        const float* scale, const float* shift, int act, float* y, hipStream_t stream);
+int try_launch_dw3_fwd(const float* x, int batch, int c, int H, int W, int fh, int fw, const float* bank, long ld, float* y,
+                       hipStream_t stream);
 
 // number of padded coordinates (in [-pad, n+pad)) that map onto index i, and the q-th of them
 __device__ __forceinline__ int pad_aliases(int i, int n, int pad, int mode, int* out) {
@@ -347,9 +349,96 @@ void patch_conv_fwd_k1m_kernel(ConvBwdArgs a, const float* __restrict__ scale, c
     if (t < ntile) tile(t, b0, o0);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Depthwise 3 x 3 with per-patch taps and ZERO padding on a plain tensor, forward and both adjoints (round 3): the middle layer of a
+// train-mode v1_0 inverted residual, which runs on the image of halo tiles laid side by side (hyperseg_v1_0.py _run_train: patches of
+// (ph + 2) x (pw + 2) = 18 x 18 / 10 x 10 pixels).  Vector code with the image-level structure the operator has: one thread per output
+// element, its nine neighbours from L1 / L2 and its patch's nine taps as uniform-ish loads -- the generic kernels (LDS-staged per patch,
+// any k / groups / padding) took 102 / 79 / ~60 us per launch at config 5 for 83 M multiply-adds.
+// ---------------------------------------------------------------------------------------------------------------------------------
+// MODE 0: y = conv(x, K).  MODE 1: dx = adjoint wrt x (the taps of the patch that owns the OUTPUT pixel, mirrored).
+template <int MODE>
+__global__ __launch_bounds__(256)
+void patch_dw3_kernel(ConvBwdArgs a, const float* __restrict__ src, float* __restrict__ dst) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int plane_id = blockIdx.z, c = plane_id % a.cin, b = plane_id / a.cin;
+    if (x >= a.W || y >= a.H) return;
+    const float* __restrict__ sp = src + (size_t)plane_id * a.H * a.W;
+    float acc = 0.0f;
+    if constexpr (MODE == 0) {
+        const float* __restrict__ kp = a.bank + (size_t)((b * a.fh + y / a.ph) * a.fw + x / a.pw) * a.ld + c * 9;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int yy = y + ky - 1, xx = x + kx - 1;
+                const bool in = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+                const float v = sp[(size_t)min(max(yy, 0), a.H - 1) * a.W + min(max(xx, 0), a.W - 1)];
+                acc = fmaf(kp[ky * 3 + kx], in ? v : 0.0f, acc);
+            }
+    } else {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int yo = y - ky + 1, xo = x - kx + 1;              // the output pixel this input feeds through tap (ky, kx)
+                const bool in = yo >= 0 && yo < a.H && xo >= 0 && xo < a.W;
+                const int yc = min(max(yo, 0), a.H - 1), xc = min(max(xo, 0), a.W - 1);
+                const float g = sp[(size_t)yc * a.W + xc];
+                const float w = a.bank[(size_t)((b * a.fh + yc / a.ph) * a.fw + xc / a.pw) * a.ld + c * 9 + ky * 3 + kx];
+                acc = fmaf(w, in ? g : 0.0f, acc);
+            }
+    }
+    dst[(size_t)plane_id * a.H * a.W + (size_t)y * a.W + x] = acc;
+}
+
+// dK[patch][c][ky][kx] = sum over the patch's pixels of dY[c][y][x] X[c][y + ky - 1][x + kx - 1] (zero outside the image): one wave per
+// (patch, channel), lanes over the pixels, nine accumulators, DPP wave sums.
+__global__ __launch_bounds__(256)
+void patch_dw3_bwd_weight_kernel(ConvBwdArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int patch = blockIdx.x, c = blockIdx.y * 4 + wave;
+    if (c >= a.cin) return;
+    const int pj = patch % a.fw, pi = (patch / a.fw) % a.fh, b = patch / (a.fw * a.fh);
+    const size_t plane = (size_t)a.H * a.W;
+    const float* __restrict__ xp = a.x + ((size_t)b * a.cin + c) * plane;
+    const float* __restrict__ gp = a.dy + ((size_t)b * a.cin + c) * plane;
+    const int y0 = pi * a.ph, x0 = pj * a.pw, npix = a.ph * a.pw;
+    float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int l = lane; l < npix; l += 64) {
+        const int u = l / a.pw, v = l - u * a.pw, y = y0 + u, x = x0 + v;
+        const float g = gp[(size_t)y * a.W + x];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int yy = y + ky - 1, xx = x + kx - 1;
+                const bool in = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+                const float val = xp[(size_t)min(max(yy, 0), a.H - 1) * a.W + min(max(xx, 0), a.W - 1)];
+                acc[ky * 3 + kx] = fmaf(g, in ? val : 0.0f, acc[ky * 3 + kx]);
+            }
+    }
+    float* __restrict__ dst = a.dbank + (size_t)patch * a.ld + c * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float s = wave_sum64(acc[t]);
+        if (lane == 0) dst[t] = s;
+    }
+}
+
 }  // namespace hs
 
 using namespace hs;
+
+// 0 = launched, 1 = not covered.  Depthwise (groups == channels), k = 3, zero padding, plain input.
+int hs::try_launch_dw3_fwd(const float* x, int batch, int c, int H, int W, int fh, int fw, const float* bank, long ld, float* y,
+                           hipStream_t stream) {
+    if (H % fh || W % fw || (long)batch * c > 65535) return 1;
+    ConvBwdArgs a{};
+    a.bank = bank; a.ld = ld; a.B = batch; a.H = H; a.W = W; a.fh = fh; a.fw = fw; a.ph = H / fh; a.pw = W / fw; a.cin = c; a.cout = c;
+    hipLaunchKernelGGL(patch_dw3_kernel<0>, dim3((W + 63) / 64, (H + 3) / 4, batch * c), dim3(256), 0, stream, a, x, y);
+    return launch_status();
+}
 
 // 0 = launched, 1 = not covered.  Plain input (no coords, no previous level), k = 1, groups = 1, patches of >= 64 pixels.
 int hs::try_launch_fwd_k1m(const float* x, int batch, int c_in, int H, int W, int fh, int fw, const float* bank, long ld, int c_out,
@@ -395,6 +484,10 @@ extern "C" int hs_patch_conv_bwd_input(const float* dy, const float* bank, int64
     if (st != HS_OK) return st;
     if (!bank || !dx) return HS_ERR_BAD_ARG;
     a.dx = dx; a.dbank = nullptr;
+    if (k == 3 && pad == 1 && pad_mode == HS_PAD_ZEROS && groups == c_in && c_in == c_out && (long)batch * c_in <= 65535) {
+        hipLaunchKernelGGL(patch_dw3_kernel<1>, dim3((W + 63) / 64, (H + 3) / 4, batch * c_in), dim3(256), 0, (hipStream_t)stream, a, dy, dx);
+        return launch_status();
+    }
     if (k == 1 && groups == 1 && a.ph * a.pw >= 16) {
         const int ct = (c_in + 15) / 16, kq = (c_out + 15) / 16;
         const dim3 grid((unsigned)(batch * fh * fw));
@@ -418,6 +511,10 @@ extern "C" int hs_patch_conv_bwd_weight(const float* x, const float* dy, int32_t
     if (st != HS_OK) return st;
     if (!x || !dbank) return HS_ERR_BAD_ARG;
     a.dx = nullptr; a.dbank = dbank;
+    if (k == 3 && pad == 1 && pad_mode == HS_PAD_ZEROS && groups == c_in && c_in == c_out && (c_in + 3) / 4 <= 65535) {
+        hipLaunchKernelGGL(patch_dw3_bwd_weight_kernel, dim3((unsigned)(batch * fh * fw), (c_in + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+        return launch_status();
+    }
     if (k == 1 && groups == 1 && a.ph * a.pw >= 16) {
         const bool vec = (a.pw & 3) == 0 && ((a.ph * a.pw) & 15) == 0 && (W & 3) == 0 && ((((size_t)x) | ((size_t)dy)) & 15) == 0;
         const int mt = (c_out + 15) / 16, nt = (c_in + 15) / 16;

@@ -36,6 +36,10 @@ def dev():
     dict(cin=22, cout=44, k=1, groups=1, mode='zeros', b=1, grid=(2, 2), patch=(18, 18)),     # a train-mode Op C halo tile: 324 pixels, scalar loads
     dict(cin=24, cout=48, k=1, groups=1, mode='zeros', b=2, grid=(1, 3), patch=(10, 10)),
     dict(cin=6, cout=20, k=1, groups=1, mode='zeros', b=1, grid=(2, 2), patch=(3, 7)),        # 21 pixels: one full chunk and 5 of the next
+    # depthwise 3x3, zero padding: the image-level vector kernels (patch_dw3_*), any patch size
+    dict(cin=44, cout=44, k=3, groups=44, mode='zeros', b=2, grid=(2, 3), patch=(18, 18)),
+    dict(cin=7, cout=7, k=3, groups=7, mode='zeros', b=1, grid=(3, 2), patch=(10, 10)),
+    dict(cin=5, cout=5, k=3, groups=5, mode='zeros', b=2, grid=(1, 1), patch=(5, 70)),       # one patch, wider than a wave's 64 columns
 ])
 def test_patch_conv_gradients_vs_oracle(dev, case):
     from oracle import hyperseg_oracle as O
