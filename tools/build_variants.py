@@ -118,6 +118,7 @@ VARIANTS = {
     'gs_tall_never': dict(flags=['-DHS_GS_TALL_MIN_WG=100000000'], extra=[], patch=None),
     'gs_tall_129': dict(flags=['-DHS_GS_TALL_MIN_WG=129'], extra=[], patch=None),
     'gs_tall_513': dict(flags=['-DHS_GS_TALL_MIN_WG=513'], extra=[], patch=None),
+    'k1m_256': dict(flags=['-DHS_K1M_MIN_PATCHES=256'], extra=[], patch=None),            # ... from 256 patches (HyperSeg-M level 1: 512)
     'k1m_off': dict(flags=['-DHS_K1M_MIN_PATCHES=2000000000'], extra=[], patch=None),   # batched k = 1 levels on the LDS-staged kernel
     's2b_light_first': dict(flags=['-DHS_S2B_LIGHT_FIRST'], extra=[], patch=None),
 }
