@@ -442,9 +442,11 @@ extern "C" int hs_depthwise_conv_fwd(const float* x, int32_t batch, int32_t chan
                                              y, channels, H, W, Ho, Wo, pad_t, pad_l, act, pool_partial, in_scale, in_shift, (int)nplanes)
     // the LDS-tiled form: BN0 + swish prologue, whole output rows per workgroup (same thread -> output map, same partials)
     const int wq = Wo / 4;
-    // Only for batched work (>= 8192 planes) on planes of >= 256 output quads: a batch-1 encoder's launches are latency-bound
-    // and the extra barrier costs more than the taps' swishes (HyperSeg-M: 1009 vs 1020 frames/s with it on everywhere).
-    if (in_scale && nplanes >= 8192 && threads == 256 && (Wo & 3) == 0 && threads % wq == 0 && (k == 3 || k == 5) &&
+    // For batched work (>= 8192 planes) and for every 5 x 5 launch (8.75 swishes per output there), on planes of >= 256 output quads:
+    // the 3 x 3 launches of a batch-1 encoder are latency-bound and the extra barrier costs more than the taps' swishes (HyperSeg-M,
+    // round 2: 1009 vs 1020 frames/s with it on everywhere; round 3 same-box A/B, profiles/round3_gemm_split_policy_ab.txt section 6:
+    // 5 x 5 only 0.7758 ms per frame against 0.7801, everywhere 0.7794, 5 x 5 incl. the 128-thread maps 0.7822).
+    if (in_scale && (nplanes >= 8192 || k == 5) && threads == 256 && (Wo & 3) == 0 && threads % wq == 0 && (k == 3 || k == 5) &&
         (stride == 1 || stride == 2)) {
         const int rows_out = threads / wq, rows_in = (rows_out - 1) * stride + k, tw = ((Wo - 1) * stride + k + 3) & ~3;
         const size_t lds = (size_t)rows_in * tw * sizeof(float);

@@ -90,9 +90,9 @@ PATCHES = {
     'px2wg': [('    constexpr size_t lds = (size_t)G::FLOATS * sizeof(float);', '    constexpr size_t lds = (size_t)G::FLOATS * sizeof(float) + 28 * 1024;')],
     # the LDS-tiled depthwise form (BN0 + swish once per input element) at batch 1: only the 5x5 launches / every launch that
     # qualifies.  The late 5x5 launches are vector-ALU bound (40 swishes per thread on the taps, ~5 waves per SIMD): DESIGN 7.1
-    'dwtile_k5': [('    if (in_scale && nplanes >= 8192 && threads == 256', '    if (in_scale && (nplanes >= 8192 || k == 5) && threads == 256')],
-    'dwtile_k5_128': [('    if (in_scale && nplanes >= 8192 && threads == 256', '    if (in_scale && (nplanes >= 8192 || k == 5) && threads >= 128')],
-    'dwtile_all': [('    if (in_scale && nplanes >= 8192 && threads == 256', '    if (in_scale && nplanes >= 1 && threads == 256')],
+    'dwtile_k5': [('    if (in_scale && (nplanes >= 8192 || k == 5) && threads == 256', '    if (in_scale && nplanes >= 8192 && threads == 256')],     # round 3: the product has it; this variant turns it OFF
+    'dwtile_k5_128': [('    if (in_scale && (nplanes >= 8192 || k == 5) && threads == 256', '    if (in_scale && (nplanes >= 8192 || k == 5) && threads >= 128')],
+    'dwtile_all': [('    if (in_scale && (nplanes >= 8192 || k == 5) && threads == 256', '    if (in_scale && nplanes >= 1 && threads == 256')],
     'ntstore': [(STORE_LINE, '                for (int jt = 0; jt < J3; ++jt) __builtin_nontemporal_store(fmaf(acc3[m][jt][r], sc, sh), &yo[yoff[jt]]);')],
 }
 
