@@ -93,6 +93,8 @@ PATCHES = {
     'dwtile_k5': [('    if (in_scale && (nplanes >= 8192 || k == 5) && threads == 256', '    if (in_scale && nplanes >= 8192 && threads == 256')],     # round 3: the product has it; this variant turns it OFF
     'dwtile_k5_128': [('    if (in_scale && (nplanes >= 8192 || k == 5) && threads == 256', '    if (in_scale && (nplanes >= 8192 || k == 5) && threads >= 128')],
     'dwtile_all': [('    if (in_scale && (nplanes >= 8192 || k == 5) && threads == 256', '    if (in_scale && nplanes >= 1 && threads == 256')],
+    'up_plainstore': [('        __builtin_nontemporal_store(v4f{o0[0], o0[1], o0[2], o0[3]}, reinterpret_cast<v4f*>(dst));\n        __builtin_nontemporal_store(v4f{o1[0], o1[1], o1[2], o1[3]}, reinterpret_cast<v4f*>(dst + Wo));',
+                       '        *reinterpret_cast<v4f*>(dst) = v4f{o0[0], o0[1], o0[2], o0[3]};\n        *reinterpret_cast<v4f*>(dst + Wo) = v4f{o1[0], o1[1], o1[2], o1[3]};')],
     'ntstore': [(STORE_LINE, '                for (int jt = 0; jt < J3; ++jt) __builtin_nontemporal_store(fmaf(acc3[m][jt][r], sc, sh), &yo[yoff[jt]]);')],
 }
 
@@ -107,6 +109,7 @@ VARIANTS = {
     'dwtile_k5': dict(flags=[], extra=[], patch='dwtile_k5', file='hs_encoder.hip'),
     'dwtile_k5_128': dict(flags=[], extra=[], patch='dwtile_k5_128', file='hs_encoder.hip'),   # + the 16x32 maps (128 threads)
     'dwtile_all': dict(flags=[], extra=[], patch='dwtile_all', file='hs_encoder.hip'),
+    'up_plainstore': dict(flags=[], extra=[], patch='up_plainstore', file='hs_patch_conv.hip'),   # final 2x upsample with ordinary stores
     'kpreload': dict(flags=['-mllvm', '-amdgpu-kernarg-preload-count=16'], extra=[], patch=None),
     's2b_kc20': dict(flags=['-DHS_S2B_KC=20'], extra=[], patch=None),          # blocked signal2weights: one LDS fill for K = 80 (40 KB)
     's2b_kc5': dict(flags=['-DHS_S2B_KC=5'], extra=[], patch=None),
