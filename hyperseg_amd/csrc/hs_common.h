@@ -126,6 +126,25 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
+// Storage types of the training-path kernels: fp32, or bf16 storage with fp32 arithmetic (rounded to nearest-even once on store).
+struct bf16_t { uint16_t v; };
+
+template <typename T> struct Store;
+template <> struct Store<float> {
+    static __device__ __forceinline__ float ld(const float* p, size_t i) { return p[i]; }
+    static __device__ __forceinline__ void st(float* p, size_t i, float x) { p[i] = x; }
+};
+template <> struct Store<bf16_t> {
+    static __device__ __forceinline__ float ld(const bf16_t* p, size_t i) { return __uint_as_float((uint32_t)p[i].v << 16); }
+    static __device__ __forceinline__ void st(bf16_t* p, size_t i, float x) {
+        uint32_t u = __float_as_uint(x);
+        if ((u & 0x7fffffffu) > 0x7f800000u) { p[i].v = (uint16_t)((u >> 16) | 0x40); return; }     // NaN stays NaN
+        u += 0x7fffu + ((u >> 16) & 1u);                                                           // round to nearest even
+        p[i].v = (uint16_t)(u >> 16);
+    }
+};
+
+
 // ---- host side ---------------------------------------------------------------------------
 inline int make_stage(const hs_stage_input* in, StageIn* out) {
     if (!in || (!in->skip && in->c_skip > 0)) return HS_ERR_BAD_ARG;

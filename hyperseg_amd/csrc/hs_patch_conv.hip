@@ -472,10 +472,9 @@ void upsample_argmax_kernel(const float* __restrict__ x, int B, int C, int Hi, i
     }
 }
 
-int try_launch_fwd_k1m(const float* x, int batch, int c_in, int H, int W, int fh, int fw, const float* bank, long ld, int c_out,
-                       const float* scale, const float* shift, int act, float* y, hipStream_t stream);           // hs_patch_conv_bwd.hip
-int try_launch_dw3_fwd(const float* x, int batch, int c, int H, int W, int fh, int fw, const float* bank, long ld, float* y,
-                       hipStream_t stream);                                                                      // hs_patch_conv_bwd.hip
+int try_fast_fwd(int dtype, const void* x, const void* bank, long ld, int batch, int c_in, int H, int W, int fh, int fw, int c_out,
+                 int k, int pad, int pad_mode, int groups, const float* scale, const float* shift, int act, void* y,
+                 hipStream_t stream);                                                                            // hs_patch_conv_bwd.hip
 int try_launch_k1m(const StageIn& si, int fh, int fw, const float* bank, long ld, int cin, int c_out,
                    const float* scale, const float* shift, int act, float* y, hipStream_t stream);     // hs_patch_conv_k1m.hip
 
@@ -504,14 +503,9 @@ extern "C" int hs_patch_conv_fwd(const hs_stage_input* in, int32_t fh, int32_t f
     a.scale = ep ? ep->scale : nullptr; a.shift = ep ? ep->shift : nullptr; a.act = ep ? ep->act : HS_ACT_NONE;
     if (a.scale && !a.shift) return HS_ERR_BAD_ARG;
     a.y = y;
-    if (k == 3 && pad == 1 && pad_mode == HS_PAD_ZEROS && groups == cin && cin == c_out && !a.in.coords && a.in.c_prev == 0 &&
-        !a.scale && a.act == HS_ACT_NONE) {                                 // plain depthwise 3x3 (the autograd path's middle layer)
-        const int r = try_launch_dw3_fwd(a.in.skip, a.in.B, cin, a.in.H, a.in.W, fh, fw, bank, (long)ld, y, (hipStream_t)stream);
-        if (r != 1) return r;
-    }
-    if (k == 1 && groups == 1 && !a.in.coords && a.in.c_prev == 0) {       // plain input (the autograd path): hs_patch_conv_bwd.hip
-        const int r = try_launch_fwd_k1m(a.in.skip, a.in.B, cin, a.in.H, a.in.W, fh, fw, bank, (long)ld, c_out, a.scale, a.shift, a.act, y,
-                                         (hipStream_t)stream);
+    if (!a.in.coords && a.in.c_prev == 0) {       // plain input (the autograd path): matrix-core / image-level forms of hs_patch_conv_bwd.hip
+        const int r = try_fast_fwd(HS_DTYPE_F32, a.in.skip, bank, (long)ld, a.in.B, cin, a.in.H, a.in.W, fh, fw, c_out, k, pad, pad_mode, groups,
+                                   a.scale, a.shift, a.act, y, (hipStream_t)stream);
         if (r != 1) return r;
     }
     if (k == 1 && groups == 1) {           // batched tiny patches: the weight stream on the matrix cores (hs_patch_conv_k1m.hip)

@@ -24,10 +24,12 @@ struct ConvBwdArgs {
     int B, H, W, fh, fw, ph, pw, cin, cout, k, pad, pad_mode, groups, cin_g, cout_g;
 };
 
-int try_launch_fwd_k1m(const float* x, int batch, int c_in, int H, int W, int fh, int fw, const float* bank, long ld, int c_out,
-                       const float* scale, const float* shift, int act, float* y, hipStream_t stream);
-int try_launch_dw3_fwd(const float* x, int batch, int c, int H, int W, int fh, int fw, const float* bank, long ld, float* y,
-                       hipStream_t stream);
+int try_fast_fwd(int dtype, const void* x, const void* bank, long ld, int batch, int c_in, int H, int W, int fh, int fw, int c_out,
+                 int k, int pad, int pad_mode, int groups, const float* scale, const float* shift, int act, void* y, hipStream_t stream);
+int try_fast_bwd_in(int dtype, const void* dy, const void* bank, long ld, int batch, int c_in, int H, int W, int fh, int fw,
+                    int c_out, int k, int pad, int pad_mode, int groups, void* dx, hipStream_t stream);
+int try_fast_bwd_w(int dtype, const void* x, const void* dy, int batch, int c_in, int H, int W, int fh, int fw, int c_out, int k,
+                   int pad, int pad_mode, int groups, void* dbank, long ld, hipStream_t stream);
 
 // number of padded coordinates (in [-pad, n+pad)) that map onto index i, and the q-th of them
 __device__ __forceinline__ int pad_aliases(int i, int n, int pad, int mode, int* out) {
@@ -135,31 +137,33 @@ using bw_f32x4 = __attribute__((ext_vector_type(4))) float;
 // VEC: patches whose rows are whole 4-pixel groups on 16-byte boundaries and whose pixel count is a multiple of 16.  Otherwise (the
 // (ph + 2) x (pw + 2) halo tiles that a train-mode v1_0 inverted residual feeds to its first 1x1 convolution: 18 x 18, 10 x 10) the
 // lane's four pixels are four 4-byte loads with their own row / column, and pixels past the patch contribute zeros.
-template <int MT, int NTI, bool VEC>
+// T: storage type (float, or bf16_t: bf16 in memory, f32 products and sums, one rounding on store -- hs_common.h Store<T>).
+template <int MT, int NTI, bool VEC, typename T>
 __global__ __launch_bounds__(256)
 void patch_conv_bwd_weight_k1m_kernel(ConvBwdArgs a) {
+    static_assert(!VEC || sizeof(T) == 4, "vector loads: fp32 storage only");
     __shared__ __attribute__((aligned(16))) float red[4][MT * NTI][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kg = lane >> 4;
     const int patch = blockIdx.x;
     const int pj = patch % a.fw, pi = (patch / a.fw) % a.fh, b = patch / (a.fw * a.fh);
     const size_t plane = (size_t)a.H * a.W;
-    const float* __restrict__ dyp[MT];
-    const float* __restrict__ xp[NTI];
+    const T* __restrict__ dyp[MT];
+    const T* __restrict__ xp[NTI];
     const size_t org = (size_t)(pi * a.ph) * a.W + pj * a.pw;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) dyp[mt] = a.dy + ((size_t)b * a.cout + min(16 * mt + n, a.cout - 1)) * plane + org;
+    for (int mt = 0; mt < MT; ++mt) dyp[mt] = (const T*)a.dy + ((size_t)b * a.cout + min(16 * mt + n, a.cout - 1)) * plane + org;
 #pragma unroll
-    for (int nt = 0; nt < NTI; ++nt) xp[nt] = a.x + ((size_t)b * a.cin + min(16 * nt + n, a.cin - 1)) * plane + org;
+    for (int nt = 0; nt < NTI; ++nt) xp[nt] = (const T*)a.x + ((size_t)b * a.cin + min(16 * nt + n, a.cin - 1)) * plane + org;
     const int npix = a.ph * a.pw, nch = (npix + 15) >> 4;                // chunks of 16 pixels in patch-linear order
     auto fetch = [&](int s, bw_f32x4 (&av)[MT], bw_f32x4 (&bv)[NTI]) {
         if constexpr (VEC) {
             const int l = 16 * s + 4 * kg, u = l / a.pw, v = l - u * a.pw;   // pw % 4 == 0: the lane's 4 pixels are one row segment
             const size_t off = (size_t)u * a.W + v;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const bw_f32x4*>(dyp[mt] + off);
+            for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const bw_f32x4*>((const float*)dyp[mt] + off);
 #pragma unroll
-            for (int nt = 0; nt < NTI; ++nt) bv[nt] = *reinterpret_cast<const bw_f32x4*>(xp[nt] + off);
+            for (int nt = 0; nt < NTI; ++nt) bv[nt] = *reinterpret_cast<const bw_f32x4*>((const float*)xp[nt] + off);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -167,9 +171,9 @@ void patch_conv_bwd_weight_k1m_kernel(ConvBwdArgs a) {
                 const size_t off = (size_t)u * a.W + v;
                 const float live = l < npix ? 1.0f : 0.0f;               // clamped address, masked by a multiply (no branch around a load)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) av[mt][j] = dyp[mt][off] * live;
+                for (int mt = 0; mt < MT; ++mt) av[mt][j] = Store<T>::ld(dyp[mt], off) * live;
 #pragma unroll
-                for (int nt = 0; nt < NTI; ++nt) bv[nt][j] = xp[nt][off];
+                for (int nt = 0; nt < NTI; ++nt) bv[nt][j] = Store<T>::ld(xp[nt], off);
             }
         }
     };
@@ -203,16 +207,16 @@ void patch_conv_bwd_weight_k1m_kernel(ConvBwdArgs a) {
         for (int nt = 0; nt < NTI; ++nt)
             *reinterpret_cast<bw_f32x4*>(&red[wave][mt * NTI + nt][4 * lane]) = acc[mt][nt];
     __syncthreads();
-    float* __restrict__ dst = a.dbank + (size_t)patch * a.ld;
+    T* __restrict__ dst = (T*)a.dbank + (size_t)patch * a.ld;
     for (int e = tid; e < MT * NTI * 256; e += 256) {
         const int tile = e >> 8, w = e & 255, ln = w >> 2, r = w & 3;
         const int o = 16 * (tile / NTI) + 4 * (ln >> 4) + r, c = 16 * (tile % NTI) + (ln & 15);
         if (o < a.cout && c < a.cin)
-            dst[(size_t)o * a.cin + c] = ((red[0][tile][w] + red[1][tile][w]) + red[2][tile][w]) + red[3][tile][w];
+            Store<T>::st(dst, (size_t)o * a.cin + c, ((red[0][tile][w] + red[1][tile][w]) + red[2][tile][w]) + red[3][tile][w]);
     }
 }
 
-template <int CT, int KQ>
+template <int CT, int KQ, typename T>
 __global__ __launch_bounds__(256)
 void patch_conv_bwd_input_k1m_kernel(ConvBwdArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -222,7 +226,7 @@ void patch_conv_bwd_input_k1m_kernel(ConvBwdArgs a) {
     const size_t plane = (size_t)a.H * a.W;
     // A[i = input channel][k = output channel] = W[o][c]: this patch's bank row, o = 16 q + 4 kg + j, c = 16 ct + n (clamped: the
     // rows / columns beyond the layer multiply zeros of B or land in rows that are never stored)
-    const float* __restrict__ wp = a.bank + (size_t)patch * a.ld;
+    const T* __restrict__ wp = (const T*)a.bank + (size_t)patch * a.ld;
     float aw[CT][KQ][4];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
@@ -230,10 +234,10 @@ void patch_conv_bwd_input_k1m_kernel(ConvBwdArgs a) {
         for (int q = 0; q < KQ; ++q)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                aw[ct][q][j] = wp[(size_t)min(16 * q + 4 * kg + j, a.cout - 1) * a.cin + min(16 * ct + n, a.cin - 1)];
+                aw[ct][q][j] = Store<T>::ld(wp, (size_t)min(16 * q + 4 * kg + j, a.cout - 1) * a.cin + min(16 * ct + n, a.cin - 1));
     const size_t org = (size_t)(pi * a.ph) * a.W + pj * a.pw;
-    const float* __restrict__ dyb = a.dy + (size_t)b * a.cout * plane + org;
-    float* __restrict__ dxb = a.dx + (size_t)b * a.cin * plane + org;
+    const T* __restrict__ dyb = (const T*)a.dy + (size_t)b * a.cout * plane + org;
+    T* __restrict__ dxb = (T*)a.dx + (size_t)b * a.cin * plane + org;
     const int npix = a.ph * a.pw, ntile = (npix + 15) >> 4;
     auto fetch = [&](int t, float (&bv)[KQ][4], size_t& off) {
         const int l = min(16 * t + n, npix - 1), u = l / a.pw, v = l - u * a.pw;     // past the patch: a live pixel, not stored
@@ -243,7 +247,7 @@ void patch_conv_bwd_input_k1m_kernel(ConvBwdArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int o = 16 * q + 4 * kg + j;
-                const float val = dyb[(size_t)min(o, a.cout - 1) * plane + off];
+                const float val = Store<T>::ld(dyb, (size_t)min(o, a.cout - 1) * plane + off);
                 bv[q][j] = o < a.cout ? val : 0.0f;
             }
     };
@@ -259,7 +263,7 @@ void patch_conv_bwd_input_k1m_kernel(ConvBwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int c = 16 * ct + 4 * kg + r;
-                if (c < a.cin && live) dxb[(size_t)c * plane + off] = acc[r];
+                if (c < a.cin && live) Store<T>::st(dxb, (size_t)c * plane + off, acc[r]);
             }
         }
     };
@@ -279,7 +283,7 @@ void patch_conv_bwd_input_k1m_kernel(ConvBwdArgs a) {
 // The forward of the same layer on a PLAIN input tensor (what the autograd path calls: no fused stage-input prologue), same structure
 // as the input-gradient kernel with the bank row read untransposed:  y[o][px] = sum_c W[o][c] x[c][px].  a.dy = x (cin channels),
 // a.dx = y (cout channels); BatchNorm affine + activation optional.
-template <int MT, int KQ>
+template <int MT, int KQ, typename T>
 __global__ __launch_bounds__(256)
 void patch_conv_fwd_k1m_kernel(ConvBwdArgs a, const float* __restrict__ scale, const float* __restrict__ shift, int act) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -287,7 +291,7 @@ void patch_conv_fwd_k1m_kernel(ConvBwdArgs a, const float* __restrict__ scale, c
     const int patch = blockIdx.x;
     const int pj = patch % a.fw, pi = (patch / a.fw) % a.fh, b = patch / (a.fw * a.fh);
     const size_t plane = (size_t)a.H * a.W;
-    const float* __restrict__ wp = a.bank + (size_t)patch * a.ld;
+    const T* __restrict__ wp = (const T*)a.bank + (size_t)patch * a.ld;
     float aw[MT][KQ][4];                                                // A[i = output channel][k = input channel]
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -295,7 +299,7 @@ void patch_conv_fwd_k1m_kernel(ConvBwdArgs a, const float* __restrict__ scale, c
         for (int q = 0; q < KQ; ++q)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                aw[mt][q][j] = wp[(size_t)min(16 * mt + n, a.cout - 1) * a.cin + min(16 * q + 4 * kg + j, a.cin - 1)];
+                aw[mt][q][j] = Store<T>::ld(wp, (size_t)min(16 * mt + n, a.cout - 1) * a.cin + min(16 * q + 4 * kg + j, a.cin - 1));
     float sc[MT][4], sh[MT][4];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -305,8 +309,8 @@ void patch_conv_fwd_k1m_kernel(ConvBwdArgs a, const float* __restrict__ scale, c
             sc[mt][r] = scale ? scale[o] : 1.0f; sh[mt][r] = scale ? shift[o] : 0.0f;
         }
     const size_t org = (size_t)(pi * a.ph) * a.W + pj * a.pw;
-    const float* __restrict__ xb = a.dy + (size_t)b * a.cin * plane + org;
-    float* __restrict__ yb = a.dx + (size_t)b * a.cout * plane + org;
+    const T* __restrict__ xb = (const T*)a.dy + (size_t)b * a.cin * plane + org;
+    T* __restrict__ yb = (T*)a.dx + (size_t)b * a.cout * plane + org;
     const int npix = a.ph * a.pw, ntile = (npix + 15) >> 4;
     auto fetch = [&](int t, float (&bv)[KQ][4], size_t& off) {
         const int l = min(16 * t + n, npix - 1), u = l / a.pw, v = l - u * a.pw;
@@ -316,7 +320,7 @@ void patch_conv_fwd_k1m_kernel(ConvBwdArgs a, const float* __restrict__ scale, c
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int c = 16 * q + 4 * kg + j;
-                const float val = xb[(size_t)min(c, a.cin - 1) * plane + off];
+                const float val = Store<T>::ld(xb, (size_t)min(c, a.cin - 1) * plane + off);
                 bv[q][j] = c < a.cin ? val : 0.0f;
             }
     };
@@ -332,7 +336,7 @@ void patch_conv_fwd_k1m_kernel(ConvBwdArgs a, const float* __restrict__ scale, c
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int o = 16 * mt + 4 * kg + r;
-                if (o < a.cout && live) yb[(size_t)o * plane + off] = apply_act(fmaf(acc[r], sc[mt][r], sh[mt][r]), act);
+                if (o < a.cout && live) Store<T>::st(yb, (size_t)o * plane + off, apply_act(fmaf(acc[r], sc[mt][r], sh[mt][r]), act));
             }
         }
     };
@@ -357,24 +361,25 @@ void patch_conv_fwd_k1m_kernel(ConvBwdArgs a, const float* __restrict__ scale, c
 // any k / groups / padding) took 102 / 79 / ~60 us per launch at config 5 for 83 M multiply-adds.
 // ---------------------------------------------------------------------------------------------------------------------------------
 // MODE 0: y = conv(x, K).  MODE 1: dx = adjoint wrt x (the taps of the patch that owns the OUTPUT pixel, mirrored).
-template <int MODE>
+template <int MODE, typename T>
 __global__ __launch_bounds__(256)
-void patch_dw3_kernel(ConvBwdArgs a, const float* __restrict__ src, float* __restrict__ dst) {
+void patch_dw3_kernel(ConvBwdArgs a, const T* __restrict__ src, T* __restrict__ dst) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int plane_id = blockIdx.z, c = plane_id % a.cin, b = plane_id / a.cin;
     if (x >= a.W || y >= a.H) return;
-    const float* __restrict__ sp = src + (size_t)plane_id * a.H * a.W;
+    const T* __restrict__ sp = src + (size_t)plane_id * a.H * a.W;
+    const T* __restrict__ bank = (const T*)a.bank;
     float acc = 0.0f;
     if constexpr (MODE == 0) {
-        const float* __restrict__ kp = a.bank + (size_t)((b * a.fh + y / a.ph) * a.fw + x / a.pw) * a.ld + c * 9;
+        const T* __restrict__ kp = bank + (size_t)((b * a.fh + y / a.ph) * a.fw + x / a.pw) * a.ld + c * 9;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int yy = y + ky - 1, xx = x + kx - 1;
                 const bool in = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-                const float v = sp[(size_t)min(max(yy, 0), a.H - 1) * a.W + min(max(xx, 0), a.W - 1)];
-                acc = fmaf(kp[ky * 3 + kx], in ? v : 0.0f, acc);
+                const float v = Store<T>::ld(sp, (size_t)min(max(yy, 0), a.H - 1) * a.W + min(max(xx, 0), a.W - 1));
+                acc = fmaf(Store<T>::ld(kp, ky * 3 + kx), in ? v : 0.0f, acc);
             }
     } else {
 #pragma unroll
@@ -384,16 +389,17 @@ void patch_dw3_kernel(ConvBwdArgs a, const float* __restrict__ src, float* __res
                 const int yo = y - ky + 1, xo = x - kx + 1;              // the output pixel this input feeds through tap (ky, kx)
                 const bool in = yo >= 0 && yo < a.H && xo >= 0 && xo < a.W;
                 const int yc = min(max(yo, 0), a.H - 1), xc = min(max(xo, 0), a.W - 1);
-                const float g = sp[(size_t)yc * a.W + xc];
-                const float w = a.bank[(size_t)((b * a.fh + yc / a.ph) * a.fw + xc / a.pw) * a.ld + c * 9 + ky * 3 + kx];
+                const float g = Store<T>::ld(sp, (size_t)yc * a.W + xc);
+                const float w = Store<T>::ld(bank, (size_t)((b * a.fh + yc / a.ph) * a.fw + xc / a.pw) * a.ld + c * 9 + ky * 3 + kx);
                 acc = fmaf(w, in ? g : 0.0f, acc);
             }
     }
-    dst[(size_t)plane_id * a.H * a.W + (size_t)y * a.W + x] = acc;
+    Store<T>::st(dst, (size_t)plane_id * a.H * a.W + (size_t)y * a.W + x, acc);
 }
 
 // dK[patch][c][ky][kx] = sum over the patch's pixels of dY[c][y][x] X[c][y + ky - 1][x + kx - 1] (zero outside the image): one wave per
 // (patch, channel), lanes over the pixels, nine accumulators, DPP wave sums.
+template <typename T>
 __global__ __launch_bounds__(256)
 void patch_dw3_bwd_weight_kernel(ConvBwdArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -401,28 +407,28 @@ void patch_dw3_bwd_weight_kernel(ConvBwdArgs a) {
     if (c >= a.cin) return;
     const int pj = patch % a.fw, pi = (patch / a.fw) % a.fh, b = patch / (a.fw * a.fh);
     const size_t plane = (size_t)a.H * a.W;
-    const float* __restrict__ xp = a.x + ((size_t)b * a.cin + c) * plane;
-    const float* __restrict__ gp = a.dy + ((size_t)b * a.cin + c) * plane;
+    const T* __restrict__ xp = (const T*)a.x + ((size_t)b * a.cin + c) * plane;
+    const T* __restrict__ gp = (const T*)a.dy + ((size_t)b * a.cin + c) * plane;
     const int y0 = pi * a.ph, x0 = pj * a.pw, npix = a.ph * a.pw;
     float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int l = lane; l < npix; l += 64) {
         const int u = l / a.pw, v = l - u * a.pw, y = y0 + u, x = x0 + v;
-        const float g = gp[(size_t)y * a.W + x];
+        const float g = Store<T>::ld(gp, (size_t)y * a.W + x);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int yy = y + ky - 1, xx = x + kx - 1;
                 const bool in = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-                const float val = xp[(size_t)min(max(yy, 0), a.H - 1) * a.W + min(max(xx, 0), a.W - 1)];
+                const float val = Store<T>::ld(xp, (size_t)min(max(yy, 0), a.H - 1) * a.W + min(max(xx, 0), a.W - 1));
                 acc[ky * 3 + kx] = fmaf(g, in ? val : 0.0f, acc[ky * 3 + kx]);
             }
     }
-    float* __restrict__ dst = a.dbank + (size_t)patch * a.ld + c * 9;
+    T* __restrict__ dst = (T*)a.dbank + (size_t)patch * a.ld + c * 9;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const float s = wave_sum64(acc[t]);
-        if (lane == 0) dst[t] = s;
+        if (lane == 0) Store<T>::st(dst, t, s);
     }
 }
 
@@ -430,33 +436,93 @@ void patch_dw3_bwd_weight_kernel(ConvBwdArgs a) {
 
 using namespace hs;
 
-// 0 = launched, 1 = not covered.  Depthwise (groups == channels), k = 3, zero padding, plain input.
-int hs::try_launch_dw3_fwd(const float* x, int batch, int c, int H, int W, int fh, int fw, const float* bank, long ld, float* y,
-                           hipStream_t stream) {
-    if (H % fh || W % fw || (long)batch * c > 65535) return 1;
-    ConvBwdArgs a{};
-    a.bank = bank; a.ld = ld; a.B = batch; a.H = H; a.W = W; a.fh = fh; a.fw = fw; a.ph = H / fh; a.pw = W / fw; a.cin = c; a.cout = c;
-    hipLaunchKernelGGL(patch_dw3_kernel<0>, dim3((W + 63) / 64, (H + 3) / 4, batch * c), dim3(256), 0, stream, a, x, y);
-    return launch_status();
-}
-
-// 0 = launched, 1 = not covered.  Plain input (no coords, no previous level), k = 1, groups = 1, patches of >= 64 pixels.
-int hs::try_launch_fwd_k1m(const float* x, int batch, int c_in, int H, int W, int fh, int fw, const float* bank, long ld, int c_out,
-                           const float* scale, const float* shift, int act, float* y, hipStream_t stream) {
-    if (H % fh || W % fw) return 1;
-    ConvBwdArgs a{};
-    a.dy = x; a.dx = y; a.bank = bank; a.ld = ld; a.B = batch; a.H = H; a.W = W; a.fh = fh; a.fw = fw; a.ph = H / fh; a.pw = W / fw;
+// ---- the matrix-core / image-level forms above behind three storage-type-aware launchers, shared by the fp32 entry points below and by
+// hs_patch_conv_plain_* (hs_patch_conv_train.hip).  0 = launched, 1 = not covered (the caller goes on to its generic kernel).
+static void fast_args(ConvBwdArgs& a, const void* bank, long ld, int batch, int c_in, int H, int W, int fh, int fw, int c_out) {
+    a = ConvBwdArgs{};
+    a.bank = (const float*)bank; a.ld = ld; a.B = batch; a.H = H; a.W = W; a.fh = fh; a.fw = fw; a.ph = H / fh; a.pw = W / fw;
     a.cin = c_in; a.cout = c_out; a.k = 1; a.groups = 1; a.cin_g = c_in; a.cout_g = c_out;
-    if (a.ph * a.pw < 64) return 1;
+}
+#define HS_T2(dtype, F32, BF16) do { if ((dtype) == HS_DTYPE_F32) { F32; } else { BF16; } } while (0)
+
+int hs::try_fast_fwd(int dtype, const void* x, const void* bank, long ld, int batch, int c_in, int H, int W, int fh, int fw, int c_out,
+                     int k, int pad, int pad_mode, int groups, const float* scale, const float* shift, int act, void* y, hipStream_t stream) {
+    if (H % fh || W % fw || (dtype != HS_DTYPE_F32 && dtype != HS_DTYPE_BF16)) return 1;
+    ConvBwdArgs a;
+    fast_args(a, bank, ld, batch, c_in, H, W, fh, fw, c_out);
+    if (k == 3 && pad == 1 && pad_mode == HS_PAD_ZEROS && groups == c_in && c_in == c_out && !scale && act == HS_ACT_NONE &&
+        (long)batch * c_in <= 65535) {                                  // plain depthwise 3x3 (the autograd path's middle layer)
+        const dim3 grid((W + 63) / 64, (H + 3) / 4, batch * c_in);
+        HS_T2(dtype, hipLaunchKernelGGL((patch_dw3_kernel<0, float>), grid, dim3(256), 0, stream, a, (const float*)x, (float*)y),
+                     hipLaunchKernelGGL((patch_dw3_kernel<0, bf16_t>), grid, dim3(256), 0, stream, a, (const bf16_t*)x, (bf16_t*)y));
+        return launch_status();
+    }
+    if (k != 1 || groups != 1 || a.ph * a.pw < 64) return 1;
+    a.dy = (const float*)x; a.dx = (float*)y;
     const int mt = (c_out + 15) / 16, kq = (c_in + 15) / 16;
     const dim3 grid((unsigned)(batch * fh * fw));
 #define HS_FW(MTV, KQV) if (mt == MTV && kq == KQV) { \
-        hipLaunchKernelGGL((patch_conv_fwd_k1m_kernel<MTV, KQV>), grid, dim3(256), 0, stream, a, scale, shift, act); return launch_status(); }
+        HS_T2(dtype, hipLaunchKernelGGL((patch_conv_fwd_k1m_kernel<MTV, KQV, float>), grid, dim3(256), 0, stream, a, scale, shift, act), \
+                     hipLaunchKernelGGL((patch_conv_fwd_k1m_kernel<MTV, KQV, bf16_t>), grid, dim3(256), 0, stream, a, scale, shift, act)); \
+        return launch_status(); }
     HS_FW(1, 1) HS_FW(1, 2) HS_FW(1, 3) HS_FW(1, 4) HS_FW(2, 1) HS_FW(2, 2) HS_FW(2, 3) HS_FW(2, 4)
     HS_FW(3, 1) HS_FW(3, 2) HS_FW(3, 3) HS_FW(3, 4) HS_FW(4, 1) HS_FW(4, 2) HS_FW(4, 3)
 #undef HS_FW
     return 1;
 }
+
+int hs::try_fast_bwd_in(int dtype, const void* dy, const void* bank, long ld, int batch, int c_in, int H, int W, int fh, int fw,
+                        int c_out, int k, int pad, int pad_mode, int groups, void* dx, hipStream_t stream) {
+    if (H % fh || W % fw || (dtype != HS_DTYPE_F32 && dtype != HS_DTYPE_BF16)) return 1;
+    ConvBwdArgs a;
+    fast_args(a, bank, ld, batch, c_in, H, W, fh, fw, c_out);
+    a.dy = (const float*)dy; a.dx = (float*)dx;
+    if (k == 3 && pad == 1 && pad_mode == HS_PAD_ZEROS && groups == c_in && c_in == c_out && (long)batch * c_in <= 65535) {
+        const dim3 grid((W + 63) / 64, (H + 3) / 4, batch * c_in);
+        HS_T2(dtype, hipLaunchKernelGGL((patch_dw3_kernel<1, float>), grid, dim3(256), 0, stream, a, (const float*)dy, (float*)dx),
+                     hipLaunchKernelGGL((patch_dw3_kernel<1, bf16_t>), grid, dim3(256), 0, stream, a, (const bf16_t*)dy, (bf16_t*)dx));
+        return launch_status();
+    }
+    if (k != 1 || groups != 1 || a.ph * a.pw < 16) return 1;
+    const int ct = (c_in + 15) / 16, kq = (c_out + 15) / 16;
+    const dim3 grid((unsigned)(batch * fh * fw));
+#define HS_BI(CTV, KQV) if (ct == CTV && kq == KQV) { \
+        HS_T2(dtype, hipLaunchKernelGGL((patch_conv_bwd_input_k1m_kernel<CTV, KQV, float>), grid, dim3(256), 0, stream, a), \
+                     hipLaunchKernelGGL((patch_conv_bwd_input_k1m_kernel<CTV, KQV, bf16_t>), grid, dim3(256), 0, stream, a)); \
+        return launch_status(); }
+    HS_BI(1, 1) HS_BI(1, 2) HS_BI(1, 3) HS_BI(1, 4) HS_BI(2, 1) HS_BI(2, 2) HS_BI(2, 3) HS_BI(2, 4)
+    HS_BI(3, 1) HS_BI(3, 2) HS_BI(3, 3) HS_BI(3, 4) HS_BI(4, 1) HS_BI(4, 2) HS_BI(4, 3) HS_BI(6, 1) HS_BI(6, 2)
+#undef HS_BI
+    return 1;
+}
+
+int hs::try_fast_bwd_w(int dtype, const void* x, const void* dy, int batch, int c_in, int H, int W, int fh, int fw, int c_out, int k,
+                       int pad, int pad_mode, int groups, void* dbank, long ld, hipStream_t stream) {
+    if (H % fh || W % fw || (dtype != HS_DTYPE_F32 && dtype != HS_DTYPE_BF16)) return 1;
+    ConvBwdArgs a;
+    fast_args(a, nullptr, ld, batch, c_in, H, W, fh, fw, c_out);
+    a.x = (const float*)x; a.dy = (const float*)dy; a.dbank = (float*)dbank;
+    if (k == 3 && pad == 1 && pad_mode == HS_PAD_ZEROS && groups == c_in && c_in == c_out && (c_in + 3) / 4 <= 65535) {
+        const dim3 grid((unsigned)(batch * fh * fw), (c_in + 3) / 4);
+        HS_T2(dtype, hipLaunchKernelGGL(patch_dw3_bwd_weight_kernel<float>, grid, dim3(256), 0, stream, a),
+                     hipLaunchKernelGGL(patch_dw3_bwd_weight_kernel<bf16_t>, grid, dim3(256), 0, stream, a));
+        return launch_status();
+    }
+    if (k != 1 || groups != 1 || a.ph * a.pw < 16) return 1;
+    const bool vec = dtype == HS_DTYPE_F32 && (a.pw & 3) == 0 && ((a.ph * a.pw) & 15) == 0 && (W & 3) == 0 &&
+                     ((((size_t)x) | ((size_t)dy)) & 15) == 0;
+    const int mt = (c_out + 15) / 16, nt = (c_in + 15) / 16;
+    const dim3 grid((unsigned)(batch * fh * fw));
+#define HS_BW(MTV, NTV) if (mt == MTV && nt == NTV) { \
+        if (vec) hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, true, float>), grid, dim3(256), 0, stream, a); \
+        else HS_T2(dtype, hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, false, float>), grid, dim3(256), 0, stream, a), \
+                          hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, false, bf16_t>), grid, dim3(256), 0, stream, a)); \
+        return launch_status(); }
+    HS_BW(1, 1) HS_BW(1, 2) HS_BW(1, 3) HS_BW(1, 4) HS_BW(2, 1) HS_BW(2, 2) HS_BW(2, 3) HS_BW(2, 4) HS_BW(3, 1) HS_BW(3, 2) HS_BW(4, 1) HS_BW(4, 2)
+#undef HS_BW
+    return 1;
+}
+#undef HS_T2
 
 static int fill_bwd(ConvBwdArgs& a, const float* x, const float* dy, const float* bank, int64_t ld, int32_t batch,
                     int32_t c_in, int32_t H, int32_t W, int32_t fh, int32_t fw, int32_t c_out, int32_t k, int32_t pad,
@@ -484,18 +550,10 @@ extern "C" int hs_patch_conv_bwd_input(const float* dy, const float* bank, int64
     if (st != HS_OK) return st;
     if (!bank || !dx) return HS_ERR_BAD_ARG;
     a.dx = dx; a.dbank = nullptr;
-    if (k == 3 && pad == 1 && pad_mode == HS_PAD_ZEROS && groups == c_in && c_in == c_out && (long)batch * c_in <= 65535) {
-        hipLaunchKernelGGL(patch_dw3_kernel<1>, dim3((W + 63) / 64, (H + 3) / 4, batch * c_in), dim3(256), 0, (hipStream_t)stream, a, dy, dx);
-        return launch_status();
-    }
-    if (k == 1 && groups == 1 && a.ph * a.pw >= 16) {
-        const int ct = (c_in + 15) / 16, kq = (c_out + 15) / 16;
-        const dim3 grid((unsigned)(batch * fh * fw));
-#define HS_BI(CTV, KQV) if (ct == CTV && kq == KQV) { \
-            hipLaunchKernelGGL((patch_conv_bwd_input_k1m_kernel<CTV, KQV>), grid, dim3(256), 0, (hipStream_t)stream, a); return launch_status(); }
-        HS_BI(1, 1) HS_BI(1, 2) HS_BI(1, 3) HS_BI(1, 4) HS_BI(2, 1) HS_BI(2, 2) HS_BI(2, 3) HS_BI(2, 4)
-        HS_BI(3, 1) HS_BI(3, 2) HS_BI(3, 3) HS_BI(3, 4) HS_BI(4, 1) HS_BI(4, 2) HS_BI(4, 3) HS_BI(6, 1) HS_BI(6, 2)
-#undef HS_BI
+    {
+        const int r = try_fast_bwd_in(HS_DTYPE_F32, dy, bank, (long)ld, batch, c_in, H, W, fh, fw, c_out, k, pad, pad_mode, groups, dx,
+                                      (hipStream_t)stream);
+        if (r != 1) return r;
     }
     const size_t total = (size_t)batch * c_in * H * W;
     const unsigned blocks = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
@@ -511,20 +569,10 @@ extern "C" int hs_patch_conv_bwd_weight(const float* x, const float* dy, int32_t
     if (st != HS_OK) return st;
     if (!x || !dbank) return HS_ERR_BAD_ARG;
     a.dx = nullptr; a.dbank = dbank;
-    if (k == 3 && pad == 1 && pad_mode == HS_PAD_ZEROS && groups == c_in && c_in == c_out && (c_in + 3) / 4 <= 65535) {
-        hipLaunchKernelGGL(patch_dw3_bwd_weight_kernel, dim3((unsigned)(batch * fh * fw), (c_in + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
-        return launch_status();
-    }
-    if (k == 1 && groups == 1 && a.ph * a.pw >= 16) {
-        const bool vec = (a.pw & 3) == 0 && ((a.ph * a.pw) & 15) == 0 && (W & 3) == 0 && ((((size_t)x) | ((size_t)dy)) & 15) == 0;
-        const int mt = (c_out + 15) / 16, nt = (c_in + 15) / 16;
-        const dim3 grid((unsigned)(batch * fh * fw));
-#define HS_BW(MTV, NTV) if (mt == MTV && nt == NTV) { \
-            if (vec) hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, true>), grid, dim3(256), 0, (hipStream_t)stream, a); \
-            else hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, false>), grid, dim3(256), 0, (hipStream_t)stream, a); \
-            return launch_status(); }
-        HS_BW(1, 1) HS_BW(1, 2) HS_BW(1, 3) HS_BW(1, 4) HS_BW(2, 1) HS_BW(2, 2) HS_BW(2, 3) HS_BW(2, 4) HS_BW(3, 1) HS_BW(3, 2) HS_BW(4, 1) HS_BW(4, 2)
-#undef HS_BW
+    {
+        const int r = try_fast_bwd_w(HS_DTYPE_F32, x, dy, batch, c_in, H, W, fh, fw, c_out, k, pad, pad_mode, groups, dbank, (long)ld,
+                                     (hipStream_t)stream);
+        if (r != 1) return r;
     }
     // output-channel block: as many channels (whole groups when the convolution is grouped) as fit beside the X tile
     const size_t npix = (size_t)a.ph * a.pw, tpos = (size_t)(a.ph + 2 * pad) * (a.pw + 2 * pad);

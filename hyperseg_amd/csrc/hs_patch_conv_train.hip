@@ -12,23 +12,6 @@
 
 namespace hs {
 
-struct bf16_t { uint16_t v; };
-
-template <typename T> struct Store;
-template <> struct Store<float> {
-    static __device__ __forceinline__ float ld(const float* p, size_t i) { return p[i]; }
-    static __device__ __forceinline__ void st(float* p, size_t i, float x) { p[i] = x; }
-};
-template <> struct Store<bf16_t> {
-    static __device__ __forceinline__ float ld(const bf16_t* p, size_t i) { return __uint_as_float((uint32_t)p[i].v << 16); }
-    static __device__ __forceinline__ void st(bf16_t* p, size_t i, float x) {
-        uint32_t u = __float_as_uint(x);
-        if ((u & 0x7fffffffu) > 0x7f800000u) { p[i].v = (uint16_t)((u >> 16) | 0x40); return; }     // NaN stays NaN
-        u += 0x7fffu + ((u >> 16) & 1u);                                                           // round to nearest even
-        p[i].v = (uint16_t)(u >> 16);
-    }
-};
-
 struct PlainArgs {
     const void* x; const void* bank; const void* dy;
     void* y; void* dx; void* dbank;
@@ -180,6 +163,14 @@ void plain_bwd_w_kernel(PlainArgs a) {
     }
 }
 
+// the matrix-core / image-level forms of hs_patch_conv_bwd.hip (k = 1 / groups = 1, depthwise 3x3 with zero padding), both storage types
+int try_fast_fwd(int dtype, const void* x, const void* bank, long ld, int batch, int c_in, int H, int W, int fh, int fw, int c_out,
+                 int k, int pad, int pad_mode, int groups, const float* scale, const float* shift, int act, void* y, hipStream_t stream);
+int try_fast_bwd_in(int dtype, const void* dy, const void* bank, long ld, int batch, int c_in, int H, int W, int fh, int fw,
+                    int c_out, int k, int pad, int pad_mode, int groups, void* dx, hipStream_t stream);
+int try_fast_bwd_w(int dtype, const void* x, const void* dy, int batch, int c_in, int H, int W, int fh, int fw, int c_out, int k,
+                   int pad, int pad_mode, int groups, void* dbank, long ld, hipStream_t stream);
+
 static int fill_plain(PlainArgs& a, int64_t ld, int32_t batch, int32_t c_in, int32_t H, int32_t W, int32_t fh, int32_t fw,
                       int32_t c_out, int32_t k, int32_t pad, int32_t pad_mode, int32_t groups) {
     if (batch <= 0 || c_in <= 0 || c_out <= 0 || H <= 0 || W <= 0 || fh <= 0 || fw <= 0 || k <= 0 || groups <= 0)
@@ -211,6 +202,11 @@ extern "C" int hs_patch_conv_plain_fwd(int32_t dtype, const void* x, const void*
     int st = fill_plain(a, ld, batch, c_in, H, W, fh, fw, c_out, k, pad, pad_mode, groups);
     if (st != HS_OK) return st;
     if (!x || !bank || !y) return HS_ERR_BAD_ARG;
+    {
+        const int r = try_fast_fwd(dtype, x, bank, (long)ld, batch, c_in, H, W, fh, fw, c_out, k, pad, pad_mode, groups, nullptr, nullptr,
+                                   HS_ACT_NONE, y, (hipStream_t)stream);
+        if (r != 1) return r;
+    }
     a.x = x; a.bank = bank; a.y = y;
     const int wrow = a.cin_g * k * k;
     a.w_stride = wrow | 1;
@@ -246,6 +242,11 @@ extern "C" int hs_patch_conv_plain_bwd_in(int32_t dtype, const void* dy, const v
     int st = fill_plain(a, ld, batch, c_in, H, W, fh, fw, c_out, k, pad, pad_mode, groups);
     if (st != HS_OK) return st;
     if (!dy || !bank || !dx) return HS_ERR_BAD_ARG;
+    {
+        const int r = try_fast_bwd_in(dtype, dy, bank, (long)ld, batch, c_in, H, W, fh, fw, c_out, k, pad, pad_mode, groups, dx,
+                                      (hipStream_t)stream);
+        if (r != 1) return r;
+    }
     a.dy = dy; a.bank = bank; a.dx = dx;
     const size_t total = (size_t)batch * c_in * H * W;
     const unsigned blocks = (unsigned)((total + 255) / 256 > 32768 ? 32768 : (total + 255) / 256);
@@ -262,6 +263,11 @@ extern "C" int hs_patch_conv_plain_bwd_w(int32_t dtype, const void* x, const voi
     int st = fill_plain(a, ld, batch, c_in, H, W, fh, fw, c_out, k, pad, pad_mode, groups);
     if (st != HS_OK) return st;
     if (!x || !dy || !dbank) return HS_ERR_BAD_ARG;
+    {
+        const int r = try_fast_bwd_w(dtype, x, dy, batch, c_in, H, W, fh, fw, c_out, k, pad, pad_mode, groups, dbank, (long)ld,
+                                     (hipStream_t)stream);
+        if (r != 1) return r;
+    }
     a.x = x; a.dy = dy; a.dbank = dbank;
     const size_t npix = (size_t)a.ph * a.pw, tpos = (size_t)(a.ph + 2 * pad) * (a.pw + 2 * pad);
     int ob = 0;

@@ -23,12 +23,16 @@ dec = model.decoder.train()
 target = torch.randint(0, 12, (2, 576, 576), device=dev)
 crit = BootstrappedCrossEntropyLoss(k=4096, thresh=0.3, ignore_index=255)
 opt = torch.optim.Adam(dec.parameters(), lr=1e-3, betas=(0.5, 0.999))
-modes = sys.argv[2:] if len(sys.argv) > 2 else ('fp32', 'bf16', 'graph')
+modes = sys.argv[2:] if len(sys.argv) > 2 else ('fp32', 'bf16', 'graph', 'graph_bf16')
 for mode in modes:
-    if mode == 'graph':                                     # the fp32 step captured once and replayed (hyperseg_amd.training.GraphedTrainStep)
+    if mode in ('graph', 'graph_bf16'):                     # the step captured once and replayed (hyperseg_amd.training.GraphedTrainStep)
         from hyperseg_amd.training import GraphedTrainStep
         opt_g = torch.optim.Adam(dec.parameters(), lr=torch.tensor(1e-3, device=dev), betas=(0.5, 0.999), capturable=True)
-        gs = GraphedTrainStep(dec, lambda p, t: crit(p.float(), t), opt_g, (pyr, s), target)
+
+        def fwd(p, sig, half=(mode == 'graph_bf16')):
+            with torch.autocast('cuda', dtype=torch.bfloat16, enabled=half):
+                return dec(p, sig)
+        gs = GraphedTrainStep(fwd, lambda p, t: crit(p.float(), t), opt_g, (pyr, s), target)
         for _ in range(2):
             gs.step()
         torch.cuda.synchronize()
@@ -36,7 +40,7 @@ for mode in modes:
         for _ in range(iters):
             loss, _ = gs.step()
         torch.cuda.synchronize()
-        print(f'config-5 decoder training step (fp32, one HIP graph per step): {(time.perf_counter() - t0) / iters * 1e3:.2f} ms/step, loss {float(loss):.4f}')
+        print(f'config-5 decoder training step ({"bf16 autocast" if mode == "graph_bf16" else "fp32"}, one HIP graph per step): {(time.perf_counter() - t0) / iters * 1e3:.2f} ms/step, loss {float(loss):.4f}')
         continue
     def step():
         opt.zero_grad()
