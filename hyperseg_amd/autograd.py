@@ -86,7 +86,9 @@ class PatchConv(torch.autograd.Function):
                     _plain_conv('bwd_in', x.dtype, dy, bank, ld, x.shape, ctx.meta, dx)
             if ctx.needs_input_grad[1]:
                 rows = c_out * (c_in // groups) * k * k
-                full = torch.zeros(bank.shape[0], bank.shape[1], device=x.device, dtype=x.dtype)
+                # the kernels write columns [0, rows) of every patch row; only trailing pad columns need the zero fill
+                alloc = torch.empty if rows == bank.shape[1] else torch.zeros
+                full = alloc(bank.shape[0], bank.shape[1], device=x.device, dtype=x.dtype)
                 assert rows <= full.shape[1]
                 if x.dtype == torch.float32:
                     st = _hip.lib.hs_patch_conv_bwd_weight(_hip.dev_ptr(x, 'x'), _hip.dev_ptr(dy, 'dy'), b, c_in, h, w, fh, fw,

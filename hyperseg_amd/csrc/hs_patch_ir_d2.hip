@@ -370,8 +370,15 @@ int hs::try_launch_ird(const StageIn& si, int fh, int fw, const float* bank, lon
     const dim3 grid((fw + 3) / 4, fh, si.B), block(256);
     const int al = (cin & 3) == 0 ? 4 : 2;                              // cin even (hid = expand * cin is a multiple of 4)
     const bool big = hid > 48 || cin > 32;                              // (RT, KQ) = (6, 3), else (3, 2)
-#define HS_D2A(PWV, RTV, KQV, ALV) hipLaunchKernelGGL((ird_pw1_kernel<PWV, RTV, KQV, ALV>), grid, block, \
-                                              ((size_t)IrdP1<PWV, KQV>::XL + (size_t)si.c_prev * IrdP1<PWV, KQV>::WP) * sizeof(float), stream, a)
+    // beyond 64 KiB of dynamic LDS (8 x 8 patches with wide inputs; pass 2 at 8 x 8: 69 KB) the kernel's ceiling is raised once per device
+#define HS_D2A(PWV, RTV, KQV, ALV) do { \
+        const size_t lds1 = ((size_t)IrdP1<PWV, KQV>::XL + (size_t)si.c_prev * IrdP1<PWV, KQV>::WP) * sizeof(float); \
+        if (lds1 > 64 * 1024) { \
+            static std::atomic<unsigned long long> done{0}; \
+            const int e = allow_full_lds((const void*)ird_pw1_kernel<PWV, RTV, KQV, ALV>, done); \
+            if (e != HS_OK) return e; \
+        } \
+        hipLaunchKernelGGL((ird_pw1_kernel<PWV, RTV, KQV, ALV>), grid, block, lds1, stream, a); } while (0)
 #define HS_D2B(PWV, RTV, KQV) do { if (al == 4) HS_D2A(PWV, RTV, KQV, 4); else HS_D2A(PWV, RTV, KQV, 2); } while (0)
     if (pw == 4) { if (big) HS_D2B(4, 6, 3); else HS_D2B(4, 3, 2); }
     else { if (big) HS_D2B(8, 6, 3); else HS_D2B(8, 3, 2); }
@@ -379,7 +386,14 @@ int hs::try_launch_ird(const StageIn& si, int fh, int fw, const float* bank, lon
 #undef HS_D2A
     int st = launch_status();
     if (st != HS_OK) return st;
-#define HS_D2C(PWV, KQV) hipLaunchKernelGGL((ird_dw_pw3_kernel<PWV, KQV>), grid, block, IrdP2<PWV>::FLOATS * sizeof(float), stream, a)
+#define HS_D2C(PWV, KQV) do { \
+        constexpr size_t lds2 = IrdP2<PWV>::FLOATS * sizeof(float); \
+        if (lds2 > 64 * 1024) { \
+            static std::atomic<unsigned long long> done{0}; \
+            const int e = allow_full_lds((const void*)ird_dw_pw3_kernel<PWV, KQV>, done); \
+            if (e != HS_OK) return e; \
+        } \
+        hipLaunchKernelGGL((ird_dw_pw3_kernel<PWV, KQV>), grid, block, lds2, stream, a); } while (0)
     const int kq = hidp / 16;
     if (pw == 4) { switch (kq) { case 1: HS_D2C(4, 1); break; case 2: HS_D2C(4, 2); break; case 3: HS_D2C(4, 3); break; case 4: HS_D2C(4, 4); break;
                                  case 5: HS_D2C(4, 5); break; default: HS_D2C(4, 6); break; } }
