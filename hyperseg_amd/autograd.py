@@ -101,6 +101,85 @@ class PatchConv(torch.autograd.Function):
         return dx, dbank, None, None, None, None, None, None
 
 
+def _tile_call(name, dtype, src, b, c, h, w, grid, dst):
+    st = getattr(_hip.lib, name)(DTYPE_CODES[dtype], src.data_ptr(), b, c, h, w, grid[0], grid[1], dst.data_ptr(), _hip.stream_ptr())
+    _hip.check(st, name)
+    return dst
+
+
+class HaloTiles(torch.autograd.Function):
+    """x (B, C, H, W) -> the image of reflect-padded halo tiles (B, C, fh (ph+2), fw (pw+2)): F.pad(reflect) -> unfold -> unfold ->
+    permute -> reshape of models/hyperseg_v1_0.py _run_train as ONE gather (hs_halo_tiles_fwd), its adjoint as one gather too."""
+
+    @staticmethod
+    def forward(ctx, x, grid):
+        x = x.contiguous()
+        b, c, h, w = x.shape
+        fh, fw = grid
+        ctx.meta = (b, c, h, w, (fh, fw), x.dtype)
+        with torch.cuda.device(x.device):
+            out = torch.empty(b, c, fh * (h // fh + 2), fw * (w // fw + 2), device=x.device, dtype=x.dtype)
+            return _tile_call('hs_halo_tiles_fwd', x.dtype, x, b, c, h, w, (fh, fw), out)
+
+    @staticmethod
+    def backward(ctx, dt):
+        b, c, h, w, grid, dtype = ctx.meta
+        dt = dt.contiguous().to(dtype)
+        with torch.cuda.device(dt.device):
+            return _tile_call('hs_halo_tiles_bwd', dtype, dt, b, c, h, w, grid, torch.empty(b, c, h, w, device=dt.device, dtype=dtype)), None
+
+
+class TileInterior(torch.autograd.Function):
+    """The image of halo tiles -> (B, C, H, W) without the halos (hs_tile_interior_fwd); adjoint: zeros on the halos."""
+
+    @staticmethod
+    def forward(ctx, t, size, grid):
+        t = t.contiguous()
+        b, c = t.shape[:2]
+        h, w = size
+        ctx.meta = (b, c, h, w, tuple(grid), t.dtype, tuple(t.shape))
+        with torch.cuda.device(t.device):
+            return _tile_call('hs_tile_interior_fwd', t.dtype, t, b, c, h, w, grid, torch.empty(b, c, h, w, device=t.device, dtype=t.dtype))
+
+    @staticmethod
+    def backward(ctx, dy):
+        b, c, h, w, grid, dtype, shape = ctx.meta
+        dy = dy.contiguous().to(dtype)
+        with torch.cuda.device(dy.device):
+            return _tile_call('hs_tile_interior_bwd', dtype, dy, b, c, h, w, grid, torch.empty(shape, device=dy.device, dtype=dtype)), None, None
+
+
+def tiles_supported(x):
+    return x.is_cuda and x.dtype in DTYPE_CODES and x.shape[0] * x.shape[1] <= 65535 and x.shape[2] >= 2 and x.shape[3] >= 2
+
+
+class BootstrapMean(torch.autograd.Function):
+    """The per-image reduction of the bootstrapped cross entropy (hyperseg/losses/bootstrapped_ce_loss.py:19-25) on the device with no
+    sort and no host read (hs_bootstrap_mean_fwd / _bwd): capturable into a HIP graph as it is."""
+
+    @staticmethod
+    def forward(ctx, values, k, thresh):
+        values = values.contiguous()
+        n = values.numel()
+        with torch.cuda.device(values.device):
+            ws = torch.empty(int(_hip.lib.hs_bootstrap_mean_workspace()), device=values.device, dtype=torch.uint8)
+            out = torch.empty(5, device=values.device, dtype=torch.float32)
+            st = _hip.lib.hs_bootstrap_mean_fwd(values.data_ptr(), n, int(k), float(thresh), ws.data_ptr(), out.data_ptr(), _hip.stream_ptr())
+            _hip.check(st, 'hs_bootstrap_mean_fwd')
+        ctx.save_for_backward(values, out)
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        values, state = ctx.saved_tensors
+        with torch.cuda.device(values.device):
+            gv = torch.empty_like(values)
+            st = _hip.lib.hs_bootstrap_mean_bwd(values.data_ptr(), values.numel(), state.data_ptr(),
+                                                g.contiguous().float().data_ptr(), gv.data_ptr(), _hip.stream_ptr())
+            _hip.check(st, 'hs_bootstrap_mean_bwd')
+        return gv, None, None
+
+
 def patch_conv_apply(*args):
     """``PatchConv.apply`` behind the one check its ``custom_fwd`` cannot make (autocast is already off inside it)."""
     if torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') != torch.bfloat16:

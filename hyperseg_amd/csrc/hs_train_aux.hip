@@ -1,0 +1,283 @@
+// Training-path helpers around the patch convolutions (BASELINE config 5; round 3).  Plain tensors, storage type T = float | bf16_t.
+//
+// 1. Halo tiles.  A train-mode v1_0 inverted residual (hyperseg_v1_0.py:328-376) applies each patch's weights to the patch's own
+//    reflect-padded (ph + 2) x (pw + 2) tile; hyperseg_amd lays those tiles side by side as one "tiled image" so that the three layers
+//    are ordinary patch convolutions (models/hyperseg_v1_0.py _run_train).  With stock ops that is F.pad(reflect) -> unfold -> unfold ->
+//    permute -> reshape (and a slice -> reshape to drop the halo again): 3 launches forward and ~6 backward per level, all of them
+//    copies.  Here each direction of each of the two re-layouts is ONE gather kernel (no atomics: the backward of the tiling sums, per
+//    image pixel, the tile positions that map onto it -- own tile, the neighbours' halos, the reflections at the image border).
+//       hs_halo_tiles_fwd      tiled[b,c, i(ph+2)+u, j(pw+2)+v] = x[b,c, reflect(i ph + u - 1), reflect(j pw + v - 1)]
+//       hs_halo_tiles_bwd      dx = adjoint of the above
+//       hs_tile_interior_fwd   y[b,c, i ph + u, j pw + v] = tiled[b,c, i(ph+2)+u+1, j(pw+2)+v+1]
+//       hs_tile_interior_bwd   dtiled = dy on the interiors, 0 on the halos
+// 2. hs_bootstrap_mean_{fwd,bwd}: the reduction of hyperseg/losses/bootstrapped_ce_loss.py:19-25 for one image without a sort and
+//    without a host read (what a captured training step needs): the k-th largest loss by a three-level radix histogram of the float
+//    bit patterns (losses are >= 0, so their bits order like integers), then both branches of the rule as sums.
+#include "hs_common.h"
+
+namespace hs {
+
+struct TileArgs { int B, C, H, W, fh, fw, ph, pw; };
+
+__device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
+
+template <typename T>
+__global__ __launch_bounds__(256)
+void halo_tiles_fwd_kernel(TileArgs a, const T* __restrict__ x, T* __restrict__ t) {
+    const int TW = a.fw * (a.pw + 2), TH = a.fh * (a.ph + 2);
+    const int X = blockIdx.x * 64 + (threadIdx.x & 63), Y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (X >= TW || Y >= TH) return;
+    const int i = Y / (a.ph + 2), u = Y - i * (a.ph + 2), j = X / (a.pw + 2), v = X - j * (a.pw + 2);
+    const int y = reflect1(i * a.ph + u - 1, a.H), xx = reflect1(j * a.pw + v - 1, a.W);
+    const size_t pl = blockIdx.z;
+    Store<T>::st(t, (pl * TH + Y) * TW + X, Store<T>::ld(x, (pl * a.H + y) * a.W + xx));
+}
+
+// candidates (tile index, position inside the tile) of one axis that map onto image index y: every padded coordinate that reflects
+// onto y (itself; -1 for y = 1; n for y = n - 2), in every tile whose p + 2 padded rows contain it (two at a patch border, three when
+// patches are one pixel wide)
+__device__ __forceinline__ int tile_sources(int y, int n, int p, int f, int (&tpos)[9]) {
+    int cnt = 0;
+    const int yps[3] = {y, y == 1 ? -1 : -2, y == n - 2 ? n : -2};      // -2: none
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        if (yps[q] == -2) continue;
+        const int Yp = yps[q] + 1;                                      // index in the padded image [0, n + 1]
+        for (int i = Yp / p; i >= 0 && Yp - i * p <= p + 1; --i)
+            if (i < f) tpos[cnt++] = i * (p + 2) + (Yp - i * p);
+    }
+    return cnt;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256)
+void halo_tiles_bwd_kernel(TileArgs a, const T* __restrict__ dt, T* __restrict__ dx) {
+    const int TW = a.fw * (a.pw + 2), TH = a.fh * (a.ph + 2);
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= a.W || y >= a.H) return;
+    int ys[9], xs[9];
+    const int ny = tile_sources(y, a.H, a.ph, a.fh, ys), nx = tile_sources(x, a.W, a.pw, a.fw, xs);
+    const size_t pl = blockIdx.z;
+    float acc = 0.0f;
+    for (int p = 0; p < ny; ++p)
+        for (int q = 0; q < nx; ++q) acc += Store<T>::ld(dt, (pl * TH + ys[p]) * TW + xs[q]);
+    Store<T>::st(dx, (pl * a.H + y) * a.W + x, acc);
+}
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256)
+void tile_interior_kernel(TileArgs a, const T* __restrict__ src, T* __restrict__ dst) {
+    const int TW = a.fw * (a.pw + 2), TH = a.fh * (a.ph + 2);
+    const size_t pl = blockIdx.z;
+    if constexpr (!BWD) {
+        const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+        if (x >= a.W || y >= a.H) return;
+        const int i = y / a.ph, j = x / a.pw;
+        Store<T>::st(dst, (pl * a.H + y) * a.W + x, Store<T>::ld(src, (pl * TH + y + 2 * i + 1) * TW + x + 2 * j + 1));
+    } else {
+        const int X = blockIdx.x * 64 + (threadIdx.x & 63), Y = blockIdx.y * 4 + (threadIdx.x >> 6);
+        if (X >= TW || Y >= TH) return;
+        const int i = Y / (a.ph + 2), u = Y - i * (a.ph + 2), j = X / (a.pw + 2), v = X - j * (a.pw + 2);
+        const bool in = u >= 1 && u <= a.ph && v >= 1 && v <= a.pw;
+        const float g = Store<T>::ld(src, (pl * a.H + min(max(i * a.ph + u - 1, 0), a.H - 1)) * a.W + min(max(j * a.pw + v - 1, 0), a.W - 1));
+        Store<T>::st(dst, (pl * TH + Y) * TW + X, in ? g : 0.0f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// bootstrapped mean.  The k-th largest of n non-negative floats by THREE radix levels over their bit patterns (bits 30..20, 19..10,
+// 9..0): per level a histogram of the losses that match the prefix selected so far -- privatised per workgroup in LDS (cross-entropy
+// losses crowd into a few hundred high-bit bins, and every ignore_index pixel is an exact 0: global atomics on those few addresses
+// serialised; the first version of this file measured slower than the sort for that reason), flushed with one global atomic per
+// non-empty bin -- then one workgroup walks the bins from the top.
+// ws (uint32): [0, 2048) level-0 histogram, [2048, 3072) level 1, [3072, 4096) level 2, then state: [4096] prefix bits selected so
+// far, [4097] number of losses known to be above the prefix' bin, [4098] t bits, [4099] count > t.
+// partial (float): per workgroup {sum over v > thresh, count > thresh, sum over v > t, count == t}, combined in workgroup order.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int BM_BINS0 = 2048, BM_BINS12 = 1024, BM_STATE = BM_BINS0 + 2 * BM_BINS12, BM_WG = 128;
+__device__ __forceinline__ int bm_shift(int level) { return level == 0 ? 20 : (level == 1 ? 10 : 0); }
+__device__ __forceinline__ int bm_bins(int level) { return level == 0 ? BM_BINS0 : BM_BINS12; }
+__device__ __forceinline__ int bm_base(int level) { return level == 0 ? 0 : (level == 1 ? BM_BINS0 : BM_BINS0 + BM_BINS12); }
+
+__global__ __launch_bounds__(256)
+void bm_hist_kernel(const float* __restrict__ v, int n, unsigned* __restrict__ ws, int level) {
+    __shared__ unsigned h[BM_BINS0];
+    const int nb = bm_bins(level), sh = bm_shift(level);
+    for (int i = threadIdx.x; i < nb; i += 256) h[i] = 0;
+    __syncthreads();
+    const unsigned prefix = level == 0 ? 0u : ws[BM_STATE];             // the bits above this level's, already shifted into place
+    const unsigned himask = level == 0 ? 0u : (0x7fffffffu >> (sh + 10)) << (sh + 10);
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+        const unsigned b = __float_as_uint(fmaxf(v[e], 0.0f)) & 0x7fffffffu;
+        if ((b & himask) == prefix) atomicAdd(&h[(b >> sh) & (nb - 1)], 1u);
+    }
+    __syncthreads();
+    unsigned* g = ws + bm_base(level);
+    for (int i = threadIdx.x; i < nb; i += 256)
+        if (h[i]) atomicAdd(&g[i], h[i]);
+}
+
+// one workgroup: the bin (scanning from the top) in which the cumulative count reaches the wanted rank; extends the prefix
+__global__ __launch_bounds__(256)
+void bm_find_kernel(unsigned* __restrict__ ws, int level, int k) {
+    __shared__ unsigned part[256];
+    __shared__ unsigned sel[2];
+    const int tid = threadIdx.x;
+    const int nbins = bm_bins(level), per = nbins / 256, sh = bm_shift(level);
+    const unsigned* h = ws + bm_base(level);
+    const unsigned above = level == 0 ? 0u : ws[BM_STATE + 1];
+    const unsigned want = (unsigned)k - above;                          // rank inside the selected prefix
+    // thread t owns bins [nbins - (t + 1) per, nbins - t per): descending order of value
+    unsigned s = 0;
+    for (int q = 0; q < per; ++q) s += h[nbins - 1 - (tid * per + q)];
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned cum = 0; int t = 0;
+        for (; t < 255 && cum + part[t] < want; ++t) cum += part[t];
+        sel[0] = (unsigned)t; sel[1] = cum;
+    }
+    __syncthreads();
+    if (tid == (int)sel[0]) {
+        unsigned cum = sel[1]; int q = 0;
+        for (; q < per - 1 && cum + h[nbins - 1 - (tid * per + q)] < want; ++q) cum += h[nbins - 1 - (tid * per + q)];
+        const unsigned bin = (unsigned)(nbins - 1 - (tid * per + q));
+        const unsigned prefix = (level == 0 ? 0u : ws[BM_STATE]) | (bin << sh);
+        ws[BM_STATE] = prefix; ws[BM_STATE + 1] = above + cum;
+        if (level == 2) { ws[BM_STATE + 2] = prefix; ws[BM_STATE + 3] = above + cum; }
+    }
+}
+
+__global__ __launch_bounds__(256)
+void bm_sums_kernel(const float* __restrict__ v, int n, float thresh, const unsigned* __restrict__ ws, float* __restrict__ partial) {
+    __shared__ float red[4][4];
+    const float t = __uint_as_float(ws[BM_STATE + 2]);
+    float s_thr = 0.f, c_thr = 0.f, s_top = 0.f, c_eq = 0.f;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+        const float x = fmaxf(v[e], 0.0f);
+        if (x > thresh) { s_thr += x; c_thr += 1.0f; }
+        if (x > t) s_top += x;
+        if (x == t) c_eq += 1.0f;
+    }
+    s_thr = wave_sum64(s_thr); c_thr = wave_sum64(c_thr); s_top = wave_sum64(s_top); c_eq = wave_sum64(c_eq);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wave][0] = s_thr; red[wave][1] = c_thr; red[wave][2] = s_top; red[wave][3] = c_eq; }
+    __syncthreads();
+    if (threadIdx.x < 4)
+        partial[blockIdx.x * 4 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// out[0] = the image's loss; out[1] = branch (1: everything above thresh, 0: the k largest), out[2] = 1 / count or 1 / k,
+// out[3] = t, out[4] = weight of a loss equal to t (the k-th largest may be tied)
+__global__ void bm_final_kernel(const float* __restrict__ partial, int nwg, const unsigned* __restrict__ ws, int k, float thresh,
+                                float* __restrict__ out) {
+    float s_thr = 0.f, c_thr = 0.f, s_top = 0.f, c_eq = 0.f;
+    for (int i = 0; i < nwg; ++i) { s_thr += partial[4 * i]; c_thr += partial[4 * i + 1]; s_top += partial[4 * i + 2]; c_eq += partial[4 * i + 3]; }
+    const float t = __uint_as_float(ws[BM_STATE + 2]);
+    const float c_gt = (float)ws[BM_STATE + 3];
+    if (c_thr > (float)k) {                    // the (k+1)-th largest exceeds thresh exactly when more than k losses do
+        out[0] = s_thr / c_thr; out[1] = 1.0f; out[2] = 1.0f / c_thr; out[3] = thresh; out[4] = 0.0f;
+    } else {
+        const float ties = (float)k - c_gt;    // how many of the losses equal to t belong to the k largest
+        out[0] = (s_top + ties * t) / (float)k; out[1] = 0.0f; out[2] = 1.0f / (float)k; out[3] = t;
+        out[4] = c_eq > 0.0f ? ties / c_eq : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(256)
+void bm_bwd_kernel(const float* __restrict__ v, int n, const float* __restrict__ state, const float* __restrict__ gout,
+                   float* __restrict__ gv) {
+    const float w = state[2] * gout[0], t = state[3], tie = state[4];
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+        const float x = fmaxf(v[e], 0.0f);
+        gv[e] = x > t ? w : (x == t ? w * tie : 0.0f);
+    }
+}
+
+}  // namespace hs
+
+using namespace hs;
+
+static int tile_args(TileArgs& a, int B, int C, int H, int W, int fh, int fw) {
+    if (B <= 0 || C <= 0 || H < 2 || W < 2 || fh <= 0 || fw <= 0) return HS_ERR_BAD_ARG;
+    if (H % fh || W % fw) return HS_ERR_NOT_DIVISIBLE;
+    if ((long)B * C > 65535) return HS_ERR_UNSUPPORTED;
+    a = TileArgs{B, C, H, W, fh, fw, H / fh, W / fw};
+    return HS_OK;
+}
+
+#define HS_TILE_LAUNCH(dtype, KERNEL_F32, KERNEL_BF16, grid, SRC, DST) \
+    if ((dtype) == HS_DTYPE_F32) hipLaunchKernelGGL(KERNEL_F32, grid, dim3(256), 0, (hipStream_t)stream, a, (const float*)(SRC), (float*)(DST)); \
+    else if ((dtype) == HS_DTYPE_BF16) hipLaunchKernelGGL(KERNEL_BF16, grid, dim3(256), 0, (hipStream_t)stream, a, (const bf16_t*)(SRC), (bf16_t*)(DST)); \
+    else return HS_ERR_BAD_ARG;
+
+extern "C" int hs_halo_tiles_fwd(int32_t dtype, const void* x, int32_t batch, int32_t channels, int32_t H, int32_t W, int32_t fh,
+                                 int32_t fw, void* tiled, void* stream) {
+    TileArgs a;
+    const int st = tile_args(a, batch, channels, H, W, fh, fw);
+    if (st != HS_OK) return st;
+    if (!x || !tiled) return HS_ERR_BAD_ARG;
+    const dim3 grid((fw * (a.pw + 2) + 63) / 64, (fh * (a.ph + 2) + 3) / 4, batch * channels);
+    HS_TILE_LAUNCH(dtype, halo_tiles_fwd_kernel<float>, halo_tiles_fwd_kernel<bf16_t>, grid, x, tiled)
+    return launch_status();
+}
+
+extern "C" int hs_halo_tiles_bwd(int32_t dtype, const void* dtiled, int32_t batch, int32_t channels, int32_t H, int32_t W,
+                                 int32_t fh, int32_t fw, void* dx, void* stream) {
+    TileArgs a;
+    const int st = tile_args(a, batch, channels, H, W, fh, fw);
+    if (st != HS_OK) return st;
+    if (!dtiled || !dx) return HS_ERR_BAD_ARG;
+    const dim3 grid((W + 63) / 64, (H + 3) / 4, batch * channels);
+    HS_TILE_LAUNCH(dtype, halo_tiles_bwd_kernel<float>, halo_tiles_bwd_kernel<bf16_t>, grid, dtiled, dx)
+    return launch_status();
+}
+
+extern "C" int hs_tile_interior_fwd(int32_t dtype, const void* tiled, int32_t batch, int32_t channels, int32_t H, int32_t W,
+                                    int32_t fh, int32_t fw, void* y, void* stream) {
+    TileArgs a;
+    const int st = tile_args(a, batch, channels, H, W, fh, fw);
+    if (st != HS_OK) return st;
+    if (!tiled || !y) return HS_ERR_BAD_ARG;
+    const dim3 grid((W + 63) / 64, (H + 3) / 4, batch * channels);
+    HS_TILE_LAUNCH(dtype, (tile_interior_kernel<float, false>), (tile_interior_kernel<bf16_t, false>), grid, tiled, y)
+    return launch_status();
+}
+
+extern "C" int hs_tile_interior_bwd(int32_t dtype, const void* dy, int32_t batch, int32_t channels, int32_t H, int32_t W,
+                                    int32_t fh, int32_t fw, void* dtiled, void* stream) {
+    TileArgs a;
+    const int st = tile_args(a, batch, channels, H, W, fh, fw);
+    if (st != HS_OK) return st;
+    if (!dy || !dtiled) return HS_ERR_BAD_ARG;
+    const dim3 grid((fw * (a.pw + 2) + 63) / 64, (fh * (a.ph + 2) + 3) / 4, batch * channels);
+    HS_TILE_LAUNCH(dtype, (tile_interior_kernel<float, true>), (tile_interior_kernel<bf16_t, true>), grid, dy, dtiled)
+    return launch_status();
+}
+
+extern "C" int64_t hs_bootstrap_mean_workspace(void) { return (int64_t)(BM_STATE + 8) * 4 + (int64_t)BM_WG * 4 * 4; }
+
+extern "C" int hs_bootstrap_mean_fwd(const float* values, int32_t n, int32_t k, float thresh, void* workspace, float* out5,
+                                     void* stream) {
+    if (!values || !workspace || !out5 || n <= 0 || k <= 0) return HS_ERR_BAD_ARG;
+    if (n <= k) return HS_ERR_UNSUPPORTED;                               // the reference indexes ranked[k]
+    hipStream_t s = (hipStream_t)stream;
+    unsigned* ws = (unsigned*)workspace;
+    float* partial = (float*)(ws + BM_STATE + 8);
+    hipError_t e = hipMemsetAsync(ws, 0, (size_t)(BM_STATE + 8) * 4, s);
+    if (e != hipSuccess) return (int)e;
+    for (int level = 0; level < 3; ++level) {
+        hipLaunchKernelGGL(bm_hist_kernel, dim3(BM_WG), dim3(256), 0, s, values, n, ws, level);
+        hipLaunchKernelGGL(bm_find_kernel, dim3(1), dim3(256), 0, s, ws, level, k);
+    }
+    hipLaunchKernelGGL(bm_sums_kernel, dim3(BM_WG), dim3(256), 0, s, values, n, thresh, (const unsigned*)ws, partial);
+    hipLaunchKernelGGL(bm_final_kernel, dim3(1), dim3(1), 0, s, (const float*)partial, BM_WG, (const unsigned*)ws, k, thresh, out5);
+    return launch_status();
+}
+
+extern "C" int hs_bootstrap_mean_bwd(const float* values, int32_t n, const float* state5, const float* grad_out, float* grad_values,
+                                     void* stream) {
+    if (!values || !state5 || !grad_out || !grad_values || n <= 0) return HS_ERR_BAD_ARG;
+    hipLaunchKernelGGL(bm_bwd_kernel, dim3(BM_WG), dim3(256), 0, (hipStream_t)stream, values, n, state5, grad_out, grad_values);
+    return launch_status();
+}

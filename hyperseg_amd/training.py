@@ -16,6 +16,9 @@ import torch.nn.functional as F
 from torch.optim.lr_scheduler import LRScheduler
 
 
+USE_HIP_BOOTSTRAP = True       # tests switch it off to reach the torch statements of the rule below
+
+
 def bootstrap_mean_reference(per_pixel, k, thresh):
     """The reference's own statement (hyperseg/losses/bootstrapped_ce_loss.py:19-25): two host reads and a full sort per image."""
     ranked = per_pixel.sort(descending=True).values
@@ -54,6 +57,10 @@ def bootstrapped_cross_entropy(pred, target, k=4096, thresh=0.3, weight=None, ig
         per_pixel = F.cross_entropy(logits.flatten(1).t(), labels.flatten(), weight=weight, ignore_index=ignore_index,
                                     reduction='none')
         on_device = per_pixel.is_cuda and per_pixel.numel() > k            # (numel <= k: the reference raises; so does its restatement)
+        if on_device and per_pixel.dtype == torch.float32 and USE_HIP_BOOTSTRAP:
+            from .autograd import BootstrapMean                            # no sort, no host read, 7 small launches: eager and captured alike
+            total = total + BootstrapMean.apply(per_pixel, k, thresh)
+            continue
         fn = bootstrap_mean_capturable if capturing and on_device else bootstrap_mean_on_device if on_device else bootstrap_mean_reference
         total = total + fn(per_pixel, k, thresh)
     return total / float(pred.shape[0])

@@ -352,6 +352,28 @@ int hs_gemm_split_up2_fwd(const void* w_frag, const float* w_inv, const float* x
 int hs_pooled_shift_fwd(const float* partial, int32_t nblk, float inv_pixels, const float* wb, const float* shift,
                         float* shift_out, int32_t rows, int32_t channels, void* stream);
 
+/* Training-path re-layouts and loss reduction (hs_train_aux.hip; dtype = hs_dtype, plain contiguous tensors).
+ * Halo tiles: a train-mode v1_0 inverted residual (hyperseg_v1_0.py:328-376) applies each patch's weights to the patch's own
+ * reflect-padded (ph+2) x (pw+2) tile; the tiles are laid side by side as one image (B, C, fh (ph+2), fw (pw+2)) so that the three layers
+ * are ordinary patch convolutions.  hs_halo_tiles_fwd builds that image from x (B, C, H, W) in one gather (stock ops: F.pad(reflect) ->
+ * unfold -> unfold -> permute -> reshape), hs_halo_tiles_bwd is its adjoint (a gather too: per image pixel the <= 16 tile positions that
+ * map onto it); hs_tile_interior_fwd drops the halos again, hs_tile_interior_bwd is its adjoint (zeros on the halos). */
+int hs_halo_tiles_fwd(int32_t dtype, const void* x, int32_t batch, int32_t channels, int32_t H, int32_t W, int32_t fh, int32_t fw,
+                      void* tiled, void* stream);
+int hs_halo_tiles_bwd(int32_t dtype, const void* dtiled, int32_t batch, int32_t channels, int32_t H, int32_t W, int32_t fh, int32_t fw,
+                      void* dx, void* stream);
+int hs_tile_interior_fwd(int32_t dtype, const void* tiled, int32_t batch, int32_t channels, int32_t H, int32_t W, int32_t fh,
+                         int32_t fw, void* y, void* stream);
+int hs_tile_interior_bwd(int32_t dtype, const void* dy, int32_t batch, int32_t channels, int32_t H, int32_t W, int32_t fh, int32_t fw,
+                         void* dtiled, void* stream);
+/* The per-image reduction of hyperseg/losses/bootstrapped_ce_loss.py:19-25 over n non-negative f32 losses, with no sort and no host
+ * read: if more than k losses exceed thresh, their mean; otherwise the mean of the k largest (the k-th largest found by a three-level
+ * radix histogram of the bit patterns; ties at it share the remaining weight).  out5 = {loss, branch, 1/count, t, tie weight}: the
+ * state hs_bootstrap_mean_bwd turns into d loss / d values.  workspace: hs_bootstrap_mean_workspace() bytes, scratch.  n > k. */
+int64_t hs_bootstrap_mean_workspace(void);
+int hs_bootstrap_mean_fwd(const float* values, int32_t n, int32_t k, float thresh, void* workspace, float* out5, void* stream);
+int hs_bootstrap_mean_bwd(const float* values, int32_t n, const float* state5, const float* grad_out, float* grad_values, void* stream);
+
 /* Materialises a stage input (B, 2*coords + c_skip + c_prev, H, W); test/diagnostic twin of the
  * fused prologue (the product path never calls it). */
 int hs_stage_input_fwd(const hs_stage_input* in, float* y, void* stream);

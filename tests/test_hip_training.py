@@ -122,6 +122,71 @@ def test_optimizer_step_runs(dev):
     assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0]
 
 
+@pytest.mark.parametrize('shape,grid', [((2, 5, 36, 20), (2, 2)), ((1, 3, 8, 12), (4, 3)), ((1, 2, 6, 6), (6, 6)), ((2, 4, 40, 130), (5, 2)),
+                                        ((1, 1, 2, 2), (1, 1))])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_halo_tiles_and_interior_vs_stock_ops(dev, shape, grid, dtype):
+    """hs_halo_tiles_* / hs_tile_interior_* (one gather per direction) == F.pad(reflect) -> unfold -> unfold -> permute -> reshape and
+    the interior slice of models/hyperseg_v1_0.py _run_train, values and gradients (patches of one pixel and one-patch images included:
+    every halo position is then a neighbour's pixel or a reflection)."""
+    import torch.nn.functional as F
+    from hyperseg_amd import autograd as HA
+    g = torch.Generator().manual_seed(sum(shape))
+    b, c, h, w = shape
+    fh, fw = grid
+    ph, pw = h // fh, w // fw
+    x0 = torch.randn(shape, generator=g).to(dev).to(dtype)
+
+    def stock(x):
+        xp = F.pad(x, (1, 1, 1, 1), mode='reflect')
+        t = xp.unfold(2, ph + 2, ph).unfold(3, pw + 2, pw)
+        return t.permute(0, 1, 2, 4, 3, 5).reshape(b, c, fh * (ph + 2), fw * (pw + 2))
+
+    def interior(t):
+        return t.reshape(b, c, fh, ph + 2, fw, pw + 2)[:, :, :, 1:-1, :, 1:-1].reshape(b, c, h, w)
+    xa, xb = x0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+    ta, tb = stock(xa.float()), HA.HaloTiles.apply(xb, grid)
+    assert tb.dtype == dtype and torch.equal(ta.to(dtype), tb)
+    r = torch.randn(ta.shape, generator=g).to(dev)
+    (ta * r).sum().backward()
+    (tb.float() * r).sum().backward()
+    tol = 1e-6 if dtype == torch.float32 else 1e-2
+    assert rel_err(xb.grad.float().cpu(), xa.grad.float().cpu()) < tol
+    ua, ub = ta.detach().to(dtype).clone().requires_grad_(True), ta.detach().to(dtype).clone().requires_grad_(True)
+    ya, yb = interior(ua), HA.TileInterior.apply(ub, (h, w), grid)
+    assert torch.equal(ya, yb)
+    r2 = torch.randn(shape, generator=g).to(dev).to(dtype)
+    (ya.float() * r2.float()).sum().backward()
+    (yb.float() * r2.float()).sum().backward()
+    assert torch.equal(ua.grad, ub.grad)
+
+
+@pytest.mark.parametrize('thresh', [0.3, 2.5, 5.0, 7.0])
+def test_bootstrap_mean_kernels_vs_reference_statement(dev, thresh):
+    """hs_bootstrap_mean_fwd / _bwd (radix selection, no sort, no host read) == the reference's rule stated with torch.sort
+    (hyperseg_amd.training.bootstrap_mean_reference): both branches, values and gradients; with ties at the k-th largest loss the kernel
+    spreads the remaining weight over the tied losses (the sort picks some of them): the loss is identical, the gradient's sum too."""
+    from hyperseg_amd import autograd as HA
+    from hyperseg_amd.training import bootstrap_mean_reference
+    g = torch.Generator().manual_seed(int(thresh * 10))
+    for n, k in ((5000, 1000), (70000, 4096), (300, 7)):
+        v = (torch.rand(n, generator=g) * 6).to(dev)
+        v[: n // 10] = 0.0                                      # ignore_index pixels: exact zeros
+        a, b = v.clone().requires_grad_(True), v.clone().requires_grad_(True)
+        ra, rb = bootstrap_mean_reference(a, k, thresh), HA.BootstrapMean.apply(b, k, thresh)
+        assert abs(float(ra) - float(rb)) < 1e-6 * abs(float(ra)) + 1e-9, (n, k, float(ra), float(rb))
+        ga, gb = torch.autograd.grad(ra, a)[0], torch.autograd.grad(rb * 3.0, b)[0] / 3.0
+        assert torch.allclose(ga, gb, rtol=1e-5, atol=1e-12), (n, k)
+    # ties straddling rank k: 50 copies of the value that the k-th largest falls on
+    v = torch.cat([torch.full((50,), 2.0), torch.rand(400, generator=g) + 3.0, torch.rand(400, generator=g)]).to(dev)
+    a, b = v.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    ra, rb = bootstrap_mean_reference(a, 420, 9.0), HA.BootstrapMean.apply(b, 420, 9.0)
+    assert abs(float(ra) - float(rb)) < 1e-6 * abs(float(ra))
+    ga, gb = torch.autograd.grad(ra, a)[0], torch.autograd.grad(rb, b)[0]
+    assert abs(float(ga.sum()) - float(gb.sum())) < 1e-6 and torch.allclose(ga[50:], gb[50:], rtol=1e-5)
+    assert torch.allclose(gb[:50], torch.full((50,), 20.0 / 50.0 / 420.0, device=dev), rtol=1e-5)      # 20 of the 50 ties belong to the top 420
+
+
 def test_graphed_train_step_equals_eager(dev):
     """hyperseg_amd.training.GraphedTrainStep: three replays of the captured forward + bootstrapped CE + backward + Adam step move
     the parameters, the BatchNorm statistics and the loss exactly as three eager steps do (same kernels, same order)."""
