@@ -153,6 +153,70 @@ def tiles_supported(x):
     return x.is_cuda and x.dtype in DTYPE_CODES and x.shape[0] * x.shape[1] <= 65535 and x.shape[2] >= 2 and x.shape[3] >= 2
 
 
+class BNActTrain(torch.autograd.Function):
+    """BatchNorm2d (training mode, batch statistics, running estimates updated in place) + none / ReLU / ReLU6 in two launches per
+    direction (hs_bn_act_train_fwd / _bwd).  fp32 parameters; x in fp32 or bf16 storage."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, act):
+        x = x.contiguous()
+        b, c = x.shape[:2]
+        px = x.numel() // (b * c)
+        dev = x.device
+        with torch.cuda.device(dev):
+            y = torch.empty_like(x)
+            mean, invstd = torch.empty(c, device=dev, dtype=torch.float32), torch.empty(c, device=dev, dtype=torch.float32)
+            ws = torch.empty(int(_hip.lib.hs_bn_train_workspace(c)), device=dev, dtype=torch.uint8)
+            st = _hip.lib.hs_bn_act_train_fwd(DTYPE_CODES[x.dtype], x.data_ptr(), b, c, px,
+                                              weight.data_ptr() if weight is not None else None,
+                                              bias.data_ptr() if bias is not None else None,
+                                              running_mean.data_ptr() if running_mean is not None else None,
+                                              running_var.data_ptr() if running_var is not None else None,
+                                              float(momentum), float(eps), int(act), mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(),
+                                              y.data_ptr(), _hip.stream_ptr())
+            _hip.check(st, 'hs_bn_act_train_fwd')
+        ctx.save_for_backward(x, weight, bias, mean, invstd)
+        ctx.meta = (b, c, px, float(eps), int(act))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias, mean, invstd = ctx.saved_tensors
+        b, c, px, eps, act = ctx.meta
+        dy = dy.contiguous().to(x.dtype)
+        dev = x.device
+        with torch.cuda.device(dev):
+            dx = torch.empty_like(x)
+            dg = torch.empty(c, device=dev, dtype=torch.float32) if weight is not None else None
+            db = torch.empty(c, device=dev, dtype=torch.float32) if bias is not None else None
+            ws = torch.empty(int(_hip.lib.hs_bn_train_workspace(c)), device=dev, dtype=torch.uint8)
+            st = _hip.lib.hs_bn_act_train_bwd(DTYPE_CODES[x.dtype], x.data_ptr(), dy.data_ptr(), b, c, px,
+                                              weight.data_ptr() if weight is not None else None,
+                                              bias.data_ptr() if bias is not None else None, mean.data_ptr(), invstd.data_ptr(), eps, act,
+                                              ws.data_ptr(), dx.data_ptr(), dg.data_ptr() if dg is not None else None,
+                                              db.data_ptr() if db is not None else None, _hip.stream_ptr())
+            _hip.check(st, 'hs_bn_act_train_bwd')
+        return dx, dg, db, None, None, None, None, None
+
+
+def bn_act(bn, act_layer, x):
+    """``act_layer(bn(x))`` -- through the fused training kernels when ``bn`` is a plain BatchNorm2d in training mode with fp32
+    parameters on the GPU and the activation is None / ReLU / ReLU6; the stock modules otherwise (eval mode, other layers, CPU)."""
+    import torch.nn as nn
+    act = 0 if act_layer is None else 1 if type(act_layer) is nn.ReLU else 2 if type(act_layer) is nn.ReLU6 else -1
+    if (USE_HIP_BN and type(bn) is nn.BatchNorm2d and bn.training and bn.track_running_stats and bn.momentum is not None and act >= 0
+            and x.is_cuda and x.dtype in DTYPE_CODES and x.dim() == 4 and bn.affine and bn.weight.dtype == torch.float32
+            and x.shape[0] * x.shape[2] * x.shape[3] > 1 and x.shape[0] * x.shape[2] * x.shape[3] < 2 ** 31):
+        y = BNActTrain.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, act)
+        bn.num_batches_tracked.add_(1)
+        return y
+    y = bn(x)
+    return y if act_layer is None else act_layer(y)
+
+
+USE_HIP_BN = True       # tests switch it off to compare with the stock modules
+
+
 class BootstrapMean(torch.autograd.Function):
     """The per-image reduction of the bootstrapped cross entropy (hyperseg/losses/bootstrapped_ce_loss.py:19-25) on the device with no
     sort and no host read (hs_bootstrap_mean_fwd / _bwd): capturable into a HIP graph as it is."""

@@ -290,15 +290,15 @@ class HyperPatchInvertedResidual(nn.Module, _SignalToWeights):
             tiles = xp.unfold(2, ph + 2, ph).unfold(3, pw + 2, pw)                 # B C fh fw ph+2 pw+2
             tiled = tiles.permute(0, 1, 2, 4, 3, 5).reshape(b, c, fh * (ph + 2), fw * (pw + 2))
         y = HA.patch_conv_apply(tiled, bank[:, :r1], grid, self.hidden_dim, 1, 0, 'zeros', 1)
-        y = self.act_layer(self.bn1(y))
+        y = HA.bn_act(self.bn1, self.act_layer, y)
         y = HA.patch_conv_apply(y, bank[:, r1:r2], grid, self.hidden_dim, 3, 1, 'zeros', self.hidden_dim)
         if own and HA.tiles_supported(y):
             y = HA.TileInterior.apply(y, (h, wd), grid)
         else:
             y = y.reshape(b, self.hidden_dim, fh, ph + 2, fw, pw + 2)[:, :, :, 1:-1, :, 1:-1].reshape(b, self.hidden_dim, h, wd)
-        y = self.act_layer(self.bn2(y))
+        y = HA.bn_act(self.bn2, self.act_layer, y)
         y = HA.patch_conv_apply(y, bank[:, r2:r3], grid, self.out_nc, 1, 0, 'zeros', 1)
-        y = self.bn3(y)
+        y = HA.bn_act(self.bn3, None, y)
         return xt + y if residual else y
 
     def _run(self, x, s, residual):

@@ -161,6 +161,56 @@ def test_halo_tiles_and_interior_vs_stock_ops(dev, shape, grid, dtype):
     assert torch.equal(ua.grad, ub.grad)
 
 
+@pytest.mark.parametrize('act', [None, 'relu', 'relu6'])
+@pytest.mark.parametrize('shape', [(2, 44, 36, 54), (1, 3, 7, 5), (3, 16, 1, 1), (2, 5, 129, 33)])
+def test_fused_training_batchnorm_vs_stock(dev, shape, act):
+    """hs_bn_act_train_fwd / _bwd behind autograd.bn_act == BatchNorm2d (train mode) + activation of torch: outputs, gradients of the
+    input, gamma and beta, running statistics and the batch counter; mean far from zero (the shifted sums), ReLU6 saturating on both sides."""
+    import copy
+    from hyperseg_amd import autograd as HA
+    g = torch.Generator().manual_seed(shape[1] * 7 + shape[2])
+    bn0 = torch.nn.BatchNorm2d(shape[1], momentum=0.1).to(dev).train()
+    with torch.no_grad():
+        bn0.weight.copy_(torch.rand(shape[1], generator=g) * 2 + 0.5)
+        bn0.bias.copy_(torch.randn(shape[1], generator=g) * 2)
+        bn0.running_mean.copy_(torch.randn(shape[1], generator=g))
+        bn0.running_var.copy_(torch.rand(shape[1], generator=g) + 0.5)
+    bn1 = copy.deepcopy(bn0)
+    bn0_var0, bn0_mean0 = bn0.running_var.clone(), bn0.running_mean.clone()
+    layer = None if act is None else (torch.nn.ReLU() if act == 'relu' else torch.nn.ReLU6())
+    x = (torch.randn(shape, generator=g) * 3 + torch.randn(1, shape[1], 1, 1, generator=g) * 40).to(dev)
+    r = torch.randn(shape, generator=g).to(dev)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    HA.USE_HIP_BN = False
+    try:
+        ya = HA.bn_act(bn0, layer, xa)
+    finally:
+        HA.USE_HIP_BN = True
+    yb = HA.bn_act(bn1, layer, xb)
+    (ya * r).sum().backward()
+    (yb * r).sum().backward()
+    # the channel means sit up to ~100 standard deviations from zero here: fp32 implementations differ at the 1e-5 level on such data,
+    # so the fused kernels are also held to the float64 statement -- they must be at least as close to it as the stock modules are
+    bn64 = copy.deepcopy(bn0).double()
+    with torch.no_grad():
+        bn64.running_mean.copy_(bn1.running_mean * 0); bn64.running_var.fill_(1)
+    x64 = x.double().requires_grad_(True)
+    y64 = bn64(x64)
+    y64 = y64 if layer is None else layer(y64)
+    (y64 * r.double()).sum().backward()
+    e_stock, e_fused = rel_err(ya.detach().double().cpu(), y64.detach().cpu()), rel_err(yb.detach().double().cpu(), y64.detach().cpu())
+    assert e_fused < max(2 * e_stock, 2e-6), (e_fused, e_stock)
+    for got, stock_g, want in ((xb.grad, xa.grad, x64.grad), (bn1.weight.grad, bn0.weight.grad, bn64.weight.grad),
+                               (bn1.bias.grad, bn0.bias.grad, bn64.bias.grad)):
+        e_s, e_f = rel_err(stock_g.double().cpu(), want.cpu()), rel_err(got.double().cpu(), want.cpu())
+        assert e_f < max(2 * e_s, 1e-5), (e_f, e_s)
+    assert rel_err(yb.detach().cpu(), ya.detach().cpu()) < max(2e-4, 3 * e_stock)      # (3 samples per channel at |mean| >> std: the stock kernel is percent-level off)
+    assert rel_err(bn1.running_mean.cpu(), (0.9 * bn0_mean0.double() + bn64.running_mean).float().cpu()) < 1e-5      # bn64 started from 0
+    batch_var = (bn64.running_var - 0.9) / 0.1                      # bn64 started from running_var = 1: its update reveals the unbiased batch variance
+    assert rel_err(bn1.running_var.cpu(), (0.9 * bn0_var0.double() + 0.1 * batch_var).float().cpu()) < 1e-4
+    assert int(bn1.num_batches_tracked) == int(bn0.num_batches_tracked) == 1
+
+
 @pytest.mark.parametrize('thresh', [0.3, 2.5, 5.0, 7.0])
 def test_bootstrap_mean_kernels_vs_reference_statement(dev, thresh):
     """hs_bootstrap_mean_fwd / _bwd (radix selection, no sort, no host read) == the reference's rule stated with torch.sort
@@ -339,7 +389,9 @@ def test_train_hyperseg_m_level_shapes(dev):
     """The Cityscapes-M decoder in train mode on a 256x512 crop (grid 8x16): its level-4 depthwise weight-gradient tile
     (68 hidden channels x 18x18 halo tiles = 192 KB if staged whole) needs the channel-blocked
     hs_patch_conv_bwd_weight; round 1 raised 'tile does not fit the LDS' here."""
-    _train_compare('M', 1, (256, 512), dev)
+    # gradients in the max norm at 3e-4 (observed 1.5e-4 on one pyramid level since BatchNorm runs on hs_bn_act_train_*: ~1e6 ReLU6 units, a
+    # handful within an ulp of a kink decide it -- see test_config5_full_workload_fp32's note; logits and statistics stay at 1e-4)
+    _train_compare('M', 1, (256, 512), dev, grad_tol=3e-4)
 
 
 # ------------------------------------------------------------------------------ bf16 storage / fp32 accumulation
