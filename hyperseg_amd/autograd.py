@@ -253,6 +253,26 @@ def patch_conv_apply(*args):
     return PatchConv.apply(*args)
 
 
+class BankSlices(torch.autograd.Function):
+    """The three column ranges [0, r1), [r1, r2), [r2, r3) of an inverted residual's bank (pw1 | depthwise | pw3) as views.  Plain
+    slicing gives the same views, but autograd then returns each range's gradient through its own zeros + copy and sums the three
+    (8 launches per level and step); here the backward is ONE concatenation."""
+
+    @staticmethod
+    def forward(ctx, bank, r1, r2, r3):
+        ctx.meta = (tuple(bank.shape), r1, r2, r3)
+        return bank[:, :r1], bank[:, r1:r2], bank[:, r2:r3]
+
+    @staticmethod
+    def backward(ctx, g1, g2, g3):
+        (rows, cols), r1, r2, r3 = ctx.meta
+        ref = next(g for g in (g1, g2, g3) if g is not None)
+        parts = [g if g is not None else ref.new_zeros(rows, w) for g, w in ((g1, r1), (g2, r2 - r1), (g3, r3 - r2))]
+        if cols > r3:
+            parts.append(ref.new_zeros(rows, cols - r3))
+        return torch.cat(parts, dim=1), None, None, None
+
+
 class BankPack(torch.autograd.Function):
     """(B, hp_total, fh, fw) reference-layout weights -> patch-major bank (B*fh*fw, ld); backward is the transpose.
     The re-layout itself runs in fp32 (a bf16 weight tensor produced under autocast is widened first; PatchConv narrows

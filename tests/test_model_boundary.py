@@ -389,6 +389,22 @@ def test_deferred_bn_shift_algebra_cpu(monkeypatch, config, split):
                 assert used.get('pooled_shift', 0) >= 1 and used.get('up2', 0) >= 1     # its pool and its upsample ride along
 
 
+def test_bank_slices_autograd_cpu():
+    """autograd.BankSlices (host logic, no GPU): the three column ranges of an inverted residual's bank as views whose gradients come
+    back as ONE concatenation -- equal to plain slicing, unused ranges and the unused tail included."""
+    from hyperseg_amd.autograd import BankSlices
+    g = torch.Generator().manual_seed(1)
+    bank = torch.randn(6, 23, generator=g)
+    a, b = bank.clone().requires_grad_(True), bank.clone().requires_grad_(True)
+    x1, x2, x3 = BankSlices.apply(a, 5, 11, 20)
+    y1, y2, y3 = b[:, :5], b[:, 5:11], b[:, 11:20]
+    assert torch.equal(x1, y1) and torch.equal(x2, y2) and torch.equal(x3, y3) and x2.data_ptr() == a.data_ptr() + 5 * 4
+    r = torch.randn(6, 9, generator=g)
+    ((x1 ** 2).sum() + (x3 * r).sum()).backward()              # the middle range takes no part
+    ((y1 ** 2).sum() + (y3 * r).sum()).backward()
+    assert torch.equal(a.grad, b.grad) and float(a.grad[:, 5:11].abs().max()) == 0.0 and float(a.grad[:, 20:].abs().max()) == 0.0
+
+
 def test_patch_ir_routes():
     """hs_patch_ir_route (host only): which kernel a fused inverted-residual level gets.  The f16-split matrix-core kernel is
     chosen by RANGES of channel counts, so every BASELINE level 4, CamVid-L's 6-level model (20-class variant included) and odd
