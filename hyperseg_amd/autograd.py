@@ -253,6 +253,27 @@ def patch_conv_apply(*args):
     return PatchConv.apply(*args)
 
 
+class UpsampleBilinear(torch.autograd.Function):
+    """F.interpolate(x, size, mode='bilinear', align_corners=False) for fp32 CUDA tensors, forward and adjoint on the HIP kernels
+    (hs_upsample_bilinear_fwd / _bwd): the previous level on its way into a stage input (materialize_stage)."""
+
+    @staticmethod
+    def forward(ctx, x, size):
+        x = x.contiguous()
+        ctx.meta = (tuple(x.shape), tuple(size))
+        return HF.upsample_bilinear(x, size)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (b, c, hi, wi), (ho, wo) = ctx.meta
+        dy = dy.contiguous().float()
+        with torch.cuda.device(dy.device):
+            dx = torch.empty(b, c, hi, wi, device=dy.device, dtype=torch.float32)
+            st = _hip.lib.hs_upsample_bilinear_bwd(dy.data_ptr(), b, c, hi, wi, ho, wo, dx.data_ptr(), _hip.stream_ptr())
+            _hip.check(st, 'hs_upsample_bilinear_bwd')
+        return dx, None
+
+
 class BankSlices(torch.autograd.Function):
     """The three column ranges [0, r1), [r1, r2), [r2, r3) of an inverted residual's bank (pw1 | depthwise | pw3) as views.  Plain
     slicing gives the same views, but autograd then returns each range's gradient through its own zeros + copy and sums the three
@@ -313,6 +334,10 @@ def materialize_stage(stage):
     parts.append(skip)
     if prev is not None:
         if prev.shape[-2:] != skip.shape[-2:]:
-            prev = F.interpolate(prev, (h, w), mode='bilinear', align_corners=False)
+            if (prev.is_cuda and prev.dtype == torch.float32 and h >= prev.shape[2] and w >= prev.shape[3]
+                    and prev.shape[0] * prev.shape[1] <= 65535):
+                prev = UpsampleBilinear.apply(prev, (h, w))
+            else:
+                prev = F.interpolate(prev, (h, w), mode='bilinear', align_corners=False)
         parts.append(prev)
     return torch.cat(parts, dim=1)

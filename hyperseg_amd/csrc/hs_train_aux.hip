@@ -330,9 +330,49 @@ void bn_bwd_apply_kernel(BnArgs a, const T* __restrict__ x, const T* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Adjoint of F.interpolate(x, (Ho, Wo), 'bilinear', align_corners=False): dx[yi][xi] = sum over the output pixels whose taps touch
+// (yi, xi) of their weights x dy -- a gather (no atomics): the candidate output rows / columns are those within the tap footprint,
+// and each one's weight on this input index is read off the same bilinear_tap the forward uses (so the border clamping, where both
+// taps of an output land on the edge sample, comes out by itself).
+// ---------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void upsample_bilinear_bwd_kernel(const float* __restrict__ dy, int planes, int Hi, int Wi, int Ho, int Wo, float sy, float sx,
+                                  float* __restrict__ dx) {
+    const int xi = blockIdx.x * 64 + (threadIdx.x & 63), yi = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (xi >= Wi || yi >= Hi) return;
+    // outputs whose source coordinate lies within (yi - 1, yi + 1): o in ((yi - 0.5) / s - 0.5, (yi + 1.5) / s - 0.5)
+    const int oy0 = max((int)floorf(((float)yi - 0.5f) / sy - 0.5f) - 1, 0), oy1 = min((int)ceilf(((float)yi + 1.5f) / sy - 0.5f) + 1, Ho - 1);
+    const int ox0 = max((int)floorf(((float)xi - 0.5f) / sx - 0.5f) - 1, 0), ox1 = min((int)ceilf(((float)xi + 1.5f) / sx - 0.5f) + 1, Wo - 1);
+    const float* __restrict__ g = dy + (size_t)blockIdx.z * Ho * Wo;
+    float acc = 0.0f;
+    for (int oy = oy0; oy <= oy1; ++oy) {
+        const Tap ty = bilinear_tap(oy, sy, Hi);
+        const float wy = (ty.i0 == yi ? ty.l0 : 0.0f) + (ty.i1 == yi ? ty.l1 : 0.0f);
+        if (wy == 0.0f) continue;
+        float row = 0.0f;
+        for (int ox = ox0; ox <= ox1; ++ox) {
+            const Tap tx = bilinear_tap(ox, sx, Wi);
+            const float wx = (tx.i0 == xi ? tx.l0 : 0.0f) + (tx.i1 == xi ? tx.l1 : 0.0f);
+            row = fmaf(wx, g[(size_t)oy * Wo + ox], row);
+        }
+        acc = fmaf(wy, row, acc);
+    }
+    dx[((size_t)blockIdx.z * Hi + yi) * Wi + xi] = acc;
+}
+
 }  // namespace hs
 
 using namespace hs;
+
+extern "C" int hs_upsample_bilinear_bwd(const float* dy, int32_t batch, int32_t channels, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,
+                                        float* dx, void* stream) {
+    if (!dy || !dx || batch <= 0 || channels <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return HS_ERR_BAD_ARG;
+    if ((long)batch * channels > 65535 || Ho < Hi || Wo < Wi) return HS_ERR_UNSUPPORTED;          // upsampling only (the decoder's use)
+    hipLaunchKernelGGL(upsample_bilinear_bwd_kernel, dim3((Wi + 63) / 64, (Hi + 3) / 4, batch * channels), dim3(256), 0, (hipStream_t)stream,
+                       dy, batch * channels, Hi, Wi, Ho, Wo, (float)Hi / (float)Ho, (float)Wi / (float)Wo, dx);
+    return launch_status();
+}
 
 static int bn_args(BnArgs& a, int B, int C, long hw, int act, float eps, float momentum) {
     if (B <= 0 || C <= 0 || hw <= 0 || act < HS_ACT_NONE || act > HS_ACT_RELU6 || eps < 0.f) return HS_ERR_BAD_ARG;

@@ -374,6 +374,11 @@ int64_t hs_bootstrap_mean_workspace(void);
 int hs_bootstrap_mean_fwd(const float* values, int32_t n, int32_t k, float thresh, void* workspace, float* out5, void* stream);
 int hs_bootstrap_mean_bwd(const float* values, int32_t n, const float* state5, const float* grad_out, float* grad_values, void* stream);
 
+/* Adjoint of hs_upsample_bilinear_fwd (F.interpolate(..., mode='bilinear', align_corners=False), Ho >= Hi, Wo >= Wi): dy (B,C,Ho,Wo) ->
+ * dx (B,C,Hi,Wi), a gather over the outputs whose taps touch each input pixel.  Training path (autograd.UpsampleBilinear). */
+int hs_upsample_bilinear_bwd(const float* dy, int32_t batch, int32_t channels, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, float* dx,
+                             void* stream);
+
 /* BatchNorm2d in TRAINING mode (torch.nn.functional.batch_norm semantics: batch statistics, biased variance for the normalisation,
  * unbiased for the running estimate, running = (1 - momentum) running + momentum batch) fused with the activation that follows it
  * (act = HS_ACT_NONE | HS_ACT_RELU | HS_ACT_RELU6), x / y / dy / dx (B, C, pixels) in `dtype` storage, parameters and statistics f32.

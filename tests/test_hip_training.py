@@ -161,6 +161,24 @@ def test_halo_tiles_and_interior_vs_stock_ops(dev, shape, grid, dtype):
     assert torch.equal(ua.grad, ub.grad)
 
 
+@pytest.mark.parametrize('shape,size', [((2, 16, 72, 72), (144, 144)), ((1, 3, 5, 7), (10, 14)), ((2, 2, 1, 1), (2, 2)), ((1, 4, 9, 6), (23, 17)),
+                                        ((1, 2, 8, 8), (8, 16))])
+def test_upsample_bilinear_autograd_vs_torch(dev, shape, size):
+    """autograd.UpsampleBilinear (hs_upsample_bilinear_fwd + the gather adjoint hs_upsample_bilinear_bwd) == F.interpolate(bilinear,
+    align_corners=False) and its autograd: exact 2x, a one-pixel map (both taps clamp onto it), non-integer ratios, one axis unchanged."""
+    import torch.nn.functional as F
+    from hyperseg_amd import autograd as HA
+    g = torch.Generator().manual_seed(sum(shape) + size[0])
+    x = torch.randn(shape, generator=g).to(dev)
+    r = torch.randn(shape[0], shape[1], *size, generator=g).to(dev)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = F.interpolate(xa, size, mode='bilinear', align_corners=False), HA.UpsampleBilinear.apply(xb, size)
+    assert rel_err(yb.detach().cpu(), ya.detach().cpu()) < 1e-6
+    (ya * r).sum().backward()
+    (yb * r).sum().backward()
+    assert rel_err(xb.grad.cpu(), xa.grad.cpu()) < 2e-6
+
+
 @pytest.mark.parametrize('act', [None, 'relu', 'relu6'])
 @pytest.mark.parametrize('shape', [(2, 44, 36, 54), (1, 3, 7, 5), (3, 16, 1, 1), (2, 5, 129, 33)])
 def test_fused_training_batchnorm_vs_stock(dev, shape, act):
