@@ -309,6 +309,12 @@ class BankPack(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dbank):
         b, c, fh, fw = ctx.shape
+        if dbank.is_cuda and dbank.dtype == torch.float32 and dbank.stride(1) == 1 and b <= 65535:
+            with torch.cuda.device(dbank.device):                  # one LDS-tiled transpose incl. the zero tail (hs_bank_unpack_fwd)
+                dw = torch.empty(ctx.shape, device=dbank.device, dtype=torch.float32)
+                st = _hip.lib.hs_bank_unpack_fwd(dbank.data_ptr(), dbank.stride(0), b, c, fh, fw, 0, ctx.rows, dw.data_ptr(), _hip.stream_ptr())
+                _hip.check(st, 'hs_bank_unpack_fwd')
+            return dw.to(ctx.dtype), None
         dw = dbank.new_zeros(ctx.shape, dtype=ctx.dtype)
         dw[:, :ctx.rows] = dbank[:, :ctx.rows].reshape(b, fh, fw, ctx.rows).permute(0, 3, 1, 2).to(ctx.dtype)
         return dw, None

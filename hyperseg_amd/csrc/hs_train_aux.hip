@@ -361,9 +361,42 @@ void upsample_bilinear_bwd_kernel(const float* __restrict__ dy, int planes, int 
     dx[((size_t)blockIdx.z * Hi + yi) * Wi + xi] = acc;
 }
 
+// Adjoint of hs_bank_pack_fwd: the patch-major gradient (B fh fw, ld) back to the reference's channel-major layout (B, hp_total, fh, fw),
+// channels [ch_offset, ch_offset + rows) from the bank and exact zeros everywhere else -- 32 x 32 LDS transpose tiles, one launch
+// (stock ops: a zeros fill + a permuted, uncoalesced copy).
+__global__ __launch_bounds__(256)
+void bank_unpack_kernel(const float* __restrict__ bank, long ld, int hp_total, int grid_sz, int ch_offset, int rows,
+                        float* __restrict__ w) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int m_base = blockIdx.x * 32, q_base = blockIdx.y * 32;       // m: channel of w, q = i fw + j
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;             // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int q = q_base + r, m = m_base + tx - ch_offset;
+        float v = 0.0f;
+        if (m >= 0 && m < rows && q < grid_sz) v = bank[((size_t)b * grid_sz + q) * ld + m];
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int m = m_base + r, q = q_base + tx;
+        if (m < hp_total && q < grid_sz) w[((size_t)b * hp_total + m) * grid_sz + q] = tile[tx][r];
+    }
+}
+
 }  // namespace hs
 
 using namespace hs;
+
+extern "C" int hs_bank_unpack_fwd(const float* bank, int64_t ld, int32_t batch, int32_t hp_total, int32_t fh, int32_t fw,
+                                  int32_t ch_offset, int32_t rows, float* w, void* stream) {
+    if (!bank || !w || batch <= 0 || hp_total <= 0 || fh <= 0 || fw <= 0 || rows <= 0 || ch_offset < 0) return HS_ERR_BAD_ARG;
+    if (ch_offset + rows > hp_total || ld < rows || batch > 65535) return HS_ERR_BAD_ARG;
+    const int grid_sz = fh * fw;
+    hipLaunchKernelGGL(bank_unpack_kernel, dim3((hp_total + 31) / 32, (grid_sz + 31) / 32, batch), dim3(256), 0, (hipStream_t)stream,
+                       bank, (long)ld, hp_total, grid_sz, ch_offset, rows, w);
+    return launch_status();
+}
 
 extern "C" int hs_upsample_bilinear_bwd(const float* dy, int32_t batch, int32_t channels, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,
                                         float* dx, void* stream) {

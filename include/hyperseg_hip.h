@@ -374,6 +374,11 @@ int64_t hs_bootstrap_mean_workspace(void);
 int hs_bootstrap_mean_fwd(const float* values, int32_t n, int32_t k, float thresh, void* workspace, float* out5, void* stream);
 int hs_bootstrap_mean_bwd(const float* values, int32_t n, const float* state5, const float* grad_out, float* grad_values, void* stream);
 
+/* Adjoint of hs_bank_pack_fwd: patch-major bank (B fh fw, ld) -> channel-major weights (B, hp_total, fh, fw): channels
+ * [ch_offset, ch_offset + rows) from the bank's columns [0, rows), exact zeros elsewhere.  Training path (autograd.BankPack). */
+int hs_bank_unpack_fwd(const float* bank, int64_t ld, int32_t batch, int32_t hp_total, int32_t fh, int32_t fw, int32_t ch_offset,
+                       int32_t rows, float* w, void* stream);
+
 /* Adjoint of hs_upsample_bilinear_fwd (F.interpolate(..., mode='bilinear', align_corners=False), Ho >= Hi, Wo >= Wi): dy (B,C,Ho,Wo) ->
  * dx (B,C,Hi,Wi), a gather over the outputs whose taps touch each input pixel.  Training path (autograd.UpsampleBilinear). */
 int hs_upsample_bilinear_bwd(const float* dy, int32_t batch, int32_t channels, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, float* dx,

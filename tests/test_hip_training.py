@@ -161,6 +161,23 @@ def test_halo_tiles_and_interior_vs_stock_ops(dev, shape, grid, dtype):
     assert torch.equal(ua.grad, ub.grad)
 
 
+def test_bank_pack_autograd_roundtrip(dev):
+    """autograd.BankPack: forward = hs_bank_pack_fwd, backward = hs_bank_unpack_fwd (one tiled transpose incl. the zero tail) == the
+    gradient of the reference layout's permute, unused trailing channels exactly zero."""
+    from hyperseg_amd import autograd as HA
+    g = torch.Generator().manual_seed(4)
+    for shape, rows in (((2, 70, 5, 7), 61), ((1, 33, 18, 18), 33), ((3, 5, 1, 1), 4)):
+        w = torch.randn(shape, generator=g).to(dev).requires_grad_(True)
+        bank = HA.BankPack.apply(w, rows)
+        b, c, fh, fw = shape
+        assert torch.equal(bank[:, :rows], w.detach()[:, :rows].permute(0, 2, 3, 1).reshape(b * fh * fw, rows))
+        r = torch.randn(bank.shape, generator=g).to(dev)
+        (bank * r).sum().backward()
+        want = torch.zeros(shape, device=dev)
+        want[:, :rows] = r[:, :rows].reshape(b, fh, fw, rows).permute(0, 3, 1, 2)
+        assert torch.equal(w.grad, want)
+
+
 @pytest.mark.parametrize('shape,size', [((2, 16, 72, 72), (144, 144)), ((1, 3, 5, 7), (10, 14)), ((2, 2, 1, 1), (2, 2)), ((1, 4, 9, 6), (23, 17)),
                                         ((1, 2, 8, 8), (8, 16))])
 def test_upsample_bilinear_autograd_vs_torch(dev, shape, size):
