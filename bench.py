@@ -67,8 +67,9 @@ class StepLoop:
     """One rank's step / drain / fence triple.  ``forward()`` produces the rank's output tensor (a graph replay returns
     the captured static output); ``comm`` is a hyperseg_amd.distributed.LogitsGatherer or None."""
 
-    def __init__(self, forward, comm=None, to_payload=None, world=1, device=None, forward_takes_step=False):
+    def __init__(self, forward, comm=None, to_payload=None, world=1, device=None, forward_takes_step=False, on_drain=None):
         self.forward, self.comm, self.world = forward, comm, world
+        self.on_drain, self.last_step = on_drain, None     # on_drain(last step): a collective carried by the step's own graph
         self.forward_takes_step = forward_takes_step      # forward(i): one HIP graph per ring slot (zero-copy collective)
         self.to_payload = to_payload or (lambda y: y)
         self.device = device
@@ -77,6 +78,7 @@ class StepLoop:
 
     def step(self, i):
         y = self.forward(i) if self.forward_takes_step else self.forward()
+        self.last_step = i
         if self.comm is not None:
             done = self.comm.submit(i, self.to_payload(y))
             if done is not None:
@@ -87,6 +89,9 @@ class StepLoop:
         if self.comm is not None:
             for done in self.comm.drain():
                 self.last = done
+        if self.on_drain is not None and self.last_step is not None:
+            self.on_drain(self.last_step)
+            self.last_step = None
 
     def fence(self):
         if self.cuda:
@@ -393,7 +398,93 @@ def two_in_flight(forward, x, y_ref, steps, warmup, batch):
             'note': 'NOT the headline: 2 requests in flight on 2 streams (one HIP graph each); value above = 1 in flight'}
 
 
-def main():
+def plan_workload(model_key, rank, world):
+    """What ``rank`` of ``world`` computes per step: m / s / sc keep bs 1 per GPU (weak scaling), l shards BASELINE config 4's
+    bs-32 batch into 32 / world contiguous frames per GPU (strong scaling; world must divide 32)."""
+    from hyperseg_amd import configs
+    from hyperseg_amd.distributed import shard_batch
+    cfg = MODELS[model_key]
+    spec = configs.MODELS[cfg]
+    h, w = spec['size']
+    if model_key == 'l':
+        lo, hi = shard_batch(spec['batch'], rank, world)
+        return dict(cfg=cfg, spec=spec, h=h, w=w, batch=hi - lo, global_batch=spec['batch'], scaling='strong', frames=(lo, hi))
+    return dict(cfg=cfg, spec=spec, h=h, w=w, batch=spec['batch'], global_batch=spec['batch'] * world, scaling='weak', frames=None)
+
+
+def select_device(local_rank, stub=False, visible=None):
+    """LOCAL_RANK -> this rank's device: one process per GPU, rank r of the node on cuda:r (torch.distributed.run exports
+    LOCAL_RANK).  Refuses to run two ranks on one GPU or without a GPU; ``stub``: the CPU / gloo plumbing test."""
+    if stub:
+        return torch.device('cpu')
+    n = torch.cuda.device_count() if visible is None else visible
+    if n < 1:
+        raise SystemExit('bench.py needs an MI355X (no GPU visible)')
+    if not 0 <= local_rank < n:
+        raise SystemExit(f'LOCAL_RANK={local_rank} but {n} GPU(s) visible: launch one rank per GPU (--nproc-per-node <= {n})')
+    return torch.device('cuda', local_rank)
+
+
+def self_traffic_passes(model_key, timeout_s=170):
+    """--traffic auto: the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass) of THIS command,
+    spawned before this process touches the GPU and outside every timed region; returns (directory | None, note).
+    Counter collection only -- '--pmc X --kernel-trace', never with a sys / hip / hsa trace domain."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which('rocprofv3')
+    if exe is None:
+        return None, 'rocprofv3 not on PATH'
+    root = tempfile.mkdtemp(prefix='hs_traffic_', dir='/tmp')
+    env = dict(os.environ, TMPDIR='/tmp', HS_BENCH_CHILD='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    for c in ('FETCH_SIZE', 'WRITE_SIZE'):
+        cmd = [exe, '--pmc', c, '--kernel-trace', '--output-format', 'csv', '-d', os.path.join(root, c), '--',
+               sys.executable, os.path.join(REPO, 'bench.py'), '--model', model_key, '--no-extras', '--steps', '10', '--warmup', '3',
+               '--repeats', '1', '--no-graph', '--traffic', 'off']
+        try:
+            r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            return None, f'rocprofv3 --pmc {c} pass timed out after {timeout_s} s'
+        if r.returncode != 0:
+            return None, f'rocprofv3 --pmc {c} pass exited {r.returncode}: ' + r.stderr.decode(errors='replace')[-200:]
+    return root, 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (eager launches, 10 steps), made by this run'
+
+
+def time_replayed(forward, x, steps, warmup, batch):
+    """One timed region of a fresh HIP graph of ``forward(x)`` (side numbers only): (frames/s, ms per step, output)."""
+    for _ in range(3):
+        y = forward(x)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        y = forward(x)
+    for _ in range(max(1, warmup)):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.replay()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return round(steps * batch / el, 2), round(1e3 * el / steps, 4), y, g
+
+
+class StubModel:
+    """HS_BENCH_STUB=1 (CPU / gloo plumbing test of this file's main(), tests/test_distributed.py): stands in for the model;
+    ``forward`` writes a rank- and step-dependent pattern of the logits' shape at 1/16 of the resolution."""
+
+    def __init__(self, plan, rank):
+        self.shape = (plan['batch'], plan['spec']['num_classes'], plan['h'] // 16, plan['w'] // 16)
+        self.rank, self.calls = rank, 0
+
+    def __call__(self, x):
+        self.calls += 1
+        return torch.full(self.shape, float(self.rank * 1000 + self.calls % 7), dtype=torch.float32)
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
@@ -407,11 +498,16 @@ def main():
                          "taken inside the final upsample kernel (HyperGen.segment; test_fps.py:194's epilogue fused)")
     ap.add_argument('--gather', default='logits', choices=['logits', 'masks'],
                     help='what the N>1 collective moves (north star: logits)')
-    ap.add_argument('--collective', default=None, choices=['allgather', 'direct', 'gather', 'none'],
-                    help="N>1: the all-gather of every rank's logits.  'direct' (default): RCCL grouped point-to-point sends / receives, "
-                         "all pairs -- every shard crosses exactly one xGMI link; 'allgather': RCCL all_gather_into_tensor (its ring moves "
-                         "N-1 shards through every link); 'gather': onto rank 0 (nn.DataParallel semantics); 'none'.  Given explicitly at N=1 it runs the collective on a "
-                         "one-rank group and reports its per-step overhead ('collective.overhead_pct')")
+    ap.add_argument('--collective', default=None, choices=['auto', 'ingraph', 'allgather', 'direct', 'gather', 'none'],
+                    help="N>1: the all-gather of every rank's logits.  'auto' (default at N>1): RCCL all_gather_into_tensor, in place, "
+                         "zero copy -- as a parallel branch INSIDE the step's HIP graph ('ingraph') or on RCCL's own stream ('allgather'), "
+                         "whichever a short calibration finds faster (both reported); 'direct': grouped RCCL point-to-point sends / "
+                         "receives, all pairs; 'gather': onto rank 0 (nn.DataParallel semantics); 'none'.  Given explicitly at N=1 it runs "
+                         "the collective on a one-rank group and reports its per-step overhead ('collective.overhead_pct')")
+    ap.add_argument('--probe-load', type=int, default=0,
+                    help='N=1 collective probe only: that many extra out-of-place all-gathers of the payload per step (one RCCL copy '
+                         'kernel each at world 1), so that RCCL kernels really run beside the forward')
+    ap.add_argument('--calib-steps', type=int, default=40, help="steps per candidate of --collective auto's calibration")
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of HIP graph replay')
     ap.add_argument('--stock-encoder', action='store_true',
                     help='leave the encoder entirely on stock PyTorch-ROCm/MIOpen (no fused depthwise HIP kernel)')
@@ -420,21 +516,26 @@ def main():
                          'round 3: parity-green inside the model and 8 %% faster, profiles/round3_first_visit.txt)')
     ap.add_argument('--split-gemm', dest='split_gemm', action='store_true', help='(default) 1x1 convolutions through hs_gemm_split_fwd')
     ap.set_defaults(split_gemm=True)
-    ap.add_argument('--ir-math', choices=['auto', 'f32', 'split'], default='auto',
-                    help='arithmetic of the fused inverted-residual decoder levels (include/hyperseg_hip.h hs_ir_math); the '
-                         'exact_f32 object re-times the step with f32')
+    ap.add_argument('--ir-math', choices=['auto', 'f32', 'split'], default='f32',
+                    help='arithmetic of the fused inverted-residual decoder levels (include/hyperseg_hip.h hs_ir_math).  Default f32: '
+                         'every product of the decoder (the hot path) on the exact-f32 matrix cores -- what `value` and `dtype` state; '
+                         'the `split_f16` object re-times the step with auto (f16 split products on the level-4 block)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the roofline / parity / protocol passes (timing only)')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
+    ap.add_argument('--traffic', default='auto', choices=['auto', 'off'],
+                    help="roofline.traffic: 'auto' = spawn the two rocprofv3 --pmc passes of this command before the timing (N=1, rank 0, "
+                         "when rocprofv3 is on PATH; ~1 minute), 'off' = null unless --traffic-dir is given")
     ap.add_argument('--traffic-dir', default=None,
                     help='directory with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (same session)')
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     # The ONE JSON line goes to the process' real stdout; everything else that writes to fd 1 (RCCL prints a version banner there
     # when its first communicator comes up, MIOpen may chat) is sent to stderr, so that the line is the only thing a reader sees.
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    stub = os.environ.get('HS_BENCH_STUB') == '1'
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -442,12 +543,16 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit('bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)')
         args.gpus = world
-    assert torch.cuda.is_available(), 'bench.py needs an MI355X'
-    dev = torch.device('cuda', local_rank)
-    torch.cuda.set_device(dev)
+    dev = select_device(local_rank, stub)
+    traffic_note = None
+    if (not stub and world == 1 and not args.no_extras and args.traffic == 'auto' and args.traffic_dir is None
+            and os.environ.get('HS_BENCH_CHILD') != '1'):
+        args.traffic_dir, traffic_note = self_traffic_passes(args.model)      # before this process initialises the GPU
+    if not stub:
+        torch.cuda.set_device(dev)
     collective_probe = world == 1 and args.collective not in (None, 'none')      # N=1: measure the collective's own cost
     if args.collective is None:
-        args.collective = 'direct' if world > 1 else 'none'
+        args.collective = 'auto' if world > 1 else 'none'
     if world > 1 or collective_probe:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if collective_probe:
@@ -455,50 +560,58 @@ def main():
             with socket.socket() as sk:
                 sk.bind(('127.0.0.1', 0))
                 os.environ.setdefault('MASTER_PORT', str(sk.getsockname()[1]))
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if stub:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from hyperseg_amd import configs
-    from hyperseg_amd.distributed import LogitsGatherer, shard_batch
-    from hyperseg_amd.utils.inference import prepare_for_inference
+    from hyperseg_amd.distributed import InGraphAllGather, LogitsGatherer
     from hyperseg_amd.utils.synthetic import fill_by_name
     import copy
 
-    cfg = MODELS[args.model]
-    spec = configs.MODELS[cfg]
-    h, w = spec['size']
-    if args.model == 'l':
-        lo, hi = shard_batch(spec['batch'], rank, world)        # strong scaling: the bs-32 batch split over the ranks
-        batch, global_batch, scaling = hi - lo, spec['batch'], 'strong'
+    plan = plan_workload(args.model, rank, world)
+    cfg, spec, h, w = plan['cfg'], plan['spec'], plan['h'], plan['w']
+    batch, global_batch, scaling = plan['batch'], plan['global_batch'], plan['scaling']
+    stock = stock_cpu = None
+    if stub:
+        model = StubModel(plan, rank)
+        x = torch.zeros(1)
+        args.no_graph = args.no_extras = True
     else:
-        batch, global_batch, scaling = spec['batch'], spec['batch'] * world, 'weak'
-    model = fill_by_name(configs.build(cfg).eval(), seed=0)       # synthetic, non-denormal, same on every rank
-    stock = copy.deepcopy(model) if rank == 0 and not args.no_extras else None
-    if not args.stock_encoder:
-        prepare_for_inference(model, fold_bn=False, fused_depthwise=True, split_gemm=args.split_gemm, ir_math=args.ir_math)
-    else:
-        from hyperseg_amd.utils.inference import set_ir_math
-        set_ir_math(model, args.ir_math)
-    model = model.to(dev)
-    torch.manual_seed(1234 + rank)
-    x = torch.rand(batch, 3, h, w, device=dev)                    # resident synthetic batch
+        from hyperseg_amd.utils.inference import prepare_for_inference
+        model = fill_by_name(configs.build(cfg).eval(), seed=0)       # synthetic, non-denormal, same on every rank
+        if rank == 0 and not args.no_extras:
+            stock, stock_cpu = copy.deepcopy(model), (copy.deepcopy(model) if world == 1 and not args.stock_encoder else None)
+        if not args.stock_encoder:
+            prepare_for_inference(model, fold_bn=False, fused_depthwise=True, split_gemm=args.split_gemm, ir_math=args.ir_math)
+        else:
+            from hyperseg_amd.utils.inference import set_ir_math
+            set_ir_math(model, args.ir_math)
+        model = model.to(dev)
+        torch.manual_seed(1234 + rank)
+        x = torch.rand(batch, 3, h, w, device=dev)                    # resident synthetic batch
     torch.set_grad_enabled(False)
 
     # ---- the step: a HIP graph of the whole forward ---------------------------------------------------------------
     forward = model.segment if args.output == 'masks' else model
     if args.output == 'masks':
         args.gather = 'masks'
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(3):
-            y = forward(x)
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
     graph = None
-    if not args.no_graph:
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            y = forward(x)
+    if stub:
+        y = forward(x)
+    else:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                y = forward(x)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        if not args.no_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                y = forward(x)
 
     def run_forward():
         nonlocal y
@@ -508,44 +621,103 @@ def main():
             y = forward(x)
         return y
 
-    comm, to_payload, zero_copy = None, None, False
-    if (world > 1 or collective_probe) and args.collective != 'none':
-        shape = tuple(y.shape) if args.gather == 'logits' else (y.shape[0],) + tuple(y.shape[-2:])
-        dtype = torch.float32 if args.gather == 'logits' else torch.uint8
-        comm = LogitsGatherer(world, shape, dtype, dev, mode=args.collective)
-        if args.gather == 'masks':
-            to_payload = lambda t: t if t.dtype == torch.uint8 else t.argmax(1).to(torch.uint8)   # noqa: E731
+    def forward_into(out):
+        """The forward with the decoder's last kernel writing the logits into ``out`` (zero copy into a ring slot)."""
+        model.decoder.output_buffer = out
+        try:
+            return forward(x)
+        finally:
+            model.decoder.output_buffer = None
+
+    # ---- the collective: candidates, calibration, choice --------------------------------------------------------------
+    shape = tuple(y.shape) if args.gather == 'logits' else (y.shape[0],) + tuple(y.shape[-2:])
+    dtype = torch.float32 if args.gather == 'logits' else torch.uint8
+    to_payload = None
+    if args.gather == 'masks':
+        to_payload = lambda t: t if t.dtype == torch.uint8 else t.argmax(1).to(torch.uint8)   # noqa: E731
+    zero_copy_ok = (graph is not None and args.gather == 'logits' and args.output != 'masks'
+                    and hasattr(getattr(model, 'decoder', None), 'forward'))
+    notes = {}
+
+    def make_loop(policy):
+        """StepLoop for one collective policy (None = no collective); returns (loop, comm, zero_copy)."""
+        if policy in (None, 'none'):
+            return StepLoop(run_forward, None, None, world, dev), None, False
+        mode = 'allgather' if policy == 'ingraph' else policy
+        comm = LogitsGatherer(world, shape, dtype, dev, mode=mode, probe_load=args.probe_load if world == 1 else 0)
+        if policy == 'ingraph':
+            if not zero_copy_ok:
+                raise RuntimeError('ingraph needs graph replay and a logits payload')
+            ing = InGraphAllGather(comm, forward_into, probe_load=args.probe_load if world == 1 else 0)
+            loop = StepLoop(ing.step, None, None, world, dev, forward_takes_step=True, on_drain=ing.drain)
+            return loop, ing, True
+        graphs = None
+        if zero_copy_ok and mode in ('allgather', 'direct'):
+            # zero copy: one HIP graph per ring slot, the decoder's last kernel writing the logits straight into the slot the
+            # collective sends from (LogitsGatherer.slot; VERDICT r2 #9: submit used to copy 39.8 MB per step)
+            from hyperseg_amd.distributed import RING
+            graphs = []
+            for k in range(RING):
+                gk = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gk):
+                    yk = forward_into(comm.slot(k))
+                graphs.append((gk, yk))
+            if not all(yk.data_ptr() == comm.slot(k).data_ptr() for k, (_, yk) in enumerate(graphs)):
+                graphs = None
+
+        def run_forward_slot(i):
+            gk, yk = graphs[i % len(graphs)]
+            gk.replay()
+            return yk
+        loop = StepLoop(run_forward_slot if graphs else run_forward, comm, to_payload, world, dev, forward_takes_step=bool(graphs))
+        return loop, comm, bool(graphs)
+
+    def agree(ok):
+        """True only if every rank says so (a policy is usable only if it came up everywhere)."""
+        if world == 1:
+            return ok
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if not stub else None)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
     base_ms = None
     if collective_probe:                                  # the same step without the collective, for the overhead figure
         base = run_timed(StepLoop(run_forward, None, None, world, dev), args.steps, args.warmup, max(1, args.repeats))
         base_ms = 1e3 * statistics.median(base) / args.steps
-    graphs = None
-    if comm is not None and graph is not None and args.gather == 'logits' and args.collective in ('allgather', 'direct') \
-            and hasattr(model.decoder, 'forward') and args.output != 'masks':
-        # zero copy: one HIP graph per ring slot, the decoder's last kernel writing the logits straight into the slot the
-        # collective sends from (LogitsGatherer.slot; VERDICT r2 #9: submit used to copy 39.8 MB per step)
-        from hyperseg_amd.distributed import RING
-        graphs = []
-        for k in range(RING):
-            model.decoder.output_buffer = comm.slot(k)
-            gk = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gk):
-                yk = forward(x)
-            graphs.append((gk, yk))
-        model.decoder.output_buffer = None
-        zero_copy = all(yk.data_ptr() == comm.slot(k).data_ptr() for k, (_, yk) in enumerate(graphs))
-        if not zero_copy:
-            graphs = None
-
-    def run_forward_slot(i):
-        gk, yk = graphs[i % len(graphs)]
-        gk.replay()
-        return yk
-    loop = StepLoop(run_forward_slot if graphs else run_forward, comm, to_payload, world, dev, forward_takes_step=bool(graphs))
+    calibration = None
+    policy = args.collective
+    if policy == 'auto':
+        candidates = (['ingraph'] if zero_copy_ok else []) + ['allgather']
+        calibration, built = {}, {}
+        for cand in candidates:
+            try:
+                trio = make_loop(cand)
+                ok = True
+            except Exception as e:                        # noqa: BLE001  (e.g. a stack that cannot capture RCCL)
+                notes[cand] = f'{type(e).__name__}: {e}'[:300]
+                trio, ok = None, False
+                if not stub:
+                    torch.cuda.synchronize()
+            if not agree(ok):
+                calibration[cand] = None
+                continue
+            t = run_timed(trio[0], args.calib_steps, min(10, args.warmup), 1)[0]
+            calibration[cand] = round(1e3 * t / args.calib_steps, 4)
+            built[cand] = trio
+        usable = {c: v for c, v in calibration.items() if v is not None}
+        if not usable:
+            raise SystemExit(f'no collective policy came up: {notes}')
+        policy = min(usable, key=usable.get)                # the calibration time is MAX-reduced: every rank picks the same
+        loop, comm, zero_copy = built[policy]
+        for c in list(built):
+            if c != policy:
+                del built[c]
+    else:
+        loop, comm, zero_copy = make_loop(policy)
     times = run_timed(loop, args.steps, args.warmup, max(1, args.repeats))
     med = statistics.median(times)
     fps = args.steps * global_batch / med
-    rank_fps = torch.tensor([args.steps * batch / med], dtype=torch.float64, device=dev)
+    rank_fps = torch.tensor([args.steps * batch / med], dtype=torch.float64, device=None if stub else dev)
     if world > 1:
         all_fps = [torch.zeros_like(rank_fps) for _ in range(world)]
         dist.all_gather(all_fps, rank_fps)
@@ -555,34 +727,50 @@ def main():
 
     out = None
     if rank == 0:
+        import hyperseg_amd.functional as HFm
+        math_name = HFm.get_ir_math(args.ir_math) if not stub else args.ir_math
         out = {
             'metric': f'frames/sec @ bs={spec["batch"]} {LABELS[args.model].split(" / ")[0]} {w}x{h}',
             'value': round(fps, 2), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * med / args.steps, 4), 'higher_is_better': True, 'scaling': scaling,
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None,
+            'dtype': 'f32' if math_name == 'f32' else 'f32 (level-4 inverted residual: products as 3-term f16 splits, f32 accumulation)',
+            'data': 'synthetic' if not stub else 'stub (HS_BENCH_STUB=1: CPU / gloo plumbing test, no model)',
             'repeats': {'n': len(times), 'ms_per_step': [round(1e3 * t / args.steps, 4) for t in times], 'value_from': 'median'},
             'config': {'workload': f'{LABELS[args.model]}, batch {batch} per GPU (global {global_batch}), whole model forward '
                                    '(encoder + context head as per "encoder", HIP decoder), resident input',
                        'encoder': 'stock PyTorch-ROCm / MIOpen' if args.stock_encoder else
                                   'hyperseg_amd.utils.inference.prepare_for_inference: MBConv blocks = hs_mbconv_expand_dw_fwd | '
                                   '1x1 GEMM + hs_depthwise_conv_fwd, hs_se_gate_fwd, 1x1 GEMM; hs_stem_conv_fwd; '
-                                  'context head = library GEMMs + hs_affine_act_fwd; 1x1 GEMMs of the MBConv blocks = ' +
+                                  'context head = 4 launches of hs_gemm_split_*; 1x1 GEMMs of the MBConv blocks = ' +
                                   ('hs_gemm_split_fwd (f16 matrix cores, split operands, f32 accumulation)' if args.split_gemm
                                    else 'library f32 GEMM (--library-gemm)'),
                        'output': f'fp32 logits {tuple(y.shape)}' if args.output == 'logits' else f'uint8 argmax masks {tuple(y.shape)}',
                        'launch': 'eager' if args.no_graph else 'hipGraph replay',
-                       'ir_math': __import__('hyperseg_amd.functional', fromlist=['x']).get_ir_math(args.ir_math) + ' (include/hyperseg_hip.h hs_ir_math: f32 storage and accumulation; auto = f16 '
-                                  'split products, f32-class, on the level-4 inverted residual; HS_IR_MATH=f32 for exact f32)',
-                       'parallelism': f'batch-sharded x{world}' + (f', RCCL {args.collective} of {args.gather}' if comm is not None else '')},
+                       'ir_math': math_name + ' (include/hyperseg_hip.h hs_ir_math)',
+                       'arithmetic': 'f32 storage and f32 accumulation everywhere.  Decoder (the hot path): ' +
+                                     ('every product exact f32 (v_mfma_f32_16x16x4_f32 / v_fma_f32)' if math_name == 'f32' else
+                                      'level-4 inverted residual products as 3-term f16 splits (1.3e-7 * sum|a||b|), the rest exact f32') +
+                                     '.  Encoder / context head (outside the path, inside the metric): 1x1 convolutions ' +
+                                     ('as 3-term f16 split products with f32 accumulation (hs_gemm_split_fwd; error below an fp32 fmaf '
+                                      "chain's) -- `library_gemm_f32` re-times the frame with IEEE f32 library GEMMs instead"
+                                      if args.split_gemm and not args.stock_encoder else 'IEEE f32 (library GEMM)'),
+                       'parallelism': f'batch-sharded x{world}' + (f', RCCL {policy} of {args.gather}' if comm is not None else '')},
             'per_rank_frames_per_s': per_rank,
             'collective': None if comm is None else {
-                'op': {'allgather': 'all_gather_into_tensor', 'direct': 'batch_isend_irecv, all pairs (one shard per link and direction)',
-                       'gather': 'gather(dst=0)'}[args.collective], 'payload': args.gather,
-                'zero_copy': zero_copy, 'copies_into_the_ring': comm.copies,
+                'policy': policy, 'requested': args.collective,
+                'calibration_ms_per_step': calibration, 'calibration_steps': args.calib_steps if calibration else None,
+                'notes': notes or None,
+                'op': {'allgather': 'all_gather_into_tensor (in place) on the RCCL stream, one submit per step',
+                       'ingraph': "all_gather_into_tensor (in place) captured into the step's HIP graph, parallel to the forward",
+                       'direct': 'batch_isend_irecv, all pairs (one shard per link and direction)',
+                       'gather': 'gather(dst=0)'}[policy], 'payload': args.gather,
+                'zero_copy': zero_copy, 'copies_into_the_ring': getattr(comm, 'copies', 0),
+                'probe_load': args.probe_load if world == 1 else None,
                 'ms_per_step_without': None if base_ms is None else round(base_ms, 4),
                 'overhead_pct': None if base_ms is None else round(100.0 * (1e3 * med / args.steps - base_ms) / base_ms, 2),
                 'bytes_sent_per_rank_per_step': comm.bytes_per_step,
-                'bytes_received_per_step': comm.bytes_per_step * world if (args.collective == 'allgather') else comm.bytes_per_step * world,
+                'bytes_received_per_rank_per_step': comm.bytes_per_step * (world - 1),
                 'completed': comm.completed},
         }
         if not args.no_extras:
@@ -606,40 +794,47 @@ def main():
             launches, dec_us, ev_overhead = instrumented_decoder(model, x, max(10, min(args.steps, 50)))
             alg_bytes, levels = decoder_levels(model, h, w, batch)
             out['roofline'] = roofline_of(launches, levels, h, w, batch, args.traffic_dir)
+            out['roofline']['traffic_source'] = traffic_note if traffic_note else \
+                ('--traffic-dir' if args.traffic_dir else 'none (--traffic off)')
             out['decoder'] = {'us_per_batch_eager': round(dec_us, 1), 'event_pair_overhead_us': round(ev_overhead, 2),
                               'algorithmic_bytes': alg_bytes,
                               'hbm_frac_of_8TBs': round(alg_bytes / (dec_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                               'launches': launches}
             if world == 1 and graph is not None:
-                # ---- the same step with the fused inverted-residual levels on the EXACT f32 matrix cores (hs_ir_math) ----
-                import hyperseg_amd.functional as HFm
-                prev_math = HFm.set_ir_math('f32')
-                try:
-                    for _ in range(3):
-                        y2 = forward(x)
-                    torch.cuda.synchronize()
-                    g2 = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g2):
-                        y2 = forward(x)
-                    for _ in range(args.warmup):
-                        g2.replay()
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    for _ in range(args.steps):
-                        g2.replay()
-                    torch.cuda.synchronize()
-                    el = time.perf_counter() - t0
-                    launches2, _, _ = instrumented_decoder(model, x, max(10, min(args.steps, 50)))
-                    dom2 = max([l for l in launches2 if l['in_decoder']], key=lambda l: l['avg_us'])
-                    out['exact_f32'] = {'value': round(args.steps * batch / el, 2), 'unit': 'frames/s',
-                                        'ms_per_step': round(1e3 * el / args.steps, 4), 'regions': 1,
-                                        'dominant_launch_us': dom2['avg_us'],
-                                        'max_abs_diff_vs_benched': float((y2 - y_bench).abs().max()) if args.output != 'masks' else None,
-                                        'note': 'HS_IR_MATH=f32: v_mfma_f32_16x16x4_f32 everywhere; the headline value uses '
-                                                'config.ir_math'}
-                    del g2
-                finally:
-                    HFm.set_ir_math(prev_math)
+                # ---- the same step under the other arithmetic of the fused inverted residual (hs_ir_math), and with IEEE-f32
+                # library GEMMs in the encoder: side numbers, one timed region each ------------------------------------------
+                headline = {'value': out['value'], 'unit': 'frames/s', 'ms_per_step': out['ms_per_step'], 'is_headline': True}
+                for key, mode, what in (('exact_f32', 'f32', 'hs_ir_math = f32: v_mfma_f32_16x16x4_f32 everywhere in the decoder'),
+                                        ('split_f16', 'auto', 'hs_ir_math = auto: level-4 products as 3-term f16 splits on '
+                                                              'v_mfma_f32_16x16x32_f16, f32 accumulation')):
+                    if HFm.get_ir_math(mode) == math_name:
+                        out[key] = dict(headline, note=what + ' -- this IS the headline configuration')
+                        continue
+                    prev_math = HFm.set_ir_math(mode)
+                    try:
+                        v, ms, y2, g2 = time_replayed(forward, x, args.steps, args.warmup, batch)
+                        launches2, _, _ = instrumented_decoder(model, x, max(10, min(args.steps, 50)))
+                        dom2 = max([l for l in launches2 if l['in_decoder']], key=lambda l: l['avg_us'])
+                        out[key] = {'value': v, 'unit': 'frames/s', 'ms_per_step': ms, 'regions': 1, 'is_headline': False,
+                                    'dominant_launch_us': dom2['avg_us'],
+                                    'max_abs_diff_vs_benched': float((y2 - y_bench).abs().max()) if args.output != 'masks' else None,
+                                    'note': what}
+                        del g2
+                    finally:
+                        HFm.set_ir_math(prev_math)
+                if stock_cpu is not None and args.split_gemm:
+                    try:
+                        prepare_for_inference(stock_cpu, fold_bn=False, fused_depthwise=True, split_gemm=False, ir_math='f32')
+                        lib = stock_cpu.to(dev)
+                        v, ms, y3, g3 = time_replayed(lib.segment if args.output == 'masks' else lib, x, args.steps, args.warmup, batch)
+                        out['library_gemm_f32'] = {'value': v, 'unit': 'frames/s', 'ms_per_step': ms, 'regions': 1,
+                                                   'max_abs_diff_vs_benched': float((y3.float() - y_bench.float()).abs().max()),
+                                                   'note': 'every product of the frame in IEEE f32: library f32 GEMMs for the 1x1 '
+                                                           'convolutions (--library-gemm) + hs_ir_math = f32'}
+                        del g3, lib
+                    except Exception as e:            # noqa: BLE001  (a side number must never cost the line)
+                        out['library_gemm_f32'] = {'error': f'{type(e).__name__}: {e}'[:300]}
+                        torch.cuda.synchronize()
             if world == 1 and graph is not None:
                 try:                                  # a side number must never cost the line
                     out['two_frames_in_flight'] = two_in_flight(forward, x, y_bench, args.steps, args.warmup, batch)
@@ -673,6 +868,12 @@ def main():
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if args.traffic_dir and traffic_note:
+        import shutil
+        shutil.rmtree(args.traffic_dir, ignore_errors=True)
+    os.dup2(json_fd, 1)                                  # a caller that imported main() gets its stdout back
+    os.close(json_fd)
+    return out
 
 
 if __name__ == '__main__':

@@ -206,15 +206,23 @@ def bn_act(bn, act_layer, x):
     act = 0 if act_layer is None else 1 if type(act_layer) is nn.ReLU else 2 if type(act_layer) is nn.ReLU6 else -1
     if (USE_HIP_BN and type(bn) is nn.BatchNorm2d and bn.training and bn.track_running_stats and bn.momentum is not None and act >= 0
             and x.is_cuda and x.dtype in DTYPE_CODES and x.dim() == 4 and bn.affine and bn.weight.dtype == torch.float32
-            and x.shape[0] * x.shape[2] * x.shape[3] > 1 and x.shape[0] * x.shape[2] * x.shape[3] < 2 ** 31):
+            and x.shape[0] * x.shape[2] * x.shape[3] > 1 and x.shape[0] * x.shape[2] * x.shape[3] < 2 ** 31
+            # raw data_ptrs of these go to the kernel: they must live on x's device (stock BN raises for a mismatch, and so does
+            # the stock route below)
+            and bn.weight.device == x.device and bn.bias.device == x.device
+            and bn.running_mean.device == x.device and bn.running_var.device == x.device):
         y = BNActTrain.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, act)
-        bn.num_batches_tracked.add_(1)
+        bn.num_batches_tracked.add_(1)      # after the launch succeeded (apply raises on a failed launch)
+        HF.bump_weights_epoch()               # running statistics changed through a raw pointer: no tensor version moved
         return y
+    if bn.training:
+        HF.bump_weights_epoch()               # stock BN's running-statistics update does not bump their versions either
     y = bn(x)
     return y if act_layer is None else act_layer(y)
 
 
 USE_HIP_BN = True       # tests switch it off to compare with the stock modules
+
 
 
 class BootstrapMean(torch.autograd.Function):

@@ -123,6 +123,7 @@ __device__ __forceinline__ float wave_sum64(float v) {
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == HS_ACT_RELU)  return fmaxf(v, 0.0f);
     if (act == HS_ACT_RELU6) return fminf(fmaxf(v, 0.0f), 6.0f);
+    if (act == HS_ACT_SWISH) return swishf(v);        // not used by any reference decoder (ReLU / ReLU6 only: SURVEY appendix D-5)
     return v;
 }
 

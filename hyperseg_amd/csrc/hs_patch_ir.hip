@@ -271,7 +271,7 @@ extern "C" int hs_patch_ir_route(const hs_stage_input* in, int32_t fh, int32_t f
                                  int32_t residual, int32_t math) {
     if (math < HS_IR_MATH_AUTO || math > HS_IR_MATH_SPLIT) return HS_ERR_BAD_ARG;
     hs_stage_input probe = *in;
-    static const float dummy = 0.0f;                             // make_stage only checks that the pointers exist
+    alignas(16) static const float dummy = 0.0f;                 // make_stage only checks that the pointers exist; 16-byte aligned like a real bank
     if (probe.c_skip > 0 && !probe.skip) probe.skip = &dummy;
     if (probe.c_prev > 0 && !probe.prev) probe.prev = &dummy;
     StageIn si;

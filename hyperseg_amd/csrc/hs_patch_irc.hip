@@ -684,7 +684,7 @@ int try_launch_irc(const StageIn& in, int fh, int fw, const float* bank, long ld
         const int bank_n = cin * hid + 9 * hid + hid * c_out;
         const int scratch = (a.ph % 16 == 0 ? IrcGeom<16>::H1_FLOATS * 4 + IrcGeom<16>::H2_HALFS * 2 : IrcGeom<8>::H1_FLOATS * 4 + IrcGeom<8>::H2_HALFS * 2);
         if (((bank_n * 4 + 1023) & ~1023) + (2 * HP + 32) * 4 > scratch) return 1;
-        if (ld * 4 < 16 || (ld & 3) != 0) return 1;             // the bank DMA moves 16-byte pieces of a 16-byte aligned row
+        if (ld * 4 < 16 || (ld & 3) != 0 || ((size_t)bank & 15) != 0) return 1;      // the bank DMA moves 16-byte pieces of 16-byte aligned rows (base included)
     }
     // region height: 16 rows (a workgroup of 4 fat waves per 16 x 16 region: the per-workgroup work -- splitting the patch's bank,
     // tile shuffles, index arithmetic -- is paid once per 256 pixels) whenever the patch allows, else 8

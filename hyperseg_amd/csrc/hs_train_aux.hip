@@ -162,7 +162,9 @@ void bm_sums_kernel(const float* __restrict__ v, int n, float thresh, const unsi
     const float t = __uint_as_float(ws[BM_STATE + 2]);
     float s_thr = 0.f, c_thr = 0.f, s_top = 0.f, c_eq = 0.f;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
-        const float x = fmaxf(v[e], 0.0f);
+        const float raw = v[e];
+        const float x = fmaxf(raw, 0.0f);
+        if (raw != raw) { s_thr += raw; s_top += raw; }     // fmaxf(NaN, 0) = 0 would hide a diverged step: a NaN loss makes BOTH branch sums NaN
         if (x > thresh) { s_thr += x; c_thr += 1.0f; }
         if (x > t) s_top += x;
         if (x == t) c_eq += 1.0f;

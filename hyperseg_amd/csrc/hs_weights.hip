@@ -340,6 +340,7 @@ static int launch_s2w_blocked(const float* signal, int batch, int c_signal, int 
                               const int* order, int n_layers, hipStream_t stream) {
     const int grid_sz = fh * fw, n_patches = batch * grid_sz;
     if ((grid_sz & 3) != 0 || n_patches < 4) return 1;
+    if (((size_t)signal & 15) != 0) return 1;            // 16-byte global_load_lds pieces: a view with an odd storage offset takes the direct kernel
     S2bArgs a;
     a.signal = signal; a.c_signal = c_signal; a.grid_sz = grid_sz; a.n_patches = n_patches; a.n_layers = n_layers;
     a.pb = (n_patches + S2B_PATCHES - 1) / S2B_PATCHES;
@@ -347,7 +348,7 @@ static int launch_s2w_blocked(const float* signal, int batch, int c_signal, int 
     int wgs = 0;
     for (int i = 0; i < n_layers; ++i) {
         const hs_s2w_layer& l = layers[order[i]];
-        if (!l.wsw_blk) return 1;
+        if (!l.wsw_blk || ((size_t)l.wsw_blk & 15) != 0) return 1;
         S2bLayer& d = a.layer[i];
         d.blk = l.wsw_blk; d.bank = l.bank; d.ld = (long)l.ld; d.signal_index = l.signal_index;
         d.cs_g = l.signal_channels / l.groups; d.rpg = l.wc / l.groups; d.rows = l.rows; d.groups = l.groups;

@@ -5,7 +5,13 @@ global frames r, r + world, ... (bs-1 streams) or a contiguous B/world slice of 
 The single collective is an RCCL ``all_gather_into_tensor`` of every rank's logits (BASELINE.json's north star; the
 reference's counterpart is nn.DataParallel's gather onto device 0, test_fps.py:155-156, available as ``mode='gather'``),
 issued asynchronously on a ring of three buffers so that RCCL (backend "nccl" on ROCm; "gloo" in the CPU tests) moves
-step i over xGMI while step i+1 is computed.
+step i over xGMI while step i+1 is computed.  Two ways to get that overlap:
+  * :class:`LogitsGatherer` -- the collective on RCCL's own stream, ordered against the compute stream with events
+    (``submit`` per step).  Works everywhere; on ROCm 7.2 an event hand-off between two HIP-graph replays costs a bubble
+    (measured at world 1: +14 % per step for an all-gather that moves nothing);
+  * :class:`InGraphAllGather` -- the collective CAPTURED into the step's HIP graph as a branch parallel to the forward
+    (replay i = forward(i) || all_gather(i - 1)): no host call and no cross-stream event between replays.
+bench.py times both at N > 1 in a short calibration and keeps the faster one (``--collective auto``).
 """
 import torch
 import torch.distributed as dist
@@ -44,11 +50,17 @@ class LogitsGatherer:
 
     ``submit(i, y)`` starts the collective of step i and returns ``(i-2, collected)`` -- the result of the collective
     issued two steps earlier, now complete -- or None during the first two steps.  The returned (world, *shape) tensor
-    lives in ring slot (i-2) % 3, which the NEXT submit (step i+1) re-targets: it is valid until then, and on the
-    nccl path the wait() inside submit orders the caller's stream after the transfer, so kernels enqueued before the
-    next submit may read it safely.  Ranks that own no result (gather mode, rank != dst) get ``collected = None``."""
+    lives in ring slot (i-2) % 3 = (i+1) % 3, i.e. THE SLOT STEP i+1 IS PRODUCED INTO.  Lifetime: with payloads copied in, it
+    is valid until ``submit(i+1)``; with zero-copy producers (``slot()``) the rank's OWN row is overwritten as soon as the
+    producer of step i+1 starts writing -- before ``submit(i+1)`` is called -- so a consumer must have read (or enqueued
+    its reads of) the collected tensor BEFORE launching the next forward.  On the nccl path the wait() inside submit
+    orders the caller's stream after the transfer, so kernels enqueued right after ``submit`` returns read it safely.
+    Ranks that own no result (gather mode, rank != dst) get ``collected = None``.
 
-    def __init__(self, world, shape, dtype, device, mode='allgather', dst=0):
+    ``probe_load``: N = 1 measurement aid only -- that many extra out-of-place all-gathers of the slot per step (at
+    world 1 each is one RCCL copy kernel of the payload), so that RCCL kernels actually run next to the forward."""
+
+    def __init__(self, world, shape, dtype, device, mode='allgather', dst=0, probe_load=0):
         if mode not in ('gather', 'allgather', 'direct'):
             raise ValueError(mode)
         self.world, self.mode, self.dst = world, mode, dst
@@ -68,6 +80,8 @@ class LogitsGatherer:
         self.step_of = [None] * RING
         self.completed = 0
         self.copies = 0                          # submits that had to copy their payload into the slot
+        self.scratch = [torch.empty((world * shape[0],) + tuple(shape[1:]), dtype=dtype, device=device)
+                        for _ in range(probe_load)] if mode == 'allgather' else []
 
     def slot(self, step):
         """Where the result of ``step`` should be produced to be sent without a copy."""
@@ -94,6 +108,7 @@ class LogitsGatherer:
         self.step_of[k] = step
         if self.mode == 'allgather':
             self.work[k] = [dist.all_gather_into_tensor(self.recv[k], self.send[k], async_op=True)]
+            self.work[k] += [dist.all_gather_into_tensor(t, self.send[k], async_op=True) for t in self.scratch]
         elif self.mode == 'direct':
             rows = self.recv[k].view((self.world,) + self.shape)
             ops = []
@@ -111,3 +126,61 @@ class LogitsGatherer:
         """Completes every outstanding collective; returns their (step, collected) pairs in step order."""
         live = sorted((k for k in range(RING) if self.work[k] is not None), key=lambda q: self.step_of[q])
         return [self._finish(k) for k in live]
+
+
+class InGraphAllGather:
+    """The per-step all-gather as a branch of the step's HIP graph, parallel to the forward.
+
+    One graph per ring slot k: ``fork -> [forward -> logits into slot k] || [all_gather_into_tensor(slot k-1), in place] -> join``.
+    Replay i therefore computes step i while RCCL moves step i-1's logits; both are nodes of ONE graph, so there is no host
+    call per collective and no event between two replays (what the stream form pays for).  After replay i the collected
+    result of step i-1 is in ``collected(i-1)``; ``drain(last)`` gathers the final step's logits eagerly.  The first replay
+    gathers a slot nobody produced yet (harmless).  ``capture_forward(out)`` must run the forward with its result written
+    to ``out`` (zero copy) and return that tensor.
+
+    Capturing an RCCL collective needs the communicator to be up: one eager collective is issued first.  If the capture
+    raises (a stack that cannot capture RCCL), the caller falls back to the stream form."""
+
+    def __init__(self, gatherer, capture_forward, probe_load=0):
+        import torch.cuda
+        g = self.g = gatherer
+        if g.mode != 'allgather':
+            raise ValueError("InGraphAllGather needs a LogitsGatherer(mode='allgather')")
+        dist.all_gather_into_tensor(g.recv[0], g.send[0])          # communicator + its streams exist before capture
+        torch.cuda.synchronize()
+        self.scratch = [torch.empty_like(g.recv[0]) for _ in range(probe_load)]
+        self.graphs = []
+        self.side = torch.cuda.Stream()
+        pool = None
+        for k in range(RING):
+            prev = (k - 1) % RING
+            gk = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gk, pool=pool):
+                cur = torch.cuda.current_stream()
+                self.side.wait_stream(cur)
+                with torch.cuda.stream(self.side):
+                    dist.all_gather_into_tensor(g.recv[prev], g.send[prev])
+                    for t in self.scratch:
+                        dist.all_gather_into_tensor(t, g.send[prev])
+                yk = capture_forward(g.send[k])
+                cur.wait_stream(self.side)
+            if yk.data_ptr() != g.send[k].data_ptr():
+                raise RuntimeError('capture_forward did not produce its result in the slot it was given')
+            pool = pool or gk.pool()
+            self.graphs.append((gk, yk))
+        self.bytes_per_step = g.bytes_per_step
+        self.completed = 0
+
+    def step(self, i):
+        gk, yk = self.graphs[i % RING]
+        gk.replay()
+        self.completed += 1
+        return yk
+
+    def collected(self, step):
+        """(world, *shape) result of ``step``; valid once the replay of step+1 (or ``drain``) has completed."""
+        return self.g.recv[step % RING].view((self.g.world,) + self.g.shape)
+
+    def drain(self, last_step):
+        if last_step is not None:
+            dist.all_gather_into_tensor(self.g.recv[last_step % RING], self.g.send[last_step % RING])

@@ -211,11 +211,11 @@ def s2w_packed(wsw_t, signal_channels, groups):
     """The transposed signal2weights weight re-laid for ``hs_signal2weights_multi_fwd``'s blocked form (hs_s2w_pack_fwd), built
     once per parameter version (the transposed tensor itself is cached per module by version, so its address is the key)."""
     import weakref
-    key = (wsw_t.data_ptr(), wsw_t._version, tuple(wsw_t.shape), signal_channels, groups, wsw_t.device)
+    key = (_WEIGHTS_EPOCH[0], wsw_t.data_ptr(), wsw_t._version, tuple(wsw_t.shape), signal_channels, groups, wsw_t.device)
     ent = _S2W_BLK.get(key)
     hit = ent[1] if ent is not None and ent[0]() is wsw_t else None       # the address alone could be a dead tensor's, reused
     if hit is None:
-        for k in [k for k, (r, _) in _S2W_BLK.items() if r() is None]:      # sources that died take their images with them
+        for k in [k for k, (r, _) in _S2W_BLK.items() if r() is None or k[0] != _WEIGHTS_EPOCH[0]]:      # dead sources and earlier weight epochs take their images with them
             del _S2W_BLK[k]
         n = _hip.lib.hs_s2w_pack_floats(signal_channels, groups, wsw_t.shape[1])
         if n < 0:
@@ -764,8 +764,21 @@ def upsample_argmax(x, size):
 # small caches keyed on parameter versions (host-side only; used by the fused inference route --
 # tensors that require grad take the hyperseg_amd.autograd route, which folds nothing)
 # ------------------------------------------------------------------------------------------
+_WEIGHTS_EPOCH = [0]
+
+
+def bump_weights_epoch():
+    """Invalidates every host-side cache derived from parameters or BatchNorm statistics (folded BN affines, transposed /
+    packed signal2weights weights, the prepared encoder's folded and split weights).  The caches are keyed on
+    (address, tensor._version, shape) -- but a HIP-graph replay of a training step, this package's raw-pointer BatchNorm
+    kernels and stock BatchNorm's running-statistics update all change values WITHOUT bumping ``_version``.
+    Called by ``training.GraphedTrainStep.step``, by ``autograd.bn_act`` and by every train() / eval() switch of the
+    package's modules, so a validation pass after any number of training steps re-derives everything once."""
+    _WEIGHTS_EPOCH[0] += 1
+
+
 def _key(*tensors):
-    return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
+    return (_WEIGHTS_EPOCH[0],) + tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
 
 
 class FoldedBN:

@@ -58,7 +58,17 @@ def register_coordinate_buffers(module, coords_res, levels):
             module.register_buffer(f'coord{h}_{w}', coordinate_grid(h, w))
 
 
-class HyperGenBase(nn.Module):
+class EpochOnModeSwitch:
+    """Mixin (before nn.Module in the bases): every train() / eval() switch invalidates the parameter-derived caches of the
+    inference route (functional.bump_weights_epoch) -- training steps change parameters and BatchNorm statistics through
+    paths that do not bump tensor versions (graph replays, raw-pointer kernels)."""
+
+    def train(self, mode=True):
+        HF.bump_weights_epoch()
+        return super().train(mode)
+
+
+class HyperGenBase(EpochOnModeSwitch, nn.Module):
     """backbone -> context head -> dynamic decoder, with the reference's list-input (image pyramid) and horizontal-flip
     inference modes (hyperseg_v1_0.py:52-91).  Subclasses create ``backbone``, ``decoder`` and ``weight_mapper``."""
 

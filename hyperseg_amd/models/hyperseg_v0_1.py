@@ -17,7 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import functional as HF
-from ._common import HyperGenBase, coordinate_grid, per_level
+from ._common import EpochOnModeSwitch, HyperGenBase, coordinate_grid, per_level
 from .layers.meta_patch import MetaPatchConv2d, make_meta_patch_conv2d_block
 from .layers.meta_sequential import MetaSequential
 
@@ -31,7 +31,7 @@ def get_image_coordinates(b, h, w, device):
     return coordinate_grid(h, w, device).repeat(b, 1, 1, 1)
 
 
-class HyperPatchInvertedResidual(nn.Module):
+class HyperPatchInvertedResidual(EpochOnModeSwitch, nn.Module):
     """pw1 (+BN+ReLU6) -> depthwise kxk reflect (+BN+ReLU6) -> pw-linear (+BN), each a patch-wise dynamic conv on the
     whole image, weights taken from consecutive channel ranges by the MetaSequential (hyperseg_v0_1.py:205-237)."""
 
@@ -104,7 +104,7 @@ class HyperPatchInvertedResidual(nn.Module):
         return self.conv(x, w)
 
 
-class MultiScaleDecoder(nn.Module):
+class MultiScaleDecoder(EpochOnModeSwitch, nn.Module):
     """hyperseg_v0_1.py:91-202.  ``forward(x, w)``: x fine -> coarse incl. the image, w = list of per-level weights."""
 
     def __init__(self, feat_channels, in_nc=3, num_classes=3, kernel_sizes=3, level_layers=1, norm_layer=nn.BatchNorm2d,

@@ -28,7 +28,7 @@ from torch.nn.modules.utils import _pair
 
 from .. import functional as HF
 from .. import autograd as HA
-from ._common import HyperGenBase, coordinate_grid, per_level, plan_levels, register_coordinate_buffers
+from ._common import EpochOnModeSwitch, HyperGenBase, coordinate_grid, per_level, plan_levels, register_coordinate_buffers
 from .layers.meta_conv import MetaConv2d, _apply_epilogue, _require_inference, assemble_block, check_padding_mode
 from .layers.meta_sequential import MetaSequential
 
@@ -110,7 +110,7 @@ class _SignalToWeights:
         return bank[:, :hp].reshape(b, fh, fw, hp).permute(0, 3, 1, 2)
 
 
-class HyperPatchNoPadding(nn.Module, _SignalToWeights):
+class HyperPatchNoPadding(EpochOnModeSwitch, nn.Module, _SignalToWeights):
     """k=1 dynamic patch-wise conv fed by the signal (hyperseg_v1_0.py:455-498) -> Op A."""
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, dilation=1, groups=1):
@@ -153,7 +153,7 @@ class HyperPatchNoPadding(nn.Module, _SignalToWeights):
         return self.forward_fused(x, s)
 
 
-class HyperPatch(nn.Module, _SignalToWeights):
+class HyperPatch(EpochOnModeSwitch, nn.Module, _SignalToWeights):
     """Dynamic patch-wise block with image-level padding fed by the signal (hyperseg_v1_0.py:501-557)."""
 
     def __init__(self, module: nn.Module, padding=0, padding_mode='reflect'):
@@ -219,7 +219,7 @@ class HyperPatchConv2d(HyperPatch):
         return self.hyper_module.groups
 
 
-class HyperPatchInvertedResidual(nn.Module, _SignalToWeights):
+class HyperPatchInvertedResidual(EpochOnModeSwitch, nn.Module, _SignalToWeights):
     """Per-patch MobileNetV2 block on a reflect halo tile (hyperseg_v1_0.py:281-376) -> Op C, one launch."""
 
     def __init__(self, in_nc, out_nc, kernel_size=3, stride=1, expand_ratio=1, norm_layer=nn.BatchNorm2d,
@@ -395,7 +395,7 @@ def divide_feature(in_feature, out_features, min_unit=8):
     return out
 
 
-class MultiScaleDecoder(nn.Module):
+class MultiScaleDecoder(EpochOnModeSwitch, nn.Module):
     """Dynamic multi-scale decoder (hyperseg_v1_0.py:94-253).  ``forward(x, s)``: x = list of feature
     maps fine -> coarse including the input image, s = signal (B, Cs, H/32, W/32)."""
 

@@ -17,14 +17,14 @@ from .. import autograd as HA
 from .. import functional as HF
 import numpy as np
 
-from ._common import HyperGenBase, coordinate_grid, per_level, plan_levels, register_coordinate_buffers
+from ._common import EpochOnModeSwitch, HyperGenBase, coordinate_grid, per_level, plan_levels, register_coordinate_buffers
 from .hyperseg_v1_0 import (HyperPatch, HyperPatchConv2d, HyperPatchInvertedResidual, HyperPatchNoPadding,  # noqa: F401
                             WeightMapper, _SignalToWeights, divide_feature, make_hyper_patch_conv2d_block,
                             next_multiply)
 from .layers.meta_sequential import MetaSequential
 
 
-class WeightLayer(nn.Module, _SignalToWeights):
+class WeightLayer(EpochOnModeSwitch, nn.Module, _SignalToWeights):
     """signal -> weights of one level (or of all unified levels): hyperseg_v1_0_unify.py:287-309."""
 
     def __init__(self, target_params):
@@ -69,7 +69,7 @@ def init_signal2weights(model, signal_features, signal_index=0, weight_groups=1)
             init_signal2weights(m, signal_features, signal_index, weight_groups)
 
 
-class MultiScaleDecoder(nn.Module):
+class MultiScaleDecoder(EpochOnModeSwitch, nn.Module):
     """hyperseg_v1_0_unify.py:96-259."""
 
     def __init__(self, feat_channels, signal_channels, num_classes=3, kernel_sizes=3, level_layers=1,

@@ -33,6 +33,10 @@ class MetaSequential(nn.Sequential):
         self.hyper_params = self._ranges[-1]
         self._folded = {}
 
+    def train(self, mode=True):
+        HF.bump_weights_epoch()             # a mode switch: parameters / BN statistics may have moved without a version bump
+        return super().train(mode)
+
     def _fold(self, idx, bn):
         cache = self._folded.get(idx)
         if cache is None:

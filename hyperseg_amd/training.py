@@ -173,4 +173,8 @@ class GraphedTrainStep:
                 if dst is not src:
                     dst.copy_(src, non_blocking=True)
         self.graph.replay()
+        # the replay moved every parameter and BatchNorm buffer WITHOUT bumping a tensor version: the eval-route caches keyed on
+        # versions (folded BN, transposed / packed signal2weights weights, split GEMM weights) must not survive it
+        from .functional import bump_weights_epoch
+        bump_weights_epoch()
         return self.loss, self.pred

@@ -12,7 +12,7 @@ from functools import partial
 
 import torch
 
-from .obj_factory import _split, obj_factory
+from .obj_factory import _split, obj_factory, reference_name
 
 
 def remove_data_parallel_from_state_dict(state_dict):
@@ -36,7 +36,11 @@ def get_arch(obj, *args, eval_partial=True, **kwargs):
     """The ``arch`` string of an object given as an expression string or a ``functools.partial``, with extra
     (keyword) arguments appended: ``'pkg.mod.fn(arg,...,key=value,...)'`` without spaces -- what train.py stores in
     every checkpoint and ``obj_factory`` turns back into the object (utils.py:96-144).  Nested partials are rendered as
-    ``functools.partial('pkg.mod.fn',...)`` like the reference does; anything else returns None."""
+    ``functools.partial('pkg.mod.fn',...)`` like the reference does; anything else returns None.  Partials of this
+    package's functions are written under the REFERENCE's module names (``hyperseg.models...``), so the strings equal the
+    reference's for the same config (tests/golden/checkpoint_ref.npz, made by the reference's own get_arch).  String
+    inputs: the reference raises for them (utils.py:116 evals a name it never imports; utils.py:126 adds a tuple to a
+    list) although train.py's ``model`` argument may be a string -- here they work as the docstring there promises."""
     if isinstance(obj, str):
         if '(' in obj and ')' in obj:
             _, own_args, own_kwargs = _split(obj)
@@ -44,7 +48,7 @@ def get_arch(obj, *args, eval_partial=True, **kwargs):
         else:
             func, own_args, own_kwargs = obj, (), {}
     elif isinstance(obj, partial):
-        func = f'{obj.func.__module__}.{obj.func.__name__}'
+        func = reference_name(obj.func.__module__, obj.func.__name__)       # always the reference's namespace
         own_args, own_kwargs = obj.args, obj.keywords
     else:
         return None
@@ -55,6 +59,21 @@ def get_arch(obj, *args, eval_partial=True, **kwargs):
         func = 'functools.partial'
     parts = [repr(o) for o in pos] + [f'{k}={v!r}' for k, v in named.items()]
     return f"{func}({','.join(parts)})".replace(' ', '')
+
+
+def _build_without_download(arch):
+    """``obj_factory(arch)`` with ``pretrained`` forced off.  train.py stores the config's partial verbatim, so every
+    released checkpoint says ``pretrained=True``; the reference then downloads the ImageNet backbone and overwrites it
+    with the checkpoint's state dict one line later (utils.py:174-177).  The state dict supplies every weight, so the
+    download is skipped (there may be no network)."""
+    if not isinstance(arch, str) or '(' not in arch:
+        return obj_factory(arch)
+    fn, args, kwargs = _split(arch)
+    if 'pretrained' in kwargs:
+        kwargs['pretrained'] = False
+    elif len(args) >= 2 and isinstance(args[1], bool) and getattr(fn, '__name__', '').endswith('efficientnet'):
+        args = (args[0], False) + tuple(args[2:])
+    return fn(*args, **kwargs)
 
 
 def load_model(model_path, name='', device=None, arch=None, return_checkpoint=False, train=False, trusted=False):
@@ -71,7 +90,7 @@ def load_model(model_path, name='', device=None, arch=None, return_checkpoint=Fa
     if arch is None and 'arch' not in checkpoint:
         raise AssertionError(f"Couldn't determine {name} model architecture!")
     arch = checkpoint['arch'] if arch is None else arch
-    model = obj_factory(arch)
+    model = _build_without_download(arch)
     if device is not None:
         model.to(device)
     model.load_state_dict(remove_data_parallel_from_state_dict(checkpoint['state_dict']))

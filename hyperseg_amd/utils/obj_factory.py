@@ -16,10 +16,24 @@ KNOWN_MODULES = {
     'hyperseg.models.layers.meta_patch': 'hyperseg_amd.models.layers.meta_patch',
     'hyperseg.models.layers.meta_sequential': 'hyperseg_amd.models.layers.meta_sequential',
     'hyperseg.models.backbones.efficientnet': 'hyperseg_amd.models.backbones.efficientnet',
+    'hyperseg.utils.polylr': 'hyperseg_amd.training',
+    'hyperseg.losses.bootstrapped_ce_loss': 'hyperseg_amd.training',
     'nn': 'torch.nn',
     'optim': 'torch.optim',
     'lr_scheduler': 'torch.optim.lr_scheduler',
 }
+
+
+# our module (, attribute) -> the reference's module: arch strings are always WRITTEN in the reference's namespace, so a
+# checkpoint saved here loads in the reference and vice versa (get_arch in utils/checkpoint.py)
+REFERENCE_MODULES = {v: k for k, v in KNOWN_MODULES.items() if k.startswith('hyperseg.') and v != 'hyperseg_amd.training'}
+REFERENCE_ATTRS = {('hyperseg_amd.training', 'PolyLR'): 'hyperseg.utils.polylr',
+                   ('hyperseg_amd.training', 'BootstrappedCrossEntropyLoss'): 'hyperseg.losses.bootstrapped_ce_loss'}
+
+
+def reference_name(module_name, attr):
+    """'hyperseg_amd.models.hyperseg_v1_0', 'hyperseg_efficientnet' -> 'hyperseg.models.hyperseg_v1_0.hyperseg_efficientnet'."""
+    return f"{REFERENCE_ATTRS.get((module_name, attr), REFERENCE_MODULES.get(module_name, module_name))}.{attr}"
 
 
 def _collect(*args, **kwargs):

@@ -42,7 +42,9 @@ typedef enum {
     HS_ERR_LDS = -4            /* tile does not fit the 160 KiB LDS */
 } hs_status;
 
-typedef enum { HS_ACT_NONE = 0, HS_ACT_RELU = 1, HS_ACT_RELU6 = 2 } hs_act;
+/* Epilogue activation.  The reference's decoder uses ReLU / ReLU6 only (hyperseg_v1_0.py:115, 283, 729); SWISH (x * sigmoid(x),
+ * efficientnet_utils.py:58-79) is what the encoder-side entry points take, and the patch-convolution epilogues accept it too. */
+typedef enum { HS_ACT_NONE = 0, HS_ACT_RELU = 1, HS_ACT_RELU6 = 2, HS_ACT_SWISH = 3 } hs_act;
 typedef enum { HS_PAD_ZEROS = 0, HS_PAD_REFLECT = 1, HS_PAD_REPLICATE = 2, HS_PAD_CIRCULAR = 3 } hs_pad_mode;
 typedef enum { HS_PREV_NONE = 0, HS_PREV_SAME = 1, HS_PREV_BILINEAR = 2 } hs_prev_mode;
 
@@ -260,7 +262,7 @@ int hs_patch_conv_plain_bwd_w(int32_t dtype, const void* x, const void* dy, int3
 
 /* Encoder-side helper ("next" row of SURVEY.md section 8f; opt-in via hyperseg_amd.utils.inference): depthwise k x k
  * convolution (k in {3,5}, stride in {1,2}) with arbitrary top/left zero padding (TF-"SAME"), + per-channel affine
- * (folded BatchNorm) + activation (hs_act, or 3 = swish) in one launch.  x (B,C,H,W), w (C,1,k,k) -> y (B,C,Ho,Wo).
+ * (folded BatchNorm) + activation (hs_act) in one launch.  x (B,C,H,W), w (C,1,k,k) -> y (B,C,Ho,Wo).
  * Replaces F.pad + F.conv2d(groups=C) + BatchNorm2d + swish of the reference's MBConvBlock
  * (hyperseg/models/backbones/efficientnet.py:59-66, 101-103). */
 int hs_depthwise_conv_fwd(const float* x, int32_t batch, int32_t channels, int32_t H, int32_t W,
@@ -305,7 +307,7 @@ int hs_mbconv_expand_dw_fwd(const float* x, int32_t batch, int32_t c_in, int32_t
 
 /* Encoder-side helper: 1x1 convolution as an fp32 MFMA GEMM with its surroundings fused,
  *   y[b,o,p] = act(scale[o] * sum_c w[o,c] * (gate[b,c] * x[b,c,p]) + shift[o]) + residual[b,o,p]
- * (gate, scale/shift, residual optional; act = hs_act or 3 = swish).  x (B,Cin,P), w (Cout,Cin), y (B,Cout,P), P = H*W.
+ * (gate, scale/shift, residual optional; act = hs_act).  x (B,Cin,P), w (Cout,Cin), y (B,Cout,P), P = H*W.
  * Replaces {SE multiply, 1x1 conv, BatchNorm2d, swish, skip add} of an MBConv block (efficientnet.py:101-103, 110-124). */
 int hs_pointwise_conv_fwd(const float* x, int32_t batch, int32_t c_in, int32_t pixels, const float* w, int32_t c_out,
                           const float* gate, const float* scale, const float* shift, int32_t act, const float* residual,
@@ -320,7 +322,7 @@ int hs_affine_act_fwd(const float* x, int32_t batch, int32_t channels, int32_t p
  * f16 matrix cores with split operands, f32 storage and accumulation,
  *   y[b,o,p] = act(sum_c w[o,c] * gate[b,c] * x[b,c,p] + shift[o]) + residual[b,o,p]
  * x (B,Cin,P), y (B,Cout,P); gate (B,Cin), shift (Cout), residual (B,Cout,P) optional, residual may be y itself (in-place
- * accumulation onto a skip tensor); act = hs_act or 3 = swish.
+ * accumulation onto a skip tensor); act = hs_act.
  * w_frag / w_inv: the STATIC weight split once on the host into two f16 pieces of every row scaled by a power of two to
  * < 2^15, in MFMA-fragment order [ceil(Cout/16)][kp/32][piece][64 lanes][8] (lane = row % 16 + 16 * kgroup holds
  * w[16 R + row % 16][32 S + 8 kgroup + j]), and the inverse row scales padded to a multiple of 16 rows

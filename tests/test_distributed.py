@@ -147,6 +147,158 @@ def test_shard_batch():
         shard_batch(32, 0, 5)
 
 
+def _load_bench():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_under_test', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def test_bench_workload_plan_and_device_selection():
+    """What the driver's N = 1, 2, 4, 8 launches make every rank do: --model l shards BASELINE config 4's bs-32 batch into
+    32 / N contiguous frames per rank (strong scaling, the shards tile [0, 32)), m / s / sc keep bs 1 per rank (weak);
+    LOCAL_RANK r -> cuda:r, refusing two ranks per GPU and a GPU-less box."""
+    bench = _load_bench()
+    for world in (1, 2, 4, 8):
+        plans = [bench.plan_workload('l', r, world) for r in range(world)]
+        assert all(p['batch'] == 32 // world and p['global_batch'] == 32 and p['scaling'] == 'strong' for p in plans)
+        assert [p['frames'] for p in plans] == [(r * 32 // world, (r + 1) * 32 // world) for r in range(world)]
+        assert (plans[0]['h'], plans[0]['w'], plans[0]['spec']['num_classes']) == (512, 512, 21)
+        for key, size in (('m', (512, 1024)), ('s', (768, 1536)), ('sc', (576, 768))):
+            p = bench.plan_workload(key, world - 1, world)
+            assert (p['batch'], p['global_batch'], p['scaling'], (p['h'], p['w'])) == (1, world, 'weak', size)
+    with pytest.raises(ValueError):
+        bench.plan_workload('l', 0, 3)
+    assert [bench.select_device(r, visible=8) for r in range(8)] == [torch.device('cuda', r) for r in range(8)]
+    for bad in (dict(local_rank=8, visible=8), dict(local_rank=1, visible=1), dict(local_rank=0, visible=0)):
+        with pytest.raises(SystemExit):
+            bench.select_device(bad['local_rank'], visible=bad['visible'])
+    assert bench.select_device(5, stub=True) == torch.device('cpu')
+
+
+@pytest.mark.parametrize('model,extra', [('m', []), ('l', []), ('m', ['--collective', 'direct']), ('m', ['--gather', 'masks'])])
+def test_bench_main_under_torch_distributed_run(model, extra):
+    """bench.py's main() ITSELF, launched exactly as the driver launches it (python -m torch.distributed.run --nproc-per-node 2
+    ... bench.py --gpus 2 --steps K --warmup W), with the model stubbed out (HS_BENCH_STUB=1: gloo, CPU): rank / world from
+    the environment, the shard plan, the policy calibration of --collective auto, the timed regions with their barriers, the
+    all-gather of the per-rank rates, and ONE JSON line on stdout (RCCL / gloo chatter goes to stderr) carrying the
+    contract's keys."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HS_BENCH_STUB='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '3',
+           '--repeats', '2', '--calib-steps', '4', '--model', model] + extra
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, timeout=240)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config'):
+        assert k in d, k
+    assert d['n_gpus'] == 2 and d['steps'] == 6 and d['warmup'] == 3 and d['unit'] == 'frames/s' and d['higher_is_better'] is True
+    assert d['scaling'] == ('strong' if model == 'l' else 'weak') and len(d['per_rank_frames_per_s']) == 2
+    per_step = 32 if model == 'l' else 2                       # global frames per step
+    assert abs(d['value'] - per_step / (d['ms_per_step'] * 1e-3)) < 0.01 * d['value']
+    assert abs(sum(d['per_rank_frames_per_s']) - d['value']) < 0.01 * d['value']
+    c = d['collective']
+    want_policy = 'direct' if 'direct' in extra else 'allgather'      # auto on CPU: the in-graph form needs HIP graphs
+    assert c['policy'] == want_policy and c['payload'] == ('masks' if 'masks' in extra else 'logits')
+    assert c['completed'] >= 6 * 2 + 3
+    if not extra:
+        assert c['requested'] == 'auto' and c['calibration_ms_per_step']['allgather'] > 0
+    classes, (h, w) = (21, (512, 512)) if model == 'l' else (19, (512, 1024))
+    frames = 16 if model == 'l' else 1
+    elems = frames * (h // 16) * (w // 16) * (1 if 'masks' in extra else classes * 4)
+    assert c['bytes_sent_per_rank_per_step'] == elems
+
+
+def _zero_copy_lifetime_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        shape = (1, 2, 3)
+        g = LogitsGatherer(world, shape, torch.float32, torch.device('cpu'), mode='allgather')
+        ok = True
+        for i in range(6):
+            g.slot(i).fill_(float(10 * i + rank))
+            done = g.submit(i, g.slot(i))
+            if done is None:
+                continue
+            step, out = done
+            want = torch.tensor([float(10 * step + r) for r in range(world)]).view(world, 1, 1, 1).expand(world, *shape)
+            ok &= bool(torch.equal(out, want))                                     # read BEFORE the next forward: intact
+            # the producer of step i+1 now writes its slot -- which is this rank's own row of the tensor just returned
+            g.slot(i + 1).fill_(-1.0)
+            ok &= bool((out[rank] == -1.0).all())                                  # own row: gone (documented lifetime)
+            others = [r for r in range(world) if r != rank]
+            ok &= bool(torch.equal(out[others], want[others]))                     # the peers' rows stay until submit(i+1)
+        g.drain()
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_zero_copy_slot_lifetime_gloo():
+    """with zero-copy slots the tensor ``submit(i)`` returns (step i-2) shares its own-rank row with the slot
+    step i+1 is produced into.  The documented contract -- consume it before launching the next forward -- is what this
+    pins: intact right after submit, own row replaced once the next producer has written, peers' rows untouched."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_zero_copy_lifetime_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=90) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]
+
+
+@pytest.mark.gpu
+def test_in_graph_all_gather_single_gpu():
+    """InGraphAllGather on the RCCL path (world 1): the all-gather captured into the step's HIP graph as a branch parallel
+    to the forward.  Replay i must leave step i's result in its slot and step i-1's collected; drain() collects the last."""
+    if not torch.cuda.is_available():
+        pytest.fail('needs the MI355X')
+    from hyperseg_amd.distributed import InGraphAllGather
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    try:
+        shape = (1, 19, 64, 128)
+        g = LogitsGatherer(1, shape, torch.float32, dev, mode='allgather')
+        counter = torch.zeros((), device=dev)
+
+        def capture_forward(out):                       # "forward": a counter kernel + the result written into the slot
+            counter.add_(1.0)
+            out.copy_(counter.expand(shape))
+            return out
+        ing = InGraphAllGather(g, capture_forward, probe_load=2)
+        counter.zero_()
+        for i in range(7):
+            y = ing.step(i)
+            torch.cuda.synchronize()
+            assert float(y.mean()) == float(i + 1)
+            if i >= 1:
+                assert float(ing.collected(i - 1).mean()) == float(i)
+                assert all(float(t.mean()) == float(i) for t in ing.scratch)       # the probe's out-of-place copies ran too
+        ing.drain(6)
+        torch.cuda.synchronize()
+        assert float(ing.collected(6).mean()) == 7.0 and ing.completed == 7
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.gpu
 def test_gatherer_on_the_rccl_path_single_gpu():
     """The nccl (= RCCL) code path of LogitsGatherer on the one GPU a test box has (world size 1): asynchronous

@@ -596,6 +596,24 @@ def test_op_c_generic_shapes_on_the_matrix_cores(HF, O, dev, shape):
     cmp(y32, ref, what=f'Op C generic {shape} (f32)')
 
 
+def test_misaligned_bank_takes_the_direct_kernels(HF, O, dev):
+    """the split kernel's LDS-DMA moves 16-byte pieces of the bank; a bank VIEW whose storage offset is not a
+    multiple of 16 bytes (rows still contiguous, ld % 4 == 0) must fall back to the exact kernels -- same numbers -- instead
+    of issuing misaligned 16-byte requests."""
+    cin_parts, cout, hid, patch, grid = ((6, 16), 16, 48, (16, 16), (3, 3))
+    skip, prev, wt, bns, ref = _op_c_case(O, cin_parts, cout, hid, patch, grid, seed=29)
+    stage = HF.StageInput(skip.to(dev), prev.to(dev), coords=True)
+    aligned = HF.bank_pack(wt.to(dev), 0, wt.shape[1])
+    buf = torch.empty(aligned.numel() + 4, device=dev)
+    for off in (1, 2, 3):
+        bank = buf[off:off + aligned.numel()].view_as(aligned)
+        bank.copy_(aligned)
+        assert bank.data_ptr() % 16 == 4 * off
+        bnf = [tuple(t.to(dev) for t in _fold(bb)) for bb in bns]
+        y = HF.patch_ir(stage, grid, bank, hid, cout, *bnf, math='split')
+        cmp(y, ref, what=f'Op C, bank offset {4 * off} bytes (split requested)')
+
+
 def test_split_and_exact_modes_agree_on_flips(HF, O, dev):
     """HyperSeg-M at 1024x512: the two arithmetic modes give the same mask except where the oracle's own top-2 margin is
     below MARGIN, and logits within REL_TOL of each other."""

@@ -316,6 +316,80 @@ def test_graphed_train_step_equals_eager(dev):
             assert torch.equal(sd1[k].cpu(), sd0[k].cpu()), k                # num_batches_tracked: 5 on both sides
 
 
+def test_validation_after_graph_replays_sees_the_trained_weights(dev):
+    """GraphedTrainStep.step updates parameters and BatchNorm buffers only through graph.replay(), which never
+    bumps a tensor ``_version`` -- the eval-route caches keyed on versions (folded BN affines, transposed + packed signal2weights
+    weights) used to survive it, so the SECOND validation of a train/validate loop ran with stale weights.  Loop:
+    eval -> 3 replays -> eval -> 3 replays -> eval; every validation output must equal a freshly built twin's that loads the
+    trained state dict (no caches), and must differ from the previous validation (the steps did move the weights)."""
+    from oracle import hyperseg_oracle as O
+    from test_hip_parity import build_decoder
+    from hyperseg_amd.training import BootstrappedCrossEntropyLoss, GraphedTrainStep
+    d = build_decoder('Sc', O).to(dev)
+    x, s = O.synth_decoder_inputs('Sc', batch=2, seed=3, size=(96, 96))
+    x = [t.to(dev) for t in x]
+    s = s.to(dev)
+    target = torch.randint(0, 12, (2, 96, 96), device=dev)
+    crit = BootstrappedCrossEntropyLoss(k=512, thresh=0.3, ignore_index=255)
+    opt = torch.optim.Adam(d.parameters(), lr=torch.tensor(1e-2, device=dev), betas=(0.5, 0.999), capturable=True)
+
+    def validate():
+        d.eval()
+        with torch.no_grad():
+            y = d(x, s).clone()
+        twin = build_decoder('Sc', O).to(dev)
+        twin.load_state_dict(d.state_dict())
+        twin.eval()
+        with torch.no_grad():
+            yt = twin(x, s)
+        assert rel_err(y.cpu(), yt.cpu()) < 1e-6
+        return y
+    y0 = validate()                                       # fills every eval-route cache
+    d.train()
+    gs = GraphedTrainStep(d, crit, opt, (x, s), target, warmup=2)
+    outs = [y0]
+    for _ in range(2):
+        d.train()
+        for _ in range(3):
+            gs.step()
+        outs.append(validate())
+        assert rel_err(outs[-1].cpu(), outs[-2].cpu()) > 1e-3
+    # and WITHOUT a mode switch in between (a caller that leaves the modules in eval mode while replaying a captured train step is
+    # unusual but legal for the caches: step() itself invalidates them)
+    d.eval()
+    with torch.no_grad():
+        before = d(x, s).clone()
+    import hyperseg_amd.functional as HF
+    epoch = HF._WEIGHTS_EPOCH[0]
+    gs.step()
+    assert HF._WEIGHTS_EPOCH[0] > epoch
+
+
+def test_bootstrap_mean_propagates_nan(dev):
+    """the kernels clamp losses with fmaxf(v, 0) and fmaxf(NaN, 0) = 0 -- a diverged step used to report a finite loss.
+    Both branches of the rule must return NaN when any per-pixel loss is NaN, like the reference's sort / mean do."""
+    from hyperseg_amd.autograd import BootstrapMean
+    g = torch.Generator().manual_seed(5)
+    v = (torch.rand(4096, generator=g) * 3).to(dev)
+    for thresh in (0.3, 5.0):
+        assert bool(torch.isfinite(BootstrapMean.apply(v, 512, thresh)))
+        bad = v.clone()
+        bad[1234] = float('nan')
+        assert bool(torch.isnan(BootstrapMean.apply(bad, 512, thresh)))
+
+
+def test_bn_act_refuses_foreign_parameters(dev):
+    """bn_act hands raw parameter pointers to the kernel -- a BatchNorm whose parameters live on the CPU, fed CUDA
+    activations, must take the stock route and raise what stock BatchNorm raises, not dereference host pointers."""
+    import torch.nn as nn
+    from hyperseg_amd.autograd import bn_act
+    bn = nn.BatchNorm2d(8).train()                        # parameters on the CPU
+    x = torch.randn(2, 8, 6, 6, device=dev)
+    with pytest.raises(RuntimeError):
+        bn_act(bn, nn.ReLU6(), x)
+    assert int(bn.num_batches_tracked) == 0
+
+
 def test_two_optimizer_steps_vs_reference(golden, dev):
     """hyperseg_amd.training.train_step x 2 on the HIP decoder == the reference's loop (train.py:118-136) run with the
     reference's BootstrappedCrossEntropyLoss / Adam(betas=(0.5, 0.999)) / PolyLR on the reference decoder
