@@ -516,10 +516,11 @@ def main(argv=None):
                          'round 3: parity-green inside the model and 8 %% faster, profiles/round3_first_visit.txt)')
     ap.add_argument('--split-gemm', dest='split_gemm', action='store_true', help='(default) 1x1 convolutions through hs_gemm_split_fwd')
     ap.set_defaults(split_gemm=True)
-    ap.add_argument('--ir-math', choices=['auto', 'f32', 'split'], default='f32',
-                    help='arithmetic of the fused inverted-residual decoder levels (include/hyperseg_hip.h hs_ir_math).  Default f32: '
-                         'every product of the decoder (the hot path) on the exact-f32 matrix cores -- what `value` and `dtype` state; '
-                         'the `split_f16` object re-times the step with auto (f16 split products on the level-4 block)')
+    ap.add_argument('--ir-math', choices=['auto', 'f32', 'split'], default='auto',
+                    help='arithmetic of the fused inverted-residual decoder levels (include/hyperseg_hip.h hs_ir_math).  Default auto '
+                         '(what serving runs): the level-4 block multiplies 3-term f16 splits of its f32 operands on the f16 matrix cores '
+                         'with f32 accumulation -- `dtype` says so in words; the `exact_f32` object re-times the step with every decoder '
+                         'product on the exact-f32 matrix cores (--ir-math f32 makes that the headline)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the roofline / parity / protocol passes (timing only)')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
@@ -734,7 +735,8 @@ def main(argv=None):
             'value': round(fps, 2), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * med / args.steps, 4), 'higher_is_better': True, 'scaling': scaling,
             'vs_baseline': None,
-            'dtype': 'f32' if math_name == 'f32' else 'f32 (level-4 inverted residual: products as 3-term f16 splits, f32 accumulation)',
+            'dtype': 'f32' if math_name == 'f32' else 'f32 storage and accumulation; level-4 inverted residual products as 3-term f16 splits '
+                                                      '(f32-class: 1.3e-7 of sum|a||b|; exact_f32 beside it)',
             'data': 'synthetic' if not stub else 'stub (HS_BENCH_STUB=1: CPU / gloo plumbing test, no model)',
             'repeats': {'n': len(times), 'ms_per_step': [round(1e3 * t / args.steps, 4) for t in times], 'value_from': 'median'},
             'config': {'workload': f'{LABELS[args.model]}, batch {batch} per GPU (global {global_batch}), whole model forward '

@@ -40,8 +40,8 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 constexpr float IRC_H2_SCALE = 4096.0f;          // h2 = relu6(.) in [0, 6] -> [0, 24576] before the f16 split
 
 // ---- geometry shared by the kernel, the launcher and the host-side layout check (hs_irc_layout) ----
-template <int RH_> struct IrcGeom {
-    static constexpr int NW = 4, NTHR = 64 * NW;
+template <int RH_, int NW_ = 4> struct IrcGeom {
+    static constexpr int NW = NW_, NTHR = 64 * NW;
     static constexpr int RH = RH_, RW = 16;                    // region
     static constexpr int HH = RH + 2, HWD = RW + 2;            // halo grid
     static constexpr int NPOS = HH * HWD;
@@ -55,7 +55,7 @@ template <int RH_> struct IrcGeom {
     static constexpr int H2_HALFS = 2 * 16 * H2_PLANE;
     static constexpr int PWH = RH / 2 + 2, PWW = RW / 2 + 2;   // low-res window of the previous level
 };
-static_assert(IrcGeom<8>::PS1 == 208 && IrcGeom<16>::PS1 == 336, "h1 plane strides the conflict model was run on");
+static_assert(IrcGeom<8>::PS1 == 208 && IrcGeom<16>::PS1 == 336 && IrcGeom<16, 8>::PS1 == 336, "h1 plane strides the conflict model was run on");
 
 __host__ __device__ inline int irc_h1_slot(int c) { return 4 * (c & 3) + (c >> 2); }
 __host__ __device__ inline int irc_h2_swz(int p) { return (p & 3) + 4 * (p >> 3); }
@@ -76,8 +76,8 @@ struct IrcArgs {
 
 // LDS map (bytes) of one workgroup; the same function sizes the launch
 struct IrcLds {
-    int taps, w1h, w1l, w3h, w3l, s1f, b1, b2s, s3f, b3, h1, h2, total;
-    int cinp, hidp, HP, CP;
+    int taps, w1h, w1l, w3h, w3l, s1f, b1, b2s, s3f, b3, h1, h2, raw, raw_rows, red, total;
+    int cinp, hidp, HP, CP, raw_chunks;
 };
 __host__ __device__ inline IrcLds irc_lds_map(int cin, int hid, int cout, int mt3, int h1_floats, int h2_halfs) {
     IrcLds m;
@@ -99,6 +99,13 @@ __host__ __device__ inline IrcLds irc_lds_map(int cin, int hid, int cout, int mt
     o = (o + 15) & ~15;
     m.h1 = o; o += h1_floats * 4;
     m.h2 = o; o += h2_halfs * 2;
+    // the raw f32 bank lands here by LDS-DMA (whole 1 KB pieces) WHILE the tiles occupy h1 | h2 (round 4: the landing zone used to
+    // alias the scratch, which chained bank wait -> split -> tiles -> B fragments one after the other)
+    o = (o + 1023) & ~1023;
+    m.raw_chunks = ((cin * hid + 9 * hid + hid * cout) * 4 + 1023) >> 10;
+    m.raw = o; o += m.raw_chunks * 1024;
+    m.raw_rows = o; o += (2 * m.HP + m.CP) * 4;           // BatchNorm scales as loaded (s1 | s2 | s3), consumed by the split
+    m.red = o; o += 16 * 4;                               // per-wave maxima of the two matrices
     m.total = o;
     return m;
 }
@@ -138,10 +145,15 @@ __device__ __forceinline__ void split2(float a, float b, float s, unsigned& hi, 
     hi = h; lo = l;
 }
 
-template <int SPL, int PPL, int MT3, int RH_>
-__global__ __launch_bounds__(256, RH_ == 8 ? 4 : 2)
+// NW_ = 8 (RH = 16 only): the same region on EIGHT waves -- two workgroups per CU then give every SIMD four waves to interleave
+// (the phases of this kernel are chains of dependent LDS round trips and vector instructions: at two waves per SIMD nothing covers
+// a wave's stalls, and both workgroups of a CU run the same phase at the same time).  Per-wave tile counts halve (pw1 6 -> 3,
+// depthwise 2 -> 1 row blocks, pw3 4 -> 2), the register budget is 128.
+template <int SPL, int PPL, int MT3, int RH_, int NW_ = 4>
+__global__ __launch_bounds__(64 * NW_, NW_ == 8 ? 4 : (RH_ == 8 ? 4 : 2))
 void patch_irc_kernel(IrcArgs a) {
-    using G = IrcGeom<RH_>;
+    using G = IrcGeom<RH_, NW_>;
+    static_assert(NW_ == 4 || (NW_ == 8 && RH_ == 16), "eight waves: one 16 x 16 region");
     constexpr int NW = G::NW;
     constexpr int NTHR = G::NTHR, RH = G::RH, RW = G::RW, HWD = G::HWD, NPOS = G::NPOS;
     constexpr int NT1 = G::NT1, J1 = G::J1, J3 = G::J3, CS = G::CS, PS1 = G::PS1;
@@ -184,24 +196,30 @@ void patch_irc_kernel(IrcArgs a) {
     const int H = a.in.H, W = a.in.W;
     const unsigned plane = (unsigned)H * (unsigned)W;
     const float* __restrict__ bank = a.bank + (size_t)patch * (size_t)a.ld;
-    const int off_kd = cin * hid, off_w3 = off_kd + 9 * hid, bank_n = off_w3 + hid * cout;
+    const int off_kd = cin * hid, off_w3 = off_kd + 9 * hid;
 
     // ================================================ prologue ==========================================================
-    // The round-3a form of this kernel fetched everything with per-lane dword loads (65 vector-memory instructions per wave,
-    // 1040 per CU): the CU's address path, not HBM, set the pace -- 11 k cycles just to ISSUE them
-    // (profiles/round3_irc_phase_cycles_a2.txt).  Now: the bank arrives by LDS-DMA in 1 KB pieces (4-5 instructions per wave,
-    // no registers), the skip tile as 16-byte row segments, and the lane <-> (position, channel) shuffles happen in LDS:
+    // Round-3 order:  all loads (bank DMA + tiles) | B | split the bank LDS -> LDS | B | tiles -> scratch | B | B fragments | B --
+    // 24.6 k of a workgroup's 52 k cycles, every phase waiting for the one before (profiles/round3_irc_phase_cycles_a6_rh16.txt:
+    // 9.4 k for the chip-wide load burst, 5.5 k for the split, 4.4 k + 5.0 k for tiles and fragments).  Round 4:
+    //   (a) tile loads (skip, previous level, BatchNorm rows) first and ALONE: 28 of the 45 KB a workgroup asks for;
+    //   (b) tiles -> scratch, then the bank's LDS-DMA is issued into its OWN landing zone and is in flight under
+    //   (c) the B fragments (the VALU-heaviest phase needs no weight);
+    //   (d) the split, cheap form: ONE scale per matrix (W1, W3) instead of one per row -- the 2^15 window of the f16 pieces
+    //       leaves 15 binades of room below the matrix maximum before a row loses f32-class accuracy (hs_ir_math in
+    //       include/hyperseg_hip.h) -- so the pass is a stream of aligned quads: ds_read_b128, 4 x v_fma_mix pairs, two ds_write_b64,
+    //       no per-row bookkeeping (round 3: 212 row jobs of <= 18 values, ~260 vector instructions per wave).
     //   scratch = h1 | h2 (dead until pw1(0)):
-    //     phase 1   raw bank f32 [whole 1 KB pieces] | s1 raw [HP] | s2 raw [HP] | s3 raw [CP]
-    //     phase 2   SK[4][192][SPL]  skip values of lane group kg at halo position pos (one ds_read of SPL floats, conflict-free:
+    //               SK[4][SKPL][SPL]  skip values of lane group kg at halo position pos (one ds_read of SPL floats, conflict-free:
     //               the planes are 0 (mod 64) dwords apart) | WN[4][WNP][PPL]  low-res window of the previous level, likewise |
     //               TY[HH][8], TX[HWD][8]  per halo row / column: bilinear taps {offset0, offset1, l0, l1} and the coordinate
     unsigned char* scr = lds_raw + L.h1;
-    const int raw_chunks = (bank_n * 4 + 1023) >> 10;
-    float* raw = reinterpret_cast<float*>(scr);
-    float* raw_s1 = reinterpret_cast<float*>(scr + raw_chunks * 1024);
+    const int raw_chunks = L.raw_chunks;
+    float* raw = reinterpret_cast<float*>(lds_raw + L.raw);
+    float* raw_s1 = reinterpret_cast<float*>(lds_raw + L.raw_rows);
     float* raw_s2 = raw_s1 + HP;
     float* raw_s3 = raw_s2 + HP;
+    unsigned* red = reinterpret_cast<unsigned*>(lds_raw + L.red);
     constexpr int SKP = 192, WNP = ((PWH * PWW + 63) / 64) * 64;
     constexpr int SKPL = ((NPOS + 63) / 64) * 64;
     static_assert(SKP == 192 && (RH != 8 || SKPL == SKP), "skip planes hold every halo position, 0 (mod 64) dwords apart");
@@ -211,23 +229,16 @@ void patch_irc_kernel(IrcArgs a) {
     float* TX = TY + G::HH * 8;
     static_assert((4 * SKPL * SPL + 4 * WNP * PPL + (G::HH + HWD) * 8) * 4 <= G::H1_FLOATS * 4 + G::H2_HALFS * 2, "phase-2 scratch fits h1 | h2");
 
-    // (1) the patch's bank: LDS-DMA, 16 bytes per lane, whole 1 KB pieces (the tail piece re-reads the row's last 16 bytes)
-    {
-        const unsigned char* gb = reinterpret_cast<const unsigned char*>(bank);
-        const unsigned last16 = (unsigned)a.ld * 4u - 16u;
-        for (int c = wave; c < raw_chunks; c += NW) {
-            const unsigned off = min((unsigned)(c * 1024 + lane * 16), last16);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + off),
-                                             (__attribute__((address_space(3))) void*)(scr + c * 1024), 16, 0, 0);
-        }
-    }
-    // (2) skip tile.  Wave w loads the channels of lane group kg = w (w SPL .. w SPL + SPL - 1); lanes 0 .. 59 = (halo row u of a
+    // (1) skip tile.  Wave w loads the channels of lane group kg = w (w SPL .. w SPL + SPL - 1); lanes 0 .. 59 = (halo row u of a
     //     pass of 10 rows, 16-byte segment sg of columns x0 - 4 + 4 sg ..): the channel is wave-uniform (scalar base), the per-lane
     //     offset is computed once per pass, and a thread ends up with an SPL-channel x 4-column block -- what phase 2 stores as one
     //     SPL-float vector per halo position.  Segments that would leave the image are clamped inside it: their halo column then
     //     comes from the reflected interior column (phase 2).
-    static_assert(NW == 4, "wave w <-> lane group kg = w");
-    constexpr int SKPASS = (G::HH + 9) / 10;                           // 1 (RH = 8) or 2 (RH = 16) passes of 10 halo rows
+    // wave w loads for lane group kg = w & 3; with eight waves the two passes of the skip tile go to the two halves of the workgroup
+    const int kgw = wave & 3, wv_hi = wave >> 2;
+    constexpr int SKPASS_ALL = (G::HH + 9) / 10;                       // 1 (RH = 8) or 2 (RH = 16) passes of 10 halo rows
+    constexpr int SKPASS = NW == 8 ? 1 : SKPASS_ALL;                   // passes per wave
+    static_assert(NW == 4 || SKPASS_ALL == 2, "eight waves share two passes");
     f32x4 sk4[SKPASS][SPL];
     const int sk_ul = lane / 6, sk_sg = lane - 6 * sk_ul;              // row of the pass (0 .. 9 live), segment
     {
@@ -235,26 +246,28 @@ void patch_irc_kernel(IrcArgs a) {
         const int c0 = min(max(x0 - 4 + 4 * sk_sg, 0), W - 4);
 #pragma unroll
         for (int pp = 0; pp < SKPASS; ++pp) {
-            const int u = min(pp * 10 + sk_ul, G::HH - 1);
+            const int u = min((NW == 8 ? wv_hi : pp) * 10 + sk_ul, G::HH - 1);
             const int yy = pad_index(y0 + u - 1, H, HS_PAD_REFLECT);
             const unsigned off = (__umul24((unsigned)yy, (unsigned)W) + (unsigned)c0) << 2;
 #pragma unroll
             for (int k = 0; k < SPL; ++k) {
-                const int ch = wave * SPL + k;                         // uniform; no branch around the load: clamp + mask
+                const int ch = kgw * SPL + k;                          // uniform; no branch around the load: clamp + mask
                 const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(skb + (size_t)min(ch, cskip - 1) * plane) + (size_t)off);
                 const float mk = ch < cskip ? 1.0f : 0.0f;
                 sk4[pp][k] = f32x4{v[0] * mk, v[1] * mk, v[2] * mk, v[3] * mk};
             }
         }
     }
-    // (3) low-res window of the previous level: rows [ly0, ly0 + PWH) x cols [lx0, lx0 + PWW), clamped at the border.  Wave w loads
+    // (2) low-res window of the previous level: rows [ly0, ly0 + PWH) x cols [lx0, lx0 + PWW), clamped at the border.  Wave w loads
     //     the PPL channels of lane group w, one channel per instruction: lanes 0 .. 4 PWH - 1 = (row r, 16-byte segment of columns
     //     x0 / 2 - 4 + 4 s ..).
     const int ly0 = (y0 >> 1) - 1, lx0 = (x0 >> 1) - 1;
     static_assert(4 * PWH <= 64, "a window channel fits one wave");
     f32x4 pw4[PPL];
     const int pw_r = min(lane >> 2, PWH - 1), pw_s = lane & 3;
-    {
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) pw4[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (NW == 4 || wave < 4) {
         const float* __restrict__ pvb = a.in.prev + (size_t)b * cprev * a.in.Hp * a.in.Wp;
         const int yy = min(max(ly0 + pw_r, 0), a.in.Hp - 1);
         const int c0 = min(max((x0 >> 1) - 4 + 4 * pw_s, 0), a.in.Wp - 4);
@@ -262,13 +275,13 @@ void patch_irc_kernel(IrcArgs a) {
         const size_t cpl = (size_t)a.in.Hp * a.in.Wp;
 #pragma unroll
         for (int k = 0; k < PPL; ++k) {
-            const int ch = wave * PPL + k;                             // uniform
+            const int ch = kgw * PPL + k;                              // uniform (eight waves: the upper four re-load the same window; only the lower four store it)
             const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(pvb + (size_t)min(ch, cprev - 1) * cpl) + (size_t)off);
             const float mk = ch < cprev ? 1.0f : 0.0f;
             pw4[k] = f32x4{v[0] * mk, v[1] * mk, v[2] * mk, v[3] * mk};
         }
     }
-    // (4) BatchNorm rows: thread t takes row t (zero beyond the real channels)
+    // (3) BatchNorm rows: thread t takes row t (zero beyond the real channels)
     static_assert(NTHR >= 96, "one pass over the BatchNorm rows");
     {
         const float mh = tid < hid ? 1.0f : 0.0f, mo = tid < cout ? 1.0f : 0.0f;
@@ -280,17 +293,278 @@ void patch_irc_kernel(IrcArgs a) {
         if (tid < 16) reinterpret_cast<unsigned*>(lds_raw + L.w3l + w3_piece * 2)[tid] = 0u;          // the 64 zero bytes
     }
     // @stamp 1
-    __syncthreads();                                       // the DMA has landed (the barrier waits for vmcnt(0)); BN rows are in LDS
+
+    // ================================================ phase 2: tiles and tap tables into the scratch ====================
+    {   // skip tile: the thread's SPL-channel x 4-column block -> one SPL-float vector per halo position of lane group kg = wave
+        const bool left = sk_sg == 0, right = sk_sg == 5;
+        const bool clamp_l = x0 == 0, clamp_r = x0 + RW == W;           // uniform: the region touches the image border
+        using skv = __attribute__((ext_vector_type(SPL))) float;
+#pragma unroll
+        for (int pp = 0; pp < SKPASS; ++pp) {
+            const int u = (NW == 8 ? wv_hi : pp) * 10 + sk_ul;
+            if (sk_ul < 10 && u < G::HH) {
+                float* d = SK + (kgw * SKPL + u * HWD + 4 * sk_sg - 3) * SPL;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int vv = 4 * sk_sg - 3 + i;
+                    if (vv >= 0 && vv < HWD) {
+                        // halo column 0 is image column x0 - 1 (element 3 of segment 0) or, reflected at the left border, column 1
+                        // (element 1 of the clamped segment); halo column 17 likewise
+                        const int src = (left && clamp_l) ? 1 : (right && clamp_r) ? 2 : i;
+                        if constexpr (SPL == 1) d[i] = src == i ? sk4[pp][0][i] : (src == 1 ? sk4[pp][0][1] : sk4[pp][0][2]);
+                        else {
+                            skv o;
+#pragma unroll
+                            for (int k = 0; k < SPL; ++k) o[k] = src == i ? sk4[pp][k][i] : (src == 1 ? sk4[pp][k][1] : sk4[pp][k][2]);
+                            *reinterpret_cast<skv*>(d + i * SPL) = o;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (lane < 4 * PWH && wave < 4) {
+        using pwv = __attribute__((ext_vector_type(PPL))) float;
+        float* d = WN + (wave * WNP + pw_r * PWW + 4 * pw_s - 3) * PPL;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = 4 * pw_s - 3 + i;
+            if (q >= 0 && q < PWW) {
+                pwv o;
+#pragma unroll
+                for (int k = 0; k < PPL; ++k) o[k] = pw4[k][i];
+                *reinterpret_cast<pwv*>(d + i * PPL) = o;
+            }
+        }
+    }
+    if (tid < G::HH + HWD) {          // per halo row: {row offset 0, row offset 1 (in window positions), l0, l1, coordinate y}; columns likewise
+        const bool isrow = tid < G::HH;
+        const int i = isrow ? tid : tid - G::HH;
+        const int p = isrow ? pad_index(y0 + i - 1, H, HS_PAD_REFLECT) : pad_index(x0 + i - 1, W, HS_PAD_REFLECT);
+        const Tap t = bilinear_tap(p, isrow ? a.in.scale_y : a.in.scale_x, isrow ? a.in.Hp : a.in.Wp);
+        const int o0 = isrow ? (t.i0 - ly0) * PWW : t.i0 - lx0, o1 = isrow ? (t.i1 - ly0) * PWW : t.i1 - lx0;
+        float* d = (isrow ? TY : TX) + i * 8;
+        d[0] = __int_as_float(o0); d[1] = __int_as_float(o1); d[2] = t.l0; d[3] = t.l1;
+        d[4] = isrow ? linspace_pm1(p, H, a.in.step_y) : linspace_pm1(p, W, a.in.step_x);
+    }
+    // (4) the patch's bank: LDS-DMA into its landing zone, 16 bytes per lane, whole 1 KB pieces (the tail piece re-reads the row's
+    //     last 16 bytes).  Issued HERE -- every register load above has been consumed -- and in flight until the barrier after the
+    //     B fragments; the barrier right below must not wait for it (a plain __syncthreads() would: it drains vmcnt).
+    {
+        const unsigned char* gb = reinterpret_cast<const unsigned char*>(bank);
+        const unsigned last16 = (unsigned)a.ld * 4u - 16u;
+        for (int c = wave; c < raw_chunks; c += NW) {
+            const unsigned off = min((unsigned)(c * 1024 + lane * 16), last16);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + off),
+                                             (__attribute__((address_space(3))) void*)(lds_raw + L.raw + c * 1024), 16, 0, 0);
+        }
+    }
     // @stamp 2
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // tiles visible; the DMA stays in flight
+    // @stamp 3
+
+    // ================================================ phase 3: the B fragments ==========================================
+    // Per halo position the lane's SPL skip values, PPL bilinear previous-level values and (tail) the two coordinates;
+    // scale = the position's maximum over all its channels -> 2^15.
+    half8 bq[J1][3];                                       // [hi | lo | tail]
+    float invb[J1];
+    int hoff[J1];
+    // Tiles in groups of GT: first every tile's tap-table rows, then every tile's skip vector and bilinear taps -- two LDS round
+    // trips per group.  (Written tile by tile the compiler drained the LDS queue 19 times for 54 reads: visit r4b, 5.8 k cycles.)
+    constexpr int GT = NW == 8 ? 2 : 3;
+#pragma unroll
+    for (int g0 = 0; g0 < J1; g0 += GT) {
+        constexpr int SV = SPL == 4 ? 4 : (SPL == 2 ? 2 : 1);
+        f32x4 ty[GT], tx[GT];
+        float cy[GT], cx[GT];
+        int pcs[GT];
+        bool lives[GT];
+#pragma unroll
+        for (int t = 0; t < GT; ++t) {
+            const int jt = g0 + t;
+            if (jt < J1) {
+                const int pos = (wave + NW * jt) * 16 + lrow;
+                lives[t] = pos < NPOS;                               // the last tile is short; tiles past NT1 are all dead
+                pcs[t] = lives[t] ? pos : 0;
+                const int u = pcs[t] / HWD, v = pcs[t] - u * HWD;
+                hoff[jt] = lives[t] ? u * CS + v : NPOS;             // dead lanes store to the plane's padding
+                ty[t] = *reinterpret_cast<const f32x4*>(TY + u * 8); tx[t] = *reinterpret_cast<const f32x4*>(TX + v * 8);
+                cy[t] = TY[u * 8 + 4]; cx[t] = TX[v * 8 + 4];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 pv[GT][4];
+        float sv[GT][SV];
+        const float* pb = WN + lk * WNP * PPL;
+#pragma unroll
+        for (int t = 0; t < GT; ++t) {
+            if (g0 + t < J1) {
+                const int r0 = __float_as_int(ty[t][0]), r1 = __float_as_int(ty[t][1]), q0 = __float_as_int(tx[t][0]), q1 = __float_as_int(tx[t][1]);
+                if constexpr (SPL == 4) {
+                    const f32x4 s4 = *reinterpret_cast<const f32x4*>(SK + (lk * SKPL + pcs[t]) * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sv[t][j] = s4[j];
+                } else if constexpr (SPL == 2) {
+                    using f32x2 = __attribute__((ext_vector_type(2))) float;
+                    const f32x2 s2 = *reinterpret_cast<const f32x2*>(SK + (lk * SKPL + pcs[t]) * 2);
+                    sv[t][0] = s2[0]; sv[t][1] = s2[1];
+                } else {
+                    sv[t][0] = SK[lk * SKPL + pcs[t]];
+                }
+                if constexpr (PPL == 4) {
+                    pv[t][0] = *reinterpret_cast<const f32x4*>(pb + (r0 + q0) * 4); pv[t][1] = *reinterpret_cast<const f32x4*>(pb + (r0 + q1) * 4);
+                    pv[t][2] = *reinterpret_cast<const f32x4*>(pb + (r1 + q0) * 4); pv[t][3] = *reinterpret_cast<const f32x4*>(pb + (r1 + q1) * 4);
+                } else {
+                    using f32x2 = __attribute__((ext_vector_type(2))) float;
+                    const f32x2 p00 = *reinterpret_cast<const f32x2*>(pb + (r0 + q0) * 2), p01 = *reinterpret_cast<const f32x2*>(pb + (r0 + q1) * 2);
+                    const f32x2 p10 = *reinterpret_cast<const f32x2*>(pb + (r1 + q0) * 2), p11 = *reinterpret_cast<const f32x2*>(pb + (r1 + q1) * 2);
+                    pv[t][0] = f32x4{p00[0], p00[1], 0.f, 0.f}; pv[t][1] = f32x4{p01[0], p01[1], 0.f, 0.f};
+                    pv[t][2] = f32x4{p10[0], p10[1], 0.f, 0.f}; pv[t][3] = f32x4{p11[0], p11[1], 0.f, 0.f};
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < GT; ++t) {
+            const int jt = g0 + t;
+            if (jt < J1) {
+                const bool live = lives[t];
+                const float w00 = ty[t][2] * tx[t][2], w01 = ty[t][2] * tx[t][3], w10 = ty[t][3] * tx[t][2], w11 = ty[t][3] * tx[t][3];
+                float kv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) kv[j] = 0.0f;
+#pragma unroll
+                for (int j = 0; j < SV; ++j) kv[j] = sv[t][j];
+#pragma unroll
+                for (int j = 0; j < PPL; ++j) kv[SPL + j] = fmaf(w11, pv[t][3][j], fmaf(w10, pv[t][2][j], fmaf(w01, pv[t][1][j], w00 * pv[t][0][j])));
+                const float cxl = live ? cx[t] : 0.0f, cyl = live ? cy[t] : 0.0f;
+                unsigned m = max(absbits(cxl), absbits(cyl));
+#pragma unroll
+                for (int j = 0; j < SPL + PPL; ++j) { kv[j] = live ? kv[j] : 0.0f; m = max(m, absbits(kv[j])); }
+                {   // maximum over the 4 lane groups that hold this position: lanes n, n + 16, n + 32, n + 48
+                    auto r16 = __builtin_amdgcn_permlane16_swap(m, m, false, false);
+                    m = max(r16[0], r16[1]);
+                    auto r32 = __builtin_amdgcn_permlane32_swap(m, m, false, false);
+                    m = max(r32[0], r32[1]);
+                }
+                const int eb = irc_exp_of(m);
+                const float sc = irc_scale_of(eb);
+                invb[jt] = irc_inv_scale_of(eb);
+                // K slots of the lane group: [skip run (SPL) | previous-level run (PPL) | zeros]
+                u32x4 qh, ql;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (2 * j < SPL + PPL) { unsigned hh, ll; split2(kv[2 * j], kv[2 * j + 1], sc, hh, ll); qh[j] = hh; ql[j] = ll; }
+                    else { qh[j] = 0u; ql[j] = 0u; }
+                }
+                bq[jt][0] = __builtin_bit_cast(half8, qh);
+                bq[jt][1] = __builtin_bit_cast(half8, ql);
+                unsigned ch, cl;
+                split2(cxl, cyl, sc, ch, cl);
+                // tail: the lane group picks the product -- 0: ah * bh, 1: al * bh, 2: ah * bl, 3: nothing
+                const u32x4 qt = {lk < 2 ? ch : (lk == 2 ? cl : 0u), 0u, 0u, 0u};
+                bq[jt][2] = __builtin_bit_cast(half8, qt);
+            }
+        }
+    }
+    // @stamp 4
+    // pw3: transpose-read addresses (halfs, relative to h2).  Lane i of a 16-lane group supplies the 4-pixel run (i & 3) of
+    // plane (i >> 2) of its block and receives pixel i of the block's 4 planes.  Row t of plane p lives in 32-byte slot t ^ swz(p).
+    int trp[2];                                            // plane base (halfs) of read rd = 0, 1; + the row slot per tile
+    int trs[2];
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+        const int p = 8 * (lk & 1) + 4 * rd + (lrow >> 2);
+        trp[rd] = p * G::H2_PLANE + 4 * (lrow & 3);
+        trs[rd] = irc_h2_swz(p);
+    }
+    const int zero_h = (int)((lds_raw + L.w3l + w3_piece * 2) - (lds_raw + L.h2)) / 2;    // the zero block, in halfs relative to h2
+    f32x4 acc3[MT3][J3];
+#pragma unroll
+    for (int m = 0; m < MT3; ++m)
+#pragma unroll
+        for (int jt = 0; jt < J3; ++jt) acc3[m][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();                                       // the scratch is dead; every wave's DMA pieces have landed (vmcnt(0) + barrier)
+    // @stamp 5
 
     // ================================================ phase 1: split the bank, LDS -> LDS ==============================
-    // One JOB per thread: a contiguous piece of one matrix row -- a W1 row (cin values) is 2 jobs, a W3 row (hid values) 4 -- so
-    // the 4216 weights of HyperSeg-M's level 4 are 212 jobs of <= 18 values, one pass of the workgroup.  (Round 3a gave a 16-lane
-    // segment a row at a time: 2 useful values per lane and round, the per-row arithmetic repeated in 16 lanes, 500 vector
-    // instructions per wave for what is 16 values per thread.)  The row maximum is the maximum of the job's values combined across
-    // the 2 / 4 neighbouring lanes of the row on the DPP path; every row scales to [2^14, 2^15) and 1 / scale goes into the
-    // BatchNorm scale that follows (s1f, s3f).
-    {
+    const int n1 = cin * hid, n3 = hid * cout;
+    int eb1 = 0, eb3 = 0;
+    if ((cin & 1) == 0 && (hid & 3) == 0) {
+        // quads of 4 consecutive weights: W1 [0, n1) and W3 [off_w3, off_w3 + n3) are whole, 16-byte aligned quads here, and with an
+        // even cin / hid the f16 images are the matrices' own row-major order (cinp = cin, hidp = hid)
+        const int nq1 = n1 >> 2, nq = nq1 + (n3 >> 2);
+        // QB quads per thread and round, ALL of a round's ds_read_b128 issued before the first use and kept in registers across
+        // the maximum's barrier (a run-time loop of read -> use -> write round trips costs one LDS latency per quad: 4.7 k cycles
+        // for 3.5 quads per thread in visit r4b)
+        constexpr int QB = NW == 8 ? 2 : 4;
+        using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+        for (int q0 = 0; q0 < nq; q0 += QB * NTHR) {                 // one round at every BASELINE shape (<= 1024 quads)
+            f32x4 v[QB];
+            unsigned m1 = 0, m3 = 0;
+#pragma unroll
+            for (int i = 0; i < QB; ++i) {
+                const int q = min(q0 + tid + i * NTHR, nq - 1);
+                v[i] = *reinterpret_cast<const f32x4*>(raw + (q < nq1 ? 4 * q : off_w3 + 4 * (q - nq1)));
+            }
+#pragma unroll
+            for (int i = 0; i < QB; ++i) {
+                const int q = q0 + tid + i * NTHR;
+                const unsigned m = q < nq ? max(max(absbits(v[i][0]), absbits(v[i][1])), max(absbits(v[i][2]), absbits(v[i][3]))) : 0u;
+                m1 = max(m1, q < nq1 ? m : 0u); m3 = max(m3, q < nq1 ? 0u : m);
+            }
+            if (q0 == 0) {                                           // the scales come from the first round's maxima ...
+                m1 = rowmax16_u(m1); m3 = rowmax16_u(m3);
+                m1 = max(max((unsigned)__builtin_amdgcn_readlane((int)m1, 0), (unsigned)__builtin_amdgcn_readlane((int)m1, 16)),
+                         max((unsigned)__builtin_amdgcn_readlane((int)m1, 32), (unsigned)__builtin_amdgcn_readlane((int)m1, 48)));
+                m3 = max(max((unsigned)__builtin_amdgcn_readlane((int)m3, 0), (unsigned)__builtin_amdgcn_readlane((int)m3, 16)),
+                         max((unsigned)__builtin_amdgcn_readlane((int)m3, 32), (unsigned)__builtin_amdgcn_readlane((int)m3, 48)));
+                if (nq > QB * NTHR) {                                // ... unless the matrices take more than one: a maximum pass first
+                    for (int q = QB * NTHR + tid; q < nq; q += NTHR) {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(raw + (q < nq1 ? 4 * q : off_w3 + 4 * (q - nq1)));
+                        const unsigned m = max(max(absbits(w[0]), absbits(w[1])), max(absbits(w[2]), absbits(w[3])));
+                        m1 = max(m1, q < nq1 ? m : 0u); m3 = max(m3, q < nq1 ? 0u : m);
+                    }
+                    m1 = rowmax16_u(m1); m3 = rowmax16_u(m3);
+                    m1 = max(max((unsigned)__builtin_amdgcn_readlane((int)m1, 0), (unsigned)__builtin_amdgcn_readlane((int)m1, 16)),
+                             max((unsigned)__builtin_amdgcn_readlane((int)m1, 32), (unsigned)__builtin_amdgcn_readlane((int)m1, 48)));
+                    m3 = max(max((unsigned)__builtin_amdgcn_readlane((int)m3, 0), (unsigned)__builtin_amdgcn_readlane((int)m3, 16)),
+                             max((unsigned)__builtin_amdgcn_readlane((int)m3, 32), (unsigned)__builtin_amdgcn_readlane((int)m3, 48)));
+                }
+                if (lane == 0) { red[2 * wave] = m1; red[2 * wave + 1] = m3; }
+                __syncthreads();
+            }
+            unsigned g1 = 0, g3 = 0;
+#pragma unroll
+            for (int w4 = 0; w4 < NW / 2; ++w4) {                    // {m1, m3} of two waves per 16-byte read
+                const u32x4 rr = *reinterpret_cast<const u32x4*>(red + 4 * w4);
+                g1 = max(g1, max(rr[0], rr[2])); g3 = max(g3, max(rr[1], rr[3]));
+            }
+            eb1 = irc_exp_of(g1);
+            eb3 = irc_exp_of(g3);
+            const float sc1m = irc_scale_of(eb1), sc3m = irc_scale_of(eb3);
+#pragma unroll
+            for (int i = 0; i < QB; ++i) {
+                const int q = q0 + tid + i * NTHR;
+                const bool is1 = q < nq1;
+                const int e = is1 ? 4 * q : 4 * (q - nq1);
+                const float sc = is1 ? sc1m : sc3m;
+                u32x2 hi, lo;
+                { unsigned h, l; split2(v[i][0], v[i][1], sc, h, l); hi[0] = h; lo[0] = l; }
+                { unsigned h, l; split2(v[i][2], v[i][3], sc, h, l); hi[1] = h; lo[1] = l; }
+                if (q < nq) {
+                    _Float16* d = (is1 ? w1h : w3h) + e;
+                    *reinterpret_cast<u32x2*>(d) = hi;
+                    *reinterpret_cast<u32x2*>(d + (is1 ? w1_piece : w3_piece)) = lo;
+                }
+            }
+        }
+        if (tid < hid) s1f[tid] = raw_s1[tid] * irc_inv_scale_of(eb1);
+        if (tid < cout) s3f[tid] = raw_s3[tid] * (irc_inv_scale_of(eb3) * (1.0f / IRC_H2_SCALE));
+    } else {
+        // odd channel counts: one JOB per thread, a contiguous piece of one matrix row (a W1 row = 2 jobs, a W3 row = 4, <= 18 values
+        // each), per-row scale from the jobs' maxima combined over the 2 / 4 neighbouring lanes on the DPP path -- the round-3 form,
+        // which also writes the zero pad column of an odd row length
         constexpr int MAXP = 12;                                       // value pairs per job: cin <= 34 -> 9, hid <= 96 -> 12
         const int ca = (((cin + 1) >> 1) + 1) & ~1, cb = (((hid + 3) >> 2) + 1) & ~1;   // piece lengths (even, rounded up): W1 rows in 2, W3 rows in 4
         const int j1n = 2 * hid, j3b = (j1n + 3) & ~3, jn = j3b + 4 * cout;
@@ -325,168 +599,34 @@ void patch_irc_kernel(IrcArgs a) {
             if (is3 && part == 0) s3f[row] = raw_s3[row] * (irc_inv_scale_of(eb) * (1.0f / IRC_H2_SCALE));
         }
     }
-    for (int e = tid; e < 9 * hid; e += NTHR) taps[e] = raw[off_kd + e] * (raw_s2[(unsigned)e / 9u] * IRC_H2_SCALE);
-    // @stamp 3
-    __syncthreads();                                       // the raw bank is dead
-    // @stamp 4
-
-    // ================================================ phase 2: tiles and tap tables into the scratch ====================
-    {   // skip tile: the thread's SPL-channel x 4-column block -> one SPL-float vector per halo position of lane group kg = wave
-        const bool left = sk_sg == 0, right = sk_sg == 5;
-        const bool clamp_l = x0 == 0, clamp_r = x0 + RW == W;           // uniform: the region touches the image border
-        using skv = __attribute__((ext_vector_type(SPL))) float;
+    {   // taps with BN2's scale folded in: 9 hid <= 864 values, the rounds' LDS reads issued together
+        constexpr int TB = NW == 8 ? 2 : 4;
+        float tv[TB], ts[TB];
 #pragma unroll
-        for (int pp = 0; pp < SKPASS; ++pp) {
-            const int u = pp * 10 + sk_ul;
-            if (sk_ul < 10 && u < G::HH) {
-                float* d = SK + (wave * SKPL + u * HWD + 4 * sk_sg - 3) * SPL;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int vv = 4 * sk_sg - 3 + i;
-                    if (vv >= 0 && vv < HWD) {
-                        // halo column 0 is image column x0 - 1 (element 3 of segment 0) or, reflected at the left border, column 1
-                        // (element 1 of the clamped segment); halo column 17 likewise
-                        const int src = (left && clamp_l) ? 1 : (right && clamp_r) ? 2 : i;
-                        if constexpr (SPL == 1) d[i] = src == i ? sk4[pp][0][i] : (src == 1 ? sk4[pp][0][1] : sk4[pp][0][2]);
-                        else {
-                            skv o;
-#pragma unroll
-                            for (int k = 0; k < SPL; ++k) o[k] = src == i ? sk4[pp][k][i] : (src == 1 ? sk4[pp][k][1] : sk4[pp][k][2]);
-                            *reinterpret_cast<skv*>(d + i * SPL) = o;
-                        }
-                    }
-                }
-            }
+        for (int i = 0; i < TB; ++i) {
+            const int e = min(tid + i * NTHR, 9 * hid - 1);
+            tv[i] = raw[off_kd + e]; ts[i] = raw_s2[(unsigned)e / 9u];
         }
-    }
-    if (lane < 4 * PWH) {
-        using pwv = __attribute__((ext_vector_type(PPL))) float;
-        float* d = WN + (wave * WNP + pw_r * PWW + 4 * pw_s - 3) * PPL;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = 4 * pw_s - 3 + i;
-            if (q >= 0 && q < PWW) {
-                pwv o;
-#pragma unroll
-                for (int k = 0; k < PPL; ++k) o[k] = pw4[k][i];
-                *reinterpret_cast<pwv*>(d + i * PPL) = o;
-            }
+        for (int i = 0; i < TB; ++i) {
+            const int e = tid + i * NTHR;
+            if (e < 9 * hid) taps[e] = tv[i] * (ts[i] * IRC_H2_SCALE);
         }
+        static_assert(TB * NTHR >= 9 * 96, "one round covers the taps of the widest block");
     }
-    if (tid < G::HH + HWD) {          // per halo row: {row offset 0, row offset 1 (in window positions), l0, l1, coordinate y}; columns likewise
-        const bool isrow = tid < G::HH;
-        const int i = isrow ? tid : tid - G::HH;
-        const int p = isrow ? pad_index(y0 + i - 1, H, HS_PAD_REFLECT) : pad_index(x0 + i - 1, W, HS_PAD_REFLECT);
-        const Tap t = bilinear_tap(p, isrow ? a.in.scale_y : a.in.scale_x, isrow ? a.in.Hp : a.in.Wp);
-        const int o0 = isrow ? (t.i0 - ly0) * PWW : t.i0 - lx0, o1 = isrow ? (t.i1 - ly0) * PWW : t.i1 - lx0;
-        float* d = (isrow ? TY : TX) + i * 8;
-        d[0] = __int_as_float(o0); d[1] = __int_as_float(o1); d[2] = t.l0; d[3] = t.l1;
-        d[4] = isrow ? linspace_pm1(p, H, a.in.step_y) : linspace_pm1(p, W, a.in.step_x);
-    }
-    // @stamp 5
-    __syncthreads();
     // @stamp 6
-
-    // ================================================ phase 3: the B fragments ==========================================
-    // Per halo position the lane's SPL skip values, PPL bilinear previous-level values and (tail) the two coordinates;
-    // scale = the position's maximum over all its channels -> 2^15.
-    half8 bq[J1][3];                                       // [hi | lo | tail]
-    float invb[J1];
-    int hoff[J1];
-#pragma unroll
-    for (int jt = 0; jt < J1; ++jt) {
-        const int pos = (wave + NW * jt) * 16 + lrow;
-        const bool live = pos < NPOS;                                // the last tile is short; tiles past NT1 are all dead
-        const int pc = live ? pos : 0;
-        const int u = pc / HWD, v = pc - u * HWD;
-        hoff[jt] = live ? u * CS + v : NPOS;                         // dead lanes store to the plane's padding
-        const f32x4 ty = *reinterpret_cast<const f32x4*>(TY + u * 8), tx = *reinterpret_cast<const f32x4*>(TX + v * 8);
-        const float cy = TY[u * 8 + 4], cx = TX[v * 8 + 4];
-        const int r0 = __float_as_int(ty[0]), r1 = __float_as_int(ty[1]), q0 = __float_as_int(tx[0]), q1 = __float_as_int(tx[1]);
-        const float w00 = ty[2] * tx[2], w01 = ty[2] * tx[3], w10 = ty[3] * tx[2], w11 = ty[3] * tx[3];
-        const float* pb = WN + lk * WNP * PPL;
-        float kv[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) kv[j] = 0.0f;
-        if constexpr (SPL == 4) {
-            const f32x4 s4 = *reinterpret_cast<const f32x4*>(SK + (lk * SKPL + pc) * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) kv[j] = s4[j];
-        } else if constexpr (SPL == 2) {
-            using f32x2 = __attribute__((ext_vector_type(2))) float;
-            const f32x2 s2 = *reinterpret_cast<const f32x2*>(SK + (lk * SKPL + pc) * 2);
-            kv[0] = s2[0]; kv[1] = s2[1];
-        } else {
-            kv[0] = SK[lk * SKPL + pc];
-        }
-        if constexpr (PPL == 4) {
-            const f32x4 p00 = *reinterpret_cast<const f32x4*>(pb + (r0 + q0) * 4), p01 = *reinterpret_cast<const f32x4*>(pb + (r0 + q1) * 4);
-            const f32x4 p10 = *reinterpret_cast<const f32x4*>(pb + (r1 + q0) * 4), p11 = *reinterpret_cast<const f32x4*>(pb + (r1 + q1) * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) kv[SPL + j] = fmaf(w11, p11[j], fmaf(w10, p10[j], fmaf(w01, p01[j], w00 * p00[j])));
-        } else {
-            using f32x2 = __attribute__((ext_vector_type(2))) float;
-            const f32x2 p00 = *reinterpret_cast<const f32x2*>(pb + (r0 + q0) * 2), p01 = *reinterpret_cast<const f32x2*>(pb + (r0 + q1) * 2);
-            const f32x2 p10 = *reinterpret_cast<const f32x2*>(pb + (r1 + q0) * 2), p11 = *reinterpret_cast<const f32x2*>(pb + (r1 + q1) * 2);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) kv[SPL + j] = fmaf(w11, p11[j], fmaf(w10, p10[j], fmaf(w01, p01[j], w00 * p00[j])));
-        }
-        const float cxl = live ? cx : 0.0f, cyl = live ? cy : 0.0f;
-        unsigned m = max(absbits(cxl), absbits(cyl));
-#pragma unroll
-        for (int j = 0; j < SPL + PPL; ++j) { kv[j] = live ? kv[j] : 0.0f; m = max(m, absbits(kv[j])); }
-        {   // maximum over the 4 lane groups that hold this position: lanes n, n + 16, n + 32, n + 48
-            auto r16 = __builtin_amdgcn_permlane16_swap(m, m, false, false);
-            m = max(r16[0], r16[1]);
-            auto r32 = __builtin_amdgcn_permlane32_swap(m, m, false, false);
-            m = max(r32[0], r32[1]);
-        }
-        const int eb = irc_exp_of(m);
-        const float sc = irc_scale_of(eb);
-        invb[jt] = irc_inv_scale_of(eb);
-        // K slots of the lane group: [skip run (SPL) | previous-level run (PPL) | zeros]
-        u32x4 qh, ql;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (2 * j < SPL + PPL) { unsigned hh, ll; split2(kv[2 * j], kv[2 * j + 1], sc, hh, ll); qh[j] = hh; ql[j] = ll; }
-            else { qh[j] = 0u; ql[j] = 0u; }
-        }
-        bq[jt][0] = __builtin_bit_cast(half8, qh);
-        bq[jt][1] = __builtin_bit_cast(half8, ql);
-        unsigned ch, cl;
-        split2(cxl, cyl, sc, ch, cl);
-        // tail: the lane group picks the product -- 0: ah * bh, 1: al * bh, 2: ah * bl, 3: nothing
-        const u32x4 qt = {lk < 2 ? ch : (lk == 2 ? cl : 0u), 0u, 0u, 0u};
-        bq[jt][2] = __builtin_bit_cast(half8, qt);
-    }
+    __syncthreads();                                       // the f16 images are complete: h1 / h2 from here on
     // @stamp 7
-    // pw3: transpose-read addresses (halfs, relative to h2).  Lane i of a 16-lane group supplies the 4-pixel run (i & 3) of
-    // plane (i >> 2) of its block and receives pixel i of the block's 4 planes.  Row t of plane p lives in 32-byte slot t ^ swz(p).
-    int trp[2];                                            // plane base (halfs) of read rd = 0, 1; + the row slot per tile
-    int trs[2];
-#pragma unroll
-    for (int rd = 0; rd < 2; ++rd) {
-        const int p = 8 * (lk & 1) + 4 * rd + (lrow >> 2);
-        trp[rd] = p * G::H2_PLANE + 4 * (lrow & 3);
-        trs[rd] = irc_h2_swz(p);
-    }
-    const int zero_h = (int)((lds_raw + L.w3l + w3_piece * 2) - (lds_raw + L.h2)) / 2;    // the zero block, in halfs relative to h2
-    f32x4 acc3[MT3][J3];
-#pragma unroll
-    for (int m = 0; m < MT3; ++m)
-#pragma unroll
-        for (int jt = 0; jt < J3; ++jt) acc3[m][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    __syncthreads();                                       // the scratch is dead: h1 / h2 from here on
-    // @stamp 8
 
     // depthwise thread map: lane = half | row_lo << 1 | channel-of-the-wave << 3 | row_hi << 5; channel = wave + 4 j; with RH = 16
     // a thread takes rows r and r + 8 of its channel (same taps).  This is the map the conflict model was run on
     // (tools/lds_conflicts.py; rows + 8 shift every lane by 144 floats == 16 (mod 64): the same bank picture).
-    constexpr int DWI = RH / 8;
-    const int dw_half = lane & 1, dw_row = ((lane >> 1) & 3) | ((lane >> 5) << 2), dw_j = (lane >> 3) & 3;
-    const int dw_c = wave + 4 * dw_j;                      // hidden channel of the chunk; its h1 slot is 4 * wave + j
+    // eight waves: waves w and w + 4 share the channels of wave w & 3 and take rows 0-7 / 8-15 (the + 8 rows of the four-wave form)
+    constexpr int DWI = NW == 8 ? 1 : RH / 8;
+    const int dw_half = lane & 1, dw_row = (((lane >> 1) & 3) | ((lane >> 5) << 2)) + (NW == 8 ? 8 * wv_hi : 0), dw_j = (lane >> 3) & 3;
+    const int dw_c = kgw + 4 * dw_j;                       // hidden channel of the chunk; its h1 slot is 4 * (wave & 3) + j
     const int dw_sw = irc_h2_swz(dw_c);
-    const float* dw_src = h1 + (4 * wave + dw_j) * PS1 + dw_row * CS + 8 * dw_half;
+    const float* dw_src = h1 + (4 * kgw + dw_j) * PS1 + dw_row * CS + 8 * dw_half;
     _Float16* dw_dst = h2 + dw_c * G::H2_PLANE + 8 * dw_half;
 
     // ================================================ stages ==========================================================
@@ -535,10 +675,20 @@ void patch_irc_kernel(IrcArgs a) {
     auto stage_dw = [&](int h0) {
         using f32x2 = __attribute__((ext_vector_type(2))) float;
         const float* kb = taps + (h0 + dw_c) * 9;
+        // every LDS read of the stage -- 9 taps, the BN2 offset, 15 DWI row pieces -- in flight before the first FMA (written row by
+        // row the compiler waited for the LDS 16 times per stage: with both workgroups of a CU in the same phase nobody covers that)
         float k[9];
 #pragma unroll
         for (int q = 0; q < 9; ++q) k[q] = kb[q];
         const float init = b2s[h0 + dw_c];
+        f32x2 rv[DWI][3][5];
+#pragma unroll
+        for (int it = 0; it < DWI; ++it)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int q = 0; q < 5; ++q) rv[it][ky][q] = *reinterpret_cast<const f32x2*>(dw_src + (8 * it + ky) * CS + 2 * q);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int it = 0; it < DWI; ++it) {
             float o[8];
@@ -548,10 +698,7 @@ void patch_irc_kernel(IrcArgs a) {
             for (int ky = 0; ky < 3; ++ky) {
                 float rowv[10];
 #pragma unroll
-                for (int q = 0; q < 5; ++q) {
-                    const f32x2 v2 = *reinterpret_cast<const f32x2*>(dw_src + (8 * it + ky) * CS + 2 * q);
-                    rowv[2 * q] = v2[0]; rowv[2 * q + 1] = v2[1];
-                }
+                for (int q = 0; q < 5; ++q) { rowv[2 * q] = rv[it][ky][q][0]; rowv[2 * q + 1] = rv[it][ky][q][1]; }
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
@@ -582,20 +729,25 @@ void patch_irc_kernel(IrcArgs a) {
             const unsigned* p32 = reinterpret_cast<const unsigned*>(p);
             a3[m] = __builtin_bit_cast(half8, u32x4{p32[0], p32[1], p32[2], p32[3]});
         }
+        half4tr xr[J3][4];                                             // the stage's 4 J3 transpose reads, all issued before the first MFMA
 #pragma unroll
         for (int jt = 0; jt < J3; ++jt) {
             const int t = wave + NW * jt;                               // region row
             const int s0 = ((t ^ trs[0]) * RW), s1 = ((t ^ trs[1]) * RW);
-            const half4tr x0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(HS_IRC_LDS_H4(h2 + trp[0] + s0));
-            const half4tr x1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(HS_IRC_LDS_H4(h2 + trp[1] + s1));
+            xr[jt][0] = __builtin_amdgcn_ds_read_tr16_b64_v4f16(HS_IRC_LDS_H4(h2 + trp[0] + s0));
+            xr[jt][1] = __builtin_amdgcn_ds_read_tr16_b64_v4f16(HS_IRC_LDS_H4(h2 + trp[1] + s1));
             const int l0 = lk < 2 ? 16 * G::H2_PLANE + trp[0] + s0 : zero_h, l1 = lk < 2 ? 16 * G::H2_PLANE + trp[1] + s1 : zero_h;
-            const half4tr y0v = __builtin_amdgcn_ds_read_tr16_b64_v4f16(HS_IRC_LDS_H4(h2 + l0));
-            const half4tr y1v = __builtin_amdgcn_ds_read_tr16_b64_v4f16(HS_IRC_LDS_H4(h2 + l1));
+            xr[jt][2] = __builtin_amdgcn_ds_read_tr16_b64_v4f16(HS_IRC_LDS_H4(h2 + l0));
+            xr[jt][3] = __builtin_amdgcn_ds_read_tr16_b64_v4f16(HS_IRC_LDS_H4(h2 + l1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jt = 0; jt < J3; ++jt) {
             half8 bh, bl;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                bh[e] = (_Float16)x0[e]; bh[4 + e] = (_Float16)x1[e];
-                bl[e] = (_Float16)y0v[e]; bl[4 + e] = (_Float16)y1v[e];
+                bh[e] = (_Float16)xr[jt][0][e]; bh[4 + e] = (_Float16)xr[jt][1][e];
+                bl[e] = (_Float16)xr[jt][2][e]; bl[4 + e] = (_Float16)xr[jt][3][e];
             }
 #pragma unroll
             for (int m = 0; m < MT3; ++m) {
@@ -623,41 +775,68 @@ void patch_irc_kernel(IrcArgs a) {
         }
     }
 
-    // ---- epilogue: bn3 + store (64-byte row runs) ----
+    // ---- epilogue: bn3 + store ----
     float* __restrict__ yb = a.y + (size_t)b * cout * plane;
+#ifdef HS_IRC_WIDE_STORE
+    // Measured and NOT kept (visit r4b, same box: 27.48 us against 26.70 with the dword stores below): through LDS (h1 is dead since the last depthwise stage; slower waves may still read h2): the accumulator layout gives a store
+    // instruction 16 lanes x 4 bytes per 64-byte row run -- 8 MT3 J3 scattered dword stores per lane, a store-issue-bound tail.
+    // Re-laid as [channel][row][16 pixels], a lane stores 16 bytes and the region leaves in cout / 4 instructions per lane.
+    if (cout * RH * RW <= G::H1_FLOATS) {
 #pragma unroll
-    for (int m = 0; m < MT3; ++m) {
+        for (int m = 0; m < MT3; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int o = m * 16 + 4 * lk + r;
-            if (o < cout) {
-                const float sc = s3f[o], sh = b3l[o];
+            for (int r = 0; r < 4; ++r) {
+                const int o = m * 16 + 4 * lk + r;
+                const float sc = s3f[min(o, CP - 1)], sh = b3l[min(o, CP - 1)];
+                if (o < cout) {
 #pragma unroll
-                for (int jt = 0; jt < J3; ++jt)
-                    yb[(unsigned)o * plane + (unsigned)((y0 + wave + NW * jt) * W + x0 + lrow)] = fmaf(acc3[m][jt][r], sc, sh);
+                    for (int jt = 0; jt < J3; ++jt) h1[(o * RH + wave + NW * jt) * RW + lrow] = fmaf(acc3[m][jt][r], sc, sh);
+                }
+            }
+        __syncthreads();
+        const int nq = cout * RH * (RW / 4);
+        for (int q = tid; q < nq; q += NTHR) {
+            const int xq = q & 3, row = (q >> 2) & (RH - 1), o = q / (4 * RH);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(h1 + (o * RH + row) * RW + 4 * xq);
+            *reinterpret_cast<f32x4*>(yb + (unsigned)o * plane + (unsigned)((y0 + row) * W + x0 + 4 * xq)) = v;
+        }
+    } else
+#endif
+    {
+#pragma unroll
+        for (int m = 0; m < MT3; ++m) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = m * 16 + 4 * lk + r;
+                if (o < cout) {
+                    const float sc = s3f[o], sh = b3l[o];
+#pragma unroll
+                    for (int jt = 0; jt < J3; ++jt)
+                        yb[(unsigned)o * plane + (unsigned)((y0 + wave + NW * jt) * W + x0 + lrow)] = fmaf(acc3[m][jt][r], sc, sh);
+                }
             }
         }
     }
     // @stamp 24
 }
 
-template <int SPL, int PPL, int MT3, int RH_>
+template <int SPL, int PPL, int MT3, int RH_, int NW_ = 4>
 static int launch_irc(IrcArgs& a, hipStream_t stream) {
-    using G = IrcGeom<RH_>;
+    using G = IrcGeom<RH_, NW_>;
     const int cin = 2 + a.in.c_skip + a.in.c_prev;
     const IrcLds L = irc_lds_map(cin, a.hid, a.cout, MT3, G::H1_FLOATS, G::H2_HALFS);
     if (L.total > 160 * 1024) return 1;
     if (a.y == nullptr) return HS_OK;                         // route query (hs_patch_ir_route): covered, nothing is launched
     if (L.total > 64 * 1024) {
         static std::atomic<unsigned long long> done{0};
-        const int e = allow_full_lds((const void*)patch_irc_kernel<SPL, PPL, MT3, RH_>, done);
+        const int e = allow_full_lds((const void*)patch_irc_kernel<SPL, PPL, MT3, RH_, NW_>, done);
         if (e != HS_OK) return e;
     }
     a.sub_y = a.ph / G::RH; a.sub_x = a.pw / G::RW;
     a.m_nsub = magic_of((unsigned)(a.sub_y * a.sub_x)); a.m_subx = magic_of((unsigned)a.sub_x);
     a.m_fw = magic_of((unsigned)a.fw); a.m_fh = magic_of((unsigned)a.fh);
     const long blocks = (long)a.in.B * a.fh * a.fw * a.sub_y * a.sub_x;
-    hipLaunchKernelGGL((patch_irc_kernel<SPL, PPL, MT3, RH_>), dim3((unsigned)blocks), dim3(64 * G::NW), (size_t)L.total, stream, a);
+    hipLaunchKernelGGL((patch_irc_kernel<SPL, PPL, MT3, RH_, NW_>), dim3((unsigned)blocks), dim3(64 * G::NW), (size_t)L.total, stream, a);
     return launch_status();
 }
 
@@ -678,20 +857,21 @@ int try_launch_irc(const StageIn& in, int fh, int fw, const float* bank, long ld
     // 32-bit element offsets from uniform bases
     if ((size_t)in.H * in.W * (size_t)(c_out > cs ? c_out : cs) >= (1u << 30) || (size_t)cp * in.Hp * in.Wp >= (1u << 30)) return 1;
     {   // rows past the last hidden channel are read unmasked and must meet finite f16 data: the W1 hi image overruns into the lo
-        // image, the lo image into W3 (irc_lds_map); the raw bank + BN rows and the phase-2 tiles must fit the h1 | h2 scratch
+        // image, the lo image into W3 (irc_lds_map); the raw bank has its own landing zone (sized by irc_lds_map, checked in launch_irc)
         const int cin = 2 + cs + cp, cinp = (cin + 1) & ~1, hidp = (hid + 1) & ~1, HP = (hid + 15) & ~15;
         if ((HP - hid) * cinp > hid * cinp || (HP - hid) * cinp > 2 * c_out * hidp + 32) return 1;
-        const int bank_n = cin * hid + 9 * hid + hid * c_out;
-        const int scratch = (a.ph % 16 == 0 ? IrcGeom<16>::H1_FLOATS * 4 + IrcGeom<16>::H2_HALFS * 2 : IrcGeom<8>::H1_FLOATS * 4 + IrcGeom<8>::H2_HALFS * 2);
-        if (((bank_n * 4 + 1023) & ~1023) + (2 * HP + 32) * 4 > scratch) return 1;
         if (ld * 4 < 16 || (ld & 3) != 0 || ((size_t)bank & 15) != 0) return 1;      // the bank DMA moves 16-byte pieces of 16-byte aligned rows (base included)
+        if (y && ((size_t)y & 15) != 0) return 1;                                     // the epilogue stores 16-byte quads
     }
     // region height: 16 rows (a workgroup of 4 fat waves per 16 x 16 region: the per-workgroup work -- splitting the patch's bank,
     // tile shuffles, index arithmetic -- is paid once per 256 pixels) whenever the patch allows, else 8
     const bool tall = a.ph % 16 == 0;
+#ifndef HS_IRC_NW
+#define HS_IRC_NW 4          // waves per 16 x 16 region (dev A/B knob: tools/build_variants.py irc_nw8)
+#endif
 #define HS_IRC_CASE(SPL, PPL) \
     if (cs <= 4 * SPL && cp <= 4 * PPL) { \
-        if (tall) return c_out <= 16 ? launch_irc<SPL, PPL, 1, 16>(a, stream) : launch_irc<SPL, PPL, 2, 16>(a, stream); \
+        if (tall) return c_out <= 16 ? launch_irc<SPL, PPL, 1, 16, HS_IRC_NW>(a, stream) : launch_irc<SPL, PPL, 2, 16, HS_IRC_NW>(a, stream); \
         return c_out <= 16 ? launch_irc<SPL, PPL, 1, 8>(a, stream) : launch_irc<SPL, PPL, 2, 8>(a, stream); \
     }
     HS_IRC_CASE(1, 2)      // <= 4 skip + <= 8 previous-level channels

@@ -18,6 +18,10 @@ BN_EPS_DEFAULT = 1e-5
 # Late-level banks on a second stream: saves ~14 us of decoder time in isolation, but a forked/joined capture makes
 # the whole-model HIP-graph replay 0.37 ms SLOWER on ROCm 7.2 (measured: 3.62 -> 3.99 ms/frame), so it is off by default.
 USE_SIDE_STREAM = os.environ.get('HS_SIDE_STREAM', '0') == '1'
+# Round 4: the finer fork -- level 0's bank on the current stream, every later level's bank as its own launch on the side stream
+# with one event each, so level l waits for ITS bank only and signal2weights overlaps the latency-bound k = 1 levels
+# (HS_SIDE_STREAM=2; measured by tools/gpu_r4c.sh, decision in DESIGN section 3.1).
+PIPELINE_BANKS = os.environ.get('HS_SIDE_STREAM', '0') == '2'
 
 
 def _round_up(n, m):
@@ -231,14 +235,18 @@ S2W_BLOCKED = os.environ.get('HS_S2W_BLOCKED', '1') == '1'     # dev A/B switch:
 
 
 @_on_operand_device
-def signal2weights_multi(signal, layers):
+def signal2weights_multi(signal, layers, buf=None):
     """All signal2weights layers of a decoder in ONE launch.  ``layers``: list of dicts with wsw_t, signal_index,
-    signal_channels, groups, rows.  Returns one BankRef per layer (views of one buffer)."""
+    signal_channels, groups, rows.  Returns one BankRef per layer (views of one buffer; ``buf``: the caller's, at least
+    ``bank_floats(signal, layers)`` floats -- for callers that issue the launch on another stream than the one that owns the memory)."""
     b, c_view, fh, fw = signal.shape
     signal, sig_ptr, c_signal = _channel_view(signal, 'signal')
     p = b * fh * fw
     lds = [_round_up(l['rows'], 4) for l in layers]
-    buf = torch.empty(p * sum(lds), device=signal.device, dtype=torch.float32)
+    if buf is None:
+        buf = torch.empty(p * sum(lds), device=signal.device, dtype=torch.float32)
+    elif buf.numel() < p * sum(lds) or buf.dtype != torch.float32 or not buf.is_contiguous():
+        raise ValueError('signal2weights_multi: buf is too small / not contiguous fp32')
     arr = (_hip.S2wLayerC * len(layers))()
     refs, off = [], 0
     for i, (l, ld) in enumerate(zip(layers, lds)):
@@ -255,6 +263,12 @@ def signal2weights_multi(signal, layers):
     st = _hip.lib.hs_signal2weights_multi_fwd(sig_ptr, b, c_signal, fh, fw, arr, len(layers), _hip.stream_ptr())
     _hip.check(st, 'hs_signal2weights_multi_fwd')
     return refs
+
+
+def bank_floats(signal, layers):
+    """Floats of the buffer :func:`signal2weights_multi` needs for ``layers``."""
+    b, _, fh, fw = signal.shape
+    return b * fh * fw * sum(_round_up(l['rows'], 4) for l in layers)
 
 
 class SideStream:

@@ -535,7 +535,27 @@ class MultiScaleDecoder(EpochOnModeSwitch, nn.Module):
                 p = HF.upsample_bilinear(p, x[0].shape[2:], out=getattr(self, 'output_buffer', None))
             return p
         side = join_level = None
-        if 0 < n_early < len(flat) and s.is_cuda and HF.USE_SIDE_STREAM:
+        bank_events = {}
+        if HF.PIPELINE_BANKS and s.is_cuda and len(groups) > 1 and len(groups[0]) > 0:
+            # level 0's bank on this stream; each later level's bank = one launch on the side stream + one event: level l waits
+            # for ITS bank only.  Bank memory is allocated here (this stream owns it); under capture the events become graph edges.
+            main = torch.cuda.current_stream(s.device)
+            fork = HF.SideStream.get(s.device)
+            per_level, k = [], 0
+            for g in groups:
+                per_level.append(layers[k:k + len(g)])
+                k += len(g)
+            bufs = [torch.empty(HF.bank_floats(s, ls), device=s.device, dtype=torch.float32) if ls else None for ls in per_level]
+            fork.wait_stream(main)
+            refs = HF.signal2weights_multi(s, per_level[0], buf=bufs[0])
+            with torch.cuda.stream(fork):
+                for l in range(1, len(per_level)):
+                    if per_level[l]:
+                        refs = refs + HF.signal2weights_multi(s, per_level[l], buf=bufs[l])
+                        ev = torch.cuda.Event()
+                        ev.record(fork)
+                        bank_events[l] = ev
+        elif 0 < n_early < len(flat) and s.is_cuda and HF.USE_SIDE_STREAM:
             main = torch.cuda.current_stream(s.device)      # the MODEL's device, not the caller's current one
             side = HF.SideStream.get(s.device)
             side.wait_stream(main)
@@ -560,11 +580,15 @@ class MultiScaleDecoder(EpochOnModeSwitch, nn.Module):
             if side is not None and level == join_level:
                 torch.cuda.current_stream(s.device).wait_stream(side)
                 side = None
+            if level in bank_events:
+                torch.cuda.current_stream(s.device).wait_event(bank_events.pop(level))
             # cat(coords, skip, bilinear(p)) is never built: the stage kernel's prologue generates it
             stage = HF.StageInput(x[-level - 1], p, coords=True)
             p = level_layers(stage, banks[level])
         if side is not None:
             torch.cuda.current_stream(s.device).wait_stream(side)
+        for ev in bank_events.values():                     # (the out_fc's bank, or a level without hyper modules: join before leaving)
+            torch.cuda.current_stream(s.device).wait_event(ev)
         if self.out_fc is not None:
             p = self.out_fc(p, banks[-1])
         if masks:

@@ -124,7 +124,21 @@ VARIANTS = {
     'k1m_256': dict(flags=['-DHS_K1M_MIN_PATCHES=256'], extra=[], patch=None),            # ... from 256 patches (HyperSeg-M level 1: 512)
     'k1m_off': dict(flags=['-DHS_K1M_MIN_PATCHES=2000000000'], extra=[], patch=None),   # batched k = 1 levels on the LDS-staged kernel
     's2b_light_first': dict(flags=['-DHS_S2B_LIGHT_FIRST'], extra=[], patch=None),
+    'irc_wide_store': dict(flags=['-DHS_IRC_WIDE_STORE'], extra=[], patch=None),         # round 4: the level-4 epilogue re-laid through LDS into 16-byte stores (measured slower)
+    'irc_nw8': dict(flags=['-DHS_IRC_NW=8'], extra=[], patch=None),                      # round 4: eight waves per 16 x 16 region (four per SIMD at two workgroups per CU)
+    'irc_r3': dict(flags=[], extra=[], patch='irc_r3', file='hs_patch_irc.hip'),          # round 3's level-4 kernel
 }
+
+def r3_irc_source():
+    """Round 3's hs_patch_irc.hip (git show e068d5a:...), for same-box A/B runs against the round-4 prologue."""
+    import subprocess
+    os.makedirs(os.path.join(B.LIB_DIR, 'dev_src'), exist_ok=True)
+    path = os.path.join(B.LIB_DIR, 'dev_src', 'hs_patch_irc_r3.hip')
+    src = subprocess.run(['git', 'show', 'e068d5a:hyperseg_amd/csrc/hs_patch_irc.hip'], cwd=B.REPO, capture_output=True, text=True, check=True).stdout
+    # the route query of round 4 passes a null y; round 3's launcher is otherwise ABI-compatible
+    open(path, 'w').write(src)
+    return path
+
 
 if __name__ == '__main__':
     for name in (sys.argv[1:] or VARIANTS):
@@ -133,7 +147,7 @@ if __name__ == '__main__':
         sources = list(B.SOURCES) + v['extra']
         if v.get('patch'):
             fname = v.get('file', 'hs_patch_ir_fused.hip')
-            src_path = stamped_irc_source() if v['patch'] == 'irc' else stamped_source(fname) if v['patch'] is True else \
+            src_path = r3_irc_source() if v['patch'] == 'irc_r3' else stamped_irc_source() if v['patch'] == 'irc' else stamped_source(fname) if v['patch'] is True else \
                 patched_source(v['patch'], PATCHES[v['patch']], fname)
             rel = os.path.relpath(src_path, B.CSRC)
             sources = [rel if s == fname else s for s in sources]

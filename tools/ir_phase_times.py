@@ -25,8 +25,8 @@ live = st[:, 24] > 0
 st = st[live]
 print(f'{name}: {live.sum()} workgroups stamped (the LAST inverted-residual launch of the decoder)')
 if os.environ.get('HS_STAMP_LABELS', 'irc') == 'irc':          # hs_patch_irc.hip ('stamps_irc' build)
-    labels = {0: 'start', 1: 'every load issued, BN rows stored', 2: 'barrier (DMA landed)', 3: 'bank split LDS -> LDS', 4: 'barrier',
-              5: 'tiles + tap tables -> scratch', 6: 'barrier', 7: 'B fragments built', 8: 'barrier', 9: 'pw1(0) + barrier',
+    labels = {0: 'start', 1: 'tile loads issued, BN rows stored', 2: 'tiles + tap tables -> scratch, bank DMA issued', 3: 'barrier',
+              4: 'B fragments built', 5: 'barrier (DMA landed)', 6: 'bank split LDS -> LDS', 7: 'barrier', 9: 'pw1(0) + barrier',
               24: 'epilogue stores issued'}
     for c in range(3):
         labels[10 + 4 * c] = f'dw[{c}{"+" if c == 2 else ""}]'
@@ -49,7 +49,7 @@ for k in sorted(labels):
         continue
     rel = col - st[:, 0]
     d = (col - st[:, prev]) if prev is not None else rel
-    print(f'  stamp {k:2d} {labels[k]:26s} since start: mean {rel.mean():9.0f}  | phase: mean {d.mean():8.0f} min {d.min():8.0f} max {d.max():8.0f}')
+    print(f'  stamp {k:2d} {labels[k]:46s} since start: mean {rel.mean():9.0f}  | phase: mean {d.mean():8.0f} min {d.min():8.0f} max {d.max():8.0f}')
     prev = k
 # residency: workgroups per CU over time, from (XCC id, HW_ID) of wave 0 of every workgroup
 hw = st[:, 31]
