@@ -60,7 +60,10 @@ def _load():
         'hs_bn_fold_fwd': ([vp, vp, vp, vp, C.c_float, i32, vp, vp, vp], C.c_int),
         'hs_patch_conv_fwd': ([C.POINTER(StageInputC), i32, i32, vp, i64, i32, i32, i32, i32, i32,
                                C.POINTER(EpilogueC), vp, vp], C.c_int),
+        'hs_patch_conv_s2w_fwd': ([C.POINTER(StageInputC), i32, i32, vp, i64, i32, i32, C.POINTER(EpilogueC), vp,
+                                   vp, i32, i32, i32, i32, C.POINTER(S2wLayerC), i32, vp], C.c_int),
         'hs_meta_conv_fwd': ([vp, i32, i32, i32, i32, vp, i64] + [i32] * 13 + [C.POINTER(EpilogueC), vp, vp], C.c_int),
+        'hs_meta_conv_bwd': ([vp, i32, i32, i32, i32, vp, i64] + [i32] * 12 + [vp, vp, vp, i64, vp], C.c_int),
         'hs_patch_conv_gen_fwd': ([C.POINTER(StageInputC), i32, i32, vp, i32, C.POINTER(S2wLayerC), i32,
                                    C.POINTER(EpilogueC), vp, vp], C.c_int),
         'hs_patch_ir_fwd': ([C.POINTER(StageInputC), i32, i32, vp, i64, i32, i32, C.POINTER(EpilogueC),
@@ -116,7 +119,7 @@ def _load():
 
 lib = _load()
 EXPORTS = ['hs_version', 'hs_build_info', 'hs_signal2weights_fwd', 'hs_signal2weights_multi_fwd', 'hs_s2w_pack_floats', 'hs_s2w_pack_fwd', 'hs_bank_pack_fwd', 'hs_bn_fold_fwd',
-           'hs_patch_conv_fwd', 'hs_meta_conv_fwd', 'hs_patch_conv_gen_fwd', 'hs_patch_ir_fwd', 'hs_patch_ir_v0_fwd', 'hs_patch_ir_v0_ws_fwd', 'hs_patch_ir_v0_workspace', 'hs_patch_ir_route', 'hs_ir_tile_map', 'hs_upsample_bilinear_fwd', 'hs_upsample_argmax_fwd',
+           'hs_patch_conv_fwd', 'hs_patch_conv_s2w_fwd', 'hs_meta_conv_fwd', 'hs_meta_conv_bwd', 'hs_patch_conv_gen_fwd', 'hs_patch_ir_fwd', 'hs_patch_ir_v0_fwd', 'hs_patch_ir_v0_ws_fwd', 'hs_patch_ir_v0_workspace', 'hs_patch_ir_route', 'hs_ir_tile_map', 'hs_upsample_bilinear_fwd', 'hs_upsample_argmax_fwd',
            'hs_stage_input_fwd', 'hs_depthwise_conv_fwd', 'hs_depthwise_pool_blocks', 'hs_stem_conv_fwd', 'hs_mbconv_tiles', 'hs_mbconv_expand_dw_fwd', 'hs_se_gate_fwd', 'hs_pointwise_conv_fwd', 'hs_affine_act_fwd', 'hs_gemm_split_kp', 'hs_gemm_split_fwd', 'hs_gemm_split_conv2x2_fwd', 'hs_gemm_split_up2_fwd', 'hs_pooled_shift_fwd', 'hs_patch_conv_bwd_input',
            'hs_patch_conv_bwd_weight', 'hs_halo_tiles_fwd', 'hs_halo_tiles_bwd', 'hs_tile_interior_fwd', 'hs_tile_interior_bwd',
            'hs_bootstrap_mean_workspace', 'hs_bootstrap_mean_fwd', 'hs_bootstrap_mean_bwd', 'hs_bn_train_workspace', 'hs_upsample_bilinear_bwd', 'hs_bank_unpack_fwd', 'hs_bn_act_train_fwd',

@@ -252,6 +252,63 @@ class BootstrapMean(torch.autograd.Function):
         return gv, None, None
 
 
+class MetaConvGeneral(torch.autograd.Function):
+    """MetaConv2d with stride / dilation / any zero padding (hs_meta_conv_fwd) under autograd: backward = hs_meta_conv_bwd (input-
+    and per-sample weight-gradient gather kernels).  fp32; the non-zero padding modes are padded by the caller with F.pad, whose
+    adjoint autograd already has (the reference does exactly that, meta_conv.py:175-181)."""
+
+    @staticmethod
+    def forward(ctx, x, w, c_out, kernel_size, stride, pads, dilation, groups):
+        x, w = x.contiguous().float(), (w if w.stride(1) == 1 else w.contiguous()).float()
+        (kh, kw), (sh, sw), (pt, pb, pl, pr), (dh, dw) = kernel_size, stride, pads, dilation
+        b, cin, h, wd = x.shape
+        ho = (h + pt + pb - dh * (kh - 1) - 1) // sh + 1
+        wo = (wd + pl + pr - dw * (kw - 1) - 1) // sw + 1
+        if ho <= 0 or wo <= 0:
+            raise ValueError(f'kernel {kernel_size} (dilation {dilation}) does not fit the padded {h}x{wd} input')
+        y = torch.empty(b, c_out, ho, wo, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            st = _hip.lib.hs_meta_conv_fwd(_hip.dev_ptr(x, 'x'), b, cin, h, wd, _hip.dev_ptr(w, 'w'), w.stride(0), c_out, kh, kw,
+                                           sh, sw, pt, pb, pl, pr, dh, dw, 0, groups, None, y.data_ptr(), _hip.stream_ptr())
+            _hip.check(st, 'hs_meta_conv_fwd')
+        ctx.save_for_backward(x, w)
+        ctx.meta = (c_out, kernel_size, stride, pads, dilation, groups)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        c_out, (kh, kw), (sh, sw), (pt, pb, pl, pr), (dh, dw), groups = ctx.meta
+        dy = dy.contiguous().float()
+        b, cin, h, wd = x.shape
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        rows = c_out * (cin // groups) * kh * kw
+        dwt = None
+        if ctx.needs_input_grad[1]:
+            dwt = (torch.empty if rows == w.shape[1] else torch.zeros)(w.shape, device=w.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            st = _hip.lib.hs_meta_conv_bwd(x.data_ptr(), b, cin, h, wd, w.data_ptr(), w.stride(0), c_out, kh, kw, sh, sw, pt, pb, pl, pr,
+                                           dh, dw, groups, dy.data_ptr(), dx.data_ptr() if dx is not None else None,
+                                           dwt.data_ptr() if dwt is not None else None, dwt.stride(0) if dwt is not None else 0,
+                                           _hip.stream_ptr())
+            _hip.check(st, 'hs_meta_conv_bwd')
+        return dx, dwt, None, None, None, None, None, None
+
+
+def meta_conv_general(x, w, c_out, kernel_size, stride, padding, dilation, padding_mode, groups):
+    """The general MetaConv2d under autograd (meta_conv.py:163-186): explicit F.pad for the non-zero modes in the reference's own
+    (quirky) order -- ``padding + padding`` = (ph, pw, ph, pw) read by F.pad as (left, right, top, bottom) -- then the zero-padding
+    Function above."""
+    import torch.nn.functional as F
+    ph, pw = padding
+    if padding_mode != 'zeros' and (ph or pw):
+        x = F.pad(x, (ph, pw, ph, pw), mode=padding_mode)
+        pads = (0, 0, 0, 0)
+    else:
+        pads = (ph, ph, pw, pw)
+    return MetaConvGeneral.apply(x, w, c_out, tuple(kernel_size), tuple(stride), pads, tuple(dilation), groups)
+
+
 def patch_conv_apply(*args):
     """``PatchConv.apply`` behind the one check its ``custom_fwd`` cannot make (autocast is already off inside it)."""
     if torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') != torch.bfloat16:

@@ -49,9 +49,98 @@ void meta_conv_kernel(MetaConvArgs a) {
     }
 }
 
+// ---- backward of the general form (round 4; zero padding -- the other modes pad explicitly with F.pad on the Python side, whose
+// adjoint autograd already has).  Gather forms, no atomics, deterministic.
+//   dX[b,c,iy,ix] = sum_{o in group(c)} sum_{ky,kx} W[b,o,c',ky,kx] dY[b,o,oy,ox]   where oy sh - pt + ky dh == iy, likewise x
+//   dW[b,m]       = sum_{oy,ox} dY[b,o,oy,ox] X[b, g cin_g + c', oy sh - pt + ky dh, ox sw - pl + kx dw]     m = ((o cin_g + c') kh + ky) kw + kx
+struct MetaConvBwdArgs {
+    const float* __restrict__ x; const float* __restrict__ w; long ldw; const float* __restrict__ dy;
+    float* __restrict__ dx; float* __restrict__ dwt; long lddw;
+    int Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, groups, Ho, Wo;
+};
+
+__global__ __launch_bounds__(256)
+void meta_conv_bwd_input_kernel(MetaConvBwdArgs a) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int cg = a.Cin / a.groups, og = a.Cout / a.groups, g = c / cg, cl = c - g * cg;
+    const int nf = cg * a.kh * a.kw;
+    const float* __restrict__ wb = a.w + (size_t)b * a.ldw;
+    const float* __restrict__ dyb = a.dy + ((size_t)b * a.Cout + (size_t)g * og) * a.Ho * a.Wo;
+    float* __restrict__ dxc = a.dx + ((size_t)b * a.Cin + c) * a.H * a.W;
+    const int npix = a.H * a.W;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < npix; p += gridDim.x * 256) {
+        const int iy = p / a.W, ix = p - iy * a.W;
+        float acc = 0.0f;
+        for (int ky = 0; ky < a.kh; ++ky) {
+            const int ty = iy + a.ph - ky * a.dh;
+            if (ty < 0 || ty % a.sh != 0) continue;
+            const int oy = ty / a.sh;
+            if (oy >= a.Ho) continue;
+            for (int kx = 0; kx < a.kw; ++kx) {
+                const int tx = ix + a.pw - kx * a.dw;
+                if (tx < 0 || tx % a.sw != 0) continue;
+                const int ox = tx / a.sw;
+                if (ox >= a.Wo) continue;
+                for (int o = 0; o < og; ++o)
+                    acc = fmaf(wb[(size_t)(g * og + o) * nf + (cl * a.kh + ky) * a.kw + kx], dyb[((size_t)o * a.Ho + oy) * a.Wo + ox], acc);
+            }
+        }
+        dxc[p] = acc;
+    }
+}
+
+__global__ __launch_bounds__(64)
+void meta_conv_bwd_weight_kernel(MetaConvBwdArgs a) {
+    const int m = blockIdx.x, b = blockIdx.y;              // one wave per weight of one sample
+    const int cg = a.Cin / a.groups, og = a.Cout / a.groups;
+    const int kx = m % a.kw, ky = (m / a.kw) % a.kh, cl = (m / (a.kw * a.kh)) % cg, o = m / (a.kw * a.kh * cg);
+    const int g = o / og;
+    const float* __restrict__ xc = a.x + ((size_t)b * a.Cin + (size_t)g * cg + cl) * a.H * a.W;
+    const float* __restrict__ dyo = a.dy + ((size_t)b * a.Cout + o) * a.Ho * a.Wo;
+    float acc = 0.0f;
+    const int npix = a.Ho * a.Wo;
+    for (int p = threadIdx.x; p < npix; p += 64) {
+        const int oy = p / a.Wo, ox = p - oy * a.Wo;
+        const int iy = oy * a.sh - a.ph + ky * a.dh, ix = ox * a.sw - a.pw + kx * a.dw;
+        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) acc = fmaf(dyo[p], xc[(size_t)iy * a.W + ix], acc);
+    }
+    acc = wave_sum64(acc);
+    if (threadIdx.x == 0) a.dwt[(size_t)b * a.lddw + m] = acc;
+}
+
 }  // namespace hs
 
 using namespace hs;
+
+extern "C" int hs_meta_conv_bwd(const float* x, int32_t batch, int32_t c_in, int32_t H, int32_t W, const float* w, int64_t ldw,
+                                int32_t c_out, int32_t kh, int32_t kw, int32_t stride_h, int32_t stride_w, int32_t pad_top,
+                                int32_t pad_bottom, int32_t pad_left, int32_t pad_right, int32_t dil_h, int32_t dil_w, int32_t groups,
+                                const float* dy, float* dx, float* dw, int64_t lddw, void* stream) {
+    if (!x || !w || !dy || (!dx && !dw) || batch <= 0 || c_in <= 0 || c_out <= 0 || H <= 0 || W <= 0 || kh <= 0 || kw <= 0 || stride_h <= 0 ||
+        stride_w <= 0 || pad_top < 0 || pad_bottom < 0 || pad_left < 0 || pad_right < 0 || dil_h <= 0 || dil_w <= 0 || groups <= 0) return HS_ERR_BAD_ARG;
+    if (c_in % groups != 0 || c_out % groups != 0) return HS_ERR_BAD_ARG;
+    const long nf = (long)(c_in / groups) * kh * kw;
+    if (ldw < nf * c_out || (dw && lddw < nf * c_out)) return HS_ERR_BAD_ARG;
+    const int eh = H + pad_top + pad_bottom - dil_h * (kh - 1) - 1, ew = W + pad_left + pad_right - dil_w * (kw - 1) - 1;
+    if (eh < 0 || ew < 0) return HS_ERR_BAD_ARG;
+    if (batch > 65535 || c_in > 65535 || nf * c_out > 2147483647L) return HS_ERR_UNSUPPORTED;
+    MetaConvBwdArgs a;
+    a.x = x; a.w = w; a.ldw = ldw; a.dy = dy; a.dx = dx; a.dwt = dw; a.lddw = lddw;
+    a.Cin = c_in; a.H = H; a.W = W; a.Cout = c_out; a.kh = kh; a.kw = kw; a.sh = stride_h; a.sw = stride_w;
+    a.ph = pad_top; a.pw = pad_left; a.dh = dil_h; a.dw = dil_w; a.groups = groups; a.Ho = eh / stride_h + 1; a.Wo = ew / stride_w + 1;
+    if (dx) {
+        const long npix = (long)H * W;
+        const unsigned strips = (unsigned)((npix + 255) / 256 > 1024 ? 1024 : (npix + 255) / 256);
+        hipLaunchKernelGGL(meta_conv_bwd_input_kernel, dim3(strips, c_in, batch), dim3(256), 0, (hipStream_t)stream, a);
+        const int st = launch_status();
+        if (st != HS_OK) return st;
+    }
+    if (dw) {
+        hipLaunchKernelGGL(meta_conv_bwd_weight_kernel, dim3((unsigned)(nf * c_out), batch), dim3(64), 0, (hipStream_t)stream, a);
+        return launch_status();
+    }
+    return HS_OK;
+}
 
 extern "C" int hs_meta_conv_fwd(const float* x, int32_t batch, int32_t c_in, int32_t H, int32_t W, const float* w, int64_t ldw,
                                 int32_t c_out, int32_t kh, int32_t kw, int32_t stride_h, int32_t stride_w, int32_t pad_top,

@@ -8,6 +8,8 @@
 // These levels (k=1 levels 0-2 of HyperSeg-M/S, and every v0_1 conv) are bound by the bank read:
 // bytes/patch = hp*4, FLOPs/patch = 2*hp*ph*pw.
 #include "hs_common.h"
+#include "hs_s2w_blocked.h"
+#include <cstddef>
 
 namespace hs {
 
@@ -114,12 +116,9 @@ struct Conv1Args {
 // instead of run-time integer divisions, which were a third of this kernel's ~970 vector instructions per wave
 // (profiles/round3_pmc_k1_and_s2w.txt).  PWL = -1: any patch size.
 template <int PWL>
-__global__ __launch_bounds__(CONV_THREADS)
-void patch_conv1x1_kernel(Conv1Args a) {
+__device__ __forceinline__ void conv1x1_body(const Conv1Args& a, const int patch, float* __restrict__ lds) {
     const int ph_ = PWL >= 0 ? (1 << PWL) : a.ph, pw_ = PWL >= 0 ? (1 << PWL) : a.pw;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
-    const int patch = blockIdx.x;
     const int pib = patch / a.fw, j = patch - pib * a.fw, b = pib / a.fh, i = pib - b * a.fh;
     const int cin = a.in.cin();
     const int npix = ph_ * pw_;
@@ -272,6 +271,38 @@ void patch_conv1x1_kernel(Conv1Args a) {
             const int u = pix / pw_, v = pix - u * pw_;
             a.y[(((size_t)b * a.cout + o) * a.in.H + (i * ph_ + u)) * a.in.W + (j * pw_ + v)] = acc;
         }
+    }
+}
+
+template <int PWL>
+__global__ __launch_bounds__(CONV_THREADS)
+void patch_conv1x1_kernel(Conv1Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    conv1x1_body<PWL>(a, (int)blockIdx.x, lds);
+}
+
+// Heterogeneous launch (round 4): workgroups [0, conv_blocks) are the k = 1 patch convolution's, the rest are blocked
+// signal2weights workgroups producing the banks of LATER levels.  The k = 1 levels are one workgroup per patch walking a
+// dependent chain (index arithmetic -> loads -> LDS -> barrier -> dot products -> store: ~6 us for ~2.5 us of traffic, the
+// chip mostly idle); signal2weights only depends on the signal, so its blocks fill that idle time instead of standing in
+// front of level 0 as their own 15 us launch.  (The same overlap as a forked HIP graph costs +100 us per frame on ROCm 7.2:
+// profiles/round4_irc_prologue_vs_round3_same_box_and_side_stream_ab.txt.)
+struct Conv1S2wArgs {
+    Conv1Args c;
+    int conv_blocks;
+    S2bArgs s;
+};
+
+template <int PWL>
+__global__ __launch_bounds__(CONV_THREADS)
+void patch_conv1x1_s2w_kernel(Conv1S2wArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int blk = (int)blockIdx.x;
+    if (blk < a.conv_blocks) {
+        conv1x1_body<PWL>(a.c, blk, lds);
+    } else {
+        const __attribute__((address_space(4))) char* ka = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+        s2b_body((const __attribute__((address_space(4))) S2bArgs*)(ka + offsetof(Conv1S2wArgs, s)), blk - a.conv_blocks, lds);
     }
 }
 
@@ -482,6 +513,49 @@ int try_launch_k1m(const StageIn& si, int fh, int fw, const float* bank, long ld
 
 using namespace hs;
 
+// The k = 1 whole-patch-per-workgroup form; ``co``: blocked signal2weights workgroups to run beside it (heterogeneous launch) or
+// null.  1 = the form does not apply.
+static int launch_conv1x1(const StageIn& si, int batch, int fh, int fw, int ph, int pw, const float* bank, long ld, int c_out, int groups,
+                          int cin_g, int cout_g, const float* scale, const float* shift, int act, float* y, const S2bArgs* co,
+                          hipStream_t stream) {
+    const int cin = si.cin();
+    const size_t hp4 = ((size_t)c_out * cin_g + 3) & ~(size_t)3;
+    size_t lds1 = (hp4 + (size_t)cin * ph * pw) * sizeof(float);
+    if (!(lds1 <= 96 * 1024 && (ld & 3) == 0 && ((uintptr_t)bank & 15) == 0 && ph * pw <= 4096)) return 1;
+    Conv1S2wArgs g;
+    Conv1Args& f = g.c;
+    f.in = si; f.fh = fh; f.fw = fw; f.ph = ph; f.pw = pw; f.bank = bank; f.ld = ld;
+    f.cout = c_out; f.groups = groups; f.cin_g = cin_g; f.cout_g = cout_g;
+    f.scale = scale; f.shift = shift; f.act = act; f.y = y;
+    const int outs = c_out * ph * pw;
+    int split = 1;
+    while (split < 64 && outs * split * 2 <= CONV_THREADS && split * 2 <= cin_g) split *= 2;
+    f.split = split;
+    const long conv_blocks = (long)batch * fh * fw;
+    if (co) {
+        g.conv_blocks = (int)conv_blocks;
+        g.s = *co;
+        if (lds1 < S2B_LDS_FLOATS * sizeof(float)) lds1 = S2B_LDS_FLOATS * sizeof(float);
+    }
+    const dim3 grid((unsigned)(conv_blocks + (co ? co->n_wg : 0)));
+#define HS_K1_LAUNCH(PWL) do { \
+        if (lds1 > 64 * 1024) { \
+            static std::atomic<unsigned long long> done{0}, done_co{0}; \
+            const int e = co ? allow_full_lds((const void*)patch_conv1x1_s2w_kernel<PWL>, done_co) \
+                             : allow_full_lds((const void*)patch_conv1x1_kernel<PWL>, done); \
+            if (e != HS_OK) return e; \
+        } \
+        if (co) hipLaunchKernelGGL(patch_conv1x1_s2w_kernel<PWL>, grid, dim3(CONV_THREADS), lds1, stream, g); \
+        else hipLaunchKernelGGL(patch_conv1x1_kernel<PWL>, grid, dim3(CONV_THREADS), lds1, stream, f); \
+        return launch_status(); } while (0)
+    if (ph == pw && ph == 1) HS_K1_LAUNCH(0);
+    if (ph == pw && ph == 2) HS_K1_LAUNCH(1);
+    if (ph == pw && ph == 4) HS_K1_LAUNCH(2);
+    if (ph == pw && ph == 8) HS_K1_LAUNCH(3);
+    HS_K1_LAUNCH(-1);
+#undef HS_K1_LAUNCH
+}
+
 extern "C" int hs_patch_conv_fwd(const hs_stage_input* in, int32_t fh, int32_t fw, const float* bank, int64_t ld,
                                  int32_t c_out, int32_t k, int32_t pad, int32_t pad_mode, int32_t groups,
                                  const hs_epilogue* ep, float* y, void* stream) {
@@ -513,33 +587,9 @@ extern "C" int hs_patch_conv_fwd(const hs_stage_input* in, int32_t fh, int32_t f
         if (r != 1) return r;
     }
     if (k == 1) {
-        const size_t hp4 = ((size_t)c_out * a.cin_g + 3) & ~(size_t)3;
-        const size_t lds1 = (hp4 + (size_t)cin * a.ph * a.pw) * sizeof(float);
-        if (lds1 <= 96 * 1024 && (ld & 3) == 0 && ((uintptr_t)bank & 15) == 0 && a.ph * a.pw <= 4096) {
-            Conv1Args f;
-            f.in = a.in; f.fh = fh; f.fw = fw; f.ph = a.ph; f.pw = a.pw; f.bank = bank; f.ld = ld;
-            f.cout = c_out; f.groups = groups; f.cin_g = a.cin_g; f.cout_g = a.cout_g;
-            f.scale = a.scale; f.shift = a.shift; f.act = a.act; f.y = y;
-            const int outs = c_out * a.ph * a.pw;
-            int split = 1;
-            while (split < 64 && outs * split * 2 <= CONV_THREADS && split * 2 <= a.cin_g) split *= 2;
-            f.split = split;
-            const dim3 grid((unsigned)((long)in->batch * fh * fw));
-#define HS_K1_LAUNCH(PWL) do { \
-                if (lds1 > 64 * 1024) { \
-                    static std::atomic<unsigned long long> done{0}; \
-                    const int e = allow_full_lds((const void*)patch_conv1x1_kernel<PWL>, done); \
-                    if (e != HS_OK) return e; \
-                } \
-                hipLaunchKernelGGL(patch_conv1x1_kernel<PWL>, grid, dim3(CONV_THREADS), lds1, (hipStream_t)stream, f); \
-                return launch_status(); } while (0)
-            if (a.ph == a.pw && a.ph == 1) HS_K1_LAUNCH(0);
-            if (a.ph == a.pw && a.ph == 2) HS_K1_LAUNCH(1);
-            if (a.ph == a.pw && a.ph == 4) HS_K1_LAUNCH(2);
-            if (a.ph == a.pw && a.ph == 8) HS_K1_LAUNCH(3);
-            HS_K1_LAUNCH(-1);
-#undef HS_K1_LAUNCH
-        }
+        const int r = launch_conv1x1(a.in, in->batch, fh, fw, a.ph, a.pw, bank, (long)ld, c_out, groups, a.cin_g, a.cout_g, a.scale, a.shift, a.act, y,
+                                     nullptr, (hipStream_t)stream);
+        if (r != 1) return r;
     }
     const int wrow = a.cin_g * k * k;
     a.w_stride = wrow | 1;
@@ -564,6 +614,42 @@ extern "C" int hs_patch_conv_fwd(const hs_stage_input* in, int32_t fh, int32_t f
     const long blocks = (long)in->batch * fh * fw * a.tiles_y * a.tiles_x;
     hipLaunchKernelGGL(patch_conv_kernel, dim3((unsigned)blocks), dim3(CONV_THREADS), lds, (hipStream_t)stream, a);
     return launch_status();
+}
+
+// hs_patch_conv_s2w_fwd: hs_patch_conv_fwd (k = 1, no padding) and hs_signal2weights_multi_fwd for ``layers`` in ONE launch (see
+// patch_conv1x1_s2w_kernel).  HS_ERR_UNSUPPORTED when either half would not take the form this launch is built from (the caller
+// then issues the two calls separately); nothing has been launched in that case.
+#ifndef HS_K1M_MIN_PATCHES
+#define HS_K1M_MIN_PATCHES 1024
+#endif
+extern "C" int hs_patch_conv_s2w_fwd(const hs_stage_input* in, int32_t fh, int32_t fw, const float* bank, int64_t ld, int32_t c_out,
+                                     int32_t groups, const hs_epilogue* ep, float* y,
+                                     const float* signal, int32_t batch, int32_t c_signal, int32_t sfh, int32_t sfw,
+                                     const hs_s2w_layer* layers, int32_t n_layers, void* stream) {
+    StageIn si;
+    int st = make_stage(in, &si);
+    if (st != HS_OK) return st;
+    if (!bank || !y || !signal || !layers || fh <= 0 || fw <= 0 || c_out <= 0 || groups <= 0) return HS_ERR_BAD_ARG;
+    if (n_layers <= 0 || n_layers > S2W_MAX_LAYERS || batch <= 0 || sfh <= 0 || sfw <= 0) return HS_ERR_BAD_ARG;
+    if ((size_t)batch * c_signal * sfh * sfw >= (1ull << 31)) return HS_ERR_UNSUPPORTED;     // 32-bit element offsets
+    if (in->H % fh != 0 || in->W % fw != 0) return HS_ERR_NOT_DIVISIBLE;
+    const int cin = si.cin();
+    if (cin % groups != 0 || c_out % groups != 0) return HS_ERR_BAD_ARG;
+    const int cin_g = cin / groups, cout_g = c_out / groups, ph = in->H / fh, pw = in->W / fw;
+    if (ld < (int64_t)c_out * cin_g) return HS_ERR_BAD_ARG;
+    const float* scale = ep ? ep->scale : nullptr; const float* shift = ep ? ep->shift : nullptr;
+    if (scale && !shift) return HS_ERR_BAD_ARG;
+    if (!si.coords && si.c_prev == 0) return HS_ERR_UNSUPPORTED;                   // plain inputs have their own forms
+    if (groups == 1 && ph == 2 && pw == 2 && (long)in->batch * fh * fw >= HS_K1M_MIN_PATCHES) return HS_ERR_UNSUPPORTED;   // the weight-stream form's
+    for (int i = 0; i < n_layers; ++i) {
+        const int chk = s2w_check_layer(layers[i], c_signal);
+        if (chk != HS_OK) return chk;
+    }
+    S2bArgs co;
+    if (s2b_fill_args(co, signal, batch, c_signal, sfh, sfw, layers, nullptr, n_layers) != 0) return HS_ERR_UNSUPPORTED;
+    const int r = launch_conv1x1(si, in->batch, fh, fw, ph, pw, bank, (long)ld, c_out, groups, cin_g, cout_g, scale, shift,
+                                 ep ? ep->act : HS_ACT_NONE, y, &co, (hipStream_t)stream);
+    return r == 1 ? HS_ERR_UNSUPPORTED : r;
 }
 
 extern "C" int hs_stage_input_fwd(const hs_stage_input* in, float* y, void* stream) {

@@ -1,0 +1,141 @@
+// The blocked form of signal2weights (hs_signal2weights_multi_fwd) as a workgroup BODY, shared by its own kernel (hs_weights.hip)
+// and by the heterogeneous launch of hs_patch_conv.hip, which runs these workgroups beside the k = 1 patch convolution's
+// (round 4: the k = 1 levels are latency-bound launches that leave most of the chip idle).
+#pragma once
+#include "hs_common.h"
+
+namespace hs {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int S2W_MAX_LAYERS = 8;
+
+#ifndef HS_S2B_KC
+#define HS_S2B_KC 10
+#endif
+constexpr int S2B_ROWS = 64, S2B_PATCHES = 64, S2B_KC = HS_S2B_KC;      // HS_S2B_KC: dev A/B knob (tools/build_variants.py)
+constexpr int S2B_LDS_FLOATS = 2 * S2B_KC * 256;
+
+struct S2bLayer {
+    const float* __restrict__ blk;          // packed weights (hs_s2w_pack_fwd)
+    float* __restrict__ bank;
+    long ld;
+    int signal_index, cs_g, rpg, rows, ks, rb, groups;
+    int wg_begin;                           // first workgroup of the layer
+};
+struct S2bArgs {
+    const float* __restrict__ signal;
+    int c_signal, grid_sz, n_patches, n_layers, pb, n_wg;
+    unsigned m_grid, m_pb;                  // magic multipliers: / grid_sz, / pb
+    S2bLayer layer[S2W_MAX_LAYERS];
+};
+
+__device__ __forceinline__ unsigned s2b_div(unsigned x, unsigned m) { return m ? __umulhi(x, m) : x; }
+static inline unsigned s2b_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / d + 1); }
+
+// One workgroup (256 threads) of the blocked form.  ``ka``: the arguments in the KERNEL-ARGUMENT segment (scalar loads, the layer
+// table indexed at run time), ``wg``: the workgroup's index among the blocked workgroups, ``lds``: S2B_LDS_FLOATS floats.
+__device__ __forceinline__ void s2b_body(const __attribute__((address_space(4))) S2bArgs* ka, const int wg, float* __restrict__ lds) {
+    int li = 0;
+    for (int q = 1; q < ka->n_layers; ++q)
+        if (wg >= ka->layer[q].wg_begin) li = q;
+    const float* __restrict__ blk = ka->layer[li].blk;
+    float* __restrict__ bank = ka->layer[li].bank;
+    const long ld = ka->layer[li].ld;
+    const int signal_index = ka->layer[li].signal_index, cs_g = ka->layer[li].cs_g, rpg = ka->layer[li].rpg;
+    const int rows = ka->layer[li].rows, KS = ka->layer[li].ks, RB = ka->layer[li].rb;
+    const int grid_sz = ka->grid_sz, n_patches = ka->n_patches, c_signal = ka->c_signal, PB = ka->pb;
+    const float* __restrict__ signal = ka->signal;
+    const int local = wg - ka->layer[li].wg_begin;
+    const int grb = (int)s2b_div((unsigned)local, ka->m_pb), pb = local - grb * PB;      // patch block fastest: neighbours share A
+    const int g = grb / RB, rb = grb - g * RB;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* A = lds;                                                                      // A fill | B fill; the output block aliases both
+    float* Bm = lds + S2B_KC * 256;
+    static_assert(S2B_PATCHES * (S2B_ROWS + 1) <= 2 * S2B_KC * 256, "the output block fits the operand fills");
+
+    // B source of this lane: (patch tile, k mod 4, 4 consecutive patches)
+    const int pt = lane >> 4, kq = (lane >> 2) & 3, j4 = lane & 3;
+    const int p4 = min(pb * S2B_PATCHES + 16 * pt + 4 * j4, n_patches - 4);                // whole 16-byte groups stay inside the signal
+    const int bb = (int)s2b_div((unsigned)p4, ka->m_grid), ij = p4 - bb * grid_sz;
+    const unsigned sig0 = (unsigned)((bb * c_signal + signal_index + g * cs_g) * grid_sz + ij);
+    const float* ablk = blk + (size_t)((g * RB + rb) * KS) * 256;
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < KS; k0 += S2B_KC) {
+        const int kn = min(S2B_KC, KS - k0);
+        if (k0 > 0) __syncthreads();                                                       // the previous fill has been consumed
+        for (int c = wave; c < kn; c += 4) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ablk + (size_t)(k0 + c) * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void*)(A + c * 256), 16, 0, 0);
+            const unsigned k = (unsigned)min(4 * (k0 + c) + kq, cs_g - 1);                 // k past the group reads a finite neighbour: A is zero there
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(signal + sig0 + k * (unsigned)grid_sz),
+                                             (__attribute__((address_space(3))) void*)(Bm + c * 256), 16, 0, 0);
+        }
+        __syncthreads();                                                                   // both fills have landed
+        for (int c = 0; c < kn; ++c) {
+            const float av = A[c * 256 + wave * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Bm[c * 256 + t * 64 + lane], acc[t], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                                                       // operands dead: the output block takes their place
+    {
+        const int j = lane & 15, q4 = lane >> 4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lds[(16 * t + j) * (S2B_ROWS + 1) + 16 * wave + 4 * q4 + r] = acc[t][r];
+    }
+    __syncthreads();
+    const int r0 = rb * S2B_ROWS, n0 = g * rpg + r0;
+    const bool row_ok = (r0 + lane) < rpg && (n0 + lane) < rows;
+#pragma unroll 4
+    for (int q = 0; q < 16; ++q) {
+        const int pl = wave * 16 + q, p = pb * S2B_PATCHES + pl;
+        const float v = lds[pl * (S2B_ROWS + 1) + lane];
+        if (row_ok && p < n_patches) bank[(size_t)p * ld + n0 + lane] = v;
+    }
+}
+
+
+// Host side: the launch arguments of the blocked form for ``layers`` (in the order ``order``); returns 1 when it does not apply
+// (a layer without packed weights, patches not in whole 16-byte groups, a misaligned operand), 0 otherwise.
+inline int s2b_fill_args(S2bArgs& a, const float* signal, int batch, int c_signal, int fh, int fw, const hs_s2w_layer* layers,
+                         const int* order, int n_layers) {
+    const int grid_sz = fh * fw, n_patches = batch * grid_sz;
+    if ((grid_sz & 3) != 0 || n_patches < 4) return 1;
+    if (((size_t)signal & 15) != 0) return 1;            // 16-byte global_load_lds pieces: a view with an odd storage offset takes the direct kernel
+    a.signal = signal; a.c_signal = c_signal; a.grid_sz = grid_sz; a.n_patches = n_patches; a.n_layers = n_layers;
+    a.pb = (n_patches + S2B_PATCHES - 1) / S2B_PATCHES;
+    a.m_grid = s2b_magic((unsigned)grid_sz); a.m_pb = s2b_magic((unsigned)a.pb);
+    int wgs = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        const hs_s2w_layer& l = layers[order ? order[i] : i];
+        if (!l.wsw_blk || ((size_t)l.wsw_blk & 15) != 0) return 1;
+        S2bLayer& d = a.layer[i];
+        d.blk = l.wsw_blk; d.bank = l.bank; d.ld = (long)l.ld; d.signal_index = l.signal_index;
+        d.cs_g = l.signal_channels / l.groups; d.rpg = l.wc / l.groups; d.rows = l.rows; d.groups = l.groups;
+        d.ks = (d.cs_g + 3) / 4; d.rb = (d.rpg + S2B_ROWS - 1) / S2B_ROWS;
+        d.wg_begin = wgs;
+        wgs += l.groups * d.rb * a.pb;
+    }
+    for (int i = n_layers; i < S2W_MAX_LAYERS; ++i) { a.layer[i] = a.layer[0]; a.layer[i].wg_begin = 0x7fffffff; }
+    a.n_wg = wgs;
+    return 0;
+}
+
+// argument checks shared by the entry points that take hs_s2w_layer tables
+inline int s2w_check_layer(const hs_s2w_layer& l, int c_signal) {
+    if (!l.wsw_t || !l.bank || l.groups <= 0 || l.rows <= 0 || l.wc <= 0 || l.ld < l.rows || l.rows > l.wc) return HS_ERR_BAD_ARG;
+    if (l.signal_index < 0 || l.signal_channels <= 0 || l.signal_index + l.signal_channels > c_signal) return HS_ERR_BAD_ARG;
+    if (l.signal_channels % l.groups != 0 || l.wc % l.groups != 0) return HS_ERR_BAD_ARG;
+    if (l.signal_channels / l.groups > 80) return HS_ERR_UNSUPPORTED;   // K-step register buckets stop at 20
+    return HS_OK;
+}
+
+}  // namespace hs

@@ -22,6 +22,11 @@ USE_SIDE_STREAM = os.environ.get('HS_SIDE_STREAM', '0') == '1'
 # with one event each, so level l waits for ITS bank only and signal2weights overlaps the latency-bound k = 1 levels
 # (HS_SIDE_STREAM=2; measured by tools/gpu_r4c.sh, decision in DESIGN section 3.1).
 PIPELINE_BANKS = os.environ.get('HS_SIDE_STREAM', '0') == '2'
+# Round 4: the banks of the later levels produced INSIDE the k = 1 levels' launches (CoScheduledBanks / hs_patch_conv_s2w_fwd).
+# MEASURED AND OFF (visit r4e, profiles/round4_coscheduled_banks_ab.txt): the carrying launches grow by what the riders take -- level 2
+# with bank 4 aboard 7.3 -> 15.2 us, kernel sum of (signal2weights + levels 0-2) 37.5 -> 39.4 us, replayed decoder 0.086 -> 0.087 ms.
+# signal2weights is a per-workgroup latency chain too, not idle-CU filler.  HS_COSCHEDULE_BANKS=1 switches it on.
+COSCHEDULE_BANKS = os.environ.get('HS_COSCHEDULE_BANKS', '0') == '1'
 
 
 def _round_up(n, m):
@@ -239,8 +244,17 @@ def signal2weights_multi(signal, layers, buf=None):
     """All signal2weights layers of a decoder in ONE launch.  ``layers``: list of dicts with wsw_t, signal_index,
     signal_channels, groups, rows.  Returns one BankRef per layer (views of one buffer; ``buf``: the caller's, at least
     ``bank_floats(signal, layers)`` floats -- for callers that issue the launch on another stream than the one that owns the memory)."""
-    b, c_view, fh, fw = signal.shape
+    b, _, fh, fw = signal.shape
     signal, sig_ptr, c_signal = _channel_view(signal, 'signal')
+    arr, refs = _s2w_layer_table(signal, layers, buf)
+    st = _hip.lib.hs_signal2weights_multi_fwd(sig_ptr, b, c_signal, fh, fw, arr, len(layers), _hip.stream_ptr())
+    _hip.check(st, 'hs_signal2weights_multi_fwd')
+    return refs
+
+
+def _s2w_layer_table(signal, layers, buf=None):
+    """The hs_s2w_layer table of ``layers`` over one bank buffer (allocated here unless given) + one BankRef per layer."""
+    b, c_view, fh, fw = signal.shape
     p = b * fh * fw
     lds = [_round_up(l['rows'], 4) for l in layers]
     if buf is None:
@@ -260,9 +274,30 @@ def signal2weights_multi(signal, layers, buf=None):
         a.rows, a.bank, a.ld = l['rows'], bank.data_ptr(), ld
         a.wsw_blk = s2w_packed(l['wsw_t'], l['signal_channels'], l['groups']).data_ptr() if S2W_BLOCKED else None
         refs.append(BankRef(bank, b, l['rows'], (fh, fw)))
-    st = _hip.lib.hs_signal2weights_multi_fwd(sig_ptr, b, c_signal, fh, fw, arr, len(layers), _hip.stream_ptr())
-    _hip.check(st, 'hs_signal2weights_multi_fwd')
-    return refs
+    return arr, refs
+
+
+class CoScheduledBanks:
+    """``with CoScheduledBanks(signal, layers) as co:`` -- the NEXT eligible k = 1 :func:`patch_conv` issued inside the block carries
+    the signal2weights work of ``layers`` in its own launch (hs_patch_conv_s2w_fwd: a heterogeneous launch, the bank producer's
+    blocks filling the idle CUs of a latency-bound k = 1 level).  On exit ``co.refs`` holds one BankRef per layer either way:
+    if no launch took the work (or the library said HS_ERR_UNSUPPORTED) it is issued as its own launch then."""
+    _active = None
+
+    def __init__(self, signal, layers):
+        self.signal, self.layers, self.refs, self.carried = signal, list(layers), None, False
+
+    def __enter__(self):
+        if CoScheduledBanks._active is not None:
+            raise RuntimeError('CoScheduledBanks blocks do not nest')
+        CoScheduledBanks._active = self if self.layers else None
+        return self
+
+    def __exit__(self, *exc):
+        CoScheduledBanks._active = None
+        if self.refs is None and exc[0] is None:
+            self.refs = signal2weights_multi(self.signal, self.layers) if self.layers else []
+        return False
 
 
 def bank_floats(signal, layers):
@@ -332,6 +367,18 @@ def patch_conv(x, grid, bank, c_out, k=1, padding=0, padding_mode='reflect', gro
     ep = _epilogue(scale, shift, act)
     y = torch.empty(b, c_out, h, w, device=stage.device, dtype=torch.float32)
     bank_ptr, ld = _bank_ptr(bank)
+    co = CoScheduledBanks._active
+    if co is not None and k == 1 and padding == 0 and co.signal.device == stage.device:
+        signal, sig_ptr, c_signal = _channel_view(co.signal, 'signal')
+        arr, refs = _s2w_layer_table(signal, co.layers)
+        sb, _, sfh, sfw = signal.shape
+        st = _hip.lib.hs_patch_conv_s2w_fwd(C.byref(st_in), fh, fw, bank_ptr, ld, c_out, groups, C.byref(ep), y.data_ptr(),
+                                            sig_ptr, sb, c_signal, sfh, sfw, arr, len(co.layers), _hip.stream_ptr())
+        if st != -3:                                   # HS_ERR_UNSUPPORTED: nothing was launched, the separate calls follow
+            _hip.check(st, 'hs_patch_conv_s2w_fwd')
+            co.refs, co.carried = refs, True
+            CoScheduledBanks._active = None
+            return y
     st = _hip.lib.hs_patch_conv_fwd(C.byref(st_in), fh, fw, bank_ptr, ld, c_out, k,
                                     padding, PAD_MODES[padding_mode], groups, C.byref(ep), y.data_ptr(),
                                     _hip.stream_ptr())

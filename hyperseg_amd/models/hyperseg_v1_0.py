@@ -468,6 +468,36 @@ class MultiScaleDecoder(EpochOnModeSwitch, nn.Module):
             self._hyper_cache.append(collect(self.out_fc) if self.out_fc is not None else [])
         return self._hyper_cache
 
+    def _coschedule_plan(self, groups, layers):
+        """Which k = 1 level's launch carries which later group's signal2weights layers: {level: [group indices]}, or None when the
+        decoder does not start with a k = 1 level.  A group must be carried by a level BEFORE the one that consumes it; among the
+        allowed carriers the least loaded takes it (cost ~ bank rows x (K + 32) per patch), the latest on a tie -- at HyperSeg-M:
+        level 0 carries banks 1 + 2, level 1 bank 3, level 2 bank 4."""
+        n_k1 = 0
+        for l, g in enumerate(groups[:self.levels]):
+            if len(g) == 1 and isinstance(g[0], HyperPatchNoPadding) and g[0].kernel_size == (1, 1):
+                n_k1 += 1
+            else:
+                break
+        if n_k1 == 0 or len(groups) < 2 or any(len(g) == 0 for g in groups[:self.levels]):
+            return None
+        starts, k0 = [], 0
+        for g in groups:
+            starts.append(k0)
+            k0 += len(g)
+        load = [0.0] * n_k1
+        carry = {}
+        for gi in range(len(groups) - 1, 0, -1):
+            ls = layers[starts[gi]:starts[gi] + len(groups[gi])]
+            if not ls:
+                continue
+            cost = sum(l['rows'] * (l['signal_channels'] / l['groups'] + 32.0) for l in ls)
+            cands = range(0, min(gi, n_k1))
+            best = min(cands, key=lambda j: (load[j], -j))
+            load[best] += cost
+            carry.setdefault(best, []).insert(0, gi)
+        return carry
+
     def _forward_autograd(self, x, s):
         """Training / gradient path: same modules, per-module weight generation, everything through autograd."""
         p = None
@@ -527,6 +557,38 @@ class MultiScaleDecoder(EpochOnModeSwitch, nn.Module):
             p = None
             for level in range(self.levels):
                 p = getattr(self, f'level_{level}')(HF.StageInput(x[-level - 1], p, coords=True), banks[level])
+            if self.out_fc is not None:
+                p = self.out_fc(p, banks[-1])
+            if masks:
+                return HF.upsample_argmax(p, x[0].shape[2:])
+            if p.shape[2:] != x[0].shape[2:]:
+                p = HF.upsample_bilinear(p, x[0].shape[2:], out=getattr(self, 'output_buffer', None))
+            return p
+        carry = self._coschedule_plan(groups, layers) if HF.COSCHEDULE_BANKS and s.is_cuda and not HF.PIPELINE_BANKS \
+            and not HF.USE_SIDE_STREAM else None
+        if carry is not None:
+            # Level 0's bank as its own launch; every later level's bank rides in the launch of an EARLIER k = 1 level
+            # (HF.CoScheduledBanks -> hs_patch_conv_s2w_fwd): the bank producer's blocks fill the CUs those latency-bound
+            # launches leave idle, instead of standing in front of level 0 as one 15 us launch.
+            per_group, k0 = [], 0
+            for g in groups:
+                per_group.append(layers[k0:k0 + len(g)])
+                k0 += len(g)
+            banks = [None] * len(groups)
+            banks[0] = HF.signal2weights_multi(s, per_group[0])
+            p = None
+            for level in range(self.levels):
+                stage = HF.StageInput(x[-level - 1], p, coords=True)
+                riders = carry.get(level, [])
+                if riders:
+                    with HF.CoScheduledBanks(s, [l for gi in riders for l in per_group[gi]]) as co:
+                        p = getattr(self, f'level_{level}')(stage, banks[level])
+                    k1 = 0
+                    for gi in riders:
+                        banks[gi] = co.refs[k1:k1 + len(per_group[gi])]
+                        k1 += len(per_group[gi])
+                else:
+                    p = getattr(self, f'level_{level}')(stage, banks[level])
             if self.out_fc is not None:
                 p = self.out_fc(p, banks[-1])
             if masks:

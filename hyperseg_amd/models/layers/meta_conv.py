@@ -86,10 +86,13 @@ class MetaConv2d(nn.Module):
             raise ValueError(f'w must be (B, {self.hyper_params}), got {tuple(w.shape)}')
         from ... import autograd as HA
         if not self._same_padded():
-            # the rest of the reference's argument set (meta_conv.py:141-186): the general kernel, inference only
+            # the rest of the reference's argument set (meta_conv.py:141-186): the general kernel; under autograd its own
+            # Function (hs_meta_conv_fwd + hs_meta_conv_bwd; no reference config trains one, the class is differentiable anyway)
             if HA.needs_grad(x if isinstance(x, torch.Tensor) else x.skip, w):
-                raise NotImplementedError('hyperseg_amd: gradients through a MetaConv2d with stride / dilation / non-"same" '
-                                          'padding (hs_meta_conv_fwd has no backward kernel; no reference config trains one)')
+                xt = HA.materialize_stage(x) if isinstance(x, HF.StageInput) else x
+                y = HA.meta_conv_general(xt, w, self.out_channels, self.kernel_size, self.stride, self.padding, self.dilation,
+                                         self.padding_mode, self.groups)
+                return _apply_epilogue(y, scale, shift, act)
             return HF.meta_conv(x, w if w.stride(1) == 1 else w.contiguous(), self.out_channels, self.kernel_size, self.stride,
                                 self.padding, self.dilation, self.padding_mode, self.groups, scale, shift, act)
         k, pad = self.kernel_size[0], self.padding[0]

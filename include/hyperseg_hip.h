@@ -128,6 +128,19 @@ int hs_patch_conv_fwd(const hs_stage_input* in, int32_t fh, int32_t fw,
                       int32_t c_out, int32_t k, int32_t pad, int32_t pad_mode, int32_t groups,
                       const hs_epilogue* ep, float* y, void* stream);
 
+/* hs_patch_conv_fwd with k = 1 (no padding) AND hs_signal2weights_multi_fwd for `layers` as ONE heterogeneous launch: the
+ * first batch*fh*fw workgroups are the patch convolution's (one per patch), the rest are signal2weights blocks writing the
+ * banks of LATER decoder levels (they depend on the signal only).  The k = 1 levels (hyperseg_v1_0.py:486-498) are
+ * latency-bound launches that leave most of the chip idle; the bank producer (hyperseg_v1_0.py:473-484) fills that time
+ * instead of preceding level 0 as its own launch.  Results are bit-identical to the two separate calls.
+ * Returns HS_ERR_UNSUPPORTED -- nothing launched -- when either half would not take the form this launch is built from
+ * (large patches, a layer without wsw_blk, unaligned operands, >= 1024 two-pixel patches): issue the two calls instead.
+ * signal (batch, c_signal, sfh, sfw); every layer's bank must be distinct from `bank` and `y`. */
+int hs_patch_conv_s2w_fwd(const hs_stage_input* in, int32_t fh, int32_t fw, const float* bank, int64_t ld,
+                          int32_t c_out, int32_t groups, const hs_epilogue* ep, float* y,
+                          const float* signal, int32_t batch, int32_t c_signal, int32_t sfh, int32_t sfw,
+                          const hs_s2w_layer* layers, int32_t n_layers, void* stream);
+
 /* MetaConv2d.forward with the reference's FULL argument set (meta_conv.py:141-186): per-sample weights w (B, rows >=
  * c_out * c_in/groups * kh * kw, row stride ldw; natural order ((o*cin_g + c)*kh + ky)*kw + kx), non-square kernels, stride,
  * dilation, any padding amounts per side and mode (F.pad semantics for reflect / replicate / circular, zero padding
@@ -140,6 +153,14 @@ int hs_meta_conv_fwd(const float* x, int32_t batch, int32_t c_in, int32_t H, int
                      int32_t c_out, int32_t kh, int32_t kw, int32_t stride_h, int32_t stride_w, int32_t pad_top,
                      int32_t pad_bottom, int32_t pad_left, int32_t pad_right, int32_t dil_h, int32_t dil_w,
                      int32_t pad_mode, int32_t groups, const hs_epilogue* ep, float* y, void* stream);
+
+/* Backward of hs_meta_conv_fwd for ZERO padding (MetaConv2d is differentiable in the reference through ATen's conv2d,
+ * meta_conv.py:163-186; the other padding modes pad explicitly first, and that pad's adjoint is the caller's): dx (B, c_in, H, W)
+ * and / or dw (B, rows, row stride lddw), either may be null.  Gather forms, deterministic. */
+int hs_meta_conv_bwd(const float* x, int32_t batch, int32_t c_in, int32_t H, int32_t W, const float* w, int64_t ldw,
+                     int32_t c_out, int32_t kh, int32_t kw, int32_t stride_h, int32_t stride_w, int32_t pad_top,
+                     int32_t pad_bottom, int32_t pad_left, int32_t pad_right, int32_t dil_h, int32_t dil_w, int32_t groups,
+                     const float* dy, float* dx, float* dw, int64_t lddw, void* stream);
 
 /* Op A with the bank generated inside the consumer: signal2weights (grouped 1x1 conv of the signal, hs_s2w_layer minus its
  * bank / ld fields, which are ignored) + k = 1 dynamic patch convolution + BatchNorm affine + activation in ONE launch --
