@@ -158,7 +158,7 @@ class BNActTrain(torch.autograd.Function):
     direction (hs_bn_act_train_fwd / _bwd).  fp32 parameters; x in fp32 or bf16 storage."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, act):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, act, counter=None):
         x = x.contiguous()
         b, c = x.shape[:2]
         px = x.numel() // (b * c)
@@ -173,7 +173,7 @@ class BNActTrain(torch.autograd.Function):
                                               running_mean.data_ptr() if running_mean is not None else None,
                                               running_var.data_ptr() if running_var is not None else None,
                                               float(momentum), float(eps), int(act), mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(),
-                                              y.data_ptr(), _hip.stream_ptr())
+                                              y.data_ptr(), counter.data_ptr() if counter is not None else None, _hip.stream_ptr())
             _hip.check(st, 'hs_bn_act_train_fwd')
         ctx.save_for_backward(x, weight, bias, mean, invstd)
         ctx.meta = (b, c, px, float(eps), int(act))
@@ -196,7 +196,7 @@ class BNActTrain(torch.autograd.Function):
                                               ws.data_ptr(), dx.data_ptr(), dg.data_ptr() if dg is not None else None,
                                               db.data_ptr() if db is not None else None, _hip.stream_ptr())
             _hip.check(st, 'hs_bn_act_train_bwd')
-        return dx, dg, db, None, None, None, None, None
+        return dx, dg, db, None, None, None, None, None, None
 
 
 def bn_act(bn, act_layer, x):
@@ -211,8 +211,12 @@ def bn_act(bn, act_layer, x):
             # the stock route below)
             and bn.weight.device == x.device and bn.bias.device == x.device
             and bn.running_mean.device == x.device and bn.running_var.device == x.device):
-        y = BNActTrain.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, act)
-        bn.num_batches_tracked.add_(1)      # after the launch succeeded (apply raises on a failed launch)
+        nbt = bn.num_batches_tracked
+        in_kernel = nbt is not None and nbt.device == x.device and nbt.dtype == torch.int64
+        # the step counter is incremented by the kernel itself (one launch less per BatchNorm and step)
+        y = BNActTrain.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, act, nbt if in_kernel else None)
+        if nbt is not None and not in_kernel:
+            nbt.add_(1)
         HF.bump_weights_epoch()               # running statistics changed through a raw pointer: no tensor version moved
         return y
     if bn.training:
@@ -324,19 +328,28 @@ class UpsampleBilinear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, size):
-        x = x.contiguous()
-        ctx.meta = (tuple(x.shape), tuple(size))
-        return HF.upsample_bilinear(x, size)
+        ctx.meta = (tuple(x.shape), tuple(size), x.dtype)
+        return HF.upsample_bilinear(x.contiguous().float(), size).to(x.dtype)     # bf16 storage: widened here, f32 arithmetic
 
     @staticmethod
     def backward(ctx, dy):
-        (b, c, hi, wi), (ho, wo) = ctx.meta
+        (b, c, hi, wi), (ho, wo), dt = ctx.meta
         dy = dy.contiguous().float()
         with torch.cuda.device(dy.device):
             dx = torch.empty(b, c, hi, wi, device=dy.device, dtype=torch.float32)
             st = _hip.lib.hs_upsample_bilinear_bwd(dy.data_ptr(), b, c, hi, wi, ho, wo, dx.data_ptr(), _hip.stream_ptr())
             _hip.check(st, 'hs_upsample_bilinear_bwd')
-        return dx, None
+        return dx.to(dt), None
+
+
+def upsample_bilinear(x, size):
+    """F.interpolate(x, size, mode='bilinear', align_corners=False), differentiable: own kernels for up-sampling CUDA tensors in
+    fp32 / bf16 storage (the decoder's final logits upsample in training), the stock op otherwise."""
+    import torch.nn.functional as F
+    if (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and size[0] >= x.shape[2] and size[1] >= x.shape[3]
+            and x.shape[0] * x.shape[1] <= 65535):
+        return UpsampleBilinear.apply(x, tuple(size))
+    return F.interpolate(x, size, mode='bilinear', align_corners=False)
 
 
 class BankSlices(torch.autograd.Function):
@@ -392,11 +405,51 @@ def patch_conv_train(x, weight, c_out, k, padding, padding_mode, groups, hp):
     return patch_conv_apply(x, bank, (fh, fw), c_out, k, padding, padding_mode, groups)
 
 
+class StageMaterialize(torch.autograd.Function):
+    """cat(coords, skip, bilinear(prev)) as ONE launch under autograd (hs_stage_input_fwd, the materialising twin of the kernels'
+    prologue): the stock formulation is two linspaces, a stack, the interpolation and a concatenation per level and step -- five
+    to six launches.  Backward: the skip's gradient is a channel range of dy (a view), the previous level's is the bilinear
+    adjoint (hs_upsample_bilinear_bwd) of its range; coordinates are constants."""
+
+    @staticmethod
+    def forward(ctx, skip, prev, coords):
+        stage = HF.StageInput(skip.contiguous().float(), prev.contiguous().float() if prev is not None else None, coords=coords)
+        ctx.meta = (tuple(skip.shape), tuple(prev.shape) if prev is not None else None, bool(coords), skip.dtype,
+                    prev.dtype if prev is not None else None)
+        return stage.materialize()
+
+    @staticmethod
+    def backward(ctx, dy):
+        (b, cs, h, w), pshape, coords, sdt, pdt = ctx.meta
+        off = 2 if coords else 0
+        dskip = dy[:, off:off + cs].to(sdt) if ctx.needs_input_grad[0] else None
+        dprev = None
+        if pshape is not None and ctx.needs_input_grad[1]:
+            _, cp, hp, wp = pshape
+            g = dy[:, off + cs:].contiguous().float()
+            if (hp, wp) == (h, w):
+                dprev = g.to(pdt)
+            else:
+                with torch.cuda.device(dy.device):
+                    dprev = torch.empty(b, cp, hp, wp, device=dy.device, dtype=torch.float32)
+                    st = _hip.lib.hs_upsample_bilinear_bwd(g.data_ptr(), b, cp, hp, wp, h, w, dprev.data_ptr(), _hip.stream_ptr())
+                    _hip.check(st, 'hs_upsample_bilinear_bwd')
+                dprev = dprev.to(pdt)
+        return dskip, dprev, None
+
+
 def materialize_stage(stage):
-    """cat(coords, skip, bilinear(prev)) with stock differentiable ops (training only)."""
+    """cat(coords, skip, bilinear(prev)), differentiable (training only): one HIP launch where the shapes allow (CUDA, an up-sampling
+    or same-size previous level), stock ops otherwise."""
     import torch.nn.functional as F
     skip, prev = stage.skip, stage.prev
     b, _, h, w = skip.shape
+    ok = skip.is_cuda and skip.dtype in (torch.float32, torch.bfloat16) and b * max(skip.shape[1], 1) <= 65535
+    if ok and prev is not None:
+        ok = prev.dtype in (torch.float32, torch.bfloat16) and h >= prev.shape[2] and w >= prev.shape[3] and \
+            prev.shape[0] * prev.shape[1] <= 65535
+    if ok and USE_HIP_STAGE:
+        return StageMaterialize.apply(skip, prev, stage.coords)
     parts = []
     if stage.coords:
         cx = torch.linspace(-1, 1, steps=w, device=skip.device)
@@ -412,3 +465,6 @@ def materialize_stage(stage):
                 prev = F.interpolate(prev, (h, w), mode='bilinear', align_corners=False)
         parts.append(prev)
     return torch.cat(parts, dim=1)
+
+
+USE_HIP_STAGE = True        # tests switch it off to compare with the stock formulation

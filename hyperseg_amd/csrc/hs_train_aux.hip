@@ -265,8 +265,9 @@ template <typename T>
 __global__ __launch_bounds__(256)
 void bn_apply_kernel(BnArgs a, const T* __restrict__ x, const float* __restrict__ partial, const float* __restrict__ gamma,
                      const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
-                     float* __restrict__ save_mean, float* __restrict__ save_invstd, T* __restrict__ y) {
+                     float* __restrict__ save_mean, float* __restrict__ save_invstd, T* __restrict__ y, long long* __restrict__ counter) {
     const int c = blockIdx.x, chunk = blockIdx.y;
+    if (counter && c == 0 && chunk == 0 && threadIdx.x == 0) *counter += 1;      // nn.BatchNorm2d.num_batches_tracked: one launch less per layer and step
     const float shift = Store<T>::ld(x, (size_t)c * a.HW);
     float s = 0.f, q = 0.f;
     for (int i = 0; i < BN_CHUNKS; ++i) { s += partial[((size_t)c * BN_CHUNKS + i) * 2]; q += partial[((size_t)c * BN_CHUNKS + i) * 2 + 1]; }
@@ -420,7 +421,8 @@ extern "C" int64_t hs_bn_train_workspace(int32_t channels) { return (int64_t)cha
 
 extern "C" int hs_bn_act_train_fwd(int32_t dtype, const void* x, int32_t batch, int32_t channels, int64_t pixels, const float* gamma,
                                    const float* beta, float* running_mean, float* running_var, float momentum, float eps, int32_t act,
-                                   float* save_mean, float* save_invstd, void* workspace, void* y, void* stream) {
+                                   float* save_mean, float* save_invstd, void* workspace, void* y, int64_t* num_batches_tracked,
+                                   void* stream) {
     BnArgs a;
     const int st = bn_args(a, batch, channels, pixels, act, eps, momentum);
     if (st != HS_OK) return st;
@@ -430,11 +432,11 @@ extern "C" int hs_bn_act_train_fwd(int32_t dtype, const void* x, int32_t batch, 
     if (dtype == HS_DTYPE_F32) {
         hipLaunchKernelGGL(bn_stats_kernel<float>, grid, dim3(256), 0, s, a, (const float*)x, (float*)workspace);
         hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, s, a, (const float*)x, (const float*)workspace, gamma, beta,
-                           running_mean, running_var, save_mean, save_invstd, (float*)y);
+                           running_mean, running_var, save_mean, save_invstd, (float*)y, (long long*)num_batches_tracked);
     } else if (dtype == HS_DTYPE_BF16) {
         hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, grid, dim3(256), 0, s, a, (const bf16_t*)x, (float*)workspace);
         hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, grid, dim3(256), 0, s, a, (const bf16_t*)x, (const float*)workspace, gamma, beta,
-                           running_mean, running_var, save_mean, save_invstd, (bf16_t*)y);
+                           running_mean, running_var, save_mean, save_invstd, (bf16_t*)y, (long long*)num_batches_tracked);
     } else return HS_ERR_BAD_ARG;
     return launch_status();
 }

@@ -506,7 +506,7 @@ class MultiScaleDecoder(EpochOnModeSwitch, nn.Module):
         if self.out_fc is not None:
             p = self.out_fc(p, s)
         if p.shape[2:] != x[0].shape[2:]:
-            p = F.interpolate(p, x[0].shape[2:], mode='bilinear', align_corners=False)
+            p = HA.upsample_bilinear(p, x[0].shape[2:])
         return p
 
     def forward(self, x, s, masks=False):

@@ -136,7 +136,7 @@ class MultiScaleDecoder(EpochOnModeSwitch, nn.Module):
                 i = level - ul + 1
                 p = self.level_blocks[level](stage, w[:, self._ranges[i]:self._ranges[i + 1]])
         if p.shape[2:] != x[0].shape[2:]:
-            p = F.interpolate(p, x[0].shape[2:], mode='bilinear', align_corners=False)
+            p = HA.upsample_bilinear(p, x[0].shape[2:])
         return p
 
     def forward(self, x, s, masks=False):

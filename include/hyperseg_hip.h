@@ -411,11 +411,12 @@ int hs_upsample_bilinear_bwd(const float* dy, int32_t batch, int32_t channels, i
  * unbiased for the running estimate, running = (1 - momentum) running + momentum batch) fused with the activation that follows it
  * (act = HS_ACT_NONE | HS_ACT_RELU | HS_ACT_RELU6), x / y / dy / dx (B, C, pixels) in `dtype` storage, parameters and statistics f32.
  * Two launches per direction.  save_mean / save_invstd (C): written by fwd, read by bwd.  gamma / beta / running_* may be NULL.
- * workspace: hs_bn_train_workspace(C) bytes, scratch.  Replaces BatchNorm2d + ReLU6 of hyperseg_v1_0.py:349-376 in train mode. */
+ * workspace: hs_bn_train_workspace(C) bytes, scratch; num_batches_tracked (optional): the module's int64 step counter, incremented by one.
+ * Replaces BatchNorm2d + ReLU6 of hyperseg_v1_0.py:349-376 in train mode. */
 int64_t hs_bn_train_workspace(int32_t channels);
 int hs_bn_act_train_fwd(int32_t dtype, const void* x, int32_t batch, int32_t channels, int64_t pixels, const float* gamma,
                         const float* beta, float* running_mean, float* running_var, float momentum, float eps, int32_t act,
-                        float* save_mean, float* save_invstd, void* workspace, void* y, void* stream);
+                        float* save_mean, float* save_invstd, void* workspace, void* y, int64_t* num_batches_tracked, void* stream);
 int hs_bn_act_train_bwd(int32_t dtype, const void* x, const void* dy, int32_t batch, int32_t channels, int64_t pixels,
                         const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, float eps, int32_t act,
                         void* workspace, void* dx, float* dgamma, float* dbeta, void* stream);

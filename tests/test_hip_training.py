@@ -246,6 +246,38 @@ def test_fused_training_batchnorm_vs_stock(dev, shape, act):
     assert int(bn1.num_batches_tracked) == int(bn0.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', [dict(b=2, cs=4, cp=16, hw=(36, 24), up=True, coords=True), dict(b=1, cs=28, cp=64, hw=(18, 18), up=True, coords=True),
+                                  dict(b=2, cs=5, cp=3, hw=(10, 14), up=False, coords=True), dict(b=2, cs=6, cp=0, hw=(9, 8), up=False, coords=True),
+                                  dict(b=1, cs=3, cp=7, hw=(12, 20), up=True, coords=False)])
+def test_stage_input_under_autograd_vs_stock_ops(dev, case, dtype):
+    """autograd.materialize_stage through ONE launch (StageMaterialize: hs_stage_input_fwd, backward = a view + the bilinear adjoint)
+    against the stock formulation it replaces -- linspace x 2, stack, interpolate, cat (hyperseg_v1_0.py:203-240): values and the
+    gradients of the skip features and of the previous level, batch 2, same-size and absent previous levels, bf16 storage."""
+    from hyperseg_amd import autograd as HA, functional as HF
+    c = case
+    g = torch.Generator().manual_seed(c['cs'] * 31 + c['cp'])
+    h, w = c['hw']
+    skip = torch.randn(c['b'], c['cs'], h, w, generator=g).to(dev).to(dtype)
+    prev = torch.randn(c['b'], c['cp'], h // 2 if c['up'] else h, w // 2 if c['up'] else w, generator=g).to(dev).to(dtype) if c['cp'] else None
+    r = torch.randn(c['b'], 2 * c['coords'] + c['cs'] + c['cp'], h, w, generator=g).to(dev)
+    outs = []
+    for own in (False, True):
+        sk = skip.clone().requires_grad_(True)
+        pv = prev.clone().requires_grad_(True) if prev is not None else None
+        HA.USE_HIP_STAGE = own
+        try:
+            y = HA.materialize_stage(HF.StageInput(sk, pv, coords=c['coords']))
+        finally:
+            HA.USE_HIP_STAGE = True
+        (y.float() * r).sum().backward()
+        outs.append((y.detach().float(), sk.grad.float(), pv.grad.float() if pv is not None else None))
+    tol = 1e-6 if dtype == torch.float32 else 1e-2
+    for a, b in zip(outs[0], outs[1]):
+        if a is not None:
+            assert rel_err(b.cpu(), a.cpu()) < tol
+
+
 @pytest.mark.parametrize('thresh', [0.3, 2.5, 5.0, 7.0])
 def test_bootstrap_mean_kernels_vs_reference_statement(dev, thresh):
     """hs_bootstrap_mean_fwd / _bwd (radix selection, no sort, no host read) == the reference's rule stated with torch.sort
