@@ -12,8 +12,9 @@ path), captured once in a HIP graph and replayed.  N > 1 is batch-sharded infere
   --model l            the bs-32 batch of BASELINE config 4 sharded 32/N frames per GPU (strong scaling);
 the single collective is the north star's all-gather of every rank's logits over RCCL / xGMI, asynchronous over a ring of three
 buffers whose slots the decoder's last kernel writes directly (zero copy: one HIP graph per slot), so it overlaps the next step:
-  --collective direct (default at N > 1)  grouped RCCL point-to-point sends / receives, all pairs: one shard per link and direction;
-  --collective allgather                  RCCL all_gather_into_tensor (in place);
+  --collective allgather (default at N > 1)  RCCL all_gather_into_tensor, in place, on RCCL's stream;
+  --collective ingraph | auto             the same collective captured into the step's HIP graph | both, calibrated, the faster one kept;
+  --collective direct                     grouped RCCL point-to-point sends / receives, all pairs: one shard per link and direction;
   --collective gather                     onto rank 0 only (nn.DataParallel's semantics);  --gather masks: uint8 argmax masks instead.
 Given explicitly at N = 1 the collective runs on a one-rank group and `collective.overhead_pct` reports its own per-step cost.
 Rank 0 writes ONE JSON line to stdout (everything else that writes to fd 1 -- RCCL's banner -- is sent to stderr).
@@ -499,9 +500,9 @@ def main(argv=None):
     ap.add_argument('--gather', default='logits', choices=['logits', 'masks'],
                     help='what the N>1 collective moves (north star: logits)')
     ap.add_argument('--collective', default=None, choices=['auto', 'ingraph', 'allgather', 'direct', 'gather', 'none'],
-                    help="N>1: the all-gather of every rank's logits.  'auto' (default at N>1): RCCL all_gather_into_tensor, in place, "
-                         "zero copy -- as a parallel branch INSIDE the step's HIP graph ('ingraph') or on RCCL's own stream ('allgather'), "
-                         "whichever a short calibration finds faster (both reported); 'direct': grouped RCCL point-to-point sends / "
+                    help="N>1: the all-gather of every rank's logits.  'allgather' (default at N>1): RCCL all_gather_into_tensor, in place, zero "
+                         "copy, on RCCL's own stream; 'ingraph': the same collective as a parallel branch INSIDE the step's HIP graph; 'auto': "
+                         "both, whichever a short calibration finds faster (both reported); 'direct': grouped RCCL point-to-point sends / "
                          "receives, all pairs; 'gather': onto rank 0 (nn.DataParallel semantics); 'none'.  Given explicitly at N=1 it runs "
                          "the collective on a one-rank group and reports its per-step overhead ('collective.overhead_pct')")
     ap.add_argument('--probe-load', type=int, default=0,
@@ -553,7 +554,10 @@ def main(argv=None):
         torch.cuda.set_device(dev)
     collective_probe = world == 1 and args.collective not in (None, 'none')      # N=1: measure the collective's own cost
     if args.collective is None:
-        args.collective = 'auto' if world > 1 else 'none'
+        # N > 1 default: the plain RCCL all_gather_into_tensor on RCCL's stream -- the most travelled path of the library, chosen for
+        # the FIRST multi-GPU run this code ever gets (no such hardware on the builder's side).  'auto' calibrates it against the
+        # in-graph form on the spot and keeps the faster one; tools/scale_run.sh runs either.
+        args.collective = 'allgather' if world > 1 else 'none'
     if world > 1 or collective_probe:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if collective_probe:

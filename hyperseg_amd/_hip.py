@@ -78,7 +78,7 @@ def _load():
         'hs_tile_interior_fwd': ([i32, vp, i32, i32, i32, i32, i32, i32, vp, vp], C.c_int),
         'hs_tile_interior_bwd': ([i32, vp, i32, i32, i32, i32, i32, i32, vp, vp], C.c_int),
         'hs_bank_unpack_fwd': ([vp, i64, i32, i32, i32, i32, i32, i32, vp, vp], C.c_int),
-        'hs_upsample_bilinear_bwd': ([vp, i32, i32, i32, i32, i32, i32, vp, vp], C.c_int),
+        'hs_upsample_bilinear_bwd': ([vp, i64, i32, i32, i32, i32, i32, i32, vp, vp], C.c_int),
         'hs_bn_train_workspace': ([i32], C.c_int64),
         'hs_bn_act_train_fwd': ([i32, vp, i32, i32, i64, vp, vp, vp, vp, C.c_float, C.c_float, i32, vp, vp, vp, vp, vp, vp], C.c_int),
         'hs_bn_act_train_bwd': ([i32, vp, vp, i32, i32, i64, vp, vp, vp, vp, C.c_float, i32, vp, vp, vp, vp, vp], C.c_int),

@@ -337,7 +337,7 @@ class UpsampleBilinear(torch.autograd.Function):
         dy = dy.contiguous().float()
         with torch.cuda.device(dy.device):
             dx = torch.empty(b, c, hi, wi, device=dy.device, dtype=torch.float32)
-            st = _hip.lib.hs_upsample_bilinear_bwd(dy.data_ptr(), b, c, hi, wi, ho, wo, dx.data_ptr(), _hip.stream_ptr())
+            st = _hip.lib.hs_upsample_bilinear_bwd(dy.data_ptr(), 0, b, c, hi, wi, ho, wo, dx.data_ptr(), _hip.stream_ptr())
             _hip.check(st, 'hs_upsample_bilinear_bwd')
         return dx.to(dt), None
 
@@ -426,13 +426,15 @@ class StageMaterialize(torch.autograd.Function):
         dprev = None
         if pshape is not None and ctx.needs_input_grad[1]:
             _, cp, hp, wp = pshape
-            g = dy[:, off + cs:].contiguous().float()
             if (hp, wp) == (h, w):
-                dprev = g.to(pdt)
+                dprev = dy[:, off + cs:].to(pdt)
             else:
+                # the previous level's channel range of dy is read IN PLACE (batch stride = all channels): no slice copy
+                dyc = dy if (dy.is_contiguous() and dy.dtype == torch.float32) else dy.contiguous().float()
                 with torch.cuda.device(dy.device):
                     dprev = torch.empty(b, cp, hp, wp, device=dy.device, dtype=torch.float32)
-                    st = _hip.lib.hs_upsample_bilinear_bwd(g.data_ptr(), b, cp, hp, wp, h, w, dprev.data_ptr(), _hip.stream_ptr())
+                    st = _hip.lib.hs_upsample_bilinear_bwd(dyc.data_ptr() + 4 * (off + cs) * h * w, dyc.shape[1] * h * w, b, cp, hp, wp, h, w,
+                                                           dprev.data_ptr(), _hip.stream_ptr())
                     _hip.check(st, 'hs_upsample_bilinear_bwd')
                 dprev = dprev.to(pdt)
         return dskip, dprev, None

@@ -340,14 +340,15 @@ void bn_bwd_apply_kernel(BnArgs a, const T* __restrict__ x, const T* __restrict_
 // taps of an output land on the edge sample, comes out by itself).
 // ---------------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
-void upsample_bilinear_bwd_kernel(const float* __restrict__ dy, int planes, int Hi, int Wi, int Ho, int Wo, float sy, float sx,
+void upsample_bilinear_bwd_kernel(const float* __restrict__ dy, int channels, long dy_batch_stride, int Hi, int Wi, int Ho, int Wo, float sy, float sx,
                                   float* __restrict__ dx) {
     const int xi = blockIdx.x * 64 + (threadIdx.x & 63), yi = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (xi >= Wi || yi >= Hi) return;
     // outputs whose source coordinate lies within (yi - 1, yi + 1): o in ((yi - 0.5) / s - 0.5, (yi + 1.5) / s - 0.5)
     const int oy0 = max((int)floorf(((float)yi - 0.5f) / sy - 0.5f) - 1, 0), oy1 = min((int)ceilf(((float)yi + 1.5f) / sy - 0.5f) + 1, Ho - 1);
     const int ox0 = max((int)floorf(((float)xi - 0.5f) / sx - 0.5f) - 1, 0), ox1 = min((int)ceilf(((float)xi + 1.5f) / sx - 0.5f) + 1, Wo - 1);
-    const float* __restrict__ g = dy + (size_t)blockIdx.z * Ho * Wo;
+    const int pb = (int)blockIdx.z / channels, pc = (int)blockIdx.z - pb * channels;             // dy may be a channel range of a wider tensor
+    const float* __restrict__ g = dy + (size_t)pb * dy_batch_stride + (size_t)pc * Ho * Wo;
     float acc = 0.0f;
     for (int oy = oy0; oy <= oy1; ++oy) {
         const Tap ty = bilinear_tap(oy, sy, Hi);
@@ -401,12 +402,14 @@ extern "C" int hs_bank_unpack_fwd(const float* bank, int64_t ld, int32_t batch, 
     return launch_status();
 }
 
-extern "C" int hs_upsample_bilinear_bwd(const float* dy, int32_t batch, int32_t channels, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,
-                                        float* dx, void* stream) {
+extern "C" int hs_upsample_bilinear_bwd(const float* dy, int64_t dy_batch_stride, int32_t batch, int32_t channels, int32_t Hi, int32_t Wi,
+                                        int32_t Ho, int32_t Wo, float* dx, void* stream) {
     if (!dy || !dx || batch <= 0 || channels <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return HS_ERR_BAD_ARG;
+    if (dy_batch_stride <= 0) dy_batch_stride = (int64_t)channels * Ho * Wo;                         // 0 = packed (B, C, Ho, Wo)
+    if (dy_batch_stride < (int64_t)channels * Ho * Wo) return HS_ERR_BAD_ARG;
     if ((long)batch * channels > 65535 || Ho < Hi || Wo < Wi) return HS_ERR_UNSUPPORTED;          // upsampling only (the decoder's use)
     hipLaunchKernelGGL(upsample_bilinear_bwd_kernel, dim3((Wi + 63) / 64, (Hi + 3) / 4, batch * channels), dim3(256), 0, (hipStream_t)stream,
-                       dy, batch * channels, Hi, Wi, Ho, Wo, (float)Hi / (float)Ho, (float)Wi / (float)Wo, dx);
+                       dy, channels, (long)dy_batch_stride, Hi, Wi, Ho, Wo, (float)Hi / (float)Ho, (float)Wi / (float)Wo, dx);
     return launch_status();
 }
 

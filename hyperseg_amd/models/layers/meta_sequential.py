@@ -15,6 +15,10 @@ import torch.nn as nn
 from ... import functional as HF
 
 
+def x_is_cuda(x):
+    return (x.skip if isinstance(x, HF.StageInput) else x).is_cuda
+
+
 def _act_code(m):
     if isinstance(m, nn.ReLU6):
         return HF.ACT_RELU6
@@ -65,6 +69,17 @@ class MetaSequential(nn.Sequential):
                     if j < n and isinstance(mods[j], nn.BatchNorm2d) and not mods[j].training and not grad:
                         scale, shift = self._fold(j, mods[j])
                         j += 1
+                    elif j < n and isinstance(mods[j], nn.BatchNorm2d) and x_is_cuda(x):
+                        # training: the convolution through autograd, then BatchNorm (batch statistics) + activation as the fused
+                        # training kernels (autograd.bn_act: two launches per direction instead of MIOpen's BN + a clamp + their adjoints)
+                        from ... import autograd as HA
+                        bn, j = mods[j], j + 1
+                        act_layer = None
+                        if j < n and _act_code(mods[j]) is not None:
+                            act_layer, j = mods[j], j + 1
+                        x = HA.bn_act(bn, act_layer, module.forward_fused(x, wi, None, None, HF.ACT_NONE))
+                        i = j
+                        continue
                     if j < n and _act_code(mods[j]) is not None:
                         act = _act_code(mods[j])
                         j += 1

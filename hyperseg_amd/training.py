@@ -53,9 +53,11 @@ def bootstrapped_cross_entropy(pred, target, k=4096, thresh=0.3, weight=None, ig
     """pred (N, C, H, W) logits, target (N, H, W) int64 -> scalar."""
     total = pred.new_zeros(())
     capturing = pred.is_cuda and torch.cuda.is_current_stream_capturing()
-    for logits, labels in zip(pred, target):
-        per_pixel = F.cross_entropy(logits.flatten(1).t(), labels.flatten(), weight=weight, ignore_index=ignore_index,
-                                    reduction='none')
+    # the per-pixel losses of the WHOLE batch in one pass over (N, C, H, W) (the reference permutes every image to (HW, C) first,
+    # bootstrapped_ce_loss.py:20-23: same values, a transposed copy + a softmax + a gather per image and direction)
+    per_all = F.cross_entropy(pred, target, weight=weight, ignore_index=ignore_index, reduction='none')
+    for per_image in per_all:
+        per_pixel = per_image.flatten()
         on_device = per_pixel.is_cuda and per_pixel.numel() > k            # (numel <= k: the reference raises; so does its restatement)
         if on_device and per_pixel.dtype == torch.float32 and USE_HIP_BOOTSTRAP:
             from .autograd import BootstrapMean                            # no sort, no host read, 7 small launches: eager and captured alike

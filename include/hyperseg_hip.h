@@ -403,9 +403,11 @@ int hs_bank_unpack_fwd(const float* bank, int64_t ld, int32_t batch, int32_t hp_
                        int32_t rows, float* w, void* stream);
 
 /* Adjoint of hs_upsample_bilinear_fwd (F.interpolate(..., mode='bilinear', align_corners=False), Ho >= Hi, Wo >= Wi): dy (B,C,Ho,Wo) ->
- * dx (B,C,Hi,Wi), a gather over the outputs whose taps touch each input pixel.  Training path (autograd.UpsampleBilinear). */
-int hs_upsample_bilinear_bwd(const float* dy, int32_t batch, int32_t channels, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, float* dx,
-                             void* stream);
+ * dx (B,C,Hi,Wi), a gather over the outputs whose taps touch each input pixel.  dy_batch_stride (floats; 0 = packed C*Ho*Wo): dy may be a
+ * channel range of a wider (B, C_total, Ho, Wo) tensor -- the previous level's slice of a stage input's gradient -- read in place.
+ * Training path (autograd.UpsampleBilinear, StageMaterialize). */
+int hs_upsample_bilinear_bwd(const float* dy, int64_t dy_batch_stride, int32_t batch, int32_t channels, int32_t Hi, int32_t Wi,
+                             int32_t Ho, int32_t Wo, float* dx, void* stream);
 
 /* BatchNorm2d in TRAINING mode (torch.nn.functional.batch_norm semantics: batch statistics, biased variance for the normalisation,
  * unbiased for the running estimate, running = (1 - momentum) running + momentum batch) fused with the activation that follows it

@@ -178,7 +178,7 @@ def test_bench_workload_plan_and_device_selection():
     assert bench.select_device(5, stub=True) == torch.device('cpu')
 
 
-@pytest.mark.parametrize('model,extra', [('m', []), ('l', []), ('m', ['--collective', 'direct']), ('m', ['--gather', 'masks'])])
+@pytest.mark.parametrize('model,extra', [('m', []), ('l', []), ('m', ['--collective', 'auto']), ('m', ['--collective', 'direct']), ('m', ['--gather', 'masks'])])
 def test_bench_main_under_torch_distributed_run(model, extra):
     """bench.py's main() ITSELF, launched exactly as the driver launches it (python -m torch.distributed.run --nproc-per-node 2
     ... bench.py --gpus 2 --steps K --warmup W), with the model stubbed out (HS_BENCH_STUB=1: gloo, CPU): rank / world from
@@ -212,6 +212,8 @@ def test_bench_main_under_torch_distributed_run(model, extra):
     assert c['policy'] == want_policy and c['payload'] == ('masks' if 'masks' in extra else 'logits')
     assert c['completed'] >= 6 * 2 + 3
     if not extra:
+        assert c['requested'] == 'allgather' and c['calibration_ms_per_step'] is None
+    if 'auto' in extra:
         assert c['requested'] == 'auto' and c['calibration_ms_per_step']['allgather'] > 0
     classes, (h, w) = (21, (512, 512)) if model == 'l' else (19, (512, 1024))
     frames = 16 if model == 'l' else 1

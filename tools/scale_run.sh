@@ -1,8 +1,8 @@
 #!/bin/bash
 # The scaling run on ONE 8-GPU MI355X node, exactly as the driver launches bench.py (one rank per GPU over RCCL / xGMI).
-#   bash tools/scale_run.sh [model=m] [steps=200] [warmup=20] [collective=auto|ingraph|allgather|direct|gather] [gather=logits|masks]
+#   bash tools/scale_run.sh [model=m] [steps=200] [warmup=20] [collective=allgather|auto|ingraph|direct|gather] [gather=logits|masks]
 # Writes gpurun_out/scale_<model>_<collective>_<gather>_N<n>.json (ONE JSON line each: `value` = whole-job frames/s) for N = 1 2 4 8 and
-# prints value and value / (N x value_1).  --collective auto (the default at N > 1) calibrates the two in-place all-gather forms
+# prints value and value / (N x value_1).  --collective allgather is bench.py's default at N > 1; auto calibrates the two in-place all-gather forms
 # (captured into the step's HIP graph | on RCCL's stream) and reports both figures under collective.calibration_ms_per_step.
 # Per-link bytes per step and direction at N ranks, payload P bytes per rank (HyperSeg-M logits: 39.8 MB; masks: 0.5 MB):
 #   allgather / ingraph : RCCL's choice; a single ring moves (N-1) x P through every link of the ring, its multi-ring / direct
@@ -10,7 +10,7 @@
 #   direct              : exactly P per link and direction (every shard crosses the one link between producer and consumer)
 #   gather              : P per link into rank 0 only
 # Each rank RECEIVES (N-1) x P per step in every all-to-all policy: 278.6 MB at N = 8 for HyperSeg-M = 357 GB/s at 1280 steps/s.
-model=${1:-m}; steps=${2:-200}; warmup=${3:-20}; coll=${4:-auto}; gather=${5:-logits}
+model=${1:-m}; steps=${2:-200}; warmup=${3:-20}; coll=${4:-allgather}; gather=${5:-logits}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd "$R"; mkdir -p gpurun_out
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 base=""
