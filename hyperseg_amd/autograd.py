@@ -229,6 +229,37 @@ USE_HIP_BN = True       # tests switch it off to compare with the stock modules
 
 
 
+class PixelCrossEntropy(torch.autograd.Function):
+    """F.cross_entropy(logits, target, ignore_index=..., reduction='none') for fp32 (N, C, H, W) CUDA logits, one launch per direction
+    (hs_cross_entropy_fwd / _bwd; stock: log-softmax + gather and their adjoints)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        logits, target = logits.contiguous(), target.contiguous()
+        n, c = logits.shape[:2]
+        px = logits.numel() // (n * c)
+        with torch.cuda.device(logits.device):
+            loss = torch.empty(target.shape, device=logits.device, dtype=torch.float32)
+            st = _hip.lib.hs_cross_entropy_fwd(logits.data_ptr(), target.data_ptr(), n, c, px, int(ignore_index), loss.data_ptr(), _hip.stream_ptr())
+            _hip.check(st, 'hs_cross_entropy_fwd')
+        ctx.save_for_backward(logits, target)
+        ctx.ignore_index = int(ignore_index)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target = ctx.saved_tensors
+        n, c = logits.shape[:2]
+        px = logits.numel() // (n * c)
+        g = g.contiguous().float()
+        with torch.cuda.device(logits.device):
+            dl = torch.empty_like(logits)
+            st = _hip.lib.hs_cross_entropy_bwd(logits.data_ptr(), target.data_ptr(), n, c, px, ctx.ignore_index, g.data_ptr(), dl.data_ptr(),
+                                               _hip.stream_ptr())
+            _hip.check(st, 'hs_cross_entropy_bwd')
+        return dl, None, None
+
+
 class BootstrapMean(torch.autograd.Function):
     """The per-image reduction of the bootstrapped cross entropy (hyperseg/losses/bootstrapped_ce_loss.py:19-25) on the device with no
     sort and no host read (hs_bootstrap_mean_fwd / _bwd): capturable into a HIP graph as it is."""

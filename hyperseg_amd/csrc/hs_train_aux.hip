@@ -388,6 +388,36 @@ void bank_unpack_kernel(const float* __restrict__ bank, long ld, int hp_total, i
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Per-pixel cross entropy of (N, C, H, W) logits against (N, H, W) int64 labels (F.cross_entropy(..., reduction='none'), no class
+// weights: what BootstrappedCrossEntropyLoss feeds its top-k rule, bootstrapped_ce_loss.py:20-23), forward and adjoint, one launch each
+// (stock: log-softmax + gather, and their two adjoints -- four launches of ~25 us at config 5).  One thread per pixel; the C logits of a
+// pixel are HW floats apart, so a wave reads C coalesced rows.  loss = log(sum exp(x - max)) + max - x[t]; ignored labels give 0 and
+// no gradient; d x[c] = (softmax[c] - [c == t]) * g.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <bool BWD>
+__global__ __launch_bounds__(256)
+void cross_entropy_kernel(const float* __restrict__ x, const long long* __restrict__ target, int C, long hw, long total, long long ignore_index,
+                          const float* __restrict__ g, float* __restrict__ out) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long n = e / hw, p = e - n * hw;
+        const float* __restrict__ xp = x + n * C * hw + p;
+        const long long t = target[e];
+        const bool live = t != ignore_index && t >= 0 && t < C;
+        float m = xp[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, xp[(long)c * hw]);
+        float sum = 0.0f;
+        for (int c = 0; c < C; ++c) sum += expf(xp[(long)c * hw] - m);
+        if (!BWD) {
+            out[e] = live ? (logf(sum) + m) - xp[(long)t * hw] : 0.0f;
+        } else {
+            float* __restrict__ dp = out + n * C * hw + p;
+            const float gi = live ? g[e] : 0.0f, inv = 1.0f / sum;
+            for (int c = 0; c < C; ++c) dp[(long)c * hw] = (expf(xp[(long)c * hw] - m) * inv - (c == (int)t ? 1.0f : 0.0f)) * gi;
+        }
+    }
+}
+
 }  // namespace hs
 
 using namespace hs;
@@ -548,5 +578,25 @@ extern "C" int hs_bootstrap_mean_bwd(const float* values, int32_t n, const float
                                      void* stream) {
     if (!values || !state5 || !grad_out || !grad_values || n <= 0) return HS_ERR_BAD_ARG;
     hipLaunchKernelGGL(bm_bwd_kernel, dim3(BM_WG), dim3(256), 0, (hipStream_t)stream, values, n, state5, grad_out, grad_values);
+    return launch_status();
+}
+
+extern "C" int hs_cross_entropy_fwd(const float* logits, const int64_t* target, int32_t batch, int32_t classes, int64_t pixels,
+                                    int64_t ignore_index, float* loss, void* stream) {
+    if (!logits || !target || !loss || batch <= 0 || classes <= 0 || pixels <= 0) return HS_ERR_BAD_ARG;
+    const long total = (long)batch * pixels;
+    const unsigned blocks = (unsigned)((total + 255) / 256 > 65535 * 16 ? 65535 * 16 : (total + 255) / 256);
+    hipLaunchKernelGGL(cross_entropy_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, (const long long*)target, classes,
+                       (long)pixels, total, (long long)ignore_index, (const float*)nullptr, loss);
+    return launch_status();
+}
+
+extern "C" int hs_cross_entropy_bwd(const float* logits, const int64_t* target, int32_t batch, int32_t classes, int64_t pixels,
+                                    int64_t ignore_index, const float* grad_loss, float* grad_logits, void* stream) {
+    if (!logits || !target || !grad_loss || !grad_logits || batch <= 0 || classes <= 0 || pixels <= 0) return HS_ERR_BAD_ARG;
+    const long total = (long)batch * pixels;
+    const unsigned blocks = (unsigned)((total + 255) / 256 > 65535 * 16 ? 65535 * 16 : (total + 255) / 256);
+    hipLaunchKernelGGL(cross_entropy_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, (const long long*)target, classes,
+                       (long)pixels, total, (long long)ignore_index, grad_loss, grad_logits);
     return launch_status();
 }

@@ -73,7 +73,10 @@ class _SignalToWeights:
                                  conv.groups, rows)
 
     def _weights_train(self, s):
-        """Differentiable reference-layout weights (B, hp, fh, fw): the grouped 1x1 conv as a stock op (training)."""
+        """Differentiable reference-layout weights (B, >= hp, fh, fw): the grouped 1x1 conv as a stock op (training).  The rows past hp
+        (``next_multiply`` padding of the grouped conv, hyperseg_v1_0.py:473-477) are NOT sliced off on the GPU route: every consumer
+        takes its row count explicitly (autograd.BankPack / patch_conv_train), and a slice would cost a zero fill + a strided copy in
+        every backward (its adjoint pads the gradient back to the conv's width)."""
         hp = int(self.hyper_params)
         if isinstance(s, HF.BankRef):
             raise RuntimeError('a precomputed bank cannot carry gradients')
@@ -92,7 +95,7 @@ class _SignalToWeights:
             wc, k = conv.weight.shape[0], conv.weight.shape[1]
             w = conv.weight.view(g, wc // g, k)
             x = sig.reshape(b, g, k, fh * fw)
-            return torch.einsum('grk,bgkp->bgrp', w, x).reshape(b, wc, fh, fw)[:, :hp]
+            return torch.einsum('grk,bgkp->bgrp', w, x).reshape(b, wc, fh, fw)
         return conv(sig)[:, :hp]
 
     def _train_mode(self, x, s):

@@ -55,7 +55,12 @@ def bootstrapped_cross_entropy(pred, target, k=4096, thresh=0.3, weight=None, ig
     capturing = pred.is_cuda and torch.cuda.is_current_stream_capturing()
     # the per-pixel losses of the WHOLE batch in one pass over (N, C, H, W) (the reference permutes every image to (HW, C) first,
     # bootstrapped_ce_loss.py:20-23: same values, a transposed copy + a softmax + a gather per image and direction)
-    per_all = F.cross_entropy(pred, target, weight=weight, ignore_index=ignore_index, reduction='none')
+    if (USE_HIP_BOOTSTRAP and weight is None and pred.is_cuda and pred.dtype == torch.float32 and pred.dim() == 4
+            and target.dtype == torch.int64 and target.device == pred.device):
+        from .autograd import PixelCrossEntropy                            # one launch per direction (hs_cross_entropy_fwd / _bwd)
+        per_all = PixelCrossEntropy.apply(pred, target, ignore_index)
+    else:
+        per_all = F.cross_entropy(pred, target, weight=weight, ignore_index=ignore_index, reduction='none')
     for per_image in per_all:
         per_pixel = per_image.flatten()
         on_device = per_pixel.is_cuda and per_pixel.numel() > k            # (numel <= k: the reference raises; so does its restatement)

@@ -423,6 +423,14 @@ int hs_bn_act_train_bwd(int32_t dtype, const void* x, const void* dy, int32_t ba
                         const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, float eps, int32_t act,
                         void* workspace, void* dx, float* dgamma, float* dbeta, void* stream);
 
+/* Per-pixel cross entropy, F.cross_entropy(logits (N,C,H,W), target (N,H,W) int64, ignore_index, reduction='none') without class
+ * weights -- what BootstrappedCrossEntropyLoss.forward computes before its top-k rule (hyperseg/losses/bootstrapped_ce_loss.py:20-23) --
+ * and its adjoint, one launch each: loss (N,H,W) (0 at ignored pixels); grad_logits (N,C,H,W) = (softmax - onehot) * grad_loss. */
+int hs_cross_entropy_fwd(const float* logits, const int64_t* target, int32_t batch, int32_t classes, int64_t pixels,
+                         int64_t ignore_index, float* loss, void* stream);
+int hs_cross_entropy_bwd(const float* logits, const int64_t* target, int32_t batch, int32_t classes, int64_t pixels,
+                         int64_t ignore_index, const float* grad_loss, float* grad_logits, void* stream);
+
 /* Materialises a stage input (B, 2*coords + c_skip + c_prev, H, W); test/diagnostic twin of the
  * fused prologue (the product path never calls it). */
 int hs_stage_input_fwd(const hs_stage_input* in, float* y, void* stream);

@@ -278,6 +278,27 @@ def test_stage_input_under_autograd_vs_stock_ops(dev, case, dtype):
             assert rel_err(b.cpu(), a.cpu()) < tol
 
 
+@pytest.mark.parametrize('shape,ignore', [((2, 12, 36, 20), 255), ((1, 19, 7, 5), -100), ((3, 3, 1, 70), 255), ((2, 21, 33, 17), 255)])
+def test_pixel_cross_entropy_vs_torch(dev, shape, ignore):
+    """hs_cross_entropy_fwd / _bwd (autograd.PixelCrossEntropy) == F.cross_entropy(..., ignore_index, reduction='none') and its
+    gradient: the per-pixel losses BootstrappedCrossEntropyLoss ranks (bootstrapped_ce_loss.py:20-23), logits at O(10) with ignored pixels."""
+    import torch.nn.functional as F
+    from hyperseg_amd.autograd import PixelCrossEntropy
+    g = torch.Generator().manual_seed(shape[1] + shape[2])
+    x = (torch.randn(shape, generator=g) * 4).to(dev)
+    t = torch.randint(0, shape[1], (shape[0],) + shape[2:], generator=g)
+    t[torch.rand(t.shape, generator=g) < 0.2] = ignore
+    t = t.to(dev)
+    r = torch.rand(t.shape, generator=g).to(dev)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    la = F.cross_entropy(xa, t, ignore_index=ignore, reduction='none')
+    lb = PixelCrossEntropy.apply(xb, t, ignore)
+    (la * r).sum().backward()
+    (lb * r).sum().backward()
+    assert float((lb - la).abs().max()) < 1e-5 and bool((lb[t == ignore] == 0).all())
+    assert rel_err(xb.grad.cpu(), xa.grad.cpu()) < 1e-6
+
+
 @pytest.mark.parametrize('thresh', [0.3, 2.5, 5.0, 7.0])
 def test_bootstrap_mean_kernels_vs_reference_statement(dev, thresh):
     """hs_bootstrap_mean_fwd / _bwd (radix selection, no sort, no host read) == the reference's rule stated with torch.sort
