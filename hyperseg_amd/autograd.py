@@ -270,7 +270,7 @@ class BootstrapMean(torch.autograd.Function):
         n = values.numel()
         with torch.cuda.device(values.device):
             ws = torch.empty(int(_hip.lib.hs_bootstrap_mean_workspace()), device=values.device, dtype=torch.uint8)
-            out = torch.empty(5, device=values.device, dtype=torch.float32)
+            out = torch.empty(8, device=values.device, dtype=torch.float32)
             st = _hip.lib.hs_bootstrap_mean_fwd(values.data_ptr(), n, int(k), float(thresh), ws.data_ptr(), out.data_ptr(), _hip.stream_ptr())
             _hip.check(st, 'hs_bootstrap_mean_fwd')
         ctx.save_for_backward(values, out)
@@ -342,6 +342,35 @@ def meta_conv_general(x, w, c_out, kernel_size, stride, padding, dilation, paddi
     else:
         pads = (ph, ph, pw, pw)
     return MetaConvGeneral.apply(x, w, c_out, tuple(kernel_size), tuple(stride), pads, tuple(dilation), groups)
+
+
+class BootstrapMeanBatched(torch.autograd.Function):
+    """BootstrapMean for every image of a batch in one set of launches (hs_bootstrap_mean_batched_fwd / _bwd: grid.y = image):
+    values (N, n) -> (N,) per-image losses.  Nine launches per step whatever the batch (the per-image form: nine per image)."""
+
+    @staticmethod
+    def forward(ctx, values, k, thresh):
+        values = values.contiguous()
+        imgs, n = values.shape
+        with torch.cuda.device(values.device):
+            ws = torch.empty(imgs * int(_hip.lib.hs_bootstrap_mean_workspace()), device=values.device, dtype=torch.uint8)
+            out = torch.empty(imgs, 8, device=values.device, dtype=torch.float32)
+            st = _hip.lib.hs_bootstrap_mean_batched_fwd(values.data_ptr(), imgs, n, int(k), float(thresh), ws.data_ptr(), out.data_ptr(),
+                                                        _hip.stream_ptr())
+            _hip.check(st, 'hs_bootstrap_mean_batched_fwd')
+        ctx.save_for_backward(values, out)
+        return out[:, 0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        values, state = ctx.saved_tensors
+        imgs, n = values.shape
+        with torch.cuda.device(values.device):
+            gv = torch.empty_like(values)
+            st = _hip.lib.hs_bootstrap_mean_batched_bwd(values.data_ptr(), imgs, n, state.data_ptr(), g.contiguous().float().data_ptr(),
+                                                        gv.data_ptr(), _hip.stream_ptr())
+            _hip.check(st, 'hs_bootstrap_mean_batched_bwd')
+        return gv, None, None
 
 
 def patch_conv_apply(*args):

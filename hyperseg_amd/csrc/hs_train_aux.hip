@@ -95,6 +95,7 @@ void tile_interior_kernel(TileArgs a, const T* __restrict__ src, T* __restrict__
 // partial (float): per workgroup {sum over v > thresh, count > thresh, sum over v > t, count == t}, combined in workgroup order.
 // ---------------------------------------------------------------------------------------------------------------------------------
 constexpr int BM_BINS0 = 2048, BM_BINS12 = 1024, BM_STATE = BM_BINS0 + 2 * BM_BINS12, BM_WG = 128;
+constexpr int BM_WS_U32 = BM_STATE + 8 + BM_WG * 4;          // 32-bit words of one image's workspace: histograms | state | partial sums
 __device__ __forceinline__ int bm_shift(int level) { return level == 0 ? 20 : (level == 1 ? 10 : 0); }
 __device__ __forceinline__ int bm_bins(int level) { return level == 0 ? BM_BINS0 : BM_BINS12; }
 __device__ __forceinline__ int bm_base(int level) { return level == 0 ? 0 : (level == 1 ? BM_BINS0 : BM_BINS0 + BM_BINS12); }
@@ -102,6 +103,7 @@ __device__ __forceinline__ int bm_base(int level) { return level == 0 ? 0 : (lev
 __global__ __launch_bounds__(256)
 void bm_hist_kernel(const float* __restrict__ v, int n, unsigned* __restrict__ ws, int level) {
     __shared__ unsigned h[BM_BINS0];
+    v += (size_t)blockIdx.y * n; ws += (size_t)blockIdx.y * BM_WS_U32;           // image blockIdx.y of a batch (its own values and workspace)
     const int nb = bm_bins(level), sh = bm_shift(level);
     for (int i = threadIdx.x; i < nb; i += 256) h[i] = 0;
     __syncthreads();
@@ -121,6 +123,7 @@ void bm_hist_kernel(const float* __restrict__ v, int n, unsigned* __restrict__ w
 __global__ __launch_bounds__(256)
 void bm_find_kernel(unsigned* __restrict__ ws, int level, int k) {
     __shared__ unsigned part[256];
+    ws += (size_t)blockIdx.y * BM_WS_U32;
     __shared__ unsigned sel[2];
     const int tid = threadIdx.x;
     const int nbins = bm_bins(level), per = nbins / 256, sh = bm_shift(level);
@@ -159,6 +162,7 @@ void bm_find_kernel(unsigned* __restrict__ ws, int level, int k) {
 __global__ __launch_bounds__(256)
 void bm_sums_kernel(const float* __restrict__ v, int n, float thresh, const unsigned* __restrict__ ws, float* __restrict__ partial) {
     __shared__ float red[4][4];
+    v += (size_t)blockIdx.y * n; ws += (size_t)blockIdx.y * BM_WS_U32; partial += (size_t)blockIdx.y * BM_WS_U32;
     const float t = __uint_as_float(ws[BM_STATE + 2]);
     float s_thr = 0.f, c_thr = 0.f, s_top = 0.f, c_eq = 0.f;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
@@ -182,6 +186,7 @@ void bm_sums_kernel(const float* __restrict__ v, int n, float thresh, const unsi
 __global__ __launch_bounds__(64)
 void bm_final_kernel(const float* __restrict__ partial, int nwg, const unsigned* __restrict__ ws, int k, float thresh,
                      float* __restrict__ out) {
+    partial += (size_t)blockIdx.y * BM_WS_U32; ws += (size_t)blockIdx.y * BM_WS_U32; out += (size_t)blockIdx.y * 8;
     float s_thr = 0.f, c_thr = 0.f, s_top = 0.f, c_eq = 0.f;
     for (int i = threadIdx.x; i < nwg; i += 64) { s_thr += partial[4 * i]; c_thr += partial[4 * i + 1]; s_top += partial[4 * i + 2]; c_eq += partial[4 * i + 3]; }
     s_thr = wave_sum64(s_thr); c_thr = wave_sum64(c_thr); s_top = wave_sum64(s_top); c_eq = wave_sum64(c_eq);
@@ -200,6 +205,7 @@ void bm_final_kernel(const float* __restrict__ partial, int nwg, const unsigned*
 __global__ __launch_bounds__(256)
 void bm_bwd_kernel(const float* __restrict__ v, int n, const float* __restrict__ state, const float* __restrict__ gout,
                    float* __restrict__ gv) {
+    v += (size_t)blockIdx.y * n; gv += (size_t)blockIdx.y * n; state += (size_t)blockIdx.y * 8; gout += blockIdx.y;
     const float w = state[2] * gout[0], t = state[3], tie = state[4];
     for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
         const float x = fmaxf(v[e], 0.0f);
@@ -556,29 +562,42 @@ extern "C" int hs_tile_interior_bwd(int32_t dtype, const void* dy, int32_t batch
 
 extern "C" int64_t hs_bootstrap_mean_workspace(void) { return (int64_t)(BM_STATE + 8) * 4 + (int64_t)BM_WG * 4 * 4; }
 
-extern "C" int hs_bootstrap_mean_fwd(const float* values, int32_t n, int32_t k, float thresh, void* workspace, float* out5,
-                                     void* stream) {
-    if (!values || !workspace || !out5 || n <= 0 || k <= 0) return HS_ERR_BAD_ARG;
+// `images` independent reductions in one set of launches (grid.y = image): values (images, n), workspace images x
+// hs_bootstrap_mean_workspace() bytes, out (images, 8) floats [loss, branch, 1 / count, t, tie weight, -, -, -]
+extern "C" int hs_bootstrap_mean_batched_fwd(const float* values, int32_t images, int32_t n, int32_t k, float thresh, void* workspace,
+                                             float* out8, void* stream) {
+    if (!values || !workspace || !out8 || n <= 0 || k <= 0 || images <= 0 || images > 65535) return HS_ERR_BAD_ARG;
     if (n <= k) return HS_ERR_UNSUPPORTED;                               // the reference indexes ranked[k]
     hipStream_t s = (hipStream_t)stream;
     unsigned* ws = (unsigned*)workspace;
     float* partial = (float*)(ws + BM_STATE + 8);
-    hipError_t e = hipMemsetAsync(ws, 0, (size_t)(BM_STATE + 8) * 4, s);
+    hipError_t e = hipMemsetAsync(ws, 0, (size_t)images * BM_WS_U32 * 4, s);
     if (e != hipSuccess) return (int)e;
     for (int level = 0; level < 3; ++level) {
-        hipLaunchKernelGGL(bm_hist_kernel, dim3(BM_WG), dim3(256), 0, s, values, n, ws, level);
-        hipLaunchKernelGGL(bm_find_kernel, dim3(1), dim3(256), 0, s, ws, level, k);
+        hipLaunchKernelGGL(bm_hist_kernel, dim3(BM_WG, images), dim3(256), 0, s, values, n, ws, level);
+        hipLaunchKernelGGL(bm_find_kernel, dim3(1, images), dim3(256), 0, s, ws, level, k);
     }
-    hipLaunchKernelGGL(bm_sums_kernel, dim3(BM_WG), dim3(256), 0, s, values, n, thresh, (const unsigned*)ws, partial);
-    hipLaunchKernelGGL(bm_final_kernel, dim3(1), dim3(64), 0, s, (const float*)partial, BM_WG, (const unsigned*)ws, k, thresh, out5);
+    hipLaunchKernelGGL(bm_sums_kernel, dim3(BM_WG, images), dim3(256), 0, s, values, n, thresh, (const unsigned*)ws, partial);
+    hipLaunchKernelGGL(bm_final_kernel, dim3(1, images), dim3(64), 0, s, (const float*)partial, BM_WG, (const unsigned*)ws, k, thresh, out8);
     return launch_status();
+}
+
+extern "C" int hs_bootstrap_mean_batched_bwd(const float* values, int32_t images, int32_t n, const float* state8, const float* grad_out,
+                                             float* grad_values, void* stream) {
+    if (!values || !state8 || !grad_out || !grad_values || n <= 0 || images <= 0 || images > 65535) return HS_ERR_BAD_ARG;
+    hipLaunchKernelGGL(bm_bwd_kernel, dim3(BM_WG, images), dim3(256), 0, (hipStream_t)stream, values, n, state8, grad_out, grad_values);
+    return launch_status();
+}
+
+// one image: out5 = the first five floats of the batched form's row (five floats are written)
+extern "C" int hs_bootstrap_mean_fwd(const float* values, int32_t n, int32_t k, float thresh, void* workspace, float* out5,
+                                     void* stream) {
+    return hs_bootstrap_mean_batched_fwd(values, 1, n, k, thresh, workspace, out5, stream);
 }
 
 extern "C" int hs_bootstrap_mean_bwd(const float* values, int32_t n, const float* state5, const float* grad_out, float* grad_values,
                                      void* stream) {
-    if (!values || !state5 || !grad_out || !grad_values || n <= 0) return HS_ERR_BAD_ARG;
-    hipLaunchKernelGGL(bm_bwd_kernel, dim3(BM_WG), dim3(256), 0, (hipStream_t)stream, values, n, state5, grad_out, grad_values);
-    return launch_status();
+    return hs_bootstrap_mean_batched_bwd(values, 1, n, state5, grad_out, grad_values, stream);
 }
 
 extern "C" int hs_cross_entropy_fwd(const float* logits, const int64_t* target, int32_t batch, int32_t classes, int64_t pixels,

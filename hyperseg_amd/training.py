@@ -61,8 +61,11 @@ def bootstrapped_cross_entropy(pred, target, k=4096, thresh=0.3, weight=None, ig
         per_all = PixelCrossEntropy.apply(pred, target, ignore_index)
     else:
         per_all = F.cross_entropy(pred, target, weight=weight, ignore_index=ignore_index, reduction='none')
-    for per_image in per_all:
-        per_pixel = per_image.flatten()
+    per_rows = per_all.flatten(1)
+    if (USE_HIP_BOOTSTRAP and per_rows.is_cuda and per_rows.dtype == torch.float32 and per_rows.shape[1] > k and per_rows.shape[0] <= 65535):
+        from .autograd import BootstrapMeanBatched                         # every image in one set of launches, no sort, no host read
+        return BootstrapMeanBatched.apply(per_rows, k, thresh).sum() / float(pred.shape[0])
+    for per_pixel in per_rows:
         on_device = per_pixel.is_cuda and per_pixel.numel() > k            # (numel <= k: the reference raises; so does its restatement)
         if on_device and per_pixel.dtype == torch.float32 and USE_HIP_BOOTSTRAP:
             from .autograd import BootstrapMean                            # no sort, no host read, 7 small launches: eager and captured alike

@@ -396,6 +396,12 @@ int hs_tile_interior_bwd(int32_t dtype, const void* dy, int32_t batch, int32_t c
 int64_t hs_bootstrap_mean_workspace(void);
 int hs_bootstrap_mean_fwd(const float* values, int32_t n, int32_t k, float thresh, void* workspace, float* out5, void* stream);
 int hs_bootstrap_mean_bwd(const float* values, int32_t n, const float* state5, const float* grad_out, float* grad_values, void* stream);
+/* The same for `images` images at once (one set of launches, grid.y = image): values (images, n), workspace images x
+ * hs_bootstrap_mean_workspace() bytes, out8 / state8 (images, 8) floats whose first five are out5 / state5 above, grad_out (images). */
+int hs_bootstrap_mean_batched_fwd(const float* values, int32_t images, int32_t n, int32_t k, float thresh, void* workspace, float* out8,
+                                  void* stream);
+int hs_bootstrap_mean_batched_bwd(const float* values, int32_t images, int32_t n, const float* state8, const float* grad_out,
+                                  float* grad_values, void* stream);
 
 /* Adjoint of hs_bank_pack_fwd: patch-major bank (B fh fw, ld) -> channel-major weights (B, hp_total, fh, fw): channels
  * [ch_offset, ch_offset + rows) from the bank's columns [0, rows), exact zeros elsewhere.  Training path (autograd.BankPack). */

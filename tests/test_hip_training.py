@@ -418,6 +418,23 @@ def test_validation_after_graph_replays_sees_the_trained_weights(dev):
     assert HF._WEIGHTS_EPOCH[0] > epoch
 
 
+def test_bootstrap_mean_batched_equals_per_image(dev):
+    """hs_bootstrap_mean_batched_fwd / _bwd (grid.y = image) == the per-image kernels, values and gradients, with the two branches of
+    the rule taken by different images of the same batch."""
+    from hyperseg_amd.autograd import BootstrapMean, BootstrapMeanBatched
+    g = torch.Generator().manual_seed(9)
+    v = torch.rand(3, 5000, generator=g)
+    v[0] *= 4.0; v[1] *= 0.2; v[2, :2000] = 0.0                   # image 0: many above thresh; image 1: none; image 2: ignored pixels (exact zeros)
+    v = v.to(dev)
+    va, vb = v.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    w = torch.tensor([0.5, 2.0, -1.0], device=dev)
+    la = torch.stack([BootstrapMean.apply(va[i], 700, 0.3) for i in range(3)])
+    lb = BootstrapMeanBatched.apply(vb, 700, 0.3)
+    (la * w).sum().backward()
+    (lb * w).sum().backward()
+    assert torch.equal(la, lb) and torch.equal(va.grad, vb.grad)
+
+
 def test_bootstrap_mean_propagates_nan(dev):
     """the kernels clamp losses with fmaxf(v, 0) and fmaxf(NaN, 0) = 0 -- a diverged step used to report a finite loss.
     Both branches of the rule must return NaN when any per-pixel loss is NaN, like the reference's sort / mean do."""
