@@ -229,6 +229,70 @@ USE_HIP_BN = True       # tests switch it off to compare with the stock modules
 
 
 
+class S2WBanksTrain(torch.autograd.Function):
+    """Every level's filter bank of a decoder from the signal, differentiably, one launch forward and three backward
+    (hs_s2w_train_fwd / _bwd): ``apply(meta, signal, *weights)`` -> one patch-major bank (B fh fw, ld) per layer.  ``meta``: one dict
+    per layer with signal_index, signal_channels, groups, rows; ``weights``: the layers' Conv2d weights (wc, K, 1, 1) as they are.
+    Replaces, per level and step: the grouped 1x1 conv as a strided-batched GEMM (+ its two adjoint GEMMs), the re-layout into
+    per-patch weights and its adjoint (BankPack), and autograd's zero fills / accumulations of the d signal slices."""
+
+    @staticmethod
+    def _table(meta, signal, weights, banks=None, dbanks=None, dws=None, dss=None):
+        arr = (_hip.S2wTrainLayerC * len(meta))()
+        for i, (m, w) in enumerate(zip(meta, weights)):
+            a = arr[i]
+            a.signal_index, a.signal_channels, a.groups = m['signal_index'], m['signal_channels'], m['groups']
+            a.w, a.wc, a.rows = w.data_ptr(), w.shape[0], m['rows']
+            a.ld = m['ld']
+            a.bank = banks[i].data_ptr() if banks is not None else None
+            a.dbank = dbanks[i].data_ptr() if dbanks is not None and dbanks[i] is not None else None
+            a.dw = dws[i].data_ptr() if dws is not None and dws[i] is not None else None
+            a.ds = dss[i].data_ptr() if dss is not None and dss[i] is not None else None
+        return arr
+
+    @staticmethod
+    def forward(ctx, meta, signal, *weights):
+        signal = signal.contiguous().float()
+        weights = [w.contiguous().float() for w in weights]
+        b, c, fh, fw = signal.shape
+        p = b * fh * fw
+        meta = [dict(m, ld=HF._round_up(m['rows'], 4)) for m in meta]
+        with torch.cuda.device(signal.device):
+            buf = torch.empty(p * sum(m['ld'] for m in meta), device=signal.device, dtype=torch.float32)
+            banks, off = [], 0
+            for m in meta:
+                banks.append(buf[off:off + p * m['ld']].view(p, m['ld']))
+                off += p * m['ld']
+            arr = S2WBanksTrain._table(meta, signal, weights, banks=banks)
+            st = _hip.lib.hs_s2w_train_fwd(signal.data_ptr(), b, c, fh, fw, arr, len(meta), _hip.stream_ptr())
+            _hip.check(st, 'hs_s2w_train_fwd')
+        ctx.save_for_backward(signal, *weights)
+        ctx.meta = meta
+        return tuple(banks)
+
+    @staticmethod
+    def backward(ctx, *dbanks):
+        signal, *weights = ctx.saved_tensors
+        meta = ctx.meta
+        b, c, fh, fw = signal.shape
+        p = b * fh * fw
+        need_s = ctx.needs_input_grad[1]
+        need_w = [ctx.needs_input_grad[2 + i] for i in range(len(meta))]
+        dbs = []
+        for m, g in zip(meta, dbanks):
+            if g is not None and not (g.dtype == torch.float32 and g.stride(1) == 1 and g.stride(0) == m['ld'] and g.shape == (p, m['ld'])):
+                g = g.float().contiguous()
+            dbs.append(g)
+        with torch.cuda.device(signal.device):
+            dws = [torch.empty_like(w) if nw else None for w, nw in zip(weights, need_w)]
+            dss = [torch.empty(b, m['signal_channels'], fh, fw, device=signal.device, dtype=torch.float32) if need_s else None for m in meta]
+            dsig = torch.empty_like(signal) if need_s else None
+            arr = S2WBanksTrain._table(meta, signal, weights, dbanks=dbs, dws=dws, dss=dss)
+            st = _hip.lib.hs_s2w_train_bwd(signal.data_ptr(), b, c, fh, fw, arr, len(meta), dsig.data_ptr() if need_s else None, _hip.stream_ptr())
+            _hip.check(st, 'hs_s2w_train_bwd')
+        return (None, dsig) + tuple(dws)
+
+
 class PixelCrossEntropy(torch.autograd.Function):
     """F.cross_entropy(logits, target, ignore_index=..., reduction='none') for fp32 (N, C, H, W) CUDA logits, one launch per direction
     (hs_cross_entropy_fwd / _bwd; stock: log-softmax + gather and their adjoints)."""
@@ -530,3 +594,4 @@ def materialize_stage(stage):
 
 
 USE_HIP_STAGE = True        # tests switch it off to compare with the stock formulation
+USE_HIP_S2W_TRAIN = True    # the decoder's banks for training from one launch (S2WBanksTrain); off: one grouped conv (GEMM) per level

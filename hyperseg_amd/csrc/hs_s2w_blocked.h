@@ -129,6 +129,10 @@ inline int s2b_fill_args(S2bArgs& a, const float* signal, int batch, int c_signa
     return 0;
 }
 
+// hs_weights.hip: the all-layers launch behind hs_signal2weights_multi_fwd (native = the weights in the conv's own layout: training)
+int s2w_multi_launch(const float* signal, int32_t batch, int32_t c_signal, int32_t fh, int32_t fw,
+                     const hs_s2w_layer* layers, int32_t n_layers, bool native, void* stream);
+
 // argument checks shared by the entry points that take hs_s2w_layer tables
 inline int s2w_check_layer(const hs_s2w_layer& l, int c_signal) {
     if (!l.wsw_t || !l.bank || l.groups <= 0 || l.rows <= 0 || l.wc <= 0 || l.ld < l.rows || l.rows > l.wc) return HS_ERR_BAD_ARG;

@@ -32,6 +32,7 @@ struct S2wLayer {
     long ld;
     int signal_index, cs_g, rows_per_group, wc, rows;
     int strips_per_group, strip_begin;     // strips of this layer start at blockIdx.x == strip_begin
+    int a_rs, a_ks;                        // weight element (n, k) at wsw_t[n * a_rs + k * a_ks]: (1, wc) transposed, (cs_g, 1) the conv's own layout
 };
 struct S2wArgs {
     const float* __restrict__ signal;
@@ -46,7 +47,7 @@ template <int KS>
 __device__ __forceinline__ void s2w_task(const float* __restrict__ wsw_t, const float* __restrict__ signal,
                                          float* __restrict__ bank, long ld, int cs_g, int rpg, int wc, int rows,
                                          int r0, int n0, size_t sig_base, int c_signal, int grid_sz, int n_patches,
-                                         int tile0, int lane, float* __restrict__ stage) {
+                                         int tile0, int lane, float* __restrict__ stage, int a_rs, int a_ks) {
     const int lrow = lane & 15, lk = lane >> 4;
     const bool a0_ok = (r0 + lrow) < rpg, a1_ok = (r0 + 16 + lrow) < rpg;
     // 32-bit element offsets from the uniform base pointers (saddr + voffset addressing: one VGPR per load);
@@ -57,8 +58,8 @@ __device__ __forceinline__ void s2w_task(const float* __restrict__ wsw_t, const 
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         const unsigned kc = (unsigned)min(ks * 4 + lk, cs_g - 1);
-        a0[ks] = wsw_t[kc * (unsigned)wc + na0];
-        a1[ks] = wsw_t[kc * (unsigned)wc + na1];
+        a0[ks] = wsw_t[kc * (unsigned)a_ks + na0 * (unsigned)a_rs];
+        a1[ks] = wsw_t[kc * (unsigned)a_ks + na1 * (unsigned)a_rs];
     }
 #pragma unroll
     for (int t = 0; t < S2W_PT; ++t) {
@@ -139,8 +140,9 @@ void signal2weights_kernel(S2wArgs a) {
     const int ksteps = (cs_g + 3) >> 2;
     __shared__ float stage_all[4 * 16 * 33];
     float* stage = stage_all + wave * (16 * 33);
+    const int a_rs = ka->layer[li].a_rs, a_ks = ka->layer[li].a_ks;
 #define HS_S2W_CASE(KS) s2w_task<KS>(wsw_t, signal, bank, ld, cs_g, rpg, wc, rows, r0, n0, sig_base, c_signal, \
-                                     grid_sz, n_patches, tile0, lane, stage)
+                                     grid_sz, n_patches, tile0, lane, stage, a_rs, a_ks)
     if (ksteps <= 2) HS_S2W_CASE(2);
     else if (ksteps <= 4) HS_S2W_CASE(4);
     else if (ksteps <= 8) HS_S2W_CASE(8);
@@ -253,8 +255,10 @@ static int launch_s2w_blocked(const float* signal, int batch, int c_signal, int 
     return launch_status();
 }
 
-extern "C" int hs_signal2weights_multi_fwd(const float* signal, int32_t batch, int32_t c_signal, int32_t fh, int32_t fw,
-                                           const hs_s2w_layer* layers, int32_t n_layers, void* stream) {
+// ``native``: wsw_t points at the Conv2d weight in its OWN (wc, cs_g) layout (the training path: weights change every step, so
+// neither the transposed copy nor the packed image of the blocked form exists); always the direct kernel then.
+int hs::s2w_multi_launch(const float* signal, int32_t batch, int32_t c_signal, int32_t fh, int32_t fw,
+                         const hs_s2w_layer* layers, int32_t n_layers, bool native, void* stream) {
     if (!signal || !layers || n_layers <= 0 || n_layers > S2W_MAX_LAYERS) return HS_ERR_BAD_ARG;
     if (batch <= 0 || fh <= 0 || fw <= 0) return HS_ERR_BAD_ARG;
     if ((size_t)batch * c_signal * fh * fw >= (1ull << 31)) return HS_ERR_UNSUPPORTED;     // 32-bit element offsets
@@ -284,9 +288,10 @@ extern "C" int hs_signal2weights_multi_fwd(const float* signal, int32_t batch, i
         d.cs_g = l.signal_channels / l.groups; d.rows_per_group = l.wc / l.groups; d.wc = l.wc; d.rows = l.rows;
         d.strips_per_group = (d.rows_per_group + S2W_STRIP - 1) / S2W_STRIP;
         d.strip_begin = strips;
+        d.a_rs = native ? d.cs_g : 1; d.a_ks = native ? 1 : l.wc;
         strips += d.strips_per_group * l.groups;
     }
-    {
+    if (!native) {
         const int st = launch_s2w_blocked(signal, batch, c_signal, fh, fw, layers, order, n_layers, (hipStream_t)stream);
         if (st != 1) return st;
     }
@@ -296,6 +301,11 @@ extern "C" int hs_signal2weights_multi_fwd(const float* signal, int32_t batch, i
     dim3 grid(strips, (tiles + 4 * S2W_PT - 1) / (4 * S2W_PT));
     hipLaunchKernelGGL(signal2weights_kernel, grid, dim3(S2W_THREADS), 0, (hipStream_t)stream, a);
     return launch_status();
+}
+
+extern "C" int hs_signal2weights_multi_fwd(const float* signal, int32_t batch, int32_t c_signal, int32_t fh, int32_t fw,
+                                           const hs_s2w_layer* layers, int32_t n_layers, void* stream) {
+    return s2w_multi_launch(signal, batch, c_signal, fh, fw, layers, n_layers, false, stream);
 }
 
 extern "C" int hs_signal2weights_fwd(const float* signal, int32_t batch, int32_t c_signal, int32_t fh, int32_t fw,

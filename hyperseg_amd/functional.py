@@ -181,6 +181,31 @@ class BankRef:
         return 4
 
 
+class TrainBank:
+    """A level's bank on the TRAINING path: the patch-major (P, ld) tensor autograd.S2WBanksTrain produced (it carries the graph
+    back to the signal and to the level's signal2weights weight).  Travels through MetaSequential like a BankRef."""
+
+    def __init__(self, bank, batch, rows, grid):
+        self.bank, self.rows, self.grid = bank, rows, tuple(grid)
+        self.shape = torch.Size((batch, rows) + self.grid)
+        self.requires_grad = True
+
+    @property
+    def device(self):
+        return self.bank.device
+
+    def __getitem__(self, idx):
+        if not (isinstance(idx, tuple) and len(idx) == 2 and idx[0] == slice(None) and isinstance(idx[1], slice) and idx[1].step in (None, 1)):
+            raise IndexError('a filter bank supports only the channel-range slice ref[:, a:b]')
+        a, b, _ = idx[1].indices(self.rows)
+        if a == 0 and b == self.rows:
+            return self
+        return TrainBank(self.bank[:, a:max(a, b)], self.shape[0], max(b - a, 0), self.grid)
+
+    def dim(self):
+        return 4
+
+
 # Levels whose patches are at most this many pixels generate their bank inside the consumer (hs_patch_conv_gen_fwd) instead
 # of reading one that hs_signal2weights_multi_fwd wrote.  OFF by default (0): measured on MI355X (profiles/round2_bank_in_
 # consumer_ab.txt) it removes 2 x 18.4 MB of HBM traffic per HyperSeg-M frame but each fused launch takes 21.8 us against

@@ -99,6 +99,8 @@ class _SignalToWeights:
         return conv(sig)[:, :hp]
 
     def _train_mode(self, x, s):
+        if isinstance(s, HF.TrainBank):
+            return torch.is_grad_enabled()
         probe = [x.skip, x.prev] if isinstance(x, HF.StageInput) else [x]
         params = [self.signal2weights.weight] if self.signal2weights is not None else []
         return not isinstance(s, HF.BankRef) and HA.needs_grad(s, *probe, *params)
@@ -145,8 +147,11 @@ class HyperPatchNoPadding(EpochOnModeSwitch, nn.Module, _SignalToWeights):
             s = HF.signal2weights_multi(s.signal, [s.layer])[0]
         if self._train_mode(x, s):
             xt = HA.materialize_stage(x) if isinstance(x, HF.StageInput) else x
-            y = HA.patch_conv_train(xt, self._weights_train(s), self.out_channels, 1, 0, 'zeros', self.groups,
-                                    self.hyper_params)
+            if isinstance(s, HF.TrainBank):          # the bank already exists, patch-major and differentiable (autograd.S2WBanksTrain)
+                y = HA.patch_conv_apply(xt, s.bank, s.grid, self.out_channels, 1, 0, 'zeros', self.groups)
+            else:
+                y = HA.patch_conv_train(xt, self._weights_train(s), self.out_channels, 1, 0, 'zeros', self.groups,
+                                        self.hyper_params)
             return _apply_epilogue(y, scale, shift, act)
         fh, fw = s.shape[-2:]
         bank = self._bank(s, self.hyper_params)
@@ -185,6 +190,9 @@ class HyperPatch(EpochOnModeSwitch, nn.Module, _SignalToWeights):
             raise NotImplementedError('HyperPatch expects the wrapped conv to be unpadded')
         if self._train_mode(x, s):
             xt = HA.materialize_stage(x) if isinstance(x, HF.StageInput) else x
+            if isinstance(s, HF.TrainBank):
+                y = HA.patch_conv_apply(xt, s.bank, s.grid, conv.out_channels, k, self.padding[0], self.padding_mode, conv.groups)
+                return _apply_epilogue(y, scale, shift, act)
             y = HA.patch_conv_train(xt, self._weights_train(s), conv.out_channels, k, self.padding[0],
                                     self.padding_mode, conv.groups, conv.hyper_params)
             return _apply_epilogue(y, scale, shift, act)
@@ -278,12 +286,15 @@ class HyperPatchInvertedResidual(EpochOnModeSwitch, nn.Module, _SignalToWeights)
         conv, the depthwise 3x3 a zero-padded k=3 patch conv whose tile interiors are kept, pw3 a k=1 patch conv on the
         re-assembled image -- three HIP convolutions with HIP backward kernels; BatchNorm / ReLU6 / gather are stock."""
         xt = HA.materialize_stage(x) if isinstance(x, HF.StageInput) else x
-        w = self._weights_train(s)
         b, c, h, wd = xt.shape
-        fh, fw = w.shape[-2:]
-        ph, pw = h // fh, wd // fw
         r1, r2, r3 = self._ranges[1], self._ranges[2], self._ranges[3]
-        bank = HA.BankPack.apply(w, r3)
+        if isinstance(s, HF.TrainBank):              # patch-major and differentiable already (autograd.S2WBanksTrain)
+            bank, (fh, fw) = s.bank, s.grid
+        else:
+            w = self._weights_train(s)
+            fh, fw = w.shape[-2:]
+            bank = HA.BankPack.apply(w, r3)
+        ph, pw = h // fh, wd // fw
         grid = (fh, fw)
         own = HA.tiles_supported(xt)
         if own:                                                                    # one gather each way (hs_halo_tiles_fwd / _bwd)
@@ -501,13 +512,37 @@ class MultiScaleDecoder(EpochOnModeSwitch, nn.Module):
             carry.setdefault(best, []).insert(0, gi)
         return carry
 
+    def _train_banks(self, s):
+        """Every level's bank for the training path in ONE launch (autograd.S2WBanksTrain: hs_s2w_train_fwd, three launches back) --
+        or None when a level cannot take it (several signal-fed modules in a level, a signal2weights with a bias, K > 80, CPU)."""
+        if not (HA.USE_HIP_S2W_TRAIN and s.is_cuda and s.dtype in (torch.float32, torch.bfloat16)):
+            return None
+        groups = self._hyper_modules()
+        if any(len(g) != 1 for g in groups[:self.levels]) or (self.out_fc is not None and len(groups[-1]) != 1):
+            return None
+        flat = [g[0] for g in groups if g]
+        meta, weights = [], []
+        for m in flat:
+            conv = m.signal2weights
+            if conv is None or conv.bias is not None or m.signal_channels // conv.groups > 80 or conv.weight.dtype != torch.float32:
+                return None
+            if m.signal_index + m.signal_channels > s.shape[1]:
+                return None
+            meta.append(dict(signal_index=m.signal_index, signal_channels=m.signal_channels, groups=conv.groups, rows=int(m.hyper_params)))
+            weights.append(conv.weight.view(conv.weight.shape[0], -1))
+        banks = HA.S2WBanksTrain.apply(meta, s, *weights)
+        b, _, fh, fw = s.shape
+        return [HF.TrainBank(bk, b, mt['rows'], (fh, fw)) for bk, mt in zip(banks, meta)]
+
     def _forward_autograd(self, x, s):
-        """Training / gradient path: same modules, per-module weight generation, everything through autograd."""
+        """Training / gradient path: same modules, everything through autograd; the banks of all levels from one launch where the
+        decoder's structure allows (_train_banks), per-module weight generation otherwise."""
+        tb = self._train_banks(s) if isinstance(s, torch.Tensor) else None
         p = None
         for level in range(self.levels):
-            p = getattr(self, f'level_{level}')(HF.StageInput(x[-level - 1], p, coords=True), s)
+            p = getattr(self, f'level_{level}')(HF.StageInput(x[-level - 1], p, coords=True), tb[level] if tb is not None else s)
         if self.out_fc is not None:
-            p = self.out_fc(p, s)
+            p = self.out_fc(p, tb[-1] if tb is not None else s)
         if p.shape[2:] != x[0].shape[2:]:
             p = HA.upsample_bilinear(p, x[0].shape[2:])
         return p

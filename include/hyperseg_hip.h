@@ -429,6 +429,29 @@ int hs_bn_act_train_bwd(int32_t dtype, const void* x, const void* dy, int32_t ba
                         const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, float eps, int32_t act,
                         void* workspace, void* dx, float* dgamma, float* dbeta, void* stream);
 
+/* signal2weights on the TRAINING path, every level of a decoder per launch (hyperseg_v1_0.py:473-484 + the permute / reshape of
+ * :334-337, 491, and their autograd): the weights are the Conv2d parameters in their OWN layout (wc, signal_channels / groups) --
+ * they change every step, so no transposed or packed copy exists -- and banks / bank gradients are patch-major (P, ld), P = batch*fh*fw.
+ *   hs_s2w_train_fwd   bank[p, n] = sum_k w[n, k] * signal[b, signal_index + g(n) * K + k, i, j],  n < rows        (one launch)
+ *   hs_s2w_train_bwd   dw[n, k] = sum_p dbank[p, n] * signal[...]  (rows in [rows, wc): exact zeros; dbank NULL = zero gradient),
+ *                      dsignal[b, c, i, j] = sum over the layers whose channel range holds c of sum_n dbank[p, n] * w[n, k]
+ *                      (channels no layer reads: zeros); `ds` is each layer's private (batch, signal_channels, fh, fw) scratch.
+ *                      dw / dsignal may be NULL (not wanted).  Three launches, no atomics. */
+typedef struct hs_s2w_train_layer {
+    int32_t signal_index, signal_channels, groups;
+    const float* w;            /* (wc, signal_channels / groups) */
+    int32_t wc, rows;
+    float* bank;               /* forward: (P, ld) out */
+    int64_t ld;
+    const float* dbank;        /* backward: (P, ld) or NULL */
+    float* dw;                 /* backward: (wc, signal_channels / groups) out or NULL */
+    float* ds;                 /* backward: scratch, see above */
+} hs_s2w_train_layer;
+int hs_s2w_train_fwd(const float* signal, int32_t batch, int32_t c_signal, int32_t fh, int32_t fw,
+                     const hs_s2w_train_layer* layers, int32_t n_layers, void* stream);
+int hs_s2w_train_bwd(const float* signal, int32_t batch, int32_t c_signal, int32_t fh, int32_t fw,
+                     const hs_s2w_train_layer* layers, int32_t n_layers, float* dsignal, void* stream);
+
 /* Per-pixel cross entropy, F.cross_entropy(logits (N,C,H,W), target (N,H,W) int64, ignore_index, reduction='none') without class
  * weights -- what BootstrappedCrossEntropyLoss.forward computes before its top-k rule (hyperseg/losses/bootstrapped_ce_loss.py:20-23) --
  * and its adjoint, one launch each: loss (N,H,W) (0 at ignored pixels); grad_logits (N,C,H,W) = (softmax - onehot) * grad_loss. */

@@ -278,6 +278,55 @@ def test_stage_input_under_autograd_vs_stock_ops(dev, case, dtype):
             assert rel_err(b.cpu(), a.cpu()) < tol
 
 
+@pytest.mark.parametrize('b,grid', [(2, (18, 18)), (1, (3, 5)), (3, (4, 4))])
+def test_s2w_banks_train_vs_grouped_conv_autograd(dev, b, grid):
+    """autograd.S2WBanksTrain (hs_s2w_train_fwd / _bwd: every level's bank in one launch, dW of every level in one, d signal in two)
+    == the grouped 1x1 convolutions + re-layout + autograd they replace (hyperseg_v1_0.py:473-484, 334-337): banks, d weight (exact zeros
+    on the next_multiply padding rows), d signal accumulated over levels that read OVERLAPPING channel ranges from 0 (appendix D-1), an
+    unused level (no gradient), odd grids, K from 3 to 80."""
+    import torch.nn.functional as F
+    from hyperseg_amd.autograd import S2WBanksTrain
+    g = torch.Generator().manual_seed(7 * b + grid[0])
+    fh, fw = grid
+    c_signal = 352
+    layers = [dict(signal_index=0, signal_channels=320, groups=4, rows=4216, wc=4216), dict(signal_index=0, signal_channels=56, groups=8, rows=1892, wc=1896),
+              dict(signal_index=8, signal_channels=24, groups=8, rows=700, wc=704), dict(signal_index=40, signal_channels=192, groups=16, rows=2352, wc=2352),
+              dict(signal_index=300, signal_channels=52, groups=4, rows=101, wc=104)]
+    s = torch.relu(torch.randn(b, c_signal, fh, fw, generator=g)).to(dev)
+    ws = [(torch.randn(l['wc'], l['signal_channels'] // l['groups'], generator=g) * 0.2).to(dev) for l in layers]
+    p = b * fh * fw
+    rs = [torch.randn(p, (l['rows'] + 3) // 4 * 4, generator=g).to(dev) for l in layers]
+    unused = 2                                                           # this level's bank takes no part in the loss
+    # stock formulation
+    sa, wa = s.clone().requires_grad_(True), [w.clone().requires_grad_(True) for w in ws]
+    loss = 0
+    ref_banks = []
+    for i, (l, w) in enumerate(zip(layers, wa)):
+        y = F.conv2d(sa[:, l['signal_index']:l['signal_index'] + l['signal_channels']], w.view(l['wc'], -1, 1, 1), groups=l['groups'])[:, :l['rows']]
+        bank = y.permute(0, 2, 3, 1).reshape(p, l['rows'])
+        ref_banks.append(bank.detach())
+        if i != unused:
+            loss = loss + (bank * rs[i][:, :l['rows']]).sum()
+    loss.backward()
+    # one launch each
+    sb, wb = s.clone().requires_grad_(True), [w.clone().requires_grad_(True) for w in ws]
+    meta = [dict(signal_index=l['signal_index'], signal_channels=l['signal_channels'], groups=l['groups'], rows=l['rows']) for l in layers]
+    banks = S2WBanksTrain.apply(meta, sb, *wb)
+    loss = 0
+    for i, (l, bank) in enumerate(zip(layers, banks)):
+        assert rel_err(bank[:, :l['rows']].detach().cpu(), ref_banks[i].cpu()) < 2e-6
+        if i != unused:
+            loss = loss + (bank[:, :l['rows']] * rs[i][:, :l['rows']]).sum()
+    loss.backward()
+    assert rel_err(sb.grad.cpu(), sa.grad.cpu()) < 1e-5
+    for i, (l, a, bb) in enumerate(zip(layers, wa, wb)):
+        if i == unused:
+            assert a.grad is None and (bb.grad is None or float(bb.grad.abs().max()) == 0.0)
+            continue
+        assert rel_err(bb.grad.cpu(), a.grad.cpu()) < 1e-5
+        assert float(bb.grad[l['rows']:].abs().max()) == 0.0 if l['rows'] < l['wc'] else True
+
+
 @pytest.mark.parametrize('shape,ignore', [((2, 12, 36, 20), 255), ((1, 19, 7, 5), -100), ((3, 3, 1, 70), 255), ((2, 21, 33, 17), 255)])
 def test_pixel_cross_entropy_vs_torch(dev, shape, ignore):
     """hs_cross_entropy_fwd / _bwd (autograd.PixelCrossEntropy) == F.cross_entropy(..., ignore_index, reduction='none') and its

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-4 visit g: training-path changes (stage input in one launch, own final upsample, BN counter in-kernel): tests + step times + profile.
-tag=${1:-r4j}; R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; mkdir -p gpurun_out; export TMPDIR=/tmp
+tag=${1:-r4k}; R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; mkdir -p gpurun_out; export TMPDIR=/tmp
 timeout 600 python -m pytest tests -m gpu -q -p no:cacheprovider -x tests/test_hip_training.py tests/test_checkpoint.py tests/test_distributed.py -k "not config5_full" > gpurun_out/pytest_$tag.log 2>&1; tail -4 gpurun_out/pytest_$tag.log
 timeout 300 python -m pytest tests -m gpu -q -p no:cacheprovider -x -k "meta_conv2d or coscheduled or config5 or train_step" > gpurun_out/pytest_${tag}_b.log 2>&1; tail -4 gpurun_out/pytest_${tag}_b.log
 timeout 200 python tools/train_step_time.py 20 > gpurun_out/train_step_$tag.txt 2>&1; cat gpurun_out/train_step_$tag.txt | tail -4
