@@ -217,9 +217,11 @@ int hs_patch_ir_v0_ws_fwd(const hs_stage_input* in, int32_t fh, int32_t fw,
  *       <= 16 skip and <= 16 previous-level channels: csrc/hs_patch_irc.hip): every f32 operand is scaled by a power of two
  *       and split into two f16 pieces, a product is ah*bh + al*bh + ah*bl accumulated in f32.  f32-class: the measured
  *       error of a dot product is BELOW an f32 fmaf chain's (tools/ubench/f16_probe.hip: 1.3e-7 vs 2.2e-7 of sum|a||b|).
- *       The scales are taken from the data (the exact maximum of every weight row, of every halo position's input column),
- *       so any overall magnitude is carried; what is not is a dynamic range beyond ~2^18 INSIDE one reduction (an input
- *       2^20 above its position's other channels meeting a weight 2^-20 of its row's maximum).
+ *       The scales are taken from the data -- the exact maximum of each weight MATRIX of the patch (pw1, pw3; even channel
+ *       counts, round 4: the f16 pieces hold 2^15 of range below that maximum, so a row keeps f32-class accuracy as long as
+ *       its own maximum is within 2^15 of the matrix's; odd channel counts keep one scale per row) and of every halo
+ *       position's input column -- so any overall magnitude is carried; what is not is a dynamic range beyond ~2^18 INSIDE
+ *       one reduction (an input 2^20 above its position's other channels meeting a weight 2^-20 of its matrix's maximum).
  *   HS_IR_MATH_AUTO   SPLIT where it is the faster form, F32 elsewhere (today the two coincide with SPLIT's coverage).
  * The reference runs these layers as fp32 torch convolutions (which cuDNN may run in TF32 there); all modes are held to the
  * same parity tolerance (tests/test_hip_parity.py).  The nn.Module mirror defaults to F32; serving / bench.py opt into AUTO
