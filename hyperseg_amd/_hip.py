@@ -162,6 +162,25 @@ def dev_ptr(t, name='tensor', dtype=torch.float32):
     return t.data_ptr()
 
 
+class _NullScope:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL_SCOPE = _NullScope()
+
+
+def device_scope(device):
+    """``torch.cuda.device(device)`` only when ``device`` is not already current: the guard's enter / exit is a few microseconds of
+    host time per launch, and an eager training step is ~150 launches that are host-bound (the common case: one GPU per process)."""
+    if device.index is None or device.index == torch.cuda.current_device():
+        return _NULL_SCOPE
+    return torch.cuda.device(device)
+
+
 def stream_ptr(device=None):
     """The caller's current HIP stream on ``device`` (default: the current device).  hyperseg_amd.functional enters
     ``torch.cuda.device(tensor.device)`` around every launch, so 'current' is the device that owns the operands."""

@@ -58,7 +58,7 @@ class PatchConv(torch.autograd.Function):
         if x.dtype == torch.float32:
             y = HF.patch_conv(x, grid, bank, c_out, k, padding, padding_mode, groups)
         else:
-            with torch.cuda.device(x.device):
+            with _hip.device_scope(x.device):
                 y = _plain_conv('fwd', x.dtype, x, bank, bank.stride(0), x.shape, meta,
                                 torch.empty(x.shape[0], c_out, x.shape[2], x.shape[3], device=x.device, dtype=x.dtype))
         ctx.save_for_backward(x, bank)
@@ -73,7 +73,7 @@ class PatchConv(torch.autograd.Function):
         dy = dy.contiguous().to(x.dtype)
         b, c_in, h, w = x.shape
         dx = dbank = None
-        with torch.cuda.device(x.device):
+        with _hip.device_scope(x.device):
             stream = _hip.stream_ptr()
             bank_ptr, ld = bank.data_ptr(), bank.stride(0)
             if ctx.needs_input_grad[0]:
@@ -117,7 +117,7 @@ class HaloTiles(torch.autograd.Function):
         b, c, h, w = x.shape
         fh, fw = grid
         ctx.meta = (b, c, h, w, (fh, fw), x.dtype)
-        with torch.cuda.device(x.device):
+        with _hip.device_scope(x.device):
             out = torch.empty(b, c, fh * (h // fh + 2), fw * (w // fw + 2), device=x.device, dtype=x.dtype)
             return _tile_call('hs_halo_tiles_fwd', x.dtype, x, b, c, h, w, (fh, fw), out)
 
@@ -125,7 +125,7 @@ class HaloTiles(torch.autograd.Function):
     def backward(ctx, dt):
         b, c, h, w, grid, dtype = ctx.meta
         dt = dt.contiguous().to(dtype)
-        with torch.cuda.device(dt.device):
+        with _hip.device_scope(dt.device):
             return _tile_call('hs_halo_tiles_bwd', dtype, dt, b, c, h, w, grid, torch.empty(b, c, h, w, device=dt.device, dtype=dtype)), None
 
 
@@ -138,14 +138,14 @@ class TileInterior(torch.autograd.Function):
         b, c = t.shape[:2]
         h, w = size
         ctx.meta = (b, c, h, w, tuple(grid), t.dtype, tuple(t.shape))
-        with torch.cuda.device(t.device):
+        with _hip.device_scope(t.device):
             return _tile_call('hs_tile_interior_fwd', t.dtype, t, b, c, h, w, grid, torch.empty(b, c, h, w, device=t.device, dtype=t.dtype))
 
     @staticmethod
     def backward(ctx, dy):
         b, c, h, w, grid, dtype, shape = ctx.meta
         dy = dy.contiguous().to(dtype)
-        with torch.cuda.device(dy.device):
+        with _hip.device_scope(dy.device):
             return _tile_call('hs_tile_interior_bwd', dtype, dy, b, c, h, w, grid, torch.empty(shape, device=dy.device, dtype=dtype)), None, None
 
 
@@ -163,7 +163,7 @@ class BNActTrain(torch.autograd.Function):
         b, c = x.shape[:2]
         px = x.numel() // (b * c)
         dev = x.device
-        with torch.cuda.device(dev):
+        with _hip.device_scope(dev):
             y = torch.empty_like(x)
             mean, invstd = torch.empty(c, device=dev, dtype=torch.float32), torch.empty(c, device=dev, dtype=torch.float32)
             ws = torch.empty(int(_hip.lib.hs_bn_train_workspace(c)), device=dev, dtype=torch.uint8)
@@ -185,7 +185,7 @@ class BNActTrain(torch.autograd.Function):
         b, c, px, eps, act = ctx.meta
         dy = dy.contiguous().to(x.dtype)
         dev = x.device
-        with torch.cuda.device(dev):
+        with _hip.device_scope(dev):
             dx = torch.empty_like(x)
             dg = torch.empty(c, device=dev, dtype=torch.float32) if weight is not None else None
             db = torch.empty(c, device=dev, dtype=torch.float32) if bias is not None else None
@@ -257,7 +257,7 @@ class S2WBanksTrain(torch.autograd.Function):
         b, c, fh, fw = signal.shape
         p = b * fh * fw
         meta = [dict(m, ld=HF._round_up(m['rows'], 4)) for m in meta]
-        with torch.cuda.device(signal.device):
+        with _hip.device_scope(signal.device):
             buf = torch.empty(p * sum(m['ld'] for m in meta), device=signal.device, dtype=torch.float32)
             banks, off = [], 0
             for m in meta:
@@ -283,7 +283,7 @@ class S2WBanksTrain(torch.autograd.Function):
             if g is not None and not (g.dtype == torch.float32 and g.stride(1) == 1 and g.stride(0) == m['ld'] and g.shape == (p, m['ld'])):
                 g = g.float().contiguous()
             dbs.append(g)
-        with torch.cuda.device(signal.device):
+        with _hip.device_scope(signal.device):
             dws = [torch.empty_like(w) if nw else None for w, nw in zip(weights, need_w)]
             dss = [torch.empty(b, m['signal_channels'], fh, fw, device=signal.device, dtype=torch.float32) if need_s else None for m in meta]
             dsig = torch.empty_like(signal) if need_s else None
@@ -302,7 +302,7 @@ class PixelCrossEntropy(torch.autograd.Function):
         logits, target = logits.contiguous(), target.contiguous()
         n, c = logits.shape[:2]
         px = logits.numel() // (n * c)
-        with torch.cuda.device(logits.device):
+        with _hip.device_scope(logits.device):
             loss = torch.empty(target.shape, device=logits.device, dtype=torch.float32)
             st = _hip.lib.hs_cross_entropy_fwd(logits.data_ptr(), target.data_ptr(), n, c, px, int(ignore_index), loss.data_ptr(), _hip.stream_ptr())
             _hip.check(st, 'hs_cross_entropy_fwd')
@@ -316,7 +316,7 @@ class PixelCrossEntropy(torch.autograd.Function):
         n, c = logits.shape[:2]
         px = logits.numel() // (n * c)
         g = g.contiguous().float()
-        with torch.cuda.device(logits.device):
+        with _hip.device_scope(logits.device):
             dl = torch.empty_like(logits)
             st = _hip.lib.hs_cross_entropy_bwd(logits.data_ptr(), target.data_ptr(), n, c, px, ctx.ignore_index, g.data_ptr(), dl.data_ptr(),
                                                _hip.stream_ptr())
@@ -332,7 +332,7 @@ class BootstrapMean(torch.autograd.Function):
     def forward(ctx, values, k, thresh):
         values = values.contiguous()
         n = values.numel()
-        with torch.cuda.device(values.device):
+        with _hip.device_scope(values.device):
             ws = torch.empty(int(_hip.lib.hs_bootstrap_mean_workspace()), device=values.device, dtype=torch.uint8)
             out = torch.empty(8, device=values.device, dtype=torch.float32)
             st = _hip.lib.hs_bootstrap_mean_fwd(values.data_ptr(), n, int(k), float(thresh), ws.data_ptr(), out.data_ptr(), _hip.stream_ptr())
@@ -343,7 +343,7 @@ class BootstrapMean(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         values, state = ctx.saved_tensors
-        with torch.cuda.device(values.device):
+        with _hip.device_scope(values.device):
             gv = torch.empty_like(values)
             st = _hip.lib.hs_bootstrap_mean_bwd(values.data_ptr(), values.numel(), state.data_ptr(),
                                                 g.contiguous().float().data_ptr(), gv.data_ptr(), _hip.stream_ptr())
@@ -366,7 +366,7 @@ class MetaConvGeneral(torch.autograd.Function):
         if ho <= 0 or wo <= 0:
             raise ValueError(f'kernel {kernel_size} (dilation {dilation}) does not fit the padded {h}x{wd} input')
         y = torch.empty(b, c_out, ho, wo, device=x.device, dtype=torch.float32)
-        with torch.cuda.device(x.device):
+        with _hip.device_scope(x.device):
             st = _hip.lib.hs_meta_conv_fwd(_hip.dev_ptr(x, 'x'), b, cin, h, wd, _hip.dev_ptr(w, 'w'), w.stride(0), c_out, kh, kw,
                                            sh, sw, pt, pb, pl, pr, dh, dw, 0, groups, None, y.data_ptr(), _hip.stream_ptr())
             _hip.check(st, 'hs_meta_conv_fwd')
@@ -385,7 +385,7 @@ class MetaConvGeneral(torch.autograd.Function):
         dwt = None
         if ctx.needs_input_grad[1]:
             dwt = (torch.empty if rows == w.shape[1] else torch.zeros)(w.shape, device=w.device, dtype=torch.float32)
-        with torch.cuda.device(x.device):
+        with _hip.device_scope(x.device):
             st = _hip.lib.hs_meta_conv_bwd(x.data_ptr(), b, cin, h, wd, w.data_ptr(), w.stride(0), c_out, kh, kw, sh, sw, pt, pb, pl, pr,
                                            dh, dw, groups, dy.data_ptr(), dx.data_ptr() if dx is not None else None,
                                            dwt.data_ptr() if dwt is not None else None, dwt.stride(0) if dwt is not None else 0,
@@ -416,7 +416,7 @@ class BootstrapMeanBatched(torch.autograd.Function):
     def forward(ctx, values, k, thresh):
         values = values.contiguous()
         imgs, n = values.shape
-        with torch.cuda.device(values.device):
+        with _hip.device_scope(values.device):
             ws = torch.empty(imgs * int(_hip.lib.hs_bootstrap_mean_workspace()), device=values.device, dtype=torch.uint8)
             out = torch.empty(imgs, 8, device=values.device, dtype=torch.float32)
             st = _hip.lib.hs_bootstrap_mean_batched_fwd(values.data_ptr(), imgs, n, int(k), float(thresh), ws.data_ptr(), out.data_ptr(),
@@ -429,7 +429,7 @@ class BootstrapMeanBatched(torch.autograd.Function):
     def backward(ctx, g):
         values, state = ctx.saved_tensors
         imgs, n = values.shape
-        with torch.cuda.device(values.device):
+        with _hip.device_scope(values.device):
             gv = torch.empty_like(values)
             st = _hip.lib.hs_bootstrap_mean_batched_bwd(values.data_ptr(), imgs, n, state.data_ptr(), g.contiguous().float().data_ptr(),
                                                         gv.data_ptr(), _hip.stream_ptr())
@@ -459,7 +459,7 @@ class UpsampleBilinear(torch.autograd.Function):
     def backward(ctx, dy):
         (b, c, hi, wi), (ho, wo), dt = ctx.meta
         dy = dy.contiguous().float()
-        with torch.cuda.device(dy.device):
+        with _hip.device_scope(dy.device):
             dx = torch.empty(b, c, hi, wi, device=dy.device, dtype=torch.float32)
             st = _hip.lib.hs_upsample_bilinear_bwd(dy.data_ptr(), 0, b, c, hi, wi, ho, wo, dx.data_ptr(), _hip.stream_ptr())
             _hip.check(st, 'hs_upsample_bilinear_bwd')
@@ -512,7 +512,7 @@ class BankPack(torch.autograd.Function):
     def backward(ctx, dbank):
         b, c, fh, fw = ctx.shape
         if dbank.is_cuda and dbank.dtype == torch.float32 and dbank.stride(1) == 1 and b <= 65535:
-            with torch.cuda.device(dbank.device):                  # one LDS-tiled transpose incl. the zero tail (hs_bank_unpack_fwd)
+            with _hip.device_scope(dbank.device):                  # one LDS-tiled transpose incl. the zero tail (hs_bank_unpack_fwd)
                 dw = torch.empty(ctx.shape, device=dbank.device, dtype=torch.float32)
                 st = _hip.lib.hs_bank_unpack_fwd(dbank.data_ptr(), dbank.stride(0), b, c, fh, fw, 0, ctx.rows, dw.data_ptr(), _hip.stream_ptr())
                 _hip.check(st, 'hs_bank_unpack_fwd')
@@ -555,7 +555,7 @@ class StageMaterialize(torch.autograd.Function):
             else:
                 # the previous level's channel range of dy is read IN PLACE (batch stride = all channels): no slice copy
                 dyc = dy if (dy.is_contiguous() and dy.dtype == torch.float32) else dy.contiguous().float()
-                with torch.cuda.device(dy.device):
+                with _hip.device_scope(dy.device):
                     dprev = torch.empty(b, cp, hp, wp, device=dy.device, dtype=torch.float32)
                     st = _hip.lib.hs_upsample_bilinear_bwd(dyc.data_ptr() + 4 * (off + cs) * h * w, dyc.shape[1] * h * w, b, cp, hp, wp, h, w,
                                                            dprev.data_ptr(), _hip.stream_ptr())
