@@ -288,7 +288,10 @@ class S2WBanksTrain(torch.autograd.Function):
             dss = [torch.empty(b, m['signal_channels'], fh, fw, device=signal.device, dtype=torch.float32) if need_s else None for m in meta]
             dsig = torch.empty_like(signal) if need_s else None
             arr = S2WBanksTrain._table(meta, signal, weights, dbanks=dbs, dws=dws, dss=dss)
-            st = _hip.lib.hs_s2w_train_bwd(signal.data_ptr(), b, c, fh, fw, arr, len(meta), dsig.data_ptr() if need_s else None, _hip.stream_ptr())
+            nws = int(_hip.lib.hs_s2w_train_workspace(b, fh, fw, arr, len(meta))) if any(need_w) else 0
+            ws = torch.empty(nws, device=signal.device, dtype=torch.uint8) if nws else None
+            st = _hip.lib.hs_s2w_train_bwd(signal.data_ptr(), b, c, fh, fw, arr, len(meta), dsig.data_ptr() if need_s else None,
+                                           ws.data_ptr() if ws is not None else None, nws, _hip.stream_ptr())
             _hip.check(st, 'hs_s2w_train_bwd')
         return (None, dsig) + tuple(dws)
 

@@ -29,10 +29,13 @@ struct StLayer {
     int signal_index, K, rpg, wc, rows, groups;
     int blocks_per_group;                   // row blocks (mode 0) / patch blocks (mode 1)
     int wg_begin;
+    long dw_off;                            // mode 0: where this layer's (wc, K) partial sums start inside one slice of the workspace
 };
 struct StArgs {
     const float* __restrict__ signal;
     int c_signal, grid_sz, n_patches, n_layers;
+    float* __restrict__ dw_partial;         // mode 0: [patch slice][sum over layers of wc K] partial sums, or null (one slice: straight into dw)
+    long dw_slice_floats;
     StLayer layer[S2W_MAX_LAYERS];
 };
 
@@ -60,88 +63,131 @@ void s2w_train_bwd_kernel(StArgs a) {
     __shared__ __attribute__((aligned(16))) float A[ST_TILE * ST_APAD];
     __shared__ __attribute__((aligned(16))) float Bm[ST_TILE * ST_KMAX];
     const int tid = threadIdx.x, lo = tid & 63, hi = tid >> 6;        // hi = wave index (uniform)
+    const int l16 = lo & 15, kk = lo >> 4;
+    const int KT = (KP + 15) >> 4;                                    // 16-wide tiles along K
     f32x4 acc[5];
 #pragma unroll
     for (int q = 0; q < 5; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int out0 = blk * ST_TILE;                                   // first row of the group (mode 0) / first patch (mode 1) of the tile
-    const int red_n = MODE == 0 ? P : rpg;
-    for (int c0 = 0; c0 < red_n; c0 += ST_TILE) {
-        if (c0 > 0) __syncthreads();
-        // ---- A: dBank, coalesced along the bank's rows
-        if (MODE == 0) {
-#pragma unroll 4
-            for (int q = 0; q < 16; ++q) {                            // i = patch of the chunk, j = lo = row of the tile
-                const int i = hi + 4 * q, p = c0 + i, r = out0 + lo, n = g * rpg + r;
-                const bool ok = dbank && p < P && r < rpg && n < rows;
-                A[i * ST_APAD + lo] = ok ? dbank[(size_t)p * ld + n] : 0.0f;
-            }
-        } else {
-#pragma unroll 4
-            for (int q = 0; q < 16; ++q) {                            // j = patch of the tile, i = lo = row of the chunk
-                const int j = hi + 4 * q, p = out0 + j, r = c0 + lo, n = g * rpg + r;
-                const bool ok = dbank && p < P && r < rpg && n < rows;
-                A[lo * ST_APAD + j] = ok ? dbank[(size_t)p * ld + n] : 0.0f;
+    // mode 0 with a workspace: the patches are cut into slices of 64 (blockIdx.y), every workgroup reduces ONE slice and leaves a partial
+    // tile; s2w_train_dwsum_kernel adds the slices in order.  (One workgroup walking all 648 patches was a 122 us latency chain on 304
+    // workgroups -- the longest launch of the config-5 step, visit r4m.)
+    const int red_lo = (MODE == 0 && ka->dw_partial) ? (int)blockIdx.y * ST_TILE : 0;
+    const int red_hi = MODE == 0 ? (ka->dw_partial ? min(red_lo + ST_TILE, P) : P) : rpg;
+    for (int c0 = red_lo; c0 < red_hi; c0 += ST_TILE) {
+        if (c0 > red_lo) __syncthreads();
+        // ---- A: dBank, coalesced along the bank's rows.  Every load is UNCONDITIONAL from a clamped address and masked afterwards: behind
+        //      `ok ? load : 0` the compiler branches around each load and waits for it at the join -- 16 serialised round trips per
+        //      thread and chunk, which is what the first version of this kernel spent its 54-80 us on (visit r4o).
+        float av16[16];
+        if (dbank) {                                                  // uniform
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int p = MODE == 0 ? c0 + hi + 4 * q : out0 + hi + 4 * q;
+                const int r = MODE == 0 ? out0 + lo : c0 + lo;
+                const int n = min(g * rpg + min(r, rpg - 1), rows - 1);
+                av16[q] = dbank[(size_t)min(p, P - 1) * ld + n];
             }
         }
         // ---- B
+        float bv20[20];
         if (MODE == 0) {                                              // S[patch c0 + lo][k]: consecutive lanes = consecutive patches
             const int p = min(c0 + lo, P - 1);
             const int bb = p / grid_sz, ij = p - bb * grid_sz;
             const float* sp = signal + ((size_t)bb * c_signal + sidx + g * K) * grid_sz + ij;
-            for (int k = hi; k < KP; k += 4)
-                Bm[lo * ST_KMAX + k] = (k < K && c0 + lo < P) ? sp[(size_t)k * grid_sz] : 0.0f;
+#pragma unroll
+            for (int q = 0; q < 20; ++q) bv20[q] = sp[(size_t)min(hi + 4 * q, K - 1) * grid_sz];
+        }
+        __builtin_amdgcn_sched_barrier(0);                            // all of the chunk's global loads are in flight before the first LDS store
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int p = MODE == 0 ? c0 + hi + 4 * q : out0 + hi + 4 * q;
+            const int r = MODE == 0 ? out0 + lo : c0 + lo;
+            const bool ok = dbank && p < P && r < rpg && g * rpg + r < rows;
+            if (MODE == 0) A[(hi + 4 * q) * ST_APAD + lo] = ok ? av16[q] : 0.0f;     // i = patch of the chunk, j = lo = row of the tile
+            else A[lo * ST_APAD + hi + 4 * q] = ok ? av16[q] : 0.0f;                 // j = patch of the tile, i = lo = row of the chunk
+        }
+        if (MODE == 0) {
+#pragma unroll
+            for (int q = 0; q < 20; ++q) {
+                const int k = hi + 4 * q;
+                if (k < 16 * KT) Bm[lo * ST_KMAX + k] = (k < K && c0 + lo < P) ? bv20[q] : 0.0f;      // columns past K: zeros (16-wide tiles)
+            }
         } else {                                                      // W[row c0 + i][k]: one linear run of 64 K floats
             const int n_first = g * rpg + c0;
-            for (int e = tid; e < ST_TILE * KP; e += 256) {
-                const int i = e / KP, k = e - i * KP;
+            const int KW = 16 * KT;
+            for (int e = tid; e < ST_TILE * KW; e += 256) {
+                const int i = e / KW, k = e - i * KW;
                 const int n = n_first + i;
-                Bm[i * ST_KMAX + k] = (k < K && c0 + i < rpg && n < wc) ? w[(size_t)n * K + k] : 0.0f;
+                const float wv = w[(size_t)min(n, wc - 1) * K + min(k, K - 1)];
+                Bm[i * ST_KMAX + k] = (k < K && c0 + i < rpg && n < wc) ? wv : 0.0f;
             }
         }
         __syncthreads();
-        // ---- acc[j][k] += A[i][j] B[i][k]: lane = j, the wave owns the k quads hi, hi + 4, ... (broadcast reads of B)
-        for (int i = 0; i < ST_TILE; ++i) {
-            const float av = A[i * ST_APAD + lo];
+        // ---- acc[j][k] += sum_i A[i][j] B[i][k] on the f32 matrix cores (v_mfma_f32_16x16x4_f32: the exact fma chain, i ascending):
+        //      wave hi owns j in [16 hi, 16 hi + 16), KT tiles of 16 k; a lane fetches ONE element of each operand per 4 reduction steps
+        //      (the vector form read B as broadcast float4s: 6 LDS instructions per step, and the launch was LDS-bound -- 54 / 80 us).
+        //      Mode 0: D[row j][k] (lanes along k: dW's rows are contiguous in k); mode 1: the operands swapped, D[k][patch j] (lanes along
+        //      the patches: d signal is contiguous in them).
+        for (int q = 0; q < ST_TILE / 4; ++q) {
+            const float av = A[(4 * q + kk) * ST_APAD + 16 * hi + l16];
 #pragma unroll
-            for (int q = 0; q < 5; ++q) {
-                const int kq = hi + 4 * q;
-                if (4 * kq < KP) {
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(Bm + i * ST_KMAX + 4 * kq);
-                    acc[q][0] = fmaf(av, b4[0], acc[q][0]); acc[q][1] = fmaf(av, b4[1], acc[q][1]);
-                    acc[q][2] = fmaf(av, b4[2], acc[q][2]); acc[q][3] = fmaf(av, b4[3], acc[q][3]);
+            for (int t = 0; t < 5; ++t) {
+                if (t < KT) {
+                    const float bv = Bm[(4 * q + kk) * ST_KMAX + 16 * t + l16];
+                    acc[t] = MODE == 0 ? __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[t], 0, 0, 0);
                 }
             }
         }
     }
-    // ---- store
+    // ---- store (D: the lane holds rows 4 kk + r, column l16 of every tile)
     if (MODE == 0) {
-        float* __restrict__ dw = ka->layer[li].dw;
-        const int r = out0 + lo, n = g * rpg + r;
-        if (dw && r < rpg && n < wc) {
+        float* __restrict__ dw = ka->dw_partial ? ka->dw_partial + (size_t)blockIdx.y * ka->dw_slice_floats + ka->layer[li].dw_off : ka->layer[li].dw;
 #pragma unroll
-            for (int q = 0; q < 5; ++q)
+        for (int r = 0; r < 4; ++r) {
+            const int rr = out0 + 16 * hi + 4 * kk + r, n = g * rpg + rr;
+            if (dw && rr < rpg && n < wc) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int k = 4 * (hi + 4 * q) + e;
-                    if (k < K) dw[(size_t)n * K + k] = acc[q][e];        // rows past `rows` accumulated zeros only
+                for (int t = 0; t < 5; ++t) {
+                    const int k = 16 * t + l16;
+                    if (t < KT && k < K) dw[(size_t)n * K + k] = acc[t][r];   // rows past `rows` accumulated zeros only
                 }
+            }
         }
     } else {
         float* __restrict__ ds = ka->layer[li].ds;
-        const int p = out0 + lo;
+        const int p = out0 + 16 * hi + l16;
         if (ds && p < P) {
             const int bb = p / grid_sz, ij = p - bb * grid_sz;
             const int Cs = K * ka->layer[li].groups;
             float* dp = ds + ((size_t)bb * Cs + g * K) * grid_sz + ij;
 #pragma unroll
-            for (int q = 0; q < 5; ++q)
+            for (int t = 0; t < 5; ++t)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int k = 4 * (hi + 4 * q) + e;
-                    if (k < K) dp[(size_t)k * grid_sz] = acc[q][e];
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 16 * t + 4 * kk + r;
+                    if (t < KT && k < K) dp[(size_t)k * grid_sz] = acc[t][r];
                 }
         }
+    }
+}
+
+// dw[layer][n][k] = sum over the patch slices of their partial tiles, in slice order (deterministic)
+__global__ __launch_bounds__(256)
+void s2w_train_dwsum_kernel(StArgs a, int n_slices) {
+    const __attribute__((address_space(4))) StArgs* ka = (const __attribute__((address_space(4))) StArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    const long total = ka->dw_slice_floats;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        int li = 0;
+        for (int q = 1; q < ka->n_layers; ++q)
+            if (e >= ka->layer[q].dw_off) li = q;
+        float* __restrict__ dw = ka->layer[li].dw;
+        if (!dw) continue;
+        float v = 0.0f;
+        for (int sl = 0; sl < n_slices; ++sl) v += ka->dw_partial[(size_t)sl * total + e];
+        dw[e - ka->layer[li].dw_off] = v;
     }
 }
 
@@ -167,9 +213,13 @@ static int st_fill(StArgs& a, const float* signal, int batch, int c_signal, int 
                    int mode, int* n_wg) {
     a.signal = signal; a.c_signal = c_signal; a.grid_sz = fh * fw; a.n_patches = batch * fh * fw; a.n_layers = n_layers;
     int wgs = 0;
+    long dw_floats = 0;
+    a.dw_partial = nullptr; a.dw_slice_floats = 0;
     for (int i = 0; i < n_layers; ++i) {
         const hs_s2w_train_layer& l = layers[i];
         StLayer& d = a.layer[i];
+        d.dw_off = dw_floats;
+        dw_floats += (long)l.wc * (l.signal_channels / l.groups);
         d.w = l.w; d.dbank = l.dbank; d.dw = l.dw; d.ds = l.ds; d.ld = (long)l.ld;
         d.signal_index = l.signal_index; d.K = l.signal_channels / l.groups; d.rpg = l.wc / l.groups; d.wc = l.wc; d.rows = l.rows;
         d.groups = l.groups;
@@ -178,7 +228,8 @@ static int st_fill(StArgs& a, const float* signal, int batch, int c_signal, int 
         const bool wanted = mode == 0 ? (l.dw != nullptr) : (l.ds != nullptr);
         wgs += wanted ? l.groups * d.blocks_per_group : 0;
     }
-    for (int i = n_layers; i < S2W_MAX_LAYERS; ++i) { a.layer[i] = a.layer[0]; a.layer[i].wg_begin = 0x7fffffff; }
+    for (int i = n_layers; i < S2W_MAX_LAYERS; ++i) { a.layer[i] = a.layer[0]; a.layer[i].wg_begin = 0x7fffffff; a.layer[i].dw_off = 0x7fffffffffffffffL; }
+    a.dw_slice_floats = dw_floats;
     *n_wg = wgs;
     return HS_OK;
 }
@@ -214,8 +265,20 @@ extern "C" int hs_s2w_train_fwd(const float* signal, int32_t batch, int32_t c_si
     return s2w_multi_launch(signal, batch, c_signal, fh, fw, tab, n_layers, true, stream);
 }
 
+extern "C" int64_t hs_s2w_train_workspace(int32_t batch, int32_t fh, int32_t fw, const hs_s2w_train_layer* layers, int32_t n_layers) {
+    if (!layers || n_layers <= 0 || n_layers > S2W_MAX_LAYERS || batch <= 0 || fh <= 0 || fw <= 0) return 0;
+    long dw_floats = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        if (layers[i].groups <= 0) return 0;
+        dw_floats += (long)layers[i].wc * (layers[i].signal_channels / layers[i].groups);
+    }
+    const long slices = ((long)batch * fh * fw + ST_TILE - 1) / ST_TILE;
+    return (int64_t)(slices * dw_floats * 4);
+}
+
 extern "C" int hs_s2w_train_bwd(const float* signal, int32_t batch, int32_t c_signal, int32_t fh, int32_t fw,
-                                const hs_s2w_train_layer* layers, int32_t n_layers, float* dsignal, void* stream) {
+                                const hs_s2w_train_layer* layers, int32_t n_layers, float* dsignal, void* workspace,
+                                int64_t workspace_bytes, void* stream) {
     const int chk = st_check(signal, batch, c_signal, fh, fw, layers, n_layers);
     if (chk != HS_OK) return chk;
     hipStream_t s = (hipStream_t)stream;
@@ -223,9 +286,19 @@ extern "C" int hs_s2w_train_bwd(const float* signal, int32_t batch, int32_t c_si
     int n_wg = 0;
     st_fill(a, signal, batch, c_signal, fh, fw, layers, n_layers, 0, &n_wg);
     if (n_wg > 0) {
-        hipLaunchKernelGGL(s2w_train_bwd_kernel<0>, dim3((unsigned)n_wg), dim3(256), 0, s, a);
-        const int st = launch_status();
+        const int n_slices = (a.n_patches + ST_TILE - 1) / ST_TILE;
+        const bool sliced = workspace && n_slices > 1 && workspace_bytes >= hs_s2w_train_workspace(batch, fh, fw, layers, n_layers) && n_slices <= 65535;
+        a.dw_partial = sliced ? (float*)workspace : nullptr;
+        hipLaunchKernelGGL(s2w_train_bwd_kernel<0>, dim3((unsigned)n_wg, sliced ? (unsigned)n_slices : 1u), dim3(256), 0, s, a);
+        int st = launch_status();
         if (st != HS_OK) return st;
+        if (sliced) {
+            const unsigned blocks = (unsigned)((a.dw_slice_floats + 255) / 256 > 2048 ? 2048 : (a.dw_slice_floats + 255) / 256);
+            hipLaunchKernelGGL(s2w_train_dwsum_kernel, dim3(blocks), dim3(256), 0, s, a, n_slices);
+            st = launch_status();
+            if (st != HS_OK) return st;
+        }
+        a.dw_partial = nullptr;
     }
     if (dsignal) {
         for (int i = 0; i < n_layers; ++i)

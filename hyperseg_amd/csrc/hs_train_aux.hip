@@ -371,6 +371,36 @@ void upsample_bilinear_bwd_kernel(const float* __restrict__ dy, int channels, lo
     dx[((size_t)blockIdx.z * Hi + yi) * Wi + xi] = acc;
 }
 
+// The exact-2x case (every use in the decoder): out[2i] = 0.25 in[i-1] + 0.75 in[i], out[2i+1] = 0.75 in[i] + 0.25 in[i+1] with the source index
+// clamped at both ends, so dIn[i] = 0.25 g[2i-1] + 0.75 g[2i] + 0.75 g[2i+1] + 0.25 g[2i+2], the weight of a tap that would leave the
+// image folded onto the border output (1.0 g[0] at i = 0, 1.0 g[2L+1] at the last row / column).  16 loads and fused multiply-adds per
+// input pixel, no tap arithmetic (the general kernel above walks the candidate outputs and recomputes their taps: 21 us per launch at
+// config 5, the second-largest line of the training step in visit r4m).
+__global__ __launch_bounds__(256)
+void upsample2x_bwd_kernel(const float* __restrict__ dy, int channels, long dy_batch_stride, int Hi, int Wi, float* __restrict__ dx) {
+    const int xi = blockIdx.x * 64 + (threadIdx.x & 63), yi = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (xi >= Wi || yi >= Hi) return;
+    const int Ho = 2 * Hi, Wo = 2 * Wi;
+    const int pb = (int)blockIdx.z / channels, pc = (int)blockIdx.z - pb * channels;
+    const float* __restrict__ g = dy + (size_t)pb * dy_batch_stride + (size_t)pc * Ho * Wo;
+    float wy[4] = {0.25f, 0.75f, 0.75f, 0.25f}, wx[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+    if (yi == 0) { wy[0] = 0.0f; wy[1] = 1.0f; }
+    if (yi == Hi - 1) { wy[3] = 0.0f; wy[2] = 1.0f; }
+    if (xi == 0) { wx[0] = 0.0f; wx[1] = 1.0f; }
+    if (xi == Wi - 1) { wx[3] = 0.0f; wx[2] = 1.0f; }
+    float acc = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int oy = min(max(2 * yi - 1 + a, 0), Ho - 1);            // clamped rows / columns carry weight 0
+        const float* __restrict__ row = g + (size_t)oy * Wo;
+        float r = 0.0f;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) r = fmaf(wx[b], row[min(max(2 * xi - 1 + b, 0), Wo - 1)], r);
+        acc = fmaf(wy[a], r, acc);
+    }
+    dx[((size_t)blockIdx.z * Hi + yi) * Wi + xi] = acc;
+}
+
 // Adjoint of hs_bank_pack_fwd: the patch-major gradient (B fh fw, ld) back to the reference's channel-major layout (B, hp_total, fh, fw),
 // channels [ch_offset, ch_offset + rows) from the bank and exact zeros everywhere else -- 32 x 32 LDS transpose tiles, one launch
 // (stock ops: a zeros fill + a permuted, uncoalesced copy).
@@ -444,6 +474,11 @@ extern "C" int hs_upsample_bilinear_bwd(const float* dy, int64_t dy_batch_stride
     if (dy_batch_stride <= 0) dy_batch_stride = (int64_t)channels * Ho * Wo;                         // 0 = packed (B, C, Ho, Wo)
     if (dy_batch_stride < (int64_t)channels * Ho * Wo) return HS_ERR_BAD_ARG;
     if ((long)batch * channels > 65535 || Ho < Hi || Wo < Wi) return HS_ERR_UNSUPPORTED;          // upsampling only (the decoder's use)
+    if (Ho == 2 * Hi && Wo == 2 * Wi) {
+        hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3((Wi + 63) / 64, (Hi + 3) / 4, batch * channels), dim3(256), 0, (hipStream_t)stream,
+                           dy, channels, (long)dy_batch_stride, Hi, Wi, dx);
+        return launch_status();
+    }
     hipLaunchKernelGGL(upsample_bilinear_bwd_kernel, dim3((Wi + 63) / 64, (Hi + 3) / 4, batch * channels), dim3(256), 0, (hipStream_t)stream,
                        dy, channels, (long)dy_batch_stride, Hi, Wi, Ho, Wo, (float)Hi / (float)Ho, (float)Wi / (float)Wo, dx);
     return launch_status();

@@ -438,7 +438,9 @@ int hs_bn_act_train_bwd(int32_t dtype, const void* x, const void* dy, int32_t ba
  *   hs_s2w_train_bwd   dw[n, k] = sum_p dbank[p, n] * signal[...]  (rows in [rows, wc): exact zeros; dbank NULL = zero gradient),
  *                      dsignal[b, c, i, j] = sum over the layers whose channel range holds c of sum_n dbank[p, n] * w[n, k]
  *                      (channels no layer reads: zeros); `ds` is each layer's private (batch, signal_channels, fh, fw) scratch.
- *                      dw / dsignal may be NULL (not wanted).  Three launches, no atomics. */
+ *                      dw / dsignal may be NULL (not wanted).  workspace (hs_s2w_train_workspace bytes, scratch, optional): the
+ *                      reduction of dw over the patches is then cut into slices of 64 patches across workgroups and a fourth launch
+ *                      adds the slices in order; without it one workgroup walks all patches of its tile.  No atomics. */
 typedef struct hs_s2w_train_layer {
     int32_t signal_index, signal_channels, groups;
     const float* w;            /* (wc, signal_channels / groups) */
@@ -451,8 +453,10 @@ typedef struct hs_s2w_train_layer {
 } hs_s2w_train_layer;
 int hs_s2w_train_fwd(const float* signal, int32_t batch, int32_t c_signal, int32_t fh, int32_t fw,
                      const hs_s2w_train_layer* layers, int32_t n_layers, void* stream);
+int64_t hs_s2w_train_workspace(int32_t batch, int32_t fh, int32_t fw, const hs_s2w_train_layer* layers, int32_t n_layers);
 int hs_s2w_train_bwd(const float* signal, int32_t batch, int32_t c_signal, int32_t fh, int32_t fw,
-                     const hs_s2w_train_layer* layers, int32_t n_layers, float* dsignal, void* stream);
+                     const hs_s2w_train_layer* layers, int32_t n_layers, float* dsignal, void* workspace, int64_t workspace_bytes,
+                     void* stream);
 
 /* Per-pixel cross entropy, F.cross_entropy(logits (N,C,H,W), target (N,H,W) int64, ignore_index, reduction='none') without class
  * weights -- what BootstrappedCrossEntropyLoss.forward computes before its top-k rule (hyperseg/losses/bootstrapped_ce_loss.py:20-23) --

@@ -179,7 +179,7 @@ def test_bank_pack_autograd_roundtrip(dev):
 
 
 @pytest.mark.parametrize('shape,size', [((2, 16, 72, 72), (144, 144)), ((1, 3, 5, 7), (10, 14)), ((2, 2, 1, 1), (2, 2)), ((1, 4, 9, 6), (23, 17)),
-                                        ((1, 2, 8, 8), (8, 16))])
+                                        ((1, 2, 8, 8), (8, 16)), ((1, 2, 1, 6), (2, 12)), ((2, 3, 6, 1), (12, 2)), ((1, 1, 2, 2), (4, 4))])
 def test_upsample_bilinear_autograd_vs_torch(dev, shape, size):
     """autograd.UpsampleBilinear (hs_upsample_bilinear_fwd + the gather adjoint hs_upsample_bilinear_bwd) == F.interpolate(bilinear,
     align_corners=False) and its autograd: exact 2x, a one-pixel map (both taps clamp onto it), non-integer ratios, one axis unchanged."""

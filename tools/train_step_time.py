@@ -19,6 +19,8 @@ with torch.no_grad():
     feats = model.backbone(x)
     s = model.weight_mapper(feats[-1]).contiguous()
     pyr = [t.contiguous() for t in [x] + feats[:-1]]
+if os.environ.get('HS_TRAIN_SIGNAL_GRAD') == '1':       # as inside a whole-model step: the signal is the context head's output and needs its gradient
+    s.requires_grad_(True)
 dec = model.decoder.train()
 target = torch.randint(0, 12, (2, 576, 576), device=dev)
 crit = BootstrappedCrossEntropyLoss(k=4096, thresh=0.3, ignore_index=255)
