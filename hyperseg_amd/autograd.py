@@ -40,18 +40,22 @@ def _plain_conv(kind, dtype, a, b, ld, shape, meta, out):
 class PatchConv(torch.autograd.Function):
     """y = patch_conv(x, bank): Op A / Op B with plain tensors.  Saves x and the bank; backward launches the input- and
     the per-patch weight-gradient kernels.  fp32 tensors take the fp32 kernels; under ``torch.autocast('cuda',
-    dtype=torch.bfloat16)`` (or with bf16 tensors) activations, bank and gradients are stored as bf16 and every sum is
-    accumulated in fp32 (hs_patch_conv_plain_*: BASELINE config 5)."""
+    dtype=torch.bfloat16)`` (or with a bf16 ``x``) the ACTIVATIONS and their gradients are stored as bf16 and every sum is
+    accumulated in fp32 (hs_patch_conv_plain_*: BASELINE config 5).  The bank and its gradient stay fp32 in both cases: they
+    sit between this layer and signal2weights, which is fp32, so a bf16 bank meant one cast launch per layer and direction
+    (30 of the 147 launches of the config-5 step under autocast, visit r4m) for a few per cent of a launch's bytes."""
 
     @staticmethod
-    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.bfloat16)
     def forward(ctx, x, bank, grid, c_out, k, padding, padding_mode, groups):
+        # (no custom_fwd(cast_inputs=...): it would narrow the bank too, and widen its gradient again in backward)
+        if torch.is_autocast_enabled('cuda') and x.is_cuda and x.is_floating_point():
+            x = x.to(torch.bfloat16)
         if x.dtype not in DTYPE_CODES:
             raise NotImplementedError(f'PatchConv: dtype {x.dtype} is not supported (supported: '
                                       f'{", ".join(str(d) for d in DTYPE_CODES)})')
         x = x.contiguous()
-        if bank.dtype != x.dtype:
-            bank = bank.to(x.dtype)
+        if bank.dtype != torch.float32:
+            bank = bank.float()
         if bank.stride(1) != 1:
             bank = bank.contiguous()
         meta = (tuple(grid), c_out, k, padding, padding_mode, groups)
@@ -66,7 +70,6 @@ class PatchConv(torch.autograd.Function):
         return y
 
     @staticmethod
-    @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, dy):
         x, bank = ctx.saved_tensors
         (fh, fw), c_out, k, pad, mode, groups = ctx.meta
@@ -88,7 +91,7 @@ class PatchConv(torch.autograd.Function):
                 rows = c_out * (c_in // groups) * k * k
                 # the kernels write columns [0, rows) of every patch row; only trailing pad columns need the zero fill
                 alloc = torch.empty if rows == bank.shape[1] else torch.zeros
-                full = alloc(bank.shape[0], bank.shape[1], device=x.device, dtype=x.dtype)
+                full = alloc(bank.shape[0], bank.shape[1], device=x.device, dtype=torch.float32)
                 assert rows <= full.shape[1]
                 if x.dtype == torch.float32:
                     st = _hip.lib.hs_patch_conv_bwd_weight(_hip.dev_ptr(x, 'x'), _hip.dev_ptr(dy, 'dy'), b, c_in, h, w, fh, fw,
@@ -297,8 +300,9 @@ class S2WBanksTrain(torch.autograd.Function):
 
 
 class PixelCrossEntropy(torch.autograd.Function):
-    """F.cross_entropy(logits, target, ignore_index=..., reduction='none') for fp32 (N, C, H, W) CUDA logits, one launch per direction
-    (hs_cross_entropy_fwd / _bwd; stock: log-softmax + gather and their adjoints)."""
+    """F.cross_entropy(logits, target, ignore_index=..., reduction='none') for fp32 / bf16 (N, C, H, W) CUDA logits, one launch per
+    direction (hs_cross_entropy_typed_fwd / _bwd; stock: log-softmax + gather and their adjoints, after a widening cast for bf16).
+    The loss is fp32 and the arithmetic f32 for either storage type; the logits' gradient has the logits' type."""
 
     @staticmethod
     def forward(ctx, logits, target, ignore_index):
@@ -307,8 +311,9 @@ class PixelCrossEntropy(torch.autograd.Function):
         px = logits.numel() // (n * c)
         with _hip.device_scope(logits.device):
             loss = torch.empty(target.shape, device=logits.device, dtype=torch.float32)
-            st = _hip.lib.hs_cross_entropy_fwd(logits.data_ptr(), target.data_ptr(), n, c, px, int(ignore_index), loss.data_ptr(), _hip.stream_ptr())
-            _hip.check(st, 'hs_cross_entropy_fwd')
+            st = _hip.lib.hs_cross_entropy_typed_fwd(DTYPE_CODES[logits.dtype], logits.data_ptr(), target.data_ptr(), n, c, px, int(ignore_index),
+                                                     loss.data_ptr(), _hip.stream_ptr())
+            _hip.check(st, 'hs_cross_entropy_typed_fwd')
         ctx.save_for_backward(logits, target)
         ctx.ignore_index = int(ignore_index)
         return loss
@@ -321,9 +326,9 @@ class PixelCrossEntropy(torch.autograd.Function):
         g = g.contiguous().float()
         with _hip.device_scope(logits.device):
             dl = torch.empty_like(logits)
-            st = _hip.lib.hs_cross_entropy_bwd(logits.data_ptr(), target.data_ptr(), n, c, px, ctx.ignore_index, g.data_ptr(), dl.data_ptr(),
-                                               _hip.stream_ptr())
-            _hip.check(st, 'hs_cross_entropy_bwd')
+            st = _hip.lib.hs_cross_entropy_typed_bwd(DTYPE_CODES[logits.dtype], logits.data_ptr(), target.data_ptr(), n, c, px, ctx.ignore_index,
+                                                     g.data_ptr(), dl.data_ptr(), _hip.stream_ptr())
+            _hip.check(st, 'hs_cross_entropy_typed_bwd')
         return dl, None, None
 
 
@@ -441,32 +446,42 @@ class BootstrapMeanBatched(torch.autograd.Function):
 
 
 def patch_conv_apply(*args):
-    """``PatchConv.apply`` behind the one check its ``custom_fwd`` cannot make (autocast is already off inside it)."""
+    """``PatchConv.apply`` behind the autocast-dtype check."""
     if torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') != torch.bfloat16:
-        # custom_fwd(cast_inputs=bfloat16) would silently force bf16 under autocast(float16): there is no fp16 storage type
+        # there is no fp16 storage type
         raise NotImplementedError(f"patch conv under torch.autocast('cuda', dtype={torch.get_autocast_dtype('cuda')}): only "
                                   'torch.bfloat16 autocast is supported (fp32 without autocast)')
     return PatchConv.apply(*args)
 
 
 class UpsampleBilinear(torch.autograd.Function):
-    """F.interpolate(x, size, mode='bilinear', align_corners=False) for fp32 CUDA tensors, forward and adjoint on the HIP kernels
-    (hs_upsample_bilinear_fwd / _bwd): the previous level on its way into a stage input (materialize_stage)."""
+    """F.interpolate(x, size, mode='bilinear', align_corners=False) for fp32 / bf16 CUDA tensors, forward and adjoint on the HIP
+    kernels (hs_upsample_bilinear_fwd / _bf16_fwd / _typed_bwd): the decoder's final logits in training.  bf16 storage in, bf16
+    storage out (f32 arithmetic, one rounding), as the stock op under autocast -- without its widen / narrow cast launches."""
 
     @staticmethod
     def forward(ctx, x, size):
         ctx.meta = (tuple(x.shape), tuple(size), x.dtype)
-        return HF.upsample_bilinear(x.contiguous().float(), size).to(x.dtype)     # bf16 storage: widened here, f32 arithmetic
+        x = x.contiguous()
+        if x.dtype == torch.float32:
+            return HF.upsample_bilinear(x, size)
+        b, c, hi, wi = x.shape
+        with _hip.device_scope(x.device):
+            y = torch.empty(b, c, size[0], size[1], device=x.device, dtype=torch.bfloat16)
+            st = _hip.lib.hs_upsample_bilinear_bf16_fwd(_hip.dev_ptr(x, 'x', torch.bfloat16), b, c, hi, wi, size[0], size[1], y.data_ptr(),
+                                                        _hip.stream_ptr())
+            _hip.check(st, 'hs_upsample_bilinear_bf16_fwd')
+        return y
 
     @staticmethod
     def backward(ctx, dy):
         (b, c, hi, wi), (ho, wo), dt = ctx.meta
-        dy = dy.contiguous().float()
+        dy = dy.contiguous().to(dt)
         with _hip.device_scope(dy.device):
-            dx = torch.empty(b, c, hi, wi, device=dy.device, dtype=torch.float32)
-            st = _hip.lib.hs_upsample_bilinear_bwd(dy.data_ptr(), 0, b, c, hi, wi, ho, wo, dx.data_ptr(), _hip.stream_ptr())
-            _hip.check(st, 'hs_upsample_bilinear_bwd')
-        return dx.to(dt), None
+            dx = torch.empty(b, c, hi, wi, device=dy.device, dtype=dt)
+            st = _hip.lib.hs_upsample_bilinear_typed_bwd(DTYPE_CODES[dt], dy.data_ptr(), 0, b, c, hi, wi, ho, wo, dx.data_ptr(), _hip.stream_ptr())
+            _hip.check(st, 'hs_upsample_bilinear_typed_bwd')
+        return dx, None
 
 
 def upsample_bilinear(x, size):
@@ -501,8 +516,8 @@ class BankSlices(torch.autograd.Function):
 
 class BankPack(torch.autograd.Function):
     """(B, hp_total, fh, fw) reference-layout weights -> patch-major bank (B*fh*fw, ld); backward is the transpose.
-    The re-layout itself runs in fp32 (a bf16 weight tensor produced under autocast is widened first; PatchConv narrows
-    the bank again), so it adds no rounding of its own."""
+    The re-layout runs in fp32 (a bf16 weight tensor produced under autocast is widened first) and the bank stays fp32 into
+    PatchConv, so neither adds a rounding of its own."""
 
     @staticmethod
     def forward(ctx, w, rows):
@@ -533,17 +548,21 @@ def patch_conv_train(x, weight, c_out, k, padding, padding_mode, groups, hp):
 
 
 class StageMaterialize(torch.autograd.Function):
-    """cat(coords, skip, bilinear(prev)) as ONE launch under autograd (hs_stage_input_fwd, the materialising twin of the kernels'
-    prologue): the stock formulation is two linspaces, a stack, the interpolation and a concatenation per level and step -- five
-    to six launches.  Backward: the skip's gradient is a channel range of dy (a view), the previous level's is the bilinear
-    adjoint (hs_upsample_bilinear_bwd) of its range; coordinates are constants."""
+    """cat(coords, skip, bilinear(prev)) as ONE launch under autograd (hs_stage_input_typed_fwd, the materialising twin of the
+    kernels' prologue): the stock formulation is two linspaces, a stack, the interpolation and a concatenation per level and
+    step -- five to six launches.  Backward: the skip's gradient is a channel range of dy (a view), the previous level's is the
+    bilinear adjoint (hs_upsample_bilinear_typed_bwd) of its range; coordinates are constants.  Under bf16 autocast (or with a
+    bf16 previous level) the previous level is read as stored and the result is written as bf16 -- what the first convolution
+    reads -- and the adjoint runs bf16 -> bf16: no cast launch on either side (18 of them per config-5 step before)."""
 
     @staticmethod
     def forward(ctx, skip, prev, coords):
-        stage = HF.StageInput(skip.contiguous().float(), prev.contiguous().float() if prev is not None else None, coords=coords)
+        low = (torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16) or \
+            (prev is not None and prev.dtype == torch.bfloat16) or skip.dtype == torch.bfloat16
+        stage = HF.StageInput(skip.contiguous().float(), prev.contiguous() if prev is not None else None, coords=coords)
         ctx.meta = (tuple(skip.shape), tuple(prev.shape) if prev is not None else None, bool(coords), skip.dtype,
                     prev.dtype if prev is not None else None)
-        return stage.materialize()
+        return stage.materialize(torch.bfloat16 if low else torch.float32)
 
     @staticmethod
     def backward(ctx, dy):
@@ -557,12 +576,14 @@ class StageMaterialize(torch.autograd.Function):
                 dprev = dy[:, off + cs:].to(pdt)
             else:
                 # the previous level's channel range of dy is read IN PLACE (batch stride = all channels): no slice copy
-                dyc = dy if (dy.is_contiguous() and dy.dtype == torch.float32) else dy.contiguous().float()
+                dyc = dy if dy.is_contiguous() else dy.contiguous()
+                if dyc.dtype not in DTYPE_CODES:
+                    dyc = dyc.float()
                 with _hip.device_scope(dy.device):
-                    dprev = torch.empty(b, cp, hp, wp, device=dy.device, dtype=torch.float32)
-                    st = _hip.lib.hs_upsample_bilinear_bwd(dyc.data_ptr() + 4 * (off + cs) * h * w, dyc.shape[1] * h * w, b, cp, hp, wp, h, w,
-                                                           dprev.data_ptr(), _hip.stream_ptr())
-                    _hip.check(st, 'hs_upsample_bilinear_bwd')
+                    dprev = torch.empty(b, cp, hp, wp, device=dy.device, dtype=dyc.dtype)
+                    st = _hip.lib.hs_upsample_bilinear_typed_bwd(DTYPE_CODES[dyc.dtype], dyc.data_ptr() + dyc.element_size() * (off + cs) * h * w,
+                                                                 dyc.shape[1] * h * w, b, cp, hp, wp, h, w, dprev.data_ptr(), _hip.stream_ptr())
+                    _hip.check(st, 'hs_upsample_bilinear_typed_bwd')
                 dprev = dprev.to(pdt)
         return dskip, dprev, None
 

@@ -54,6 +54,24 @@ __device__ __forceinline__ Tap bilinear_tap(int dst, float scale, int in_size) {
 
 // Precomputed per-position sampling state of a stage input: everything that does not depend
 // on the channel.  (y, x) are in-image coordinates (already mapped through pad_index).
+// Storage types of the training-path kernels: fp32, or bf16 storage with fp32 arithmetic (rounded to nearest-even once on store).
+struct bf16_t { uint16_t v; };
+
+template <typename T> struct Store;
+template <> struct Store<float> {
+    static __device__ __forceinline__ float ld(const float* p, size_t i) { return p[i]; }
+    static __device__ __forceinline__ void st(float* p, size_t i, float x) { p[i] = x; }
+};
+template <> struct Store<bf16_t> {
+    static __device__ __forceinline__ float ld(const bf16_t* p, size_t i) { return __uint_as_float((uint32_t)p[i].v << 16); }
+    static __device__ __forceinline__ void st(bf16_t* p, size_t i, float x) {
+        uint32_t u = __float_as_uint(x);
+        if ((u & 0x7fffffffu) > 0x7f800000u) { p[i].v = (uint16_t)((u >> 16) | 0x40); return; }     // NaN stays NaN
+        u += 0x7fffu + ((u >> 16) & 1u);                                                           // round to nearest even
+        p[i].v = (uint16_t)(u >> 16);
+    }
+};
+
 struct StagePos {
     int y, x;             // -1 in either => zero padding
     Tap ty, tx;           // only valid for prev_mode == HS_PREV_BILINEAR
@@ -69,7 +87,9 @@ __device__ __forceinline__ StagePos stage_pos(const StageIn& s, int y, int x) {
     return p;
 }
 
-// Value of stage-input channel c of batch b at a sampled position.
+// Value of stage-input channel c of batch b at a sampled position.  TP: storage type of the previous level (fp32 everywhere but the
+// training path under bf16 autocast, hs_stage_input_typed_fwd).
+template <typename TP = float>
 __device__ __forceinline__ float stage_value(const StageIn& s, int b, int c, const StagePos& p) {
     if (p.y < 0 || p.x < 0) return 0.0f;
     if (s.coords) {
@@ -80,12 +100,12 @@ __device__ __forceinline__ float stage_value(const StageIn& s, int b, int c, con
     if (c < s.c_skip)
         return s.skip[(((size_t)b * s.c_skip + c) * s.H + p.y) * s.W + p.x];
     c -= s.c_skip;
-    const float* base = s.prev + ((size_t)b * s.c_prev + c) * s.Hp * s.Wp;
-    if (s.prev_mode == HS_PREV_SAME) return base[(size_t)p.y * s.Wp + p.x];
-    const float* r0 = base + (size_t)p.ty.i0 * s.Wp;
-    const float* r1 = base + (size_t)p.ty.i1 * s.Wp;
-    float top = p.tx.l0 * r0[p.tx.i0] + p.tx.l1 * r0[p.tx.i1];
-    float bot = p.tx.l0 * r1[p.tx.i0] + p.tx.l1 * r1[p.tx.i1];
+    const TP* base = (const TP*)s.prev + ((size_t)b * s.c_prev + c) * s.Hp * s.Wp;
+    if (s.prev_mode == HS_PREV_SAME) return Store<TP>::ld(base, (size_t)p.y * s.Wp + p.x);
+    const TP* r0 = base + (size_t)p.ty.i0 * s.Wp;
+    const TP* r1 = base + (size_t)p.ty.i1 * s.Wp;
+    float top = p.tx.l0 * Store<TP>::ld(r0, p.tx.i0) + p.tx.l1 * Store<TP>::ld(r0, p.tx.i1);
+    float bot = p.tx.l0 * Store<TP>::ld(r1, p.tx.i0) + p.tx.l1 * Store<TP>::ld(r1, p.tx.i1);
     return p.ty.l0 * top + p.ty.l1 * bot;
 }
 
@@ -126,25 +146,6 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == HS_ACT_SWISH) return swishf(v);        // not used by any reference decoder (ReLU / ReLU6 only: SURVEY appendix D-5)
     return v;
 }
-
-// Storage types of the training-path kernels: fp32, or bf16 storage with fp32 arithmetic (rounded to nearest-even once on store).
-struct bf16_t { uint16_t v; };
-
-template <typename T> struct Store;
-template <> struct Store<float> {
-    static __device__ __forceinline__ float ld(const float* p, size_t i) { return p[i]; }
-    static __device__ __forceinline__ void st(float* p, size_t i, float x) { p[i] = x; }
-};
-template <> struct Store<bf16_t> {
-    static __device__ __forceinline__ float ld(const bf16_t* p, size_t i) { return __uint_as_float((uint32_t)p[i].v << 16); }
-    static __device__ __forceinline__ void st(bf16_t* p, size_t i, float x) {
-        uint32_t u = __float_as_uint(x);
-        if ((u & 0x7fffffffu) > 0x7f800000u) { p[i].v = (uint16_t)((u >> 16) | 0x40); return; }     // NaN stays NaN
-        u += 0x7fffu + ((u >> 16) & 1u);                                                           // round to nearest even
-        p[i].v = (uint16_t)(u >> 16);
-    }
-};
-
 
 // ---- host side ---------------------------------------------------------------------------
 inline int make_stage(const hs_stage_input* in, StageIn* out) {

@@ -419,13 +419,15 @@ void upsample2x_argmax_kernel(const float* __restrict__ x, int B, int C, int Hi,
 }
 
 // ------------------------------------------------------------------------------------------
-__global__ void stage_input_kernel(StageIn s, float* __restrict__ y) {
+// TP / TO: storage of the previous level / of the result (fp32; bf16 on the training path under autocast: hs_stage_input_typed_fwd)
+template <typename TP, typename TO>
+__global__ void stage_input_kernel(StageIn s, TO* __restrict__ y) {
     const size_t n = (size_t)s.B * s.cin() * s.H * s.W;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
         const int x = e % s.W; size_t r = e / s.W;
         const int yy = r % s.H; r /= s.H;
         const int c = r % s.cin(); const int b = r / s.cin();
-        y[e] = stage_value(s, b, c, stage_pos(s, yy, x));
+        Store<TO>::st(y, e, stage_value<TP>(s, b, c, stage_pos(s, yy, x)));
     }
 }
 
@@ -469,6 +471,28 @@ void upsample_bilinear_kernel(const float* __restrict__ x, int planes, int Hi, i
             *reinterpret_cast<float4*>(dst) = make_float4(out[0], out[1], out[2], out[3]);
         } else {
             for (int i = 0; i < 4 && 4 * q + i < Wo; ++i) dst[i] = out[i];
+        }
+    }
+}
+
+// bf16 storage (the training path's final logits under autocast): the same taps and f32 arithmetic, one rounding on store
+__global__ __launch_bounds__(256)
+void upsample_bilinear_bf16_kernel(const bf16_t* __restrict__ x, int planes, int Hi, int Wi, int Ho, int Wo,
+                                   float scale_y, float scale_x, bf16_t* __restrict__ y) {
+    const int wq = (Wo + 3) / 4;
+    const size_t n = (size_t)planes * Ho * wq;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const int q = e % wq; size_t r = e / wq;
+        const int yo = r % Ho; const size_t pl = r / Ho;
+        const Row4 t = row4_taps(yo, q, Hi, Wi, Wo, scale_y, scale_x);
+        const bf16_t* r0 = x + pl * Hi * Wi + (size_t)t.ty.i0 * Wi;
+        const bf16_t* r1 = x + pl * Hi * Wi + (size_t)t.ty.i1 * Wi;
+        bf16_t* dst = y + (pl * Ho + yo) * Wo + 4 * q;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float top = t.tx[i].l0 * Store<bf16_t>::ld(r0, t.tx[i].i0) + t.tx[i].l1 * Store<bf16_t>::ld(r0, t.tx[i].i1);
+            const float bot = t.tx[i].l0 * Store<bf16_t>::ld(r1, t.tx[i].i0) + t.tx[i].l1 * Store<bf16_t>::ld(r1, t.tx[i].i1);
+            if (4 * q + i < Wo) Store<bf16_t>::st(dst, i, t.ty.l0 * top + t.ty.l1 * bot);
         }
     }
 }
@@ -652,15 +676,24 @@ extern "C" int hs_patch_conv_s2w_fwd(const hs_stage_input* in, int32_t fh, int32
     return r == 1 ? HS_ERR_UNSUPPORTED : r;
 }
 
-extern "C" int hs_stage_input_fwd(const hs_stage_input* in, float* y, void* stream) {
+extern "C" int hs_stage_input_typed_fwd(const hs_stage_input* in, int32_t prev_dtype, int32_t out_dtype, void* y, void* stream) {
     StageIn s;
     int st = make_stage(in, &s);
     if (st != HS_OK) return st;
     if (!y) return HS_ERR_BAD_ARG;
+    if ((prev_dtype != HS_DTYPE_F32 && prev_dtype != HS_DTYPE_BF16) || (out_dtype != HS_DTYPE_F32 && out_dtype != HS_DTYPE_BF16)) return HS_ERR_BAD_ARG;
     const size_t n = (size_t)s.B * s.cin() * s.H * s.W;
-    const unsigned blocks = (unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
-    hipLaunchKernelGGL(stage_input_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s, y);
+    const dim3 blocks((unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256));
+    hipStream_t q = (hipStream_t)stream;
+    if (prev_dtype == HS_DTYPE_F32 && out_dtype == HS_DTYPE_F32) hipLaunchKernelGGL((stage_input_kernel<float, float>), blocks, dim3(256), 0, q, s, (float*)y);
+    else if (prev_dtype == HS_DTYPE_F32) hipLaunchKernelGGL((stage_input_kernel<float, bf16_t>), blocks, dim3(256), 0, q, s, (bf16_t*)y);
+    else if (out_dtype == HS_DTYPE_F32) hipLaunchKernelGGL((stage_input_kernel<bf16_t, float>), blocks, dim3(256), 0, q, s, (float*)y);
+    else hipLaunchKernelGGL((stage_input_kernel<bf16_t, bf16_t>), blocks, dim3(256), 0, q, s, (bf16_t*)y);
     return launch_status();
+}
+
+extern "C" int hs_stage_input_fwd(const hs_stage_input* in, float* y, void* stream) {
+    return hs_stage_input_typed_fwd(in, HS_DTYPE_F32, HS_DTYPE_F32, y, stream);
 }
 
 extern "C" int hs_upsample_argmax_fwd(const float* x, int32_t batch, int32_t channels, int32_t Hi, int32_t Wi,
@@ -676,6 +709,16 @@ extern "C" int hs_upsample_argmax_fwd(const float* x, int32_t batch, int32_t cha
     const size_t n = (size_t)batch * Ho * ((Wo + 3) / 4);
     hipLaunchKernelGGL(upsample_argmax_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        x, batch, channels, Hi, Wi, Ho, Wo, (float)Hi / (float)Ho, (float)Wi / (float)Wo, mask);
+    return launch_status();
+}
+
+extern "C" int hs_upsample_bilinear_bf16_fwd(const void* x, int32_t batch, int32_t channels, int32_t Hi, int32_t Wi,
+                                             int32_t Ho, int32_t Wo, void* y, void* stream) {
+    if (!x || !y || batch <= 0 || channels <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return HS_ERR_BAD_ARG;
+    const size_t n = (size_t)batch * channels * Ho * ((Wo + 3) / 4);
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256);
+    hipLaunchKernelGGL(upsample_bilinear_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, batch * channels, Hi, Wi, Ho, Wo, (float)Hi / (float)Ho, (float)Wi / (float)Wo, (bf16_t*)y);
     return launch_status();
 }
 

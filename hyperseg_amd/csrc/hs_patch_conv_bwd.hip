@@ -137,7 +137,8 @@ using bw_f32x4 = __attribute__((ext_vector_type(4))) float;
 // VEC: patches whose rows are whole 4-pixel groups on 16-byte boundaries and whose pixel count is a multiple of 16.  Otherwise (the
 // (ph + 2) x (pw + 2) halo tiles that a train-mode v1_0 inverted residual feeds to its first 1x1 convolution: 18 x 18, 10 x 10) the
 // lane's four pixels are four 4-byte loads with their own row / column, and pixels past the patch contribute zeros.
-// T: storage type (float, or bf16_t: bf16 in memory, f32 products and sums, one rounding on store -- hs_common.h Store<T>).
+// T: storage type of the ACTIVATIONS and their gradients (float, or bf16_t: bf16 in memory, f32 products and sums, one rounding on
+// store -- hs_common.h Store<T>); the bank and its gradient are fp32 either way (hs_patch_conv_train.hip's header).
 template <int MT, int NTI, bool VEC, typename T>
 __global__ __launch_bounds__(256)
 void patch_conv_bwd_weight_k1m_kernel(ConvBwdArgs a) {
@@ -207,12 +208,12 @@ void patch_conv_bwd_weight_k1m_kernel(ConvBwdArgs a) {
         for (int nt = 0; nt < NTI; ++nt)
             *reinterpret_cast<bw_f32x4*>(&red[wave][mt * NTI + nt][4 * lane]) = acc[mt][nt];
     __syncthreads();
-    T* __restrict__ dst = (T*)a.dbank + (size_t)patch * a.ld;
+    float* __restrict__ dst = a.dbank + (size_t)patch * a.ld;
     for (int e = tid; e < MT * NTI * 256; e += 256) {
         const int tile = e >> 8, w = e & 255, ln = w >> 2, r = w & 3;
         const int o = 16 * (tile / NTI) + 4 * (ln >> 4) + r, c = 16 * (tile % NTI) + (ln & 15);
         if (o < a.cout && c < a.cin)
-            Store<T>::st(dst, (size_t)o * a.cin + c, ((red[0][tile][w] + red[1][tile][w]) + red[2][tile][w]) + red[3][tile][w]);
+            dst[(size_t)o * a.cin + c] = ((red[0][tile][w] + red[1][tile][w]) + red[2][tile][w]) + red[3][tile][w];
     }
 }
 
@@ -226,7 +227,7 @@ void patch_conv_bwd_input_k1m_kernel(ConvBwdArgs a) {
     const size_t plane = (size_t)a.H * a.W;
     // A[i = input channel][k = output channel] = W[o][c]: this patch's bank row, o = 16 q + 4 kg + j, c = 16 ct + n (clamped: the
     // rows / columns beyond the layer multiply zeros of B or land in rows that are never stored)
-    const T* __restrict__ wp = (const T*)a.bank + (size_t)patch * a.ld;
+    const float* __restrict__ wp = a.bank + (size_t)patch * a.ld;
     float aw[CT][KQ][4];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
@@ -234,7 +235,7 @@ void patch_conv_bwd_input_k1m_kernel(ConvBwdArgs a) {
         for (int q = 0; q < KQ; ++q)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                aw[ct][q][j] = Store<T>::ld(wp, (size_t)min(16 * q + 4 * kg + j, a.cout - 1) * a.cin + min(16 * ct + n, a.cin - 1));
+                aw[ct][q][j] = wp[(size_t)min(16 * q + 4 * kg + j, a.cout - 1) * a.cin + min(16 * ct + n, a.cin - 1)];
     const size_t org = (size_t)(pi * a.ph) * a.W + pj * a.pw;
     const T* __restrict__ dyb = (const T*)a.dy + (size_t)b * a.cout * plane + org;
     T* __restrict__ dxb = (T*)a.dx + (size_t)b * a.cin * plane + org;
@@ -291,7 +292,7 @@ void patch_conv_fwd_k1m_kernel(ConvBwdArgs a, const float* __restrict__ scale, c
     const int patch = blockIdx.x;
     const int pj = patch % a.fw, pi = (patch / a.fw) % a.fh, b = patch / (a.fw * a.fh);
     const size_t plane = (size_t)a.H * a.W;
-    const T* __restrict__ wp = (const T*)a.bank + (size_t)patch * a.ld;
+    const float* __restrict__ wp = a.bank + (size_t)patch * a.ld;
     float aw[MT][KQ][4];                                                // A[i = output channel][k = input channel]
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -299,7 +300,7 @@ void patch_conv_fwd_k1m_kernel(ConvBwdArgs a, const float* __restrict__ scale, c
         for (int q = 0; q < KQ; ++q)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                aw[mt][q][j] = Store<T>::ld(wp, (size_t)min(16 * mt + n, a.cout - 1) * a.cin + min(16 * q + 4 * kg + j, a.cin - 1));
+                aw[mt][q][j] = wp[(size_t)min(16 * mt + n, a.cout - 1) * a.cin + min(16 * q + 4 * kg + j, a.cin - 1)];
     float sc[MT][4], sh[MT][4];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -368,10 +369,10 @@ void patch_dw3_kernel(ConvBwdArgs a, const T* __restrict__ src, T* __restrict__ 
     const int plane_id = blockIdx.z, c = plane_id % a.cin, b = plane_id / a.cin;
     if (x >= a.W || y >= a.H) return;
     const T* __restrict__ sp = src + (size_t)plane_id * a.H * a.W;
-    const T* __restrict__ bank = (const T*)a.bank;
+    const float* __restrict__ bank = a.bank;
     float acc = 0.0f;
     if constexpr (MODE == 0) {
-        const T* __restrict__ kp = bank + (size_t)((b * a.fh + y / a.ph) * a.fw + x / a.pw) * a.ld + c * 9;
+        const float* __restrict__ kp = bank + (size_t)((b * a.fh + y / a.ph) * a.fw + x / a.pw) * a.ld + c * 9;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -379,7 +380,7 @@ void patch_dw3_kernel(ConvBwdArgs a, const T* __restrict__ src, T* __restrict__ 
                 const int yy = y + ky - 1, xx = x + kx - 1;
                 const bool in = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
                 const float v = Store<T>::ld(sp, (size_t)min(max(yy, 0), a.H - 1) * a.W + min(max(xx, 0), a.W - 1));
-                acc = fmaf(Store<T>::ld(kp, ky * 3 + kx), in ? v : 0.0f, acc);
+                acc = fmaf(kp[ky * 3 + kx], in ? v : 0.0f, acc);
             }
     } else {
 #pragma unroll
@@ -390,7 +391,7 @@ void patch_dw3_kernel(ConvBwdArgs a, const T* __restrict__ src, T* __restrict__ 
                 const bool in = yo >= 0 && yo < a.H && xo >= 0 && xo < a.W;
                 const int yc = min(max(yo, 0), a.H - 1), xc = min(max(xo, 0), a.W - 1);
                 const float g = Store<T>::ld(sp, (size_t)yc * a.W + xc);
-                const float w = Store<T>::ld(bank, (size_t)((b * a.fh + yc / a.ph) * a.fw + xc / a.pw) * a.ld + c * 9 + ky * 3 + kx);
+                const float w = bank[(size_t)((b * a.fh + yc / a.ph) * a.fw + xc / a.pw) * a.ld + c * 9 + ky * 3 + kx];
                 acc = fmaf(w, in ? g : 0.0f, acc);
             }
     }
@@ -424,11 +425,11 @@ void patch_dw3_bwd_weight_kernel(ConvBwdArgs a) {
                 acc[ky * 3 + kx] = fmaf(g, in ? val : 0.0f, acc[ky * 3 + kx]);
             }
     }
-    T* __restrict__ dst = (T*)a.dbank + (size_t)patch * a.ld + c * 9;
+    float* __restrict__ dst = a.dbank + (size_t)patch * a.ld + c * 9;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const float s = wave_sum64(acc[t]);
-        if (lane == 0) Store<T>::st(dst, t, s);
+        if (lane == 0) dst[t] = s;
     }
 }
 

@@ -5,9 +5,12 @@
 //     hs_patch_conv_plain_fwd     y      = patch_conv(x, bank)                      (Op A / Op B, meta_patch.py:35-57)
 //     hs_patch_conv_plain_bwd_in  dx     = adjoint w.r.t. x (padding folded back)   
 //     hs_patch_conv_plain_bwd_w   dbank  = per-patch weight gradient
-// The reference has no reduced-precision path at all; bf16 here means: activations, banks and gradients are
-// READ and WRITTEN as bf16 (half the HBM bytes of the fp32 kernels, which is what these memory-bound kernels pay for),
-// every product and sum is fp32, results are rounded to nearest-even once on store.
+// The reference has no reduced-precision path at all; bf16 here means: ACTIVATIONS and their gradients are READ and
+// WRITTEN as bf16 (half the HBM bytes of the fp32 kernels, which is what these memory-bound kernels pay for), every product and
+// sum is fp32, results are rounded to nearest-even once on store.  The BANK and its gradient are fp32 in either case (round 4):
+// the bank is the output of signal2weights and its gradient the input of that layer's adjoint, both fp32 ("master weights"), it
+// is a few per cent of a launch's bytes, and storing it as bf16 cost a cast launch per layer and direction (30 of the config-5
+// step's 147 launches).
 #include "hs_common.h"
 
 namespace hs {
@@ -25,7 +28,7 @@ template <typename T>
 __global__ __launch_bounds__(256)
 void plain_fwd_kernel(PlainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const T* __restrict__ x = (const T*)a.x; const T* __restrict__ bank = (const T*)a.bank; T* __restrict__ y = (T*)a.y;
+    const T* __restrict__ x = (const T*)a.x; const float* __restrict__ bank = (const float*)a.bank; T* __restrict__ y = (T*)a.y;
     const int tid = threadIdx.x;
     int blk = blockIdx.x;
     const int tx_i = blk % a.tiles_x; blk /= a.tiles_x;
@@ -41,7 +44,7 @@ void plain_fwd_kernel(PlainArgs a) {
     const size_t wbase = (size_t)patch * a.ld;
     for (int e = tid; e < a.cout * wrow; e += 256) {
         const int o = e / wrow, r = e - o * wrow;
-        wl[o * a.w_stride + r] = Store<T>::ld(bank, wbase + e);
+        wl[o * a.w_stride + r] = bank[wbase + e];
     }
     for (int e = tid; e < a.cin * tpos; e += 256) {
         const int c = e / tpos, pos = e - c * tpos;
@@ -85,7 +88,7 @@ __device__ __forceinline__ int pad_aliases_of(int i, int n, int pad, int mode, i
 template <typename T>
 __global__ __launch_bounds__(256)
 void plain_bwd_in_kernel(PlainArgs a) {
-    const T* __restrict__ dy = (const T*)a.dy; const T* __restrict__ bank = (const T*)a.bank; T* __restrict__ dx = (T*)a.dx;
+    const T* __restrict__ dy = (const T*)a.dy; const float* __restrict__ bank = (const float*)a.bank; T* __restrict__ dx = (T*)a.dx;
     const size_t total = (size_t)a.B * a.cin * a.H * a.W;
     const int kk = a.k * a.k;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
@@ -109,7 +112,7 @@ void plain_bwd_in_kernel(PlainArgs a) {
                         const size_t wb = (size_t)p * a.ld + (size_t)cl * kk + ky * a.k + kx;
                         const size_t db = (((size_t)b * a.cout + g * a.cout_g) * a.H + yo) * a.W + xo;
                         for (int o = 0; o < a.cout_g; ++o)
-                            acc = fmaf(Store<T>::ld(bank, wb + (size_t)(g * a.cout_g + o) * a.cin_g * kk),
+                            acc = fmaf(bank[wb + (size_t)(g * a.cout_g + o) * a.cin_g * kk],
                                        Store<T>::ld(dy, db + (size_t)o * a.H * a.W), acc);
                     }
             }
@@ -122,7 +125,7 @@ template <typename T>
 __global__ __launch_bounds__(256)
 void plain_bwd_w_kernel(PlainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const T* __restrict__ x = (const T*)a.x; const T* __restrict__ dy = (const T*)a.dy; T* __restrict__ dbank = (T*)a.dbank;
+    const T* __restrict__ x = (const T*)a.x; const T* __restrict__ dy = (const T*)a.dy; float* __restrict__ dbank = (float*)a.dbank;
     const int patch = blockIdx.x;
     const int o0 = blockIdx.y * a.ob;
     const int on = min(a.ob, a.cout - o0);
@@ -159,7 +162,7 @@ void plain_bwd_w_kernel(PlainArgs a) {
         float acc = 0.0f;
         for (int u = 0; u < a.ph; ++u)
             for (int v = 0; v < a.pw; ++v) acc = fmaf(dr[u * a.pw + v], xr[u * HW + v], acc);
-        Store<T>::st(dbank, (size_t)patch * a.ld + (size_t)o * wrow + (idx - ol * wrow), acc);
+        dbank[(size_t)patch * a.ld + (size_t)o * wrow + (idx - ol * wrow)] = acc;
     }
 }
 

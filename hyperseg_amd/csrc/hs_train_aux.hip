@@ -345,16 +345,17 @@ void bn_bwd_apply_kernel(BnArgs a, const T* __restrict__ x, const T* __restrict_
 // and each one's weight on this input index is read off the same bilinear_tap the forward uses (so the border clamping, where both
 // taps of an output land on the edge sample, comes out by itself).
 // ---------------------------------------------------------------------------------------------------------------------------------
+template <typename T>
 __global__ __launch_bounds__(256)
-void upsample_bilinear_bwd_kernel(const float* __restrict__ dy, int channels, long dy_batch_stride, int Hi, int Wi, int Ho, int Wo, float sy, float sx,
-                                  float* __restrict__ dx) {
+void upsample_bilinear_bwd_kernel(const T* __restrict__ dy, int channels, long dy_batch_stride, int Hi, int Wi, int Ho, int Wo, float sy, float sx,
+                                  T* __restrict__ dx) {
     const int xi = blockIdx.x * 64 + (threadIdx.x & 63), yi = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (xi >= Wi || yi >= Hi) return;
     // outputs whose source coordinate lies within (yi - 1, yi + 1): o in ((yi - 0.5) / s - 0.5, (yi + 1.5) / s - 0.5)
     const int oy0 = max((int)floorf(((float)yi - 0.5f) / sy - 0.5f) - 1, 0), oy1 = min((int)ceilf(((float)yi + 1.5f) / sy - 0.5f) + 1, Ho - 1);
     const int ox0 = max((int)floorf(((float)xi - 0.5f) / sx - 0.5f) - 1, 0), ox1 = min((int)ceilf(((float)xi + 1.5f) / sx - 0.5f) + 1, Wo - 1);
     const int pb = (int)blockIdx.z / channels, pc = (int)blockIdx.z - pb * channels;             // dy may be a channel range of a wider tensor
-    const float* __restrict__ g = dy + (size_t)pb * dy_batch_stride + (size_t)pc * Ho * Wo;
+    const T* __restrict__ g = dy + (size_t)pb * dy_batch_stride + (size_t)pc * Ho * Wo;
     float acc = 0.0f;
     for (int oy = oy0; oy <= oy1; ++oy) {
         const Tap ty = bilinear_tap(oy, sy, Hi);
@@ -364,11 +365,11 @@ void upsample_bilinear_bwd_kernel(const float* __restrict__ dy, int channels, lo
         for (int ox = ox0; ox <= ox1; ++ox) {
             const Tap tx = bilinear_tap(ox, sx, Wi);
             const float wx = (tx.i0 == xi ? tx.l0 : 0.0f) + (tx.i1 == xi ? tx.l1 : 0.0f);
-            row = fmaf(wx, g[(size_t)oy * Wo + ox], row);
+            row = fmaf(wx, Store<T>::ld(g, (size_t)oy * Wo + ox), row);
         }
         acc = fmaf(wy, row, acc);
     }
-    dx[((size_t)blockIdx.z * Hi + yi) * Wi + xi] = acc;
+    Store<T>::st(dx, ((size_t)blockIdx.z * Hi + yi) * Wi + xi, acc);
 }
 
 // The exact-2x case (every use in the decoder): out[2i] = 0.25 in[i-1] + 0.75 in[i], out[2i+1] = 0.75 in[i] + 0.25 in[i+1] with the source index
@@ -376,13 +377,14 @@ void upsample_bilinear_bwd_kernel(const float* __restrict__ dy, int channels, lo
 // image folded onto the border output (1.0 g[0] at i = 0, 1.0 g[2L+1] at the last row / column).  16 loads and fused multiply-adds per
 // input pixel, no tap arithmetic (the general kernel above walks the candidate outputs and recomputes their taps: 21 us per launch at
 // config 5, the second-largest line of the training step in visit r4m).
+template <typename T>
 __global__ __launch_bounds__(256)
-void upsample2x_bwd_kernel(const float* __restrict__ dy, int channels, long dy_batch_stride, int Hi, int Wi, float* __restrict__ dx) {
+void upsample2x_bwd_kernel(const T* __restrict__ dy, int channels, long dy_batch_stride, int Hi, int Wi, T* __restrict__ dx) {
     const int xi = blockIdx.x * 64 + (threadIdx.x & 63), yi = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (xi >= Wi || yi >= Hi) return;
     const int Ho = 2 * Hi, Wo = 2 * Wi;
     const int pb = (int)blockIdx.z / channels, pc = (int)blockIdx.z - pb * channels;
-    const float* __restrict__ g = dy + (size_t)pb * dy_batch_stride + (size_t)pc * Ho * Wo;
+    const T* __restrict__ g = dy + (size_t)pb * dy_batch_stride + (size_t)pc * Ho * Wo;
     float wy[4] = {0.25f, 0.75f, 0.75f, 0.25f}, wx[4] = {0.25f, 0.75f, 0.75f, 0.25f};
     if (yi == 0) { wy[0] = 0.0f; wy[1] = 1.0f; }
     if (yi == Hi - 1) { wy[3] = 0.0f; wy[2] = 1.0f; }
@@ -392,13 +394,13 @@ void upsample2x_bwd_kernel(const float* __restrict__ dy, int channels, long dy_b
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const int oy = min(max(2 * yi - 1 + a, 0), Ho - 1);            // clamped rows / columns carry weight 0
-        const float* __restrict__ row = g + (size_t)oy * Wo;
+        const T* __restrict__ row = g + (size_t)oy * Wo;
         float r = 0.0f;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) r = fmaf(wx[b], row[min(max(2 * xi - 1 + b, 0), Wo - 1)], r);
+        for (int b = 0; b < 4; ++b) r = fmaf(wx[b], Store<T>::ld(row, min(max(2 * xi - 1 + b, 0), Wo - 1)), r);
         acc = fmaf(wy[a], r, acc);
     }
-    dx[((size_t)blockIdx.z * Hi + yi) * Wi + xi] = acc;
+    Store<T>::st(dx, ((size_t)blockIdx.z * Hi + yi) * Wi + xi, acc);
 }
 
 // Adjoint of hs_bank_pack_fwd: the patch-major gradient (B fh fw, ld) back to the reference's channel-major layout (B, hp_total, fh, fw),
@@ -431,25 +433,25 @@ void bank_unpack_kernel(const float* __restrict__ bank, long ld, int hp_total, i
 // pixel are HW floats apart, so a wave reads C coalesced rows.  loss = log(sum exp(x - max)) + max - x[t]; ignored labels give 0 and
 // no gradient; d x[c] = (softmax[c] - [c == t]) * g.
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <bool BWD>
+template <bool BWD, typename T>
 __global__ __launch_bounds__(256)
-void cross_entropy_kernel(const float* __restrict__ x, const long long* __restrict__ target, int C, long hw, long total, long long ignore_index,
-                          const float* __restrict__ g, float* __restrict__ out) {
+void cross_entropy_kernel(const T* __restrict__ x, const long long* __restrict__ target, int C, long hw, long total, long long ignore_index,
+                          const float* __restrict__ g, void* __restrict__ out_) {
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const long n = e / hw, p = e - n * hw;
-        const float* __restrict__ xp = x + n * C * hw + p;
+        const T* __restrict__ xp = x + n * C * hw + p;
         const long long t = target[e];
         const bool live = t != ignore_index && t >= 0 && t < C;
-        float m = xp[0];
-        for (int c = 1; c < C; ++c) m = fmaxf(m, xp[(long)c * hw]);
+        float m = Store<T>::ld(xp, 0);
+        for (int c = 1; c < C; ++c) m = fmaxf(m, Store<T>::ld(xp, (long)c * hw));
         float sum = 0.0f;
-        for (int c = 0; c < C; ++c) sum += expf(xp[(long)c * hw] - m);
+        for (int c = 0; c < C; ++c) sum += expf(Store<T>::ld(xp, (long)c * hw) - m);
         if (!BWD) {
-            out[e] = live ? (logf(sum) + m) - xp[(long)t * hw] : 0.0f;
+            ((float*)out_)[e] = live ? (logf(sum) + m) - Store<T>::ld(xp, (long)(live ? t : 0) * hw) : 0.0f;
         } else {
-            float* __restrict__ dp = out + n * C * hw + p;
+            T* __restrict__ dp = (T*)out_ + n * C * hw + p;
             const float gi = live ? g[e] : 0.0f, inv = 1.0f / sum;
-            for (int c = 0; c < C; ++c) dp[(long)c * hw] = (expf(xp[(long)c * hw] - m) * inv - (c == (int)t ? 1.0f : 0.0f)) * gi;
+            for (int c = 0; c < C; ++c) Store<T>::st(dp, (long)c * hw, (expf(Store<T>::ld(xp, (long)c * hw) - m) * inv - (c == (int)t ? 1.0f : 0.0f)) * gi);
         }
     }
 }
@@ -468,20 +470,32 @@ extern "C" int hs_bank_unpack_fwd(const float* bank, int64_t ld, int32_t batch, 
     return launch_status();
 }
 
-extern "C" int hs_upsample_bilinear_bwd(const float* dy, int64_t dy_batch_stride, int32_t batch, int32_t channels, int32_t Hi, int32_t Wi,
-                                        int32_t Ho, int32_t Wo, float* dx, void* stream) {
+extern "C" int hs_upsample_bilinear_typed_bwd(int32_t dtype, const void* dy, int64_t dy_batch_stride, int32_t batch, int32_t channels, int32_t Hi,
+                                              int32_t Wi, int32_t Ho, int32_t Wo, void* dx, void* stream) {
     if (!dy || !dx || batch <= 0 || channels <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return HS_ERR_BAD_ARG;
+    if (dtype != HS_DTYPE_F32 && dtype != HS_DTYPE_BF16) return HS_ERR_BAD_ARG;
     if (dy_batch_stride <= 0) dy_batch_stride = (int64_t)channels * Ho * Wo;                         // 0 = packed (B, C, Ho, Wo)
     if (dy_batch_stride < (int64_t)channels * Ho * Wo) return HS_ERR_BAD_ARG;
     if ((long)batch * channels > 65535 || Ho < Hi || Wo < Wi) return HS_ERR_UNSUPPORTED;          // upsampling only (the decoder's use)
+    const dim3 grid((Wi + 63) / 64, (Hi + 3) / 4, batch * channels);
+    hipStream_t q = (hipStream_t)stream;
+    const long bs = (long)dy_batch_stride;
+    const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
     if (Ho == 2 * Hi && Wo == 2 * Wi) {
-        hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3((Wi + 63) / 64, (Hi + 3) / 4, batch * channels), dim3(256), 0, (hipStream_t)stream,
-                           dy, channels, (long)dy_batch_stride, Hi, Wi, dx);
+        if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, grid, dim3(256), 0, q, (const float*)dy, channels, bs, Hi, Wi, (float*)dx);
+        else hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16_t>, grid, dim3(256), 0, q, (const bf16_t*)dy, channels, bs, Hi, Wi, (bf16_t*)dx);
         return launch_status();
     }
-    hipLaunchKernelGGL(upsample_bilinear_bwd_kernel, dim3((Wi + 63) / 64, (Hi + 3) / 4, batch * channels), dim3(256), 0, (hipStream_t)stream,
-                       dy, channels, (long)dy_batch_stride, Hi, Wi, Ho, Wo, (float)Hi / (float)Ho, (float)Wi / (float)Wo, dx);
+    if (dtype == HS_DTYPE_F32)
+        hipLaunchKernelGGL(upsample_bilinear_bwd_kernel<float>, grid, dim3(256), 0, q, (const float*)dy, channels, bs, Hi, Wi, Ho, Wo, sy, sx, (float*)dx);
+    else
+        hipLaunchKernelGGL(upsample_bilinear_bwd_kernel<bf16_t>, grid, dim3(256), 0, q, (const bf16_t*)dy, channels, bs, Hi, Wi, Ho, Wo, sy, sx, (bf16_t*)dx);
     return launch_status();
+}
+
+extern "C" int hs_upsample_bilinear_bwd(const float* dy, int64_t dy_batch_stride, int32_t batch, int32_t channels, int32_t Hi, int32_t Wi,
+                                        int32_t Ho, int32_t Wo, float* dx, void* stream) {
+    return hs_upsample_bilinear_typed_bwd(HS_DTYPE_F32, dy, dy_batch_stride, batch, channels, Hi, Wi, Ho, Wo, dx, stream);
 }
 
 static int bn_args(BnArgs& a, int B, int C, long hw, int act, float eps, float momentum) {
@@ -635,22 +649,42 @@ extern "C" int hs_bootstrap_mean_bwd(const float* values, int32_t n, const float
     return hs_bootstrap_mean_batched_bwd(values, 1, n, state5, grad_out, grad_values, stream);
 }
 
+extern "C" int hs_cross_entropy_typed_fwd(int32_t dtype, const void* logits, const int64_t* target, int32_t batch, int32_t classes, int64_t pixels,
+                                          int64_t ignore_index, float* loss, void* stream) {
+    if (!logits || !target || !loss || batch <= 0 || classes <= 0 || pixels <= 0) return HS_ERR_BAD_ARG;
+    if (dtype != HS_DTYPE_F32 && dtype != HS_DTYPE_BF16) return HS_ERR_BAD_ARG;
+    const long total = (long)batch * pixels;
+    const dim3 blocks((unsigned)((total + 255) / 256 > 65535 * 16 ? 65535 * 16 : (total + 255) / 256));
+    if (dtype == HS_DTYPE_F32)
+        hipLaunchKernelGGL((cross_entropy_kernel<false, float>), blocks, dim3(256), 0, (hipStream_t)stream, (const float*)logits, (const long long*)target,
+                           classes, (long)pixels, total, (long long)ignore_index, (const float*)nullptr, (void*)loss);
+    else
+        hipLaunchKernelGGL((cross_entropy_kernel<false, bf16_t>), blocks, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, (const long long*)target,
+                           classes, (long)pixels, total, (long long)ignore_index, (const float*)nullptr, (void*)loss);
+    return launch_status();
+}
+
+extern "C" int hs_cross_entropy_typed_bwd(int32_t dtype, const void* logits, const int64_t* target, int32_t batch, int32_t classes, int64_t pixels,
+                                          int64_t ignore_index, const float* grad_loss, void* grad_logits, void* stream) {
+    if (!logits || !target || !grad_loss || !grad_logits || batch <= 0 || classes <= 0 || pixels <= 0) return HS_ERR_BAD_ARG;
+    if (dtype != HS_DTYPE_F32 && dtype != HS_DTYPE_BF16) return HS_ERR_BAD_ARG;
+    const long total = (long)batch * pixels;
+    const dim3 blocks((unsigned)((total + 255) / 256 > 65535 * 16 ? 65535 * 16 : (total + 255) / 256));
+    if (dtype == HS_DTYPE_F32)
+        hipLaunchKernelGGL((cross_entropy_kernel<true, float>), blocks, dim3(256), 0, (hipStream_t)stream, (const float*)logits, (const long long*)target,
+                           classes, (long)pixels, total, (long long)ignore_index, grad_loss, grad_logits);
+    else
+        hipLaunchKernelGGL((cross_entropy_kernel<true, bf16_t>), blocks, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, (const long long*)target,
+                           classes, (long)pixels, total, (long long)ignore_index, grad_loss, grad_logits);
+    return launch_status();
+}
+
 extern "C" int hs_cross_entropy_fwd(const float* logits, const int64_t* target, int32_t batch, int32_t classes, int64_t pixels,
                                     int64_t ignore_index, float* loss, void* stream) {
-    if (!logits || !target || !loss || batch <= 0 || classes <= 0 || pixels <= 0) return HS_ERR_BAD_ARG;
-    const long total = (long)batch * pixels;
-    const unsigned blocks = (unsigned)((total + 255) / 256 > 65535 * 16 ? 65535 * 16 : (total + 255) / 256);
-    hipLaunchKernelGGL(cross_entropy_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, (const long long*)target, classes,
-                       (long)pixels, total, (long long)ignore_index, (const float*)nullptr, loss);
-    return launch_status();
+    return hs_cross_entropy_typed_fwd(HS_DTYPE_F32, logits, target, batch, classes, pixels, ignore_index, loss, stream);
 }
 
 extern "C" int hs_cross_entropy_bwd(const float* logits, const int64_t* target, int32_t batch, int32_t classes, int64_t pixels,
                                     int64_t ignore_index, const float* grad_loss, float* grad_logits, void* stream) {
-    if (!logits || !target || !grad_loss || !grad_logits || batch <= 0 || classes <= 0 || pixels <= 0) return HS_ERR_BAD_ARG;
-    const long total = (long)batch * pixels;
-    const unsigned blocks = (unsigned)((total + 255) / 256 > 65535 * 16 ? 65535 * 16 : (total + 255) / 256);
-    hipLaunchKernelGGL(cross_entropy_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, (const long long*)target, classes,
-                       (long)pixels, total, (long long)ignore_index, grad_loss, grad_logits);
-    return launch_status();
+    return hs_cross_entropy_typed_bwd(HS_DTYPE_F32, logits, target, batch, classes, pixels, ignore_index, grad_loss, grad_logits, stream);
 }

@@ -80,26 +80,32 @@ class StageInput:
     def device(self):
         return self.skip.device
 
-    def c_struct(self):
+    def c_struct(self, prev_dtype=torch.float32):
         b, cs, h, w = self.skip.shape
         st = _hip.StageInputC()
         st.skip = _hip.dev_ptr(self.skip, 'stage input (skip)')
         st.batch, st.H, st.W, st.c_skip = b, h, w, cs
         st.coords = int(self.coords)
         if self.prev is not None:
-            st.prev = _hip.dev_ptr(self.prev, 'stage input (prev)')
+            st.prev = _hip.dev_ptr(self.prev, 'stage input (prev)', prev_dtype)
             st.c_prev, st.Hp, st.Wp = self.prev.shape[1], self.prev.shape[2], self.prev.shape[3]
             st.prev_mode = _hip.PREV_SAME if self.prev.shape[2:] == self.skip.shape[2:] else _hip.PREV_BILINEAR
         else:
             st.prev, st.c_prev, st.Hp, st.Wp, st.prev_mode = None, 0, 0, 0, _hip.PREV_NONE
         return st
 
-    def materialize(self):
-        """The concatenated tensor itself (diagnostics / modules that cannot consume a lazy input)."""
-        st = self.c_struct()
-        y = torch.empty(self.shape, device=self.device, dtype=torch.float32)
-        with torch.cuda.device(self.device):
-            _hip.check(_hip.lib.hs_stage_input_fwd(C.byref(st), y.data_ptr(), _hip.stream_ptr()), 'hs_stage_input_fwd')
+    def materialize(self, dtype=torch.float32):
+        """The concatenated tensor itself (diagnostics / modules that cannot consume a lazy input; the training path, where
+        ``dtype`` = torch.bfloat16 under autocast and the previous level may be stored as bf16: hs_stage_input_typed_fwd)."""
+        codes = {torch.float32: 0, torch.bfloat16: 1}
+        pdt = self.prev.dtype if self.prev is not None else torch.float32
+        if dtype not in codes or pdt not in codes:
+            raise NotImplementedError(f'stage input: storage types {pdt} -> {dtype} (supported: float32, bfloat16)')
+        st = self.c_struct(pdt)
+        y = torch.empty(self.shape, device=self.device, dtype=dtype)
+        with _hip.device_scope(self.device):
+            _hip.check(_hip.lib.hs_stage_input_typed_fwd(C.byref(st), codes[pdt], codes[dtype], y.data_ptr(), _hip.stream_ptr()),
+                       'hs_stage_input_typed_fwd')
         return y
 
 

@@ -51,16 +51,16 @@ def bootstrap_mean_capturable(per_pixel, k, thresh):
 
 def bootstrapped_cross_entropy(pred, target, k=4096, thresh=0.3, weight=None, ignore_index=-100):
     """pred (N, C, H, W) logits, target (N, H, W) int64 -> scalar."""
-    total = pred.new_zeros(())
+    total = pred.new_zeros((), dtype=torch.float32)
     capturing = pred.is_cuda and torch.cuda.is_current_stream_capturing()
     # the per-pixel losses of the WHOLE batch in one pass over (N, C, H, W) (the reference permutes every image to (HW, C) first,
     # bootstrapped_ce_loss.py:20-23: same values, a transposed copy + a softmax + a gather per image and direction)
-    if (USE_HIP_BOOTSTRAP and weight is None and pred.is_cuda and pred.dtype == torch.float32 and pred.dim() == 4
+    if (USE_HIP_BOOTSTRAP and weight is None and pred.is_cuda and pred.dtype in (torch.float32, torch.bfloat16) and pred.dim() == 4
             and target.dtype == torch.int64 and target.device == pred.device):
-        from .autograd import PixelCrossEntropy                            # one launch per direction (hs_cross_entropy_fwd / _bwd)
+        from .autograd import PixelCrossEntropy                            # one launch per direction (hs_cross_entropy_typed_fwd / _bwd)
         per_all = PixelCrossEntropy.apply(pred, target, ignore_index)
     else:
-        per_all = F.cross_entropy(pred, target, weight=weight, ignore_index=ignore_index, reduction='none')
+        per_all = F.cross_entropy(pred.float(), target, weight=weight, ignore_index=ignore_index, reduction='none')
     per_rows = per_all.flatten(1)
     if (USE_HIP_BOOTSTRAP and per_rows.is_cuda and per_rows.dtype == torch.float32 and per_rows.shape[1] > k and per_rows.shape[0] <= 65535):
         from .autograd import BootstrapMeanBatched                         # every image in one set of launches, no sort, no host read

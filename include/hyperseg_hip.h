@@ -246,6 +246,10 @@ int hs_ir_tile_map(int32_t reg, int32_t mode, int32_t pwr, int32_t* n_tiles, int
  * (hyperseg_v1_0.py:250-251).  x (B,C,Hi,Wi) -> y (B,C,Ho,Wo). */
 int hs_upsample_bilinear_fwd(const float* x, int32_t batch, int32_t channels, int32_t Hi, int32_t Wi,
                              int32_t Ho, int32_t Wo, float* y, void* stream);
+/* ... on bf16 storage (x and y bf16, same taps, f32 arithmetic, one rounding on store): the training path's final logits under
+ * torch.autocast(bfloat16) (autograd.UpsampleBilinear). */
+int hs_upsample_bilinear_bf16_fwd(const void* x, int32_t batch, int32_t channels, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,
+                                  void* y, void* stream);
 
 /* The same resize with the class argmax taken in registers: mask (B, Ho, Wo) uint8 = argmax_c of the upsampled logits,
  * bit-identical to argmax over hs_upsample_bilinear_fwd's output (shared arithmetic), ties -> lowest class; channels
@@ -267,11 +271,12 @@ int hs_patch_conv_bwd_weight(const float* x, const float* dy, int32_t batch, int
                              int32_t fh, int32_t fw, int32_t c_out, int32_t k, int32_t pad, int32_t pad_mode,
                              int32_t groups, float* dbank, int64_t ld, void* stream);
 
-/* Training-path twins with a storage type: HS_DTYPE_F32, or HS_DTYPE_BF16 = bf16 storage (activations, banks, gradients
- * read and written as bf16: half the HBM bytes) with fp32 accumulation (BASELINE config 5; the reference has no reduced-
- * precision path: SURVEY 8d).  Plain (B, C, H, W) tensors, no fused prologue / epilogue -- the training route composes the
- * stage input, BatchNorm and activations with stock differentiable ops (hyperseg_amd/autograd.py).  Same math as
- * hs_patch_conv_fwd / hs_patch_conv_bwd_input / hs_patch_conv_bwd_weight above. */
+/* Training-path twins with a storage type: HS_DTYPE_F32, or HS_DTYPE_BF16 = bf16 storage of the ACTIVATIONS and their gradients
+ * (x, y, dy, dx read and written as bf16: half the HBM bytes) with fp32 accumulation (BASELINE config 5; the reference has no
+ * reduced-precision path: SURVEY 8d).  `bank` and `dbank` are fp32 (const float* / float*) for either dtype: the bank comes out of
+ * signal2weights and its gradient goes into that layer's adjoint, both fp32.  Plain (B, C, H, W) tensors, no fused prologue /
+ * epilogue -- the training route composes the stage input, BatchNorm and activations with its own differentiable ops
+ * (hyperseg_amd/autograd.py).  Same math as hs_patch_conv_fwd / hs_patch_conv_bwd_input / hs_patch_conv_bwd_weight above. */
 typedef enum { HS_DTYPE_F32 = 0, HS_DTYPE_BF16 = 1 } hs_dtype;
 int hs_patch_conv_plain_fwd(int32_t dtype, const void* x, const void* bank, int64_t ld, int32_t batch, int32_t c_in,
                             int32_t H, int32_t W, int32_t fh, int32_t fw, int32_t c_out, int32_t k, int32_t pad,
@@ -416,6 +421,10 @@ int hs_bank_unpack_fwd(const float* bank, int64_t ld, int32_t batch, int32_t hp_
  * Training path (autograd.UpsampleBilinear, StageMaterialize). */
 int hs_upsample_bilinear_bwd(const float* dy, int64_t dy_batch_stride, int32_t batch, int32_t channels, int32_t Hi, int32_t Wi,
                              int32_t Ho, int32_t Wo, float* dx, void* stream);
+/* ... with a storage type (hs_dtype; dy and dx alike, dy_batch_stride in ELEMENTS, f32 arithmetic, one rounding on store): the bf16
+ * training step keeps the stage inputs and their gradients in bf16 (autograd.StageMaterialize under torch.autocast). */
+int hs_upsample_bilinear_typed_bwd(int32_t dtype, const void* dy, int64_t dy_batch_stride, int32_t batch, int32_t channels, int32_t Hi,
+                                   int32_t Wi, int32_t Ho, int32_t Wo, void* dx, void* stream);
 
 /* BatchNorm2d in TRAINING mode (torch.nn.functional.batch_norm semantics: batch statistics, biased variance for the normalisation,
  * unbiased for the running estimate, running = (1 - momentum) running + momentum batch) fused with the activation that follows it
@@ -465,10 +474,20 @@ int hs_cross_entropy_fwd(const float* logits, const int64_t* target, int32_t bat
                          int64_t ignore_index, float* loss, void* stream);
 int hs_cross_entropy_bwd(const float* logits, const int64_t* target, int32_t batch, int32_t classes, int64_t pixels,
                          int64_t ignore_index, const float* grad_loss, float* grad_logits, void* stream);
+/* ... with the logits' storage type (hs_dtype; the logits' gradient alike; loss and grad_loss fp32; f32 arithmetic): bf16 logits straight
+ * from the decoder under torch.autocast(bfloat16), where the stock op widens them with a cast launch first. */
+int hs_cross_entropy_typed_fwd(int32_t dtype, const void* logits, const int64_t* target, int32_t batch, int32_t classes, int64_t pixels,
+                               int64_t ignore_index, float* loss, void* stream);
+int hs_cross_entropy_typed_bwd(int32_t dtype, const void* logits, const int64_t* target, int32_t batch, int32_t classes, int64_t pixels,
+                               int64_t ignore_index, const float* grad_loss, void* grad_logits, void* stream);
 
 /* Materialises a stage input (B, 2*coords + c_skip + c_prev, H, W); test/diagnostic twin of the
  * fused prologue (the product path never calls it). */
 int hs_stage_input_fwd(const hs_stage_input* in, float* y, void* stream);
+/* ... with storage types (hs_dtype): in->prev points at prev_dtype elements, y at out_dtype elements; in->skip is fp32.  The training
+ * path's stage input under bf16 autocast (autograd.StageMaterialize): the previous level is read as it is stored and the result is
+ * written in the type the first convolution reads, instead of a cast launch on either side. */
+int hs_stage_input_typed_fwd(const hs_stage_input* in, int32_t prev_dtype, int32_t out_dtype, void* y, void* stream);
 
 #ifdef __cplusplus
 }

@@ -348,6 +348,51 @@ def test_pixel_cross_entropy_vs_torch(dev, shape, ignore):
     assert rel_err(xb.grad.cpu(), xa.grad.cpu()) < 1e-6
 
 
+def test_bf16_storage_twins_round_the_fp32_kernels_once(dev):
+    """The storage-typed kernels that keep the bf16 training step free of cast launches -- hs_stage_input_typed_fwd, hs_upsample_
+    bilinear_bf16_fwd / _typed_bwd, hs_cross_entropy_typed_fwd / _bwd -- are the fp32 kernels on the widened values with ONE rounding of
+    the result: bit-equal to `fp32 kernel(x.float()).to(bfloat16)`; the loss of bf16 logits (fp32 out) is bit-equal to the fp32 kernel's."""
+    from hyperseg_amd import autograd as HA, functional as HF
+    g = torch.Generator().manual_seed(77)
+    bf = torch.bfloat16
+    skip = torch.randn(2, 5, 12, 20, generator=g).to(dev)
+    for prev_shape in ((2, 7, 6, 10), (2, 7, 12, 20), (2, 3, 5, 7), None):
+        prev = torch.randn(prev_shape, generator=g).to(dev).to(bf) if prev_shape else None
+        want = HF.StageInput(skip, prev.float() if prev is not None else None, coords=True).materialize()
+        got = HF.StageInput(skip, prev, coords=True).materialize(bf)
+        assert got.dtype == bf and torch.equal(got, want.to(bf))
+        assert torch.equal(HF.StageInput(skip, prev, coords=True).materialize(torch.float32), want)      # bf16 previous level, fp32 result
+        if prev is None:
+            continue
+        # autograd: bf16 in, bf16 out, the adjoint against the fp32 adjoint of the widened gradient
+        pa = prev.clone().requires_grad_(True)
+        y = HA.StageMaterialize.apply(skip, pa, True)
+        assert y.dtype == bf
+        r = torch.randn(y.shape, generator=g).to(dev).to(bf)
+        y.backward(r)
+        pb = prev.float().requires_grad_(True)
+        HA.StageMaterialize.apply(skip, pb, True).backward(r.float())
+        assert pa.grad.dtype == bf and torch.equal(pa.grad, pb.grad.to(bf))
+    x = torch.randn(2, 12, 9, 11, generator=g).to(dev).to(bf)
+    for size in ((18, 22), (36, 44), (20, 30)):
+        xa, xb = x.clone().requires_grad_(True), x.float().requires_grad_(True)
+        ya, yb = HA.upsample_bilinear(xa, size), HA.upsample_bilinear(xb, size)
+        assert ya.dtype == bf and torch.equal(ya, yb.to(bf))
+        r = torch.randn(ya.shape, generator=g).to(dev).to(bf)
+        ya.backward(r); yb.backward(r.float())
+        assert xa.grad.dtype == bf and torch.equal(xa.grad, xb.grad.to(bf))
+    logits = (torch.randn(2, 12, 16, 24, generator=g) * 4).to(dev).to(bf)
+    t = torch.randint(0, 12, (2, 16, 24), generator=g)
+    t[torch.rand(t.shape, generator=g) < 0.2] = 255
+    t = t.to(dev)
+    la, lb = logits.clone().requires_grad_(True), logits.float().requires_grad_(True)
+    pa, pb = HA.PixelCrossEntropy.apply(la, t, 255), HA.PixelCrossEntropy.apply(lb, t, 255)
+    assert pa.dtype == torch.float32 and torch.equal(pa, pb)
+    r = torch.rand(t.shape, generator=g).to(dev)
+    (pa * r).sum().backward(); (pb * r).sum().backward()
+    assert la.grad.dtype == bf and torch.equal(la.grad, lb.grad.to(bf))
+
+
 @pytest.mark.parametrize('thresh', [0.3, 2.5, 5.0, 7.0])
 def test_bootstrap_mean_kernels_vs_reference_statement(dev, thresh):
     """hs_bootstrap_mean_fwd / _bwd (radix selection, no sort, no host read) == the reference's rule stated with torch.sort

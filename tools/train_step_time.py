@@ -35,7 +35,7 @@ for mode in modes:
         def fwd(p, sig, half=(mode == 'graph_bf16')):
             with torch.autocast('cuda', dtype=torch.bfloat16, enabled=half):
                 return dec(p, sig)
-        gs = GraphedTrainStep(fwd, lambda p, t: crit(p.float(), t), opt_g, (pyr, s), target)
+        gs = GraphedTrainStep(fwd, crit, opt_g, (pyr, s), target)
         for _ in range(2):
             gs.step()
         torch.cuda.synchronize()
@@ -49,7 +49,7 @@ for mode in modes:
         opt.zero_grad()
         with torch.autocast('cuda', dtype=torch.bfloat16, enabled=(mode == 'bf16')):
             pred = dec(pyr, s)
-        loss = crit(pred.float(), target)
+        loss = crit(pred, target)
         loss.backward()
         opt.step()
         return loss
