@@ -152,6 +152,56 @@ class TileInterior(torch.autograd.Function):
             return _tile_call('hs_tile_interior_bwd', dtype, dy, b, c, h, w, grid, torch.empty(shape, device=dy.device, dtype=dtype)), None, None
 
 
+class DwTilesValid(torch.autograd.Function):
+    """The middle layer of a train-mode v1_0 inverted residual: a VALID depthwise 3x3 of every halo tile with the patch's own taps
+    (hyperseg_v1_0.py:352-360), tile image (B, C, fh (ph+2), fw (pw+2)) -> (B, C, H, W), one launch per direction and operand
+    (hs_dw_tiles_fwd / _bwd_in / _bwd_w).  ``bank``: the depthwise column range (P, 9 C) of the block's fp32 bank (a view)."""
+
+    @staticmethod
+    def forward(ctx, t, bank, size, grid):
+        t = t.contiguous()
+        b, c = t.shape[:2]
+        h, w = size
+        if bank.dtype != torch.float32 or bank.stride(1) != 1:
+            bank = bank.float().contiguous()
+        ctx.meta = (b, c, h, w, tuple(grid), t.dtype)
+        with _hip.device_scope(t.device):
+            y = torch.empty(b, c, h, w, device=t.device, dtype=t.dtype)
+            st = _hip.lib.hs_dw_tiles_fwd(DTYPE_CODES[t.dtype], t.data_ptr(), bank.data_ptr(), bank.stride(0), b, c, h, w, grid[0], grid[1],
+                                          y.data_ptr(), _hip.stream_ptr())
+            _hip.check(st, 'hs_dw_tiles_fwd')
+        ctx.save_for_backward(t, bank)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        t, bank = ctx.saved_tensors
+        b, c, h, w, grid, dtype = ctx.meta
+        dy = dy.contiguous().to(dtype)
+        dt = dbank = None
+        with _hip.device_scope(dy.device):
+            if ctx.needs_input_grad[0]:
+                dt = torch.empty_like(t)
+                st = _hip.lib.hs_dw_tiles_bwd_in(DTYPE_CODES[dtype], dy.data_ptr(), bank.data_ptr(), bank.stride(0), b, c, h, w, grid[0], grid[1],
+                                                 dt.data_ptr(), _hip.stream_ptr())
+                _hip.check(st, 'hs_dw_tiles_bwd_in')
+            if ctx.needs_input_grad[1]:
+                alloc = torch.empty if bank.shape[1] == 9 * c else torch.zeros
+                dbank = alloc(bank.shape[0], bank.shape[1], device=dy.device, dtype=torch.float32)
+                st = _hip.lib.hs_dw_tiles_bwd_w(DTYPE_CODES[dtype], t.data_ptr(), dy.data_ptr(), b, c, h, w, grid[0], grid[1], dbank.data_ptr(),
+                                                dbank.stride(0), _hip.stream_ptr())
+                _hip.check(st, 'hs_dw_tiles_bwd_w')
+        return dt, dbank, None, None
+
+
+def dw_tiles_supported(t, size, grid):
+    """hs_dw_tiles_*: CUDA fp32 / bf16, even patch width (two adjacent elements per thread)."""
+    return tiles_supported(t) and USE_HIP_DW_TILES and size[0] % grid[0] == 0 and size[1] % grid[1] == 0 and (size[1] // grid[1]) % 2 == 0
+
+
+USE_HIP_DW_TILES = True     # tests switch it off to compare with the two-launch route (zero-padded depthwise on the tile image + TileInterior)
+
+
 def tiles_supported(x):
     return x.is_cuda and x.dtype in DTYPE_CODES and x.shape[0] * x.shape[1] <= 65535 and x.shape[2] >= 2 and x.shape[3] >= 2
 

@@ -54,6 +54,11 @@ __device__ __forceinline__ Tap bilinear_tap(int dst, float scale, int in_size) {
 
 // Precomputed per-position sampling state of a stage input: everything that does not depend
 // on the channel.  (y, x) are in-image coordinates (already mapped through pad_index).
+// n / d for 0 <= n < 2^21 and a run-time divisor d whose reciprocal the host passes as a float: floor((n + 0.5) * (1 / d)) -- (n + 0.5) / d
+// sits >= 0.5 / d away from the next integer on either side while the float error is <= 2^-22 n / d, so the truncation is exact.  Three
+// instructions; the compiler's 32-bit division by a run-time value is ~25 (the image-level training kernels did up to 18 per thread).
+__device__ __forceinline__ int div_by_inv(int n, float inv_d) { return (int)(((float)n + 0.5f) * inv_d); }
+
 // Storage types of the training-path kernels: fp32, or bf16 storage with fp32 arithmetic (rounded to nearest-even once on store).
 struct bf16_t { uint16_t v; };
 

@@ -22,6 +22,7 @@ struct ConvBwdArgs {
     float* __restrict__ dbank;         // (P, ld)
     long ld;
     int B, H, W, fh, fw, ph, pw, cin, cout, k, pad, pad_mode, groups, cin_g, cout_g;
+    float inv_ph, inv_pw;              // 1 / ph, 1 / pw (div_by_inv: the image-level depthwise kernels)
 };
 
 int try_fast_fwd(int dtype, const void* x, const void* bank, long ld, int batch, int c_in, int H, int W, int fh, int fw, int c_out,
@@ -133,6 +134,7 @@ void patch_conv_bwd_weight_kernel(ConvBwdArgs a, int ob) {
 // everything else (k > 1, groups, patches that are not a multiple of 16 pixels / 4 columns, very wide layers).
 // ---------------------------------------------------------------------------------------------------------------------------------
 using bw_f32x4 = __attribute__((ext_vector_type(4))) float;
+using bw_f32x2 = __attribute__((ext_vector_type(2))) float;
 
 // VEC: patches whose rows are whole 4-pixel groups on 16-byte boundaries and whose pixel count is a multiple of 16.  Otherwise (the
 // (ph + 2) x (pw + 2) halo tiles that a train-mode v1_0 inverted residual feeds to its first 1x1 convolution: 18 x 18, 10 x 10) the
@@ -398,6 +400,89 @@ void patch_dw3_kernel(ConvBwdArgs a, const T* __restrict__ src, T* __restrict__ 
     Store<T>::st(dst, (size_t)plane_id * a.H * a.W + (size_t)y * a.W + x, acc);
 }
 
+// The same two operators with TWO horizontally adjacent elements per thread (even patch and image widths: every use in the decoders) and no
+// integer division (round 4; the one-element form above stays for odd widths).  A thread's 3 x 4 neighbourhood is 9 loads (the middle pair
+// of a row is one 8-byte -- bf16: 4-byte -- load) instead of 18, its patch row / column come from div_by_inv, and a neighbour's patch is the
+// own one +- 1 decided from the position inside the tile: the one-element adjoint did 18 divisions by run-time values per thread (~450 of its
+// ~520 vector instructions; 52 us per launch at config 5 against 30 for the forward, which does two).  Same fma chain per element (tap-major,
+// ky then kx): bit-identical results.
+template <typename T> struct Pair;
+template <> struct Pair<float> {
+    static __device__ __forceinline__ void ld(const float* p, size_t i, float& a, float& b) {
+        const bw_f32x2 v = *reinterpret_cast<const bw_f32x2*>(p + i); a = v[0]; b = v[1];
+    }
+    static __device__ __forceinline__ void st(float* p, size_t i, float a, float b) { *reinterpret_cast<bw_f32x2*>(p + i) = bw_f32x2{a, b}; }
+};
+template <> struct Pair<bf16_t> {
+    static __device__ __forceinline__ void ld(const bf16_t* p, size_t i, float& a, float& b) {
+        const uint32_t v = *reinterpret_cast<const uint32_t*>(p + i); a = __uint_as_float(v << 16); b = __uint_as_float(v & 0xffff0000u);
+    }
+    static __device__ __forceinline__ void st(bf16_t* p, size_t i, float a, float b) { Store<bf16_t>::st(p, i, a); Store<bf16_t>::st(p, i + 1, b); }
+};
+
+template <int MODE, typename T>
+__global__ __launch_bounds__(256)
+void patch_dw3_pair_kernel(ConvBwdArgs a, const T* __restrict__ src, T* __restrict__ dst) {
+    const int x0 = 2 * (blockIdx.x * 64 + (threadIdx.x & 63)), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int plane_id = blockIdx.z;
+    if (x0 >= a.W || y >= a.H) return;
+    const int b = div_by_inv(plane_id, 1.0f / (float)a.cin), c = plane_id - b * a.cin;
+    const T* __restrict__ sp = src + (size_t)plane_id * a.H * a.W;
+    const int ty = div_by_inv(y, a.inv_ph), u = y - ty * a.ph, tx = div_by_inv(x0, a.inv_pw), v = x0 - tx * a.pw;   // v even, v + 1 < pw
+    // ---- the 3 x 4 neighbourhood: rows y - 1 .. y + 1, columns x0 - 1 .. x0 + 2, zero outside the image (clamped loads, masked by multiplies)
+    float s[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int yy = y + r - 1;
+        const bool row_in = yy >= 0 && yy < a.H;
+        const size_t rb = (size_t)min(max(yy, 0), a.H - 1) * a.W;
+        float m0, m1;
+        Pair<T>::ld(sp, rb + x0, m0, m1);
+        const float l = Store<T>::ld(sp, rb + max(x0 - 1, 0)), rr = Store<T>::ld(sp, rb + min(x0 + 2, a.W - 1));
+        s[r][0] = (row_in && x0 > 0) ? l : 0.0f;                           // (loads unconditional, selects afterwards)
+        s[r][1] = row_in ? m0 : 0.0f; s[r][2] = row_in ? m1 : 0.0f;
+        s[r][3] = (row_in && x0 + 2 < a.W) ? rr : 0.0f;
+    }
+    const float* __restrict__ bank = a.bank;
+    float acc0 = 0.0f, acc1 = 0.0f;
+    if constexpr (MODE == 0) {
+        const float* __restrict__ kp = bank + (size_t)((b * a.fh + ty) * a.fw + tx) * a.ld + c * 9;
+        float kv[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) kv[t] = kp[t];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                acc0 = fmaf(kv[ky * 3 + kx], s[ky][kx], acc0);
+                acc1 = fmaf(kv[ky * 3 + kx], s[ky][kx + 1], acc1);
+            }
+    } else {
+        // input pixel (y, x0 + j) feeds output (y - ky + 1, x0 + j - kx + 1) through tap (ky, kx) of the patch that owns THAT output:
+        // row of s = 2 - ky, column = j - kx + 2; the owner's tile row / column = own +- 1 at the tile's border
+        const int pr[3] = {min(ty + (u == a.ph - 1 ? 1 : 0), a.fh - 1), ty, max(ty - (u == 0 ? 1 : 0), 0)};            // ky = 0, 1, 2
+        // columns of s 0 .. 3 = image columns x0 - 1 .. x0 + 2
+        const int pc[4] = {max(tx - (v == 0 ? 1 : 0), 0), tx, tx, min(tx + (v + 2 == a.pw ? 1 : 0), a.fw - 1)};
+        float w0[9], w1[9];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const size_t row = (size_t)(b * a.fh + pr[ky]) * a.fw;
+                w0[ky * 3 + kx] = bank[(row + pc[2 - kx]) * a.ld + c * 9 + ky * 3 + kx];
+                w1[ky * 3 + kx] = bank[(row + pc[3 - kx]) * a.ld + c * 9 + ky * 3 + kx];
+            }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                acc0 = fmaf(w0[ky * 3 + kx], s[2 - ky][2 - kx], acc0);
+                acc1 = fmaf(w1[ky * 3 + kx], s[2 - ky][3 - kx], acc1);
+            }
+    }
+    Pair<T>::st(dst, (size_t)plane_id * a.H * a.W + (size_t)y * a.W + x0, acc0, acc1);
+}
+
 // dK[patch][c][ky][kx] = sum over the patch's pixels of dY[c][y][x] X[c][y + ky - 1][x + kx - 1] (zero outside the image): one wave per
 // (patch, channel), lanes over the pixels, nine accumulators, DPP wave sums.
 template <typename T>
@@ -433,6 +518,192 @@ void patch_dw3_bwd_weight_kernel(ConvBwdArgs a) {
     }
 }
 
+// ... and the weight gradient with two adjacent pixels per lane (even patch width): 10 loads per pair instead of 20, rows from div_by_inv.
+template <typename T>
+__global__ __launch_bounds__(256)
+void patch_dw3_bwd_weight_pair_kernel(ConvBwdArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int patch = blockIdx.x, c = blockIdx.y * 4 + wave;
+    if (c >= a.cin) return;
+    const int pj = patch % a.fw, pi = (patch / a.fw) % a.fh, b = patch / (a.fw * a.fh);
+    const size_t plane = (size_t)a.H * a.W;
+    const T* __restrict__ xp = (const T*)a.x + ((size_t)b * a.cin + c) * plane;
+    const T* __restrict__ gp = (const T*)a.dy + ((size_t)b * a.cin + c) * plane;
+    const int y0 = pi * a.ph, x0 = pj * a.pw, hw = a.pw >> 1, npair = a.ph * hw;
+    const float inv_hw = 2.0f * a.inv_pw;
+    float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int l = lane; l < npair; l += 64) {
+        const int u = div_by_inv(l, inv_hw), v = 2 * (l - u * hw), y = y0 + u, x = x0 + v;
+        float g0, g1;
+        Pair<T>::ld(gp, (size_t)y * a.W + x, g0, g1);
+        float s[3][4];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int yy = y + r - 1;
+            const bool row_in = yy >= 0 && yy < a.H;
+            const size_t rb = (size_t)min(max(yy, 0), a.H - 1) * a.W;
+            float m0, m1;
+            Pair<T>::ld(xp, rb + x, m0, m1);
+            const float lf = Store<T>::ld(xp, rb + max(x - 1, 0)), rr = Store<T>::ld(xp, rb + min(x + 2, a.W - 1));
+            s[r][0] = (row_in && x > 0) ? lf : 0.0f;
+            s[r][1] = row_in ? m0 : 0.0f; s[r][2] = row_in ? m1 : 0.0f;
+            s[r][3] = (row_in && x + 2 < a.W) ? rr : 0.0f;
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                acc[ky * 3 + kx] = fmaf(g0, s[ky][kx], acc[ky * 3 + kx]);
+                acc[ky * 3 + kx] = fmaf(g1, s[ky][kx + 1], acc[ky * 3 + kx]);
+            }
+    }
+    float* __restrict__ dst = a.dbank + (size_t)patch * a.ld + c * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float sum = wave_sum64(acc[t]);
+        if (lane == 0) dst[t] = sum;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The middle layer of a train-mode v1_0 inverted residual AS THE REFERENCE STATES IT (round 4): a VALID depthwise 3 x 3 on every halo tile,
+//     y[b][c][i ph + u][j pw + v] = sum_{ky,kx} K[patch (b,i,j)][c][ky][kx] t[b][c][i (ph+2) + u + ky][j (pw+2) + v + kx]
+// from the image of halo tiles (B, C, fh (ph+2), fw (pw+2)) straight to the block's (B, C, H, W) map.  Rounds 3-4 ran it as a zero-padded
+// convolution over the whole tile image followed by a gather that drops every tile's ring (hs_tile_interior_*): 27 % more outputs than are
+// kept, a 37 MB intermediate written and read again at config 5, an adjoint that had to look up the NEIGHBOURING patches' taps for ring
+// positions whose gradient is zero by construction, and two extra launches per direction.  Here everything is tile-local: two adjacent
+// elements per thread (even pw), aligned 8-byte loads, no bounds tests in the forward, the patch's own nine taps in the adjoint.  The fma
+// chains run tap-major (ky, then kx) like patch_dw3_*: the kept values are bit-identical to the two-launch route.
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct DwtArgs {
+    const float* __restrict__ bank;    // (P, ld): taps of patch p, channel c at [p ld + 9 c + 3 ky + kx]
+    float* __restrict__ dbank;
+    long ld;
+    int B, C, H, W, fh, fw, ph, pw;
+    float inv_ph, inv_pw, inv_ph2, inv_pw2, inv_c;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256)
+void dw_tiles_fwd_kernel(DwtArgs a, const T* __restrict__ t, T* __restrict__ y) {
+    const int x0 = 2 * (blockIdx.x * 64 + (threadIdx.x & 63)), yy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int plane_id = blockIdx.z;
+    if (x0 >= a.W || yy >= a.H) return;
+    const int b = div_by_inv(plane_id, a.inv_c), c = plane_id - b * a.C;
+    const int i = div_by_inv(yy, a.inv_ph), u = yy - i * a.ph, j = div_by_inv(x0, a.inv_pw), v = x0 - j * a.pw;
+    const int TW = a.fw * (a.pw + 2), TH = a.fh * (a.ph + 2);
+    const T* __restrict__ tp = t + ((size_t)plane_id * TH + (size_t)i * (a.ph + 2) + u) * TW + (size_t)j * (a.pw + 2) + v;
+    const float* __restrict__ kp = a.bank + (size_t)((b * a.fh + i) * a.fw + j) * a.ld + c * 9;
+    float s[3][4], kv[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        Pair<T>::ld(tp, (size_t)r * TW, s[r][0], s[r][1]);
+        Pair<T>::ld(tp, (size_t)r * TW + 2, s[r][2], s[r][3]);
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) kv[q] = kp[q];
+    float acc0 = 0.0f, acc1 = 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            acc0 = fmaf(kv[ky * 3 + kx], s[ky][kx], acc0);
+            acc1 = fmaf(kv[ky * 3 + kx], s[ky][kx + 1], acc1);
+        }
+    Pair<T>::st(y, ((size_t)plane_id * a.H + yy) * a.W + x0, acc0, acc1);
+}
+
+// dt[tile position (U, V)] = sum_{ky,kx} K[ky][kx] dy[U - ky][V - kx] over the patch's own outputs (0 <= U - ky < ph, 0 <= V - kx < pw)
+template <typename T>
+__global__ __launch_bounds__(256)
+void dw_tiles_bwd_in_kernel(DwtArgs a, const T* __restrict__ dy, T* __restrict__ dt) {
+    const int TW = a.fw * (a.pw + 2), TH = a.fh * (a.ph + 2);
+    const int X0 = 2 * (blockIdx.x * 64 + (threadIdx.x & 63)), Y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int plane_id = blockIdx.z;
+    if (X0 >= TW || Y >= TH) return;
+    const int b = div_by_inv(plane_id, a.inv_c), c = plane_id - b * a.C;
+    const int i = div_by_inv(Y, a.inv_ph2), U = Y - i * (a.ph + 2), j = div_by_inv(X0, a.inv_pw2), V0 = X0 - j * (a.pw + 2);
+    const T* __restrict__ gp = dy + ((size_t)plane_id * a.H + (size_t)i * a.ph) * a.W + (size_t)j * a.pw;       // the patch's (0, 0) output
+    const float* __restrict__ kp = a.bank + (size_t)((b * a.fh + i) * a.fw + j) * a.ld + c * 9;
+    // rows U - 2 .. U, columns V0 - 2 .. V0 + 1 of the patch's outputs: two aligned pairs per row, each wholly inside or wholly outside
+    const bool left = V0 >= 2, right = V0 <= a.pw - 2;
+    const int cl = left ? V0 - 2 : 0, cr = right ? V0 : 0;
+    float g[3][4], kv[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {                                     // r <-> output row U - 2 + r
+        const int ur = U - 2 + r;
+        const bool row_in = ur >= 0 && ur < a.ph;
+        const size_t rb = (size_t)min(max(ur, 0), a.ph - 1) * a.W;
+        float l0, l1, r0, r1;
+        Pair<T>::ld(gp, rb + cl, l0, l1);
+        Pair<T>::ld(gp, rb + cr, r0, r1);
+        g[r][0] = (row_in && left) ? l0 : 0.0f; g[r][1] = (row_in && left) ? l1 : 0.0f;
+        g[r][2] = (row_in && right) ? r0 : 0.0f; g[r][3] = (row_in && right) ? r1 : 0.0f;
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) kv[q] = kp[q];
+    float acc0 = 0.0f, acc1 = 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {                              // output (U - ky, V - kx): row index 2 - ky, column index V - kx - (V0 - 2)
+            acc0 = fmaf(kv[ky * 3 + kx], g[2 - ky][2 - kx], acc0);
+            acc1 = fmaf(kv[ky * 3 + kx], g[2 - ky][3 - kx], acc1);
+        }
+    Pair<T>::st(dt, ((size_t)plane_id * TH + Y) * TW + X0, acc0, acc1);
+}
+
+// dK[patch][c][ky][kx] = sum over the patch's outputs (u, v) of dy[u][v] t[u + ky][v + kx]: one wave per (patch, channel), a lane owns output pairs
+template <typename T>
+__global__ __launch_bounds__(256)
+void dw_tiles_bwd_w_kernel(DwtArgs a, const T* __restrict__ t, const T* __restrict__ dy) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int patch = blockIdx.x, c = blockIdx.y * 4 + wave;
+    if (c >= a.C) return;
+    const int j = patch % a.fw, i = (patch / a.fw) % a.fh, b = patch / (a.fw * a.fh);
+    const int TW = a.fw * (a.pw + 2), TH = a.fh * (a.ph + 2);
+    const T* __restrict__ tp = t + (((size_t)b * a.C + c) * TH + (size_t)i * (a.ph + 2)) * TW + (size_t)j * (a.pw + 2);
+    const T* __restrict__ gp = dy + (((size_t)b * a.C + c) * a.H + (size_t)i * a.ph) * a.W + (size_t)j * a.pw;
+    const int hw = a.pw >> 1, npair = a.ph * hw;
+    const float inv_hw = 2.0f * a.inv_pw;
+    float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int l = lane; l < npair; l += 64) {
+        const int u = div_by_inv(l, inv_hw), v = 2 * (l - u * hw);
+        float g0, g1, s[3][4];
+        Pair<T>::ld(gp, (size_t)u * a.W + v, g0, g1);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            Pair<T>::ld(tp, (size_t)(u + r) * TW + v, s[r][0], s[r][1]);
+            Pair<T>::ld(tp, (size_t)(u + r) * TW + v + 2, s[r][2], s[r][3]);
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                acc[ky * 3 + kx] = fmaf(g0, s[ky][kx], acc[ky * 3 + kx]);
+                acc[ky * 3 + kx] = fmaf(g1, s[ky][kx + 1], acc[ky * 3 + kx]);
+            }
+    }
+    float* __restrict__ dst = a.dbank + (size_t)patch * a.ld + c * 9;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const float sum = wave_sum64(acc[q]);
+        if (lane == 0) dst[q] = sum;
+    }
+}
+
+static int dwt_args(DwtArgs& a, int dtype, const void* p, const void* q, long ld, int B, int C, int H, int W, int fh, int fw) {
+    if (!p || !q || B <= 0 || C <= 0 || H <= 0 || W <= 0 || fh <= 0 || fw <= 0 || ld < 9L * C) return HS_ERR_BAD_ARG;
+    if (dtype != HS_DTYPE_F32 && dtype != HS_DTYPE_BF16) return HS_ERR_BAD_ARG;
+    if (H % fh || W % fw) return HS_ERR_NOT_DIVISIBLE;
+    const int ph = H / fh, pw = W / fw;
+    // pairs: even patch width (then W and the tile image's width are even too); 8-byte aligned tensors; div_by_inv's range
+    if ((pw & 1) || ((((size_t)p) | ((size_t)q)) & 7) || (long)B * C > 65535 || H + 2 * fh >= (1 << 21) || W + 2 * fw >= (1 << 21)) return HS_ERR_UNSUPPORTED;
+    a = DwtArgs{nullptr, nullptr, ld, B, C, H, W, fh, fw, ph, pw, 1.0f / (float)ph, 1.0f / (float)pw, 1.0f / (float)(ph + 2), 1.0f / (float)(pw + 2),
+                1.0f / (float)C};
+    return HS_OK;
+}
+
 }  // namespace hs
 
 using namespace hs;
@@ -443,6 +714,11 @@ static void fast_args(ConvBwdArgs& a, const void* bank, long ld, int batch, int 
     a = ConvBwdArgs{};
     a.bank = (const float*)bank; a.ld = ld; a.B = batch; a.H = H; a.W = W; a.fh = fh; a.fw = fw; a.ph = H / fh; a.pw = W / fw;
     a.cin = c_in; a.cout = c_out; a.k = 1; a.groups = 1; a.cin_g = c_in; a.cout_g = c_out;
+    a.inv_ph = 1.0f / (float)a.ph; a.inv_pw = 1.0f / (float)a.pw;
+}
+// the pair forms: even patch and image widths (a pair never straddles a tile or a row), 8-byte aligned planes, div_by_inv's range
+static bool dw3_pairs(const ConvBwdArgs& a, const void* p, const void* q) {
+    return (a.pw & 1) == 0 && (a.W & 1) == 0 && ((((size_t)p) | ((size_t)q)) & 7) == 0 && a.H < (1 << 21) && a.W < (1 << 21) && (long)a.B * a.cin < (1 << 21);
 }
 #define HS_T2(dtype, F32, BF16) do { if ((dtype) == HS_DTYPE_F32) { F32; } else { BF16; } } while (0)
 
@@ -453,6 +729,12 @@ int hs::try_fast_fwd(int dtype, const void* x, const void* bank, long ld, int ba
     fast_args(a, bank, ld, batch, c_in, H, W, fh, fw, c_out);
     if (k == 3 && pad == 1 && pad_mode == HS_PAD_ZEROS && groups == c_in && c_in == c_out && !scale && act == HS_ACT_NONE &&
         (long)batch * c_in <= 65535) {                                  // plain depthwise 3x3 (the autograd path's middle layer)
+        if (dw3_pairs(a, x, y)) {
+            const dim3 grid2((W / 2 + 63) / 64, (H + 3) / 4, batch * c_in);
+            HS_T2(dtype, hipLaunchKernelGGL((patch_dw3_pair_kernel<0, float>), grid2, dim3(256), 0, stream, a, (const float*)x, (float*)y),
+                         hipLaunchKernelGGL((patch_dw3_pair_kernel<0, bf16_t>), grid2, dim3(256), 0, stream, a, (const bf16_t*)x, (bf16_t*)y));
+            return launch_status();
+        }
         const dim3 grid((W + 63) / 64, (H + 3) / 4, batch * c_in);
         HS_T2(dtype, hipLaunchKernelGGL((patch_dw3_kernel<0, float>), grid, dim3(256), 0, stream, a, (const float*)x, (float*)y),
                      hipLaunchKernelGGL((patch_dw3_kernel<0, bf16_t>), grid, dim3(256), 0, stream, a, (const bf16_t*)x, (bf16_t*)y));
@@ -479,6 +761,12 @@ int hs::try_fast_bwd_in(int dtype, const void* dy, const void* bank, long ld, in
     fast_args(a, bank, ld, batch, c_in, H, W, fh, fw, c_out);
     a.dy = (const float*)dy; a.dx = (float*)dx;
     if (k == 3 && pad == 1 && pad_mode == HS_PAD_ZEROS && groups == c_in && c_in == c_out && (long)batch * c_in <= 65535) {
+        if (dw3_pairs(a, dy, dx)) {
+            const dim3 grid2((W / 2 + 63) / 64, (H + 3) / 4, batch * c_in);
+            HS_T2(dtype, hipLaunchKernelGGL((patch_dw3_pair_kernel<1, float>), grid2, dim3(256), 0, stream, a, (const float*)dy, (float*)dx),
+                         hipLaunchKernelGGL((patch_dw3_pair_kernel<1, bf16_t>), grid2, dim3(256), 0, stream, a, (const bf16_t*)dy, (bf16_t*)dx));
+            return launch_status();
+        }
         const dim3 grid((W + 63) / 64, (H + 3) / 4, batch * c_in);
         HS_T2(dtype, hipLaunchKernelGGL((patch_dw3_kernel<1, float>), grid, dim3(256), 0, stream, a, (const float*)dy, (float*)dx),
                      hipLaunchKernelGGL((patch_dw3_kernel<1, bf16_t>), grid, dim3(256), 0, stream, a, (const bf16_t*)dy, (bf16_t*)dx));
@@ -505,6 +793,11 @@ int hs::try_fast_bwd_w(int dtype, const void* x, const void* dy, int batch, int 
     a.x = (const float*)x; a.dy = (const float*)dy; a.dbank = (float*)dbank;
     if (k == 3 && pad == 1 && pad_mode == HS_PAD_ZEROS && groups == c_in && c_in == c_out && (c_in + 3) / 4 <= 65535) {
         const dim3 grid((unsigned)(batch * fh * fw), (c_in + 3) / 4);
+        if (dw3_pairs(a, x, dy)) {
+            HS_T2(dtype, hipLaunchKernelGGL(patch_dw3_bwd_weight_pair_kernel<float>, grid, dim3(256), 0, stream, a),
+                         hipLaunchKernelGGL(patch_dw3_bwd_weight_pair_kernel<bf16_t>, grid, dim3(256), 0, stream, a));
+            return launch_status();
+        }
         HS_T2(dtype, hipLaunchKernelGGL(patch_dw3_bwd_weight_kernel<float>, grid, dim3(256), 0, stream, a),
                      hipLaunchKernelGGL(patch_dw3_bwd_weight_kernel<bf16_t>, grid, dim3(256), 0, stream, a));
         return launch_status();
@@ -605,5 +898,45 @@ extern "C" int hs_patch_conv_bwd_weight(const float* x, const float* dy, int32_t
     const unsigned nblk = (unsigned)((c_out + ob - 1) / ob);
     hipLaunchKernelGGL(patch_conv_bwd_weight_kernel, dim3((unsigned)(batch * fh * fw), nblk), dim3(256), lds,
                        (hipStream_t)stream, a, ob);
+    return launch_status();
+}
+
+// ---- valid depthwise 3 x 3 on halo tiles (dw_tiles_*): the middle layer of a train-mode v1_0 inverted residual, tile image <-> (B, C, H, W)
+extern "C" int hs_dw_tiles_fwd(int32_t dtype, const void* tiled, const float* bank, int64_t ld, int32_t batch, int32_t channels, int32_t H,
+                               int32_t W, int32_t fh, int32_t fw, void* y, void* stream) {
+    DwtArgs a;
+    const int st = dwt_args(a, dtype, tiled, y, (long)ld, batch, channels, H, W, fh, fw);
+    if (st != HS_OK) return st;
+    if (!bank || (((size_t)bank) & 3)) return HS_ERR_BAD_ARG;
+    a.bank = bank;
+    const dim3 grid((W / 2 + 63) / 64, (H + 3) / 4, batch * channels);
+    if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL(dw_tiles_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a, (const float*)tiled, (float*)y);
+    else hipLaunchKernelGGL(dw_tiles_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, a, (const bf16_t*)tiled, (bf16_t*)y);
+    return launch_status();
+}
+
+extern "C" int hs_dw_tiles_bwd_in(int32_t dtype, const void* dy, const float* bank, int64_t ld, int32_t batch, int32_t channels, int32_t H,
+                                  int32_t W, int32_t fh, int32_t fw, void* dtiled, void* stream) {
+    DwtArgs a;
+    const int st = dwt_args(a, dtype, dy, dtiled, (long)ld, batch, channels, H, W, fh, fw);
+    if (st != HS_OK) return st;
+    if (!bank) return HS_ERR_BAD_ARG;
+    a.bank = bank;
+    const dim3 grid((fw * (a.pw + 2) / 2 + 63) / 64, (fh * (a.ph + 2) + 3) / 4, batch * channels);
+    if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL(dw_tiles_bwd_in_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a, (const float*)dy, (float*)dtiled);
+    else hipLaunchKernelGGL(dw_tiles_bwd_in_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, a, (const bf16_t*)dy, (bf16_t*)dtiled);
+    return launch_status();
+}
+
+extern "C" int hs_dw_tiles_bwd_w(int32_t dtype, const void* tiled, const void* dy, int32_t batch, int32_t channels, int32_t H, int32_t W,
+                                 int32_t fh, int32_t fw, float* dbank, int64_t ld, void* stream) {
+    DwtArgs a;
+    const int st = dwt_args(a, dtype, tiled, dy, (long)ld, batch, channels, H, W, fh, fw);
+    if (st != HS_OK) return st;
+    if (!dbank) return HS_ERR_BAD_ARG;
+    a.dbank = dbank;
+    const dim3 grid((unsigned)(batch * fh * fw), (channels + 3) / 4);
+    if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL(dw_tiles_bwd_w_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a, (const float*)tiled, (const float*)dy);
+    else hipLaunchKernelGGL(dw_tiles_bwd_w_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, a, (const bf16_t*)tiled, (const bf16_t*)dy);
     return launch_status();
 }

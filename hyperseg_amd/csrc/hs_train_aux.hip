@@ -17,7 +17,7 @@
 
 namespace hs {
 
-struct TileArgs { int B, C, H, W, fh, fw, ph, pw; };
+struct TileArgs { int B, C, H, W, fh, fw, ph, pw; float inv_ph, inv_pw, inv_ph2, inv_pw2; };      // reciprocals of ph, pw, ph + 2, pw + 2 (div_by_inv)
 
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
 
@@ -27,7 +27,7 @@ void halo_tiles_fwd_kernel(TileArgs a, const T* __restrict__ x, T* __restrict__ 
     const int TW = a.fw * (a.pw + 2), TH = a.fh * (a.ph + 2);
     const int X = blockIdx.x * 64 + (threadIdx.x & 63), Y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (X >= TW || Y >= TH) return;
-    const int i = Y / (a.ph + 2), u = Y - i * (a.ph + 2), j = X / (a.pw + 2), v = X - j * (a.pw + 2);
+    const int i = div_by_inv(Y, a.inv_ph2), u = Y - i * (a.ph + 2), j = div_by_inv(X, a.inv_pw2), v = X - j * (a.pw + 2);
     const int y = reflect1(i * a.ph + u - 1, a.H), xx = reflect1(j * a.pw + v - 1, a.W);
     const size_t pl = blockIdx.z;
     Store<T>::st(t, (pl * TH + Y) * TW + X, Store<T>::ld(x, (pl * a.H + y) * a.W + xx));
@@ -36,14 +36,14 @@ void halo_tiles_fwd_kernel(TileArgs a, const T* __restrict__ x, T* __restrict__ 
 // candidates (tile index, position inside the tile) of one axis that map onto image index y: every padded coordinate that reflects
 // onto y (itself; -1 for y = 1; n for y = n - 2), in every tile whose p + 2 padded rows contain it (two at a patch border, three when
 // patches are one pixel wide)
-__device__ __forceinline__ int tile_sources(int y, int n, int p, int f, int (&tpos)[9]) {
+__device__ __forceinline__ int tile_sources(int y, int n, int p, float inv_p, int f, int (&tpos)[9]) {
     int cnt = 0;
     const int yps[3] = {y, y == 1 ? -1 : -2, y == n - 2 ? n : -2};      // -2: none
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         if (yps[q] == -2) continue;
         const int Yp = yps[q] + 1;                                      // index in the padded image [0, n + 1]
-        for (int i = Yp / p; i >= 0 && Yp - i * p <= p + 1; --i)
+        for (int i = div_by_inv(Yp, inv_p); i >= 0 && Yp - i * p <= p + 1; --i)
             if (i < f) tpos[cnt++] = i * (p + 2) + (Yp - i * p);
     }
     return cnt;
@@ -56,7 +56,7 @@ void halo_tiles_bwd_kernel(TileArgs a, const T* __restrict__ dt, T* __restrict__
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= a.W || y >= a.H) return;
     int ys[9], xs[9];
-    const int ny = tile_sources(y, a.H, a.ph, a.fh, ys), nx = tile_sources(x, a.W, a.pw, a.fw, xs);
+    const int ny = tile_sources(y, a.H, a.ph, a.inv_ph, a.fh, ys), nx = tile_sources(x, a.W, a.pw, a.inv_pw, a.fw, xs);
     const size_t pl = blockIdx.z;
     float acc = 0.0f;
     for (int p = 0; p < ny; ++p)
@@ -72,12 +72,12 @@ void tile_interior_kernel(TileArgs a, const T* __restrict__ src, T* __restrict__
     if constexpr (!BWD) {
         const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
         if (x >= a.W || y >= a.H) return;
-        const int i = y / a.ph, j = x / a.pw;
+        const int i = div_by_inv(y, a.inv_ph), j = div_by_inv(x, a.inv_pw);
         Store<T>::st(dst, (pl * a.H + y) * a.W + x, Store<T>::ld(src, (pl * TH + y + 2 * i + 1) * TW + x + 2 * j + 1));
     } else {
         const int X = blockIdx.x * 64 + (threadIdx.x & 63), Y = blockIdx.y * 4 + (threadIdx.x >> 6);
         if (X >= TW || Y >= TH) return;
-        const int i = Y / (a.ph + 2), u = Y - i * (a.ph + 2), j = X / (a.pw + 2), v = X - j * (a.pw + 2);
+        const int i = div_by_inv(Y, a.inv_ph2), u = Y - i * (a.ph + 2), j = div_by_inv(X, a.inv_pw2), v = X - j * (a.pw + 2);
         const bool in = u >= 1 && u <= a.ph && v >= 1 && v <= a.pw;
         const float g = Store<T>::ld(src, (pl * a.H + min(max(i * a.ph + u - 1, 0), a.H - 1)) * a.W + min(max(j * a.pw + v - 1, 0), a.W - 1));
         Store<T>::st(dst, (pl * TH + Y) * TW + X, in ? g : 0.0f);
@@ -556,7 +556,8 @@ static int tile_args(TileArgs& a, int B, int C, int H, int W, int fh, int fw) {
     if (B <= 0 || C <= 0 || H < 2 || W < 2 || fh <= 0 || fw <= 0) return HS_ERR_BAD_ARG;
     if (H % fh || W % fw) return HS_ERR_NOT_DIVISIBLE;
     if ((long)B * C > 65535) return HS_ERR_UNSUPPORTED;
-    a = TileArgs{B, C, H, W, fh, fw, H / fh, W / fw};
+    a = TileArgs{B, C, H, W, fh, fw, H / fh, W / fw, 1.0f / (float)(H / fh), 1.0f / (float)(W / fw), 1.0f / (float)(H / fh + 2), 1.0f / (float)(W / fw + 2)};
+    if (H + 2 * fh >= (1 << 21) || W + 2 * fw >= (1 << 21)) return HS_ERR_UNSUPPORTED;          // div_by_inv's range
     return HS_OK;
 }
 

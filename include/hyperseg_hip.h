@@ -396,6 +396,18 @@ int hs_tile_interior_fwd(int32_t dtype, const void* tiled, int32_t batch, int32_
                          int32_t fw, void* y, void* stream);
 int hs_tile_interior_bwd(int32_t dtype, const void* dy, int32_t batch, int32_t channels, int32_t H, int32_t W, int32_t fh, int32_t fw,
                          void* dtiled, void* stream);
+/* The middle layer of that block as the reference states it -- a VALID depthwise 3 x 3 of every halo tile with the patch's own taps
+ * (hyperseg_v1_0.py:352-360: F.conv2d on the unfolded, padded patches with padding 0): tile image (B, C, fh (ph+2), fw (pw+2)) -> (B, C, H, W)
+ * in one launch, its two adjoints in one launch each.  Replaces hs_patch_conv_plain_* (k = 3, zero padding, on the whole tile image) +
+ * hs_tile_interior_*: no ring outputs, no intermediate.  bank / dbank: fp32 (P, ld) with the taps of channel c at columns [9 c, 9 c + 9)
+ * (the depthwise range of the block's bank: pass bank + r1); dtype = hs_dtype of the activations.  Even patch widths only
+ * (HS_ERR_UNSUPPORTED otherwise: the caller keeps the two-launch route).  autograd.DwTilesValid. */
+int hs_dw_tiles_fwd(int32_t dtype, const void* tiled, const float* bank, int64_t ld, int32_t batch, int32_t channels, int32_t H, int32_t W,
+                    int32_t fh, int32_t fw, void* y, void* stream);
+int hs_dw_tiles_bwd_in(int32_t dtype, const void* dy, const float* bank, int64_t ld, int32_t batch, int32_t channels, int32_t H, int32_t W,
+                       int32_t fh, int32_t fw, void* dtiled, void* stream);
+int hs_dw_tiles_bwd_w(int32_t dtype, const void* tiled, const void* dy, int32_t batch, int32_t channels, int32_t H, int32_t W, int32_t fh,
+                      int32_t fw, float* dbank, int64_t ld, void* stream);
 /* The per-image reduction of hyperseg/losses/bootstrapped_ce_loss.py:19-25 over n non-negative f32 losses, with no sort and no host
  * read: if more than k losses exceed thresh, their mean; otherwise the mean of the k largest (the k-th largest found by a three-level
  * radix histogram of the bit patterns; ties at it share the remaining weight).  out5 = {loss, branch, 1/count, t, tie weight}: the

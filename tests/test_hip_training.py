@@ -40,6 +40,8 @@ def dev():
     dict(cin=44, cout=44, k=3, groups=44, mode='zeros', b=2, grid=(2, 3), patch=(18, 18)),
     dict(cin=7, cout=7, k=3, groups=7, mode='zeros', b=1, grid=(3, 2), patch=(10, 10)),
     dict(cin=5, cout=5, k=3, groups=5, mode='zeros', b=2, grid=(1, 1), patch=(5, 70)),       # one patch, wider than a wave's 64 columns
+    dict(cin=6, cout=6, k=3, groups=6, mode='zeros', b=1, grid=(2, 3), patch=(6, 7)),        # odd width: the one-element-per-thread kernels
+    dict(cin=3, cout=3, k=3, groups=3, mode='zeros', b=2, grid=(3, 5), patch=(4, 2)),        # a pair IS a tile row: both neighbours in other patches
 ])
 def test_patch_conv_gradients_vs_oracle(dev, case):
     from oracle import hyperseg_oracle as O
@@ -346,6 +348,39 @@ def test_pixel_cross_entropy_vs_torch(dev, shape, ignore):
     (lb * r).sum().backward()
     assert float((lb - la).abs().max()) < 1e-5 and bool((lb[t == ignore] == 0).all())
     assert rel_err(xb.grad.cpu(), xa.grad.cpu()) < 1e-6
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(2, 5, (3, 4), (16, 16)), (1, 44, (2, 3), (8, 8)), (2, 3, (3, 5), (5, 2)), (1, 7, (1, 1), (3, 70)), (2, 4, (2, 2), (1, 6))])
+def test_dw_tiles_valid_vs_two_launch_route(dev, shape, dtype):
+    """hs_dw_tiles_fwd / _bwd_in / _bwd_w (autograd.DwTilesValid: the valid depthwise 3x3 of every halo tile) against the route it replaces --
+    the zero-padded depthwise patch convolution over the whole tile image + TileInterior: the kept outputs and the input gradient are
+    bit-identical (same fma chains; the ring's gradient is zero by construction), the tap gradient sums in another order (1e-5; bf16: one
+    rounding of products that are exact in f32, the same tolerance).  And against the reference's own statement: F.conv2d with padding 0 on
+    the unfolded tiles, groups = B * patches * C."""
+    import torch.nn.functional as F
+    from hyperseg_amd import autograd as HA
+    b, c, (fh, fw), (ph, pw) = shape
+    h, w = fh * ph, fw * pw
+    g = torch.Generator().manual_seed(c + ph)
+    t = torch.randn(b, c, fh * (ph + 2), fw * (pw + 2), generator=g).to(dev).to(dtype)
+    bank = (torch.randn(b * fh * fw, 9 * c + 5, generator=g) * 0.3).to(dev)
+    r = torch.randn(b, c, h, w, generator=g).to(dev).to(dtype)
+    ta, ka = t.clone().requires_grad_(True), bank.clone().requires_grad_(True)
+    ya = HA.DwTilesValid.apply(ta, ka[:, 2:2 + 9 * c], (h, w), (fh, fw))
+    ya.backward(r)
+    tb, kb = t.clone().requires_grad_(True), bank.clone().requires_grad_(True)
+    yb = HA.TileInterior.apply(HA.patch_conv_apply(tb, kb[:, 2:2 + 9 * c], (fh, fw), c, 3, 1, 'zeros', c), (h, w), (fh, fw))
+    yb.backward(r)
+    assert ya.dtype == dtype and torch.equal(ya, yb)
+    assert torch.equal(ta.grad, tb.grad)
+    assert rel_err(ka.grad.cpu(), kb.grad.cpu()) < 1e-5
+    assert bool((ka.grad[:, :2] == 0).all()) and bool((ka.grad[:, 2 + 9 * c:] == 0).all())
+    if dtype == torch.float32:                                      # the reference statement on the CPU
+        tiles = t.cpu().reshape(b, c, fh, ph + 2, fw, pw + 2).permute(0, 2, 4, 1, 3, 5).reshape(1, b * fh * fw * c, ph + 2, pw + 2)
+        kern = bank.cpu()[:, 2:2 + 9 * c].reshape(b * fh * fw * c, 1, 3, 3)
+        want = F.conv2d(tiles, kern, padding=0, groups=b * fh * fw * c).reshape(b, fh, fw, c, ph, pw).permute(0, 3, 1, 4, 2, 5).reshape(b, c, h, w)
+        assert rel_err(ya.detach().cpu(), want) < 1e-5
 
 
 def test_bf16_storage_twins_round_the_fp32_kernels_once(dev):
