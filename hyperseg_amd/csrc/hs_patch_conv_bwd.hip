@@ -161,7 +161,7 @@ void patch_conv_bwd_weight_k1m_kernel(ConvBwdArgs a) {
     const int npix = a.ph * a.pw, nch = (npix + 15) >> 4;                // chunks of 16 pixels in patch-linear order
     auto fetch = [&](int s, bw_f32x4 (&av)[MT], bw_f32x4 (&bv)[NTI]) {
         if constexpr (VEC) {
-            const int l = 16 * s + 4 * kg, u = l / a.pw, v = l - u * a.pw;   // pw % 4 == 0: the lane's 4 pixels are one row segment
+            const int l = 16 * s + 4 * kg, u = div_by_inv(l, a.inv_pw), v = l - u * a.pw;   // pw % 4 == 0: the lane's 4 pixels are one row segment
             const size_t off = (size_t)u * a.W + v;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const bw_f32x4*>((const float*)dyp[mt] + off);
@@ -170,7 +170,7 @@ void patch_conv_bwd_weight_k1m_kernel(ConvBwdArgs a) {
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int l = 16 * s + 4 * kg + j, lc = min(l, npix - 1), u = lc / a.pw, v = lc - u * a.pw;
+                const int l = 16 * s + 4 * kg + j, lc = min(l, npix - 1), u = div_by_inv(lc, a.inv_pw), v = lc - u * a.pw;
                 const size_t off = (size_t)u * a.W + v;
                 const float live = l < npix ? 1.0f : 0.0f;               // clamped address, masked by a multiply (no branch around a load)
 #pragma unroll
@@ -243,7 +243,7 @@ void patch_conv_bwd_input_k1m_kernel(ConvBwdArgs a) {
     T* __restrict__ dxb = (T*)a.dx + (size_t)b * a.cin * plane + org;
     const int npix = a.ph * a.pw, ntile = (npix + 15) >> 4;
     auto fetch = [&](int t, float (&bv)[KQ][4], size_t& off) {
-        const int l = min(16 * t + n, npix - 1), u = l / a.pw, v = l - u * a.pw;     // past the patch: a live pixel, not stored
+        const int l = min(16 * t + n, npix - 1), u = div_by_inv(l, a.inv_pw), v = l - u * a.pw;     // past the patch: a live pixel, not stored
         off = (size_t)u * a.W + v;
 #pragma unroll
         for (int q = 0; q < KQ; ++q)
@@ -316,7 +316,7 @@ void patch_conv_fwd_k1m_kernel(ConvBwdArgs a, const float* __restrict__ scale, c
     T* __restrict__ yb = (T*)a.dx + (size_t)b * a.cout * plane + org;
     const int npix = a.ph * a.pw, ntile = (npix + 15) >> 4;
     auto fetch = [&](int t, float (&bv)[KQ][4], size_t& off) {
-        const int l = min(16 * t + n, npix - 1), u = l / a.pw, v = l - u * a.pw;
+        const int l = min(16 * t + n, npix - 1), u = div_by_inv(l, a.inv_pw), v = l - u * a.pw;
         off = (size_t)u * a.W + v;
 #pragma unroll
         for (int q = 0; q < KQ; ++q)
@@ -515,6 +515,43 @@ void patch_dw3_bwd_weight_kernel(ConvBwdArgs a) {
     for (int t = 0; t < 9; ++t) {
         const float s = wave_sum64(acc[t]);
         if (lane == 0) dst[t] = s;
+    }
+}
+
+// dX of a k = 1, groups = 1 layer on patches of fewer than 16 pixels (levels 0 and 1 of a v1_0 decoder: 1 and 4 pixels): one workgroup per
+// patch, a lane owns an input channel c and reads W[o][c] for o = 0 .. cout - 1 -- consecutive lanes, consecutive addresses -- against the
+// patch's dY[o][px] (the same address in every lane: one broadcast load).  The element-wise kernel at the top of this file walked the bank
+// with a stride of cin per thread and divided twice per element: 24.7 us for the 7.8 MB bank of config 5's level 1.
+template <typename T>
+__global__ __launch_bounds__(128)
+void patch_conv_bwd_input_tiny_kernel(ConvBwdArgs a) {
+    const int patch = blockIdx.x;
+    const int pj = patch % a.fw, pi = (patch / a.fw) % a.fh, b = patch / (a.fw * a.fh);
+    const size_t plane = (size_t)a.H * a.W;
+    const size_t org = (size_t)(pi * a.ph) * a.W + pj * a.pw;
+    const int npix = a.ph * a.pw;                                        // <= 15
+    const float* __restrict__ wp = a.bank + (size_t)patch * a.ld;
+    const T* __restrict__ dyb = (const T*)a.dy + (size_t)b * a.cout * plane + org;
+    T* __restrict__ dxb = (T*)a.dx + (size_t)b * a.cin * plane + org;
+    int off[15];
+#pragma unroll
+    for (int q = 0; q < 15; ++q) {
+        const int l = min(q, npix - 1), u = div_by_inv(l, a.inv_pw), v = l - u * a.pw;
+        off[q] = u * a.W + v;
+    }
+    for (int c = threadIdx.x; c < a.cin; c += 128) {
+        float acc[15];
+#pragma unroll
+        for (int q = 0; q < 15; ++q) acc[q] = 0.0f;
+        for (int o = 0; o < a.cout; ++o) {
+            const float w = wp[(size_t)o * a.cin + c];
+#pragma unroll
+            for (int q = 0; q < 15; ++q)
+                if (q < npix) acc[q] = fmaf(w, Store<T>::ld(dyb, (size_t)o * plane + off[q]), acc[q]);      // (uniform condition)
+        }
+#pragma unroll
+        for (int q = 0; q < 15; ++q)
+            if (q < npix) Store<T>::st(dxb, (size_t)c * plane + off[q], acc[q]);
     }
 }
 
@@ -772,7 +809,13 @@ int hs::try_fast_bwd_in(int dtype, const void* dy, const void* bank, long ld, in
                      hipLaunchKernelGGL((patch_dw3_kernel<1, bf16_t>), grid, dim3(256), 0, stream, a, (const bf16_t*)dy, (bf16_t*)dx));
         return launch_status();
     }
-    if (k != 1 || groups != 1 || a.ph * a.pw < 16) return 1;
+    if (k == 1 && groups == 1 && a.ph * a.pw < 16) {
+        const dim3 gridt((unsigned)(batch * fh * fw));
+        HS_T2(dtype, hipLaunchKernelGGL(patch_conv_bwd_input_tiny_kernel<float>, gridt, dim3(128), 0, stream, a),
+                     hipLaunchKernelGGL(patch_conv_bwd_input_tiny_kernel<bf16_t>, gridt, dim3(128), 0, stream, a));
+        return launch_status();
+    }
+    if (k != 1 || groups != 1) return 1;
     const int ct = (c_in + 15) / 16, kq = (c_out + 15) / 16;
     const dim3 grid((unsigned)(batch * fh * fw));
 #define HS_BI(CTV, KQV) if (ct == CTV && kq == KQV) { \

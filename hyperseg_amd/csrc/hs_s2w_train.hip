@@ -42,7 +42,7 @@ struct StArgs {
 // MODE 0: dW tile = rows [n0, n0 + 64) of group g, reduction over the patches.   A[i][j] = dBank[patch i][row j], B[i][k] = S[patch i][k]
 // MODE 1: dS tile = patches [p0, p0 + 64) of group g, reduction over the group's rows.  A[i][j] = dBank[patch j][row i], B[i][k] = W[row i][k]
 template <int MODE>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256)         // (a minimum-occupancy hint of 3 or 4 makes the register allocator spill the 36 loads in flight)
 void s2w_train_bwd_kernel(StArgs a) {
     const __attribute__((address_space(4))) StArgs* ka = (const __attribute__((address_space(4))) StArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     const int wg = (int)blockIdx.x;
@@ -87,7 +87,9 @@ void s2w_train_bwd_kernel(StArgs a) {
                 const int p = MODE == 0 ? c0 + hi + 4 * q : out0 + hi + 4 * q;
                 const int r = MODE == 0 ? out0 + lo : c0 + lo;
                 const int n = min(g * rpg + min(r, rpg - 1), rows - 1);
-                av16[q] = dbank[(size_t)min(p, P - 1) * ld + n];
+                // 32-bit element offsets from the layer's (uniform) base: one address register per load in flight instead of two
+                // (P ld < 2^31 is checked on the host), which is what keeps 36 loads in flight under 128 VGPRs
+                av16[q] = dbank[(unsigned)(min(p, P - 1) * (int)ld + n)];
             }
         }
         // ---- B
@@ -95,9 +97,9 @@ void s2w_train_bwd_kernel(StArgs a) {
         if (MODE == 0) {                                              // S[patch c0 + lo][k]: consecutive lanes = consecutive patches
             const int p = min(c0 + lo, P - 1);
             const int bb = p / grid_sz, ij = p - bb * grid_sz;
-            const float* sp = signal + ((size_t)bb * c_signal + sidx + g * K) * grid_sz + ij;
+            const unsigned so = (unsigned)((bb * c_signal + sidx + g * K) * grid_sz + ij);          // (B c_signal grid < 2^31: st_check)
 #pragma unroll
-            for (int q = 0; q < 20; ++q) bv20[q] = sp[(size_t)min(hi + 4 * q, K - 1) * grid_sz];
+            for (int q = 0; q < 20; ++q) bv20[q] = signal[so + (unsigned)(min(hi + 4 * q, K - 1) * grid_sz)];
         }
         __builtin_amdgcn_sched_barrier(0);                            // all of the chunk's global loads are in flight before the first LDS store
 #pragma unroll
@@ -243,6 +245,7 @@ static int st_check(const float* signal, int batch, int c_signal, int fh, int fw
         if (l.signal_index < 0 || l.signal_channels <= 0 || l.signal_index + l.signal_channels > c_signal) return HS_ERR_BAD_ARG;
         if (l.signal_channels % l.groups != 0 || l.wc % l.groups != 0) return HS_ERR_BAD_ARG;
         if (l.signal_channels / l.groups > ST_KMAX) return HS_ERR_UNSUPPORTED;
+        if ((size_t)batch * fh * fw * (size_t)l.ld >= (1ull << 31)) return HS_ERR_UNSUPPORTED;      // 32-bit element offsets into dBank
     }
     return HS_OK;
 }

@@ -49,18 +49,41 @@ __device__ __forceinline__ int tile_sources(int y, int n, int p, float inv_p, in
     return cnt;
 }
 
+// the same list for patches of >= 2 rows, without the search: the own tile always; the tile above / below when y is the patch's first / last
+// row (tiles overlap by their rings); the image's reflections (padded row -1 = row 1, padded row n = row n - 2) in the first / last tile
+__device__ __forceinline__ int tile_sources_p2(int y, int n, int p, float inv_p, int f, int (&tpos)[3]) {
+    const int i = div_by_inv(y, inv_p), u = y - i * p;
+    int cnt = 0;
+    tpos[cnt++] = i * (p + 2) + u + 1;
+    if (u == 0 && i > 0) tpos[cnt++] = (i - 1) * (p + 2) + p + 1;
+    if (u == p - 1 && i + 1 < f) tpos[cnt++] = (i + 1) * (p + 2);
+    if (y == 1) tpos[cnt++] = 0;
+    if (y == n - 2) tpos[cnt++] = (f - 1) * (p + 2) + p + 1;
+    return cnt;                                                         // <= 3: y == 1 or n - 2 is a first / last row only when p == 2, f == 1
+}
+
 template <typename T>
 __global__ __launch_bounds__(256)
 void halo_tiles_bwd_kernel(TileArgs a, const T* __restrict__ dt, T* __restrict__ dx) {
     const int TW = a.fw * (a.pw + 2), TH = a.fh * (a.ph + 2);
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= a.W || y >= a.H) return;
-    int ys[9], xs[9];
-    const int ny = tile_sources(y, a.H, a.ph, a.inv_ph, a.fh, ys), nx = tile_sources(x, a.W, a.pw, a.inv_pw, a.fw, xs);
     const size_t pl = blockIdx.z;
     float acc = 0.0f;
-    for (int p = 0; p < ny; ++p)
-        for (int q = 0; q < nx; ++q) acc += Store<T>::ld(dt, (pl * TH + ys[p]) * TW + xs[q]);
+    if (a.ph >= 3 && a.pw >= 3) {                                       // (uniform) at most 2 x 2 sources... 3 with a reflection: no search, no division
+        int ys[3], xs[3];
+        const int ny = tile_sources_p2(y, a.H, a.ph, a.inv_ph, a.fh, ys), nx = tile_sources_p2(x, a.W, a.pw, a.inv_pw, a.fw, xs);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                if (p < ny && q < nx) acc += Store<T>::ld(dt, (pl * TH + ys[p]) * TW + xs[q]);
+    } else {
+        int ys[9], xs[9];
+        const int ny = tile_sources(y, a.H, a.ph, a.inv_ph, a.fh, ys), nx = tile_sources(x, a.W, a.pw, a.inv_pw, a.fw, xs);
+        for (int p = 0; p < ny; ++p)
+            for (int q = 0; q < nx; ++q) acc += Store<T>::ld(dt, (pl * TH + ys[p]) * TW + xs[q]);
+    }
     Store<T>::st(dx, (pl * a.H + y) * a.W + x, acc);
 }
 
@@ -433,7 +456,9 @@ void bank_unpack_kernel(const float* __restrict__ bank, long ld, int hp_total, i
 // pixel are HW floats apart, so a wave reads C coalesced rows.  loss = log(sum exp(x - max)) + max - x[t]; ignored labels give 0 and
 // no gradient; d x[c] = (softmax[c] - [c == t]) * g.
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <bool BWD, typename T>
+// CF: the class count at compile time (12 CamVid, 19 Cityscapes, 21 VOC: the reference's datasets) -- a pixel's logits are then loaded ONCE
+// into registers, all in flight together, instead of three dependent passes over them (max, sum, result); 0 = any count, the three passes.
+template <bool BWD, typename T, int CF>
 __global__ __launch_bounds__(256)
 void cross_entropy_kernel(const T* __restrict__ x, const long long* __restrict__ target, int C, long hw, long total, long long ignore_index,
                           const float* __restrict__ g, void* __restrict__ out_) {
@@ -442,18 +467,51 @@ void cross_entropy_kernel(const T* __restrict__ x, const long long* __restrict__
         const T* __restrict__ xp = x + n * C * hw + p;
         const long long t = target[e];
         const bool live = t != ignore_index && t >= 0 && t < C;
-        float m = Store<T>::ld(xp, 0);
-        for (int c = 1; c < C; ++c) m = fmaxf(m, Store<T>::ld(xp, (long)c * hw));
-        float sum = 0.0f;
-        for (int c = 0; c < C; ++c) sum += expf(Store<T>::ld(xp, (long)c * hw) - m);
-        if (!BWD) {
-            ((float*)out_)[e] = live ? (logf(sum) + m) - Store<T>::ld(xp, (long)(live ? t : 0) * hw) : 0.0f;
+        if constexpr (CF > 0) {
+            float v[CF];
+#pragma unroll
+            for (int c = 0; c < CF; ++c) v[c] = Store<T>::ld(xp, (long)c * hw);
+            const float gi = BWD ? g[e] : 0.0f;
+            float m = v[0];
+#pragma unroll
+            for (int c = 1; c < CF; ++c) m = fmaxf(m, v[c]);
+            float sum = 0.0f, xt = 0.0f;
+#pragma unroll
+            for (int c = 0; c < CF; ++c) {
+                sum += expf(v[c] - m);
+                xt = (c == (int)t) ? v[c] : xt;
+            }
+            if constexpr (!BWD) {
+                ((float*)out_)[e] = live ? (logf(sum) + m) - xt : 0.0f;
+            } else {
+                T* __restrict__ dp = (T*)out_ + n * C * hw + p;
+                const float gl = live ? gi : 0.0f, inv = 1.0f / sum;
+#pragma unroll
+                for (int c = 0; c < CF; ++c) Store<T>::st(dp, (long)c * hw, (expf(v[c] - m) * inv - (c == (int)t ? 1.0f : 0.0f)) * gl);
+            }
         } else {
-            T* __restrict__ dp = (T*)out_ + n * C * hw + p;
-            const float gi = live ? g[e] : 0.0f, inv = 1.0f / sum;
-            for (int c = 0; c < C; ++c) Store<T>::st(dp, (long)c * hw, (expf(Store<T>::ld(xp, (long)c * hw) - m) * inv - (c == (int)t ? 1.0f : 0.0f)) * gi);
+            float m = Store<T>::ld(xp, 0);
+            for (int c = 1; c < C; ++c) m = fmaxf(m, Store<T>::ld(xp, (long)c * hw));
+            float sum = 0.0f;
+            for (int c = 0; c < C; ++c) sum += expf(Store<T>::ld(xp, (long)c * hw) - m);
+            if constexpr (!BWD) {
+                ((float*)out_)[e] = live ? (logf(sum) + m) - Store<T>::ld(xp, (long)(live ? t : 0) * hw) : 0.0f;
+            } else {
+                T* __restrict__ dp = (T*)out_ + n * C * hw + p;
+                const float gi = live ? g[e] : 0.0f, inv = 1.0f / sum;
+                for (int c = 0; c < C; ++c) Store<T>::st(dp, (long)c * hw, (expf(Store<T>::ld(xp, (long)c * hw) - m) * inv - (c == (int)t ? 1.0f : 0.0f)) * gi);
+            }
         }
     }
+}
+
+template <bool BWD, typename T>
+static void launch_cross_entropy(dim3 blocks, hipStream_t s, const T* x, const long long* target, int C, long hw, long total, long long ignore_index,
+                                 const float* g, void* out) {
+    if (C == 12) hipLaunchKernelGGL((cross_entropy_kernel<BWD, T, 12>), blocks, dim3(256), 0, s, x, target, C, hw, total, ignore_index, g, out);
+    else if (C == 19) hipLaunchKernelGGL((cross_entropy_kernel<BWD, T, 19>), blocks, dim3(256), 0, s, x, target, C, hw, total, ignore_index, g, out);
+    else if (C == 21) hipLaunchKernelGGL((cross_entropy_kernel<BWD, T, 21>), blocks, dim3(256), 0, s, x, target, C, hw, total, ignore_index, g, out);
+    else hipLaunchKernelGGL((cross_entropy_kernel<BWD, T, 0>), blocks, dim3(256), 0, s, x, target, C, hw, total, ignore_index, g, out);
 }
 
 }  // namespace hs
@@ -657,11 +715,11 @@ extern "C" int hs_cross_entropy_typed_fwd(int32_t dtype, const void* logits, con
     const long total = (long)batch * pixels;
     const dim3 blocks((unsigned)((total + 255) / 256 > 65535 * 16 ? 65535 * 16 : (total + 255) / 256));
     if (dtype == HS_DTYPE_F32)
-        hipLaunchKernelGGL((cross_entropy_kernel<false, float>), blocks, dim3(256), 0, (hipStream_t)stream, (const float*)logits, (const long long*)target,
-                           classes, (long)pixels, total, (long long)ignore_index, (const float*)nullptr, (void*)loss);
+        launch_cross_entropy<false, float>(blocks, (hipStream_t)stream, (const float*)logits, (const long long*)target, classes, (long)pixels, total,
+                                           (long long)ignore_index, nullptr, (void*)loss);
     else
-        hipLaunchKernelGGL((cross_entropy_kernel<false, bf16_t>), blocks, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, (const long long*)target,
-                           classes, (long)pixels, total, (long long)ignore_index, (const float*)nullptr, (void*)loss);
+        launch_cross_entropy<false, bf16_t>(blocks, (hipStream_t)stream, (const bf16_t*)logits, (const long long*)target, classes, (long)pixels, total,
+                                            (long long)ignore_index, nullptr, (void*)loss);
     return launch_status();
 }
 
@@ -672,11 +730,11 @@ extern "C" int hs_cross_entropy_typed_bwd(int32_t dtype, const void* logits, con
     const long total = (long)batch * pixels;
     const dim3 blocks((unsigned)((total + 255) / 256 > 65535 * 16 ? 65535 * 16 : (total + 255) / 256));
     if (dtype == HS_DTYPE_F32)
-        hipLaunchKernelGGL((cross_entropy_kernel<true, float>), blocks, dim3(256), 0, (hipStream_t)stream, (const float*)logits, (const long long*)target,
-                           classes, (long)pixels, total, (long long)ignore_index, grad_loss, grad_logits);
+        launch_cross_entropy<true, float>(blocks, (hipStream_t)stream, (const float*)logits, (const long long*)target, classes, (long)pixels, total,
+                                          (long long)ignore_index, grad_loss, grad_logits);
     else
-        hipLaunchKernelGGL((cross_entropy_kernel<true, bf16_t>), blocks, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, (const long long*)target,
-                           classes, (long)pixels, total, (long long)ignore_index, grad_loss, grad_logits);
+        launch_cross_entropy<true, bf16_t>(blocks, (hipStream_t)stream, (const bf16_t*)logits, (const long long*)target, classes, (long)pixels, total,
+                                           (long long)ignore_index, grad_loss, grad_logits);
     return launch_status();
 }
 
