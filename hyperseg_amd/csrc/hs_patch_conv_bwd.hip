@@ -525,6 +525,7 @@ void patch_dw3_bwd_weight_kernel(ConvBwdArgs a) {
 template <typename T>
 __global__ __launch_bounds__(128)
 void patch_conv_bwd_input_tiny_kernel(ConvBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float tiny_dy[];     // [cout][16]: the patch's dY, zero past its pixels
     const int patch = blockIdx.x;
     const int pj = patch % a.fw, pi = (patch / a.fw) % a.fh, b = patch / (a.fw * a.fh);
     const size_t plane = (size_t)a.H * a.W;
@@ -533,25 +534,39 @@ void patch_conv_bwd_input_tiny_kernel(ConvBwdArgs a) {
     const float* __restrict__ wp = a.bank + (size_t)patch * a.ld;
     const T* __restrict__ dyb = (const T*)a.dy + (size_t)b * a.cout * plane + org;
     T* __restrict__ dxb = (T*)a.dx + (size_t)b * a.cin * plane + org;
-    int off[15];
-#pragma unroll
-    for (int q = 0; q < 15; ++q) {
-        const int l = min(q, npix - 1), u = div_by_inv(l, a.inv_pw), v = l - u * a.pw;
-        off[q] = u * a.W + v;
+    for (int e = threadIdx.x; e < a.cout * 16; e += 128) {
+        const int o = e >> 4, q = e & 15, l = min(q, npix - 1), u = div_by_inv(l, a.inv_pw), v = l - u * a.pw;
+        const float val = Store<T>::ld(dyb, (size_t)o * plane + (size_t)u * a.W + v);
+        tiny_dy[e] = q < npix ? val : 0.0f;
     }
+    __syncthreads();
     for (int c = threadIdx.x; c < a.cin; c += 128) {
-        float acc[15];
+        float acc[16];
 #pragma unroll
-        for (int q = 0; q < 15; ++q) acc[q] = 0.0f;
-        for (int o = 0; o < a.cout; ++o) {
-            const float w = wp[(size_t)o * a.cin + c];
+        for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+        for (int o0 = 0; o0 < a.cout; o0 += 8) {                         // eight weight loads in flight, dY broadcast from LDS
+            float w[8];
 #pragma unroll
-            for (int q = 0; q < 15; ++q)
-                if (q < npix) acc[q] = fmaf(w, Store<T>::ld(dyb, (size_t)o * plane + off[q]), acc[q]);      // (uniform condition)
+            for (int j = 0; j < 8; ++j) w[j] = wp[(size_t)min(o0 + j, a.cout - 1) * a.cin + c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (o0 + j < a.cout) {                                   // (uniform)
+                    const bw_f32x4* d4 = reinterpret_cast<const bw_f32x4*>(tiny_dy + 16 * (o0 + j));
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const bw_f32x4 d = d4[g];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[4 * g + r] = fmaf(w[j], d[r], acc[4 * g + r]);
+                    }
+                }
+            }
         }
 #pragma unroll
         for (int q = 0; q < 15; ++q)
-            if (q < npix) Store<T>::st(dxb, (size_t)c * plane + off[q], acc[q]);
+            if (q < npix) {
+                const int u = div_by_inv(q, a.inv_pw), v = q - u * a.pw;
+                Store<T>::st(dxb, (size_t)c * plane + (size_t)u * a.W + v, acc[q]);
+            }
     }
 }
 
@@ -809,10 +824,10 @@ int hs::try_fast_bwd_in(int dtype, const void* dy, const void* bank, long ld, in
                      hipLaunchKernelGGL((patch_dw3_kernel<1, bf16_t>), grid, dim3(256), 0, stream, a, (const bf16_t*)dy, (bf16_t*)dx));
         return launch_status();
     }
-    if (k == 1 && groups == 1 && a.ph * a.pw < 16) {
+    if (k == 1 && groups == 1 && a.ph * a.pw < 16 && c_out <= 1024) {
         const dim3 gridt((unsigned)(batch * fh * fw));
-        HS_T2(dtype, hipLaunchKernelGGL(patch_conv_bwd_input_tiny_kernel<float>, gridt, dim3(128), 0, stream, a),
-                     hipLaunchKernelGGL(patch_conv_bwd_input_tiny_kernel<bf16_t>, gridt, dim3(128), 0, stream, a));
+        HS_T2(dtype, hipLaunchKernelGGL(patch_conv_bwd_input_tiny_kernel<float>, gridt, dim3(128), (size_t)c_out * 64, stream, a),
+                     hipLaunchKernelGGL(patch_conv_bwd_input_tiny_kernel<bf16_t>, gridt, dim3(128), (size_t)c_out * 64, stream, a));
         return launch_status();
     }
     if (k != 1 || groups != 1) return 1;

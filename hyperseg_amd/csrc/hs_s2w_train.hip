@@ -132,6 +132,10 @@ void s2w_train_bwd_kernel(StArgs a) {
         //      (the vector form read B as broadcast float4s: 6 LDS instructions per step, and the launch was LDS-bound -- 54 / 80 us).
         //      Mode 0: D[row j][k] (lanes along k: dW's rows are contiguous in k); mode 1: the operands swapped, D[k][patch j] (lanes along
         //      the patches: d signal is contiguous in them).
+        // a wave whose 16 rows (mode 0) / patches (mode 1) lie past the group's rows / the last patch has nothing to accumulate: the f32 matrix
+        // instruction occupies the SIMD's FMA lanes for ~38 cycles, and the launch is bound by their number (phase-removal variants of
+        // tools/build_variants.py, visit r4w: 59.7 us with, 25.8 us without the products; loads and stores each within 1 us of nothing)
+        if (out0 + 16 * hi >= (MODE == 0 ? rpg : P)) continue;          // (wave-uniform; the barriers are at the top of the chunk loop)
         for (int q = 0; q < ST_TILE / 4; ++q) {
             const float av = A[(4 * q + kk) * ST_APAD + 16 * hi + l16];
 #pragma unroll

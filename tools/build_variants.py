@@ -95,6 +95,12 @@ PATCHES = {
     'dwtile_all': [('    if (in_scale && (nplanes >= 8192 || k == 5) && threads == 256', '    if (in_scale && nplanes >= 1 && threads == 256')],
     'up_plainstore': [('        __builtin_nontemporal_store(v4f{o0[0], o0[1], o0[2], o0[3]}, reinterpret_cast<v4f*>(dst));\n        __builtin_nontemporal_store(v4f{o1[0], o1[1], o1[2], o1[3]}, reinterpret_cast<v4f*>(dst + Wo));',
                        '        *reinterpret_cast<v4f*>(dst) = v4f{o0[0], o0[1], o0[2], o0[3]};\n        *reinterpret_cast<v4f*>(dst + Wo) = v4f{o1[0], o1[1], o1[2], o1[3]};')],
+    # round 4: where do the 60 us of s2w_train_bwd_kernel<0> go?  one phase removed per variant (results are wrong: timing only)
+    's2wt_noA': [('av16[q] = dbank[(unsigned)(min(p, P - 1) * (int)ld + n)];', 'av16[q] = (float)n;')],
+    's2wt_noB': [('for (int q = 0; q < 20; ++q) bv20[q] = signal[so + (unsigned)(min(hi + 4 * q, K - 1) * grid_sz)];', 'for (int q = 0; q < 20; ++q) bv20[q] = (float)(so + q);')],
+    's2wt_nomfma': [('''                    acc[t] = MODE == 0 ? __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[t], 0, 0, 0);''', '                    acc[t][0] += av * bv;')],
+    's2wt_nostore': [('if (t < KT && k < K) dw[(size_t)n * K + k] = acc[t][r];', 'if (t < KT && k < K && acc[t][r] == 12345.0f) dw[(size_t)n * K + k] = acc[t][r];')],
     'ntstore': [(STORE_LINE, '                for (int jt = 0; jt < J3; ++jt) __builtin_nontemporal_store(fmaf(acc3[m][jt][r], sc, sh), &yo[yoff[jt]]);')],
 }
 
@@ -127,6 +133,10 @@ VARIANTS = {
     'irc_wide_store': dict(flags=['-DHS_IRC_WIDE_STORE'], extra=[], patch=None),         # round 4: the level-4 epilogue re-laid through LDS into 16-byte stores (measured slower)
     'irc_nw8': dict(flags=['-DHS_IRC_NW=8'], extra=[], patch=None),                      # round 4: eight waves per 16 x 16 region (four per SIMD at two workgroups per CU)
     'irc_r3': dict(flags=[], extra=[], patch='irc_r3', file='hs_patch_irc.hip'),          # round 3's level-4 kernel
+    's2wt_noA': dict(flags=[], extra=[], patch='s2wt_noA', file='hs_s2w_train.hip'),
+    's2wt_noB': dict(flags=[], extra=[], patch='s2wt_noB', file='hs_s2w_train.hip'),
+    's2wt_nomfma': dict(flags=[], extra=[], patch='s2wt_nomfma', file='hs_s2w_train.hip'),
+    's2wt_nostore': dict(flags=[], extra=[], patch='s2wt_nostore', file='hs_s2w_train.hip'),
 }
 
 def r3_irc_source():
