@@ -39,6 +39,27 @@ struct StArgs {
     StLayer layer[S2W_MAX_LAYERS];
 };
 
+// acc[t] += A^T B over one staged chunk of 64 reduction steps, KTV 16-wide tiles along K: operands of four steps requested from LDS together
+template <int MODE, int KTV>
+__device__ __forceinline__ void st_products(const float* __restrict__ A, const float* __restrict__ Bm, int hi, int l16, int kk, f32x4 (&acc)[5]) {
+#pragma unroll
+    for (int q0 = 0; q0 < ST_TILE / 4; q0 += 4) {
+        float av[4], bv[4][KTV];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            av[j] = A[(4 * (q0 + j) + kk) * ST_APAD + 16 * hi + l16];
+#pragma unroll
+            for (int t = 0; t < KTV; ++t) bv[j][t] = Bm[(4 * (q0 + j) + kk) * ST_KMAX + 16 * t + l16];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < KTV; ++t)
+                acc[t] = MODE == 0 ? __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j][t], acc[t], 0, 0, 0)
+                                   : __builtin_amdgcn_mfma_f32_16x16x4f32(bv[j][t], av[j], acc[t], 0, 0, 0);
+    }
+}
+
 // MODE 0: dW tile = rows [n0, n0 + 64) of group g, reduction over the patches.   A[i][j] = dBank[patch i][row j], B[i][k] = S[patch i][k]
 // MODE 1: dS tile = patches [p0, p0 + 64) of group g, reduction over the group's rows.  A[i][j] = dBank[patch j][row i], B[i][k] = W[row i][k]
 template <int MODE>
@@ -132,20 +153,19 @@ void s2w_train_bwd_kernel(StArgs a) {
         //      (the vector form read B as broadcast float4s: 6 LDS instructions per step, and the launch was LDS-bound -- 54 / 80 us).
         //      Mode 0: D[row j][k] (lanes along k: dW's rows are contiguous in k); mode 1: the operands swapped, D[k][patch j] (lanes along
         //      the patches: d signal is contiguous in them).
-        // a wave whose 16 rows (mode 0) / patches (mode 1) lie past the group's rows / the last patch has nothing to accumulate: the f32 matrix
-        // instruction occupies the SIMD's FMA lanes for ~38 cycles, and the launch is bound by their number (phase-removal variants of
-        // tools/build_variants.py, visit r4w: 59.7 us with, 25.8 us without the products; loads and stores each within 1 us of nothing)
+        // a wave whose 16 rows (mode 0) / patches (mode 1) lie past the group's rows / the last patch has nothing to accumulate.
+        // (phase-removal variants of tools/build_variants.py, visit r4w: 59.7 us with, 25.8 us without the products; loads and stores each
+        // within 1 us of nothing)
         if (out0 + 16 * hi >= (MODE == 0 ? rpg : P)) continue;          // (wave-uniform; the barriers are at the top of the chunk loop)
-        for (int q = 0; q < ST_TILE / 4; ++q) {
-            const float av = A[(4 * q + kk) * ST_APAD + 16 * hi + l16];
-#pragma unroll
-            for (int t = 0; t < 5; ++t) {
-                if (t < KT) {
-                    const float bv = Bm[(4 * q + kk) * ST_KMAX + 16 * t + l16];
-                    acc[t] = MODE == 0 ? __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0)
-                                       : __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[t], 0, 0, 0);
-                }
-            }
+        // (KT is a property of the LAYER, so it is only known per workgroup: one straight-line body per value, chosen by a uniform switch.
+        //  With `if (t < KT)` inside the loops the compiler emitted 80 branch blocks that shuffled the accumulators between AGPRs and VGPRs
+        //  around every matrix instruction -- 5100 lines of ISA, 34 of the launch's 60 us.)
+        switch (KT) {
+            case 1: st_products<MODE, 1>(A, Bm, hi, l16, kk, acc); break;
+            case 2: st_products<MODE, 2>(A, Bm, hi, l16, kk, acc); break;
+            case 3: st_products<MODE, 3>(A, Bm, hi, l16, kk, acc); break;
+            case 4: st_products<MODE, 4>(A, Bm, hi, l16, kk, acc); break;
+            default: st_products<MODE, 5>(A, Bm, hi, l16, kk, acc); break;
         }
     }
     // ---- store (D: the lane holds rows 4 kk + r, column l16 of every tile)

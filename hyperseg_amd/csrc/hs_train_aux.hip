@@ -362,6 +362,99 @@ void bn_bwd_apply_kernel(BnArgs a, const T* __restrict__ x, const T* __restrict_
     }
 }
 
+// Small channels (B HW <= BN_SMALL_MAX = 16 x 1024 elements: the k = 1 levels at config 5) in ONE launch per direction: a workgroup of 1024
+// threads owns a channel and holds it in registers -- every load of the channel in flight at once, statistics through LDS, the result from
+// the registers.  The two-launch form costs such a layer 4 x ~5.5 us per step -- the launches' own floor -- for a few tens of KB.
+// Same shift (the channel's first element), same formulas; the sums associate differently (one workgroup instead of 32 slices).
+// (A first version that also took the 41 472-element channels of level 3, streaming them twice through one workgroup, measured 14.6 /
+// 19.3 us per launch against 2 x 6.5 / 2 x 8.5: a channel that does not fit the registers wants the 32-slice grid.)
+constexpr int BN_SMALL_PER = 16, BN_SMALL_THREADS = 1024, BN_SMALL_MAX = BN_SMALL_PER * BN_SMALL_THREADS;
+__device__ __forceinline__ void bn_block_sum2_n(float& s0, float& s1, float (*red)[2]) {       // 16 waves, summed in wave order
+    s0 = wave_sum64(s0); s1 = wave_sum64(s1);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wave][0] = s0; red[wave][1] = s1; }
+    __syncthreads();
+    float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+    for (int w = 0; w < BN_SMALL_THREADS / 64; ++w) { t0 += red[w][0]; t1 += red[w][1]; }
+    s0 = t0; s1 = t1;
+}
+// element k of this thread: e = tid + 1024 k of the channel's (batch, pixel) range; clamped index (the mask is applied by the caller)
+__device__ __forceinline__ void bn_small_index(const BnArgs& a, int c, size_t (&idx)[BN_SMALL_PER]) {
+    const int total = a.B * a.HW;
+    const float inv_hw = 1.0f / (float)a.HW;
+#pragma unroll
+    for (int k = 0; k < BN_SMALL_PER; ++k) {
+        const int e = min((int)threadIdx.x + BN_SMALL_THREADS * k, total - 1), b = div_by_inv(e, inv_hw), p = e - b * a.HW;
+        idx[k] = ((size_t)b * a.C + c) * a.HW + p;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(BN_SMALL_THREADS)
+void bn_fwd_small_kernel(BnArgs a, const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                         float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ save_mean,
+                         float* __restrict__ save_invstd, T* __restrict__ y, long long* __restrict__ counter) {
+    __shared__ float red[BN_SMALL_THREADS / 64][2];
+    const int c = blockIdx.x, total = a.B * a.HW;
+    if (counter && c == 0 && threadIdx.x == 0) *counter += 1;
+    size_t idx[BN_SMALL_PER];
+    bn_small_index(a, c, idx);
+    float v[BN_SMALL_PER];
+#pragma unroll
+    for (int k = 0; k < BN_SMALL_PER; ++k) v[k] = Store<T>::ld(x, idx[k]);
+    const float shift = Store<T>::ld(x, (size_t)c * a.HW);
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int k = 0; k < BN_SMALL_PER; ++k) {
+        const float d = ((int)threadIdx.x + BN_SMALL_THREADS * k < total) ? v[k] - shift : 0.0f;
+        s += d; q = fmaf(d, d, q);
+    }
+    bn_block_sum2_n(s, q, red);
+    const float n = (float)total;
+    const float md = s / n, var = fmaxf(q / n - md * md, 0.f), mean = md + shift, invstd = rsqrtf(var + a.eps);
+    if (threadIdx.x == 0) {
+        save_mean[c] = mean; save_invstd[c] = invstd;
+        if (running_mean) {
+            running_mean[c] = (1.f - a.momentum) * running_mean[c] + a.momentum * mean;
+            running_var[c] = (1.f - a.momentum) * running_var[c] + a.momentum * (n > 1.f ? var * n / (n - 1.f) : var);
+        }
+    }
+    const float g = gamma ? gamma[c] * invstd : invstd, bb = (beta ? beta[c] : 0.f) - mean * g;
+#pragma unroll
+    for (int k = 0; k < BN_SMALL_PER; ++k)
+        if ((int)threadIdx.x + BN_SMALL_THREADS * k < total) Store<T>::st(y, idx[k], bn_act(fmaf(v[k], g, bb), a.act));
+}
+
+template <typename T>
+__global__ __launch_bounds__(BN_SMALL_THREADS)
+void bn_bwd_small_kernel(BnArgs a, const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ gamma,
+                         const float* __restrict__ beta, const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+                         T* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float red[BN_SMALL_THREADS / 64][2];
+    const int c = blockIdx.x, total = a.B * a.HW;
+    size_t idx[BN_SMALL_PER];
+    bn_small_index(a, c, idx);
+    float xh[BN_SMALL_PER], d[BN_SMALL_PER];
+#pragma unroll
+    for (int k = 0; k < BN_SMALL_PER; ++k) { xh[k] = Store<T>::ld(x, idx[k]); d[k] = Store<T>::ld(dy, idx[k]); }
+    const float mean = save_mean[c], invstd = save_invstd[c], g = gamma ? gamma[c] : 1.f, bb = beta ? beta[c] : 0.f;
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int k = 0; k < BN_SMALL_PER; ++k) {
+        xh[k] = (xh[k] - mean) * invstd;
+        d[k] = ((int)threadIdx.x + BN_SMALL_THREADS * k < total) ? d[k] * bn_act_grad(fmaf(xh[k], g, bb), a.act) : 0.0f;
+        s += d[k]; q = fmaf(d[k], xh[k], q);
+    }
+    bn_block_sum2_n(s, q, red);
+    if (threadIdx.x == 0) { if (dgamma) dgamma[c] = q; if (dbeta) dbeta[c] = s; }
+    const float n = (float)total;
+    const float k0 = g * invstd, ms = s / n, mq = q / n;
+#pragma unroll
+    for (int k = 0; k < BN_SMALL_PER; ++k)
+        if ((int)threadIdx.x + BN_SMALL_THREADS * k < total) Store<T>::st(dx, idx[k], k0 * (d[k] - ms - xh[k] * mq));
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Adjoint of F.interpolate(x, (Ho, Wo), 'bilinear', align_corners=False): dx[yi][xi] = sum over the output pixels whose taps touch
 // (yi, xi) of their weights x dy -- a gather (no atomics): the candidate output rows / columns are those within the tap footprint,
@@ -575,6 +668,15 @@ extern "C" int hs_bn_act_train_fwd(int32_t dtype, const void* x, int32_t batch, 
     if (!x || !y || !save_mean || !save_invstd || !workspace || ((running_mean != nullptr) != (running_var != nullptr))) return HS_ERR_BAD_ARG;
     const dim3 grid(channels, BN_CHUNKS);
     hipStream_t s = (hipStream_t)stream;
+    if ((long)batch * pixels <= BN_SMALL_MAX && (dtype == HS_DTYPE_F32 || dtype == HS_DTYPE_BF16)) {            // one launch: a workgroup per channel
+        if (dtype == HS_DTYPE_F32)
+            hipLaunchKernelGGL(bn_fwd_small_kernel<float>, dim3(channels), dim3(BN_SMALL_THREADS), 0, s, a, (const float*)x, gamma, beta, running_mean,
+                               running_var, save_mean, save_invstd, (float*)y, (long long*)num_batches_tracked);
+        else
+            hipLaunchKernelGGL(bn_fwd_small_kernel<bf16_t>, dim3(channels), dim3(BN_SMALL_THREADS), 0, s, a, (const bf16_t*)x, gamma, beta, running_mean,
+                               running_var, save_mean, save_invstd, (bf16_t*)y, (long long*)num_batches_tracked);
+        return launch_status();
+    }
     if (dtype == HS_DTYPE_F32) {
         hipLaunchKernelGGL(bn_stats_kernel<float>, grid, dim3(256), 0, s, a, (const float*)x, (float*)workspace);
         hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, s, a, (const float*)x, (const float*)workspace, gamma, beta,
@@ -596,6 +698,15 @@ extern "C" int hs_bn_act_train_bwd(int32_t dtype, const void* x, const void* dy,
     if (!x || !dy || !dx || !save_mean || !save_invstd || !workspace) return HS_ERR_BAD_ARG;
     const dim3 grid(channels, BN_CHUNKS);
     hipStream_t s = (hipStream_t)stream;
+    if ((long)batch * pixels <= BN_SMALL_MAX && (dtype == HS_DTYPE_F32 || dtype == HS_DTYPE_BF16)) {
+        if (dtype == HS_DTYPE_F32)
+            hipLaunchKernelGGL(bn_bwd_small_kernel<float>, dim3(channels), dim3(BN_SMALL_THREADS), 0, s, a, (const float*)x, (const float*)dy, gamma, beta,
+                               save_mean, save_invstd, (float*)dx, dgamma, dbeta);
+        else
+            hipLaunchKernelGGL(bn_bwd_small_kernel<bf16_t>, dim3(channels), dim3(BN_SMALL_THREADS), 0, s, a, (const bf16_t*)x, (const bf16_t*)dy, gamma, beta,
+                               save_mean, save_invstd, (bf16_t*)dx, dgamma, dbeta);
+        return launch_status();
+    }
     if (dtype == HS_DTYPE_F32) {
         hipLaunchKernelGGL(bn_bwd_stats_kernel<float>, grid, dim3(256), 0, s, a, (const float*)x, (const float*)dy, gamma, beta, save_mean,
                            save_invstd, (float*)workspace);

@@ -199,7 +199,8 @@ def test_upsample_bilinear_autograd_vs_torch(dev, shape, size):
 
 
 @pytest.mark.parametrize('act', [None, 'relu', 'relu6'])
-@pytest.mark.parametrize('shape', [(2, 44, 36, 54), (1, 3, 7, 5), (3, 16, 1, 1), (2, 5, 129, 33)])
+@pytest.mark.parametrize('shape', [(2, 44, 36, 54), (1, 3, 7, 5), (3, 16, 1, 1), (2, 5, 129, 33),          # one launch per direction (<= 16384 elements per channel)
+                                   (2, 6, 200, 160), (1, 3, 300, 211), (2, 4, 96, 86)])                  # two launches: 32 slices per channel
 def test_fused_training_batchnorm_vs_stock(dev, shape, act):
     """hs_bn_act_train_fwd / _bwd behind autograd.bn_act == BatchNorm2d (train mode) + activation of torch: outputs, gradients of the
     input, gamma and beta, running statistics and the batch counter; mean far from zero (the shifted sums), ReLU6 saturating on both sides."""
