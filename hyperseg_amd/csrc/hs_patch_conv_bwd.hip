@@ -141,10 +141,12 @@ using bw_f32x2 = __attribute__((ext_vector_type(2))) float;
 // lane's four pixels are four 4-byte loads with their own row / column, and pixels past the patch contribute zeros.
 // T: storage type of the ACTIVATIONS and their gradients (float, or bf16_t: bf16 in memory, f32 products and sums, one rounding on
 // store -- hs_common.h Store<T>); the bank and its gradient are fp32 either way (hs_patch_conv_train.hip's header).
-template <int MT, int NTI, bool VEC, typename T>
+// VEC = 2 (round 4): even patch and image widths -- the halo tiles -- read as aligned PAIRS (two 8-byte loads per lane, operand and chunk,
+// instead of four 4-byte ones; a pair never straddles a patch row).
+template <int MT, int NTI, int VEC, typename T>
 __global__ __launch_bounds__(256)
 void patch_conv_bwd_weight_k1m_kernel(ConvBwdArgs a) {
-    static_assert(!VEC || sizeof(T) == 4, "vector loads: fp32 storage only");
+    static_assert(VEC == 0 || sizeof(T) == 4, "vector loads: fp32 storage only");
     __shared__ __attribute__((aligned(16))) float red[4][MT * NTI][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kg = lane >> 4;
@@ -160,7 +162,24 @@ void patch_conv_bwd_weight_k1m_kernel(ConvBwdArgs a) {
     for (int nt = 0; nt < NTI; ++nt) xp[nt] = (const T*)a.x + ((size_t)b * a.cin + min(16 * nt + n, a.cin - 1)) * plane + org;
     const int npix = a.ph * a.pw, nch = (npix + 15) >> 4;                // chunks of 16 pixels in patch-linear order
     auto fetch = [&](int s, bw_f32x4 (&av)[MT], bw_f32x4 (&bv)[NTI]) {
-        if constexpr (VEC) {
+        if constexpr (VEC == 2) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int l = 16 * s + 4 * kg + 2 * h, lc = min(l, npix - 2), u = div_by_inv(lc, a.inv_pw), v = lc - u * a.pw;   // npix even: a pair is live or not
+                const size_t off = (size_t)u * a.W + v;
+                const float live = l < npix ? 1.0f : 0.0f;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const bw_f32x2 p = *reinterpret_cast<const bw_f32x2*>((const float*)dyp[mt] + off);
+                    av[mt][2 * h] = p[0] * live; av[mt][2 * h + 1] = p[1] * live;
+                }
+#pragma unroll
+                for (int nt = 0; nt < NTI; ++nt) {
+                    const bw_f32x2 p = *reinterpret_cast<const bw_f32x2*>((const float*)xp[nt] + off);
+                    bv[nt][2 * h] = p[0]; bv[nt][2 * h + 1] = p[1];
+                }
+            }
+        } else if constexpr (VEC == 1) {
             const int l = 16 * s + 4 * kg, u = div_by_inv(l, a.inv_pw), v = l - u * a.pw;   // pw % 4 == 0: the lane's 4 pixels are one row segment
             const size_t off = (size_t)u * a.W + v;
 #pragma unroll
@@ -865,10 +884,12 @@ int hs::try_fast_bwd_w(int dtype, const void* x, const void* dy, int batch, int 
                      ((((size_t)x) | ((size_t)dy)) & 15) == 0;
     const int mt = (c_out + 15) / 16, nt = (c_in + 15) / 16;
     const dim3 grid((unsigned)(batch * fh * fw));
+    const bool pairs = !vec && dtype == HS_DTYPE_F32 && (a.pw & 1) == 0 && (W & 1) == 0 && ((((size_t)x) | ((size_t)dy)) & 7) == 0;
 #define HS_BW(MTV, NTV) if (mt == MTV && nt == NTV) { \
-        if (vec) hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, true, float>), grid, dim3(256), 0, stream, a); \
-        else HS_T2(dtype, hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, false, float>), grid, dim3(256), 0, stream, a), \
-                          hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, false, bf16_t>), grid, dim3(256), 0, stream, a)); \
+        if (vec) hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 1, float>), grid, dim3(256), 0, stream, a); \
+        else if (pairs) hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 2, float>), grid, dim3(256), 0, stream, a); \
+        else HS_T2(dtype, hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 0, float>), grid, dim3(256), 0, stream, a), \
+                          hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 0, bf16_t>), grid, dim3(256), 0, stream, a)); \
         return launch_status(); }
     HS_BW(1, 1) HS_BW(1, 2) HS_BW(1, 3) HS_BW(1, 4) HS_BW(2, 1) HS_BW(2, 2) HS_BW(2, 3) HS_BW(2, 4) HS_BW(3, 1) HS_BW(3, 2) HS_BW(4, 1) HS_BW(4, 2)
 #undef HS_BW

@@ -19,6 +19,10 @@ namespace hs {
 constexpr int ST_TILE = 64;                 // output rows (dW) / patches (dS) per workgroup, and the reduction chunk
 constexpr int ST_KMAX = 80;                 // signal channels per group
 constexpr int ST_APAD = ST_TILE + 1;
+#ifndef HS_ST_SLICE
+#define HS_ST_SLICE 256
+#endif
+constexpr int ST_SLICE = HS_ST_SLICE;         // patches per dW slice (a multiple of ST_TILE): one workgroup reduces ST_SLICE / ST_TILE chunks into one partial tile
 
 struct StLayer {
     const float* __restrict__ w;            // (wc, K)
@@ -91,11 +95,12 @@ void s2w_train_bwd_kernel(StArgs a) {
     for (int q = 0; q < 5; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int out0 = blk * ST_TILE;                                   // first row of the group (mode 0) / first patch (mode 1) of the tile
-    // mode 0 with a workspace: the patches are cut into slices of 64 (blockIdx.y), every workgroup reduces ONE slice and leaves a partial
+    // mode 0 with a workspace: the patches are cut into slices of ST_SLICE (blockIdx.y; 64 / 128 / 256 patches per slice measured 36.7 + 6.1 /
+    // 31.8 + 5 / 29.9 + 4.4 us for this launch + the slice sum at config 5, visit r5a), every workgroup reduces ONE slice and leaves a partial
     // tile; s2w_train_dwsum_kernel adds the slices in order.  (One workgroup walking all 648 patches was a 122 us latency chain on 304
     // workgroups -- the longest launch of the config-5 step, visit r4m.)
-    const int red_lo = (MODE == 0 && ka->dw_partial) ? (int)blockIdx.y * ST_TILE : 0;
-    const int red_hi = MODE == 0 ? (ka->dw_partial ? min(red_lo + ST_TILE, P) : P) : rpg;
+    const int red_lo = (MODE == 0 && ka->dw_partial) ? (int)blockIdx.y * ST_SLICE : 0;
+    const int red_hi = MODE == 0 ? (ka->dw_partial ? min(red_lo + ST_SLICE, P) : P) : rpg;
     for (int c0 = red_lo; c0 < red_hi; c0 += ST_TILE) {
         if (c0 > red_lo) __syncthreads();
         // ---- A: dBank, coalesced along the bank's rows.  Every load is UNCONDITIONAL from a clamped address and masked afterwards: behind
@@ -299,7 +304,7 @@ extern "C" int64_t hs_s2w_train_workspace(int32_t batch, int32_t fh, int32_t fw,
         if (layers[i].groups <= 0) return 0;
         dw_floats += (long)layers[i].wc * (layers[i].signal_channels / layers[i].groups);
     }
-    const long slices = ((long)batch * fh * fw + ST_TILE - 1) / ST_TILE;
+    const long slices = ((long)batch * fh * fw + ST_SLICE - 1) / ST_SLICE;
     return (int64_t)(slices * dw_floats * 4);
 }
 
@@ -313,7 +318,7 @@ extern "C" int hs_s2w_train_bwd(const float* signal, int32_t batch, int32_t c_si
     int n_wg = 0;
     st_fill(a, signal, batch, c_signal, fh, fw, layers, n_layers, 0, &n_wg);
     if (n_wg > 0) {
-        const int n_slices = (a.n_patches + ST_TILE - 1) / ST_TILE;
+        const int n_slices = (a.n_patches + ST_SLICE - 1) / ST_SLICE;
         const bool sliced = workspace && n_slices > 1 && workspace_bytes >= hs_s2w_train_workspace(batch, fh, fw, layers, n_layers) && n_slices <= 65535;
         a.dw_partial = sliced ? (float*)workspace : nullptr;
         hipLaunchKernelGGL(s2w_train_bwd_kernel<0>, dim3((unsigned)n_wg, sliced ? (unsigned)n_slices : 1u), dim3(256), 0, s, a);

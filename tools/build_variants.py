@@ -119,7 +119,7 @@ VARIANTS = {
     'kpreload': dict(flags=['-mllvm', '-amdgpu-kernarg-preload-count=16'], extra=[], patch=None),
     's2b_kc20': dict(flags=['-DHS_S2B_KC=20'], extra=[], patch=None),          # blocked signal2weights: one LDS fill for K = 80 (40 KB)
     's2b_kc5': dict(flags=['-DHS_S2B_KC=5'], extra=[], patch=None),
-    # split GEMM: 16-pixel workgroups when the 32-pixel grid has at most this many workgroups (product: 128)
+    # split GEMM: 16-pixel workgroups when the 32-pixel grid has at most this many workgroups (product: 256)
     'gs_narrow_0': dict(flags=['-DHS_GS_NARROW_MAX_WG=0'], extra=[], patch=None),
     'gs_narrow_192': dict(flags=['-DHS_GS_NARROW_MAX_WG=192'], extra=[], patch=None),
     'gs_narrow_384': dict(flags=['-DHS_GS_NARROW_MAX_WG=384'], extra=[], patch=None),
@@ -133,6 +133,8 @@ VARIANTS = {
     'irc_wide_store': dict(flags=['-DHS_IRC_WIDE_STORE'], extra=[], patch=None),         # round 4: the level-4 epilogue re-laid through LDS into 16-byte stores (measured slower)
     'irc_nw8': dict(flags=['-DHS_IRC_NW=8'], extra=[], patch=None),                      # round 4: eight waves per 16 x 16 region (four per SIMD at two workgroups per CU)
     'irc_r3': dict(flags=[], extra=[], patch='irc_r3', file='hs_patch_irc.hip'),          # round 3's level-4 kernel
+    'st_slice64': dict(flags=['-DHS_ST_SLICE=64'], extra=[], patch=None),                 # round 4: patches per dW slice of the s2w backward (product: 256)
+    'st_slice128': dict(flags=['-DHS_ST_SLICE=128'], extra=[], patch=None),
     's2wt_noA': dict(flags=[], extra=[], patch='s2wt_noA', file='hs_s2w_train.hip'),
     's2wt_noB': dict(flags=[], extra=[], patch='s2wt_noB', file='hs_s2w_train.hip'),
     's2wt_nomfma': dict(flags=[], extra=[], patch='s2wt_nomfma', file='hs_s2w_train.hip'),
