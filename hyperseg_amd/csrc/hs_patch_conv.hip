@@ -430,6 +430,17 @@ __global__ void stage_input_kernel(StageIn s, TO* __restrict__ y) {
         Store<TO>::st(y, e, stage_value<TP>(s, b, c, stage_pos(s, yy, x)));
     }
 }
+// the same on a (64 x 4 pixels, plane) grid: no per-element division (three of them were most of the element-wise form's instructions;
+// the training step launches it once per level: 5 x 8.4 -> us at config 5)
+template <typename TP, typename TO>
+__global__ __launch_bounds__(256)
+void stage_input_plane_kernel(StageIn s, TO* __restrict__ y) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), yy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= s.W || yy >= s.H) return;
+    const int plane = blockIdx.z, cin = s.cin();
+    const int b = plane / cin, c = plane - b * cin;                       // (uniform)
+    Store<TO>::st(y, ((size_t)plane * s.H + yy) * s.W + x, stage_value<TP>(s, b, c, stage_pos(s, yy, x)));
+}
 
 // Bilinear resize (align_corners=False).  One thread = 4 consecutive output pixels of a row; bilinear_row4 is shared by
 // the logits kernel and the fused argmax kernel.
@@ -685,6 +696,14 @@ extern "C" int hs_stage_input_typed_fwd(const hs_stage_input* in, int32_t prev_d
     const size_t n = (size_t)s.B * s.cin() * s.H * s.W;
     const dim3 blocks((unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256));
     hipStream_t q = (hipStream_t)stream;
+    if ((long)s.B * s.cin() <= 65535) {
+        const dim3 g2((s.W + 63) / 64, (s.H + 3) / 4, s.B * s.cin());
+        if (prev_dtype == HS_DTYPE_F32 && out_dtype == HS_DTYPE_F32) hipLaunchKernelGGL((stage_input_plane_kernel<float, float>), g2, dim3(256), 0, q, s, (float*)y);
+        else if (prev_dtype == HS_DTYPE_F32) hipLaunchKernelGGL((stage_input_plane_kernel<float, bf16_t>), g2, dim3(256), 0, q, s, (bf16_t*)y);
+        else if (out_dtype == HS_DTYPE_F32) hipLaunchKernelGGL((stage_input_plane_kernel<bf16_t, float>), g2, dim3(256), 0, q, s, (float*)y);
+        else hipLaunchKernelGGL((stage_input_plane_kernel<bf16_t, bf16_t>), g2, dim3(256), 0, q, s, (bf16_t*)y);
+        return launch_status();
+    }
     if (prev_dtype == HS_DTYPE_F32 && out_dtype == HS_DTYPE_F32) hipLaunchKernelGGL((stage_input_kernel<float, float>), blocks, dim3(256), 0, q, s, (float*)y);
     else if (prev_dtype == HS_DTYPE_F32) hipLaunchKernelGGL((stage_input_kernel<float, bf16_t>), blocks, dim3(256), 0, q, s, (bf16_t*)y);
     else if (out_dtype == HS_DTYPE_F32) hipLaunchKernelGGL((stage_input_kernel<bf16_t, float>), blocks, dim3(256), 0, q, s, (float*)y);

@@ -589,6 +589,43 @@ void patch_conv_bwd_input_tiny_kernel(ConvBwdArgs a) {
     }
 }
 
+// dW of the same tiny-patch layers: dW[o][c] = sum over the patch's <= 15 pixels of dY[o][px] X[c][px], one workgroup per patch, both operands
+// staged in LDS (row stride 17: consecutive c fall on consecutive banks), every thread a run of consecutive bank columns -- coalesced
+// stores, one reciprocal multiplication per output (the general kernel below divides three times per output and stages a padded tile).
+template <typename T>
+__global__ __launch_bounds__(256)
+void patch_conv_bwd_weight_tiny_kernel(ConvBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float tiny_w[];      // [cout][17] dY | [cin][17] X
+    const int patch = blockIdx.x;
+    const int pj = patch % a.fw, pi = (patch / a.fw) % a.fh, b = patch / (a.fw * a.fh);
+    const size_t plane = (size_t)a.H * a.W;
+    const size_t org = (size_t)(pi * a.ph) * a.W + pj * a.pw;
+    const int npix = a.ph * a.pw;
+    float* __restrict__ dyl = tiny_w;
+    float* __restrict__ xl = tiny_w + (size_t)a.cout * 17;
+    const T* __restrict__ dyb = (const T*)a.dy + (size_t)b * a.cout * plane + org;
+    const T* __restrict__ xb = (const T*)a.x + (size_t)b * a.cin * plane + org;
+    for (int e = threadIdx.x; e < (a.cout + a.cin) * 16; e += 256) {
+        const int row = e >> 4, q = e & 15, l = min(q, npix - 1), u = div_by_inv(l, a.inv_pw), v = l - u * a.pw;
+        const size_t off = (size_t)u * a.W + v;
+        const bool is_dy = row < a.cout;                                 // (both loads unconditional from clamped rows; one is kept)
+        const float gd = Store<T>::ld(dyb, (size_t)min(row, a.cout - 1) * plane + off);
+        const float gx = Store<T>::ld(xb, (size_t)min(max(row - a.cout, 0), a.cin - 1) * plane + off);
+        if (q < 15) tiny_w[(size_t)row * 17 + q] = q < npix ? (is_dy ? gd : gx) : 0.0f;
+    }
+    __syncthreads();
+    const float inv_cin = 1.0f / (float)a.cin;
+    float* __restrict__ dst = a.dbank + (size_t)patch * a.ld;
+    for (int idx = threadIdx.x; idx < a.cout * a.cin; idx += 256) {
+        const int o = div_by_inv(idx, inv_cin), c = idx - o * a.cin;
+        float acc = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 15; ++q)
+            if (q < npix) acc = fmaf(dyl[o * 17 + q], xl[c * 17 + q], acc);      // (uniform bound; pixel order as the general kernel's)
+        dst[idx] = acc;
+    }
+}
+
 // ... and the weight gradient with two adjacent pixels per lane (even patch width): 10 loads per pair instead of 20, rows from div_by_inv.
 template <typename T>
 __global__ __launch_bounds__(256)
@@ -849,7 +886,7 @@ int hs::try_fast_bwd_in(int dtype, const void* dy, const void* bank, long ld, in
                      hipLaunchKernelGGL(patch_conv_bwd_input_tiny_kernel<bf16_t>, gridt, dim3(128), (size_t)c_out * 64, stream, a));
         return launch_status();
     }
-    if (k != 1 || groups != 1) return 1;
+    if (k != 1 || groups != 1 || a.ph * a.pw < 16) return 1;
     const int ct = (c_in + 15) / 16, kq = (c_out + 15) / 16;
     const dim3 grid((unsigned)(batch * fh * fw));
 #define HS_BI(CTV, KQV) if (ct == CTV && kq == KQV) { \
@@ -877,6 +914,13 @@ int hs::try_fast_bwd_w(int dtype, const void* x, const void* dy, int batch, int 
         }
         HS_T2(dtype, hipLaunchKernelGGL(patch_dw3_bwd_weight_kernel<float>, grid, dim3(256), 0, stream, a),
                      hipLaunchKernelGGL(patch_dw3_bwd_weight_kernel<bf16_t>, grid, dim3(256), 0, stream, a));
+        return launch_status();
+    }
+    if (k == 1 && groups == 1 && a.ph * a.pw < 16 && (long)c_out * c_in < (1 << 21) && (size_t)(c_out + c_in) * 17 * 4 <= 64 * 1024) {
+        const dim3 gridt((unsigned)(batch * fh * fw));
+        const size_t lds = (size_t)(c_out + c_in) * 17 * 4;
+        HS_T2(dtype, hipLaunchKernelGGL(patch_conv_bwd_weight_tiny_kernel<float>, gridt, dim3(256), lds, stream, a),
+                     hipLaunchKernelGGL(patch_conv_bwd_weight_tiny_kernel<bf16_t>, gridt, dim3(256), lds, stream, a));
         return launch_status();
     }
     if (k != 1 || groups != 1 || a.ph * a.pw < 16) return 1;

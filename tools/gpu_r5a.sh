@@ -8,7 +8,7 @@ for n in 10 30; do
     f=$(find /tmp/prof_t_$n -name '*kernel_stats.csv' | head -1); cp "$f" $R/gpurun_out/train_stats_fp32_${n}_$tag.csv )
 done
 python tools/train_launch_count.py gpurun_out/train_stats_fp32_10_$tag.csv 10 gpurun_out/train_stats_fp32_30_$tag.csv 30 34 | cut -c1-170 | tee gpurun_out/train_launches_$tag.txt
-for v in st_slice64 st_slice256; do
+for v in ; do
   export HS_HIP_LIB=$R/hyperseg_amd/lib/libhyperseg_hip_$v.so
   ( cd /tmp && rm -rf /tmp/prof_v && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_v -- python $R/tools/train_step_time.py 10 fp32 > /tmp/prof_v.log 2>&1
     f=$(find /tmp/prof_v -name '*kernel_stats.csv' | head -1); echo "$v: $(grep -E 's2w_train_bwd_kernel<0>|s2w_train_dwsum' $f | awk -F'"' '{split($3,q,","); printf "%s avg %.2f us | ", substr($2,1,40), q[4]/1000}')" )
