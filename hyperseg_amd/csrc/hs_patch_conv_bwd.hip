@@ -135,6 +135,21 @@ void patch_conv_bwd_weight_kernel(ConvBwdArgs a, int ob) {
 // ---------------------------------------------------------------------------------------------------------------------------------
 using bw_f32x4 = __attribute__((ext_vector_type(4))) float;
 using bw_f32x2 = __attribute__((ext_vector_type(2))) float;
+// two adjacent elements as one aligned access (8 bytes fp32, 4 bytes bf16)
+template <typename T> struct Pair;
+template <> struct Pair<float> {
+    static __device__ __forceinline__ void ld(const float* p, size_t i, float& a, float& b) {
+        const bw_f32x2 v = *reinterpret_cast<const bw_f32x2*>(p + i); a = v[0]; b = v[1];
+    }
+    static __device__ __forceinline__ void st(float* p, size_t i, float a, float b) { *reinterpret_cast<bw_f32x2*>(p + i) = bw_f32x2{a, b}; }
+};
+template <> struct Pair<bf16_t> {
+    static __device__ __forceinline__ void ld(const bf16_t* p, size_t i, float& a, float& b) {
+        const uint32_t v = *reinterpret_cast<const uint32_t*>(p + i); a = __uint_as_float(v << 16); b = __uint_as_float(v & 0xffff0000u);
+    }
+    static __device__ __forceinline__ void st(bf16_t* p, size_t i, float a, float b) { Store<bf16_t>::st(p, i, a); Store<bf16_t>::st(p, i + 1, b); }
+};
+
 
 // VEC: patches whose rows are whole 4-pixel groups on 16-byte boundaries and whose pixel count is a multiple of 16.  Otherwise (the
 // (ph + 2) x (pw + 2) halo tiles that a train-mode v1_0 inverted residual feeds to its first 1x1 convolution: 18 x 18, 10 x 10) the
@@ -238,7 +253,73 @@ void patch_conv_bwd_weight_k1m_kernel(ConvBwdArgs a) {
     }
 }
 
-template <int CT, int KQ, typename T>
+// The pixel stream both of these kernels are: out[m][px] = epi(sum_k A[m][k] in[k][px]) over one patch, A (this patch's weights, MT x KQ
+// fragments) in registers, the waves taking pixel tiles in turn with the next tile's operands in flight.  PX = 1: a lane owns pixel
+// 16 t + n of tile t.  PX = 2 (round 4; even patch and image widths): a lane owns the ADJACENT pixels 32 t + 2 n and + 1 of a 32-pixel
+// super-tile -- one 8-byte load per input row and one 8-byte store per output row instead of two 4-byte ones (16 lanes cover 128
+// contiguous bytes instead of 64), the even and the odd pixels going through the matrix cores as two tiles.  Same products in the same
+// order per pixel: bit-identical to PX = 1.
+template <int MT, int KQ, int PX, typename T, typename EPI>
+__device__ __forceinline__ void k1m_pixel_stream(const ConvBwdArgs& a, const float (&aw)[MT][KQ][4], const T* __restrict__ src, T* __restrict__ dst,
+                                                 int kin, int mout, size_t plane, int n, int kg, int wave, EPI epi) {
+    constexpr int TP = 16 * PX;                                         // pixels per (super-)tile
+    const int npix = a.ph * a.pw, ntile = (npix + TP - 1) / TP;
+    auto fetch = [&](int t, float (&bv)[PX][KQ][4], size_t& off) {
+        const int l = min(TP * t + PX * n, npix - PX), u = div_by_inv(l, a.inv_pw), v = l - u * a.pw;     // past the patch: live pixels, not stored
+        off = (size_t)u * a.W + v;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 16 * q + 4 * kg + j;
+                const size_t at = (size_t)min(k, kin - 1) * plane + off;
+                if constexpr (PX == 2) {
+                    float v0, v1;
+                    Pair<T>::ld(src, at, v0, v1);
+                    bv[0][q][j] = k < kin ? v0 : 0.0f; bv[1][q][j] = k < kin ? v1 : 0.0f;
+                } else {
+                    const float val = Store<T>::ld(src, at);
+                    bv[0][q][j] = k < kin ? val : 0.0f;
+                }
+            }
+    };
+    auto tile = [&](int t, const float (&bv)[PX][KQ][4], size_t off) {
+        const bool live = TP * t + PX * n < npix;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            bw_f32x4 acc[PX];
+#pragma unroll
+            for (int h = 0; h < PX; ++h) {
+                acc[h] = bw_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < KQ; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[mt][q][j], bv[h][q][j], acc[h], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = 16 * mt + 4 * kg + r;
+                if (m < mout && live) {
+                    if constexpr (PX == 2) Pair<T>::st(dst, (size_t)m * plane + off, epi(acc[0][r], mt, r), epi(acc[1][r], mt, r));
+                    else Store<T>::st(dst, (size_t)m * plane + off, epi(acc[0][r], mt, r));
+                }
+            }
+        }
+    };
+    float b0[PX][KQ][4], b1[PX][KQ][4];
+    size_t o0 = 0, o1 = 0;
+    int t = wave;
+    if (t < ntile) fetch(t, b0, o0);
+    for (; t + 4 < ntile; t += 8) {
+        fetch(t + 4, b1, o1);
+        tile(t, b0, o0);
+        if (t + 8 < ntile) fetch(t + 8, b0, o0);
+        tile(t + 4, b1, o1);
+    }
+    if (t < ntile) tile(t, b0, o0);
+}
+
+template <int CT, int KQ, int PX, typename T>
 __global__ __launch_bounds__(256)
 void patch_conv_bwd_input_k1m_kernel(ConvBwdArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -260,52 +341,13 @@ void patch_conv_bwd_input_k1m_kernel(ConvBwdArgs a) {
     const size_t org = (size_t)(pi * a.ph) * a.W + pj * a.pw;
     const T* __restrict__ dyb = (const T*)a.dy + (size_t)b * a.cout * plane + org;
     T* __restrict__ dxb = (T*)a.dx + (size_t)b * a.cin * plane + org;
-    const int npix = a.ph * a.pw, ntile = (npix + 15) >> 4;
-    auto fetch = [&](int t, float (&bv)[KQ][4], size_t& off) {
-        const int l = min(16 * t + n, npix - 1), u = div_by_inv(l, a.inv_pw), v = l - u * a.pw;     // past the patch: a live pixel, not stored
-        off = (size_t)u * a.W + v;
-#pragma unroll
-        for (int q = 0; q < KQ; ++q)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int o = 16 * q + 4 * kg + j;
-                const float val = Store<T>::ld(dyb, (size_t)min(o, a.cout - 1) * plane + off);
-                bv[q][j] = o < a.cout ? val : 0.0f;
-            }
-    };
-    auto tile = [&](int t, const float (&bv)[KQ][4], size_t off) {
-        const bool live = 16 * t + n < npix;
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            bw_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int q = 0; q < KQ; ++q)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[ct][q][j], bv[q][j], acc, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int c = 16 * ct + 4 * kg + r;
-                if (c < a.cin && live) Store<T>::st(dxb, (size_t)c * plane + off, acc[r]);
-            }
-        }
-    };
-    float b0[KQ][4], b1[KQ][4];
-    size_t o0 = 0, o1 = 0;
-    int t = wave;
-    if (t < ntile) fetch(t, b0, o0);
-    for (; t + 4 < ntile; t += 8) {
-        fetch(t + 4, b1, o1);
-        tile(t, b0, o0);
-        if (t + 8 < ntile) fetch(t + 8, b0, o0);
-        tile(t + 4, b1, o1);
-    }
-    if (t < ntile) tile(t, b0, o0);
+    k1m_pixel_stream<CT, KQ, PX, T>(a, aw, dyb, dxb, a.cout, a.cin, plane, n, kg, wave, [](float v, int, int) { return v; });
 }
 
 // The forward of the same layer on a PLAIN input tensor (what the autograd path calls: no fused stage-input prologue), same structure
 // as the input-gradient kernel with the bank row read untransposed:  y[o][px] = sum_c W[o][c] x[c][px].  a.dy = x (cin channels),
 // a.dx = y (cout channels); BatchNorm affine + activation optional.
-template <int MT, int KQ, typename T>
+template <int MT, int KQ, int PX, typename T>
 __global__ __launch_bounds__(256)
 void patch_conv_fwd_k1m_kernel(ConvBwdArgs a, const float* __restrict__ scale, const float* __restrict__ shift, int act) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -333,46 +375,8 @@ void patch_conv_fwd_k1m_kernel(ConvBwdArgs a, const float* __restrict__ scale, c
     const size_t org = (size_t)(pi * a.ph) * a.W + pj * a.pw;
     const T* __restrict__ xb = (const T*)a.dy + (size_t)b * a.cin * plane + org;
     T* __restrict__ yb = (T*)a.dx + (size_t)b * a.cout * plane + org;
-    const int npix = a.ph * a.pw, ntile = (npix + 15) >> 4;
-    auto fetch = [&](int t, float (&bv)[KQ][4], size_t& off) {
-        const int l = min(16 * t + n, npix - 1), u = div_by_inv(l, a.inv_pw), v = l - u * a.pw;
-        off = (size_t)u * a.W + v;
-#pragma unroll
-        for (int q = 0; q < KQ; ++q)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = 16 * q + 4 * kg + j;
-                const float val = Store<T>::ld(xb, (size_t)min(c, a.cin - 1) * plane + off);
-                bv[q][j] = c < a.cin ? val : 0.0f;
-            }
-    };
-    auto tile = [&](int t, const float (&bv)[KQ][4], size_t off) {
-        const bool live = 16 * t + n < npix;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            bw_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int q = 0; q < KQ; ++q)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[mt][q][j], bv[q][j], acc, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int o = 16 * mt + 4 * kg + r;
-                if (o < a.cout && live) Store<T>::st(yb, (size_t)o * plane + off, apply_act(fmaf(acc[r], sc[mt][r], sh[mt][r]), act));
-            }
-        }
-    };
-    float b0[KQ][4], b1[KQ][4];
-    size_t o0 = 0, o1 = 0;
-    int t = wave;
-    if (t < ntile) fetch(t, b0, o0);
-    for (; t + 4 < ntile; t += 8) {
-        fetch(t + 4, b1, o1);
-        tile(t, b0, o0);
-        if (t + 8 < ntile) fetch(t + 8, b0, o0);
-        tile(t + 4, b1, o1);
-    }
-    if (t < ntile) tile(t, b0, o0);
+    k1m_pixel_stream<MT, KQ, PX, T>(a, aw, xb, yb, a.cin, a.cout, plane, n, kg, wave,
+                                    [&](float v, int mt, int r) { return apply_act(fmaf(v, sc[mt][r], sh[mt][r]), act); });
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -425,20 +429,6 @@ void patch_dw3_kernel(ConvBwdArgs a, const T* __restrict__ src, T* __restrict__ 
 // own one +- 1 decided from the position inside the tile: the one-element adjoint did 18 divisions by run-time values per thread (~450 of its
 // ~520 vector instructions; 52 us per launch at config 5 against 30 for the forward, which does two).  Same fma chain per element (tap-major,
 // ky then kx): bit-identical results.
-template <typename T> struct Pair;
-template <> struct Pair<float> {
-    static __device__ __forceinline__ void ld(const float* p, size_t i, float& a, float& b) {
-        const bw_f32x2 v = *reinterpret_cast<const bw_f32x2*>(p + i); a = v[0]; b = v[1];
-    }
-    static __device__ __forceinline__ void st(float* p, size_t i, float a, float b) { *reinterpret_cast<bw_f32x2*>(p + i) = bw_f32x2{a, b}; }
-};
-template <> struct Pair<bf16_t> {
-    static __device__ __forceinline__ void ld(const bf16_t* p, size_t i, float& a, float& b) {
-        const uint32_t v = *reinterpret_cast<const uint32_t*>(p + i); a = __uint_as_float(v << 16); b = __uint_as_float(v & 0xffff0000u);
-    }
-    static __device__ __forceinline__ void st(bf16_t* p, size_t i, float a, float b) { Store<bf16_t>::st(p, i, a); Store<bf16_t>::st(p, i + 1, b); }
-};
-
 template <int MODE, typename T>
 __global__ __launch_bounds__(256)
 void patch_dw3_pair_kernel(ConvBwdArgs a, const T* __restrict__ src, T* __restrict__ dst) {
@@ -852,9 +842,14 @@ int hs::try_fast_fwd(int dtype, const void* x, const void* bank, long ld, int ba
     a.dy = (const float*)x; a.dx = (float*)y;
     const int mt = (c_out + 15) / 16, kq = (c_in + 15) / 16;
     const dim3 grid((unsigned)(batch * fh * fw));
+    // even widths, aligned planes, patches of at least four super-tiles: two adjacent pixels per lane (measured at config 5, visit r5c: 23.8 -> 23.1
+    // and 13.3 -> 12.1 us on the 324- / 256-pixel patches, 7.4 -> 9.5 us on the 16-pixel ones, where half of a super-tile's lanes idle)
+    const bool px2 = dw3_pairs(a, x, y) && a.ph * a.pw >= 128;
 #define HS_FW(MTV, KQV) if (mt == MTV && kq == KQV) { \
-        HS_T2(dtype, hipLaunchKernelGGL((patch_conv_fwd_k1m_kernel<MTV, KQV, float>), grid, dim3(256), 0, stream, a, scale, shift, act), \
-                     hipLaunchKernelGGL((patch_conv_fwd_k1m_kernel<MTV, KQV, bf16_t>), grid, dim3(256), 0, stream, a, scale, shift, act)); \
+        if (px2) HS_T2(dtype, hipLaunchKernelGGL((patch_conv_fwd_k1m_kernel<MTV, KQV, 2, float>), grid, dim3(256), 0, stream, a, scale, shift, act), \
+                              hipLaunchKernelGGL((patch_conv_fwd_k1m_kernel<MTV, KQV, 2, bf16_t>), grid, dim3(256), 0, stream, a, scale, shift, act)); \
+        else HS_T2(dtype, hipLaunchKernelGGL((patch_conv_fwd_k1m_kernel<MTV, KQV, 1, float>), grid, dim3(256), 0, stream, a, scale, shift, act), \
+                          hipLaunchKernelGGL((patch_conv_fwd_k1m_kernel<MTV, KQV, 1, bf16_t>), grid, dim3(256), 0, stream, a, scale, shift, act)); \
         return launch_status(); }
     HS_FW(1, 1) HS_FW(1, 2) HS_FW(1, 3) HS_FW(1, 4) HS_FW(2, 1) HS_FW(2, 2) HS_FW(2, 3) HS_FW(2, 4)
     HS_FW(3, 1) HS_FW(3, 2) HS_FW(3, 3) HS_FW(3, 4) HS_FW(4, 1) HS_FW(4, 2) HS_FW(4, 3)
@@ -889,9 +884,12 @@ int hs::try_fast_bwd_in(int dtype, const void* dy, const void* bank, long ld, in
     if (k != 1 || groups != 1 || a.ph * a.pw < 16) return 1;
     const int ct = (c_in + 15) / 16, kq = (c_out + 15) / 16;
     const dim3 grid((unsigned)(batch * fh * fw));
+    const bool px2 = dw3_pairs(a, dy, dx) && a.ph * a.pw >= 128;
 #define HS_BI(CTV, KQV) if (ct == CTV && kq == KQV) { \
-        HS_T2(dtype, hipLaunchKernelGGL((patch_conv_bwd_input_k1m_kernel<CTV, KQV, float>), grid, dim3(256), 0, stream, a), \
-                     hipLaunchKernelGGL((patch_conv_bwd_input_k1m_kernel<CTV, KQV, bf16_t>), grid, dim3(256), 0, stream, a)); \
+        if (px2) HS_T2(dtype, hipLaunchKernelGGL((patch_conv_bwd_input_k1m_kernel<CTV, KQV, 2, float>), grid, dim3(256), 0, stream, a), \
+                              hipLaunchKernelGGL((patch_conv_bwd_input_k1m_kernel<CTV, KQV, 2, bf16_t>), grid, dim3(256), 0, stream, a)); \
+        else HS_T2(dtype, hipLaunchKernelGGL((patch_conv_bwd_input_k1m_kernel<CTV, KQV, 1, float>), grid, dim3(256), 0, stream, a), \
+                          hipLaunchKernelGGL((patch_conv_bwd_input_k1m_kernel<CTV, KQV, 1, bf16_t>), grid, dim3(256), 0, stream, a)); \
         return launch_status(); }
     HS_BI(1, 1) HS_BI(1, 2) HS_BI(1, 3) HS_BI(1, 4) HS_BI(2, 1) HS_BI(2, 2) HS_BI(2, 3) HS_BI(2, 4)
     HS_BI(3, 1) HS_BI(3, 2) HS_BI(3, 3) HS_BI(3, 4) HS_BI(4, 1) HS_BI(4, 2) HS_BI(4, 3) HS_BI(6, 1) HS_BI(6, 2)
