@@ -19,6 +19,7 @@
 //   shift, the activation and the residual, and are stored as 128-byte runs; the tail's operands are requested before the
 //   barrier.  (The probed dev kernel had only the accumulate-onto-Y tail; shift / activation / separate residual are new.)
 #include "hs_common.h"
+#include <type_traits>
 
 namespace hs {
 
@@ -263,35 +264,48 @@ void gemm_split_kernel(GemmSplitArgs a) {
         }
     }
     __syncthreads();
+    // the tail once per ACTIVATION (a uniform run-time value) instead of `apply_act(v, a.act)` -- three scalar compare-and-branch pairs per
+    // output -- inside the unrolled element loop.  Same-box A/B of the whole frame: 0.7760 / 0.7764 vs 0.7765 / 0.7777 ms, i.e. nothing
+    // measurable (profiles/round4_gemm_split_tail_unswitch_ab.txt): uniform branches are not what these 5-7 us launches wait for.
+    auto tail = [&](auto act_kind) {
+        constexpr int ACT = decltype(act_kind)::value;
 #pragma unroll
-    for (int i = 0; i < TE; ++i) {
-        const int e = tid + i * nthr;
-        if (e < NE) {
-            const int row = 16 * r0 + e / NP, col = n0 + (e & (NP - 1));
-            float t = 0.0f;
+        for (int i = 0; i < TE; ++i) {
+            const int e = tid + i * nthr;
+            if (e < NE) {
+                const int row = 16 * r0 + e / NP, col = n0 + (e & (NP - 1));
+                float t = 0.0f;
 #pragma unroll
-            for (int w = 0; w < nwv; ++w) t += gs_red[w * NE + e];
-            const bool live = row < a.M && col < a.N;
-            float v = fmaf(t, wi[i], sh[i]);
-            v = (a.act == 3 ? swishf(v) : apply_act(v, a.act)) + yo[i];
-            if (live) {
-                if (a.up2_wo > 0) {                                     // pixel (oy, ox) -> the 2x2 block at (2 oy, 2 ox) of a 2 Wo wide map
-                    const int oy = col / a.up2_wo, ox = col - oy * a.up2_wo;
-                    float* dst = yb + (size_t)row * (4 * a.N) + (size_t)(2 * oy) * (2 * a.up2_wo) + 2 * ox;
-                    *reinterpret_cast<gs_f32x2*>(dst) = gs_f32x2{v, v};
-                    *reinterpret_cast<gs_f32x2*>(dst + 2 * a.up2_wo) = gs_f32x2{v, v};
-                } else {
-                    yb[(size_t)row * a.N + col] = v;
+                for (int w = 0; w < nwv; ++w) t += gs_red[w * NE + e];
+                const bool live = row < a.M && col < a.N;
+                float v = fmaf(t, wi[i], sh[i]);
+                if constexpr (ACT == HS_ACT_SWISH) v = swishf(v);
+                else if constexpr (ACT == HS_ACT_RELU) v = fmaxf(v, 0.0f);
+                else if constexpr (ACT == HS_ACT_RELU6) v = fminf(fmaxf(v, 0.0f), 6.0f);
+                v += yo[i];
+                if (live) {
+                    if (a.up2_wo > 0) {                                 // pixel (oy, ox) -> the 2x2 block at (2 oy, 2 ox) of a 2 Wo wide map
+                        const int oy = col / a.up2_wo, ox = col - oy * a.up2_wo;
+                        float* dst = yb + (size_t)row * (4 * a.N) + (size_t)(2 * oy) * (2 * a.up2_wo) + 2 * ox;
+                        *reinterpret_cast<gs_f32x2*>(dst) = gs_f32x2{v, v};
+                        *reinterpret_cast<gs_f32x2*>(dst + 2 * a.up2_wo) = gs_f32x2{v, v};
+                    } else {
+                        yb[(size_t)row * a.N + col] = v;
+                    }
                 }
-            }
-            if constexpr (NP == 16) {                                   // 16 consecutive lanes = one output row of this workgroup
-                if (a.pool_partial) {
-                    const float rs = rowsum16(live ? v : 0.0f);
-                    if ((e & 15) == 0 && row < a.M) a.pool_partial[((size_t)b * a.M + row) * gridDim.x + blockIdx.x] = rs;
+                if constexpr (NP == 16) {                               // 16 consecutive lanes = one output row of this workgroup
+                    if (a.pool_partial) {
+                        const float rs = rowsum16(live ? v : 0.0f);
+                        if ((e & 15) == 0 && row < a.M) a.pool_partial[((size_t)b * a.M + row) * gridDim.x + blockIdx.x] = rs;
+                    }
                 }
             }
         }
-    }
+    };
+    if (a.act == HS_ACT_SWISH) tail(std::integral_constant<int, HS_ACT_SWISH>{});
+    else if (a.act == HS_ACT_NONE) tail(std::integral_constant<int, HS_ACT_NONE>{});
+    else if (a.act == HS_ACT_RELU) tail(std::integral_constant<int, HS_ACT_RELU>{});
+    else tail(std::integral_constant<int, HS_ACT_RELU6>{});
 }
 
 // shift_out[m] = shift[m] + sum_c wb[m][c] * mean[c], mean[c] = inv_p * sum_j partial[c][j]: the context head's deepest merge, where

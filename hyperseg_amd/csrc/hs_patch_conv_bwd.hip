@@ -347,7 +347,12 @@ void patch_conv_bwd_input_k1m_kernel(ConvBwdArgs a) {
 // The forward of the same layer on a PLAIN input tensor (what the autograd path calls: no fused stage-input prologue), same structure
 // as the input-gradient kernel with the bank row read untransposed:  y[o][px] = sum_c W[o][c] x[c][px].  a.dy = x (cin channels),
 // a.dx = y (cout channels); BatchNorm affine + activation optional.
-template <int MT, int KQ, int PX, typename T>
+// AFFINE: a BatchNorm affine + activation follows in the epilogue.  The training path passes none -- and with the choice left to run time
+// (`scale ? scale[o] : 1`, `apply_act(v, act)`) the compiler had built twelve serialised load-and-wait blocks at the top of the kernel and
+// ~10 branch blocks around every stored value: 4600 lines of ISA, the launch 2x what its bytes need (visit r5c, ISA read with
+// tools/isa_phases.py's recipe).  The template removes both; with AFFINE the rows are loaded unconditionally and ReLU / ReLU6 are one clamp
+// whose bounds depend on `act` (swish, which no reference decoder uses, keeps its branch).
+template <int MT, int KQ, int PX, bool AFFINE, typename T>
 __global__ __launch_bounds__(256)
 void patch_conv_fwd_k1m_kernel(ConvBwdArgs a, const float* __restrict__ scale, const float* __restrict__ shift, int act) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -364,19 +369,27 @@ void patch_conv_fwd_k1m_kernel(ConvBwdArgs a, const float* __restrict__ scale, c
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 aw[mt][q][j] = wp[(size_t)min(16 * mt + n, a.cout - 1) * a.cin + min(16 * q + 4 * kg + j, a.cin - 1)];
-    float sc[MT][4], sh[MT][4];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int o = min(16 * mt + 4 * kg + r, a.cout - 1);
-            sc[mt][r] = scale ? scale[o] : 1.0f; sh[mt][r] = scale ? shift[o] : 0.0f;
-        }
     const size_t org = (size_t)(pi * a.ph) * a.W + pj * a.pw;
     const T* __restrict__ xb = (const T*)a.dy + (size_t)b * a.cin * plane + org;
     T* __restrict__ yb = (T*)a.dx + (size_t)b * a.cout * plane + org;
-    k1m_pixel_stream<MT, KQ, PX, T>(a, aw, xb, yb, a.cin, a.cout, plane, n, kg, wave,
-                                    [&](float v, int mt, int r) { return apply_act(fmaf(v, sc[mt][r], sh[mt][r]), act); });
+    if constexpr (AFFINE) {
+        float sc[MT][4], sh[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = min(16 * mt + 4 * kg + r, a.cout - 1);
+                sc[mt][r] = scale[o]; sh[mt][r] = shift[o];
+            }
+        const float hi = act == HS_ACT_RELU6 ? 6.0f : __builtin_inff();
+        const bool plain = act == HS_ACT_NONE, swish = act == HS_ACT_SWISH;
+        k1m_pixel_stream<MT, KQ, PX, T>(a, aw, xb, yb, a.cin, a.cout, plane, n, kg, wave, [&](float v, int mt, int r) {
+            const float z = fmaf(v, sc[mt][r], sh[mt][r]);
+            return plain ? z : (swish ? swishf(z) : fminf(fmaxf(z, 0.0f), hi));       // ReLU / ReLU6 as apply_act states them
+        });
+    } else {
+        k1m_pixel_stream<MT, KQ, PX, T>(a, aw, xb, yb, a.cin, a.cout, plane, n, kg, wave, [](float v, int, int) { return v; });
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -845,15 +858,18 @@ int hs::try_fast_fwd(int dtype, const void* x, const void* bank, long ld, int ba
     // even widths, aligned planes, patches of at least four super-tiles: two adjacent pixels per lane (measured at config 5, visit r5c: 23.8 -> 23.1
     // and 13.3 -> 12.1 us on the 324- / 256-pixel patches, 7.4 -> 9.5 us on the 16-pixel ones, where half of a super-tile's lanes idle)
     const bool px2 = dw3_pairs(a, x, y) && a.ph * a.pw >= 128;
+    const bool affine = scale != nullptr || act != HS_ACT_NONE;
+    if (affine && (!scale || !shift)) return 1;                         // an activation without the affine rows: the generic kernel
+#define HS_FW_L(MTV, KQV, PXV, AFV) HS_T2(dtype, hipLaunchKernelGGL((patch_conv_fwd_k1m_kernel<MTV, KQV, PXV, AFV, float>), grid, dim3(256), 0, stream, a, scale, shift, act), \
+                                                 hipLaunchKernelGGL((patch_conv_fwd_k1m_kernel<MTV, KQV, PXV, AFV, bf16_t>), grid, dim3(256), 0, stream, a, scale, shift, act))
 #define HS_FW(MTV, KQV) if (mt == MTV && kq == KQV) { \
-        if (px2) HS_T2(dtype, hipLaunchKernelGGL((patch_conv_fwd_k1m_kernel<MTV, KQV, 2, float>), grid, dim3(256), 0, stream, a, scale, shift, act), \
-                              hipLaunchKernelGGL((patch_conv_fwd_k1m_kernel<MTV, KQV, 2, bf16_t>), grid, dim3(256), 0, stream, a, scale, shift, act)); \
-        else HS_T2(dtype, hipLaunchKernelGGL((patch_conv_fwd_k1m_kernel<MTV, KQV, 1, float>), grid, dim3(256), 0, stream, a, scale, shift, act), \
-                          hipLaunchKernelGGL((patch_conv_fwd_k1m_kernel<MTV, KQV, 1, bf16_t>), grid, dim3(256), 0, stream, a, scale, shift, act)); \
+        if (px2 && affine) HS_FW_L(MTV, KQV, 2, true); else if (px2) HS_FW_L(MTV, KQV, 2, false); \
+        else if (affine) HS_FW_L(MTV, KQV, 1, true); else HS_FW_L(MTV, KQV, 1, false); \
         return launch_status(); }
     HS_FW(1, 1) HS_FW(1, 2) HS_FW(1, 3) HS_FW(1, 4) HS_FW(2, 1) HS_FW(2, 2) HS_FW(2, 3) HS_FW(2, 4)
     HS_FW(3, 1) HS_FW(3, 2) HS_FW(3, 3) HS_FW(3, 4) HS_FW(4, 1) HS_FW(4, 2) HS_FW(4, 3)
 #undef HS_FW
+#undef HS_FW_L
     return 1;
 }
 

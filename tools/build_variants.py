@@ -133,6 +133,7 @@ VARIANTS = {
     'irc_wide_store': dict(flags=['-DHS_IRC_WIDE_STORE'], extra=[], patch=None),         # round 4: the level-4 epilogue re-laid through LDS into 16-byte stores (measured slower)
     'irc_nw8': dict(flags=['-DHS_IRC_NW=8'], extra=[], patch=None),                      # round 4: eight waves per 16 x 16 region (four per SIMD at two workgroups per CU)
     'irc_r3': dict(flags=[], extra=[], patch='irc_r3', file='hs_patch_irc.hip'),          # round 3's level-4 kernel
+    'gs_tail_switch': dict(flags=[], extra=[], patch='git:b89aa7e', file='hs_gemm_split.hip'),   # round 4: the split GEMM with apply_act(v, a.act) inside the unrolled tail
     'st_slice64': dict(flags=['-DHS_ST_SLICE=64'], extra=[], patch=None),                 # round 4: patches per dW slice of the s2w backward (product: 256)
     'st_slice128': dict(flags=['-DHS_ST_SLICE=128'], extra=[], patch=None),
     's2wt_noA': dict(flags=[], extra=[], patch='s2wt_noA', file='hs_s2w_train.hip'),
@@ -140,6 +141,16 @@ VARIANTS = {
     's2wt_nomfma': dict(flags=[], extra=[], patch='s2wt_nomfma', file='hs_s2w_train.hip'),
     's2wt_nostore': dict(flags=[], extra=[], patch='s2wt_nostore', file='hs_s2w_train.hip'),
 }
+
+def git_source(rev, fname, tag):
+    """<rev>:hyperseg_amd/csrc/<fname> as a dev source (same-box A/B of a kernel file against an earlier commit)."""
+    import subprocess
+    os.makedirs(os.path.join(B.LIB_DIR, 'dev_src'), exist_ok=True)
+    path = os.path.join(B.LIB_DIR, 'dev_src', fname.replace('.hip', f'_{tag}.hip'))
+    src = subprocess.run(['git', 'show', f'{rev}:hyperseg_amd/csrc/{fname}'], cwd=B.REPO, capture_output=True, text=True, check=True).stdout
+    open(path, 'w').write(src)
+    return path
+
 
 def r3_irc_source():
     """Round 3's hs_patch_irc.hip (git show e068d5a:...), for same-box A/B runs against the round-4 prologue."""
@@ -159,7 +170,7 @@ if __name__ == '__main__':
         sources = list(B.SOURCES) + v['extra']
         if v.get('patch'):
             fname = v.get('file', 'hs_patch_ir_fused.hip')
-            src_path = r3_irc_source() if v['patch'] == 'irc_r3' else stamped_irc_source() if v['patch'] == 'irc' else stamped_source(fname) if v['patch'] is True else \
+            src_path = git_source(v['patch'][4:], fname, name) if str(v['patch']).startswith('git:') else r3_irc_source() if v['patch'] == 'irc_r3' else stamped_irc_source() if v['patch'] == 'irc' else stamped_source(fname) if v['patch'] is True else \
                 patched_source(v['patch'], PATCHES[v['patch']], fname)
             rel = os.path.relpath(src_path, B.CSRC)
             sources = [rel if s == fname else s for s in sources]
