@@ -182,11 +182,10 @@ void patch_conv_bwd_weight_k1m_kernel(ConvBwdArgs a) {
             for (int h = 0; h < 2; ++h) {
                 const int l = 16 * s + 4 * kg + 2 * h, lc = min(l, npix - 2), u = div_by_inv(lc, a.inv_pw), v = lc - u * a.pw;   // npix even: a pair is live or not
                 const size_t off = (size_t)u * a.W + v;
-                const float live = l < npix ? 1.0f : 0.0f;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const bw_f32x2 p = *reinterpret_cast<const bw_f32x2*>((const float*)dyp[mt] + off);
-                    av[mt][2 * h] = p[0] * live; av[mt][2 * h + 1] = p[1] * live;
+                    av[mt][2 * h] = p[0]; av[mt][2 * h + 1] = p[1];         // (the pixels past the patch are masked in products())
                 }
 #pragma unroll
                 for (int nt = 0; nt < NTI; ++nt) {
@@ -195,7 +194,7 @@ void patch_conv_bwd_weight_k1m_kernel(ConvBwdArgs a) {
                 }
             }
         } else if constexpr (VEC == 1) {
-            const int l = 16 * s + 4 * kg, u = div_by_inv(l, a.inv_pw), v = l - u * a.pw;   // pw % 4 == 0: the lane's 4 pixels are one row segment
+            const int l = min(16 * s + 4 * kg, npix - 4), u = div_by_inv(l, a.inv_pw), v = l - u * a.pw;   // pw % 4 == 0: the lane's 4 pixels are one row segment (clamped: chunks past the end are fetched, never used)
             const size_t off = (size_t)u * a.W + v;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const bw_f32x4*>((const float*)dyp[mt] + off);
@@ -206,9 +205,8 @@ void patch_conv_bwd_weight_k1m_kernel(ConvBwdArgs a) {
             for (int j = 0; j < 4; ++j) {
                 const int l = 16 * s + 4 * kg + j, lc = min(l, npix - 1), u = div_by_inv(lc, a.inv_pw), v = lc - u * a.pw;
                 const size_t off = (size_t)u * a.W + v;
-                const float live = l < npix ? 1.0f : 0.0f;               // clamped address, masked by a multiply (no branch around a load)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) av[mt][j] = Store<T>::ld(dyp[mt], off) * live;
+                for (int mt = 0; mt < MT; ++mt) av[mt][j] = Store<T>::ld(dyp[mt], off);     // clamped address; masked by a multiply in products()
 #pragma unroll
                 for (int nt = 0; nt < NTI; ++nt) bv[nt][j] = Store<T>::ld(xp[nt], off);
             }
@@ -219,24 +217,38 @@ void patch_conv_bwd_weight_k1m_kernel(ConvBwdArgs a) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NTI; ++nt) acc[mt][nt] = bw_f32x4{0.f, 0.f, 0.f, 0.f};
-    auto products = [&](const bw_f32x4 (&av)[MT], const bw_f32x4 (&bv)[NTI]) {
+    // (the mask of the last, partial chunk is applied HERE, on use: as a multiply inside fetch() it made the pipeline below wait for a
+    //  chunk's loads as soon as they were issued)
+    auto products = [&](int s, const bw_f32x4 (&av)[MT], const bw_f32x4 (&bv)[NTI]) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
+            const float live = (VEC == 1 || 16 * s + 4 * kg + j < npix) ? 1.0f : 0.0f;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt) {
+                const float am = VEC == 1 ? av[mt][j] : av[mt][j] * live;
 #pragma unroll
-                for (int nt = 0; nt < NTI; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][j], bv[nt][j], acc[mt][nt], 0, 0, 0);
+                for (int nt = 0; nt < NTI; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(am, bv[nt][j], acc[mt][nt], 0, 0, 0);
+            }
+        }
     };
+    // two operand buffers, every fetch of the steady path unconditional (a chunk past the end reads the patch's last pixels again and is
+    // never multiplied): with `if (s < nch) fetch(...)` the compiler had folded the two halves back into one load -> wait -> 24 products
+    // loop -- no request in flight under the products, one exposed round trip per chunk (k1m_pixel_stream below has the same story)
     bw_f32x4 a0[MT], b0[NTI], a1[MT], b1[NTI];
     int s = wave;
-    if (s < nch) fetch(s, a0, b0);
-    for (; s + 4 < nch; s += 8) {                                        // two chunks per trip, the next one's operands in flight
-        fetch(s + 4, a1, b1);
-        products(a0, b0);
-        if (s + 8 < nch) fetch(s + 8, a0, b0);
-        products(a1, b1);
+    fetch(s, a0, b0);
+    fetch(s + 4, a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    for (; s + 8 < nch; s += 8) {
+        products(s, a0, b0);
+        fetch(s + 8, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        products(s + 4, a1, b1);
+        fetch(s + 12, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
     }
-    if (s < nch) products(a0, b0);
+    if (s < nch) products(s, a0, b0);
+    if (s + 4 < nch) products(s + 4, a1, b1);
     // ---- the four partial tiles meet in LDS; element (tile, lane, r) = D row 4 (lane / 16) + r, column lane % 16
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -258,9 +270,11 @@ void patch_conv_bwd_weight_k1m_kernel(ConvBwdArgs a) {
 // 16 t + n of tile t.  PX = 2 (round 4; even patch and image widths): a lane owns the ADJACENT pixels 32 t + 2 n and + 1 of a 32-pixel
 // super-tile -- one 8-byte load per input row and one 8-byte store per output row instead of two 4-byte ones (16 lanes cover 128
 // contiguous bytes instead of 64), the even and the odd pixels going through the matrix cores as two tiles.  Same products in the same
-// order per pixel: bit-identical to PX = 1.
+// order per pixel: bit-identical to PX = 1.  `aw` arrives as LOADED (clamped addresses); its reduction slots k >= kin are zeroed here, after
+// the first two tiles' requests have left (the stream reads a repeated row there): masks on either operand ahead of those requests made the
+// compiler wait for everything before the second tile's loads were issued -- one exposed round trip per workgroup.
 template <int MT, int KQ, int PX, typename T, typename EPI>
-__device__ __forceinline__ void k1m_pixel_stream(const ConvBwdArgs& a, const float (&aw)[MT][KQ][4], const T* __restrict__ src, T* __restrict__ dst,
+__device__ __forceinline__ void k1m_pixel_stream(const ConvBwdArgs& a, float (&aw)[MT][KQ][4], const T* __restrict__ src, T* __restrict__ dst,
                                                  int kin, int mout, size_t plane, int n, int kg, int wave, EPI epi) {
     constexpr int TP = 16 * PX;                                         // pixels per (super-)tile
     const int npix = a.ph * a.pw, ntile = (npix + TP - 1) / TP;
@@ -273,14 +287,10 @@ __device__ __forceinline__ void k1m_pixel_stream(const ConvBwdArgs& a, const flo
             for (int j = 0; j < 4; ++j) {
                 const int k = 16 * q + 4 * kg + j;
                 const size_t at = (size_t)min(k, kin - 1) * plane + off;
-                if constexpr (PX == 2) {
-                    float v0, v1;
-                    Pair<T>::ld(src, at, v0, v1);
-                    bv[0][q][j] = k < kin ? v0 : 0.0f; bv[1][q][j] = k < kin ? v1 : 0.0f;
-                } else {
-                    const float val = Store<T>::ld(src, at);
-                    bv[0][q][j] = k < kin ? val : 0.0f;
-                }
+                // rows past kin repeat the last row: the caller's A fragments are ZERO there (a select on the loaded value here made the
+                // compiler wait for this tile's loads before it issued the next tile's: one exposed round trip per workgroup)
+                if constexpr (PX == 2) Pair<T>::ld(src, at, bv[0][q][j], bv[1][q][j]);
+                else bv[0][q][j] = Store<T>::ld(src, at);
             }
     };
     auto tile = [&](int t, const float (&bv)[PX][KQ][4], size_t off) {
@@ -306,17 +316,38 @@ __device__ __forceinline__ void k1m_pixel_stream(const ConvBwdArgs& a, const flo
             }
         }
     };
+    // Software pipeline over two operand buffers.  Every fetch on the steady path is UNCONDITIONAL (a tile index past the end reads the
+    // patch's last pixels again -- fetch clamps -- and is never stored): a fetch under `if (t < ntile)` is a control-flow join at which the
+    // compiler's wait-count bookkeeping assumes the shorter path, i.e. waits for the newest loads instead of the oldest -- vmcnt(0) before
+    // the first product with the second tile's requests in the queue (ISA of visit r5d's build).
     float b0[PX][KQ][4], b1[PX][KQ][4];
     size_t o0 = 0, o1 = 0;
     int t = wave;
-    if (t < ntile) fetch(t, b0, o0);
-    for (; t + 4 < ntile; t += 8) {
-        fetch(t + 4, b1, o1);
+    // @stamp 0
+    fetch(t, b0, o0);
+    fetch(t + 4, b1, o1);
+    __builtin_amdgcn_sched_barrier(0);
+    // @stamp 1
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int q = 0; q < KQ; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) aw[mt][q][j] = 16 * q + 4 * kg + j < kin ? aw[mt][q][j] : 0.0f;
+    // @stamp 2
+    for (; t + 8 < ntile; t += 8) {                                     // tiles t and t + 4 exist, t + 8 does: both buffers are refilled
         tile(t, b0, o0);
-        if (t + 8 < ntile) fetch(t + 8, b0, o0);
+        // @stamp 3 + (t >> 2 < 10 ? t >> 2 : 10)
+        fetch(t + 8, b0, o0);
+        __builtin_amdgcn_sched_barrier(0);
         tile(t + 4, b1, o1);
+        fetch(t + 12, b1, o1);
+        __builtin_amdgcn_sched_barrier(0);
     }
+    // @stamp 20
     if (t < ntile) tile(t, b0, o0);
+    if (t + 4 < ntile) tile(t + 4, b1, o1);
+    // @stamp 24
 }
 
 template <int CT, int KQ, int PX, typename T>
@@ -329,7 +360,14 @@ void patch_conv_bwd_input_k1m_kernel(ConvBwdArgs a) {
     const size_t plane = (size_t)a.H * a.W;
     // A[i = input channel][k = output channel] = W[o][c]: this patch's bank row, o = 16 q + 4 kg + j, c = 16 ct + n (clamped: the
     // rows / columns beyond the layer multiply zeros of B or land in rows that are never stored)
+    // The patch's weights go through LDS: ONE coalesced pass of the workgroup over the bank row, then every lane picks its fragment
+    // elements with ds_read.  Picked straight from global memory -- 24 loads per lane, each instruction 64 scattered dwords, every wave of
+    // the workgroup fetching the same fragments again -- they held the CU's address path for ~8 k cycles before the first pixel request
+    // got through (tools/k1m_phase_times.py, visit r5e: 8.2 k of a workgroup's 25 k cycles at config 5's level 4, 4.8 k of 12.8 k at level 3).
+    __shared__ float wl[16 * KQ * 16 * CT];
     const float* __restrict__ wp = a.bank + (size_t)patch * a.ld;
+    for (int e = tid; e < a.cout * a.cin; e += 256) wl[e] = wp[e];
+    __syncthreads();
     float aw[CT][KQ][4];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
@@ -337,7 +375,7 @@ void patch_conv_bwd_input_k1m_kernel(ConvBwdArgs a) {
         for (int q = 0; q < KQ; ++q)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                aw[ct][q][j] = wp[(size_t)min(16 * q + 4 * kg + j, a.cout - 1) * a.cin + min(16 * ct + n, a.cin - 1)];
+                aw[ct][q][j] = wl[min(16 * q + 4 * kg + j, a.cout - 1) * a.cin + min(16 * ct + n, a.cin - 1)];
     const size_t org = (size_t)(pi * a.ph) * a.W + pj * a.pw;
     const T* __restrict__ dyb = (const T*)a.dy + (size_t)b * a.cout * plane + org;
     T* __restrict__ dxb = (T*)a.dx + (size_t)b * a.cin * plane + org;
@@ -360,7 +398,10 @@ void patch_conv_fwd_k1m_kernel(ConvBwdArgs a, const float* __restrict__ scale, c
     const int patch = blockIdx.x;
     const int pj = patch % a.fw, pi = (patch / a.fw) % a.fh, b = patch / (a.fw * a.fh);
     const size_t plane = (size_t)a.H * a.W;
+    __shared__ float wl[16 * MT * 16 * KQ];                             // the patch's weights, staged by one coalesced pass (see the input-gradient kernel)
     const float* __restrict__ wp = a.bank + (size_t)patch * a.ld;
+    for (int e = tid; e < a.cout * a.cin; e += 256) wl[e] = wp[e];
+    __syncthreads();
     float aw[MT][KQ][4];                                                // A[i = output channel][k = input channel]
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -368,7 +409,7 @@ void patch_conv_fwd_k1m_kernel(ConvBwdArgs a, const float* __restrict__ scale, c
         for (int q = 0; q < KQ; ++q)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                aw[mt][q][j] = wp[(size_t)min(16 * mt + n, a.cout - 1) * a.cin + min(16 * q + 4 * kg + j, a.cin - 1)];
+                aw[mt][q][j] = wl[min(16 * mt + n, a.cout - 1) * a.cin + min(16 * q + 4 * kg + j, a.cin - 1)];
     const size_t org = (size_t)(pi * a.ph) * a.W + pj * a.pw;
     const T* __restrict__ xb = (const T*)a.dy + (size_t)b * a.cin * plane + org;
     T* __restrict__ yb = (T*)a.dx + (size_t)b * a.cout * plane + org;
