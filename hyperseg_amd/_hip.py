@@ -79,13 +79,13 @@ def _load():
         'hs_patch_ir_v0_ws_fwd': ([C.POINTER(StageInputC), i32, i32, vp, i64, i32, i32, C.POINTER(EpilogueC),
                                    C.POINTER(EpilogueC), C.POINTER(EpilogueC), i32, vp, i64, vp, vp], C.c_int),
         'hs_patch_ir_v0_workspace': ([C.POINTER(StageInputC), i32, i32, i32, i32], C.c_int64),
-        'hs_halo_tiles_fwd': ([i32, vp, i32, i32, i32, i32, i32, i32, vp, vp], C.c_int),
-        'hs_halo_tiles_bwd': ([i32, vp, i32, i32, i32, i32, i32, i32, vp, vp], C.c_int),
+        'hs_halo_tiles_fwd': ([i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp], C.c_int),
+        'hs_halo_tiles_bwd': ([i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp], C.c_int),
         'hs_tile_interior_fwd': ([i32, vp, i32, i32, i32, i32, i32, i32, vp, vp], C.c_int),
         'hs_tile_interior_bwd': ([i32, vp, i32, i32, i32, i32, i32, i32, vp, vp], C.c_int),
-        'hs_dw_tiles_fwd': ([i32, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp, vp], C.c_int),
-        'hs_dw_tiles_bwd_in': ([i32, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp, vp], C.c_int),
-        'hs_dw_tiles_bwd_w': ([i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, i64, vp], C.c_int),
+        'hs_dw_tiles_fwd': ([i32, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp, i32, vp], C.c_int),
+        'hs_dw_tiles_bwd_in': ([i32, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp, i32, vp], C.c_int),
+        'hs_dw_tiles_bwd_w': ([i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, i64, i32, vp], C.c_int),
         'hs_bank_unpack_fwd': ([vp, i64, i32, i32, i32, i32, i32, i32, vp, vp], C.c_int),
         'hs_upsample_bilinear_bwd': ([vp, i64, i32, i32, i32, i32, i32, i32, vp, vp], C.c_int),
         'hs_upsample_bilinear_bf16_fwd': ([vp, i32, i32, i32, i32, i32, i32, vp, vp], C.c_int),

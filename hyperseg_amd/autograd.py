@@ -104,32 +104,37 @@ class PatchConv(torch.autograd.Function):
         return dx, dbank, None, None, None, None, None, None
 
 
-def _tile_call(name, dtype, src, b, c, h, w, grid, dst):
-    st = getattr(_hip.lib, name)(DTYPE_CODES[dtype], src.data_ptr(), b, c, h, w, grid[0], grid[1], dst.data_ptr(), _hip.stream_ptr())
+def _tile_call(name, dtype, src, b, c, h, w, grid, dst, layout=None):
+    args = (DTYPE_CODES[dtype], src.data_ptr(), b, c, h, w, grid[0], grid[1], dst.data_ptr())
+    st = getattr(_hip.lib, name)(*args, _hip.stream_ptr()) if layout is None else getattr(_hip.lib, name)(*args, int(layout), _hip.stream_ptr())
     _hip.check(st, name)
     return dst
 
 
 class HaloTiles(torch.autograd.Function):
-    """x (B, C, H, W) -> the image of reflect-padded halo tiles (B, C, fh (ph+2), fw (pw+2)): F.pad(reflect) -> unfold -> unfold ->
-    permute -> reshape of models/hyperseg_v1_0.py _run_train as ONE gather (hs_halo_tiles_fwd), its adjoint as one gather too."""
+    """x (B, C, H, W) -> its reflect-padded halo tiles: F.pad(reflect) -> unfold -> unfold -> permute -> reshape of models/hyperseg_v1_0.py
+    _run_train as ONE gather (hs_halo_tiles_fwd), the adjoint as one gather too.  ``patch_major`` False: the tiles side by side as one
+    image (B, C, fh (ph+2), fw (pw+2)); True: one tile after the other, (B fh fw, C, ph+2, pw+2) -- every operand of a patch contiguous,
+    the block's 1x1 layers then run as patch convolutions with a (1, 1) grid over B fh fw frames."""
 
     @staticmethod
-    def forward(ctx, x, grid):
+    def forward(ctx, x, grid, patch_major=False):
         x = x.contiguous()
         b, c, h, w = x.shape
         fh, fw = grid
-        ctx.meta = (b, c, h, w, (fh, fw), x.dtype)
+        ctx.meta = (b, c, h, w, (fh, fw), x.dtype, bool(patch_major))
         with _hip.device_scope(x.device):
-            out = torch.empty(b, c, fh * (h // fh + 2), fw * (w // fw + 2), device=x.device, dtype=x.dtype)
-            return _tile_call('hs_halo_tiles_fwd', x.dtype, x, b, c, h, w, (fh, fw), out)
+            shape = (b * fh * fw, c, h // fh + 2, w // fw + 2) if patch_major else (b, c, fh * (h // fh + 2), fw * (w // fw + 2))
+            out = torch.empty(shape, device=x.device, dtype=x.dtype)
+            return _tile_call('hs_halo_tiles_fwd', x.dtype, x, b, c, h, w, (fh, fw), out, layout=patch_major)
 
     @staticmethod
     def backward(ctx, dt):
-        b, c, h, w, grid, dtype = ctx.meta
+        b, c, h, w, grid, dtype, pm = ctx.meta
         dt = dt.contiguous().to(dtype)
         with _hip.device_scope(dt.device):
-            return _tile_call('hs_halo_tiles_bwd', dtype, dt, b, c, h, w, grid, torch.empty(b, c, h, w, device=dt.device, dtype=dtype)), None
+            return _tile_call('hs_halo_tiles_bwd', dtype, dt, b, c, h, w, grid, torch.empty(b, c, h, w, device=dt.device, dtype=dtype),
+                              layout=pm), None, None
 
 
 class TileInterior(torch.autograd.Function):
@@ -154,21 +159,23 @@ class TileInterior(torch.autograd.Function):
 
 class DwTilesValid(torch.autograd.Function):
     """The middle layer of a train-mode v1_0 inverted residual: a VALID depthwise 3x3 of every halo tile with the patch's own taps
-    (hyperseg_v1_0.py:352-360), tile image (B, C, fh (ph+2), fw (pw+2)) -> (B, C, H, W), one launch per direction and operand
-    (hs_dw_tiles_fwd / _bwd_in / _bwd_w).  ``bank``: the depthwise column range (P, 9 C) of the block's fp32 bank (a view)."""
+    (hyperseg_v1_0.py:352-360), tiles -> (B, C, H, W), one launch per direction and operand (hs_dw_tiles_fwd / _bwd_in / _bwd_w).
+    ``t``: the tiles as HaloTiles lays them out (``patch_major`` alike); ``bank``: the depthwise column range (P, 9 C) of the block's
+    fp32 bank (a view)."""
 
     @staticmethod
-    def forward(ctx, t, bank, size, grid):
+    def forward(ctx, t, bank, size, grid, patch_major=False):
         t = t.contiguous()
-        b, c = t.shape[:2]
         h, w = size
+        c = t.shape[1]
+        b = t.shape[0] // (grid[0] * grid[1]) if patch_major else t.shape[0]
         if bank.dtype != torch.float32 or bank.stride(1) != 1:
             bank = bank.float().contiguous()
-        ctx.meta = (b, c, h, w, tuple(grid), t.dtype)
+        ctx.meta = (b, c, h, w, tuple(grid), t.dtype, bool(patch_major))
         with _hip.device_scope(t.device):
             y = torch.empty(b, c, h, w, device=t.device, dtype=t.dtype)
             st = _hip.lib.hs_dw_tiles_fwd(DTYPE_CODES[t.dtype], t.data_ptr(), bank.data_ptr(), bank.stride(0), b, c, h, w, grid[0], grid[1],
-                                          y.data_ptr(), _hip.stream_ptr())
+                                          y.data_ptr(), int(patch_major), _hip.stream_ptr())
             _hip.check(st, 'hs_dw_tiles_fwd')
         ctx.save_for_backward(t, bank)
         return y
@@ -176,22 +183,22 @@ class DwTilesValid(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         t, bank = ctx.saved_tensors
-        b, c, h, w, grid, dtype = ctx.meta
+        b, c, h, w, grid, dtype, pm = ctx.meta
         dy = dy.contiguous().to(dtype)
         dt = dbank = None
         with _hip.device_scope(dy.device):
             if ctx.needs_input_grad[0]:
                 dt = torch.empty_like(t)
                 st = _hip.lib.hs_dw_tiles_bwd_in(DTYPE_CODES[dtype], dy.data_ptr(), bank.data_ptr(), bank.stride(0), b, c, h, w, grid[0], grid[1],
-                                                 dt.data_ptr(), _hip.stream_ptr())
+                                                 dt.data_ptr(), int(pm), _hip.stream_ptr())
                 _hip.check(st, 'hs_dw_tiles_bwd_in')
             if ctx.needs_input_grad[1]:
                 alloc = torch.empty if bank.shape[1] == 9 * c else torch.zeros
                 dbank = alloc(bank.shape[0], bank.shape[1], device=dy.device, dtype=torch.float32)
                 st = _hip.lib.hs_dw_tiles_bwd_w(DTYPE_CODES[dtype], t.data_ptr(), dy.data_ptr(), b, c, h, w, grid[0], grid[1], dbank.data_ptr(),
-                                                dbank.stride(0), _hip.stream_ptr())
+                                                dbank.stride(0), int(pm), _hip.stream_ptr())
                 _hip.check(st, 'hs_dw_tiles_bwd_w')
-        return dt, dbank, None, None
+        return dt, dbank, None, None, None
 
 
 def dw_tiles_supported(t, size, grid):
@@ -200,6 +207,7 @@ def dw_tiles_supported(t, size, grid):
 
 
 USE_HIP_DW_TILES = True     # tests switch it off to compare with the two-launch route (zero-padded depthwise on the tile image + TileInterior)
+USE_PATCH_MAJOR_TILES = True   # the block's tiles one after the other instead of side by side (contiguous per-patch operands); off: the image of tiles
 
 
 def tiles_supported(x):

@@ -733,7 +733,17 @@ struct DwtArgs {
     long ld;
     int B, C, H, W, fh, fw, ph, pw;
     float inv_ph, inv_pw, inv_ph2, inv_pw2, inv_c;
+    int pm;                            // layout of the tiles: 0 = image of tiles (B, C, fh (ph+2), fw (pw+2)), 1 = patch-major (B fh fw, C, ph+2, pw+2)
 };
+// origin of tile (i, j), channel c of frame b, and the distance between its rows
+__device__ __forceinline__ size_t dwt_tile(const DwtArgs& a, int b, int c, int i, int j, int& row_stride) {
+    if (a.pm) {
+        row_stride = a.pw + 2;
+        return ((((size_t)b * a.fh + i) * a.fw + j) * a.C + c) * (size_t)((a.ph + 2) * (a.pw + 2));
+    }
+    row_stride = a.fw * (a.pw + 2);
+    return (((size_t)b * a.C + c) * (size_t)(a.fh * (a.ph + 2)) + (size_t)i * (a.ph + 2)) * row_stride + (size_t)j * (a.pw + 2);
+}
 
 template <typename T>
 __global__ __launch_bounds__(256)
@@ -743,8 +753,8 @@ void dw_tiles_fwd_kernel(DwtArgs a, const T* __restrict__ t, T* __restrict__ y) 
     if (x0 >= a.W || yy >= a.H) return;
     const int b = div_by_inv(plane_id, a.inv_c), c = plane_id - b * a.C;
     const int i = div_by_inv(yy, a.inv_ph), u = yy - i * a.ph, j = div_by_inv(x0, a.inv_pw), v = x0 - j * a.pw;
-    const int TW = a.fw * (a.pw + 2), TH = a.fh * (a.ph + 2);
-    const T* __restrict__ tp = t + ((size_t)plane_id * TH + (size_t)i * (a.ph + 2) + u) * TW + (size_t)j * (a.pw + 2) + v;
+    int TW;
+    const T* __restrict__ tp = t + dwt_tile(a, b, c, i, j, TW) + (size_t)u * TW + v;
     const float* __restrict__ kp = a.bank + (size_t)((b * a.fh + i) * a.fw + j) * a.ld + c * 9;
     float s[3][4], kv[9];
 #pragma unroll
@@ -802,7 +812,9 @@ void dw_tiles_bwd_in_kernel(DwtArgs a, const T* __restrict__ dy, T* __restrict__
             acc0 = fmaf(kv[ky * 3 + kx], g[2 - ky][2 - kx], acc0);
             acc1 = fmaf(kv[ky * 3 + kx], g[2 - ky][3 - kx], acc1);
         }
-    Pair<T>::st(dt, ((size_t)plane_id * TH + Y) * TW + X0, acc0, acc1);
+    int RS;
+    const size_t torg = dwt_tile(a, b, c, i, j, RS);
+    Pair<T>::st(dt, torg + (size_t)U * RS + V0, acc0, acc1);
 }
 
 // dK[patch][c][ky][kx] = sum over the patch's outputs (u, v) of dy[u][v] t[u + ky][v + kx]: one wave per (patch, channel), a lane owns output pairs
@@ -813,8 +825,8 @@ void dw_tiles_bwd_w_kernel(DwtArgs a, const T* __restrict__ t, const T* __restri
     const int patch = blockIdx.x, c = blockIdx.y * 4 + wave;
     if (c >= a.C) return;
     const int j = patch % a.fw, i = (patch / a.fw) % a.fh, b = patch / (a.fw * a.fh);
-    const int TW = a.fw * (a.pw + 2), TH = a.fh * (a.ph + 2);
-    const T* __restrict__ tp = t + (((size_t)b * a.C + c) * TH + (size_t)i * (a.ph + 2)) * TW + (size_t)j * (a.pw + 2);
+    int TW;
+    const T* __restrict__ tp = t + dwt_tile(a, b, c, i, j, TW);
     const T* __restrict__ gp = dy + (((size_t)b * a.C + c) * a.H + (size_t)i * a.ph) * a.W + (size_t)j * a.pw;
     const int hw = a.pw >> 1, npair = a.ph * hw;
     const float inv_hw = 2.0f * a.inv_pw;
@@ -844,7 +856,7 @@ void dw_tiles_bwd_w_kernel(DwtArgs a, const T* __restrict__ t, const T* __restri
     }
 }
 
-static int dwt_args(DwtArgs& a, int dtype, const void* p, const void* q, long ld, int B, int C, int H, int W, int fh, int fw) {
+static int dwt_args(DwtArgs& a, int dtype, const void* p, const void* q, long ld, int B, int C, int H, int W, int fh, int fw, int pm) {
     if (!p || !q || B <= 0 || C <= 0 || H <= 0 || W <= 0 || fh <= 0 || fw <= 0 || ld < 9L * C) return HS_ERR_BAD_ARG;
     if (dtype != HS_DTYPE_F32 && dtype != HS_DTYPE_BF16) return HS_ERR_BAD_ARG;
     if (H % fh || W % fw) return HS_ERR_NOT_DIVISIBLE;
@@ -852,7 +864,7 @@ static int dwt_args(DwtArgs& a, int dtype, const void* p, const void* q, long ld
     // pairs: even patch width (then W and the tile image's width are even too); 8-byte aligned tensors; div_by_inv's range
     if ((pw & 1) || ((((size_t)p) | ((size_t)q)) & 7) || (long)B * C > 65535 || H + 2 * fh >= (1 << 21) || W + 2 * fw >= (1 << 21)) return HS_ERR_UNSUPPORTED;
     a = DwtArgs{nullptr, nullptr, ld, B, C, H, W, fh, fw, ph, pw, 1.0f / (float)ph, 1.0f / (float)pw, 1.0f / (float)(ph + 2), 1.0f / (float)(pw + 2),
-                1.0f / (float)C};
+                1.0f / (float)C, pm ? 1 : 0};
     return HS_OK;
 }
 
@@ -1081,9 +1093,9 @@ extern "C" int hs_patch_conv_bwd_weight(const float* x, const float* dy, int32_t
 
 // ---- valid depthwise 3 x 3 on halo tiles (dw_tiles_*): the middle layer of a train-mode v1_0 inverted residual, tile image <-> (B, C, H, W)
 extern "C" int hs_dw_tiles_fwd(int32_t dtype, const void* tiled, const float* bank, int64_t ld, int32_t batch, int32_t channels, int32_t H,
-                               int32_t W, int32_t fh, int32_t fw, void* y, void* stream) {
+                               int32_t W, int32_t fh, int32_t fw, void* y, int32_t patch_major, void* stream) {
     DwtArgs a;
-    const int st = dwt_args(a, dtype, tiled, y, (long)ld, batch, channels, H, W, fh, fw);
+    const int st = dwt_args(a, dtype, tiled, y, (long)ld, batch, channels, H, W, fh, fw, patch_major);
     if (st != HS_OK) return st;
     if (!bank || (((size_t)bank) & 3)) return HS_ERR_BAD_ARG;
     a.bank = bank;
@@ -1094,9 +1106,9 @@ extern "C" int hs_dw_tiles_fwd(int32_t dtype, const void* tiled, const float* ba
 }
 
 extern "C" int hs_dw_tiles_bwd_in(int32_t dtype, const void* dy, const float* bank, int64_t ld, int32_t batch, int32_t channels, int32_t H,
-                                  int32_t W, int32_t fh, int32_t fw, void* dtiled, void* stream) {
+                                  int32_t W, int32_t fh, int32_t fw, void* dtiled, int32_t patch_major, void* stream) {
     DwtArgs a;
-    const int st = dwt_args(a, dtype, dy, dtiled, (long)ld, batch, channels, H, W, fh, fw);
+    const int st = dwt_args(a, dtype, dy, dtiled, (long)ld, batch, channels, H, W, fh, fw, patch_major);
     if (st != HS_OK) return st;
     if (!bank) return HS_ERR_BAD_ARG;
     a.bank = bank;
@@ -1107,9 +1119,9 @@ extern "C" int hs_dw_tiles_bwd_in(int32_t dtype, const void* dy, const float* ba
 }
 
 extern "C" int hs_dw_tiles_bwd_w(int32_t dtype, const void* tiled, const void* dy, int32_t batch, int32_t channels, int32_t H, int32_t W,
-                                 int32_t fh, int32_t fw, float* dbank, int64_t ld, void* stream) {
+                                 int32_t fh, int32_t fw, float* dbank, int64_t ld, int32_t patch_major, void* stream) {
     DwtArgs a;
-    const int st = dwt_args(a, dtype, tiled, dy, (long)ld, batch, channels, H, W, fh, fw);
+    const int st = dwt_args(a, dtype, tiled, dy, (long)ld, batch, channels, H, W, fh, fw, patch_major);
     if (st != HS_OK) return st;
     if (!dbank) return HS_ERR_BAD_ARG;
     a.dbank = dbank;

@@ -17,7 +17,18 @@
 
 namespace hs {
 
-struct TileArgs { int B, C, H, W, fh, fw, ph, pw; float inv_ph, inv_pw, inv_ph2, inv_pw2; };      // reciprocals of ph, pw, ph + 2, pw + 2 (div_by_inv)
+struct TileArgs { int B, C, H, W, fh, fw, ph, pw; float inv_ph, inv_pw, inv_ph2, inv_pw2; int pm; };      // reciprocals of ph, pw, ph + 2, pw + 2 (div_by_inv)
+// Where tile (i, j) of plane pl = b C + c keeps its position (U, V).  pm = 0: the IMAGE of tiles (B, C, fh (ph+2), fw (pw+2)) -- tiles side by
+// side, what the generic patch convolutions take.  pm = 1: PATCH-MAJOR (B fh fw, C, ph+2, pw+2) -- every operand of a patch one contiguous
+// run, each patch a 1 x 1-grid "image" of its own for the patch convolutions (round 4: in the image of tiles a tile row is 72 bytes of a
+// 128-byte line that the neighbouring tile's workgroup fetches again).
+__device__ __forceinline__ size_t tile_addr(const TileArgs& a, size_t pl, int i, int U, int j, int V) {
+    if (a.pm) {
+        const int b = (int)pl / a.C, c = (int)pl - b * a.C;              // (uniform: pl = blockIdx.z)
+        return ((((size_t)b * a.fh + i) * a.fw + j) * a.C + c) * (size_t)((a.ph + 2) * (a.pw + 2)) + (size_t)U * (a.pw + 2) + V;
+    }
+    return (pl * (size_t)(a.fh * (a.ph + 2)) + (size_t)i * (a.ph + 2) + U) * (size_t)(a.fw * (a.pw + 2)) + (size_t)j * (a.pw + 2) + V;
+}
 
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
 
@@ -30,7 +41,7 @@ void halo_tiles_fwd_kernel(TileArgs a, const T* __restrict__ x, T* __restrict__ 
     const int i = div_by_inv(Y, a.inv_ph2), u = Y - i * (a.ph + 2), j = div_by_inv(X, a.inv_pw2), v = X - j * (a.pw + 2);
     const int y = reflect1(i * a.ph + u - 1, a.H), xx = reflect1(j * a.pw + v - 1, a.W);
     const size_t pl = blockIdx.z;
-    Store<T>::st(t, (pl * TH + Y) * TW + X, Store<T>::ld(x, (pl * a.H + y) * a.W + xx));
+    Store<T>::st(t, tile_addr(a, pl, i, u, j, v), Store<T>::ld(x, (pl * a.H + y) * a.W + xx));
 }
 
 // candidates (tile index, position inside the tile) of one axis that map onto image index y: every padded coordinate that reflects
@@ -77,12 +88,18 @@ void halo_tiles_bwd_kernel(TileArgs a, const T* __restrict__ dt, T* __restrict__
         for (int p = 0; p < 3; ++p)
 #pragma unroll
             for (int q = 0; q < 3; ++q)
-                if (p < ny && q < nx) acc += Store<T>::ld(dt, (pl * TH + ys[p]) * TW + xs[q]);
+                if (p < ny && q < nx) {
+                    const int ti = div_by_inv(ys[p], a.inv_ph2), tj = div_by_inv(xs[q], a.inv_pw2);
+                    acc += Store<T>::ld(dt, tile_addr(a, pl, ti, ys[p] - ti * (a.ph + 2), tj, xs[q] - tj * (a.pw + 2)));
+                }
     } else {
         int ys[9], xs[9];
         const int ny = tile_sources(y, a.H, a.ph, a.inv_ph, a.fh, ys), nx = tile_sources(x, a.W, a.pw, a.inv_pw, a.fw, xs);
         for (int p = 0; p < ny; ++p)
-            for (int q = 0; q < nx; ++q) acc += Store<T>::ld(dt, (pl * TH + ys[p]) * TW + xs[q]);
+            for (int q = 0; q < nx; ++q) {
+                const int ti = div_by_inv(ys[p], a.inv_ph2), tj = div_by_inv(xs[q], a.inv_pw2);
+                acc += Store<T>::ld(dt, tile_addr(a, pl, ti, ys[p] - ti * (a.ph + 2), tj, xs[q] - tj * (a.pw + 2)));
+            }
     }
     Store<T>::st(dx, (pl * a.H + y) * a.W + x, acc);
 }
@@ -721,11 +738,11 @@ extern "C" int hs_bn_act_train_bwd(int32_t dtype, const void* x, const void* dy,
     return launch_status();
 }
 
-static int tile_args(TileArgs& a, int B, int C, int H, int W, int fh, int fw) {
+static int tile_args(TileArgs& a, int B, int C, int H, int W, int fh, int fw, int pm = 0) {
     if (B <= 0 || C <= 0 || H < 2 || W < 2 || fh <= 0 || fw <= 0) return HS_ERR_BAD_ARG;
     if (H % fh || W % fw) return HS_ERR_NOT_DIVISIBLE;
     if ((long)B * C > 65535) return HS_ERR_UNSUPPORTED;
-    a = TileArgs{B, C, H, W, fh, fw, H / fh, W / fw, 1.0f / (float)(H / fh), 1.0f / (float)(W / fw), 1.0f / (float)(H / fh + 2), 1.0f / (float)(W / fw + 2)};
+    a = TileArgs{B, C, H, W, fh, fw, H / fh, W / fw, 1.0f / (float)(H / fh), 1.0f / (float)(W / fw), 1.0f / (float)(H / fh + 2), 1.0f / (float)(W / fw + 2), pm ? 1 : 0};
     if (H + 2 * fh >= (1 << 21) || W + 2 * fw >= (1 << 21)) return HS_ERR_UNSUPPORTED;          // div_by_inv's range
     return HS_OK;
 }
@@ -736,9 +753,9 @@ static int tile_args(TileArgs& a, int B, int C, int H, int W, int fh, int fw) {
     else return HS_ERR_BAD_ARG;
 
 extern "C" int hs_halo_tiles_fwd(int32_t dtype, const void* x, int32_t batch, int32_t channels, int32_t H, int32_t W, int32_t fh,
-                                 int32_t fw, void* tiled, void* stream) {
+                                 int32_t fw, void* tiled, int32_t patch_major, void* stream) {
     TileArgs a;
-    const int st = tile_args(a, batch, channels, H, W, fh, fw);
+    const int st = tile_args(a, batch, channels, H, W, fh, fw, patch_major);
     if (st != HS_OK) return st;
     if (!x || !tiled) return HS_ERR_BAD_ARG;
     const dim3 grid((fw * (a.pw + 2) + 63) / 64, (fh * (a.ph + 2) + 3) / 4, batch * channels);
@@ -747,9 +764,9 @@ extern "C" int hs_halo_tiles_fwd(int32_t dtype, const void* x, int32_t batch, in
 }
 
 extern "C" int hs_halo_tiles_bwd(int32_t dtype, const void* dtiled, int32_t batch, int32_t channels, int32_t H, int32_t W,
-                                 int32_t fh, int32_t fw, void* dx, void* stream) {
+                                 int32_t fh, int32_t fw, void* dx, int32_t patch_major, void* stream) {
     TileArgs a;
-    const int st = tile_args(a, batch, channels, H, W, fh, fw);
+    const int st = tile_args(a, batch, channels, H, W, fh, fw, patch_major);
     if (st != HS_OK) return st;
     if (!dtiled || !dx) return HS_ERR_BAD_ARG;
     const dim3 grid((W + 63) / 64, (H + 3) / 4, batch * channels);

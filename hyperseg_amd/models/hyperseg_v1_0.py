@@ -297,16 +297,22 @@ class HyperPatchInvertedResidual(EpochOnModeSwitch, nn.Module, _SignalToWeights)
         ph, pw = h // fh, wd // fw
         grid = (fh, fw)
         own = HA.tiles_supported(xt)
+        # patch-major tiles (B fh fw, C, ph+2, pw+2): every operand of a patch one contiguous run; the 1x1 layer on them is a patch convolution
+        # with a (1, 1) grid over B fh fw frames -- same kernels, same bank rows -- and BatchNorm sees the same multiset of values per channel
+        pm = own and HA.USE_PATCH_MAJOR_TILES and HA.USE_HIP_DW_TILES and h % fh == 0 and wd % fw == 0 and pw % 2 == 0 \
+            and b * fh * fw * max(c, self.hidden_dim) <= 65535
         if own:                                                                    # one gather each way (hs_halo_tiles_fwd / _bwd)
-            tiled = HA.HaloTiles.apply(xt, grid)
+            tiled = HA.HaloTiles.apply(xt, grid, pm)
         else:
             xp = F.pad(xt, (1, 1, 1, 1), mode='reflect')
             tiles = xp.unfold(2, ph + 2, ph).unfold(3, pw + 2, pw)                 # B C fh fw ph+2 pw+2
             tiled = tiles.permute(0, 1, 2, 4, 3, 5).reshape(b, c, fh * (ph + 2), fw * (pw + 2))
         bank1, bank2, bank3 = HA.BankSlices.apply(bank, r1, r2, r3)             # one concatenation in the backward instead of 3 x (zeros + copy) + 2 adds
-        y = HA.patch_conv_apply(tiled, bank1, grid, self.hidden_dim, 1, 0, 'zeros', 1)
+        y = HA.patch_conv_apply(tiled, bank1, (1, 1) if pm else grid, self.hidden_dim, 1, 0, 'zeros', 1)
         y = HA.bn_act(self.bn1, self.act_layer, y)
-        if own and HA.dw_tiles_supported(y, (h, wd), grid):
+        if pm:
+            y = HA.DwTilesValid.apply(y, bank2, (h, wd), grid, True)
+        elif own and HA.dw_tiles_supported(y, (h, wd), grid):
             # the valid depthwise 3x3 of every tile, straight to the (B, hidden, H, W) map: one launch per direction and operand
             y = HA.DwTilesValid.apply(y, bank2, (h, wd), grid)
         elif own and HA.tiles_supported(y):

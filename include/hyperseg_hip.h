@@ -389,9 +389,12 @@ int hs_pooled_shift_fwd(const float* partial, int32_t nblk, float inv_pixels, co
  * unfold -> unfold -> permute -> reshape), hs_halo_tiles_bwd is its adjoint (a gather too: per image pixel the <= 16 tile positions that
  * map onto it); hs_tile_interior_fwd drops the halos again, hs_tile_interior_bwd is its adjoint (zeros on the halos). */
 int hs_halo_tiles_fwd(int32_t dtype, const void* x, int32_t batch, int32_t channels, int32_t H, int32_t W, int32_t fh, int32_t fw,
-                      void* tiled, void* stream);
+                      void* tiled, int32_t patch_major, void* stream);
 int hs_halo_tiles_bwd(int32_t dtype, const void* dtiled, int32_t batch, int32_t channels, int32_t H, int32_t W, int32_t fh, int32_t fw,
-                      void* dx, void* stream);
+                      void* dx, int32_t patch_major, void* stream);
+/* patch_major (hs_halo_tiles_*, hs_dw_tiles_*): 0 = the tiles side by side as one image (B, C, fh (ph+2), fw (pw+2)); 1 = one tile after the
+ * other, (B fh fw, C, ph+2, pw+2) -- every operand of a patch is then one contiguous run and the block's 1x1 layers are patch convolutions
+ * with a (1, 1) grid over B fh fw "frames" (same kernels, same bank rows).  hs_tile_interior_* take the image form only. */
 int hs_tile_interior_fwd(int32_t dtype, const void* tiled, int32_t batch, int32_t channels, int32_t H, int32_t W, int32_t fh,
                          int32_t fw, void* y, void* stream);
 int hs_tile_interior_bwd(int32_t dtype, const void* dy, int32_t batch, int32_t channels, int32_t H, int32_t W, int32_t fh, int32_t fw,
@@ -403,11 +406,11 @@ int hs_tile_interior_bwd(int32_t dtype, const void* dy, int32_t batch, int32_t c
  * (the depthwise range of the block's bank: pass bank + r1); dtype = hs_dtype of the activations.  Even patch widths only
  * (HS_ERR_UNSUPPORTED otherwise: the caller keeps the two-launch route).  autograd.DwTilesValid. */
 int hs_dw_tiles_fwd(int32_t dtype, const void* tiled, const float* bank, int64_t ld, int32_t batch, int32_t channels, int32_t H, int32_t W,
-                    int32_t fh, int32_t fw, void* y, void* stream);
+                    int32_t fh, int32_t fw, void* y, int32_t patch_major, void* stream);
 int hs_dw_tiles_bwd_in(int32_t dtype, const void* dy, const float* bank, int64_t ld, int32_t batch, int32_t channels, int32_t H, int32_t W,
-                       int32_t fh, int32_t fw, void* dtiled, void* stream);
+                       int32_t fh, int32_t fw, void* dtiled, int32_t patch_major, void* stream);
 int hs_dw_tiles_bwd_w(int32_t dtype, const void* tiled, const void* dy, int32_t batch, int32_t channels, int32_t H, int32_t W, int32_t fh,
-                      int32_t fw, float* dbank, int64_t ld, void* stream);
+                      int32_t fw, float* dbank, int64_t ld, int32_t patch_major, void* stream);
 /* The per-image reduction of hyperseg/losses/bootstrapped_ce_loss.py:19-25 over n non-negative f32 losses, with no sort and no host
  * read: if more than k losses exceed thresh, their mean; otherwise the mean of the k largest (the k-th largest found by a three-level
  * radix histogram of the bit patterns; ties at it share the remaining weight).  out5 = {loss, branch, 1/count, t, tie weight}: the

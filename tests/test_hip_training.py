@@ -163,6 +163,40 @@ def test_halo_tiles_and_interior_vs_stock_ops(dev, shape, grid, dtype):
     assert torch.equal(ua.grad, ub.grad)
 
 
+@pytest.mark.parametrize('shape,grid', [((2, 5, 36, 20), (2, 2)), ((1, 3, 8, 12), (4, 3)), ((2, 4, 40, 130), (5, 2)), ((1, 2, 6, 6), (6, 6)), ((1, 1, 2, 2), (1, 1))])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_patch_major_tiles_are_the_tile_image_permuted(dev, shape, grid, dtype):
+    """HaloTiles(patch_major=True) lays the same tiles out one after the other, (B fh fw, C, ph+2, pw+2): values and the adjoint equal the
+    image-of-tiles form under that permutation, bit for bit; DwTilesValid on either layout gives the same output and gradients."""
+    from hyperseg_amd import autograd as HA
+    b, c, h, w = shape
+    fh, fw = grid
+    ph, pw = h // fh, w // fw
+    g = torch.Generator().manual_seed(sum(shape) + fh)
+    x = torch.randn(shape, generator=g).to(dev).to(dtype)
+
+    def to_pm(t):                                                # image of tiles -> patch-major
+        return t.reshape(b, c, fh, ph + 2, fw, pw + 2).permute(0, 2, 4, 1, 3, 5).reshape(b * fh * fw, c, ph + 2, pw + 2)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ta, tb = HA.HaloTiles.apply(xa, grid, False), HA.HaloTiles.apply(xb, grid, True)
+    assert tb.shape == (b * fh * fw, c, ph + 2, pw + 2) and torch.equal(to_pm(ta), tb)
+    r = torch.randn(ta.shape, generator=g).to(dev).to(dtype)
+    ta.backward(r)
+    tb.backward(to_pm(r).contiguous())
+    assert torch.equal(xa.grad, xb.grad)
+    if pw % 2:
+        return                                                   # hs_dw_tiles_*: even patch widths
+    bank = (torch.randn(b * fh * fw, 9 * c, generator=g) * 0.3).to(dev)
+    t0 = ta.detach()
+    ua, ub = t0.clone().requires_grad_(True), to_pm(t0).contiguous().requires_grad_(True)
+    ka, kb = bank.clone().requires_grad_(True), bank.clone().requires_grad_(True)
+    ya, yb = HA.DwTilesValid.apply(ua, ka, (h, w), grid, False), HA.DwTilesValid.apply(ub, kb, (h, w), grid, True)
+    assert torch.equal(ya, yb)
+    r2 = torch.randn(ya.shape, generator=g).to(dev).to(dtype)
+    ya.backward(r2); yb.backward(r2)
+    assert torch.equal(to_pm(ua.grad), ub.grad) and torch.equal(ka.grad, kb.grad)
+
+
 def test_bank_pack_autograd_roundtrip(dev):
     """autograd.BankPack: forward = hs_bank_pack_fwd, backward = hs_bank_unpack_fwd (one tiled transpose incl. the zero tail) == the
     gradient of the reference layout's permute, unused trailing channels exactly zero."""
