@@ -17,17 +17,22 @@
 
 namespace hs {
 
-struct TileArgs { int B, C, H, W, fh, fw, ph, pw; float inv_ph, inv_pw, inv_ph2, inv_pw2; int pm; };      // reciprocals of ph, pw, ph + 2, pw + 2 (div_by_inv)
+struct TileArgs { int B, C, H, W, fh, fw, ph, pw; float inv_ph, inv_pw, inv_ph2, inv_pw2; int pm; float inv_c; };      // reciprocals of ph, pw, ph + 2, pw + 2 (div_by_inv)
 // Where tile (i, j) of plane pl = b C + c keeps its position (U, V).  pm = 0: the IMAGE of tiles (B, C, fh (ph+2), fw (pw+2)) -- tiles side by
 // side, what the generic patch convolutions take.  pm = 1: PATCH-MAJOR (B fh fw, C, ph+2, pw+2) -- every operand of a patch one contiguous
 // run, each patch a 1 x 1-grid "image" of its own for the patch convolutions (round 4: in the image of tiles a tile row is 72 bytes of a
 // 128-byte line that the neighbouring tile's workgroup fetches again).
-__device__ __forceinline__ size_t tile_addr(const TileArgs& a, size_t pl, int i, int U, int j, int V) {
-    if (a.pm) {
-        const int b = (int)pl / a.C, c = (int)pl - b * a.C;              // (uniform: pl = blockIdx.z)
-        return ((((size_t)b * a.fh + i) * a.fw + j) * a.C + c) * (size_t)((a.ph + 2) * (a.pw + 2)) + (size_t)U * (a.pw + 2) + V;
-    }
-    return (pl * (size_t)(a.fh * (a.ph + 2)) + (size_t)i * (a.ph + 2) + U) * (size_t)(a.fw * (a.pw + 2)) + (size_t)j * (a.pw + 2) + V;
+struct TilePlane { size_t pm_base, im_base; };                         // per thread, once: where plane pl = b C + c starts in either layout
+__device__ __forceinline__ TilePlane tile_plane(const TileArgs& a, size_t pl) {
+    const int b = div_by_inv((int)pl, a.inv_c), c = (int)pl - b * a.C;
+    TilePlane t;
+    t.pm_base = ((size_t)b * a.fh * a.fw * a.C + c) * (size_t)((a.ph + 2) * (a.pw + 2));        // + (i fw + j) C tile_size
+    t.im_base = pl * (size_t)(a.fh * (a.ph + 2)) * (size_t)(a.fw * (a.pw + 2));
+    return t;
+}
+__device__ __forceinline__ size_t tile_addr(const TileArgs& a, const TilePlane& t, int i, int U, int j, int V) {
+    if (a.pm) return t.pm_base + (size_t)(i * a.fw + j) * a.C * (size_t)((a.ph + 2) * (a.pw + 2)) + (size_t)U * (a.pw + 2) + V;
+    return t.im_base + ((size_t)i * (a.ph + 2) + U) * (size_t)(a.fw * (a.pw + 2)) + (size_t)j * (a.pw + 2) + V;
 }
 
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
@@ -41,7 +46,7 @@ void halo_tiles_fwd_kernel(TileArgs a, const T* __restrict__ x, T* __restrict__ 
     const int i = div_by_inv(Y, a.inv_ph2), u = Y - i * (a.ph + 2), j = div_by_inv(X, a.inv_pw2), v = X - j * (a.pw + 2);
     const int y = reflect1(i * a.ph + u - 1, a.H), xx = reflect1(j * a.pw + v - 1, a.W);
     const size_t pl = blockIdx.z;
-    Store<T>::st(t, tile_addr(a, pl, i, u, j, v), Store<T>::ld(x, (pl * a.H + y) * a.W + xx));
+    Store<T>::st(t, tile_addr(a, tile_plane(a, pl), i, u, j, v), Store<T>::ld(x, (pl * a.H + y) * a.W + xx));
 }
 
 // candidates (tile index, position inside the tile) of one axis that map onto image index y: every padded coordinate that reflects
@@ -80,6 +85,7 @@ void halo_tiles_bwd_kernel(TileArgs a, const T* __restrict__ dt, T* __restrict__
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= a.W || y >= a.H) return;
     const size_t pl = blockIdx.z;
+    const TilePlane tp = tile_plane(a, pl);
     float acc = 0.0f;
     if (a.ph >= 3 && a.pw >= 3) {                                       // (uniform) at most 2 x 2 sources... 3 with a reflection: no search, no division
         int ys[3], xs[3];
@@ -90,7 +96,7 @@ void halo_tiles_bwd_kernel(TileArgs a, const T* __restrict__ dt, T* __restrict__
             for (int q = 0; q < 3; ++q)
                 if (p < ny && q < nx) {
                     const int ti = div_by_inv(ys[p], a.inv_ph2), tj = div_by_inv(xs[q], a.inv_pw2);
-                    acc += Store<T>::ld(dt, tile_addr(a, pl, ti, ys[p] - ti * (a.ph + 2), tj, xs[q] - tj * (a.pw + 2)));
+                    acc += Store<T>::ld(dt, tile_addr(a, tp, ti, ys[p] - ti * (a.ph + 2), tj, xs[q] - tj * (a.pw + 2)));
                 }
     } else {
         int ys[9], xs[9];
@@ -98,7 +104,7 @@ void halo_tiles_bwd_kernel(TileArgs a, const T* __restrict__ dt, T* __restrict__
         for (int p = 0; p < ny; ++p)
             for (int q = 0; q < nx; ++q) {
                 const int ti = div_by_inv(ys[p], a.inv_ph2), tj = div_by_inv(xs[q], a.inv_pw2);
-                acc += Store<T>::ld(dt, tile_addr(a, pl, ti, ys[p] - ti * (a.ph + 2), tj, xs[q] - tj * (a.pw + 2)));
+                acc += Store<T>::ld(dt, tile_addr(a, tp, ti, ys[p] - ti * (a.ph + 2), tj, xs[q] - tj * (a.pw + 2)));
             }
     }
     Store<T>::st(dx, (pl * a.H + y) * a.W + x, acc);
@@ -742,7 +748,7 @@ static int tile_args(TileArgs& a, int B, int C, int H, int W, int fh, int fw, in
     if (B <= 0 || C <= 0 || H < 2 || W < 2 || fh <= 0 || fw <= 0) return HS_ERR_BAD_ARG;
     if (H % fh || W % fw) return HS_ERR_NOT_DIVISIBLE;
     if ((long)B * C > 65535) return HS_ERR_UNSUPPORTED;
-    a = TileArgs{B, C, H, W, fh, fw, H / fh, W / fw, 1.0f / (float)(H / fh), 1.0f / (float)(W / fw), 1.0f / (float)(H / fh + 2), 1.0f / (float)(W / fw + 2), pm ? 1 : 0};
+    a = TileArgs{B, C, H, W, fh, fw, H / fh, W / fw, 1.0f / (float)(H / fh), 1.0f / (float)(W / fw), 1.0f / (float)(H / fh + 2), 1.0f / (float)(W / fw + 2), pm ? 1 : 0, 1.0f / (float)C};
     if (H + 2 * fh >= (1 << 21) || W + 2 * fw >= (1 << 21)) return HS_ERR_UNSUPPORTED;          // div_by_inv's range
     return HS_OK;
 }
