@@ -161,7 +161,7 @@ template <> struct Pair<bf16_t> {
 template <int MT, int NTI, int VEC, typename T>
 __global__ __launch_bounds__(256)
 void patch_conv_bwd_weight_k1m_kernel(ConvBwdArgs a) {
-    static_assert(VEC == 0 || sizeof(T) == 4, "vector loads: fp32 storage only");
+    static_assert(VEC != 1 || sizeof(T) == 4, "16-byte loads: fp32 storage only (pairs serve both storage types)");
     __shared__ __attribute__((aligned(16))) float red[4][MT * NTI][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kg = lane >> 4;
@@ -184,13 +184,15 @@ void patch_conv_bwd_weight_k1m_kernel(ConvBwdArgs a) {
                 const size_t off = (size_t)u * a.W + v;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    const bw_f32x2 p = *reinterpret_cast<const bw_f32x2*>((const float*)dyp[mt] + off);
-                    av[mt][2 * h] = p[0]; av[mt][2 * h + 1] = p[1];         // (the pixels past the patch are masked in products())
+                    float p0, p1;
+                    Pair<T>::ld(dyp[mt], off, p0, p1);                     // 8 bytes (fp32) / 4 bytes (bf16)
+                    av[mt][2 * h] = p0; av[mt][2 * h + 1] = p1;             // (the pixels past the patch are masked in products())
                 }
 #pragma unroll
                 for (int nt = 0; nt < NTI; ++nt) {
-                    const bw_f32x2 p = *reinterpret_cast<const bw_f32x2*>((const float*)xp[nt] + off);
-                    bv[nt][2 * h] = p[0]; bv[nt][2 * h + 1] = p[1];
+                    float p0, p1;
+                    Pair<T>::ld(xp[nt], off, p0, p1);
+                    bv[nt][2 * h] = p0; bv[nt][2 * h + 1] = p1;
                 }
             }
         } else if constexpr (VEC == 1) {
@@ -995,10 +997,11 @@ int hs::try_fast_bwd_w(int dtype, const void* x, const void* dy, int batch, int 
                      ((((size_t)x) | ((size_t)dy)) & 15) == 0;
     const int mt = (c_out + 15) / 16, nt = (c_in + 15) / 16;
     const dim3 grid((unsigned)(batch * fh * fw));
-    const bool pairs = !vec && dtype == HS_DTYPE_F32 && (a.pw & 1) == 0 && (W & 1) == 0 && ((((size_t)x) | ((size_t)dy)) & 7) == 0;
+    const bool pairs = !vec && (a.pw & 1) == 0 && (W & 1) == 0 && ((((size_t)x) | ((size_t)dy)) & 7) == 0;       // either storage type
 #define HS_BW(MTV, NTV) if (mt == MTV && nt == NTV) { \
         if (vec) hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 1, float>), grid, dim3(256), 0, stream, a); \
-        else if (pairs) hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 2, float>), grid, dim3(256), 0, stream, a); \
+        else if (pairs) HS_T2(dtype, hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 2, float>), grid, dim3(256), 0, stream, a), \
+                                     hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 2, bf16_t>), grid, dim3(256), 0, stream, a)); \
         else HS_T2(dtype, hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 0, float>), grid, dim3(256), 0, stream, a), \
                           hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 0, bf16_t>), grid, dim3(256), 0, stream, a)); \
         return launch_status(); }
