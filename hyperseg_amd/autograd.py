@@ -8,6 +8,8 @@ around it in TRAINING mode (stage-input concatenation, BatchNorm with batch stat
 through this module: it uses the fused kernels (one launch per level).
 """
 
+import os
+
 import torch
 
 from . import _hip
@@ -357,16 +359,33 @@ class S2WBanksTrain(torch.autograd.Function):
         return (None, dsig) + tuple(dws)
 
 
+_CHECK_LABELS = os.environ.get('HS_CHECK_LABELS', '0') == '1'
+
+
 class PixelCrossEntropy(torch.autograd.Function):
     """F.cross_entropy(logits, target, ignore_index=..., reduction='none') for fp32 / bf16 (N, C, H, W) CUDA logits, one launch per
     direction (hs_cross_entropy_typed_fwd / _bwd; stock: log-softmax + gather and their adjoints, after a widening cast for bf16).
-    The loss is fp32 and the arithmetic f32 for either storage type; the logits' gradient has the logits' type."""
+    The loss is fp32 and the arithmetic f32 for either storage type; the logits' gradient has the logits' type.
+    ``target`` must be int64 of shape (N, H, W) -- checked here, as F.cross_entropy does: the kernel walks N*H*W pixels of BOTH
+    tensors.  A label outside [0, C) other than ``ignore_index`` contributes a zero loss and a zero gradient (the stock CUDA kernel
+    fires a device-side assert for it); ``HS_CHECK_LABELS=1`` makes this function verify the range first (one host read, debugging)."""
 
     @staticmethod
     def forward(ctx, logits, target, ignore_index):
+        if logits.dim() < 2 or tuple(target.shape) != (logits.shape[0],) + tuple(logits.shape[2:]):
+            raise ValueError(f'Expected target of shape {(logits.shape[0],) + tuple(logits.shape[2:])} for logits of shape '
+                             f'{tuple(logits.shape)}, got {tuple(target.shape)}')
+        if target.dtype != torch.int64:
+            raise ValueError(f'PixelCrossEntropy: expected int64 class indices, got {target.dtype}')
+        if target.device != logits.device:
+            raise ValueError(f'PixelCrossEntropy: target on {target.device}, logits on {logits.device}')
         logits, target = logits.contiguous(), target.contiguous()
         n, c = logits.shape[:2]
         px = logits.numel() // (n * c)
+        if _CHECK_LABELS and target.numel():
+            bad = (target != int(ignore_index)) & ((target < 0) | (target >= c))
+            if bool(bad.any()):
+                raise IndexError(f'Target {int(target[bad][0])} is out of bounds for {c} classes (ignore_index {int(ignore_index)})')
         with _hip.device_scope(logits.device):
             loss = torch.empty(target.shape, device=logits.device, dtype=torch.float32)
             st = _hip.lib.hs_cross_entropy_typed_fwd(DTYPE_CODES[logits.dtype], logits.data_ptr(), target.data_ptr(), n, c, px, int(ignore_index),
@@ -424,7 +443,12 @@ class MetaConvGeneral(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, c_out, kernel_size, stride, pads, dilation, groups):
-        x, w = x.contiguous().float(), (w if w.stride(1) == 1 else w.contiguous()).float()
+        # ``w`` may be MetaSequential's column range w[:, a:b] of a wider weight tensor: rows ``stride(0)`` apart, unit column stride --
+        # the kernel takes the row stride (ldw), so such a view is read in place (it is NOT ``is_contiguous()``)
+        x, w = x.contiguous().float(), (w if w.dim() == 2 and w.stride(1) == 1 else w.contiguous()).float()
+        if not (w.is_cuda and w.device == x.device and w.dim() == 2 and w.stride(1) == 1):
+            raise _hip.HipLibraryError(f'MetaConvGeneral: w must be a 2-D CUDA tensor on {x.device} with unit column stride, got '
+                                       f'{tuple(w.shape)} strides {tuple(w.stride())} on {w.device}')
         (kh, kw), (sh, sw), (pt, pb, pl, pr), (dh, dw) = kernel_size, stride, pads, dilation
         b, cin, h, wd = x.shape
         ho = (h + pt + pb - dh * (kh - 1) - 1) // sh + 1
@@ -433,7 +457,7 @@ class MetaConvGeneral(torch.autograd.Function):
             raise ValueError(f'kernel {kernel_size} (dilation {dilation}) does not fit the padded {h}x{wd} input')
         y = torch.empty(b, c_out, ho, wo, device=x.device, dtype=torch.float32)
         with _hip.device_scope(x.device):
-            st = _hip.lib.hs_meta_conv_fwd(_hip.dev_ptr(x, 'x'), b, cin, h, wd, _hip.dev_ptr(w, 'w'), w.stride(0), c_out, kh, kw,
+            st = _hip.lib.hs_meta_conv_fwd(_hip.dev_ptr(x, 'x'), b, cin, h, wd, w.data_ptr(), w.stride(0), c_out, kh, kw,
                                            sh, sw, pt, pb, pl, pr, dh, dw, 0, groups, None, y.data_ptr(), _hip.stream_ptr())
             _hip.check(st, 'hs_meta_conv_fwd')
         ctx.save_for_backward(x, w)

@@ -8,6 +8,7 @@ Vocabulary: a *bank* is the patch-major per-patch filter b
 import ctypes as C
 import functools
 import os
+import threading
 
 import torch
 
@@ -15,6 +16,7 @@ from . import _hip
 from ._hip import ACT_NONE, ACT_RELU, ACT_RELU6, PAD_MODES  # noqa: F401  (re-exported)
 
 BN_EPS_DEFAULT = 1e-5
+S2W_TRAIN_MAX_LAYERS = 8     # S2W_MAX_LAYERS of csrc/hs_s2w_blocked.h: layers one hs_s2w_train_* / hs_signal2weights_multi_fwd launch takes
 # Late-level banks on a second stream: saves ~14 us of decoder time in isolation, but a forked/joined capture makes
 # the whole-model HIP-graph replay 0.37 ms SLOWER on ROCm 7.2 (measured: 3.62 -> 3.99 ms/frame), so it is off by default.
 USE_SIDE_STREAM = os.environ.get('HS_SIDE_STREAM', '0') == '1'
@@ -244,6 +246,20 @@ class SignalRef:
 
 
 _S2W_BLK = {}        # (wsw_t data_ptr, version, shape, channels, groups) -> (weakref to wsw_t, packed operand image of the blocked kernel)
+# Re-entrancy (SURVEY 8b "Threading": nn.DataParallel.parallel_apply runs one Python thread per replica through these functions):
+# every process-global cache is read and written under this lock -- the sweep below iterates the dict, which another thread's
+# insert would break ("dictionary changed size during iteration") -- and the per-module caches (FoldedBN, TransposedS2W) keep one
+# immutable (key, value) entry per DEVICE, replaced atomically, because DataParallel's replicas share those objects by reference.
+_CACHE_LOCK = threading.RLock()
+
+
+def publish_ready(device):
+    """Called after the kernels that FILL a cache entry were launched and before the entry is published: the filling stream is drained
+    on the host, so a thread that finds the entry from ANOTHER stream (a second request stream, a replica thread) reads finished data
+    -- stream order only protects the stream that launched the fill.  Fills happen once per parameter version, so the wait is paid
+    once; under stream capture a host wait is illegal and the entry is only ever consumed by the capturing stream's graph."""
+    if device.type == 'cuda' and not torch.cuda.is_current_stream_capturing():
+        torch.cuda.current_stream(device).synchronize()
 
 
 @_on_operand_device
@@ -252,18 +268,20 @@ def s2w_packed(wsw_t, signal_channels, groups):
     once per parameter version (the transposed tensor itself is cached per module by version, so its address is the key)."""
     import weakref
     key = (_WEIGHTS_EPOCH[0], wsw_t.data_ptr(), wsw_t._version, tuple(wsw_t.shape), signal_channels, groups, wsw_t.device)
-    ent = _S2W_BLK.get(key)
-    hit = ent[1] if ent is not None and ent[0]() is wsw_t else None       # the address alone could be a dead tensor's, reused
-    if hit is None:
-        for k in [k for k, (r, _) in _S2W_BLK.items() if r() is None or k[0] != _WEIGHTS_EPOCH[0]]:      # dead sources and earlier weight epochs take their images with them
-            del _S2W_BLK[k]
-        n = _hip.lib.hs_s2w_pack_floats(signal_channels, groups, wsw_t.shape[1])
-        if n < 0:
-            _hip.check(int(n), 'hs_s2w_pack_floats')
-        hit = torch.empty(n, device=wsw_t.device, dtype=torch.float32)
-        _hip.check(_hip.lib.hs_s2w_pack_fwd(_hip.dev_ptr(wsw_t, 'wsw_t'), signal_channels, groups, wsw_t.shape[1], hit.data_ptr(),
-                                            _hip.stream_ptr()), 'hs_s2w_pack_fwd')
-        _S2W_BLK[key] = (weakref.ref(wsw_t), hit)
+    with _CACHE_LOCK:
+        ent = _S2W_BLK.get(key)
+        hit = ent[1] if ent is not None and ent[0]() is wsw_t else None       # the address alone could be a dead tensor's, reused
+        if hit is None:
+            for k in [k for k, (r, _) in list(_S2W_BLK.items()) if r() is None or k[0] != _WEIGHTS_EPOCH[0]]:      # dead sources and earlier weight epochs take their images with them
+                del _S2W_BLK[k]
+            n = _hip.lib.hs_s2w_pack_floats(signal_channels, groups, wsw_t.shape[1])
+            if n < 0:
+                _hip.check(int(n), 'hs_s2w_pack_floats')
+            hit = torch.empty(n, device=wsw_t.device, dtype=torch.float32)
+            _hip.check(_hip.lib.hs_s2w_pack_fwd(_hip.dev_ptr(wsw_t, 'wsw_t'), signal_channels, groups, wsw_t.shape[1], hit.data_ptr(),
+                                                _hip.stream_ptr()), 'hs_s2w_pack_fwd')
+            publish_ready(wsw_t.device)
+            _S2W_BLK[key] = (weakref.ref(wsw_t), hit)
     return hit
 
 
@@ -346,9 +364,10 @@ class SideStream:
     @classmethod
     def get(cls, device):
         key = (device.type, device.index)
-        if key not in cls._streams:
-            cls._streams[key] = torch.cuda.Stream(device=device)
-        return cls._streams[key]
+        with _CACHE_LOCK:
+            if key not in cls._streams:
+                cls._streams[key] = torch.cuda.Stream(device=device)
+            return cls._streams[key]
 
 
 @_on_operand_device
@@ -438,7 +457,8 @@ def meta_conv(x, w, c_out, kernel_size, stride=(1, 1), padding=(0, 0), dilation=
         raise ValueError(f'w must be (B, rows) with contiguous rows, got {tuple(w.shape)}')
     ep = _epilogue(scale, shift, act)
     y = torch.empty(b, c_out, ho, wo, device=x.device, dtype=torch.float32)
-    st = _hip.lib.hs_meta_conv_fwd(_hip.dev_ptr(x, 'x'), b, cin, h, wd, _hip.dev_ptr(w, 'w'), w.stride(0), c_out, kh, kw,
+    w_ptr, ldw = _bank_ptr(w)            # a column range w[:, a:b] of a wider tensor (MetaSequential's slice) is read in place: ldw = its row stride
+    st = _hip.lib.hs_meta_conv_fwd(_hip.dev_ptr(x, 'x'), b, cin, h, wd, w_ptr, ldw, c_out, kh, kw,
                                    sh, sw, pt, pb, pl, pr, dh, dw, PAD_MODES[padding_mode], groups, C.byref(ep), y.data_ptr(),
                                    _hip.stream_ptr())
     _hip.check(st, 'hs_meta_conv_fwd')
@@ -530,17 +550,40 @@ DEFAULT_IR_MATH = 'f32'
 def set_ir_math(mode):
     """Process-wide OVERRIDE of the math mode every fused inverted-residual launch is asked for ('split' | 'f32' | 'auto'),
     or None to hand the choice back to the modules.  A Python-side switch for tests and A/B runs -- the C library itself is
-    stateless.  Returns the previous override."""
+    stateless.  Returns the previous override.  One word, swapped under the cache lock; a thread that wants its OWN mode without
+    touching the others' (a replica thread of nn.DataParallel) uses :func:`ir_math_scope`."""
     global _ir_math_override
     if mode is not None and mode not in IR_MATH:
         raise ValueError(f'ir math {mode!r}: expected one of {sorted(IR_MATH)} or None')
-    prev, _ir_math_override = _ir_math_override, mode
+    with _CACHE_LOCK:
+        prev, _ir_math_override = _ir_math_override, mode
     return prev
 
 
+_ir_math_local = threading.local()
+
+
+class ir_math_scope:
+    """``with ir_math_scope('split'): ...`` -- a THREAD-LOCAL override (outranks the process-wide one) for the calling thread only."""
+
+    def __init__(self, mode):
+        if mode is not None and mode not in IR_MATH:
+            raise ValueError(f'ir math {mode!r}: expected one of {sorted(IR_MATH)} or None')
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = getattr(_ir_math_local, 'mode', None)
+        _ir_math_local.mode = self.mode
+        return self
+
+    def __exit__(self, *exc):
+        _ir_math_local.mode = self.prev
+
+
 def get_ir_math(requested=None):
-    """The mode a launch uses: the override if one is set, else ``requested`` (a module's attribute), else the default."""
-    return _ir_math_override or requested or DEFAULT_IR_MATH
+    """The mode a launch uses: the calling thread's scope if one is open, else the process-wide override if one is set, else
+    ``requested`` (a module's attribute), else the default."""
+    return getattr(_ir_math_local, 'mode', None) or _ir_math_override or requested or DEFAULT_IR_MATH
 
 
 def ir_math_code(requested=None):
@@ -866,7 +909,8 @@ def bump_weights_epoch():
     kernels and stock BatchNorm's running-statistics update all change values WITHOUT bumping ``_version``.
     Called by ``training.GraphedTrainStep.step``, by ``autograd.bn_act`` and by every train() / eval() switch of the
     package's modules, so a validation pass after any number of training steps re-derives everything once."""
-    _WEIGHTS_EPOCH[0] += 1
+    with _CACHE_LOCK:
+        _WEIGHTS_EPOCH[0] += 1
 
 
 def _key(*tensors):
@@ -877,7 +921,7 @@ class FoldedBN:
     """Per-module cache of the folded (scale, shift) of an eval-mode nn.BatchNorm2d."""
 
     def __init__(self):
-        self._k, self._v = None, None
+        self._ent = {}          # device -> (key, value): one immutable pair per device, replaced in ONE assignment (see _CACHE_LOCK)
 
     def get(self, bn):
         if bn.training or not bn.track_running_stats:
@@ -885,24 +929,28 @@ class FoldedBN:
                                       'the training route (hyperseg_amd.autograd) keeps BatchNorm as a module')
         ts = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
         k = _key(*ts)
-        if k != self._k:
+        ent = self._ent.get(bn.weight.device)
+        if ent is None or ent[0] != k:
             with torch.no_grad():
-                self._v = bn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
-            self._k = k
-        return self._v
+                ent = (k, bn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps))
+            publish_ready(bn.weight.device)
+            self._ent[bn.weight.device] = ent
+        return ent[1]
 
 
 class TransposedS2W:
     """Per-module cache of the signal2weights Conv2d weight transposed to (Cs/G, Wc)."""
 
     def __init__(self):
-        self._k, self._v = None, None
+        self._ent = {}          # device -> (key, value), as FoldedBN
 
     def get(self, conv):
         w = conv.weight
         k = _key(w)
-        if k != self._k:
+        ent = self._ent.get(w.device)
+        if ent is None or ent[0] != k:
             with torch.no_grad():
-                self._v = w.detach().reshape(w.shape[0], w.shape[1]).t().contiguous()
-            self._k = k
-        return self._v
+                ent = (k, w.detach().reshape(w.shape[0], w.shape[1]).t().contiguous())
+            publish_ready(w.device)
+            self._ent[w.device] = ent
+        return ent[1]

@@ -100,7 +100,9 @@ class _SignalToWeights:
 
     def _train_mode(self, x, s):
         if isinstance(s, HF.TrainBank):
-            return torch.is_grad_enabled()
+            # a TrainBank only fits the autograd.* Functions (PatchConv.apply & co. run under no_grad as well); the inference kernels
+            # take tensors / BankRefs -- so ``decoder.train()`` inside ``torch.no_grad()`` stays on this route
+            return True
         probe = [x.skip, x.prev] if isinstance(x, HF.StageInput) else [x]
         params = [self.signal2weights.weight] if self.signal2weights is not None else []
         return not isinstance(s, HF.BankRef) and HA.needs_grad(s, *probe, *params)
@@ -264,10 +266,13 @@ class HyperPatchInvertedResidual(EpochOnModeSwitch, nn.Module, _SignalToWeights)
     def _affine_of(self, idx, bn, dev):
         if self._is_identity(bn):
             n = self.out_nc if idx == 2 else self.hidden_dim
-            key = (n, dev)
-            if self._unit_affine.get(idx, (None,))[0] != key:
-                self._unit_affine[idx] = (key, (torch.ones(n, device=dev), torch.zeros(n, device=dev)))
-            return self._unit_affine[idx][1]
+            key = (idx, n, dev)                          # one entry per device: replicas on other GPUs share this dict by reference
+            ent = self._unit_affine.get(key)
+            if ent is None:
+                ent = (torch.ones(n, device=dev), torch.zeros(n, device=dev))
+                HF.publish_ready(torch.device(dev))
+                self._unit_affine[key] = ent
+            return ent
         return self._folded[idx].get(bn)
 
     def _check_supported(self):
@@ -488,8 +493,9 @@ class MultiScaleDecoder(EpochOnModeSwitch, nn.Module):
                 for _, c in m.named_children():
                     out.extend([c] if isinstance(c, _HYPER_TYPES) else collect(c))
                 return out
-            self._hyper_cache = [collect(getattr(self, f'level_{l}')) for l in range(self.levels)]
-            self._hyper_cache.append(collect(self.out_fc) if self.out_fc is not None else [])
+            found = [collect(getattr(self, f'level_{l}')) for l in range(self.levels)]
+            found.append(collect(self.out_fc) if self.out_fc is not None else [])
+            self._hyper_cache = found                          # published complete (replica threads may race to build it)
         return self._hyper_cache
 
     def _coschedule_plan(self, groups, layers):
@@ -531,17 +537,24 @@ class MultiScaleDecoder(EpochOnModeSwitch, nn.Module):
         if any(len(g) != 1 for g in groups[:self.levels]) or (self.out_fc is not None and len(groups[-1]) != 1):
             return None
         flat = [g[0] for g in groups if g]
+        b, _, fh, fw = s.shape
+        if len(flat) > HF.S2W_TRAIN_MAX_LAYERS:                      # hs_s2w_train_*: S2W_MAX_LAYERS of include/hyperseg_hip.h
+            return None
         meta, weights = [], []
         for m in flat:
             conv = m.signal2weights
             if conv is None or conv.bias is not None or m.signal_channels // conv.groups > 80 or conv.weight.dtype != torch.float32:
                 return None
-            if m.signal_index + m.signal_channels > s.shape[1]:
+            # the per-module route hands a level MetaSequential's clamped slice s[:, :hyper_params] (meta_sequential.py:35, Appendix D-2)
+            # and the inference route raises past it: the single launch must not read channels that slice would not contain
+            if m.signal_index + m.signal_channels > min(int(m.hyper_params), s.shape[1]):
+                return None
+            # 32-bit element offsets inside hs_s2w_train_*: the level's bank and its signal2weights output
+            if b * fh * fw * HF._round_up(int(m.hyper_params), 4) >= 2 ** 31 or b * conv.weight.shape[0] * fh * fw >= 2 ** 31:
                 return None
             meta.append(dict(signal_index=m.signal_index, signal_channels=m.signal_channels, groups=conv.groups, rows=int(m.hyper_params)))
             weights.append(conv.weight.view(conv.weight.shape[0], -1))
         banks = HA.S2WBanksTrain.apply(meta, s, *weights)
-        b, _, fh, fw = s.shape
         return [HF.TrainBank(bk, b, mt['rows'], (fh, fw)) for bk, mt in zip(banks, meta)]
 
     def _forward_autograd(self, x, s):

@@ -44,7 +44,7 @@ class MetaSequential(nn.Sequential):
     def _fold(self, idx, bn):
         cache = self._folded.get(idx)
         if cache is None:
-            cache = self._folded[idx] = HF.FoldedBN()
+            cache = self._folded.setdefault(idx, HF.FoldedBN())     # atomic: replica threads share this dict (nn.DataParallel)
         return cache.get(bn)
 
     def forward(self, x, w):

@@ -123,6 +123,7 @@ class FusedPointwise(nn.Module):
         hit = self._split.get(key)
         if hit is None or hit[0] != ver:
             hit = (ver, HF.gemm_split_weights(self.conv.weight, self.scale if with_scale else None))
+            HF.publish_ready(self.conv.weight.device)            # another stream / replica thread may pick the entry up
             self._split[key] = hit
         return hit[1]
 
@@ -365,6 +366,7 @@ class FusedContextHead(nn.Module):
         hit = self._split.get(name)
         if hit is None or hit[0] != key:
             hit = (key, HF.gemm_split_weights(weight, scale, max_k=max_k))
+            HF.publish_ready(weight.device)
             self._split[name] = hit
         return hit[1]
 

@@ -15,13 +15,12 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
-@pytest.fixture(autouse=True)
-def _deterministic_draws():
-    """Every test starts from the same CPU and device random state: a few GPU tests draw inputs / targets on the device without a generator
-    of their own, and a tolerance that holds for almost every draw (test_graphed_train_step_equals_eager compares trajectories of Adam
-    steps) must not decide a run by chance."""
-    torch.manual_seed(20260927)
-    yield
+def G(seed):
+    """A fresh CPU generator: every random draw of the suite names its own seed (``torch.rand(..., generator=G(n)).to(dev)``), so no test
+    depends on the process-wide random state or on which tests ran before it.  (Round 4 pinned a 1-in-25 GPU failure of
+    test_graphed_train_step_equals_eager with a blanket autouse ``torch.manual_seed``; round 5 derived that test's tolerances from a
+    200-seed sweep instead -- tools/graphed_step_seed_sweep.py, profiles/round5_graphed_step_seed_sweep.txt -- and removed the blanket.)"""
+    return torch.Generator().manual_seed(int(seed))
 
 
 def load_golden(name):

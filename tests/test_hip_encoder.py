@@ -9,7 +9,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import rel_err
+from conftest import G, rel_err
 
 pytestmark = pytest.mark.gpu
 REL_TOL = 2e-5
@@ -186,7 +186,7 @@ def test_prepared_encoder_matches_stock(dev, batch, size):
     prepare_for_inference(fused, fold_bn=False, fused_depthwise=True)
     assert any(b._fused_dw.defer_shift for b in fused.backbone._blocks)
     stock, fused = stock.to(dev), fused.to(dev)
-    x = torch.rand(batch, 3, *size, device=dev)
+    x = torch.rand(batch, 3, *size, generator=G(1002)).to(dev)
     with torch.no_grad():
         fs, ff = stock.backbone(x), fused.backbone(x)
         for a, b in zip(fs, ff):
@@ -210,7 +210,7 @@ def test_benched_configuration_replay_matches_stock(dev, split_gemm):
     fused = copy.deepcopy(stock)
     prepare_for_inference(fused, fold_bn=False, fused_depthwise=True, split_gemm=split_gemm)
     stock, fused = stock.to(dev), fused.to(dev)
-    x = torch.rand(1, 3, 512, 1024, device=dev)
+    x = torch.rand(1, 3, 512, 1024, generator=G(1003)).to(dev)
     with torch.no_grad():
         ys = stock(x)
         side = torch.cuda.Stream()
@@ -231,7 +231,7 @@ def test_benched_configuration_replay_matches_stock(dev, split_gemm):
         clear = (top2[:, 0] - top2[:, 1]) > 1e-4
         assert bool((yf.argmax(1)[clear] == ys.argmax(1)[clear]).all())
         # a second frame through the same graph (the static input buffer is rewritten in place)
-        x2 = torch.rand(1, 3, 512, 1024, device=dev)
+        x2 = torch.rand(1, 3, 512, 1024, generator=G(1004)).to(dev)
         x.copy_(x2)
         graph.replay()
         torch.cuda.synchronize()
@@ -278,8 +278,14 @@ def test_benched_configuration_vs_reference_fixture_full_size(dev, golden, ir_ma
     clear = torch.from_numpy(np.unpackbits(g['clear_bits'].numpy())[:512 * 1024].reshape(1, 512, 1024).astype(bool))
     assert int(clear.sum()) == int(g['n_clear'])
     assert bool((y.argmax(1).to(torch.uint8)[clear] == g['mask'][clear]).all())
-    # the unclear pixels (margin <= 1e-3 of the scale): report, do not demand
+    # the unclear pixels (margin <= 1e-3 of the scale): a flip can only happen THERE, so their count bounds the whole frame's
+    # flips; the observed number is in the message of both outcomes
     flips = int((y.argmax(1).to(torch.uint8) != g['mask']).sum())
+    n_unclear = int((~clear).sum())
+    assert flips <= n_unclear, f'ir_math={ir_math}: {flips} argmax flips over the frame, only {n_unclear} pixels are unclear'
+    # observed on MI355X (round 5): 0 flips in either mode; a loose ceiling well under the unclear count catches a drift in error
+    # long before it reaches a clear pixel
+    assert flips <= max(8, n_unclear // 16), f'ir_math={ir_math}: {flips} flips among {n_unclear} unclear pixels (expected ~0)'
     print(f'ir_math={ir_math}: max sample err {float((y[:, :, 3::16, 5::16] - g["y"]).abs().max()) / scale:.2e} of scale, '
           f'{flips} argmax flips over the whole frame ({int((~clear).sum())} unclear pixels)')
 
@@ -296,15 +302,15 @@ def test_prepared_routes_fall_back_and_refresh(dev):
     prepare_for_inference(fused, fold_bn=False, fused_depthwise=True)
     fused = fused.to(dev)
     # (1) 480 x 480: the /32 stage is 15 x 15
-    x = torch.rand(1, 3, 480, 480, device=dev)
+    x = torch.rand(1, 3, 480, 480, generator=G(1005)).to(dev)
     assert not fused.backbone._fused_ok(x)
     with torch.no_grad():
         for a, b in zip(stock.backbone(x), fused.backbone(x)):
             assert rel_err(b.cpu(), a.cpu()) < 1e-5           # both run the stock route (MIOpen may pick different solvers per call)
-        x2 = torch.rand(1, 3, 256, 512, device=dev)
+        x2 = torch.rand(1, 3, 256, 512, generator=G(1006)).to(dev)
         assert fused.backbone._fused_ok(x2)
     # (2) autograd through an eval-mode prepared backbone
-    xg = torch.rand(1, 3, 256, 512, device=dev, requires_grad=True)
+    xg = torch.rand(1, 3, 256, 512, generator=G(1007)).to(dev).requires_grad_(True)
     assert not fused.backbone._fused_ok(xg)
     feats = fused.backbone(xg)
     feats[-1].square().mean().backward()
@@ -330,8 +336,8 @@ def test_graphed_model_serves_like_eager(dev):
     model = model.to(dev)
     served = GraphedModel(model, clone_output=True)
     with torch.no_grad():
-        xs = [torch.rand(1, 3, 256, 512, device=dev), torch.rand(1, 3, 256, 512).pin_memory(),
-              torch.rand(1, 3, 128, 256, device=dev), torch.rand(1, 3, 256, 512, device=dev)]
+        xs = [torch.rand(1, 3, 256, 512, generator=G(1008)).to(dev), torch.rand(1, 3, 256, 512, generator=G(1009)).pin_memory(),
+              torch.rand(1, 3, 128, 256, generator=G(1010)).to(dev), torch.rand(1, 3, 256, 512, generator=G(1011)).to(dev)]
         for x in xs:
             y = served(x)
             assert rel_err(y.cpu(), model(x.to(dev)).cpu()) < 1e-5
@@ -350,7 +356,7 @@ def test_graphed_model_serves_like_eager(dev):
         assert len(served._graphs) == 0
         assert rel_err(served(xs[0]).cpu(), other(xs[0]).cpu()) < 1e-4
     # under autograd the wrapper steps aside
-    xg = torch.rand(1, 3, 128, 256, device=dev, requires_grad=True)
+    xg = torch.rand(1, 3, 128, 256, generator=G(1012)).to(dev).requires_grad_(True)
     assert not served._graphable(xg) and not served._graphable(xs[0])       # grad mode is on again here
     with torch.no_grad():
         assert served._graphable(xs[0])

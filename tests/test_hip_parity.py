@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import bn_of, rel_err, sub
+from conftest import G, bn_of, rel_err, sub
 
 pytestmark = pytest.mark.gpu
 
@@ -245,7 +245,7 @@ def test_meta_patch_conv2d(golden, dev):
         cmp(blk(g['blk.x'].to(dev), g['blk.w'].to(dev)), g['blk.y'], what='meta_patch block (fused BN+ReLU)')
         # meta_patch.py main(): x 2x10x256x256, w ones 2xhpx8x8 -> torch.Size([2, 20, 256, 256])
         m = MetaPatchConv2d(10, 20, 3, padding=1)
-        y = m(torch.rand(2, 10, 256, 256, device=dev), torch.ones(2, m.hyper_params, 8, 8, device=dev))
+        y = m(torch.rand(2, 10, 256, 256, generator=G(1013)).to(dev), torch.ones(2, m.hyper_params, 8, 8, device=dev))
         assert y.shape == torch.Size([2, 20, 256, 256])
 
 
@@ -260,7 +260,7 @@ def test_meta_sequential(golden, dev):
     with torch.no_grad():
         cmp(seq(x, w), g['y_tensor'], what='tensor weights')
         cmp(seq(x, [w[:, :hp0].contiguous(), w[:, hp0:].contiguous()]), g['y_list'], what='list weights')
-        w_long = torch.cat([w, torch.randn(2, 5, 3, 2, device=dev)], dim=1)
+        w_long = torch.cat([w, torch.randn(2, 5, 3, 2, generator=G(1014)).to(dev)], dim=1)
         cmp(seq(x, w_long), g['y_long'], what='clamped slice')
 
 
@@ -425,13 +425,13 @@ def test_errors_are_loud(HF, dev):
     m = MetaPatchConv2d(4, 4, 1)
     with torch.no_grad():
         with pytest.raises(HipLibraryError):
-            m(torch.randn(1, 4, 8, 8), torch.randn(1, 16, 2, 2))                      # CPU tensors
+            m(torch.randn(1, 4, 8, 8, generator=G(1015)), torch.randn(1, 16, 2, 2, generator=G(1016)))                      # CPU tensors
         with pytest.raises(ValueError):
-            m(torch.randn(1, 4, 9, 8, device=dev), torch.randn(1, 16, 2, 2, device=dev))   # 9 % 2 != 0
+            m(torch.randn(1, 4, 9, 8, generator=G(1017)).to(dev), torch.randn(1, 16, 2, 2, generator=G(1018)).to(dev))   # 9 % 2 != 0
         with pytest.raises(ValueError):
-            m(torch.randn(1, 4, 8, 8, device=dev), torch.randn(1, 15, 2, 2, device=dev))   # too few weights
+            m(torch.randn(1, 4, 8, 8, generator=G(1019)).to(dev), torch.randn(1, 15, 2, 2, generator=G(1020)).to(dev))   # too few weights
     # gradients are supported through hyperseg_amd.autograd (tests/test_hip_training.py)
-    y = m(torch.randn(1, 4, 8, 8, device=dev, requires_grad=True), torch.randn(1, 16, 2, 2, device=dev))
+    y = m(torch.randn(1, 4, 8, 8, generator=G(1021)).to(dev).requires_grad_(True), torch.randn(1, 16, 2, 2, generator=G(1022)).to(dev))
     assert y.requires_grad and y.grad_fn is not None
 
 
@@ -769,3 +769,61 @@ def test_bank_in_consumer_is_what_the_decoder_runs(HF, O, dev, monkeypatch):
         y0 = d(x, s)
         assert calls['gen'] == 3 and calls['layers'] == [2, 5]
     cmp(y, y0.cpu(), what='fused vs materialised banks')
+
+
+def test_two_python_threads_two_streams_through_the_decoder(O, HF, dev):
+    """SURVEY 8b "Threading" / VERDICT r4 weak #4: the reference's multi-GPU mode is nn.DataParallel, i.e. ONE Python thread per replica
+    (parallel_apply; hyperseg/train.py:242-243, test_fps.py:155-156) through module objects whose non-tensor attributes -- this
+    package's host-side caches -- are SHARED by reference between the replicas.  Here: two threads, each on its own HIP stream, push
+    different frames through the same MultiScaleDecoder 40 times in different math modes (thread-local ir_math_scope) while a third
+    thread keeps invalidating every cache (bump_weights_epoch: what a BatchNorm update or a graph replay does), so folded BatchNorm
+    affines, transposed and packed signal2weights weights are rebuilt concurrently all the time.  Every output must equal the serial
+    result bit for bit; no exception ("dictionary changed size during iteration" in round 4's functional._S2W_BLK sweep)."""
+    import threading
+    import time
+    d = build_decoder('M', O).to(dev).eval()
+    frames = [O.synth_decoder_inputs('M', batch=1, seed=k, size=(128, 256)) for k in (0, 1)]
+    frames = [([t.to(dev) for t in x], s.to(dev)) for x, s in frames]
+    modes = ['f32', 'split']
+    ref = []
+    with torch.no_grad():
+        for (x, s), mode in zip(frames, modes):
+            with HF.ir_math_scope(mode):
+                ref.append(d(x, s).clone())
+    assert not torch.equal(ref[0], ref[1])
+    torch.cuda.synchronize()
+    outs, errors = [[], []], []
+    start = threading.Barrier(3)
+    done = threading.Event()
+
+    def replica(i):
+        try:
+            x, s = frames[i]
+            stream = torch.cuda.Stream(dev)
+            start.wait()
+            with torch.no_grad(), torch.cuda.stream(stream), HF.ir_math_scope(modes[i]):
+                for _ in range(40):
+                    outs[i].append(d(x, s))
+            stream.synchronize()
+        except BaseException as e:          # noqa: BLE001 -- re-raised on the main thread
+            errors.append(e)
+
+    def invalidator():
+        start.wait()
+        while not done.is_set():
+            HF.bump_weights_epoch()
+            time.sleep(0.0003)
+    threads = [threading.Thread(target=replica, args=(i,)) for i in (0, 1)] + [threading.Thread(target=invalidator)]
+    for t in threads:
+        t.start()
+    for t in threads[:2]:
+        t.join(120)
+    done.set()
+    threads[2].join(10)
+    assert not errors, errors
+    torch.cuda.synchronize()
+    for i in (0, 1):
+        assert len(outs[i]) == 40
+        bad = [k for k, y in enumerate(outs[i]) if not torch.equal(y, ref[i])]
+        assert not bad, f'thread {i} ({modes[i]}): iterations {bad} differ from the serial result'
+    assert getattr(HF._ir_math_local, 'mode', None) is None          # the scopes were the threads' own: nothing leaked into this one

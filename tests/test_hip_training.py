@@ -4,7 +4,7 @@ own train-mode outputs, gradients and BatchNorm running statistics (fixtures tra
 import pytest
 import torch
 
-from conftest import rel_err, sub
+from conftest import G, rel_err, sub
 from test_oracle_golden import TINY
 
 pytestmark = pytest.mark.gpu
@@ -113,7 +113,7 @@ def test_optimizer_step_runs(dev):
     x = [t.to(dev) for t in x]
     s = s.to(dev).requires_grad_(True)
     opt = torch.optim.Adam(d.parameters(), lr=1e-3, betas=(0.5, 0.999))
-    target = torch.randint(0, 12, (2, 96, 96), device=dev)
+    target = torch.randint(0, 12, (2, 96, 96), generator=G(1023)).to(dev)
     losses = []
     for _ in range(3):
         opt.zero_grad()
@@ -491,46 +491,74 @@ def test_bootstrap_mean_kernels_vs_reference_statement(dev, thresh):
 
 def test_graphed_train_step_equals_eager(dev):
     """hyperseg_amd.training.GraphedTrainStep: three replays of the captured forward + bootstrapped CE + backward + Adam step move
-    the parameters, the BatchNorm statistics and the loss exactly as three eager steps do (same kernels, same order)."""
+    the parameters, the BatchNorm statistics and the loss as three eager steps do.  Two comparisons with DIFFERENT bars, each derived
+    from tools/graphed_step_seed_sweep.py (200 target seeds on MI355X: profiles/round5_graphed_step_seed_sweep.txt):
+      * replays vs eager steps of the SAME capturable optimizer (twin C): same kernels, same order, same arithmetic -- the capture
+        itself must change nothing, so the bar is rounding level (sweep: G-C columns);
+      * replays vs eager steps of plain ``torch.optim.Adam`` (twin P, what a user's un-captured loop runs): the capturable form does
+        its bias correction with a device-side step tensor, the plain form with host floats; the last-bit difference of the step
+        size is amplified wherever a gradient component sits at rounding-noise level (Adam's update is ~lr * sign(g) there), so a
+        parameter may differ by up to ~2 lr per step taken -- the budget below is that mechanism's bound (10 lr for 5 steps), with
+        the mean held far lower (sweep: C-P columns).  Round 4's 1-in-25 failure was this comparison under an un-seeded target."""
     import copy
     from oracle import hyperseg_oracle as O
     from test_hip_parity import build_decoder
     from hyperseg_amd.training import BootstrappedCrossEntropyLoss, GraphedTrainStep
+    lr = 1e-3
     d0 = build_decoder('Sc', O).to(dev).train()
-    d1 = copy.deepcopy(d0)
+    d1, d2 = copy.deepcopy(d0), copy.deepcopy(d0)
     x, s = O.synth_decoder_inputs('Sc', batch=2, seed=3, size=(96, 96))
     x = [t.to(dev) for t in x]
     s = s.to(dev)
-    target = torch.randint(0, 12, (2, 96, 96), device=dev)
+    target = torch.randint(0, 12, (2, 96, 96), generator=G(1024)).to(dev)
     crit = BootstrappedCrossEntropyLoss(k=512, thresh=0.3, ignore_index=255)
-    o0 = torch.optim.Adam(d0.parameters(), lr=1e-3, betas=(0.5, 0.999))
-    o1 = torch.optim.Adam(d1.parameters(), lr=torch.tensor(1e-3, device=dev), betas=(0.5, 0.999), capturable=True)
+    o0 = torch.optim.Adam(d0.parameters(), lr=lr, betas=(0.5, 0.999))
+    o1 = torch.optim.Adam(d1.parameters(), lr=torch.tensor(lr, device=dev), betas=(0.5, 0.999), capturable=True)
+    o2 = torch.optim.Adam(d2.parameters(), lr=torch.tensor(lr, device=dev), betas=(0.5, 0.999), capturable=True)
     with pytest.raises(ValueError):
         GraphedTrainStep(d1, crit, o1, (x, s), target, warmup=0)       # the optimizer state must exist before the capture
     gs = GraphedTrainStep(d1, crit, o1, (x, s), target, warmup=2)      # two REAL steps (eager, side stream), then the capture
-    eager = []
-    for _ in range(5):
-        o0.zero_grad()
-        loss = crit(d0(x, s), target)
-        loss.backward()
-        o0.step()
-        eager.append(float(loss))
+
+    def eager_steps(d, o):
+        out = []
+        for _ in range(5):
+            o.zero_grad()
+            loss = crit(d(x, s), target)
+            loss.backward()
+            o.step()
+            out.append(float(loss))
+            del loss
+        return out
+    plain, twin = eager_steps(d0, o0), eager_steps(d2, o2)
     graphed = [float(gs.step()[0]) for _ in range(3)]
     # capture itself ran nothing: the three replays are steps 3-5
-    assert all(abs(a - b) < 1e-4 * abs(a) for a, b in zip(eager[2:], graphed)), (eager, graphed)
-    assert eager[-1] < eager[0]
-    # Adam moves every parameter by ~lr * sign(grad) per step: where a gradient is at rounding-noise level the sign may differ between
-    # the capturable (device-side bias correction) and the plain optimizer, so parameters get a budget of a few lr, not a relative one
-    sd0, sd1 = d0.state_dict(), d1.state_dict()
+    assert all(abs(a - b) <= GRAPH_VS_TWIN_LOSS * abs(a) for a, b in zip(twin[2:], graphed)), (twin, graphed)
+    assert all(abs(a - b) < GRAPH_VS_PLAIN_LOSS * abs(a) for a, b in zip(plain[2:], graphed)), (plain, graphed)
+    assert plain[-1] < plain[0]
+    sd0, sd1, sd2 = d0.state_dict(), d1.state_dict(), d2.state_dict()
+    worst = {'twin': 0.0, 'plain max': 0.0, 'plain mean': 0.0}
     for k in sd0:
         if sd0[k].dtype.is_floating_point:
-            diff = (sd1[k] - sd0[k]).abs()
+            dt, dp = (sd1[k] - sd2[k]).abs(), (sd1[k] - sd0[k]).abs()
             if 'running_' in k:
+                assert rel_err(sd1[k].cpu(), sd2[k].cpu()) <= GRAPH_VS_TWIN_STAT, k
                 assert rel_err(sd1[k].cpu(), sd0[k].cpu()) < 2e-2, k          # statistics of activations whose weights differ by a few lr
             else:
-                assert float(diff.max()) <= 10 * 1e-3 and float(diff.mean()) < 0.5 * 1e-3, (k, float(diff.max()), float(diff.mean()))
+                assert float(dt.max()) <= GRAPH_VS_TWIN_PARAM_LR * lr, (k, float(dt.max()))
+                assert float(dp.max()) <= 10 * lr and float(dp.mean()) < 0.5 * lr, (k, float(dp.max()), float(dp.mean()))
+                worst = {'twin': max(worst['twin'], float(dt.max())), 'plain max': max(worst['plain max'], float(dp.max())),
+                         'plain mean': max(worst['plain mean'], float(dp.mean()))}
         else:
-            assert torch.equal(sd1[k].cpu(), sd0[k].cpu()), k                # num_batches_tracked: 5 on both sides
+            assert torch.equal(sd1[k].cpu(), sd0[k].cpu()) and torch.equal(sd1[k].cpu(), sd2[k].cpu()), k   # num_batches_tracked: 5 everywhere
+    print(f'graphed vs capturable twin: max parameter gap {worst["twin"] / lr:.2e} lr; vs plain Adam: max {worst["plain max"] / lr:.2f} lr, '
+          f'mean {worst["plain mean"] / lr:.3f} lr')
+
+
+# Bars of test_graphed_train_step_equals_eager, from the 200-seed sweep (profiles/round5_graphed_step_seed_sweep.txt; header there)
+GRAPH_VS_TWIN_LOSS = 1e-6        # replays vs eager steps of the same capturable optimizer
+GRAPH_VS_TWIN_PARAM_LR = 1e-2    # ... parameters, in units of lr
+GRAPH_VS_TWIN_STAT = 1e-5        # ... BatchNorm running statistics (relative to the tensor's scale)
+GRAPH_VS_PLAIN_LOSS = 1e-3       # replays vs eager steps of plain Adam (different bias-correction arithmetic)
 
 
 def test_validation_after_graph_replays_sees_the_trained_weights(dev):
@@ -546,7 +574,7 @@ def test_validation_after_graph_replays_sees_the_trained_weights(dev):
     x, s = O.synth_decoder_inputs('Sc', batch=2, seed=3, size=(96, 96))
     x = [t.to(dev) for t in x]
     s = s.to(dev)
-    target = torch.randint(0, 12, (2, 96, 96), device=dev)
+    target = torch.randint(0, 12, (2, 96, 96), generator=G(1025)).to(dev)
     crit = BootstrappedCrossEntropyLoss(k=512, thresh=0.3, ignore_index=255)
     opt = torch.optim.Adam(d.parameters(), lr=torch.tensor(1e-2, device=dev), betas=(0.5, 0.999), capturable=True)
 
@@ -618,7 +646,7 @@ def test_bn_act_refuses_foreign_parameters(dev):
     import torch.nn as nn
     from hyperseg_amd.autograd import bn_act
     bn = nn.BatchNorm2d(8).train()                        # parameters on the CPU
-    x = torch.randn(2, 8, 6, 6, device=dev)
+    x = torch.randn(2, 8, 6, 6, generator=G(1026)).to(dev)
     with pytest.raises(RuntimeError):
         bn_act(bn, nn.ReLU6(), x)              # (stock BatchNorm2d counts the batch before it fails: the counter is not checked)
 
@@ -777,14 +805,23 @@ def test_patch_conv_bf16_storage_vs_fp32_oracle(dev, case):
 
 
 def _emulated_bf16(monkeypatch):
-    """Route hyperseg_amd.autograd's bf16 convolutions through the fp32 kernels with bf16 roundings at the same points
-    (inputs already are bf16 values; the result is rounded to bf16): "bf16 storage, fp32 accumulation" computed by the
-    kernels that the fp32 tests pin to the oracle."""
+    """The bf16 training step computed by the FP32 kernels (the ones the fp32 tests pin to the oracle and the reference fixtures) with
+    bf16 roundings at the same points: "bf16 storage, fp32 accumulation" emulated for EVERY storage-typed kernel of the step, not only
+    the convolutions (round 4's typed kernels -- hs_halo_tiles_*, hs_tile_interior_*, hs_dw_tiles_*,
+    hs_bn_act_train_*, hs_stage_input_typed_fwd, hs_upsample_bilinear_bf16_fwd / _typed_bwd, hs_cross_entropy_typed_* -- used to
+    run as bf16 kernels in BOTH legs of the step-level comparisons, i.e. were compared with themselves there).
+
+    Mechanics: (1) ``autograd._plain_conv`` (the hs_patch_conv_plain_* launcher) widens its bf16 operands -- already bf16 values --
+    runs the fp32 kernel and rounds the result once; (2) every other Function with a bf16 twin gets forward / backward wrappers that
+    widen bf16 tensor arguments exactly, call the real implementation (which then takes its fp32 branch), and round to bf16 the
+    outputs the bf16 kernels store as bf16 (activations forward, activation gradients backward; banks, their gradients,
+    BatchNorm statistics and the loss are fp32 in both legs).  The reference has no bf16 twin: this emulation IS the bf16 oracle."""
     import hyperseg_amd.autograd as HA
+    BF = torch.bfloat16
     real = HA._plain_conv
 
     def emulated(kind, dtype, a, b, ld, shape, meta, out):
-        if dtype != torch.bfloat16:
+        if dtype != BF:
             return real(kind, dtype, a, b, ld, shape, meta, out)
         a32 = a.float().contiguous()
         b32 = b.float().contiguous()
@@ -794,6 +831,58 @@ def _emulated_bf16(monkeypatch):
         out.copy_(out32)
         return out
     monkeypatch.setattr(HA, '_plain_conv', emulated)
+
+    def widen(t):
+        return t.float() if isinstance(t, torch.Tensor) and t.dtype == BF else t
+
+    def rnd(t):
+        return t.to(BF) if isinstance(t, torch.Tensor) and t.is_floating_point() else t
+
+    def wrap(cls, fwd_low=(0,), bwd_low=(0,), low_rule=None, no_autocast=False):
+        """``fwd_low`` / ``bwd_low``: indices of the forward outputs / backward gradients the bf16 kernels store as bf16."""
+        real_f, real_b = cls.forward, cls.backward
+
+        def fwd(ctx, *args):
+            low = low_rule(*args) if low_rule is not None else any(isinstance(a, torch.Tensor) and a.dtype == BF for a in args)
+            ctx._emu_low = bool(low)
+            ctx._emu_in_dtypes = [a.dtype if isinstance(a, torch.Tensor) else None for a in args]
+            if not low:
+                return real_f(ctx, *args)
+            with torch.autocast('cuda', enabled=not no_autocast and torch.is_autocast_enabled('cuda'), dtype=BF):
+                out = real_f(ctx, *[widen(a) for a in args])
+            if isinstance(out, tuple):
+                return tuple(rnd(o) if i in fwd_low else o for i, o in enumerate(out))
+            assert out.dtype == torch.float32, (cls.__name__, out.dtype)         # the fp32 branch ran
+            return rnd(out) if 0 in fwd_low else out
+
+        def bwd(ctx, *grads):
+            if not ctx._emu_low:
+                return real_b(ctx, *grads)
+            out = real_b(ctx, *[widen(g) for g in grads])
+            out = list(out) if isinstance(out, tuple) else [out]
+            for i in bwd_low:
+                if out[i] is not None:
+                    out[i] = rnd(out[i])                 # stored as bf16 by the typed kernel ...
+                    dt = ctx._emu_in_dtypes[i]
+                    if dt is not None and dt != BF:
+                        out[i] = out[i].to(dt)           # ... then cast to the input's type, as the real Function / autograd does
+            return tuple(out)
+        monkeypatch.setattr(cls, 'forward', staticmethod(fwd))
+        monkeypatch.setattr(cls, 'backward', staticmethod(bwd))
+
+    wrap(HA.HaloTiles)
+    wrap(HA.TileInterior)
+    wrap(HA.DwTilesValid)                                 # (t, bank, ...): y bf16; dt bf16, dbank fp32
+    wrap(HA.BNActTrain)                                   # (x, weight, bias, ...): y bf16; dx bf16, dgamma / dbeta fp32
+    wrap(HA.PixelCrossEntropy, fwd_low=())                # loss fp32; d logits bf16
+    wrap(HA.UpsampleBilinear)
+
+    def stage_low(skip, prev, coords):
+        return (torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == BF) or \
+            (prev is not None and prev.dtype == BF) or skip.dtype == BF
+    # (skip, prev, coords): the stage input is WRITTEN as bf16 under autocast even from fp32 operands, so the fp32 kernel has to run
+    # with autocast off; d skip is a slice of dy (bf16 values already), d prev comes out of the typed bilinear adjoint as bf16
+    wrap(HA.StageMaterialize, bwd_low=(0, 1), low_rule=stage_low, no_autocast=True)
 
 
 def _bf16_step(d, x, w, r, dev):
@@ -880,3 +969,90 @@ def test_config5_bf16_training_step(dev, monkeypatch):
     assert not bad, 'bf16 kernels vs emulation: %s\n(all: %s; fp32-vs-bf16 rel L2: %s)' % (
         ', '.join(f'{k}={v:.2e}' for k, v in bad.items()), ', '.join(f'{k}={v:.1e}' for k, v in errs.items()),
         ', '.join(f'{k}={rel_l2(g16[k].cpu(), g32[k].cpu()):.1e}' for k in g32))
+
+
+def test_train_mode_forward_under_no_grad(golden, dev):
+    """``decoder.train()`` inside ``torch.no_grad()`` -- what a train-mode sanity pass or a BatchNorm recalibration
+    loop does -- raised in round 4 (a TrainBank reached the inference kernels).  It must run, give the train-mode logits of the
+    reference fixture (batch statistics), and move the running statistics exactly as a grad-enabled train-mode forward does."""
+    import copy
+    g = golden('train_t_v1_0')
+    c = TINY['t_v1_0']
+    d = make_decoder(c)
+    d.load_state_dict(sub(g, 'p.'), strict=False)
+    d = d.to(dev).train()
+    twin = copy.deepcopy(d)
+    x = [g[f'x{i}'].to(dev) for i in range(6)]
+    s = g['s'].to(dev)
+    with torch.no_grad():
+        y = d(x, s)
+    assert not y.requires_grad and rel_err(y.cpu(), g['y']) < TOL
+    yt = twin(x, s)                                         # grad enabled: the autograd route the fixture pins
+    assert torch.equal(y, yt.detach())
+    for (k, a), (_, b) in zip(d.state_dict().items(), twin.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
+def test_train_banks_guards_fall_back_to_the_per_level_route(golden, dev, monkeypatch):
+    """ADVICE r4 (low x2): decoders the single-launch training banks (hs_s2w_train_*) cannot take -- more than S2W_MAX_LAYERS layers,
+    32-bit offsets exceeded, a level whose signal range passes MetaSequential's clamped slice -- must take the per-level route (same
+    values and gradients), not fail with HS_ERR_*."""
+    import hyperseg_amd.functional as HF
+    g = golden('train_t_v1_0')
+    c = TINY['t_v1_0']
+
+    def run(limit):
+        monkeypatch.setattr(HF, 'S2W_TRAIN_MAX_LAYERS', limit)
+        d = make_decoder(c)
+        d.load_state_dict(sub(g, 'p.'), strict=False)
+        d = d.to(dev).train()
+        s = g['s'].to(dev).requires_grad_(True)
+        taken = d._train_banks(s) is not None
+        y = d([g[f'x{i}'].to(dev) for i in range(6)], s)
+        (y * g['r'].to(dev)).sum().backward()
+        return taken, y.detach(), s.grad.clone()
+    on, y1, g1 = run(8)
+    off, y2, g2 = run(2)                                    # five signal-fed modules > 2: every level makes its own bank
+    assert on and not off
+    assert rel_err(y1.cpu(), g['y']) < TOL and rel_err(y2.cpu(), g['y']) < TOL
+    assert rel_err(g1.cpu(), g['gs']) < TOL and rel_err(g2.cpu(), g['gs']) < TOL
+
+
+def test_pixel_cross_entropy_refuses_a_mismatched_target(dev):
+    """a target that is not (N, H, W) of the logits made the kernel read and write out of bounds; F.cross_entropy
+    raises for it, and so must the HIP path (reachable through BootstrappedCrossEntropyLoss with an un-resized prediction)."""
+    from hyperseg_amd import autograd as HA
+    logits = torch.randn(2, 5, 8, 12, generator=G(2001)).to(dev)
+    with pytest.raises(ValueError):
+        HA.PixelCrossEntropy.apply(logits, torch.zeros(2, 4, 6, dtype=torch.int64, device=dev), 255)
+    with pytest.raises(ValueError):
+        HA.PixelCrossEntropy.apply(logits, torch.zeros(2, 8, 12, dtype=torch.int32, device=dev), 255)
+    with pytest.raises(ValueError):
+        HA.PixelCrossEntropy.apply(logits, torch.zeros(2, 8, 12, dtype=torch.int64), 255)           # target left on the CPU
+    t = torch.randint(0, 5, (2, 8, 12), generator=G(2002)).to(dev)
+    loss = HA.PixelCrossEntropy.apply(logits, t, 255)
+    assert rel_err(loss.cpu(), torch.nn.functional.cross_entropy(logits, t, reduction='none').cpu()) < 1e-6
+
+
+def test_general_meta_conv_on_a_column_range_of_a_wider_weight_tensor(dev):
+    """MetaSequential hands a MetaConv2d the view w[:, a:b] of the batch's weight tensor -- rows ``stride(0)`` apart,
+    not ``is_contiguous()`` for B > 1.  The general (strided / dilated) MetaConv2d must read it in place, in inference and under
+    autograd, and agree with the same rows as a contiguous tensor."""
+    from hyperseg_amd.models.layers.meta_conv import MetaConv2d
+    m = MetaConv2d(4, 6, (3, 2), stride=(2, 1), padding=(1, 0), dilation=(1, 2), groups=2)
+    x = torch.randn(3, 4, 11, 9, generator=G(2003)).to(dev)
+    wide = torch.randn(3, m.hyper_params + 10, generator=G(2004)).to(dev)
+    view = wide[:, 7:7 + m.hyper_params]
+    assert not view.is_contiguous() and view.stride(1) == 1
+    with torch.no_grad():
+        y_view, y_copy = m(x, view), m(x, view.contiguous())
+    assert torch.equal(y_view, y_copy)
+    xg, wg = x.clone().requires_grad_(True), wide.clone().requires_grad_(True)
+    yg = m(xg, wg[:, 7:7 + m.hyper_params])
+    assert torch.equal(yg.detach(), y_copy)
+    r = torch.randn(yg.shape, generator=G(2005)).to(dev)
+    (yg * r).sum().backward()
+    xc, wc = x.clone().requires_grad_(True), view.contiguous().clone().requires_grad_(True)
+    (m(xc, wc) * r).sum().backward()
+    assert torch.equal(xg.grad, xc.grad) and torch.equal(wg.grad[:, 7:7 + m.hyper_params], wc.grad)
+    assert float(wg.grad[:, :7].abs().max()) == 0.0 and float(wg.grad[:, 7 + m.hyper_params:].abs().max()) == 0.0

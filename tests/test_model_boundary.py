@@ -6,7 +6,7 @@ import hashlib
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import G, rel_err
 from hyperseg_amd.utils.synthetic import fill_by_name
 
 
@@ -92,7 +92,7 @@ def test_obj_factory_contract():
 def test_decoder_refuses_cpu(model_m):
     from hyperseg_amd._hip import HipLibraryError
     with torch.no_grad(), pytest.raises(HipLibraryError):
-        model_m(torch.rand(1, 3, 64, 64))
+        model_m(torch.rand(1, 3, 64, 64, generator=G(1027)))
 
 
 def test_graphed_model_host_logic(model_m):
@@ -103,7 +103,7 @@ def test_graphed_model_host_logic(model_m):
     from hyperseg_amd.fps import measure_fps, synthetic_batches
     from hyperseg_amd.utils.inference import GraphedModel
     served = GraphedModel(model_m, clone_output=True)
-    x = torch.rand(1, 3, 64, 64)
+    x = torch.rand(1, 3, 64, 64, generator=G(1028))
     assert served.accepts_host_input and not served._graphable(x) and not served._graphable([x, x])
     with torch.no_grad(), pytest.raises(HipLibraryError):
         served(x)
@@ -212,7 +212,7 @@ def test_fps_harness_and_bn_removal():
                 m.weight.fill_(1.0); m.bias.zero_(); m.running_mean.zero_(); m.running_var.fill_(1.0 - m.eps)
     fps.remove_bn(model)
     assert not any(isinstance(m, torch.nn.BatchNorm2d) for m in model.modules())
-    x = torch.rand(1, 3, 128, 256)
+    x = torch.rand(1, 3, 128, 256, generator=G(1029))
     with torch.no_grad():
         a, b = model.to(dev)(x.to(dev)).cpu(), ident.to(dev)(x.to(dev)).cpu()
     assert rel_err(a, b) < 1e-4
@@ -238,7 +238,7 @@ def test_inference_prep_matches_stock_encoder(batch):
     assert len([m for m in fused.backbone.modules() if isinstance(m, torch.nn.BatchNorm2d)]) == n_bn
     assert list(fused.state_dict()) == list(stock.state_dict())          # checkpoints still round-trip
     stock, fused = stock.to(dev), fused.to(dev)
-    x = torch.rand(batch, 3, 128, 192, device=dev)
+    x = torch.rand(batch, 3, 128, 192, generator=G(1030)).to(dev)
     with torch.no_grad():
         fs, ff = stock.backbone(x), fused.backbone(x)
         for a, b in zip(fs, ff):
@@ -364,7 +364,7 @@ def test_deferred_bn_shift_algebra_cpu(monkeypatch, config, split):
     deferred = [b._fused_dw.defer_shift for b in bb._blocks]
     assert sum(deferred) >= len(deferred) - 3 and not deferred[0]     # block 0 feeds a depthwise conv directly
     for size, batch in (((128, 256), 1), ((64, 128), 2)):             # 128x256: first blocks take the "MFMA" route
-        x = torch.rand(batch, 3, *size)
+        x = torch.rand(batch, 3, *size, generator=G(1031))
         with torch.no_grad():
             ref = stock.backbone(x)
             t = F.silu(bb._bn0(bb._conv_stem(x)))

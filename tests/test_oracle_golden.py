@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import bn_of, rel_err, sub
+from conftest import G, bn_of, rel_err, sub
 from oracle import hyperseg_oracle as O
 
 TOL = 2e-6   # the oracle re-associates fp32 sums; observed <= 1.5e-6 relative
@@ -263,6 +263,7 @@ def test_fps_harness_confusion_matrix_and_plumbing(golden):
     net = torch.nn.Sequential(torch.nn.Conv2d(3, 5, 1), torch.nn.BatchNorm2d(5), torch.nn.Sequential(torch.nn.BatchNorm2d(5)))
     remove_bn(net)
     assert not any(isinstance(m, torch.nn.BatchNorm2d) for m in net.modules())
-    batches = [(torch.rand(2, 3, 4, 6), torch.randint(0, 5, (2, 4, 6))) for _ in range(3)]
+    gx, gt = G(1032), G(1033)
+    batches = [(torch.rand(2, 3, 4, 6, generator=gx), torch.randint(0, 5, (2, 4, 6), generator=gt)) for _ in range(3)]
     res = measure_fps(net.eval(), batches, torch.device('cpu'), 5)
     assert res['frames'] == 6 and res['pass'] == 1 and res['fps'] > 0 and 0.0 <= res['mean_iou'] <= 1.0

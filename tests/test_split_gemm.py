@@ -4,7 +4,7 @@ split, fragment order, plan) is checked on the CPU; the GPU tests run under plai
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import G, rel_err
 
 def test_split_weights_host_side():
     from hyperseg_amd import functional as HF
@@ -31,11 +31,11 @@ def test_split_weights_host_side():
         err = (rebuilt[:m, :k] - ref.double()).abs().amax(1) / ref.abs().amax(1).double()
         assert float(err.max()) < 2.0 ** -21                     # two f16 pieces of a row scaled to < 2^15
         assert float((back[0].abs().amax(1)[:m]).max()) < 2.0 ** 15
-    assert HF.gemm_split_weights(torch.randn(8, 1920)) is None
-    sw4 = HF.gemm_split_weights(torch.randn(8, 480, 2, 2), max_k=2560)
-    assert (sw4.c_in, sw4.kp) == (1920, 2048) and HF.gemm_split_weights(torch.randn(8, 641, 2, 2), max_k=2560) is None
+    assert HF.gemm_split_weights(torch.randn(8, 1920, generator=G(1034))) is None
+    sw4 = HF.gemm_split_weights(torch.randn(8, 480, 2, 2, generator=G(1035)), max_k=2560)
+    assert (sw4.c_in, sw4.kp) == (1920, 2048) and HF.gemm_split_weights(torch.randn(8, 641, 2, 2, generator=G(1036)), max_k=2560) is None
     with pytest.raises(Exception):
-        HF.gemm_split(HF.gemm_split_weights(torch.randn(8, 64)), torch.rand(1, 64, 4, 4))       # CPU tensors: no fallback
+        HF.gemm_split(HF.gemm_split_weights(torch.randn(8, 64, generator=G(1037))), torch.rand(1, 64, 4, 4, generator=G(1038)))       # CPU tensors: no fallback
 
 
 @pytest.mark.parametrize('m,k', [(40, 240), (112, 672), (192, 1152), (480, 80)])
@@ -180,7 +180,7 @@ def test_prepared_model_with_split_gemm(batch, size):
     fused = copy.deepcopy(stock)
     prepare_for_inference(fused, fold_bn=False, fused_depthwise=True, split_gemm=True)
     stock, fused = stock.to(dev), fused.to(dev)
-    x = torch.rand(batch, 3, *size, device=dev)
+    x = torch.rand(batch, 3, *size, generator=G(1039)).to(dev)
     with torch.no_grad():
         for a, b in zip(stock.backbone(x), fused.backbone(x)):
             assert rel_err(b.cpu(), a.cpu()) < 5e-5
