@@ -39,6 +39,9 @@ Extra objects on the line:
                 sync; hyperseg_amd/fps.py) on the same model, N = 1 only.
   cpu_baseline  the CPU oracle ("port": stock encoder on CPU + oracle/cpu_port.py decoder) timed on the host cores of
                 this box on a bounded sample of the same workload (N = 1, rank 0, --model m only).
+  other_configs the other BASELINE configurations as side objects of the default run (N = 1, --model m): `s` = HyperSeg-S 1536x768
+                (config 3: whole-model frames/s, decoder launch table, its dominant launch's roofline), `train_sc` = the config-5
+                training step of the CamVid-S decoder replayed as one HIP graph, fp32 and bf16 (ms per step, step-level roofline).
 """
 import argparse
 import json
@@ -373,6 +376,122 @@ def cpu_baseline(model_cpu, size, budget_s=20.0):
             'decoder_ms': round(1e3 * dec / n, 2), 'encoder_ms': round(1e3 * enc / n, 2)}
 
 
+# --------------------------------------------------------------------------------------------- other BASELINE configs, side objects
+def side_model(key, dev, steps, warmup, ir_math, split_gemm):
+    """BASELINE config 3 (and any other --model key) as a SIDE object of the default run: whole-model frames/s of one timed region of
+    HIP-graph replays, the decoder's eager launch table and the roofline of ITS dominant launch (event-timed like the headline's;
+    `traffic` null: no PMC pass is spent on side objects).  Built, measured and freed outside every headline region."""
+    from hyperseg_amd import configs
+    from hyperseg_amd.utils.inference import prepare_for_inference
+    from hyperseg_amd.utils.synthetic import fill_by_name
+    plan = plan_workload(key, 0, 1)
+    h, w, batch = plan['h'], plan['w'], plan['batch']
+    model = fill_by_name(configs.build(plan['cfg']).eval(), seed=0)
+    prepare_for_inference(model, fold_bn=False, fused_depthwise=True, split_gemm=split_gemm, ir_math=ir_math)
+    model = model.to(dev)
+    x = torch.rand(batch, 3, h, w, generator=torch.Generator().manual_seed(4321)).to(dev)
+    v, ms, y, g = time_replayed(model, x, steps, warmup, batch)
+    launches, dec_us, _ = instrumented_decoder(model, x, 6)
+    alg_bytes, levels = decoder_levels(model, h, w, batch)
+    roof = roofline_of(launches, levels, h, w, batch, None)
+    roof['traffic_source'] = 'none (side object: no PMC pass)'
+    out = {'workload': f'{LABELS[key]}, batch {batch}, whole model forward, resident input, hipGraph replay', 'value': v, 'unit': 'frames/s',
+           'ms_per_step': ms, 'steps': steps, 'regions': 1, 'ir_math': ir_math, 'finite': bool(torch.isfinite(y).all()),
+           'decoder': {'us_per_batch_eager': round(dec_us, 1), 'algorithmic_bytes': alg_bytes,
+                       'hbm_frac_of_8TBs': round(alg_bytes / (dec_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                       'launches': [(l['kernel'], l['avg_us']) for l in launches if l['in_decoder']]},
+           'roofline': roof}
+    del g, model
+    return out
+
+
+def side_train_step(dev, iters):
+    """BASELINE config 5 as a SIDE object: one training step of the CamVid-S decoder (576x576 crops, bs 2: forward + bootstrapped cross
+    entropy + backward + Adam) replayed as ONE HIP graph (hyperseg_amd.training.GraphedTrainStep), fp32 and under bf16 autocast
+    (bf16 activation storage, f32 accumulation; banks, statistics and the optimizer fp32).  Roofline at STEP level -- the step is a
+    chain of small launches, none of which dominates: algorithmic bytes of the step (forward bytes of SURVEY 8d x 3: the forward pass,
+    the input-gradient pass and the weight-gradient pass each touch the forward's tensors once) / the replayed step time; the longest
+    kernel of an eager step from torch.profiler beside it when the profiler is available."""
+    from hyperseg_amd import configs
+    from hyperseg_amd.training import BootstrappedCrossEntropyLoss, GraphedTrainStep
+    from hyperseg_amd.utils.synthetic import fill_by_name
+    torch.set_grad_enabled(True)
+    try:
+        model = fill_by_name(configs.build('hyperseg-s-camvid'), seed=0).to(dev)
+        gen = torch.Generator().manual_seed(99)
+        x = torch.rand(2, 3, 576, 576, generator=gen).to(dev)
+        with torch.no_grad():
+            model.eval()
+            feats = model.backbone(x)
+            sig = model.weight_mapper(feats[-1]).contiguous()
+            pyr = [t.contiguous() for t in [x] + feats[:-1]]
+        alg_fwd, _ = decoder_levels(model, 576, 576, 2)
+        dec = model.decoder.train()
+        target = torch.randint(0, 12, (2, 576, 576), generator=gen).to(dev)
+        crit = BootstrappedCrossEntropyLoss(k=4096, thresh=0.3, ignore_index=255)
+        res = {'workload': 'HyperSeg-S / CamVid decoder training step, 576x576 crops, batch 2: forward + bootstrapped CE + backward + Adam, '
+                           'one HIP graph per step (encoder features and signal resident, as tools/train_step_time.py)'}
+        state0 = {k: v.clone() for k, v in dec.state_dict().items()}
+        for mode in ('fp32', 'bf16'):
+            dec.load_state_dict(state0)
+            opt = torch.optim.Adam(dec.parameters(), lr=torch.tensor(1e-3, device=dev), betas=(0.5, 0.999), capturable=True, fused=True)
+
+            def fwd(p, s_, half=(mode == 'bf16')):
+                with torch.autocast('cuda', dtype=torch.bfloat16, enabled=half):
+                    return dec(p, s_)
+            gs = GraphedTrainStep(fwd, crit, opt, (pyr, sig), target)
+            for _ in range(3):
+                gs.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                loss, _ = gs.step()
+            torch.cuda.synchronize()
+            ms = 1e3 * (time.perf_counter() - t0) / iters
+            res[mode] = {'ms_per_step': round(ms, 4), 'steps_per_s': round(1e3 / ms, 1), 'steps': iters, 'loss_after': round(float(loss), 4),
+                         'finite': bool(torch.isfinite(loss))}
+            del gs, opt, loss
+        res['bf16_speedup_over_fp32'] = round(res['fp32']['ms_per_step'] / res['bf16']['ms_per_step'], 3)
+        step_bytes = 3 * alg_fwd
+        t_s = res['fp32']['ms_per_step'] * 1e-3
+        res['roofline'] = {'bound': 'hbm', 'kernel': 'whole replayed fp32 step (launch-latency-bound chain; no single dominant kernel)',
+                           'achieved': round(step_bytes / t_s / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                           'frac': round(step_bytes / t_s / 1e9 / HBM_PEAK_GBS, 4), 'traffic': None, 'algorithmic_bytes': step_bytes,
+                           'note': f'algorithmic bytes = 3 x the forward pass\' {alg_fwd} B (SURVEY 8d definition)'}
+        try:                                                  # the longest kernel of one eager fp32 step (kineto / roctracer)
+            from torch.profiler import ProfilerActivity, profile
+            dec.load_state_dict(state0)
+            opt = torch.optim.Adam(dec.parameters(), lr=1e-3, betas=(0.5, 0.999), fused=True)
+
+            def eager():
+                opt.zero_grad(set_to_none=True)
+                loss = crit(dec(pyr, sig), target)
+                loss.backward()
+                opt.step()
+            eager()
+            torch.cuda.synchronize()
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                for _ in range(3):
+                    eager()
+                torch.cuda.synchronize()
+            rows = []
+            for e in prof.key_averages():
+                tot = getattr(e, 'device_time_total', None)
+                tot = getattr(e, 'cuda_time_total', 0.0) if tot is None else tot
+                if tot and e.count:
+                    rows.append((tot / e.count, e.count / 3.0, e.key))
+            total = sum(a * c for a, c, _ in rows)
+            top = max(rows)
+            res['dominant_kernel'] = {'name': top[2][:120], 'avg_us': round(top[0], 2), 'launches_per_step': round(top[1], 1),
+                                      'kernel_time_per_step_us': round(total, 1), 'kernels_per_step': round(sum(c for _, c, _ in rows), 1),
+                                      'source': 'torch.profiler (device activities), 3 eager fp32 steps'}
+        except Exception as e:                                # noqa: BLE001
+            res['dominant_kernel'] = {'error': f'{type(e).__name__}: {e}'[:200]}
+        return res
+    finally:
+        torch.set_grad_enabled(False)
+
+
 # --------------------------------------------------------------------------------------------- main
 def two_in_flight(forward, x, y_ref, steps, warmup, batch):
     """A serving-style side number, never ``value``: two independent requests of the benched batch in flight.  Each is a
@@ -511,14 +630,22 @@ def main(argv=None):
     ap.add_argument('--output', default='logits', choices=['logits', 'masks'],
                     help="what a step produces: fp32 logits (the reference's forward, default) or uint8 argmax masks "
                          "taken inside the final upsample kernel (HyperGen.segment; test_fps.py:194's epilogue fused)")
-    ap.add_argument('--gather', default='logits', choices=['logits', 'masks'],
-                    help='what the N>1 collective moves (north star: logits)')
-    ap.add_argument('--collective', default=None, choices=['auto', 'ingraph', 'allgather', 'direct', 'gather', 'none'],
-                    help="N>1: the all-gather of every rank's logits.  'allgather' (default at N>1): RCCL all_gather_into_tensor, in place, zero "
-                         "copy, on RCCL's own stream; 'ingraph': the same collective as a parallel branch INSIDE the step's HIP graph; 'auto': "
-                         "both, whichever a short calibration finds faster (both reported); 'direct': grouped RCCL point-to-point sends / "
-                         "receives, all pairs; 'gather': onto rank 0 (nn.DataParallel semantics); 'none'.  Given explicitly at N=1 it runs "
-                         "the collective on a one-rank group and reports its per-step overhead ('collective.overhead_pct')")
+    ap.add_argument('--gather', default='logits', choices=['logits', 'masks', 'auto'],
+                    help="what the N>1 collective moves (north star: logits); 'auto': logits unless no logits schedule fits the xGMI "
+                         'links at the measured step rate (--collective fit) or the masks candidate calibrates faster (--collective auto)')
+    ap.add_argument('--collective', default=None, choices=['fit', 'auto', 'ingraph', 'allgather', 'direct', 'gather', 'none'],
+                    help="N>1: the all-gather of every rank's logits.  'fit' (default at N>1): the schedule whose busiest xGMI link keeps up "
+                         "with the measured single-GPU step rate (hyperseg_amd.distributed.fitting_policy): the RCCL ring all-gather if "
+                         "(N-1) x payload x steps/s fits one link, else the all-pairs schedule ('direct': one shard per link and direction); "
+                         "'allgather': RCCL all_gather_into_tensor, in place, zero copy, on RCCL's own stream; 'ingraph': the same collective as "
+                         "a parallel branch INSIDE the step's HIP graph; 'auto': ingraph, allgather, direct (and the masks payload) timed in a "
+                         "short calibration, the fastest kept; 'direct': grouped RCCL point-to-point sends / receives, all pairs; 'gather': "
+                         "onto rank 0 (nn.DataParallel semantics); 'none'.  Given explicitly at N=1 it runs the collective on a one-rank "
+                         "group and reports its per-step overhead ('collective.overhead_pct')")
+    ap.add_argument('--link-gbs', type=float, default=None,
+                    help='xGMI bandwidth of one link in one direction, GB/s (default: hyperseg_amd.distributed.XGMI_LINK_GBS_PER_DIRECTION = 76.5)')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='skip the other_configs side objects (HyperSeg-S 1536x768 and the config-5 training step) of the default run')
     ap.add_argument('--probe-load', type=int, default=0,
                     help='N=1 collective probe only: that many extra out-of-place all-gathers of the payload per step (one RCCL copy '
                          'kernel each at world 1), so that RCCL kernels really run beside the forward')
@@ -568,10 +695,13 @@ def main(argv=None):
         torch.cuda.set_device(dev)
     collective_probe = world == 1 and args.collective not in (None, 'none')      # N=1: measure the collective's own cost
     if args.collective is None:
-        # N > 1 default: the plain RCCL all_gather_into_tensor on RCCL's stream -- the most travelled path of the library, chosen for
-        # the FIRST multi-GPU run this code ever gets (no such hardware on the builder's side).  'auto' calibrates it against the
-        # in-graph form on the spot and keeps the faster one; tools/scale_run.sh runs either.
-        args.collective = 'allgather' if world > 1 else 'none'
+        # N > 1 default: 'fit' -- the logits all-gather on the schedule whose busiest xGMI link keeps up with the step rate this very run
+        # measures on its own GPU (round 4's default, the ring all-gather, needs ~300 GB/s per link at 8 x HyperSeg-M against ~77 per
+        # direction; the all-pairs schedule needs 51).  No calibration of collectives, one decision from one all-reduced number: the
+        # FIRST multi-GPU run this code ever gets cannot diverge between ranks.  'auto' times every candidate instead.
+        args.collective = 'fit' if world > 1 else 'none'
+    if args.collective == 'fit' and world == 1:
+        args.collective = 'allgather'                       # N = 1 probe: nothing to fit
     if world > 1 or collective_probe:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if collective_probe:
@@ -649,19 +779,29 @@ def main(argv=None):
             model.decoder.output_buffer = None
 
     # ---- the collective: candidates, calibration, choice --------------------------------------------------------------
-    shape = tuple(y.shape) if args.gather == 'logits' else (y.shape[0],) + tuple(y.shape[-2:])
-    dtype = torch.float32 if args.gather == 'logits' else torch.uint8
-    to_payload = None
-    if args.gather == 'masks':
-        to_payload = lambda t: t if t.dtype == torch.uint8 else t.argmax(1).to(torch.uint8)   # noqa: E731
-    zero_copy_ok = (graph is not None and args.gather == 'logits' and args.output != 'masks'
-                    and hasattr(getattr(model, 'decoder', None), 'forward'))
+    from hyperseg_amd.distributed import XGMI_LINK_GBS_PER_DIRECTION, LINK_HEADROOM, fitting_policy, link_gbs_needed, link_schedule
+    link_gbs = args.link_gbs if args.link_gbs is not None else XGMI_LINK_GBS_PER_DIRECTION
+
+    def payload_spec(gather):
+        """(shape, dtype, to_payload, bytes) of what one rank contributes per step."""
+        if gather == 'logits':
+            shp, dt, conv = tuple(y.shape), torch.float32, None
+        else:
+            shp, dt = (y.shape[0],) + tuple(y.shape[-2:]), torch.uint8
+            conv = lambda t: t if t.dtype == torch.uint8 else t.argmax(1).to(torch.uint8)   # noqa: E731
+        return shp, dt, conv, int(torch.empty((), dtype=dt).element_size()) * int(torch.Size(shp).numel())
+    if args.output == 'masks' and args.gather != 'masks':
+        args.gather = 'masks'
+    gather = 'logits' if args.gather == 'auto' else args.gather
     notes = {}
 
-    def make_loop(policy):
+    def make_loop(policy, gather=None):
         """StepLoop for one collective policy (None = no collective); returns (loop, comm, zero_copy)."""
         if policy in (None, 'none'):
             return StepLoop(run_forward, None, None, world, dev), None, False
+        shape, dtype, to_payload, _ = payload_spec(gather)
+        zero_copy_ok = (graph is not None and gather == 'logits' and args.output != 'masks'
+                        and hasattr(getattr(model, 'decoder', None), 'forward'))
         mode = 'allgather' if policy == 'ingraph' else policy
         comm = LogitsGatherer(world, shape, dtype, dev, mode=mode, probe_load=args.probe_load if world == 1 else 0)
         if policy == 'ingraph':
@@ -705,34 +845,51 @@ def main(argv=None):
         base_ms = 1e3 * statistics.median(base) / args.steps
     calibration = None
     policy = args.collective
-    if policy == 'auto':
-        candidates = (['ingraph'] if zero_copy_ok else []) + ['allgather']
+    fit = None
+    if policy == 'fit':
+        # this rank's own step rate (no collective), MAX-reduced like every timed region: every rank computes the same decision
+        t = run_timed(StepLoop(run_forward, None, None, world, dev), args.calib_steps, min(10, args.warmup), 1)[0]
+        rate = args.calib_steps / t
+        nbytes = payload_spec(gather)[3]
+        policy, fits = fitting_policy(world, nbytes, rate, link_gbs)
+        if not fits and args.gather == 'auto':
+            gather = 'masks'
+            policy, fits = fitting_policy(world, payload_spec('masks')[3], rate, link_gbs)
+        fit = {'steps_per_s_without_collective': round(rate, 1), 'fits': fits,
+               'link_gbs_needed': {c: round(link_gbs_needed(c, world, payload_spec(gather)[3], rate), 2) for c in ('allgather', 'direct')}}
+        loop, comm, zero_copy = make_loop(policy, gather)
+    elif policy == 'auto':
+        graphable = graph is not None and args.output != 'masks' and hasattr(getattr(model, 'decoder', None), 'forward')
+        candidates = [(c, gather) for c in ((['ingraph'] if graphable and gather == 'logits' else []) + ['allgather', 'direct'])]
+        if gather == 'logits':
+            candidates.append(('allgather', 'masks'))       # timed and reported; eligible only under --gather auto
         calibration, built = {}, {}
-        for cand in candidates:
+        for cand, gth in candidates:
+            label = cand if gth == gather else f'{cand}:{gth}'
             try:
-                trio = make_loop(cand)
+                trio = make_loop(cand, gth)
                 ok = True
             except Exception as e:                        # noqa: BLE001  (e.g. a stack that cannot capture RCCL)
-                notes[cand] = f'{type(e).__name__}: {e}'[:300]
+                notes[label] = f'{type(e).__name__}: {e}'[:300]
                 trio, ok = None, False
                 if not stub:
                     torch.cuda.synchronize()
             if not agree(ok):
-                calibration[cand] = None
+                calibration[label] = None
                 continue
             t = run_timed(trio[0], args.calib_steps, min(10, args.warmup), 1)[0]
-            calibration[cand] = round(1e3 * t / args.calib_steps, 4)
-            built[cand] = trio
-        usable = {c: v for c, v in calibration.items() if v is not None}
+            calibration[label] = round(1e3 * t / args.calib_steps, 4)
+            built[label] = (trio, cand, gth)
+        usable = {c: v for c, v in calibration.items() if v is not None and (args.gather == 'auto' or built[c][2] == gather)}
         if not usable:
             raise SystemExit(f'no collective policy came up: {notes}')
-        policy = min(usable, key=usable.get)                # the calibration time is MAX-reduced: every rank picks the same
-        loop, comm, zero_copy = built[policy]
+        best = min(usable, key=usable.get)                  # the calibration time is MAX-reduced: every rank picks the same
+        (loop, comm, zero_copy), policy, gather = built[best]
         for c in list(built):
-            if c != policy:
+            if c != best:
                 del built[c]
     else:
-        loop, comm, zero_copy = make_loop(policy)
+        loop, comm, zero_copy = make_loop(policy, gather)
     times = run_timed(loop, args.steps, args.warmup, max(1, args.repeats))
     med = statistics.median(times)
     fps = args.steps * global_batch / med
@@ -775,7 +932,7 @@ def main(argv=None):
                                      ('as 3-term f16 split products with f32 accumulation (hs_gemm_split_fwd; error below an fp32 fmaf '
                                       "chain's) -- `library_gemm_f32` re-times the frame with IEEE f32 library GEMMs instead"
                                       if args.split_gemm and not args.stock_encoder else 'IEEE f32 (library GEMM)'),
-                       'parallelism': f'batch-sharded x{world}' + (f', RCCL {policy} of {args.gather}' if comm is not None else '')},
+                       'parallelism': f'batch-sharded x{world}' + (f', RCCL {policy} of {gather}' if comm is not None else '')},
             'per_rank_frames_per_s': per_rank,
             'collective': None if comm is None else {
                 'policy': policy, 'requested': args.collective,
@@ -784,7 +941,13 @@ def main(argv=None):
                 'op': {'allgather': 'all_gather_into_tensor (in place) on the RCCL stream, one submit per step',
                        'ingraph': "all_gather_into_tensor (in place) captured into the step's HIP graph, parallel to the forward",
                        'direct': 'batch_isend_irecv, all pairs (one shard per link and direction)',
-                       'gather': 'gather(dst=0)'}[policy], 'payload': args.gather,
+                       'gather': 'gather(dst=0)'}[policy], 'payload': gather,
+                'fit': fit,
+                # bytes across the busiest xGMI link in one direction per step under this schedule (hyperseg_amd.distributed.link_schedule),
+                # what that asks of the link at the measured step rate, and what a link has
+                **link_schedule(policy, world, comm.bytes_per_step),
+                'link_gbs_needed_at_this_rate': round(link_gbs_needed(policy, world, comm.bytes_per_step, args.steps / med), 2),
+                'link_gbs_per_direction': link_gbs, 'link_headroom': LINK_HEADROOM,
                 'zero_copy': zero_copy, 'copies_into_the_ring': getattr(comm, 'copies', 0),
                 'probe_load': args.probe_load if world == 1 else None,
                 'ms_per_step_without': None if base_ms is None else round(base_ms, 4),
@@ -883,6 +1046,22 @@ def main(argv=None):
                 out['cpu_baseline'] = None
                 if args.model == 'm' and not args.no_cpu_baseline:
                     out['cpu_baseline'] = cpu_baseline(fill_by_name(configs.build(cfg).eval(), seed=0), (h, w), args.cpu_budget)
+                if args.model == 'm' and graph is not None and not args.no_other_configs and not args.stock_encoder:
+                    # ---- the other BASELINE configs on the driver's line: config 3 (1536x768) and config 5 (training
+                    # step, fp32 + bf16), one short region each, after and outside every headline region; never `value` ------------
+                    graph = None                          # free the headline's graph pool before the side models are built
+                    torch.cuda.empty_cache()
+                    other = {}
+                    for name, fn in (('s', lambda: side_model('s', dev, 60, 10, args.ir_math, args.split_gemm)),
+                                     ('train_sc', lambda: side_train_step(dev, 40))):
+                        t_side = time.perf_counter()
+                        try:
+                            other[name] = fn()
+                        except Exception as e:            # noqa: BLE001  (a side number must never cost the line)
+                            other[name] = {'error': f'{type(e).__name__}: {e}'[:300]}
+                            torch.cuda.synchronize()
+                        other[name]['wall_s'] = round(time.perf_counter() - t_side, 1)
+                    out['other_configs'] = other
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + '\n').encode())
     if dist.is_available() and dist.is_initialized():

@@ -17,6 +17,49 @@ import torch
 import torch.distributed as dist
 
 RING = 3
+# xGMI on an MI355X node: every GPU pair has its own link (7 per GPU), ~153 GB/s per link counting both directions --
+# ~76.5 GB/s each way.  A collective policy "fits" when the bytes it moves across its busiest link in one direction per step,
+# times the step rate, stay under LINK_HEADROOM of that.
+XGMI_LINK_GBS_PER_DIRECTION = 76.5
+LINK_HEADROOM = 0.8
+
+
+def link_schedule(policy, world, payload_bytes):
+    """Bytes per step that ``policy`` moves for one rank's payload of ``payload_bytes`` on a fully connected xGMI node:
+      per_link_bytes     across the BUSIEST link in one direction;
+      bytes_in_per_gpu   received by the busiest GPU (all of its links together);
+      links_per_gpu      links of a GPU that carry data.
+    ``allgather`` / ``ingraph``: priced as ONE ring (RCCL's all-gather forwards every shard around the ring: (world - 1) shards
+    cross each ring link; RCCL may stripe the payload over several rings on different links -- the single ring is the conservative
+    figure, per_link_bytes_if_striped the optimistic one: every shard over its own direct link).  ``direct``: the all-pairs schedule
+    of LogitsGatherer(mode='direct'), one shard per link and direction.  ``gather``: everything onto one rank, one shard per link."""
+    n, s = int(world), int(payload_bytes)
+    if n <= 1 or policy in (None, 'none'):
+        return dict(per_link_bytes=0, per_link_bytes_if_striped=0, bytes_in_per_gpu=0, links_per_gpu=0)
+    if policy in ('allgather', 'ingraph'):
+        return dict(per_link_bytes=(n - 1) * s, per_link_bytes_if_striped=s, bytes_in_per_gpu=(n - 1) * s, links_per_gpu=2 if n > 2 else 1)
+    if policy == 'direct':
+        return dict(per_link_bytes=s, per_link_bytes_if_striped=s, bytes_in_per_gpu=(n - 1) * s, links_per_gpu=n - 1)
+    if policy == 'gather':
+        return dict(per_link_bytes=s, per_link_bytes_if_striped=s, bytes_in_per_gpu=(n - 1) * s, links_per_gpu=n - 1)
+    raise ValueError(policy)
+
+
+def link_gbs_needed(policy, world, payload_bytes, steps_per_s):
+    """GB/s the busiest link has to sustain in one direction for ``policy`` to keep up with ``steps_per_s``."""
+    return link_schedule(policy, world, payload_bytes)['per_link_bytes'] * float(steps_per_s) / 1e9
+
+
+def fitting_policy(world, payload_bytes, steps_per_s, link_gbs=XGMI_LINK_GBS_PER_DIRECTION, headroom=LINK_HEADROOM):
+    """The first policy of (allgather, direct) whose busiest link stays under ``headroom * link_gbs`` at ``steps_per_s``, and
+    whether it actually fits: ('allgather' | 'direct', fits).  HyperSeg-M at 8 ranks (39.8 MB of logits, ~1290 steps/s per GPU):
+    the ring needs 7 x 39.8 MB x 1290 = 359 GB/s per link -- no; all-pairs 51 GB/s -- yes.  When not even the all-pairs schedule
+    fits the caller can move uint8 masks instead (76x fewer bytes; bench.py --gather masks / auto)."""
+    budget = headroom * link_gbs
+    for policy in ('allgather', 'direct'):
+        if link_gbs_needed(policy, world, payload_bytes, steps_per_s) <= budget:
+            return policy, True
+    return 'direct', False
 
 
 def shard_frames(n_frames, rank, world):

@@ -178,7 +178,9 @@ def test_bench_workload_plan_and_device_selection():
     assert bench.select_device(5, stub=True) == torch.device('cpu')
 
 
-@pytest.mark.parametrize('model,extra', [('m', []), ('l', []), ('m', ['--collective', 'auto']), ('m', ['--collective', 'direct']), ('m', ['--gather', 'masks'])])
+@pytest.mark.parametrize('model,extra', [('m', []), ('l', []), ('m', ['--collective', 'auto']), ('m', ['--collective', 'direct']), ('m', ['--gather', 'masks']),
+                                         ('m', ['--link-gbs', '1e-9']), ('m', ['--link-gbs', '1e-9', '--gather', 'auto']),
+                                         ('m', ['--collective', 'auto', '--gather', 'auto'])])
 def test_bench_main_under_torch_distributed_run(model, extra):
     """bench.py's main() ITSELF, launched exactly as the driver launches it (python -m torch.distributed.run --nproc-per-node 2
     ... bench.py --gpus 2 --steps K --warmup W), with the model stubbed out (HS_BENCH_STUB=1: gloo, CPU): rank / world from
@@ -208,17 +210,56 @@ def test_bench_main_under_torch_distributed_run(model, extra):
     assert abs(d['value'] - per_step / (d['ms_per_step'] * 1e-3)) < 0.01 * d['value']
     assert abs(sum(d['per_rank_frames_per_s']) - d['value']) < 0.01 * d['value']
     c = d['collective']
-    want_policy = 'direct' if 'direct' in extra else 'allgather'      # auto on CPU: the in-graph form needs HIP graphs
-    assert c['policy'] == want_policy and c['payload'] == ('masks' if 'masks' in extra else 'logits')
+    starved = '--link-gbs' in extra                            # a link budget nothing fits: the all-pairs schedule, and masks under --gather auto
+    auto = ['--collective', 'auto'] == extra[:2]
+    want_policy = 'direct' if 'direct' in extra or starved else 'allgather'      # auto on CPU: the in-graph form needs HIP graphs
+    want_payload = 'masks' if 'masks' in extra or (starved and 'auto' in extra[2:]) else 'logits'
+    if auto:                                                   # whichever calibrated fastest among the eligible candidates
+        assert c['policy'] in ('allgather', 'direct') and c['requested'] == 'auto'
+        cal = c['calibration_ms_per_step']
+        assert cal['allgather'] > 0 and cal['direct'] > 0 and cal['allgather:masks'] > 0 and 'ingraph' not in cal
+        if 'auto' not in extra[2:]:
+            assert c['payload'] == 'logits'                    # the masks candidate is timed, not eligible, unless --gather auto
+        want_policy, want_payload = c['policy'], c['payload']
+    assert c['policy'] == want_policy and c['payload'] == want_payload
     assert c['completed'] >= 6 * 2 + 3
-    if not extra:
-        assert c['requested'] == 'allgather' and c['calibration_ms_per_step'] is None
-    if 'auto' in extra:
-        assert c['requested'] == 'auto' and c['calibration_ms_per_step']['allgather'] > 0
+    if not extra or starved:
+        assert c['requested'] == 'fit' and c['calibration_ms_per_step'] is None
+        assert c['fit']['steps_per_s_without_collective'] > 0 and c['fit']['fits'] is (not starved)
     classes, (h, w) = (21, (512, 512)) if model == 'l' else (19, (512, 1024))
     frames = 16 if model == 'l' else 1
-    elems = frames * (h // 16) * (w // 16) * (1 if 'masks' in extra else classes * 4)
+    elems = frames * (h // 16) * (w // 16) * (1 if want_payload == 'masks' else classes * 4)
     assert c['bytes_sent_per_rank_per_step'] == elems
+    # the per-link accounting on the line IS the schedule of hyperseg_amd.distributed.link_schedule for the policy that ran
+    from hyperseg_amd.distributed import link_gbs_needed, link_schedule
+    sched = link_schedule(want_policy, 2, elems)
+    assert {k: c[k] for k in sched} == sched
+    assert c['per_link_bytes'] == elems                        # world 2: ring and all-pairs both move one shard over the one link
+    rate = 1e3 / d['ms_per_step']
+    assert abs(c['link_gbs_needed_at_this_rate'] - link_gbs_needed(want_policy, 2, elems, rate)) <= 0.02 + 0.02 * c['link_gbs_needed_at_this_rate']
+
+
+def test_link_schedule_and_fitting_policy():
+    """The per-link arithmetic behind bench.py's N > 1 default: at 8 x HyperSeg-M the RCCL ring all-gather of fp32 logits
+    asks ~360 GB/s of one xGMI link and direction (76.5 available), the all-pairs schedule 51 -- the default must be the latter -- while
+    HyperSeg-L's strong-scaled batch and any masks payload fit the ring."""
+    from hyperseg_amd.distributed import LINK_HEADROOM, XGMI_LINK_GBS_PER_DIRECTION, fitting_policy, link_gbs_needed, link_schedule
+    m_logits = 19 * 512 * 1024 * 4
+    assert link_schedule('allgather', 8, m_logits) == dict(per_link_bytes=7 * m_logits, per_link_bytes_if_striped=m_logits,
+                                                           bytes_in_per_gpu=7 * m_logits, links_per_gpu=2)
+    assert link_schedule('direct', 8, m_logits) == dict(per_link_bytes=m_logits, per_link_bytes_if_striped=m_logits,
+                                                        bytes_in_per_gpu=7 * m_logits, links_per_gpu=7)
+    assert link_schedule('gather', 4, 10)['per_link_bytes'] == 10 and link_schedule('none', 8, 10)['per_link_bytes'] == 0
+    assert link_schedule('allgather', 1, 10)['per_link_bytes'] == 0
+    assert abs(link_gbs_needed('allgather', 8, m_logits, 1290.0) - 359.8) < 0.5 and abs(link_gbs_needed('direct', 8, m_logits, 1290.0) - 51.4) < 0.1
+    assert fitting_policy(8, m_logits, 1290.0) == ('direct', True)
+    assert fitting_policy(2, m_logits, 1290.0) == ('allgather', True)          # one shard over the one link either way: 51 GB/s
+    assert fitting_policy(8, m_logits // 76, 1290.0) == ('allgather', True)    # uint8 masks
+    assert fitting_policy(8, m_logits, 1290.0, link_gbs=10.0) == ('direct', False)
+    s_logits = 19 * 768 * 1536 * 4                                            # HyperSeg-S at ~810 steps/s: all-pairs needs 72.6 > 0.8 x 76.5
+    assert fitting_policy(8, s_logits, 810.0) == ('direct', False) and LINK_HEADROOM * XGMI_LINK_GBS_PER_DIRECTION < 72.6
+    with pytest.raises(ValueError):
+        link_schedule('ring', 8, 1)
 
 
 def _zero_copy_lifetime_worker(rank, world, port, q):
