@@ -262,6 +262,27 @@ def publish_ready(device):
         torch.cuda.current_stream(device).synchronize()
 
 
+def producer_stream(device):
+    """Identity of the stream a cache entry is being filled on (kept with the entry; see :func:`adopt`)."""
+    return torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0
+
+
+def adopt(value, device, filled_on):
+    """A cache hit from ANOTHER stream than the one the entry was filled on: tell the caching allocator that the entry's tensors are
+    in use on the caller's stream (``Tensor.record_stream``).  Without it the memory goes back to the FILLING stream's pool the moment
+    the entry is replaced (a new parameter version) and the last Python reference dies -- while kernels the other stream launched on
+    it may still be in flight -- and the filling stream's next allocation overwrites what they read.  (Found by
+    tests/test_hip_parity.py::test_two_python_threads_two_streams_through_the_decoder: 23 of 40 outputs of one thread differed.)
+    Returns ``value``."""
+    if device.type == 'cuda':
+        cur = torch.cuda.current_stream(device)
+        if cur.cuda_stream != filled_on:
+            for t in (value if isinstance(value, (tuple, list)) else (value,)):
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(cur)
+    return value
+
+
 @_on_operand_device
 def s2w_packed(wsw_t, signal_channels, groups):
     """The transposed signal2weights weight re-laid for ``hs_signal2weights_multi_fwd``'s blocked form (hs_s2w_pack_fwd), built
@@ -271,8 +292,10 @@ def s2w_packed(wsw_t, signal_channels, groups):
     with _CACHE_LOCK:
         ent = _S2W_BLK.get(key)
         hit = ent[1] if ent is not None and ent[0]() is wsw_t else None       # the address alone could be a dead tensor's, reused
+        if hit is not None:
+            adopt(hit, wsw_t.device, ent[2])
         if hit is None:
-            for k in [k for k, (r, _) in list(_S2W_BLK.items()) if r() is None or k[0] != _WEIGHTS_EPOCH[0]]:      # dead sources and earlier weight epochs take their images with them
+            for k in [k for k, (r, _, _) in list(_S2W_BLK.items()) if r() is None or k[0] != _WEIGHTS_EPOCH[0]]:      # dead sources and earlier weight epochs take their images with them
                 del _S2W_BLK[k]
             n = _hip.lib.hs_s2w_pack_floats(signal_channels, groups, wsw_t.shape[1])
             if n < 0:
@@ -281,7 +304,7 @@ def s2w_packed(wsw_t, signal_channels, groups):
             _hip.check(_hip.lib.hs_s2w_pack_fwd(_hip.dev_ptr(wsw_t, 'wsw_t'), signal_channels, groups, wsw_t.shape[1], hit.data_ptr(),
                                                 _hip.stream_ptr()), 'hs_s2w_pack_fwd')
             publish_ready(wsw_t.device)
-            _S2W_BLK[key] = (weakref.ref(wsw_t), hit)
+            _S2W_BLK[key] = (weakref.ref(wsw_t), hit, producer_stream(wsw_t.device))
     return hit
 
 
@@ -929,13 +952,15 @@ class FoldedBN:
                                       'the training route (hyperseg_amd.autograd) keeps BatchNorm as a module')
         ts = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
         k = _key(*ts)
-        ent = self._ent.get(bn.weight.device)
+        dev = bn.weight.device
+        ent = self._ent.get(dev)
         if ent is None or ent[0] != k:
             with torch.no_grad():
-                ent = (k, bn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps))
-            publish_ready(bn.weight.device)
-            self._ent[bn.weight.device] = ent
-        return ent[1]
+                ent = (k, bn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps), producer_stream(dev))
+            publish_ready(dev)
+            self._ent[dev] = ent
+            return ent[1]
+        return adopt(ent[1], dev, ent[2])
 
 
 class TransposedS2W:
@@ -950,7 +975,8 @@ class TransposedS2W:
         ent = self._ent.get(w.device)
         if ent is None or ent[0] != k:
             with torch.no_grad():
-                ent = (k, w.detach().reshape(w.shape[0], w.shape[1]).t().contiguous())
+                ent = (k, w.detach().reshape(w.shape[0], w.shape[1]).t().contiguous(), producer_stream(w.device))
             publish_ready(w.device)
             self._ent[w.device] = ent
-        return ent[1]
+            return ent[1]
+        return adopt(ent[1], w.device, ent[2])

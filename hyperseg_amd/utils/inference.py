@@ -122,9 +122,11 @@ class FusedPointwise(nn.Module):
         key, ver = (bool(with_scale), device), HF._key(*srcs)       # in-place updates of the weight / BN scale are seen
         hit = self._split.get(key)
         if hit is None or hit[0] != ver:
-            hit = (ver, HF.gemm_split_weights(self.conv.weight, self.scale if with_scale else None))
+            hit = (ver, HF.gemm_split_weights(self.conv.weight, self.scale if with_scale else None), HF.producer_stream(self.conv.weight.device))
             HF.publish_ready(self.conv.weight.device)            # another stream / replica thread may pick the entry up
             self._split[key] = hit
+        elif hit[1] is not None:
+            HF.adopt((hit[1].frag, hit[1].inv), self.conv.weight.device, hit[2])
         return hit[1]
 
     @torch.no_grad()
@@ -365,9 +367,11 @@ class FusedContextHead(nn.Module):
         key = HF._key(weight, scale)
         hit = self._split.get(name)
         if hit is None or hit[0] != key:
-            hit = (key, HF.gemm_split_weights(weight, scale, max_k=max_k))
+            hit = (key, HF.gemm_split_weights(weight, scale, max_k=max_k), HF.producer_stream(weight.device))
             HF.publish_ready(weight.device)
             self._split[name] = hit
+        elif hit[1] is not None:
+            HF.adopt((hit[1].frag, hit[1].inv), weight.device, hit[2])
         return hit[1]
 
     def forward(self, x):

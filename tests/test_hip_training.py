@@ -555,10 +555,15 @@ def test_graphed_train_step_equals_eager(dev):
 
 
 # Bars of test_graphed_train_step_equals_eager, from the 200-seed sweep (profiles/round5_graphed_step_seed_sweep.txt; header there)
-GRAPH_VS_TWIN_LOSS = 1e-6        # replays vs eager steps of the same capturable optimizer
-GRAPH_VS_TWIN_PARAM_LR = 1e-2    # ... parameters, in units of lr
-GRAPH_VS_TWIN_STAT = 1e-5        # ... BatchNorm running statistics (relative to the tensor's scale)
-GRAPH_VS_PLAIN_LOSS = 1e-3       # replays vs eager steps of plain Adam (different bias-correction arithmetic)
+# G-C (replays vs eager steps of the same capturable optimizer): 0 in every column for all 200 seeds -- the capture changes NOTHING, so
+# the bar is bit equality.  C-P (capturable vs plain Adam), worst of 200 seeds after 5 steps: loss gap 5.4e-5 relative (p99 3.3e-5),
+# largest parameter gap 2.73 lr (p99 2.68), largest per-tensor mean gap 0.11 lr, running statistics 6.8e-3 -- the bars below keep a
+# factor >= 3 over those maxima.  (Round 4 asserted a loss gap < 1e-4: the sweep's maximum is within 2x of it, which is what a
+# 1-in-25 failure under an un-seeded target looks like.)
+GRAPH_VS_TWIN_LOSS = 0.0         # replays vs eager steps of the same capturable optimizer: bit-equal
+GRAPH_VS_TWIN_PARAM_LR = 0.0     # ... parameters, in units of lr
+GRAPH_VS_TWIN_STAT = 0.0         # ... BatchNorm running statistics
+GRAPH_VS_PLAIN_LOSS = 3e-4       # replays vs eager steps of plain Adam (different bias-correction arithmetic)
 
 
 def test_validation_after_graph_replays_sees_the_trained_weights(dev):
