@@ -663,6 +663,10 @@ def main(argv=None):
                          '(what serving runs): the level-4 block multiplies 3-term f16 splits of its f32 operands on the f16 matrix cores '
                          'with f32 accumulation -- `dtype` says so in words; the `exact_f32` object re-times the step with every decoder '
                          'product on the exact-f32 matrix cores (--ir-math f32 makes that the headline)')
+    ap.add_argument('--chain-k1', dest='chain_k1', action='store_true',
+                    help="the decoder's three coarse k = 1 levels as ONE launch with in-launch neighbour hand-offs (hs_k1_chain_fwd)")
+    ap.add_argument('--no-chain-k1', dest='chain_k1', action='store_false', help='one launch per k = 1 level')
+    ap.set_defaults(chain_k1=False)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the roofline / parity / protocol passes (timing only)')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
@@ -733,7 +737,8 @@ def main(argv=None):
         if rank == 0 and not args.no_extras:
             stock, stock_cpu = copy.deepcopy(model), (copy.deepcopy(model) if world == 1 and not args.stock_encoder else None)
         if not args.stock_encoder:
-            prepare_for_inference(model, fold_bn=False, fused_depthwise=True, split_gemm=args.split_gemm, ir_math=args.ir_math)
+            prepare_for_inference(model, fold_bn=False, fused_depthwise=True, split_gemm=args.split_gemm, ir_math=args.ir_math,
+                                  chain_k1=args.chain_k1)
         else:
             from hyperseg_amd.utils.inference import set_ir_math
             set_ir_math(model, args.ir_math)

@@ -459,6 +459,72 @@ def patch_conv(x, grid, bank, c_out, k=1, padding=0, padding_mode='reflect', gro
     return y
 
 
+class K1Chain:
+    """hs_k1_chain_fwd for one decoder: the three coarse k = 1 levels as ONE launch whose workgroups hand their level outputs to
+    the neighbouring cells inside the launch (csrc/hs_k1_chain.hip).  Owns the launch's workspace -- the generation counter the
+    kernel keeps between calls lives there -- one per (device, batch, grid): ONE frame in flight per K1Chain (two concurrent
+    launches on one workspace would corrupt each other's hand-offs; two_frames_in_flight-style callers keep the chain off).
+    ``run`` returns the level-2 output, or None when the library refuses the shape / the grid is not resident at once (the caller
+    then issues the three hs_patch_conv_fwd launches)."""
+
+    def __init__(self):
+        self._ws = {}
+        self._refused = set()
+
+    def run(self, skips, banks, couts, affines, acts):
+        """``skips``: the three skip features (B, c, fh << l, fw << l); ``banks``: (P, ld) fp32 tensors; ``affines``: (scale, shift) or
+        None per level; ``acts``: activation codes."""
+        dev = skips[0].device
+        b, _, fh, fw = skips[0].shape
+        key = (dev, b, fh, fw, tuple(couts), tuple(s.shape[1] for s in skips))
+        if key in self._refused:
+            return None
+        arr = (_hip.K1LevelC * 3)()
+        keep = []
+        for l in range(3):
+            sk = skips[l]
+            if tuple(sk.shape[2:]) != (fh << l, fw << l) or sk.shape[0] != b:
+                return None
+            a = arr[l]
+            a.skip, a.c_skip = _hip.dev_ptr(sk, f'skip feature of level {l}'), sk.shape[1]
+            a.bank, a.ld = _bank_ptr(banks[l])
+            a.c_out = couts[l]
+            if affines[l] is not None:
+                a.scale, a.shift = _hip.dev_ptr(affines[l][0], 'scale'), _hip.dev_ptr(affines[l][1], 'shift')
+            else:
+                a.scale, a.shift = None, None
+            a.act = acts[l]
+            keep.append(sk)
+        with _hip.device_scope(dev):
+            ws = self._ws.get(key)
+            if ws is None:
+                n = int(_hip.lib.hs_k1_chain_workspace(b, fh, fw, arr, 3))
+                if n < 0:
+                    self._refused.add(key)
+                    return None
+                # zero-filled ONCE: generation 0; under stream capture the fill would become a node of the graph and every replay
+                # would restart at generation 1 -- legal (the kernel then re-publishes everything with tag 1 over zeroed granules)
+                ws = torch.zeros(n, device=dev, dtype=torch.uint8)
+                publish_ready(dev)
+                self._ws[key] = ws
+            y = torch.empty(b, couts[2], 4 * fh, 4 * fw, device=dev, dtype=torch.float32)
+            st = _hip.lib.hs_k1_chain_fwd(b, fh, fw, arr, 3, ws.data_ptr(), y.data_ptr(), _hip.stream_ptr())
+        if st == -3:                              # HS_ERR_UNSUPPORTED: shape or residency -- nothing was launched
+            self._refused.add(key)
+            return None
+        _hip.check(st, 'hs_k1_chain_fwd')
+        return y
+
+    def error_word(self):
+        """Non-zero if a launch on any of this object's workspaces abandoned a wait (host read: diagnostics / tests only)."""
+        return max([int(ws[:4].view(torch.int32).item()) for ws in self._ws.values()] or [0])
+
+
+# The three coarse k = 1 levels as one launch: opt-in per decoder (``decoder.chain_k1 = True``; prepare_for_inference(chain_k1=True)
+# sets it), or process-wide with HS_K1_CHAIN=1 (dev A/B switch).
+K1_CHAIN = os.environ.get('HS_K1_CHAIN', '0') == '1'
+
+
 @_on_operand_device
 def meta_conv(x, w, c_out, kernel_size, stride=(1, 1), padding=(0, 0), dilation=(1, 1), padding_mode='zeros', groups=1,
               scale=None, shift=None, act=ACT_NONE):

@@ -528,6 +528,44 @@ class MultiScaleDecoder(EpochOnModeSwitch, nn.Module):
             carry.setdefault(best, []).insert(0, gi)
         return carry
 
+    def _run_k1_chain(self, x, banks):
+        """Levels 0-2 through functional.K1Chain when each is [HyperPatchNoPadding(k = 1, groups = 1), eval BatchNorm?, ReLU | ReLU6?]
+        on patches of 1, 2 and 4 pixels with a materialised bank -- the layout every v1_0 reference configuration builds
+        (hyperseg_v1_0.py:728-760); None otherwise (the caller runs the levels one launch each)."""
+        from .layers.meta_sequential import _act_code
+        if self.levels < 3:
+            return None
+        skips, bnk, couts, affines, acts = [], [], [], [], []
+        for l in range(3):
+            seq = getattr(self, f'level_{l}')
+            mods = list(seq)
+            ref = banks[l][0] if len(banks[l]) == 1 else None
+            if not mods or not isinstance(mods[0], HyperPatchNoPadding) or not isinstance(ref, HF.BankRef):
+                return None
+            conv = mods[0]
+            if conv.kernel_size != (1, 1) or conv.stride != (1, 1) or conv.dilation != (1, 1) or conv.groups != 1 or ref.rows != conv.hyper_params:
+                return None
+            k, aff, act = 1, None, HF.ACT_NONE
+            if k < len(mods) and isinstance(mods[k], nn.BatchNorm2d):
+                bn = mods[k]
+                if bn.training or (torch.is_grad_enabled() and bn.weight is not None and bn.weight.requires_grad):
+                    return None
+                aff = seq._fold(k, bn)
+                k += 1
+            if k < len(mods) and _act_code(mods[k]) is not None:
+                act = _act_code(mods[k])
+                k += 1
+            if k != len(mods):
+                return None                                  # a Dropout or any other tail: the generic route
+            sk = x[-l - 1]
+            prev_c = couts[-1] if couts else 0
+            if not (sk.is_cuda and sk.dtype == torch.float32 and sk.is_contiguous()) or 2 + sk.shape[1] + prev_c != conv.in_channels:
+                return None
+            skips.append(sk); bnk.append(ref.bank); couts.append(conv.out_channels); affines.append(aff); acts.append(act)
+        if getattr(self, '_k1_chain', None) is None:
+            self._k1_chain = HF.K1Chain()
+        return self._k1_chain.run(skips, bnk, couts, affines, acts)
+
     def _train_banks(self, s):
         """Every level's bank for the training path in ONE launch (autograd.S2WBanksTrain: hs_s2w_train_fwd, three launches back) --
         or None when a level cannot take it (several signal-fed modules in a level, a signal2weights with a bias, K > 80, CPU)."""
@@ -697,8 +735,12 @@ class MultiScaleDecoder(EpochOnModeSwitch, nn.Module):
         for g in groups:
             banks.append(refs[k:k + len(g)])
             k += len(g)
-        p = None
-        for level in range(self.levels):
+        p, first = None, 0
+        if (getattr(self, 'chain_k1', False) or HF.K1_CHAIN) and side is None and not bank_events and s.is_cuda:
+            # the three coarse k = 1 levels as ONE launch (hs_k1_chain_fwd); None: the shape / residency is not covered
+            p = self._run_k1_chain(x, banks)
+            first = 3 if p is not None else 0
+        for level in range(first, self.levels):
             level_layers = getattr(self, f'level_{level}')
             if side is not None and level == join_level:
                 torch.cuda.current_stream(s.device).wait_stream(side)

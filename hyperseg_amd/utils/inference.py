@@ -514,15 +514,21 @@ def set_ir_math(model, mode):
     return n
 
 
-def prepare_for_inference(model, fold_bn=True, channels_last=False, fused_depthwise=False, split_gemm=False, ir_math='auto'):
+def prepare_for_inference(model, fold_bn=True, channels_last=False, fused_depthwise=False, split_gemm=False, ir_math='auto',
+                          chain_k1=False):
     """In place; returns the number of BatchNorms folded by ``fold_bn``.  ``model``: a HyperGen in eval mode (module
     docstring for what each switch does).  The fused routes are installed first, so ``fold_bn`` only touches the
     Conv -> BatchNorm pairs that no fused route reads.  ``ir_math``: :func:`set_ir_math` for the decoder ('auto' = the
-    f16-split inverted residual wherever it exists -- what serving and bench.py run; None leaves the modules' 'f32')."""
+    f16-split inverted residual wherever it exists -- what serving and bench.py run; None leaves the modules' 'f32').
+    ``chain_k1``: the decoder's three coarse k = 1 levels as ONE launch with in-launch neighbour hand-offs (hs_k1_chain_fwd;
+    v1_0 decoders whose whole grid is resident at once -- the others keep one launch per level).  One frame in flight per model:
+    the launch keeps its generation counter in a per-decoder workspace."""
     assert not model.training, 'call model.eval() first'
     folded = 0
     if ir_math is not None:
         set_ir_math(model, ir_math)
+    if hasattr(model, 'decoder'):
+        model.decoder.chain_k1 = bool(chain_k1)
     if fused_depthwise and any(getattr(b, '_fused_dw', None) is not None for b in model.backbone._blocks):
         raise RuntimeError('prepare_for_inference(fused_depthwise=True) was already applied to this model: the deferred '
                            'BatchNorm shifts would be absorbed twice')

@@ -141,6 +141,34 @@ int hs_patch_conv_s2w_fwd(const hs_stage_input* in, int32_t fh, int32_t fw, cons
                           const float* signal, int32_t batch, int32_t c_signal, int32_t sfh, int32_t sfw,
                           const hs_s2w_layer* layers, int32_t n_layers, void* stream);
 
+/* The decoder's three coarse k = 1 levels (patches of 1 x 1, 2 x 2 and 4 x 4 pixels: MultiScaleDecoder.forward's first three
+ * iterations, hyperseg_v1_0.py:221-253, each `cat(coords, skip, bilinear2x(prev))` -> HyperPatchNoPadding (:486-498) -> BatchNorm ->
+ * ReLU, :728-760) as ONE launch: one workgroup per grid cell walks level 0 -> 1 -> 2, every bank / skip pixel / BatchNorm row of
+ * all three levels requested at the top of the kernel, and a level's outputs handed to the NEIGHBOURING cells' workgroups inside
+ * the launch (the 2x bilinear upsample reads a one-pixel ring around a cell) as 8-byte {value, generation} granules -- one
+ * agent-scope store each, polled by the consumer until the generation matches.  Same values as three hs_patch_conv_fwd calls
+ * (same operations per output; the dot products' summation order differs at rounding level).
+ *   levels[l]: skip (batch, c_skip, fh << l, fw << l); bank of the level, patch-major, rows o * c_in + c with
+ *              c_in = 2 + c_skip + c_out of the previous level (0 for l = 0), row stride ld (multiple of 4, 16-byte aligned);
+ *              scale / shift / act: the epilogue (scale null: none).   y (batch, levels[2].c_out, 4 fh, 4 fw).
+ *   workspace: hs_k1_chain_workspace() bytes, 16-byte aligned, ZERO-FILLED ONCE by the caller and then left alone: it carries the
+ *              generation counter between calls (kernel arguments are frozen under graph replay, so the state lives in memory the
+ *              kernel owns).  One workspace per (batch, fh, fw) and per stream: two launches must not share it concurrently.
+ *              Its first 32-bit word is an error flag: non-zero after a launch whose workgroups gave up waiting for a neighbour
+ *              (bounded spins: ~0.2 s) -- the results of that launch are invalid.
+ * HS_ERR_UNSUPPORTED -- nothing launched -- unless n_levels == 3, every bank fits its LDS-DMA budget (24 / 12 / 4 KB),
+ * c_out <= 64, c_skip * pixels <= 256 per level, AND the whole grid (batch * fh * fw workgroups) is resident at once on the
+ * current device (workgroups wait for their neighbours): the caller then issues the three hs_patch_conv_fwd calls. */
+typedef struct hs_k1_level {
+    const float* skip; int32_t c_skip;
+    const float* bank; int64_t ld;
+    int32_t c_out;
+    const float* scale; const float* shift; int32_t act;
+} hs_k1_level;
+int64_t hs_k1_chain_workspace(int32_t batch, int32_t fh, int32_t fw, const hs_k1_level* levels, int32_t n_levels);   /* bytes, or a negative hs_status */
+int hs_k1_chain_fwd(int32_t batch, int32_t fh, int32_t fw, const hs_k1_level* levels, int32_t n_levels, void* workspace,
+                    float* y, void* stream);
+
 /* MetaConv2d.forward with the reference's FULL argument set (meta_conv.py:141-186): per-sample weights w (B, rows >=
  * c_out * c_in/groups * kh * kw, row stride ldw; natural order ((o*cin_g + c)*kh + ky)*kw + kx), non-square kernels, stride,
  * dilation, any padding amounts per side and mode (F.pad semantics for reflect / replicate / circular, zero padding

@@ -827,3 +827,45 @@ def test_two_python_threads_two_streams_through_the_decoder(O, HF, dev):
         bad = [k for k, y in enumerate(outs[i]) if not torch.equal(y, ref[i])]
         assert not bad, f'thread {i} ({modes[i]}): iterations {bad} differ from the serial result'
     assert getattr(HF._ir_math_local, 'mode', None) is None          # the scopes were the threads' own: nothing leaked into this one
+
+
+@pytest.mark.parametrize('name,size', [('M', None), ('M', (128, 256)), ('M', (32, 64)), ('Sc', None)])
+def test_k1_chain_equals_the_three_launches(O, HF, dev, name, size):
+    """hs_k1_chain_fwd (levels 0-2 as ONE launch with in-launch neighbour hand-offs, csrc/hs_k1_chain.hip) against the three
+    hs_patch_conv_fwd launches it replaces, through the whole decoder: full HyperSeg-M (512 cells: the whole grid resident) and CamVid-S
+    grids, a 4 x 8 grid and a 1 x 2 grid (every cell on the border: all hand-offs clamped).  Same operations per output, another summation
+    order: rounding-level agreement.  Six calls in a row (the generation counter in the workspace advances per call), then the same
+    decoder captured in a HIP graph and replayed (kernel arguments frozen: the generation must come from memory), and the error word
+    (a workgroup that gave up waiting for a neighbour) must stay 0."""
+    d = build_decoder(name, O).to(dev).eval()
+    kw = {} if size is None else dict(size=size)
+    frames = [O.synth_decoder_inputs(name, batch=1, seed=k, **kw) for k in (0, 1)]
+    frames = [([t.to(dev) for t in x], s.to(dev)) for x, s in frames]
+    with torch.no_grad():
+        ref = [d(x, s).clone() for x, s in frames]
+        d.chain_k1 = True
+        for it in range(6):
+            x, s = frames[it & 1]
+            y = d(x, s)
+            assert d._k1_chain is not None and d._k1_chain._ws, 'the chain refused a shape it is built for'
+            assert rel_err(y.cpu(), ref[it & 1].cpu()) < REL_TOL, f'call {it}'
+        assert d._k1_chain.error_word() == 0
+        # graph replay: same launch parameters every time
+        x, s = frames[0]
+        xs, ss = [t.clone() for t in x], s.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            d(xs, ss)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            yg = d(xs, ss)
+        for it in range(5):
+            for dst, src in zip(xs + [ss], frames[it & 1][0] + [frames[it & 1][1]]):
+                dst.copy_(src)
+            g.replay()
+            torch.cuda.synchronize()
+            assert rel_err(yg.cpu(), ref[it & 1].cpu()) < REL_TOL, f'replay {it}'
+        assert d._k1_chain.error_word() == 0

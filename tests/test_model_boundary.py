@@ -446,3 +446,30 @@ def test_c_abi_exports_match_header():
     assert lib.hs_version() == 1
     lib.hs_build_info.restype = ctypes.c_char_p
     assert b'gfx950' in lib.hs_build_info()
+
+
+def test_k1_chain_plan_on_the_host():
+    """hs_k1_chain_workspace is host logic only (no device call): the shapes of the v1_0 configurations are accepted, the workspace is the
+    header word block + one 8-byte granule per level-0 / level-1 output, and shapes past the kernel's LDS-DMA / thread budgets are refused
+    with HS_ERR_UNSUPPORTED (the caller then issues three hs_patch_conv_fwd launches)."""
+    import ctypes as C
+    from hyperseg_amd import _hip
+
+    def plan(batch, fh, fw, chans, n=3):
+        arr = (_hip.K1LevelC * 3)()
+        dummy = C.c_void_p(4096)                           # never dereferenced by the planner: alignment is all it looks at
+        prev = 0
+        for l, (cs, co) in enumerate(chans):
+            arr[l].skip, arr[l].c_skip, arr[l].bank, arr[l].c_out = dummy, cs, dummy, co
+            arr[l].ld = (co * (2 + cs + prev) + 3) & ~3
+            arr[l].scale = arr[l].shift = None
+            prev = co
+        return int(_hip.lib.hs_k1_chain_workspace(batch, fh, fw, arr, n))
+    m = [(80, 64), (28, 32), (10, 16)]                      # HyperSeg-M / CamVid-S levels 0-2: 82 -> 64, 94 -> 32, 44 -> 16
+    assert plan(1, 16, 32, m) == 256 + 8 * 512 * (64 + 4 * 32)
+    assert plan(1, 24, 48, [(128, 32), (28, 16), (8, 8)]) == 256 + 8 * 1152 * (32 + 4 * 16)        # HyperSeg-S
+    assert plan(1, 16, 32, m, n=2) == -3                     # three levels or nothing
+    assert plan(1, 16, 32, [(80, 96), (28, 32), (10, 16)]) == -3          # c_out > 64
+    assert plan(1, 16, 32, [(120, 64), (28, 32), (10, 16)]) == -3         # level-0 bank past 24 KB
+    assert plan(1, 16, 32, [(80, 64), (70, 32), (10, 16)]) == -3          # 70 skip channels x 4 pixels > 256 gather lanes
+    assert plan(0, 16, 32, m) == -1

@@ -113,6 +113,13 @@ PATCHES = {
     's2wt_nomfma': [('''                    acc[t] = MODE == 0 ? __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0)
                                        : __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[t], 0, 0, 0);''', '                    acc[t][0] += av * bv;')],
     's2wt_nostore': [('if (t < KT && k < K) dw[(size_t)n * K + k] = acc[t][r];', 'if (t < KT && k < K && acc[t][r] == 12345.0f) dw[(size_t)n * K + k] = acc[t][r];')],
+    # round 5 (VERDICT r4 #1a): the two level-4 workgroups that share a CU start in phase and meet at every barrier together; delay one of
+    # them by a fraction of a chunk so that one's waits fall under the other's vector work.  Which blocks share a CU is not specified:
+    # 'hi' assumes blocks b and b + 256 (the dispatcher fills every CU once before it doubles up), 'lo' assumes b and b + 1.
+    'irc_stag_hi40': [('    // @stamp 0\n', '    if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_sleep(40);\n')],
+    'irc_stag_hi100': [('    // @stamp 0\n', '    if ((blockIdx.x >> 8) & 1) { __builtin_amdgcn_s_sleep(100); }\n')],
+    'irc_stag_lo40': [('    // @stamp 0\n', '    if (blockIdx.x & 1) __builtin_amdgcn_s_sleep(40);\n')],
+    'irc_stag_xcd40': [('    // @stamp 0\n', '    if ((blockIdx.x >> 3) & 1) __builtin_amdgcn_s_sleep(40);\n')],
     'ntstore': [(STORE_LINE, '                for (int jt = 0; jt < J3; ++jt) __builtin_nontemporal_store(fmaf(acc3[m][jt][r], sc, sh), &yo[yoff[jt]]);')],
 }
 
@@ -146,6 +153,10 @@ VARIANTS = {
     'irc_wide_store': dict(flags=['-DHS_IRC_WIDE_STORE'], extra=[], patch=None),         # round 4: the level-4 epilogue re-laid through LDS into 16-byte stores (measured slower)
     'irc_nw8': dict(flags=['-DHS_IRC_NW=8'], extra=[], patch=None),                      # round 4: eight waves per 16 x 16 region (four per SIMD at two workgroups per CU)
     'irc_r3': dict(flags=[], extra=[], patch='irc_r3', file='hs_patch_irc.hip'),          # round 3's level-4 kernel
+    'irc_stag_hi40': dict(flags=[], extra=[], patch='irc_stag_hi40', file='hs_patch_irc.hip'),      # round 5: staggered co-resident level-4 workgroups
+    'irc_stag_hi100': dict(flags=[], extra=[], patch='irc_stag_hi100', file='hs_patch_irc.hip'),
+    'irc_stag_lo40': dict(flags=[], extra=[], patch='irc_stag_lo40', file='hs_patch_irc.hip'),
+    'irc_stag_xcd40': dict(flags=[], extra=[], patch='irc_stag_xcd40', file='hs_patch_irc.hip'),
     'gs_tail_switch': dict(flags=[], extra=[], patch='git:b89aa7e', file='hs_gemm_split.hip'),   # round 4: the split GEMM with apply_act(v, a.act) inside the unrolled tail
     'st_slice64': dict(flags=['-DHS_ST_SLICE=64'], extra=[], patch=None),                 # round 4: patches per dW slice of the s2w backward (product: 256)
     'st_slice128': dict(flags=['-DHS_ST_SLICE=128'], extra=[], patch=None),
