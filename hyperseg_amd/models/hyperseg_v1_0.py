@@ -539,6 +539,9 @@ class MultiScaleDecoder(EpochOnModeSwitch, nn.Module):
         for l in range(3):
             seq = getattr(self, f'level_{l}')
             mods = list(seq)
+            while len(mods) == 1 and isinstance(mods[0], MetaSequential):      # level_<l> = MetaSequential(block), block = MetaSequential(conv, norm, act)
+                seq = mods[0]
+                mods = list(seq)
             ref = banks[l][0] if len(banks[l]) == 1 else None
             if not mods or not isinstance(mods[0], HyperPatchNoPadding) or not isinstance(ref, HF.BankRef):
                 return None

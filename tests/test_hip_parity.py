@@ -778,7 +778,8 @@ def test_two_python_threads_two_streams_through_the_decoder(O, HF, dev):
     different frames through the same MultiScaleDecoder 40 times in different math modes (thread-local ir_math_scope) while a third
     thread keeps invalidating every cache (bump_weights_epoch: what a BatchNorm update or a graph replay does), so folded BatchNorm
     affines, transposed and packed signal2weights weights are rebuilt concurrently all the time.  Every output must equal the serial
-    result bit for bit; no exception ("dictionary changed size during iteration" in round 4's functional._S2W_BLK sweep)."""
+    result bit for bit; no exception ("dictionary changed size during iteration" in round 4's functional._S2W_BLK sweep).
+    Three phases, so that a failure says WHAT breaks: (A) one thread on a side stream, (B) two threads, (C) two threads + the invalidator."""
     import threading
     import time
     d = build_decoder('M', O).to(dev).eval()
@@ -790,42 +791,58 @@ def test_two_python_threads_two_streams_through_the_decoder(O, HF, dev):
         for (x, s), mode in zip(frames, modes):
             with HF.ir_math_scope(mode):
                 ref.append(d(x, s).clone())
+                again = d(x, s)
+            assert torch.equal(again, ref[-1]), f'the serial forward itself is not reproducible in mode {mode}'
     assert not torch.equal(ref[0], ref[1])
     torch.cuda.synchronize()
-    outs, errors = [[], []], []
-    start = threading.Barrier(3)
-    done = threading.Event()
 
-    def replica(i):
-        try:
-            x, s = frames[i]
-            stream = torch.cuda.Stream(dev)
+    def phase(which, invalidate, n_iter=40):
+        outs, errors = {i: [] for i in which}, []
+        start = threading.Barrier(len(which) + (1 if invalidate else 0))
+        done = threading.Event()
+
+        def replica(i):
+            try:
+                x, s = frames[i]
+                stream = torch.cuda.Stream(dev)
+                start.wait()
+                with torch.no_grad(), torch.cuda.stream(stream), HF.ir_math_scope(modes[i]):
+                    for _ in range(n_iter):
+                        outs[i].append(d(x, s))
+                stream.synchronize()
+            except BaseException as e:          # noqa: BLE001 -- re-raised on the main thread
+                errors.append(e)
+
+        def invalidator():
             start.wait()
-            with torch.no_grad(), torch.cuda.stream(stream), HF.ir_math_scope(modes[i]):
-                for _ in range(40):
-                    outs[i].append(d(x, s))
-            stream.synchronize()
-        except BaseException as e:          # noqa: BLE001 -- re-raised on the main thread
-            errors.append(e)
-
-    def invalidator():
-        start.wait()
-        while not done.is_set():
-            HF.bump_weights_epoch()
-            time.sleep(0.0003)
-    threads = [threading.Thread(target=replica, args=(i,)) for i in (0, 1)] + [threading.Thread(target=invalidator)]
-    for t in threads:
-        t.start()
-    for t in threads[:2]:
-        t.join(120)
-    done.set()
-    threads[2].join(10)
-    assert not errors, errors
-    torch.cuda.synchronize()
-    for i in (0, 1):
-        assert len(outs[i]) == 40
-        bad = [k for k, y in enumerate(outs[i]) if not torch.equal(y, ref[i])]
-        assert not bad, f'thread {i} ({modes[i]}): iterations {bad} differ from the serial result'
+            while not done.is_set():
+                HF.bump_weights_epoch()
+                time.sleep(0.0003)
+        threads = [threading.Thread(target=replica, args=(i,)) for i in which]
+        inv = threading.Thread(target=invalidator) if invalidate else None
+        for t in threads + ([inv] if inv else []):
+            t.start()
+        for t in threads:
+            t.join(120)
+        done.set()
+        if inv:
+            inv.join(10)
+        assert not errors, errors
+        torch.cuda.synchronize()
+        report = []
+        for i in which:
+            assert len(outs[i]) == n_iter
+            bad = [k for k, y in enumerate(outs[i]) if not torch.equal(y, ref[i])]
+            if bad:
+                worst = max(float((outs[i][k].double() - ref[i].double()).abs().max()) for k in bad)
+                nan = sum(int(torch.isnan(outs[i][k]).sum()) for k in bad)
+                report.append(f'thread {i} ({modes[i]}): {len(bad)} of {n_iter} outputs differ from the serial result (first {bad[:6]}), '
+                              f'max |diff| {worst:.3e} of scale {float(ref[i].abs().max()):.3e}, {nan} NaNs')
+        return report
+    for name, which, inv in (('A: one thread, side stream', (0,), False), ('A2: one thread, side stream, split', (1,), False),
+                             ('B: two threads', (0, 1), False), ('C: two threads + cache invalidator', (0, 1), True)):
+        rep = phase(which, inv)
+        assert not rep, f'phase {name}: ' + '; '.join(rep)
     assert getattr(HF._ir_math_local, 'mode', None) is None          # the scopes were the threads' own: nothing leaked into this one
 
 
