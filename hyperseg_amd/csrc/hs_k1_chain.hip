@@ -155,6 +155,7 @@ void k1_chain_kernel(KcArgs a) {
     gu64* const gx0 = (gu64*)a.x0;
     gu64* const gx1 = (gu64*)a.x1;
     gu32* const gerr = (gu32*)a.err;
+    // @stamp 0
 
     // ---------------------------------------------------------------- every HBM load of the workgroup, level 0's operands first
     // ALL of them by LDS-DMA (16-byte pieces for the banks, 4-byte gathers for skip pixels, BatchNorm rows and the generation word):
@@ -208,9 +209,11 @@ void k1_chain_kernel(KcArgs a) {
     dma_rows(a.L[1], 1);
     dma_rows(a.L[2], 2);
     __builtin_amdgcn_sched_barrier(0);
+    // @stamp 1
     // group 0 has landed when at most group 1's operations are outstanding (vector-memory operations complete in issue order)
     static_assert(KC_P1 + KC_P2 + 2 + 4 == 10, "the count in the s_waitcnt below");
     asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    // @stamp 2
     {   // level 0's input vector: the coordinates over what the gather put in slots 0 and 1 (wave 0 wrote them itself: ordered by its wait)
         if (tid == 0) xin0[0] = linspace_pm1(j, fw, a.L[0].step_x);
         if (tid == 1) xin0[1] = linspace_pm1(i, fh, a.L[0].step_y);
@@ -222,6 +225,7 @@ void k1_chain_kernel(KcArgs a) {
     const unsigned g_prev = *reinterpret_cast<const unsigned*>(lds + M.genw);
     unsigned gen = (unsigned)__builtin_amdgcn_readfirstlane((int)g_prev) + 1u;
     gen = gen ? gen : 1u;
+    // @stamp 3
 
     // ---------------------------------------------------------------- level 0: c0 outputs of one pixel
     {
@@ -234,14 +238,20 @@ void k1_chain_kernel(KcArgs a) {
             const int oo = live ? o : 0;
             float acc = kc_dot(wl0 + oo * cin0, xin0, cin0, 1, part, split);
             acc = apply_act(fmaf(acc, sc[oo], sh[oo]), a.L[0].act);
+            // group 1 (the later levels' operands) has had level 0's whole duration to land: the wait for it goes HERE, in front of the
+            // publishing stores -- behind them a vmcnt(0) would also wait for the stores' own write-through round trip (stores count in
+            // vmcnt on gfx9-class hardware), which nobody in this workgroup needs
+            if (base + per_pass >= c0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (live && part == 0) {
                 own0[o] = acc;
                 __hip_atomic_store(gx0 + (size_t)cell * c0 + o, ((u64)gen << 32) | (u64)__float_as_uint(acc), KC_RLX_AGENT);
             }
         }
     }
-    // the later levels' operands: everything this wave asked for has landed after vmcnt(0); the barrier makes it the workgroup's
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // @stamp 4
+    // every wave's share of group 1 has landed (waited for above); the barrier makes it the workgroup's, and level 0's bank region free
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // @stamp 5
     if (tid < 64) {   // levels without an epilogue: unit rows (read after the next barrier)
         if (!a.L[1].scale) { reinterpret_cast<float*>(lds + M.sc[1])[tid] = 1.0f; reinterpret_cast<float*>(lds + M.sh[1])[tid] = 0.0f; }
         if (!a.L[2].scale) { reinterpret_cast<float*>(lds + M.sc[2])[tid] = 1.0f; reinterpret_cast<float*>(lds + M.sh[2])[tid] = 0.0f; }
@@ -263,6 +273,7 @@ void k1_chain_kernel(KcArgs a) {
             v[q] = 0u;
         }
         kc_gather<NQ>(g, need, gen, v, gerr, 1u);
+        // @stamp 6
 #pragma unroll
         for (int q = 0; q < NQ; ++q) if (need[q]) nb0[dst[q]] = __uint_as_float(v[q]);
         if (tid < c0) nb0[4 * c0 + tid] = own0[tid];
@@ -287,6 +298,7 @@ void k1_chain_kernel(KcArgs a) {
     }
     __syncthreads();
 
+    // @stamp 7
     // ---------------------------------------------------------------- level 1: c1 outputs x 4 pixels
     {
         const int split = a.L[1].split, part = tid & (split - 1), per_pass = KC_THREADS / split;
@@ -307,6 +319,7 @@ void k1_chain_kernel(KcArgs a) {
     }
     __syncthreads();
 
+    // @stamp 8
     // ---------------------------------------------------------------- level 1 -> 2: the 4 x 4 level-1 pixels [2i - 1, 2i + 2] x [2j - 1, 2j + 2]
     {
         constexpr int NQ = 4;                                                    // 16 c1 <= 1024
@@ -325,6 +338,7 @@ void k1_chain_kernel(KcArgs a) {
             v[q] = 0u;
         }
         kc_gather<NQ>(g, need, gen, v, gerr, 2u);
+        // @stamp 9
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             if (live[q]) nb1[dst[q]] = need[q] ? __uint_as_float(v[q]) : own1[own[q]];
@@ -348,6 +362,7 @@ void k1_chain_kernel(KcArgs a) {
     }
     __syncthreads();
 
+    // @stamp 10
     // ---------------------------------------------------------------- level 2: c2 outputs x 16 pixels, plain stores (the next launch reads them)
     {
         const int split = a.L[2].split, part = tid & (split - 1), per_pass = KC_THREADS / split;
@@ -364,6 +379,7 @@ void k1_chain_kernel(KcArgs a) {
                 a.y[(((size_t)b * c2 + o) * H2 + (4 * i + (px >> 2))) * W2 + (4 * j + (px & 3))] = acc;
         }
     }
+    // @stamp 24
 }
 
 // resident workgroups of this kernel on the current device, (CUs, per CU); cached per device (write-once, idempotent)

@@ -335,6 +335,11 @@ def _s2w_layer_table(signal, layers, buf=None):
         raise ValueError('signal2weights_multi: buf is too small / not contiguous fp32')
     arr = (_hip.S2wLayerC * len(layers))()
     refs, off = [], 0
+    # The packed weight images are owned by the cache, and the cache drops an entry as soon as the weight epoch moves (another
+    # thread's BatchNorm update / mode switch, between two layers of this very loop): every image whose ADDRESS goes into the table
+    # is kept alive by the table's first BankRef until the banks themselves die -- i.e. past the launch.  (Round 5's thread test: an
+    # image freed between two s2w_packed calls was overwritten by the next layer's pack; wrong banks, 50 % of the logits' scale.)
+    keep = []
     for i, (l, ld) in enumerate(zip(layers, lds)):
         if l['signal_index'] + l['signal_channels'] > c_view:
             raise ValueError('signal slice out of range')
@@ -344,8 +349,15 @@ def _s2w_layer_table(signal, layers, buf=None):
         a.signal_index, a.signal_channels, a.groups = l['signal_index'], l['signal_channels'], l['groups']
         a.wsw_t, a.wc = _hip.dev_ptr(l['wsw_t'], 'wsw_t'), l['wsw_t'].shape[1]
         a.rows, a.bank, a.ld = l['rows'], bank.data_ptr(), ld
-        a.wsw_blk = s2w_packed(l['wsw_t'], l['signal_channels'], l['groups']).data_ptr() if S2W_BLOCKED else None
+        if S2W_BLOCKED:
+            keep.append(s2w_packed(l['wsw_t'], l['signal_channels'], l['groups']))
+            a.wsw_blk = keep[-1].data_ptr()
+        else:
+            a.wsw_blk = None
+        keep.append(l['wsw_t'])
         refs.append(BankRef(bank, b, l['rows'], (fh, fw)))
+    for r in refs:
+        r._operands = keep
     return arr, refs
 
 

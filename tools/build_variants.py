@@ -70,6 +70,18 @@ def stamped_irc_source():
     return path
 
 
+def stamped_kc_source():
+    """hs_k1_chain.hip carries '// @stamp <n>' comments at its phase boundaries: the dev build turns them into stamps (tools/kc_phase_times.py)."""
+    src = open(os.path.join(B.CSRC, 'hs_k1_chain.hip')).read()
+    src = src.replace('namespace hs {\n', 'namespace hs {\n' + STAMP_DECL, 1)
+    src, n = re.subn(r'// @stamp ([^\n]+)\n', r'HS_STAMP(\1);\n', src)
+    assert n >= 10, n
+    os.makedirs(os.path.join(B.LIB_DIR, 'dev_src'), exist_ok=True)
+    path = os.path.join(B.LIB_DIR, 'dev_src', 'hs_k1_chain_stamps.hip')
+    open(path, 'w').write(src)
+    return path
+
+
 def stamped_k1m_source():
     """hs_patch_conv_bwd.hip's k1m_pixel_stream carries '// @stamp <expr>' comments: the dev build turns them into stamps (wave 0 of a workgroup)."""
     src = open(os.path.join(B.CSRC, 'hs_patch_conv_bwd.hip')).read()
@@ -126,7 +138,8 @@ PATCHES = {
 VARIANTS = {
     'stamps': dict(flags=[], extra=[], patch=True),
     'stamps_irc': dict(flags=[], extra=[], patch='irc', file='hs_patch_irc.hip'),
-    'stamps_k1m': dict(flags=[], extra=[], patch='k1m', file='hs_patch_conv_bwd.hip'),      # round 4: phase stamps of k1m_pixel_stream (tools/k1m_phase_times.py)
+    'stamps_k1m': dict(flags=[], extra=[], patch='k1m', file='hs_patch_conv_bwd.hip'),
+    'stamps_kc': dict(flags=[], extra=[], patch='kc', file='hs_k1_chain.hip'),              # round 5: phase stamps of the k = 1 chain kernel (tools/kc_phase_times.py)      # round 4: phase stamps of k1m_pixel_stream (tools/k1m_phase_times.py)
     'nostore': dict(flags=[], extra=[], patch='nostore'),
     'ntstore': dict(flags=[], extra=[], patch='ntstore'),
     'px2wg': dict(flags=[], extra=[], patch='px2wg', file='hs_patch_ir_px.hip'),
@@ -194,7 +207,7 @@ if __name__ == '__main__':
         sources = list(B.SOURCES) + v['extra']
         if v.get('patch'):
             fname = v.get('file', 'hs_patch_ir_fused.hip')
-            src_path = stamped_k1m_source() if v['patch'] == 'k1m' else git_source(v['patch'][4:], fname, name) if str(v['patch']).startswith('git:') else r3_irc_source() if v['patch'] == 'irc_r3' else stamped_irc_source() if v['patch'] == 'irc' else stamped_source(fname) if v['patch'] is True else \
+            src_path = stamped_kc_source() if v['patch'] == 'kc' else stamped_k1m_source() if v['patch'] == 'k1m' else git_source(v['patch'][4:], fname, name) if str(v['patch']).startswith('git:') else r3_irc_source() if v['patch'] == 'irc_r3' else stamped_irc_source() if v['patch'] == 'irc' else stamped_source(fname) if v['patch'] is True else \
                 patched_source(v['patch'], PATCHES[v['patch']], fname)
             rel = os.path.relpath(src_path, B.CSRC)
             sources = [rel if s == fname else s for s in sources]

@@ -1,0 +1,25 @@
+#!/bin/bash
+# round 5, visit 3: hs_k1_chain_fwd parity (after the matcher fix), the thread test in phases, chain off / on per kernel and per frame
+tag=${1:-r5v3}; R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 300 python -m pytest tests/test_hip_parity.py -m gpu -q -p no:cacheprovider -k "k1_chain or two_python_threads" > gpurun_out/pytest_chain_$tag.log 2>&1
+echo "chain pytest rc=$?"; tail -4 gpurun_out/pytest_chain_$tag.log | cut -c1-300
+grep -E "^E  " gpurun_out/pytest_chain_$tag.log | head -20 | cut -c1-400
+out=$R/gpurun_out/variants_$tag.txt; : > $out
+export HS_IR_MATH=auto
+for v in product chain; do
+  lib=$R/hyperseg_amd/lib/libhyperseg_hip.so; chain=0
+  [ $v = chain ] && chain=1
+  rm -rf /tmp/pv; cd /tmp
+  HS_K1_CHAIN=$chain timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pv -- python $R/tools/decoder_loop.py M 60 > /tmp/pv.log 2>&1
+  cd $R; echo "== $v (M)" | tee -a $out; grep "decoder" /tmp/pv.log | tee -a $out
+  f=$(find /tmp/pv -name '*kernel_stats.csv' | head -1)
+  [ -n "$f" ] && python tools/kstats.py $f hs:: 12 | cut -c1-150 | tee -a $out
+done
+unset HS_IR_MATH
+for rep in 1 2; do
+  for c in --no-chain-k1 --chain-k1; do
+    timeout 200 python bench.py --no-extras --steps 300 --warmup 30 --repeats 3 $c > /tmp/b.json 2>/tmp/b.err
+    python -c "
+import json; d=json.load(open('/tmp/b.json')); print('bench $c', d['value'], d['ms_per_step'], d['repeats']['ms_per_step'])" 2>&1 | tee -a $out
+  done
+done
