@@ -472,27 +472,28 @@ def patch_conv(x, grid, bank, c_out, k=1, padding=0, padding_mode='reflect', gro
 
 
 class K1Chain:
-    """hs_k1_chain_fwd for one decoder: the three coarse k = 1 levels as ONE launch whose workgroups hand their level outputs to
-    the neighbouring cells inside the launch (csrc/hs_k1_chain.hip).  Owns the launch's workspace -- the generation counter the
-    kernel keeps between calls lives there -- one per (device, batch, grid): ONE frame in flight per K1Chain (two concurrent
-    launches on one workspace would corrupt each other's hand-offs; two_frames_in_flight-style callers keep the chain off).
-    ``run`` returns the level-2 output, or None when the library refuses the shape / the grid is not resident at once (the caller
-    then issues the three hs_patch_conv_fwd launches)."""
+    """hs_decoder_chain_fwd for one decoder: the three coarse k = 1 levels -- and the first inverted-residual level behind them when
+    ``ir`` is given -- as ONE launch whose workgroups hand their level outputs to the neighbouring cells inside the launch
+    (csrc/hs_k1_chain.hip).  Owns the launch's workspace -- the generation counter the kernel keeps between calls lives there -- one
+    per (device, batch, grid, shapes): ONE frame in flight per K1Chain (two concurrent launches on one workspace would corrupt each
+    other's hand-offs; two_frames_in_flight-style callers keep the chain off).  ``run`` returns the last level's output, or None when
+    the library refuses the shape / the grid is not resident at once (the caller then issues the per-level launches)."""
 
     def __init__(self):
         self._ws = {}
         self._refused = set()
 
-    def run(self, skips, banks, couts, affines, acts):
+    def run(self, skips, banks, couts, affines, acts, ir=None):
         """``skips``: the three skip features (B, c, fh << l, fw << l); ``banks``: (P, ld) fp32 tensors; ``affines``: (scale, shift) or
-        None per level; ``acts``: activation codes."""
+        None per level; ``acts``: activation codes.  ``ir``: dict(skip, bank, hidden, c_out, bn=[(s, b) | None] * 3) of the inverted
+        residual on the 8 x 8-pixel patches."""
         dev = skips[0].device
         b, _, fh, fw = skips[0].shape
-        key = (dev, b, fh, fw, tuple(couts), tuple(s.shape[1] for s in skips))
+        key = (dev, b, fh, fw, tuple(couts), tuple(s.shape[1] for s in skips),
+               None if ir is None else (ir['skip'].shape[1], ir['hidden'], ir['c_out']))
         if key in self._refused:
             return None
         arr = (_hip.K1LevelC * 3)()
-        keep = []
         for l in range(3):
             sk = skips[l]
             if tuple(sk.shape[2:]) != (fh << l, fw << l) or sk.shape[0] != b:
@@ -506,11 +507,24 @@ class K1Chain:
             else:
                 a.scale, a.shift = None, None
             a.act = acts[l]
-            keep.append(sk)
+        irc = None
+        if ir is not None:
+            sk = ir['skip']
+            if tuple(sk.shape[2:]) != (fh << 3, fw << 3) or sk.shape[0] != b:
+                return None
+            irc = _hip.ChainIrLevelC()
+            irc.skip, irc.c_skip = _hip.dev_ptr(sk, 'skip feature of the inverted residual'), sk.shape[1]
+            irc.bank, irc.ld = _bank_ptr(ir['bank'])
+            irc.hidden, irc.c_out = ir['hidden'], ir['c_out']
+            for k, bn in enumerate(ir['bn']):
+                sc, sh = (None, None) if bn is None else (_hip.dev_ptr(bn[0], 'bn scale'), _hip.dev_ptr(bn[1], 'bn shift'))
+                setattr(irc, f's{k + 1}', sc)
+                setattr(irc, f'b{k + 1}', sh)
+        irp = C.byref(irc) if irc is not None else None
         with _hip.device_scope(dev):
             ws = self._ws.get(key)
             if ws is None:
-                n = int(_hip.lib.hs_k1_chain_workspace(b, fh, fw, arr, 3))
+                n = int(_hip.lib.hs_decoder_chain_workspace(b, fh, fw, arr, 3, irp))
                 if n < 0:
                     self._refused.add(key)
                     return None
@@ -519,12 +533,13 @@ class K1Chain:
                 ws = torch.zeros(n, device=dev, dtype=torch.uint8)
                 publish_ready(dev)
                 self._ws[key] = ws
-            y = torch.empty(b, couts[2], 4 * fh, 4 * fw, device=dev, dtype=torch.float32)
-            st = _hip.lib.hs_k1_chain_fwd(b, fh, fw, arr, 3, ws.data_ptr(), y.data_ptr(), _hip.stream_ptr())
+            scale = 8 if ir is not None else 4
+            y = torch.empty(b, ir['c_out'] if ir is not None else couts[2], scale * fh, scale * fw, device=dev, dtype=torch.float32)
+            st = _hip.lib.hs_decoder_chain_fwd(b, fh, fw, arr, 3, irp, ws.data_ptr(), y.data_ptr(), _hip.stream_ptr())
         if st == -3:                              # HS_ERR_UNSUPPORTED: shape or residency -- nothing was launched
             self._refused.add(key)
             return None
-        _hip.check(st, 'hs_k1_chain_fwd')
+        _hip.check(st, 'hs_decoder_chain_fwd')
         return y
 
     def error_word(self):
@@ -532,9 +547,11 @@ class K1Chain:
         return max([int(ws[:4].view(torch.int32).item()) for ws in self._ws.values()] or [0])
 
 
-# The three coarse k = 1 levels as one launch: opt-in per decoder (``decoder.chain_k1 = True``; prepare_for_inference(chain_k1=True)
-# sets it), or process-wide with HS_K1_CHAIN=1 (dev A/B switch).
+# The three coarse k = 1 levels (+ the first inverted-residual level) as one launch: opt-in per decoder (``decoder.chain_k1 = True``;
+# prepare_for_inference(chain_k1=True) sets it), or process-wide with HS_K1_CHAIN=1 (dev A/B switch).  HS_K1_CHAIN_IR=0 keeps the
+# inverted residual out of the chain (A/B).
 K1_CHAIN = os.environ.get('HS_K1_CHAIN', '0') == '1'
+K1_CHAIN_IR = os.environ.get('HS_K1_CHAIN_IR', '1') == '1'
 
 
 @_on_operand_device

@@ -567,7 +567,30 @@ class MultiScaleDecoder(EpochOnModeSwitch, nn.Module):
             skips.append(sk); bnk.append(ref.bank); couts.append(conv.out_channels); affines.append(aff); acts.append(act)
         if getattr(self, '_k1_chain', None) is None:
             self._k1_chain = HF.K1Chain()
-        return self._k1_chain.run(skips, bnk, couts, affines, acts)
+        # the first inverted-residual level rides in the same launch when it is the block every reference configuration builds
+        # (3 x 3 depthwise, stride 1, reflect halo, BatchNorm2d | identity, ReLU6, no residual) on 8 x 8-pixel patches
+        ir = None
+        if HF.K1_CHAIN_IR and self.levels > 3 and getattr(self, 'chain_ir', True):
+            mods = list(getattr(self, 'level_3'))
+            while len(mods) == 1 and isinstance(mods[0], MetaSequential):
+                mods = list(mods[0])
+            ref = banks[3][0] if len(banks[3]) == 1 else None
+            blk = mods[0] if len(mods) == 1 else None
+            if isinstance(blk, HyperPatchInvertedResidual) and isinstance(ref, HF.BankRef) and ref.rows == blk.hyper_params \
+                    and not blk.use_res_connect and blk.kernel_size == (3, 3) and blk.stride == 1 and blk.padding_mode == 'reflect' \
+                    and isinstance(blk.act_layer, nn.ReLU6) \
+                    and all((isinstance(q, nn.BatchNorm2d) and not q.training and not (torch.is_grad_enabled() and q.weight.requires_grad))
+                            or blk._is_identity(q) for q in (blk.bn1, blk.bn2, blk.bn3)):
+                sk = x[-4]
+                if sk.is_cuda and sk.dtype == torch.float32 and sk.is_contiguous() and 2 + sk.shape[1] + couts[2] == blk.in_nc:
+                    bns = [None if blk._is_identity(q) else blk._affine_of(k, q, sk.device) for k, q in enumerate((blk.bn1, blk.bn2, blk.bn3))]
+                    ir = dict(skip=sk, bank=ref.bank, hidden=blk.hidden_dim, c_out=blk.out_nc, bn=bns)
+        if ir is not None:
+            y = self._k1_chain.run(skips, bnk, couts, affines, acts, ir=ir)
+            if y is not None:
+                return y, 4
+        y = self._k1_chain.run(skips, bnk, couts, affines, acts)
+        return (y, 3) if y is not None else None
 
     def _train_banks(self, s):
         """Every level's bank for the training path in ONE launch (autograd.S2WBanksTrain: hs_s2w_train_fwd, three launches back) --
@@ -741,8 +764,8 @@ class MultiScaleDecoder(EpochOnModeSwitch, nn.Module):
         p, first = None, 0
         if (getattr(self, 'chain_k1', False) or HF.K1_CHAIN) and side is None and not bank_events and s.is_cuda:
             # the three coarse k = 1 levels as ONE launch (hs_k1_chain_fwd); None: the shape / residency is not covered
-            p = self._run_k1_chain(x, banks)
-            first = 3 if p is not None else 0
+            done = self._run_k1_chain(x, banks)
+            p, first = done if done is not None else (None, 0)
         for level in range(first, self.levels):
             level_layers = getattr(self, f'level_{level}')
             if side is not None and level == join_level:

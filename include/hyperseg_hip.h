@@ -169,6 +169,28 @@ int64_t hs_k1_chain_workspace(int32_t batch, int32_t fh, int32_t fw, const hs_k1
 int hs_k1_chain_fwd(int32_t batch, int32_t fh, int32_t fw, const hs_k1_level* levels, int32_t n_levels, void* workspace,
                     float* y, void* stream);
 
+/* The same launch carrying the decoder's FIRST INVERTED-RESIDUAL level as well (HyperPatchInvertedResidual on 8 x 8-pixel patches,
+ * hyperseg_v1_0.py:281-376; Op C of hs_patch_ir_fwd): behind level 2 every workgroup hands its 4 x 4 outputs to the neighbouring
+ * cells, assembles the reflect halo tile of ITS patch (coords, skip, bilinear 2x of level 2) and runs pw1 -> BN1 -> ReLU6 ->
+ * depthwise 3 x 3 -> BN2 -> ReLU6 -> pw3 -> BN3 with the hidden activations in LDS -- exact f32 (v_mfma_f32_16x16x4_f32 for the two
+ * 1 x 1 layers, v_fma_f32 for the depthwise one).  ir == NULL: hs_k1_chain_fwd.
+ *   ir: skip (batch, c_skip, 8 fh, 8 fw); bank rows [pw1: hidden x c_in | depthwise: hidden x 9 | pw3: c_out x hidden] with
+ *       c_in = 2 + c_skip + levels[2].c_out, row stride ld; s1 / b1 ... s3 / b3: the three folded BatchNorms (a null scale: none).
+ *       No residual connection (the reference adds one only when c_in == c_out, which no decoder level has).
+ *   y (batch, ir->c_out, 8 fh, 8 fw).  workspace: hs_decoder_chain_workspace() bytes, otherwise as for hs_k1_chain_fwd.
+ * HS_ERR_UNSUPPORTED in addition when hidden > 64 or not a multiple of 4, c_out > 64, c_skip x 100 > 768, levels[2].c_out > 21,
+ * the bank is larger than 12 KB, or the workgroup's LDS (~63 KB at HyperSeg-M) would pass 64 KB. */
+typedef struct hs_chain_ir_level {
+    const float* skip; int32_t c_skip;
+    const float* bank; int64_t ld;
+    int32_t hidden, c_out;
+    const float* s1; const float* b1; const float* s2; const float* b2; const float* s3; const float* b3;
+} hs_chain_ir_level;
+int64_t hs_decoder_chain_workspace(int32_t batch, int32_t fh, int32_t fw, const hs_k1_level* levels, int32_t n_levels,
+                                   const hs_chain_ir_level* ir);
+int hs_decoder_chain_fwd(int32_t batch, int32_t fh, int32_t fw, const hs_k1_level* levels, int32_t n_levels,
+                         const hs_chain_ir_level* ir, void* workspace, float* y, void* stream);
+
 /* MetaConv2d.forward with the reference's FULL argument set (meta_conv.py:141-186): per-sample weights w (B, rows >=
  * c_out * c_in/groups * kh * kw, row stride ldw; natural order ((o*cin_g + c)*kh + ky)*kw + kx), non-square kernels, stride,
  * dilation, any padding amounts per side and mode (F.pad semantics for reflect / replicate / circular, zero padding

@@ -846,15 +846,19 @@ def test_two_python_threads_two_streams_through_the_decoder(O, HF, dev):
     assert getattr(HF._ir_math_local, 'mode', None) is None          # the scopes were the threads' own: nothing leaked into this one
 
 
+@pytest.mark.parametrize('with_ir', [True, False])
 @pytest.mark.parametrize('name,size', [('M', None), ('M', (128, 256)), ('M', (32, 64)), ('Sc', None)])
-def test_k1_chain_equals_the_three_launches(O, HF, dev, name, size):
+def test_k1_chain_equals_the_three_launches(O, HF, dev, name, size, with_ir):
     """hs_k1_chain_fwd (levels 0-2 as ONE launch with in-launch neighbour hand-offs, csrc/hs_k1_chain.hip) against the three
     hs_patch_conv_fwd launches it replaces, through the whole decoder: full HyperSeg-M (512 cells: the whole grid resident) and CamVid-S
     grids, a 4 x 8 grid and a 1 x 2 grid (every cell on the border: all hand-offs clamped).  Same operations per output, another summation
     order: rounding-level agreement.  Six calls in a row (the generation counter in the workspace advances per call), then the same
     decoder captured in a HIP graph and replayed (kernel arguments frozen: the generation must come from memory), and the error word
-    (a workgroup that gave up waiting for a neighbour) must stay 0."""
+    (a workgroup that gave up waiting for a neighbour) must stay 0.  ``with_ir``: the first inverted-residual level (8 x 8-pixel
+    patches) rides in the same launch (hs_decoder_chain_fwd) -- exact f32 on the matrix cores, against hs_patch_ir_fwd in every math mode
+    the suite runs (the reference tolerance is the same for all of them)."""
     d = build_decoder(name, O).to(dev).eval()
+    d.chain_ir = with_ir
     kw = {} if size is None else dict(size=size)
     frames = [O.synth_decoder_inputs(name, batch=1, seed=k, **kw) for k in (0, 1)]
     frames = [([t.to(dev) for t in x], s.to(dev)) for x, s in frames]
@@ -865,6 +869,7 @@ def test_k1_chain_equals_the_three_launches(O, HF, dev, name, size):
             x, s = frames[it & 1]
             y = d(x, s)
             assert d._k1_chain is not None and d._k1_chain._ws, 'the chain refused a shape it is built for'
+            assert any((k[-1] is not None) == with_ir for k in d._k1_chain._ws), 'the inverted residual did not ride in the chain'
             assert rel_err(y.cpu(), ref[it & 1].cpu()) < REL_TOL, f'call {it}'
         assert d._k1_chain.error_word() == 0
         # graph replay: same launch parameters every time

@@ -473,3 +473,22 @@ def test_k1_chain_plan_on_the_host():
     assert plan(1, 16, 32, [(120, 64), (28, 32), (10, 16)]) == -3         # level-0 bank past 24 KB
     assert plan(1, 16, 32, [(80, 64), (70, 32), (10, 16)]) == -3          # 70 skip channels x 4 pixels > 256 gather lanes
     assert plan(0, 16, 32, m) == -1
+
+    def plan_ir(batch, fh, fw, chans, cs3, hid, co3):
+        arr = (_hip.K1LevelC * 3)()
+        dummy = C.c_void_p(4096)
+        prev = 0
+        for l, (cs, co) in enumerate(chans):
+            arr[l].skip, arr[l].c_skip, arr[l].bank, arr[l].c_out = dummy, cs, dummy, co
+            arr[l].ld = (co * (2 + cs + prev) + 3) & ~3
+            prev = co
+        ir = _hip.ChainIrLevelC()
+        ir.skip, ir.c_skip, ir.bank, ir.hidden, ir.c_out = dummy, cs3, dummy, hid, co3
+        cin = 2 + cs3 + prev
+        ir.ld = (cin * hid + 9 * hid + hid * co3 + 3) & ~3
+        return int(_hip.lib.hs_decoder_chain_workspace(batch, fh, fw, arr, 3, C.byref(ir)))
+    # with the first inverted-residual level (HyperSeg-M / CamVid-S level 3: 24 -> 48 -> 16 on 8 x 8 patches): + 16 granules x 16 channels per cell
+    assert plan_ir(1, 16, 32, m, 6, 48, 16) == 256 + 8 * 512 * (64 + 4 * 32 + 16 * 16)
+    assert plan_ir(1, 16, 32, m, 6, 46, 16) == -3            # hidden not a multiple of 4
+    assert plan_ir(1, 16, 32, m, 6, 96, 16) == -3            # hidden > 64
+    assert plan_ir(1, 16, 32, m, 8, 48, 16) == -3            # 800 skip-halo gathers > 768

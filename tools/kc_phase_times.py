@@ -22,9 +22,10 @@ buf = np.zeros(n, dtype=np.int64)
 assert fn(buf.ctypes.data, n) == 0
 st = buf.reshape(8192, 32)
 st = st[st[:, 24] > 0]
-labels = {0: 'start', 1: 'all DMA issued (groups 0 + 1)', 2: 'group 0 landed (vmcnt(10))', 3: 'barrier, generation read', 4: 'level 0 dots + publish',
-          5: 'barrier (group 1 landed)', 6: 'gather 0 -> 1 (neighbours\' level 0)', 7: 'stage 1 built (2 barriers)', 8: 'level 1 dots + publish + barrier',
-          9: 'gather 1 -> 2', 10: 'stage 2 built (2 barriers)', 24: 'level 2 dots + stores'}
+labels = {0: 'start', 1: 'all DMA issued (groups 0 + 1)', 2: 'group 0 landed (vmcnt(10))', 3: 'barrier, generation read', 4: 'level 0 products + barrier + publish',
+          5: 'barrier (group 1 landed)', 6: 'gather 0 -> 1 (neighbours\' level 0)', 7: 'stage 1 built (2 barriers)', 8: 'level 1 products + publish',
+          9: 'gather 1 -> 2', 10: 'stage 2 built (2 barriers)', 11: 'level 2 products + publish / stores', 12: 'gather 2 -> 3 (6 x 6 window)',
+          13: 'halo tile built (2 barriers)', 14: 'pw1 + bn1 + relu6 -> h1', 15: 'depthwise + bn2 + relu6 -> h2', 24: 'pw3 + bn3 + stores (end)'}
 print(f'{name}: {len(st)} workgroups stamped; shader clock cycles (wave 0 of every workgroup)')
 prev = None
 for k in sorted(labels):
