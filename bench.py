@@ -664,9 +664,9 @@ def main(argv=None):
                          'with f32 accumulation -- `dtype` says so in words; the `exact_f32` object re-times the step with every decoder '
                          'product on the exact-f32 matrix cores (--ir-math f32 makes that the headline)')
     ap.add_argument('--chain-k1', dest='chain_k1', action='store_true',
-                    help="the decoder's three coarse k = 1 levels as ONE launch with in-launch neighbour hand-offs (hs_k1_chain_fwd)")
+                    help="(default) the decoder's three coarse k = 1 levels as ONE launch with in-launch neighbour hand-offs (hs_k1_chain_fwd)")
     ap.add_argument('--no-chain-k1', dest='chain_k1', action='store_false', help='one launch per k = 1 level')
-    ap.set_defaults(chain_k1=False)
+    ap.set_defaults(chain_k1=True)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the roofline / parity / protocol passes (timing only)')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
@@ -930,6 +930,9 @@ def main(argv=None):
                        'output': f'fp32 logits {tuple(y.shape)}' if args.output == 'logits' else f'uint8 argmax masks {tuple(y.shape)}',
                        'launch': 'eager' if args.no_graph else 'hipGraph replay',
                        'ir_math': math_name + ' (include/hyperseg_hip.h hs_ir_math)',
+                       'decoder_launches': ('signal2weights | levels 0-2 as one launch (hs_k1_chain_fwd: in-launch neighbour hand-offs) | '
+                                            'level 3 | level 4 | upsample' if getattr(getattr(model, 'decoder', None), 'chain_k1', False)
+                                            else 'signal2weights | one launch per level | upsample'),
                        'arithmetic': 'f32 storage and f32 accumulation everywhere.  Decoder (the hot path): ' +
                                      ('every product exact f32 (v_mfma_f32_16x16x4_f32 / v_fma_f32)' if math_name == 'f32' else
                                       'level-4 inverted residual products as 3-term f16 splits (1.3e-7 * sum|a||b|), the rest exact f32') +
@@ -1024,11 +1027,21 @@ def main(argv=None):
                         out['library_gemm_f32'] = {'error': f'{type(e).__name__}: {e}'[:300]}
                         torch.cuda.synchronize()
             if world == 1 and graph is not None:
+                dec_mod = getattr(model, 'decoder', None)
+                chain_was = getattr(dec_mod, 'chain_k1', False)
                 try:                                  # a side number must never cost the line
+                    # two launches of the chained levels must not share the chain's workspace concurrently (one frame in flight per
+                    # decoder: functional.K1Chain): the two request graphs are captured with one launch per level
+                    if dec_mod is not None:
+                        dec_mod.chain_k1 = False
                     out['two_frames_in_flight'] = two_in_flight(forward, x, y_bench, args.steps, args.warmup, batch)
+                    out['two_frames_in_flight']['note'] += '; captured with chain_k1 off (one launch per decoder level)'
                 except Exception as e:                # noqa: BLE001
                     out['two_frames_in_flight'] = {'error': f'{type(e).__name__}: {e}'[:300]}
                     torch.cuda.synchronize()
+                finally:
+                    if dec_mod is not None:
+                        dec_mod.chain_k1 = chain_was
             if world == 1:
                 # ---- the reference harness' own protocol (sync + pinned H2D + eager forward per iteration) -------------
                 from hyperseg_amd.fps import measure_fps, synthetic_batches

@@ -552,6 +552,8 @@ class K1Chain:
 # inverted residual out of the chain (A/B).
 K1_CHAIN = os.environ.get('HS_K1_CHAIN', '0') == '1'
 K1_CHAIN_IR = os.environ.get('HS_K1_CHAIN_IR', '1') == '1'
+# Whether a chained decoder carries its first inverted-residual level in the chain launch unless ``decoder.chain_ir`` says otherwise
+K1_CHAIN_IR_DEFAULT = os.environ.get('HS_K1_CHAIN_IR_DEFAULT', '0') == '1'
 
 
 @_on_operand_device

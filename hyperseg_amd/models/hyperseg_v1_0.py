@@ -570,7 +570,7 @@ class MultiScaleDecoder(EpochOnModeSwitch, nn.Module):
         # the first inverted-residual level rides in the same launch when it is the block every reference configuration builds
         # (3 x 3 depthwise, stride 1, reflect halo, BatchNorm2d | identity, ReLU6, no residual) on 8 x 8-pixel patches
         ir = None
-        if HF.K1_CHAIN_IR and self.levels > 3 and getattr(self, 'chain_ir', True):
+        if HF.K1_CHAIN_IR and self.levels > 3 and getattr(self, 'chain_ir', HF.K1_CHAIN_IR_DEFAULT):
             mods = list(getattr(self, 'level_3'))
             while len(mods) == 1 and isinstance(mods[0], MetaSequential):
                 mods = list(mods[0])

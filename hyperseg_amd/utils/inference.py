@@ -515,7 +515,7 @@ def set_ir_math(model, mode):
 
 
 def prepare_for_inference(model, fold_bn=True, channels_last=False, fused_depthwise=False, split_gemm=False, ir_math='auto',
-                          chain_k1=False):
+                          chain_k1=True):
     """In place; returns the number of BatchNorms folded by ``fold_bn``.  ``model``: a HyperGen in eval mode (module
     docstring for what each switch does).  The fused routes are installed first, so ``fold_bn`` only touches the
     Conv -> BatchNorm pairs that no fused route reads.  ``ir_math``: :func:`set_ir_math` for the decoder ('auto' = the
