@@ -87,7 +87,7 @@ struct KcArgs {
 };
 
 // LDS map (bytes).  rows[k]: 64-float arrays -- levels 0-2 scale / shift (0-5), inverted residual s1 b1 s2 b2 s3 b3 (6-11)
-struct KcLds { int bank[4], dump, rows, xin0, sk1, sk2, sk3, genw, own0, own1, own2, part, total;
+struct KcLds { int bank[4], dump, rows, xin0, sk1, sk2, sk3, genw, own0, own1, own2, part, tab, total;
                int nb0, xin1, nb1, xin2, alias1_end;            // inside bank 0's region once level 0 is done
                int h1, xt, nb2, h2, alias2_end; };              // inside banks 0-2 once level 2 is done
 
@@ -108,6 +108,7 @@ __host__ __device__ inline KcLds kc_lds_map(const KcLevel* L, const KcIr& R) {
     m.own1 = o; o += 4 * 64 * 4;
     m.own2 = o; o += ir ? 16 * L[2].cout * 4 : 0;
     m.part = o; o += KC_WAVES * 256 * 4;      // partial 16 x 16 tiles of the K-split products
+    m.tab = o; o += ir ? 20 * 8 * 4 : 0;      // per halo row / column of the inverted residual: bilinear taps into level 2's window, coordinate
     m.total = o;
     int q = m.bank[0];
     m.nb0 = q; q += 9 * L[0].cout * 4;
@@ -272,39 +273,33 @@ void decoder_chain_kernel(KcArgs a) {
         const int c = kc_clamp(tid >> 4, 0, cs2 - 1), px = tid & 15;
         dma_word(a.L[2].skip + ((((size_t)b * cs2 + c) * H2 + (4 * i + (px >> 2))) * W2 + (4 * j + (px & 3))), M.sk2 + wave * 256);
     }
-    if constexpr (IR) {
-#pragma unroll
-        for (int q = 0; q < KC_P3; ++q) dma_bank(a.R.bank, a.R.ld, M.bank[3], a.R.pieces, q);
-        // the skip feature on the patch's reflect halo: element e = (channel, halo position)
-#pragma unroll
-        for (int q = 0; q < KC_SK3; ++q) {
-            const int e = min(tid + q * KC_THREADS, a.R.c_skip * KC_HALO - 1);
-            const int c = e / KC_HALO, pos = e - c * KC_HALO, u = pos / 10, v = pos - u * 10;
-            const int yy = pad_index(8 * i + u - 1, H3, HS_PAD_REFLECT), xx = pad_index(8 * j + v - 1, W3, HS_PAD_REFLECT);
-            dma_word(a.R.skip + ((((size_t)b * a.R.c_skip + c) * H3 + yy) * W3 + xx), M.sk3 + (q * KC_THREADS + wave * 64) * 4);
-        }
-    }
     if (wave == 1) {
         dma_row(a.L[1].scale, c1, 2); dma_row(a.L[1].shift, c1, 3);
         dma_row(a.L[2].scale, c2, 4); dma_row(a.L[2].shift, c2, 5);
     }
-    if constexpr (IR) {
-        if (wave == 2) { dma_row(a.R.s1, a.R.hid, 6); dma_row(a.R.b1, a.R.hid, 7); dma_row(a.R.s2, a.R.hid, 8); dma_row(a.R.b2, a.R.hid, 9); }
-        if (wave == 3) { dma_row(a.R.s3, a.R.cout, 10); dma_row(a.R.b3, a.R.cout, 11); }
-    }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (IR) {
+        // while group 0 is in flight: the inverted residual's tap table -- per halo row u / column v of the patch: the REFLECTED image
+        // position's bilinear taps into level 2's 6 x 6 window {offset 0, offset 1, l0, l1} and its coordinate value
+        if (tid < 20) {
+            const bool isrow = tid < 10;
+            const int k = isrow ? tid : tid - 10;
+            const int p = isrow ? pad_index(8 * i + k - 1, H3, HS_PAD_REFLECT) : pad_index(8 * j + k - 1, W3, HS_PAD_REFLECT);
+            const Tap t = bilinear_tap(p, 0.5f, isrow ? H2 : W2);
+            float* d = reinterpret_cast<float*>(lds + M.tab) + tid * 8;
+            const int base = isrow ? 4 * i - 1 : 4 * j - 1;
+            d[0] = __int_as_float(t.i0 - base); d[1] = __int_as_float(t.i1 - base); d[2] = t.l0; d[3] = t.l1;
+            d[4] = isrow ? linspace_pm1(p, H3, a.R.step_y) : linspace_pm1(p, W3, a.R.step_x);
+        }
+    }
     // @stamp 1
     // group 0 has landed when at most group 1's operations are outstanding (vector-memory operations complete in issue order).
-    // Group 1 per wave: banks KC_P1 + KC_P2 (+ KC_P3), skip gathers 2 (+ KC_SK3), rows: wave 1: 4; with the inverted residual wave 2: 4, wave 3: 2
-    static_assert(KC_P1 + KC_P2 + 2 == 6 && KC_P1 + KC_P2 + KC_P3 + 2 + KC_SK3 == 12, "the counts in the s_waitcnt's below");
-    if constexpr (!IR) {
-        if (wave == 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-        if (wave == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (wave == 3) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    }
+    // Group 1 per wave: banks KC_P1 + KC_P2, skip gathers 2; wave 1 adds the four BatchNorm rows of levels 1 and 2.  (The inverted
+    // residual's operands are requested later, behind level 0's publishing stores: at the top they delayed level 0 by ~2.7 k cycles of
+    // DMA issue -- profiles/round5_chain_v2_*_v5.txt -- and they have until level 3 to land.)
+    static_assert(KC_P1 + KC_P2 + 2 == 6, "the counts in the s_waitcnt's below");
+    if (wave == 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     // @stamp 2
     {   // level 0's input vector: the coordinates over what the gather put in slots 0 and 1, zeros up to the next whole k-step (each
         // slot was written by the DMA of the wave that owns the thread: ordered by that wave's wait)
@@ -332,6 +327,24 @@ void decoder_chain_kernel(KcArgs a) {
         __hip_atomic_store(gx0 + (size_t)cell * c0 + tid, ((u64)gen << 32) | (u64)__float_as_uint(v), KC_RLX_AGENT);
     }
     // @stamp 4
+    if constexpr (IR) {
+        // the inverted residual's operands (bank, skip feature on the reflect halo, BatchNorm rows): requested now, they land while this
+        // workgroup waits for its neighbours' level-0 outputs; every later __syncthreads() / poll wait covers them
+#pragma unroll
+        for (int q = 0; q < KC_P3; ++q) dma_bank(a.R.bank, a.R.ld, M.bank[3], a.R.pieces, q);
+        {
+            const float* skb = a.R.skip + (size_t)b * a.R.c_skip * H3 * W3;      // (uniform base; 32-bit element offsets below)
+#pragma unroll
+            for (int q = 0; q < KC_SK3; ++q) {
+                const int e = min(tid + q * KC_THREADS, a.R.c_skip * KC_HALO - 1);
+                const int c = e / KC_HALO, pos = e - c * KC_HALO, u = pos / 10, v = pos - u * 10;
+                const int yy = pad_index(8 * i + u - 1, H3, HS_PAD_REFLECT), xx = pad_index(8 * j + v - 1, W3, HS_PAD_REFLECT);
+                dma_word(skb + (unsigned)((c * H3 + yy) * W3 + xx), M.sk3 + (q * KC_THREADS + wave * 64) * 4);
+            }
+        }
+        if (wave == 2) { dma_row(a.R.s1, a.R.hid, 6); dma_row(a.R.b1, a.R.hid, 7); dma_row(a.R.s2, a.R.hid, 8); dma_row(a.R.b2, a.R.hid, 9); }
+        if (wave == 3) { dma_row(a.R.s3, a.R.cout, 10); dma_row(a.R.b3, a.R.cout, 11); }
+    }
     if (tid < 64) {   // levels without an epilogue: unit rows (read two barriers further down)
         if (!a.L[1].scale) { rows[128 + tid] = 1.0f; rows[192 + tid] = 0.0f; }
         if (!a.L[2].scale) { rows[256 + tid] = 1.0f; rows[320 + tid] = 0.0f; }
@@ -489,10 +502,10 @@ void decoder_chain_kernel(KcArgs a) {
             }
             // the halo tile's rows that do not depend on level 2: coordinates, skip feature (both at the REFLECTED position: the block pads
             // the stage input, hyperseg_v1_0.py:339-345), zero rows up to a whole k-step; unit rows for absent BatchNorms
+            const float* tab = reinterpret_cast<const float*>(lds + M.tab);
             for (int e = tid; e < 2 * KC_HALO; e += KC_THREADS) {
                 const int c = e >= KC_HALO ? 1 : 0, pos = e - c * KC_HALO, u = pos / 10, vv = pos - u * 10;
-                xt[c * KC_LDT + pos] = c == 0 ? linspace_pm1(pad_index(8 * j + vv - 1, W3, HS_PAD_REFLECT), W3, a.R.step_x)
-                                              : linspace_pm1(pad_index(8 * i + u - 1, H3, HS_PAD_REFLECT), H3, a.R.step_y);
+                xt[c * KC_LDT + pos] = c == 0 ? tab[(10 + vv) * 8 + 4] : tab[u * 8 + 4];
             }
             for (int e = tid; e < cs3 * KC_HALO; e += KC_THREADS) {
                 const int c = e / KC_HALO, pos = e - c * KC_HALO;
@@ -506,33 +519,67 @@ void decoder_chain_kernel(KcArgs a) {
             }
         }
         __syncthreads();
-        // bilinear 2x of level 2 at the halo positions: c2 channels x 100 positions
-        for (int e = tid; e < c2 * KC_HALO; e += KC_THREADS) {
-            const int cp = e / KC_HALO, pos = e - cp * KC_HALO, u = pos / 10, vv = pos - u * 10;
-            const int yy = pad_index(8 * i + u - 1, H3, HS_PAD_REFLECT), xx = pad_index(8 * j + vv - 1, W3, HS_PAD_REFLECT);
-            const Tap ty = bilinear_tap(yy, 0.5f, H2), tx = bilinear_tap(xx, 0.5f, W2);
-            const float* r0 = nb2 + ((ty.i0 - (4 * i - 1)) * 6) * c2 + cp;
-            const float* r1 = nb2 + ((ty.i1 - (4 * i - 1)) * 6) * c2 + cp;
-            const int x0i = (tx.i0 - (4 * j - 1)) * c2, x1i = (tx.i1 - (4 * j - 1)) * c2;
-            const float top = tx.l0 * r0[x0i] + tx.l1 * r0[x1i];
-            const float bot = tx.l0 * r1[x0i] + tx.l1 * r1[x1i];
-            xt[(2 + cs3 + cp) * KC_LDT + pos] = ty.l0 * top + ty.l1 * bot;
+        // bilinear 2x of level 2 at the halo positions: thread = (position, channel group); the position's taps come from the table
+        {
+            const float* tab = reinterpret_cast<const float*>(lds + M.tab);
+            for (int e = tid; e < c2 * KC_HALO; e += KC_THREADS) {
+                const int cp = e / KC_HALO, pos = e - cp * KC_HALO, u = pos / 10, vv = pos - u * 10;
+                const float* ty = tab + u * 8;
+                const float* tx = tab + (10 + vv) * 8;
+                const float* r0 = nb2 + (__float_as_int(ty[0]) * 6) * c2 + cp;
+                const float* r1 = nb2 + (__float_as_int(ty[1]) * 6) * c2 + cp;
+                const int x0i = __float_as_int(tx[0]) * c2, x1i = __float_as_int(tx[1]) * c2;
+                const float top = tx[2] * r0[x0i] + tx[3] * r0[x1i];
+                const float bot = tx[2] * r1[x0i] + tx[3] * r1[x1i];
+                xt[(2 + cs3 + cp) * KC_LDT + pos] = ty[2] * top + ty[3] * bot;
+            }
         }
         __syncthreads();
         // @stamp 13
         // ------------------------------------------------------------ pw1: h1 = relu6(bn1(W1 . x)) on the 100 halo positions (7 column tiles)
+        // wave w takes column tiles w and w + 4; all of its (row tile, column tile) accumulators advance together through K -- up to
+        // eight independent matrix-core chains per wave (one tile at a time was a chain of dependent products, 40+ cycles each, with
+        // the LDS reads of every step exposed: 8.6 k cycles for 36 products per wave, profiles/round5_chain_v2_*_v5.txt)
         {
             const int lrow = lane & 15, lk = lane >> 4;
             const int kst = a.R.kp >> 2, mt = (hid + 15) >> 4;
-            for (int n = wave; n < KC_LDT / 16; n += KC_WAVES) {
-                for (int m = 0; m < mt; ++m) {
-                    const int row = min(m * 16 + lrow, hid - 1);
-                    kc4 acc = {0.f, 0.f, 0.f, 0.f};
-                    acc = kc_mma(wl3 + row * cin3 + lk, xt + lk * KC_LDT + n * 16 + lrow, KC_LDT, 0, kst, acc);
+            const int n0 = wave, n1 = wave + KC_WAVES;
+            const bool two = n1 < KC_LDT / 16;                                   // (uniform)
+            kc4 acc[2][4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int h = m * 16 + 4 * lk + r;
-                        if (h < hid) h1[h * KC_LDT + n * 16 + lrow] = fminf(fmaxf(fmaf(acc[r], s1[h], b1[h]), 0.0f), 6.0f);
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[q][m] = kc4{0.f, 0.f, 0.f, 0.f};
+            const float* wr[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) wr[m] = wl3 + min(m * 16 + lrow, hid - 1) * cin3 + lk;
+            const float* x0 = xt + lk * KC_LDT + n0 * 16 + lrow;
+            const float* x1 = xt + lk * KC_LDT + (two ? n1 : n0) * 16 + lrow;
+#pragma unroll 2
+            for (int ks = 0; ks < kst; ++ks) {
+                float av[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) av[m] = wr[m][4 * ks];
+                const float b0 = x0[4 * ks * KC_LDT], b1 = x1[4 * ks * KC_LDT];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    if (m < mt) {
+                        acc[0][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], b0, acc[0][m], 0, 0, 0);
+                        if (two) acc[1][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], b1, acc[1][m], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if (q == 0 || two) {
+                    const int n = q == 0 ? n0 : n1;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int h = m * 16 + 4 * lk + r;
+                            if (m < mt && h < hid) h1[h * KC_LDT + n * 16 + lrow] = fminf(fmaxf(fmaf(acc[q][m][r], s1[h], b1[h]), 0.0f), 6.0f);
+                        }
                     }
                 }
             }
