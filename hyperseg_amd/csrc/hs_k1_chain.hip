@@ -104,8 +104,10 @@ __host__ __device__ inline KcLds kc_lds_map(const KcLevel* L, const KcIr& R) {
     m.sk2 = o; o += 256 * 4;
     m.sk3 = o; o += ir ? KC_SK3 * 256 * 4 : 0;
     m.genw = o; o += 64 * 4;
-    m.own0 = o; o += 64 * 4;
-    m.own1 = o; o += 4 * 64 * 4;
+    // own0 / own1 (this cell's level-0 / level-1 outputs for its own next level): first written after every LDS-DMA of the workgroup
+    // has landed -- without the inverted residual (whose operands are requested later) they can live in the dump area
+    if (!ir && 256 + 4 * L[1].cout * 4 <= 1024) { m.own0 = m.dump; m.own1 = m.dump + 256; }
+    else { m.own0 = o; o += 64 * 4; m.own1 = o; o += 4 * 64 * 4; }
     m.own2 = o; o += ir ? 16 * L[2].cout * 4 : 0;
     m.part = o; o += KC_WAVES * 256 * 4;      // partial 16 x 16 tiles of the K-split products
     m.tab = o; o += ir ? 20 * 8 * 4 : 0;      // per halo row / column of the inverted residual: bilinear taps into level 2's window, coordinate
@@ -736,7 +738,8 @@ extern "C" int hs_decoder_chain_fwd(int32_t batch, int32_t fh, int32_t fw, const
     // The occupancy query answers one workgroup per CU high when the SGPR file is what limits a 256-thread workgroup (admitted =
     // min(API, 8, 800 / (ceil(sgprs / 16) * 16 + 16)): MI355X_MICROARCH.md, residency); for any SGPR count a kernel can have that
     // bound is >= 5, and LDS / VGPR limits are reported exactly -- so min(API, 5) workgroups per CU is never more than the hardware
-    // admits.  (These kernels: ~100 SGPRs, < 64 VGPRs; 29-63 KB of LDS is what limits them at the decoder's shapes: 2-5 per CU.)
+    // admits.  (These kernels: ~100 SGPRs, < 64 VGPRs; 32-63 KB of LDS is what limits them at the decoder's shapes: 2-5 per CU --
+    // HyperSeg-S's 1152 cells need the 5: its workgroup is 32 512 bytes.)
     const long cells = (long)batch * fh * fw;
     const int admitted = per_cu < 5 ? per_cu : 5;
     if (admitted < 1 || cells > (long)admitted * cus) return HS_ERR_UNSUPPORTED;

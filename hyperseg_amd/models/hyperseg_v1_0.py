@@ -424,6 +424,74 @@ def divide_feature(in_feature, out_features, min_unit=8):
     return out
 
 
+def run_decoder_chain(owner, seqs, refs, x):
+    """The coarse levels of a v1_0 / unify decoder through functional.K1Chain (hs_k1_chain_fwd / hs_decoder_chain_fwd): levels 0-2 when
+    each is [HyperPatchNoPadding(k = 1, groups = 1), eval BatchNorm?, ReLU | ReLU6?] on patches of 1, 2 and 4 pixels with a materialised
+    bank -- the layout every v1_0 reference configuration builds (hyperseg_v1_0.py:728-760) -- and, when ``owner.chain_ir`` says so, the
+    first inverted-residual level behind them.  ``seqs``: the levels' MetaSequentials; ``refs``: their BankRefs; ``x``: the feature
+    pyramid.  Returns (output, number of levels done) or None (the caller runs the levels one launch each).  The K1Chain object (it
+    owns the launch's workspace) lives on ``owner``."""
+    from .layers.meta_sequential import _act_code
+    if len(seqs) < 3:
+        return None
+    skips, bnk, couts, affines, acts = [], [], [], [], []
+    for l in range(3):
+        seq = seqs[l]
+        mods = list(seq)
+        while len(mods) == 1 and isinstance(mods[0], MetaSequential):      # level_<l> = MetaSequential(block), block = MetaSequential(conv, norm, act)
+            seq = mods[0]
+            mods = list(seq)
+        ref = refs[l]
+        if not mods or not isinstance(mods[0], HyperPatchNoPadding) or not isinstance(ref, HF.BankRef):
+            return None
+        conv = mods[0]
+        if conv.kernel_size != (1, 1) or conv.stride != (1, 1) or conv.dilation != (1, 1) or conv.groups != 1 or ref.rows != conv.hyper_params:
+            return None
+        k, aff, act = 1, None, HF.ACT_NONE
+        if k < len(mods) and isinstance(mods[k], nn.BatchNorm2d):
+            bn = mods[k]
+            if bn.training or (torch.is_grad_enabled() and bn.weight is not None and bn.weight.requires_grad):
+                return None
+            aff = seq._fold(k, bn)
+            k += 1
+        if k < len(mods) and _act_code(mods[k]) is not None:
+            act = _act_code(mods[k])
+            k += 1
+        if k != len(mods):
+            return None                                  # a Dropout or any other tail: the generic route
+        sk = x[-l - 1]
+        prev_c = couts[-1] if couts else 0
+        if not (sk.is_cuda and sk.dtype == torch.float32 and sk.is_contiguous()) or 2 + sk.shape[1] + prev_c != conv.in_channels:
+            return None
+        skips.append(sk); bnk.append(ref.bank); couts.append(conv.out_channels); affines.append(aff); acts.append(act)
+    if getattr(owner, '_k1_chain', None) is None:
+        owner._k1_chain = HF.K1Chain()
+    # the first inverted-residual level rides in the same launch when it is the block every reference configuration builds
+    # (3 x 3 depthwise, stride 1, reflect halo, BatchNorm2d | identity, ReLU6, no residual) on 8 x 8-pixel patches
+    ir = None
+    if HF.K1_CHAIN_IR and len(seqs) > 3 and getattr(owner, 'chain_ir', HF.K1_CHAIN_IR_DEFAULT):
+        mods = list(seqs[3])
+        while len(mods) == 1 and isinstance(mods[0], MetaSequential):
+            mods = list(mods[0])
+        ref = refs[3]
+        blk = mods[0] if len(mods) == 1 else None
+        if isinstance(blk, HyperPatchInvertedResidual) and isinstance(ref, HF.BankRef) and ref.rows == blk.hyper_params \
+                and not blk.use_res_connect and blk.kernel_size == (3, 3) and blk.stride == 1 and blk.padding_mode == 'reflect' \
+                and isinstance(blk.act_layer, nn.ReLU6) \
+                and all((isinstance(q, nn.BatchNorm2d) and not q.training and not (torch.is_grad_enabled() and q.weight.requires_grad))
+                        or blk._is_identity(q) for q in (blk.bn1, blk.bn2, blk.bn3)):
+            sk = x[-4]
+            if sk.is_cuda and sk.dtype == torch.float32 and sk.is_contiguous() and 2 + sk.shape[1] + couts[2] == blk.in_nc:
+                bns = [None if blk._is_identity(q) else blk._affine_of(k, q, sk.device) for k, q in enumerate((blk.bn1, blk.bn2, blk.bn3))]
+                ir = dict(skip=sk, bank=ref.bank, hidden=blk.hidden_dim, c_out=blk.out_nc, bn=bns)
+    if ir is not None:
+        y = owner._k1_chain.run(skips, bnk, couts, affines, acts, ir=ir)
+        if y is not None:
+            return y, 4
+    y = owner._k1_chain.run(skips, bnk, couts, affines, acts)
+    return (y, 3) if y is not None else None
+
+
 class MultiScaleDecoder(EpochOnModeSwitch, nn.Module):
     """Dynamic multi-scale decoder (hyperseg_v1_0.py:94-253).  ``forward(x, s)``: x = list of feature
     maps fine -> coarse including the input image, s = signal (B, Cs, H/32, W/32)."""
@@ -529,68 +597,10 @@ class MultiScaleDecoder(EpochOnModeSwitch, nn.Module):
         return carry
 
     def _run_k1_chain(self, x, banks):
-        """Levels 0-2 through functional.K1Chain when each is [HyperPatchNoPadding(k = 1, groups = 1), eval BatchNorm?, ReLU | ReLU6?]
-        on patches of 1, 2 and 4 pixels with a materialised bank -- the layout every v1_0 reference configuration builds
-        (hyperseg_v1_0.py:728-760); None otherwise (the caller runs the levels one launch each)."""
-        from .layers.meta_sequential import _act_code
-        if self.levels < 3:
-            return None
-        skips, bnk, couts, affines, acts = [], [], [], [], []
-        for l in range(3):
-            seq = getattr(self, f'level_{l}')
-            mods = list(seq)
-            while len(mods) == 1 and isinstance(mods[0], MetaSequential):      # level_<l> = MetaSequential(block), block = MetaSequential(conv, norm, act)
-                seq = mods[0]
-                mods = list(seq)
-            ref = banks[l][0] if len(banks[l]) == 1 else None
-            if not mods or not isinstance(mods[0], HyperPatchNoPadding) or not isinstance(ref, HF.BankRef):
-                return None
-            conv = mods[0]
-            if conv.kernel_size != (1, 1) or conv.stride != (1, 1) or conv.dilation != (1, 1) or conv.groups != 1 or ref.rows != conv.hyper_params:
-                return None
-            k, aff, act = 1, None, HF.ACT_NONE
-            if k < len(mods) and isinstance(mods[k], nn.BatchNorm2d):
-                bn = mods[k]
-                if bn.training or (torch.is_grad_enabled() and bn.weight is not None and bn.weight.requires_grad):
-                    return None
-                aff = seq._fold(k, bn)
-                k += 1
-            if k < len(mods) and _act_code(mods[k]) is not None:
-                act = _act_code(mods[k])
-                k += 1
-            if k != len(mods):
-                return None                                  # a Dropout or any other tail: the generic route
-            sk = x[-l - 1]
-            prev_c = couts[-1] if couts else 0
-            if not (sk.is_cuda and sk.dtype == torch.float32 and sk.is_contiguous()) or 2 + sk.shape[1] + prev_c != conv.in_channels:
-                return None
-            skips.append(sk); bnk.append(ref.bank); couts.append(conv.out_channels); affines.append(aff); acts.append(act)
-        if getattr(self, '_k1_chain', None) is None:
-            self._k1_chain = HF.K1Chain()
-        # the first inverted-residual level rides in the same launch when it is the block every reference configuration builds
-        # (3 x 3 depthwise, stride 1, reflect halo, BatchNorm2d | identity, ReLU6, no residual) on 8 x 8-pixel patches
-        ir = None
-        if HF.K1_CHAIN_IR and self.levels > 3 and getattr(self, 'chain_ir', HF.K1_CHAIN_IR_DEFAULT):
-            mods = list(getattr(self, 'level_3'))
-            while len(mods) == 1 and isinstance(mods[0], MetaSequential):
-                mods = list(mods[0])
-            ref = banks[3][0] if len(banks[3]) == 1 else None
-            blk = mods[0] if len(mods) == 1 else None
-            if isinstance(blk, HyperPatchInvertedResidual) and isinstance(ref, HF.BankRef) and ref.rows == blk.hyper_params \
-                    and not blk.use_res_connect and blk.kernel_size == (3, 3) and blk.stride == 1 and blk.padding_mode == 'reflect' \
-                    and isinstance(blk.act_layer, nn.ReLU6) \
-                    and all((isinstance(q, nn.BatchNorm2d) and not q.training and not (torch.is_grad_enabled() and q.weight.requires_grad))
-                            or blk._is_identity(q) for q in (blk.bn1, blk.bn2, blk.bn3)):
-                sk = x[-4]
-                if sk.is_cuda and sk.dtype == torch.float32 and sk.is_contiguous() and 2 + sk.shape[1] + couts[2] == blk.in_nc:
-                    bns = [None if blk._is_identity(q) else blk._affine_of(k, q, sk.device) for k, q in enumerate((blk.bn1, blk.bn2, blk.bn3))]
-                    ir = dict(skip=sk, bank=ref.bank, hidden=blk.hidden_dim, c_out=blk.out_nc, bn=bns)
-        if ir is not None:
-            y = self._k1_chain.run(skips, bnk, couts, affines, acts, ir=ir)
-            if y is not None:
-                return y, 4
-        y = self._k1_chain.run(skips, bnk, couts, affines, acts)
-        return (y, 3) if y is not None else None
+        """Levels 0-2 (+ the first inverted-residual level) through functional.K1Chain: (output, levels done) or None."""
+        seqs = [getattr(self, f'level_{l}') for l in range(min(self.levels, 4))]
+        refs = [b[0] if len(b) == 1 else None for b in banks[:len(seqs)]]
+        return run_decoder_chain(self, seqs, refs, x)
 
     def _train_banks(self, s):
         """Every level's bank for the training path in ONE launch (autograd.S2WBanksTrain: hs_s2w_train_fwd, three launches back) --

@@ -164,8 +164,13 @@ class MultiScaleDecoder(EpochOnModeSwitch, nn.Module):
         keep = [i for i, r in enumerate(refs) if r is None]
         for i, r in zip(keep, HF.signal2weights_multi(s, [layers[i] for i in keep])):
             refs[i] = r
-        p = None
-        for level in range(self.levels):
+        p, first = None, 0
+        if (getattr(self, 'chain_k1', False) or HF.K1_CHAIN) and s.is_cuda and ul - 1 >= 3:
+            # levels 0-2 have weight layers of their own: one launch for the three of them (hs_k1_chain_fwd); None: shape / residency not covered
+            from .hyperseg_v1_0 import run_decoder_chain
+            done = run_decoder_chain(self, [self.level_blocks[l] for l in range(3)], refs[:3], x)
+            p, first = done if done is not None else (None, 0)
+        for level in range(first, self.levels):
             stage = HF.StageInput(x[-level - 1], p, coords=True)
             if level < ul - 1:
                 w = refs[level]

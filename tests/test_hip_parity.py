@@ -846,8 +846,9 @@ def test_two_python_threads_two_streams_through_the_decoder(O, HF, dev):
     assert getattr(HF._ir_math_local, 'mode', None) is None          # the scopes were the threads' own: nothing leaked into this one
 
 
-@pytest.mark.parametrize('with_ir', [True, False])
-@pytest.mark.parametrize('name,size', [('M', None), ('M', (128, 256)), ('M', (32, 64)), ('Sc', None)])
+@pytest.mark.parametrize('name,size,with_ir', [('M', None, False), ('M', (128, 256), False), ('M', (32, 64), False), ('Sc', None, False),
+                                               ('S', None, False),          # the unify decoder, 1152 cells: five 32.5 KB workgroups per CU
+                                               ('M', None, True), ('M', (128, 256), True), ('M', (32, 64), True), ('Sc', None, True)])
 def test_k1_chain_equals_the_three_launches(O, HF, dev, name, size, with_ir):
     """hs_k1_chain_fwd (levels 0-2 as ONE launch with in-launch neighbour hand-offs, csrc/hs_k1_chain.hip) against the three
     hs_patch_conv_fwd launches it replaces, through the whole decoder: full HyperSeg-M (512 cells: the whole grid resident) and CamVid-S
