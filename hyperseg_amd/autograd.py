@@ -262,18 +262,26 @@ class BNActTrain(torch.autograd.Function):
         return dx, dg, db, None, None, None, None, None, None
 
 
+def _bn_hip_act(bn, act_layer, x):
+    """Activation code (0 none, 1 ReLU, 2 ReLU6) when ``act_layer(bn(x))`` can go through the fused training kernels -- a plain
+    BatchNorm2d in training mode with fp32 parameters on x's device, batch statistics over more than one element -- else -1."""
+    import torch.nn as nn
+    act = 0 if act_layer is None else 1 if type(act_layer) is nn.ReLU else 2 if type(act_layer) is nn.ReLU6 else -1
+    ok = (USE_HIP_BN and type(bn) is nn.BatchNorm2d and bn.training and bn.track_running_stats and bn.momentum is not None and act >= 0
+          and x.is_cuda and x.dtype in DTYPE_CODES and x.dim() == 4 and bn.affine and bn.weight.dtype == torch.float32
+          and x.shape[0] * x.shape[2] * x.shape[3] > 1 and x.shape[0] * x.shape[2] * x.shape[3] < 2 ** 31
+          # raw data_ptrs of these go to the kernel: they must live on x's device (stock BN raises for a mismatch, and so does
+          # the stock route)
+          and bn.weight.device == x.device and bn.bias.device == x.device
+          and bn.running_mean.device == x.device and bn.running_var.device == x.device)
+    return act if ok else -1
+
+
 def bn_act(bn, act_layer, x):
     """``act_layer(bn(x))`` -- through the fused training kernels when ``bn`` is a plain BatchNorm2d in training mode with fp32
     parameters on the GPU and the activation is None / ReLU / ReLU6; the stock modules otherwise (eval mode, other layers, CPU)."""
-    import torch.nn as nn
-    act = 0 if act_layer is None else 1 if type(act_layer) is nn.ReLU else 2 if type(act_layer) is nn.ReLU6 else -1
-    if (USE_HIP_BN and type(bn) is nn.BatchNorm2d and bn.training and bn.track_running_stats and bn.momentum is not None and act >= 0
-            and x.is_cuda and x.dtype in DTYPE_CODES and x.dim() == 4 and bn.affine and bn.weight.dtype == torch.float32
-            and x.shape[0] * x.shape[2] * x.shape[3] > 1 and x.shape[0] * x.shape[2] * x.shape[3] < 2 ** 31
-            # raw data_ptrs of these go to the kernel: they must live on x's device (stock BN raises for a mismatch, and so does
-            # the stock route below)
-            and bn.weight.device == x.device and bn.bias.device == x.device
-            and bn.running_mean.device == x.device and bn.running_var.device == x.device):
+    act = _bn_hip_act(bn, act_layer, x)
+    if act >= 0:
         nbt = bn.num_batches_tracked
         in_kernel = nbt is not None and nbt.device == x.device and nbt.dtype == torch.int64
         # the step counter is incremented by the kernel itself (one launch less per BatchNorm and step)
@@ -286,6 +294,91 @@ def bn_act(bn, act_layer, x):
         HF.bump_weights_epoch()               # stock BN's running-statistics update does not bump their versions either
     y = bn(x)
     return y if act_layer is None else act_layer(y)
+
+
+class DwTilesBN(torch.autograd.Function):
+    """BatchNorm (training mode) + activation + the valid depthwise 3 x 3 of every halo tile WITHOUT the normalised copy of the tiles
+    (round 5; hyperseg_v1_0.py:346-360): forward = hs_bn_train_stats_fwd on the raw tiles, then hs_dw_tiles_bn_fwd (normalise on load,
+    statistics finalised and the running estimates updated by the same launch) -- two launches where BNActTrain + DwTilesValid took
+    three, and the largest tensor of a config-5 step (the normalised tile image of level 4: 37 MB written and read back) never exists.
+    Backward: the tap gradient from the raw tiles + saved statistics (hs_dw_tiles_bn_bwd_w), the tiles' gradient through the valid
+    depthwise adjoint and then BatchNorm's own adjoint (hs_dw_tiles_bwd_in, hs_bn_act_train_bwd): the same four launches as before.
+    Same arithmetic per value as the two Functions it replaces; bf16 storage skips the intermediate's rounding."""
+
+    @staticmethod
+    def forward(ctx, t, weight, bias, running_mean, running_var, momentum, eps, act, counter, bank, size, grid, patch_major):
+        t = t.contiguous()
+        h, w = size
+        c = t.shape[1]
+        fh, fw = grid
+        b = t.shape[0] // (fh * fw) if patch_major else t.shape[0]
+        px = t.numel() // (t.shape[0] * c)
+        if bank.dtype != torch.float32 or bank.stride(1) != 1:
+            bank = bank.float().contiguous()
+        dev = t.device
+        with _hip.device_scope(dev):
+            y = torch.empty(b, c, h, w, device=dev, dtype=t.dtype)
+            mean, invstd = torch.empty(c, device=dev, dtype=torch.float32), torch.empty(c, device=dev, dtype=torch.float32)
+            ws = torch.empty(int(_hip.lib.hs_bn_train_workspace(c)), device=dev, dtype=torch.uint8)
+            code = DTYPE_CODES[t.dtype]
+            _hip.check(_hip.lib.hs_bn_train_stats_fwd(code, t.data_ptr(), t.shape[0], c, px, ws.data_ptr(), _hip.stream_ptr()), 'hs_bn_train_stats_fwd')
+            st = _hip.lib.hs_dw_tiles_bn_fwd(code, t.data_ptr(), ws.data_ptr(), weight.data_ptr(), bias.data_ptr(),
+                                             running_mean.data_ptr() if running_mean is not None else None,
+                                             running_var.data_ptr() if running_var is not None else None, float(momentum), float(eps), int(act),
+                                             mean.data_ptr(), invstd.data_ptr(), counter.data_ptr() if counter is not None else None,
+                                             bank.data_ptr(), bank.stride(0), b, c, h, w, fh, fw, y.data_ptr(), int(patch_major), _hip.stream_ptr())
+            _hip.check(st, 'hs_dw_tiles_bn_fwd')
+        ctx.save_for_backward(t, weight, bias, mean, invstd, bank)
+        ctx.meta = (b, c, h, w, (fh, fw), float(eps), int(act), bool(patch_major), px)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        t, weight, bias, mean, invstd, bank = ctx.saved_tensors
+        b, c, h, w, (fh, fw), eps, act, pm, px = ctx.meta
+        dy = dy.contiguous().to(t.dtype)
+        dev = t.device
+        code = DTYPE_CODES[t.dtype]
+        dt = dbank = dg = db = None
+        with _hip.device_scope(dev):
+            stream = _hip.stream_ptr()
+            if ctx.needs_input_grad[9]:
+                alloc = torch.empty if bank.shape[1] == 9 * c else torch.zeros
+                dbank = alloc(bank.shape[0], bank.shape[1], device=dev, dtype=torch.float32)
+                st = _hip.lib.hs_dw_tiles_bn_bwd_w(code, t.data_ptr(), dy.data_ptr(), weight.data_ptr(), bias.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                                   act, b, c, h, w, fh, fw, dbank.data_ptr(), dbank.stride(0), int(pm), stream)
+                _hip.check(st, 'hs_dw_tiles_bn_bwd_w')
+            if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+                da = torch.empty_like(t)                                         # gradient of the (never materialised) normalised tiles
+                st = _hip.lib.hs_dw_tiles_bwd_in(code, dy.data_ptr(), bank.data_ptr(), bank.stride(0), b, c, h, w, fh, fw, da.data_ptr(), int(pm), stream)
+                _hip.check(st, 'hs_dw_tiles_bwd_in')
+                dt = torch.empty_like(t)
+                dg = torch.empty(c, device=dev, dtype=torch.float32)
+                db = torch.empty(c, device=dev, dtype=torch.float32)
+                ws = torch.empty(int(_hip.lib.hs_bn_train_workspace(c)), device=dev, dtype=torch.uint8)
+                st = _hip.lib.hs_bn_act_train_bwd(code, t.data_ptr(), da.data_ptr(), t.shape[0], c, px, weight.data_ptr(), bias.data_ptr(),
+                                                  mean.data_ptr(), invstd.data_ptr(), eps, act, ws.data_ptr(), dt.data_ptr(), dg.data_ptr(), db.data_ptr(), stream)
+                _hip.check(st, 'hs_bn_act_train_bwd')
+        return dt, dg, db, None, None, None, None, None, None, dbank, None, None, None
+
+
+def dw_tiles_bn(bn, act_layer, t, bank, size, grid, patch_major):
+    """``DwTilesValid(bn_act(bn, act_layer, t), bank)`` as DwTilesBN where the fused training BatchNorm applies (and USE_DW_BN_FUSED),
+    the two Functions otherwise."""
+    act = _bn_hip_act(bn, act_layer, t) if USE_DW_BN_FUSED and bn.weight is not None else -1
+    if act < 0:
+        return DwTilesValid.apply(bn_act(bn, act_layer, t), bank, size, grid, patch_major)
+    nbt = bn.num_batches_tracked
+    in_kernel = nbt is not None and nbt.device == t.device and nbt.dtype == torch.int64
+    y = DwTilesBN.apply(t, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, act, nbt if in_kernel else None,
+                        bank, tuple(size), tuple(grid), bool(patch_major))
+    if nbt is not None and not in_kernel:
+        nbt.add_(1)
+    HF.bump_weights_epoch()
+    return y
+
+
+USE_DW_BN_FUSED = True  # tests switch it off to compare with BNActTrain + DwTilesValid
 
 
 USE_HIP_BN = True       # tests switch it off to compare with the stock modules

@@ -77,6 +77,11 @@ template <> struct Store<bf16_t> {
     }
 };
 
+// Slices a training-mode BatchNorm channel is cut into: partial[(c * BN_CHUNKS + chunk) * 2 + {0, 1}] = {sum, sum of squares} of
+// (x - shift) over the slice, shift = the channel's first element (hs_train_aux.hip: bn_stats_kernel; consumers that normalise on load
+// re-derive mean / invstd from the 32 pairs: hs_patch_conv_bwd.hip dw_tiles_*).
+constexpr int BN_CHUNKS = 32;
+
 struct StagePos {
     int y, x;             // -1 in either => zero padding
     Tap ty, tx;           // only valid for prev_mode == HS_PREV_BILINEAR

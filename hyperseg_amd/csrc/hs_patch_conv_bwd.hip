@@ -737,6 +737,21 @@ struct DwtArgs {
     float inv_ph, inv_pw, inv_ph2, inv_pw2, inv_c;
     int pm;                            // layout of the tiles: 0 = image of tiles (B, C, fh (ph+2), fw (pw+2)), 1 = patch-major (B fh fw, C, ph+2, pw+2)
 };
+// BatchNorm (training mode) + activation applied to the TILES ON LOAD (round 5): the block's first 1x1 layer writes its raw output, a
+// statistics pass leaves {sum, sum of squares} per channel and slice, and this layer normalises what it reads -- the normalised copy
+// (37 MB at config 5's level 4: bn_apply's read + write were the two largest passes of the step) is never written.  Same arithmetic
+// as hs_train_aux.hip's bn_apply_kernel: y = act(fma(x, gamma invstd, beta - mean gamma invstd)).
+struct DwtBn {
+    const float* __restrict__ partial;        // forward: [C][BN_CHUNKS][2] from hs_bn_train_stats_fwd; null: mean / invstd are given
+    const float* __restrict__ gamma; const float* __restrict__ beta;
+    float* mean; float* invstd;               // forward: written (channel c by the workgroup of plane (0, c), block (0, 0)); backward: read
+    float* running_mean; float* running_var; long long* counter;
+    float eps, momentum, n;                   // n = elements per channel of the tile tensor
+    long shift_stride;                        // elements between the first elements of consecutive channels (the statistics' shift)
+    int act;
+};
+__device__ __forceinline__ float dwt_act(float z, int act) { return act == HS_ACT_RELU ? fmaxf(z, 0.f) : (act == HS_ACT_RELU6 ? fminf(fmaxf(z, 0.f), 6.f) : z); }
+
 // origin of tile (i, j), channel c of frame b, and the distance between its rows
 __device__ __forceinline__ size_t dwt_tile(const DwtArgs& a, int b, int c, int i, int j, int& row_stride) {
     if (a.pm) {
@@ -747,13 +762,31 @@ __device__ __forceinline__ size_t dwt_tile(const DwtArgs& a, int b, int c, int i
     return (((size_t)b * a.C + c) * (size_t)(a.fh * (a.ph + 2)) + (size_t)i * (a.ph + 2)) * row_stride + (size_t)j * (a.pw + 2);
 }
 
-template <typename T>
+template <typename T, bool BN>
 __global__ __launch_bounds__(256)
-void dw_tiles_fwd_kernel(DwtArgs a, const T* __restrict__ t, T* __restrict__ y) {
+void dw_tiles_fwd_kernel(DwtArgs a, DwtBn n, const T* __restrict__ t, T* __restrict__ y) {
     const int x0 = 2 * (blockIdx.x * 64 + (threadIdx.x & 63)), yy = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int plane_id = blockIdx.z;
-    if (x0 >= a.W || yy >= a.H) return;
     const int b = div_by_inv(plane_id, a.inv_c), c = plane_id - b * a.C;
+    float g = 1.0f, bb = 0.0f;
+    if constexpr (BN) {
+        // mean / invstd of channel c from the 32 slice sums (uniform over the workgroup: scalar loads), exactly as bn_apply_kernel forms them
+        const float shift = Store<T>::ld(t, (size_t)c * n.shift_stride);
+        float s = 0.f, q = 0.f;
+        for (int i = 0; i < BN_CHUNKS; ++i) { s += n.partial[((size_t)c * BN_CHUNKS + i) * 2]; q += n.partial[((size_t)c * BN_CHUNKS + i) * 2 + 1]; }
+        const float md = s / n.n, var = fmaxf(q / n.n - md * md, 0.f), mean = md + shift, invstd = rsqrtf(var + n.eps);
+        g = n.gamma ? n.gamma[c] * invstd : invstd;
+        bb = (n.beta ? n.beta[c] : 0.f) - mean * g;
+        if (b == 0 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {          // one writer per channel
+            n.mean[c] = mean; n.invstd[c] = invstd;
+            if (n.running_mean) {
+                n.running_mean[c] = (1.f - n.momentum) * n.running_mean[c] + n.momentum * mean;
+                n.running_var[c] = (1.f - n.momentum) * n.running_var[c] + n.momentum * (n.n > 1.f ? var * n.n / (n.n - 1.f) : var);
+            }
+            if (n.counter && c == 0) *n.counter += 1;
+        }
+    }
+    if (x0 >= a.W || yy >= a.H) return;
     const int i = div_by_inv(yy, a.inv_ph), u = yy - i * a.ph, j = div_by_inv(x0, a.inv_pw), v = x0 - j * a.pw;
     int TW;
     const T* __restrict__ tp = t + dwt_tile(a, b, c, i, j, TW) + (size_t)u * TW + v;
@@ -766,6 +799,12 @@ void dw_tiles_fwd_kernel(DwtArgs a, const T* __restrict__ t, T* __restrict__ y) 
     }
 #pragma unroll
     for (int q = 0; q < 9; ++q) kv[q] = kp[q];
+    if constexpr (BN) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s[r][q] = dwt_act(fmaf(s[r][q], g, bb), n.act);
+    }
     float acc0 = 0.0f, acc1 = 0.0f;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
@@ -820,13 +859,19 @@ void dw_tiles_bwd_in_kernel(DwtArgs a, const T* __restrict__ dy, T* __restrict__
 }
 
 // dK[patch][c][ky][kx] = sum over the patch's outputs (u, v) of dy[u][v] t[u + ky][v + kx]: one wave per (patch, channel), a lane owns output pairs
-template <typename T>
+template <typename T, bool BN>
 __global__ __launch_bounds__(256)
-void dw_tiles_bwd_w_kernel(DwtArgs a, const T* __restrict__ t, const T* __restrict__ dy) {
+void dw_tiles_bwd_w_kernel(DwtArgs a, DwtBn n, const T* __restrict__ t, const T* __restrict__ dy) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int patch = blockIdx.x, c = blockIdx.y * 4 + wave;
     if (c >= a.C) return;
     const int j = patch % a.fw, i = (patch / a.fw) % a.fh, b = patch / (a.fw * a.fh);
+    float g = 1.0f, bb = 0.0f;
+    if constexpr (BN) {                                              // the saved statistics: the tiles are normalised on load, as in the forward
+        const float mean = n.mean[c], invstd = n.invstd[c];
+        g = n.gamma ? n.gamma[c] * invstd : invstd;
+        bb = (n.beta ? n.beta[c] : 0.f) - mean * g;
+    }
     int TW;
     const T* __restrict__ tp = t + dwt_tile(a, b, c, i, j, TW);
     const T* __restrict__ gp = dy + (((size_t)b * a.C + c) * a.H + (size_t)i * a.ph) * a.W + (size_t)j * a.pw;
@@ -841,6 +886,12 @@ void dw_tiles_bwd_w_kernel(DwtArgs a, const T* __restrict__ t, const T* __restri
         for (int r = 0; r < 3; ++r) {
             Pair<T>::ld(tp, (size_t)(u + r) * TW + v, s[r][0], s[r][1]);
             Pair<T>::ld(tp, (size_t)(u + r) * TW + v + 2, s[r][2], s[r][3]);
+        }
+        if constexpr (BN) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s[r][q] = dwt_act(fmaf(s[r][q], g, bb), n.act);
         }
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
@@ -1103,8 +1154,37 @@ extern "C" int hs_dw_tiles_fwd(int32_t dtype, const void* tiled, const float* ba
     if (!bank || (((size_t)bank) & 3)) return HS_ERR_BAD_ARG;
     a.bank = bank;
     const dim3 grid((W / 2 + 63) / 64, (H + 3) / 4, batch * channels);
-    if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL(dw_tiles_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a, (const float*)tiled, (float*)y);
-    else hipLaunchKernelGGL(dw_tiles_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, a, (const bf16_t*)tiled, (bf16_t*)y);
+    if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_fwd_kernel<float, false>), grid, dim3(256), 0, (hipStream_t)stream, a, DwtBn{}, (const float*)tiled, (float*)y);
+    else hipLaunchKernelGGL((dw_tiles_fwd_kernel<bf16_t, false>), grid, dim3(256), 0, (hipStream_t)stream, a, DwtBn{}, (const bf16_t*)tiled, (bf16_t*)y);
+    return launch_status();
+}
+
+// elements per channel of the tile tensor and the distance between the first elements of consecutive channels, in either layout
+static void dwt_bn_geometry(const DwtArgs& a, DwtBn& n) {
+    const long tile = (long)(a.ph + 2) * (a.pw + 2);
+    n.n = (float)((long)a.B * a.fh * a.fw * tile);
+    n.shift_stride = a.pm ? tile : (long)a.fh * a.fw * tile;
+}
+
+// hs_dw_tiles_fwd with training-mode BatchNorm + activation applied to the tiles ON LOAD: `bn_partial` = hs_bn_train_stats_fwd's
+// workspace for the tile tensor seen as (B', C, pixels) -- patch-major: B' = batch fh fw frames of (ph + 2)(pw + 2) pixels; image of
+// tiles: B' = batch frames of fh (ph + 2) x fw (pw + 2) pixels.  Writes save_mean / save_invstd, updates the running estimates and the
+// step counter exactly as hs_bn_act_train_fwd does.
+extern "C" int hs_dw_tiles_bn_fwd(int32_t dtype, const void* tiled, const float* bn_partial, const float* gamma, const float* beta,
+                                  float* running_mean, float* running_var, float momentum, float eps, int32_t act, float* save_mean,
+                                  float* save_invstd, int64_t* num_batches_tracked, const float* bank, int64_t ld, int32_t batch,
+                                  int32_t channels, int32_t H, int32_t W, int32_t fh, int32_t fw, void* y, int32_t patch_major, void* stream) {
+    DwtArgs a;
+    const int st = dwt_args(a, dtype, tiled, y, (long)ld, batch, channels, H, W, fh, fw, patch_major);
+    if (st != HS_OK) return st;
+    if (!bank || (((size_t)bank) & 3) || !bn_partial || !save_mean || !save_invstd || ((running_mean != nullptr) != (running_var != nullptr)) ||
+        act < HS_ACT_NONE || act > HS_ACT_RELU6 || eps < 0.f) return HS_ERR_BAD_ARG;
+    a.bank = bank;
+    DwtBn n{bn_partial, gamma, beta, save_mean, save_invstd, running_mean, running_var, (long long*)num_batches_tracked, eps, momentum, 0.f, 0, act};
+    dwt_bn_geometry(a, n);
+    const dim3 grid((W / 2 + 63) / 64, (H + 3) / 4, batch * channels);
+    if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_fwd_kernel<float, true>), grid, dim3(256), 0, (hipStream_t)stream, a, n, (const float*)tiled, (float*)y);
+    else hipLaunchKernelGGL((dw_tiles_fwd_kernel<bf16_t, true>), grid, dim3(256), 0, (hipStream_t)stream, a, n, (const bf16_t*)tiled, (bf16_t*)y);
     return launch_status();
 }
 
@@ -1129,7 +1209,23 @@ extern "C" int hs_dw_tiles_bwd_w(int32_t dtype, const void* tiled, const void* d
     if (!dbank) return HS_ERR_BAD_ARG;
     a.dbank = dbank;
     const dim3 grid((unsigned)(batch * fh * fw), (channels + 3) / 4);
-    if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL(dw_tiles_bwd_w_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a, (const float*)tiled, (const float*)dy);
-    else hipLaunchKernelGGL(dw_tiles_bwd_w_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, a, (const bf16_t*)tiled, (const bf16_t*)dy);
+    if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<float, false>), grid, dim3(256), 0, (hipStream_t)stream, a, DwtBn{}, (const float*)tiled, (const float*)dy);
+    else hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<bf16_t, false>), grid, dim3(256), 0, (hipStream_t)stream, a, DwtBn{}, (const bf16_t*)tiled, (const bf16_t*)dy);
+    return launch_status();
+}
+
+// hs_dw_tiles_bwd_w on the RAW tiles of hs_dw_tiles_bn_fwd: the same on-load normalisation from the saved statistics
+extern "C" int hs_dw_tiles_bn_bwd_w(int32_t dtype, const void* tiled, const void* dy, const float* gamma, const float* beta, const float* save_mean,
+                                    const float* save_invstd, int32_t act, int32_t batch, int32_t channels, int32_t H, int32_t W, int32_t fh,
+                                    int32_t fw, float* dbank, int64_t ld, int32_t patch_major, void* stream) {
+    DwtArgs a;
+    const int st = dwt_args(a, dtype, tiled, dy, (long)ld, batch, channels, H, W, fh, fw, patch_major);
+    if (st != HS_OK) return st;
+    if (!dbank || !save_mean || !save_invstd || act < HS_ACT_NONE || act > HS_ACT_RELU6) return HS_ERR_BAD_ARG;
+    a.dbank = dbank;
+    DwtBn n{nullptr, gamma, beta, const_cast<float*>(save_mean), const_cast<float*>(save_invstd), nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0, act};
+    const dim3 grid((unsigned)(batch * fh * fw), (channels + 3) / 4);
+    if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<float, true>), grid, dim3(256), 0, (hipStream_t)stream, a, n, (const float*)tiled, (const float*)dy);
+    else hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<bf16_t, true>), grid, dim3(256), 0, (hipStream_t)stream, a, n, (const bf16_t*)tiled, (const bf16_t*)dy);
     return launch_status();
 }

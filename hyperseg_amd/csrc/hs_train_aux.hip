@@ -267,7 +267,6 @@ void bm_bwd_kernel(const float* __restrict__ v, int n, const float* __restrict__
 // taken around the channel's first element (a shift: E[(x - s)^2] - E[x - s]^2 does not cancel when |mean| >> std).
 // MIOpen's spatial kernels + a clamp kernel (+ hardtanh_backward) were 0.53 + 0.1 ms of a 2.5 ms config-5 step.
 // ---------------------------------------------------------------------------------------------------------------------------------
-constexpr int BN_CHUNKS = 32;
 
 struct BnArgs { int B, C, HW, act; float eps, momentum; };
 
@@ -709,6 +708,20 @@ extern "C" int hs_bn_act_train_fwd(int32_t dtype, const void* x, int32_t batch, 
         hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, grid, dim3(256), 0, s, a, (const bf16_t*)x, (const float*)workspace, gamma, beta,
                            running_mean, running_var, save_mean, save_invstd, (bf16_t*)y, (long long*)num_batches_tracked);
     } else return HS_ERR_BAD_ARG;
+    return launch_status();
+}
+
+// The statistics pass alone (partial sums per channel and slice into `workspace`): for consumers that normalise on load
+// (hs_dw_tiles_bn_fwd) instead of reading a normalised copy
+extern "C" int hs_bn_train_stats_fwd(int32_t dtype, const void* x, int32_t batch, int32_t channels, int64_t pixels, void* workspace, void* stream) {
+    BnArgs a;
+    const int st = bn_args(a, batch, channels, pixels, HS_ACT_NONE, 0.f, 0.f);
+    if (st != HS_OK) return st;
+    if (!x || !workspace) return HS_ERR_BAD_ARG;
+    const dim3 grid(channels, BN_CHUNKS);
+    if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL(bn_stats_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a, (const float*)x, (float*)workspace);
+    else if (dtype == HS_DTYPE_BF16) hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, a, (const bf16_t*)x, (float*)workspace);
+    else return HS_ERR_BAD_ARG;
     return launch_status();
 }
 

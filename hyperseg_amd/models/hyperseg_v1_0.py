@@ -314,18 +314,20 @@ class HyperPatchInvertedResidual(EpochOnModeSwitch, nn.Module, _SignalToWeights)
             tiled = tiles.permute(0, 1, 2, 4, 3, 5).reshape(b, c, fh * (ph + 2), fw * (pw + 2))
         bank1, bank2, bank3 = HA.BankSlices.apply(bank, r1, r2, r3)             # one concatenation in the backward instead of 3 x (zeros + copy) + 2 adds
         y = HA.patch_conv_apply(tiled, bank1, (1, 1) if pm else grid, self.hidden_dim, 1, 0, 'zeros', 1)
-        y = HA.bn_act(self.bn1, self.act_layer, y)
         if pm:
-            y = HA.DwTilesValid.apply(y, bank2, (h, wd), grid, True)
+            # BatchNorm1 + ReLU6 applied to the raw tiles ON LOAD by the depthwise layer (autograd.DwTilesBN): no normalised copy
+            y = HA.dw_tiles_bn(self.bn1, self.act_layer, y, bank2, (h, wd), grid, True)
         elif own and HA.dw_tiles_supported(y, (h, wd), grid):
             # the valid depthwise 3x3 of every tile, straight to the (B, hidden, H, W) map: one launch per direction and operand
-            y = HA.DwTilesValid.apply(y, bank2, (h, wd), grid)
-        elif own and HA.tiles_supported(y):
-            y = HA.patch_conv_apply(y, bank2, grid, self.hidden_dim, 3, 1, 'zeros', self.hidden_dim)
-            y = HA.TileInterior.apply(y, (h, wd), grid)
+            y = HA.dw_tiles_bn(self.bn1, self.act_layer, y, bank2, (h, wd), grid, False)
         else:
-            y = HA.patch_conv_apply(y, bank2, grid, self.hidden_dim, 3, 1, 'zeros', self.hidden_dim)
-            y = y.reshape(b, self.hidden_dim, fh, ph + 2, fw, pw + 2)[:, :, :, 1:-1, :, 1:-1].reshape(b, self.hidden_dim, h, wd)
+            y = HA.bn_act(self.bn1, self.act_layer, y)
+            if own and HA.tiles_supported(y):
+                y = HA.patch_conv_apply(y, bank2, grid, self.hidden_dim, 3, 1, 'zeros', self.hidden_dim)
+                y = HA.TileInterior.apply(y, (h, wd), grid)
+            else:
+                y = HA.patch_conv_apply(y, bank2, grid, self.hidden_dim, 3, 1, 'zeros', self.hidden_dim)
+                y = y.reshape(b, self.hidden_dim, fh, ph + 2, fw, pw + 2)[:, :, :, 1:-1, :, 1:-1].reshape(b, self.hidden_dim, h, wd)
         y = HA.bn_act(self.bn2, self.act_layer, y)
         y = HA.patch_conv_apply(y, bank3, grid, self.out_nc, 1, 0, 'zeros', 1)
         y = HA.bn_act(self.bn3, None, y)

@@ -498,6 +498,22 @@ int hs_upsample_bilinear_typed_bwd(int32_t dtype, const void* dy, int64_t dy_bat
  * workspace: hs_bn_train_workspace(C) bytes, scratch; num_batches_tracked (optional): the module's int64 step counter, incremented by one.
  * Replaces BatchNorm2d + ReLU6 of hyperseg_v1_0.py:349-376 in train mode. */
 int64_t hs_bn_train_workspace(int32_t channels);
+/* The statistics pass of hs_bn_act_train_fwd alone: {sum, sum of squares} around the channel's first element, per channel and slice,
+ * into `workspace` (hs_bn_train_workspace(C) bytes) -- for consumers that normalise on load instead of reading a normalised copy. */
+int hs_bn_train_stats_fwd(int32_t dtype, const void* x, int32_t batch, int32_t channels, int64_t pixels, void* workspace, void* stream);
+/* The train-mode inverted residual's BatchNorm1 + ReLU6 + depthwise 3 x 3 (hyperseg_v1_0.py:346-360) without the normalised copy of the
+ * halo tiles: hs_dw_tiles_fwd / _bwd_w reading the RAW output of the first 1 x 1 layer and applying act(gamma invstd (x - mean) + beta)
+ * on load.  _fwd: `bn_partial` = hs_bn_train_stats_fwd's workspace for the tile tensor viewed as (B', C, pixels) (patch-major: B' =
+ * batch fh fw, pixels = (ph + 2)(pw + 2)); writes save_mean / save_invstd (C floats each), updates running_mean / running_var
+ * (optional) and num_batches_tracked (optional) exactly as hs_bn_act_train_fwd.  _bwd_w: the tap gradient from the raw tiles and the
+ * saved statistics.  The BatchNorm's own adjoint stays hs_bn_act_train_bwd on (raw tiles, hs_dw_tiles_bwd_in's result). */
+int hs_dw_tiles_bn_fwd(int32_t dtype, const void* tiled, const float* bn_partial, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float momentum, float eps, int32_t act, float* save_mean,
+                       float* save_invstd, int64_t* num_batches_tracked, const float* bank, int64_t ld, int32_t batch,
+                       int32_t channels, int32_t H, int32_t W, int32_t fh, int32_t fw, void* y, int32_t patch_major, void* stream);
+int hs_dw_tiles_bn_bwd_w(int32_t dtype, const void* tiled, const void* dy, const float* gamma, const float* beta, const float* save_mean,
+                         const float* save_invstd, int32_t act, int32_t batch, int32_t channels, int32_t H, int32_t W, int32_t fh,
+                         int32_t fw, float* dbank, int64_t ld, int32_t patch_major, void* stream);
 int hs_bn_act_train_fwd(int32_t dtype, const void* x, int32_t batch, int32_t channels, int64_t pixels, const float* gamma,
                         const float* beta, float* running_mean, float* running_var, float momentum, float eps, int32_t act,
                         float* save_mean, float* save_invstd, void* workspace, void* y, int64_t* num_batches_tracked, void* stream);

@@ -878,6 +878,7 @@ def _emulated_bf16(monkeypatch):
     wrap(HA.HaloTiles)
     wrap(HA.TileInterior)
     wrap(HA.DwTilesValid)                                 # (t, bank, ...): y bf16; dt bf16, dbank fp32
+    wrap(HA.DwTilesBN)                                    # (raw tiles, weight, bias, ..., bank, ...): y bf16; d tiles bf16, the rest fp32
     wrap(HA.BNActTrain)                                   # (x, weight, bias, ...): y bf16; dx bf16, dgamma / dbeta fp32
     wrap(HA.PixelCrossEntropy, fwd_low=())                # loss fp32; d logits bf16
     wrap(HA.UpsampleBilinear)
@@ -1061,3 +1062,51 @@ def test_general_meta_conv_on_a_column_range_of_a_wider_weight_tensor(dev):
     (m(xc, wc) * r).sum().backward()
     assert torch.equal(xg.grad, xc.grad) and torch.equal(wg.grad[:, 7:7 + m.hyper_params], wc.grad)
     assert float(wg.grad[:, :7].abs().max()) == 0.0 and float(wg.grad[:, 7 + m.hyper_params:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('patch_major', [True, False])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_dw_tiles_bn_on_load_equals_batchnorm_then_depthwise(dev, patch_major, dtype):
+    """autograd.DwTilesBN (round 5: BatchNorm1 + ReLU6 applied to the raw halo tiles ON LOAD by the depthwise layer, statistics finalised
+    by the same launch) against the two Functions it replaces (BNActTrain, then DwTilesValid): fp32 -- the same arithmetic per value, so
+    outputs, all four gradients, saved / running statistics and the step counter are BIT-EQUAL (channels large enough for the two-launch
+    BatchNorm on both sides); bf16 storage -- the fused form skips the rounding of the normalised copy, so it is held to the fp32 result
+    at bf16's resolution instead."""
+    import copy
+    import torch.nn as nn
+    from hyperseg_amd import autograd as HA
+    b, c, fh, fw, ph, pw = 2, 8, 3, 3, 32, 32
+    h, w = fh * ph, fw * pw
+    shape = (b * fh * fw, c, ph + 2, pw + 2) if patch_major else (b, c, fh * (ph + 2), fw * (pw + 2))
+    t0 = (torch.randn(shape, generator=G(3101)) * 1.7 + 0.4).to(dev)
+    bank0 = torch.randn(b * fh * fw, 9 * c + 3, generator=G(3102)).to(dev)[:, :9 * c]          # a column range of a wider bank (row stride 9c + 3)
+    r = torch.randn(b, c, h, w, generator=G(3103)).to(dev)
+    bn0 = nn.BatchNorm2d(c, momentum=0.1).to(dev).train()
+    with torch.no_grad():
+        bn0.weight.copy_(torch.rand(c, generator=G(3104)) + 0.5)
+        bn0.bias.copy_(torch.randn(c, generator=G(3105)) * 0.3)
+
+    def run(fused, dt):
+        prev = HA.USE_DW_BN_FUSED
+        HA.USE_DW_BN_FUSED = fused
+        try:
+            bn = copy.deepcopy(bn0)
+            t = t0.to(dt).clone().requires_grad_(True)
+            bank = bank0.clone().requires_grad_(True)
+            y = HA.dw_tiles_bn(bn, nn.ReLU6(), t, bank, (h, w), (fh, fw), patch_major)
+            (y.float() * r).sum().backward()
+            return dict(y=y.detach().float(), dt=t.grad.float(), dbank=bank.grad, dg=bn.weight.grad, db=bn.bias.grad, rm=bn.running_mean.clone(),
+                        rv=bn.running_var.clone(), n=int(bn.num_batches_tracked))
+        finally:
+            HA.USE_DW_BN_FUSED = prev
+    two, one = run(False, dtype), run(True, dtype)
+    assert one['n'] == two['n'] == 1
+    if dtype == torch.float32:
+        for k in ('y', 'dt', 'dbank', 'dg', 'db', 'rm', 'rv'):
+            assert torch.equal(one[k], two[k]), k
+    else:
+        ref = run(False, torch.float32)
+        for k in ('y', 'dt', 'dbank', 'dg', 'db'):
+            e_one, e_two = rel_l2(one[k].cpu(), ref[k].cpu()), rel_l2(two[k].cpu(), ref[k].cpu())
+            assert e_one < 2e-2 and e_one < 2.0 * e_two + 1e-3, (k, e_one, e_two)          # no worse than the route that rounds the copy
+        assert torch.allclose(one['rm'], two['rm'], rtol=1e-5, atol=1e-6) and torch.allclose(one['rv'], two['rv'], rtol=1e-5, atol=1e-6)
