@@ -212,9 +212,26 @@ def instrumented_decoder(model, x, n_inst):
             return r
         return f
     feats = model.backbone(x)
+    # the chained levels (functional.K1Chain.run -> hs_k1_chain_fwd / hs_decoder_chain_fwd) are one launch of three / four levels
+    chain_run = HF.K1Chain.run
+
+    def chain_wrap(self, *a, **k):
+        name = 'decoder_chain' if k.get('ir') is not None else 'k1_chain'
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = chain_run(self, *a, **k)
+        for _ in range(reps[0] - 1):
+            chain_run(self, *a, **k)
+        e1.record()
+        if r is not None:                         # a refused shape launched nothing: the per-level launches follow and are recorded
+            if reps[0] > 1:
+                recs.setdefault((counter[0], name), []).append((e0, e1))
+            counter[0] += 1
+        return r
     try:
         for n in names:
             setattr(HF, n, wrap(n))
+        HF.K1Chain.run = chain_wrap
         dec_evs = []
         for it in range(2 * n_inst):
             reps[0] = 1 if it < n_inst else EVENT_REPS          # first half: the decoder's own duration; second half: per-launch averages
@@ -234,6 +251,7 @@ def instrumented_decoder(model, x, n_inst):
     finally:
         for n in names:
             setattr(HF, n, orig[n])
+        HF.K1Chain.run = chain_run
     cal = []
     for _ in range(50):                      # an empty event pair on a busy stream is not 0: calibrate and report it
         torch.cuda._sleep(200_000)
@@ -256,12 +274,23 @@ def instrumented_decoder(model, x, n_inst):
 
 def roofline_of(launches, levels, h, w, batch, traffic_dir):
     """The dominant decoder launch against the roof that binds it."""
-    conv = [l for l in launches if l['kernel'] in ('hs_patch_conv_fwd', 'hs_patch_ir_fwd', 'hs_patch_ir_v0_fwd') and l['in_decoder']]
+    spans = {'hs_patch_conv_fwd': 1, 'hs_patch_ir_fwd': 1, 'hs_patch_ir_v0_fwd': 1, 'hs_k1_chain_fwd': 3, 'hs_decoder_chain_fwd': 4}
+    conv = [l for l in launches if l['kernel'] in spans and l['in_decoder']]
     per = {}
-    # one launch per level when every level is fused (v1_0 / unify / fused v0_1); otherwise no per-level attribution
-    if len(conv) == len(levels):
-        for l, lv in zip(conv, levels):
-            per[l['idx']] = lv
+    # every level fused into a launch of its own or into the chain launch (levels 0-2 / 0-3): attribute levels to launches in order;
+    # otherwise (a level split over several launches) no per-level attribution
+    if sum(spans[l['kernel']] for l in conv) == len(levels):
+        at = 0
+        for l in conv:
+            n = spans[l['kernel']]
+            if n == 1:
+                per[l['idx']] = levels[at]
+            else:                                   # the chain: the levels' bytes and multiply-adds together
+                grp = levels[at:at + n]
+                per[l['idx']] = dict(level='-'.join(str(g['level']) for g in grp), cin=grp[0]['cin'], cout=grp[-1]['cout'], hidden=0, route=None,
+                                     macs=sum(g['macs'] for g in grp), in_bytes=sum(g['in_bytes'] for g in grp),
+                                     bank_bytes=sum(g['bank_bytes'] for g in grp), out_bytes=sum(g['out_bytes'] for g in grp))
+            at += n
     dom = max([l for l in launches if l['in_decoder']], key=lambda l: l['avg_us'])
     t_s = dom['avg_us'] * 1e-6
     traffic = pmc_traffic(traffic_dir, dom['kernel'])
