@@ -140,6 +140,7 @@ def test_coscheduled_banks_heterogeneous_launch(HF, O, dev, monkeypatch):
     (HF.CoScheduledBanks).  (1) raw: level 0 of HyperSeg-M carrying the banks of levels 1 + 2 -- output and banks bit-identical
     to the separate launches; odd grid / batch 2 / a k = 3 convolution inside the block (not eligible: the banks are produced
     on exit).  (2) the whole HyperSeg-M decoder with the co-scheduling on and off: bit-identical logits."""
+    monkeypatch.setattr(HF, 'K1_CHAIN', False)          # bit-identity is between two per-level routes (the chained levels sum in another order)
     plan = O.config_plan('M')
     params = O.synth_decoder_params(plan, seed=5)
     x, s = O.synth_decoder_inputs('M', batch=1, seed=5)
