@@ -159,6 +159,16 @@ class TileInterior(torch.autograd.Function):
             return _tile_call('hs_tile_interior_bwd', dtype, dy, b, c, h, w, grid, torch.empty(shape, device=dy.device, dtype=dtype)), None, None
 
 
+def _dw_tiles_input_gradient(t, dy, bank, shape, grid, patch_major):
+    """hs_dw_tiles_bwd_in: the valid depthwise adjoint, a halo-tile image like ``t`` (same layout and storage type)."""
+    b, c, h, w = shape
+    dt = torch.empty_like(t)
+    st = _hip.lib.hs_dw_tiles_bwd_in(DTYPE_CODES[t.dtype], dy.data_ptr(), bank.data_ptr(), bank.stride(0), b, c, h, w, grid[0], grid[1],
+                                     dt.data_ptr(), int(patch_major), _hip.stream_ptr())
+    _hip.check(st, 'hs_dw_tiles_bwd_in')
+    return dt
+
+
 class DwTilesValid(torch.autograd.Function):
     """The middle layer of a train-mode v1_0 inverted residual: a VALID depthwise 3x3 of every halo tile with the patch's own taps
     (hyperseg_v1_0.py:352-360), tiles -> (B, C, H, W), one launch per direction and operand (hs_dw_tiles_fwd / _bwd_in / _bwd_w).
@@ -190,10 +200,7 @@ class DwTilesValid(torch.autograd.Function):
         dt = dbank = None
         with _hip.device_scope(dy.device):
             if ctx.needs_input_grad[0]:
-                dt = torch.empty_like(t)
-                st = _hip.lib.hs_dw_tiles_bwd_in(DTYPE_CODES[dtype], dy.data_ptr(), bank.data_ptr(), bank.stride(0), b, c, h, w, grid[0], grid[1],
-                                                 dt.data_ptr(), int(pm), _hip.stream_ptr())
-                _hip.check(st, 'hs_dw_tiles_bwd_in')
+                dt = _dw_tiles_input_gradient(t, dy, bank, (b, c, h, w), grid, pm)
             if ctx.needs_input_grad[1]:
                 alloc = torch.empty if bank.shape[1] == 9 * c else torch.zeros
                 dbank = alloc(bank.shape[0], bank.shape[1], device=dy.device, dtype=torch.float32)
@@ -349,9 +356,7 @@ class DwTilesBN(torch.autograd.Function):
                                                    act, b, c, h, w, fh, fw, dbank.data_ptr(), dbank.stride(0), int(pm), stream)
                 _hip.check(st, 'hs_dw_tiles_bn_bwd_w')
             if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-                da = torch.empty_like(t)                                         # gradient of the (never materialised) normalised tiles
-                st = _hip.lib.hs_dw_tiles_bwd_in(code, dy.data_ptr(), bank.data_ptr(), bank.stride(0), b, c, h, w, fh, fw, da.data_ptr(), int(pm), stream)
-                _hip.check(st, 'hs_dw_tiles_bwd_in')
+                da = _dw_tiles_input_gradient(t, dy, bank, (b, c, h, w), (fh, fw), pm)   # gradient of the (never materialised) normalised tiles, stored in t's type
                 dt = torch.empty_like(t)
                 dg = torch.empty(c, device=dev, dtype=torch.float32)
                 db = torch.empty(c, device=dev, dtype=torch.float32)

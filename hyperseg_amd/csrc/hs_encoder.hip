@@ -11,6 +11,7 @@
 // separate pad kernel.  Replaces: F.pad + F.conv2d(groups=C) + BatchNorm2d + SiLU of
 // hyperseg/models/backbones/efficientnet.py:59-66, 101-103.
 #include "hs_common.h"
+#include "hs_se_tail.h"
 
 namespace hs {
 
@@ -26,10 +27,11 @@ __global__ __launch_bounds__(256)
 void depthwise_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
                            const float* __restrict__ shift, float* __restrict__ y, int C, int H, int W, int Ho, int Wo,
                            int pad_t, int pad_l, int act, float* __restrict__ pool_partial,
-                           const float* __restrict__ in_scale, const float* __restrict__ in_shift, int nplanes) {
+                           const float* __restrict__ in_scale, const float* __restrict__ in_shift, int nplanes, SeTail se) {
     const int plane = blockIdx.y + blockIdx.z * gridDim.y;       // b*C + c (folded over y/z: more than 65535 planes at bs 32)
     if (plane >= nplanes) return;
     const int c = plane % C;
+    const unsigned se_gen = se.ws ? se_tag(se, plane / C) : 0u;  // hs_se_tail.h: requested here, needed when the partial is published
     // optional prologue: the taps are swish(in_scale[c] * x + in_shift[c]) -- the BatchNorm + swish of the 1x1 expand
     // convolution that produced x, applied on load so that the raw GEMM output needs no elementwise pass of its own
     // (fetched AFTER the taps have been requested in the untiled form: the compiler issues a scalar load where the source
@@ -154,7 +156,7 @@ void depthwise_conv_kernel(const float* __restrict__ x, const float* __restrict_
     }
     }
     // squeeze-excite pooling: deterministic per-workgroup partial sums of the outputs (summed by hs_se_gate_fwd)
-    if (pool_partial) {
+    if (pool_partial || se.ws) {
         __shared__ float wsum[4];
         psum = wave_sum64(psum);
         if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = psum;
@@ -162,8 +164,14 @@ void depthwise_conv_kernel(const float* __restrict__ x, const float* __restrict_
         if (threadIdx.x == 0) {
             float t = 0.0f;
             for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += wsum[i];
-            pool_partial[(size_t)plane * gridDim.x + blockIdx.x] = t;
+            if (se.ws) se_publish(se.ws, se_ws_pg(se) + (size_t)plane * gridDim.x + blockIdx.x, t, se_gen);
+            else pool_partial[(size_t)plane * gridDim.x + blockIdx.x] = t;
         }
+    }
+    // the squeeze-excite gate by the last workgroups of the launch (hs_se_tail.h): the same partial sums, summed in the same order
+    if (se.ws) {
+        __shared__ float se_lds[SE_LDS_FLOATS];
+        se_tail_run(se, plane / C, (long)c * gridDim.x + blockIdx.x, (long)C * gridDim.x, se_gen, se_lds);
     }
 }
 
@@ -423,11 +431,11 @@ void se_gate_fused_kernel(const float* __restrict__ partial, int nblk, float inv
 
 using namespace hs;
 
-extern "C" int hs_depthwise_conv_fwd(const float* x, int32_t batch, int32_t channels, int32_t H, int32_t W,
-                                     const float* w, int32_t k, int32_t stride, int32_t pad_t, int32_t pad_l,
-                                     int32_t Ho, int32_t Wo, const float* scale, const float* shift, int32_t act,
-                                     float* y, float* pool_partial, const float* in_scale, const float* in_shift,
-                                     void* stream) {
+static int depthwise_conv_launch(const float* x, int32_t batch, int32_t channels, int32_t H, int32_t W,
+                                 const float* w, int32_t k, int32_t stride, int32_t pad_t, int32_t pad_l,
+                                 int32_t Ho, int32_t Wo, const float* scale, const float* shift, int32_t act,
+                                 float* y, float* pool_partial, const float* in_scale, const float* in_shift,
+                                 const hs_se_tail* se_in, void* stream) {
     if ((in_scale != nullptr) != (in_shift != nullptr)) return HS_ERR_BAD_ARG;
     if (!x || !w || !y || batch <= 0 || channels <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return HS_ERR_BAD_ARG;
     if (pad_t < 0 || pad_l < 0 || (scale && !shift)) return HS_ERR_BAD_ARG;
@@ -438,8 +446,13 @@ extern "C" int hs_depthwise_conv_fwd(const float* x, int32_t batch, int32_t chan
     const int gy = nplanes > 65535 ? 32768 : (int)nplanes;
     dim3 grid((quads + threads - 1) / threads, gy, (unsigned)((nplanes + gy - 1) / gy));
     hipStream_t s = (hipStream_t)stream;
+    SeTail se{};
+    if (se_in) {
+        const int st = make_se_tail(se_in, batch, channels, (int)grid.x, (long)channels * grid.x, Ho * Wo, se);
+        if (st != HS_OK) return st;
+    }
 #define HS_DW(KK, SS, PP) hipLaunchKernelGGL((depthwise_conv_kernel<KK, SS, PP, false>), grid, dim3(threads), 0, s, x, w, scale, shift, \
-                                             y, channels, H, W, Ho, Wo, pad_t, pad_l, act, pool_partial, in_scale, in_shift, (int)nplanes)
+                                             y, channels, H, W, Ho, Wo, pad_t, pad_l, act, pool_partial, in_scale, in_shift, (int)nplanes, se)
     // the LDS-tiled form: BN0 + swish prologue, whole output rows per workgroup (same thread -> output map, same partials)
     const int wq = Wo / 4;
     // For batched work (>= 8192 planes) and for every 5 x 5 launch (8.75 swishes per output there), on planes of >= 256 output quads:
@@ -452,7 +465,7 @@ extern "C" int hs_depthwise_conv_fwd(const float* x, int32_t batch, int32_t chan
         const size_t lds = (size_t)rows_in * tw * sizeof(float);
         if (lds <= 64 * 1024) {
 #define HS_DWT(KK, SS) hipLaunchKernelGGL((depthwise_conv_kernel<KK, SS, -1, true>), grid, dim3(threads), lds, s, x, w, scale, shift, y, \
-                                          channels, H, W, Ho, Wo, pad_t, pad_l, act, pool_partial, in_scale, in_shift, (int)nplanes)
+                                          channels, H, W, Ho, Wo, pad_t, pad_l, act, pool_partial, in_scale, in_shift, (int)nplanes, se)
             if (k == 3 && stride == 1) HS_DWT(3, 1); else if (k == 3) HS_DWT(3, 2); else if (stride == 1) HS_DWT(5, 1); else HS_DWT(5, 2);
 #undef HS_DWT
             return launch_status();
@@ -466,6 +479,41 @@ extern "C" int hs_depthwise_conv_fwd(const float* x, int32_t batch, int32_t chan
     else return HS_ERR_UNSUPPORTED;
 #undef HS_DW
     return launch_status();
+}
+
+extern "C" int hs_depthwise_conv_fwd(const float* x, int32_t batch, int32_t channels, int32_t H, int32_t W,
+                                     const float* w, int32_t k, int32_t stride, int32_t pad_t, int32_t pad_l,
+                                     int32_t Ho, int32_t Wo, const float* scale, const float* shift, int32_t act,
+                                     float* y, float* pool_partial, const float* in_scale, const float* in_shift,
+                                     void* stream) {
+    return depthwise_conv_launch(x, batch, channels, H, W, w, k, stride, pad_t, pad_l, Ho, Wo, scale, shift, act, y, pool_partial,
+                                 in_scale, in_shift, nullptr, stream);
+}
+
+// The same launch finishing the block's squeeze-excite gate in its last workgroups (hs_se_tail.h): no pool partials come back,
+// se->gate (B, C) does.  HS_ERR_UNSUPPORTED: this shape keeps hs_se_gate_fwd.
+extern "C" int hs_depthwise_conv_se_fwd(const float* x, int32_t batch, int32_t channels, int32_t H, int32_t W,
+                                        const float* w, int32_t k, int32_t stride, int32_t pad_t, int32_t pad_l,
+                                        int32_t Ho, int32_t Wo, const float* scale, const float* shift, int32_t act,
+                                        float* y, const float* in_scale, const float* in_shift, const hs_se_tail* se,
+                                        void* stream) {
+    if (!se) return HS_ERR_BAD_ARG;
+    return depthwise_conv_launch(x, batch, channels, H, W, w, k, stride, pad_t, pad_l, Ho, Wo, scale, shift, act, y, nullptr,
+                                 in_scale, in_shift, se, stream);
+}
+
+// bytes of the (zero-initialised, exclusively owned) workspace of a launch with an SE tail; 0: the shape is not covered
+extern "C" int64_t hs_se_tail_workspace(int32_t batch, int32_t channels, int32_t c_squeezed, int32_t nblk, int64_t wgs_per_batch) {
+    int T, L;
+    if (batch <= 0 || !se_tail_plan(channels, c_squeezed, nblk, wgs_per_batch, T, L)) return 0;
+    SeTail t{};
+    t.B = batch; t.C = channels; t.Csq = c_squeezed; t.nblk = nblk; t.T = T; t.L = L;
+    return (int64_t)(se_ws_words(t) * sizeof(se_u64));
+}
+
+extern "C" int hs_se_tail_tails(int32_t channels, int32_t c_squeezed, int32_t nblk, int64_t wgs_per_batch) {
+    int T, L;
+    return se_tail_plan(channels, c_squeezed, nblk, wgs_per_batch, T, L) ? T : 0;
 }
 
 extern "C" int hs_depthwise_pool_blocks(int32_t Ho, int32_t Wo) {

@@ -18,6 +18,7 @@
 // The depthwise taps accumulate in the same (ky, kx) order as depthwise_conv_kernel, so the two routes differ only by the
 // k-order of the expand GEMM.
 #include "hs_common.h"
+#include "hs_se_tail.h"
 
 namespace hs {
 
@@ -28,6 +29,7 @@ struct MbxArgs {
     const float* __restrict__ w_dw; const float* __restrict__ s1; const float* __restrict__ b1;
     float* __restrict__ y; float* __restrict__ pool;
     int Cin, Cmid, H, W, Ho, Wo, pad_t, pad_l, tiles_y, tiles_x, chunks_per_wg, ngroups;
+    SeTail se;                          // hs_se_tail.h: ws != null -> the partials are published as granules and the last workgroups finish the gate
 };
 
 template <int K, int S, int OTH, int OTW> struct MbxGeom {
@@ -58,6 +60,7 @@ void mbconv_expand_dw_kernel(MbxArgs a) {
     const int tx = blk % a.tiles_x; blk /= a.tiles_x;
     const int ty = blk % a.tiles_y;
     const int b = blk / a.tiles_y;
+    const unsigned se_gen = a.se.ws ? se_tag(a.se, b) : 0u;
     const int oy0 = ty * OTH, ox0 = tx * OTW;
     const int iy0 = oy0 * S - a.pad_t, ix0 = ox0 * S - a.pad_l;
     const int Cin = a.Cin, Cmid = a.Cmid;
@@ -201,15 +204,23 @@ void mbconv_expand_dw_kernel(MbxArgs a) {
                 }
             }
             // SE pooling: one partial sum per (channel, tile), reduced over the channel's 16 lanes
-            if (a.pool) {
+            if (a.pool || a.se.ws) {
                 psum = rowsum16(psum);         // the channel's 16 lanes are one DPP row
-                if (u == 0 && h < Cmid) a.pool[((size_t)b * Cmid + h) * ntiles + ty * a.tiles_x + tx] = psum;
+                const size_t pidx = ((size_t)b * Cmid + h) * ntiles + ty * a.tiles_x + tx;
+                if (u == 0 && h < Cmid) {
+                    if (a.se.ws) se_publish(a.se.ws, se_ws_pg(a.se) + pidx, psum, se_gen);
+                    else a.pool[pidx] = psum;
+                }
             }
         }
         if constexpr (HOIST) {
             if (ch + 1 < c_end) fetch_pw(ch + 1);
         }
         __syncthreads();               // h1 is rewritten by the next chunk's pw
+    }
+    if (a.se.ws) {                     // h1 is free now (>= 16 x 364 floats > SE_LDS_FLOATS)
+        const long per_b = (long)ntiles * a.ngroups;
+        se_tail_run(a.se, b, (long)blockIdx.x - (long)b * per_b, per_b, se_gen, h1);
     }
 }
 
@@ -244,11 +255,31 @@ extern "C" int hs_mbconv_tiles(int32_t k, int32_t stride, int32_t Ho, int32_t Wo
     return ((Ho + oth - 1) / oth) * ((Wo + otw - 1) / otw);
 }
 
-extern "C" int hs_mbconv_expand_dw_fwd(const float* x, int32_t batch, int32_t c_in, int32_t H, int32_t W,
-                                       const float* w_expand, int32_t c_mid, const float* scale0, const float* shift0,
-                                       const float* w_dw, int32_t k, int32_t stride, int32_t pad_t, int32_t pad_l,
-                                       int32_t Ho, int32_t Wo, const float* scale1, const float* shift1, float* y,
-                                       float* pool_partial, void* stream) {
+// tiles and channel-chunk groups of a launch (enough workgroups to fill 256 CUs a few times over, but as few re-loads of the
+// input tile as that allows)
+static void mbx_grid(int batch, int c_mid, int stride, int Ho, int Wo, int& tiles_y, int& tiles_x, int& cpw, int& ngroups) {
+    const int oth = stride == 1 ? 16 : 8, otw = 16;
+    tiles_y = (Ho + oth - 1) / oth; tiles_x = (Wo + otw - 1) / otw;
+    const int nchunks = (c_mid + 15) / 16;
+    const long tiles = (long)batch * tiles_y * tiles_x;
+    cpw = nchunks;
+    while (cpw > 1 && tiles * ((nchunks + cpw - 1) / cpw) < 768) --cpw;
+    ngroups = (nchunks + cpw - 1) / cpw;
+}
+
+extern "C" int64_t hs_mbconv_se_workgroups(int32_t batch, int32_t c_mid, int32_t k, int32_t stride, int32_t Ho, int32_t Wo) {
+    (void)k;
+    if (batch <= 0 || c_mid <= 0 || Ho <= 0 || Wo <= 0 || (stride != 1 && stride != 2)) return 0;
+    int ty, tx, cpw, ng;
+    mbx_grid(batch, c_mid, stride, Ho, Wo, ty, tx, cpw, ng);
+    return (int64_t)ty * tx * ng;
+}
+
+static int mbconv_launch(const float* x, int32_t batch, int32_t c_in, int32_t H, int32_t W,
+                         const float* w_expand, int32_t c_mid, const float* scale0, const float* shift0,
+                         const float* w_dw, int32_t k, int32_t stride, int32_t pad_t, int32_t pad_l,
+                         int32_t Ho, int32_t Wo, const float* scale1, const float* shift1, float* y,
+                         float* pool_partial, const hs_se_tail* se_in, void* stream) {
     if (!x || !w_expand || !scale0 || !shift0 || !w_dw || !scale1 || !shift1 || !y) return HS_ERR_BAD_ARG;
     if (batch <= 0 || c_in <= 0 || c_mid <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || pad_t < 0 || pad_l < 0)
         return HS_ERR_BAD_ARG;
@@ -256,18 +287,37 @@ extern "C" int hs_mbconv_expand_dw_fwd(const float* x, int32_t batch, int32_t c_
     a.x = x; a.w_e = w_expand; a.s0 = scale0; a.b0 = shift0; a.w_dw = w_dw; a.s1 = scale1; a.b1 = shift1;
     a.y = y; a.pool = pool_partial;
     a.Cin = c_in; a.Cmid = c_mid; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.pad_t = pad_t; a.pad_l = pad_l;
-    const int oth = stride == 1 ? 16 : 8, otw = 16;
-    a.tiles_y = (Ho + oth - 1) / oth; a.tiles_x = (Wo + otw - 1) / otw;
-    // enough workgroups to fill 256 CUs a few times over, but as few re-loads of the input tile as that allows
-    const int nchunks = (c_mid + 15) / 16;
-    const long tiles = (long)batch * a.tiles_y * a.tiles_x;
-    int cpw = nchunks;
-    while (cpw > 1 && tiles * ((nchunks + cpw - 1) / cpw) < 768) --cpw;
-    a.chunks_per_wg = cpw; a.ngroups = (nchunks + cpw - 1) / cpw;
+    if (stride != 1 && stride != 2) return HS_ERR_UNSUPPORTED;
+    mbx_grid(batch, c_mid, stride, Ho, Wo, a.tiles_y, a.tiles_x, a.chunks_per_wg, a.ngroups);
+    a.se = SeTail{};
+    if (se_in) {
+        const int st = make_se_tail(se_in, batch, c_mid, a.tiles_y * a.tiles_x, (long)a.tiles_y * a.tiles_x * a.ngroups, Ho * Wo, a.se);
+        if (st != HS_OK) return st;
+    }
     hipStream_t s = (hipStream_t)stream;
     if (k == 3 && stride == 1) return dispatch_ks<3, 1, 16, 16>(a, batch, s);
     if (k == 3 && stride == 2) return dispatch_ks<3, 2, 8, 16>(a, batch, s);
     if (k == 5 && stride == 1) return dispatch_ks<5, 1, 16, 16>(a, batch, s);
     if (k == 5 && stride == 2) return dispatch_ks<5, 2, 8, 16>(a, batch, s);
     return HS_ERR_UNSUPPORTED;
+}
+
+extern "C" int hs_mbconv_expand_dw_fwd(const float* x, int32_t batch, int32_t c_in, int32_t H, int32_t W,
+                                       const float* w_expand, int32_t c_mid, const float* scale0, const float* shift0,
+                                       const float* w_dw, int32_t k, int32_t stride, int32_t pad_t, int32_t pad_l,
+                                       int32_t Ho, int32_t Wo, const float* scale1, const float* shift1, float* y,
+                                       float* pool_partial, void* stream) {
+    return mbconv_launch(x, batch, c_in, H, W, w_expand, c_mid, scale0, shift0, w_dw, k, stride, pad_t, pad_l, Ho, Wo, scale1, shift1, y,
+                         pool_partial, nullptr, stream);
+}
+
+// The same launch finishing the block's squeeze-excite gate in its last workgroups (hs_se_tail.h)
+extern "C" int hs_mbconv_expand_dw_se_fwd(const float* x, int32_t batch, int32_t c_in, int32_t H, int32_t W,
+                                          const float* w_expand, int32_t c_mid, const float* scale0, const float* shift0,
+                                          const float* w_dw, int32_t k, int32_t stride, int32_t pad_t, int32_t pad_l,
+                                          int32_t Ho, int32_t Wo, const float* scale1, const float* shift1, float* y,
+                                          const hs_se_tail* se, void* stream) {
+    if (!se) return HS_ERR_BAD_ARG;
+    return mbconv_launch(x, batch, c_in, H, W, w_expand, c_mid, scale0, shift0, w_dw, k, stride, pad_t, pad_l, Ho, Wo, scale1, shift1, y,
+                         nullptr, se, stream);
 }

@@ -738,17 +738,114 @@ def ir_tile_map(reg, mode, pwr):
     return nt3.value, np.ctypeslib.as_array(buf).reshape(nt.value, 16, 3).copy()
 
 
+class ExclusiveWorkspaces:
+    """Zero-initialised device buffers that belong to ONE launch at a time, for kernels that keep protocol state in memory across
+    launches (csrc/hs_se_tail.h: generation words + tagged granules; the state a launch leaves is the state the next one expects,
+    so a buffer may serve any number of launches IN SEQUENCE but never two at once).
+
+    ``take(device, signature, nbytes)``: eager calls get the buffer of (current stream, signature) -- launches of one stream are
+    ordered.  Calls made while a HIP graph is being captured get a buffer that belongs to THAT capture (and is kept alive for as long
+    as this object lives: the graph's kernel arguments point at it): prepared, zeroed spares are handed out, because an allocation
+    inside a capture would put its zero-fill into the graph and wipe the state at every replay -- correct, but a memset node per use.
+    Spares are topped up by every eager call, so "run eagerly once, then capture" (what every capture site of this repository does:
+    lazily built buffers have to exist before a capture anyway) never allocates inside a capture; ``captured_zero_fills`` counts the
+    times it had to.  A capture is recognised by the eager -> capturing transition seen here: two captures with no eager call
+    between them share buffers, which is only wrong if their graphs are then replayed concurrently."""
+    SPARES = 2
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._eager, self._spares, self._captured = {}, {}, {}
+        self._epoch, self._was_capturing = 0, False
+        self.captured_zero_fills = 0
+
+    @staticmethod
+    def _zeros(device, nbytes):
+        return torch.zeros((nbytes + 7) // 8, dtype=torch.int64, device=device)
+
+    def take(self, device, signature, nbytes):
+        capturing = torch.cuda.is_current_stream_capturing()
+        stream = torch.cuda.current_stream(device).cuda_stream
+        with self._lock:
+            if capturing and not self._was_capturing:
+                self._epoch += 1
+            self._was_capturing = capturing
+            skey = (device.index, signature, nbytes)
+            if capturing:
+                key = (stream, self._epoch) + skey
+                t = self._captured.get(key)
+                if t is None:
+                    pool = self._spares.get(skey)
+                    if pool:
+                        t = pool.pop()
+                    else:
+                        self.captured_zero_fills += 1
+                        t = self._zeros(device, nbytes)
+                    self._captured[key] = t
+                return t
+            key = (stream,) + skey
+            t = self._eager.get(key)
+            if t is None:
+                t = self._eager[key] = self._zeros(device, nbytes)
+            pool = self._spares.setdefault(skey, [])
+            while len(pool) < self.SPARES:
+                pool.append(self._zeros(device, nbytes))
+            return t
+
+
+SE_WORKSPACES = ExclusiveWorkspaces()
+SE_TAIL = os.environ.get('HS_SE_TAIL', '1') != '0'      # A/B switch: 0 = the squeeze-excite gate as its own launch(es), hs_se_gate_fwd
+
+
+def se_tail_descriptor(device, batch, channels, nblk, wgs_per_batch, w_reduce, b_reduce, w_expand_t, b_expand):
+    """(hs_se_tail struct, gate tensor, keep-alive tuple) for a pooling launch that finishes the squeeze-excite gate itself
+    (include/hyperseg_hip.h hs_se_tail), or None when the shape is not covered (the caller then pools and calls :func:`se_gate`)."""
+    csq = w_reduce.shape[0]
+    nbytes = int(_hip.lib.hs_se_tail_workspace(batch, channels, csq, nblk, wgs_per_batch))
+    if nbytes <= 0:
+        return None
+    ws = SE_WORKSPACES.take(device, (batch, channels, csq, nblk, int(wgs_per_batch)), nbytes)
+    gate = torch.empty(batch, channels, device=device, dtype=torch.float32)
+    d = _hip.SeTailC()
+    d.w_reduce, d.b_reduce = _hip.dev_ptr(w_reduce, 'w_reduce'), _hip.dev_ptr(b_reduce, 'b_reduce')
+    d.w_expand_t, d.b_expand = _hip.dev_ptr(w_expand_t, 'w_expand_t'), _hip.dev_ptr(b_expand, 'b_expand')
+    d.c_squeezed = csq
+    d.gate, d.squeezed, d.workspace = gate.data_ptr(), None, ws.data_ptr()
+    return d, gate, ws
+
+
+def se_tail_error(ws, batch):
+    """The error word of a tail workspace (nonzero: a bounded wait gave up and the gate of that launch is NaN); synchronises."""
+    return int(ws[batch].item())
+
+
 @_on_operand_device
 def depthwise_conv_bn_act(x, weight, stride, pad_top, pad_left, out_size, scale=None, shift=None, act=0, pool=False,
-                          in_scale=None, in_shift=None):
+                          in_scale=None, in_shift=None, se=None):
     """Depthwise conv (k 3|5, stride 1|2, TF-"SAME" zero padding given as top/left offsets) + affine + activation
     (3 = swish) in one launch.  ``pool=True`` also returns the per-workgroup partial sums of the outputs (B*C, nblk)
     for :func:`se_gate`.  ``in_scale``/``in_shift`` (C): the taps are swish(in_scale*x + in_shift) -- x is then the RAW
-    output of the 1x1 expand GEMM.  Encoder-side helper, opt-in (utils/inference.py)."""
+    output of the 1x1 expand GEMM.  ``se=(w_reduce, b_reduce, w_expand_t, b_expand)`` with ``pool=True``: the launch finishes the
+    squeeze-excite gate itself where it can (hs_depthwise_conv_se_fwd) and returns (y, gate (B, C), True) instead of
+    (y, partial, False).  Encoder-side helper, opt-in (utils/inference.py)."""
     b, c, h, w = x.shape
     k = weight.shape[-1]
     ho, wo = out_size
     y = torch.empty(b, c, ho, wo, device=x.device, dtype=torch.float32)
+    if se is not None and pool and SE_TAIL:
+        nblk = _hip.lib.hs_depthwise_pool_blocks(ho, wo)
+        desc = se_tail_descriptor(x.device, b, c, nblk, c * nblk, *se)
+        if desc is not None:
+            d, gate, _ws = desc
+            st = _hip.lib.hs_depthwise_conv_se_fwd(_hip.dev_ptr(x, 'x'), b, c, h, w, _hip.dev_ptr(weight, 'weight'), k, stride,
+                                                   pad_top, pad_left, ho, wo,
+                                                   _hip.dev_ptr(scale, 'scale') if scale is not None else None,
+                                                   _hip.dev_ptr(shift, 'shift') if shift is not None else None, int(act), y.data_ptr(),
+                                                   _hip.dev_ptr(in_scale, 'in_scale') if in_scale is not None else None,
+                                                   _hip.dev_ptr(in_shift, 'in_shift') if in_shift is not None else None,
+                                                   C.byref(d), _hip.stream_ptr())
+            _hip.check(st, 'hs_depthwise_conv_se_fwd')
+            return y, gate, True
     partial = None
     if pool:
         partial = torch.empty(b * c, _hip.lib.hs_depthwise_pool_blocks(ho, wo), device=x.device, dtype=torch.float32)
@@ -761,6 +858,8 @@ def depthwise_conv_bn_act(x, weight, stride, pad_top, pad_left, out_size, scale=
                                         _hip.dev_ptr(in_shift, 'in_shift') if in_shift is not None else None,
                                         _hip.stream_ptr())
     _hip.check(st, 'hs_depthwise_conv_fwd')
+    if se is not None and pool:
+        return y, partial, False
     return (y, partial) if pool else y
 
 
@@ -779,14 +878,27 @@ def stem_conv_bn_swish(x, weight, pad_top, pad_left, out_size, scale, shift):
 
 
 @_on_operand_device
-def mbconv_expand_dw(x, w_expand, scale0, shift0, w_dw, stride, pad_top, pad_left, out_size, scale1, shift1, pool=True):
+def mbconv_expand_dw(x, w_expand, scale0, shift0, w_dw, stride, pad_top, pad_left, out_size, scale1, shift1, pool=True, se=None):
     """1x1 expand + BN + swish + depthwise k x k (TF-"SAME" zero padding of the ACTIVATION) + BN + swish in one launch
     (+ SE pooling partial sums): the expanded tensor never reaches HBM.  x (B,Cin,H,W), w_expand (Cmid,Cin[,1,1]),
-    w_dw (Cmid,1,k,k) -> y (B,Cmid,Ho,Wo)[, partial (B*Cmid, ntiles)].  Encoder-side helper, opt-in."""
+    w_dw (Cmid,1,k,k) -> y (B,Cmid,Ho,Wo)[, partial (B*Cmid, ntiles)].  ``se``: as in :func:`depthwise_conv_bn_act`
+    (hs_mbconv_expand_dw_se_fwd; returns (y, gate | partial, bool)).  Encoder-side helper, opt-in."""
     b, cin, h, w = x.shape
     cmid, k = w_dw.shape[0], w_dw.shape[-1]
     ho, wo = out_size
     y = torch.empty(b, cmid, ho, wo, device=x.device, dtype=torch.float32)
+    if se is not None and pool and SE_TAIL:
+        nblk = _hip.lib.hs_mbconv_tiles(k, stride, ho, wo)
+        desc = se_tail_descriptor(x.device, b, cmid, nblk, int(_hip.lib.hs_mbconv_se_workgroups(b, cmid, k, stride, ho, wo)), *se)
+        if desc is not None:
+            d, gate, _ws = desc
+            st = _hip.lib.hs_mbconv_expand_dw_se_fwd(_hip.dev_ptr(x, 'x'), b, cin, h, w, _hip.dev_ptr(w_expand, 'w_expand'), cmid,
+                                                     _hip.dev_ptr(scale0, 'scale0'), _hip.dev_ptr(shift0, 'shift0'),
+                                                     _hip.dev_ptr(w_dw, 'w_dw'), k, stride, pad_top, pad_left, ho, wo,
+                                                     _hip.dev_ptr(scale1, 'scale1'), _hip.dev_ptr(shift1, 'shift1'), y.data_ptr(),
+                                                     C.byref(d), _hip.stream_ptr())
+            _hip.check(st, 'hs_mbconv_expand_dw_se_fwd')
+            return y, gate, True
     partial = None
     if pool:
         partial = torch.empty(b * cmid, _hip.lib.hs_mbconv_tiles(k, stride, ho, wo), device=x.device, dtype=torch.float32)
@@ -796,6 +908,8 @@ def mbconv_expand_dw(x, w_expand, scale0, shift0, w_dw, stride, pad_top, pad_lef
                                           _hip.dev_ptr(scale1, 'scale1'), _hip.dev_ptr(shift1, 'shift1'), y.data_ptr(),
                                           partial.data_ptr() if pool else None, _hip.stream_ptr())
     _hip.check(st, 'hs_mbconv_expand_dw_fwd')
+    if se is not None and pool:
+        return y, partial, False
     return (y, partial) if pool else y
 
 

@@ -139,7 +139,11 @@ class FusedPointwise(nn.Module):
     def uses_mfma(self, x):
         """Small-K, many-pixel layers run as one fused MFMA GEMM; large-K layers keep the library GEMM
         (tools/bench_mbconv.py times both routes per layer)."""
-        return x.shape[1] <= PW_MFMA_MAX_CIN and x.shape[2] * x.shape[3] >= PW_MFMA_MIN_PIXELS
+        return self.mfma_covers(x.shape[1], x.shape[2] * x.shape[3])
+
+    @staticmethod
+    def mfma_covers(channels, pixels):
+        return channels <= PW_MFMA_MAX_CIN and pixels >= PW_MFMA_MIN_PIXELS
 
     def raw(self, x):
         """The bare GEMM: W (Cout, Cin) @ x (Cin, HW) per frame (a strided-batched GEMM with a shared A for a batch); BN +
@@ -238,6 +242,10 @@ class FusedMBConv(nn.Module):
             self.pad_h, self.pad_w = 2 * conv.padding[0], 2 * conv.padding[1]
         self.skip = blk.stride == 1 and blk.in_f == blk.out_f
         self._exp_t = None                       # (Csq, C) transposed SE expand weight, built on first use
+        self._red_w = None                       # (Csq, C) view of the SE reduce weight
+        # the gate by the pooling launch's last workgroups (round 5) -- only where the project convolution takes the gate as a vector
+        # (our split GEMM / MFMA kernels); the library-GEMM route folds it into the weights and keeps hs_se_gate_fwd
+        self.se_tail = True
         # constant-offset bookkeeping (see the class docstring)
         if in_offset is not None:
             assert self.expand is not None, 'a depthwise conv cannot consume an offset tensor (zero padding)'
@@ -263,10 +271,22 @@ class FusedMBConv(nn.Module):
         ho = (h + self.pad_h - self.k) // self.stride + 1
         wo = (w + self.pad_w - self.k) // self.stride + 1
         lean = True                               # library GEMMs with nothing around them (batched for b > 1)
+        red, exp = blk._se_reduce, blk._se_expand
+        if self._exp_t is None or self._exp_t.device != x.device:
+            self._exp_t = exp.weight.detach().flatten(1).t().contiguous()
+        if self._red_w is None or self._red_w.device != x.device:
+            self._red_w = red.weight.detach().flatten(1)             # a view: (Csq, C)
+        # round 5: the pooling launch finishes the squeeze-excite gate in its last workgroups (csrc/hs_se_tail.h) -- `gated` says
+        # whether `pooled` is already the gate (B, C) or still the partial sums for HF.se_gate
+        proj = self.project
+        cmid = blk._depthwise_conv.weight.shape[0]
+        lean_gemm = lean and (cmid > LEAN_MFMA_MAX_CIN if self.defer_shift else not proj.mfma_covers(cmid, ho * wo))
+        folds = lean_gemm and not (proj.split_gemm and proj.split_weights(True, x.device) is not None)      # gate folded into the weights
+        se = (self._red_w, red.bias, self._exp_t, exp.bias) if self.se_tail and not folds else None
         if self.fuses_expand(x, ho, wo):
-            y, partial = HF.mbconv_expand_dw(x, self.expand.conv.weight, self.expand.scale, self.expand.shift,
-                                             blk._depthwise_conv.weight, self.stride, self.pad_t, self.pad_l, (ho, wo),
-                                             self.scale, self.shift, pool=True)
+            out = HF.mbconv_expand_dw(x, self.expand.conv.weight, self.expand.scale, self.expand.shift,
+                                      blk._depthwise_conv.weight, self.stride, self.pad_t, self.pad_l, (ho, wo),
+                                      self.scale, self.shift, pool=True, se=se)
         else:
             in_scale = in_shift = None
             if self.expand is not None:
@@ -275,30 +295,31 @@ class FusedMBConv(nn.Module):
                     x = self.expand.raw(x)
                 else:
                     x = self.expand(x)
-            y, partial = HF.depthwise_conv_bn_act(x, blk._depthwise_conv.weight, self.stride, self.pad_t, self.pad_l,
-                                                  (ho, wo), self.scale, self.shift, act=3, pool=True,
-                                                  in_scale=in_scale, in_shift=in_shift)
-        red, exp = blk._se_reduce, blk._se_expand
-        if self._exp_t is None or self._exp_t.device != x.device:
-            self._exp_t = exp.weight.detach().flatten(1).t().contiguous()
+            out = HF.depthwise_conv_bn_act(x, blk._depthwise_conv.weight, self.stride, self.pad_t, self.pad_l,
+                                           (ho, wo), self.scale, self.shift, act=3, pool=True,
+                                           in_scale=in_scale, in_shift=in_shift, se=se)
+        y, pooled, gated = out if se is not None else (out[0], out[1], False)
+
+        def se_gate(**fold):
+            if gated and not fold:
+                return pooled
+            return HF.se_gate(pooled, b, ho * wo, red.weight, red.bias, self._exp_t, exp.bias, **fold)
         skip = inputs.contiguous() if self.skip else None
-        proj = self.project
         # deferred shift -> nothing follows the GEMM: the bare library GEMM wins for all but the smallest K; otherwise the
         # MFMA kernel with its fused epilogue wins wherever it applies (few channels, many pixels)
-        if lean and (y.shape[1] > LEAN_MFMA_MAX_CIN if self.defer_shift else not proj.uses_mfma(y)):
+        if lean_gemm:
             sw = proj.split_weights(True, y.device) if proj.split_gemm else None
             if sw is not None:
                 # our own GEMM (f16 matrix cores, split operands): the BN2 scale is folded into the static split weights, the
                 # gate multiplies the rows of y on load -- no per-frame copy of the project weights is written
-                gate = HF.se_gate(partial, b, ho * wo, red.weight, red.bias, self._exp_t, exp.bias)
+                gate = se_gate()
                 if self.defer_shift:
                     if skip is None:
                         return HF.gemm_split(sw, y, gate=gate)
                     return HF.gemm_split(sw, y, gate=gate, residual=skip, out=skip)     # in place: no other consumer
                 return HF.gemm_split(sw, y, gate=gate, shift=proj.shift, residual=skip)
             # gate (and BN2 scale) folded into the project weights by the SE kernel: ~1e5 weights instead of a pass over y
-            wp = HF.se_gate(partial, b, ho * wo, red.weight, red.bias, self._exp_t, exp.bias,
-                            w_proj=proj.conv.weight, out_scale=proj.scale)
+            wp = se_gate(w_proj=proj.conv.weight, out_scale=proj.scale)
             cmid = y.shape[1]
             with gemm_library(ho * wo, b):
                 if b == 1:
@@ -318,8 +339,7 @@ class FusedMBConv(nn.Module):
                         return skip
                     out = torch.bmm(w3d, y3d).view(b, -1, ho, wo)
             return HF.affine_act_(out, None, proj.shift, 0, skip)
-        gate = HF.se_gate(partial, b, ho * wo, red.weight, red.bias, self._exp_t, exp.bias)
-        return proj(y, gate=gate, residual=skip)
+        return proj(y, gate=se_gate(), residual=skip)
 
 
 CTX_DOWN_SPLIT = os.environ.get('HS_CTX_DOWN_SPLIT', '1') != '0'      # A/B switch (tools/gpu_ab_env.sh): 0 = F.conv2d + affine for the head's down blocks

@@ -358,6 +358,33 @@ int hs_depthwise_conv_fwd(const float* x, int32_t batch, int32_t channels, int32
  * BatchNorm scale -- into the project weights: w_scaled[b, o, c] = w_proj[o, c] * gate[b, c] * out_scale[o].
  * w_reduce is (c_squeezed, channels); w_expand is passed TRANSPOSED, (c_squeezed, channels): both are read coalesced. */
 int hs_depthwise_pool_blocks(int32_t Ho, int32_t Wo);
+
+/* The squeeze-excite gate finished by the LAST workgroups of the pooling launch itself (round 5, csrc/hs_se_tail.h) instead of by
+ * hs_se_gate_fwd: hs_depthwise_conv_se_fwd / hs_mbconv_expand_dw_se_fwd are the launches above without pool_partial and with this
+ * descriptor; gate (B, channels) and, optionally, squeezed (B, c_squeezed) come back.  Same sums in the same order per channel; the
+ * two matrix-vector products are split over <= 32 workgroups and re-assembled in slice order (deterministic).
+ * workspace: hs_se_tail_workspace(batch, channels, c_squeezed, nblk, wgs_per_batch) bytes (nblk = hs_depthwise_pool_blocks /
+ * hs_mbconv_tiles; wgs_per_batch = channels * nblk for the depthwise launch, hs_mbconv_se_workgroups for the fused one), 8-byte
+ * aligned, ZERO before its first use and owned by one launch at a time (two streams need two); the launches keep it consistent.
+ * Its word [batch] is an error flag: nonzero after a launch whose bounded waits gave up (the gate is then NaN).
+ * hs_se_tail_workspace returns 0 -- and the launches HS_ERR_UNSUPPORTED -- for shapes the tail does not cover
+ * (c_squeezed > 128, > 512 partials per channel, fewer workgroups than tails). */
+typedef struct hs_se_tail {
+    const float* w_reduce;    /* (c_squeezed, channels)            efficientnet.py:107 _se_reduce */
+    const float* b_reduce;    /* (c_squeezed) */
+    const float* w_expand_t;  /* (c_squeezed, channels): _se_expand's weight TRANSPOSED */
+    const float* b_expand;    /* (channels) */
+    int32_t c_squeezed;
+    float* gate;              /* out (B, channels) = sigmoid(expand(swish(reduce(mean)))) */
+    float* squeezed;          /* out (B, c_squeezed), optional */
+    void* workspace;
+} hs_se_tail;
+int64_t hs_se_tail_workspace(int32_t batch, int32_t channels, int32_t c_squeezed, int32_t nblk, int64_t wgs_per_batch);
+int hs_se_tail_tails(int32_t channels, int32_t c_squeezed, int32_t nblk, int64_t wgs_per_batch);   /* workgroups that finish the gate; 0: not covered */
+int hs_depthwise_conv_se_fwd(const float* x, int32_t batch, int32_t channels, int32_t H, int32_t W,
+                             const float* w, int32_t k, int32_t stride, int32_t pad_t, int32_t pad_l,
+                             int32_t Ho, int32_t Wo, const float* scale, const float* shift, int32_t act,
+                             float* y, const float* in_scale, const float* in_shift, const hs_se_tail* se, void* stream);
 int hs_se_gate_fwd(const float* partial, int32_t batch, int32_t channels, int32_t nblk, float inv_hw,
                    const float* w_reduce, const float* b_reduce, int32_t c_squeezed, const float* w_expand,
                    const float* b_expand, float* squeezed, float* gate, const float* w_proj, int32_t c_out,
@@ -382,6 +409,12 @@ int hs_mbconv_expand_dw_fwd(const float* x, int32_t batch, int32_t c_in, int32_t
                             const float* w_dw, int32_t k, int32_t stride, int32_t pad_t, int32_t pad_l,
                             int32_t Ho, int32_t Wo, const float* scale1, const float* shift1, float* y,
                             float* pool_partial, void* stream);
+int64_t hs_mbconv_se_workgroups(int32_t batch, int32_t c_mid, int32_t k, int32_t stride, int32_t Ho, int32_t Wo);   /* per batch element */
+int hs_mbconv_expand_dw_se_fwd(const float* x, int32_t batch, int32_t c_in, int32_t H, int32_t W,
+                               const float* w_expand, int32_t c_mid, const float* scale0, const float* shift0,
+                               const float* w_dw, int32_t k, int32_t stride, int32_t pad_t, int32_t pad_l,
+                               int32_t Ho, int32_t Wo, const float* scale1, const float* shift1, float* y,
+                               const hs_se_tail* se, void* stream);
 
 /* Encoder-side helper: 1x1 convolution as an fp32 MFMA GEMM with its surroundings fused,
  *   y[b,o,p] = act(scale[o] * sum_c w[o,c] * (gate[b,c] * x[b,c,p]) + shift[o]) + residual[b,o,p]

@@ -151,6 +151,122 @@ def test_se_gate(HF, dev, c, csq, nblk, cout, batch):
     assert rel_err(ws.cpu().view(batch, cout, c), wp[None] * gate_ref[:, None, :] * osc[None, :, None]) < REL_TOL
 
 
+def _se_params(g, c, csq, dev):
+    w1, b1 = torch.randn(csq, c, generator=g) / c ** 0.5, torch.randn(csq, generator=g) * 0.1
+    w2, b2 = torch.randn(c, csq, generator=g) / csq ** 0.5, torch.randn(c, generator=g) * 0.1
+    return (w1, b1, w2, b2), tuple(t.to(dev) for t in (w1, b1, w2.t().contiguous(), b2))
+
+
+def _gate_ref(y_ref, w1, b1, w2, b2):
+    return torch.sigmoid(swish(y_ref.mean((2, 3)) @ w1.t() + b1) @ w2.t() + b2)
+
+
+# (channels, squeezed, k, stride, H, W, prologue): the EfficientNet-B1 shapes of HyperSeg-M's depthwise-route blocks (stage 1 at a
+# quarter of the map, stages 5-7 as they are), ragged ones, single-wave workgroups (8 x 16 maps), Csq > 64 with a single wave
+SE_DW_CASES = [(32, 8, 3, 1, 64, 128, False), (480, 20, 5, 1, 32, 64, True), (672, 28, 5, 2, 32, 64, True), (1152, 48, 5, 1, 16, 32, True),
+               (1920, 80, 3, 1, 16, 32, True), (50, 3, 3, 1, 9, 12, False), (200, 70, 3, 1, 8, 16, True), (13, 5, 5, 2, 33, 47, False)]
+
+
+@pytest.mark.parametrize('c,csq,k,stride,h,w,pre', SE_DW_CASES)
+@pytest.mark.parametrize('batch', [1, 2])
+def test_depthwise_conv_finishes_the_se_gate(HF, dev, c, csq, k, stride, h, w, pre, batch):
+    """hs_depthwise_conv_se_fwd (round 5, csrc/hs_se_tail.h): the pooling launch's last workgroups compute the squeeze-excite gate
+    (efficientnet.py:106-111) -- same activation as the plain launch bit for bit, gate against fp32 PyTorch and against
+    hs_se_gate_fwd on the plain launch's partial sums; three launches in a row on the same workspace (its generation words move),
+    error word clear."""
+    g = torch.Generator().manual_seed(c * 3 + csq + k + h)
+    x = torch.randn(batch, c, h, w, generator=g)
+    wt = torch.randn(c, 1, k, k, generator=g) * 0.3
+    scale, shift = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1
+    isc, ish = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1
+    (w1, b1, w2, b2), se = _se_params(g, c, csq, dev)
+    ho, wo = -(-h // stride), -(-w // stride)
+    ph, pw = max((ho - 1) * stride + k - h, 0), max((wo - 1) * stride + k - w, 0)
+    xin = swish(x * isc.view(1, -1, 1, 1) + ish.view(1, -1, 1, 1)) if pre else x
+    ref = F.conv2d(F.pad(xin, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2)), wt, stride=stride, groups=c)
+    ref = swish(ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    args = (x.to(dev), wt.to(dev), stride, ph // 2, pw // 2, (ho, wo), scale.to(dev), shift.to(dev))
+    kw = dict(act=3, pool=True, in_scale=isc.to(dev) if pre else None, in_shift=ish.to(dev) if pre else None)
+    y0, partial = HF.depthwise_conv_bn_act(*args, **kw)
+    gate0 = HF.se_gate(partial, batch, ho * wo, se[0], se[1], se[2], se[3])
+    nblk = partial.shape[1]
+    assert HF._hip.lib.hs_se_tail_tails(c, csq, nblk, c * nblk) > 0, 'this shape is meant to be covered'
+    sig, nbytes = (batch, c, csq, nblk, c * nblk), int(HF._hip.lib.hs_se_tail_workspace(batch, c, csq, nblk, c * nblk))
+    gen0 = [int(v) for v in HF.SE_WORKSPACES.take(dev, sig, nbytes)[:batch].cpu()]
+    for rep in range(3):
+        y, gate, gated = HF.depthwise_conv_bn_act(*args, se=se, **kw)
+        assert gated and gate.shape == (batch, c)
+        assert torch.equal(y, y0)
+        assert rel_err(gate.cpu(), _gate_ref(ref, w1, b1, w2, b2)) < REL_TOL
+        assert rel_err(gate.cpu(), gate0.cpu()) < 2e-6          # the same partial sums; the matrix-vector products re-associated
+    ws = HF.SE_WORKSPACES.take(dev, sig, nbytes)
+    assert HF.se_tail_error(ws, batch) == 0
+    assert [int(v) for v in ws[:batch].cpu()] == [v + 3 for v in gen0]      # one generation per launch and batch element
+
+
+@pytest.mark.parametrize('cin,cmid,csq,k,stride,h,w', [(16, 96, 4, 3, 2, 64, 128), (24, 144, 6, 3, 1, 32, 48), (24, 144, 6, 5, 2, 50, 70),
+                                                       (40, 240, 10, 5, 1, 33, 47), (40, 100, 7, 3, 2, 31, 45), (80, 480, 20, 3, 1, 16, 32),
+                                                       (6, 20, 2, 3, 1, 9, 9), (16, 96, 4, 3, 2, 256, 256)])
+def test_mbconv_expand_dw_finishes_the_se_gate(HF, dev, cin, cmid, csq, k, stride, h, w):
+    """hs_mbconv_expand_dw_se_fwd: as above for the fused expand + depthwise launch (many tiles per channel, chunk groups)."""
+    g = torch.Generator().manual_seed(cin * 7 + cmid + k + stride)
+    b = 2
+    x = torch.randn(b, cin, h, w, generator=g)
+    we = torch.randn(cmid, cin, 1, 1, generator=g) / cin ** 0.5
+    wd = torch.randn(cmid, 1, k, k, generator=g) * 0.3
+    s0, b0 = torch.rand(cmid, generator=g) + 0.5, torch.randn(cmid, generator=g) * 0.3
+    s1, b1 = torch.rand(cmid, generator=g) + 0.5, torch.randn(cmid, generator=g) * 0.1
+    (w1, bb1, w2, bb2), se = _se_params(g, cmid, csq, dev)
+    ho, wo = -(-h // stride), -(-w // stride)
+    ph, pw = max((ho - 1) * stride + k - h, 0), max((wo - 1) * stride + k - w, 0)
+    mid = swish(F.conv2d(x, we) * s0.view(1, -1, 1, 1) + b0.view(1, -1, 1, 1))
+    ref = F.conv2d(F.pad(mid, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2)), wd, stride=stride, groups=cmid)
+    ref = swish(ref * s1.view(1, -1, 1, 1) + b1.view(1, -1, 1, 1))
+    args = (x.to(dev), we.to(dev), s0.to(dev), b0.to(dev), wd.to(dev), stride, ph // 2, pw // 2, (ho, wo), s1.to(dev), b1.to(dev))
+    y0, partial = HF.mbconv_expand_dw(*args, pool=True)
+    gate0 = HF.se_gate(partial, b, ho * wo, se[0], se[1], se[2], se[3])
+    for rep in range(2):
+        y, gate, gated = HF.mbconv_expand_dw(*args, pool=True, se=se)
+        assert gated
+        assert torch.equal(y, y0)
+        assert rel_err(gate.cpu(), _gate_ref(ref, w1, bb1, w2, bb2)) < REL_TOL
+        assert rel_err(gate.cpu(), gate0.cpu()) < 2e-6
+
+
+def test_se_tail_under_graph_replay_and_two_streams(HF, dev):
+    """The tail's workspace carries state from launch to launch: (a) a captured launch keeps working over many replays WITHOUT a
+    zero-fill inside the graph (functional.ExclusiveWorkspaces hands the capture a prepared buffer), (b) two streams get two
+    buffers, so interleaved launches of the same block from two streams do not trample each other."""
+    c, csq, k, h, w = 480, 20, 5, 32, 64
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, c, h, w, generator=g).to(dev)
+    wt = (torch.randn(c, 1, k, k, generator=g) * 0.3).to(dev)
+    scale, shift = (torch.rand(c, generator=g) + 0.5).to(dev), (torch.randn(c, generator=g) * 0.1).to(dev)
+    _, se = _se_params(g, c, csq, dev)
+    args = (x, wt, 1, 2, 2, (h, w), scale, shift)
+    y0, gate0, _ = HF.depthwise_conv_bn_act(*args, act=3, pool=True, se=se)
+    torch.cuda.synchronize()
+    fills = HF.SE_WORKSPACES.captured_zero_fills
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        y1, gate1, _ = HF.depthwise_conv_bn_act(*args, act=3, pool=True, se=se)
+    assert HF.SE_WORKSPACES.captured_zero_fills == fills
+    for _ in range(5):
+        gate1.fill_(-1.0)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(gate1, gate0) and torch.equal(y1, y0)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = []
+    for _ in range(20):
+        for s in streams:
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                outs.append(HF.depthwise_conv_bn_act(*args, act=3, pool=True, se=se)[1])
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, gate0) for o in outs)
+
+
 @pytest.mark.parametrize('cin,cout,hw', [(16, 96, (64, 128)), (96, 24, (32, 64)), (32, 16, (16, 20)), (50, 37, (9, 12))])
 def test_pointwise_conv_and_affine(HF, dev, cin, cout, hw):
     g = torch.Generator().manual_seed(cin * cout)

@@ -492,3 +492,25 @@ def test_k1_chain_plan_on_the_host():
     assert plan_ir(1, 16, 32, m, 6, 46, 16) == -3            # hidden not a multiple of 4
     assert plan_ir(1, 16, 32, m, 6, 96, 16) == -3            # hidden > 64
     assert plan_ir(1, 16, 32, m, 8, 48, 16) == -3            # 800 skip-halo gathers > 768
+
+
+def test_se_tail_plan_on_the_host():
+    """csrc/hs_se_tail.h's split of a block's squeeze-excite gate over the last workgroups of its pooling launch (host-side plan,
+    no launch): every MBConv block of EfficientNet-B1 at HyperSeg-M's 1024x512 is covered, <= 32 tails, <= 2048 partial granules
+    and <= 64 channels each; shapes outside the plan return 0 (the caller keeps hs_se_gate_fwd)."""
+    from hyperseg_amd import _hip
+    lib = _hip.lib
+    # (channels, squeezed, partials per channel, workgroups per batch element)
+    blocks = [(32, 8, 128, 32 * 128), (16, 4, 128, 16 * 128), (96, 4, 256, 256), (144, 6, 128, 256), (144, 6, 64, 192), (240, 10, 64, 256),
+              (240, 10, 16, 240), (480, 20, 2, 960), (672, 28, 2, 1344), (672, 28, 1, 672), (1152, 48, 1, 1152), (1920, 80, 1, 1920)]
+    for c, csq, nblk, wgs in blocks:
+        t = lib.hs_se_tail_tails(c, csq, nblk, wgs)
+        assert 1 <= t <= 32, (c, csq, nblk, t)
+        per = -(-c // t)
+        assert per <= 64 + 3 and per * nblk <= 2048 + 3 * nblk, (c, nblk, t)
+        words = lib.hs_se_tail_workspace(2, c, csq, nblk, wgs) // 8
+        assert words == 2 + 1 + 2 * t * csq + 2 * c * nblk
+    assert lib.hs_se_tail_tails(64, 200, 1, 64) == 0            # > 128 squeezed channels
+    assert lib.hs_se_tail_tails(64, 8, 1024, 64 * 1024) == 0    # > 512 partials per channel
+    assert lib.hs_se_tail_tails(640, 8, 1, 4) == 0              # fewer workgroups than tails
+    assert lib.hs_se_tail_workspace(1, 64, 200, 1, 64) == 0
