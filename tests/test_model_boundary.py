@@ -263,7 +263,7 @@ def test_deferred_bn_shift_algebra_cpu(monkeypatch, config, split):
         return t * torch.sigmoid(t) if act == 3 else (torch.relu(t) if act == 1 else (t.clamp(0, 6) if act == 2 else t))
 
     def dw(x, weight, stride, pad_top, pad_left, out_size, scale=None, shift=None, act=0, pool=False, in_scale=None,
-           in_shift=None):
+           in_shift=None, se=None):                          # se: the stand-in leaves the gate to se_gate below (gated = False)
         if in_scale is not None:
             x = act_of(x * in_scale.view(1, -1, 1, 1) + in_shift.view(1, -1, 1, 1), 3)
         k = weight.shape[-1]
@@ -271,7 +271,7 @@ def test_deferred_bn_shift_algebra_cpu(monkeypatch, config, split):
         pb, pr = (ho - 1) * stride + k - x.shape[2] - pad_top, (wo - 1) * stride + k - x.shape[3] - pad_left
         y = F.conv2d(F.pad(x, (pad_left, pr, pad_top, pb)), weight, stride=stride, groups=x.shape[1])
         y = act_of(y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1), act)
-        return y, y.sum((2, 3)).view(-1, 1)
+        return (y, y.sum((2, 3)).view(-1, 1)) + ((False,) if se is not None else ())
 
     def se_gate(partial, batch, hw, w_reduce, b_reduce, w_expand_t, b_expand, w_proj=None, out_scale=None):
         pooled = partial.sum(1).view(batch, -1) / hw
@@ -296,9 +296,9 @@ def test_deferred_bn_shift_algebra_cpu(monkeypatch, config, split):
         x.copy_(y if residual is None else y + residual)
         return x
 
-    def expand_dw(x, w_expand, scale0, shift0, w_dw, stride, pad_top, pad_left, out_size, scale1, shift1, pool=True):
+    def expand_dw(x, w_expand, scale0, shift0, w_dw, stride, pad_top, pad_left, out_size, scale1, shift1, pool=True, se=None):
         hmid = pointwise(x, w_expand.view(w_expand.shape[0], -1, 1, 1), None, scale0, shift0, 3)
-        return dw(hmid, w_dw, stride, pad_top, pad_left, out_size, scale1, shift1, act=3, pool=True)
+        return dw(hmid, w_dw, stride, pad_top, pad_left, out_size, scale1, shift1, act=3, pool=True, se=se)
 
     used = {'n': 0, 'gated': 0, 'accumulated': 0}
 
