@@ -169,9 +169,10 @@ void depthwise_conv_kernel(const float* __restrict__ x, const float* __restrict_
         }
     }
     // the squeeze-excite gate by the last workgroups of the launch (hs_se_tail.h): the same partial sums, summed in the same order
+    // (its LDS: the dynamic segment -- the input tile of the TILE form is dead by now; the host sizes it for both uses)
     if (se.ws) {
-        __shared__ float se_lds[SE_LDS_FLOATS];
-        se_tail_run(se, plane / C, (long)c * gridDim.x + blockIdx.x, (long)C * gridDim.x, se_gen, se_lds);
+        if constexpr (TILE) __syncthreads();
+        se_tail_run(se, plane / C, (long)c * gridDim.x + blockIdx.x, (long)C * gridDim.x, se_gen, dw_tile);
     }
 }
 
@@ -451,7 +452,8 @@ static int depthwise_conv_launch(const float* x, int32_t batch, int32_t channels
         const int st = make_se_tail(se_in, batch, channels, (int)grid.x, (long)channels * grid.x, Ho * Wo, se);
         if (st != HS_OK) return st;
     }
-#define HS_DW(KK, SS, PP) hipLaunchKernelGGL((depthwise_conv_kernel<KK, SS, PP, false>), grid, dim3(threads), 0, s, x, w, scale, shift, \
+    const size_t se_lds = se_in ? (size_t)se_lds_floats(se.Csq) * sizeof(float) : 0;
+#define HS_DW(KK, SS, PP) hipLaunchKernelGGL((depthwise_conv_kernel<KK, SS, PP, false>), grid, dim3(threads), se_lds, s, x, w, scale, shift, \
                                              y, channels, H, W, Ho, Wo, pad_t, pad_l, act, pool_partial, in_scale, in_shift, (int)nplanes, se)
     // the LDS-tiled form: BN0 + swish prologue, whole output rows per workgroup (same thread -> output map, same partials)
     const int wq = Wo / 4;
@@ -462,8 +464,9 @@ static int depthwise_conv_launch(const float* x, int32_t batch, int32_t channels
     if (in_scale && (nplanes >= 8192 || k == 5) && threads == 256 && (Wo & 3) == 0 && threads % wq == 0 && (k == 3 || k == 5) &&
         (stride == 1 || stride == 2)) {
         const int rows_out = threads / wq, rows_in = (rows_out - 1) * stride + k, tw = ((Wo - 1) * stride + k + 3) & ~3;
-        const size_t lds = (size_t)rows_in * tw * sizeof(float);
-        if (lds <= 64 * 1024) {
+        const size_t tile_lds = (size_t)rows_in * tw * sizeof(float);
+        const size_t lds = tile_lds > se_lds ? tile_lds : se_lds;
+        if (tile_lds <= 64 * 1024) {
 #define HS_DWT(KK, SS) hipLaunchKernelGGL((depthwise_conv_kernel<KK, SS, -1, true>), grid, dim3(threads), lds, s, x, w, scale, shift, y, \
                                           channels, H, W, Ho, Wo, pad_t, pad_l, act, pool_partial, in_scale, in_shift, (int)nplanes, se)
             if (k == 3 && stride == 1) HS_DWT(3, 1); else if (k == 3) HS_DWT(3, 2); else if (stride == 1) HS_DWT(5, 1); else HS_DWT(5, 2);

@@ -218,7 +218,7 @@ void mbconv_expand_dw_kernel(MbxArgs a) {
         }
         __syncthreads();               // h1 is rewritten by the next chunk's pw
     }
-    if (a.se.ws) {                     // h1 is free now (>= 16 x 364 floats > SE_LDS_FLOATS)
+    if (a.se.ws) {                     // h1 is free now (the host sized the segment for the tail as well)
         const long per_b = (long)ntiles * a.ngroups;
         se_tail_run(a.se, b, (long)blockIdx.x - (long)b * per_b, per_b, se_gen, h1);
     }
@@ -227,7 +227,12 @@ void mbconv_expand_dw_kernel(MbxArgs a) {
 template <int K, int S, int OTH, int OTW, int KS>
 static int launch_mbx(const MbxArgs& a, int batch, hipStream_t stream) {
     using G = MbxGeom<K, S, OTH, OTW>;
-    const size_t lds = (size_t)16 * G::H1P * sizeof(float);
+    size_t lds = (size_t)16 * G::H1P * sizeof(float);
+    if (a.se.ws) {
+        const size_t tail = (size_t)se_lds_floats(a.se.Csq) * sizeof(float);
+        if (tail > 64 * 1024) return HS_ERR_UNSUPPORTED;
+        if (tail > lds) lds = tail;
+    }
     const size_t blocks = (size_t)batch * a.tiles_y * a.tiles_x * a.ngroups;
     if (blocks > 0x7fffffffu) return HS_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((mbconv_expand_dw_kernel<K, S, OTH, OTW, KS>), dim3((unsigned)blocks), dim3(256), lds, stream, a);

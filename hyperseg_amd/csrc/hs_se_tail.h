@@ -34,8 +34,10 @@ typedef __attribute__((address_space(1))) unsigned se_gu32;
 #define SE_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 constexpr int SE_SPIN_LIMIT = 1 << 17;
-constexpr int SE_MAX_TAILS = 32, SE_MAX_L = 128, SE_MAX_CSQ = 128, SE_MAX_STAGE = 2048;
-constexpr int SE_LDS_FLOATS = SE_MAX_STAGE + SE_MAX_L + SE_MAX_L + SE_MAX_CSQ + 4 * SE_MAX_L;      // stage | mean | (pad rows) | z | red
+constexpr int SE_MAX_TAILS = 32, SE_MAX_L = 64, SE_MAX_CSQ = 96, SE_MAX_STAGE = 2048, SE_STAGE = 2560;
+// LDS of a tail (floats): stage (partials [L][nblk + 1], later the z shares [T][Csq]) | mean [64] | z [SE_MAX_CSQ] | gate partial sums
+// [4][64] | this slice's reduce weights [Csq][64] | expand weights [Csq][64]  -- 17 KB at Csq = 10, 53 KB at Csq = 80
+__host__ __device__ inline int se_lds_floats(int Csq) { return SE_STAGE + 64 + SE_MAX_CSQ + 4 * 64 + 2 * 64 * Csq; }
 
 struct SeTail {                           // by value in the kernarg segment; ws == nullptr: plain pool partials, no tail
     const float* w1; const float* b1;     // reduce conv (Csq, C), (Csq)
@@ -55,12 +57,11 @@ __host__ __device__ inline size_t se_ws_words(const SeTail& t) { return se_ws_pg
 inline bool se_tail_plan(int C, int Csq, int nblk, long wgs_per_batch, int& T, int& L) {
     if (C <= 0 || Csq <= 0 || Csq > SE_MAX_CSQ || nblk <= 0 || nblk > SE_MAX_STAGE / 4) return false;
     L = SE_MAX_STAGE / nblk;
-    if (L > 64) L = 64;                   // <= 64 channels per tail: its expand-weight slice is <= Csq x 256 bytes
+    if (L > SE_MAX_L) L = SE_MAX_L;       // <= 64 channels per tail: one lane per channel, weight rows of 256 bytes
     L &= ~3;
     if (L < 4) return false;
     T = (C + L - 1) / L;
-    if (T > SE_MAX_TAILS) { L = ((C + SE_MAX_TAILS - 1) / SE_MAX_TAILS + 3) & ~3; T = (C + L - 1) / L; }
-    if (L > SE_MAX_L || (long)L * nblk > SE_MAX_STAGE || T > SE_MAX_TAILS || T > wgs_per_batch) return false;
+    if (T > SE_MAX_TAILS || (long)T * Csq > SE_STAGE || T > wgs_per_batch) return false;
     return true;
 }
 
@@ -104,8 +105,13 @@ __device__ __forceinline__ bool se_gather(se_gu64* (&g)[NQ], const bool (&need)[
 }
 
 // Called by EVERY workgroup of the launch after its last partial has been published; `widx` = the workgroup's index among the
-// `total` workgroups of batch element b (any fixed order), `lds` = SE_LDS_FLOATS floats nobody else uses any more.  All threads of
-// the workgroup call it together (it has barriers); the blockDim.x must be a multiple of 64.
+// `total` workgroups of batch element b (any fixed order), `lds` = se_lds_floats(Csq) floats nobody else uses any more.  All threads of
+// the workgroup call it together (it has barriers); blockDim.x must be a multiple of 64.
+//
+// A tail is a chain of dependent round trips, so everything that does not depend on another workgroup is requested FIRST: the slice's
+// reduce / expand weight rows go to LDS by LDS-DMA (no registers, all rows in flight; first version: loaded in batches of 8 rows where
+// they were needed -- 2 + Csq / 16 more round trips, 6-12 us per tail, visit r5v7), the biases to registers; each of the two waits
+// (partials, z shares) is ONE gather spread over all threads.
 __device__ __forceinline__ void se_tail_run(const SeTail& t, int b, long widx, long total, unsigned tag, float* lds) {
     const long s_l = total - 1 - widx;
     if (s_l >= t.T) return;                                          // uniform: not a tail
@@ -113,107 +119,95 @@ __device__ __forceinline__ void se_tail_run(const SeTail& t, int b, long widx, l
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, nw = nthr >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // uniform: row addresses below stay in scalar registers
     const int C = t.C, Csq = t.Csq, nblk = t.nblk, T = t.T;
-    const int c0 = s * t.L, Ls = min(t.L, C - c0);                   // this tail's channels [c0, c0 + Ls); Ls >= 1 by the plan
-    float* stage = lds;                                              // [Ls][nblk + 1]
-    float* mean = lds + SE_MAX_STAGE + SE_MAX_L;                     // [Ls]   (stage rows are padded by one word: <= SE_MAX_STAGE + L)
-    float* zs = mean + SE_MAX_L;                                     // [Csq]
-    float* red = zs + SE_MAX_CSQ;                                    // [<= 4][SE_MAX_L] partial gate sums
+    const int c0 = s * t.L, Ls = min(t.L, C - c0);                   // this tail's channels [c0, c0 + Ls); 1 <= Ls <= 64 by the plan
+    float* stage = lds;
+    float* mean = lds + SE_STAGE;                                    // [64], zero past Ls
+    float* zs = mean + 64;                                           // [Csq]
+    float* red = zs + SE_MAX_CSQ;                                    // [<= 4][64] partial gate sums
+    float* w1s = red + 4 * 64;                                       // [Csq][64]: row j = w1[j][c0 + lane]
+    float* w2s = w1s + 64 * Csq;                                     // [Csq][64]: row j = w2t[j][c0 + lane]
     se_gu64* zg = (se_gu64*)t.ws + se_ws_zg(t) + (size_t)b * T * Csq;
     se_gu64* pg = (se_gu64*)t.ws + se_ws_pg(t) + ((size_t)b * C + c0) * nblk;
     bool good = true;
 
+    // ---- 0. weights of the slice -> LDS (lane l of a row -> its word l; lanes past the slice re-read its last channel, times mean 0)
+    const int cl = min(lane, Ls - 1);
+    for (int j = wave; j < Csq; j += nw) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(t.w1 + (size_t)j * C + c0 + cl),
+                                         (__attribute__((address_space(3))) void*)(w1s + j * 64), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(t.w2t + (size_t)j * C + c0 + cl),
+                                         (__attribute__((address_space(3))) void*)(w2s + j * 64), 4, 0, 0);
+    }
+    const float b1v = t.b1[min(tid, Csq - 1)], b2v = t.b2[c0 + cl];
+
     // ---- 1. the slice's pool partials -> means
     const int units = Ls * nblk;                                     // <= SE_MAX_STAGE, contiguous granules
-    for (int e0 = tid; e0 < units; e0 += nthr * 4) {
-        se_gu64* g[4]; bool need[4]; float v[4];
+    for (int e0 = tid; e0 < units; e0 += nthr * 8) {
+        se_gu64* g[8]; bool need[8]; float v[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const int e = e0 + q * nthr; need[q] = e < units; g[q] = pg + min(e, units - 1); }
-        good &= se_gather<4>(g, need, tag, v);
+        for (int q = 0; q < 8; ++q) { const int e = e0 + q * nthr; need[q] = e < units; g[q] = pg + min(e, units - 1); }
+        good &= se_gather<8>(g, need, tag, v);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 8; ++q) {
             const int e = e0 + q * nthr;
             if (e < units) { const int ch = e / nblk; stage[ch * (nblk + 1) + (e - ch * nblk)] = v[q]; }
         }
     }
     __syncthreads();
-    for (int ch = tid; ch < Ls; ch += nthr) {
+    for (int ch = tid; ch < 64; ch += nthr) {
         const float* run = stage + ch * (nblk + 1);
         float a = 0.0f;
-        for (int i = 0; i < nblk; ++i) a += run[i];
+        if (ch < Ls)
+            for (int i = 0; i < nblk; ++i) a += run[i];
         mean[ch] = a * t.inv_hw;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's weight rows have landed
     __syncthreads();
 
-    // ---- 2. this slice's share of every squeezed channel: wave = row j, lanes = the slice's channels (L <= 128: two per lane)
+    // ---- 2. this slice's share of every squeezed channel: wave = row j, lane = channel
     {
-        const int ca = min(lane, Ls - 1), cb = min(lane + 64, Ls - 1);
-        const float ma = lane < Ls ? mean[ca] : 0.0f, mb = lane + 64 < Ls ? mean[cb] : 0.0f;
-        const bool two = Ls > 64;                                    // uniform
-        for (int j0 = wave; j0 < Csq; j0 += nw * 8) {
-            float wa[8], wb[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const float* row = t.w1 + (size_t)min(j0 + u * nw, Csq - 1) * C + c0;
-                wa[u] = row[ca];
-                wb[u] = two ? row[cb] : 0.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = j0 + u * nw;
-                const float p = wave_sum64(fmaf(wa[u], ma, wb[u] * mb));
-                if (j < Csq && lane == 0) se_publish((se_u64*)t.ws, se_ws_zg(t) + ((size_t)b * T + s) * Csq + j, p, tag);
-            }
+        const float m = mean[lane];
+        for (int j = wave; j < Csq; j += nw) {
+            const float p = wave_sum64(w1s[j * 64 + lane] * m);
+            if (lane == 0) se_publish((se_u64*)t.ws, se_ws_zg(t) + ((size_t)b * T + s) * Csq + j, p, tag);
         }
     }
 
     // ---- 3. every slice's share -> z (slice order: the same sum in every tail)
-    for (int jb = 0; jb < Csq; jb += nthr) {                         // (one pass unless the workgroup is a single wave and Csq > 64)
-        const int jt = jb + tid, j = min(jt, Csq - 1);
-        float a = 0.0f;
-        for (int s0 = 0; s0 < T; s0 += 4) {
-            se_gu64* g[4]; bool need[4]; float v[4];
+    const int nz = T * Csq;                                          // <= SE_STAGE
+    for (int e0 = tid; e0 < nz; e0 += nthr * 8) {
+        se_gu64* g[8]; bool need[8]; float v[8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { need[q] = s0 + q < T && jt < Csq; g[q] = zg + (size_t)min(s0 + q, T - 1) * Csq + j; }
-            good &= se_gather<4>(g, need, tag, v);
+        for (int q = 0; q < 8; ++q) { const int e = e0 + q * nthr; need[q] = e < nz; g[q] = zg + min(e, nz - 1); }
+        good &= se_gather<8>(g, need, tag, v);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) if (s0 + q < T) a += v[q];
-        }
-        if (jt < Csq) {
-            const float z = swishf(a + t.b1[j]);
-            zs[jt] = z;
-            if (s == 0 && t.z_out) t.z_out[(size_t)b * Csq + jt] = z;
-        }
+        for (int q = 0; q < 8; ++q) { const int e = e0 + q * nthr; if (e < nz) stage[e] = v[q]; }
     }
     good = __syncthreads_and(good);                                  // one verdict for the workgroup
+    for (int j = tid; j < Csq; j += nthr) {
+        float a = 0.0f;
+        for (int s2 = 0; s2 < T; ++s2) a += stage[s2 * Csq + j];
+        const float z = swishf(a + (j == tid ? b1v : t.b1[j]));
+        zs[j] = z;
+        if (s == 0 && t.z_out) t.z_out[(size_t)b * Csq + j] = z;
+    }
+    __syncthreads();
 
-    // ---- 4. the slice's gates: thread = (channel, part of the squeezed channels), parts summed in order
+    // ---- 4. the slice's gates: thread = (channel, wave's share of the squeezed channels), shares summed in wave order
     {
-        const int Lp = Ls > 64 ? 128 : 64;
-        const int nparts = nthr >= Lp ? min(nthr / Lp, 4) : 1;       // nthr = 64 with Ls > 64: two passes below
-        for (int cbase = 0; cbase < Ls; cbase += (nthr >= Lp ? Lp : nthr)) {
-            const int span = nthr >= Lp ? Lp : nthr;
-            const int cl = cbase + tid % span, part = __builtin_amdgcn_readfirstlane(tid / span);      // span = 64 k: uniform per wave
-            const int cc = c0 + min(cl, Ls - 1);
-            float acc = 0.0f;
-            if (part < nparts) {
-                const int jq = (Csq + nparts - 1) / nparts, ja = part * jq, jb = min(ja + jq, Csq);
-                for (int j0 = ja; j0 < jb; j0 += 16) {
-                    float wv[16];
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) wv[u] = t.w2t[(size_t)min(j0 + u, Csq - 1) * C + cc];
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) if (j0 + u < jb) acc = fmaf(wv[u], zs[j0 + u], acc);
-                }
-                red[part * SE_MAX_L + (cl - cbase)] = acc;
-            }
-            __syncthreads();
-            if (part == 0 && cl < Ls) {
-                float a = red[cl - cbase];
-                for (int p = 1; p < nparts; ++p) a += red[p * SE_MAX_L + (cl - cbase)];
-                const float gv = sigmoidf_fast(a + t.b2[cc]);
-                t.gate[(size_t)b * C + cc] = good ? gv : __int_as_float(0x7fc00000);
-            }
-            __syncthreads();
+        const int nparts = min(nw, 4);
+        const int jq = (Csq + nparts - 1) / nparts, ja = wave * jq, jb = min(ja + jq, Csq);
+        float acc = 0.0f;
+        if (wave < nparts) {
+            for (int j = ja; j < jb; ++j) acc = fmaf(w2s[j * 64 + lane], zs[j], acc);
+            red[wave * 64 + lane] = acc;
+        }
+        __syncthreads();
+        if (wave == 0 && lane < Ls) {
+            float a = red[lane];
+            for (int p = 1; p < nparts; ++p) a += red[p * 64 + lane];
+            const float gv = sigmoidf_fast(a + b2v);
+            t.gate[(size_t)b * C + c0 + lane] = good ? gv : __int_as_float(0x7fc00000);
         }
     }
     if (!good && tid == 0) __hip_atomic_store((se_gu32*)(t.ws + t.B), 1u, SE_RLX_AGENT);

@@ -368,7 +368,7 @@ int hs_depthwise_pool_blocks(int32_t Ho, int32_t Wo);
  * aligned, ZERO before its first use and owned by one launch at a time (two streams need two); the launches keep it consistent.
  * Its word [batch] is an error flag: nonzero after a launch whose bounded waits gave up (the gate is then NaN).
  * hs_se_tail_workspace returns 0 -- and the launches HS_ERR_UNSUPPORTED -- for shapes the tail does not cover
- * (c_squeezed > 128, > 512 partials per channel, fewer workgroups than tails). */
+ * (c_squeezed > 96, > 512 partials per channel, more than 32 tails of <= 64 channels, fewer workgroups than tails). */
 typedef struct hs_se_tail {
     const float* w_reduce;    /* (c_squeezed, channels)            efficientnet.py:107 _se_reduce */
     const float* b_reduce;    /* (c_squeezed) */

@@ -510,7 +510,7 @@ def test_se_tail_plan_on_the_host():
         assert per <= 64 + 3 and per * nblk <= 2048 + 3 * nblk, (c, nblk, t)
         words = lib.hs_se_tail_workspace(2, c, csq, nblk, wgs) // 8
         assert words == 2 + 1 + 2 * t * csq + 2 * c * nblk
-    assert lib.hs_se_tail_tails(64, 200, 1, 64) == 0            # > 128 squeezed channels
+    assert lib.hs_se_tail_tails(64, 200, 1, 64) == 0            # > 96 squeezed channels
     assert lib.hs_se_tail_tails(64, 8, 1024, 64 * 1024) == 0    # > 512 partials per channel
     assert lib.hs_se_tail_tails(640, 8, 1, 4) == 0              # fewer workgroups than tails
     assert lib.hs_se_tail_workspace(1, 64, 200, 1, 64) == 0
