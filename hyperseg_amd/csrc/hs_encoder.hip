@@ -314,12 +314,24 @@ void se_excite_kernel(const float* __restrict__ z, const float* __restrict__ w2t
 // rows -- is issued before the first use (one memory round trip), a wave owns whole reduce rows (no block-wide reductions in
 // the squeeze), and only two barriers separate the phases: a dependent launch in a replayed graph costs 1.6-2.2 us on this
 // box (profiles/round2_graph_launch_floor.txt) while the squeeze launch it removes took 4.6 us.
-constexpr int SEF_MAX_C = 768, SEF_MAX_CSQ = 32, SEF_MAX_UNITS = 2048;
+// Round 5: a second instantiation <24, 1> for the EARLY blocks (C <= 256 but 64-256 pool partials per channel: 2304-6144 units), which
+// used to take the two-launch route only because their partial sums did not fit the 8 loads per thread: 24 loads per thread, one
+// 256-channel column block of the reduce weights.
+// MEASURED NEGATIVE (visit r5v10, profiles/round5_se_tail_negative.txt): 0.7836 / 0.7855 ms per HyperSeg-M frame with it against 0.7760 /
+// 0.7768 without, same box, interleaved -- every one of the 2-4 workgroups walks all 18-24 k partial sums and then adds 64-256 of them per
+// channel serially, which costs more than the launch it saves.  Kept behind the build switch (tests/test_hip_encoder.py::test_se_gate
+// covers the shapes either way); the product build leaves those blocks on the two-launch route.
+#ifndef HS_SE_FUSED_WIDE
+#define HS_SE_FUSED_WIDE 0
+#endif
+constexpr int SEF_MAX_CSQ = 32;
+template <int PV, int W1U>
 __global__ __launch_bounds__(256)
 void se_gate_fused_kernel(const float* __restrict__ partial, int nblk, float inv_hw, const float* __restrict__ w1,
                           const float* __restrict__ b1, const float* __restrict__ w2t, const float* __restrict__ b2, int C,
                           int Csq, float* __restrict__ z_out, float* __restrict__ gate, const float* __restrict__ w_proj,
                           int Cout, const float* __restrict__ out_scale, float* __restrict__ w_scaled) {
+    constexpr int SEF_MAX_C = 256 * W1U, SEF_MAX_UNITS = 256 * PV;
     __shared__ __attribute__((aligned(16))) float mean_c[SEF_MAX_C];
     __shared__ float se_part[SEF_MAX_UNITS + SEF_MAX_C];     // per-channel runs of partial sums, one pad word per channel
     __shared__ float zs[SEF_MAX_CSQ];
@@ -333,13 +345,13 @@ void se_gate_fused_kernel(const float* __restrict__ partial, int nblk, float inv
     const bool vec = (nblk & 3) == 0;
     const int qn = vec ? nblk >> 2 : nblk, units = C * qn;                          // <= SEF_MAX_UNITS
     const float* __restrict__ pb = partial + (size_t)b * C * nblk;
-    float4 pv[8];
+    float4 pv[PV];
     if (vec) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) pv[k] = reinterpret_cast<const float4*>(pb)[min(tid + 256 * k, units - 1)];
+        for (int k = 0; k < PV; ++k) pv[k] = reinterpret_cast<const float4*>(pb)[min(tid + 256 * k, units - 1)];
     } else {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) pv[k] = make_float4(pb[min(tid + 256 * k, units - 1)], 0.0f, 0.0f, 0.0f);
+        for (int k = 0; k < PV; ++k) pv[k] = make_float4(pb[min(tid + 256 * k, units - 1)], 0.0f, 0.0f, 0.0f);
     }
     float wp[16], osc[16];
     if (w_proj) {
@@ -354,15 +366,15 @@ void se_gate_fused_kernel(const float* __restrict__ partial, int nblk, float inv
 #pragma unroll
     for (int u = 0; u < 8; ++u) w2v[u] = w2t[(size_t)min(j0 + u, Csq - 1) * C + cc];
     const float b2v = b2[cc];
-    const int c4 = C >> 2;                                                          // C % 4 == 0, c4 <= 192
-    float4 w1v[8][3];
+    const int c4 = C >> 2;                                                          // C % 4 == 0, c4 <= 64 W1U
+    float4 w1v[8][W1U];
     float b1v[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int j = min(wave + 4 * r, Csq - 1);
         b1v[r] = b1[j];
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
+        for (int u = 0; u < W1U; ++u) {
             w1v[r][u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (4 * r < Csq && 64 * u < c4)                                         // uniform: rows / columns that exist
                 w1v[r][u] = reinterpret_cast<const float4*>(w1 + (size_t)j * C)[min(lane + 64 * u, c4 - 1)];
@@ -370,7 +382,7 @@ void se_gate_fused_kernel(const float* __restrict__ partial, int nblk, float inv
     }
     // ---- phase A: channel means
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < PV; ++k) {
         const int e = tid + 256 * k;
         if (e < units) {
             const int ch = e / qn;
@@ -386,9 +398,9 @@ void se_gate_fused_kernel(const float* __restrict__ partial, int nblk, float inv
     }
     __syncthreads();
     // ---- phase B: squeezed activations, wave w owns rows w, w + 4, ...; sums over the wave on the DPP path
-    float4 mv[3];
+    float4 mv[W1U];
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
+    for (int u = 0; u < W1U; ++u) {
         const int k = lane + 64 * u;
         mv[u] = *reinterpret_cast<const float4*>(mean_c + 4 * min(k, c4 - 1));
         if (k >= c4) mv[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -398,7 +410,7 @@ void se_gate_fused_kernel(const float* __restrict__ partial, int nblk, float inv
         if (4 * r < Csq) {                                                          // uniform
             float a = 0.0f;
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
+            for (int u = 0; u < W1U; ++u) {
                 a = fmaf(w1v[r][u].x, mv[u].x, a); a = fmaf(w1v[r][u].y, mv[u].y, a);
                 a = fmaf(w1v[r][u].z, mv[u].z, a); a = fmaf(w1v[r][u].w, mv[u].w, a);
             }
@@ -536,8 +548,14 @@ extern "C" int hs_se_gate_fwd(const float* partial, int32_t batch, int32_t chann
     hipStream_t s = (hipStream_t)stream;
     const int row_groups = w_proj ? (c_out + 63) / 64 : 1;
     const long units = (long)channels * ((nblk & 3) == 0 ? nblk >> 2 : nblk);
-    if ((channels & 3) == 0 && channels <= SEF_MAX_C && c_squeezed <= SEF_MAX_CSQ && units <= SEF_MAX_UNITS) {
-        hipLaunchKernelGGL(se_gate_fused_kernel, dim3((channels + 63) / 64, batch, row_groups), dim3(256), 0, s, partial, nblk,
+    if ((channels & 3) == 0 && channels <= 768 && c_squeezed <= SEF_MAX_CSQ && units <= 2048) {
+        hipLaunchKernelGGL((se_gate_fused_kernel<8, 3>), dim3((channels + 63) / 64, batch, row_groups), dim3(256), 0, s, partial, nblk,
+                           inv_hw, w_reduce, b_reduce, w_expand, b_expand, channels, c_squeezed, squeezed, gate, w_proj, c_out,
+                           out_scale, w_scaled);
+        return launch_status();
+    }
+    if (HS_SE_FUSED_WIDE && (channels & 3) == 0 && channels <= 256 && c_squeezed <= SEF_MAX_CSQ && units <= 6144) {
+        hipLaunchKernelGGL((se_gate_fused_kernel<24, 1>), dim3((channels + 63) / 64, batch, row_groups), dim3(256), 0, s, partial, nblk,
                            inv_hw, w_reduce, b_reduce, w_expand, b_expand, channels, c_squeezed, squeezed, gate, w_proj, c_out,
                            out_scale, w_scaled);
         return launch_status();

@@ -794,7 +794,10 @@ class ExclusiveWorkspaces:
 
 
 SE_WORKSPACES = ExclusiveWorkspaces()
-SE_TAIL = os.environ.get('HS_SE_TAIL', '1') != '0'      # A/B switch: 0 = the squeeze-excite gate as its own launch(es), hs_se_gate_fwd
+# Opt-in (HS_SE_TAIL=1): measured on the MI355X (visits r5v7 / r5v8, profiles/round5_se_tail_negative.txt) the tails are correct
+# (tests/test_hip_encoder.py runs them whatever this says) but cost 5-9 us per block -- two memory-side hand-offs of ~2.5 us each --
+# against the 5.3 / 9.6 us of the launches they remove: 0.796 ms per HyperSeg-M frame against 0.776.
+SE_TAIL = os.environ.get('HS_SE_TAIL', '0') != '0'
 
 
 def se_tail_descriptor(device, batch, channels, nblk, wgs_per_batch, w_reduce, b_reduce, w_expand_t, b_expand):

@@ -131,7 +131,9 @@ def test_mbconv_expand_dw(HF, dev, cin, cmid, k, stride, h, w):
 
 
 @pytest.mark.parametrize('c,csq,nblk,cout', [(32, 8, 128, 16), (96, 4, 32, 24), (240, 10, 8, 40), (672, 28, 2, 112),
-                                             (1152, 48, 1, 320), (1920, 80, 1, 320), (50, 3, 5, 7)])
+                                             (1152, 48, 1, 320), (1920, 80, 1, 320), (50, 3, 5, 7),
+                                             # the early blocks' shapes (64-256 partials per channel): the wide one-launch form of round 5
+                                             (96, 4, 256, 24), (144, 6, 128, 24), (240, 10, 64, 40), (100, 5, 51, 7)])
 @pytest.mark.parametrize('batch', [1, 2])
 def test_se_gate(HF, dev, c, csq, nblk, cout, batch):
     g = torch.Generator().manual_seed(c + csq)
@@ -169,11 +171,12 @@ SE_DW_CASES = [(32, 8, 3, 1, 64, 128, False), (480, 20, 5, 1, 32, 64, True), (67
 
 @pytest.mark.parametrize('c,csq,k,stride,h,w,pre', SE_DW_CASES)
 @pytest.mark.parametrize('batch', [1, 2])
-def test_depthwise_conv_finishes_the_se_gate(HF, dev, c, csq, k, stride, h, w, pre, batch):
+def test_depthwise_conv_finishes_the_se_gate(HF, dev, monkeypatch, c, csq, k, stride, h, w, pre, batch):
     """hs_depthwise_conv_se_fwd (round 5, csrc/hs_se_tail.h): the pooling launch's last workgroups compute the squeeze-excite gate
     (efficientnet.py:106-111) -- same activation as the plain launch bit for bit, gate against fp32 PyTorch and against
     hs_se_gate_fwd on the plain launch's partial sums; three launches in a row on the same workspace (its generation words move),
     error word clear."""
+    monkeypatch.setattr(HF, 'SE_TAIL', True)               # opt-in in the product (functional.SE_TAIL): a measured negative, kept correct
     g = torch.Generator().manual_seed(c * 3 + csq + k + h)
     x = torch.randn(batch, c, h, w, generator=g)
     wt = torch.randn(c, 1, k, k, generator=g) * 0.3
@@ -207,8 +210,9 @@ def test_depthwise_conv_finishes_the_se_gate(HF, dev, c, csq, k, stride, h, w, p
 @pytest.mark.parametrize('cin,cmid,csq,k,stride,h,w', [(16, 96, 4, 3, 2, 64, 128), (24, 144, 6, 3, 1, 32, 48), (24, 144, 6, 5, 2, 50, 70),
                                                        (40, 240, 10, 5, 1, 33, 47), (40, 100, 7, 3, 2, 31, 45), (80, 480, 20, 3, 1, 16, 32),
                                                        (6, 20, 2, 3, 1, 9, 9), (16, 96, 4, 3, 2, 256, 256)])
-def test_mbconv_expand_dw_finishes_the_se_gate(HF, dev, cin, cmid, csq, k, stride, h, w):
+def test_mbconv_expand_dw_finishes_the_se_gate(HF, dev, monkeypatch, cin, cmid, csq, k, stride, h, w):
     """hs_mbconv_expand_dw_se_fwd: as above for the fused expand + depthwise launch (many tiles per channel, chunk groups)."""
+    monkeypatch.setattr(HF, 'SE_TAIL', True)               # opt-in in the product (functional.SE_TAIL): a measured negative, kept correct
     g = torch.Generator().manual_seed(cin * 7 + cmid + k + stride)
     b = 2
     x = torch.randn(b, cin, h, w, generator=g)
@@ -233,10 +237,11 @@ def test_mbconv_expand_dw_finishes_the_se_gate(HF, dev, cin, cmid, csq, k, strid
         assert rel_err(gate.cpu(), gate0.cpu()) < 2e-6
 
 
-def test_se_tail_under_graph_replay_and_two_streams(HF, dev):
+def test_se_tail_under_graph_replay_and_two_streams(HF, dev, monkeypatch):
     """The tail's workspace carries state from launch to launch: (a) a captured launch keeps working over many replays WITHOUT a
     zero-fill inside the graph (functional.ExclusiveWorkspaces hands the capture a prepared buffer), (b) two streams get two
     buffers, so interleaved launches of the same block from two streams do not trample each other."""
+    monkeypatch.setattr(HF, 'SE_TAIL', True)               # opt-in in the product (functional.SE_TAIL): a measured negative, kept correct
     c, csq, k, h, w = 480, 20, 5, 32, 64
     g = torch.Generator().manual_seed(5)
     x = torch.randn(1, c, h, w, generator=g).to(dev)
@@ -311,6 +316,40 @@ def test_prepared_encoder_matches_stock(dev, batch, size):
         assert rel_err(yf, ys) < 1e-4
         # twice: the in-place skip accumulation must not corrupt anything that outlives a forward
         assert rel_err(fused(x).cpu(), ys) < 1e-4
+
+
+def test_prepared_encoder_with_se_tails_matches_without(dev, monkeypatch):
+    """The benched encoder configuration (split GEMMs) with every covered block's squeeze-excite gate finished by its pooling launch
+    (functional.SE_TAIL, opt-in) against the default route, eagerly and as a HIP-graph replay (the tails' workspaces carry state from
+    replay to replay; no zero-fill may have been captured)."""
+    from hyperseg_amd import configs, functional as HF
+    from hyperseg_amd.utils.inference import prepare_for_inference, GraphedModel
+    from hyperseg_amd.utils.synthetic import fill_by_name
+    m = fill_by_name(configs.build('hyperseg-m').eval(), seed=7)
+    prepare_for_inference(m, fold_bn=False, fused_depthwise=True, split_gemm=True)
+    m = m.to(dev)
+    x = torch.rand(1, 3, 256, 512, generator=G(1003)).to(dev)
+    with torch.no_grad():
+        y0 = m(x).clone()
+        monkeypatch.setattr(HF, 'SE_TAIL', True)
+        launches = {'n': 0}
+        real = HF.se_tail_descriptor
+
+        def counting(*a, **k):
+            out = real(*a, **k)
+            launches['n'] += out is not None
+            return out
+        monkeypatch.setattr(HF, 'se_tail_descriptor', counting)
+        y1 = m(x).clone()
+        assert launches['n'] >= 20, launches                 # 23 MBConv blocks; the ones whose project conv folds the gate keep hs_se_gate_fwd
+        assert rel_err(y1.cpu(), y0.cpu()) < 2e-5
+        fills = HF.SE_WORKSPACES.captured_zero_fills
+        gm = GraphedModel(m)
+        for _ in range(4):
+            yg = gm(x)
+            torch.cuda.synchronize()
+            assert torch.equal(yg, y1)
+        assert HF.SE_WORKSPACES.captured_zero_fills == fills
 
 
 @pytest.mark.parametrize('split_gemm', [True, False], ids=['split_gemm', 'library_gemm'])
