@@ -172,6 +172,127 @@ void signal2weights_blocked_kernel(S2bArgs a) {
     s2b_body((const __attribute__((address_space(4))) S2bArgs*)__builtin_amdgcn_kernarg_segment_ptr(), (int)blockIdx.x, lds);
 }
 
+// ------------------------------------------------------------------------------------------
+// The blocked form as a STREAM (round 5; VERDICT r4 #5a): fewer workgroups, each walking several 64-row x 64-patch blocks with the
+// NEXT fill's LDS-DMA in flight while the current block is multiplied, staged and stored.
+// In the one-block-per-workgroup launch above all 8832 waves are resident from the first cycle and in the same phase at the same
+// time -- the DMA burst, the matrix-core phase and 32 MB of stores follow each other chip-wide (profiles/round3_pmc_k1_and_s2w.txt), 16 us
+// where the stores alone need ~8.  Here a workgroup owns two operand buffers (2 x 20 KB: four workgroups per CU): per fill it waits
+// for the fill to land, requests the next one (the next K chunk of the block, or the first chunk of its next block, blocks strided by
+// the grid so that every workgroup gets heavy and light layers alike) into the other buffer, multiplies, and when the block is complete
+// sends D out through the buffer it has just consumed.  Same blocks, same instruction, same k order: bit-identical banks.
+// (vmcnt counts stores as well and is only ordered among operations of one kind, so the wait at the top is vmcnt(0): it also waits for
+// the previous block's store acknowledgements -- by then the next fill has been in flight for a whole block.)
+// ------------------------------------------------------------------------------------------
+// MEASURED NEGATIVE (visit r5v11, profiles/round5_s2w_stream_negative.txt): 19.5 us against 16.3 at HyperSeg-M, 23.6 against 19.3 at S,
+// whole frame 0.779 against 0.775 ms -- 736 workgroups x 3 blocks keep 12 waves per CU where the one-block form keeps 32, and the walk
+// is wait -> barrier -> products -> barrier -> stage -> barrier -> stores per block with nothing of the SAME workgroup to overlap but the
+// next fill.  Off in the product build (-DHS_S2B_STREAM=1 builds it; parity is the same tests either way).
+#ifndef HS_S2B_STREAM
+#define HS_S2B_STREAM 0
+#endif
+constexpr int S2B_STREAM_WG_PER_CU = 4;
+
+struct S2bBlock {
+    const float* ablk; float* bank; long ld;
+    unsigned sig0;                         // this lane's signal element offset at k = 0
+    int cs_g, KS, n0, rows_left, pb;       // rows_left: valid rows of the block from n0 on (<= 0: none for this lane's row)
+};
+
+__device__ __forceinline__ void s2b_decode(const __attribute__((address_space(4))) S2bArgs* ka, const int wg, const int lane, S2bBlock& b) {
+    int li = 0;
+    for (int q = 1; q < ka->n_layers; ++q)
+        if (wg >= ka->layer[q].wg_begin) li = q;
+    const int rpg = ka->layer[li].rpg, rows = ka->layer[li].rows, KS = ka->layer[li].ks, RB = ka->layer[li].rb;
+    const int cs_g = ka->layer[li].cs_g, grid_sz = ka->grid_sz, PB = ka->pb;
+    const int local = wg - ka->layer[li].wg_begin;
+    const int grb = (int)s2b_div((unsigned)local, ka->m_pb), pb = local - grb * PB;
+    const int g = grb / RB, rb = grb - g * RB;
+    const int pt = lane >> 4, j4 = lane & 3;
+    const int p4 = min(pb * S2B_PATCHES + 16 * pt + 4 * j4, ka->n_patches - 4);
+    const int bb = (int)s2b_div((unsigned)p4, ka->m_grid), ij = p4 - bb * grid_sz;
+    b.sig0 = (unsigned)((bb * ka->c_signal + ka->layer[li].signal_index + g * cs_g) * grid_sz + ij);
+    b.ablk = ka->layer[li].blk + (size_t)((g * RB + rb) * KS) * 256;
+    b.bank = ka->layer[li].bank; b.ld = ka->layer[li].ld;
+    b.cs_g = cs_g; b.KS = KS; b.pb = pb;
+    const int r0 = rb * S2B_ROWS;
+    b.n0 = g * rpg + r0;
+    b.rows_left = min(rpg - r0, rows - b.n0);
+}
+
+__device__ __forceinline__ void s2b_issue_fill(const __attribute__((address_space(4))) S2bArgs* ka, const S2bBlock& b, const int k0,
+                                               float* __restrict__ A, const int wave, const int lane) {
+    float* Bm = A + S2B_KC * 256;
+    const int kn = min(S2B_KC, b.KS - k0), kq = (lane >> 2) & 3;
+    const unsigned grid_sz = (unsigned)ka->grid_sz;
+    for (int c = wave; c < kn; c += 4) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b.ablk + (size_t)(k0 + c) * 256 + lane * 4),
+                                         (__attribute__((address_space(3))) void*)(A + c * 256), 16, 0, 0);
+        const unsigned k = (unsigned)min(4 * (k0 + c) + kq, b.cs_g - 1);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ka->signal + b.sig0 + k * grid_sz),
+                                         (__attribute__((address_space(3))) void*)(Bm + c * 256), 16, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(256)
+void signal2weights_stream_kernel(S2bArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float s2b_lds[];                        // 2 x S2B_LDS_FLOATS
+    const __attribute__((address_space(4))) S2bArgs* ka = (const __attribute__((address_space(4))) S2bArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_wg = ka->n_wg, stride = (int)gridDim.x, n_patches = ka->n_patches;
+    int blk = (int)blockIdx.x, k0 = 0, buf = 0;
+    S2bBlock cur, nxt;
+    s2b_decode(ka, blk, lane, cur);
+    s2b_issue_fill(ka, cur, 0, s2b_lds, wave, lane);
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (;;) {
+        const int kn = min(S2B_KC, cur.KS - k0);
+        const bool last_chunk = k0 + S2B_KC >= cur.KS;                                     // uniform
+        const int nblk = last_chunk ? blk + stride : blk, nk0 = last_chunk ? 0 : k0 + S2B_KC;
+        const bool has_next = nblk < n_wg;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   // this wave's part of the fill (and its earlier stores)
+        __syncthreads();                                                                   // the whole fill; the other buffer is free
+        if (has_next) {
+            if (last_chunk) s2b_decode(ka, nblk, lane, nxt); else nxt = cur;
+            s2b_issue_fill(ka, nxt, nk0, s2b_lds + (buf ^ 1) * S2B_LDS_FLOATS, wave, lane);
+        }
+        float* A = s2b_lds + buf * S2B_LDS_FLOATS;
+        const float* Bm = A + S2B_KC * 256;
+        for (int c = 0; c < kn; ++c) {
+            const float av = A[c * 256 + wave * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Bm[c * 256 + t * 64 + lane], acc[t], 0, 0, 0);
+        }
+        if (last_chunk) {
+            __syncthreads();                                                               // operands dead: the output block takes their place
+            {
+                const int j = lane & 15, q4 = lane >> 4;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        A[(16 * t + j) * (S2B_ROWS + 1) + 16 * wave + 4 * q4 + r] = acc[t][r];
+                        acc[t][r] = 0.0f;
+                    }
+            }
+            __syncthreads();
+            const bool row_ok = lane < cur.rows_left;
+#pragma unroll 4
+            for (int q = 0; q < 16; ++q) {
+                const int pl = wave * 16 + q, p = cur.pb * S2B_PATCHES + pl;
+                const float v = A[pl * (S2B_ROWS + 1) + lane];
+                if (row_ok && p < n_patches) cur.bank[(size_t)p * cur.ld + cur.n0 + lane] = v;
+            }
+        }
+        if (!has_next) break;
+        cur = nxt; blk = nblk; k0 = nk0; buf ^= 1;
+    }
+}
+
 // hs_s2w_pack_fwd: (cs_g, wc) transposed conv weight -> the blocked kernel's LDS images, zero-padded
 __global__ void s2w_pack_kernel(const float* __restrict__ wsw_t, int cs_g, int wc, int groups, int rb_n, int ks_n,
                                 float* __restrict__ out, long total) {
@@ -251,6 +372,18 @@ static int launch_s2w_blocked(const float* signal, int batch, int c_signal, int 
                               const int* order, int n_layers, hipStream_t stream) {
     S2bArgs a;
     if (s2b_fill_args(a, signal, batch, c_signal, fh, fw, layers, order, n_layers) != 0) return 1;
+    // the stream form where there is more than one block per workgroup slot to walk; small launches keep one block per workgroup
+    static const int cus_of_device0 = [] {                                                 // (one process per GPU: every visible device is the same part)
+        int dev = 0, cus = 0;
+        return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) ? cus : 256;
+    }();
+    const int slots = cus_of_device0 * S2B_STREAM_WG_PER_CU;
+    if (HS_S2B_STREAM && a.n_wg > slots) {
+        const int per = (a.n_wg + slots - 1) / slots;                                      // blocks per workgroup (the last ones one fewer)
+        const int wgs = (a.n_wg + per - 1) / per;
+        hipLaunchKernelGGL(signal2weights_stream_kernel, dim3((unsigned)wgs), dim3(256), (size_t)2 * S2B_LDS_FLOATS * sizeof(float), stream, a);
+        return launch_status();
+    }
     hipLaunchKernelGGL(signal2weights_blocked_kernel, dim3((unsigned)a.n_wg), dim3(256), 0, stream, a);
     return launch_status();
 }

@@ -1122,7 +1122,8 @@ def test_dw_tiles_bn_on_load_equals_batchnorm_then_depthwise(dev, patch_major, d
         ref = run(False, torch.float32)
         for k in ('y', 'dt', 'dbank', 'dg', 'db'):
             e_one, e_two = rel_l2(one[k].cpu(), ref[k].cpu()), rel_l2(two[k].cpu(), ref[k].cpu())
-            # no worse than the route that rounds the copy; the absolute bound is bf16's own (the tiles' gradient goes through BatchNorm's
-            # adjoint, whose mean-subtractions cancel: 2.7e-2 measured for BOTH routes, which share those three launches)
-            assert e_one < 4e-2 and e_one < 2.0 * e_two + 1e-3, (k, e_one, e_two)
+            # no worse than the route that rounds the copy.  The absolute bound only catches garbage: it is bf16's own error through
+            # BatchNorm's adjoint, whose mean-subtractions cancel (measured, identical for BOTH routes -- they share those three
+            # launches: dt 2.7e-2, db 4.1e-2 at the patch-major parametrisation)
+            assert e_one < 1e-1 and e_one < 2.0 * e_two + 1e-3, (k, e_one, e_two)
         assert torch.allclose(one['rm'], two['rm'], rtol=1e-5, atol=1e-6) and torch.allclose(one['rv'], two['rv'], rtol=1e-5, atol=1e-6)
