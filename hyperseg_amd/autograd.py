@@ -386,6 +386,97 @@ def dw_tiles_bn(bn, act_layer, t, bank, size, grid, patch_major):
 USE_DW_BN_FUSED = True  # tests switch it off to compare with BNActTrain + DwTilesValid
 
 
+class PatchConvBN(torch.autograd.Function):
+    """BatchNorm (training mode) + activation + the k = 1 per-patch convolution that follows, WITHOUT the normalised copy of the input
+    (round 5; BatchNorm2 + ReLU6 + the last 1 x 1 layer of a train-mode inverted residual, hyperseg_v1_0.py:361-370): forward =
+    hs_bn_train_stats_fwd on the raw hidden map, then hs_patch_conv_bn_fwd (statistics finalised, running estimates updated and the
+    input normalised as it is read) -- two launches where BNActTrain + PatchConv took three.  Backward: the weight gradient from the raw
+    input + saved statistics (hs_patch_conv_bn_bwd_w), the input gradient through the convolution's adjoint and then BatchNorm's own
+    (hs_patch_conv_plain_bwd_in, hs_bn_act_train_bwd).  Same arithmetic per value as the two Functions it replaces."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, act, counter, bank, grid, c_out):
+        if torch.is_autocast_enabled('cuda') and x.is_floating_point():
+            x = x.to(torch.bfloat16)
+        x = x.contiguous()
+        b, c, h, w = x.shape
+        fh, fw = grid
+        if bank.dtype != torch.float32 or bank.stride(1) != 1:
+            bank = bank.float().contiguous()
+        dev = x.device
+        with _hip.device_scope(dev):
+            y = torch.empty(b, c_out, h, w, device=dev, dtype=x.dtype)
+            mean, invstd = torch.empty(c, device=dev, dtype=torch.float32), torch.empty(c, device=dev, dtype=torch.float32)
+            ws = torch.empty(int(_hip.lib.hs_bn_train_workspace(c)), device=dev, dtype=torch.uint8)
+            code = DTYPE_CODES[x.dtype]
+            _hip.check(_hip.lib.hs_bn_train_stats_fwd(code, x.data_ptr(), b, c, h * w, ws.data_ptr(), _hip.stream_ptr()), 'hs_bn_train_stats_fwd')
+            st = _hip.lib.hs_patch_conv_bn_fwd(code, x.data_ptr(), ws.data_ptr(), weight.data_ptr(), bias.data_ptr(),
+                                               running_mean.data_ptr() if running_mean is not None else None,
+                                               running_var.data_ptr() if running_var is not None else None, float(momentum), float(eps), int(act),
+                                               mean.data_ptr(), invstd.data_ptr(), counter.data_ptr() if counter is not None else None,
+                                               bank.data_ptr(), bank.stride(0), b, c, h, w, fh, fw, int(c_out), y.data_ptr(), _hip.stream_ptr())
+            _hip.check(st, 'hs_patch_conv_bn_fwd')
+        ctx.save_for_backward(x, weight, bias, mean, invstd, bank)
+        ctx.meta = (b, c, h, w, (fh, fw), float(eps), int(act), int(c_out))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias, mean, invstd, bank = ctx.saved_tensors
+        b, c, h, w, (fh, fw), eps, act, c_out = ctx.meta
+        dy = dy.contiguous().to(x.dtype)
+        dev = x.device
+        code = DTYPE_CODES[x.dtype]
+        dx = dbank = dg = db = None
+        with _hip.device_scope(dev):
+            stream = _hip.stream_ptr()
+            if ctx.needs_input_grad[9]:
+                alloc = torch.empty if bank.shape[1] == c_out * c else torch.zeros
+                dbank = alloc(bank.shape[0], bank.shape[1], device=dev, dtype=torch.float32)
+                st = _hip.lib.hs_patch_conv_bn_bwd_w(code, x.data_ptr(), dy.data_ptr(), weight.data_ptr(), bias.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                                     act, b, c, h, w, fh, fw, c_out, dbank.data_ptr(), dbank.stride(0), stream)
+                _hip.check(st, 'hs_patch_conv_bn_bwd_w')
+            if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+                da = _conv_input_gradient(x, dy, bank, (fh, fw), c_out)              # gradient of the (never materialised) normalised map, in x's type
+                dx = torch.empty_like(x)
+                dg = torch.empty(c, device=dev, dtype=torch.float32)
+                db = torch.empty(c, device=dev, dtype=torch.float32)
+                ws = torch.empty(int(_hip.lib.hs_bn_train_workspace(c)), device=dev, dtype=torch.uint8)
+                st = _hip.lib.hs_bn_act_train_bwd(code, x.data_ptr(), da.data_ptr(), b, c, h * w, weight.data_ptr(), bias.data_ptr(),
+                                                  mean.data_ptr(), invstd.data_ptr(), eps, act, ws.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), stream)
+                _hip.check(st, 'hs_bn_act_train_bwd')
+        return dx, dg, db, None, None, None, None, None, None, dbank, None, None
+
+
+def _conv_input_gradient(x, dy, bank, grid, c_out):
+    """hs_patch_conv_plain_bwd_in of a k = 1 layer: d input, a map like ``x`` (same storage type)."""
+    return _plain_conv('bwd_in', x.dtype, dy, bank, bank.stride(0), x.shape, (tuple(grid), c_out, 1, 0, 'zeros', 1), torch.empty_like(x))
+
+
+def patch_conv_bn(bn, act_layer, x, bank, grid, c_out):
+    """``patch_conv_apply(bn_act(bn, act_layer, x), bank, grid, c_out, 1, 0, 'zeros', 1)`` as PatchConvBN where the fused training
+    BatchNorm applies, the layer is inside hs_patch_conv_bn_fwd's range (c_out <= 32, <= 64 input channels, patches of >= 64 pixels)
+    and USE_CONV_BN_FUSED; the two Functions otherwise."""
+    act = _bn_hip_act(bn, act_layer, x) if USE_CONV_BN_FUSED and bn.weight is not None else -1
+    b, c, h, w = x.shape
+    fh, fw = grid
+    covered = act >= 0 and c_out <= 32 and c <= 64 and h % fh == 0 and w % fw == 0 and (h // fh) * (w // fw) >= 64 \
+        and (not torch.is_autocast_enabled('cuda') or torch.get_autocast_dtype('cuda') == torch.bfloat16)
+    if not covered:
+        return patch_conv_apply(bn_act(bn, act_layer, x), bank, grid, c_out, 1, 0, 'zeros', 1)
+    nbt = bn.num_batches_tracked
+    in_kernel = nbt is not None and nbt.device == x.device and nbt.dtype == torch.int64
+    y = PatchConvBN.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, act, nbt if in_kernel else None,
+                          bank, tuple(grid), int(c_out))
+    if nbt is not None and not in_kernel:
+        nbt.add_(1)
+    HF.bump_weights_epoch()
+    return y
+
+
+USE_CONV_BN_FUSED = True  # tests switch it off to compare with BNActTrain + PatchConv
+
+
 USE_HIP_BN = True       # tests switch it off to compare with the stock modules
 
 

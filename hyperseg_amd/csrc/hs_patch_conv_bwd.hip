@@ -158,9 +158,19 @@ template <> struct Pair<bf16_t> {
 // store -- hs_common.h Store<T>); the bank and its gradient are fp32 either way (hs_patch_conv_train.hip's header).
 // VEC = 2 (round 4): even patch and image widths -- the halo tiles -- read as aligned PAIRS (two 8-byte loads per lane, operand and chunk,
 // instead of four 4-byte ones; a pair never straddles a patch row).
-template <int MT, int NTI, int VEC, typename T>
+__device__ __forceinline__ float dwt_act(float z, int act) { return act == HS_ACT_RELU ? fmaxf(z, 0.f) : (act == HS_ACT_RELU6 ? fminf(fmaxf(z, 0.f), 6.f) : z); }
+struct ConvBn {
+    const float* __restrict__ partial;        // [cin][BN_CHUNKS][2], or null: mean / invstd are given (the weight gradient)
+    const float* __restrict__ gamma; const float* __restrict__ beta;
+    float* mean; float* invstd; float* running_mean; float* running_var; long long* counter;
+    float eps, momentum, n;                   // n = elements per channel
+    int act;
+};
+// BNL (round 5): the layer's input is act(BatchNorm(x)) with x RAW in memory -- normalised on use from the saved statistics (the weight
+// gradient of patch_conv_bn_fwd_k1m_kernel's layer); a lane's NTI input channels are fixed, so their (scale, shift) sit in registers.
+template <int MT, int NTI, int VEC, typename T, bool BNL = false>
 __global__ __launch_bounds__(256)
-void patch_conv_bwd_weight_k1m_kernel(ConvBwdArgs a) {
+void patch_conv_bwd_weight_k1m_kernel(ConvBwdArgs a, ConvBn bn) {
     static_assert(VEC != 1 || sizeof(T) == 4, "16-byte loads: fp32 storage only (pairs serve both storage types)");
     __shared__ __attribute__((aligned(16))) float red[4][MT * NTI][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -176,6 +186,15 @@ void patch_conv_bwd_weight_k1m_kernel(ConvBwdArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NTI; ++nt) xp[nt] = (const T*)a.x + ((size_t)b * a.cin + min(16 * nt + n, a.cin - 1)) * plane + org;
     const int npix = a.ph * a.pw, nch = (npix + 15) >> 4;                // chunks of 16 pixels in patch-linear order
+    float bng[NTI], bnb[NTI];
+    if constexpr (BNL) {
+#pragma unroll
+        for (int nt = 0; nt < NTI; ++nt) {
+            const int c = min(16 * nt + n, a.cin - 1);
+            const float g = (bn.gamma ? bn.gamma[c] : 1.0f) * bn.invstd[c];
+            bng[nt] = g; bnb[nt] = (bn.beta ? bn.beta[c] : 0.f) - bn.mean[c] * g;
+        }
+    }
     auto fetch = [&](int s, bw_f32x4 (&av)[MT], bw_f32x4 (&bv)[NTI]) {
         if constexpr (VEC == 2) {
 #pragma unroll
@@ -229,7 +248,11 @@ void patch_conv_bwd_weight_k1m_kernel(ConvBwdArgs a) {
             for (int mt = 0; mt < MT; ++mt) {
                 const float am = VEC == 1 ? av[mt][j] : av[mt][j] * live;
 #pragma unroll
-                for (int nt = 0; nt < NTI; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(am, bv[nt][j], acc[mt][nt], 0, 0, 0);
+                for (int nt = 0; nt < NTI; ++nt) {
+                    float xv = bv[nt][j];
+                    if constexpr (BNL) xv = dwt_act(fmaf(xv, bng[nt], bnb[nt]), bn.act);      // (recomputed per output tile: MT <= 2 on this route)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(am, xv, acc[mt][nt], 0, 0, 0);
+                }
             }
         }
     };
@@ -275,9 +298,12 @@ void patch_conv_bwd_weight_k1m_kernel(ConvBwdArgs a) {
 // order per pixel: bit-identical to PX = 1.  `aw` arrives as LOADED (clamped addresses); its reduction slots k >= kin are zeroed here, after
 // the first two tiles' requests have left (the stream reads a repeated row there): masks on either operand ahead of those requests made the
 // compiler wait for everything before the second tile's loads were issued -- one exposed round trip per workgroup.
-template <int MT, int KQ, int PX, typename T, typename EPI>
+struct K1mIdentity { __device__ __forceinline__ float operator()(float v, int, int) const { return v; } };
+// PRE (round 5): applied to every loaded input value ON USE, pre(value, q, j) for reduction row k = 16 q + 4 kg + j -- a training-mode
+// BatchNorm + activation normalised on load (patch_conv_bn_fwd_k1m_kernel); applied inside tile(), never in fetch() (see above).
+template <int MT, int KQ, int PX, typename T, typename EPI, typename PRE = K1mIdentity>
 __device__ __forceinline__ void k1m_pixel_stream(const ConvBwdArgs& a, float (&aw)[MT][KQ][4], const T* __restrict__ src, T* __restrict__ dst,
-                                                 int kin, int mout, size_t plane, int n, int kg, int wave, EPI epi) {
+                                                 int kin, int mout, size_t plane, int n, int kg, int wave, EPI epi, PRE pre = PRE{}) {
     constexpr int TP = 16 * PX;                                         // pixels per (super-)tile
     const int npix = a.ph * a.pw, ntile = (npix + TP - 1) / TP;
     auto fetch = [&](int t, float (&bv)[PX][KQ][4], size_t& off) {
@@ -295,8 +321,15 @@ __device__ __forceinline__ void k1m_pixel_stream(const ConvBwdArgs& a, float (&a
                 else bv[0][q][j] = Store<T>::ld(src, at);
             }
     };
-    auto tile = [&](int t, const float (&bv)[PX][KQ][4], size_t off) {
+    auto tile = [&](int t, const float (&bl)[PX][KQ][4], size_t off) {
         const bool live = TP * t + PX * n < npix;
+        float bv[PX][KQ][4];                                            // (identity PRE: the copy folds away)
+#pragma unroll
+        for (int h = 0; h < PX; ++h)
+#pragma unroll
+            for (int q = 0; q < KQ; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[h][q][j] = pre(bl[h][q][j], q, j);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             bw_f32x4 acc[PX];
@@ -433,6 +466,77 @@ void patch_conv_fwd_k1m_kernel(ConvBwdArgs a, const float* __restrict__ scale, c
     } else {
         k1m_pixel_stream<MT, KQ, PX, T>(a, aw, xb, yb, a.cin, a.cout, plane, n, kg, wave, [](float v, int, int) { return v; });
     }
+}
+
+// Training-mode BatchNorm + activation of the INPUT normalised on load (round 5: BatchNorm2 + ReLU6 in front of the train-mode inverted
+// residual's last 1 x 1 layer, hyperseg_v1_0.py:361-370, without the normalised copy of the hidden map): the forward above on the RAW
+// input.  `bn` as in dw_tiles_fwd_kernel: with `partial` (hs_bn_train_stats_fwd's slice sums) the workgroup finalises every input
+// channel's statistics while the patch's weights are staged -- thread c sums channel c's 32 slice pairs exactly as bn_apply_kernel does --
+// and patch 0 of frame 0 stores mean / invstd and updates the running estimates; the lanes then keep (scale, shift) of THEIR reduction
+// rows in registers: 3 vector operations per loaded value against the MT matrix instructions it feeds.
+template <int KQ, typename T>
+__device__ __forceinline__ void conv_bn_rows(const ConvBn& n, const T* __restrict__ x, size_t plane, int cin, bool writer, float* gb /* LDS [2][16 KQ] */) {
+    const int c = threadIdx.x;
+    if (c < 16 * KQ) {
+        float g = 0.f, bb = 0.f;
+        if (c < cin) {
+            float mean, invstd;
+            if (n.partial) {
+                const float shift = Store<T>::ld(x, (size_t)c * plane);           // the statistics' shift: the channel's first element (frame 0)
+                float s = 0.f, q = 0.f;
+                for (int i = 0; i < BN_CHUNKS; ++i) { s += n.partial[((size_t)c * BN_CHUNKS + i) * 2]; q += n.partial[((size_t)c * BN_CHUNKS + i) * 2 + 1]; }
+                const float md = s / n.n, var = fmaxf(q / n.n - md * md, 0.f);
+                mean = md + shift; invstd = rsqrtf(var + n.eps);
+                if (writer) {
+                    n.mean[c] = mean; n.invstd[c] = invstd;
+                    if (n.running_mean) {
+                        n.running_mean[c] = (1.f - n.momentum) * n.running_mean[c] + n.momentum * mean;
+                        n.running_var[c] = (1.f - n.momentum) * n.running_var[c] + n.momentum * (n.n > 1.f ? var * n.n / (n.n - 1.f) : var);
+                    }
+                    if (n.counter && c == 0) *n.counter += 1;
+                }
+            } else {
+                mean = n.mean[c]; invstd = n.invstd[c];
+            }
+            g = n.gamma ? n.gamma[c] * invstd : invstd;
+            bb = (n.beta ? n.beta[c] : 0.f) - mean * g;
+        }
+        gb[c] = g; gb[16 * KQ + c] = bb;
+    }
+}
+
+template <int MT, int KQ, int PX, typename T>
+__global__ __launch_bounds__(256)
+void patch_conv_bn_fwd_k1m_kernel(ConvBwdArgs a, ConvBn bn) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kg = lane >> 4;
+    const int patch = blockIdx.x;
+    const int pj = patch % a.fw, pi = (patch / a.fw) % a.fh, b = patch / (a.fw * a.fh);
+    const size_t plane = (size_t)a.H * a.W;
+    __shared__ float wl[16 * MT * 16 * KQ];
+    __shared__ float gb[2 * 16 * KQ];
+    const float* __restrict__ wp = a.bank + (size_t)patch * a.ld;
+    for (int e = tid; e < a.cout * a.cin; e += 256) wl[e] = wp[e];
+    conv_bn_rows<KQ, T>(bn, (const T*)a.dy, plane, a.cin, patch == 0, gb);
+    __syncthreads();
+    float aw[MT][KQ][4], sc[KQ][4], sh[KQ][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int q = 0; q < KQ; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                aw[mt][q][j] = wl[min(16 * mt + n, a.cout - 1) * a.cin + min(16 * q + 4 * kg + j, a.cin - 1)];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sc[q][j] = gb[16 * q + 4 * kg + j]; sh[q][j] = gb[16 * KQ + 16 * q + 4 * kg + j]; }
+    const size_t org = (size_t)(pi * a.ph) * a.W + pj * a.pw;
+    const T* __restrict__ xb = (const T*)a.dy + (size_t)b * a.cin * plane + org;
+    T* __restrict__ yb = (T*)a.dx + (size_t)b * a.cout * plane + org;
+    const int act = bn.act;
+    k1m_pixel_stream<MT, KQ, PX, T>(a, aw, xb, yb, a.cin, a.cout, plane, n, kg, wave, [](float v, int, int) { return v; },
+                                    [&](float v, int q, int j) { return dwt_act(fmaf(v, sc[q][j], sh[q][j]), act); });
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -750,7 +854,6 @@ struct DwtBn {
     long shift_stride;                        // elements between the first elements of consecutive channels (the statistics' shift)
     int act;
 };
-__device__ __forceinline__ float dwt_act(float z, int act) { return act == HS_ACT_RELU ? fmaxf(z, 0.f) : (act == HS_ACT_RELU6 ? fminf(fmaxf(z, 0.f), 6.f) : z); }
 
 // origin of tile (i, j), channel c of frame b, and the distance between its rows
 __device__ __forceinline__ size_t dwt_tile(const DwtArgs& a, int b, int c, int i, int j, int& row_stride) {
@@ -1050,11 +1153,11 @@ int hs::try_fast_bwd_w(int dtype, const void* x, const void* dy, int batch, int 
     const dim3 grid((unsigned)(batch * fh * fw));
     const bool pairs = !vec && (a.pw & 1) == 0 && (W & 1) == 0 && ((((size_t)x) | ((size_t)dy)) & 7) == 0;       // either storage type
 #define HS_BW(MTV, NTV) if (mt == MTV && nt == NTV) { \
-        if (vec) hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 1, float>), grid, dim3(256), 0, stream, a); \
-        else if (pairs) HS_T2(dtype, hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 2, float>), grid, dim3(256), 0, stream, a), \
-                                     hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 2, bf16_t>), grid, dim3(256), 0, stream, a)); \
-        else HS_T2(dtype, hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 0, float>), grid, dim3(256), 0, stream, a), \
-                          hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 0, bf16_t>), grid, dim3(256), 0, stream, a)); \
+        if (vec) hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 1, float>), grid, dim3(256), 0, stream, a, ConvBn{}); \
+        else if (pairs) HS_T2(dtype, hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 2, float>), grid, dim3(256), 0, stream, a, ConvBn{}), \
+                                     hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 2, bf16_t>), grid, dim3(256), 0, stream, a, ConvBn{})); \
+        else HS_T2(dtype, hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 0, float>), grid, dim3(256), 0, stream, a, ConvBn{}), \
+                          hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 0, bf16_t>), grid, dim3(256), 0, stream, a, ConvBn{})); \
         return launch_status(); }
     HS_BW(1, 1) HS_BW(1, 2) HS_BW(1, 3) HS_BW(1, 4) HS_BW(2, 1) HS_BW(2, 2) HS_BW(2, 3) HS_BW(2, 4) HS_BW(3, 1) HS_BW(3, 2) HS_BW(4, 1) HS_BW(4, 2)
 #undef HS_BW
@@ -1229,3 +1332,65 @@ extern "C" int hs_dw_tiles_bn_bwd_w(int32_t dtype, const void* tiled, const void
     else hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<bf16_t, true>), grid, dim3(256), 0, (hipStream_t)stream, a, n, (const bf16_t*)tiled, (const bf16_t*)dy);
     return launch_status();
 }
+
+// ---- round 5: the train-mode inverted residual's BatchNorm2 + ReLU6 normalised ON LOAD by its last 1 x 1 layer (no normalised copy of
+// the hidden map): forward on the raw input + hs_bn_train_stats_fwd's slice sums, weight gradient on the raw input + saved statistics.
+// k = 1, groups = 1, c_out <= 32, c_in <= 64, patches of >= 64 pixels; anything else: HS_ERR_UNSUPPORTED (the caller normalises first).
+#define HS_T2(dtype, F32, BF16) do { if ((dtype) == HS_DTYPE_F32) { F32; } else { BF16; } } while (0)
+extern "C" int hs_patch_conv_bn_fwd(int32_t dtype, const void* x, const float* bn_partial, const float* gamma, const float* beta,
+                                    float* running_mean, float* running_var, float momentum, float eps, int32_t act, float* save_mean,
+                                    float* save_invstd, int64_t* num_batches_tracked, const float* bank, int64_t ld, int32_t batch,
+                                    int32_t c_in, int32_t H, int32_t W, int32_t fh, int32_t fw, int32_t c_out, void* y, void* stream) {
+    if (!x || !y || !bank || !bn_partial || !save_mean || !save_invstd || batch <= 0 || c_in <= 0 || c_out <= 0 || H <= 0 || W <= 0 || fh <= 0 || fw <= 0)
+        return HS_ERR_BAD_ARG;
+    if ((dtype != HS_DTYPE_F32 && dtype != HS_DTYPE_BF16) || ((running_mean != nullptr) != (running_var != nullptr)) ||
+        act < HS_ACT_NONE || act > HS_ACT_RELU6 || eps < 0.f || ld < (int64_t)c_in * c_out) return HS_ERR_BAD_ARG;
+    if (H % fh || W % fw) return HS_ERR_NOT_DIVISIBLE;
+    ConvBwdArgs a;
+    fast_args(a, bank, (long)ld, batch, c_in, H, W, fh, fw, c_out);
+    const int mt = (c_out + 15) / 16, kq = (c_in + 15) / 16;
+    if (a.ph * a.pw < 64 || mt > 2 || kq > 4 || (long)batch * fh * fw > 0x7fffffffL) return HS_ERR_UNSUPPORTED;
+    a.dy = (const float*)x; a.dx = (float*)y;
+    ConvBn bn{bn_partial, gamma, beta, save_mean, save_invstd, running_mean, running_var, (long long*)num_batches_tracked, eps, momentum,
+              (float)((double)batch * H * W), act};
+    const dim3 grid((unsigned)(batch * fh * fw));
+    hipStream_t s = (hipStream_t)stream;
+    const bool px2 = dw3_pairs(a, x, y) && a.ph * a.pw >= 128;
+#define HS_FB_L(MTV, KQV, PXV) HS_T2(dtype, hipLaunchKernelGGL((patch_conv_bn_fwd_k1m_kernel<MTV, KQV, PXV, float>), grid, dim3(256), 0, s, a, bn), \
+                                            hipLaunchKernelGGL((patch_conv_bn_fwd_k1m_kernel<MTV, KQV, PXV, bf16_t>), grid, dim3(256), 0, s, a, bn))
+#define HS_FB(MTV, KQV) if (mt == MTV && kq == KQV) { if (px2) HS_FB_L(MTV, KQV, 2); else HS_FB_L(MTV, KQV, 1); return launch_status(); }
+    HS_FB(1, 1) HS_FB(1, 2) HS_FB(1, 3) HS_FB(1, 4) HS_FB(2, 1) HS_FB(2, 2) HS_FB(2, 3) HS_FB(2, 4)
+#undef HS_FB
+#undef HS_FB_L
+    return HS_ERR_UNSUPPORTED;
+}
+
+extern "C" int hs_patch_conv_bn_bwd_w(int32_t dtype, const void* x, const void* dy, const float* gamma, const float* beta, const float* save_mean,
+                                      const float* save_invstd, int32_t act, int32_t batch, int32_t c_in, int32_t H, int32_t W, int32_t fh,
+                                      int32_t fw, int32_t c_out, float* dbank, int64_t ld, void* stream) {
+    if (!x || !dy || !dbank || !save_mean || !save_invstd || batch <= 0 || c_in <= 0 || c_out <= 0 || H <= 0 || W <= 0 || fh <= 0 || fw <= 0)
+        return HS_ERR_BAD_ARG;
+    if ((dtype != HS_DTYPE_F32 && dtype != HS_DTYPE_BF16) || act < HS_ACT_NONE || act > HS_ACT_RELU6 || ld < (int64_t)c_in * c_out) return HS_ERR_BAD_ARG;
+    if (H % fh || W % fw) return HS_ERR_NOT_DIVISIBLE;
+    ConvBwdArgs a;
+    fast_args(a, nullptr, (long)ld, batch, c_in, H, W, fh, fw, c_out);
+    a.x = (const float*)x; a.dy = (const float*)dy; a.dbank = dbank;
+    const int mt = (c_out + 15) / 16, nt = (c_in + 15) / 16;
+    if (a.ph * a.pw < 16 || mt > 2 || nt > 4) return HS_ERR_UNSUPPORTED;
+    ConvBn bn{nullptr, gamma, beta, const_cast<float*>(save_mean), const_cast<float*>(save_invstd), nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, act};
+    const bool vec = dtype == HS_DTYPE_F32 && (a.pw & 3) == 0 && ((a.ph * a.pw) & 15) == 0 && (W & 3) == 0 && ((((size_t)x) | ((size_t)dy)) & 15) == 0;
+    const bool pairs = !vec && (a.pw & 1) == 0 && (W & 1) == 0 && ((((size_t)x) | ((size_t)dy)) & 7) == 0;
+    const dim3 grid((unsigned)(batch * fh * fw));
+    hipStream_t s = (hipStream_t)stream;
+#define HS_BWB(MTV, NTV) if (mt == MTV && nt == NTV) { \
+        if (vec) hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 1, float, true>), grid, dim3(256), 0, s, a, bn); \
+        else if (pairs) HS_T2(dtype, hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 2, float, true>), grid, dim3(256), 0, s, a, bn), \
+                                     hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 2, bf16_t, true>), grid, dim3(256), 0, s, a, bn)); \
+        else HS_T2(dtype, hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 0, float, true>), grid, dim3(256), 0, s, a, bn), \
+                          hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 0, bf16_t, true>), grid, dim3(256), 0, s, a, bn)); \
+        return launch_status(); }
+    HS_BWB(1, 1) HS_BWB(1, 2) HS_BWB(1, 3) HS_BWB(1, 4) HS_BWB(2, 1) HS_BWB(2, 2) HS_BWB(2, 3) HS_BWB(2, 4)
+#undef HS_BWB
+    return HS_ERR_UNSUPPORTED;
+}
+#undef HS_T2

@@ -328,8 +328,8 @@ class HyperPatchInvertedResidual(EpochOnModeSwitch, nn.Module, _SignalToWeights)
             else:
                 y = HA.patch_conv_apply(y, bank2, grid, self.hidden_dim, 3, 1, 'zeros', self.hidden_dim)
                 y = y.reshape(b, self.hidden_dim, fh, ph + 2, fw, pw + 2)[:, :, :, 1:-1, :, 1:-1].reshape(b, self.hidden_dim, h, wd)
-        y = HA.bn_act(self.bn2, self.act_layer, y)
-        y = HA.patch_conv_apply(y, bank3, grid, self.out_nc, 1, 0, 'zeros', 1)
+        # BatchNorm2 + ReLU6 applied to the raw hidden map ON LOAD by the last 1x1 layer (autograd.PatchConvBN) where it is covered
+        y = HA.patch_conv_bn(self.bn2, self.act_layer, y, bank3, grid, self.out_nc)
         y = HA.bn_act(self.bn3, None, y)
         return xt + y if residual else y
 

@@ -547,6 +547,18 @@ int hs_dw_tiles_bn_fwd(int32_t dtype, const void* tiled, const float* bn_partial
 int hs_dw_tiles_bn_bwd_w(int32_t dtype, const void* tiled, const void* dy, const float* gamma, const float* beta, const float* save_mean,
                          const float* save_invstd, int32_t act, int32_t batch, int32_t channels, int32_t H, int32_t W, int32_t fh,
                          int32_t fw, float* dbank, int64_t ld, int32_t patch_major, void* stream);
+/* The same move at the block's second cut (round 5): BatchNorm2 + ReLU6 normalised on load by the LAST 1 x 1 layer (hyperseg_v1_0.py:361-370),
+ * x (B, c_in, H, W) RAW, bank rows = this layer's (c_out, c_in) weights per patch, k = 1.  _fwd: bn_partial = hs_bn_train_stats_fwd's
+ * workspace for x; save_mean / save_invstd / running_* / num_batches_tracked as hs_bn_act_train_fwd.  _bwd_w: the weight gradient on the raw
+ * input + saved statistics.  The input gradient is hs_patch_conv_plain_bwd_in unchanged (it yields the gradient of the normalised map),
+ * BatchNorm's adjoint hs_bn_act_train_bwd on (x, that).  c_out <= 32, c_in <= 64, patches >= 64 pixels; else HS_ERR_UNSUPPORTED. */
+int hs_patch_conv_bn_fwd(int32_t dtype, const void* x, const float* bn_partial, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, float momentum, float eps, int32_t act, float* save_mean,
+                         float* save_invstd, int64_t* num_batches_tracked, const float* bank, int64_t ld, int32_t batch,
+                         int32_t c_in, int32_t H, int32_t W, int32_t fh, int32_t fw, int32_t c_out, void* y, void* stream);
+int hs_patch_conv_bn_bwd_w(int32_t dtype, const void* x, const void* dy, const float* gamma, const float* beta, const float* save_mean,
+                           const float* save_invstd, int32_t act, int32_t batch, int32_t c_in, int32_t H, int32_t W, int32_t fh,
+                           int32_t fw, int32_t c_out, float* dbank, int64_t ld, void* stream);
 int hs_bn_act_train_fwd(int32_t dtype, const void* x, int32_t batch, int32_t channels, int64_t pixels, const float* gamma,
                         const float* beta, float* running_mean, float* running_var, float momentum, float eps, int32_t act,
                         float* save_mean, float* save_invstd, void* workspace, void* y, int64_t* num_batches_tracked, void* stream);

@@ -852,6 +852,12 @@ def _emulated_bf16(monkeypatch):
         out = real_dz(*a, **k)
         return out.to(BF).float() if low_depth[0] and out.dtype == torch.float32 else out
     monkeypatch.setattr(HA, '_dw_tiles_input_gradient', emulated_dz)
+    real_cz = HA._conv_input_gradient                     # ... and PatchConvBN.backward's (the convolution's adjoint, read by BatchNorm's)
+
+    def emulated_cz(*a, **k):
+        out = real_cz(*a, **k)
+        return out.to(BF).float() if low_depth[0] and out.dtype == torch.float32 else out
+    monkeypatch.setattr(HA, '_conv_input_gradient', emulated_cz)
 
     def wrap(cls, fwd_low=(0,), bwd_low=(0,), low_rule=None, no_autocast=False):
         """``fwd_low`` / ``bwd_low``: indices of the forward outputs / backward gradients the bf16 kernels store as bf16."""
@@ -893,6 +899,7 @@ def _emulated_bf16(monkeypatch):
     wrap(HA.TileInterior)
     wrap(HA.DwTilesValid)                                 # (t, bank, ...): y bf16; dt bf16, dbank fp32
     wrap(HA.DwTilesBN)                                    # (raw tiles, weight, bias, ..., bank, ...): y bf16; d tiles bf16, the rest fp32
+    wrap(HA.PatchConvBN, no_autocast=True)                # (raw map, weight, bias, ..., bank, ...): y bf16; d map bf16, the rest fp32
     wrap(HA.BNActTrain)                                   # (x, weight, bias, ...): y bf16; dx bf16, dgamma / dbeta fp32
     wrap(HA.PixelCrossEntropy, fwd_low=())                # loss fp32; d logits bf16
     wrap(HA.UpsampleBilinear)
@@ -1125,5 +1132,77 @@ def test_dw_tiles_bn_on_load_equals_batchnorm_then_depthwise(dev, patch_major, d
             # no worse than the route that rounds the copy.  The absolute bound only catches garbage: it is bf16's own error through
             # BatchNorm's adjoint, whose mean-subtractions cancel (measured, identical for BOTH routes -- they share those three
             # launches: dt 2.7e-2, db 4.1e-2 at the patch-major parametrisation)
+            assert e_one < 1e-1 and e_one < 2.0 * e_two + 1e-3, (k, e_one, e_two)
+        assert torch.allclose(one['rm'], two['rm'], rtol=1e-5, atol=1e-6) and torch.allclose(one['rv'], two['rv'], rtol=1e-5, atol=1e-6)
+
+
+# (hidden channels, classes, grid, patch edge): config 5's two inverted-residual levels (44 -> 12 on 16 x 16 patches: two pixels per lane;
+# 48 -> 16 on 8 x 8: one), 64 -> 19 (two output tiles, four reduction tiles), odd counts, a column range of a wider bank
+CONV_BN_CASES = [(44, 12, (3, 3), 16), (48, 16, (3, 2), 8), (64, 19, (2, 2), 16), (13, 5, (2, 3), 8), (17, 32, (1, 2), 12)]
+
+
+@pytest.mark.parametrize('c,cout,grid,p', CONV_BN_CASES)
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_patch_conv_bn_on_load_equals_batchnorm_then_conv(dev, c, cout, grid, p, dtype):
+    """autograd.PatchConvBN (round 5: BatchNorm2 + ReLU6 applied to the raw hidden map ON LOAD by the inverted residual's last 1 x 1 layer)
+    against the two Functions it replaces (BNActTrain, then PatchConv): fp32 -- same arithmetic per value, same matrix-core pixel stream,
+    so outputs, all four gradients, saved / running statistics and the step counter are BIT-EQUAL; bf16 storage -- the fused form skips
+    the rounding of the normalised copy and is held to the fp32 result at bf16's resolution, no worse than the two-step route."""
+    import copy
+    import torch.nn as nn
+    from hyperseg_amd import autograd as HA
+    b = 2
+    fh, fw = grid
+    h, w = fh * p, fw * p
+    x0 = (torch.randn(b, c, h, w, generator=G(3201)) * 1.3 + 0.5).to(dev)
+    bank0 = (torch.randn(b * fh * fw, cout * c + 5, generator=G(3202)) / c ** 0.5).to(dev)[:, 2:2 + cout * c]
+    r = torch.randn(b, cout, h, w, generator=G(3203)).to(dev)
+    bn0 = nn.BatchNorm2d(c, momentum=0.1).to(dev).train()
+    with torch.no_grad():
+        bn0.weight.copy_(torch.rand(c, generator=G(3204)) + 0.5)
+        bn0.bias.copy_(torch.randn(c, generator=G(3205)) * 0.3)
+
+    def run(fused, dt):
+        prev = HA.USE_CONV_BN_FUSED
+        HA.USE_CONV_BN_FUSED = fused
+        try:
+            bn = copy.deepcopy(bn0)
+            x = x0.to(dt).clone().requires_grad_(True)
+            bank = bank0.clone().requires_grad_(True)
+            y = HA.patch_conv_bn(bn, nn.ReLU6(), x, bank, grid, cout)
+            (y.float() * r).sum().backward()
+            return dict(y=y.detach().float(), dx=x.grad.float(), dbank=bank.grad, dg=bn.weight.grad, db=bn.bias.grad, rm=bn.running_mean.clone(),
+                        rv=bn.running_var.clone(), n=int(bn.num_batches_tracked))
+        finally:
+            HA.USE_CONV_BN_FUSED = prev
+    calls = {'n': 0}
+    real = HA.PatchConvBN.apply
+
+    def counting(*a):
+        calls['n'] += 1
+        return real(*a)
+    HA.PatchConvBN.apply = counting
+    try:
+        two, one = run(False, dtype), run(True, dtype)
+    finally:
+        HA.PatchConvBN.apply = real
+    assert calls['n'] == 1, 'the fused Function is meant to cover this shape'
+    assert one['n'] == two['n'] == 1
+    # against plain PyTorch (fp32): batch_norm + relu6 + the per-patch 1x1 convolution as a batched matmul
+    if dtype == torch.float32:
+        xr = x0.clone().requires_grad_(True)
+        bnr = copy.deepcopy(bn0)
+        z = torch.nn.functional.relu6(bnr(xr))
+        zt = z.view(b, c, fh, p, fw, p).permute(0, 2, 4, 1, 3, 5).reshape(b * fh * fw, c, p * p)
+        yr = torch.bmm(bank0.reshape(b * fh * fw, cout, c), zt).view(b, fh, fw, cout, p, p).permute(0, 3, 1, 4, 2, 5).reshape(b, cout, h, w)
+        (yr * r).sum().backward()
+        assert rel_l2(one['y'].cpu(), yr.detach().cpu()) < 2e-5
+        assert rel_l2(one['dx'].cpu(), xr.grad.cpu()) < 2e-4 and rel_l2(one['dg'].cpu(), bnr.weight.grad.cpu()) < 2e-4
+        for k in ('y', 'dx', 'dbank', 'dg', 'db', 'rm', 'rv'):
+            assert torch.equal(one[k], two[k]), k
+    else:
+        ref = run(False, torch.float32)
+        for k in ('y', 'dx', 'dbank', 'dg', 'db'):
+            e_one, e_two = rel_l2(one[k].cpu(), ref[k].cpu()), rel_l2(two[k].cpu(), ref[k].cpu())
             assert e_one < 1e-1 and e_one < 2.0 * e_two + 1e-3, (k, e_one, e_two)
         assert torch.allclose(one['rm'], two['rm'], rtol=1e-5, atol=1e-6) and torch.allclose(one['rv'], two['rv'], rtol=1e-5, atol=1e-6)
