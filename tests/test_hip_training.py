@@ -1138,7 +1138,9 @@ def test_dw_tiles_bn_on_load_equals_batchnorm_then_depthwise(dev, patch_major, d
 
 # (hidden channels, classes, grid, patch edge): config 5's two inverted-residual levels (44 -> 12 on 16 x 16 patches: two pixels per lane;
 # 48 -> 16 on 8 x 8: one), 64 -> 19 (two output tiles, four reduction tiles), odd counts, a column range of a wider bank
-CONV_BN_CASES = [(44, 12, (3, 3), 16), (48, 16, (3, 2), 8), (64, 19, (2, 2), 16), (13, 5, (2, 3), 8), (17, 32, (1, 2), 12)]
+# -- all with > 16 384 elements per channel, so that BOTH routes take the two-launch statistics (below that BNActTrain sums a channel in one
+# workgroup's registers, in another order: the last case, held to 1e-5 instead of bit equality)
+CONV_BN_CASES = [(44, 12, (6, 6), 16), (48, 16, (12, 12), 8), (64, 19, (6, 6), 16), (13, 5, (12, 12), 8), (17, 32, (8, 8), 12), (24, 8, (2, 3), 8)]
 
 
 @pytest.mark.parametrize('c,cout,grid,p', CONV_BN_CASES)
@@ -1199,7 +1201,10 @@ def test_patch_conv_bn_on_load_equals_batchnorm_then_conv(dev, c, cout, grid, p,
         assert rel_l2(one['y'].cpu(), yr.detach().cpu()) < 2e-5
         assert rel_l2(one['dx'].cpu(), xr.grad.cpu()) < 2e-4 and rel_l2(one['dg'].cpu(), bnr.weight.grad.cpu()) < 2e-4
         for k in ('y', 'dx', 'dbank', 'dg', 'db', 'rm', 'rv'):
-            assert torch.equal(one[k], two[k]), k
+            if b * h * w > 16384:
+                assert torch.equal(one[k], two[k]), k
+            else:
+                assert rel_l2(one[k].cpu(), two[k].cpu()) < 1e-5, k
     else:
         ref = run(False, torch.float32)
         for k in ('y', 'dx', 'dbank', 'dg', 'db'):
