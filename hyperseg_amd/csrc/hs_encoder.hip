@@ -761,12 +761,15 @@ extern "C" int hs_affine_act_fwd(const float* x, int32_t batch, int32_t channels
 // 1 KB contiguous per store instruction.
 // ---------------------------------------------------------------------------------------------------------------
 namespace hs {
+#ifndef HS_STEM_CG
+#define HS_STEM_CG 4                  // output channels per thread: 4 / 8 / 16 measured 15.0 / 16.1 / 16.5 us, frame 0.7761-0.7734 / 0.7773-0.7755 / 0.7763-0.7769 ms (visit r5v15; tools/build_variants.py stem_cg*)
+#endif
 template <int CIN, int PL>
 __global__ __launch_bounds__(256)
 void stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
                       const float* __restrict__ shift, float* __restrict__ y, int Cout, int H, int W, int Ho, int Wo,
                       int pad_t, int pad_l) {
-    constexpr int K = 3, S = 2, NCOL = 3 * S + K, CG = 8;
+    constexpr int K = 3, S = 2, NCOL = 3 * S + K, CG = HS_STEM_CG;
     const int wq = (Wo + 3) >> 2;
     const int q0 = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = q0 < Ho * wq;
@@ -858,7 +861,7 @@ extern "C" int hs_stem_conv_fwd(const float* x, int32_t batch, int32_t c_in, int
         pad_t < 0 || pad_l < 0) return HS_ERR_BAD_ARG;
     if (c_in != 3 || batch > 65535) return HS_ERR_UNSUPPORTED;
     const int quads = Ho * ((Wo + 3) / 4);
-    dim3 grid((quads + 255) / 256, (c_out + 7) / 8, batch);
+    dim3 grid((quads + 255) / 256, (c_out + HS_STEM_CG - 1) / HS_STEM_CG, batch);
     const bool vec = (W & 3) == 0 && (((size_t)x) & 15) == 0;
 #define HS_STEM(PP) hipLaunchKernelGGL((hs::stem_conv_kernel<3, PP>), grid, dim3(256), 0, (hipStream_t)stream, x, w, scale, shift, \
                                        y, c_out, H, W, Ho, Wo, pad_t, pad_l)

@@ -177,6 +177,8 @@ VARIANTS = {
     's2wt_noB': dict(flags=[], extra=[], patch='s2wt_noB', file='hs_s2w_train.hip'),
     's2wt_nomfma': dict(flags=[], extra=[], patch='s2wt_nomfma', file='hs_s2w_train.hip'),
     's2wt_nostore': dict(flags=[], extra=[], patch='s2wt_nostore', file='hs_s2w_train.hip'),
+    'stem_cg8': dict(flags=['-DHS_STEM_CG=8'], extra=[], patch=None),                      # round 5: output channels per thread of the stem (product: 4; rounds 1-4: 8)
+    'stem_cg16': dict(flags=['-DHS_STEM_CG=16'], extra=[], patch=None),
 }
 
 def git_source(rev, fname, tag):
