@@ -68,11 +68,7 @@ __device__ __forceinline__ void s2b_body(const __attribute__((address_space(4)))
     for (int k0 = 0; k0 < KS; k0 += S2B_KC) {
         const int kn = min(S2B_KC, KS - k0);
         if (k0 > 0) __syncthreads();                                                       // the previous fill has been consumed
-#ifdef HS_S2B_DEV_NOFILL
-        for (int c = wave; c < kn && ka->n_layers < 0; c += 4) {
-#else
         for (int c = wave; c < kn; c += 4) {
-#endif
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ablk + (size_t)(k0 + c) * 256 + lane * 4),
                                              (__attribute__((address_space(3))) void*)(A + c * 256), 16, 0, 0);
             const unsigned k = (unsigned)min(4 * (k0 + c) + kq, cs_g - 1);                 // k past the group reads a finite neighbour: A is zero there
@@ -80,11 +76,7 @@ __device__ __forceinline__ void s2b_body(const __attribute__((address_space(4)))
                                              (__attribute__((address_space(3))) void*)(Bm + c * 256), 16, 0, 0);
         }
         __syncthreads();                                                                   // both fills have landed
-#ifdef HS_S2B_DEV_NOMFMA
-        for (int c = 0; c < kn && ka->n_layers < 0; ++c) {
-#else
         for (int c = 0; c < kn; ++c) {
-#endif
             const float av = A[c * 256 + wave * 64 + lane];
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -106,11 +98,7 @@ __device__ __forceinline__ void s2b_body(const __attribute__((address_space(4)))
     for (int q = 0; q < 16; ++q) {
         const int pl = wave * 16 + q, p = pb * S2B_PATCHES + pl;
         const float v = lds[pl * (S2B_ROWS + 1) + lane];
-#ifdef HS_S2B_DEV_NOSTORE
-        if (row_ok && p < n_patches && ka->n_layers < 0) bank[(size_t)p * ld + n0 + lane] = v;
-#else
         if (row_ok && p < n_patches) bank[(size_t)p * ld + n0 + lane] = v;
-#endif
     }
 }
 

@@ -179,10 +179,6 @@ VARIANTS = {
     's2wt_nostore': dict(flags=[], extra=[], patch='s2wt_nostore', file='hs_s2w_train.hip'),
     'stem_cg8': dict(flags=['-DHS_STEM_CG=8'], extra=[], patch=None),                      # round 5: output channels per thread of the stem (product: 4; rounds 1-4: 8)
     'stem_cg16': dict(flags=['-DHS_STEM_CG=16'], extra=[], patch=None),
-    # round 5: phase removal in the blocked signal2weights body (results are WRONG by construction: timing only)
-    's2b_nostore': dict(flags=['-DHS_S2B_DEV_NOSTORE'], extra=[], patch=None),
-    's2b_nofill': dict(flags=['-DHS_S2B_DEV_NOFILL'], extra=[], patch=None),
-    's2b_nomfma': dict(flags=['-DHS_S2B_DEV_NOMFMA'], extra=[], patch=None),
 }
 
 def git_source(rev, fname, tag):
