@@ -39,6 +39,44 @@ def _plain_conv(kind, dtype, a, b, ld, shape, meta, out):
     return out
 
 
+class _BankGradBuffer:
+    """One gradient buffer for the three column ranges BankSlices hands out (round 5): the layers that consume the ranges write their
+    weight gradients straight into views of ONE (patches, ld) tensor, and BankSlices.backward returns it as it is -- where each layer
+    allocated its own (patches, range) tensor, the backward of every inverted-residual level was a concatenation launch over the whole
+    bank (two CatArrayBatchedCopy per config-5 step).  Created per BankSlices.forward, filled per backward pass, dropped when returned."""
+
+    def __init__(self, shape, ranges):
+        self.shape, self.ranges, self.buf = tuple(shape), tuple(ranges), None
+
+    def view(self, index, device):
+        if self.buf is None:
+            self.buf = torch.empty(self.shape, device=device, dtype=torch.float32)
+            if self.shape[1] > self.ranges[-1][1]:
+                self.buf[:, self.ranges[-1][1]:].zero_()        # the row's pad columns (read by nobody; kept finite)
+        c0, c1 = self.ranges[index]
+        return self.buf[:, c0:c1]
+
+    def owns(self, grads):
+        if self.buf is None or any(g is None for g in grads):
+            return False
+        return all(g.dtype == torch.float32 and g.stride() == self.buf.stride() and g.shape == (self.shape[0], c1 - c0)
+                   and g.data_ptr() == self.buf.data_ptr() + 4 * c0 for g, (c0, c1) in zip(grads, self.ranges))
+
+
+def _grad_slot(bank):
+    """(buffer, index) a BankSlices range carries, or None (read in forward, from the tensor object the caller passed)."""
+    return getattr(bank, '_hs_grad_slot', None)
+
+
+def _dbank_for(slot, bank, written_cols, device):
+    """The weight-gradient tensor of a layer whose kernels write columns [0, written_cols) of every row: a view of the shared buffer when
+    the layer's bank is a BankSlices range of exactly that width, else its own allocation (zero-filled where the kernels do not write)."""
+    if slot is not None and written_cols == bank.shape[1]:
+        return slot[0].view(slot[1], device)
+    alloc = torch.empty if written_cols == bank.shape[1] else torch.zeros
+    return alloc(bank.shape[0], bank.shape[1], device=device, dtype=torch.float32)
+
+
 class PatchConv(torch.autograd.Function):
     """y = patch_conv(x, bank): Op A / Op B with plain tensors.  Saves x and the bank; backward launches the input- and
     the per-patch weight-gradient kernels.  fp32 tensors take the fp32 kernels; under ``torch.autocast('cuda',
@@ -56,6 +94,7 @@ class PatchConv(torch.autograd.Function):
             raise NotImplementedError(f'PatchConv: dtype {x.dtype} is not supported (supported: '
                                       f'{", ".join(str(d) for d in DTYPE_CODES)})')
         x = x.contiguous()
+        ctx.grad_slot = _grad_slot(bank)
         if bank.dtype != torch.float32:
             bank = bank.float()
         if bank.stride(1) != 1:
@@ -92,8 +131,7 @@ class PatchConv(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 rows = c_out * (c_in // groups) * k * k
                 # the kernels write columns [0, rows) of every patch row; only trailing pad columns need the zero fill
-                alloc = torch.empty if rows == bank.shape[1] else torch.zeros
-                full = alloc(bank.shape[0], bank.shape[1], device=x.device, dtype=torch.float32)
+                full = _dbank_for(ctx.grad_slot, bank, rows, x.device)
                 assert rows <= full.shape[1]
                 if x.dtype == torch.float32:
                     st = _hip.lib.hs_patch_conv_bwd_weight(_hip.dev_ptr(x, 'x'), _hip.dev_ptr(dy, 'dy'), b, c_in, h, w, fh, fw,
@@ -177,6 +215,7 @@ class DwTilesValid(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, t, bank, size, grid, patch_major=False):
+        ctx.grad_slot = _grad_slot(bank)
         t = t.contiguous()
         h, w = size
         c = t.shape[1]
@@ -202,8 +241,7 @@ class DwTilesValid(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 dt = _dw_tiles_input_gradient(t, dy, bank, (b, c, h, w), grid, pm)
             if ctx.needs_input_grad[1]:
-                alloc = torch.empty if bank.shape[1] == 9 * c else torch.zeros
-                dbank = alloc(bank.shape[0], bank.shape[1], device=dy.device, dtype=torch.float32)
+                dbank = _dbank_for(ctx.grad_slot, bank, 9 * c, dy.device)
                 st = _hip.lib.hs_dw_tiles_bwd_w(DTYPE_CODES[dtype], t.data_ptr(), dy.data_ptr(), b, c, h, w, grid[0], grid[1], dbank.data_ptr(),
                                                 dbank.stride(0), int(pm), _hip.stream_ptr())
                 _hip.check(st, 'hs_dw_tiles_bwd_w')
@@ -314,6 +352,7 @@ class DwTilesBN(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, t, weight, bias, running_mean, running_var, momentum, eps, act, counter, bank, size, grid, patch_major):
+        ctx.grad_slot = _grad_slot(bank)
         t = t.contiguous()
         h, w = size
         c = t.shape[1]
@@ -350,8 +389,7 @@ class DwTilesBN(torch.autograd.Function):
         with _hip.device_scope(dev):
             stream = _hip.stream_ptr()
             if ctx.needs_input_grad[9]:
-                alloc = torch.empty if bank.shape[1] == 9 * c else torch.zeros
-                dbank = alloc(bank.shape[0], bank.shape[1], device=dev, dtype=torch.float32)
+                dbank = _dbank_for(ctx.grad_slot, bank, 9 * c, dev)
                 st = _hip.lib.hs_dw_tiles_bn_bwd_w(code, t.data_ptr(), dy.data_ptr(), weight.data_ptr(), bias.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
                                                    act, b, c, h, w, fh, fw, dbank.data_ptr(), dbank.stride(0), int(pm), stream)
                 _hip.check(st, 'hs_dw_tiles_bn_bwd_w')
@@ -384,6 +422,7 @@ def dw_tiles_bn(bn, act_layer, t, bank, size, grid, patch_major):
 
 
 USE_DW_BN_FUSED = True  # tests switch it off to compare with BNActTrain + DwTilesValid
+USE_SHARED_BANK_GRAD = True  # BankSlices: one gradient buffer for the three ranges (tests switch it off to compare with the concatenation)
 
 
 class PatchConvBN(torch.autograd.Function):
@@ -396,6 +435,7 @@ class PatchConvBN(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, act, counter, bank, grid, c_out):
+        ctx.grad_slot = _grad_slot(bank)
         if torch.is_autocast_enabled('cuda') and x.is_floating_point():
             x = x.to(torch.bfloat16)
         x = x.contiguous()
@@ -431,8 +471,7 @@ class PatchConvBN(torch.autograd.Function):
         with _hip.device_scope(dev):
             stream = _hip.stream_ptr()
             if ctx.needs_input_grad[9]:
-                alloc = torch.empty if bank.shape[1] == c_out * c else torch.zeros
-                dbank = alloc(bank.shape[0], bank.shape[1], device=dev, dtype=torch.float32)
+                dbank = _dbank_for(ctx.grad_slot, bank, c_out * c, dev)
                 st = _hip.lib.hs_patch_conv_bn_bwd_w(code, x.data_ptr(), dy.data_ptr(), weight.data_ptr(), bias.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
                                                      act, b, c, h, w, fh, fw, c_out, dbank.data_ptr(), dbank.stride(0), stream)
                 _hip.check(st, 'hs_patch_conv_bn_bwd_w')
@@ -773,11 +812,22 @@ class BankSlices(torch.autograd.Function):
     @staticmethod
     def forward(ctx, bank, r1, r2, r3):
         ctx.meta = (tuple(bank.shape), r1, r2, r3)
-        return bank[:, :r1], bank[:, r1:r2], bank[:, r2:r3]
+        outs = bank[:, :r1], bank[:, r1:r2], bank[:, r2:r3]
+        ctx.grads = None
+        if USE_SHARED_BANK_GRAD and bank.is_cuda:
+            ctx.grads = _BankGradBuffer(bank.shape, ((0, r1), (r1, r2), (r2, r3)))
+            for i, o in enumerate(outs):
+                o._hs_grad_slot = (ctx.grads, i)           # read by the consuming Function's forward (the object the caller passes on)
+        return outs
 
     @staticmethod
     def backward(ctx, g1, g2, g3):
         (rows, cols), r1, r2, r3 = ctx.meta
+        if ctx.grads is not None:
+            buf, owned = ctx.grads.buf, ctx.grads.owns((g1, g2, g3))
+            ctx.grads.buf = None                            # a second backward pass fills a new one
+            if owned:
+                return buf, None, None, None
         ref = next(g for g in (g1, g2, g3) if g is not None)
         parts = [g if g is not None else ref.new_zeros(rows, w) for g, w in ((g1, r1), (g2, r2 - r1), (g3, r3 - r2))]
         if cols > r3:

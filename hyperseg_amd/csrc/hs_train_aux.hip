@@ -894,3 +894,88 @@ extern "C" int hs_cross_entropy_bwd(const float* logits, const int64_t* target, 
                                     int64_t ignore_index, const float* grad_loss, float* grad_logits, void* stream) {
     return hs_cross_entropy_typed_bwd(HS_DTYPE_F32, logits, target, batch, classes, pixels, ignore_index, grad_loss, grad_logits, stream);
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Adam for a whole parameter list in ONE launch (round 5; the training step's optimizer, hyperseg/train.py:185-188 builds torch.optim.Adam).
+// torch's fused Adam is one launch too, but cuts the list into 65 536-element chunks -- a dozen workgroups for the decoder's ~0.7 M
+// parameters, 25 us of a 0.88 ms step; here a workgroup takes 1024 elements (float4 per thread), ~700 workgroups.
+// Arithmetic as torch's adam_math (fused_adam_utils.cuh), opmath float:  g += wd p (coupled) | p -= lr wd p (decoupled);
+// m = lerp(m, g, 1 - b1);  v = b2 v + (1 - b2) g g;  p -= (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps).
+// The step count lives on the device (graph replay freezes kernel arguments): one word PER WORKGROUP, read and incremented by its own
+// workgroup only (a shared word would be read by some workgroups after another had incremented it).
+// ------------------------------------------------------------------------------------------------------------------------------
+namespace hs {
+constexpr int ADAM_MAX_TENSORS = 48, ADAM_BLOCK = 1024;
+struct AdamTable {
+    float* p[ADAM_MAX_TENSORS]; const float* g[ADAM_MAX_TENSORS]; float* m[ADAM_MAX_TENSORS]; float* v[ADAM_MAX_TENSORS];
+    int first_block[ADAM_MAX_TENSORS + 1];       // workgroups [first_block[i], first_block[i + 1]) belong to tensor i
+    long numel[ADAM_MAX_TENSORS];
+    int n;
+};
+
+__global__ __launch_bounds__(256)
+void adam_kernel(AdamTable t, const float* __restrict__ lr_dev, float lr_host, float b1, float b2, float eps, float wd, int decoupled,
+                 int maximize, float* __restrict__ steps) {
+    const __attribute__((address_space(4))) AdamTable* kt = (const __attribute__((address_space(4))) AdamTable*)__builtin_amdgcn_kernarg_segment_ptr();
+    const int blk = (int)blockIdx.x;
+    int i = 0;
+    for (int q = 1; q < kt->n; ++q)
+        if (blk >= kt->first_block[q]) i = q;
+    const float step = steps[blk] + 1.0f;
+    const float lr = lr_dev ? *lr_dev : lr_host;
+    const float bc1 = 1.0f - powf(b1, step), bc2 = 1.0f - powf(b2, step);
+    const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2);
+    const long n = kt->numel[i], e0 = (long)(blk - kt->first_block[i]) * ADAM_BLOCK + 4 * (long)threadIdx.x;
+    float* __restrict__ p = kt->p[i]; const float* __restrict__ g = kt->g[i];
+    float* __restrict__ m = kt->m[i]; float* __restrict__ v = kt->v[i];
+    auto one = [&](float& pv, float gv, float& mv, float& vv) {
+        if (maximize) gv = -gv;
+        if (wd != 0.0f) { if (decoupled) pv -= lr * wd * pv; else gv += wd * pv; }
+        { const float w = 1.0f - b1, d = gv - mv; mv = w < 0.5f ? mv + w * d : gv - d * (1.0f - w); }      // std::lerp(m, g, 1 - b1), as torch
+        vv = b2 * vv + (1.0f - b2) * gv * gv;
+        pv -= step_size * mv / (sqrtf(vv) / bc2_sqrt + eps);
+    };
+    if (e0 + 3 < n && ((((size_t)p) | ((size_t)g) | ((size_t)m) | ((size_t)v)) & 15) == 0) {
+        float4 pv = *reinterpret_cast<const float4*>(p + e0), mv = *reinterpret_cast<const float4*>(m + e0), vv = *reinterpret_cast<const float4*>(v + e0);
+        const float4 gv = *reinterpret_cast<const float4*>(g + e0);
+        one(pv.x, gv.x, mv.x, vv.x); one(pv.y, gv.y, mv.y, vv.y); one(pv.z, gv.z, mv.z, vv.z); one(pv.w, gv.w, mv.w, vv.w);
+        *reinterpret_cast<float4*>(p + e0) = pv; *reinterpret_cast<float4*>(m + e0) = mv; *reinterpret_cast<float4*>(v + e0) = vv;
+    } else {
+        for (long e = e0; e < n && e < e0 + 4; ++e) {
+            float pv = p[e], mv = m[e], vv = v[e];
+            one(pv, g[e], mv, vv);
+            p[e] = pv; m[e] = mv; v[e] = vv;
+        }
+    }
+    __syncthreads();                                           // every thread has read the step word
+    if (threadIdx.x == 0) steps[blk] = step;
+}
+}  // namespace hs
+
+extern "C" int64_t hs_adam_blocks(const int64_t* numel, int32_t n) {
+    if (!numel || n <= 0 || n > hs::ADAM_MAX_TENSORS) return 0;
+    int64_t b = 0;
+    for (int i = 0; i < n; ++i) { if (numel[i] <= 0) return 0; b += (numel[i] + hs::ADAM_BLOCK - 1) / hs::ADAM_BLOCK; }
+    return b < 0x7fffffff ? b : 0;
+}
+
+extern "C" int hs_adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
+                            int32_t n, const float* lr_device, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t decoupled,
+                            int32_t maximize, float* steps, void* stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !steps || n <= 0) return HS_ERR_BAD_ARG;
+    if (n > hs::ADAM_MAX_TENSORS) return HS_ERR_UNSUPPORTED;
+    hs::AdamTable t{};
+    int b = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i] || numel[i] <= 0) return HS_ERR_BAD_ARG;
+        t.p[i] = params[i]; t.g[i] = grads[i]; t.m[i] = exp_avg[i]; t.v[i] = exp_avg_sq[i]; t.numel[i] = (long)numel[i];
+        t.first_block[i] = b;
+        const int64_t nb = (numel[i] + hs::ADAM_BLOCK - 1) / hs::ADAM_BLOCK;
+        if (nb + b >= 0x7fffffff) return HS_ERR_UNSUPPORTED;
+        b += (int)nb;
+    }
+    t.first_block[n] = b; t.n = n;
+    hipLaunchKernelGGL(hs::adam_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, t, lr_device, lr, beta1, beta2, eps, weight_decay,
+                       decoupled, maximize, steps);
+    return hs::launch_status();
+}

@@ -98,6 +98,80 @@ class PolyLR(LRScheduler):
         return [base * decay for base in self.base_lrs]
 
 
+class Adam(torch.optim.Optimizer):
+    """``torch.optim.Adam`` / ``AdamW`` arithmetic (no amsgrad) with the whole parameter list of a group updated by ONE launch of
+    1024-element workgroups (``hs_adam_step``; round 5).  The reference trains with ``optim.Adam(lr, betas=(0.5, 0.999))``
+    (hyperseg/train.py:185-188, configs/train/*); torch's fused form is one launch too, but it cuts the list into 65 536-element
+    chunks -- a dozen workgroups for the decoder's ~0.7 M parameters, 25 us of a 0.88 ms config-5 step.
+
+    Capturable by construction: the step count lives on the device (one word per workgroup, incremented by the kernel), ``lr`` may be a
+    float or a one-element CUDA tensor (what a scheduler updates in place under a captured step, ``GraphedTrainStep``).  fp32 CUDA
+    parameters with dense fp32 gradients only; every parameter of a group that has a gradient takes part, and the SET of those
+    parameters must not change between steps (the per-workgroup step words are laid out for it; a change raises)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled_weight_decay=False, maximize=False):
+        if not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0 or eps < 0.0 or weight_decay < 0.0:
+            raise ValueError('hyperseg_amd.training.Adam: invalid hyper-parameters')
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay,
+                                      decoupled_weight_decay=bool(decoupled_weight_decay), maximize=bool(maximize)))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        import ctypes as C
+        from . import _hip
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            ps = [p for p in group['params'] if p.grad is not None]
+            if not ps:
+                continue
+            for p in ps:
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.dtype == torch.float32
+                        and not p.grad.is_sparse and p.grad.device == p.device):
+                    raise NotImplementedError('hyperseg_amd.training.Adam: contiguous fp32 CUDA parameters with dense fp32 gradients only')
+            dev = ps[0].device
+            for lo in range(0, len(ps), 48):                                   # hs_adam_step takes up to 48 tensors per launch
+                chunk = ps[lo:lo + 48]
+                for p in chunk:
+                    st = self.state[p]
+                    if not st:
+                        st['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                        st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                n = len(chunk)
+                numel = (C.c_int64 * n)(*[p.numel() for p in chunk])
+                key = f'_hs_steps_{lo}'
+                sig = tuple(p.numel() for p in chunk)
+                held = group.get(key)
+                if held is None:
+                    blocks = int(_hip.lib.hs_adam_blocks(numel, n))
+                    if blocks <= 0:
+                        raise NotImplementedError('hyperseg_amd.training.Adam: parameter list not covered by hs_adam_step')
+                    held = group[key] = (sig, torch.zeros(blocks, device=dev, dtype=torch.float32))
+                elif held[0] != sig:
+                    raise RuntimeError('hyperseg_amd.training.Adam: the set of parameters with gradients changed between steps')
+                grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in chunk]
+                arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])      # noqa: E731
+                lr = group['lr']
+                lr_dev = lr if isinstance(lr, torch.Tensor) and lr.is_cuda else None
+                if lr_dev is not None and (lr_dev.dtype != torch.float32 or lr_dev.numel() != 1):
+                    raise NotImplementedError('hyperseg_amd.training.Adam: a device learning rate must be one fp32 element')
+                with _hip.device_scope(dev):
+                    status = _hip.lib.hs_adam_step(arr(chunk), arr(grads), arr([self.state[p]['exp_avg'] for p in chunk]),
+                                                   arr([self.state[p]['exp_avg_sq'] for p in chunk]), numel, n,
+                                                   lr_dev.data_ptr() if lr_dev is not None else None, 0.0 if lr_dev is not None else float(lr),
+                                                   float(group['betas'][0]), float(group['betas'][1]), float(group['eps']), float(group['weight_decay']),
+                                                   int(group['decoupled_weight_decay']), int(group['maximize']), held[1].data_ptr(), _hip.stream_ptr(dev))
+                _hip.check(status, 'hs_adam_step')
+        return loss
+
+    def steps_taken(self, group=0):
+        """The step count of a group as the device holds it (synchronises)."""
+        held = self.param_groups[group].get('_hs_steps_0')
+        return 0 if held is None else int(held[1][0].item())
+
+
 def train_step(model, criterion, optimizer, scheduler, x, target):
     """One optimisation step; returns (loss, prediction).  ``model`` is any callable producing (N, C, h, w) logits."""
     pred = model(x)

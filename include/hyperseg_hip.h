@@ -499,6 +499,14 @@ int hs_dw_tiles_bwd_w(int32_t dtype, const void* tiled, const void* dy, int32_t 
  * radix histogram of the bit patterns; ties at it share the remaining weight).  out5 = {loss, branch, 1/count, t, tie weight}: the
  * state hs_bootstrap_mean_bwd turns into d loss / d values.  workspace: hs_bootstrap_mean_workspace() bytes, scratch.  n > k. */
 int64_t hs_bootstrap_mean_workspace(void);
+/* Adam (torch.optim.Adam / AdamW arithmetic, no amsgrad) for up to 48 fp32 tensors in ONE launch of 1024-element workgroups: the
+ * training loop's optimizer step (hyperseg/train.py:185-188) without torch's 65 536-element chunking.  The arrays are HOST arrays of device
+ * pointers; `steps`: hs_adam_blocks(numel, n) floats on the device, zero before the first step, owned by this parameter list (one step
+ * count per workgroup: graph replay freezes kernel arguments); lr_device (optional) overrides lr.  decoupled: AdamW's weight decay. */
+int64_t hs_adam_blocks(const int64_t* numel, int32_t n);
+int hs_adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
+                 int32_t n, const float* lr_device, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t decoupled,
+                 int32_t maximize, float* steps, void* stream);
 int hs_bootstrap_mean_fwd(const float* values, int32_t n, int32_t k, float thresh, void* workspace, float* out5, void* stream);
 int hs_bootstrap_mean_bwd(const float* values, int32_t n, const float* state5, const float* grad_out, float* grad_values, void* stream);
 /* The same for `images` images at once (one set of launches, grid.y = image): values (images, n), workspace images x

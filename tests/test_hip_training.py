@@ -124,6 +124,128 @@ def test_optimizer_step_runs(dev):
     assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0]
 
 
+@pytest.mark.parametrize('kw', [dict(betas=(0.5, 0.999)), dict(betas=(0.9, 0.99), weight_decay=0.01),
+                                dict(betas=(0.9, 0.999), weight_decay=0.05, decoupled_weight_decay=True), dict(betas=(0.5, 0.999), maximize=True)],
+                         ids=['config5', 'l2', 'adamw', 'maximize'])
+def test_adam_one_launch_equals_torch_adam(dev, kw):
+    """hyperseg_amd.training.Adam (hs_adam_step: the whole parameter list in one launch, step count on the device) against
+    torch.optim.Adam / AdamW over 6 steps on tensors of awkward sizes (1, 3, 1023, 1024, 1025 elements, a matrix, 60 tensors = two
+    launches): parameters within 2e-6 of the scale after every step, float and device-tensor learning rates, a learning-rate change
+    between steps."""
+    from hyperseg_amd.training import Adam
+    sizes = [(1,), (3,), (1023,), (1024,), (1025,), (37, 53), (4216, 80)] + [(17 + i,) for i in range(53)]
+    g = G(4101)
+    p0 = [torch.randn(sz, generator=g) for sz in sizes]
+    grads = [[torch.randn(sz, generator=g) * (0.1 + 0.3 * k) for sz in sizes] for k in range(6)]
+    tkw = {k: v for k, v in kw.items() if k != 'decoupled_weight_decay'}
+    ref_cls = torch.optim.AdamW if kw.get('decoupled_weight_decay') else torch.optim.Adam
+    for lr_as_tensor in (False, True):
+        pa = [torch.nn.Parameter(t.clone().to(dev)) for t in p0]
+        pb = [torch.nn.Parameter(t.clone().to(dev)) for t in p0]
+        lr = torch.tensor(3e-3, device=dev) if lr_as_tensor else 3e-3
+        ours = Adam(pa, lr=lr.clone() if lr_as_tensor else lr, **kw)
+        ref = ref_cls(pb, lr=3e-3, **tkw)
+        for k in range(6):
+            if k == 3:                                      # a scheduler's update
+                if lr_as_tensor:
+                    ours.param_groups[0]['lr'].fill_(1e-3)
+                else:
+                    ours.param_groups[0]['lr'] = 1e-3
+                ref.param_groups[0]['lr'] = 1e-3
+            for a, b_, gr in zip(pa, pb, grads[k]):
+                a.grad = gr.to(dev).clone()
+                b_.grad = gr.to(dev).clone()
+            ours.step()
+            ref.step()
+            for i, (a, b_) in enumerate(zip(pa, pb)):
+                assert rel_err(a.detach().cpu(), b_.detach().cpu()) < 2e-6, (k, i, sizes[i])
+        assert ours.steps_taken() == 6
+        st_a, st_b = ours.state[pa[6]], ref.state[pb[6]]
+        assert rel_err(st_a['exp_avg'].cpu(), st_b['exp_avg'].cpu()) < 2e-6 and rel_err(st_a['exp_avg_sq'].cpu(), st_b['exp_avg_sq'].cpu()) < 2e-6
+
+
+def test_graphed_train_step_with_the_one_launch_adam(dev):
+    """GraphedTrainStep around hyperseg_amd.training.Adam: three replays of the captured step equal three eager steps of a twin BIT FOR BIT
+    (same kernels, same order; the per-workgroup step words advance under replay), and the loss goes down."""
+    from oracle import hyperseg_oracle as O
+    from test_hip_parity import build_decoder
+    from hyperseg_amd.training import Adam, GraphedTrainStep, BootstrappedCrossEntropyLoss
+    import copy
+    d0 = build_decoder('Sc', O).to(dev).train()
+    d1 = copy.deepcopy(d0)
+    x, s = O.synth_decoder_inputs('Sc', batch=2, seed=9, size=(96, 96))
+    x = [t.to(dev) for t in x]
+    s = s.to(dev)
+    target = torch.randint(0, 12, (2, 96, 96), generator=G(4102)).to(dev)
+    crit = BootstrappedCrossEntropyLoss()
+    o0 = Adam(d0.parameters(), lr=torch.tensor(2e-3, device=dev), betas=(0.5, 0.999))
+    o1 = Adam(d1.parameters(), lr=torch.tensor(2e-3, device=dev), betas=(0.5, 0.999))
+    step = GraphedTrainStep(d0, crit, o0, (x, s), target, warmup=1)
+    losses_e = []
+    for _ in range(1 + 3):                                 # the twin: the warm-up step + three more, eagerly
+        o1.zero_grad(set_to_none=True)
+        loss = crit(d1(x, s), target)
+        loss.backward()
+        o1.step()
+        losses_e.append(float(loss.detach()))
+    losses_g = [float(step.step()[0]) for _ in range(3)]
+    torch.cuda.synchronize()
+    assert losses_g == losses_e[1:], (losses_g, losses_e)
+    for (k, a), (_, b_) in zip(d0.state_dict().items(), d1.state_dict().items()):
+        assert torch.equal(a, b_), k
+    assert o0.steps_taken() == o1.steps_taken() == 4 and losses_g[-1] < losses_e[0]
+
+
+@pytest.mark.parametrize('autocast', [False, True], ids=['fp32', 'bf16'])
+def test_bank_slices_share_one_gradient_buffer(dev, autocast):
+    """autograd.BankSlices (round 5): the three layers of a train-mode inverted residual write their weight gradients into views of ONE
+    (patches, ld) buffer, which BankSlices.backward returns as it is -- every gradient of the decoder bit-equal to the route that
+    concatenates three separately allocated tensors, and no concatenation is launched for the banks."""
+    from oracle import hyperseg_oracle as O
+    from test_hip_parity import build_decoder
+    from hyperseg_amd import autograd as HA
+    d = build_decoder('Sc', O).to(dev).train()
+    x, s0 = O.synth_decoder_inputs('Sc', batch=2, seed=5, size=(96, 96))
+    x = [t.to(dev) for t in x]
+    r = torch.randn(2, 12, 96, 96, generator=G(1031)).to(dev)
+    state = {k: v.clone() for k, v in d.state_dict().items()}
+
+    def run(shared):
+        prev = HA.USE_SHARED_BANK_GRAD
+        HA.USE_SHARED_BANK_GRAD = shared
+        returned = {'buffers': 0, 'cats': 0}
+        real_b, real_cat = HA.BankSlices.backward, torch.cat
+
+        def counting_backward(ctx, *g):
+            out = real_b(ctx, *g)
+            returned['buffers'] += 1
+            return out
+
+        def counting_cat(*a, **k):
+            returned['cats'] += 1
+            return real_cat(*a, **k)
+        HA.BankSlices.backward = staticmethod(counting_backward)
+        torch.cat = counting_cat
+        try:
+            d.load_state_dict(state)
+            d.zero_grad()
+            s = s0.to(dev).clone().requires_grad_(True)
+            with torch.autocast('cuda', dtype=torch.bfloat16, enabled=autocast):
+                y = d(x, s)
+            (y.float() * r).sum().backward()
+            return {**{k: v.grad.clone() for k, v in d.named_parameters() if v.grad is not None}, 'signal': s.grad.clone()}, returned
+        finally:
+            HA.USE_SHARED_BANK_GRAD = prev
+            HA.BankSlices.backward = staticmethod(real_b)
+            torch.cat = real_cat
+    (one, n_one), (two, n_two) = run(True), run(False)
+    assert n_one['buffers'] == n_two['buffers'] == 2                 # the two inverted-residual levels
+    assert n_two['cats'] - n_one['cats'] == 2, (n_one, n_two)        # ... whose concatenations are gone
+    assert set(one) == set(two)
+    for k in one:
+        assert torch.equal(one[k], two[k]), k
+
+
 @pytest.mark.parametrize('shape,grid', [((2, 5, 36, 20), (2, 2)), ((1, 3, 8, 12), (4, 3)), ((1, 2, 6, 6), (6, 6)), ((2, 4, 40, 130), (5, 2)),
                                         ((1, 1, 2, 2), (1, 1))])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])

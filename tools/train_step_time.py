@@ -25,12 +25,18 @@ dec = model.decoder.train()
 target = torch.randint(0, 12, (2, 576, 576), device=dev)
 crit = BootstrappedCrossEntropyLoss(k=4096, thresh=0.3, ignore_index=255)
 FUSED = os.environ.get('HS_ADAM_FUSED', '1') == '1'      # torch's single-launch Adam (same arithmetic as the foreach form the reference's optim.Adam resolves to)
-opt = torch.optim.Adam(dec.parameters(), lr=1e-3, betas=(0.5, 0.999), fused=FUSED)
+OURS = os.environ.get('HS_ADAM', 'ours') == 'ours'        # hyperseg_amd.training.Adam (one launch of 1024-element workgroups); 'torch': torch.optim.Adam
+if os.environ.get('HS_SHARED_BANK_GRAD') == '0':
+    import hyperseg_amd.autograd as _HA
+    _HA.USE_SHARED_BANK_GRAD = False
+from hyperseg_amd.training import Adam as OwnAdam
+opt = OwnAdam(dec.parameters(), lr=1e-3, betas=(0.5, 0.999)) if OURS else torch.optim.Adam(dec.parameters(), lr=1e-3, betas=(0.5, 0.999), fused=FUSED)
 modes = sys.argv[2:] if len(sys.argv) > 2 else ('fp32', 'bf16', 'graph', 'graph_bf16')
 for mode in modes:
     if mode in ('graph', 'graph_bf16'):                     # the step captured once and replayed (hyperseg_amd.training.GraphedTrainStep)
         from hyperseg_amd.training import GraphedTrainStep
-        opt_g = torch.optim.Adam(dec.parameters(), lr=torch.tensor(1e-3, device=dev), betas=(0.5, 0.999), capturable=True, fused=FUSED)
+        opt_g = OwnAdam(dec.parameters(), lr=torch.tensor(1e-3, device=dev), betas=(0.5, 0.999)) if OURS else \
+            torch.optim.Adam(dec.parameters(), lr=torch.tensor(1e-3, device=dev), betas=(0.5, 0.999), capturable=True, fused=FUSED)
 
         def fwd(p, sig, half=(mode == 'graph_bf16')):
             with torch.autocast('cuda', dtype=torch.bfloat16, enabled=half):
