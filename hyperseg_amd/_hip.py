@@ -147,7 +147,7 @@ def _load():
         'hs_patch_conv_bn_fwd': ([i32, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, i32, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp, vp], C.c_int),
         'hs_patch_conv_bn_bwd_w': ([i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, vp], C.c_int),
         'hs_adam_blocks': ([vp, i32], C.c_int64),
-        'hs_adam_step': ([vp, vp, vp, vp, vp, i32, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, i32, i32, vp, vp], C.c_int),
+        'hs_adam_step': ([vp, vp, vp, vp, vp, i32, vp, C.c_float, C.c_double, C.c_double, C.c_float, C.c_float, i32, i32, vp, vp], C.c_int),
         'hs_depthwise_pool_blocks': ([i32, i32], C.c_int),
         'hs_depthwise_conv_se_fwd': ([vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, C.POINTER(SeTailC), vp], C.c_int),
         'hs_mbconv_expand_dw_se_fwd': ([vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, C.POINTER(SeTailC), vp], C.c_int),

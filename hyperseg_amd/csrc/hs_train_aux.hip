@@ -914,7 +914,7 @@ struct AdamTable {
 };
 
 __global__ __launch_bounds__(256)
-void adam_kernel(AdamTable t, const float* __restrict__ lr_dev, float lr_host, float b1, float b2, float eps, float wd, int decoupled,
+void adam_kernel(AdamTable t, const float* __restrict__ lr_dev, float lr_host, double b1d, double b2d, float eps, float wd, int decoupled,
                  int maximize, float* __restrict__ steps) {
     const __attribute__((address_space(4))) AdamTable* kt = (const __attribute__((address_space(4))) AdamTable*)__builtin_amdgcn_kernarg_segment_ptr();
     const int blk = (int)blockIdx.x;
@@ -923,7 +923,9 @@ void adam_kernel(AdamTable t, const float* __restrict__ lr_dev, float lr_host, f
         if (blk >= kt->first_block[q]) i = q;
     const float step = steps[blk] + 1.0f;
     const float lr = lr_dev ? *lr_dev : lr_host;
-    const float bc1 = 1.0f - powf(b1, step), bc2 = 1.0f - powf(b2, step);
+    // the betas are doubles as in torch (1 - 0.999f is 1.3e-5 off 1 - 0.999), narrowed where torch narrows them
+    const float b2 = (float)b2d, om1 = (float)(1.0 - b1d), om2 = (float)(1.0 - b2d);
+    const float bc1 = (float)(1.0 - pow(b1d, (double)step)), bc2 = (float)(1.0 - pow(b2d, (double)step));
     const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2);
     const long n = kt->numel[i], e0 = (long)(blk - kt->first_block[i]) * ADAM_BLOCK + 4 * (long)threadIdx.x;
     float* __restrict__ p = kt->p[i]; const float* __restrict__ g = kt->g[i];
@@ -931,8 +933,8 @@ void adam_kernel(AdamTable t, const float* __restrict__ lr_dev, float lr_host, f
     auto one = [&](float& pv, float gv, float& mv, float& vv) {
         if (maximize) gv = -gv;
         if (wd != 0.0f) { if (decoupled) pv -= lr * wd * pv; else gv += wd * pv; }
-        { const float w = 1.0f - b1, d = gv - mv; mv = w < 0.5f ? mv + w * d : gv - d * (1.0f - w); }      // std::lerp(m, g, 1 - b1), as torch
-        vv = b2 * vv + (1.0f - b2) * gv * gv;
+        { const float d = gv - mv; mv = om1 < 0.5f ? mv + om1 * d : gv - d * (1.0f - om1); }      // std::lerp(m, g, 1 - b1), as torch
+        vv = b2 * vv + om2 * gv * gv;
         pv -= step_size * mv / (sqrtf(vv) / bc2_sqrt + eps);
     };
     if (e0 + 3 < n && ((((size_t)p) | ((size_t)g) | ((size_t)m) | ((size_t)v)) & 15) == 0) {
@@ -960,7 +962,7 @@ extern "C" int64_t hs_adam_blocks(const int64_t* numel, int32_t n) {
 }
 
 extern "C" int hs_adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
-                            int32_t n, const float* lr_device, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t decoupled,
+                            int32_t n, const float* lr_device, float lr, double beta1, double beta2, float eps, float weight_decay, int32_t decoupled,
                             int32_t maximize, float* steps, void* stream) {
     if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !steps || n <= 0) return HS_ERR_BAD_ARG;
     if (n > hs::ADAM_MAX_TENSORS) return HS_ERR_UNSUPPORTED;
@@ -975,7 +977,7 @@ extern "C" int hs_adam_step(float* const* params, const float* const* grads, flo
         b += (int)nb;
     }
     t.first_block[n] = b; t.n = n;
-    hipLaunchKernelGGL(hs::adam_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, t, lr_device, lr, beta1, beta2, eps, weight_decay,
-                       decoupled, maximize, steps);
+    hipLaunchKernelGGL(hs::adam_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, t, lr_device, lr, beta1, beta2, eps,
+                       weight_decay, decoupled, maximize, steps);
     return hs::launch_status();
 }

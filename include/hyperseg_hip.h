@@ -505,7 +505,7 @@ int64_t hs_bootstrap_mean_workspace(void);
  * count per workgroup: graph replay freezes kernel arguments); lr_device (optional) overrides lr.  decoupled: AdamW's weight decay. */
 int64_t hs_adam_blocks(const int64_t* numel, int32_t n);
 int hs_adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
-                 int32_t n, const float* lr_device, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t decoupled,
+                 int32_t n, const float* lr_device, float lr, double beta1, double beta2, float eps, float weight_decay, int32_t decoupled,
                  int32_t maximize, float* steps, void* stream);
 int hs_bootstrap_mean_fwd(const float* values, int32_t n, int32_t k, float thresh, void* workspace, float* out5, void* stream);
 int hs_bootstrap_mean_bwd(const float* values, int32_t n, const float* state5, const float* grad_out, float* grad_values, void* stream);

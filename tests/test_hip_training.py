@@ -952,8 +952,8 @@ def _emulated_bf16(monkeypatch):
             return real(kind, dtype, a, b, ld, shape, meta, out)
         a32 = a.float().contiguous()
         b32 = b.float().contiguous()
-        ld32 = b32.stride(0) if kind != 'bwd_w' else out.stride(0)
         out32 = torch.zeros(out.shape, device=out.device, dtype=torch.float32)
+        ld32 = b32.stride(0) if kind != 'bwd_w' else out32.stride(0)           # (``out`` may be a column range of a wider buffer: BankSlices)
         real(kind, torch.float32, a32, b32, ld32, shape, meta, out32)
         out.copy_(out32)
         return out
