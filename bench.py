@@ -458,12 +458,18 @@ def side_train_step(dev, iters):
         dec = model.decoder.train()
         target = torch.randint(0, 12, (2, 576, 576), generator=gen).to(dev)
         crit = BootstrappedCrossEntropyLoss(k=4096, thresh=0.3, ignore_index=255)
+        from hyperseg_amd.training import Adam as OneLaunchAdam
         res = {'workload': 'HyperSeg-S / CamVid decoder training step, 576x576 crops, batch 2: forward + bootstrapped CE + backward + Adam, '
-                           'one HIP graph per step (encoder features and signal resident, as tools/train_step_time.py)'}
+                           'one HIP graph per step (encoder features and signal resident, as tools/train_step_time.py)',
+               'optimizer': 'hyperseg_amd.training.Adam (torch.optim.Adam arithmetic, the whole parameter list in one launch: hs_adam_step); '
+                            'the same step with torch.optim.Adam(capturable, fused) is timed beside it as fp32_torch_adam'}
         state0 = {k: v.clone() for k, v in dec.state_dict().items()}
-        for mode in ('fp32', 'bf16'):
+        for mode in ('fp32', 'bf16', 'fp32_torch_adam'):
             dec.load_state_dict(state0)
-            opt = torch.optim.Adam(dec.parameters(), lr=torch.tensor(1e-3, device=dev), betas=(0.5, 0.999), capturable=True, fused=True)
+            if mode == 'fp32_torch_adam':
+                opt = torch.optim.Adam(dec.parameters(), lr=torch.tensor(1e-3, device=dev), betas=(0.5, 0.999), capturable=True, fused=True)
+            else:
+                opt = OneLaunchAdam(dec.parameters(), lr=torch.tensor(1e-3, device=dev), betas=(0.5, 0.999))
 
             def fwd(p, s_, half=(mode == 'bf16')):
                 with torch.autocast('cuda', dtype=torch.bfloat16, enabled=half):
@@ -490,7 +496,7 @@ def side_train_step(dev, iters):
         try:                                                  # the longest kernel of one eager fp32 step (kineto / roctracer)
             from torch.profiler import ProfilerActivity, profile
             dec.load_state_dict(state0)
-            opt = torch.optim.Adam(dec.parameters(), lr=1e-3, betas=(0.5, 0.999), fused=True)
+            opt = OneLaunchAdam(dec.parameters(), lr=1e-3, betas=(0.5, 0.999))
 
             def eager():
                 opt.zero_grad(set_to_none=True)
