@@ -865,22 +865,40 @@ __device__ __forceinline__ size_t dwt_tile(const DwtArgs& a, int b, int c, int i
     return (((size_t)b * a.C + c) * (size_t)(a.fh * (a.ph + 2)) + (size_t)i * (a.ph + 2)) * row_stride + (size_t)j * (a.pw + 2);
 }
 
-template <typename T, bool BN>
+// RPT: output rows per thread (1, or 2 where the patch height is even -- the two rows then share one patch and three of the four tile
+// rows they read: 8 pair loads and 16 normalisations for 4 outputs instead of 12 and 24, half as many workgroups to finalise the
+// statistics in; round 5: 20.8 us with one row at config 5's level 4 against 13.8 without the normalisation).
+template <typename T, bool BN, int RPT = 1>
 __global__ __launch_bounds__(256)
 void dw_tiles_fwd_kernel(DwtArgs a, DwtBn n, const T* __restrict__ t, T* __restrict__ y) {
-    const int x0 = 2 * (blockIdx.x * 64 + (threadIdx.x & 63)), yy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x0 = 2 * (blockIdx.x * 64 + (threadIdx.x & 63)), yy = RPT * (blockIdx.y * 4 + (threadIdx.x >> 6));
     const int plane_id = blockIdx.z;
     const int b = div_by_inv(plane_id, a.inv_c), c = plane_id - b * a.C;
+    if (x0 >= a.W || yy >= a.H) return;
+    const int i = div_by_inv(yy, a.inv_ph), u = yy - i * a.ph, j = div_by_inv(x0, a.inv_pw), v = x0 - j * a.pw;
+    int TW;
+    const T* __restrict__ tp = t + dwt_tile(a, b, c, i, j, TW) + (size_t)u * TW + v;
+    const float* __restrict__ kp = a.bank + (size_t)((b * a.fh + i) * a.fw + j) * a.ld + c * 9;
+    float s[2 + RPT][4], kv[9];
+#pragma unroll
+    for (int r = 0; r < 2 + RPT; ++r) {
+        Pair<T>::ld(tp, (size_t)r * TW, s[r][0], s[r][1]);
+        Pair<T>::ld(tp, (size_t)r * TW + 2, s[r][2], s[r][3]);
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) kv[q] = kp[q];
+    // (the statistics are finalised HERE, with the tile and tap requests already out: at the top of the kernel the 64 scalar loads and
+    //  their serial sums sat in front of every workgroup's first vector load -- 23.8 -> 20.8 us for this launch, visits r5v19 / r5v20)
     float g = 1.0f, bb = 0.0f;
     if constexpr (BN) {
         // mean / invstd of channel c from the 32 slice sums (uniform over the workgroup: scalar loads), exactly as bn_apply_kernel forms them
         const float shift = Store<T>::ld(t, (size_t)c * n.shift_stride);
-        float s = 0.f, q = 0.f;
-        for (int i = 0; i < BN_CHUNKS; ++i) { s += n.partial[((size_t)c * BN_CHUNKS + i) * 2]; q += n.partial[((size_t)c * BN_CHUNKS + i) * 2 + 1]; }
-        const float md = s / n.n, var = fmaxf(q / n.n - md * md, 0.f), mean = md + shift, invstd = rsqrtf(var + n.eps);
+        float ps = 0.f, pq = 0.f;
+        for (int ci = 0; ci < BN_CHUNKS; ++ci) { ps += n.partial[((size_t)c * BN_CHUNKS + ci) * 2]; pq += n.partial[((size_t)c * BN_CHUNKS + ci) * 2 + 1]; }
+        const float md = ps / n.n, var = fmaxf(pq / n.n - md * md, 0.f), mean = md + shift, invstd = rsqrtf(var + n.eps);
         g = n.gamma ? n.gamma[c] * invstd : invstd;
         bb = (n.beta ? n.beta[c] : 0.f) - mean * g;
-        if (b == 0 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {          // one writer per channel
+        if (b == 0 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {          // one writer per channel (never out of range: x0 = yy = 0)
             n.mean[c] = mean; n.invstd[c] = invstd;
             if (n.running_mean) {
                 n.running_mean[c] = (1.f - n.momentum) * n.running_mean[c] + n.momentum * mean;
@@ -888,35 +906,23 @@ void dw_tiles_fwd_kernel(DwtArgs a, DwtBn n, const T* __restrict__ t, T* __restr
             }
             if (n.counter && c == 0) *n.counter += 1;
         }
-    }
-    if (x0 >= a.W || yy >= a.H) return;
-    const int i = div_by_inv(yy, a.inv_ph), u = yy - i * a.ph, j = div_by_inv(x0, a.inv_pw), v = x0 - j * a.pw;
-    int TW;
-    const T* __restrict__ tp = t + dwt_tile(a, b, c, i, j, TW) + (size_t)u * TW + v;
-    const float* __restrict__ kp = a.bank + (size_t)((b * a.fh + i) * a.fw + j) * a.ld + c * 9;
-    float s[3][4], kv[9];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        Pair<T>::ld(tp, (size_t)r * TW, s[r][0], s[r][1]);
-        Pair<T>::ld(tp, (size_t)r * TW + 2, s[r][2], s[r][3]);
-    }
-#pragma unroll
-    for (int q = 0; q < 9; ++q) kv[q] = kp[q];
-    if constexpr (BN) {
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
+        for (int r = 0; r < 2 + RPT; ++r)
 #pragma unroll
             for (int q = 0; q < 4; ++q) s[r][q] = dwt_act(fmaf(s[r][q], g, bb), n.act);
     }
-    float acc0 = 0.0f, acc1 = 0.0f;
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+    for (int ro = 0; ro < RPT; ++ro) {
+        float acc0 = 0.0f, acc1 = 0.0f;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            acc0 = fmaf(kv[ky * 3 + kx], s[ky][kx], acc0);
-            acc1 = fmaf(kv[ky * 3 + kx], s[ky][kx + 1], acc1);
-        }
-    Pair<T>::st(y, ((size_t)plane_id * a.H + yy) * a.W + x0, acc0, acc1);
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                acc0 = fmaf(kv[ky * 3 + kx], s[ro + ky][kx], acc0);
+                acc1 = fmaf(kv[ky * 3 + kx], s[ro + ky][kx + 1], acc1);
+            }
+        Pair<T>::st(y, ((size_t)plane_id * a.H + yy + ro) * a.W + x0, acc0, acc1);
+    }
 }
 
 // dt[tile position (U, V)] = sum_{ky,kx} K[ky][kx] dy[U - ky][V - kx] over the patch's own outputs (0 <= U - ky < ph, 0 <= V - kx < pw)
@@ -962,7 +968,9 @@ void dw_tiles_bwd_in_kernel(DwtArgs a, const T* __restrict__ dy, T* __restrict__
 }
 
 // dK[patch][c][ky][kx] = sum over the patch's outputs (u, v) of dy[u][v] t[u + ky][v + kx]: one wave per (patch, channel), a lane owns output pairs
-template <typename T, bool BN>
+// RPT: output rows per lane and iteration (2 where the patch height is even: 16 tile values normalised for 4 output gradients instead of
+// 24; both the plain and the BN form take the same RPT for a shape, so they stay bit-equal to each other)
+template <typename T, bool BN, int RPT = 1>
 __global__ __launch_bounds__(256)
 void dw_tiles_bwd_w_kernel(DwtArgs a, DwtBn n, const T* __restrict__ t, const T* __restrict__ dy) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -978,31 +986,34 @@ void dw_tiles_bwd_w_kernel(DwtArgs a, DwtBn n, const T* __restrict__ t, const T*
     int TW;
     const T* __restrict__ tp = t + dwt_tile(a, b, c, i, j, TW);
     const T* __restrict__ gp = dy + (((size_t)b * a.C + c) * a.H + (size_t)i * a.ph) * a.W + (size_t)j * a.pw;
-    const int hw = a.pw >> 1, npair = a.ph * hw;
+    const int hw = a.pw >> 1, npair = (a.ph / RPT) * hw;
     const float inv_hw = 2.0f * a.inv_pw;
     float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int l = lane; l < npair; l += 64) {
-        const int u = div_by_inv(l, inv_hw), v = 2 * (l - u * hw);
-        float g0, g1, s[3][4];
-        Pair<T>::ld(gp, (size_t)u * a.W + v, g0, g1);
+        const int ur = div_by_inv(l, inv_hw), u = RPT * ur, v = 2 * (l - ur * hw);
+        float g0[RPT], g1[RPT], s[2 + RPT][4];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
+        for (int ro = 0; ro < RPT; ++ro) Pair<T>::ld(gp, (size_t)(u + ro) * a.W + v, g0[ro], g1[ro]);
+#pragma unroll
+        for (int r = 0; r < 2 + RPT; ++r) {
             Pair<T>::ld(tp, (size_t)(u + r) * TW + v, s[r][0], s[r][1]);
             Pair<T>::ld(tp, (size_t)(u + r) * TW + v + 2, s[r][2], s[r][3]);
         }
         if constexpr (BN) {
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
+            for (int r = 0; r < 2 + RPT; ++r)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) s[r][q] = dwt_act(fmaf(s[r][q], g, bb), n.act);
         }
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        for (int ro = 0; ro < RPT; ++ro)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                acc[ky * 3 + kx] = fmaf(g0, s[ky][kx], acc[ky * 3 + kx]);
-                acc[ky * 3 + kx] = fmaf(g1, s[ky][kx + 1], acc[ky * 3 + kx]);
-            }
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    acc[ky * 3 + kx] = fmaf(g0[ro], s[ro + ky][kx], acc[ky * 3 + kx]);
+                    acc[ky * 3 + kx] = fmaf(g1[ro], s[ro + ky][kx + 1], acc[ky * 3 + kx]);
+                }
     }
     float* __restrict__ dst = a.dbank + (size_t)patch * a.ld + c * 9;
 #pragma unroll
@@ -1285,6 +1296,12 @@ extern "C" int hs_dw_tiles_bn_fwd(int32_t dtype, const void* tiled, const float*
     a.bank = bank;
     DwtBn n{bn_partial, gamma, beta, save_mean, save_invstd, running_mean, running_var, (long long*)num_batches_tracked, eps, momentum, 0.f, 0, act};
     dwt_bn_geometry(a, n);
+    if ((a.ph & 1) == 0) {                 // two output rows per thread: they share a patch
+        const dim3 grid2((W / 2 + 63) / 64, (H / 2 + 3) / 4, batch * channels);
+        if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_fwd_kernel<float, true, 2>), grid2, dim3(256), 0, (hipStream_t)stream, a, n, (const float*)tiled, (float*)y);
+        else hipLaunchKernelGGL((dw_tiles_fwd_kernel<bf16_t, true, 2>), grid2, dim3(256), 0, (hipStream_t)stream, a, n, (const bf16_t*)tiled, (bf16_t*)y);
+        return launch_status();
+    }
     const dim3 grid((W / 2 + 63) / 64, (H + 3) / 4, batch * channels);
     if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_fwd_kernel<float, true>), grid, dim3(256), 0, (hipStream_t)stream, a, n, (const float*)tiled, (float*)y);
     else hipLaunchKernelGGL((dw_tiles_fwd_kernel<bf16_t, true>), grid, dim3(256), 0, (hipStream_t)stream, a, n, (const bf16_t*)tiled, (bf16_t*)y);
@@ -1312,7 +1329,10 @@ extern "C" int hs_dw_tiles_bwd_w(int32_t dtype, const void* tiled, const void* d
     if (!dbank) return HS_ERR_BAD_ARG;
     a.dbank = dbank;
     const dim3 grid((unsigned)(batch * fh * fw), (channels + 3) / 4);
-    if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<float, false>), grid, dim3(256), 0, (hipStream_t)stream, a, DwtBn{}, (const float*)tiled, (const float*)dy);
+    if ((a.ph & 1) == 0) {
+        if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<float, false, 2>), grid, dim3(256), 0, (hipStream_t)stream, a, DwtBn{}, (const float*)tiled, (const float*)dy);
+        else hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<bf16_t, false, 2>), grid, dim3(256), 0, (hipStream_t)stream, a, DwtBn{}, (const bf16_t*)tiled, (const bf16_t*)dy);
+    } else if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<float, false>), grid, dim3(256), 0, (hipStream_t)stream, a, DwtBn{}, (const float*)tiled, (const float*)dy);
     else hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<bf16_t, false>), grid, dim3(256), 0, (hipStream_t)stream, a, DwtBn{}, (const bf16_t*)tiled, (const bf16_t*)dy);
     return launch_status();
 }
@@ -1328,7 +1348,10 @@ extern "C" int hs_dw_tiles_bn_bwd_w(int32_t dtype, const void* tiled, const void
     a.dbank = dbank;
     DwtBn n{nullptr, gamma, beta, const_cast<float*>(save_mean), const_cast<float*>(save_invstd), nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0, act};
     const dim3 grid((unsigned)(batch * fh * fw), (channels + 3) / 4);
-    if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<float, true>), grid, dim3(256), 0, (hipStream_t)stream, a, n, (const float*)tiled, (const float*)dy);
+    if ((a.ph & 1) == 0) {
+        if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<float, true, 2>), grid, dim3(256), 0, (hipStream_t)stream, a, n, (const float*)tiled, (const float*)dy);
+        else hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<bf16_t, true, 2>), grid, dim3(256), 0, (hipStream_t)stream, a, n, (const bf16_t*)tiled, (const bf16_t*)dy);
+    } else if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<float, true>), grid, dim3(256), 0, (hipStream_t)stream, a, n, (const float*)tiled, (const float*)dy);
     else hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<bf16_t, true>), grid, dim3(256), 0, (hipStream_t)stream, a, n, (const bf16_t*)tiled, (const bf16_t*)dy);
     return launch_status();
 }
