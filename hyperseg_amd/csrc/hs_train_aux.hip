@@ -136,8 +136,11 @@ void tile_interior_kernel(TileArgs a, const T* __restrict__ src, T* __restrict__
 // losses crowd into a few hundred high-bit bins, and every ignore_index pixel is an exact 0: global atomics on those few addresses
 // serialised; the first version of this file measured slower than the sort for that reason), flushed with one global atomic per
 // non-empty bin -- then one workgroup walks the bins from the top.
-// ws (uint32): [0, 2048) level-0 histogram, [2048, 3072) level 1, [3072, 4096) level 2, then state: [4096] prefix bits selected so
-// far, [4097] number of losses known to be above the prefix' bin, [4098] t bits, [4099] count > t.
+// ws (uint32): [0, 2048) level-0 histogram, [2048, 3072) level 1, [3072, 4096) level 2, then state, one pair PER LEVEL:
+// [4096 + 2 l] the prefix bits selected after level l, [4097 + 2 l] the number of losses known to be above that prefix' bin
+// (level 2's pair = t's bits and the count > t).  Round 5: the bin walk of level l runs at the TOP of the next launch (the histogram
+// of level l + 1, the sums after level 2), redundantly in each of its workgroups, instead of as a one-workgroup launch of its own
+// (3 launches of 3.6 us per step); a pair per level because workgroup 0 stores level l's pair while the others still read level l - 1's.
 // partial (float): per workgroup {sum over v > thresh, count > thresh, sum over v > t, count == t}, combined in workgroup order.
 // ---------------------------------------------------------------------------------------------------------------------------------
 constexpr int BM_BINS0 = 2048, BM_BINS12 = 1024, BM_STATE = BM_BINS0 + 2 * BM_BINS12, BM_WG = 128;
@@ -146,35 +149,15 @@ __device__ __forceinline__ int bm_shift(int level) { return level == 0 ? 20 : (l
 __device__ __forceinline__ int bm_bins(int level) { return level == 0 ? BM_BINS0 : BM_BINS12; }
 __device__ __forceinline__ int bm_base(int level) { return level == 0 ? 0 : (level == 1 ? BM_BINS0 : BM_BINS0 + BM_BINS12); }
 
-__global__ __launch_bounds__(256)
-void bm_hist_kernel(const float* __restrict__ v, int n, unsigned* __restrict__ ws, int level) {
-    __shared__ unsigned h[BM_BINS0];
-    v += (size_t)blockIdx.y * n; ws += (size_t)blockIdx.y * BM_WS_U32;           // image blockIdx.y of a batch (its own values and workspace)
-    const int nb = bm_bins(level), sh = bm_shift(level);
-    for (int i = threadIdx.x; i < nb; i += 256) h[i] = 0;
-    __syncthreads();
-    const unsigned prefix = level == 0 ? 0u : ws[BM_STATE];             // the bits above this level's, already shifted into place
-    const unsigned himask = level == 0 ? 0u : (0x7fffffffu >> (sh + 10)) << (sh + 10);
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
-        const unsigned b = __float_as_uint(fmaxf(v[e], 0.0f)) & 0x7fffffffu;
-        if ((b & himask) == prefix) atomicAdd(&h[(b >> sh) & (nb - 1)], 1u);
-    }
-    __syncthreads();
-    unsigned* g = ws + bm_base(level);
-    for (int i = threadIdx.x; i < nb; i += 256)
-        if (h[i]) atomicAdd(&g[i], h[i]);
-}
-
-// one workgroup: the bin (scanning from the top) in which the cumulative count reaches the wanted rank; extends the prefix
-__global__ __launch_bounds__(256)
-void bm_find_kernel(unsigned* __restrict__ ws, int level, int k) {
-    __shared__ unsigned part[256];
-    ws += (size_t)blockIdx.y * BM_WS_U32;
-    __shared__ unsigned sel[2];
+// The bin (scanning from the top) in which the cumulative count of level `level`'s histogram reaches the wanted rank, given the pair
+// after level - 1; every thread of the workgroup gets the pair after `level` (all 256 threads call it; part / sel: LDS).
+__device__ __forceinline__ void bm_find_body(const unsigned* __restrict__ ws, int level, int k, unsigned* part, unsigned* sel,
+                                             unsigned& prefix_out, unsigned& above_out) {
     const int tid = threadIdx.x;
     const int nbins = bm_bins(level), per = nbins / 256, sh = bm_shift(level);
     const unsigned* h = ws + bm_base(level);
-    const unsigned above = level == 0 ? 0u : ws[BM_STATE + 1];
+    const unsigned prefix_in = level == 0 ? 0u : ws[BM_STATE + 2 * (level - 1)];
+    const unsigned above = level == 0 ? 0u : ws[BM_STATE + 2 * (level - 1) + 1];
     const unsigned want = (unsigned)k - above;                          // rank inside the selected prefix
     // thread t owns bins [nbins - (t + 1) per, nbins - t per): descending order of value; exclusive prefix of the threads' sums by a
     // wave scan + the four wave totals (a serial walk over 256 partial sums by one thread was 8 us of this 9 us kernel)
@@ -199,17 +182,47 @@ void bm_find_kernel(unsigned* __restrict__ ws, int level, int k) {
         unsigned cum = sel[1]; int q = 0;
         for (; q < per - 1 && cum + h[nbins - 1 - (tid * per + q)] < want; ++q) cum += h[nbins - 1 - (tid * per + q)];
         const unsigned bin = (unsigned)(nbins - 1 - (tid * per + q));
-        const unsigned prefix = (level == 0 ? 0u : ws[BM_STATE]) | (bin << sh);
-        ws[BM_STATE] = prefix; ws[BM_STATE + 1] = above + cum;
-        if (level == 2) { ws[BM_STATE + 2] = prefix; ws[BM_STATE + 3] = above + cum; }
+        sel[2] = prefix_in | (bin << sh); sel[3] = above + cum;
     }
+    __syncthreads();
+    prefix_out = sel[2]; above_out = sel[3];
 }
 
 __global__ __launch_bounds__(256)
-void bm_sums_kernel(const float* __restrict__ v, int n, float thresh, const unsigned* __restrict__ ws, float* __restrict__ partial) {
+void bm_hist_kernel(const float* __restrict__ v, int n, unsigned* __restrict__ ws, int level, int k) {
+    __shared__ unsigned h[BM_BINS0];
+    __shared__ unsigned part[4], sel[4];
+    v += (size_t)blockIdx.y * n; ws += (size_t)blockIdx.y * BM_WS_U32;           // image blockIdx.y of a batch (its own values and workspace)
+    const int nb = bm_bins(level), sh = bm_shift(level);
+    for (int i = threadIdx.x; i < nb; i += 256) h[i] = 0;
+    unsigned prefix = 0u;                                               // the bits above this level's, already shifted into place
+    if (level > 0) {
+        unsigned above;
+        bm_find_body(ws, level - 1, k, part, sel, prefix, above);       // (its barriers also cover the zero fill above)
+        if (blockIdx.x == 0 && threadIdx.x == 0) { ws[BM_STATE + 2 * (level - 1)] = prefix; ws[BM_STATE + 2 * (level - 1) + 1] = above; }
+    } else {
+        __syncthreads();
+    }
+    const unsigned himask = level == 0 ? 0u : (0x7fffffffu >> (sh + 10)) << (sh + 10);
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+        const unsigned b = __float_as_uint(fmaxf(v[e], 0.0f)) & 0x7fffffffu;
+        if ((b & himask) == prefix) atomicAdd(&h[(b >> sh) & (nb - 1)], 1u);
+    }
+    __syncthreads();
+    unsigned* g = ws + bm_base(level);
+    for (int i = threadIdx.x; i < nb; i += 256)
+        if (h[i]) atomicAdd(&g[i], h[i]);
+}
+
+__global__ __launch_bounds__(256)
+void bm_sums_kernel(const float* __restrict__ v, int n, float thresh, unsigned* __restrict__ ws, float* __restrict__ partial, int k) {
     __shared__ float red[4][4];
+    __shared__ unsigned part[4], sel[4];
     v += (size_t)blockIdx.y * n; ws += (size_t)blockIdx.y * BM_WS_U32; partial += (size_t)blockIdx.y * BM_WS_U32;
-    const float t = __uint_as_float(ws[BM_STATE + 2]);
+    unsigned tbits, above;
+    bm_find_body(ws, 2, k, part, sel, tbits, above);                    // the last level's bin walk: t and the count above it
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ws[BM_STATE + 4] = tbits; ws[BM_STATE + 5] = above; }
+    const float t = __uint_as_float(tbits);
     float s_thr = 0.f, c_thr = 0.f, s_top = 0.f, c_eq = 0.f;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
         const float raw = v[e];
@@ -237,8 +250,8 @@ void bm_final_kernel(const float* __restrict__ partial, int nwg, const unsigned*
     for (int i = threadIdx.x; i < nwg; i += 64) { s_thr += partial[4 * i]; c_thr += partial[4 * i + 1]; s_top += partial[4 * i + 2]; c_eq += partial[4 * i + 3]; }
     s_thr = wave_sum64(s_thr); c_thr = wave_sum64(c_thr); s_top = wave_sum64(s_top); c_eq = wave_sum64(c_eq);
     if (threadIdx.x != 0) return;
-    const float t = __uint_as_float(ws[BM_STATE + 2]);
-    const float c_gt = (float)ws[BM_STATE + 3];
+    const float t = __uint_as_float(ws[BM_STATE + 4]);
+    const float c_gt = (float)ws[BM_STATE + 5];
     if (c_thr > (float)k) {                    // the (k+1)-th largest exceeds thresh exactly when more than k losses do
         out[0] = s_thr / c_thr; out[1] = 1.0f; out[2] = 1.0f / c_thr; out[3] = thresh; out[4] = 0.0f;
     } else {
@@ -828,11 +841,9 @@ extern "C" int hs_bootstrap_mean_batched_fwd(const float* values, int32_t images
     float* partial = (float*)(ws + BM_STATE + 8);
     hipError_t e = hipMemsetAsync(ws, 0, (size_t)images * BM_WS_U32 * 4, s);
     if (e != hipSuccess) return (int)e;
-    for (int level = 0; level < 3; ++level) {
-        hipLaunchKernelGGL(bm_hist_kernel, dim3(BM_WG, images), dim3(256), 0, s, values, n, ws, level);
-        hipLaunchKernelGGL(bm_find_kernel, dim3(1, images), dim3(256), 0, s, ws, level, k);
-    }
-    hipLaunchKernelGGL(bm_sums_kernel, dim3(BM_WG, images), dim3(256), 0, s, values, n, thresh, (const unsigned*)ws, partial);
+    for (int level = 0; level < 3; ++level)
+        hipLaunchKernelGGL(bm_hist_kernel, dim3(BM_WG, images), dim3(256), 0, s, values, n, ws, level, k);
+    hipLaunchKernelGGL(bm_sums_kernel, dim3(BM_WG, images), dim3(256), 0, s, values, n, thresh, ws, partial, k);
     hipLaunchKernelGGL(bm_final_kernel, dim3(1, images), dim3(64), 0, s, (const float*)partial, BM_WG, (const unsigned*)ws, k, thresh, out8);
     return launch_status();
 }
