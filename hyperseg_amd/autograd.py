@@ -755,6 +755,38 @@ class BootstrapMeanBatched(torch.autograd.Function):
         return gv, None, None
 
 
+class BootstrapMeanOfBatch(torch.autograd.Function):
+    """The loss module's batch form (round 5): values (N, n) -> the MEAN of the N per-image bootstrapped losses, a 0-dim tensor, from the
+    same launches as BootstrapMeanBatched plus a one-thread mean; the adjoint takes the one upstream gradient as it is.  Replaces
+    ``BootstrapMeanBatched.apply(...).sum() / N`` and what autograd makes of it: a clone, a reduction, two scalar multiplications, a
+    contiguous copy of the expanded gradient -- six stock launches of a config-5 step."""
+
+    @staticmethod
+    def forward(ctx, values, k, thresh):
+        values = values.contiguous()
+        imgs, n = values.shape
+        with _hip.device_scope(values.device):
+            ws = torch.empty(imgs * int(_hip.lib.hs_bootstrap_mean_workspace()), device=values.device, dtype=torch.uint8)
+            out = torch.empty(imgs * 8 + 1, device=values.device, dtype=torch.float32)          # (imgs, 8) state | the mean
+            st = _hip.lib.hs_bootstrap_mean_of_batch_fwd(values.data_ptr(), imgs, n, int(k), float(thresh), ws.data_ptr(), out.data_ptr(),
+                                                         out.data_ptr() + 4 * imgs * 8, _hip.stream_ptr())
+            _hip.check(st, 'hs_bootstrap_mean_of_batch_fwd')
+        ctx.save_for_backward(values, out)
+        return out[imgs * 8:].view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        values, state = ctx.saved_tensors
+        imgs, n = values.shape
+        if g.dtype != torch.float32 or not g.is_contiguous():
+            g = g.float().contiguous()
+        with _hip.device_scope(values.device):
+            gv = torch.empty_like(values)
+            st = _hip.lib.hs_bootstrap_mean_of_batch_bwd(values.data_ptr(), imgs, n, state.data_ptr(), g.data_ptr(), gv.data_ptr(), _hip.stream_ptr())
+            _hip.check(st, 'hs_bootstrap_mean_of_batch_bwd')
+        return gv, None, None
+
+
 def patch_conv_apply(*args):
     """``PatchConv.apply`` behind the autocast-dtype check."""
     if torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') != torch.bfloat16:

@@ -261,11 +261,19 @@ void bm_final_kernel(const float* __restrict__ partial, int nwg, const unsigned*
     }
 }
 
+// gout_stride 1: one upstream gradient per image; 0: ONE gradient of the batch mean (scale = 1 / images)
+// the mean of the per-image losses (bootstrapped_ce_loss.py: loss / batch), one thread: round 5, instead of clone + sum + div launches
+__global__ void bm_batch_mean_kernel(const float* __restrict__ out8, int images, float* __restrict__ mean_out) {
+    float t = 0.0f;
+    for (int i = 0; i < images; ++i) t += out8[(size_t)i * 8];
+    mean_out[0] = t / (float)images;
+}
+
 __global__ __launch_bounds__(256)
-void bm_bwd_kernel(const float* __restrict__ v, int n, const float* __restrict__ state, const float* __restrict__ gout,
-                   float* __restrict__ gv) {
-    v += (size_t)blockIdx.y * n; gv += (size_t)blockIdx.y * n; state += (size_t)blockIdx.y * 8; gout += blockIdx.y;
-    const float w = state[2] * gout[0], t = state[3], tie = state[4];
+void bm_bwd_kernel(const float* __restrict__ v, int n, const float* __restrict__ state, const float* __restrict__ gout, int gout_stride,
+                   float scale, float* __restrict__ gv) {
+    v += (size_t)blockIdx.y * n; gv += (size_t)blockIdx.y * n; state += (size_t)blockIdx.y * 8; gout += blockIdx.y * gout_stride;
+    const float w = state[2] * (gout[0] * scale), t = state[3], tie = state[4];
     for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
         const float x = fmaxf(v[e], 0.0f);
         gv[e] = x > t ? w : (x == t ? w * tie : 0.0f);
@@ -851,7 +859,26 @@ extern "C" int hs_bootstrap_mean_batched_fwd(const float* values, int32_t images
 extern "C" int hs_bootstrap_mean_batched_bwd(const float* values, int32_t images, int32_t n, const float* state8, const float* grad_out,
                                              float* grad_values, void* stream) {
     if (!values || !state8 || !grad_out || !grad_values || n <= 0 || images <= 0 || images > 65535) return HS_ERR_BAD_ARG;
-    hipLaunchKernelGGL(bm_bwd_kernel, dim3(BM_WG, images), dim3(256), 0, (hipStream_t)stream, values, n, state8, grad_out, grad_values);
+    hipLaunchKernelGGL(bm_bwd_kernel, dim3(BM_WG, images), dim3(256), 0, (hipStream_t)stream, values, n, state8, grad_out, 1, 1.0f, grad_values);
+    return launch_status();
+}
+
+// The batch form the loss module uses (round 5): hs_bootstrap_mean_batched_fwd + the mean of the per-image losses in `mean_out` (one
+// float), and its adjoint from ONE upstream gradient (of that mean).
+extern "C" int hs_bootstrap_mean_of_batch_fwd(const float* values, int32_t images, int32_t n, int32_t k, float thresh, void* workspace,
+                                              float* out8, float* mean_out, void* stream) {
+    if (!mean_out) return HS_ERR_BAD_ARG;
+    const int st = hs_bootstrap_mean_batched_fwd(values, images, n, k, thresh, workspace, out8, stream);
+    if (st != HS_OK) return st;
+    hipLaunchKernelGGL(bm_batch_mean_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const float*)out8, images, mean_out);
+    return launch_status();
+}
+
+extern "C" int hs_bootstrap_mean_of_batch_bwd(const float* values, int32_t images, int32_t n, const float* state8, const float* grad_mean,
+                                              float* grad_values, void* stream) {
+    if (!values || !state8 || !grad_mean || !grad_values || n <= 0 || images <= 0 || images > 65535) return HS_ERR_BAD_ARG;
+    hipLaunchKernelGGL(bm_bwd_kernel, dim3(BM_WG, images), dim3(256), 0, (hipStream_t)stream, values, n, state8, grad_mean, 0, 1.0f / (float)images,
+                       grad_values);
     return launch_status();
 }
 

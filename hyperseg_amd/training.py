@@ -51,7 +51,6 @@ def bootstrap_mean_capturable(per_pixel, k, thresh):
 
 def bootstrapped_cross_entropy(pred, target, k=4096, thresh=0.3, weight=None, ignore_index=-100):
     """pred (N, C, H, W) logits, target (N, H, W) int64 -> scalar."""
-    total = pred.new_zeros((), dtype=torch.float32)
     capturing = pred.is_cuda and torch.cuda.is_current_stream_capturing()
     # the per-pixel losses of the WHOLE batch in one pass over (N, C, H, W) (the reference permutes every image to (HW, C) first,
     # bootstrapped_ce_loss.py:20-23: same values, a transposed copy + a softmax + a gather per image and direction)
@@ -63,8 +62,9 @@ def bootstrapped_cross_entropy(pred, target, k=4096, thresh=0.3, weight=None, ig
         per_all = F.cross_entropy(pred.float(), target, weight=weight, ignore_index=ignore_index, reduction='none')
     per_rows = per_all.flatten(1)
     if (USE_HIP_BOOTSTRAP and per_rows.is_cuda and per_rows.dtype == torch.float32 and per_rows.shape[1] > k and per_rows.shape[0] <= 65535):
-        from .autograd import BootstrapMeanBatched                         # every image in one set of launches, no sort, no host read
-        return BootstrapMeanBatched.apply(per_rows, k, thresh).sum() / float(pred.shape[0])
+        from .autograd import BootstrapMeanOfBatch                         # every image in one set of launches, no sort, no host read; the
+        return BootstrapMeanOfBatch.apply(per_rows, k, thresh)             # batch mean from the same launches (no sum / div launches)
+    total = pred.new_zeros((), dtype=torch.float32)
     for per_pixel in per_rows:
         on_device = per_pixel.is_cuda and per_pixel.numel() > k            # (numel <= k: the reference raises; so does its restatement)
         if on_device and per_pixel.dtype == torch.float32 and USE_HIP_BOOTSTRAP:

@@ -499,6 +499,12 @@ int hs_dw_tiles_bwd_w(int32_t dtype, const void* tiled, const void* dy, int32_t 
  * radix histogram of the bit patterns; ties at it share the remaining weight).  out5 = {loss, branch, 1/count, t, tie weight}: the
  * state hs_bootstrap_mean_bwd turns into d loss / d values.  workspace: hs_bootstrap_mean_workspace() bytes, scratch.  n > k. */
 int64_t hs_bootstrap_mean_workspace(void);
+/* The batch form the loss module uses: the batched reduction + the mean of the per-image losses (bootstrapped_ce_loss.py:33, loss / batch)
+ * in mean_out (one float), and the adjoint from the ONE upstream gradient of that mean. */
+int hs_bootstrap_mean_of_batch_fwd(const float* values, int32_t images, int32_t n, int32_t k, float thresh, void* workspace,
+                                   float* out8, float* mean_out, void* stream);
+int hs_bootstrap_mean_of_batch_bwd(const float* values, int32_t images, int32_t n, const float* state8, const float* grad_mean,
+                                   float* grad_values, void* stream);
 /* Adam (torch.optim.Adam / AdamW arithmetic, no amsgrad) for up to 48 fp32 tensors in ONE launch of 1024-element workgroups: the
  * training loop's optimizer step (hyperseg/train.py:185-188) without torch's 65 536-element chunking.  The arrays are HOST arrays of device
  * pointers; `steps`: hs_adam_blocks(numel, n) floats on the device, zero before the first step, owned by this parameter list (one step
