@@ -514,3 +514,30 @@ def test_se_tail_plan_on_the_host():
     assert lib.hs_se_tail_tails(64, 8, 1024, 64 * 1024) == 0    # > 512 partials per channel
     assert lib.hs_se_tail_tails(640, 8, 1, 4) == 0              # fewer workgroups than tails
     assert lib.hs_se_tail_workspace(1, 64, 200, 1, 64) == 0
+
+
+def test_training_host_logic_without_a_gpu():
+    """Round-5 training helpers, the parts that run without a device: the shared bank-gradient buffer's bookkeeping (autograd._BankGradBuffer:
+    its views tile one tensor, it recognises its own views and nothing else), the one-launch Adam's refusals (CPU parameters are NOT
+    stepped by some fallback: NotImplementedError) and hs_adam_blocks' workgroup count."""
+    import ctypes as C
+    from hyperseg_amd import _hip, autograd as HA
+    from hyperseg_amd.training import Adam
+    buf = HA._BankGradBuffer((5, 12), ((0, 3), (3, 7), (7, 10)))
+    v = [buf.view(i, torch.device('cpu')) for i in range(3)]
+    assert [tuple(t.shape) for t in v] == [(5, 3), (5, 4), (5, 3)] and all(t.stride() == (12, 1) for t in v)
+    assert float(buf.buf[:, 10:].abs().max()) == 0.0                    # the pad columns are zeroed once
+    for i, t in enumerate(v):
+        t.fill_(i + 1.0)
+    assert buf.owns(v) and torch.equal(buf.buf[:, :10], torch.tensor([1.0] * 3 + [2.0] * 4 + [3.0] * 3).expand(5, 10))
+    assert not buf.owns([v[0], v[1], None]) and not buf.owns([v[0], v[1], torch.zeros(5, 3)]) and not buf.owns([v[1], v[0], v[2]])
+    assert not HA._BankGradBuffer((5, 12), ((0, 3), (3, 7), (7, 10))).owns(v)          # another buffer's views
+    p = torch.nn.Parameter(torch.zeros(4))
+    p.grad = torch.ones(4)
+    with pytest.raises(NotImplementedError):
+        Adam([p], lr=1e-3).step()
+    with pytest.raises(ValueError):
+        Adam([p], lr=1e-3, betas=(1.0, 0.999))
+    numel = (C.c_int64 * 4)(1, 1024, 1025, 4216 * 80)
+    assert _hip.lib.hs_adam_blocks(numel, 4) == 1 + 1 + 2 + 330
+    assert _hip.lib.hs_adam_blocks(numel, 0) == 0 and _hip.lib.hs_adam_blocks((C.c_int64 * 1)(0), 1) == 0
