@@ -640,6 +640,25 @@ def time_replayed(forward, x, steps, warmup, batch):
     return round(steps * batch / el, 2), round(1e3 * el / steps, 4), y, g
 
 
+def launch_ranks(n, argv):
+    """Re-runs this file as ``n`` ranks of one node under torch.distributed.run (127.0.0.1 rendezvous on a free port) and returns
+    the launcher's exit code; the children inherit stdout, so rank 0's one JSON line is the only thing printed there."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: what RCCL needs on this driver
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__), *argv]
+    sys.stdout.flush()
+    rc = subprocess.run(cmd, env=env).returncode
+    if rc != 0:
+        sys.exit(rc)
+    return rc
+
+
 class StubModel:
     """HS_BENCH_STUB=1 (CPU / gloo plumbing test of this file's main(), tests/test_distributed.py): stands in for the model;
     ``forward`` writes a rank- and step-dependent pattern of the logits' shape at 1/16 of the resolution."""
@@ -711,6 +730,11 @@ def main(argv=None):
     ap.add_argument('--traffic-dir', default=None,
                     help='directory with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (same session)')
     args = ap.parse_args(argv)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N` (the shape of the driver's N = 1 command; the reference's counterpart is one command for N
+        # GPUs too: nn.DataParallel, test_fps.py:155-156): launch the N ranks ourselves, one process per GPU, under torch.distributed.run;
+        # rank 0's JSON line is this process' stdout
+        return launch_ranks(args.gpus, sys.argv[1:] if argv is None else list(argv))
     # The ONE JSON line goes to the process' real stdout; everything else that writes to fd 1 (RCCL prints a version banner there
     # when its first communicator comes up, MIOpen may chat) is sent to stderr, so that the line is the only thing a reader sees.
     sys.stdout.flush()
@@ -722,9 +746,7 @@ def main(argv=None):
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit('bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)')
-        args.gpus = world
+        args.gpus = world                                   # the launcher's world size is the truth (torchrun --nproc-per-node)
     dev = select_device(local_rank, stub)
     traffic_note = None
     if (not stub and world == 1 and not args.no_extras and args.traffic == 'auto' and args.traffic_dir is None

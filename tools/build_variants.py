@@ -132,8 +132,21 @@ PATCHES = {
     'irc_stag_hi100': [('    // @stamp 0\n', '    if ((blockIdx.x >> 8) & 1) { __builtin_amdgcn_s_sleep(100); }\n')],
     'irc_stag_lo40': [('    // @stamp 0\n', '    if (blockIdx.x & 1) __builtin_amdgcn_s_sleep(40);\n')],
     'irc_stag_xcd40': [('    // @stamp 0\n', '    if ((blockIdx.x >> 3) & 1) __builtin_amdgcn_s_sleep(40);\n')],
+    # round 6: TIMING-ONLY builds of the level-4 kernel (results are wrong) -- what a bank that arrives already split
+    # by its producer would buy: the split phase + its barrier removed; the f32 landing zone removed (the DMA lands on the f16 images);
+    # the 16 x 8 regions at 4 workgroups per CU that the smaller LDS footprint then allows
+    'irc_nosplit': [('    if ((cin & 1) == 0 && (hid & 3) == 0) {\n        // quads of 4 consecutive weights', '    if (cin < 0) {\n        // quads of 4 consecutive weights'),
+                    ('    } else {\n        // odd channel counts: one JOB per thread', '    } else if (cin < 0) {\n        // odd channel counts: one JOB per thread')],
+    'irc_inplace': [('    if ((cin & 1) == 0 && (hid & 3) == 0) {\n        // quads of 4 consecutive weights', '    if (cin < 0) {\n        // quads of 4 consecutive weights'),
+                    ('    } else {\n        // odd channel counts: one JOB per thread', '    } else if (cin < 0) {\n        // odd channel counts: one JOB per thread'),
+                    ('    m.raw = o; o += m.raw_chunks * 1024;', '    m.raw = 0;'),
+                    ('            tv[i] = raw[off_kd + e]; ts[i] = raw_s2[(unsigned)e / 9u];', '            tv[i] = 1.0f; ts[i] = 1.0f;'),
+                    ('            if (e < 9 * hid) taps[e] = tv[i] * (ts[i] * IRC_H2_SCALE);', '            if (e < 0) taps[e] = tv[i] * (ts[i] * IRC_H2_SCALE);')],
+    'irc_rh8': [('    const bool tall = a.ph % 16 == 0;', '    const bool tall = false;')],
     'ntstore': [(STORE_LINE, '                for (int jt = 0; jt < J3; ++jt) __builtin_nontemporal_store(fmaf(acc3[m][jt][r], sc, sh), &yo[yoff[jt]]);')],
 }
+
+PATCHES['irc_rh8_inplace'] = PATCHES['irc_inplace'] + PATCHES['irc_rh8']
 
 VARIANTS = {
     'stamps': dict(flags=[], extra=[], patch=True),
@@ -170,6 +183,10 @@ VARIANTS = {
     'irc_stag_hi100': dict(flags=[], extra=[], patch='irc_stag_hi100', file='hs_patch_irc.hip'),
     'irc_stag_lo40': dict(flags=[], extra=[], patch='irc_stag_lo40', file='hs_patch_irc.hip'),
     'irc_stag_xcd40': dict(flags=[], extra=[], patch='irc_stag_xcd40', file='hs_patch_irc.hip'),
+    'irc_nosplit': dict(flags=[], extra=[], patch='irc_nosplit', file='hs_patch_irc.hip'),       # round 6: timing only
+    'irc_inplace': dict(flags=[], extra=[], patch='irc_inplace', file='hs_patch_irc.hip'),
+    'irc_rh8': dict(flags=[], extra=[], patch='irc_rh8', file='hs_patch_irc.hip'),
+    'irc_rh8_inplace': dict(flags=[], extra=[], patch='irc_rh8_inplace', file='hs_patch_irc.hip'),
     'gs_tail_switch': dict(flags=[], extra=[], patch='git:b89aa7e', file='hs_gemm_split.hip'),   # round 4: the split GEMM with apply_act(v, a.act) inside the unrolled tail
     'st_slice64': dict(flags=['-DHS_ST_SLICE=64'], extra=[], patch=None),                 # round 4: patches per dW slice of the s2w backward (product: 256)
     'st_slice128': dict(flags=['-DHS_ST_SLICE=128'], extra=[], patch=None),
