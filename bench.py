@@ -61,9 +61,10 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy peak 6290
 FP32_PEAK_TFLOPS = 157.3       # f32 vector == f32-input MFMA dense peak
 F16_PEAK_TFLOPS = 2500.0       # dense f16 / bf16 MFMA peak (MI355X_MICROARCH.md)
-MODELS = {'m': 'hyperseg-m', 's': 'hyperseg-s', 'sc': 'hyperseg-s-camvid', 'l': 'hyperseg-l'}
+MODELS = {'m': 'hyperseg-m', 's': 'hyperseg-s', 'sc': 'hyperseg-s-camvid', 'l': 'hyperseg-l', 'lc': 'hyperseg-l-camvid'}
 LABELS = {'m': 'HyperSeg-M / EfficientNet-B1 / 1024x512', 's': 'HyperSeg-S / EfficientNet-B1 / 1536x768',
-          'sc': 'HyperSeg-S / EfficientNet-B1 / CamVid 768x576', 'l': 'HyperSeg-L / EfficientNet-B3 / 512x512'}
+          'sc': 'HyperSeg-S / EfficientNet-B1 / CamVid 768x576', 'l': 'HyperSeg-L / EfficientNet-B3 / 512x512',
+          'lc': 'HyperSeg-L / EfficientNet-B1 / CamVid 1024x768 (six-level v1_0 decoder)'}
 
 
 # --------------------------------------------------------------------------------------------- the timed loop
@@ -364,7 +365,7 @@ def pmc_traffic(traffic_dir, kernel):
     return best
 
 
-def cpu_baseline(model_cpu, size, budget_s=20.0):
+def cpu_baseline(model_cpu, size, budget_s=12.0):
     """CPU 'port' baseline on this box's host cores: stock encoder + context head on CPU, then the reference's
     ATen op sequence for the decoder (oracle/cpu_port.py, pinned to the oracle).  The thread count is chosen by a
     one-frame calibration over {8, 16, 32, 64, all} (more threads than that only slows these small ops down) and
@@ -400,8 +401,9 @@ def cpu_baseline(model_cpu, size, budget_s=20.0):
             enc, dec, n = enc + e, dec + d, n + 1
     total = enc + dec
     return {'value': round(n / total, 3), 'unit': 'frames/s', 'cores': best[1], 'kind': 'port',
-            'sample': f'{n} frames of HyperSeg-M 1024x512 bs1 ({total:.1f} s) on {best[1]} of {ncpu} host threads: '
-                      f'stock encoder + context head on CPU + oracle/cpu_port.py decoder',
+            'sample': f'{n} frames of HyperSeg-M 1024x512 bs1 ({total:.1f} s) on {best[1]} of {ncpu} host threads '
+                      f'(thread count = the fastest of {{8, 16, 32, 64, all {ncpu}}} in a one-frame calibration: more threads slow these '
+                      f'small ops down, so the choice favours the CPU): stock encoder + context head on CPU + oracle/cpu_port.py decoder',
             'decoder_ms': round(1e3 * dec / n, 2), 'encoder_ms': round(1e3 * enc / n, 2)}
 
 
@@ -640,6 +642,37 @@ def time_replayed(forward, x, steps, warmup, batch):
     return round(steps * batch / el, 2), round(1e3 * el / steps, 4), y, g
 
 
+class Legs:
+    """Wall seconds per leg of a run (`legs_s` on the line: where a default run's minutes go -- the timed regions are milliseconds)."""
+
+    def __init__(self):
+        self.t, self.out = time.perf_counter(), {}
+
+    def mark(self, name):
+        now = time.perf_counter()
+        self.out[name] = round(self.out.get(name, 0.0) + now - self.t, 1)
+        self.t = now
+
+
+def decoder_launches_text(model, launches=None):
+    """What the decoder's launches WERE: from the instrumented table when there is one, else from what the warm-up forwards left behind
+    (a K1Chain that has launched = levels 0-2 went out as one launch) -- never from a flag (HyperSeg-L's line said "chain")."""
+    dec = getattr(model, 'decoder', None)
+    if dec is None:
+        return None
+    if launches:
+        names = [l['kernel'] for l in launches if l['in_decoder']]
+        return ' | '.join(names) + f' ({len(names)} launches, in issue order)'
+    kc = getattr(dec, '_k1_chain', None)
+    chained = kc is not None and bool(kc._ws)
+    n = dec.levels
+    head = 'signal2weights (one launch for every level) | ' if type(dec).__module__.split('.')[-1] != 'hyperseg_v0_1' else ''
+    tail = ' | final 2x upsample' if (32 >> (n - 1)) > 1 else ''
+    if chained:
+        return head + f'levels 0-2 as one launch (hs_k1_chain_fwd: in-launch neighbour hand-offs) | one launch per level 3..{n - 1}' + tail
+    return head + f'one launch per level 0..{n - 1}' + tail
+
+
 def launch_ranks(n, argv):
     """Re-runs this file as ``n`` ranks of one node under torch.distributed.run (127.0.0.1 rendezvous on a free port) and returns
     the launcher's exit code; the children inherit stdout, so rank 0's one JSON line is the only thing printed there."""
@@ -680,7 +713,8 @@ def main(argv=None):
     ap.add_argument('--repeats', type=int, default=5, help='timed regions of --steps steps each; value = their median')
     ap.add_argument('--model', default='m', choices=sorted(MODELS),
                     help='m: HyperSeg-M 1024x512 bs1/GPU (default, the headline metric); s: HyperSeg-S 1536x768 bs1/GPU; '
-                         'sc: CamVid-S 768x576; l: HyperSeg-L 512x512, global batch 32 sharded over the GPUs')
+                         'sc: CamVid-S 768x576; l: HyperSeg-L 512x512, global batch 32 sharded over the GPUs; lc: CamVid HyperSeg-L 1024x768 '
+                         '(configs/train/camvid_efficientnet_b1_hyperseg-l.py: six-level v1_0 decoder)')
     ap.add_argument('--output', default='logits', choices=['logits', 'masks'],
                     help="what a step produces: fp32 logits (the reference's forward, default) or uint8 argmax masks "
                          "taken inside the final upsample kernel (HyperGen.segment; test_fps.py:194's epilogue fused)")
@@ -723,7 +757,7 @@ def main(argv=None):
     ap.set_defaults(chain_k1=True)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the roofline / parity / protocol passes (timing only)')
-    ap.add_argument('--cpu-budget', type=float, default=20.0)
+    ap.add_argument('--cpu-budget', type=float, default=12.0)
     ap.add_argument('--traffic', default='auto', choices=['auto', 'off'],
                     help="roofline.traffic: 'auto' = spawn the two rocprofv3 --pmc passes of this command before the timing (N=1, rank 0, "
                          "when rocprofv3 is on PATH; ~1 minute), 'off' = null unless --traffic-dir is given")
@@ -741,6 +775,7 @@ def main(argv=None):
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    legs = Legs()
     stub = os.environ.get('HS_BENCH_STUB') == '1'
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -752,6 +787,7 @@ def main(argv=None):
     if (not stub and world == 1 and not args.no_extras and args.traffic == 'auto' and args.traffic_dir is None
             and os.environ.get('HS_BENCH_CHILD') != '1'):
         args.traffic_dir, traffic_note = self_traffic_passes(args.model)      # before this process initialises the GPU
+        legs.mark('pmc_traffic_passes')
     if not stub:
         torch.cuda.set_device(dev)
     collective_probe = world == 1 and args.collective not in (None, 'none')      # N=1: measure the collective's own cost
@@ -823,6 +859,8 @@ def main(argv=None):
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 y = forward(x)
+
+    legs.mark('build_prepare_capture')
 
     def run_forward():
         nonlocal y
@@ -987,9 +1025,7 @@ def main(argv=None):
                        'output': f'fp32 logits {tuple(y.shape)}' if args.output == 'logits' else f'uint8 argmax masks {tuple(y.shape)}',
                        'launch': 'eager' if args.no_graph else 'hipGraph replay',
                        'ir_math': math_name + ' (include/hyperseg_hip.h hs_ir_math)',
-                       'decoder_launches': ('signal2weights | levels 0-2 as one launch (hs_k1_chain_fwd: in-launch neighbour hand-offs) | '
-                                            'level 3 | level 4 | upsample' if getattr(getattr(model, 'decoder', None), 'chain_k1', False)
-                                            else 'signal2weights | one launch per level | upsample'),
+                       'decoder_launches': decoder_launches_text(model),
                        'arithmetic': 'f32 storage and f32 accumulation everywhere.  Decoder (the hot path): ' +
                                      ('every product exact f32 (v_mfma_f32_16x16x4_f32 / v_fma_f32)' if math_name == 'f32' else
                                       'level-4 inverted residual products as 3-term f16 splits (1.3e-7 * sum|a||b|), the rest exact f32') +
@@ -1021,6 +1057,7 @@ def main(argv=None):
                 'bytes_received_per_rank_per_step': comm.bytes_per_step * (world - 1),
                 'completed': comm.completed},
         }
+        legs.mark('timed_regions_and_collective')
         if not args.no_extras:
             # ---- the benched configuration against the eager stock model, outside the timed regions -----------------
             stock = stock.to(dev)
@@ -1038,16 +1075,19 @@ def main(argv=None):
                 out['parity'] = {'vs': 'eager stock-encoder model, same batch', 'max_rel_err': err,
                                  'argmax_flips': flips, 'pixels_with_margin_gt_1e-4': int(clear.sum()), 'pixels': int(clear.numel())}
             del stock, ys
+            legs.mark('parity_vs_stock')
             # ---- roofline of the dominant decoder launch -------------------------------------------------------------
             launches, dec_us, ev_overhead = instrumented_decoder(model, x, max(10, min(args.steps, 50)))
             alg_bytes, levels = decoder_levels(model, h, w, batch)
             out['roofline'] = roofline_of(launches, levels, h, w, batch, args.traffic_dir)
             out['roofline']['traffic_source'] = traffic_note if traffic_note else \
                 ('--traffic-dir' if args.traffic_dir else 'none (--traffic off)')
+            out['config']['decoder_launches'] = decoder_launches_text(model, launches)
             out['decoder'] = {'us_per_batch_eager': round(dec_us, 1), 'event_pair_overhead_us': round(ev_overhead, 2),
                               'algorithmic_bytes': alg_bytes,
                               'hbm_frac_of_8TBs': round(alg_bytes / (dec_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                               'launches': launches}
+            legs.mark('roofline_launch_table')
             if world == 1 and graph is not None:
                 # ---- the same step under the other arithmetic of the fused inverted residual (hs_ir_math), and with IEEE-f32
                 # library GEMMs in the encoder: side numbers, one timed region each ------------------------------------------
@@ -1083,6 +1123,7 @@ def main(argv=None):
                     except Exception as e:            # noqa: BLE001  (a side number must never cost the line)
                         out['library_gemm_f32'] = {'error': f'{type(e).__name__}: {e}'[:300]}
                         torch.cuda.synchronize()
+            legs.mark('arithmetic_legs')
             if world == 1 and graph is not None:
                 dec_mod = getattr(model, 'decoder', None)
                 chain_was = getattr(dec_mod, 'chain_k1', False)
@@ -1099,6 +1140,7 @@ def main(argv=None):
                 finally:
                     if dec_mod is not None:
                         dec_mod.chain_k1 = chain_was
+            legs.mark('two_frames_in_flight')
             if world == 1:
                 # ---- the reference harness' own protocol (sync + pinned H2D + eager forward per iteration) -------------
                 from hyperseg_amd.fps import measure_fps, synthetic_batches
@@ -1118,9 +1160,11 @@ def main(argv=None):
                 except Exception as e:                # noqa: BLE001
                     out['fps_reference_protocol']['graphed'] = {'error': f'{type(e).__name__}: {e}'[:300]}
                     torch.cuda.synchronize()
+                legs.mark('fps_reference_protocol')
                 out['cpu_baseline'] = None
                 if args.model == 'm' and not args.no_cpu_baseline:
                     out['cpu_baseline'] = cpu_baseline(fill_by_name(configs.build(cfg).eval(), seed=0), (h, w), args.cpu_budget)
+                legs.mark('cpu_baseline')
                 if args.model == 'm' and graph is not None and not args.no_other_configs and not args.stock_encoder:
                     # ---- the other BASELINE configs on the driver's line: config 3 (1536x768) and config 5 (training
                     # step, fp32 + bf16), one short region each, after and outside every headline region; never `value` ------------
@@ -1137,6 +1181,8 @@ def main(argv=None):
                             torch.cuda.synchronize()
                         other[name]['wall_s'] = round(time.perf_counter() - t_side, 1)
                     out['other_configs'] = other
+                    legs.mark('other_configs')
+        out['legs_s'] = legs.out
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + '\n').encode())
     if dist.is_available() and dist.is_initialized():

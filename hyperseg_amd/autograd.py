@@ -408,7 +408,7 @@ class DwTilesBN(torch.autograd.Function):
 def dw_tiles_bn(bn, act_layer, t, bank, size, grid, patch_major):
     """``DwTilesValid(bn_act(bn, act_layer, t), bank)`` as DwTilesBN where the fused training BatchNorm applies (and USE_DW_BN_FUSED),
     the two Functions otherwise."""
-    act = _bn_hip_act(bn, act_layer, t) if USE_DW_BN_FUSED and bn.weight is not None else -1
+    act = _bn_hip_act(bn, act_layer, t) if USE_DW_BN_FUSED and getattr(bn, 'weight', None) is not None else -1      # nn.Identity / 'Unit' norms: no weight -> the two Functions
     if act < 0:
         return DwTilesValid.apply(bn_act(bn, act_layer, t), bank, size, grid, patch_major)
     nbt = bn.num_batches_tracked
@@ -496,7 +496,7 @@ def patch_conv_bn(bn, act_layer, x, bank, grid, c_out):
     """``patch_conv_apply(bn_act(bn, act_layer, x), bank, grid, c_out, 1, 0, 'zeros', 1)`` as PatchConvBN where the fused training
     BatchNorm applies, the layer is inside hs_patch_conv_bn_fwd's range (c_out <= 32, <= 64 input channels, patches of >= 64 pixels)
     and USE_CONV_BN_FUSED; the two Functions otherwise."""
-    act = _bn_hip_act(bn, act_layer, x) if USE_CONV_BN_FUSED and bn.weight is not None else -1
+    act = _bn_hip_act(bn, act_layer, x) if USE_CONV_BN_FUSED and getattr(bn, 'weight', None) is not None else -1
     b, c, h, w = x.shape
     fh, fw = grid
     covered = act >= 0 and c_out <= 32 and c <= 64 and h % fh == 0 and w % fw == 0 and (h // fh) * (w // fw) >= 64 \

@@ -18,6 +18,13 @@ MODELS = {
              "with_out_fc=False, decoder_dropout=None, weight_groups=[64, 32, 32, 16, 8], decoder_groups=1, "
              "inference_hflip=True, coords_res=[(576, 576), (576, 768)])",
         num_classes=12, size=(576, 768), batch=1),
+    # configs/train/camvid_efficientnet_b1_hyperseg-l.py:35-38 (evaluated at 1024 x 768: val_img_transforms, :21); README.md:31
+    'hyperseg-l-camvid': dict(
+        arch="hyperseg.models.hyperseg_v1_0.hyperseg_efficientnet('efficientnet-b1', False, levels=2, "
+             "kernel_sizes=(1, 1, 1, 3, 3, 3), level_channels=[64, 32, 16, 16, 16, 16], expand_ratio=2, "
+             "inference_hflip=True, with_out_fc=False, decoder_dropout=None, weight_groups=[64, 32, 32, 16, 8, 8], "
+             "coords_res=[(768, 768), (768, 1024)])",
+        num_classes=12, size=(768, 1024), batch=1),
     # configs/train/cityscapes_efficientnet_b1_hyperseg-s.py:36-40
     'hyperseg-s': dict(
         arch="hyperseg.models.hyperseg_v1_0_unify.hyperseg_efficientnet('efficientnet-b1', False, levels=2, "

@@ -471,17 +471,101 @@ def patch_conv(x, grid, bank, c_out, k=1, padding=0, padding_mode='reflect', gro
     return y
 
 
+class ChainGate:
+    """One chained launch at a time per device.  hs_decoder_chain_fwd's workgroups spin on their neighbours: the launch needs its WHOLE
+    grid resident, which the host checks against an EMPTY chip -- two chained launches running at once (two streams / threads of one
+    model, two prepared models) can starve each other of residency, the bounded spins then give up and the logits are wrong.  The gate
+    orders chained launches ACROSS streams with events (a launch on stream B waits for the previous chained launch on stream A; launches
+    of one stream are ordered anyway); ``serialize`` does the same around the replay of a graph that contains a chained launch
+    (utils.inference.GraphedModel).  Process-wide, per device; the lock spans "wait on the previous event -> launch -> record"."""
+    _gates, _glock = {}, threading.Lock()
+
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.last_stream, self.last_event = None, None
+        self._events, self._turn = None, 0
+
+    @classmethod
+    def of(cls, device):
+        with cls._glock:
+            g = cls._gates.get(device.index)
+            if g is None:
+                g = cls._gates[device.index] = cls()
+            return g
+
+    def enter(self, device):
+        """Call with ``lock`` held, outside a capture: the current stream waits for the previous chained launch of another stream."""
+        cur = torch.cuda.current_stream(device)
+        if self.last_event is not None and self.last_stream != cur.cuda_stream:
+            cur.wait_event(self.last_event)
+        return cur
+
+    def leave(self, cur):
+        if self._events is None:
+            self._events = [torch.cuda.Event(), torch.cuda.Event()]
+        self._turn ^= 1
+        ev = self._events[self._turn]
+        ev.record(cur)
+        self.last_stream, self.last_event = cur.cuda_stream, ev
+
+
+# counts the chained launches issued while a stream capture is open: a capture site compares it before / after to learn whether its
+# graph contains one (GraphedModel then replays through ChainGate)
+CHAIN_LAUNCHES_CAPTURED = [0]
+
+
 class K1Chain:
     """hs_decoder_chain_fwd for one decoder: the three coarse k = 1 levels -- and the first inverted-residual level behind them when
     ``ir`` is given -- as ONE launch whose workgroups hand their level outputs to the neighbouring cells inside the launch
-    (csrc/hs_k1_chain.hip).  Owns the launch's workspace -- the generation counter the kernel keeps between calls lives there -- one
-    per (device, batch, grid, shapes): ONE frame in flight per K1Chain (two concurrent launches on one workspace would corrupt each
-    other's hand-offs; two_frames_in_flight-style callers keep the chain off).  ``run`` returns the last level's output, or None when
-    the library refuses the shape / the grid is not resident at once (the caller then issues the per-level launches)."""
+    (csrc/hs_k1_chain.hip).  ``run`` returns the last level's output, or None when the library refuses the shape / the grid is not
+    resident at once (the caller then issues the per-level launches).
+
+    Safe by construction (SURVEY 8b "re-entrant"): the launch's workspace -- the generation counter the kernel keeps
+    between calls lives there -- belongs to ONE stream (eager) or ONE capture (ExclusiveWorkspaces), so two streams through one
+    decoder never share hand-off granules; chained launches of different streams are ordered by ChainGate, so two of them never
+    compete for residency; and the kernel's error word (a bounded spin that gave up) is copied to pinned memory every ``POLL_EVERY``
+    calls and checked on every call -- a frame computed from an abandoned wait raises instead of being returned silently."""
+    POLL_EVERY = 16
 
     def __init__(self):
-        self._ws = {}
+        self._ws = {}                        # key -> workspace signature (what has been launched at least once)
         self._refused = set()
+        self._pool = ExclusiveWorkspaces()
+        self._taken = {}                     # id(tensor) -> (tensor, pinned mirror of its error word)
+        self._calls = 0
+        self._lock = threading.Lock()
+
+    @property
+    def refuses_everything(self):
+        return bool(self._refused) and not self._ws
+
+    def _workspace(self, dev, key, nbytes):
+        ws = self._pool.take(dev, key[1:], nbytes)
+        with self._lock:
+            if id(ws) not in self._taken:
+                self._taken[id(ws)] = [ws, None]     # the pinned mirror is made by request_error_copy: no host allocation under capture
+        return ws
+
+    def check_errors(self):
+        """Raises if a launch on any workspace of this object abandoned a wait (reads the pinned mirrors: no synchronisation)."""
+        with self._lock:
+            bad = [int(m.item()) for _, m in self._taken.values() if m is not None and int(m.item()) != 0]
+        if bad:
+            raise RuntimeError(f'hs_decoder_chain_fwd abandoned a wait (error word {bad[0]:#x}): its grid was not resident at once -- '
+                               'another kernel held the chip; the frame is wrong.  Keep chained launches behind ChainGate '
+                               '(GraphedModel does) or turn the chain off (prepare_for_inference(chain_k1=False))')
+
+    def request_error_copy(self, device):
+        """Asynchronous copies of every workspace's error word into its pinned mirror, on the current stream (not under capture)."""
+        if torch.cuda.is_current_stream_capturing():
+            return
+        with self._lock:
+            for ent in self._taken.values():
+                if ent[1] is None:
+                    ent[1] = torch.zeros(1, dtype=torch.int32).pin_memory()
+            pairs = [(ws, m) for ws, m in self._taken.values() if ws.device == device]
+        for ws, m in pairs:
+            m.copy_(ws[:1].view(torch.int32)[:1], non_blocking=True)
 
     def run(self, skips, banks, couts, affines, acts, ir=None):
         """``skips``: the three skip features (B, c, fh << l, fw << l); ``banks``: (P, ld) fp32 tensors; ``affines``: (scale, shift) or
@@ -521,30 +605,52 @@ class K1Chain:
                 setattr(irc, f's{k + 1}', sc)
                 setattr(irc, f'b{k + 1}', sh)
         irp = C.byref(irc) if irc is not None else None
+        self.check_errors()
+        capturing = torch.cuda.is_current_stream_capturing()
         with _hip.device_scope(dev):
-            ws = self._ws.get(key)
-            if ws is None:
+            n = self._ws.get(key)
+            if n is None:
                 n = int(_hip.lib.hs_decoder_chain_workspace(b, fh, fw, arr, 3, irp))
                 if n < 0:
                     self._refused.add(key)
                     return None
-                # zero-filled ONCE: generation 0; under stream capture the fill would become a node of the graph and every replay
-                # would restart at generation 1 -- legal (the kernel then re-publishes everything with tag 1 over zeroed granules)
-                ws = torch.zeros(n, device=dev, dtype=torch.uint8)
-                publish_ready(dev)
-                self._ws[key] = ws
+            # zero-filled ONCE per (stream | capture): generation 0.  A fill inside a capture would become a node of the graph and every
+            # replay would restart at generation 1 -- legal, but a memset node per frame: ExclusiveWorkspaces hands out prepared spares
+            ws = self._workspace(dev, key, n)
             scale = 8 if ir is not None else 4
             y = torch.empty(b, ir['c_out'] if ir is not None else couts[2], scale * fh, scale * fw, device=dev, dtype=torch.float32)
-            st = _hip.lib.hs_decoder_chain_fwd(b, fh, fw, arr, 3, irp, ws.data_ptr(), y.data_ptr(), _hip.stream_ptr())
+            gate = ChainGate.of(dev)
+            if capturing:
+                st = _hip.lib.hs_decoder_chain_fwd(b, fh, fw, arr, 3, irp, ws.data_ptr(), y.data_ptr(), _hip.stream_ptr())
+                CHAIN_LAUNCHES_CAPTURED[0] += 1
+            else:
+                with gate.lock:
+                    cur = gate.enter(dev)
+                    st = _hip.lib.hs_decoder_chain_fwd(b, fh, fw, arr, 3, irp, ws.data_ptr(), y.data_ptr(), _hip.stream_ptr())
+                    if st == 0:
+                        gate.leave(cur)
         if st == -3:                              # HS_ERR_UNSUPPORTED: shape or residency -- nothing was launched
             self._refused.add(key)
             return None
         _hip.check(st, 'hs_decoder_chain_fwd')
+        self._ws[key] = n
+        self._calls += 1
+        if not capturing and self._calls % self.POLL_EVERY == 0:
+            self.request_error_copy(dev)
         return y
 
+    def reset(self):
+        """Drops every workspace (and a raised error with them): the next call starts at generation 0 on fresh buffers.  Graphs captured
+        through this object keep their own references alive and must be re-captured."""
+        with self._lock:
+            self._taken.clear()
+        self._pool = ExclusiveWorkspaces()
+
     def error_word(self):
-        """Non-zero if a launch on any of this object's workspaces abandoned a wait (host read: diagnostics / tests only)."""
-        return max([int(ws[:4].view(torch.int32).item()) for ws in self._ws.values()] or [0])
+        """Non-zero if a launch on any of this object's workspaces abandoned a wait (synchronising host read: diagnostics / tests)."""
+        with self._lock:
+            wss = [ws for ws, _ in self._taken.values()]
+        return max([int(ws[:1].view(torch.int32)[0].item()) for ws in wss] or [0])
 
 
 # The three coarse k = 1 levels (+ the first inverted-residual level) as one launch: opt-in per decoder (``decoder.chain_k1 = True``;

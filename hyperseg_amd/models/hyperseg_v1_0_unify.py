@@ -153,7 +153,13 @@ class MultiScaleDecoder(EpochOnModeSwitch, nn.Module):
         # weight layer is produced by one launch
         fh, fw = s.shape[-2:]
         refs = [None] * len(wl)
+        # the chained launch (levels 0-2) reads materialised banks: with it on, those levels' banks come from the one signal2weights
+        # launch instead of being generated inside their consumers (the SignalRefs made the hook below dead)
+        chain = (getattr(self, 'chain_k1', False) or HF.K1_CHAIN) and s.is_cuda and ul - 1 >= 3 and \
+            not (getattr(self, '_k1_chain', None) is not None and getattr(self._k1_chain, 'refuses_everything', False))
         for lvl in range(min(ul - 1, self.levels)):
+            if chain and lvl < 3:
+                continue
             mods = [m for m in self.level_blocks[lvl][0].children()] if len(self.level_blocks[lvl]) == 1 and \
                 isinstance(self.level_blocks[lvl][0], MetaSequential) else []
             hl, wdt = x[-lvl - 1].shape[-2:]
@@ -165,7 +171,7 @@ class MultiScaleDecoder(EpochOnModeSwitch, nn.Module):
         for i, r in zip(keep, HF.signal2weights_multi(s, [layers[i] for i in keep])):
             refs[i] = r
         p, first = None, 0
-        if (getattr(self, 'chain_k1', False) or HF.K1_CHAIN) and s.is_cuda and ul - 1 >= 3:
+        if chain:
             # levels 0-2 have weight layers of their own: one launch for the three of them (hs_k1_chain_fwd); None: shape / residency not covered
             from .hyperseg_v1_0 import run_decoder_chain
             done = run_decoder_chain(self, [self.level_blocks[l] for l in range(3)], refs[:3], x)

@@ -148,9 +148,19 @@ class Adam(torch.optim.Optimizer):
                     blocks = int(_hip.lib.hs_adam_blocks(numel, n))
                     if blocks <= 0:
                         raise NotImplementedError('hyperseg_amd.training.Adam: parameter list not covered by hs_adam_step')
-                    held = group[key] = (sig, torch.zeros(blocks, device=dev, dtype=torch.float32))
+                    # a loaded state (ours or a torch.optim.Adam checkpoint, train.py:227) carries the steps taken as state[p]['step']:
+                    # the bias corrections must continue from there, not restart at t = 1 on warm moments
+                    seeds = {float(self.state[p]['step']) for p in chunk if 'step' in self.state[p]}
+                    if len(seeds) > 1:
+                        raise NotImplementedError('hyperseg_amd.training.Adam: the parameters of one launch must share one step count')
+                    held = group[key] = (sig, torch.full((blocks,), seeds.pop() if seeds else 0.0, device=dev, dtype=torch.float32))
                 elif held[0] != sig:
                     raise RuntimeError('hyperseg_amd.training.Adam: the set of parameters with gradients changed between steps')
+                elif held[1].device != dev:
+                    raise RuntimeError('hyperseg_amd.training.Adam: the step words live on another device than the parameters')
+                chunks = self.__dict__.setdefault('_hs_chunks', {})
+                for p in chunk:
+                    chunks[p] = (id(group), key)
                 grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in chunk]
                 arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])      # noqa: E731
                 lr = group['lr']
@@ -165,6 +175,46 @@ class Adam(torch.optim.Optimizer):
                                                    int(group['decoupled_weight_decay']), int(group['maximize']), held[1].data_ptr(), _hip.stream_ptr(dev))
                 _hip.check(status, 'hs_adam_step')
         return loss
+
+    def _detached_step_words(self):
+        """Removes the per-workgroup step words from the param groups (they are launch-layout state, not checkpoint state) and returns
+        what it removed plus the count each one holds."""
+        removed, counts = [], {}
+        for g in self.param_groups:
+            for k in [k for k in g if isinstance(k, str) and k.startswith('_hs_steps_')]:
+                held = g.pop(k)
+                removed.append((g, k, held))
+                counts[(id(g), k)] = float(held[1][0].item())
+        return removed, counts
+
+    def state_dict(self):
+        """torch.optim.Adam's checkpoint format: per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq``, param groups without the device
+        step words -- loadable by torch.optim.Adam and by this class on any device (synchronises: reads the step count)."""
+        removed, counts = self._detached_step_words()
+        try:
+            for p, where in self.__dict__.get('_hs_chunks', {}).items():
+                if where in counts and self.state.get(p):
+                    self.state[p]['step'] = torch.tensor(counts[where], dtype=torch.float32)
+            return super().state_dict()
+        finally:
+            for g, k, held in removed:
+                g[k] = held
+
+    def load_state_dict(self, state_dict):
+        """Accepts this class' checkpoints and torch.optim.Adam's (hyperseg/train.py:227 resumes from one): moments go to the
+        parameters' device (torch does that), the step count is re-seeded onto the device by the next step() from ``state[p]['step']``."""
+        super().load_state_dict(state_dict)
+        for g in self.param_groups:                                              # step words of an older checkpoint format: never trusted,
+            for k in [k for k in g if isinstance(k, str) and k.startswith('_hs_steps_')]:      # they may sit on the wrong device
+                held = g.pop(k)
+                try:
+                    count = float(held[1].reshape(-1)[0])
+                except Exception:                                                # noqa: BLE001
+                    continue
+                for p in g['params']:
+                    if self.state.get(p) and 'step' not in self.state[p]:
+                        self.state[p]['step'] = torch.tensor(count, dtype=torch.float32)
+        self.__dict__['_hs_chunks'] = {}
 
     def steps_taken(self, group=0):
         """The step count of a group as the device holds it (synchronises)."""

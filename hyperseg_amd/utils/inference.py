@@ -600,7 +600,8 @@ class GraphedModel(nn.Module):
         super().__init__()
         self.model = model
         self.masks, self.warmup, self.clone_output, self.max_graphs = bool(masks), int(warmup), bool(clone_output), int(max_graphs)
-        self._graphs = {}                      # (shape, dtype, device) -> (graph, static_in, static_out)
+        self._graphs = {}                      # (shape, dtype, device) -> (graph, static_in, static_out, chained-launch owners)
+        self._replays = 0
         self._hook = model.register_load_state_dict_post_hook(lambda module, incompatible: self.reset())
 
     def reset(self):
@@ -632,9 +633,15 @@ class GraphedModel(nn.Module):
             main.wait_stream(side)
             torch.cuda.synchronize(device)
             graph = torch.cuda.CUDAGraph()
+            from .. import functional as HF
+            chained = HF.CHAIN_LAUNCHES_CAPTURED[0]
             with torch.cuda.graph(graph):
                 static_out = self._eager(static_in)
-        self._graphs[key] = (graph, static_in, static_out)
+            # a graph that contains the decoder's chained launch (hs_decoder_chain_fwd: its whole grid must be resident at once) is
+            # replayed behind functional.ChainGate: never beside another chained launch on this device, whatever stream that one is on
+            chains = [m._k1_chain for m in self.model.modules() if getattr(m, '_k1_chain', None) is not None] \
+                if HF.CHAIN_LAUNCHES_CAPTURED[0] != chained else []
+        self._graphs[key] = (graph, static_in, static_out, chains)
         return self._graphs[key]
 
     accepts_host_input = True                  # hyperseg_amd.fps.measure_fps hands the pinned host batch over as it is
@@ -650,8 +657,23 @@ class GraphedModel(nn.Module):
         entry = self._graphs.get(key)
         if entry is None:
             entry = self._capture(key, x, device)
-        graph, static_in, static_out = entry
+        graph, static_in, static_out, chains = entry
         with torch.cuda.device(device):        # the replay and the input copy go to the MODEL's device and its current stream
-            static_in.copy_(x, non_blocking=True)
-            graph.replay()
+            if chains:
+                from .. import functional as HF
+                for ch in chains:              # pinned mirrors of the kernel's error word: a frame built on an abandoned wait raises
+                    ch.check_errors()
+                gate = HF.ChainGate.of(device)
+                with gate.lock:
+                    cur = gate.enter(device)
+                    static_in.copy_(x, non_blocking=True)
+                    graph.replay()
+                    gate.leave(cur)
+                self._replays += 1
+                if self._replays % HF.K1Chain.POLL_EVERY == 0:
+                    for ch in chains:
+                        ch.request_error_copy(device)
+            else:
+                static_in.copy_(x, non_blocking=True)
+                graph.replay()
             return static_out.clone() if self.clone_output else static_out

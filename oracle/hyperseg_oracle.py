@@ -580,6 +580,12 @@ CONFIGS = {
                weight_groups=[64, 32, 32, 16, 8]),
     'L': dict(variant='v0_1', size=(512, 512), feat=[3, 6, 8, 12, 34, 96], signal=1536, num_classes=21,
               kernel_sizes=[1, 1, 3, 3, 3, 3], expand_ratio=2),
+    # CamVid HyperSeg-L (configs/train/camvid_efficientnet_b1_hyperseg-l.py:35-38; not a BASELINE config): the only shipped v1_0
+    # decoder with SIX levels -- three k = 1, then three inverted residuals, the last on 32 x 32-pixel patches of the full-resolution
+    # image (the raw image is its skip) -- evaluated at 1024 x 768 (val_img_transforms, :21); backbone taps as CamVid-S
+    'Lc': dict(variant='v1_0', size=(768, 1024), feat=[3, 4, 6, 10, 28, 80], signal=1280, num_classes=12,
+               kernel_sizes=[1, 1, 1, 3, 3, 3], level_channels=[64, 32, 16, 16, 16, 16], expand_ratio=2,
+               weight_groups=[64, 32, 32, 16, 8, 8]),
 }
 
 

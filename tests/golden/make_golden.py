@@ -323,7 +323,7 @@ def gen_decoders():
 
     # full BASELINE shapes: seeds + SHA-256 of the argmax mask + strided logits sample
     arrs = {}
-    for name in ('M', 'S', 'Sc', 'L'):
+    for name in ('M', 'S', 'Sc', 'L', 'Lc'):
         plan = O.config_plan(name)
         params = O.synth_decoder_params(plan, seed=0)
         dec = ref_decoder(name)

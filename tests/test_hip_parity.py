@@ -391,9 +391,10 @@ def build_decoder(name, O):
 _FULL_REF = {}
 
 
-@pytest.mark.parametrize('name', ['M', 'Sc', 'S', 'L'])
+@pytest.mark.parametrize('name', ['M', 'Sc', 'S', 'L', 'Lc'])
 def test_full_config(golden, O, dev, name, ir_math):
-    """HyperSeg-M 1024x512 / CamVid-S 768x576 / HyperSeg-S 1536x768 (unify) / HyperSeg-L 512x512 bs4 = the per-GPU shard of config 4 (v0_1)
+    """HyperSeg-M 1024x512 / CamVid-S 768x576 / HyperSeg-S 1536x768 (unify) / HyperSeg-L 512x512 bs4 = the per-GPU shard of config 4 (v0_1) /
+    CamVid HyperSeg-L 1024x768 (the six-level v1_0 decoder: three k = 1 levels, then three inverted residuals, the last on 32 x 32-pixel patches)
     decoders on the seeded synthetic workload of SURVEY 8(d): vs the oracle on the full tensor, vs the
     reference's own sampled logits and masks."""
     g = golden('decoder_full_configs')
@@ -772,7 +773,8 @@ def test_bank_in_consumer_is_what_the_decoder_runs(HF, O, dev, monkeypatch):
     cmp(y, y0.cpu(), what='fused vs materialised banks')
 
 
-def test_two_python_threads_two_streams_through_the_decoder(O, HF, dev):
+@pytest.mark.parametrize('chain', [False, True], ids=['three_launches', 'chain_k1'])
+def test_two_python_threads_two_streams_through_the_decoder(O, HF, dev, chain):
     """SURVEY 8b "Threading" / VERDICT r4 weak #4: the reference's multi-GPU mode is nn.DataParallel, i.e. ONE Python thread per replica
     (parallel_apply; hyperseg/train.py:242-243, test_fps.py:155-156) through module objects whose non-tensor attributes -- this
     package's host-side caches -- are SHARED by reference between the replicas.  Here: two threads, each on its own HIP stream, push
@@ -784,6 +786,10 @@ def test_two_python_threads_two_streams_through_the_decoder(O, HF, dev):
     import threading
     import time
     d = build_decoder('M', O).to(dev).eval()
+    # chain_k1 (VERDICT r5 #4 / ADVICE r5): levels 0-2 as hs_k1_chain_fwd, whose workspace carries protocol state between launches and
+    # whose grid must be resident at once -- one workspace per stream (functional.K1Chain) and chained launches ordered across streams
+    # (functional.ChainGate), so the same bit-equality holds and the kernel's error word stays 0
+    d.chain_k1 = chain
     frames = [O.synth_decoder_inputs('M', batch=1, seed=k, size=(128, 256)) for k in (0, 1)]
     frames = [([t.to(dev) for t in x], s.to(dev)) for x, s in frames]
     modes = ['f32', 'split']
@@ -845,6 +851,25 @@ def test_two_python_threads_two_streams_through_the_decoder(O, HF, dev):
         rep = phase(which, inv)
         assert not rep, f'phase {name}: ' + '; '.join(rep)
     assert getattr(HF._ir_math_local, 'mode', None) is None          # the scopes were the threads' own: nothing leaked into this one
+    if chain:
+        kc = d._k1_chain
+        assert kc is not None and kc._ws, 'the chain refused a shape it is built for'
+        assert len(kc._taken) >= 3, 'main stream + one workspace per replica stream'
+        assert kc.error_word() == 0
+        kc.request_error_copy(dev)
+        torch.cuda.synchronize()
+        kc.check_errors()                                             # pinned mirrors: nothing abandoned a wait
+        # ... and a raised error word is what check_errors reports: poke one workspace, mirror it, expect the refusal of the next frame
+        ws = next(iter(kc._taken.values()))[0]
+        ws[:1].view(torch.int32)[:1].fill_(0x51)
+        kc.request_error_copy(dev)
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError, match='abandoned a wait'):
+            with torch.no_grad():
+                d(*frames[0])
+        kc.reset()
+        with torch.no_grad(), HF.ir_math_scope(modes[0]):
+            assert torch.equal(d(*frames[0]), ref[0])
 
 
 @pytest.mark.parametrize('name,size,with_ir', [('M', None, False), ('M', (128, 256), False), ('M', (32, 64), False), ('Sc', None, False),

@@ -1333,3 +1333,90 @@ def test_patch_conv_bn_on_load_equals_batchnorm_then_conv(dev, c, cout, grid, p,
             e_one, e_two = rel_l2(one[k].cpu(), ref[k].cpu()), rel_l2(two[k].cpu(), ref[k].cpu())
             assert e_one < 1e-1 and e_one < 2.0 * e_two + 1e-3, (k, e_one, e_two)
         assert torch.allclose(one['rm'], two['rm'], rtol=1e-5, atol=1e-6) and torch.allclose(one['rv'], two['rv'], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('patch', [(8, 8), (3, 5)])
+def test_train_mode_inverted_residual_with_identity_norms(dev, patch):
+    """HyperPatchInvertedResidual supports norm_layer=nn.Identity (the FPS harness' BN -> identity switch, test_fps.py:147,
+    319-332); in train mode / under gradients the on-load BatchNorm routes (dw_tiles_bn, patch_conv_bn) must fall through to the plain
+    Functions instead of reading `bn.weight`.  Forward and both gradients against autograd of the CPU oracle with unit affines."""
+    import torch.nn as nn
+    from oracle import hyperseg_oracle as O
+    from hyperseg_amd.models import hyperseg_v1_0 as M
+    g = torch.Generator().manual_seed(5)
+    cin, cout, b, (fh, fw), cs, grp = 6, 4, 2, (2, 3), 8, 2
+    h, w = fh * patch[0], fw * patch[1]
+    m = M.HyperPatchInvertedResidual(cin, cout, 3, expand_ratio=2, norm_layer=nn.Identity)
+    m.init_signal2weights(cs, 0, grp)
+    with torch.no_grad():
+        m.signal2weights.weight.copy_(torch.randn(m.signal2weights.weight.shape, generator=g) * 0.5)
+    w_s2w = m.signal2weights.weight.detach().clone()
+    x, s = torch.randn(b, cin, h, w, generator=g), torch.randn(b, cs + 3, fh, fw, generator=g)
+    r = torch.randn(b, cout, h, w, generator=g)
+    unit = lambda n: dict(weight=torch.ones(n), bias=torch.zeros(n), running_mean=torch.zeros(n), running_var=torch.full((n,), 1.0 - O.BN_EPS))
+    xo, so, wo = x.clone().requires_grad_(True), s.clone().requires_grad_(True), w_s2w.clone().requires_grad_(True)
+    wt = O.signal2weights(so, wo, 0, cs, grp, m.hyper_params)
+    yo = O.patch_inverted_residual_v1(xo, wt, m.hidden_dim, cout, unit(m.hidden_dim), unit(m.hidden_dim), unit(cout))
+    (yo * r).sum().backward()
+    m = m.to(dev).train()
+    xg, sg = x.to(dev).requires_grad_(True), s.to(dev).requires_grad_(True)
+    yg = m(xg, sg)
+    (yg * r.to(dev)).sum().backward()
+    assert rel_err(yg.detach().cpu(), yo.detach()) < TOL
+    assert rel_err(xg.grad.cpu(), xo.grad) < TOL and rel_err(sg.grad.cpu(), so.grad) < TOL
+    assert rel_err(m.signal2weights.weight.grad.cpu(), wo.grad) < TOL
+    with torch.no_grad():                                    # train() under no_grad takes the same route (TrainBank or not)
+        assert rel_err(m(x.to(dev), s.to(dev)).cpu(), yo.detach()) < TOL
+
+
+def test_adam_checkpoint_round_trip_and_resume_from_torch_adam(dev, tmp_path):
+    """hyperseg_amd.training.Adam's state_dict is torch.optim.Adam's format (per-parameter step, no device step words in the
+    param groups).  (a) 3 steps, save, load with map_location='cpu' (what utils/checkpoint.py does) into a NEW optimizer, 3 more steps ==
+    6 uninterrupted steps bit for bit, steps_taken 6; (b) resuming from a torch.optim.Adam checkpoint (hyperseg/train.py:227) continues the
+    bias corrections at t = 4 (within 2e-6 of torch's own 6 steps; restarting at t = 1 would be off by ~30x in the update size);
+    (c) torch.optim.Adam loads OUR checkpoint."""
+    from hyperseg_amd.training import Adam
+    sizes = [(5,), (1025,), (37, 53)]
+    g = G(4201)
+    p0 = [torch.randn(sz, generator=g) for sz in sizes]
+    grads = [[torch.randn(sz, generator=g) * 0.2 for sz in sizes] for _ in range(6)]
+    kw = dict(lr=3e-3, betas=(0.5, 0.999))
+
+    def run(opt, ps, ks):
+        for k in ks:
+            for p, gr in zip(ps, grads[k]):
+                p.grad = gr.to(dev).clone()
+            opt.step()
+
+    mk = lambda: [torch.nn.Parameter(t.clone().to(dev)) for t in p0]      # noqa: E731
+    pa = mk(); oa = Adam(pa, **kw); run(oa, pa, range(6))                   # uninterrupted
+    pb = mk(); ob = Adam(pb, **kw); run(ob, pb, range(3))
+    sd = ob.state_dict()
+    assert not any(str(k).startswith('_hs_steps') for k in sd['param_groups'][0]) and float(sd['state'][0]['step']) == 3.0
+    torch.save(dict(opt=sd, params=[p.detach() for p in pb]), tmp_path / 'ck.pth')
+    assert ob.steps_taken() == 3                                           # saving left the live optimizer intact
+    ck = torch.load(tmp_path / 'ck.pth', map_location='cpu')
+    pc = [torch.nn.Parameter(t.to(dev)) for t in ck['params']]
+    oc = Adam(pc, **kw)
+    oc.load_state_dict(ck['opt'])
+    run(oc, pc, range(3, 6))
+    assert oc.steps_taken() == 6
+    for a, c in zip(pa, pc):
+        assert torch.equal(a, c)
+    # (b) from torch's own optimizer
+    pt = mk(); ot = torch.optim.Adam(pt, **kw); run(ot, pt, range(3))
+    torch.save(ot.state_dict(), tmp_path / 'torch.pth')
+    pd = [torch.nn.Parameter(p.detach().clone()) for p in pt]
+    od = Adam(pd, **kw)
+    od.load_state_dict(torch.load(tmp_path / 'torch.pth', map_location='cpu'))
+    run(od, pd, range(3, 6)); run(ot, pt, range(3, 6))
+    assert od.steps_taken() == 6
+    for a, b_ in zip(pd, pt):
+        assert rel_err(a.detach().cpu(), b_.detach().cpu()) < 2e-6
+    # (c) torch reads ours
+    pe = [torch.nn.Parameter(p.detach().clone()) for p in pb]
+    oe = torch.optim.Adam(pe, **kw)
+    oe.load_state_dict(ck['opt'])
+    run(oe, pe, range(3, 6))
+    for a, e in zip(pa, pe):
+        assert rel_err(e.detach().cpu(), a.detach().cpu()) < 2e-6

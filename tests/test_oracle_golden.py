@@ -156,7 +156,7 @@ def test_tiny_decoders(golden, name):
     assert bool((y.argmax(1) == g['y'].argmax(1)).all())
 
 
-@pytest.mark.parametrize('name', ['M', 'S', 'Sc', 'L'])
+@pytest.mark.parametrize('name', ['M', 'S', 'Sc', 'L', 'Lc'])
 def test_full_config_samples(golden, name):
     """Full BASELINE shapes: strided logits sample and margin-aware mask agreement vs the reference."""
     g = golden('decoder_full_configs')
