@@ -389,7 +389,11 @@ def cpu_baseline(model_cpu, size, budget_s=12.0):
         best = None
         for nt in sorted({min(n, ncpu) for n in (8, 16, 32, 64, ncpu)}):
             torch.set_num_threads(nt)
-            frame()
+            t_first = sum(frame())
+            # the candidates are ascending and the time is unimodal in the thread count: once a count is clearly slower than the best the
+            # larger ones are not tried (round 6: at 256 threads ONE frame took over a minute -- 165 of the default run's 180 s)
+            if best is not None and t_first > 1.5 * best[0]:
+                break
             t = sum(frame())
             if best is None or t < best[0]:
                 best = (t, nt)
@@ -402,8 +406,8 @@ def cpu_baseline(model_cpu, size, budget_s=12.0):
     total = enc + dec
     return {'value': round(n / total, 3), 'unit': 'frames/s', 'cores': best[1], 'kind': 'port',
             'sample': f'{n} frames of HyperSeg-M 1024x512 bs1 ({total:.1f} s) on {best[1]} of {ncpu} host threads '
-                      f'(thread count = the fastest of {{8, 16, 32, 64, all {ncpu}}} in a one-frame calibration: more threads slow these '
-                      f'small ops down, so the choice favours the CPU): stock encoder + context head on CPU + oracle/cpu_port.py decoder',
+                      f'(thread count = the fastest of {{8, 16, 32, 64, all {ncpu}}} in an ascending one-frame calibration that stops at the first count '
+                      f'1.5x slower than the best: more threads slow these small ops down, so the choice favours the CPU): stock encoder + context head on CPU + oracle/cpu_port.py decoder',
             'decoder_ms': round(1e3 * dec / n, 2), 'encoder_ms': round(1e3 * enc / n, 2)}
 
 

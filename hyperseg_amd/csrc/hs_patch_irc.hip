@@ -283,15 +283,26 @@ void patch_irc_kernel(IrcArgs a) {
     }
     // (3) BatchNorm rows: thread t takes row t (zero beyond the real channels)
     static_assert(NTHR >= 96, "one pass over the BatchNorm rows");
-    {
-        const float mh = tid < hid ? 1.0f : 0.0f, mo = tid < cout ? 1.0f : 0.0f;
-        const unsigned th = (unsigned)min(tid, hid - 1), to = (unsigned)min(tid, cout - 1);
-        const float v_s1 = ldg(a.s1, th) * mh, v_b1 = ldg(a.b1, th) * mh, v_s2 = ldg(a.s2, th) * mh, v_b2 = ldg(a.b2, th) * mh;
-        const float v_s3 = ldg(a.s3, to) * mo, v_b3 = ldg(a.b3, to) * mo;
-        if (tid < HP) { raw_s1[tid] = v_s1; raw_s2[tid] = v_s2; b1l[tid] = v_b1; b2s[tid] = v_b2 * IRC_H2_SCALE; if (tid >= hid) s1f[tid] = 0.0f; }
-        if (tid < CP) { raw_s3[tid] = v_s3; b3l[tid] = v_b3; if (tid >= cout) s3f[tid] = 0.0f; }
-        if (tid < 16) reinterpret_cast<unsigned*>(lds_raw + L.w3l + w3_piece * 2)[tid] = 0u;          // the 64 zero bytes
+    const float bn_mh = tid < hid ? 1.0f : 0.0f, bn_mo = tid < cout ? 1.0f : 0.0f;
+    const unsigned bn_th = (unsigned)min(tid, hid - 1), bn_to = (unsigned)min(tid, cout - 1);
+    const float r_s1 = ldg(a.s1, bn_th), r_b1 = ldg(a.b1, bn_th), r_s2 = ldg(a.s2, bn_th), r_b2 = ldg(a.b2, bn_th);
+    const float r_s3 = ldg(a.s3, bn_to), r_b3 = ldg(a.b3, bn_to);                       // first use below the tap tables
+    // (3b) the tap tables need no loaded value: built HERE, under the loads' round trip (round 6: they used to follow the first wait;
+    //      ~100 dependent vector instructions with two divisions on wave 0, the wave every barrier then waits for)
+    if (tid < G::HH + HWD) {          // per halo row: {row offset 0, row offset 1 (in window positions), l0, l1, coordinate y}; columns likewise
+        const bool isrow = tid < G::HH;
+        const int i = isrow ? tid : tid - G::HH;
+        const int p = isrow ? pad_index(y0 + i - 1, H, HS_PAD_REFLECT) : pad_index(x0 + i - 1, W, HS_PAD_REFLECT);
+        const Tap t = bilinear_tap(p, isrow ? a.in.scale_y : a.in.scale_x, isrow ? a.in.Hp : a.in.Wp);
+        const int o0 = isrow ? (t.i0 - ly0) * PWW : t.i0 - lx0, o1 = isrow ? (t.i1 - ly0) * PWW : t.i1 - lx0;
+        float* d = (isrow ? TY : TX) + i * 8;
+        d[0] = __int_as_float(o0); d[1] = __int_as_float(o1); d[2] = t.l0; d[3] = t.l1;
+        d[4] = isrow ? linspace_pm1(p, H, a.in.step_y) : linspace_pm1(p, W, a.in.step_x);
     }
+    if (tid < 16) reinterpret_cast<unsigned*>(lds_raw + L.w3l + w3_piece * 2)[tid] = 0u;          // the 64 zero bytes
+    __builtin_amdgcn_sched_barrier(0);
+    if (tid < HP) { raw_s1[tid] = r_s1 * bn_mh; raw_s2[tid] = r_s2 * bn_mh; b1l[tid] = r_b1 * bn_mh; b2s[tid] = r_b2 * bn_mh * IRC_H2_SCALE; if (tid >= hid) s1f[tid] = 0.0f; }
+    if (tid < CP) { raw_s3[tid] = r_s3 * bn_mo; b3l[tid] = r_b3 * bn_mo; if (tid >= cout) s3f[tid] = 0.0f; }
     // @stamp 1
 
     // ================================================ phase 2: tiles and tap tables into the scratch ====================
@@ -336,16 +347,6 @@ void patch_irc_kernel(IrcArgs a) {
                 *reinterpret_cast<pwv*>(d + i * PPL) = o;
             }
         }
-    }
-    if (tid < G::HH + HWD) {          // per halo row: {row offset 0, row offset 1 (in window positions), l0, l1, coordinate y}; columns likewise
-        const bool isrow = tid < G::HH;
-        const int i = isrow ? tid : tid - G::HH;
-        const int p = isrow ? pad_index(y0 + i - 1, H, HS_PAD_REFLECT) : pad_index(x0 + i - 1, W, HS_PAD_REFLECT);
-        const Tap t = bilinear_tap(p, isrow ? a.in.scale_y : a.in.scale_x, isrow ? a.in.Hp : a.in.Wp);
-        const int o0 = isrow ? (t.i0 - ly0) * PWW : t.i0 - lx0, o1 = isrow ? (t.i1 - ly0) * PWW : t.i1 - lx0;
-        float* d = (isrow ? TY : TX) + i * 8;
-        d[0] = __int_as_float(o0); d[1] = __int_as_float(o1); d[2] = t.l0; d[3] = t.l1;
-        d[4] = isrow ? linspace_pm1(p, H, a.in.step_y) : linspace_pm1(p, W, a.in.step_x);
     }
     // (4) the patch's bank: LDS-DMA into its landing zone, 16 bytes per lane, whole 1 KB pieces (the tail piece re-reads the row's
     //     last 16 bytes).  Issued HERE -- every register load above has been consumed -- and in flight until the barrier after the
@@ -751,8 +752,10 @@ void patch_irc_kernel(IrcArgs a) {
             }
 #pragma unroll
             for (int m = 0; m < MT3; ++m) {
-                acc3[m][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a3[m], bl, acc3[m][jt], 0, 0, 0);
-                acc3[m][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a3[m], bh, acc3[m][jt], 0, 0, 0);
+                // operand roles swapped (round 6): D[pixel][channel] -- a lane ends up with 4 CONSECUTIVE PIXELS (4 lk .. 4 lk + 3) of ONE
+                // output channel (16 m + lrow), i.e. one 16-byte store per row where D[channel][pixel] cost four 4-byte stores
+                acc3[m][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, a3[m], acc3[m][jt], 0, 0, 0);
+                acc3[m][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, a3[m], acc3[m][jt], 0, 0, 0);
             }
         }
     };
@@ -777,44 +780,19 @@ void patch_irc_kernel(IrcArgs a) {
 
     // ---- epilogue: bn3 + store ----
     float* __restrict__ yb = a.y + (size_t)b * cout * plane;
-#ifdef HS_IRC_WIDE_STORE
-    // Measured and NOT kept (visit r4b, same box: 27.48 us against 26.70 with the dword stores below): through LDS (h1 is dead since the last depthwise stage; slower waves may still read h2): the accumulator layout gives a store
-    // instruction 16 lanes x 4 bytes per 64-byte row run -- 8 MT3 J3 scattered dword stores per lane, a store-issue-bound tail.
-    // Re-laid as [channel][row][16 pixels], a lane stores 16 bytes and the region leaves in cout / 4 instructions per lane.
-    if (cout * RH * RW <= G::H1_FLOATS) {
+    // the epilogue is store-ISSUE bound (visit r6v3: a quarter of the store instructions, timing only, 26.5 -> 25.8 us): with the swapped
+    // operand roles of pw3 a lane holds pixels 4 lk .. 4 lk + 3 of channel 16 m + lrow -- one BatchNorm row per lane and m, and
+    // MT3 J3 16-byte stores per lane where the D[channel][pixel] layout issued 4 MT3 J3 dword stores
 #pragma unroll
-        for (int m = 0; m < MT3; ++m)
+    for (int m = 0; m < MT3; ++m) {
+        const int o = m * 16 + lrow;
+        if (o < cout) {
+            const float sc = s3f[o], sh = b3l[o];
+            float* __restrict__ yo = yb + (size_t)((unsigned)o * plane + (unsigned)((y0 + wave) * W + x0 + 4 * lk));
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int o = m * 16 + 4 * lk + r;
-                const float sc = s3f[min(o, CP - 1)], sh = b3l[min(o, CP - 1)];
-                if (o < cout) {
-#pragma unroll
-                    for (int jt = 0; jt < J3; ++jt) h1[(o * RH + wave + NW * jt) * RW + lrow] = fmaf(acc3[m][jt][r], sc, sh);
-                }
-            }
-        __syncthreads();
-        const int nq = cout * RH * (RW / 4);
-        for (int q = tid; q < nq; q += NTHR) {
-            const int xq = q & 3, row = (q >> 2) & (RH - 1), o = q / (4 * RH);
-            const f32x4 v = *reinterpret_cast<const f32x4*>(h1 + (o * RH + row) * RW + 4 * xq);
-            *reinterpret_cast<f32x4*>(yb + (unsigned)o * plane + (unsigned)((y0 + row) * W + x0 + 4 * xq)) = v;
-        }
-    } else
-#endif
-    {
-#pragma unroll
-        for (int m = 0; m < MT3; ++m) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int o = m * 16 + 4 * lk + r;
-                if (o < cout) {
-                    const float sc = s3f[o], sh = b3l[o];
-#pragma unroll
-                    for (int jt = 0; jt < J3; ++jt)
-                        yb[(unsigned)o * plane + (unsigned)((y0 + wave + NW * jt) * W + x0 + lrow)] = fmaf(acc3[m][jt][r], sc, sh);
-                }
-            }
+            for (int jt = 0; jt < J3; ++jt)
+                *reinterpret_cast<f32x4*>(yo + (unsigned)(NW * jt * W)) =
+                    f32x4{fmaf(acc3[m][jt][0], sc, sh), fmaf(acc3[m][jt][1], sc, sh), fmaf(acc3[m][jt][2], sc, sh), fmaf(acc3[m][jt][3], sc, sh)};
         }
     }
     // @stamp 24

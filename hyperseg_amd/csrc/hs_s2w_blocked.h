@@ -14,6 +14,7 @@ constexpr int S2W_MAX_LAYERS = 8;
 #endif
 constexpr int S2B_ROWS = 64, S2B_PATCHES = 64, S2B_KC = HS_S2B_KC;      // HS_S2B_KC: dev A/B knob (tools/build_variants.py)
 constexpr int S2B_LDS_FLOATS = 2 * S2B_KC * 256;
+constexpr int S2B_DS = 68;                                              // floats per patch of the staged output block: 64 rows + the <= 3-float alignment shift, == 4 (mod 32)
 
 struct S2bLayer {
     const float* __restrict__ blk;          // packed weights (hs_s2w_pack_fwd)
@@ -53,7 +54,7 @@ __device__ __forceinline__ void s2b_body(const __attribute__((address_space(4)))
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* A = lds;                                                                      // A fill | B fill; the output block aliases both
     float* Bm = lds + S2B_KC * 256;
-    static_assert(S2B_PATCHES * (S2B_ROWS + 1) <= 2 * S2B_KC * 256, "the output block fits the operand fills");
+    static_assert(S2B_PATCHES * S2B_DS <= 2 * S2B_KC * 256, "the output block fits the operand fills");
 
     // B source of this lane: (patch tile, k mod 4, 4 consecutive patches)
     const int pt = lane >> 4, kq = (lane >> 2) & 3, j4 = lane & 3;
@@ -84,21 +85,41 @@ __device__ __forceinline__ void s2b_body(const __attribute__((address_space(4)))
         }
     }
     __syncthreads();                                                                       // operands dead: the output block takes their place
+    // D leaves through LDS as [patch][S2B_DS floats]: the patch's 64 bank rows, SHIFTED by al = n0 & 3 so that 16-byte aligned quads of
+    // the bank row (row start p * ld: ld is a multiple of 4) are 16-byte aligned in LDS too.  Round 6: the stores were 16 dword
+    // instructions per lane (256-byte runs) -- a store-issue-bound tail (3.6 of the launch's 16 us at HyperSeg-M, 790 MB at HyperSeg-L
+    // bs 32: profiles/round5_s2w_phase_removal.txt); now <= 5 dwordx4 instructions per lane, single floats only at the two ends of
+    // a block whose first row is not a multiple of 4 (rows per group 147, 281, 1054 ...)
+    const int r0 = rb * S2B_ROWS, n0 = g * rpg + r0;
+    const int al = n0 & 3;                                                                 // uniform
     {
         const int j = lane & 15, q4 = lane >> 4;
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) lds[(16 * t + j) * (S2B_ROWS + 1) + 16 * wave + 4 * q4 + r] = acc[t][r];
+        for (int t = 0; t < 4; ++t) {
+            float* d = lds + (16 * t + j) * S2B_DS + 16 * wave + 4 * q4 + al;
+            if (al == 0) *reinterpret_cast<f32x4*>(d) = acc[t];                            // conflict-free: 8 lanes x 4 dwords cover the 32 banks (S2B_DS == 4 mod 32)
+            else { d[0] = acc[t][0]; d[1] = acc[t][1]; d[2] = acc[t][2]; d[3] = acc[t][3]; }
+        }
     }
     __syncthreads();
-    const int r0 = rb * S2B_ROWS, n0 = g * rpg + r0;
-    const bool row_ok = (r0 + lane) < rpg && (n0 + lane) < rows;
-#pragma unroll 4
-    for (int q = 0; q < 16; ++q) {
-        const int pl = wave * 16 + q, p = pb * S2B_PATCHES + pl;
-        const float v = lds[pl * (S2B_ROWS + 1) + lane];
-        if (row_ok && p < n_patches) bank[(size_t)p * ld + n0 + lane] = v;
+    const int nv = min(min(rpg - r0, rows - n0), S2B_ROWS);                                // valid rows of the block (uniform; <= 0: a block of padding rows)
+    float* __restrict__ brow = bank + (n0 - al);
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {                                                       // 16 patches x 17 quads per wave
+        const int item = it * 64 + lane;
+        const int pq = item / 17, quad = item - 17 * pq;
+        const int pl = wave * 16 + pq, p = pb * S2B_PATCHES + pl;
+        const int e0 = 4 * quad - al;                                                      // block row of the quad's first float
+        if (pq < 16 && p < n_patches && e0 + 3 >= 0 && e0 < nv) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(lds + pl * S2B_DS + 4 * quad);
+            float* dst = brow + (size_t)p * ld + 4 * quad;
+            if (e0 >= 0 && e0 + 3 < nv) *reinterpret_cast<f32x4*>(dst) = v;
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e0 + e >= 0 && e0 + e < nv) dst[e] = v[e];
+            }
+        }
     }
 }
 
@@ -117,6 +138,7 @@ inline int s2b_fill_args(S2bArgs& a, const float* signal, int batch, int c_signa
     for (int i = 0; i < n_layers; ++i) {
         const hs_s2w_layer& l = layers[order ? order[i] : i];
         if (!l.wsw_blk || ((size_t)l.wsw_blk & 15) != 0) return 1;
+        if (((size_t)l.bank & 15) != 0 || (l.ld & 3) != 0) return 1;      // 16-byte stores into 16-byte aligned bank rows (the direct kernel takes anything)
         S2bLayer& d = a.layer[i];
         d.blk = l.wsw_blk; d.bank = l.bank; d.ld = (long)l.ld; d.signal_index = l.signal_index;
         d.cs_g = l.signal_channels / l.groups; d.rpg = l.wc / l.groups; d.rows = l.rows; d.groups = l.groups;

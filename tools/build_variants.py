@@ -143,10 +143,18 @@ PATCHES = {
                     ('            tv[i] = raw[off_kd + e]; ts[i] = raw_s2[(unsigned)e / 9u];', '            tv[i] = 1.0f; ts[i] = 1.0f;'),
                     ('            if (e < 9 * hid) taps[e] = tv[i] * (ts[i] * IRC_H2_SCALE);', '            if (e < 0) taps[e] = tv[i] * (ts[i] * IRC_H2_SCALE);')],
     'irc_rh8': [('    const bool tall = a.ph % 16 == 0;', '    const bool tall = false;')],
+    # round 6: TIMING-ONLY bounds for the "swap the matrix-core operand roles" idea (a lane then owns 4 consecutive pixels of ONE channel:
+    # one 16-byte store where it now issues four 4-byte stores): a quarter of the epilogue's global stores / of pw1's LDS stores
+    'irc_store_quarter': [('                    for (int jt = 0; jt < J3; ++jt)\n                        yb[(unsigned)o * plane + (unsigned)((y0 + wave + NW * jt) * W + x0 + lrow)] = fmaf(acc3[m][jt][r], sc, sh);',
+                           '                    for (int jt = 0; jt < J3; ++jt)\n                        if (r == 0) yb[(unsigned)o * plane + (unsigned)((y0 + wave + NW * jt) * W + x0 + lrow)] = fmaf(acc3[m][jt][r], sc, sh) + acc3[m][jt][1] + acc3[m][jt][2] + acc3[m][jt][3];')],
+    'irc_h1_quarter': [('                for (int r = 0; r < 4; ++r)\n                    dst[4 * r * PS1] = __builtin_amdgcn_fmed3f(fmaf(acc[r], sc1[r] * ib, sh1[r]), 0.0f, 6.0f);',
+                        '                for (int r = 0; r < 1; ++r) dst[0] = __builtin_amdgcn_fmed3f(fmaf(acc[0], sc1[0] * ib, sh1[0]), 0.0f, 6.0f) + __builtin_amdgcn_fmed3f(fmaf(acc[1], sc1[1] * ib, sh1[1]), 0.0f, 6.0f) + __builtin_amdgcn_fmed3f(fmaf(acc[2], sc1[2] * ib, sh1[2]), 0.0f, 6.0f) + __builtin_amdgcn_fmed3f(fmaf(acc[3], sc1[3] * ib, sh1[3]), 0.0f, 6.0f);')],
     'ntstore': [(STORE_LINE, '                for (int jt = 0; jt < J3; ++jt) __builtin_nontemporal_store(fmaf(acc3[m][jt][r], sc, sh), &yo[yoff[jt]]);')],
 }
 
 PATCHES['irc_rh8_inplace'] = PATCHES['irc_inplace'] + PATCHES['irc_rh8']
+
+PATCHES['irc_both_quarter'] = PATCHES['irc_store_quarter'] + PATCHES['irc_h1_quarter']
 
 VARIANTS = {
     'stamps': dict(flags=[], extra=[], patch=True),
@@ -176,7 +184,9 @@ VARIANTS = {
     'k1m_256': dict(flags=['-DHS_K1M_MIN_PATCHES=256'], extra=[], patch=None),            # ... from 256 patches (HyperSeg-M level 1: 512)
     'k1m_off': dict(flags=['-DHS_K1M_MIN_PATCHES=2000000000'], extra=[], patch=None),   # batched k = 1 levels on the LDS-staged kernel
     's2b_light_first': dict(flags=['-DHS_S2B_LIGHT_FIRST'], extra=[], patch=None),
-    'irc_wide_store': dict(flags=['-DHS_IRC_WIDE_STORE'], extra=[], patch=None),         # round 4: the level-4 epilogue re-laid through LDS into 16-byte stores (measured slower)
+    'irc_wide_store': dict(flags=['-DHS_IRC_WIDE_STORE'], extra=[], patch='git:9d8dcac', file='hs_patch_irc.hip'),   # (round 5's source: the flag left the product in round 6)
+    'irc_r5': dict(flags=[], extra=[], patch='git:9d8dcac', file='hs_patch_irc.hip'),                      # round 5's level-4 kernel, for same-box A/Bs
+         # round 4: the level-4 epilogue re-laid through LDS into 16-byte stores (measured slower)
     'irc_nw8': dict(flags=['-DHS_IRC_NW=8'], extra=[], patch=None),                      # round 4: eight waves per 16 x 16 region (four per SIMD at two workgroups per CU)
     'irc_r3': dict(flags=[], extra=[], patch='irc_r3', file='hs_patch_irc.hip'),          # round 3's level-4 kernel
     'irc_stag_hi40': dict(flags=[], extra=[], patch='irc_stag_hi40', file='hs_patch_irc.hip'),      # round 5: staggered co-resident level-4 workgroups
@@ -187,6 +197,9 @@ VARIANTS = {
     'irc_inplace': dict(flags=[], extra=[], patch='irc_inplace', file='hs_patch_irc.hip'),
     'irc_rh8': dict(flags=[], extra=[], patch='irc_rh8', file='hs_patch_irc.hip'),
     'irc_rh8_inplace': dict(flags=[], extra=[], patch='irc_rh8_inplace', file='hs_patch_irc.hip'),
+    'irc_store_quarter': dict(flags=[], extra=[], patch='irc_store_quarter', file='hs_patch_irc.hip'),
+    'irc_h1_quarter': dict(flags=[], extra=[], patch='irc_h1_quarter', file='hs_patch_irc.hip'),
+    'irc_both_quarter': dict(flags=[], extra=[], patch='irc_both_quarter', file='hs_patch_irc.hip'),
     'gs_tail_switch': dict(flags=[], extra=[], patch='git:b89aa7e', file='hs_gemm_split.hip'),   # round 4: the split GEMM with apply_act(v, a.act) inside the unrolled tail
     'st_slice64': dict(flags=['-DHS_ST_SLICE=64'], extra=[], patch=None),                 # round 4: patches per dW slice of the s2w backward (product: 256)
     'st_slice128': dict(flags=['-DHS_ST_SLICE=128'], extra=[], patch=None),
