@@ -58,313 +58,15 @@ import torch.distributed as dist
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy peak 6290
-FP32_PEAK_TFLOPS = 157.3       # f32 vector == f32-input MFMA dense peak
-F16_PEAK_TFLOPS = 2500.0       # dense f16 / bf16 MFMA peak (MI355X_MICROARCH.md)
-MODELS = {'m': 'hyperseg-m', 's': 'hyperseg-s', 'sc': 'hyperseg-s-camvid', 'l': 'hyperseg-l', 'lc': 'hyperseg-l-camvid'}
-LABELS = {'m': 'HyperSeg-M / EfficientNet-B1 / 1024x512', 's': 'HyperSeg-S / EfficientNet-B1 / 1536x768',
-          'sc': 'HyperSeg-S / EfficientNet-B1 / CamVid 768x576', 'l': 'HyperSeg-L / EfficientNet-B3 / 512x512',
-          'lc': 'HyperSeg-L / EfficientNet-B1 / CamVid 1024x768 (six-level v1_0 decoder)'}
+from hyperseg_amd.benchlib.constants import F16_PEAK_TFLOPS, FP32_PEAK_TFLOPS, HBM_PEAK_GBS, LABELS, MODELS  # noqa: E402,F401
+from hyperseg_amd.benchlib.decoder_probe import (EVENT_REPS, decoder_launches_text, decoder_levels, instrumented_decoder,  # noqa: E402,F401
+                                                 pmc_traffic, roofline_of, self_traffic_passes)
+from hyperseg_amd.benchlib.launch import StubModel, launch_ranks, plan_workload, select_device  # noqa: E402,F401
+from hyperseg_amd.benchlib.side_configs import side_model, side_train_step  # noqa: E402,F401
+from hyperseg_amd.benchlib.timing import Legs, StepLoop, run_timed, time_replayed, two_in_flight  # noqa: E402,F401
 
 
-# --------------------------------------------------------------------------------------------- the timed loop
-class StepLoop:
-    """One rank's step / drain / fence triple.  ``forward()`` produces the rank's output tensor (a graph replay returns
-    the captured static output); ``comm`` is a hyperseg_amd.distributed.LogitsGatherer or None."""
-
-    def __init__(self, forward, comm=None, to_payload=None, world=1, device=None, forward_takes_step=False, on_drain=None):
-        self.forward, self.comm, self.world = forward, comm, world
-        self.on_drain, self.last_step = on_drain, None     # on_drain(last step): a collective carried by the step's own graph
-        self.forward_takes_step = forward_takes_step      # forward(i): one HIP graph per ring slot (zero-copy collective)
-        self.to_payload = to_payload or (lambda y: y)
-        self.device = device
-        self.last = None              # the most recent collected (step, tensor) pair, for checks outside the timing
-        self.cuda = device is not None and device.type == 'cuda'
-
-    def step(self, i):
-        y = self.forward(i) if self.forward_takes_step else self.forward()
-        self.last_step = i
-        if self.comm is not None:
-            done = self.comm.submit(i, self.to_payload(y))
-            if done is not None:
-                self.last = done
-        return y
-
-    def drain(self):
-        if self.comm is not None:
-            for done in self.comm.drain():
-                self.last = done
-        if self.on_drain is not None and self.last_step is not None:
-            self.on_drain(self.last_step)
-            self.last_step = None
-
-    def fence(self):
-        if self.cuda:
-            torch.cuda.synchronize(self.device)
-        if self.world > 1:
-            dist.barrier()
-            if self.cuda:
-                torch.cuda.synchronize(self.device)
-
-
-def run_timed(loop, steps, warmup, repeats=1):
-    """W untimed steps, then ``repeats`` regions of exactly ``steps`` steps; returns the per-region wall time, MAX over
-    ranks.  Step indices keep increasing across regions (the gatherer's ring is indexed by them)."""
-    i = 0
-    for _ in range(warmup):
-        loop.step(i)
-        i += 1
-    loop.drain()
-    times = []
-    for _ in range(repeats):
-        loop.fence()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            loop.step(i)
-            i += 1
-        loop.drain()
-        loop.fence()
-        elapsed = time.perf_counter() - t0
-        if loop.world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=loop.device if loop.cuda else None)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        times.append(elapsed)
-    return times
-
-
-# --------------------------------------------------------------------------------------------- decoder accounting
-def decoder_levels(model, h, w, batch):
-    """Algorithmic HBM bytes and MACs of every decoder level (definition: SURVEY.md section 8d): skips read once, each
-    level output written once and read once at its own resolution, banks read once, intermediates 0 B."""
-    dec = model.decoder
-    fh, fw = h // 32, w // 32
-    p = batch * fh * fw
-    feat = [3] + model.backbone.feat_channels[:-1]
-    levels, prev_c = [], 0
-    for l in range(dec.levels):
-        blk = getattr(dec, f'level_{l}', None)
-        if blk is None:
-            blk = dec.level_blocks[l]                       # unify variant
-        blk = blk[0]
-        first = blk[0] if isinstance(blk, torch.nn.Sequential) else blk
-        stride = 32 >> l
-        hl, wl = h // stride, w // stride
-        skip_c = feat[::-1][l]
-        hid = getattr(first, 'hidden_dim', 0)
-        if not hid and hasattr(first, 'conv'):              # v0_1 inverted residual: three blocks
-            c1, c3 = first.conv[0][0], first.conv[-1][0]
-            cin, hid, cout = c1.in_channels, c1.out_channels, c3.out_channels
-        elif hid:
-            cin, cout = first.in_nc, first.out_nc
-        else:
-            cin, cout = first.in_channels, first.out_channels
-        if hid:
-            ph, pw = hl // fh, wl // fw
-            halo = (ph + 2) * (pw + 2) if hasattr(first, 'hidden_dim') else ph * pw     # Op C runs pw1 on the halo tile
-            macs = p * (halo * cin * hid + ph * pw * (9 * hid + hid * cout))
-            hp = cin * hid + 9 * hid + hid * cout
-        else:
-            macs = batch * hl * wl * cin * cout
-            hp = cin * cout
-        route = None
-        if hid and hasattr(first, 'hidden_dim'):            # Op C: which kernel the level gets under the module's math mode
-            import hyperseg_amd.functional as HF
-            route = HF.patch_ir_route((batch, hl, wl), skip_c, prev_c, (fh, fw), hid, cout, math=getattr(first, 'ir_math', None))
-        levels.append(dict(level=l, cin=cin, cout=cout, hidden=hid, macs=macs, route=route,
-                           in_bytes=4 * batch * (skip_c * hl * wl + prev_c * (hl // 2) * (wl // 2)),
-                           bank_bytes=4 * p * hp, out_bytes=4 * batch * cout * hl * wl))
-        prev_c = cout
-    total = sum(lv['in_bytes'] + lv['bank_bytes'] + lv['out_bytes'] for lv in levels)
-    if (32 >> (dec.levels - 1)) > 1:                       # v1_0 / unify stop at stride 2: final 2x upsample of the logits
-        total += 4 * batch * levels[-1]['cout'] * ((h // 2) * (w // 2) + h * w)
-    return total, levels
-
-
-EVENT_REPS = 8      # identical back-to-back launches per event pair (instrumented_decoder)
-
-
-def instrumented_decoder(model, x, n_inst):
-    """Per-launch durations of the decoder's HIP launches: HIP events on the launch stream around every hyperseg_amd
-    functional entry point, n_inst eager decoder passes with the GPU parked so that the host enqueues a whole pass before
-    its first launch starts (device time, not host launch gaps).  An event pair costs ~5 us of its own on this stack
-    (`event_pair_overhead_us`: a fifth of the dominant launch), so every launch is issued EVENT_REPS times back to back
-    between its two events -- same arguments, same result -- and the average is reported: the pair's cost is amortised and
-    the figure agrees with rocprofv3's kernel duration to about an inter-kernel gap (profiles/).  The decoder's total
-    (`decoder_us`) is taken from separate passes with single launches.  Returns (launches, decoder_us, event_overhead_us)."""
-    import hyperseg_amd.functional as HF
-    names = ['signal2weights', 'signal2weights_multi', 'bank_pack', 'patch_conv', 'patch_ir', 'patch_ir_v0', 'upsample_bilinear']
-    orig = {n: getattr(HF, n) for n in names}
-    recs, counter = {}, [0]
-
-    reps = [1]
-
-    def wrap(n):
-        def f(*a, **k):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = orig[n](*a, **k)
-            for _ in range(reps[0] - 1):
-                orig[n](*a, **k)
-            e1.record()
-            if reps[0] > 1:
-                recs.setdefault((counter[0], n), []).append((e0, e1))
-            counter[0] += 1
-            return r
-        return f
-    feats = model.backbone(x)
-    # the chained levels (functional.K1Chain.run -> hs_k1_chain_fwd / hs_decoder_chain_fwd) are one launch of three / four levels
-    chain_run = HF.K1Chain.run
-
-    def chain_wrap(self, *a, **k):
-        name = 'decoder_chain' if k.get('ir') is not None else 'k1_chain'
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        r = chain_run(self, *a, **k)
-        for _ in range(reps[0] - 1):
-            chain_run(self, *a, **k)
-        e1.record()
-        if r is not None:                         # a refused shape launched nothing: the per-level launches follow and are recorded
-            if reps[0] > 1:
-                recs.setdefault((counter[0], name), []).append((e0, e1))
-            counter[0] += 1
-        return r
-    try:
-        for n in names:
-            setattr(HF, n, wrap(n))
-        HF.K1Chain.run = chain_wrap
-        dec_evs = []
-        for it in range(2 * n_inst):
-            reps[0] = 1 if it < n_inst else EVENT_REPS          # first half: the decoder's own duration; second half: per-launch averages
-            counter[0] = 0
-            head = model.weight_mapper(feats[-1])
-            head = head.contiguous() if isinstance(head, torch.Tensor) else head
-            pyr = [t.contiguous() for t in [x] + feats[:-1]]
-            d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda._sleep(1_000_000 * reps[0])              # long enough for the host to enqueue the whole pass behind it
-            first = counter[0]
-            d0.record()
-            model.decoder(pyr, head)
-            d1.record()
-            if reps[0] == 1:
-                dec_evs.append((d0, d1, first))
-        torch.cuda.synchronize()
-    finally:
-        for n in names:
-            setattr(HF, n, orig[n])
-        HF.K1Chain.run = chain_run
-    cal = []
-    for _ in range(50):                      # an empty event pair on a busy stream is not 0: calibrate and report it
-        torch.cuda._sleep(200_000)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); e1.record()
-        cal.append((e0, e1))
-    torch.cuda.synchronize()
-    cal = sorted(a.elapsed_time(b) * 1e3 for a, b in cal)
-    ev_overhead = cal[len(cal) // 2]
-    first_dec = dec_evs[0][2]
-    launches = []
-    for (i, n), evs in sorted(recs.items()):
-        ts = [a.elapsed_time(b) * 1e3 / EVENT_REPS for a, b in evs]
-        avg = sum(ts) / len(ts)
-        launches.append(dict(idx=i, kernel='hs_' + n + '_fwd', in_decoder=i >= first_dec, avg_us=round(avg, 2),
-                             minus_event_overhead_us=round(max(avg - ev_overhead / EVENT_REPS, 0.0), 2), launches_per_event_pair=EVENT_REPS))
-    dec_us = sum(a.elapsed_time(b) for a, b, _ in dec_evs) * 1e3 / len(dec_evs)
-    return launches, dec_us, ev_overhead
-
-
-def roofline_of(launches, levels, h, w, batch, traffic_dir):
-    """The dominant decoder launch against the roof that binds it."""
-    spans = {'hs_patch_conv_fwd': 1, 'hs_patch_ir_fwd': 1, 'hs_patch_ir_v0_fwd': 1, 'hs_k1_chain_fwd': 3, 'hs_decoder_chain_fwd': 4}
-    conv = [l for l in launches if l['kernel'] in spans and l['in_decoder']]
-    per = {}
-    # every level fused into a launch of its own or into the chain launch (levels 0-2 / 0-3): attribute levels to launches in order;
-    # otherwise (a level split over several launches) no per-level attribution
-    if sum(spans[l['kernel']] for l in conv) == len(levels):
-        at = 0
-        for l in conv:
-            n = spans[l['kernel']]
-            if n == 1:
-                per[l['idx']] = levels[at]
-            else:                                   # the chain: the levels' bytes and multiply-adds together
-                grp = levels[at:at + n]
-                per[l['idx']] = dict(level='-'.join(str(g['level']) for g in grp), cin=grp[0]['cin'], cout=grp[-1]['cout'], hidden=0, route=None,
-                                     macs=sum(g['macs'] for g in grp), in_bytes=sum(g['in_bytes'] for g in grp),
-                                     bank_bytes=sum(g['bank_bytes'] for g in grp), out_bytes=sum(g['out_bytes'] for g in grp))
-            at += n
-    dom = max([l for l in launches if l['in_decoder']], key=lambda l: l['avg_us'])
-    t_s = dom['avg_us'] * 1e-6
-    traffic = pmc_traffic(traffic_dir, dom['kernel'])
-    lv = per.get(dom['idx'])
-    if lv is not None and lv['hidden']:
-        flops = 2.0 * lv['macs']
-        kbytes = lv['in_bytes'] + lv['bank_bytes'] + lv['out_bytes']
-        t_fl, t_by = flops / (FP32_PEAK_TFLOPS * 1e12), kbytes / (HBM_PEAK_GBS * 1e9)
-        if lv.get('route') == 'split_mfma':
-            # The f16-split kernel issues 3 f16 products per f32 product on v_mfma_f32_16x16x32_f16: its matrix-core roof is
-            # 3 x flops at the f16 peak, which the launch's HBM time exceeds -- the roof that binds it is HBM (VERDICT r2 #3).
-            t_f16 = 3.0 * flops / (F16_PEAK_TFLOPS * 1e12)
-            if t_by >= t_f16:
-                return {'bound': 'hbm', 'kernel': f"{dom['kernel']} (level {lv['level']}: {lv['cin']}->{lv['hidden']}->{lv['cout']} ch, "
-                                                  'f16-split matrix-core form hs_patch_irc.hip)',
-                        'achieved': round(kbytes / t_s / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                        'frac': round(kbytes / t_s / 1e9 / HBM_PEAK_GBS, 4), 'traffic': traffic, 'avg_launch_us': dom['avg_us'],
-                        'algorithmic_bytes': kbytes, 'algorithmic_flops': flops,
-                        'f32_mfma_frac': round(flops / t_s / 1e12 / FP32_PEAK_TFLOPS, 4),
-                        'f16_mfma_frac': round(3.0 * flops / t_s / 1e12 / F16_PEAK_TFLOPS, 4),
-                        'note': f'roofs of this launch: HBM {t_by * 1e6:.1f} us at 8 TB/s (binding), f16 matrix cores {t_f16 * 1e6:.1f} us '
-                                f'(3 products per f32 product), f32 matrix cores {t_fl * 1e6:.1f} us (what the exact-f32 form would '
-                                'need; reported as f32_mfma_frac for comparison with rounds 1-2)'}
-        if t_fl >= t_by:
-            return {'bound': 'mfma', 'kernel': f"{dom['kernel']} (level {lv['level']}: {lv['cin']}->{lv['hidden']}->{lv['cout']} ch)",
-                    'achieved': round(flops / t_s / 1e12, 3), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(flops / t_s / 1e12 / FP32_PEAK_TFLOPS, 4), 'traffic': traffic,
-                    'avg_launch_us': dom['avg_us'], 'algorithmic_flops': flops, 'algorithmic_bytes': kbytes,
-                    'hbm_frac': round(kbytes / t_s / 1e9 / HBM_PEAK_GBS, 4),
-                    'note': 'priced against the f32 peak: f32 vector peak == f32-input MFMA dense peak (157.3 TF/s); the launch needs '
-                            f'{t_fl * 1e6:.1f} us at that peak and {t_by * 1e6:.1f} us at the 8 TB/s HBM peak'}
-    if lv is not None:
-        kbytes = lv['in_bytes'] + lv['bank_bytes'] + lv['out_bytes']
-    elif dom['kernel'] in ('hs_signal2weights_multi_fwd', 'hs_signal2weights_fwd'):
-        kbytes = sum(x['bank_bytes'] for x in levels)
-    elif dom['kernel'] == 'hs_upsample_bilinear_fwd':
-        kbytes = 4 * batch * levels[-1]['cout'] * ((h // 2) * (w // 2) + h * w)
-    else:
-        kbytes = 0
-    return {'bound': 'hbm', 'kernel': dom['kernel'], 'achieved': round(kbytes / t_s / 1e9, 1), 'peak': HBM_PEAK_GBS,
-            'unit': 'GB/s', 'frac': round(kbytes / t_s / 1e9 / HBM_PEAK_GBS, 4), 'traffic': traffic,
-            'avg_launch_us': dom['avg_us'], 'algorithmic_bytes': kbytes}
-
-
-def pmc_traffic(traffic_dir, kernel):
-    """HBM bytes per launch of the dominant kernel from rocprofv3 --pmc passes of THIS command made in the same session
-    (FETCH_SIZE and WRITE_SIZE in separate passes; KB units; FETCH_SIZE doubled: gfx950 tallies 128-B reads at 64 B --
-    MI355X_MICROARCH.md, HBM section).  None when no such passes were handed over: never a stored constant."""
-    if not traffic_dir:
-        return None
-    import csv
-    import glob
-    stem = {'hs_patch_ir_fwd': 'patch_ir', 'hs_patch_ir_v0_fwd': 'patch_ir',
-            'hs_patch_conv_fwd': 'patch_conv', 'hs_upsample_bilinear_fwd': 'upsample2x_kernel',
-            'hs_signal2weights_multi_fwd': 'signal2weights'}.get(kernel)
-    if stem is None:
-        return None
-    acc = {}
-    for f in glob.glob(os.path.join(traffic_dir, '**', '*counter_collection.csv'), recursive=True):
-        for r in csv.DictReader(open(f)):
-            if stem in r['Kernel_Name'] and r['Counter_Name'] in ('FETCH_SIZE', 'WRITE_SIZE'):
-                a = acc.setdefault((r['Kernel_Name'], r['Counter_Name']), [0, 0.0])
-                a[0] += 1
-                a[1] += float(r['Counter_Value'])
-    best = None
-    for (kname, cname), (n, v) in acc.items():          # the instantiation with the most bytes = the dominant level
-        other = acc.get((kname, 'WRITE_SIZE' if cname == 'FETCH_SIZE' else 'FETCH_SIZE'))
-        if cname == 'FETCH_SIZE' and other:
-            tot = int((2 * v / n + other[1] / other[0]) * 1024)
-            best = tot if best is None else max(best, tot)
-    return best
-
-
+# --------------------------------------------------------------------------------------------- the CPU baseline (the one leg that may import oracle/)
 def cpu_baseline(model_cpu, size, budget_s=12.0):
     """CPU 'port' baseline on this box's host cores: stock encoder + context head on CPU, then the reference's
     ATen op sequence for the decoder (oracle/cpu_port.py, pinned to the oracle).  The thread count is chosen by a
@@ -409,304 +111,6 @@ def cpu_baseline(model_cpu, size, budget_s=12.0):
                       f'(thread count = the fastest of {{8, 16, 32, 64, all {ncpu}}} in an ascending one-frame calibration that stops at the first count '
                       f'1.5x slower than the best: more threads slow these small ops down, so the choice favours the CPU): stock encoder + context head on CPU + oracle/cpu_port.py decoder',
             'decoder_ms': round(1e3 * dec / n, 2), 'encoder_ms': round(1e3 * enc / n, 2)}
-
-
-# --------------------------------------------------------------------------------------------- other BASELINE configs, side objects
-def side_model(key, dev, steps, warmup, ir_math, split_gemm):
-    """BASELINE config 3 (and any other --model key) as a SIDE object of the default run: whole-model frames/s of one timed region of
-    HIP-graph replays, the decoder's eager launch table and the roofline of ITS dominant launch (event-timed like the headline's;
-    `traffic` null: no PMC pass is spent on side objects).  Built, measured and freed outside every headline region."""
-    from hyperseg_amd import configs
-    from hyperseg_amd.utils.inference import prepare_for_inference
-    from hyperseg_amd.utils.synthetic import fill_by_name
-    plan = plan_workload(key, 0, 1)
-    h, w, batch = plan['h'], plan['w'], plan['batch']
-    model = fill_by_name(configs.build(plan['cfg']).eval(), seed=0)
-    prepare_for_inference(model, fold_bn=False, fused_depthwise=True, split_gemm=split_gemm, ir_math=ir_math)
-    model = model.to(dev)
-    x = torch.rand(batch, 3, h, w, generator=torch.Generator().manual_seed(4321)).to(dev)
-    v, ms, y, g = time_replayed(model, x, steps, warmup, batch)
-    launches, dec_us, _ = instrumented_decoder(model, x, 6)
-    alg_bytes, levels = decoder_levels(model, h, w, batch)
-    roof = roofline_of(launches, levels, h, w, batch, None)
-    roof['traffic_source'] = 'none (side object: no PMC pass)'
-    out = {'workload': f'{LABELS[key]}, batch {batch}, whole model forward, resident input, hipGraph replay', 'value': v, 'unit': 'frames/s',
-           'ms_per_step': ms, 'steps': steps, 'regions': 1, 'ir_math': ir_math, 'finite': bool(torch.isfinite(y).all()),
-           'decoder': {'us_per_batch_eager': round(dec_us, 1), 'algorithmic_bytes': alg_bytes,
-                       'hbm_frac_of_8TBs': round(alg_bytes / (dec_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                       'launches': [(l['kernel'], l['avg_us']) for l in launches if l['in_decoder']]},
-           'roofline': roof}
-    del g, model
-    return out
-
-
-def side_train_step(dev, iters):
-    """BASELINE config 5 as a SIDE object: one training step of the CamVid-S decoder (576x576 crops, bs 2: forward + bootstrapped cross
-    entropy + backward + Adam) replayed as ONE HIP graph (hyperseg_amd.training.GraphedTrainStep), fp32 and under bf16 autocast
-    (bf16 activation storage, f32 accumulation; banks, statistics and the optimizer fp32).  Roofline at STEP level -- the step is a
-    chain of small launches, none of which dominates: algorithmic bytes of the step (forward bytes of SURVEY 8d x 3: the forward pass,
-    the input-gradient pass and the weight-gradient pass each touch the forward's tensors once) / the replayed step time; the longest
-    kernel of an eager step from torch.profiler beside it when the profiler is available."""
-    from hyperseg_amd import configs
-    from hyperseg_amd.training import BootstrappedCrossEntropyLoss, GraphedTrainStep
-    from hyperseg_amd.utils.synthetic import fill_by_name
-    torch.set_grad_enabled(True)
-    try:
-        model = fill_by_name(configs.build('hyperseg-s-camvid'), seed=0).to(dev)
-        gen = torch.Generator().manual_seed(99)
-        x = torch.rand(2, 3, 576, 576, generator=gen).to(dev)
-        with torch.no_grad():
-            model.eval()
-            feats = model.backbone(x)
-            sig = model.weight_mapper(feats[-1]).contiguous()
-            pyr = [t.contiguous() for t in [x] + feats[:-1]]
-        alg_fwd, _ = decoder_levels(model, 576, 576, 2)
-        dec = model.decoder.train()
-        target = torch.randint(0, 12, (2, 576, 576), generator=gen).to(dev)
-        crit = BootstrappedCrossEntropyLoss(k=4096, thresh=0.3, ignore_index=255)
-        from hyperseg_amd.training import Adam as OneLaunchAdam
-        res = {'workload': 'HyperSeg-S / CamVid decoder training step, 576x576 crops, batch 2: forward + bootstrapped CE + backward + Adam, '
-                           'one HIP graph per step (encoder features and signal resident, as tools/train_step_time.py)',
-               'optimizer': 'hyperseg_amd.training.Adam (torch.optim.Adam arithmetic, the whole parameter list in one launch: hs_adam_step); '
-                            'the same step with torch.optim.Adam(capturable, fused) is timed beside it as fp32_torch_adam'}
-        state0 = {k: v.clone() for k, v in dec.state_dict().items()}
-        for mode in ('fp32', 'bf16', 'fp32_torch_adam'):
-            dec.load_state_dict(state0)
-            if mode == 'fp32_torch_adam':
-                opt = torch.optim.Adam(dec.parameters(), lr=torch.tensor(1e-3, device=dev), betas=(0.5, 0.999), capturable=True, fused=True)
-            else:
-                opt = OneLaunchAdam(dec.parameters(), lr=torch.tensor(1e-3, device=dev), betas=(0.5, 0.999))
-
-            def fwd(p, s_, half=(mode == 'bf16')):
-                with torch.autocast('cuda', dtype=torch.bfloat16, enabled=half):
-                    return dec(p, s_)
-            gs = GraphedTrainStep(fwd, crit, opt, (pyr, sig), target)
-            for _ in range(3):
-                gs.step()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(iters):
-                loss, _ = gs.step()
-            torch.cuda.synchronize()
-            ms = 1e3 * (time.perf_counter() - t0) / iters
-            res[mode] = {'ms_per_step': round(ms, 4), 'steps_per_s': round(1e3 / ms, 1), 'steps': iters, 'loss_after': round(float(loss), 4),
-                         'finite': bool(torch.isfinite(loss))}
-            del gs, opt, loss
-        res['bf16_speedup_over_fp32'] = round(res['fp32']['ms_per_step'] / res['bf16']['ms_per_step'], 3)
-        step_bytes = 3 * alg_fwd
-        t_s = res['fp32']['ms_per_step'] * 1e-3
-        res['roofline'] = {'bound': 'hbm', 'kernel': 'whole replayed fp32 step (launch-latency-bound chain; no single dominant kernel)',
-                           'achieved': round(step_bytes / t_s / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                           'frac': round(step_bytes / t_s / 1e9 / HBM_PEAK_GBS, 4), 'traffic': None, 'algorithmic_bytes': step_bytes,
-                           'note': f'algorithmic bytes = 3 x the forward pass\' {alg_fwd} B (SURVEY 8d definition)'}
-        try:                                                  # the longest kernel of one eager fp32 step (kineto / roctracer)
-            from torch.profiler import ProfilerActivity, profile
-            dec.load_state_dict(state0)
-            opt = OneLaunchAdam(dec.parameters(), lr=1e-3, betas=(0.5, 0.999))
-
-            def eager():
-                opt.zero_grad(set_to_none=True)
-                loss = crit(dec(pyr, sig), target)
-                loss.backward()
-                opt.step()
-            eager()
-            torch.cuda.synchronize()
-            with profile(activities=[ProfilerActivity.CUDA]) as prof:
-                for _ in range(3):
-                    eager()
-                torch.cuda.synchronize()
-            rows = []
-            for e in prof.key_averages():
-                tot = getattr(e, 'device_time_total', None)
-                tot = getattr(e, 'cuda_time_total', 0.0) if tot is None else tot
-                if tot and e.count:
-                    rows.append((tot / e.count, e.count / 3.0, e.key))
-            total = sum(a * c for a, c, _ in rows)
-            top = max(rows)
-            res['dominant_kernel'] = {'name': top[2][:120], 'avg_us': round(top[0], 2), 'launches_per_step': round(top[1], 1),
-                                      'kernel_time_per_step_us': round(total, 1), 'kernels_per_step': round(sum(c for _, c, _ in rows), 1),
-                                      'source': 'torch.profiler (device activities), 3 eager fp32 steps'}
-        except Exception as e:                                # noqa: BLE001
-            res['dominant_kernel'] = {'error': f'{type(e).__name__}: {e}'[:200]}
-        return res
-    finally:
-        torch.set_grad_enabled(False)
-
-
-# --------------------------------------------------------------------------------------------- main
-def two_in_flight(forward, x, y_ref, steps, warmup, batch):
-    """A serving-style side number, never ``value``: two independent requests of the benched batch in flight.  Each is a
-    HIP graph of the same forward, captured and replayed on ITS OWN stream (own capture stream => own library workspaces,
-    own graph memory pool; no fork/join inside a graph), launched alternately.  The bs-1 frame is a chain of ~200
-    latency-bound launches that each fill a fraction of the 256 CUs, so a second chain COULD overlap almost for free.
-    Measured (round 2, ROCm 7.2): it does not -- 1026 vs 1018 frames/s at HyperSeg-M, graph replays issued from two streams
-    execute back to back -- so the number documents that there is nothing to gain this way.  Outputs are compared with the
-    single-stream run."""
-    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-    xs = [x, x.clone()]
-    graphs, outs = [], []
-    for s, xi in zip(streams, xs):
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            forward(xi)
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=s):
-            yi = forward(xi)
-        graphs.append(g)
-        outs.append(yi)
-
-    def run(n):
-        for i in range(n):
-            with torch.cuda.stream(streams[i & 1]):
-                graphs[i & 1].replay()
-
-    run(2 * max(1, warmup))
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(steps)
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    diff = max(float((o.float() - y_ref.float()).abs().max()) for o in outs)
-    return {'value': round(steps * batch / el, 2), 'unit': 'frames/s', 'ms_per_step': round(1e3 * el / steps, 4),
-            'max_abs_diff_vs_benched': diff,
-            'note': 'NOT the headline: 2 requests in flight on 2 streams (one HIP graph each); value above = 1 in flight'}
-
-
-def plan_workload(model_key, rank, world):
-    """What ``rank`` of ``world`` computes per step: m / s / sc keep bs 1 per GPU (weak scaling), l shards BASELINE config 4's
-    bs-32 batch into 32 / world contiguous frames per GPU (strong scaling; world must divide 32)."""
-    from hyperseg_amd import configs
-    from hyperseg_amd.distributed import shard_batch
-    cfg = MODELS[model_key]
-    spec = configs.MODELS[cfg]
-    h, w = spec['size']
-    if model_key == 'l':
-        lo, hi = shard_batch(spec['batch'], rank, world)
-        return dict(cfg=cfg, spec=spec, h=h, w=w, batch=hi - lo, global_batch=spec['batch'], scaling='strong', frames=(lo, hi))
-    return dict(cfg=cfg, spec=spec, h=h, w=w, batch=spec['batch'], global_batch=spec['batch'] * world, scaling='weak', frames=None)
-
-
-def select_device(local_rank, stub=False, visible=None):
-    """LOCAL_RANK -> this rank's device: one process per GPU, rank r of the node on cuda:r (torch.distributed.run exports
-    LOCAL_RANK).  Refuses to run two ranks on one GPU or without a GPU; ``stub``: the CPU / gloo plumbing test."""
-    if stub:
-        return torch.device('cpu')
-    n = torch.cuda.device_count() if visible is None else visible
-    if n < 1:
-        raise SystemExit('bench.py needs an MI355X (no GPU visible)')
-    if not 0 <= local_rank < n:
-        raise SystemExit(f'LOCAL_RANK={local_rank} but {n} GPU(s) visible: launch one rank per GPU (--nproc-per-node <= {n})')
-    return torch.device('cuda', local_rank)
-
-
-def self_traffic_passes(model_key, timeout_s=170):
-    """--traffic auto: the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass) of THIS command,
-    spawned before this process touches the GPU and outside every timed region; returns (directory | None, note).
-    Counter collection only -- '--pmc X --kernel-trace', never with a sys / hip / hsa trace domain."""
-    import shutil
-    import subprocess
-    import tempfile
-    exe = shutil.which('rocprofv3')
-    if exe is None:
-        return None, 'rocprofv3 not on PATH'
-    root = tempfile.mkdtemp(prefix='hs_traffic_', dir='/tmp')
-    env = dict(os.environ, TMPDIR='/tmp', HS_BENCH_CHILD='1')
-    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
-        env.pop(k, None)
-    for c in ('FETCH_SIZE', 'WRITE_SIZE'):
-        cmd = [exe, '--pmc', c, '--kernel-trace', '--output-format', 'csv', '-d', os.path.join(root, c), '--',
-               sys.executable, os.path.join(REPO, 'bench.py'), '--model', model_key, '--no-extras', '--steps', '10', '--warmup', '3',
-               '--repeats', '1', '--no-graph', '--traffic', 'off']
-        try:
-            r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
-        except subprocess.TimeoutExpired:
-            return None, f'rocprofv3 --pmc {c} pass timed out after {timeout_s} s'
-        if r.returncode != 0:
-            return None, f'rocprofv3 --pmc {c} pass exited {r.returncode}: ' + r.stderr.decode(errors='replace')[-200:]
-    return root, 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (eager launches, 10 steps), made by this run'
-
-
-def time_replayed(forward, x, steps, warmup, batch):
-    """One timed region of a fresh HIP graph of ``forward(x)`` (side numbers only): (frames/s, ms per step, output)."""
-    for _ in range(3):
-        y = forward(x)
-    torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        y = forward(x)
-    for _ in range(max(1, warmup)):
-        g.replay()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        g.replay()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    return round(steps * batch / el, 2), round(1e3 * el / steps, 4), y, g
-
-
-class Legs:
-    """Wall seconds per leg of a run (`legs_s` on the line: where a default run's minutes go -- the timed regions are milliseconds)."""
-
-    def __init__(self):
-        self.t, self.out = time.perf_counter(), {}
-
-    def mark(self, name):
-        now = time.perf_counter()
-        self.out[name] = round(self.out.get(name, 0.0) + now - self.t, 1)
-        self.t = now
-
-
-def decoder_launches_text(model, launches=None):
-    """What the decoder's launches WERE: from the instrumented table when there is one, else from what the warm-up forwards left behind
-    (a K1Chain that has launched = levels 0-2 went out as one launch) -- never from a flag (HyperSeg-L's line said "chain")."""
-    dec = getattr(model, 'decoder', None)
-    if dec is None:
-        return None
-    if launches:
-        names = [l['kernel'] for l in launches if l['in_decoder']]
-        return ' | '.join(names) + f' ({len(names)} launches, in issue order)'
-    kc = getattr(dec, '_k1_chain', None)
-    chained = kc is not None and bool(kc._ws)
-    n = dec.levels
-    head = 'signal2weights (one launch for every level) | ' if type(dec).__module__.split('.')[-1] != 'hyperseg_v0_1' else ''
-    tail = ' | final 2x upsample' if (32 >> (n - 1)) > 1 else ''
-    if chained:
-        return head + f'levels 0-2 as one launch (hs_k1_chain_fwd: in-launch neighbour hand-offs) | one launch per level 3..{n - 1}' + tail
-    return head + f'one launch per level 0..{n - 1}' + tail
-
-
-def launch_ranks(n, argv):
-    """Re-runs this file as ``n`` ranks of one node under torch.distributed.run (127.0.0.1 rendezvous on a free port) and returns
-    the launcher's exit code; the children inherit stdout, so rank 0's one JSON line is the only thing printed there."""
-    import socket
-    import subprocess
-    with socket.socket() as sk:
-        sk.bind(('127.0.0.1', 0))
-        port = sk.getsockname()[1]
-    env = dict(os.environ)
-    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: what RCCL needs on this driver
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.abspath(__file__), *argv]
-    sys.stdout.flush()
-    rc = subprocess.run(cmd, env=env).returncode
-    if rc != 0:
-        sys.exit(rc)
-    return rc
-
-
-class StubModel:
-    """HS_BENCH_STUB=1 (CPU / gloo plumbing test of this file's main(), tests/test_distributed.py): stands in for the model;
-    ``forward`` writes a rank- and step-dependent pattern of the logits' shape at 1/16 of the resolution."""
-
-    def __init__(self, plan, rank):
-        self.shape = (plan['batch'], plan['spec']['num_classes'], plan['h'] // 16, plan['w'] // 16)
-        self.rank, self.calls = rank, 0
-
-    def __call__(self, x):
-        self.calls += 1
-        return torch.full(self.shape, float(self.rank * 1000 + self.calls % 7), dtype=torch.float32)
 
 
 def main(argv=None):

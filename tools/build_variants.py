@@ -149,6 +149,12 @@ PATCHES = {
                            '                    for (int jt = 0; jt < J3; ++jt)\n                        if (r == 0) yb[(unsigned)o * plane + (unsigned)((y0 + wave + NW * jt) * W + x0 + lrow)] = fmaf(acc3[m][jt][r], sc, sh) + acc3[m][jt][1] + acc3[m][jt][2] + acc3[m][jt][3];')],
     'irc_h1_quarter': [('                for (int r = 0; r < 4; ++r)\n                    dst[4 * r * PS1] = __builtin_amdgcn_fmed3f(fmaf(acc[r], sc1[r] * ib, sh1[r]), 0.0f, 6.0f);',
                         '                for (int r = 0; r < 1; ++r) dst[0] = __builtin_amdgcn_fmed3f(fmaf(acc[0], sc1[0] * ib, sh1[0]), 0.0f, 6.0f) + __builtin_amdgcn_fmed3f(fmaf(acc[1], sc1[1] * ib, sh1[1]), 0.0f, 6.0f) + __builtin_amdgcn_fmed3f(fmaf(acc[2], sc1[2] * ib, sh1[2]), 0.0f, 6.0f) + __builtin_amdgcn_fmed3f(fmaf(acc[3], sc1[3] * ib, sh1[3]), 0.0f, 6.0f);')],
+    # round 6: TIMING-ONLY bound of a barrier-free chunk loop (every wave owning a strip of the region end to end): the chunk loop's
+    # three workgroup barriers replaced by the wave's own LDS wait -- results are wrong (the waves still depend on each other's data)
+    'irc_nobarrier': [('        stage_dw(h0);\n        // @stamp 10 + 4 * (h0 < 32 ? h0 / 16 : 2)\n        __syncthreads();',
+                       '        stage_dw(h0);\n        // @stamp 10 + 4 * (h0 < 32 ? h0 / 16 : 2)\n        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");'),
+                      ('            stage_pw1(h0 + 16);\n            __syncthreads();',
+                       '            stage_pw1(h0 + 16);\n            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");')],
     'ntstore': [(STORE_LINE, '                for (int jt = 0; jt < J3; ++jt) __builtin_nontemporal_store(fmaf(acc3[m][jt][r], sc, sh), &yo[yoff[jt]]);')],
 }
 
@@ -200,6 +206,7 @@ VARIANTS = {
     'irc_store_quarter': dict(flags=[], extra=[], patch='irc_store_quarter', file='hs_patch_irc.hip'),
     'irc_h1_quarter': dict(flags=[], extra=[], patch='irc_h1_quarter', file='hs_patch_irc.hip'),
     'irc_both_quarter': dict(flags=[], extra=[], patch='irc_both_quarter', file='hs_patch_irc.hip'),
+    'irc_nobarrier': dict(flags=[], extra=[], patch='irc_nobarrier', file='hs_patch_irc.hip'),
     'gs_tail_switch': dict(flags=[], extra=[], patch='git:b89aa7e', file='hs_gemm_split.hip'),   # round 4: the split GEMM with apply_act(v, a.act) inside the unrolled tail
     'st_slice64': dict(flags=['-DHS_ST_SLICE=64'], extra=[], patch=None),                 # round 4: patches per dW slice of the s2w backward (product: 256)
     'st_slice128': dict(flags=['-DHS_ST_SLICE=128'], extra=[], patch=None),
