@@ -29,6 +29,7 @@
 // are run-time values, the templates only size register arrays -- there is no table of literal shapes.
 #include "hs_ir_common.h"
 
+
 namespace hs {
 
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
@@ -71,6 +72,7 @@ struct IrcArgs {
     const float* __restrict__ s3; const float* __restrict__ b3;
     float* __restrict__ y;
     int sub_y, sub_x;            // regions per patch
+    int prio;                    // 0 | 1 | 2 | 3: whose turn it is on a CU (see the kernel)
     unsigned m_nsub, m_subx, m_fw, m_fh;      // magic_of(sub_y * sub_x), (sub_x), (fw), (fh)
 };
 
@@ -183,6 +185,18 @@ void patch_irc_kernel(IrcArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // provably uniform: scalar branches, scalar address bases
     const int lrow = lane & 15, lk = lane >> 4;
     // @stamp 0
+    // Whose turn it is on a CU (round 6, visits r6v9 / r6v10).  The hardware arbitrates oldest wave first: of the two workgroups a CU holds,
+    // the one that started first lives 40.0 k cycles and the one that started 49 cycles later 50.3 k, and the launch lasts as long as the
+    // slower one.  The wave's slot on its SIMD (HW_ID.WAVE_ID: 0 for the first resident workgroup, 1 for the second; a newcomer inherits
+    // the slot that was freed) tells the two apart without any memory.  a.prio: 0 = leave it to the hardware; 1 / 3 = the two take turns
+    // at raised priority per chunk / per stage (equal lifetimes, 48.4 k / 49.5 k: the CU's throughput is NOT conserved -- turns cost
+    // 8 % of it -- so the launch gains 1-3 %, not the 10 % the imbalance suggested); 2 = the younger workgroup first (best when the
+    // launch runs several generations of workgroups per CU: HyperSeg-S 46.1 -> 44.5 us).
+    const int wslot = (int)(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 4) & 1u);        // HW_REG_HW_ID, bits [3:0] = wave slot
+    const int prio = a.prio;
+    if (prio == 2 && wslot) __builtin_amdgcn_s_setprio(2);
+#define HS_IRC_TURN(phase) do { if (prio & 1) { if (((phase) + wslot) & 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); } } while (0)
+    HS_IRC_TURN(0);
     // blocks go round-robin to the 8 XCDs: relabel so that every XCD owns a contiguous range -- the regions of one patch
     // (consecutive indices) then share one L2 for the patch's bank and their common halo rows
     int blk = blockIdx.x;
@@ -363,6 +377,7 @@ void patch_irc_kernel(IrcArgs a) {
     // @stamp 2
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // tiles visible; the DMA stays in flight
     // @stamp 3
+    HS_IRC_TURN(1);
 
     // ================================================ phase 3: the B fragments ==========================================
     // Per halo position the lane's SPL skip values, PPL bilinear previous-level values and (tail) the two coordinates;
@@ -487,6 +502,7 @@ void patch_irc_kernel(IrcArgs a) {
         for (int jt = 0; jt < J3; ++jt) acc3[m][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();                                       // the scratch is dead; every wave's DMA pieces have landed (vmcnt(0) + barrier)
     // @stamp 5
+    HS_IRC_TURN(2);
 
     // ================================================ phase 1: split the bank, LDS -> LDS ==============================
     const int n1 = cin * hid, n3 = hid * cout;
@@ -618,6 +634,7 @@ void patch_irc_kernel(IrcArgs a) {
     // @stamp 6
     __syncthreads();                                       // the f16 images are complete: h1 / h2 from here on
     // @stamp 7
+    HS_IRC_TURN(3);
 
     // depthwise thread map: lane = half | row_lo << 1 | channel-of-the-wave << 3 | row_hi << 5; channel = wave + 4 j; with RH = 16
     // a thread takes rows r and r + 8 of its channel (same taps).  This is the map the conflict model was run on
@@ -765,10 +782,12 @@ void patch_irc_kernel(IrcArgs a) {
     __syncthreads();
     // @stamp 9
     for (int h0 = 0; h0 < HP; h0 += 16) {
+        HS_IRC_TURN(prio == 3 ? (h0 >> 3) : (h0 >> 4));
         stage_dw(h0);
         // @stamp 10 + 4 * (h0 < 32 ? h0 / 16 : 2)
         __syncthreads();
         // @stamp 11 + 4 * (h0 < 32 ? h0 / 16 : 2)
+        if (prio == 3) HS_IRC_TURN((h0 >> 3) + 1);
         stage_pw3(h0);
         // @stamp 12 + 4 * (h0 < 32 ? h0 / 16 : 2)
         if (h0 + 16 < HP) {
@@ -778,6 +797,7 @@ void patch_irc_kernel(IrcArgs a) {
         }
     }
 
+    __builtin_amdgcn_s_setprio(0);
     // ---- epilogue: bn3 + store ----
     float* __restrict__ yb = a.y + (size_t)b * cout * plane;
     // the epilogue is store-ISSUE bound (visit r6v3: a quarter of the store instructions, timing only, 26.5 -> 25.8 us): with the swapped
@@ -814,6 +834,10 @@ static int launch_irc(IrcArgs& a, hipStream_t stream) {
     a.m_nsub = magic_of((unsigned)(a.sub_y * a.sub_x)); a.m_subx = magic_of((unsigned)a.sub_x);
     a.m_fw = magic_of((unsigned)a.fw); a.m_fh = magic_of((unsigned)a.fh);
     const long blocks = (long)a.in.B * a.fh * a.fw * a.sub_y * a.sub_x;
+    {   // one generation of workgroups (<= 2 per CU): turns per stage; several generations: the younger workgroup first (visit r6v11)
+        static const int forced = [] { const char* e = getenv("HS_IRC_PRIO"); return e ? atoi(e) : -1; }();      // dev A/B knob
+        a.prio = forced >= 0 ? forced : (blocks > 2 * 256 ? 2 : 3);
+    }
     hipLaunchKernelGGL((patch_irc_kernel<SPL, PPL, MT3, RH_, NW_>), dim3((unsigned)blocks), dim3(64 * G::NW), (size_t)L.total, stream, a);
     return launch_status();
 }

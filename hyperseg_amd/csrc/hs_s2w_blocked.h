@@ -9,6 +9,9 @@ namespace hs {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int S2W_MAX_LAYERS = 8;
 
+#ifndef HS_S2B_NT
+#define HS_S2B_NT 0
+#endif
 #ifndef HS_S2B_KC
 #define HS_S2B_KC 10
 #endif
@@ -113,7 +116,11 @@ __device__ __forceinline__ void s2b_body(const __attribute__((address_space(4)))
         if (pq < 16 && p < n_patches && e0 + 3 >= 0 && e0 < nv) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(lds + pl * S2B_DS + 4 * quad);
             float* dst = brow + (size_t)p * ld + 4 * quad;
+#if HS_S2B_NT
+            if (e0 >= 0 && e0 + 3 < nv) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));      // dev A/B (tools/build_variants.py s2b_nt)
+#else
             if (e0 >= 0 && e0 + 3 < nv) *reinterpret_cast<f32x4*>(dst) = v;
+#endif
             else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)

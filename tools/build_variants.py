@@ -189,6 +189,7 @@ VARIANTS = {
     'gs_tall_513': dict(flags=['-DHS_GS_TALL_MIN_WG=513'], extra=[], patch=None),
     'k1m_256': dict(flags=['-DHS_K1M_MIN_PATCHES=256'], extra=[], patch=None),            # ... from 256 patches (HyperSeg-M level 1: 512)
     'k1m_off': dict(flags=['-DHS_K1M_MIN_PATCHES=2000000000'], extra=[], patch=None),   # batched k = 1 levels on the LDS-staged kernel
+    's2b_nt': dict(flags=['-DHS_S2B_NT=1'], extra=[], patch=None),                    # round 6: non-temporal bank stores of the blocked signal2weights
     's2b_light_first': dict(flags=['-DHS_S2B_LIGHT_FIRST'], extra=[], patch=None),
     'irc_wide_store': dict(flags=['-DHS_IRC_WIDE_STORE'], extra=[], patch='git:9d8dcac', file='hs_patch_irc.hip'),   # (round 5's source: the flag left the product in round 6)
     'irc_r5': dict(flags=[], extra=[], patch='git:9d8dcac', file='hs_patch_irc.hip'),                      # round 5's level-4 kernel, for same-box A/Bs
@@ -206,6 +207,9 @@ VARIANTS = {
     'irc_store_quarter': dict(flags=[], extra=[], patch='irc_store_quarter', file='hs_patch_irc.hip'),
     'irc_h1_quarter': dict(flags=[], extra=[], patch='irc_h1_quarter', file='hs_patch_irc.hip'),
     'irc_both_quarter': dict(flags=[], extra=[], patch='irc_both_quarter', file='hs_patch_irc.hip'),
+    'irc_prio0': dict(flags=['-DHS_IRC_PRIO=0'], extra=[], patch=None),             # round 6: s_setprio turns of the CU's two level-4 workgroups: off / younger always first / per stage
+    'irc_prio2': dict(flags=['-DHS_IRC_PRIO=2'], extra=[], patch=None),
+    'irc_prio3': dict(flags=['-DHS_IRC_PRIO=3'], extra=[], patch=None),
     'irc_nobarrier': dict(flags=[], extra=[], patch='irc_nobarrier', file='hs_patch_irc.hip'),
     'gs_tail_switch': dict(flags=[], extra=[], patch='git:b89aa7e', file='hs_gemm_split.hip'),   # round 4: the split GEMM with apply_act(v, a.act) inside the unrolled tail
     'st_slice64': dict(flags=['-DHS_ST_SLICE=64'], extra=[], patch=None),                 # round 4: patches per dW slice of the s2w backward (product: 256)

@@ -77,3 +77,29 @@ print(f'  shader clock while these workgroups ran (cycle counter / 100 MHz real-
 print(f'  workgroup lifetime: mean {(st[:, 24] - st[:, 0]).mean():.0f}, p10 {np.percentile(st[:, 24] - st[:, 0], 10):.0f}, p90 {np.percentile(st[:, 24] - st[:, 0], 90):.0f}')
 print(f'  workgroup start spread: {(st[:, 0] - t0).max()} cycles; total mean {(st[:, 24] - st[:, 0]).mean():.0f}, '
       f'first start -> last end {st[:, 24].max() - t0}')
+# round 6: the launch on the chip-wide 100 MHz clock (s_memrealtime is the same counter on every XCD): when workgroups start and end
+rs, re = st[:, 30].astype(np.float64), st[:, 29].astype(np.float64)
+r0 = rs.min()
+q = lambda a, p: np.percentile(a, p)     # noqa: E731
+print(f'  real time (us since the first workgroup started): starts p0 {0.0:.2f} p10 {q(rs - r0, 10) / 100:.2f} p50 {q(rs - r0, 50) / 100:.2f} '
+      f'p90 {q(rs - r0, 90) / 100:.2f} p100 {(rs - r0).max() / 100:.2f} | ends p0 {(re - r0).min() / 100:.2f} p10 {q(re - r0, 10) / 100:.2f} '
+      f'p50 {q(re - r0, 50) / 100:.2f} p90 {q(re - r0, 90) / 100:.2f} p100 {(re - r0).max() / 100:.2f}')
+first_per_cu = sorted(min(a for a, _ in iv) for iv in per_cu.values())
+order = np.argsort(rs)
+print(f'  the 256th workgroup (of {len(rs)}) started {(np.sort(rs)[min(255, len(rs) - 1)] - r0) / 100:.2f} us after the first; the last {(rs.max() - r0) / 100:.2f} us')
+# round 6: who is slow?  lifetimes by the order in which a CU's workgroups started, and the phase sums of the two classes
+rank = np.zeros(len(st), dtype=np.int64)
+for k in per_cu:
+    ids = [i for i in range(len(st)) if int(cu_key[i]) == k]
+    for r, i in enumerate(sorted(ids, key=lambda i: st[i, 0])):
+        rank[i] = r
+life = (st[:, 24] - st[:, 0]).astype(np.float64)
+for r in sorted(set(rank.tolist()))[:4]:
+    m = rank == r
+    print(f'  workgroups that started {r + 1}. on their CU: n {int(m.sum())}, lifetime mean {life[m].mean():.0f} p10 {np.percentile(life[m], 10):.0f} p90 {np.percentile(life[m], 90):.0f}; '
+          f'start offset to the CU\'s first: mean {np.mean([st[i, 0] - min(a for a, _ in per_cu[int(cu_key[i])]) for i in np.nonzero(m)[0]]):.0f} cycles; '
+          f'prologue (-> stamp 7) {np.mean(st[m, 7] - st[m, 0]):.0f}, chunk loop + epilogue {np.mean(st[m, 24] - st[m, 7]):.0f}')
+print('  lifetime by XCD: ' + ', '.join(f'{int(x)}: {life[xcc == x].mean():.0f}' for x in sorted(set(xcc.tolist()))))
+slow = life >= np.percentile(life, 90)
+print(f'  slowest 10 %: started {np.mean(rank[slow] == 0) * 100:.0f} % first on their CU; prologue {np.mean(st[slow, 7] - st[slow, 0]):.0f} vs all {np.mean(st[:, 7] - st[:, 0]):.0f}; '
+      f'chunks {np.mean(st[slow, 24] - st[slow, 7]):.0f} vs all {np.mean(st[:, 24] - st[:, 7]):.0f}')
