@@ -43,12 +43,21 @@ class _BankGradBuffer:
     """One gradient buffer for the three column ranges BankSlices hands out (round 5): the layers that consume the ranges write their
     weight gradients straight into views of ONE (patches, ld) tensor, and BankSlices.backward returns it as it is -- where each layer
     allocated its own (patches, range) tensor, the backward of every inverted-residual level was a concatenation launch over the whole
-    bank (two CatArrayBatchedCopy per config-5 step).  Created per BankSlices.forward, filled per backward pass, dropped when returned."""
+    bank (two CatArrayBatchedCopy per config-5 step).  Created per BankSlices.forward, filled per backward pass, dropped when returned.
+
+    Contract: ONE consumer per range and backward pass.  A range handed to two consumers (not something this package's modules do) would
+    have the second weight-gradient kernel overwrite the first's result inside the shared buffer before autograd adds the two -- so a
+    SECOND request for a range in the same pass returns None and the caller allocates privately; ``owns`` then fails for the
+    shared views' sum and BankSlices.backward takes the concatenating route."""
 
     def __init__(self, shape, ranges):
         self.shape, self.ranges, self.buf = tuple(shape), tuple(ranges), None
+        self.taken = set()
 
     def view(self, index, device):
+        if index in self.taken:
+            return None                                          # a second consumer of the same range: private allocation, autograd adds
+        self.taken.add(index)
         if self.buf is None:
             self.buf = torch.empty(self.shape, device=device, dtype=torch.float32)
             if self.shape[1] > self.ranges[-1][1]:
@@ -72,7 +81,9 @@ def _dbank_for(slot, bank, written_cols, device):
     """The weight-gradient tensor of a layer whose kernels write columns [0, written_cols) of every row: a view of the shared buffer when
     the layer's bank is a BankSlices range of exactly that width, else its own allocation (zero-filled where the kernels do not write)."""
     if slot is not None and written_cols == bank.shape[1]:
-        return slot[0].view(slot[1], device)
+        shared = slot[0].view(slot[1], device)
+        if shared is not None:
+            return shared
     alloc = torch.empty if written_cols == bank.shape[1] else torch.zeros
     return alloc(bank.shape[0], bank.shape[1], device=device, dtype=torch.float32)
 
@@ -858,6 +869,7 @@ class BankSlices(torch.autograd.Function):
         if ctx.grads is not None:
             buf, owned = ctx.grads.buf, ctx.grads.owns((g1, g2, g3))
             ctx.grads.buf = None                            # a second backward pass fills a new one
+            ctx.grads.taken = set()
             if owned:
                 return buf, None, None, None
         ref = next(g for g in (g1, g2, g3) if g is not None)

@@ -1420,3 +1420,36 @@ def test_adam_checkpoint_round_trip_and_resume_from_torch_adam(dev, tmp_path):
     run(oe, pe, range(3, 6))
     for a, e in zip(pa, pe):
         assert rel_err(e.detach().cpu(), a.detach().cpu()) < 2e-6
+
+
+def test_bank_slices_range_with_two_consumers(dev):
+    """a BankSlices range consumed by TWO layers -- not something this package's modules do -- must not have the second
+    weight-gradient kernel overwrite the first inside the shared buffer: the second request of a range gets a private tensor, autograd adds
+    the two, BankSlices.backward takes the concatenating route.  Gradient of the bank == the same graph without the shared buffer, and the
+    doubled range really is the sum of two different contributions."""
+    from hyperseg_amd import autograd as HA
+    g = G(4301)
+    b, c, (fh, fw), (ph, pw), cout = 2, 6, (2, 3), (8, 8), 4
+    h, w = fh * ph, fw * pw
+    xa = torch.randn(b, c, h, w, generator=g).to(dev)
+    xb = torch.randn(b, c, h, w, generator=g).to(dev)
+    bank0 = (torch.randn(b * fh * fw, cout * c + 9 * c + 8, generator=g) * 0.3).to(dev)
+    r = torch.randn(b, cout, h, w, generator=g).to(dev)
+
+    def run(shared):
+        prev = HA.USE_SHARED_BANK_GRAD
+        HA.USE_SHARED_BANK_GRAD = shared
+        try:
+            bank = bank0.clone().requires_grad_(True)
+            k1, k2, _ = HA.BankSlices.apply(bank, cout * c, cout * c + 9 * c, cout * c + 9 * c + 8)
+            ya = HA.patch_conv_apply(xa, k1, (fh, fw), cout, 1, 0, 'zeros', 1)          # two consumers of the SAME range k1
+            yb = HA.patch_conv_apply(xb, k1, (fh, fw), cout, 1, 0, 'zeros', 1)
+            yc = HA.patch_conv_apply(xa, k2, (fh, fw), c, 3, 1, 'zeros', c)
+            ((ya + 2 * yb) * r).sum().backward(retain_graph=False)
+            (yc.sum() * 0).backward() if False else None
+            return bank.grad.clone()
+        finally:
+            HA.USE_SHARED_BANK_GRAD = prev
+    ga, gb = run(True), run(False)
+    assert torch.equal(ga, gb)
+    assert float(ga[:, :cout * c].abs().max()) > 0 and bool((ga[:, cout * c:] == 0).all())     # k2 / the tail took no gradient in this graph
