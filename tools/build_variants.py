@@ -155,6 +155,19 @@ PATCHES = {
                        '        stage_dw(h0);\n        // @stamp 10 + 4 * (h0 < 32 ? h0 / 16 : 2)\n        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");'),
                       ('            stage_pw1(h0 + 16);\n            __syncthreads();',
                        '            stage_pw1(h0 + 16);\n            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");')],
+    # round 6: TIMING-ONLY -- is the lane-per-pixel Op D kernel (HyperSeg-L level 5: 705 MB of logits per bs-32 batch) bound by its stores?
+    'px_nostore': [('            if (o < COUT) yo[(size_t)o * plane] = fmaf(acc3[og][r], bnl[16 * HQ + o], bnl[16 * HQ + 4 * OQ + o]);',
+                    '            if (o == 0) yo[(size_t)o * plane] = fmaf(acc3[og][r], bnl[16 * HQ + o], bnl[16 * HQ + 4 * OQ + o]); else asm volatile("" :: "v"(acc3[og][r]));')],
+    # round 6: the wave-slot priority of the level-4 kernel tried on the lane-per-pixel Op D kernel (HyperSeg-L level 5: 32 generations of 4 workgroups per CU)
+    'px_prio_young': [('    int blk = blockIdx.x;                 // XCD-contiguous region ranges (as the tiled kernels)',
+                       '    { const unsigned sl = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | 4) & 3u; if (sl == 3) __builtin_amdgcn_s_setprio(3); else if (sl == 2) __builtin_amdgcn_s_setprio(2); else if (sl == 1) __builtin_amdgcn_s_setprio(1); }\n    int blk = blockIdx.x;                 // XCD-contiguous region ranges (as the tiled kernels)')],
+    'px_prio_odd': [('    int blk = blockIdx.x;                 // XCD-contiguous region ranges (as the tiled kernels)',
+                     '    { const unsigned sl = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | 4) & 1u; if (sl) __builtin_amdgcn_s_setprio(2); }\n    int blk = blockIdx.x;                 // XCD-contiguous region ranges (as the tiled kernels)')],
+    # round 6: wave-slot priority in the chain kernel (two workgroups per CU that WAIT for their neighbours: the slowest cell sets the pace)
+    'kc_prio_young': [('    const int cell = (int)blockIdx.x;\n    const int pib = cell / fw',
+                       '    if (__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 4) & 1u) __builtin_amdgcn_s_setprio(2);\n    const int cell = (int)blockIdx.x;\n    const int pib = cell / fw')],
+    'kc_prio_old': [('    const int cell = (int)blockIdx.x;\n    const int pib = cell / fw',
+                     '    if (!(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 4) & 1u)) __builtin_amdgcn_s_setprio(2);\n    const int cell = (int)blockIdx.x;\n    const int pib = cell / fw')],
     'ntstore': [(STORE_LINE, '                for (int jt = 0; jt < J3; ++jt) __builtin_nontemporal_store(fmaf(acc3[m][jt][r], sc, sh), &yo[yoff[jt]]);')],
 }
 
@@ -211,6 +224,11 @@ VARIANTS = {
     'irc_prio2': dict(flags=['-DHS_IRC_PRIO=2'], extra=[], patch=None),
     'irc_prio3': dict(flags=['-DHS_IRC_PRIO=3'], extra=[], patch=None),
     'irc_nobarrier': dict(flags=[], extra=[], patch='irc_nobarrier', file='hs_patch_irc.hip'),
+    'px_nostore': dict(flags=[], extra=[], patch='px_nostore', file='hs_patch_ir_px.hip'),
+    'px_prio_young': dict(flags=[], extra=[], patch='px_prio_young', file='hs_patch_ir_px.hip'),
+    'px_prio_odd': dict(flags=[], extra=[], patch='px_prio_odd', file='hs_patch_ir_px.hip'),
+    'kc_prio_young': dict(flags=[], extra=[], patch='kc_prio_young', file='hs_k1_chain.hip'),
+    'kc_prio_old': dict(flags=[], extra=[], patch='kc_prio_old', file='hs_k1_chain.hip'),
     'gs_tail_switch': dict(flags=[], extra=[], patch='git:b89aa7e', file='hs_gemm_split.hip'),   # round 4: the split GEMM with apply_act(v, a.act) inside the unrolled tail
     'st_slice64': dict(flags=['-DHS_ST_SLICE=64'], extra=[], patch=None),                 # round 4: patches per dW slice of the s2w backward (product: 256)
     'st_slice128': dict(flags=['-DHS_ST_SLICE=128'], extra=[], patch=None),
