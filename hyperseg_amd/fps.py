@@ -117,12 +117,21 @@ def main(argv=None):
     ap.add_argument('--prepare', action='store_true', help='hyperseg_amd.utils.inference.prepare_for_inference (fused encoder)')
     ap.add_argument('--graph', action='store_true', help='replay one HIP graph per frame (utils.inference.GraphedModel) '
                                                          'instead of launching eagerly; same protocol otherwise')
-    ap.add_argument('--cpu-only', action='store_true')
+    ap.add_argument('-t', '--trace', action='store_true',
+                    help="the reference's torch.jit.trace switch (test_fps.py:49-50, 150-152).  The mirror's modules call the C ABI through "
+                         "ctypes, which the tracer cannot see, so a traced module would be wrong; the purpose of tracing there -- no Python / "
+                         "dispatcher cost per frame -- is served by one HIP-graph replay per frame: --trace selects --graph")
+    ap.add_argument('--gpus', nargs='+', type=int, metavar='N', default=None,
+                    help='GPU ids (test_fps.py:31-32): more than one wraps the model in nn.DataParallel exactly as the reference does '
+                         '(test_fps.py:155-156; one Python thread per replica -- the mirror is re-entrant for that); the first id is the primary device')
+    ap.add_argument('--cpu-only', '--cpu_only', dest='cpu_only', action='store_true')
     args = ap.parse_args(argv)
+    if args.trace:
+        args.graph = True
 
     from . import configs
     from .utils.synthetic import fill_by_name
-    device = torch.device('cpu' if args.cpu_only or not torch.cuda.is_available() else 'cuda:0')
+    device = torch.device('cpu' if args.cpu_only or not torch.cuda.is_available() else f'cuda:{args.gpus[0] if args.gpus else 0}')
     spec = configs.MODELS[args.config]
     if args.arch:
         from .utils.obj_factory import obj_factory
@@ -136,6 +145,10 @@ def main(argv=None):
         from .utils.inference import prepare_for_inference
         prepare_for_inference(model, fold_bn=False, fused_depthwise=True)
     model = model.to(device)
+    if args.gpus and len(args.gpus) > 1 and device.type == 'cuda':
+        if args.graph:
+            raise SystemExit('--graph / --trace replay a captured graph on ONE device: with several --gpus use bench.py --gpus N (one process per GPU)')
+        model = torch.nn.DataParallel(model, args.gpus)
     if args.graph and device.type == 'cuda':
         from .utils.inference import GraphedModel
         model = GraphedModel(model)
