@@ -918,3 +918,33 @@ def test_k1_chain_equals_the_three_launches(O, HF, dev, name, size, with_ir):
             torch.cuda.synchronize()
             assert rel_err(yg.cpu(), ref[it & 1].cpu()) < REL_TOL, f'replay {it}'
         assert d._k1_chain.error_word() == 0
+
+
+@pytest.mark.parametrize('case', [dict(b=1, fh=4, fw=8, hps=(35, 1000, 147 * 3 + 1), grps=(4, 16, 3), cs=(16, 64, 24)),          # rows per group 9, 63, 148: every alignment
+                                  dict(b=3, fh=4, fw=6, hps=(9, 70, 257), grps=(1, 2, 1), cs=(8, 12, 5)),                        # 72 patches: a partial patch block; 257 rows: a 1-row block
+                                  dict(b=1, fh=16, fw=32, hps=(2352, 4216), grps=(16, 4), cs=(192, 320))])                       # HyperSeg-M levels 3-4 (147, 1054 rows per group)
+def test_signal2weights_blocked_stores_stay_inside_their_rows(HF, O, dev, case):
+    """Round 6: the blocked signal2weights writes 16-byte quads of the bank rows, single floats only at the two ends of a block whose first
+    row is not a multiple of 4.  Into a buffer pre-filled with a sentinel: every bank value equals the oracle's, and NOTHING else is touched --
+    the pad columns [hp, ld) of every row and the floats behind the last bank keep the sentinel (an over-wide store at a block edge would
+    show there or in the neighbouring group's rows, which the value check covers)."""
+    g = G(2001)
+    c = case
+    c_sig = max(c['cs']) + 5
+    s = torch.randn(c['b'], c_sig, c['fh'], c['fw'], generator=g).clamp(min=-0.5)
+    layers, refs = [], []
+    for hp, grp, cs in zip(c['hps'], c['grps'], c['cs']):
+        rows = O.next_multiply(hp, grp)
+        w = torch.randn(rows, cs // grp, 1, 1, generator=g)
+        layers.append(dict(wsw_t=w.reshape(rows, -1).t().contiguous().to(dev), signal_index=2, signal_channels=cs, groups=grp, rows=hp))
+        refs.append(O.signal2weights(s, w, 2, cs, grp, hp).permute(0, 2, 3, 1).reshape(-1, hp))
+    n = HF.bank_floats(s, layers)
+    sentinel = -12345.5
+    buf = torch.full((n + 64,), sentinel, device=dev)
+    out = HF.signal2weights_multi(s.to(dev), layers, buf=buf[:n])
+    torch.cuda.synchronize()
+    for ref, o, hp in zip(refs, out, c['hps']):
+        cmp(o.bank[:, :hp], ref, what=f's2w rows {hp}')
+        if o.bank.shape[1] > hp:
+            assert bool((o.bank[:, hp:] == sentinel).all()), f'pad columns of the {hp}-row bank were written'
+    assert bool((buf[n:] == sentinel).all()), 'floats behind the last bank were written'
