@@ -211,6 +211,16 @@ int try_launch_ird(const StageIn& si, int fh, int fw, const float* bank, long ld
 
 using namespace hs;
 
+// HS_IR_MATH_AUTO = "the faster form".  Measured (round 6, profiles/round6_auto_math_narrow_shapes_v17.txt): for the narrow blocks of
+// CamVid HyperSeg-L -- <= 4 skip channels, so most of the split kernel's per-region cost is its fixed prologue -- in launches of more than
+// one generation of 16 x 16 regions (> 2 per CU) the exact-f32 matrix-core kernel wins (level 5, 21 -> 42 -> 12 on 3072 regions: 81.4 vs
+// 88-90 us; level 4, 22 -> 44 -> 16 on 768: 25.4 vs 26.9), while the same width in ONE generation (CamVid-S level 4, 432 regions: 18.3-18.7 vs
+// 19.8) and every wider shape (HyperSeg-M 25.2 vs 31.6, HyperSeg-S 43.3 vs 49.8) stay on the split form.
+static bool ir_auto_prefers_f32(int math, int c_skip, long patches, int ph, int pw) {
+    if (math != HS_IR_MATH_AUTO || c_skip > 4 || ph % 16 != 0 || pw % 16 != 0) return false;
+    return patches * (ph / 16) * (pw / 16) > 2 * 256;
+}
+
 extern "C" int hs_patch_ir_fwd(const hs_stage_input* in, int32_t fh, int32_t fw, const float* bank, int64_t ld,
                                int32_t hidden, int32_t c_out, const hs_epilogue* bn1, const hs_epilogue* bn2,
                                const hs_epilogue* bn3, int32_t residual, int32_t math, float* y, void* stream) {
@@ -240,6 +250,11 @@ extern "C" int hs_patch_ir_fwd(const hs_stage_input* in, int32_t fh, int32_t fw,
     const long blocks = (long)in->batch * fh * fw * a.tiles_y * a.tiles_x;
     hipStream_t s = (hipStream_t)stream;
     const bool fused_form = in->coords && a.in.prev_mode == HS_PREV_BILINEAR && !a.residual;
+    if (fused_form && ir_auto_prefers_f32(math, in->c_skip, (long)in->batch * fh * fw, a.ph, a.pw)) {
+        const int st_m = try_launch_ir_fused(0, a.in, fh, fw, bank, (long)ld, a.cin, in->c_skip, hidden, c_out,
+                                             a.s1, a.b1, a.s2, a.b2, a.s3, a.b3, y, s);
+        if (st_m != 1) return st_m;
+    }
     if (fused_form && math != HS_IR_MATH_F32) {
         // f16 matrix cores on split operands: any channel counts up to 16 + 16 -> 32 on patches >= 8 x 16 pixels
         const int st_c = try_launch_irc(a.in, fh, fw, bank, (long)ld, hidden, c_out, a.s1, a.b1, a.s2, a.b2, a.s3, a.b3, y, s);
@@ -282,6 +297,10 @@ extern "C" int hs_patch_ir_route(const hs_stage_input* in, int32_t fh, int32_t f
     const int cin = si.cin();
     const long ld = (((long)cin * hidden + 9L * hidden + (long)hidden * c_out) + 3) & ~3L;
     const bool fused_form = in->coords && si.prev_mode == HS_PREV_BILINEAR && !residual;
+    if (fused_form && ir_auto_prefers_f32(math, in->c_skip, (long)in->batch * fh * fw, in->H / fh, in->W / fw) &&
+        try_launch_ir_fused(0, si, fh, fw, &dummy, ld, cin, in->c_skip, hidden, c_out, &dummy, &dummy, &dummy, &dummy,
+                            &dummy, &dummy, nullptr, nullptr) == HS_OK)
+        return HS_IR_ROUTE_F32_MFMA;
     if (fused_form && math != HS_IR_MATH_F32 &&
         try_launch_irc(si, fh, fw, &dummy, ld, hidden, c_out, &dummy, &dummy, &dummy, &dummy, &dummy, &dummy, nullptr, nullptr) == HS_OK)
         return HS_IR_ROUTE_SPLIT_MFMA;

@@ -535,6 +535,8 @@ int try_launch_ir_fused(int mode, const StageIn& in, int fh, int fw, const float
             HS_IRF_CASE(26, 16, 19, 16, 0, 16)   // HyperSeg-S level 4
             HS_IRF_CASE(22, 4, 12, 16, 0, 16)    // CamVid-S level 4 (12 classes)
             HS_IRF_CASE(24, 6, 16, 16, 0, 16)    // level-3 shapes on larger patches
+            HS_IRF_CASE(22, 4, 16, 16, 0, 16)    // CamVid HyperSeg-L level 4 (configs/train/camvid_efficientnet_b1_hyperseg-l.py: 22 -> 44 -> 16)
+            HS_IRF_CASE(21, 3, 12, 16, 0, 16)    // CamVid HyperSeg-L level 5 (21 -> 42 -> 12 on 32 x 32-pixel patches of the raw image)
         }
         if (p % 8 == 0) {
             HS_IRF_CASE(24, 6, 16, 8, 0, 8)      // HyperSeg-M / CamVid-S level 3

@@ -272,7 +272,8 @@ int hs_patch_ir_v0_ws_fwd(const hs_stage_input* in, int32_t fh, int32_t fw,
  *       its own maximum is within 2^15 of the matrix's; odd channel counts keep one scale per row) and of every halo
  *       position's input column -- so any overall magnitude is carried; what is not is a dynamic range beyond ~2^18 INSIDE
  *       one reduction (an input 2^20 above its position's other channels meeting a weight 2^-20 of its matrix's maximum).
- *   HS_IR_MATH_AUTO   SPLIT where it is the faster form, F32 elsewhere (today the two coincide with SPLIT's coverage).
+ *   HS_IR_MATH_AUTO   SPLIT where it is the faster form, F32 elsewhere: SPLIT wherever it applies, except narrow blocks (<= 4 skip
+ *       channels) in launches of more than 512 16 x 16 regions, where the exact-f32 kernel measured faster (CamVid HyperSeg-L levels 4-5).
  * The reference runs these layers as fp32 torch convolutions (which cuDNN may run in TF32 there); all modes are held to the
  * same parity tolerance (tests/test_hip_parity.py).  The nn.Module mirror defaults to F32; serving / bench.py opt into AUTO
  * (hyperseg_amd.utils.inference.prepare_for_inference(ir_math='auto')). */
