@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 6, evidence visit B (the round's LAST code): whole GPU suite, default bench line, rocprofv3 kernel stats of the bench command for
 # every model, smoke().
-tag=${1:-r6fb}; R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; mkdir -p gpurun_out; export TMPDIR=/tmp
+tag=${1:-r6fc}; R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; mkdir -p gpurun_out; export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider > gpurun_out/pytest_gpu_$tag.log 2>&1
 echo "pytest rc=$?" >> gpurun_out/pytest_gpu_$tag.log
 grep -E "passed|failed" gpurun_out/pytest_gpu_$tag.log | tail -2
