@@ -168,6 +168,11 @@ PATCHES = {
                        '    if (__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 4) & 1u) __builtin_amdgcn_s_setprio(2);\n    const int cell = (int)blockIdx.x;\n    const int pib = cell / fw')],
     'kc_prio_old': [('    const int cell = (int)blockIdx.x;\n    const int pib = cell / fw',
                      '    if (!(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 4) & 1u)) __builtin_amdgcn_s_setprio(2);\n    const int cell = (int)blockIdx.x;\n    const int pib = cell / fw')],
+    # round 6: wave-slot priority in the exact-f32 fused kernel (CamVid-L levels 4-5: several generations of two workgroups per CU; level 3 of M: one)
+    'irf_prio_young': [('    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;\n',
+                        '    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;\n    if (__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 4) & 1u) __builtin_amdgcn_s_setprio(2);\n')],
+    'irf_prio_old': [('    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;\n',
+                      '    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;\n    if (!(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 4) & 1u)) __builtin_amdgcn_s_setprio(2);\n')],
     'ntstore': [(STORE_LINE, '                for (int jt = 0; jt < J3; ++jt) __builtin_nontemporal_store(fmaf(acc3[m][jt][r], sc, sh), &yo[yoff[jt]]);')],
 }
 
@@ -229,6 +234,8 @@ VARIANTS = {
     'px_prio_odd': dict(flags=[], extra=[], patch='px_prio_odd', file='hs_patch_ir_px.hip'),
     'kc_prio_young': dict(flags=[], extra=[], patch='kc_prio_young', file='hs_k1_chain.hip'),
     'kc_prio_old': dict(flags=[], extra=[], patch='kc_prio_old', file='hs_k1_chain.hip'),
+    'irf_prio_young': dict(flags=[], extra=[], patch='irf_prio_young'),
+    'irf_prio_old': dict(flags=[], extra=[], patch='irf_prio_old'),
     'gs_tail_switch': dict(flags=[], extra=[], patch='git:b89aa7e', file='hs_gemm_split.hip'),   # round 4: the split GEMM with apply_act(v, a.act) inside the unrolled tail
     'st_slice64': dict(flags=['-DHS_ST_SLICE=64'], extra=[], patch=None),                 # round 4: patches per dW slice of the s2w backward (product: 256)
     'st_slice128': dict(flags=['-DHS_ST_SLICE=128'], extra=[], patch=None),
