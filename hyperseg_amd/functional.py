@@ -531,6 +531,7 @@ class K1Chain:
         self._ws = {}                        # key -> workspace signature (what has been launched at least once)
         self._refused = set()
         self._pool = ExclusiveWorkspaces()
+        self._pool.SPARES = 4                # a zero-copy collective ring captures one graph per slot (three): no zero-fill node in any of them
         self._taken = {}                     # id(tensor) -> (tensor, pinned mirror of its error word)
         self._calls = 0
         self._lock = threading.Lock()
@@ -645,6 +646,7 @@ class K1Chain:
         with self._lock:
             self._taken.clear()
         self._pool = ExclusiveWorkspaces()
+        self._pool.SPARES = 4
 
     def error_word(self):
         """Non-zero if a launch on any of this object's workspaces abandoned a wait (synchronising host read: diagnostics / tests)."""
