@@ -172,6 +172,8 @@ def test_bench_workload_plan_and_device_selection():
     with pytest.raises(ValueError):
         bench.plan_workload('l', 0, 3)
     assert [bench.select_device(r, visible=8) for r in range(8)] == [torch.device('cuda', r) for r in range(8)]
+    lc = bench.plan_workload('lc', 3, 8)                        # CamVid HyperSeg-L (round 6): bs 1 per GPU like m / s / sc
+    assert (lc['cfg'], lc['h'], lc['w'], lc['batch'], lc['global_batch'], lc['scaling']) == ('hyperseg-l-camvid', 768, 1024, 1, 8, 'weak')
     for bad in (dict(local_rank=8, visible=8), dict(local_rank=1, visible=1), dict(local_rank=0, visible=0)):
         with pytest.raises(SystemExit):
             bench.select_device(bad['local_rank'], visible=bad['visible'])

@@ -515,3 +515,55 @@ def test_graphed_model_serves_like_eager(dev):
     assert not served._graphable(xg) and not served._graphable(xs[0])       # grad mode is on again here
     with torch.no_grad():
         assert served._graphable(xs[0])
+
+
+def test_two_graphed_models_replay_from_two_threads_with_the_chain_on(dev):
+    """VERDICT r5 #4 on the serving wrapper: TWO GraphedModel wrappers of one prepared model (chain_k1 on: each captured graph holds the
+    chained launch with a workspace of its own) replayed from two Python threads on two streams at once.  functional.ChainGate orders the
+    replays (the chained launch needs its whole grid resident: two at once could starve each other into the bounded spins' give-up), so
+    every output equals the serial result bit for bit, both graphs are known to contain a chained launch, and the kernel's error word,
+    mirrored by the wrappers' polling, stays 0."""
+    import threading
+    from hyperseg_amd import configs
+    from hyperseg_amd import functional as HF
+    from hyperseg_amd.utils.inference import GraphedModel, prepare_for_inference
+    from hyperseg_amd.utils.synthetic import fill_by_name
+    model = fill_by_name(configs.build('hyperseg-m').eval(), seed=7)
+    prepare_for_inference(model, fold_bn=False, fused_depthwise=True, split_gemm=True, chain_k1=True)
+    model = model.to(dev)
+    xs = [torch.rand(1, 3, 256, 512, generator=G(1301 + i)).to(dev) for i in range(2)]
+    served = [GraphedModel(model, clone_output=True) for _ in range(2)]
+    with torch.no_grad():
+        ref = [served[i](xs[i]).clone() for i in range(2)]                 # captures (serially) + the serial results
+        assert all(torch.equal(served[i](xs[i]), ref[i]) for i in range(2))
+    assert all(len(s._graphs) == 1 and next(iter(s._graphs.values()))[3] for s in served), 'the captured graphs must know they hold a chained launch'
+    kc = model.decoder._k1_chain
+    assert kc is not None and kc._ws
+    outs, errors = {0: [], 1: []}, []
+    start = threading.Barrier(2)
+
+    def replica(i):
+        try:
+            stream = torch.cuda.Stream(dev)
+            start.wait()
+            with torch.no_grad(), torch.cuda.stream(stream):
+                for _ in range(60):
+                    outs[i].append(served[i](xs[i]))
+            stream.synchronize()
+        except BaseException as e:          # noqa: BLE001 -- re-raised on the main thread
+            errors.append(e)
+    threads = [threading.Thread(target=replica, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not errors, errors
+    torch.cuda.synchronize()
+    for i in range(2):
+        bad = [k for k, y in enumerate(outs[i]) if not torch.equal(y, ref[i])]
+        assert len(outs[i]) == 60 and not bad, f'wrapper {i}: {len(bad)} of 60 replays differ from the serial result (first {bad[:5]})'
+    assert kc.error_word() == 0
+    kc.request_error_copy(dev)
+    torch.cuda.synchronize()
+    kc.check_errors()
+    assert served[0]._replays >= 60 and HF.ChainGate.of(dev).last_event is not None
