@@ -544,3 +544,29 @@ def test_training_host_logic_without_a_gpu():
     numel = (C.c_int64 * 4)(1, 1024, 1025, 4216 * 80)
     assert _hip.lib.hs_adam_blocks(numel, 4) == 1 + 1 + 2 + 330
     assert _hip.lib.hs_adam_blocks(numel, 0) == 0 and _hip.lib.hs_adam_blocks((C.c_int64 * 1)(0), 1) == 0
+
+
+def test_the_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it.  Nothing under
+    hyperseg_amd/ (the package, incl. hyperseg_amd/benchlib: bench.py's other legs) may -- a product path that routes through the CPU oracle
+    would void every parity claim -- and in bench.py the import sits inside cpu_baseline() only."""
+    import ast
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def oracle_imports(path):
+        tree = ast.parse(open(path).read())
+        hits = []
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Import) and any(a.name.split('.')[0] == 'oracle' for a in node.names):
+                hits.append(node.lineno)
+            if isinstance(node, ast.ImportFrom) and node.level == 0 and (node.module or '').split('.')[0] == 'oracle':
+                hits.append(node.lineno)
+        return tree, hits
+    for d, _, files in os.walk(os.path.join(root, 'hyperseg_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                assert not oracle_imports(os.path.join(d, f))[1], f'{os.path.join(d, f)} imports oracle/'
+    tree, hits = oracle_imports(os.path.join(root, 'bench.py'))
+    cb = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == 'cpu_baseline')
+    assert hits and all(cb.lineno <= h <= cb.end_lineno for h in hits), 'bench.py may import oracle/ inside cpu_baseline() only'
