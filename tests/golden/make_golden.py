@@ -478,6 +478,11 @@ MODEL_KW = {
     'L': dict(mod='v0_1', name='efficientnet-b3', num_classes=21, kw=dict(
         levels=3, kernel_sizes=(1, 1, 3, 3, 3, 3), expand_ratio=2, inference_hflip=True, with_out_fc=False,
         decoder_dropout=None, weight_groups=16)),
+    # CamVid HyperSeg-L (configs/train/camvid_efficientnet_b1_hyperseg-l.py:35-38): the six-level v1_0 model
+    'Lc': dict(mod='v1_0', name='efficientnet-b1', num_classes=12, kw=dict(
+        levels=2, kernel_sizes=(1, 1, 1, 3, 3, 3), level_channels=[64, 32, 16, 16, 16, 16], expand_ratio=2,
+        inference_hflip=True, with_out_fc=False, decoder_dropout=None, weight_groups=[64, 32, 32, 16, 8, 8],
+        coords_res=[(768, 768), (768, 1024)])),
 }
 
 

@@ -20,12 +20,13 @@ def model_m():
     return fill_by_name(configs.build('hyperseg-m').eval(), seed=11)
 
 
-MODELS = {'M': 'hyperseg-m', 'S': 'hyperseg-s', 'L': 'hyperseg-l'}
+MODELS = {'M': 'hyperseg-m', 'S': 'hyperseg-s', 'L': 'hyperseg-l', 'Lc': 'hyperseg-l-camvid'}
 
 
-@pytest.mark.parametrize('tag', ['S', 'L'])
+@pytest.mark.parametrize('tag', ['S', 'L', 'Lc'])
 def test_state_dict_and_context_head_other_variants(golden, tag):
-    """unify (HyperSeg-S) and v0_1 (HyperSeg-L): key/shape hashes + encoder/context-head numerics on CPU."""
+    """unify (HyperSeg-S), v0_1 (HyperSeg-L) and the six-level v1_0 model (CamVid HyperSeg-L, round 6): key/shape hashes +
+    encoder/context-head numerics on CPU."""
     from hyperseg_amd import configs
     g = golden(f'model_{tag}')
     m = fill_by_name(configs.build(MODELS[tag]).eval(), seed=11)
@@ -44,9 +45,12 @@ def test_state_dict_and_context_head_other_variants(golden, tag):
         assert [(w.signal_index, w.signal_channels) for w in m.decoder.weight_blocks] == \
                [(0, 576), (576, 128), (704, 64), (768, 512)]
         assert tuple(sd['decoder.weight_blocks.3.signal2weights.weight'].shape) == (3680, 32, 1, 1)
-    else:
+    elif tag == 'L':
         assert tuple(sd['weight_mapper.out_conv.conv_1.weight'].shape) == (4496, 17, 1, 1)
         assert m.decoder.param_groups == [9408, 4488, 6624, 1716, 992, 902]
+    else:                                       # CamVid-L: six levels, hyper-parameter counts as the reference builds them
+        assert m.decoder.levels == 6 and m.decoder.param_groups == [5248, 3008, 704, 2352, 2068, 1764]
+        assert tuple(sd['decoder.level_5.0.signal2weights.weight'].shape) == (1768, 16, 1, 1)      # next_multiply(1764, 8 groups)
 
 
 def test_state_dict_contract(golden, model_m):
@@ -126,7 +130,7 @@ def test_graphed_model_host_logic(model_m):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('tag', ['S', 'L'])
+@pytest.mark.parametrize('tag', ['S', 'L', 'Lc'])
 def test_model_end_to_end_other_variants(golden, tag):
     from hyperseg_amd import configs
     g = golden(f'model_{tag}')
@@ -158,7 +162,7 @@ def test_model_m_end_to_end(golden, model_m):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('tag', ['M', 'S', 'L'])
+@pytest.mark.parametrize('tag', ['M', 'S', 'L', 'Lc'])
 def test_segment_equals_argmax_of_forward(golden, tag):
     """HyperGen.segment (argmax fused into the final upsample) == forward(x).argmax(1), bit for bit."""
     from hyperseg_amd import configs
