@@ -476,8 +476,8 @@ class ChainGate:
     grid resident, which the host checks against an EMPTY chip -- two chained launches running at once (two streams / threads of one
     model, two prepared models) can starve each other of residency, the bounded spins then give up and the logits are wrong.  The gate
     orders chained launches ACROSS streams with events (a launch on stream B waits for the previous chained launch on stream A; launches
-    of one stream are ordered anyway); ``serialize`` does the same around the replay of a graph that contains a chained launch
-    (utils.inference.GraphedModel).  Process-wide, per device; the lock spans "wait on the previous event -> launch -> record"."""
+    of one stream are ordered anyway); utils.inference.GraphedModel brackets the replay of a graph that contains a chained launch with the
+    same ``enter`` / ``leave`` pair.  Process-wide, per device; the lock spans "wait on the previous event -> launch -> record"."""
     _gates, _glock = {}, threading.Lock()
 
     def __init__(self):
