@@ -77,6 +77,8 @@ for idx, blk in enumerate(bb._blocks):
               f'{err:9.1e} pool {perr:.1e}')
     t = blk(t)
 print(f'sum unfused {tot_a:.1f} us   fused {tot_b:.1f} us')
+if os.environ.get('HS_BENCH_MBCONV_FIRST_TABLE_ONLY'):
+    sys.exit(0)
 
 # ---- every 1x1 convolution of the encoder: library GEMM (torch.mm) vs hs_pointwise_conv_fwd (bare GEMM, no epilogue) ----
 print(f'\n{"blk":>3} {"conv":>7} {"cin":>5} {"cout":>5} {"pixels":>7} {"mm_us":>8} {"mfma_us":>8}')

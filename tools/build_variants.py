@@ -173,6 +173,10 @@ PATCHES = {
                         '    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;\n    if (__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 4) & 1u) __builtin_amdgcn_s_setprio(2);\n')],
     'irf_prio_old': [('    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;\n',
                       '    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;\n    if (!(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 4) & 1u)) __builtin_amdgcn_s_setprio(2);\n')],
+    # round 6 (second half): TIMING-ONLY bound of the depthwise stage on packed FMAs (two hidden channels per lane: v_pk_fma_f32): half of
+    # the stage's 72 v_fma_f32 per row block removed -- results are wrong
+    'irc_dw_half': [('                    for (int v = 0; v < 8; ++v) o[v] = fmaf(k[ky * 3 + kx], rowv[v + kx], o[v]);',
+                     '                    for (int v = 0; v < 8; v += 2) o[v] = fmaf(k[ky * 3 + kx], rowv[v + kx], o[v]);')],
     'ntstore': [(STORE_LINE, '                for (int jt = 0; jt < J3; ++jt) __builtin_nontemporal_store(fmaf(acc3[m][jt][r], sc, sh), &yo[yoff[jt]]);')],
 }
 
@@ -228,6 +232,7 @@ VARIANTS = {
     'irc_prio0': dict(flags=['-DHS_IRC_PRIO=0'], extra=[], patch=None),             # round 6: s_setprio turns of the CU's two level-4 workgroups: off / younger always first / per stage
     'irc_prio2': dict(flags=['-DHS_IRC_PRIO=2'], extra=[], patch=None),
     'irc_prio3': dict(flags=['-DHS_IRC_PRIO=3'], extra=[], patch=None),
+    'irc_dw_half': dict(flags=[], extra=[], patch='irc_dw_half', file='hs_patch_irc.hip'),
     'irc_nobarrier': dict(flags=[], extra=[], patch='irc_nobarrier', file='hs_patch_irc.hip'),
     'px_nostore': dict(flags=[], extra=[], patch='px_nostore', file='hs_patch_ir_px.hip'),
     'px_prio_young': dict(flags=[], extra=[], patch='px_prio_young', file='hs_patch_ir_px.hip'),
