@@ -15,7 +15,7 @@ REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, 'csrc')
 LIB_DIR = os.path.join(PKG, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libhyperseg_hip.so')
-SOURCES = ['hs_weights.hip', 'hs_patch_conv.hip', 'hs_patch_conv_gen.hip', 'hs_patch_conv_k1m.hip', 'hs_k1_chain.hip', 'hs_meta_conv.hip', 'hs_patch_ir.hip', 'hs_patch_ir_fused.hip', 'hs_patch_irc.hip', 'hs_patch_ir_px.hip', 'hs_patch_ir_d2.hip', 'hs_encoder.hip', 'hs_mbconv.hip', 'hs_gemm_split.hip', 'hs_patch_conv_bwd.hip', 'hs_patch_conv_train.hip', 'hs_train_aux.hip', 'hs_s2w_train.hip']
+SOURCES = ['hs_weights.hip', 'hs_patch_conv.hip', 'hs_patch_conv_gen.hip', 'hs_patch_conv_k1m.hip', 'hs_k1_chain.hip', 'hs_meta_conv.hip', 'hs_patch_ir.hip', 'hs_patch_ir_fused.hip', 'hs_patch_irc.hip', 'hs_patch_ir_px.hip', 'hs_patch_ir_d2.hip', 'hs_encoder.hip', 'hs_mbconv.hip', 'hs_mbconv_lean.hip', 'hs_gemm_split.hip', 'hs_patch_conv_bwd.hip', 'hs_patch_conv_train.hip', 'hs_train_aux.hip', 'hs_s2w_train.hip']
 HEADERS = [os.path.join(CSRC, 'hs_common.h'), os.path.join(CSRC, 'hs_ir_tiles.h'), os.path.join(CSRC, 'hs_ir_common.h'), os.path.join(CSRC, 'hs_s2w_blocked.h'), os.path.join(CSRC, 'hs_se_tail.h'), os.path.join(REPO, 'include', 'hyperseg_hip.h')]
 # -amdgpu-kernarg-preload-count=16: gfx950 preloads the first 16 kernel-argument dwords into SGPRs at wave launch, so the
 # first address computations do not wait for a scalar load (round 3, visit r5a: 0.9168 -> 0.9019 ms per HyperSeg-M frame,

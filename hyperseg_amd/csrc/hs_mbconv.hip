@@ -250,25 +250,39 @@ static int dispatch_ks(const MbxArgs& a, int batch, hipStream_t stream) {
     return HS_ERR_UNSUPPORTED;         // wider inputs: the B fragments no longer fit the register file -> unfused route
 }
 
+int try_launch_mbconv_lean(const float* x, int batch, int c_in, int H, int W, const float* w_expand, int c_mid, const float* scale0,
+                           const float* shift0, const float* w_dw, int k, int stride, int pad_t, int pad_l, int Ho, int Wo,
+                           const float* scale1, const float* shift1, float* y, float* pool, int oth, int tiles_y, int tiles_x,
+                           int chunks_per_wg, int ngroups, hipStream_t stream);                 // hs_mbconv_lean.hip
+
 }  // namespace hs
 
 using namespace hs;
 
+// dev A/B knobs of the tile shape (round 6): output-tile height per stride and the workgroup count below which a launch is cut
+// into more channel-chunk groups
+static int mbx_knob(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static int mbx_oth(int stride) {
+    static const int o1 = mbx_knob("HS_MBX_OTH1", 16), o2 = mbx_knob("HS_MBX_OTH2", 8);
+    return stride == 1 ? o1 : o2;
+}
+
 extern "C" int hs_mbconv_tiles(int32_t k, int32_t stride, int32_t Ho, int32_t Wo) {
     (void)k;
-    const int oth = stride == 1 ? 16 : 8, otw = 16;
+    const int oth = mbx_oth(stride), otw = 16;
     return ((Ho + oth - 1) / oth) * ((Wo + otw - 1) / otw);
 }
 
 // tiles and channel-chunk groups of a launch (enough workgroups to fill 256 CUs a few times over, but as few re-loads of the
 // input tile as that allows)
 static void mbx_grid(int batch, int c_mid, int stride, int Ho, int Wo, int& tiles_y, int& tiles_x, int& cpw, int& ngroups) {
-    const int oth = stride == 1 ? 16 : 8, otw = 16;
+    const int oth = mbx_oth(stride), otw = 16;
     tiles_y = (Ho + oth - 1) / oth; tiles_x = (Wo + otw - 1) / otw;
     const int nchunks = (c_mid + 15) / 16;
     const long tiles = (long)batch * tiles_y * tiles_x;
+    static const int min_wg = mbx_knob("HS_MBX_MIN_WG", 768);
     cpw = nchunks;
-    while (cpw > 1 && tiles * ((nchunks + cpw - 1) / cpw) < 768) --cpw;
+    while (cpw > 1 && tiles * ((nchunks + cpw - 1) / cpw) < min_wg) --cpw;
     ngroups = (nchunks + cpw - 1) / cpw;
 }
 
@@ -294,16 +308,23 @@ static int mbconv_launch(const float* x, int32_t batch, int32_t c_in, int32_t H,
     a.Cin = c_in; a.Cmid = c_mid; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.pad_t = pad_t; a.pad_l = pad_l;
     if (stride != 1 && stride != 2) return HS_ERR_UNSUPPORTED;
     mbx_grid(batch, c_mid, stride, Ho, Wo, a.tiles_y, a.tiles_x, a.chunks_per_wg, a.ngroups);
+    hipStream_t s = (hipStream_t)stream;
+    if (!se_in && (stride == 1 || stride == 2)) {      // the lean form (hs_mbconv_lean.hip) wherever the shape allows: same tiles, same sums
+        const int st = try_launch_mbconv_lean(x, batch, c_in, H, W, w_expand, c_mid, scale0, shift0, w_dw, k, stride, pad_t, pad_l, Ho, Wo,
+                                              scale1, shift1, y, pool_partial, mbx_oth(stride), a.tiles_y, a.tiles_x, a.chunks_per_wg,
+                                              a.ngroups, s);
+        if (st != 1) return st;
+    }
     a.se = SeTail{};
     if (se_in) {
         const int st = make_se_tail(se_in, batch, c_mid, a.tiles_y * a.tiles_x, (long)a.tiles_y * a.tiles_x * a.ngroups, Ho * Wo, a.se);
         if (st != HS_OK) return st;
     }
-    hipStream_t s = (hipStream_t)stream;
-    if (k == 3 && stride == 1) return dispatch_ks<3, 1, 16, 16>(a, batch, s);
-    if (k == 3 && stride == 2) return dispatch_ks<3, 2, 8, 16>(a, batch, s);
-    if (k == 5 && stride == 1) return dispatch_ks<5, 1, 16, 16>(a, batch, s);
-    if (k == 5 && stride == 2) return dispatch_ks<5, 2, 8, 16>(a, batch, s);
+    const int oth = mbx_oth(stride);
+    if (k == 3 && stride == 1) return oth == 8 ? dispatch_ks<3, 1, 8, 16>(a, batch, s) : dispatch_ks<3, 1, 16, 16>(a, batch, s);
+    if (k == 3 && stride == 2) return oth == 4 ? dispatch_ks<3, 2, 4, 16>(a, batch, s) : dispatch_ks<3, 2, 8, 16>(a, batch, s);
+    if (k == 5 && stride == 1) return oth == 8 ? dispatch_ks<5, 1, 8, 16>(a, batch, s) : dispatch_ks<5, 1, 16, 16>(a, batch, s);
+    if (k == 5 && stride == 2) return oth == 4 ? dispatch_ks<5, 2, 4, 16>(a, batch, s) : dispatch_ks<5, 2, 8, 16>(a, batch, s);
     return HS_ERR_UNSUPPORTED;
 }
 

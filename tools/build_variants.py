@@ -177,6 +177,17 @@ PATCHES = {
     # the stage's 72 v_fma_f32 per row block removed -- results are wrong
     'irc_dw_half': [('                    for (int v = 0; v < 8; ++v) o[v] = fmaf(k[ky * 3 + kx], rowv[v + kx], o[v]);',
                      '                    for (int v = 0; v < 8; v += 2) o[v] = fmaf(k[ky * 3 + kx], rowv[v + kx], o[v]);')],
+    # round 6: TIMING-ONLY phase removal in the lean fused expand + depthwise kernel (hs_mbconv_lean.hip): results are wrong
+    'mbl_noswish': [('                        const float sv = swishf(fmaf(acc[r], sc0[r], sh0[r]));', '                        const float sv = fmaf(acc[r], sc0[r], sh0[r]);'),
+                    ('            for (int v = 0; v < G::NOUT; ++v) o[v] = swishf(fmaf(o[v], sc1, sh1));', '            for (int v = 0; v < G::NOUT; ++v) o[v] = fmaf(o[v], sc1, sh1);')],
+    'mbl_nostore': [('                *reinterpret_cast<f32x4*>(dst + 4 * qd) = f32x4{o[4 * qd], o[4 * qd + 1], o[4 * qd + 2], o[4 * qd + 3]};',
+                     '                if (o[4 * qd] == 12345.0f) *reinterpret_cast<f32x4*>(dst + 4 * qd) = f32x4{o[4 * qd], o[4 * qd + 1], o[4 * qd + 2], o[4 * qd + 3]};')],
+    'mbl_noload': [('        for (int ks = 0; ks < KS; ++ks) bf[jt][ks] = mbl_ld(xb + (size_t)(4 * ks) * plane, off);',
+                    '        for (int ks = 0; ks < KS; ++ks) bf[jt][ks] = __uint_as_float(off + ks) * 1e-9f;')],
+    'mbl_nomfma': [('                for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks], bf[jt][ks], acc, 0, 0, 0);',
+                    '                for (int ks = 0; ks < KS; ++ks) acc[ks & 3] += af[ks] * bf[jt][ks];')],
+    'mbl_nodw': [('                    for (int v = 0; v < G::NOUT; ++v) o[v] = fmaf(kd[ky * K + kx], rowv[v * S + kx], o[v]);',
+                  '                    for (int v = 0; v < G::NOUT; ++v) if (kx == 0) o[v] = fmaf(kd[ky * K + kx], rowv[v * S + kx], o[v]);')],
     'ntstore': [(STORE_LINE, '                for (int jt = 0; jt < J3; ++jt) __builtin_nontemporal_store(fmaf(acc3[m][jt][r], sc, sh), &yo[yoff[jt]]);')],
 }
 
@@ -233,6 +244,11 @@ VARIANTS = {
     'irc_prio2': dict(flags=['-DHS_IRC_PRIO=2'], extra=[], patch=None),
     'irc_prio3': dict(flags=['-DHS_IRC_PRIO=3'], extra=[], patch=None),
     'irc_dw_half': dict(flags=[], extra=[], patch='irc_dw_half', file='hs_patch_irc.hip'),
+    'mbl_noswish': dict(flags=[], extra=[], patch='mbl_noswish', file='hs_mbconv_lean.hip'),
+    'mbl_nostore': dict(flags=[], extra=[], patch='mbl_nostore', file='hs_mbconv_lean.hip'),
+    'mbl_noload': dict(flags=[], extra=[], patch='mbl_noload', file='hs_mbconv_lean.hip'),
+    'mbl_nomfma': dict(flags=[], extra=[], patch='mbl_nomfma', file='hs_mbconv_lean.hip'),
+    'mbl_nodw': dict(flags=[], extra=[], patch='mbl_nodw', file='hs_mbconv_lean.hip'),
     'irc_nobarrier': dict(flags=[], extra=[], patch='irc_nobarrier', file='hs_patch_irc.hip'),
     'px_nostore': dict(flags=[], extra=[], patch='px_nostore', file='hs_patch_ir_px.hip'),
     'px_prio_young': dict(flags=[], extra=[], patch='px_prio_young', file='hs_patch_ir_px.hip'),
