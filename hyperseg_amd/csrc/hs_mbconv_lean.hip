@@ -224,6 +224,9 @@ void mbconv_lean_kernel(MblArgs a) {
                 }
             }
             if (a.pool && u == 0) a.pool[((size_t)b * Cmid + h) * ntiles + ty * a.tiles_x + tx] = psum;
+            // (Tried: the wave's 4 channels x OTH rows through an LDS staging area so that 4 adjacent lanes write one 64-byte row segment
+            // per store instruction instead of 16 bytes of 64 different segments -- 163.3 vs 162.0 us over the 7 launches, frame 0.7568 /
+            // 0.7571 vs 0.7559 / 0.7573 ms: neutral, profiles/round6_mbconv_lean_output_staging_neutral_w7.txt.  The stores' cost is bytes.)
         }
         if (more) HS_MBL_BARRIER();                 // h1 is rewritten by the next chunk's pw
     }
@@ -256,6 +259,7 @@ int try_launch_mbconv_lean(const float* x, int batch, int c_in, int H, int W, co
     a.Cmid = c_mid; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.pad_t = pad_t; a.pad_l = pad_l;
     a.tiles_y = tiles_y; a.tiles_x = tiles_x; a.chunks_per_wg = chunks_per_wg; a.ngroups = ngroups;
     const int ks = c_in >> 2;
+    if (k == 5 && stride == 2 && oth == 8 && ks > 6) return 1;      // that instantiation does not fit the register file (spills)
 #define HS_MBL_KS(K_, S_, OTH_) \
     if (k == K_ && stride == S_ && oth == OTH_) { \
         if (ks == 4) return launch_mbl<K_, S_, OTH_, 16, 4>(a, batch, stream); \
