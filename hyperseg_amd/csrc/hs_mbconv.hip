@@ -255,6 +255,11 @@ int try_launch_mbconv_lean(const float* x, int batch, int c_in, int H, int W, co
                            const float* scale1, const float* shift1, float* y, float* pool, int oth, int tiles_y, int tiles_x,
                            int chunks_per_wg, int ngroups, hipStream_t stream);                 // hs_mbconv_lean.hip
 
+int try_launch_stem_dw_lean(const float* x, int batch, int sH, int sW, const float* w28, int c_mid, const float* scale0, const float* shift0,
+                            int spad_t, int spad_l, int Hs, int Ws, const float* w_dw, int k, int pad_t, int pad_l, const float* scale1,
+                            const float* shift1, float* y, float* pool, int oth, int tiles_y, int tiles_x, int chunks_per_wg, int ngroups,
+                            hipStream_t stream);                                               // hs_mbconv_lean.hip
+
 }  // namespace hs
 
 using namespace hs;
@@ -346,4 +351,23 @@ extern "C" int hs_mbconv_expand_dw_se_fwd(const float* x, int32_t batch, int32_t
     if (!se) return HS_ERR_BAD_ARG;
     return mbconv_launch(x, batch, c_in, H, W, w_expand, c_mid, scale0, shift0, w_dw, k, stride, pad_t, pad_l, Ho, Wo, scale1, shift1, y,
                          nullptr, se, stream);
+}
+
+// The encoder's stem and the first block's depthwise half in ONE launch (hs_mbconv_lean.hip, STEM form):
+//   y = swish(BN1(depthwise_3x3(zero-pad(swish(BN0(conv3x3/s2(zero-pad(x))))))))   (+ per-tile sums of y for the SE pool)
+// x (B,3,H,W); w_stem28 (c_mid, 28) = the stem weight flattened to (c_mid, 27) with one zero column; (Hs, Ws) the stem's output size
+// = y's; pool_partial (optional) (B*c_mid, hs_mbconv_tiles(3, 1, Hs, Ws)).  HS_ERR_UNSUPPORTED for shapes the launch does not cover
+// (the caller then runs hs_stem_conv_fwd + hs_depthwise_conv_fwd).  Replaces efficientnet.py:321-322 + 59-66 / 101-103 of block 0.
+extern "C" int hs_stem_dw_fwd(const float* x, int32_t batch, int32_t H, int32_t W, const float* w_stem28, int32_t c_mid,
+                              const float* scale0, const float* shift0, int32_t stem_pad_t, int32_t stem_pad_l, int32_t Hs, int32_t Ws,
+                              const float* w_dw, int32_t k, int32_t pad_t, int32_t pad_l, const float* scale1, const float* shift1,
+                              float* y, float* pool_partial, void* stream) {
+    if (!x || !w_stem28 || !scale0 || !shift0 || !w_dw || !scale1 || !shift1 || !y) return HS_ERR_BAD_ARG;
+    if (batch <= 0 || c_mid <= 0 || H <= 0 || W <= 0 || Hs <= 0 || Ws <= 0 || pad_t < 0 || pad_l < 0) return HS_ERR_BAD_ARG;
+    int tiles_y, tiles_x, cpw, ngroups;
+    mbx_grid(batch, c_mid, 1, Hs, Ws, tiles_y, tiles_x, cpw, ngroups);
+    const int st = try_launch_stem_dw_lean(x, batch, H, W, w_stem28, c_mid, scale0, shift0, stem_pad_t, stem_pad_l, Hs, Ws, w_dw, k, pad_t,
+                                           pad_l, scale1, shift1, y, pool_partial, mbx_oth(1), tiles_y, tiles_x, cpw, ngroups,
+                                           (hipStream_t)stream);
+    return st == 1 ? HS_ERR_UNSUPPORTED : st;
 }

@@ -11,6 +11,10 @@
 //   * the block decode is scalar, with host-made magic numbers for the two divisions.
 #include "hs_common.h"
 
+#ifndef HS_MBL_STAGE
+#define HS_MBL_STAGE 1      // output stores through a per-wave LDS staging area (dev A/B knob: tools/build_variants.py mbl_nostage)
+#endif
+
 namespace hs {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -21,6 +25,7 @@ struct MblArgs {
     float* __restrict__ y; float* __restrict__ pool;
     int Cmid, H, W, Ho, Wo, pad_t, pad_l, tiles_y, tiles_x, chunks_per_wg, ngroups;
     unsigned m_ngroups, m_tiles_x, m_tiles_y;      // 2^32 / d + 1 (0: d == 1)
+    int sH, sW, spad_t, spad_l;                    // STEM form: the raw image x (B, 3, sH, sW) and the stem conv's (top, left) padding
 };
 
 template <int K, int S, int OTH, int OTW> struct MblGeom {
@@ -39,7 +44,7 @@ template <int K, int S, int OTH, int OTW> struct MblGeom {
     static constexpr int SROW = OTW + 4;
     static constexpr int STG_WAVE = 4 * OTH * SROW;                           // floats per wave
     static constexpr int H1_FLOATS = 16 * H1P;
-    static constexpr int LDS_FLOATS = H1_FLOATS + 4 * STG_WAVE;
+    static constexpr int LDS_FLOATS = H1_FLOATS + (HS_MBL_STAGE ? 4 * STG_WAVE : 0);
     static_assert(16 % OTH == 0 && OTW % NSEG == 0 && (NOUT * S) % 4 == 0 && NOUT % 4 == 0 && OTW == 16, "tile shape");
 };
 
@@ -53,11 +58,17 @@ __device__ __forceinline__ f32x4 mbl_ld4(const float* __restrict__ base, unsigne
     return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + (size_t)byte_off);
 }
 
-template <int K, int S, int OTH, int OTW, int KS>
+// STEM (round 6): the "expand" is EfficientNet's stem -- Conv2d(3, Cmid, 3, stride 2, TF-"SAME" zero padding of the IMAGE) + BN + swish
+// (efficientnet.py:321-322) -- feeding the first block's depthwise conv (that block has no expand conv): the same GEMM with
+// K = 27 (+ 1 zero column: w_e is the stem weight flattened to (Cmid, 27) and padded to 28), its B operand gathered from the image
+// through the 3 x 3 / stride-2 window, k = 9 c + 3 ky + kx.  The stem's output map (16.8 MB at 1024 x 512: written by one launch, read
+// back by the next) never exists; a.H / a.W are ITS size (what the depthwise conv pads and tiles), a.sH / a.sW the image's.
+template <int K, int S, int OTH, int OTW, int KS, bool STEM = false>
 __global__ __launch_bounds__(256, 2)
 void mbconv_lean_kernel(MblArgs a) {
     using G = MblGeom<K, S, OTH, OTW>;
     constexpr int Cin = 4 * KS;
+    static_assert(!STEM || KS == 7, "the stem's K = 27 -> 28");
     extern __shared__ __attribute__((aligned(16))) float h1[];                 // [16][H1P]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -71,13 +82,12 @@ void mbconv_lean_kernel(MblArgs a) {
     const int oy0 = ty * OTH, ox0 = tx * OTW;
     const int iy0 = oy0 * S - a.pad_t, ix0 = ox0 * S - a.pad_l;
     const int Cmid = a.Cmid, H = a.H, W = a.W;
-    const unsigned plane = (unsigned)H * (unsigned)W;
-    const float* __restrict__ xb = a.x + (size_t)b * Cin * plane;
+    const unsigned plane = STEM ? (unsigned)a.sH * (unsigned)a.sW : (unsigned)H * (unsigned)W;
+    const float* __restrict__ xb = a.x + (size_t)b * (STEM ? 3 : Cin) * plane;
 
     // dw role of this thread: hidden channel hh of the chunk, output row / row segment
     const int hh = tid >> 4, u = tid & 15;
     const int drow = u % OTH, dseg = u / OTH;
-    const int oy = oy0 + drow, ox = ox0 + dseg * G::NOUT;
     const int ntiles = a.tiles_y * a.tiles_x;
     const int nchunks = Cmid >> 4;
     const int c_begin = grp * a.chunks_per_wg;
@@ -119,17 +129,61 @@ void mbconv_lean_kernel(MblArgs a) {
     // ---- the input halo tile -> B fragments (registers): bf[jt][ks] = x[4 ks + lk][position (wave + 4 jt) 16 + lrow] ----------
     float bf[G::J][KS];
     int h1off[G::J];                   // LDS offset of this lane's position (-1: none); bit 30: inside the image
+    // STEM: this lane's K index of k-step ks is k = 4 ks + lk = 9 c + 3 ky + kx (k = 27: the zero column, any valid tap)
+    int koff[STEM ? KS : 1], kyx[STEM ? KS : 1];
+    unsigned smask[STEM ? G::J : 1];
+    bool stem_inside = true;
+    if constexpr (STEM) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k = min(4 * ks + lk, 26), c = k / 9, r = k - 9 * c, ky = r / 3, kx = r - 3 * ky;
+            koff[ks] = c * (int)plane + ky * a.sW + kx; kyx[ks] = 4 * ky + kx;
+        }
+#pragma unroll
+        for (int jt = 0; jt < G::J; ++jt) smask[jt] = 0u;
+        // rows / columns of the stem's map this tile's halo touches (clamped as the loader clamps them) and their windows
+        const int y_lo = min(max(iy0, 0), H - 1), y_hi = min(max(iy0 + G::IH - 1, 0), H - 1);
+        const int x_lo = min(max(ix0, 0), W - 1), x_hi = min(max(ix0 + G::IW - 1, 0), W - 1);
+        stem_inside = 2 * y_lo - a.spad_t >= 0 && 2 * y_hi - a.spad_t + 2 < a.sH && 2 * x_lo - a.spad_l >= 0 && 2 * x_hi - a.spad_l + 2 < a.sW;
+    }
 #pragma unroll
     for (int jt = 0; jt < G::J; ++jt) {
         const int pos = (wave + 4 * jt) * 16 + lrow;
         const bool ok = pos < G::NPOS;
-        const int pu = pos / G::IW, pv = pos - pu * G::IW;
+        const int pu = (STEM && !ok ? 0 : pos) / G::IW, pv = (STEM && !ok ? 0 : pos) - pu * G::IW;      // STEM: a dead lane gathers position 0's window
         const int yy = iy0 + pu, xx = ix0 + pv;
         const bool in = ok && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-        const unsigned off = ((in ? (unsigned)(yy * W + xx) : 0u) + (unsigned)lk * plane) << 2;
+        if constexpr (!STEM) {
+            const unsigned off = ((in ? (unsigned)(yy * W + xx) : 0u) + (unsigned)lk * plane) << 2;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) bf[jt][ks] = mbl_ld(xb + (size_t)(4 * ks) * plane, off);
+            for (int ks = 0; ks < KS; ++ks) bf[jt][ks] = mbl_ld(xb + (size_t)(4 * ks) * plane, off);
+        } else {
+            // window origin of this stem-output position in the image (positions outside the stem's map: any valid one)
+            const int by = 2 * min(max(yy, 0), H - 1) - a.spad_t, bx = 2 * min(max(xx, 0), W - 1) - a.spad_l;
+            if (stem_inside) {                                                 // uniform: no tap of this tile leaves the image
+                const int base = by * a.sW + bx;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) bf[jt][ks] = mbl_ld(xb, (unsigned)(base + koff[ks]) << 2);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int iy = by + kyx[ks] / 4, ix = bx + (kyx[ks] & 3);
+                    const int e = koff[ks] - (kyx[ks] / 4) * a.sW - (kyx[ks] & 3)            // c * plane
+                                  + min(max(iy, 0), a.sH - 1) * a.sW + min(max(ix, 0), a.sW - 1);
+                    bf[jt][ks] = mbl_ld(xb, (unsigned)e << 2);
+                    smask[jt] |= ((unsigned)iy < (unsigned)a.sH && (unsigned)ix < (unsigned)a.sW ? 1u : 0u) << ks;
+                }
+            }
+        }
         h1off[jt] = ok ? ((pu * G::RS + pv) | (in ? (1 << 30) : 0)) : -1;
+    }
+    if constexpr (STEM) {
+        if (!stem_inside) {                                                    // zero padding of the image: after every load is out
+#pragma unroll
+            for (int jt = 0; jt < G::J; ++jt)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) bf[jt][ks] = (smask[jt] >> ks) & 1u ? bf[jt][ks] : 0.0f;
+        }
     }
 
     // every prologue load has landed before the loop is entered: the loop body then holds no wait that its first pass needs and the
@@ -197,12 +251,11 @@ void mbconv_lean_kernel(MblArgs a) {
             __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) as an instruction the compiler's own wait insertion sees (an asm string it does not)
             if (more) take_dw();
             __builtin_amdgcn_sched_barrier(0);
-            // A lane owns NOUT consecutive pixels of ONE row: stored from here, a wave's store instruction would touch 64 different
-            // 64-byte row segments with 16 bytes each -- four 16-byte requests per segment where one 64-byte request does, and the
-            // launch's stores are bound by requests, not bytes (visit r6w4: 5.6 of 19.4 us; 18.9 MB / 16 B at the L2s' ~128 requests
-            // per clock = 4.4 us).  So the wave's 4 channels x OTH rows go through its own LDS staging area (no barrier: nobody else
-            // touches it) and leave as (channel, row, quarter) = 4 adjacent lanes per 64-byte segment.
-            {
+            // A lane owns NOUT consecutive pixels of ONE row: stored from here, a wave's store instruction touches 64 different 64-byte
+            // row segments with 16 bytes each.  HS_MBL_STAGE = 1 sends the wave's 4 channels x OTH rows through its own LDS staging area
+            // (no barrier: nobody else touches it) so that they leave as (channel, row, quarter) = 4 adjacent lanes per 64-byte segment:
+            // 168.7 -> 162.0 us over HyperSeg-M's 7 launches, frame 0.757 -> 0.749 ms (profiles/round6_stem_dw_and_output_staging_ab_w9.txt).
+            if constexpr (HS_MBL_STAGE) {
                 float* stg = h1 + G::H1_FLOATS + wave * G::STG_WAVE;
                 float* sw = stg + ((hh & 3) * OTH + drow) * G::SROW + dseg * G::NOUT;
 #pragma unroll
@@ -222,25 +275,27 @@ void mbconv_lean_kernel(MblArgs a) {
                     float* __restrict__ d4 = a.y + (((size_t)b * Cmid + (h0 + 4 * wave + sc)) * a.Ho + (oy0 + sr)) * a.Wo + ox0 + 4 * sq;
                     *reinterpret_cast<f32x4*>(d4) = ov[i];
                 }
+            } else {
+                float* __restrict__ dst = a.y + (((size_t)b * Cmid + h) * a.Ho + oy0 + drow) * a.Wo + ox0 + dseg * G::NOUT;
+#pragma unroll
+                for (int qd = 0; qd < G::NOUT / 4; ++qd)
+                    *reinterpret_cast<f32x4*>(dst + 4 * qd) = f32x4{o[4 * qd], o[4 * qd + 1], o[4 * qd + 2], o[4 * qd + 3]};
             }
             if (a.pool && u == 0) a.pool[((size_t)b * Cmid + h) * ntiles + ty * a.tiles_x + tx] = psum;
-            // (Tried: the wave's 4 channels x OTH rows through an LDS staging area so that 4 adjacent lanes write one 64-byte row segment
-            // per store instruction instead of 16 bytes of 64 different segments -- 163.3 vs 162.0 us over the 7 launches, frame 0.7568 /
-            // 0.7571 vs 0.7559 / 0.7573 ms: neutral, profiles/round6_mbconv_lean_output_staging_neutral_w7.txt.  The stores' cost is bytes.)
         }
         if (more) HS_MBL_BARRIER();                 // h1 is rewritten by the next chunk's pw
     }
 #undef HS_MBL_BARRIER
 }
 
-template <int K, int S, int OTH, int OTW, int KS>
+template <int K, int S, int OTH, int OTW, int KS, bool STEM = false>
 static int launch_mbl(MblArgs& a, int batch, hipStream_t stream) {
     using G = MblGeom<K, S, OTH, OTW>;
     const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float);
     const size_t blocks = (size_t)batch * a.tiles_y * a.tiles_x * a.ngroups;
     if (blocks > 0x7fffffffu) return 1;
     a.m_ngroups = mbl_magic((unsigned)a.ngroups); a.m_tiles_x = mbl_magic((unsigned)a.tiles_x); a.m_tiles_y = mbl_magic((unsigned)a.tiles_y);
-    hipLaunchKernelGGL((mbconv_lean_kernel<K, S, OTH, OTW, KS>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((mbconv_lean_kernel<K, S, OTH, OTW, KS, STEM>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
     return launch_status();
 }
 
@@ -258,6 +313,7 @@ int try_launch_mbconv_lean(const float* x, int batch, int c_in, int H, int W, co
     a.x = x; a.w_e = w_expand; a.s0 = scale0; a.b0 = shift0; a.w_dw = w_dw; a.s1 = scale1; a.b1 = shift1; a.y = y; a.pool = pool;
     a.Cmid = c_mid; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.pad_t = pad_t; a.pad_l = pad_l;
     a.tiles_y = tiles_y; a.tiles_x = tiles_x; a.chunks_per_wg = chunks_per_wg; a.ngroups = ngroups;
+    a.sH = a.sW = a.spad_t = a.spad_l = 0;
     const int ks = c_in >> 2;
     if (k == 5 && stride == 2 && oth == 8 && ks > 6) return 1;      // that instantiation does not fit the register file (spills)
 #define HS_MBL_KS(K_, S_, OTH_) \
@@ -270,6 +326,26 @@ int try_launch_mbconv_lean(const float* x, int batch, int c_in, int H, int W, co
     HS_MBL_KS(3, 1, 16) HS_MBL_KS(3, 1, 8) HS_MBL_KS(5, 1, 16) HS_MBL_KS(5, 1, 8)
     HS_MBL_KS(3, 2, 8) HS_MBL_KS(3, 2, 4) HS_MBL_KS(5, 2, 8) HS_MBL_KS(5, 2, 4)
 #undef HS_MBL_KS
+    return 1;
+}
+
+// The stem form: x = the image (B, 3, sH, sW), w28 = the stem weight (c_mid, 27) padded to 28 columns, (Hs, Ws) = the stem's output map
+// = the depthwise conv's input and (stride 1, "SAME") output size.  Returns 1 when the shape is not covered.
+int try_launch_stem_dw_lean(const float* x, int batch, int sH, int sW, const float* w28, int c_mid, const float* scale0, const float* shift0,
+                            int spad_t, int spad_l, int Hs, int Ws, const float* w_dw, int k, int pad_t, int pad_l, const float* scale1,
+                            const float* shift1, float* y, float* pool, int oth, int tiles_y, int tiles_x, int chunks_per_wg, int ngroups,
+                            hipStream_t stream) {
+    if (k != 3 || (c_mid & 15) != 0 || Hs % oth != 0 || Ws % 16 != 0 || spad_t < 0 || spad_l < 0) return 1;
+    if ((size_t)3 * sH * sW >= (1u << 29)) return 1;                          // 32-bit byte offsets, with room for the clamped windows
+    if (2 * (Hs - 1) - spad_t >= sH || 2 * (Ws - 1) - spad_l >= sW) return 1;  // every output's window starts inside the image
+    if ((((size_t)y | (size_t)scale0 | (size_t)shift0) & 15) != 0) return 1;
+    MblArgs a;
+    a.x = x; a.w_e = w28; a.s0 = scale0; a.b0 = shift0; a.w_dw = w_dw; a.s1 = scale1; a.b1 = shift1; a.y = y; a.pool = pool;
+    a.Cmid = c_mid; a.H = Hs; a.W = Ws; a.Ho = Hs; a.Wo = Ws; a.pad_t = pad_t; a.pad_l = pad_l;
+    a.tiles_y = tiles_y; a.tiles_x = tiles_x; a.chunks_per_wg = chunks_per_wg; a.ngroups = ngroups;
+    a.sH = sH; a.sW = sW; a.spad_t = spad_t; a.spad_l = spad_l;
+    if (oth == 16) return launch_mbl<3, 1, 16, 16, 7, true>(a, batch, stream);
+    if (oth == 8) return launch_mbl<3, 1, 8, 16, 7, true>(a, batch, stream);
     return 1;
 }
 

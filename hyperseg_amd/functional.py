@@ -989,6 +989,27 @@ def stem_conv_bn_swish(x, weight, pad_top, pad_left, out_size, scale, shift):
 
 
 @_on_operand_device
+def stem_dw(x, w_stem28, scale0, shift0, stem_pad_top, stem_pad_left, stem_out_size, w_dw, pad_top, pad_left, scale1, shift1, pool=True):
+    """The encoder's stem (3x3 stride-2 conv of the image + BN + swish) and the first block's depthwise 3x3 + BN + swish (+ SE
+    pooling partial sums) in ONE launch: the stem's output map never reaches HBM (hs_stem_dw_fwd).  ``w_stem28``: the stem weight
+    flattened to (Cmid, 27) plus one zero column.  Returns ``(y, partial)`` / ``y``, or ``None`` when the launch does not cover the
+    shape (the caller then runs the two launches).  Encoder-side helper, opt-in."""
+    b, _, h, w = x.shape
+    cmid, k = w_dw.shape[0], w_dw.shape[-1]
+    hs_, ws_ = stem_out_size
+    y = torch.empty(b, cmid, hs_, ws_, device=x.device, dtype=torch.float32)
+    partial = torch.empty(b * cmid, _hip.lib.hs_mbconv_tiles(k, 1, hs_, ws_), device=x.device, dtype=torch.float32) if pool else None
+    st = _hip.lib.hs_stem_dw_fwd(_hip.dev_ptr(x, 'x'), b, h, w, _hip.dev_ptr(w_stem28, 'w_stem28'), cmid, _hip.dev_ptr(scale0, 'scale0'),
+                                 _hip.dev_ptr(shift0, 'shift0'), stem_pad_top, stem_pad_left, hs_, ws_, _hip.dev_ptr(w_dw, 'w_dw'), k,
+                                 pad_top, pad_left, _hip.dev_ptr(scale1, 'scale1'), _hip.dev_ptr(shift1, 'shift1'), y.data_ptr(),
+                                 partial.data_ptr() if pool else None, _hip.stream_ptr())
+    if st == -3:                       # HS_ERR_UNSUPPORTED: nothing was launched
+        return None
+    _hip.check(st, 'hs_stem_dw_fwd')
+    return (y, partial) if pool else y
+
+
+@_on_operand_device
 def mbconv_expand_dw(x, w_expand, scale0, shift0, w_dw, stride, pad_top, pad_left, out_size, scale1, shift1, pool=True, se=None):
     """1x1 expand + BN + swish + depthwise k x k (TF-"SAME" zero padding of the ACTIVATION) + BN + swish in one launch
     (+ SE pooling partial sums): the expanded tensor never reaches HBM.  x (B,Cin,H,W), w_expand (Cmid,Cin[,1,1]),

@@ -213,7 +213,10 @@ class EfficientNet(nn.Module):
                 blk._fused_active = None
 
     def _extract_features_list(self, inputs, use):
-        if self._fused_stem is not None and use:
+        f0 = self._blocks[0]._fused_dw if len(self._blocks) else None
+        if self._fused_stem is not None and use and f0 is not None and getattr(f0, '_stem', None) is not None:
+            x = inputs                          # block 0's fused route runs the stem itself (one launch with its depthwise half)
+        elif self._fused_stem is not None and use:
             x = self._fused_stem(inputs)
         else:
             x = F.silu(self._bn0(self._conv_stem(inputs)))

@@ -66,6 +66,7 @@ def _bn_affine(bn):
 
 
 # output pixels from which the fused expand + depthwise kernel is used (tools/bench_mbconv.py measures both routes)
+STEM_DW = os.environ.get('HS_STEM_DW', '1') != '0'       # stem + block 0's depthwise half as one launch (hs_stem_dw_fwd); 0: two launches
 FUSE_EXPAND_MIN_PIXELS = int(os.environ.get('HS_FUSE_EXPAND_MIN_PIXELS', '2048'))
 FUSE_EXPAND_MAX_CIN = int(os.environ.get('HS_FUSE_EXPAND_MAX_CIN', '40'))      # wider inputs: 1 wave / SIMD, slower than GEMM + dw
 
@@ -200,13 +201,18 @@ class FusedStem(nn.Module):
         else:
             self.pad_t, self.pad_l = conv.padding
             self.pad_h, self.pad_w = 2 * conv.padding[0], 2 * conv.padding[1]
+        # the weight as the GEMM operand of hs_stem_dw_fwd: (Cout, 27) + one zero column (rebuilt with the module by _install_fused)
+        with torch.no_grad():
+            self.register_buffer('w28', nn.functional.pad(conv.weight.detach().flatten(1), (0, 1)).contiguous(), persistent=False)
+
+    def out_size(self, x):
+        h, w = x.shape[2:]
+        return (h + self.pad_h - 3) // 2 + 1, (w + self.pad_w - 3) // 2 + 1
 
     def forward(self, x):
         from .. import functional as HF
         x = x.contiguous()
-        h, w = x.shape[2:]
-        ho, wo = (h + self.pad_h - 3) // 2 + 1, (w + self.pad_w - 3) // 2 + 1
-        return HF.stem_conv_bn_swish(x, self._conv[0].weight, self.pad_t, self.pad_l, (ho, wo), self.scale, self.shift)
+        return HF.stem_conv_bn_swish(x, self._conv[0].weight, self.pad_t, self.pad_l, self.out_size(x), self.scale, self.shift)
 
 
 class FusedMBConv(nn.Module):
@@ -246,6 +252,9 @@ class FusedMBConv(nn.Module):
         # the gate by the pooling launch's last workgroups (round 5) -- only where the project convolution takes the gate as a vector
         # (our split GEMM / MFMA kernels); the library-GEMM route folds it into the weights and keeps hs_se_gate_fwd
         self.se_tail = True
+        # block 0 only (round 6): the encoder's FusedStem, when stem + this block's depthwise half run as ONE launch (hs_stem_dw_fwd);
+        # the block is then handed the IMAGE.  A list: the stem module stays registered once, under the backbone
+        self._stem = None
         # constant-offset bookkeeping (see the class docstring)
         if in_offset is not None:
             assert self.expand is not None, 'a depthwise conv cannot consume an offset tensor (zero padding)'
@@ -266,6 +275,13 @@ class FusedMBConv(nn.Module):
 
     def forward(self, inputs, blk):
         from .. import functional as HF
+        pre = None
+        if self._stem is not None and inputs.shape[1] == 3:      # inputs is the image: stem + depthwise half in one launch, or the stem's own launch first
+            stem = self._stem[0]
+            img = inputs.contiguous()
+            pre = HF.stem_dw(img, stem.w28, stem.scale, stem.shift, stem.pad_t, stem.pad_l, stem.out_size(img),
+                             blk._depthwise_conv.weight, self.pad_t, self.pad_l, self.scale, self.shift, pool=True) if STEM_DW else None
+            inputs = pre[0] if pre is not None else stem(img)         # (pre: only the shape is read below -- skip is off for this block)
         x = inputs.contiguous()
         b, _, h, w = x.shape
         ho = (h + self.pad_h - self.k) // self.stride + 1
@@ -283,7 +299,9 @@ class FusedMBConv(nn.Module):
         lean_gemm = lean and (cmid > LEAN_MFMA_MAX_CIN if self.defer_shift else not proj.mfma_covers(cmid, ho * wo))
         folds = lean_gemm and not (proj.split_gemm and proj.split_weights(True, x.device) is not None)      # gate folded into the weights
         se = (self._red_w, red.bias, self._exp_t, exp.bias) if self.se_tail and not folds else None
-        if self.fuses_expand(x, ho, wo):
+        if pre is not None:
+            out = (pre[0], pre[1], False) if se is not None else pre
+        elif self.fuses_expand(x, ho, wo):
             out = HF.mbconv_expand_dw(x, self.expand.conv.weight, self.expand.scale, self.expand.shift,
                                       blk._depthwise_conv.weight, self.stride, self.pad_t, self.pad_l, (ho, wo),
                                       self.scale, self.shift, pool=True, se=se)
@@ -497,6 +515,9 @@ def _fuse_backbone(bb):
     stem = bb._conv_stem
     if stem.kernel_size == (3, 3) and stem.stride == (2, 2) and stem.in_channels == 3 and isinstance(bb._bn0, nn.BatchNorm2d):
         bb._fused_stem = FusedStem(stem, bb._bn0)
+        f0 = blocks[0]._fused_dw if blocks else None
+        if f0 is not None and f0.expand is None and f0.k == 3 and f0.stride == 1 and not f0.skip:
+            f0._stem = [bb._fused_stem]           # EfficientNet._extract_features_list then hands block 0 the image
     bb._fused_head = FusedPointwise(bb._conv_head, bb._bn1, act=3)
     if offset is not None:
         bb._fused_head.absorb_input_offset(offset)

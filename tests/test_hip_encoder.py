@@ -130,6 +130,34 @@ def test_mbconv_expand_dw(HF, dev, cin, cmid, k, stride, h, w):
     assert rel_err(pooled, ref.mean((2, 3))) < REL_TOL
 
 
+@pytest.mark.parametrize('cmid,h,w,covered', [(32, 64, 96, True), (32, 32, 64, True), (16, 96, 32, True), (32, 66, 96, False), (24, 64, 64, False)])
+def test_stem_dw(HF, dev, cmid, h, w, covered):
+    """hs_stem_dw_fwd == swish(BN1(depthwise3x3(zero-pad(swish(BN0(conv3x3/s2(zero-pad(image)))))))) + SE pooling partial sums: the stem's
+    TF-"SAME" padding (bottom / right only on even images), border tiles (windows that leave the image), whole-tile shapes only --
+    everything else returns None (the caller then runs the two launches)."""
+    g = torch.Generator().manual_seed(cmid + h + w)
+    b = 2
+    x = torch.rand(b, 3, h, w, generator=g)
+    ws = torch.randn(cmid, 3, 3, 3, generator=g) * 0.3
+    wd = torch.randn(cmid, 1, 3, 3, generator=g) * 0.3
+    s0, b0 = torch.rand(cmid, generator=g) + 0.5, torch.randn(cmid, generator=g) * 0.3
+    s1, b1 = torch.rand(cmid, generator=g) + 0.5, torch.randn(cmid, generator=g) * 0.1
+    hs, wsz = -(-h // 2), -(-w // 2)
+    ph, pw = max((hs - 1) * 2 + 3 - h, 0), max((wsz - 1) * 2 + 3 - w, 0)
+    mid = swish(F.conv2d(F.pad(x, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2)), ws, stride=2) * s0.view(1, -1, 1, 1) + b0.view(1, -1, 1, 1))
+    ref = swish(F.conv2d(F.pad(mid, (1, 1, 1, 1)), wd, groups=cmid) * s1.view(1, -1, 1, 1) + b1.view(1, -1, 1, 1))
+    w28 = F.pad(ws.flatten(1), (0, 1)).contiguous()
+    out = HF.stem_dw(x.to(dev), w28.to(dev), s0.to(dev), b0.to(dev), ph // 2, pw // 2, (hs, wsz), wd.to(dev), 1, 1, s1.to(dev), b1.to(dev),
+                     pool=True)
+    if not covered:
+        assert out is None
+        return
+    y, partial = out
+    assert rel_err(y.cpu(), ref) < REL_TOL
+    pooled = partial.cpu().sum(1).view(b, cmid) / (hs * wsz)
+    assert rel_err(pooled, ref.mean((2, 3))) < REL_TOL
+
+
 @pytest.mark.parametrize('c,csq,nblk,cout', [(32, 8, 128, 16), (96, 4, 32, 24), (240, 10, 8, 40), (672, 28, 2, 112),
                                              (1152, 48, 1, 320), (1920, 80, 1, 320), (50, 3, 5, 7),
                                              # the early blocks' shapes (64-256 partials per channel): the wide one-launch form of round 5
