@@ -307,6 +307,90 @@ void se_excite_kernel(const float* __restrict__ z, const float* __restrict__ w2t
     se_excite_body(blockIdx.x, blockIdx.z, blockIdx.y, z, w2t, b2, C, Csq, gate, w_proj, Cout, out_scale, w_scaled, red);
 }
 
+// The EARLY blocks' gate in one launch (round 6): few channels (<= 144), a handful of squeezed channels (<= 8) -- but 64-256 pool
+// partials per channel, which is why they took the squeeze + excite pair (10 us for 25 k additions).  Round 5's wide instantiation of
+// se_gate_fused_kernel lost to that pair because every thread added a channel's 64-256 partials serially; here a channel's partials
+// are ONE 16-byte load per lane of a wave (<= 64 loads x 4 = 256 partials), every load of the workgroup is issued before the first
+// use, a channel's sum is four in-lane additions + the DPP wave sum, and one workgroup does the whole gate: partials -> means ->
+// squeezed -> gate, two barriers.  Sums are in a fixed order (deterministic); the order differs from the pair's, i.e. gates agree to
+// rounding (test_se_gate).  Measured (visit r6w10, same box, interleaved): HyperSeg-M frame 0.7465 -> 0.7444 ms for its four launches,
+// CamVid-S unchanged (0.7877 vs 0.7887): the launch is ~9.5 us against the pair's 10 -- ONE compute unit pulling a block's 96-147 KB of
+// partials (written a moment ago through other XCDs' L2s) is the cost, not the arithmetic; the first form (a DPP wave sum per
+// channel) was slower than the pair (0.7495 ms).  profiles/round6_se_gate_early_ab_w10.txt.
+constexpr int SEE_MAX_IT = 36;                       // channels per wave: C <= 144
+__global__ __launch_bounds__(256)
+void se_gate_early_kernel(const float* __restrict__ partial, int nblk, float inv_hw, const float* __restrict__ w1,
+                          const float* __restrict__ b1, const float* __restrict__ w2t, const float* __restrict__ b2, int C,
+                          int Csq, float* __restrict__ z_out, float* __restrict__ gate) {
+    __shared__ __attribute__((aligned(16))) float part[4 * SEE_MAX_IT * 64];      // [channel][lane]
+    __shared__ __attribute__((aligned(16))) float mean_c[4 * SEE_MAX_IT];
+    __shared__ float zs[8];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y;
+    const int nu = nblk >> 2;                                                   // 16-byte units per channel, <= 64
+    const float4* __restrict__ pb = reinterpret_cast<const float4*>(partial + (size_t)b * C * nblk);
+    const int nit = (C + 3) >> 2;
+    const bool lane_ok = lane < nu;
+    float4 pv[SEE_MAX_IT];
+#pragma unroll
+    for (int i = 0; i < SEE_MAX_IT; ++i) {
+        const int c = min(4 * i + wave, C - 1);
+        pv[i] = i < nit ? pb[(size_t)c * nu + (lane_ok ? lane : 0)] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // squeeze rows of this wave (j = wave, wave + 4) and this thread's gate column: requested with the partials
+    const int c4 = min(4 * lane, C - 4);                                        // C % 4 == 0: lanes past the end re-read the last quad
+    float4 w1v[2];
+    float b1v[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int j = min(wave + 4 * r, Csq - 1);
+        w1v[r] = *reinterpret_cast<const float4*>(w1 + (size_t)j * C + c4);
+        b1v[r] = b1[j];
+    }
+    const int tc = min(tid, C - 1);
+    float w2v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w2v[j] = w2t[(size_t)min(j, Csq - 1) * C + tc];
+    const float b2v = b2[tc];
+    __builtin_amdgcn_sched_barrier(0);
+    // per-channel sums in two steps through LDS: lane sums -> part[channel][lane]; then a thread per (channel, quarter) adds 16 of them
+    // and a quad of lanes combines (a DPP wave sum per channel -- 36 dependent readlane chains per wave -- made this launch slower than
+    // the pair it replaces: visit r6w10)
+#pragma unroll
+    for (int i = 0; i < SEE_MAX_IT; ++i)
+        if (i < nit) part[min(4 * i + wave, C - 1) * 64 + lane] = lane_ok ? (pv[i].x + pv[i].y) + (pv[i].z + pv[i].w) : 0.0f;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int job = tid + 256 * r, c = min(job >> 2, C - 1), q = job & 3;
+        const float4* src = reinterpret_cast<const float4*>(part + c * 64 + 16 * q);
+        const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+        float t = (((v0.x + v0.y) + (v0.z + v0.w)) + ((v1.x + v1.y) + (v1.z + v1.w))) + (((v2.x + v2.y) + (v2.z + v2.w)) + ((v3.x + v3.y) + (v3.z + v3.w)));
+        int x = __float_as_int(t);
+        x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false)));      // quad_perm [1,0,3,2]
+        x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false)));      // quad_perm [2,3,0,1]
+        if (q == 0 && job < 4 * C) mean_c[c] = __int_as_float(x) * inv_hw;
+    }
+    __syncthreads();
+    {
+        const float4 mv = 4 * lane < C ? *reinterpret_cast<const float4*>(mean_c + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int j = wave + 4 * r;
+            const float t = wave_sum64(fmaf(w1v[r].w, mv.w, fmaf(w1v[r].z, mv.z, fmaf(w1v[r].y, mv.y, w1v[r].x * mv.x))));
+            if (lane == 0 && j < Csq) zs[j] = swishf(t + b1v[r]);
+        }
+    }
+    __syncthreads();
+    if (z_out && tid < Csq) z_out[(size_t)b * Csq + tid] = zs[tid];
+    float acc = b2v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (j < Csq) acc = fmaf(w2v[j], zs[j], acc);
+    if (tid < C) gate[(size_t)b * C + tid] = sigmoidf_fast(acc);
+}
+
 // The whole gate in ONE launch, for the blocks whose reduce weights are small enough that every excite workgroup can
 // re-derive the squeezed vector for itself (C <= 768, Csq <= 32: 16 of EfficientNet-B1's 23 blocks).  Same grid as
 // se_excite_kernel.  Rejected variant (ii) above walked the reduce rows one block-wide reduction at a time; here every
@@ -553,6 +637,15 @@ extern "C" int hs_se_gate_fwd(const float* partial, int32_t batch, int32_t chann
                            inv_hw, w_reduce, b_reduce, w_expand, b_expand, channels, c_squeezed, squeezed, gate, w_proj, c_out,
                            out_scale, w_scaled);
         return launch_status();
+    }
+    {   // the early blocks (many partials, few channels) as one single-workgroup launch
+        static const bool off = [] { const char* e = getenv("HS_SE_EARLY"); return e && atoi(e) == 0; }();      // dev A/B knob
+        if (!off && !w_proj && (channels & 3) == 0 && channels <= 4 * SEE_MAX_IT && c_squeezed <= 8 && (nblk & 3) == 0 && nblk <= 256 &&
+            ((size_t)partial & 15) == 0 && ((size_t)w_reduce & 15) == 0) {
+            hipLaunchKernelGGL(se_gate_early_kernel, dim3(1, batch), dim3(256), 0, s, partial, nblk, inv_hw, w_reduce, b_reduce, w_expand,
+                               b_expand, channels, c_squeezed, squeezed, gate);
+            return launch_status();
+        }
     }
     if (HS_SE_FUSED_WIDE && (channels & 3) == 0 && channels <= 256 && c_squeezed <= SEF_MAX_CSQ && units <= 6144) {
         hipLaunchKernelGGL((se_gate_fused_kernel<24, 1>), dim3((channels + 63) / 64, batch, row_groups), dim3(256), 0, s, partial, nblk,
