@@ -22,7 +22,10 @@ namespace hs {
 // ONCE, with the prologue applied once per input element -- on load from L1 every tap of every output re-applied it
 // (K*(3S+K)/4 = 8.75 swishes per output at K = 5: the batch-32 launches of HyperSeg-L were bound by exactly that: 90 us
 // per 5x5 launch) -- zero padding materialised in the tile, tap rows read back as aligned ds_read_b128.
-template <int K, int S, int PL, bool TILE>
+// SET: the squeeze-excite tail of round 5 (hs_se_tail.h, opt-in) compiled in.  The product's launches instantiate SET = false: the
+// tail is two thirds of the kernel's code and its descriptor 20 more kernel-argument dwords (round 6: HyperSeg-M frame 0.7436 ->
+// 0.7407 ms, profiles/round6_depthwise_without_se_tail_ab_w11.txt).
+template <int K, int S, int PL, bool TILE, bool SET>
 __global__ __launch_bounds__(256)
 void depthwise_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
                            const float* __restrict__ shift, float* __restrict__ y, int C, int H, int W, int Ho, int Wo,
@@ -31,7 +34,8 @@ void depthwise_conv_kernel(const float* __restrict__ x, const float* __restrict_
     const int plane = blockIdx.y + blockIdx.z * gridDim.y;       // b*C + c (folded over y/z: more than 65535 planes at bs 32)
     if (plane >= nplanes) return;
     const int c = plane % C;
-    const unsigned se_gen = se.ws ? se_tag(se, plane / C) : 0u;  // hs_se_tail.h: requested here, needed when the partial is published
+    unsigned se_gen = 0u;                                        // hs_se_tail.h: requested here, needed when the partial is published
+    if constexpr (SET) se_gen = se.ws ? se_tag(se, plane / C) : 0u;
     // optional prologue: the taps are swish(in_scale[c] * x + in_shift[c]) -- the BatchNorm + swish of the 1x1 expand
     // convolution that produced x, applied on load so that the raw GEMM output needs no elementwise pass of its own
     // (fetched AFTER the taps have been requested in the untiled form: the compiler issues a scalar load where the source
@@ -156,7 +160,7 @@ void depthwise_conv_kernel(const float* __restrict__ x, const float* __restrict_
     }
     }
     // squeeze-excite pooling: deterministic per-workgroup partial sums of the outputs (summed by hs_se_gate_fwd)
-    if (pool_partial || se.ws) {
+    if (pool_partial || (SET && se.ws)) {
         __shared__ float wsum[4];
         psum = wave_sum64(psum);
         if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = psum;
@@ -164,15 +168,17 @@ void depthwise_conv_kernel(const float* __restrict__ x, const float* __restrict_
         if (threadIdx.x == 0) {
             float t = 0.0f;
             for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += wsum[i];
-            if (se.ws) se_publish(se.ws, se_ws_pg(se) + (size_t)plane * gridDim.x + blockIdx.x, t, se_gen);
+            if (SET && se.ws) se_publish(se.ws, se_ws_pg(se) + (size_t)plane * gridDim.x + blockIdx.x, t, se_gen);
             else pool_partial[(size_t)plane * gridDim.x + blockIdx.x] = t;
         }
     }
     // the squeeze-excite gate by the last workgroups of the launch (hs_se_tail.h): the same partial sums, summed in the same order
     // (its LDS: the dynamic segment -- the input tile of the TILE form is dead by now; the host sizes it for both uses)
-    if (se.ws) {
-        if constexpr (TILE) __syncthreads();
-        se_tail_run(se, plane / C, (long)c * gridDim.x + blockIdx.x, (long)C * gridDim.x, se_gen, dw_tile);
+    if constexpr (SET) {
+        if (se.ws) {
+            if constexpr (TILE) __syncthreads();
+            se_tail_run(se, plane / C, (long)c * gridDim.x + blockIdx.x, (long)C * gridDim.x, se_gen, dw_tile);
+        }
     }
 }
 
@@ -321,13 +327,17 @@ constexpr int SEE_MAX_IT = 36;                       // channels per wave: C <= 
 __global__ __launch_bounds__(256)
 void se_gate_early_kernel(const float* __restrict__ partial, int nblk, float inv_hw, const float* __restrict__ w1,
                           const float* __restrict__ b1, const float* __restrict__ w2t, const float* __restrict__ b2, int C,
-                          int Csq, float* __restrict__ z_out, float* __restrict__ gate) {
+                          int Csq, float* __restrict__ z_out, float* __restrict__ gate, int fold) {
+    // fold (1, 2, 4): a channel with more than 256 partials enters as `fold` pseudo-channels of nblk partials each (C and nblk are the
+    // pseudo-channels' counts; the real channel c is pseudo-channels fold c .. fold c + fold - 1): stem + block 0 has 512 tiles
     __shared__ __attribute__((aligned(16))) float part[4 * SEE_MAX_IT * 64];      // [channel][lane]
     __shared__ __attribute__((aligned(16))) float mean_c[4 * SEE_MAX_IT];
+    __shared__ float mean_p[4 * SEE_MAX_IT];
     __shared__ float zs[8];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y;
+    const int Cr = C / fold;                                                    // real channels
     const int nu = nblk >> 2;                                                   // 16-byte units per channel, <= 64
     const float4* __restrict__ pb = reinterpret_cast<const float4*>(partial + (size_t)b * C * nblk);
     const int nit = (C + 3) >> 2;
@@ -339,19 +349,19 @@ void se_gate_early_kernel(const float* __restrict__ partial, int nblk, float inv
         pv[i] = i < nit ? pb[(size_t)c * nu + (lane_ok ? lane : 0)] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // squeeze rows of this wave (j = wave, wave + 4) and this thread's gate column: requested with the partials
-    const int c4 = min(4 * lane, C - 4);                                        // C % 4 == 0: lanes past the end re-read the last quad
+    const int c4 = min(4 * lane, Cr - 4);                                       // Cr % 4 == 0: lanes past the end re-read the last quad
     float4 w1v[2];
     float b1v[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int j = min(wave + 4 * r, Csq - 1);
-        w1v[r] = *reinterpret_cast<const float4*>(w1 + (size_t)j * C + c4);
+        w1v[r] = *reinterpret_cast<const float4*>(w1 + (size_t)j * Cr + c4);
         b1v[r] = b1[j];
     }
-    const int tc = min(tid, C - 1);
+    const int tc = min(tid, Cr - 1);
     float w2v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) w2v[j] = w2t[(size_t)min(j, Csq - 1) * C + tc];
+    for (int j = 0; j < 8; ++j) w2v[j] = w2t[(size_t)min(j, Csq - 1) * Cr + tc];
     const float b2v = b2[tc];
     __builtin_amdgcn_sched_barrier(0);
     // per-channel sums in two steps through LDS: lane sums -> part[channel][lane]; then a thread per (channel, quarter) adds 16 of them
@@ -370,11 +380,19 @@ void se_gate_early_kernel(const float* __restrict__ partial, int nblk, float inv
         int x = __float_as_int(t);
         x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false)));      // quad_perm [1,0,3,2]
         x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false)));      // quad_perm [2,3,0,1]
-        if (q == 0 && job < 4 * C) mean_c[c] = __int_as_float(x) * inv_hw;
+        if (q == 0 && job < 4 * C) (fold > 1 ? mean_p : mean_c)[c] = __int_as_float(x) * inv_hw;
+    }
+    if (fold > 1) {                                                             // uniform
+        __syncthreads();
+        if (tid < Cr) {
+            float t = mean_p[tid * fold];
+            for (int f = 1; f < fold; ++f) t += mean_p[tid * fold + f];
+            mean_c[tid] = t;
+        }
     }
     __syncthreads();
     {
-        const float4 mv = 4 * lane < C ? *reinterpret_cast<const float4*>(mean_c + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 mv = 4 * lane < Cr ? *reinterpret_cast<const float4*>(mean_c + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int j = wave + 4 * r;
@@ -388,7 +406,7 @@ void se_gate_early_kernel(const float* __restrict__ partial, int nblk, float inv
 #pragma unroll
     for (int j = 0; j < 8; ++j)
         if (j < Csq) acc = fmaf(w2v[j], zs[j], acc);
-    if (tid < C) gate[(size_t)b * C + tid] = sigmoidf_fast(acc);
+    if (tid < Cr) gate[(size_t)b * Cr + tid] = sigmoidf_fast(acc);
 }
 
 // The whole gate in ONE launch, for the blocks whose reduce weights are small enough that every excite workgroup can
@@ -549,8 +567,9 @@ static int depthwise_conv_launch(const float* x, int32_t batch, int32_t channels
         if (st != HS_OK) return st;
     }
     const size_t se_lds = se_in ? (size_t)se_lds_floats(se.Csq) * sizeof(float) : 0;
-#define HS_DW(KK, SS, PP) hipLaunchKernelGGL((depthwise_conv_kernel<KK, SS, PP, false>), grid, dim3(threads), se_lds, s, x, w, scale, shift, \
+#define HS_DW_(KK, SS, PP, SETV) hipLaunchKernelGGL((depthwise_conv_kernel<KK, SS, PP, false, SETV>), grid, dim3(threads), se_lds, s, x, w, scale, shift, \
                                              y, channels, H, W, Ho, Wo, pad_t, pad_l, act, pool_partial, in_scale, in_shift, (int)nplanes, se)
+#define HS_DW(KK, SS, PP) do { if (se_in) HS_DW_(KK, SS, PP, true); else HS_DW_(KK, SS, PP, false); } while (0)
     // the LDS-tiled form: BN0 + swish prologue, whole output rows per workgroup (same thread -> output map, same partials)
     const int wq = Wo / 4;
     // For batched work (>= 8192 planes) and for every 5 x 5 launch (8.75 swishes per output there), on planes of >= 256 output quads:
@@ -563,10 +582,12 @@ static int depthwise_conv_launch(const float* x, int32_t batch, int32_t channels
         const size_t tile_lds = (size_t)rows_in * tw * sizeof(float);
         const size_t lds = tile_lds > se_lds ? tile_lds : se_lds;
         if (tile_lds <= 64 * 1024) {
-#define HS_DWT(KK, SS) hipLaunchKernelGGL((depthwise_conv_kernel<KK, SS, -1, true>), grid, dim3(threads), lds, s, x, w, scale, shift, y, \
+#define HS_DWT_(KK, SS, SETV) hipLaunchKernelGGL((depthwise_conv_kernel<KK, SS, -1, true, SETV>), grid, dim3(threads), lds, s, x, w, scale, shift, y, \
                                           channels, H, W, Ho, Wo, pad_t, pad_l, act, pool_partial, in_scale, in_shift, (int)nplanes, se)
+#define HS_DWT(KK, SS) do { if (se_in) HS_DWT_(KK, SS, true); else HS_DWT_(KK, SS, false); } while (0)
             if (k == 3 && stride == 1) HS_DWT(3, 1); else if (k == 3) HS_DWT(3, 2); else if (stride == 1) HS_DWT(5, 1); else HS_DWT(5, 2);
 #undef HS_DWT
+#undef HS_DWT_
             return launch_status();
         }
     }
@@ -577,6 +598,7 @@ static int depthwise_conv_launch(const float* x, int32_t batch, int32_t channels
     else if (k == 5 && stride == 2) { if (vec && pad_l == 1) HS_DW(5, 2, 1); else if (vec && pad_l == 2) HS_DW(5, 2, 2); else HS_DW(5, 2, -1); }
     else return HS_ERR_UNSUPPORTED;
 #undef HS_DW
+#undef HS_DW_
     return launch_status();
 }
 
@@ -640,10 +662,11 @@ extern "C" int hs_se_gate_fwd(const float* partial, int32_t batch, int32_t chann
     }
     {   // the early blocks (many partials, few channels) as one single-workgroup launch
         static const bool off = [] { const char* e = getenv("HS_SE_EARLY"); return e && atoi(e) == 0; }();      // dev A/B knob
-        if (!off && !w_proj && (channels & 3) == 0 && channels <= 4 * SEE_MAX_IT && c_squeezed <= 8 && (nblk & 3) == 0 && nblk <= 256 &&
-            ((size_t)partial & 15) == 0 && ((size_t)w_reduce & 15) == 0) {
-            hipLaunchKernelGGL(se_gate_early_kernel, dim3(1, batch), dim3(256), 0, s, partial, nblk, inv_hw, w_reduce, b_reduce, w_expand,
-                               b_expand, channels, c_squeezed, squeezed, gate);
+        const int fold = nblk <= 256 ? 1 : (nblk <= 512 ? 2 : 4);                // pseudo-channels per channel (<= 256 partials each)
+        if (!off && !w_proj && (channels & 3) == 0 && channels * fold <= 4 * SEE_MAX_IT && c_squeezed <= 8 && (nblk & (4 * fold - 1)) == 0 &&
+            nblk <= 1024 && ((size_t)partial & 15) == 0 && ((size_t)w_reduce & 15) == 0) {
+            hipLaunchKernelGGL(se_gate_early_kernel, dim3(1, batch), dim3(256), 0, s, partial, nblk / fold, inv_hw, w_reduce, b_reduce, w_expand,
+                               b_expand, channels * fold, c_squeezed, squeezed, gate, fold);
             return launch_status();
         }
     }

@@ -161,7 +161,9 @@ def test_stem_dw(HF, dev, cmid, h, w, covered):
 @pytest.mark.parametrize('c,csq,nblk,cout', [(32, 8, 128, 16), (96, 4, 32, 24), (240, 10, 8, 40), (672, 28, 2, 112),
                                              (1152, 48, 1, 320), (1920, 80, 1, 320), (50, 3, 5, 7),
                                              # the early blocks' shapes (64-256 partials per channel): the wide one-launch form of round 5
-                                             (96, 4, 256, 24), (144, 6, 128, 24), (240, 10, 64, 40), (100, 5, 51, 7)])
+                                             (96, 4, 256, 24), (144, 6, 128, 24), (240, 10, 64, 40), (100, 5, 51, 7),
+                                             # round 6: the single-workgroup gate with 2 / 4 loads per channel and lane (stem + block 0: 512 tiles)
+                                             (32, 8, 512, 16), (16, 4, 1024, 16), (72, 6, 300, 24)])
 @pytest.mark.parametrize('batch', [1, 2])
 def test_se_gate(HF, dev, c, csq, nblk, cout, batch):
     g = torch.Generator().manual_seed(c + csq)

@@ -250,6 +250,7 @@ VARIANTS = {
     'mbl_nomfma': dict(flags=[], extra=[], patch='mbl_nomfma', file='hs_mbconv_lean.hip'),
     'mbl_nodw': dict(flags=[], extra=[], patch='mbl_nodw', file='hs_mbconv_lean.hip'),
     'mbl_nostage': dict(flags=['-DHS_MBL_STAGE=0'], extra=[], patch=None),      # lean fused expand + depthwise kernel: direct output stores (no LDS staging)
+    'enc_se_in': dict(flags=[], extra=[], patch='git:64a8791', file='hs_encoder.hip'),      # round 6: depthwise kernel with the squeeze-excite tail compiled into every instantiation (same-box A/B)
     'irc_nobarrier': dict(flags=[], extra=[], patch='irc_nobarrier', file='hs_patch_irc.hip'),
     'px_nostore': dict(flags=[], extra=[], patch='px_nostore', file='hs_patch_ir_px.hip'),
     'px_prio_young': dict(flags=[], extra=[], patch='px_prio_young', file='hs_patch_ir_px.hip'),
