@@ -698,7 +698,11 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 // NB = number of 16-channel K batches (fully unrolled, double buffered: the loads of batch i+1 are in flight while the
 // MFMAs of batch i run), NT = 16-pixel tiles per wave (the host shrinks it until the launch has >= 512 workgroups).
-template <int NB, int NT>
+// VEC (round 6; NT = 4, P % 64 == 0, 16-byte aligned maps): the wave's 4 pixel tiles are INTERLEAVED -- tile n holds pixels
+// p0 + 4 lrow + n -- so a lane's four B values of a k-row are ONE 16-byte load, its four outputs of a row ONE 16-byte store (and one
+// 16-byte residual load): the matrix-core instruction does not care which pixel a column is, and these launches are bound by the
+// number of vector-memory instructions (4-byte gathers: 64 of them per lane at NB = 2).  Same products, same sums: bit-identical.
+template <int NB, int NT, bool VEC = false>
 __global__ __launch_bounds__(256)
 void pointwise_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ gate,
                            const float* __restrict__ scale, const float* __restrict__ shift,
@@ -722,7 +726,8 @@ void pointwise_conv_kernel(const float* __restrict__ x, const float* __restrict_
     for (int m = 0; m < 2; ++m) { const int o = o0 + 16 * m + lrow; ook[m] = o < Cout; orow[m] = ook[m] ? o : Cout - 1; }
     int pcol[NT]; bool pok[NT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) { const int p = p0 + 16 * n + lrow; pok[n] = p < P; pcol[n] = pok[n] ? p : P - 1; }
+    for (int n = 0; n < NT; ++n) { const int p = VEC ? p0 + 4 * lrow + n : p0 + 16 * n + lrow; pok[n] = p < P; pcol[n] = pok[n] ? p : P - 1; }
+    static_assert(!VEC || NT == 4, "interleaved tiles: four pixels per lane");
     constexpr int KU = 4;                                   // k-steps per batch (16 input channels)
     float av[2][KU][2], bv[2][KU][NT];
     auto load_batch = [&](int i, float (&a)[KU][2], float (&bb)[KU][NT]) {
@@ -736,8 +741,14 @@ void pointwise_conv_kernel(const float* __restrict__ x, const float* __restrict_
             const float g = (gb ? gb[kc] : 1.0f) * (kok ? 1.0f : 0.0f);
 #pragma unroll
             for (int m = 0; m < 2; ++m) a[u][m] = w[(size_t)orow[m] * Cin + kc] * (ook[m] ? 1.0f : 0.0f);
+            if constexpr (VEC) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (size_t)kc * P + pcol[0]);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) bb[u][n] = xb[(size_t)kc * P + pcol[n]] * g;
+                for (int n = 0; n < NT; ++n) bb[u][n] = v[n] * g;
+            } else {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) bb[u][n] = xb[(size_t)kc * P + pcol[n]] * g;
+            }
         }
     };
     load_batch(0, av[0], bv[0]);
@@ -759,8 +770,14 @@ void pointwise_conv_kernel(const float* __restrict__ x, const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int o = min(o0 + 16 * m + 4 * lk + r, Cout - 1);
+                if constexpr (VEC) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(residual + ((size_t)b * Cout + o) * P + pcol[0]);
 #pragma unroll
-                for (int n = 0; n < NT; ++n) rv[m][r][n] = residual[((size_t)b * Cout + o) * P + pcol[n]];
+                    for (int n = 0; n < NT; ++n) rv[m][r][n] = v[n];
+                } else {
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) rv[m][r][n] = residual[((size_t)b * Cout + o) * P + pcol[n]];
+                }
             }
     } else {
 #pragma unroll
@@ -787,14 +804,20 @@ void pointwise_conv_kernel(const float* __restrict__ x, const float* __restrict_
         for (int r = 0; r < 4; ++r) {
             const int o = o0 + 16 * m + 4 * lk + r;
             if (o >= Cout) continue;
+            float ov[NT];
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                if (!pok[n]) continue;
                 float v = fmaf(acc[m][n][r], scv[m][r], shv[m][r]);
                 if (act == 3) v = swishf(v);
                 else v = apply_act(v, act);
-                v += rv[m][r][n];
-                y[((size_t)b * Cout + o) * P + pcol[n]] = v;
+                ov[n] = v + rv[m][r][n];
+            }
+            if constexpr (VEC) {
+                *reinterpret_cast<f32x4*>(y + ((size_t)b * Cout + o) * P + pcol[0]) = f32x4{ov[0], ov[1], ov[2], ov[3]};
+            } else {
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    if (pok[n]) y[((size_t)b * Cout + o) * P + pcol[n]] = ov[n];
             }
         }
 }
@@ -805,7 +828,11 @@ static int launch_pointwise(int nt, dim3 grid, hipStream_t s, const float* x, co
                             int pixels, int act) {
 #define HS_PW(NT) hipLaunchKernelGGL((pointwise_conv_kernel<NB, NT>), grid, dim3(256), 0, s, x, w, gate, scale, shift, \
                                      residual, y, c_in, c_out, pixels, act)
-    if (nt == 4) HS_PW(4); else if (nt == 2) HS_PW(2); else HS_PW(1);
+    static const bool vec_off = [] { const char* e = getenv("HS_PW_VEC"); return e && atoi(e) == 0; }();      // dev A/B knob
+    const bool vec = !vec_off && nt == 4 && (pixels & 63) == 0 && ((((size_t)x | (size_t)y | (size_t)residual)) & 15) == 0;
+    if (vec) hipLaunchKernelGGL((pointwise_conv_kernel<NB, 4, true>), grid, dim3(256), 0, s, x, w, gate, scale, shift, residual, y, c_in,
+                                c_out, pixels, act);
+    else if (nt == 4) HS_PW(4); else if (nt == 2) HS_PW(2); else HS_PW(1);
 #undef HS_PW
     return launch_status();
 }

@@ -302,7 +302,9 @@ def test_se_tail_under_graph_replay_and_two_streams(HF, dev, monkeypatch):
     assert all(torch.equal(o, gate0) for o in outs)
 
 
-@pytest.mark.parametrize('cin,cout,hw', [(16, 96, (64, 128)), (96, 24, (32, 64)), (32, 16, (16, 20)), (50, 37, (9, 12))])
+@pytest.mark.parametrize('cin,cout,hw', [(16, 96, (64, 128)), (96, 24, (32, 64)), (32, 16, (16, 20)), (50, 37, (9, 12)),
+                                         # full-size stage-1 maps: 4 pixel tiles per wave, the interleaved 16-byte form (round 6)
+                                         (32, 16, (256, 512)), (16, 16, (256, 512)), (24, 40, (256, 256))])
 def test_pointwise_conv_and_affine(HF, dev, cin, cout, hw):
     g = torch.Generator().manual_seed(cin * cout)
     b = 2
