@@ -425,8 +425,8 @@ def main(argv=None):
             'config': {'workload': f'{LABELS[args.model]}, batch {batch} per GPU (global {global_batch}), whole model forward '
                                    '(encoder + context head as per "encoder", HIP decoder), resident input',
                        'encoder': 'stock PyTorch-ROCm / MIOpen' if args.stock_encoder else
-                                  'hyperseg_amd.utils.inference.prepare_for_inference: MBConv blocks = hs_mbconv_expand_dw_fwd | '
-                                  '1x1 GEMM + hs_depthwise_conv_fwd, hs_se_gate_fwd, 1x1 GEMM; hs_stem_conv_fwd; '
+                                  'hyperseg_amd.utils.inference.prepare_for_inference: stem + block 0 depthwise = hs_stem_dw_fwd; MBConv blocks = '
+                                  'hs_mbconv_expand_dw_fwd | 1x1 GEMM + hs_depthwise_conv_fwd, hs_se_gate_fwd, 1x1 GEMM; '
                                   'context head = 4 launches of hs_gemm_split_*; 1x1 GEMMs of the MBConv blocks = ' +
                                   ('hs_gemm_split_fwd (f16 matrix cores, split operands, f32 accumulation)' if args.split_gemm
                                    else 'library f32 GEMM (--library-gemm)'),
