@@ -315,13 +315,15 @@ int try_launch_mbconv_lean(const float* x, int batch, int c_in, int H, int W, co
     a.tiles_y = tiles_y; a.tiles_x = tiles_x; a.chunks_per_wg = chunks_per_wg; a.ngroups = ngroups;
     a.sH = a.sW = a.spad_t = a.spad_l = 0;
     const int ks = c_in >> 2;
-    if (k == 5 && ((stride == 2 && oth == 8 && ks > 6) || (oth == 16 && ks > 10))) return 1;      // those instantiations do not fit the register file (spills)
+    if (k == 5 && stride == 2 && oth == 8 && ks > 6) return 1;      // that instantiation does not fit the register file (spills)
+    // (Cin = 80 -- KS = 20, HyperSeg-M's 64 x 32 blocks -- was instantiated and measured in round 6: 11.5 us against the GEMM + depthwise
+    // pair's 12.2 per block in isolation, but the whole frame LOSES 4.5 us with the fusion threshold raised to 80 channels:
+    // profiles/round6_mbconv_lean_cin80_negative_w13.txt.  Not instantiated.)
 #define HS_MBL_KS(K_, S_, OTH_) \
     if (k == K_ && stride == S_ && oth == OTH_) { \
         if (ks == 4) return launch_mbl<K_, S_, OTH_, 16, 4>(a, batch, stream); \
         if (ks == 6) return launch_mbl<K_, S_, OTH_, 16, 6>(a, batch, stream); \
         if (ks == 10) return launch_mbl<K_, S_, OTH_, 16, 10>(a, batch, stream); \
-        if constexpr (S_ == 1) { if (ks == 20) return launch_mbl<K_, S_, OTH_, 16, 20>(a, batch, stream); } \
         return 1; \
     }
     HS_MBL_KS(3, 1, 16) HS_MBL_KS(3, 1, 8) HS_MBL_KS(5, 1, 16) HS_MBL_KS(5, 1, 8)
