@@ -365,8 +365,8 @@ static int launch_gemm_split_plain(const void* w_frag, const float* w_inv, const
     if (!w_frag || !w_inv || !x || !y || batch <= 0 || c_out <= 0 || c_in <= 0 || pixels <= 0) return HS_ERR_BAD_ARG;
     if (act < 0 || act > 3) return HS_ERR_BAD_ARG;
     int nwv, ks, nch;
-    if (!gemm_split_plan(c_in, nwv, ks, nch) || nch != 1) return HS_ERR_UNSUPPORTED;      // Cin > 1280: the library GEMM
-    if (kp != nwv * ks * 32 || (ks > 1 && nwv != 8)) return HS_ERR_BAD_ARG;
+    if (!gemm_split_plan(c_in, nwv, ks, nch)) return HS_ERR_UNSUPPORTED;                  // Cin > 2560: the library GEMM
+    if (kp != nwv * nch * ks * 32 || (ks > 1 && nwv != 8)) return HS_ERR_BAD_ARG;
     if (batch > 65535 || (c_out + 31) / 32 > 65535) return HS_ERR_UNSUPPORTED;
     GemmSplitArgs a{(const _Float16*)w_frag, w_inv, gate, x, shift, residual, y, c_out, c_in, kp / 32, pixels, act, 0, nullptr, up2_wo};
     dim3 grid((pixels + 31) / 32, ((c_out + 15) / 16 + 1) / 2, batch);
@@ -385,6 +385,17 @@ static int launch_gemm_split_plain(const void* w_frag, const float* w_inv, const
         else if (tall) hipLaunchKernelGGL((gemm_split_kernel<KSV, NWV, F, 2, 4, 1, false>), grid, dim3(64 * NWV), lds, s, a); \
         else hipLaunchKernelGGL((gemm_split_kernel<KSV, NWV, F, 2, 2, 1, false>), grid, dim3(64 * NWV), lds, s, a); } while (0)
 #define HS_GS(KSV, NWV) do { if (fast) HS_GS_(KSV, NWV, true); else HS_GS_(KSV, NWV, false); } while (0)
+    if (nch == 2) {
+        // 1280 < Cin <= 2560 (round 6: HyperSeg-M's last project conv, K = 1920): two chunks of KS k-steps per wave, each scaled by its own
+        // per-pixel power of two; the 16-pixel form only (every launch of this depth is on a 16 x 32 map or smaller), FAST shapes only
+        if (!fast || up2_wo > 0) return HS_ERR_UNSUPPORTED;
+        grid.x = (pixels + 15) / 16; grid.y = ((c_out + 15) / 16 + 1) / 2;
+        const size_t lds2 = (size_t)8 * 512 * sizeof(float);
+#define HS_GS2(KSV) hipLaunchKernelGGL((gemm_split_kernel<KSV, 8, true, 1, 2, 2, false>), grid, dim3(512), lds2, s, a)
+        switch (ks) { case 3: HS_GS2(3); break; case 4: HS_GS2(4); break; case 5: HS_GS2(5); break; default: return HS_ERR_UNSUPPORTED; }
+#undef HS_GS2
+        return launch_status();
+    }
     switch (ks) {
         case 1: if (nwv == 2) HS_GS(1, 2); else if (nwv == 4) HS_GS(1, 4); else HS_GS(1, 8); break;
         case 2: HS_GS(2, 8); break;

@@ -66,6 +66,9 @@ def _bn_affine(bn):
 
 
 # output pixels from which the fused expand + depthwise kernel is used (tools/bench_mbconv.py measures both routes)
+# round 6: the split GEMM covers 1280 < K <= 2560 on its two-chunk form (tests/test_split_gemm.py), but HyperSeg-M's one such layer -- the last
+# project conv, K = 1920 -- measured 1.8 us SLOWER on it than on the library GEMM (profiles/round6_split_gemm_k1920_negative_w14.txt)
+SPLIT_GEMM_MAX_K = int(os.environ.get('HS_SPLIT_GEMM_MAX_K', '1280'))
 STEM_DW = os.environ.get('HS_STEM_DW', '1') != '0'       # stem + block 0's depthwise half as one launch (hs_stem_dw_fwd); 0: two launches
 FUSE_EXPAND_MIN_PIXELS = int(os.environ.get('HS_FUSE_EXPAND_MIN_PIXELS', '2048'))
 FUSE_EXPAND_MAX_CIN = int(os.environ.get('HS_FUSE_EXPAND_MAX_CIN', '40'))      # wider inputs: 1 wave / SIMD, slower than GEMM + dw
@@ -123,7 +126,7 @@ class FusedPointwise(nn.Module):
         key, ver = (bool(with_scale), device), HF._key(*srcs)       # in-place updates of the weight / BN scale are seen
         hit = self._split.get(key)
         if hit is None or hit[0] != ver:
-            hit = (ver, HF.gemm_split_weights(self.conv.weight, self.scale if with_scale else None), HF.producer_stream(self.conv.weight.device))
+            hit = (ver, HF.gemm_split_weights(self.conv.weight, self.scale if with_scale else None, max_k=SPLIT_GEMM_MAX_K), HF.producer_stream(self.conv.weight.device))
             HF.publish_ready(self.conv.weight.device)            # another stream / replica thread may pick the entry up
             self._split[key] = hit
         elif hit[1] is not None:

@@ -81,7 +81,9 @@ def test_split_arithmetic_emulated(m, k):
 @pytest.mark.gpu
 @pytest.mark.parametrize('m,k,hw,batch', [(40, 240, (64, 128), 1), (80, 480, (32, 64), 2), (112, 672, (32, 64), 1), (192, 1152, (16, 32), 1),
                                           (320, 1152, (16, 32), 2), (480, 80, (32, 64), 1), (19, 33, (5, 7), 1), (1280, 320, (16, 32), 1),
-                                          (40, 36, (33, 129), 1)])      # odd pixel count on a wide grid: the scalar-load form, 32-pixel blocks
+                                          (40, 36, (33, 129), 1),      # odd pixel count on a wide grid: the scalar-load form, 32-pixel blocks
+                                          # round 6: 1280 < K <= 2560 on the two-chunk form (HyperSeg-M's last project conv: K = 1920)
+                                          (320, 1920, (16, 32), 1), (320, 1920, (16, 32), 2), (100, 1400, (8, 16), 1), (64, 2560, (8, 8), 1)])
 def test_gemm_split_vs_float64(m, k, hw, batch):
     from hyperseg_amd import functional as HF
     dev = torch.device('cuda:0')
@@ -90,11 +92,11 @@ def test_gemm_split_vs_float64(m, k, hw, batch):
     x = (torch.randn(batch, k, *hw, generator=g) * torch.rand(1, k, 1, 1, generator=g) * 4).to(dev)
     gate = torch.rand(batch, k, generator=g).to(dev)
     scale = (torch.rand(m, generator=g) + 0.5).to(dev)
-    sw = HF.gemm_split_weights(w, scale)
+    sw = HF.gemm_split_weights(w, scale, max_k=2560)
     ref = torch.einsum('ok,bkn->bon', (w * scale[:, None]).double(), (x.flatten(2) * gate[:, :, None]).double()).view(batch, m, *hw)
     y = HF.gemm_split(sw, x, gate=gate)
     assert rel_err(y.double().cpu(), ref.cpu()) < 2e-6
-    y0 = HF.gemm_split(HF.gemm_split_weights(w), x)
+    y0 = HF.gemm_split(HF.gemm_split_weights(w, max_k=2560), x)
     ref0 = torch.einsum('ok,bkn->bon', w.double(), x.flatten(2).double()).view(batch, m, *hw)
     assert rel_err(y0.double().cpu(), ref0.cpu()) < 2e-6
     acc = torch.ones_like(y)
