@@ -291,7 +291,8 @@ void mbconv_lean_kernel(MblArgs a) {
 template <int K, int S, int OTH, int OTW, int KS, bool STEM = false>
 static int launch_mbl(MblArgs& a, int batch, hipStream_t stream) {
     using G = MblGeom<K, S, OTH, OTW>;
-    const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float);
+    static const int lds_pad = [] { const char* e = getenv("HS_MBX_LDS_PAD"); return e ? atoi(e) : 0; }();      // dev knob: fewer co-resident workgroups (KB)
+    const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float) + (size_t)lds_pad * 1024;
     const size_t blocks = (size_t)batch * a.tiles_y * a.tiles_x * a.ngroups;
     if (blocks > 0x7fffffffu) return 1;
     a.m_ngroups = mbl_magic((unsigned)a.ngroups); a.m_tiles_x = mbl_magic((unsigned)a.tiles_x); a.m_tiles_y = mbl_magic((unsigned)a.tiles_y);
