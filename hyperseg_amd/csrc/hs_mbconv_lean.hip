@@ -1,5 +1,5 @@
 // The lean form of hs_mbconv.hip's launch (round 6): same tiles, same chunk groups, same arithmetic order -- bit-identical y and
-// pool partials -- for the shapes the benched encoders actually run (Cin a multiple of 4, Cmid a multiple of 16, whole tiles, no
+// pool partials -- for the shapes the benched encoders actually run (Cin a multiple of 4, Cmid a multiple of 16, whole tile columns, no
 // squeeze-excite tail).  The general kernel spends more vector instructions on being general than on the block: 862 per wave for
 // 36 matrix products, 80 transcendentals and 144 depthwise FMAs at HyperSeg-M's 24 -> 144 blocks (64-bit address arithmetic per
 // load, clamps and mask multiplies for ragged channel counts, SGPR spills around the tail's arguments), at 160 registers = 3
@@ -246,6 +246,8 @@ void mbconv_lean_kernel(MblArgs a) {
             for (int v = 0; v < G::NOUT; ++v) o[v] = swishf(fmaf(o[v], sc1, sh1));
 #pragma unroll
             for (int qd = 0; qd < G::NOUT / 4; ++qd) psum += (o[4 * qd] + o[4 * qd + 1]) + (o[4 * qd + 2] + o[4 * qd + 3]);
+            const bool rowok = oy0 + drow < a.Ho;            // the last tile row of a map whose height is not a multiple of OTH (CamVid: 72, 36)
+            if (!rowok) psum = 0.0f;
             if (a.pool) psum = rowsum16(psum);      // SE pooling: one partial sum per (channel, tile), reduced over the channel's 16 lanes
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) as an instruction the compiler's own wait insertion sees (an asm string it does not)
@@ -273,13 +275,15 @@ void mbconv_lean_kernel(MblArgs a) {
                     const int idx = i * 64 + lane;
                     const int sq = idx & 3, sr = (idx >> 2) % OTH, sc = idx / (4 * OTH);
                     float* __restrict__ d4 = a.y + (((size_t)b * Cmid + (h0 + 4 * wave + sc)) * a.Ho + (oy0 + sr)) * a.Wo + ox0 + 4 * sq;
-                    *reinterpret_cast<f32x4*>(d4) = ov[i];
+                    if (oy0 + sr < a.Ho) *reinterpret_cast<f32x4*>(d4) = ov[i];
                 }
             } else {
                 float* __restrict__ dst = a.y + (((size_t)b * Cmid + h) * a.Ho + oy0 + drow) * a.Wo + ox0 + dseg * G::NOUT;
+                if (rowok) {
 #pragma unroll
-                for (int qd = 0; qd < G::NOUT / 4; ++qd)
-                    *reinterpret_cast<f32x4*>(dst + 4 * qd) = f32x4{o[4 * qd], o[4 * qd + 1], o[4 * qd + 2], o[4 * qd + 3]};
+                    for (int qd = 0; qd < G::NOUT / 4; ++qd)
+                        *reinterpret_cast<f32x4*>(dst + 4 * qd) = f32x4{o[4 * qd], o[4 * qd + 1], o[4 * qd + 2], o[4 * qd + 3]};
+                }
             }
             if (a.pool && u == 0) a.pool[((size_t)b * Cmid + h) * ntiles + ty * a.tiles_x + tx] = psum;
         }
@@ -307,7 +311,7 @@ int try_launch_mbconv_lean(const float* x, int batch, int c_in, int H, int W, co
                            int chunks_per_wg, int ngroups, hipStream_t stream) {
     static const bool off = [] { const char* e = getenv("HS_MBX_LEAN"); return e && atoi(e) == 0; }();      // dev A/B knob
     if (off) return 1;
-    if ((c_in & 3) != 0 || (c_mid & 15) != 0 || Ho % oth != 0 || Wo % 16 != 0) return 1;
+    if ((c_in & 3) != 0 || (c_mid & 15) != 0 || Wo % 16 != 0) return 1;             // (a ragged LAST TILE ROW is fine: rows past Ho are neither stored nor pooled)
     if ((size_t)c_in * H * W >= (1u << 30)) return 1;                       // 32-bit byte offsets from the batch element's base
     if ((((size_t)y | (size_t)scale0 | (size_t)shift0) & 15) != 0) return 1;
     MblArgs a;
@@ -339,7 +343,7 @@ int try_launch_stem_dw_lean(const float* x, int batch, int sH, int sW, const flo
                             int spad_t, int spad_l, int Hs, int Ws, const float* w_dw, int k, int pad_t, int pad_l, const float* scale1,
                             const float* shift1, float* y, float* pool, int oth, int tiles_y, int tiles_x, int chunks_per_wg, int ngroups,
                             hipStream_t stream) {
-    if (k != 3 || (c_mid & 15) != 0 || Hs % oth != 0 || Ws % 16 != 0 || spad_t < 0 || spad_l < 0) return 1;
+    if (k != 3 || (c_mid & 15) != 0 || Ws % 16 != 0 || spad_t < 0 || spad_l < 0) return 1;
     if ((size_t)3 * sH * sW >= (1u << 29)) return 1;                          // 32-bit byte offsets, with room for the clamped windows
     if (2 * (Hs - 1) - spad_t >= sH || 2 * (Ws - 1) - spad_l >= sW) return 1;  // every output's window starts inside the image
     if ((((size_t)y | (size_t)scale0 | (size_t)shift0) & 15) != 0) return 1;

@@ -409,7 +409,7 @@ int hs_mbconv_tiles(int32_t k, int32_t stride, int32_t Ho, int32_t Wo);
  *   y = swish(BN1(depthwise_3x3(zero-pad(swish(BN0(conv3x3/s2(zero-pad(x))))))))   (+ per-tile sums of y for the SE pool)
  * x (B,3,H,W); w_stem28 (c_mid, 28): the stem weight (c_mid,3,3,3) flattened to (c_mid, 27) plus one zero column; (Hs, Ws) = the
  * stem's output size = y's (B,c_mid,Hs,Ws); pool_partial (optional) (B*c_mid, hs_mbconv_tiles(3, 1, Hs, Ws)).  The stem's output
- * map never reaches HBM.  HS_ERR_UNSUPPORTED outside k = 3, c_mid % 16 == 0, whole 16-pixel tiles (the caller then runs
+ * map never reaches HBM.  HS_ERR_UNSUPPORTED outside k = 3, c_mid % 16 == 0, Ws % 16 == 0 (the caller then runs
  * hs_stem_conv_fwd + hs_depthwise_conv_fwd).  Replaces efficientnet.py:321-322 and 59-66 / 101-103 of MBConvBlock 0. */
 int hs_stem_dw_fwd(const float* x, int32_t batch, int32_t H, int32_t W, const float* w_stem28, int32_t c_mid,
                    const float* scale0, const float* shift0, int32_t stem_pad_t, int32_t stem_pad_l, int32_t Hs, int32_t Ws,

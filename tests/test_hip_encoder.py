@@ -107,7 +107,9 @@ def test_stem_conv(HF, dev, h, w, cout, pads):
 
 @pytest.mark.parametrize('cin,cmid,k,stride,h,w', [(16, 96, 3, 2, 64, 128), (24, 144, 3, 1, 32, 48), (24, 144, 5, 2, 50, 70),
                                                    (40, 240, 5, 1, 33, 47), (40, 100, 3, 2, 31, 45), (80, 480, 3, 1, 16, 32),
-                                                   (80, 200, 5, 1, 20, 36), (6, 20, 3, 1, 9, 9), (48, 40, 5, 2, 17, 40)])
+                                                   (80, 200, 5, 1, 20, 36), (6, 20, 3, 1, 9, 9), (48, 40, 5, 2, 17, 40),
+                                                   # round 6, the lean kernel with a ragged last tile row (CamVid: 96 x 72 and 48 x 36 maps) and whole tiles
+                                                   (24, 144, 5, 1, 72, 96), (40, 240, 3, 2, 72, 96), (24, 144, 3, 1, 40, 32), (16, 96, 3, 2, 64, 64)])
 def test_mbconv_expand_dw(HF, dev, cin, cmid, k, stride, h, w):
     """hs_mbconv_expand_dw_fwd == depthwise(zero-pad(swish(BN0(expand(x))))) -> BN1 -> swish, incl. ragged edge tiles,
     channel counts that are not multiples of the 16-channel chunk / 4-wide k-step, and the SE pooling partial sums."""
@@ -130,10 +132,11 @@ def test_mbconv_expand_dw(HF, dev, cin, cmid, k, stride, h, w):
     assert rel_err(pooled, ref.mean((2, 3))) < REL_TOL
 
 
-@pytest.mark.parametrize('cmid,h,w,covered', [(32, 64, 96, True), (32, 32, 64, True), (16, 96, 32, True), (32, 66, 96, False), (24, 64, 64, False)])
+@pytest.mark.parametrize('cmid,h,w,covered', [(32, 64, 96, True), (32, 32, 64, True), (16, 96, 32, True), (32, 66, 96, True), (32, 50, 64, True),
+                                              (32, 64, 72, False), (24, 64, 64, False)])
 def test_stem_dw(HF, dev, cmid, h, w, covered):
     """hs_stem_dw_fwd == swish(BN1(depthwise3x3(zero-pad(swish(BN0(conv3x3/s2(zero-pad(image)))))))) + SE pooling partial sums: the stem's
-    TF-"SAME" padding (bottom / right only on even images), border tiles (windows that leave the image), whole-tile shapes only --
+    TF-"SAME" padding (bottom / right only on even images), border tiles (windows that leave the image), a ragged last tile row; tile columns whole --
     everything else returns None (the caller then runs the two launches)."""
     g = torch.Generator().manual_seed(cmid + h + w)
     b = 2
