@@ -42,7 +42,11 @@ template <int K, int S, int OTH, int OTW> struct MblGeom {
     // output staging (per wave: its 4 hidden channels x OTH rows, rows padded to 20 floats: conflict-free 16-byte writes at a lane
     // stride of one row) -- see the store of the depthwise stage
     static constexpr int SROW = OTW + 4;
-    static constexpr int STG_WAVE = 4 * OTH * SROW;                           // floats per wave
+    // channels of a wave staged at a time.  (2 -- two passes, 10 KB less LDS, 4 workgroups per CU -- together with a single-chunk
+    // specialisation of the kernel at 89 instead of 146 registers was measured in visit r6w17: 167.0 against 163.9 us over the 7 launches,
+    // frame 0.7459 against 0.7408 ms.  More co-resident workgroups are not better here, as fewer were not in r6w15: three per CU it is.)
+    static constexpr int STG_CH = 4;
+    static constexpr int STG_WAVE = STG_CH * OTH * SROW;                      // floats per wave
     static constexpr int H1_FLOATS = 16 * H1P;
     static constexpr int LDS_FLOATS = H1_FLOATS + (HS_MBL_STAGE ? 4 * STG_WAVE : 0);
     static_assert(16 % OTH == 0 && OTW % NSEG == 0 && (NOUT * S) % 4 == 0 && NOUT % 4 == 0 && OTW == 16, "tile shape");
@@ -259,23 +263,36 @@ void mbconv_lean_kernel(MblArgs a) {
             // 168.7 -> 162.0 us over HyperSeg-M's 7 launches, frame 0.757 -> 0.749 ms (profiles/round6_stem_dw_and_output_staging_ab_w9.txt).
             if constexpr (HS_MBL_STAGE) {
                 float* stg = h1 + G::H1_FLOATS + wave * G::STG_WAVE;
-                float* sw = stg + ((hh & 3) * OTH + drow) * G::SROW + dseg * G::NOUT;
+                constexpr int NPASS = 4 / G::STG_CH;                              // passes over the wave's 4 channels
+                constexpr int NLD = G::STG_CH * OTH * 4 / 64;                       // 16-byte pieces per lane and pass
+                static_assert(NLD >= 1, "a pass fills every lane");
 #pragma unroll
-                for (int qd = 0; qd < G::NOUT / 4; ++qd)
-                    *reinterpret_cast<f32x4*>(sw + 4 * qd) = f32x4{o[4 * qd], o[4 * qd + 1], o[4 * qd + 2], o[4 * qd + 3]};
-                f32x4 ov[G::NOUT / 4];
+                for (int ps = 0; ps < NPASS; ++ps) {
+                    if (NPASS == 1 || ((hh & 3) >> 1) == ps) {
+                        float* sw = stg + (((hh & 3) % G::STG_CH) * OTH + drow) * G::SROW + dseg * G::NOUT;
 #pragma unroll
-                for (int i = 0; i < G::NOUT / 4; ++i) {
-                    const int idx = i * 64 + lane;
-                    const int sq = idx & 3, sr = (idx >> 2) % OTH, sc = idx / (4 * OTH);
-                    ov[i] = *reinterpret_cast<const f32x4*>(stg + (sc * OTH + sr) * G::SROW + 4 * sq);
-                }
+                        for (int qd = 0; qd < G::NOUT / 4; ++qd)
+                            *reinterpret_cast<f32x4*>(sw + 4 * qd) = f32x4{o[4 * qd], o[4 * qd + 1], o[4 * qd + 2], o[4 * qd + 3]};
+                    }
+                    // a lane reads what OTHER lanes of its wave wrote: nothing in the language orders its own write (another address)
+                    // before its read (the two-pass form of visit r6w17 came out reordered: rel err 1.2), so the order is pinned for the
+                    // compiler -- the hardware executes a wave's LDS instructions in order, which is all it takes
+                    asm volatile("" ::: "memory");
+                    f32x4 ov[NLD];
 #pragma unroll
-                for (int i = 0; i < G::NOUT / 4; ++i) {
-                    const int idx = i * 64 + lane;
-                    const int sq = idx & 3, sr = (idx >> 2) % OTH, sc = idx / (4 * OTH);
-                    float* __restrict__ d4 = a.y + (((size_t)b * Cmid + (h0 + 4 * wave + sc)) * a.Ho + (oy0 + sr)) * a.Wo + ox0 + 4 * sq;
-                    if (oy0 + sr < a.Ho) *reinterpret_cast<f32x4*>(d4) = ov[i];
+                    for (int i = 0; i < NLD; ++i) {
+                        const int idx = i * 64 + lane;
+                        const int sq = idx & 3, sr = (idx >> 2) % OTH, sc = idx / (4 * OTH);
+                        ov[i] = *reinterpret_cast<const f32x4*>(stg + (sc * OTH + sr) * G::SROW + 4 * sq);
+                    }
+                    asm volatile("" ::: "memory");                                  // ... and the next pass's writes stay behind these reads
+#pragma unroll
+                    for (int i = 0; i < NLD; ++i) {
+                        const int idx = i * 64 + lane;
+                        const int sq = idx & 3, sr = (idx >> 2) % OTH, sc = idx / (4 * OTH) + G::STG_CH * ps;
+                        float* __restrict__ d4 = a.y + (((size_t)b * Cmid + (h0 + 4 * wave + sc)) * a.Ho + (oy0 + sr)) * a.Wo + ox0 + 4 * sq;
+                        if (oy0 + sr < a.Ho) *reinterpret_cast<f32x4*>(d4) = ov[i];
+                    }
                 }
             } else {
                 float* __restrict__ dst = a.y + (((size_t)b * Cmid + h) * a.Ho + oy0 + drow) * a.Wo + ox0 + dseg * G::NOUT;
