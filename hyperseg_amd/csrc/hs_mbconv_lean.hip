@@ -345,6 +345,7 @@ int try_launch_mbconv_lean(const float* x, int batch, int c_in, int H, int W, co
     if (k == K_ && stride == S_ && oth == OTH_) { \
         if (ks == 4) return launch_mbl<K_, S_, OTH_, 16, 4>(a, batch, stream); \
         if (ks == 6) return launch_mbl<K_, S_, OTH_, 16, 6>(a, batch, stream); \
+        if (ks == 8) return launch_mbl<K_, S_, OTH_, 16, 8>(a, batch, stream);      /* EfficientNet-B3's 32-channel blocks (HyperSeg-L) */ \
         if (ks == 10) return launch_mbl<K_, S_, OTH_, 16, 10>(a, batch, stream); \
         return 1; \
     }

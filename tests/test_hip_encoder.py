@@ -109,7 +109,9 @@ def test_stem_conv(HF, dev, h, w, cout, pads):
                                                    (40, 240, 5, 1, 33, 47), (40, 100, 3, 2, 31, 45), (80, 480, 3, 1, 16, 32),
                                                    (80, 200, 5, 1, 20, 36), (6, 20, 3, 1, 9, 9), (48, 40, 5, 2, 17, 40),
                                                    # round 6, the lean kernel with a ragged last tile row (CamVid: 96 x 72 and 48 x 36 maps) and whole tiles
-                                                   (24, 144, 5, 1, 72, 96), (40, 240, 3, 2, 72, 96), (24, 144, 3, 1, 40, 32), (16, 96, 3, 2, 64, 64)])
+                                                   (24, 144, 5, 1, 72, 96), (40, 240, 3, 2, 72, 96), (24, 144, 3, 1, 40, 32), (16, 96, 3, 2, 64, 64),
+                                                   # EfficientNet-B3's 32-channel blocks (HyperSeg-L)
+                                                   (32, 192, 3, 1, 32, 64), (32, 192, 5, 2, 64, 64)])
 def test_mbconv_expand_dw(HF, dev, cin, cmid, k, stride, h, w):
     """hs_mbconv_expand_dw_fwd == depthwise(zero-pad(swish(BN0(expand(x))))) -> BN1 -> swish, incl. ragged edge tiles,
     channel counts that are not multiples of the 16-channel chunk / 4-wide k-step, and the SE pooling partial sums."""
