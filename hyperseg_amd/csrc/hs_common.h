@@ -65,10 +65,17 @@ struct bf16_t { uint16_t v; };
 template <typename T> struct Store;
 template <> struct Store<float> {
     static __device__ __forceinline__ float ld(const float* p, size_t i) { return p[i]; }
+    // raw / cvt: a load whose widening is kept out of the (predicated) load itself, so that a batch of loads stays in flight together
+    typedef float raw_t;
+    static __device__ __forceinline__ raw_t raw(const float* p, size_t i) { return p[i]; }
+    static __device__ __forceinline__ float cvt(raw_t r) { return r; }
     static __device__ __forceinline__ void st(float* p, size_t i, float x) { p[i] = x; }
 };
 template <> struct Store<bf16_t> {
     static __device__ __forceinline__ float ld(const bf16_t* p, size_t i) { return __uint_as_float((uint32_t)p[i].v << 16); }
+    typedef uint32_t raw_t;           // a 16-bit raw type gets packed two to a register, which waits for each load
+    static __device__ __forceinline__ raw_t raw(const bf16_t* p, size_t i) { return p[i].v; }
+    static __device__ __forceinline__ float cvt(raw_t r) { return __uint_as_float(r << 16); }
     static __device__ __forceinline__ void st(bf16_t* p, size_t i, float x) {
         uint32_t u = __float_as_uint(x);
         if ((u & 0x7fffffffu) > 0x7f800000u) { p[i].v = (uint16_t)((u >> 16) | 0x40); return; }     // NaN stays NaN

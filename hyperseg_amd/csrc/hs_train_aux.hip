@@ -300,8 +300,17 @@ struct BnWalk {
     int e, b, p;
     __device__ __forceinline__ BnWalk(const BnArgs& a, int lo) { e = lo + (int)threadIdx.x; b = e / a.HW; p = e - b * a.HW; }
     __device__ __forceinline__ size_t at(const BnArgs& a, int c) const { return ((size_t)b * a.C + c) * a.HW + p; }
-    __device__ __forceinline__ void next(const BnArgs& a) { e += 256; p += 256; while (p >= a.HW) { p -= a.HW; ++b; } }
+    // BIG (HW >= 256: every real layer): at most one image boundary per step, taken as a select -- no branch between a batch's loads
+    template <bool BIG> __device__ __forceinline__ void next(const BnArgs& a) {
+        e += 256; p += 256;
+        if (BIG) { const bool wrap = p >= a.HW; p -= wrap ? a.HW : 0; b += wrap ? 1 : 0; }
+        else while (p >= a.HW) { p -= a.HW; ++b; }
+    }
 };
+// A slice is walked BN_BATCH elements per thread at a time: the batch's loads are all requested before the first is used (round 6: the
+// one-load-per-iteration loops waited out a full memory round trip 20 times per thread at config 5's level 4: 9-11 us per launch for
+// 13 MB); a thread still takes its elements in the same order, so every sum is bit-identical to the serial walk's.
+constexpr int BN_BATCH = 8;
 __device__ __forceinline__ void bn_block_sum2(float& s0, float& s1, float (*red)[2]) {
     s0 = wave_sum64(s0); s1 = wave_sum64(s1);
     const int wave = threadIdx.x >> 6;
@@ -309,6 +318,21 @@ __device__ __forceinline__ void bn_block_sum2(float& s0, float& s1, float (*red)
     __syncthreads();
     s0 = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
     s1 = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+}
+
+template <typename T, bool BIG>
+__device__ __forceinline__ void bn_stats_walk(const BnArgs& a, const T* __restrict__ x, int c, int lo, int hi, float shift, float& s, float& q) {
+    for (BnWalk w(a, lo); w.e < hi;) {
+        typename Store<T>::raw_t v[BN_BATCH];
+        const int e0 = w.e;
+        const size_t at0 = (size_t)c * a.HW;        // the channel's first element: what a lane past the slice's end loads instead (unpredicated: a
+                                                    // predicated 16-bit load drags its widening, and with it a wait, into the branch)
+#pragma unroll
+        for (int u = 0; u < BN_BATCH; ++u) { v[u] = Store<T>::raw(x, w.e < hi ? w.at(a, c) : at0); w.template next<BIG>(a); }
+#pragma unroll
+        for (int u = 0; u < BN_BATCH; ++u)
+            if (e0 + 256 * u < hi) { const float d = Store<T>::cvt(v[u]) - shift; s += d; q = fmaf(d, d, q); }
+    }
 }
 
 template <typename T>
@@ -320,10 +344,8 @@ void bn_stats_kernel(BnArgs a, const T* __restrict__ x, float* __restrict__ part
     int lo, hi;
     bn_slice(a, chunk, lo, hi);
     float s = 0.f, q = 0.f;
-    for (BnWalk w(a, lo); w.e < hi; w.next(a)) {
-        const float d = Store<T>::ld(x, w.at(a, c)) - shift;
-        s += d; q = fmaf(d, d, q);
-    }
+    if (a.HW >= 256) bn_stats_walk<T, true>(a, x, c, lo, hi, shift, s, q);
+    else bn_stats_walk<T, false>(a, x, c, lo, hi, shift, s, q);
     bn_block_sum2(s, q, red);
     if (threadIdx.x == 0) { partial[((size_t)c * BN_CHUNKS + chunk) * 2] = s; partial[((size_t)c * BN_CHUNKS + chunk) * 2 + 1] = q; }
 }
@@ -331,6 +353,22 @@ void bn_stats_kernel(BnArgs a, const T* __restrict__ x, float* __restrict__ part
 __device__ __forceinline__ float bn_act(float z, int act) { return act == HS_ACT_RELU ? fmaxf(z, 0.f) : (act == HS_ACT_RELU6 ? fminf(fmaxf(z, 0.f), 6.f) : z); }
 __device__ __forceinline__ float bn_act_grad(float z, int act) {
     return act == HS_ACT_RELU ? (z > 0.f ? 1.f : 0.f) : (act == HS_ACT_RELU6 ? ((z > 0.f && z < 6.f) ? 1.f : 0.f) : 1.f);
+}
+
+template <typename T, bool BIG>
+__device__ __forceinline__ void bn_apply_walk(const BnArgs& a, const T* __restrict__ x, T* __restrict__ y, int c, int lo, int hi, float g, float bb) {
+    for (BnWalk w(a, lo); w.e < hi;) {
+        typename Store<T>::raw_t v[BN_BATCH];
+        size_t at[BN_BATCH];
+        const int e0 = w.e;
+        const size_t at0 = (size_t)c * a.HW;        // the channel's first element: what a lane past the slice's end loads instead (unpredicated: a
+                                                    // predicated 16-bit load drags its widening, and with it a wait, into the branch)
+#pragma unroll
+        for (int u = 0; u < BN_BATCH; ++u) { at[u] = w.e < hi ? w.at(a, c) : at0; v[u] = Store<T>::raw(x, at[u]); w.template next<BIG>(a); }
+#pragma unroll
+        for (int u = 0; u < BN_BATCH; ++u)
+            if (e0 + 256 * u < hi) Store<T>::st(y, at[u], bn_act(fmaf(Store<T>::cvt(v[u]), g, bb), a.act));
+    }
 }
 
 template <typename T>
@@ -355,9 +393,34 @@ void bn_apply_kernel(BnArgs a, const T* __restrict__ x, const float* __restrict_
     const float g = gamma ? gamma[c] * invstd : invstd, bb = (beta ? beta[c] : 0.f) - mean * g;
     int lo, hi;
     bn_slice(a, chunk, lo, hi);
-    for (BnWalk w(a, lo); w.e < hi; w.next(a)) {
-        const size_t i = w.at(a, c);
-        Store<T>::st(y, i, bn_act(fmaf(Store<T>::ld(x, i), g, bb), a.act));
+    if (a.HW >= 256) bn_apply_walk<T, true>(a, x, y, c, lo, hi, g, bb);
+    else bn_apply_walk<T, false>(a, x, y, c, lo, hi, g, bb);
+}
+
+// the backward pair's walk: APPLY false -> the two sums (s, q), APPLY true -> dx from the finished sums (k0, ms, mq)
+template <typename T, bool BIG, bool APPLY>
+__device__ __forceinline__ void bn_bwd_walk(const BnArgs& a, const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int c, int lo,
+                                            int hi, float mean, float invstd, float g, float bb, float k0, float ms, float mq, float& s, float& q) {
+    for (BnWalk w(a, lo); w.e < hi;) {
+        typename Store<T>::raw_t vx[BN_BATCH], vd[BN_BATCH];
+        size_t at[BN_BATCH];
+        const int e0 = w.e;
+        const size_t at0 = (size_t)c * a.HW;        // the channel's first element: what a lane past the slice's end loads instead (unpredicated: a
+                                                    // predicated 16-bit load drags its widening, and with it a wait, into the branch)
+#pragma unroll
+        for (int u = 0; u < BN_BATCH; ++u) {
+            at[u] = w.e < hi ? w.at(a, c) : at0;
+            vx[u] = Store<T>::raw(x, at[u]); vd[u] = Store<T>::raw(dy, at[u]);
+            w.template next<BIG>(a);
+        }
+#pragma unroll
+        for (int u = 0; u < BN_BATCH; ++u)
+            if (e0 + 256 * u < hi) {
+                const float xh = (Store<T>::cvt(vx[u]) - mean) * invstd;
+                const float d = Store<T>::cvt(vd[u]) * bn_act_grad(fmaf(xh, g, bb), a.act);
+                if (APPLY) Store<T>::st(dx, at[u], k0 * (d - ms - xh * mq));
+                else { s += d; q = fmaf(d, xh, q); }
+            }
     }
 }
 
@@ -372,12 +435,8 @@ void bn_bwd_stats_kernel(BnArgs a, const T* __restrict__ x, const T* __restrict_
     int lo, hi;
     bn_slice(a, chunk, lo, hi);
     float s = 0.f, q = 0.f;
-    for (BnWalk w(a, lo); w.e < hi; w.next(a)) {
-        const size_t i = w.at(a, c);
-        const float xh = (Store<T>::ld(x, i) - mean) * invstd;
-        const float d = Store<T>::ld(dy, i) * bn_act_grad(fmaf(xh, g, bb), a.act);
-        s += d; q = fmaf(d, xh, q);
-    }
+    if (a.HW >= 256) bn_bwd_walk<T, true, false>(a, x, dy, (T*)nullptr, c, lo, hi, mean, invstd, g, bb, 0.f, 0.f, 0.f, s, q);
+    else bn_bwd_walk<T, false, false>(a, x, dy, (T*)nullptr, c, lo, hi, mean, invstd, g, bb, 0.f, 0.f, 0.f, s, q);
     bn_block_sum2(s, q, red);
     if (threadIdx.x == 0) { partial[((size_t)c * BN_CHUNKS + chunk) * 2] = s; partial[((size_t)c * BN_CHUNKS + chunk) * 2 + 1] = q; }
 }
@@ -397,12 +456,9 @@ void bn_bwd_apply_kernel(BnArgs a, const T* __restrict__ x, const T* __restrict_
     const float k0 = g * invstd, ms = s / n, mq = q / n;
     int lo, hi;
     bn_slice(a, chunk, lo, hi);
-    for (BnWalk w(a, lo); w.e < hi; w.next(a)) {
-        const size_t i = w.at(a, c);
-        const float xh = (Store<T>::ld(x, i) - mean) * invstd;
-        const float d = Store<T>::ld(dy, i) * bn_act_grad(fmaf(xh, g, bb), a.act);
-        Store<T>::st(dx, i, k0 * (d - ms - xh * mq));
-    }
+    float u0 = 0.f, u1 = 0.f;
+    if (a.HW >= 256) bn_bwd_walk<T, true, true>(a, x, dy, dx, c, lo, hi, mean, invstd, g, bb, k0, ms, mq, u0, u1);
+    else bn_bwd_walk<T, false, true>(a, x, dy, dx, c, lo, hi, mean, invstd, g, bb, k0, ms, mq, u0, u1);
 }
 
 // Small channels (B HW <= BN_SMALL_MAX = 16 x 1024 elements: the k = 1 levels at config 5) in ONE launch per direction: a workgroup of 1024
