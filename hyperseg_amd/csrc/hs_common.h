@@ -69,6 +69,7 @@ template <> struct Store<float> {
     typedef float raw_t;
     static __device__ __forceinline__ raw_t raw(const float* p, size_t i) { return p[i]; }
     static __device__ __forceinline__ float cvt(raw_t r) { return r; }
+    static __device__ __forceinline__ void pin(raw_t&) {}
     static __device__ __forceinline__ void st(float* p, size_t i, float x) { p[i] = x; }
 };
 template <> struct Store<bf16_t> {
@@ -76,12 +77,30 @@ template <> struct Store<bf16_t> {
     typedef uint32_t raw_t;           // a 16-bit raw type gets packed two to a register, which waits for each load
     static __device__ __forceinline__ raw_t raw(const bf16_t* p, size_t i) { return p[i].v; }
     static __device__ __forceinline__ float cvt(raw_t r) { return __uint_as_float(r << 16); }
+    // pin: keeps the widening on this side of a predicated load's branch (the compiler otherwise moves the shift -- and a wait -- into it)
+    static __device__ __forceinline__ void pin(raw_t& r) { asm volatile("" : "+v"(r)); }
     static __device__ __forceinline__ void st(bf16_t* p, size_t i, float x) {
         uint32_t u = __float_as_uint(x);
         if ((u & 0x7fffffffu) > 0x7f800000u) { p[i].v = (uint16_t)((u >> 16) | 0x40); return; }     // NaN stays NaN
         u += 0x7fffu + ((u >> 16) & 1u);                                                           // round to nearest even
         p[i].v = (uint16_t)(u >> 16);
     }
+};
+
+// two adjacent elements as one aligned load / store (the address must be a multiple of two elements)
+using bw_f32x2 = __attribute__((ext_vector_type(2))) float;
+template <typename T> struct Pair;
+template <> struct Pair<float> {
+    static __device__ __forceinline__ void ld(const float* p, size_t i, float& a, float& b) {
+        const bw_f32x2 v = *reinterpret_cast<const bw_f32x2*>(p + i); a = v[0]; b = v[1];
+    }
+    static __device__ __forceinline__ void st(float* p, size_t i, float a, float b) { *reinterpret_cast<bw_f32x2*>(p + i) = bw_f32x2{a, b}; }
+};
+template <> struct Pair<bf16_t> {
+    static __device__ __forceinline__ void ld(const bf16_t* p, size_t i, float& a, float& b) {
+        const uint32_t v = *reinterpret_cast<const uint32_t*>(p + i); a = __uint_as_float(v << 16); b = __uint_as_float(v & 0xffff0000u);
+    }
+    static __device__ __forceinline__ void st(bf16_t* p, size_t i, float a, float b) { Store<bf16_t>::st(p, i, a); Store<bf16_t>::st(p, i + 1, b); }
 };
 
 // Slices a training-mode BatchNorm channel is cut into: partial[(c * BN_CHUNKS + chunk) * 2 + {0, 1}] = {sum, sum of squares} of

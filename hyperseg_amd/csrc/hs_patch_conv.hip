@@ -435,11 +435,18 @@ __global__ void stage_input_kernel(StageIn s, TO* __restrict__ y) {
 template <typename TP, typename TO>
 __global__ __launch_bounds__(256)
 void stage_input_plane_kernel(StageIn s, TO* __restrict__ y) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), yy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= s.W || yy >= s.H) return;
+    // four rows per thread (yy0, + 4, + 8, + 12), their taps requested before the first store (round 6: one element per thread ran at
+    // 1.9 TB/s on config 5's level 4)
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), yy0 = blockIdx.y * 16 + (threadIdx.x >> 6);
+    if (x >= s.W || yy0 >= s.H) return;
     const int plane = blockIdx.z, cin = s.cin();
     const int b = plane / cin, c = plane - b * cin;                       // (uniform)
-    Store<TO>::st(y, ((size_t)plane * s.H + yy) * s.W + x, stage_value<TP>(s, b, c, stage_pos(s, yy, x)));
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = stage_value<TP>(s, b, c, stage_pos(s, min(yy0 + 4 * r, s.H - 1), x));
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (yy0 + 4 * r < s.H) Store<TO>::st(y, ((size_t)plane * s.H + yy0 + 4 * r) * s.W + x, v[r]);
 }
 
 // Bilinear resize (align_corners=False).  One thread = 4 consecutive output pixels of a row; bilinear_row4 is shared by
@@ -697,7 +704,7 @@ extern "C" int hs_stage_input_typed_fwd(const hs_stage_input* in, int32_t prev_d
     const dim3 blocks((unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256));
     hipStream_t q = (hipStream_t)stream;
     if ((long)s.B * s.cin() <= 65535) {
-        const dim3 g2((s.W + 63) / 64, (s.H + 3) / 4, s.B * s.cin());
+        const dim3 g2((s.W + 63) / 64, (s.H + 15) / 16, s.B * s.cin());            // four rows per thread
         if (prev_dtype == HS_DTYPE_F32 && out_dtype == HS_DTYPE_F32) hipLaunchKernelGGL((stage_input_plane_kernel<float, float>), g2, dim3(256), 0, q, s, (float*)y);
         else if (prev_dtype == HS_DTYPE_F32) hipLaunchKernelGGL((stage_input_plane_kernel<float, bf16_t>), g2, dim3(256), 0, q, s, (bf16_t*)y);
         else if (out_dtype == HS_DTYPE_F32) hipLaunchKernelGGL((stage_input_plane_kernel<bf16_t, float>), g2, dim3(256), 0, q, s, (float*)y);

@@ -134,21 +134,8 @@ void patch_conv_bwd_weight_kernel(ConvBwdArgs a, int ob) {
 // everything else (k > 1, groups, patches that are not a multiple of 16 pixels / 4 columns, very wide layers).
 // ---------------------------------------------------------------------------------------------------------------------------------
 using bw_f32x4 = __attribute__((ext_vector_type(4))) float;
-using bw_f32x2 = __attribute__((ext_vector_type(2))) float;
 // two adjacent elements as one aligned access (8 bytes fp32, 4 bytes bf16)
-template <typename T> struct Pair;
-template <> struct Pair<float> {
-    static __device__ __forceinline__ void ld(const float* p, size_t i, float& a, float& b) {
-        const bw_f32x2 v = *reinterpret_cast<const bw_f32x2*>(p + i); a = v[0]; b = v[1];
-    }
-    static __device__ __forceinline__ void st(float* p, size_t i, float a, float b) { *reinterpret_cast<bw_f32x2*>(p + i) = bw_f32x2{a, b}; }
-};
-template <> struct Pair<bf16_t> {
-    static __device__ __forceinline__ void ld(const bf16_t* p, size_t i, float& a, float& b) {
-        const uint32_t v = *reinterpret_cast<const uint32_t*>(p + i); a = __uint_as_float(v << 16); b = __uint_as_float(v & 0xffff0000u);
-    }
-    static __device__ __forceinline__ void st(bf16_t* p, size_t i, float a, float b) { Store<bf16_t>::st(p, i, a); Store<bf16_t>::st(p, i + 1, b); }
-};
+// Pair<T> (two adjacent elements, one aligned load / store): hs_common.h
 
 
 // VEC: patches whose rows are whole 4-pixel groups on 16-byte boundaries and whose pixel count is a multiple of 16.  Otherwise (the
@@ -926,23 +913,26 @@ void dw_tiles_fwd_kernel(DwtArgs a, DwtBn n, const T* __restrict__ t, T* __restr
 }
 
 // dt[tile position (U, V)] = sum_{ky,kx} K[ky][kx] dy[U - ky][V - kx] over the patch's own outputs (0 <= U - ky < ph, 0 <= V - kx < pw)
-template <typename T>
+// RPT: tile rows per thread (2 where the patch height is even: rows U, U + 1 of one tile share three of the four output rows they read and
+// the nine taps -- 8 pair loads + 9 tap loads for 4 values instead of 12 + 18, half the workgroups; round 6: the one-row form ran at
+// 2.1 TB/s at config 5's level 4, 1.2 TB/s at level 3).  Per value the same fma chain (ky, then kx) as before: bit-identical.
+template <typename T, int RPT = 1>
 __global__ __launch_bounds__(256)
 void dw_tiles_bwd_in_kernel(DwtArgs a, const T* __restrict__ dy, T* __restrict__ dt) {
     const int TW = a.fw * (a.pw + 2), TH = a.fh * (a.ph + 2);
-    const int X0 = 2 * (blockIdx.x * 64 + (threadIdx.x & 63)), Y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int X0 = 2 * (blockIdx.x * 64 + (threadIdx.x & 63)), Y = RPT * (blockIdx.y * 4 + (threadIdx.x >> 6));
     const int plane_id = blockIdx.z;
     if (X0 >= TW || Y >= TH) return;
     const int b = div_by_inv(plane_id, a.inv_c), c = plane_id - b * a.C;
     const int i = div_by_inv(Y, a.inv_ph2), U = Y - i * (a.ph + 2), j = div_by_inv(X0, a.inv_pw2), V0 = X0 - j * (a.pw + 2);
     const T* __restrict__ gp = dy + ((size_t)plane_id * a.H + (size_t)i * a.ph) * a.W + (size_t)j * a.pw;       // the patch's (0, 0) output
     const float* __restrict__ kp = a.bank + (size_t)((b * a.fh + i) * a.fw + j) * a.ld + c * 9;
-    // rows U - 2 .. U, columns V0 - 2 .. V0 + 1 of the patch's outputs: two aligned pairs per row, each wholly inside or wholly outside
+    // rows U - 2 .. U + RPT - 1, columns V0 - 2 .. V0 + 1 of the patch's outputs: two aligned pairs per row, each wholly inside or wholly outside
     const bool left = V0 >= 2, right = V0 <= a.pw - 2;
     const int cl = left ? V0 - 2 : 0, cr = right ? V0 : 0;
-    float g[3][4], kv[9];
+    float g[2 + RPT][4], kv[9];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {                                     // r <-> output row U - 2 + r
+    for (int r = 0; r < 2 + RPT; ++r) {                               // r <-> output row U - 2 + r
         const int ur = U - 2 + r;
         const bool row_in = ur >= 0 && ur < a.ph;
         const size_t rb = (size_t)min(max(ur, 0), a.ph - 1) * a.W;
@@ -954,28 +944,37 @@ void dw_tiles_bwd_in_kernel(DwtArgs a, const T* __restrict__ dy, T* __restrict__
     }
 #pragma unroll
     for (int q = 0; q < 9; ++q) kv[q] = kp[q];
-    float acc0 = 0.0f, acc1 = 0.0f;
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {                              // output (U - ky, V - kx): row index 2 - ky, column index V - kx - (V0 - 2)
-            acc0 = fmaf(kv[ky * 3 + kx], g[2 - ky][2 - kx], acc0);
-            acc1 = fmaf(kv[ky * 3 + kx], g[2 - ky][3 - kx], acc1);
-        }
     int RS;
     const size_t torg = dwt_tile(a, b, c, i, j, RS);
-    Pair<T>::st(dt, torg + (size_t)U * RS + V0, acc0, acc1);
+#pragma unroll
+    for (int ro = 0; ro < RPT; ++ro) {
+        float acc0 = 0.0f, acc1 = 0.0f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {                          // output (U + ro - ky, V - kx): row index 2 + ro - ky, column index V - kx - (V0 - 2)
+                acc0 = fmaf(kv[ky * 3 + kx], g[2 + ro - ky][2 - kx], acc0);
+                acc1 = fmaf(kv[ky * 3 + kx], g[2 + ro - ky][3 - kx], acc1);
+            }
+        Pair<T>::st(dt, torg + (size_t)(U + ro) * RS + V0, acc0, acc1);
+    }
 }
 
 // dK[patch][c][ky][kx] = sum over the patch's outputs (u, v) of dy[u][v] t[u + ky][v + kx]: one wave per (patch, channel), a lane owns output pairs
 // RPT: output rows per lane and iteration (2 where the patch height is even: 16 tile values normalised for 4 output gradients instead of
 // 24; both the plain and the BN form take the same RPT for a shape, so they stay bit-equal to each other)
-template <typename T, bool BN, int RPT = 1>
+// ROWS (round 6): a patch of <= 16 element pairs per thread pass (8 x 8 patches at RPT = 2: config 5's level 3) left 48 of a wave's 64 lanes
+// idle and paid nine 64-lane reductions per (patch, channel); with ROWS each row of 16 lanes takes a channel of its own -- four channels per
+// wave, a 16-lane reduction (rowsum16: the very sums wave_sum64 forms from a wave whose other rows hold zeros, so dbank is bit-identical).
+template <typename T, bool BN, int RPT = 1, bool ROWS = false>
 __global__ __launch_bounds__(256)
 void dw_tiles_bwd_w_kernel(DwtArgs a, DwtBn n, const T* __restrict__ t, const T* __restrict__ dy) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int patch = blockIdx.x, c = blockIdx.y * 4 + wave;
-    if (c >= a.C) return;
+    constexpr int LPC = ROWS ? 16 : 64;                              // lanes per channel
+    const int lane = threadIdx.x & (LPC - 1), wave = threadIdx.x >> 6;
+    const int patch = blockIdx.x, cw = ROWS ? (blockIdx.y * 4 + wave) * 4 + (int)((threadIdx.x & 63) >> 4) : blockIdx.y * 4 + wave;
+    if (!ROWS && cw >= a.C) return;
+    const bool live = cw < a.C;                                      // ROWS: a row past the last channel works on the last one and writes nothing
+    const int c = live ? cw : a.C - 1;
     const int j = patch % a.fw, i = (patch / a.fw) % a.fh, b = patch / (a.fw * a.fh);
     float g = 1.0f, bb = 0.0f;
     if constexpr (BN) {                                              // the saved statistics: the tiles are normalised on load, as in the forward
@@ -989,7 +988,7 @@ void dw_tiles_bwd_w_kernel(DwtArgs a, DwtBn n, const T* __restrict__ t, const T*
     const int hw = a.pw >> 1, npair = (a.ph / RPT) * hw;
     const float inv_hw = 2.0f * a.inv_pw;
     float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int l = lane; l < npair; l += 64) {
+    for (int l = lane; l < npair; l += LPC) {
         const int ur = div_by_inv(l, inv_hw), u = RPT * ur, v = 2 * (l - ur * hw);
         float g0[RPT], g1[RPT], s[2 + RPT][4];
 #pragma unroll
@@ -1018,8 +1017,8 @@ void dw_tiles_bwd_w_kernel(DwtArgs a, DwtBn n, const T* __restrict__ t, const T*
     float* __restrict__ dst = a.dbank + (size_t)patch * a.ld + c * 9;
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
-        const float sum = wave_sum64(acc[q]);
-        if (lane == 0) dst[q] = sum;
+        const float sum = ROWS ? rowsum16(acc[q]) : wave_sum64(acc[q]);
+        if (lane == 0 && live) dst[q] = sum;
     }
 }
 
@@ -1315,9 +1314,15 @@ extern "C" int hs_dw_tiles_bwd_in(int32_t dtype, const void* dy, const float* ba
     if (st != HS_OK) return st;
     if (!bank) return HS_ERR_BAD_ARG;
     a.bank = bank;
+    if ((a.ph & 1) == 0) {                 // two tile rows per thread: they share a tile (ph + 2 is even)
+        const dim3 grid2((fw * (a.pw + 2) / 2 + 63) / 64, (fh * (a.ph + 2) / 2 + 3) / 4, batch * channels);
+        if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_bwd_in_kernel<float, 2>), grid2, dim3(256), 0, (hipStream_t)stream, a, (const float*)dy, (float*)dtiled);
+        else hipLaunchKernelGGL((dw_tiles_bwd_in_kernel<bf16_t, 2>), grid2, dim3(256), 0, (hipStream_t)stream, a, (const bf16_t*)dy, (bf16_t*)dtiled);
+        return launch_status();
+    }
     const dim3 grid((fw * (a.pw + 2) / 2 + 63) / 64, (fh * (a.ph + 2) + 3) / 4, batch * channels);
-    if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL(dw_tiles_bwd_in_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a, (const float*)dy, (float*)dtiled);
-    else hipLaunchKernelGGL(dw_tiles_bwd_in_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, a, (const bf16_t*)dy, (bf16_t*)dtiled);
+    if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_bwd_in_kernel<float, 1>), grid, dim3(256), 0, (hipStream_t)stream, a, (const float*)dy, (float*)dtiled);
+    else hipLaunchKernelGGL((dw_tiles_bwd_in_kernel<bf16_t, 1>), grid, dim3(256), 0, (hipStream_t)stream, a, (const bf16_t*)dy, (bf16_t*)dtiled);
     return launch_status();
 }
 
@@ -1329,7 +1334,11 @@ extern "C" int hs_dw_tiles_bwd_w(int32_t dtype, const void* tiled, const void* d
     if (!dbank) return HS_ERR_BAD_ARG;
     a.dbank = dbank;
     const dim3 grid((unsigned)(batch * fh * fw), (channels + 3) / 4);
-    if ((a.ph & 1) == 0) {
+    if ((a.ph & 1) == 0 && (a.ph / 2) * (a.pw / 2) <= 16) {                  // a channel per row of 16 lanes
+        const dim3 gridr((unsigned)(batch * fh * fw), (channels + 15) / 16);
+        if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<float, false, 2, true>), gridr, dim3(256), 0, (hipStream_t)stream, a, DwtBn{}, (const float*)tiled, (const float*)dy);
+        else hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<bf16_t, false, 2, true>), gridr, dim3(256), 0, (hipStream_t)stream, a, DwtBn{}, (const bf16_t*)tiled, (const bf16_t*)dy);
+    } else if ((a.ph & 1) == 0) {
         if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<float, false, 2>), grid, dim3(256), 0, (hipStream_t)stream, a, DwtBn{}, (const float*)tiled, (const float*)dy);
         else hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<bf16_t, false, 2>), grid, dim3(256), 0, (hipStream_t)stream, a, DwtBn{}, (const bf16_t*)tiled, (const bf16_t*)dy);
     } else if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<float, false>), grid, dim3(256), 0, (hipStream_t)stream, a, DwtBn{}, (const float*)tiled, (const float*)dy);
@@ -1348,7 +1357,11 @@ extern "C" int hs_dw_tiles_bn_bwd_w(int32_t dtype, const void* tiled, const void
     a.dbank = dbank;
     DwtBn n{nullptr, gamma, beta, const_cast<float*>(save_mean), const_cast<float*>(save_invstd), nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0, act};
     const dim3 grid((unsigned)(batch * fh * fw), (channels + 3) / 4);
-    if ((a.ph & 1) == 0) {
+    if ((a.ph & 1) == 0 && (a.ph / 2) * (a.pw / 2) <= 16) {                  // a channel per row of 16 lanes
+        const dim3 gridr((unsigned)(batch * fh * fw), (channels + 15) / 16);
+        if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<float, true, 2, true>), gridr, dim3(256), 0, (hipStream_t)stream, a, n, (const float*)tiled, (const float*)dy);
+        else hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<bf16_t, true, 2, true>), gridr, dim3(256), 0, (hipStream_t)stream, a, n, (const bf16_t*)tiled, (const bf16_t*)dy);
+    } else if ((a.ph & 1) == 0) {
         if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<float, true, 2>), grid, dim3(256), 0, (hipStream_t)stream, a, n, (const float*)tiled, (const float*)dy);
         else hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<bf16_t, true, 2>), grid, dim3(256), 0, (hipStream_t)stream, a, n, (const bf16_t*)tiled, (const bf16_t*)dy);
     } else if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<float, true>), grid, dim3(256), 0, (hipStream_t)stream, a, n, (const float*)tiled, (const float*)dy);

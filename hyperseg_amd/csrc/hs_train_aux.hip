@@ -40,13 +40,26 @@ __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >
 template <typename T>
 __global__ __launch_bounds__(256)
 void halo_tiles_fwd_kernel(TileArgs a, const T* __restrict__ x, T* __restrict__ t) {
+    // four tile rows per thread (Y, Y + 4, Y + 8, Y + 12: a wave still walks 64 consecutive columns of one row), their loads requested together;
+    // the column arithmetic is shared (round 6: one element per thread -- 21 k workgroups of a load and a store each -- ran at 2.2 TB/s)
     const int TW = a.fw * (a.pw + 2), TH = a.fh * (a.ph + 2);
-    const int X = blockIdx.x * 64 + (threadIdx.x & 63), Y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (X >= TW || Y >= TH) return;
-    const int i = div_by_inv(Y, a.inv_ph2), u = Y - i * (a.ph + 2), j = div_by_inv(X, a.inv_pw2), v = X - j * (a.pw + 2);
-    const int y = reflect1(i * a.ph + u - 1, a.H), xx = reflect1(j * a.pw + v - 1, a.W);
+    const int X = blockIdx.x * 64 + (threadIdx.x & 63), Y0 = blockIdx.y * 16 + (threadIdx.x >> 6);
+    if (X >= TW || Y0 >= TH) return;
+    const int j = div_by_inv(X, a.inv_pw2), v = X - j * (a.pw + 2), xx = reflect1(j * a.pw + v - 1, a.W);
     const size_t pl = blockIdx.z;
-    Store<T>::st(t, tile_addr(a, tile_plane(a, pl), i, u, j, v), Store<T>::ld(x, (pl * a.H + y) * a.W + xx));
+    const TilePlane tp = tile_plane(a, pl);
+    typename Store<T>::raw_t val[4];
+    size_t dst[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int Y = min(Y0 + 4 * r, TH - 1);                        // a row past the end repeats the last one (and is not stored)
+        const int i = div_by_inv(Y, a.inv_ph2), u = Y - i * (a.ph + 2), y = reflect1(i * a.ph + u - 1, a.H);
+        val[r] = Store<T>::raw(x, (pl * a.H + y) * a.W + xx);
+        dst[r] = tile_addr(a, tp, i, u, j, v);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (Y0 + 4 * r < TH) Store<T>::st(t, dst[r], Store<T>::cvt(val[r]));
 }
 
 // candidates (tile index, position inside the tile) of one axis that map onto image index y: every padded coordinate that reflects
@@ -78,6 +91,9 @@ __device__ __forceinline__ int tile_sources_p2(int y, int n, int p, float inv_p,
     return cnt;                                                         // <= 3: y == 1 or n - 2 is a first / last row only when p == 2, f == 1
 }
 
+// (Round 6, visits x3 / x4: two forms with the candidate loads in flight together -- 2 x 2 unpredicated loads per pixel; four rows per thread with
+//  shared column parts, 32-bit offsets and predicated loads -- both measured SLOWER on config 5 (23.0 -> 45.6 / 38.4 us at level 4, 10.0 -> 34.2 /
+//  32.5 us at level 3) although they execute fewer instructions and wait once; the serial form below stays.  profiles/round6_train_*_x3/x4.)
 template <typename T>
 __global__ __launch_bounds__(256)
 void halo_tiles_bwd_kernel(TileArgs a, const T* __restrict__ dt, T* __restrict__ dx) {
@@ -214,10 +230,43 @@ void bm_hist_kernel(const float* __restrict__ v, int n, unsigned* __restrict__ w
         if (h[i]) atomicAdd(&g[i], h[i]);
 }
 
+// out[0] = the image's loss; out[1] = branch (1: everything above thresh, 0: the k largest), out[2] = 1 / count or 1 / k,
+// out[3] = t, out[4] = weight of a loss equal to t (the k-th largest may be tied).  One wave; lane 0 writes.  `partial` may have been written by
+// other workgroups of the SAME launch (bm_sums_kernel's tail): read past this CU's L1.
+__device__ __forceinline__ float bm_final_body(const float* __restrict__ partial, int nwg, const unsigned* __restrict__ ws, int k, float thresh,
+                                               float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    float s_thr = 0.f, c_thr = 0.f, s_top = 0.f, c_eq = 0.f;
+    for (int i = lane; i < nwg; i += 64) {
+        s_thr += __hip_atomic_load(partial + 4 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c_thr += __hip_atomic_load(partial + 4 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_top += __hip_atomic_load(partial + 4 * i + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c_eq += __hip_atomic_load(partial + 4 * i + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_thr = wave_sum64(s_thr); c_thr = wave_sum64(c_thr); s_top = wave_sum64(s_top); c_eq = wave_sum64(c_eq);
+    const float t = __uint_as_float(__hip_atomic_load(ws + BM_STATE + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const float c_gt = (float)__hip_atomic_load(ws + BM_STATE + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float o0, o1, o2, o3, o4;
+    if (c_thr > (float)k) {                    // the (k+1)-th largest exceeds thresh exactly when more than k losses do
+        o0 = s_thr / c_thr; o1 = 1.0f; o2 = 1.0f / c_thr; o3 = thresh; o4 = 0.0f;
+    } else {
+        const float ties = (float)k - c_gt;    // how many of the losses equal to t belong to the k largest
+        o0 = (s_top + ties * t) / (float)k; o1 = 0.0f; o2 = 1.0f / (float)k; o3 = t;
+        o4 = c_eq > 0.0f ? ties / c_eq : 0.0f;
+    }
+    if (lane == 0) { out[0] = o0; out[1] = o1; out[2] = o2; out[3] = o3; out[4] = o4; }
+    return o0;
+}
+
+// Round 6: the per-image final and the batch mean run in the TAIL of this launch -- the workgroup that finishes last (a counter in image 0's state
+// word 7, which the tail returns to zero) combines every image's partial sums in workgroup order, exactly as the two one-workgroup launches it
+// replaces did (bm_final_kernel, bm_batch_mean_kernel: ~5 us each at the step's launch floor).
 __global__ __launch_bounds__(256)
-void bm_sums_kernel(const float* __restrict__ v, int n, float thresh, unsigned* __restrict__ ws, float* __restrict__ partial, int k) {
+void bm_sums_kernel(const float* __restrict__ v, int n, float thresh, unsigned* __restrict__ ws, float* __restrict__ partial, int k,
+                    float* __restrict__ out8, float* __restrict__ mean_out) {
     __shared__ float red[4][4];
     __shared__ unsigned part[4], sel[4];
+    unsigned* const ws0 = ws; float* const partial0 = partial;
     v += (size_t)blockIdx.y * n; ws += (size_t)blockIdx.y * BM_WS_U32; partial += (size_t)blockIdx.y * BM_WS_U32;
     unsigned tbits, above;
     bm_find_body(ws, 2, k, part, sel, tbits, above);                    // the last level's bin walk: t and the count above it
@@ -238,37 +287,24 @@ void bm_sums_kernel(const float* __restrict__ v, int n, float thresh, unsigned* 
     __syncthreads();
     if (threadIdx.x < 4)
         partial[blockIdx.x * 4 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-}
-
-// out[0] = the image's loss; out[1] = branch (1: everything above thresh, 0: the k largest), out[2] = 1 / count or 1 / k,
-// out[3] = t, out[4] = weight of a loss equal to t (the k-th largest may be tied)
-__global__ __launch_bounds__(64)
-void bm_final_kernel(const float* __restrict__ partial, int nwg, const unsigned* __restrict__ ws, int k, float thresh,
-                     float* __restrict__ out) {
-    partial += (size_t)blockIdx.y * BM_WS_U32; ws += (size_t)blockIdx.y * BM_WS_U32; out += (size_t)blockIdx.y * 8;
-    float s_thr = 0.f, c_thr = 0.f, s_top = 0.f, c_eq = 0.f;
-    for (int i = threadIdx.x; i < nwg; i += 64) { s_thr += partial[4 * i]; c_thr += partial[4 * i + 1]; s_top += partial[4 * i + 2]; c_eq += partial[4 * i + 3]; }
-    s_thr = wave_sum64(s_thr); c_thr = wave_sum64(c_thr); s_top = wave_sum64(s_top); c_eq = wave_sum64(c_eq);
-    if (threadIdx.x != 0) return;
-    const float t = __uint_as_float(ws[BM_STATE + 4]);
-    const float c_gt = (float)ws[BM_STATE + 5];
-    if (c_thr > (float)k) {                    // the (k+1)-th largest exceeds thresh exactly when more than k losses do
-        out[0] = s_thr / c_thr; out[1] = 1.0f; out[2] = 1.0f / c_thr; out[3] = thresh; out[4] = 0.0f;
-    } else {
-        const float ties = (float)k - c_gt;    // how many of the losses equal to t belong to the k largest
-        out[0] = (s_top + ties * t) / (float)k; out[1] = 0.0f; out[2] = 1.0f / (float)k; out[3] = t;
-        out[4] = c_eq > 0.0f ? ties / c_eq : 0.0f;
+    // ---- tail: the last workgroup of the launch finishes every image
+    __threadfence();                                                    // this workgroup's partial sums (and workgroup 0's state pair) before its ticket
+    __syncthreads();
+    if (threadIdx.x == 0) sel[0] = atomicAdd(ws0 + BM_STATE + 7, 1u);
+    __syncthreads();
+    if (sel[0] != gridDim.x * gridDim.y - 1 || threadIdx.x >= 64) return;
+    __threadfence();
+    const int images = gridDim.y;
+    float mean = 0.0f;
+    for (int i = 0; i < images; ++i)
+        mean += bm_final_body(partial0 + (size_t)i * BM_WS_U32, (int)gridDim.x, ws0 + (size_t)i * BM_WS_U32, k, thresh, out8 + (size_t)i * 8);
+    if (threadIdx.x == 0) {
+        if (mean_out) mean_out[0] = mean / (float)images;
+        ws0[BM_STATE + 7] = 0u;                                         // the next call finds its counter at zero without a memset of its own
     }
 }
 
 // gout_stride 1: one upstream gradient per image; 0: ONE gradient of the batch mean (scale = 1 / images)
-// the mean of the per-image losses (bootstrapped_ce_loss.py: loss / batch), one thread: round 5, instead of clone + sum + div launches
-__global__ void bm_batch_mean_kernel(const float* __restrict__ out8, int images, float* __restrict__ mean_out) {
-    float t = 0.0f;
-    for (int i = 0; i < images; ++i) t += out8[(size_t)i * 8];
-    mean_out[0] = t / (float)images;
-}
-
 __global__ __launch_bounds__(256)
 void bm_bwd_kernel(const float* __restrict__ v, int n, const float* __restrict__ state, const float* __restrict__ gout, int gout_stride,
                    float scale, float* __restrict__ gv) {
@@ -592,30 +628,45 @@ void upsample_bilinear_bwd_kernel(const T* __restrict__ dy, int channels, long d
 // image folded onto the border output (1.0 g[0] at i = 0, 1.0 g[2L+1] at the last row / column).  16 loads and fused multiply-adds per
 // input pixel, no tap arithmetic (the general kernel above walks the candidate outputs and recomputes their taps: 21 us per launch at
 // config 5, the second-largest line of the training step in visit r4m).
+// Round 6: a thread owns a 2 x 2 block of input pixels -- their footprints are 6 rows x 6 columns of g, fetched as 6 x 4 aligned pairs (24
+// 8-byte loads for four values where the one-pixel form issued 64 4-byte loads: it ran at 2.3 TB/s on the step's largest map); per value the
+// same two fma chains (columns, then rows), so dx is bit-identical.  A pair that would start outside the row is clamped inside it: every
+// element read in its place carries weight 0, as the clamped single loads did.
 template <typename T>
 __global__ __launch_bounds__(256)
 void upsample2x_bwd_kernel(const T* __restrict__ dy, int channels, long dy_batch_stride, int Hi, int Wi, T* __restrict__ dx) {
-    const int xi = blockIdx.x * 64 + (threadIdx.x & 63), yi = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (xi >= Wi || yi >= Hi) return;
+    const int xi0 = 2 * (blockIdx.x * 64 + (threadIdx.x & 63)), yi0 = 2 * (blockIdx.y * 4 + (threadIdx.x >> 6));
+    if (xi0 >= Wi || yi0 >= Hi) return;
     const int Ho = 2 * Hi, Wo = 2 * Wi;
     const int pb = (int)blockIdx.z / channels, pc = (int)blockIdx.z - pb * channels;
     const T* __restrict__ g = dy + (size_t)pb * dy_batch_stride + (size_t)pc * Ho * Wo;
-    float wy[4] = {0.25f, 0.75f, 0.75f, 0.25f}, wx[4] = {0.25f, 0.75f, 0.75f, 0.25f};
-    if (yi == 0) { wy[0] = 0.0f; wy[1] = 1.0f; }
-    if (yi == Hi - 1) { wy[3] = 0.0f; wy[2] = 1.0f; }
-    if (xi == 0) { wx[0] = 0.0f; wx[1] = 1.0f; }
-    if (xi == Wi - 1) { wx[3] = 0.0f; wx[2] = 1.0f; }
-    float acc = 0.0f;
+    float v[6][8];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const int oy = min(max(2 * yi - 1 + a, 0), Ho - 1);            // clamped rows / columns carry weight 0
-        const T* __restrict__ row = g + (size_t)oy * Wo;
-        float r = 0.0f;
+    for (int r = 0; r < 6; ++r) {
+        const T* __restrict__ row = g + (size_t)min(max(2 * yi0 - 1 + r, 0), Ho - 1) * Wo;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) r = fmaf(wx[b], Store<T>::ld(row, min(max(2 * xi - 1 + b, 0), Wo - 1)), r);
-        acc = fmaf(wy[a], r, acc);
+        for (int q = 0; q < 4; ++q) Pair<T>::ld(row, (size_t)min(max(2 * xi0 - 2 + 2 * q, 0), Wo - 2), v[r][2 * q], v[r][2 * q + 1]);
     }
-    Store<T>::st(dx, ((size_t)blockIdx.z * Hi + yi) * Wi + xi, acc);
+#pragma unroll
+    for (int dyi = 0; dyi < 2; ++dyi)
+#pragma unroll
+        for (int dxi = 0; dxi < 2; ++dxi) {
+            const int yi = yi0 + dyi, xi = xi0 + dxi;
+            float wy[4] = {0.25f, 0.75f, 0.75f, 0.25f}, wx[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+            if (yi == 0) { wy[0] = 0.0f; wy[1] = 1.0f; }
+            if (yi == Hi - 1) { wy[3] = 0.0f; wy[2] = 1.0f; }
+            if (xi == 0) { wx[0] = 0.0f; wx[1] = 1.0f; }
+            if (xi == Wi - 1) { wx[3] = 0.0f; wx[2] = 1.0f; }
+            float acc = 0.0f;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                float r = 0.0f;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) r = fmaf(wx[b], v[2 * dyi + a][2 * dxi + b + 1], r);
+                acc = fmaf(wy[a], r, acc);
+            }
+            if (yi < Hi && xi < Wi) Store<T>::st(dx, ((size_t)blockIdx.z * Hi + yi) * Wi + xi, acc);
+        }
 }
 
 // Adjoint of hs_bank_pack_fwd: the patch-major gradient (B fh fw, ld) back to the reference's channel-major layout (B, hp_total, fh, fw),
@@ -731,9 +782,12 @@ extern "C" int hs_upsample_bilinear_typed_bwd(int32_t dtype, const void* dy, int
     hipStream_t q = (hipStream_t)stream;
     const long bs = (long)dy_batch_stride;
     const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
-    if (Ho == 2 * Hi && Wo == 2 * Wi) {
-        if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, grid, dim3(256), 0, q, (const float*)dy, channels, bs, Hi, Wi, (float*)dx);
-        else hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16_t>, grid, dim3(256), 0, q, (const bf16_t*)dy, channels, bs, Hi, Wi, (bf16_t*)dx);
+    // the 2 x 2 form reads aligned pairs: every row of g must start on a pair boundary (Wo = 2 Wi is even; the base and the batch stride decide)
+    const size_t pair_bytes = dtype == HS_DTYPE_F32 ? 8 : 4;
+    if (Ho == 2 * Hi && Wo == 2 * Wi && (reinterpret_cast<size_t>(dy) % pair_bytes) == 0 && (bs & 1) == 0) {
+        const dim3 grid2(((Wi + 1) / 2 + 63) / 64, ((Hi + 1) / 2 + 3) / 4, batch * channels);
+        if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, grid2, dim3(256), 0, q, (const float*)dy, channels, bs, Hi, Wi, (float*)dx);
+        else hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16_t>, grid2, dim3(256), 0, q, (const bf16_t*)dy, channels, bs, Hi, Wi, (bf16_t*)dx);
         return launch_status();
     }
     if (dtype == HS_DTYPE_F32)
@@ -854,7 +908,7 @@ extern "C" int hs_halo_tiles_fwd(int32_t dtype, const void* x, int32_t batch, in
     const int st = tile_args(a, batch, channels, H, W, fh, fw, patch_major);
     if (st != HS_OK) return st;
     if (!x || !tiled) return HS_ERR_BAD_ARG;
-    const dim3 grid((fw * (a.pw + 2) + 63) / 64, (fh * (a.ph + 2) + 3) / 4, batch * channels);
+    const dim3 grid((fw * (a.pw + 2) + 63) / 64, (fh * (a.ph + 2) + 15) / 16, batch * channels);        // four rows per thread
     HS_TILE_LAUNCH(dtype, halo_tiles_fwd_kernel<float>, halo_tiles_fwd_kernel<bf16_t>, grid, x, tiled)
     return launch_status();
 }
@@ -896,8 +950,8 @@ extern "C" int64_t hs_bootstrap_mean_workspace(void) { return (int64_t)(BM_STATE
 
 // `images` independent reductions in one set of launches (grid.y = image): values (images, n), workspace images x
 // hs_bootstrap_mean_workspace() bytes, out (images, 8) floats [loss, branch, 1 / count, t, tie weight, -, -, -]
-extern "C" int hs_bootstrap_mean_batched_fwd(const float* values, int32_t images, int32_t n, int32_t k, float thresh, void* workspace,
-                                             float* out8, void* stream) {
+static int bootstrap_mean_fwd(const float* values, int32_t images, int32_t n, int32_t k, float thresh, void* workspace, float* out8,
+                              float* mean_out, void* stream) {
     if (!values || !workspace || !out8 || n <= 0 || k <= 0 || images <= 0 || images > 65535) return HS_ERR_BAD_ARG;
     if (n <= k) return HS_ERR_UNSUPPORTED;                               // the reference indexes ranked[k]
     hipStream_t s = (hipStream_t)stream;
@@ -907,9 +961,12 @@ extern "C" int hs_bootstrap_mean_batched_fwd(const float* values, int32_t images
     if (e != hipSuccess) return (int)e;
     for (int level = 0; level < 3; ++level)
         hipLaunchKernelGGL(bm_hist_kernel, dim3(BM_WG, images), dim3(256), 0, s, values, n, ws, level, k);
-    hipLaunchKernelGGL(bm_sums_kernel, dim3(BM_WG, images), dim3(256), 0, s, values, n, thresh, ws, partial, k);
-    hipLaunchKernelGGL(bm_final_kernel, dim3(1, images), dim3(64), 0, s, (const float*)partial, BM_WG, (const unsigned*)ws, k, thresh, out8);
+    hipLaunchKernelGGL(bm_sums_kernel, dim3(BM_WG, images), dim3(256), 0, s, values, n, thresh, ws, partial, k, out8, mean_out);
     return launch_status();
+}
+extern "C" int hs_bootstrap_mean_batched_fwd(const float* values, int32_t images, int32_t n, int32_t k, float thresh, void* workspace,
+                                             float* out8, void* stream) {
+    return bootstrap_mean_fwd(values, images, n, k, thresh, workspace, out8, nullptr, stream);
 }
 
 extern "C" int hs_bootstrap_mean_batched_bwd(const float* values, int32_t images, int32_t n, const float* state8, const float* grad_out,
@@ -924,10 +981,7 @@ extern "C" int hs_bootstrap_mean_batched_bwd(const float* values, int32_t images
 extern "C" int hs_bootstrap_mean_of_batch_fwd(const float* values, int32_t images, int32_t n, int32_t k, float thresh, void* workspace,
                                               float* out8, float* mean_out, void* stream) {
     if (!mean_out) return HS_ERR_BAD_ARG;
-    const int st = hs_bootstrap_mean_batched_fwd(values, images, n, k, thresh, workspace, out8, stream);
-    if (st != HS_OK) return st;
-    hipLaunchKernelGGL(bm_batch_mean_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const float*)out8, images, mean_out);
-    return launch_status();
+    return bootstrap_mean_fwd(values, images, n, k, thresh, workspace, out8, mean_out, stream);
 }
 
 extern "C" int hs_bootstrap_mean_of_batch_bwd(const float* values, int32_t images, int32_t n, const float* state8, const float* grad_mean,
