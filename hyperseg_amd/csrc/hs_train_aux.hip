@@ -270,7 +270,10 @@ void bm_sums_kernel(const float* __restrict__ v, int n, float thresh, unsigned* 
     v += (size_t)blockIdx.y * n; ws += (size_t)blockIdx.y * BM_WS_U32; partial += (size_t)blockIdx.y * BM_WS_U32;
     unsigned tbits, above;
     bm_find_body(ws, 2, k, part, sel, tbits, above);                    // the last level's bin walk: t and the count above it
-    if (blockIdx.x == 0 && threadIdx.x == 0) { ws[BM_STATE + 4] = tbits; ws[BM_STATE + 5] = above; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                          // (agent-scope stores: the tail below reads them from another CU)
+        __hip_atomic_store(ws + BM_STATE + 4, tbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ws + BM_STATE + 5, above, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     const float t = __uint_as_float(tbits);
     float s_thr = 0.f, c_thr = 0.f, s_top = 0.f, c_eq = 0.f;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
@@ -286,14 +289,16 @@ void bm_sums_kernel(const float* __restrict__ v, int n, float thresh, unsigned* 
     if ((threadIdx.x & 63) == 0) { red[wave][0] = s_thr; red[wave][1] = c_thr; red[wave][2] = s_top; red[wave][3] = c_eq; }
     __syncthreads();
     if (threadIdx.x < 4)
-        partial[blockIdx.x * 4 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    // ---- tail: the last workgroup of the launch finishes every image
-    __threadfence();                                                    // this workgroup's partial sums (and workgroup 0's state pair) before its ticket
+        __hip_atomic_store(partial + blockIdx.x * 4 + threadIdx.x, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ---- tail: the last workgroup of the launch finishes every image.  The sums and the state pair leave as agent-scope (write-through) stores,
+    // each thread waits for its own to be acknowledged, then the workgroup takes its ticket; the tail reads with agent-scope loads.  (A
+    // __threadfence() here -- an L2 write-back per workgroup on this part -- cost the launch 15 us, visit x5.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) sel[0] = atomicAdd(ws0 + BM_STATE + 7, 1u);
+    if (threadIdx.x == 0) sel[0] = __hip_atomic_fetch_add(ws0 + BM_STATE + 7, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (sel[0] != gridDim.x * gridDim.y - 1 || threadIdx.x >= 64) return;
-    __threadfence();
     const int images = gridDim.y;
     float mean = 0.0f;
     for (int i = 0; i < images; ++i)
