@@ -675,6 +675,55 @@ class BootstrapMean(torch.autograd.Function):
         return gv, None, None
 
 
+class BootstrappedCrossEntropy(torch.autograd.Function):
+    """``BootstrappedCrossEntropyLoss.forward`` (hyperseg/losses/bootstrapped_ce_loss.py:15-27) as ONE Function (round 6): logits (N, C, H, W)
+    fp32 / bf16, target (N, H, W) int64 -> the batch mean of the per-image bootstrapped losses, a 0-dim fp32 tensor.  The same values as
+    ``BootstrapMeanOfBatch.apply(PixelCrossEntropy.apply(...).flatten(1), k, thresh)`` bit for bit, with ONE launch backward
+    (hs_bootstrapped_ce_bwd: the pixel weights are formed inside the cross entropy's adjoint) where the pair takes two and an (N, HW)
+    gradient tensor between them.  (A forward that also took the selection's first histogram level while making the losses measured
+    slower -- hs_train_aux.hip -- and is not in.)"""
+
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index, k, thresh):
+        if logits.dim() != 4 or tuple(target.shape) != (logits.shape[0],) + tuple(logits.shape[2:]):
+            raise ValueError(f'Expected target of shape {(logits.shape[0],) + tuple(logits.shape[2:])} for logits of shape '
+                             f'{tuple(logits.shape)}, got {tuple(target.shape)}')
+        if target.dtype != torch.int64 or target.device != logits.device:
+            raise ValueError(f'BootstrappedCrossEntropy: expected int64 class indices on {logits.device}, got {target.dtype} on {target.device}')
+        logits, target = logits.contiguous(), target.contiguous()
+        n, c = logits.shape[:2]
+        px = logits.numel() // (n * c)
+        if _CHECK_LABELS and target.numel():
+            bad = (target != int(ignore_index)) & ((target < 0) | (target >= c))
+            if bool(bad.any()):
+                raise IndexError(f'Target {int(target[bad][0])} is out of bounds for {c} classes (ignore_index {int(ignore_index)})')
+        with _hip.device_scope(logits.device):
+            ws = torch.empty(n * int(_hip.lib.hs_bootstrap_mean_workspace()), device=logits.device, dtype=torch.uint8)
+            loss = torch.empty(n, px, device=logits.device, dtype=torch.float32)
+            out = torch.empty(n * 8 + 1, device=logits.device, dtype=torch.float32)              # (N, 8) state | the mean
+            st = _hip.lib.hs_bootstrapped_ce_fwd(DTYPE_CODES[logits.dtype], logits.data_ptr(), target.data_ptr(), n, c, px, int(ignore_index),
+                                                 int(k), float(thresh), ws.data_ptr(), loss.data_ptr(), out.data_ptr(),
+                                                 out.data_ptr() + 4 * n * 8, _hip.stream_ptr())
+            _hip.check(st, 'hs_bootstrapped_ce_fwd')
+        ctx.save_for_backward(logits, target, loss, out)
+        ctx.ignore_index = int(ignore_index)
+        return out[n * 8:].view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, loss, state = ctx.saved_tensors
+        n, c = logits.shape[:2]
+        px = logits.numel() // (n * c)
+        if g.dtype != torch.float32 or not g.is_contiguous():
+            g = g.float().contiguous()
+        with _hip.device_scope(logits.device):
+            dl = torch.empty_like(logits)
+            st = _hip.lib.hs_bootstrapped_ce_bwd(DTYPE_CODES[logits.dtype], logits.data_ptr(), target.data_ptr(), n, c, px, ctx.ignore_index,
+                                                 loss.data_ptr(), state.data_ptr(), g.data_ptr(), dl.data_ptr(), _hip.stream_ptr())
+            _hip.check(st, 'hs_bootstrapped_ce_bwd')
+        return dl, None, None, None, None
+
+
 class MetaConvGeneral(torch.autograd.Function):
     """MetaConv2d with stride / dilation / any zero padding (hs_meta_conv_fwd) under autograd: backward = hs_meta_conv_bwd (input-
     and per-sample weight-gradient gather kernels).  fp32; the non-zero padding modes are padded by the caller with F.pad, whose

@@ -706,10 +706,26 @@ void bank_unpack_kernel(const float* __restrict__ bank, long ld, int hp_total, i
 // ---------------------------------------------------------------------------------------------------------------------------------
 // CF: the class count at compile time (12 CamVid, 19 Cityscapes, 21 VOC: the reference's datasets) -- a pixel's logits are then loaded ONCE
 // into registers, all in flight together, instead of three dependent passes over them (max, sum, result); 0 = any count, the three passes.
+// The upstream gradient of pixel e: g[e] as it is, or -- bootstrapped form (hs_bootstrapped_ce_bwd, round 6) -- formed HERE from the pixel's own loss
+// g[e], its image's selection state (out8 of the forward: 1 / count, t, tie weight) and the ONE gradient of the batch mean, exactly as
+// bm_bwd_kernel writes it (whose launch and whose (N, HW) gradient tensor this replaces).
+__device__ __forceinline__ float ce_upstream(const float* __restrict__ g, long e, long n, const float* __restrict__ bstate,
+                                             const float* __restrict__ gmean, float gscale) {
+    const float v = g[e];
+    if (!bstate) return v;
+    const float* __restrict__ st = bstate + n * 8;
+    const float w = st[2] * (gmean[0] * gscale), t = st[3], tie = st[4], xv = fmaxf(v, 0.0f);
+    return xv > t ? w : (xv == t ? w * tie : 0.0f);
+}
+
+// (Round 6, visit x8: a forward variant that also took level 0 of the selection's histograms while it made the losses -- an LDS histogram per
+//  workgroup pass, flushed with one global atomic per non-empty bin -- measured 38.5 us against 10.3 + 6.8 for the two launches: the loss launch
+//  has 2592 workgroups where bm_hist_kernel has 256, and their flushes meet on the few hundred bins the losses crowd into.  Removed.)
 template <bool BWD, typename T, int CF>
 __global__ __launch_bounds__(256)
 void cross_entropy_kernel(const T* __restrict__ x, const long long* __restrict__ target, int C, long hw, long total, long long ignore_index,
-                          const float* __restrict__ g, void* __restrict__ out_) {
+                          const float* __restrict__ g, void* __restrict__ out_, const float* __restrict__ bstate, const float* __restrict__ gmean,
+                          float gscale) {
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const long n = e / hw, p = e - n * hw;
         const T* __restrict__ xp = x + n * C * hw + p;
@@ -719,7 +735,7 @@ void cross_entropy_kernel(const T* __restrict__ x, const long long* __restrict__
             float v[CF];
 #pragma unroll
             for (int c = 0; c < CF; ++c) v[c] = Store<T>::ld(xp, (long)c * hw);
-            const float gi = BWD ? g[e] : 0.0f;
+            const float gi = BWD ? ce_upstream(g, e, n, bstate, gmean, gscale) : 0.0f;
             float m = v[0];
 #pragma unroll
             for (int c = 1; c < CF; ++c) m = fmaxf(m, v[c]);
@@ -746,7 +762,7 @@ void cross_entropy_kernel(const T* __restrict__ x, const long long* __restrict__
                 ((float*)out_)[e] = live ? (logf(sum) + m) - Store<T>::ld(xp, (long)(live ? t : 0) * hw) : 0.0f;
             } else {
                 T* __restrict__ dp = (T*)out_ + n * C * hw + p;
-                const float gi = live ? g[e] : 0.0f, inv = 1.0f / sum;
+                const float gi = live ? ce_upstream(g, e, n, bstate, gmean, gscale) : 0.0f, inv = 1.0f / sum;
                 for (int c = 0; c < C; ++c) Store<T>::st(dp, (long)c * hw, (expf(Store<T>::ld(xp, (long)c * hw) - m) * inv - (c == (int)t ? 1.0f : 0.0f)) * gi);
             }
         }
@@ -755,11 +771,11 @@ void cross_entropy_kernel(const T* __restrict__ x, const long long* __restrict__
 
 template <bool BWD, typename T>
 static void launch_cross_entropy(dim3 blocks, hipStream_t s, const T* x, const long long* target, int C, long hw, long total, long long ignore_index,
-                                 const float* g, void* out) {
-    if (C == 12) hipLaunchKernelGGL((cross_entropy_kernel<BWD, T, 12>), blocks, dim3(256), 0, s, x, target, C, hw, total, ignore_index, g, out);
-    else if (C == 19) hipLaunchKernelGGL((cross_entropy_kernel<BWD, T, 19>), blocks, dim3(256), 0, s, x, target, C, hw, total, ignore_index, g, out);
-    else if (C == 21) hipLaunchKernelGGL((cross_entropy_kernel<BWD, T, 21>), blocks, dim3(256), 0, s, x, target, C, hw, total, ignore_index, g, out);
-    else hipLaunchKernelGGL((cross_entropy_kernel<BWD, T, 0>), blocks, dim3(256), 0, s, x, target, C, hw, total, ignore_index, g, out);
+                                 const float* g, void* out, const float* bstate = nullptr, const float* gmean = nullptr, float gscale = 1.0f) {
+    if (C == 12) hipLaunchKernelGGL((cross_entropy_kernel<BWD, T, 12>), blocks, dim3(256), 0, s, x, target, C, hw, total, ignore_index, g, out, bstate, gmean, gscale);
+    else if (C == 19) hipLaunchKernelGGL((cross_entropy_kernel<BWD, T, 19>), blocks, dim3(256), 0, s, x, target, C, hw, total, ignore_index, g, out, bstate, gmean, gscale);
+    else if (C == 21) hipLaunchKernelGGL((cross_entropy_kernel<BWD, T, 21>), blocks, dim3(256), 0, s, x, target, C, hw, total, ignore_index, g, out, bstate, gmean, gscale);
+    else hipLaunchKernelGGL((cross_entropy_kernel<BWD, T, 0>), blocks, dim3(256), 0, s, x, target, C, hw, total, ignore_index, g, out, bstate, gmean, gscale);
 }
 
 }  // namespace hs
@@ -1046,6 +1062,37 @@ extern "C" int hs_cross_entropy_fwd(const float* logits, const int64_t* target, 
 extern "C" int hs_cross_entropy_bwd(const float* logits, const int64_t* target, int32_t batch, int32_t classes, int64_t pixels,
                                     int64_t ignore_index, const float* grad_loss, float* grad_logits, void* stream) {
     return hs_cross_entropy_typed_bwd(HS_DTYPE_F32, logits, target, batch, classes, pixels, ignore_index, grad_loss, grad_logits, stream);
+}
+
+// BootstrappedCrossEntropyLoss.forward as ONE entry (round 6; hyperseg/losses/bootstrapped_ce_loss.py:15-27): hs_cross_entropy_typed_fwd +
+// hs_bootstrap_mean_of_batch_fwd (six launches), keeping what the one-launch adjoint below needs.  Same values bit for bit.
+extern "C" int hs_bootstrapped_ce_fwd(int32_t dtype, const void* logits, const int64_t* target, int32_t batch, int32_t classes, int64_t pixels,
+                                      int64_t ignore_index, int32_t k, float thresh, void* workspace, float* loss, float* out8, float* mean_out,
+                                      void* stream) {
+    if (!workspace || !out8 || !mean_out || k <= 0 || batch > 65535) return HS_ERR_BAD_ARG;
+    if (pixels <= k || pixels > 0x7fffffffL) return HS_ERR_UNSUPPORTED;  // the reference indexes ranked[k]
+    const int st = hs_cross_entropy_typed_fwd(dtype, logits, target, batch, classes, pixels, ignore_index, loss, stream);
+    if (st != HS_OK) return st;
+    return bootstrap_mean_fwd(loss, batch, (int32_t)pixels, k, thresh, workspace, out8, mean_out, stream);
+}
+
+// ... and its adjoint as ONE launch: grad_logits = (softmax - onehot) x the pixel's weight, the weight formed in the launch from the saved losses,
+// the saved selection state (out8) and the one upstream gradient of the mean (hs_bootstrap_mean_of_batch_bwd + hs_cross_entropy_typed_bwd: two
+// launches and an (N, HW) tensor between them).
+extern "C" int hs_bootstrapped_ce_bwd(int32_t dtype, const void* logits, const int64_t* target, int32_t batch, int32_t classes, int64_t pixels,
+                                      int64_t ignore_index, const float* loss, const float* state8, const float* grad_mean, void* grad_logits,
+                                      void* stream) {
+    if (!logits || !target || !loss || !state8 || !grad_mean || !grad_logits || batch <= 0 || classes <= 0 || pixels <= 0) return HS_ERR_BAD_ARG;
+    if (dtype != HS_DTYPE_F32 && dtype != HS_DTYPE_BF16) return HS_ERR_BAD_ARG;
+    const long total = (long)batch * pixels;
+    const dim3 blocks((unsigned)((total + 255) / 256 > 65535 * 16 ? 65535 * 16 : (total + 255) / 256));
+    if (dtype == HS_DTYPE_F32)
+        launch_cross_entropy<true, float>(blocks, (hipStream_t)stream, (const float*)logits, (const long long*)target, classes, (long)pixels, total,
+                                          (long long)ignore_index, loss, grad_logits, state8, grad_mean, 1.0f / (float)batch);
+    else
+        launch_cross_entropy<true, bf16_t>(blocks, (hipStream_t)stream, (const bf16_t*)logits, (const long long*)target, classes, (long)pixels, total,
+                                           (long long)ignore_index, loss, grad_logits, state8, grad_mean, 1.0f / (float)batch);
+    return launch_status();
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------

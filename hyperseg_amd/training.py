@@ -17,6 +17,7 @@ from torch.optim.lr_scheduler import LRScheduler
 
 
 USE_HIP_BOOTSTRAP = True       # tests switch it off to reach the torch statements of the rule below
+USE_FUSED_LOSS = True          # False: cross entropy and the bootstrapped mean as two Functions (two launches backward; the fused one's equality test)
 
 
 def bootstrap_mean_reference(per_pixel, k, thresh):
@@ -54,8 +55,12 @@ def bootstrapped_cross_entropy(pred, target, k=4096, thresh=0.3, weight=None, ig
     capturing = pred.is_cuda and torch.cuda.is_current_stream_capturing()
     # the per-pixel losses of the WHOLE batch in one pass over (N, C, H, W) (the reference permutes every image to (HW, C) first,
     # bootstrapped_ce_loss.py:20-23: same values, a transposed copy + a softmax + a gather per image and direction)
-    if (USE_HIP_BOOTSTRAP and weight is None and pred.is_cuda and pred.dtype in (torch.float32, torch.bfloat16) and pred.dim() == 4
-            and target.dtype == torch.int64 and target.device == pred.device):
+    hip_ce = (USE_HIP_BOOTSTRAP and weight is None and pred.is_cuda and pred.dtype in (torch.float32, torch.bfloat16) and pred.dim() == 4
+              and target.dtype == torch.int64 and target.device == pred.device)
+    if hip_ce and USE_FUSED_LOSS and pred.shape[2] * pred.shape[3] > k and pred.shape[0] <= 65535 and pred.shape[2] * pred.shape[3] < 2 ** 31:
+        from .autograd import BootstrappedCrossEntropy                     # the whole loss as one Function: its adjoint is one launch (round 6)
+        return BootstrappedCrossEntropy.apply(pred, target, ignore_index, k, thresh)
+    if hip_ce:
         from .autograd import PixelCrossEntropy                            # one launch per direction (hs_cross_entropy_typed_fwd / _bwd)
         per_all = PixelCrossEntropy.apply(pred, target, ignore_index)
     else:

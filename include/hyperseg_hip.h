@@ -631,6 +631,17 @@ int hs_cross_entropy_typed_fwd(int32_t dtype, const void* logits, const int64_t*
                                int64_t ignore_index, float* loss, void* stream);
 int hs_cross_entropy_typed_bwd(int32_t dtype, const void* logits, const int64_t* target, int32_t batch, int32_t classes, int64_t pixels,
                                int64_t ignore_index, const float* grad_loss, void* grad_logits, void* stream);
+/* BootstrappedCrossEntropyLoss.forward / backward as one entry each (hyperseg/losses/bootstrapped_ce_loss.py:15-27: per-pixel cross entropy, then per
+ * image the mean of the losses above `thresh` if more than k exceed it, else of the k largest; the batch's mean of those).  Forward:
+ * hs_cross_entropy_typed_fwd + hs_bootstrap_mean_of_batch_fwd; loss (N, pixels) fp32 = the per-pixel losses (kept for the adjoint),
+ * out8 (N, 8) = the per-image selection state of hs_bootstrap_mean_batched_fwd, mean_out[0] = the loss.  workspace: N x hs_bootstrap_mean_workspace()
+ * bytes, any contents.  pixels > k (the reference indexes ranked[k]).  Backward: ONE launch (the pixel weights are formed inside the cross entropy's
+ * adjoint: no hs_bootstrap_mean_of_batch_bwd launch, no (N, pixels) gradient tensor), grad_logits (N, C, pixels) in the logits' type from the saved
+ * `loss`, `out8` and the one upstream gradient grad_mean[0].  Values identical to the separate entries'. */
+int hs_bootstrapped_ce_fwd(int32_t dtype, const void* logits, const int64_t* target, int32_t batch, int32_t classes, int64_t pixels,
+                           int64_t ignore_index, int32_t k, float thresh, void* workspace, float* loss, float* out8, float* mean_out, void* stream);
+int hs_bootstrapped_ce_bwd(int32_t dtype, const void* logits, const int64_t* target, int32_t batch, int32_t classes, int64_t pixels,
+                           int64_t ignore_index, const float* loss, const float* state8, const float* grad_mean, void* grad_logits, void* stream);
 
 /* Materialises a stage input (B, 2*coords + c_skip + c_prev, H, W); test/diagnostic twin of the
  * fused prologue (the product path never calls it). */

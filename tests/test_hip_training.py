@@ -754,6 +754,60 @@ def test_bootstrap_mean_batched_equals_per_image(dev):
     assert torch.equal(la, lb) and torch.equal(va.grad, vb.grad)
 
 
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('classes,hw', [(12, (40, 52)), (19, (33, 47)), (7, (40, 52))])
+def test_fused_bootstrapped_cross_entropy_equals_the_two_functions(dev, dtype, classes, hw):
+    """hs_bootstrapped_ce_fwd / _bwd (round 6: the whole loss as one Function -- the pixel weights formed inside the cross entropy's adjoint, one
+    launch backward) == PixelCrossEntropy + BootstrapMeanOfBatch, loss and logits' gradient bit for bit:
+    both branches of the rule in one batch, ignored pixels, a pixel count that is not a multiple of 256 (workgroup passes that straddle two
+    images), the templated class counts and the generic one, bf16 logits."""
+    import hyperseg_amd.training as T
+    g = torch.Generator().manual_seed(21)
+    h, w = hw
+    x = torch.randn(3, classes, h, w, generator=g) * 3.0
+    x[1] *= 0.02                                                    # image 1: every loss ~ log C ... above thresh only if thresh is small
+    x[2, :, :, : w // 2] *= 10.0
+    t = torch.randint(0, classes, (3, h, w), generator=g)
+    t[0, :5] = 255
+    t[2, ::3, ::2] = 255
+    x = x.to(dev)
+    if dtype == 'bf16':
+        x = x.bfloat16()
+    t = t.to(dev)
+    for k, thresh in ((300, 0.3), (300, 3.0), (h * w - 1, 50.0)):
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        T.USE_FUSED_LOSS = True
+        try:
+            la = T.bootstrapped_cross_entropy(xa, t, k=k, thresh=thresh, ignore_index=255)
+            T.USE_FUSED_LOSS = False
+            lb = T.bootstrapped_cross_entropy(xb, t, k=k, thresh=thresh, ignore_index=255)
+        finally:
+            T.USE_FUSED_LOSS = True
+        (la * 1.7).backward()
+        (lb * 1.7).backward()
+        assert la.dtype == torch.float32 and la.dim() == 0
+        assert torch.equal(la, lb), (k, thresh, float(la), float(lb))
+        assert torch.equal(xa.grad, xb.grad), (k, thresh)
+        assert bool(torch.isfinite(la)) and float(xa.grad.float().abs().sum()) > 0.0
+    bad = x.clone()
+    bad[0, 0, 10, 3] = float('nan')                                 # (a pixel that is not ignored)
+    assert bool(torch.isnan(T.bootstrapped_cross_entropy(bad, t, k=300, thresh=0.3, ignore_index=255)))
+
+
+def test_fused_bootstrapped_cross_entropy_argument_checks(dev):
+    from hyperseg_amd.autograd import BootstrappedCrossEntropy
+    import hyperseg_amd.training as T
+    x = torch.randn(2, 12, 16, 16, device=dev)
+    t = torch.randint(0, 12, (2, 16, 16), device=dev)
+    with pytest.raises(ValueError):
+        BootstrappedCrossEntropy.apply(x, t[:, :8], 255, 10, 0.3)
+    with pytest.raises(ValueError):
+        BootstrappedCrossEntropy.apply(x, t.int(), 255, 10, 0.3)
+    # k >= pixels: the module keeps the route whose error is the reference's (ranked[k] out of range)
+    with pytest.raises(Exception):
+        T.bootstrapped_cross_entropy(x, t, k=256, thresh=0.3)
+
+
 def test_bootstrap_mean_propagates_nan(dev):
     """the kernels clamp losses with fmaxf(v, 0) and fmaxf(NaN, 0) = 0 -- a diverged step used to report a finite loss.
     Both branches of the rule must return NaN when any per-pixel loss is NaN, like the reference's sort / mean do."""
