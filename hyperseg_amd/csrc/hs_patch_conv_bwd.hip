@@ -12,6 +12,17 @@
 // with the patch's dY and padded X tiles in LDS, bwd_input one thread per input element.
 #include "hs_common.h"
 
+// dev A/B switches of round 6's row-count changes (the product build leaves them at 1)
+#ifndef HS_DWT_FWD_RPT4
+#define HS_DWT_FWD_RPT4 1
+#endif
+#ifndef HS_DWT_BWD_IN_RPT3
+#define HS_DWT_BWD_IN_RPT3 1
+#endif
+#ifndef HS_DWT_BWD_W_CPW
+#define HS_DWT_BWD_W_CPW 1              // 2 measured slower (21.8 -> 23.5 us at config 5's level 4, visit x10): left at 1
+#endif
+
 namespace hs {
 
 struct ConvBwdArgs {
@@ -966,59 +977,83 @@ void dw_tiles_bwd_in_kernel(DwtArgs a, const T* __restrict__ dy, T* __restrict__
 // ROWS (round 6): a patch of <= 16 element pairs per thread pass (8 x 8 patches at RPT = 2: config 5's level 3) left 48 of a wave's 64 lanes
 // idle and paid nine 64-lane reductions per (patch, channel); with ROWS each row of 16 lanes takes a channel of its own -- four channels per
 // wave, a 16-lane reduction (rowsum16: the very sums wave_sum64 forms from a wave whose other rows hold zeros, so dbank is bit-identical).
-template <typename T, bool BN, int RPT = 1, bool ROWS = false>
+// CPW (round 6): channels per wave in the 64-lane form -- a wave requests one channel's ten pairs, reduces and retires (28 k waves of one memory
+// round trip each at config 5's level 4); two channels per wave (both sets of requests out before the first product) measured SLOWER: see
+// HS_DWT_BWD_W_CPW.
+template <typename T, bool BN, int RPT = 1, bool ROWS = false, int CPW = 1>
 __global__ __launch_bounds__(256)
 void dw_tiles_bwd_w_kernel(DwtArgs a, DwtBn n, const T* __restrict__ t, const T* __restrict__ dy) {
+    static_assert(!ROWS || CPW == 1, "ROWS: a channel per row of 16 lanes");
     constexpr int LPC = ROWS ? 16 : 64;                              // lanes per channel
     const int lane = threadIdx.x & (LPC - 1), wave = threadIdx.x >> 6;
-    const int patch = blockIdx.x, cw = ROWS ? (blockIdx.y * 4 + wave) * 4 + (int)((threadIdx.x & 63) >> 4) : blockIdx.y * 4 + wave;
+    const int patch = blockIdx.x, cw = ROWS ? (blockIdx.y * 4 + wave) * 4 + (int)((threadIdx.x & 63) >> 4) : (blockIdx.y * 4 + wave) * CPW;
     if (!ROWS && cw >= a.C) return;
-    const bool live = cw < a.C;                                      // ROWS: a row past the last channel works on the last one and writes nothing
-    const int c = live ? cw : a.C - 1;
     const int j = patch % a.fw, i = (patch / a.fw) % a.fh, b = patch / (a.fw * a.fh);
-    float g = 1.0f, bb = 0.0f;
-    if constexpr (BN) {                                              // the saved statistics: the tiles are normalised on load, as in the forward
-        const float mean = n.mean[c], invstd = n.invstd[c];
-        g = n.gamma ? n.gamma[c] * invstd : invstd;
-        bb = (n.beta ? n.beta[c] : 0.f) - mean * g;
+    bool live[CPW];                                                  // a channel past the last works on the last one and writes nothing
+    int c[CPW], TW = 0;
+    float g[CPW], bb[CPW];
+    const T* __restrict__ tp[CPW];
+    const T* __restrict__ gp[CPW];
+#pragma unroll
+    for (int k = 0; k < CPW; ++k) {
+        live[k] = cw + k < a.C;
+        c[k] = live[k] ? cw + k : a.C - 1;
+        g[k] = 1.0f; bb[k] = 0.0f;
+        if constexpr (BN) {                                          // the saved statistics: the tiles are normalised on load, as in the forward
+            const float mean = n.mean[c[k]], invstd = n.invstd[c[k]];
+            g[k] = n.gamma ? n.gamma[c[k]] * invstd : invstd;
+            bb[k] = (n.beta ? n.beta[c[k]] : 0.f) - mean * g[k];
+        }
+        tp[k] = t + dwt_tile(a, b, c[k], i, j, TW);
+        gp[k] = dy + (((size_t)b * a.C + c[k]) * a.H + (size_t)i * a.ph) * a.W + (size_t)j * a.pw;
     }
-    int TW;
-    const T* __restrict__ tp = t + dwt_tile(a, b, c, i, j, TW);
-    const T* __restrict__ gp = dy + (((size_t)b * a.C + c) * a.H + (size_t)i * a.ph) * a.W + (size_t)j * a.pw;
     const int hw = a.pw >> 1, npair = (a.ph / RPT) * hw;
     const float inv_hw = 2.0f * a.inv_pw;
-    float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float acc[CPW][9];
+#pragma unroll
+    for (int k = 0; k < CPW; ++k)
+#pragma unroll
+        for (int q = 0; q < 9; ++q) acc[k][q] = 0.f;
     for (int l = lane; l < npair; l += LPC) {
         const int ur = div_by_inv(l, inv_hw), u = RPT * ur, v = 2 * (l - ur * hw);
-        float g0[RPT], g1[RPT], s[2 + RPT][4];
+        float g0[CPW][RPT], g1[CPW][RPT], s[CPW][2 + RPT][4];
 #pragma unroll
-        for (int ro = 0; ro < RPT; ++ro) Pair<T>::ld(gp, (size_t)(u + ro) * a.W + v, g0[ro], g1[ro]);
+        for (int k = 0; k < CPW; ++k) {
 #pragma unroll
-        for (int r = 0; r < 2 + RPT; ++r) {
-            Pair<T>::ld(tp, (size_t)(u + r) * TW + v, s[r][0], s[r][1]);
-            Pair<T>::ld(tp, (size_t)(u + r) * TW + v + 2, s[r][2], s[r][3]);
-        }
-        if constexpr (BN) {
+            for (int ro = 0; ro < RPT; ++ro) Pair<T>::ld(gp[k], (size_t)(u + ro) * a.W + v, g0[k][ro], g1[k][ro]);
 #pragma unroll
-            for (int r = 0; r < 2 + RPT; ++r)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) s[r][q] = dwt_act(fmaf(s[r][q], g, bb), n.act);
+            for (int r = 0; r < 2 + RPT; ++r) {
+                Pair<T>::ld(tp[k], (size_t)(u + r) * TW + v, s[k][r][0], s[k][r][1]);
+                Pair<T>::ld(tp[k], (size_t)(u + r) * TW + v + 2, s[k][r][2], s[k][r][3]);
+            }
         }
 #pragma unroll
-        for (int ro = 0; ro < RPT; ++ro)
+        for (int k = 0; k < CPW; ++k) {
+            if constexpr (BN) {
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+                for (int r = 0; r < 2 + RPT; ++r)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    acc[ky * 3 + kx] = fmaf(g0[ro], s[ro + ky][kx], acc[ky * 3 + kx]);
-                    acc[ky * 3 + kx] = fmaf(g1[ro], s[ro + ky][kx + 1], acc[ky * 3 + kx]);
-                }
+                    for (int q = 0; q < 4; ++q) s[k][r][q] = dwt_act(fmaf(s[k][r][q], g[k], bb[k]), n.act);
+            }
+#pragma unroll
+            for (int ro = 0; ro < RPT; ++ro)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        acc[k][ky * 3 + kx] = fmaf(g0[k][ro], s[k][ro + ky][kx], acc[k][ky * 3 + kx]);
+                        acc[k][ky * 3 + kx] = fmaf(g1[k][ro], s[k][ro + ky][kx + 1], acc[k][ky * 3 + kx]);
+                    }
+        }
     }
-    float* __restrict__ dst = a.dbank + (size_t)patch * a.ld + c * 9;
 #pragma unroll
-    for (int q = 0; q < 9; ++q) {
-        const float sum = ROWS ? rowsum16(acc[q]) : wave_sum64(acc[q]);
-        if (lane == 0 && live) dst[q] = sum;
+    for (int k = 0; k < CPW; ++k) {
+        float* __restrict__ dst = a.dbank + (size_t)patch * a.ld + c[k] * 9;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const float sum = ROWS ? rowsum16(acc[k][q]) : wave_sum64(acc[k][q]);
+            if (lane == 0 && live[k]) dst[q] = sum;
+        }
     }
 }
 
@@ -1295,6 +1330,12 @@ extern "C" int hs_dw_tiles_bn_fwd(int32_t dtype, const void* tiled, const float*
     a.bank = bank;
     DwtBn n{bn_partial, gamma, beta, save_mean, save_invstd, running_mean, running_var, (long long*)num_batches_tracked, eps, momentum, 0.f, 0, act};
     dwt_bn_geometry(a, n);
+    if ((a.ph & 3) == 0 && HS_DWT_FWD_RPT4) {       // four output rows per thread (round 6): six tile rows for four outputs rows instead of eight
+        const dim3 grid4((W / 2 + 63) / 64, (H / 4 + 3) / 4, batch * channels);
+        if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_fwd_kernel<float, true, 4>), grid4, dim3(256), 0, (hipStream_t)stream, a, n, (const float*)tiled, (float*)y);
+        else hipLaunchKernelGGL((dw_tiles_fwd_kernel<bf16_t, true, 4>), grid4, dim3(256), 0, (hipStream_t)stream, a, n, (const bf16_t*)tiled, (bf16_t*)y);
+        return launch_status();
+    }
     if ((a.ph & 1) == 0) {                 // two output rows per thread: they share a patch
         const dim3 grid2((W / 2 + 63) / 64, (H / 2 + 3) / 4, batch * channels);
         if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_fwd_kernel<float, true, 2>), grid2, dim3(256), 0, (hipStream_t)stream, a, n, (const float*)tiled, (float*)y);
@@ -1314,6 +1355,12 @@ extern "C" int hs_dw_tiles_bwd_in(int32_t dtype, const void* dy, const float* ba
     if (st != HS_OK) return st;
     if (!bank) return HS_ERR_BAD_ARG;
     a.bank = bank;
+    if ((a.ph + 2) % 3 == 0 && HS_DWT_BWD_IN_RPT3) {        // three tile rows per thread (round 6): five output rows for three tile rows instead of six
+        const dim3 grid3((fw * (a.pw + 2) / 2 + 63) / 64, (fh * (a.ph + 2) / 3 + 3) / 4, batch * channels);
+        if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_bwd_in_kernel<float, 3>), grid3, dim3(256), 0, (hipStream_t)stream, a, (const float*)dy, (float*)dtiled);
+        else hipLaunchKernelGGL((dw_tiles_bwd_in_kernel<bf16_t, 3>), grid3, dim3(256), 0, (hipStream_t)stream, a, (const bf16_t*)dy, (bf16_t*)dtiled);
+        return launch_status();
+    }
     if ((a.ph & 1) == 0) {                 // two tile rows per thread: they share a tile (ph + 2 is even)
         const dim3 grid2((fw * (a.pw + 2) / 2 + 63) / 64, (fh * (a.ph + 2) / 2 + 3) / 4, batch * channels);
         if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_bwd_in_kernel<float, 2>), grid2, dim3(256), 0, (hipStream_t)stream, a, (const float*)dy, (float*)dtiled);
@@ -1339,8 +1386,9 @@ extern "C" int hs_dw_tiles_bwd_w(int32_t dtype, const void* tiled, const void* d
         if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<float, false, 2, true>), gridr, dim3(256), 0, (hipStream_t)stream, a, DwtBn{}, (const float*)tiled, (const float*)dy);
         else hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<bf16_t, false, 2, true>), gridr, dim3(256), 0, (hipStream_t)stream, a, DwtBn{}, (const bf16_t*)tiled, (const bf16_t*)dy);
     } else if ((a.ph & 1) == 0) {
-        if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<float, false, 2>), grid, dim3(256), 0, (hipStream_t)stream, a, DwtBn{}, (const float*)tiled, (const float*)dy);
-        else hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<bf16_t, false, 2>), grid, dim3(256), 0, (hipStream_t)stream, a, DwtBn{}, (const bf16_t*)tiled, (const bf16_t*)dy);
+        const dim3 gridc((unsigned)(batch * fh * fw), (channels + 4 * HS_DWT_BWD_W_CPW - 1) / (4 * HS_DWT_BWD_W_CPW));
+        if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<float, false, 2, false, HS_DWT_BWD_W_CPW>), gridc, dim3(256), 0, (hipStream_t)stream, a, DwtBn{}, (const float*)tiled, (const float*)dy);
+        else hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<bf16_t, false, 2, false, HS_DWT_BWD_W_CPW>), gridc, dim3(256), 0, (hipStream_t)stream, a, DwtBn{}, (const bf16_t*)tiled, (const bf16_t*)dy);
     } else if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<float, false>), grid, dim3(256), 0, (hipStream_t)stream, a, DwtBn{}, (const float*)tiled, (const float*)dy);
     else hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<bf16_t, false>), grid, dim3(256), 0, (hipStream_t)stream, a, DwtBn{}, (const bf16_t*)tiled, (const bf16_t*)dy);
     return launch_status();
@@ -1362,8 +1410,9 @@ extern "C" int hs_dw_tiles_bn_bwd_w(int32_t dtype, const void* tiled, const void
         if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<float, true, 2, true>), gridr, dim3(256), 0, (hipStream_t)stream, a, n, (const float*)tiled, (const float*)dy);
         else hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<bf16_t, true, 2, true>), gridr, dim3(256), 0, (hipStream_t)stream, a, n, (const bf16_t*)tiled, (const bf16_t*)dy);
     } else if ((a.ph & 1) == 0) {
-        if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<float, true, 2>), grid, dim3(256), 0, (hipStream_t)stream, a, n, (const float*)tiled, (const float*)dy);
-        else hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<bf16_t, true, 2>), grid, dim3(256), 0, (hipStream_t)stream, a, n, (const bf16_t*)tiled, (const bf16_t*)dy);
+        const dim3 gridc((unsigned)(batch * fh * fw), (channels + 4 * HS_DWT_BWD_W_CPW - 1) / (4 * HS_DWT_BWD_W_CPW));
+        if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<float, true, 2, false, HS_DWT_BWD_W_CPW>), gridc, dim3(256), 0, (hipStream_t)stream, a, n, (const float*)tiled, (const float*)dy);
+        else hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<bf16_t, true, 2, false, HS_DWT_BWD_W_CPW>), gridc, dim3(256), 0, (hipStream_t)stream, a, n, (const bf16_t*)tiled, (const bf16_t*)dy);
     } else if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<float, true>), grid, dim3(256), 0, (hipStream_t)stream, a, n, (const float*)tiled, (const float*)dy);
     else hipLaunchKernelGGL((dw_tiles_bwd_w_kernel<bf16_t, true>), grid, dim3(256), 0, (hipStream_t)stream, a, n, (const bf16_t*)tiled, (const bf16_t*)dy);
     return launch_status();
