@@ -15,6 +15,14 @@
 //    bit patterns (losses are >= 0, so their bits order like integers), then both branches of the rule as sums.
 #include "hs_common.h"
 
+#ifndef HS_HALO_BWD_CH_SMALL
+#define HS_HALO_BWD_CH_SMALL 2
+#endif
+#ifndef HS_HALO_BWD_CH_BIG
+#define HS_HALO_BWD_CH_BIG 4          // channels per thread of halo_tiles_bwd_patch_kernel: 256-pixel patches (BIG) 2 / 4 / 8 -> 17.8 / 16.4 / 20.2 us at config 5's
+                                       // level 4, smaller ones (SMALL) 1 / 2 / 4 -> 9.3 / 8.2 / 9.6 us at level 3 (visits x11 - x14)
+#endif
+
 namespace hs {
 
 struct TileArgs { int B, C, H, W, fh, fw, ph, pw; float inv_ph, inv_pw, inv_ph2, inv_pw2; int pm; float inv_c; };      // reciprocals of ph, pw, ph + 2, pw + 2 (div_by_inv)
@@ -93,7 +101,8 @@ __device__ __forceinline__ int tile_sources_p2(int y, int n, int p, float inv_p,
 
 // (Round 6, visits x3 / x4: two forms with the candidate loads in flight together -- 2 x 2 unpredicated loads per pixel; four rows per thread with
 //  shared column parts, 32-bit offsets and predicated loads -- both measured SLOWER on config 5 (23.0 -> 45.6 / 38.4 us at level 4, 10.0 -> 34.2 /
-//  32.5 us at level 3) although they execute fewer instructions and wait once; the serial form below stays.  profiles/round6_train_*_x3/x4.)
+//  32.5 us at level 3) although they execute fewer instructions and wait once.  What moved the launch in the end is below: mapped by patch, several
+//  channels per thread (halo_tiles_bwd_patch_kernel); this kernel stays for the patch shapes that one does not take.)
 template <typename T>
 __global__ __launch_bounds__(256)
 void halo_tiles_bwd_kernel(TileArgs a, const T* __restrict__ dt, T* __restrict__ dx) {
@@ -124,6 +133,66 @@ void halo_tiles_bwd_kernel(TileArgs a, const T* __restrict__ dt, T* __restrict__
             }
     }
     Store<T>::st(dx, (pl * a.H + y) * a.W + x, acc);
+}
+
+// Round 6, third form -- mapped by PATCH: a workgroup owns the pixels of one patch for 256 / (ph pw) consecutive channels, thread = pixel (u, v).
+// The sources of a pixel are then read off its position with no search and no division by the tile size: its own tile at (u + 1, v + 1); the
+// tile above / below (left / right) when it sits in the patch's first / last row (column) -- their ring rows; the image's reflections for row /
+// column 1 and n - 2 -- in tile_sources_p2's order, so the sum is the one-pixel kernel's bit for bit.  A wave reads four 16-pixel rows of ONE
+// tile (consecutive lines in either layout) where the image-mapped kernel above reads a row across four tiles, and the candidate loads are
+// requested before the first sum.  Patches of 3 x 3 ... 256 pixels whose pixel count divides 256; the rest keeps the kernel above.
+// HB_CH channels per thread: the sources and their offsets depend on the pixel only, so one source list serves HB_CH planes and the candidate
+// loads of all of them are in flight together (one channel per thread -- a wave of one dependent load and one store behind ~150 instructions of
+// set-up -- took the same 23 us as the image-mapped kernel: 57 k such waves, 4.6 generations of them on the chip).
+template <typename T, int HB_CH>
+__global__ __launch_bounds__(256)
+void halo_tiles_bwd_patch_kernel(TileArgs a, const T* __restrict__ dt, T* __restrict__ dx, float inv_npx) {
+    const int npx = a.ph * a.pw, per = 256 / npx;
+    const int lt = div_by_inv((int)threadIdx.x, inv_npx), k = (int)threadIdx.x - lt * npx;
+    const int c0 = (blockIdx.y * per + lt) * HB_CH, b = blockIdx.z;
+    if (c0 >= a.C) return;
+    const int j = (int)blockIdx.x % a.fw, i = (int)blockIdx.x / a.fw;                       // (uniform)
+    const int u = div_by_inv(k, a.inv_pw), v = k - u * a.pw;
+    const int y = i * a.ph + u, x = j * a.pw + v;
+    const size_t pl0 = (size_t)b * a.C + c0;
+    const TilePlane tp = tile_plane(a, pl0);
+    const size_t cstride = a.pm ? (size_t)((a.ph + 2) * (a.pw + 2)) : (size_t)(a.fh * (a.ph + 2)) * (size_t)(a.fw * (a.pw + 2));   // next channel's tile
+    int ty[3], uy[3], tx[3], vx[3], ny = 0, nx = 0;
+    ty[ny] = i; uy[ny++] = u + 1;
+    if (u == 0 && i > 0) { ty[ny] = i - 1; uy[ny++] = a.ph + 1; }
+    if (u == a.ph - 1 && i + 1 < a.fh) { ty[ny] = i + 1; uy[ny++] = 0; }
+    if (y == 1) { ty[ny] = 0; uy[ny++] = 0; }
+    if (y == a.H - 2) { ty[ny] = a.fh - 1; uy[ny++] = a.ph + 1; }
+    tx[nx] = j; vx[nx++] = v + 1;
+    if (v == 0 && j > 0) { tx[nx] = j - 1; vx[nx++] = a.pw + 1; }
+    if (v == a.pw - 1 && j + 1 < a.fw) { tx[nx] = j + 1; vx[nx++] = 0; }
+    if (x == 1) { tx[nx] = 0; vx[nx++] = 0; }
+    if (x == a.W - 2) { tx[nx] = a.fw - 1; vx[nx++] = a.pw + 1; }
+    const int nch = min(HB_CH, a.C - c0);
+    typename Store<T>::raw_t val[HB_CH][3][3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const bool on = p < ny && q < nx;
+            const size_t at = on ? tile_addr(a, tp, ty[p], uy[p], tx[q], vx[q]) : 0;
+#pragma unroll
+            for (int ch = 0; ch < HB_CH; ++ch)
+                val[ch][p][q] = (on && ch < nch) ? Store<T>::raw(dt, at + (size_t)ch * cstride) : typename Store<T>::raw_t(0);
+        }
+#pragma unroll
+    for (int ch = 0; ch < HB_CH; ++ch) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                typename Store<T>::raw_t w = val[ch][p][q];
+                Store<T>::pin(w);
+                if (p < ny && q < nx) acc += Store<T>::cvt(w);
+            }
+        if (ch < nch) Store<T>::st(dx, ((pl0 + ch) * a.H + y) * a.W + x, acc);
+    }
 }
 
 template <typename T, bool BWD>
@@ -940,6 +1009,20 @@ extern "C" int hs_halo_tiles_bwd(int32_t dtype, const void* dtiled, int32_t batc
     const int st = tile_args(a, batch, channels, H, W, fh, fw, patch_major);
     if (st != HS_OK) return st;
     if (!dtiled || !dx) return HS_ERR_BAD_ARG;
+    const int npx = a.ph * a.pw;
+    if (a.ph >= 3 && a.pw >= 3 && npx <= 256 && 256 % npx == 0 && batch <= 65535) {       // mapped by patch
+        const int per = 256 / npx;
+        const float inv_npx = 1.0f / (float)npx;
+        const int ch = per == 1 ? HS_HALO_BWD_CH_BIG : HS_HALO_BWD_CH_SMALL;      // channels per thread
+        const dim3 gridp((unsigned)(fh * fw), (unsigned)((channels + per * ch - 1) / (per * ch)), (unsigned)batch);
+        if (dtype != HS_DTYPE_F32 && dtype != HS_DTYPE_BF16) return HS_ERR_BAD_ARG;
+#define HS_HB_LAUNCH(CH) \
+        if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((halo_tiles_bwd_patch_kernel<float, CH>), gridp, dim3(256), 0, (hipStream_t)stream, a, (const float*)dtiled, (float*)dx, inv_npx); \
+        else hipLaunchKernelGGL((halo_tiles_bwd_patch_kernel<bf16_t, CH>), gridp, dim3(256), 0, (hipStream_t)stream, a, (const bf16_t*)dtiled, (bf16_t*)dx, inv_npx);
+        if (ch == 8) { HS_HB_LAUNCH(8) } else if (ch == 4) { HS_HB_LAUNCH(4) } else { HS_HB_LAUNCH(2) }
+#undef HS_HB_LAUNCH
+        return launch_status();
+    }
     const dim3 grid((W + 63) / 64, (H + 3) / 4, batch * channels);
     HS_TILE_LAUNCH(dtype, halo_tiles_bwd_kernel<float>, halo_tiles_bwd_kernel<bf16_t>, grid, dtiled, dx)
     return launch_status();

@@ -246,8 +246,13 @@ def test_bank_slices_share_one_gradient_buffer(dev, autocast):
         assert torch.equal(one[k], two[k]), k
 
 
-@pytest.mark.parametrize('shape,grid', [((2, 5, 36, 20), (2, 2)), ((1, 3, 8, 12), (4, 3)), ((1, 2, 6, 6), (6, 6)), ((2, 4, 40, 130), (5, 2)),
-                                        ((1, 1, 2, 2), (1, 1))])
+# (the last five shapes: patches whose pixel count divides 256 -- the adjoint mapped by patch, halo_tiles_bwd_patch_kernel, round 6: 16 x 16 with a
+#  ragged last channel group, 8 x 8 and 4 x 4 with several tiles per workgroup, a one-patch image with both reflections on one axis, 4 x 8)
+HALO_SHAPES = [((2, 5, 36, 20), (2, 2)), ((1, 3, 8, 12), (4, 3)), ((1, 2, 6, 6), (6, 6)), ((2, 4, 40, 130), (5, 2)), ((1, 1, 2, 2), (1, 1)),
+               ((2, 5, 32, 48), (2, 3)), ((1, 7, 16, 24), (2, 3)), ((2, 3, 12, 8), (3, 2)), ((1, 3, 4, 64), (1, 1)), ((1, 9, 8, 24), (2, 3))]
+
+
+@pytest.mark.parametrize('shape,grid', HALO_SHAPES)
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_halo_tiles_and_interior_vs_stock_ops(dev, shape, grid, dtype):
     """hs_halo_tiles_* / hs_tile_interior_* (one gather per direction) == F.pad(reflect) -> unfold -> unfold -> permute -> reshape and
@@ -285,7 +290,7 @@ def test_halo_tiles_and_interior_vs_stock_ops(dev, shape, grid, dtype):
     assert torch.equal(ua.grad, ub.grad)
 
 
-@pytest.mark.parametrize('shape,grid', [((2, 5, 36, 20), (2, 2)), ((1, 3, 8, 12), (4, 3)), ((2, 4, 40, 130), (5, 2)), ((1, 2, 6, 6), (6, 6)), ((1, 1, 2, 2), (1, 1))])
+@pytest.mark.parametrize('shape,grid', HALO_SHAPES)
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_patch_major_tiles_are_the_tile_image_permuted(dev, shape, grid, dtype):
     """HaloTiles(patch_major=True) lays the same tiles out one after the other, (B fh fw, C, ph+2, pw+2): values and the adjoint equal the
