@@ -127,6 +127,9 @@ def _load():
         'hs_bootstrapped_ce_bwd': ([i32, vp, vp, i32, i32, i64, i64, vp, vp, vp, vp, vp], C.c_int),
         'hs_bn_act_train_fwd': ([i32, vp, i32, i32, i64, vp, vp, vp, vp, C.c_float, C.c_float, i32, vp, vp, vp, vp, vp, vp], C.c_int),
         'hs_bn_act_train_bwd': ([i32, vp, vp, i32, i32, i64, vp, vp, vp, vp, C.c_float, i32, vp, vp, vp, vp, vp], C.c_int),
+        'hs_dw_tiles_bn_bwd_in_partials': ([i32, i32, i32, i32, i32], C.c_int64),
+        'hs_dw_tiles_bn_bwd_in': ([i32, vp, vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp], C.c_int),
+        'hs_bn_act_train_bwd_apply': ([i32, vp, vp, i32, i32, i64, vp, vp, vp, vp, i32, vp, i64, vp, vp, vp, vp], C.c_int),
         'hs_bootstrap_mean_workspace': ([], C.c_int64),
         'hs_bootstrap_mean_fwd': ([vp, i32, i32, C.c_float, vp, vp, vp], C.c_int),
         'hs_bootstrap_mean_bwd': ([vp, i32, vp, vp, vp, vp], C.c_int),
@@ -183,7 +186,7 @@ EXPORTS = ['hs_version', 'hs_build_info', 'hs_signal2weights_fwd', 'hs_signal2we
            'hs_stage_input_fwd', 'hs_depthwise_conv_fwd', 'hs_depthwise_pool_blocks', 'hs_stem_conv_fwd', 'hs_stem_dw_fwd', 'hs_mbconv_tiles', 'hs_mbconv_expand_dw_fwd', 'hs_se_gate_fwd', 'hs_depthwise_conv_se_fwd', 'hs_mbconv_expand_dw_se_fwd', 'hs_se_tail_workspace', 'hs_se_tail_tails', 'hs_mbconv_se_workgroups', 'hs_pointwise_conv_fwd', 'hs_affine_act_fwd', 'hs_gemm_split_kp', 'hs_gemm_split_fwd', 'hs_gemm_split_conv2x2_fwd', 'hs_gemm_split_up2_fwd', 'hs_pooled_shift_fwd', 'hs_patch_conv_bwd_input',
            'hs_patch_conv_bwd_weight', 'hs_halo_tiles_fwd', 'hs_halo_tiles_bwd', 'hs_tile_interior_fwd', 'hs_tile_interior_bwd', 'hs_dw_tiles_fwd', 'hs_dw_tiles_bwd_in', 'hs_dw_tiles_bwd_w',
            'hs_s2w_train_fwd', 'hs_s2w_train_workspace', 'hs_s2w_train_bwd', 'hs_cross_entropy_fwd', 'hs_cross_entropy_bwd', 'hs_cross_entropy_typed_fwd', 'hs_cross_entropy_typed_bwd', 'hs_bootstrapped_ce_fwd', 'hs_bootstrapped_ce_bwd', 'hs_bootstrap_mean_workspace', 'hs_bootstrap_mean_fwd', 'hs_bootstrap_mean_bwd', 'hs_bootstrap_mean_batched_fwd', 'hs_bootstrap_mean_batched_bwd', 'hs_bn_train_workspace', 'hs_bn_train_stats_fwd', 'hs_dw_tiles_bn_fwd', 'hs_dw_tiles_bn_bwd_w', 'hs_patch_conv_bn_fwd', 'hs_patch_conv_bn_bwd_w', 'hs_adam_blocks', 'hs_adam_step', 'hs_bootstrap_mean_of_batch_fwd', 'hs_bootstrap_mean_of_batch_bwd', 'hs_upsample_bilinear_bwd', 'hs_upsample_bilinear_typed_bwd', 'hs_upsample_bilinear_bf16_fwd', 'hs_stage_input_typed_fwd', 'hs_bank_unpack_fwd', 'hs_bn_act_train_fwd',
-           'hs_bn_act_train_bwd', 'hs_patch_conv_plain_fwd', 'hs_patch_conv_plain_bwd_in', 'hs_patch_conv_plain_bwd_w']
+           'hs_bn_act_train_bwd', 'hs_dw_tiles_bn_bwd_in_partials', 'hs_dw_tiles_bn_bwd_in', 'hs_bn_act_train_bwd_apply', 'hs_patch_conv_plain_fwd', 'hs_patch_conv_plain_bwd_in', 'hs_patch_conv_plain_bwd_w']
 
 
 def check(status, what):

@@ -405,14 +405,27 @@ class DwTilesBN(torch.autograd.Function):
                                                    act, b, c, h, w, fh, fw, dbank.data_ptr(), dbank.stride(0), int(pm), stream)
                 _hip.check(st, 'hs_dw_tiles_bn_bwd_w')
             if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-                da = _dw_tiles_input_gradient(t, dy, bank, (b, c, h, w), (fh, fw), pm)   # gradient of the (never materialised) normalised tiles, stored in t's type
                 dt = torch.empty_like(t)
                 dg = torch.empty(c, device=dev, dtype=torch.float32)
                 db = torch.empty(c, device=dev, dtype=torch.float32)
-                ws = torch.empty(int(_hip.lib.hs_bn_train_workspace(c)), device=dev, dtype=torch.uint8)
-                st = _hip.lib.hs_bn_act_train_bwd(code, t.data_ptr(), da.data_ptr(), t.shape[0], c, px, weight.data_ptr(), bias.data_ptr(),
-                                                  mean.data_ptr(), invstd.data_ptr(), eps, act, ws.data_ptr(), dt.data_ptr(), dg.data_ptr(), db.data_ptr(), stream)
-                _hip.check(st, 'hs_bn_act_train_bwd')
+                if USE_DW_BN_BWD_FUSED:
+                    # round 6: the depthwise adjoint leaves BatchNorm1's two sums as one pair per workgroup; no statistics launch
+                    npart = int(_hip.lib.hs_dw_tiles_bn_bwd_in_partials(b, h, w, fh, fw))
+                    da = torch.empty_like(t)
+                    part = torch.empty(c * npart * 2, device=dev, dtype=torch.float32)
+                    st = _hip.lib.hs_dw_tiles_bn_bwd_in(code, dy.data_ptr(), bank.data_ptr(), bank.stride(0), t.data_ptr(), weight.data_ptr(), bias.data_ptr(),
+                                                        mean.data_ptr(), invstd.data_ptr(), act, b, c, h, w, fh, fw, da.data_ptr(), part.data_ptr(), int(pm), stream)
+                    _hip.check(st, 'hs_dw_tiles_bn_bwd_in')
+                    st = _hip.lib.hs_bn_act_train_bwd_apply(code, t.data_ptr(), da.data_ptr(), t.shape[0], c, px, weight.data_ptr(), bias.data_ptr(),
+                                                            mean.data_ptr(), invstd.data_ptr(), act, part.data_ptr(), npart, dt.data_ptr(), dg.data_ptr(),
+                                                            db.data_ptr(), stream)
+                    _hip.check(st, 'hs_bn_act_train_bwd_apply')
+                else:
+                    da = _dw_tiles_input_gradient(t, dy, bank, (b, c, h, w), (fh, fw), pm)   # gradient of the (never materialised) normalised tiles, stored in t's type
+                    ws = torch.empty(int(_hip.lib.hs_bn_train_workspace(c)), device=dev, dtype=torch.uint8)
+                    st = _hip.lib.hs_bn_act_train_bwd(code, t.data_ptr(), da.data_ptr(), t.shape[0], c, px, weight.data_ptr(), bias.data_ptr(),
+                                                      mean.data_ptr(), invstd.data_ptr(), eps, act, ws.data_ptr(), dt.data_ptr(), dg.data_ptr(), db.data_ptr(), stream)
+                    _hip.check(st, 'hs_bn_act_train_bwd')
         return dt, dg, db, None, None, None, None, None, None, dbank, None, None, None
 
 
@@ -433,6 +446,7 @@ def dw_tiles_bn(bn, act_layer, t, bank, size, grid, patch_major):
 
 
 USE_DW_BN_FUSED = True  # tests switch it off to compare with BNActTrain + DwTilesValid
+USE_DW_BN_BWD_FUSED = True        # False: BatchNorm1's adjoint with its own statistics launch (hs_bn_act_train_bwd; bit-equal to the two Functions)
 USE_SHARED_BANK_GRAD = True  # BankSlices: one gradient buffer for the three ranges (tests switch it off to compare with the concatenation)
 
 

@@ -927,47 +927,85 @@ void dw_tiles_fwd_kernel(DwtArgs a, DwtBn n, const T* __restrict__ t, T* __restr
 // RPT: tile rows per thread (2 where the patch height is even: rows U, U + 1 of one tile share three of the four output rows they read and
 // the nine taps -- 8 pair loads + 9 tap loads for 4 values instead of 12 + 18, half the workgroups; round 6: the one-row form ran at
 // 2.1 TB/s at config 5's level 4, 1.2 TB/s at level 3).  Per value the same fma chain (ky, then kx) as before: bit-identical.
-template <typename T, int RPT = 1>
+// STATS (round 6): the launch also leaves the two sums BatchNorm1's adjoint needs -- per channel, sum of d and of d x_hat over the tile tensor,
+// d = dt act'(z), from the RAW tiles `xt` and the saved statistics (n: gamma, beta, mean, invstd, act) -- as one {s, q} pair per workgroup in
+// `partial` [c][workgroup of the channel][2]; bn_bwd_apply_np_kernel combines a channel's pairs in workgroup order.  The statistics pass of
+// the two-launch adjoint (a read of both tile tensors: 15.6 us at config 5's level 4) is gone; d is formed from the value as STORED (bf16: after
+// its rounding), as the separate pass read it.
+__device__ __forceinline__ float dwt_stored(float v, float*) { return v; }
+__device__ __forceinline__ float dwt_stored(float v, bf16_t*) { bf16_t r; Store<bf16_t>::st(&r, 0, v); return Store<bf16_t>::ld(&r, 0); }
+template <typename T, int RPT = 1, bool STATS = false>
 __global__ __launch_bounds__(256)
-void dw_tiles_bwd_in_kernel(DwtArgs a, const T* __restrict__ dy, T* __restrict__ dt) {
+void dw_tiles_bwd_in_kernel(DwtArgs a, const T* __restrict__ dy, T* __restrict__ dt, DwtBn n, const T* __restrict__ xt, float* __restrict__ partial) {
+    __shared__ float red[4][2];
     const int TW = a.fw * (a.pw + 2), TH = a.fh * (a.ph + 2);
     const int X0 = 2 * (blockIdx.x * 64 + (threadIdx.x & 63)), Y = RPT * (blockIdx.y * 4 + (threadIdx.x >> 6));
     const int plane_id = blockIdx.z;
-    if (X0 >= TW || Y >= TH) return;
+    const bool live = X0 < TW && Y < TH;
+    if (!STATS && !live) return;
     const int b = div_by_inv(plane_id, a.inv_c), c = plane_id - b * a.C;
-    const int i = div_by_inv(Y, a.inv_ph2), U = Y - i * (a.ph + 2), j = div_by_inv(X0, a.inv_pw2), V0 = X0 - j * (a.pw + 2);
-    const T* __restrict__ gp = dy + ((size_t)plane_id * a.H + (size_t)i * a.ph) * a.W + (size_t)j * a.pw;       // the patch's (0, 0) output
-    const float* __restrict__ kp = a.bank + (size_t)((b * a.fh + i) * a.fw + j) * a.ld + c * 9;
-    // rows U - 2 .. U + RPT - 1, columns V0 - 2 .. V0 + 1 of the patch's outputs: two aligned pairs per row, each wholly inside or wholly outside
-    const bool left = V0 >= 2, right = V0 <= a.pw - 2;
-    const int cl = left ? V0 - 2 : 0, cr = right ? V0 : 0;
-    float g[2 + RPT][4], kv[9];
+    float s_d = 0.0f, s_q = 0.0f;
+    if (live) {
+        const int i = div_by_inv(Y, a.inv_ph2), U = Y - i * (a.ph + 2), j = div_by_inv(X0, a.inv_pw2), V0 = X0 - j * (a.pw + 2);
+        const T* __restrict__ gp = dy + ((size_t)plane_id * a.H + (size_t)i * a.ph) * a.W + (size_t)j * a.pw;       // the patch's (0, 0) output
+        const float* __restrict__ kp = a.bank + (size_t)((b * a.fh + i) * a.fw + j) * a.ld + c * 9;
+        // rows U - 2 .. U + RPT - 1, columns V0 - 2 .. V0 + 1 of the patch's outputs: two aligned pairs per row, each wholly inside or wholly outside
+        const bool left = V0 >= 2, right = V0 <= a.pw - 2;
+        const int cl = left ? V0 - 2 : 0, cr = right ? V0 : 0;
+        float g[2 + RPT][4], kv[9], xv[RPT][2];
 #pragma unroll
-    for (int r = 0; r < 2 + RPT; ++r) {                               // r <-> output row U - 2 + r
-        const int ur = U - 2 + r;
-        const bool row_in = ur >= 0 && ur < a.ph;
-        const size_t rb = (size_t)min(max(ur, 0), a.ph - 1) * a.W;
-        float l0, l1, r0, r1;
-        Pair<T>::ld(gp, rb + cl, l0, l1);
-        Pair<T>::ld(gp, rb + cr, r0, r1);
-        g[r][0] = (row_in && left) ? l0 : 0.0f; g[r][1] = (row_in && left) ? l1 : 0.0f;
-        g[r][2] = (row_in && right) ? r0 : 0.0f; g[r][3] = (row_in && right) ? r1 : 0.0f;
-    }
+        for (int r = 0; r < 2 + RPT; ++r) {                           // r <-> output row U - 2 + r
+            const int ur = U - 2 + r;
+            const bool row_in = ur >= 0 && ur < a.ph;
+            const size_t rb = (size_t)min(max(ur, 0), a.ph - 1) * a.W;
+            float l0, l1, r0, r1;
+            Pair<T>::ld(gp, rb + cl, l0, l1);
+            Pair<T>::ld(gp, rb + cr, r0, r1);
+            g[r][0] = (row_in && left) ? l0 : 0.0f; g[r][1] = (row_in && left) ? l1 : 0.0f;
+            g[r][2] = (row_in && right) ? r0 : 0.0f; g[r][3] = (row_in && right) ? r1 : 0.0f;
+        }
 #pragma unroll
-    for (int q = 0; q < 9; ++q) kv[q] = kp[q];
-    int RS;
-    const size_t torg = dwt_tile(a, b, c, i, j, RS);
+        for (int q = 0; q < 9; ++q) kv[q] = kp[q];
+        int RS;
+        const size_t torg = dwt_tile(a, b, c, i, j, RS);
+        if constexpr (STATS) {
 #pragma unroll
-    for (int ro = 0; ro < RPT; ++ro) {
-        float acc0 = 0.0f, acc1 = 0.0f;
+            for (int ro = 0; ro < RPT; ++ro) Pair<T>::ld(xt, torg + (size_t)(U + ro) * RS + V0, xv[ro][0], xv[ro][1]);
+        }
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        for (int ro = 0; ro < RPT; ++ro) {
+            float acc0 = 0.0f, acc1 = 0.0f;
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {                          // output (U + ro - ky, V - kx): row index 2 + ro - ky, column index V - kx - (V0 - 2)
-                acc0 = fmaf(kv[ky * 3 + kx], g[2 + ro - ky][2 - kx], acc0);
-                acc1 = fmaf(kv[ky * 3 + kx], g[2 + ro - ky][3 - kx], acc1);
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {                      // output (U + ro - ky, V - kx): row index 2 + ro - ky, column index V - kx - (V0 - 2)
+                    acc0 = fmaf(kv[ky * 3 + kx], g[2 + ro - ky][2 - kx], acc0);
+                    acc1 = fmaf(kv[ky * 3 + kx], g[2 + ro - ky][3 - kx], acc1);
+                }
+            Pair<T>::st(dt, torg + (size_t)(U + ro) * RS + V0, acc0, acc1);
+            if constexpr (STATS) {
+                const float mean = n.mean[c], invstd = n.invstd[c], gm = n.gamma ? n.gamma[c] : 1.f, bt = n.beta ? n.beta[c] : 0.f;
+                const float accs[2] = {dwt_stored(acc0, (T*)nullptr), dwt_stored(acc1, (T*)nullptr)};
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float xh = (xv[ro][e] - mean) * invstd, z = fmaf(xh, gm, bt);
+                    const float gr = n.act == HS_ACT_RELU ? (z > 0.f ? 1.f : 0.f) : (n.act == HS_ACT_RELU6 ? ((z > 0.f && z < 6.f) ? 1.f : 0.f) : 1.f);
+                    const float d = accs[e] * gr;
+                    s_d += d; s_q = fmaf(d, xh, s_q);
+                }
             }
-        Pair<T>::st(dt, torg + (size_t)(U + ro) * RS + V0, acc0, acc1);
+        }
+    }
+    if constexpr (STATS) {
+        s_d = wave_sum64(s_d); s_q = wave_sum64(s_q);
+        const int wave = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { red[wave][0] = s_d; red[wave][1] = s_q; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const size_t np = (size_t)a.B * gridDim.y * gridDim.x, widx = ((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            partial[((size_t)c * np + widx) * 2] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+            partial[((size_t)c * np + widx) * 2 + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+        }
     }
 }
 
@@ -1348,6 +1386,23 @@ extern "C" int hs_dw_tiles_bn_fwd(int32_t dtype, const void* tiled, const float*
     return launch_status();
 }
 
+// rows per thread of hs_dw_tiles_bwd_in*: 3 where the tile height allows, else 2 (even patches), else 1
+static int dwt_bwd_in_rows(const DwtArgs& a) { return ((a.ph + 2) % 3 == 0 && HS_DWT_BWD_IN_RPT3) ? 3 : ((a.ph & 1) == 0 ? 2 : 1); }
+static dim3 dwt_bwd_in_grid(const DwtArgs& a, int rpt) {
+    return dim3((a.fw * (a.pw + 2) / 2 + 63) / 64, (a.fh * (a.ph + 2) / rpt + 3) / 4, a.B * a.C);
+}
+template <bool STATS>
+static int dwt_bwd_in_launch(int dtype, const DwtArgs& a, const void* dy, void* dtiled, const DwtBn& n, const void* xt, float* partial, void* stream) {
+    const int rpt = dwt_bwd_in_rows(a);
+    const dim3 grid = dwt_bwd_in_grid(a, rpt);
+#define HS_DWT_BI(RPT) \
+    if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_bwd_in_kernel<float, RPT, STATS>), grid, dim3(256), 0, (hipStream_t)stream, a, (const float*)dy, (float*)dtiled, n, (const float*)xt, partial); \
+    else hipLaunchKernelGGL((dw_tiles_bwd_in_kernel<bf16_t, RPT, STATS>), grid, dim3(256), 0, (hipStream_t)stream, a, (const bf16_t*)dy, (bf16_t*)dtiled, n, (const bf16_t*)xt, partial);
+    if (rpt == 3) { HS_DWT_BI(3) } else if (rpt == 2) { HS_DWT_BI(2) } else { HS_DWT_BI(1) }
+#undef HS_DWT_BI
+    return launch_status();
+}
+
 extern "C" int hs_dw_tiles_bwd_in(int32_t dtype, const void* dy, const float* bank, int64_t ld, int32_t batch, int32_t channels, int32_t H,
                                   int32_t W, int32_t fh, int32_t fw, void* dtiled, int32_t patch_major, void* stream) {
     DwtArgs a;
@@ -1355,22 +1410,30 @@ extern "C" int hs_dw_tiles_bwd_in(int32_t dtype, const void* dy, const float* ba
     if (st != HS_OK) return st;
     if (!bank) return HS_ERR_BAD_ARG;
     a.bank = bank;
-    if ((a.ph + 2) % 3 == 0 && HS_DWT_BWD_IN_RPT3) {        // three tile rows per thread (round 6): five output rows for three tile rows instead of six
-        const dim3 grid3((fw * (a.pw + 2) / 2 + 63) / 64, (fh * (a.ph + 2) / 3 + 3) / 4, batch * channels);
-        if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_bwd_in_kernel<float, 3>), grid3, dim3(256), 0, (hipStream_t)stream, a, (const float*)dy, (float*)dtiled);
-        else hipLaunchKernelGGL((dw_tiles_bwd_in_kernel<bf16_t, 3>), grid3, dim3(256), 0, (hipStream_t)stream, a, (const bf16_t*)dy, (bf16_t*)dtiled);
-        return launch_status();
-    }
-    if ((a.ph & 1) == 0) {                 // two tile rows per thread: they share a tile (ph + 2 is even)
-        const dim3 grid2((fw * (a.pw + 2) / 2 + 63) / 64, (fh * (a.ph + 2) / 2 + 3) / 4, batch * channels);
-        if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_bwd_in_kernel<float, 2>), grid2, dim3(256), 0, (hipStream_t)stream, a, (const float*)dy, (float*)dtiled);
-        else hipLaunchKernelGGL((dw_tiles_bwd_in_kernel<bf16_t, 2>), grid2, dim3(256), 0, (hipStream_t)stream, a, (const bf16_t*)dy, (bf16_t*)dtiled);
-        return launch_status();
-    }
-    const dim3 grid((fw * (a.pw + 2) / 2 + 63) / 64, (fh * (a.ph + 2) + 3) / 4, batch * channels);
-    if (dtype == HS_DTYPE_F32) hipLaunchKernelGGL((dw_tiles_bwd_in_kernel<float, 1>), grid, dim3(256), 0, (hipStream_t)stream, a, (const float*)dy, (float*)dtiled);
-    else hipLaunchKernelGGL((dw_tiles_bwd_in_kernel<bf16_t, 1>), grid, dim3(256), 0, (hipStream_t)stream, a, (const bf16_t*)dy, (bf16_t*)dtiled);
-    return launch_status();
+    return dwt_bwd_in_launch<false>(dtype, a, dy, dtiled, DwtBn{}, nullptr, nullptr, stream);
+}
+
+// hs_dw_tiles_bwd_in for a layer whose tiles are normalised on load (hs_dw_tiles_bn_fwd), leaving -- besides the gradient of the normalised tiles
+// in `dtiled` -- the two sums of BatchNorm1's adjoint over the tile tensor as one pair per workgroup in `partial` (round 6):
+// hs_dw_tiles_bn_bwd_in_partials() pairs per channel, combined by hs_bn_act_train_bwd_apply.  `tiled`: the RAW tiles (the forward's input).
+extern "C" int64_t hs_dw_tiles_bn_bwd_in_partials(int32_t batch, int32_t H, int32_t W, int32_t fh, int32_t fw) {
+    if (batch <= 0 || H <= 0 || W <= 0 || fh <= 0 || fw <= 0 || H % fh || W % fw) return 0;
+    DwtArgs a{};
+    a.B = batch; a.C = 1; a.fh = fh; a.fw = fw; a.ph = H / fh; a.pw = W / fw;
+    const dim3 g = dwt_bwd_in_grid(a, dwt_bwd_in_rows(a));
+    return (int64_t)batch * g.y * g.x;
+}
+extern "C" int hs_dw_tiles_bn_bwd_in(int32_t dtype, const void* dy, const float* bank, int64_t ld, const void* tiled, const float* gamma,
+                                     const float* beta, const float* save_mean, const float* save_invstd, int32_t act, int32_t batch,
+                                     int32_t channels, int32_t H, int32_t W, int32_t fh, int32_t fw, void* dtiled, float* partial,
+                                     int32_t patch_major, void* stream) {
+    DwtArgs a;
+    const int st = dwt_args(a, dtype, dy, dtiled, (long)ld, batch, channels, H, W, fh, fw, patch_major);
+    if (st != HS_OK) return st;
+    if (!bank || !tiled || !save_mean || !save_invstd || !partial || act < HS_ACT_NONE || act > HS_ACT_RELU6 || (((size_t)tiled) & 7)) return HS_ERR_BAD_ARG;
+    a.bank = bank;
+    DwtBn n{nullptr, gamma, beta, const_cast<float*>(save_mean), const_cast<float*>(save_invstd), nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0, act};
+    return dwt_bwd_in_launch<true>(dtype, a, dy, dtiled, n, tiled, partial, stream);
 }
 
 extern "C" int hs_dw_tiles_bwd_w(int32_t dtype, const void* tiled, const void* dy, int32_t batch, int32_t channels, int32_t H, int32_t W,

@@ -571,6 +571,29 @@ void bn_bwd_apply_kernel(BnArgs a, const T* __restrict__ x, const T* __restrict_
     else bn_bwd_walk<T, false, true>(a, x, dy, dx, c, lo, hi, mean, invstd, g, bb, k0, ms, mq, u0, u1);
 }
 
+// bn_bwd_apply_kernel with the channel's sums given as `np` pairs (any count: the producer's workgroups -- hs_dw_tiles_bn_bwd_in -- instead of a
+// statistics launch's 32 slices), combined here in pair order: thread t takes pairs t, t + 256, ..., then the workgroup's fixed tree.
+template <typename T>
+__global__ __launch_bounds__(256)
+void bn_bwd_apply_np_kernel(BnArgs a, const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ partial, int np,
+                            const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ save_mean,
+                            const float* __restrict__ save_invstd, T* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float red[4][2];
+    const int c = blockIdx.x, chunk = blockIdx.y;
+    float s = 0.f, q = 0.f;
+    for (int i = threadIdx.x; i < np; i += 256) { s += partial[((size_t)c * np + i) * 2]; q += partial[((size_t)c * np + i) * 2 + 1]; }
+    bn_block_sum2(s, q, red);
+    if (chunk == 0 && threadIdx.x == 0) { if (dgamma) dgamma[c] = q; if (dbeta) dbeta[c] = s; }
+    const float n = (float)((long)a.B * a.HW);
+    const float mean = save_mean[c], invstd = save_invstd[c], g = gamma ? gamma[c] : 1.f, bb = beta ? beta[c] : 0.f;
+    const float k0 = g * invstd, ms = s / n, mq = q / n;
+    int lo, hi;
+    bn_slice(a, chunk, lo, hi);
+    float u0 = 0.f, u1 = 0.f;
+    if (a.HW >= 256) bn_bwd_walk<T, true, true>(a, x, dy, dx, c, lo, hi, mean, invstd, g, bb, k0, ms, mq, u0, u1);
+    else bn_bwd_walk<T, false, true>(a, x, dy, dx, c, lo, hi, mean, invstd, g, bb, k0, ms, mq, u0, u1);
+}
+
 // Small channels (B HW <= BN_SMALL_MAX = 16 x 1024 elements: the k = 1 levels at config 5) in ONE launch per direction: a workgroup of 1024
 // threads owns a channel and holds it in registers -- every load of the channel in flight at once, statistics through LDS, the result from
 // the registers.  The two-launch form costs such a layer 4 x ~5.5 us per step -- the launches' own floor -- for a few tens of KB.
@@ -975,6 +998,27 @@ extern "C" int hs_bn_act_train_bwd(int32_t dtype, const void* x, const void* dy,
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, dim3(256), 0, s, a, (const bf16_t*)x, (const bf16_t*)dy, (const float*)workspace,
                            gamma, beta, save_mean, save_invstd, (bf16_t*)dx, dgamma, dbeta);
     } else return HS_ERR_BAD_ARG;
+    return launch_status();
+}
+
+// The second half of hs_bn_act_train_bwd alone, from sums some producer left as `n_partials` {sum d, sum d x_hat} pairs per channel
+// (partial[(c n_partials + i) 2 + {0, 1}]; hs_dw_tiles_bn_bwd_in): dx, dgamma, dbeta.  One launch.
+extern "C" int hs_bn_act_train_bwd_apply(int32_t dtype, const void* x, const void* dy, int32_t batch, int32_t channels, int64_t pixels,
+                                         const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, int32_t act,
+                                         const float* partial, int64_t n_partials, void* dx, float* dgamma, float* dbeta, void* stream) {
+    BnArgs a;
+    const int st = bn_args(a, batch, channels, pixels, act, 0.f, 0.f);
+    if (st != HS_OK) return st;
+    if (!x || !dy || !dx || !save_mean || !save_invstd || !partial || n_partials <= 0 || n_partials > 0x7fffffffL) return HS_ERR_BAD_ARG;
+    const dim3 grid(channels, BN_CHUNKS);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == HS_DTYPE_F32)
+        hipLaunchKernelGGL(bn_bwd_apply_np_kernel<float>, grid, dim3(256), 0, s, a, (const float*)x, (const float*)dy, partial, (int)n_partials, gamma, beta,
+                           save_mean, save_invstd, (float*)dx, dgamma, dbeta);
+    else if (dtype == HS_DTYPE_BF16)
+        hipLaunchKernelGGL(bn_bwd_apply_np_kernel<bf16_t>, grid, dim3(256), 0, s, a, (const bf16_t*)x, (const bf16_t*)dy, partial, (int)n_partials, gamma, beta,
+                           save_mean, save_invstd, (bf16_t*)dx, dgamma, dbeta);
+    else return HS_ERR_BAD_ARG;
     return launch_status();
 }
 

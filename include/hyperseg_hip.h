@@ -590,6 +590,19 @@ int hs_bn_act_train_fwd(int32_t dtype, const void* x, int32_t batch, int32_t cha
 int hs_bn_act_train_bwd(int32_t dtype, const void* x, const void* dy, int32_t batch, int32_t channels, int64_t pixels,
                         const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, float eps, int32_t act,
                         void* workspace, void* dx, float* dgamma, float* dbeta, void* stream);
+/* BatchNorm1's adjoint of a train-mode inverted residual WITHOUT its statistics launch (round 6; hyperseg_v1_0.py:352-360 under autograd): the
+ * valid depthwise adjoint hs_dw_tiles_bwd_in, given the RAW tiles `tiled` and the statistics hs_dw_tiles_bn_fwd saved, also leaves the adjoint's two
+ * per-channel sums over the tile tensor (sum of d, sum of d x_hat; d = dtiled act'(bn(tiled))) as one pair per workgroup: partial holds
+ * channels x hs_dw_tiles_bn_bwd_in_partials(batch, H, W, fh, fw) pairs of floats.  hs_bn_act_train_bwd_apply = the second launch of
+ * hs_bn_act_train_bwd from such pairs (n_partials per channel, combined in order): dx, dgamma, dbeta.  Same values as the two-launch adjoint up to
+ * the association of the sums. */
+int64_t hs_dw_tiles_bn_bwd_in_partials(int32_t batch, int32_t H, int32_t W, int32_t fh, int32_t fw);
+int hs_dw_tiles_bn_bwd_in(int32_t dtype, const void* dy, const float* bank, int64_t ld, const void* tiled, const float* gamma, const float* beta,
+                          const float* save_mean, const float* save_invstd, int32_t act, int32_t batch, int32_t channels, int32_t H, int32_t W,
+                          int32_t fh, int32_t fw, void* dtiled, float* partial, int32_t patch_major, void* stream);
+int hs_bn_act_train_bwd_apply(int32_t dtype, const void* x, const void* dy, int32_t batch, int32_t channels, int64_t pixels, const float* gamma,
+                              const float* beta, const float* save_mean, const float* save_invstd, int32_t act, const float* partial,
+                              int64_t n_partials, void* dx, float* dgamma, float* dbeta, void* stream);
 
 /* signal2weights on the TRAINING path, every level of a decoder per launch (hyperseg_v1_0.py:473-484 + the permute / reshape of
  * :334-337, 491, and their autograd): the weights are the Conv2d parameters in their OWN layout (wc, signal_channels / groups) --
