@@ -436,7 +436,8 @@ template <typename TP, typename TO>
 __global__ __launch_bounds__(256)
 void stage_input_plane_kernel(StageIn s, TO* __restrict__ y) {
     // four rows per thread (yy0, + 4, + 8, + 12), their taps requested before the first store (round 6: one element per thread ran at
-    // 1.9 TB/s on config 5's level 4)
+    // 1.9 TB/s on config 5's level 4; two PLANES per thread on top -- the sampling positions shared -- measured slower on the small
+    // levels, +1.7 us each, and no faster on the large one: visit x18)
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), yy0 = blockIdx.y * 16 + (threadIdx.x >> 6);
     if (x >= s.W || yy0 >= s.H) return;
     const int plane = blockIdx.z, cin = s.cin();

@@ -48,26 +48,34 @@ __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >
 template <typename T>
 __global__ __launch_bounds__(256)
 void halo_tiles_fwd_kernel(TileArgs a, const T* __restrict__ x, T* __restrict__ t) {
-    // four tile rows per thread (Y, Y + 4, Y + 8, Y + 12: a wave still walks 64 consecutive columns of one row), their loads requested together;
-    // the column arithmetic is shared (round 6: one element per thread -- 21 k workgroups of a load and a store each -- ran at 2.2 TB/s)
+    // four tile rows (Y, Y + 4, Y + 8, Y + 12: a wave still walks 64 consecutive columns of one row) of TWO planes per thread, the eight loads
+    // requested together; the row / column arithmetic and the offset inside a plane's tiles are shared by the planes (round 6: one element per
+    // thread -- 21 k workgroups of a load and a store each -- ran at 2.2 TB/s)
     const int TW = a.fw * (a.pw + 2), TH = a.fh * (a.ph + 2);
     const int X = blockIdx.x * 64 + (threadIdx.x & 63), Y0 = blockIdx.y * 16 + (threadIdx.x >> 6);
     if (X >= TW || Y0 >= TH) return;
     const int j = div_by_inv(X, a.inv_pw2), v = X - j * (a.pw + 2), xx = reflect1(j * a.pw + v - 1, a.W);
-    const size_t pl = blockIdx.z;
-    const TilePlane tp = tile_plane(a, pl);
-    typename Store<T>::raw_t val[4];
+    const size_t pl0 = (size_t)blockIdx.z * 2, npl = (size_t)a.B * a.C;
+    const bool two = pl0 + 1 < npl;
+    const TilePlane tp0 = tile_plane(a, pl0), tp1 = tile_plane(a, two ? pl0 + 1 : pl0), zero{0, 0};
+    const size_t base0 = a.pm ? tp0.pm_base : tp0.im_base, base1 = a.pm ? tp1.pm_base : tp1.im_base;
+    typename Store<T>::raw_t val[2][4];
     size_t dst[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int Y = min(Y0 + 4 * r, TH - 1);                        // a row past the end repeats the last one (and is not stored)
         const int i = div_by_inv(Y, a.inv_ph2), u = Y - i * (a.ph + 2), y = reflect1(i * a.ph + u - 1, a.H);
-        val[r] = Store<T>::raw(x, (pl * a.H + y) * a.W + xx);
-        dst[r] = tile_addr(a, tp, i, u, j, v);
+        const size_t src = (size_t)y * a.W + xx;
+        val[0][r] = Store<T>::raw(x, pl0 * a.H * a.W + src);
+        val[1][r] = Store<T>::raw(x, (two ? pl0 + 1 : pl0) * a.H * a.W + src);
+        dst[r] = tile_addr(a, zero, i, u, j, v);                      // offset inside a plane's tiles: the same for every plane
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-        if (Y0 + 4 * r < TH) Store<T>::st(t, dst[r], Store<T>::cvt(val[r]));
+        if (Y0 + 4 * r < TH) {
+            Store<T>::st(t, base0 + dst[r], Store<T>::cvt(val[0][r]));
+            if (two) Store<T>::st(t, base1 + dst[r], Store<T>::cvt(val[1][r]));
+        }
 }
 
 // candidates (tile index, position inside the tile) of one axis that map onto image index y: every padded coordinate that reflects
@@ -1042,7 +1050,7 @@ extern "C" int hs_halo_tiles_fwd(int32_t dtype, const void* x, int32_t batch, in
     const int st = tile_args(a, batch, channels, H, W, fh, fw, patch_major);
     if (st != HS_OK) return st;
     if (!x || !tiled) return HS_ERR_BAD_ARG;
-    const dim3 grid((fw * (a.pw + 2) + 63) / 64, (fh * (a.ph + 2) + 15) / 16, batch * channels);        // four rows per thread
+    const dim3 grid((fw * (a.pw + 2) + 63) / 64, (fh * (a.ph + 2) + 15) / 16, (batch * channels + 1) / 2);        // four rows of two planes per thread
     HS_TILE_LAUNCH(dtype, halo_tiles_fwd_kernel<float>, halo_tiles_fwd_kernel<bf16_t>, grid, x, tiled)
     return launch_status();
 }

@@ -1271,7 +1271,8 @@ def test_general_meta_conv_on_a_column_range_of_a_wider_weight_tensor(dev):
 
 @pytest.mark.parametrize('patch_major', [True, False])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-def test_dw_tiles_bn_on_load_equals_batchnorm_then_depthwise(dev, patch_major, dtype):
+@pytest.mark.parametrize('geom', [(2, 8, 3, 3, 32, 32), (2, 8, 6, 6, 16, 16), (2, 6, 10, 10, 7, 8)], ids=['32x32', '16x16', '7x8'])
+def test_dw_tiles_bn_on_load_equals_batchnorm_then_depthwise(dev, patch_major, dtype, geom):
     """autograd.DwTilesBN (round 5: BatchNorm1 + ReLU6 applied to the raw halo tiles ON LOAD by the depthwise layer, statistics finalised
     by the same launch) against the two Functions it replaces (BNActTrain, then DwTilesValid): fp32 -- the same arithmetic per value, so
     outputs, all four gradients, saved / running statistics and the step counter are BIT-EQUAL (channels large enough for the two-launch
@@ -1280,7 +1281,7 @@ def test_dw_tiles_bn_on_load_equals_batchnorm_then_depthwise(dev, patch_major, d
     import copy
     import torch.nn as nn
     from hyperseg_amd import autograd as HA
-    b, c, fh, fw, ph, pw = 2, 8, 3, 3, 32, 32
+    b, c, fh, fw, ph, pw = geom            # 32 x 32: two tile rows per thread in the adjoint; 16 x 16 and 7 x 8: three (round 6); each > 16 384 elements per channel
     h, w = fh * ph, fw * pw
     shape = (b * fh * fw, c, ph + 2, pw + 2) if patch_major else (b, c, fh * (ph + 2), fw * (pw + 2))
     t0 = (torch.randn(shape, generator=G(3101)) * 1.7 + 0.4).to(dev)
