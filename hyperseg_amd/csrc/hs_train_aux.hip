@@ -1201,6 +1201,9 @@ extern "C" int hs_cross_entropy_bwd(const float* logits, const int64_t* target, 
 
 // BootstrappedCrossEntropyLoss.forward as ONE entry (round 6; hyperseg/losses/bootstrapped_ce_loss.py:15-27): hs_cross_entropy_typed_fwd +
 // hs_bootstrap_mean_of_batch_fwd (six launches), keeping what the one-launch adjoint below needs.  Same values bit for bit.
+// (Clearing the selection's workspace inside the loss launch instead of by the memset launch was tried -- visits x20 - x22: the memset's 5 us go, but
+//  the four launches that count into the workspace afterwards get slower by 4 us between them (bm_sums_kernel 7.0 -> 9.7), plain or write-through
+//  stores alike: a wash, not in.)
 extern "C" int hs_bootstrapped_ce_fwd(int32_t dtype, const void* logits, const int64_t* target, int32_t batch, int32_t classes, int64_t pixels,
                                       int64_t ignore_index, int32_t k, float thresh, void* workspace, float* loss, float* out8, float* mean_out,
                                       void* stream) {
