@@ -359,6 +359,21 @@ def test_upsample_bilinear_autograd_vs_torch(dev, shape, size):
     assert rel_err(xb.grad.cpu(), xa.grad.cpu()) < 2e-6
 
 
+@pytest.mark.parametrize('shape,size', [((2, 12, 72, 72), (144, 144)), ((1, 3, 6, 10), (12, 20)), ((1, 2, 1, 6), (2, 12)), ((1, 1, 2, 2), (4, 4)),
+                                        ((1, 3, 5, 7), (10, 14)), ((1, 4, 9, 6), (23, 17))])
+def test_upsample_bilinear_bf16_equals_the_fp32_kernel_rounded_once(dev, shape, size):
+    """hs_upsample_bilinear_bf16_fwd (bf16 storage, f32 arithmetic) == hs_upsample_bilinear_fwd on the widened input, rounded to bf16 once, bit for
+    bit: the exact-2x shapes with an even width take upsample2x_bf16_kernel (round 6: 2 x 4 outputs per thread, 8-byte stores), the others the
+    general kernel."""
+    from hyperseg_amd import autograd as HA
+    g = torch.Generator().manual_seed(sum(shape) + size[1])
+    x = (torch.randn(shape, generator=g) * 3).to(dev).bfloat16()
+    y16 = HA.UpsampleBilinear.apply(x, size)
+    y32 = HA.UpsampleBilinear.apply(x.float(), size)
+    assert y16.dtype == torch.bfloat16 and y16.shape == y32.shape
+    assert torch.equal(y16, y32.bfloat16())
+
+
 @pytest.mark.parametrize('act', [None, 'relu', 'relu6'])
 @pytest.mark.parametrize('shape', [(2, 44, 36, 54), (1, 3, 7, 5), (3, 16, 1, 1), (2, 5, 129, 33),          # one launch per direction (<= 16384 elements per channel)
                                    (2, 6, 200, 160), (1, 3, 300, 211), (2, 4, 96, 86)])                  # two launches: 32 slices per channel
