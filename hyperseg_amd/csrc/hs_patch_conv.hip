@@ -7,6 +7,7 @@
 //      conflict-free and the weight reads are broadcasts; stores are row-contiguous.
 // These levels (k=1 levels 0-2 of HyperSeg-M/S, and every v0_1 conv) are bound by the bank read:
 // bytes/patch = hp*4, FLOPs/patch = 2*hp*ph*pw.
+#include <type_traits>
 #include "hs_common.h"
 #include "hs_s2w_blocked.h"
 #include <cstddef>
@@ -115,7 +116,9 @@ struct Conv1Args {
 // value too): the index arithmetic -- e -> (channel, pixel), pixel -> (row, column), output -> (o, pixel) -- is shifts and masks
 // instead of run-time integer divisions, which were a third of this kernel's ~970 vector instructions per wave
 // (profiles/round3_pmc_k1_and_s2w.txt).  PWL = -1: any patch size.
-template <int PWL>
+// TS (round 6): storage type of the input (given as the stage's `skip`) and of the output: float everywhere but the bf16 training step's k = 1
+// levels (launch_conv1x1_bf16: no coordinates, no previous level, no epilogue), whose generic kernel was 6 us per launch slower than this one.
+template <int PWL, typename TS = float>
 __device__ __forceinline__ void conv1x1_body(const Conv1Args& a, const int patch, float* __restrict__ lds) {
     const int ph_ = PWL >= 0 ? (1 << PWL) : a.ph, pw_ = PWL >= 0 ? (1 << PWL) : a.pw;
     const int tid = threadIdx.x;
@@ -177,7 +180,7 @@ __device__ __forceinline__ void conv1x1_body(const Conv1Args& a, const int patch
         if (s.c_skip > 0) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                sk[q] = s.skip[(((size_t)b * s.c_skip + min(max(cc[q], 0), s.c_skip - 1)) * s.H + yy[q]) * s.W + xx[q]];
+                sk[q] = Store<TS>::ld(reinterpret_cast<const TS*>(s.skip), (((size_t)b * s.c_skip + min(max(cc[q], 0), s.c_skip - 1)) * s.H + yy[q]) * s.W + xx[q]);
         }
         // a same-resolution previous level is the bilinear form with both taps on the pixel and weights (1, 0): one arm
         const bool bilinear = s.prev_mode != HS_PREV_SAME;
@@ -232,7 +235,8 @@ __device__ __forceinline__ void conv1x1_body(const Conv1Args& a, const int patch
     for (int e = tid + 4 * CONV_THREADS; e < total_x; e += CONV_THREADS) {
         const int c = e / npix, pix = e - c * npix;
         const int u = pix / pw_, vv = pix - u * pw_;
-        xl[e] = stage_value(a.in, b, c, stage_pos(a.in, y0 + u, x0 + vv));
+        if constexpr (std::is_same<TS, float>::value) xl[e] = stage_value(a.in, b, c, stage_pos(a.in, y0 + u, x0 + vv));
+        else xl[e] = Store<TS>::ld(reinterpret_cast<const TS*>(a.in.skip), (((size_t)b * a.in.c_skip + c) * a.in.H + (y0 + u)) * a.in.W + (x0 + vv));     // (typed form: skip only)
     }
     __syncthreads();
 
@@ -269,16 +273,16 @@ __device__ __forceinline__ void conv1x1_body(const Conv1Args& a, const int patch
             }
             acc = apply_act(acc, a.act);
             const int u = pix / pw_, v = pix - u * pw_;
-            a.y[(((size_t)b * a.cout + o) * a.in.H + (i * ph_ + u)) * a.in.W + (j * pw_ + v)] = acc;
+            Store<TS>::st(reinterpret_cast<TS*>(a.y), (((size_t)b * a.cout + o) * a.in.H + (i * ph_ + u)) * a.in.W + (j * pw_ + v), acc);
         }
     }
 }
 
-template <int PWL>
+template <int PWL, typename TS = float>
 __global__ __launch_bounds__(CONV_THREADS)
 void patch_conv1x1_kernel(Conv1Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    conv1x1_body<PWL>(a, (int)blockIdx.x, lds);
+    conv1x1_body<PWL, TS>(a, (int)blockIdx.x, lds);
 }
 
 // Heterogeneous launch (round 4): workgroups [0, conv_blocks) are the k = 1 patch convolution's, the rest are blocked
@@ -654,6 +658,36 @@ static int launch_conv1x1(const StageIn& si, int batch, int fh, int fw, int ph, 
     HS_K1_LAUNCH(-1);
 #undef HS_K1_LAUNCH
 }
+
+// The same form for the bf16 training step's k = 1 levels (hs_patch_conv_plain_fwd, hs_patch_conv_train.hip): x (B, cin, H, W) and y (B, c_out, H, W)
+// in bf16, fp32 bank, groups = 1, no epilogue.  1 = the form does not apply (the caller keeps its generic kernel).
+namespace hs {
+int launch_conv1x1_bf16(const void* x, int batch, int cin, int H, int W, int fh, int fw, const float* bank, long ld, int c_out, void* y,
+                        hipStream_t stream) {
+    const int ph = H / fh, pw = W / fw;
+    const size_t hp4 = ((size_t)c_out * cin + 3) & ~(size_t)3;
+    const size_t lds1 = (hp4 + (size_t)cin * ph * pw) * sizeof(float);
+    if (!(lds1 <= 64 * 1024 && (ld & 3) == 0 && ((uintptr_t)bank & 15) == 0 && ph * pw <= 64 && cin >= 1)) return 1;
+    Conv1Args f{};
+    f.in.skip = reinterpret_cast<const float*>(x); f.in.prev = nullptr;
+    f.in.B = batch; f.in.H = H; f.in.W = W; f.in.c_skip = cin; f.in.c_prev = 0; f.in.Hp = 1; f.in.Wp = 1; f.in.coords = 0; f.in.prev_mode = HS_PREV_NONE;
+    f.in.step_x = f.in.step_y = 0.0f; f.in.scale_y = f.in.scale_x = 1.0f;
+    f.fh = fh; f.fw = fw; f.ph = ph; f.pw = pw; f.bank = bank; f.ld = ld;
+    f.cout = c_out; f.groups = 1; f.cin_g = cin; f.cout_g = c_out;
+    f.scale = nullptr; f.shift = nullptr; f.act = HS_ACT_NONE; f.y = reinterpret_cast<float*>(y);
+    const int outs = c_out * ph * pw;
+    int split = 1;
+    while (split < 64 && outs * split * 2 <= CONV_THREADS && split * 2 <= cin) split *= 2;
+    f.split = split;
+    const dim3 grid((unsigned)((long)batch * fh * fw));
+    if (ph == pw && ph == 1) hipLaunchKernelGGL((patch_conv1x1_kernel<0, bf16_t>), grid, dim3(CONV_THREADS), lds1, stream, f);
+    else if (ph == pw && ph == 2) hipLaunchKernelGGL((patch_conv1x1_kernel<1, bf16_t>), grid, dim3(CONV_THREADS), lds1, stream, f);
+    else if (ph == pw && ph == 4) hipLaunchKernelGGL((patch_conv1x1_kernel<2, bf16_t>), grid, dim3(CONV_THREADS), lds1, stream, f);
+    else if (ph == pw && ph == 8) hipLaunchKernelGGL((patch_conv1x1_kernel<3, bf16_t>), grid, dim3(CONV_THREADS), lds1, stream, f);
+    else hipLaunchKernelGGL((patch_conv1x1_kernel<-1, bf16_t>), grid, dim3(CONV_THREADS), lds1, stream, f);
+    return launch_status();
+}
+}  // namespace hs
 
 extern "C" int hs_patch_conv_fwd(const hs_stage_input* in, int32_t fh, int32_t fw, const float* bank, int64_t ld,
                                  int32_t c_out, int32_t k, int32_t pad, int32_t pad_mode, int32_t groups,

@@ -193,6 +193,13 @@ static int fill_plain(PlainArgs& a, int64_t ld, int32_t batch, int32_t c_in, int
 
 }  // namespace hs
 
+namespace hs {
+int launch_conv1x1_bf16(const void* x, int batch, int cin, int H, int W, int fh, int fw, const float* bank, long ld, int c_out, void* y,
+                        hipStream_t stream);                                                         // hs_patch_conv.hip
+}
+#ifndef HS_PLAIN_K1_BF16
+#define HS_PLAIN_K1_BF16 1
+#endif
 using namespace hs;
 
 #define HS_BY_DTYPE(dtype, CALL_F32, CALL_BF16) \
@@ -208,6 +215,10 @@ extern "C" int hs_patch_conv_plain_fwd(int32_t dtype, const void* x, const void*
     {
         const int r = try_fast_fwd(dtype, x, bank, (long)ld, batch, c_in, H, W, fh, fw, c_out, k, pad, pad_mode, groups, nullptr, nullptr,
                                    HS_ACT_NONE, y, (hipStream_t)stream);
+        if (r != 1) return r;
+    }
+    if (dtype == HS_DTYPE_BF16 && k == 1 && pad == 0 && groups == 1 && HS_PLAIN_K1_BF16) {     // tiny patches in bf16: the inference path's k = 1 form, typed (round 6)
+        const int r = launch_conv1x1_bf16(x, batch, c_in, H, W, fh, fw, (const float*)bank, (long)ld, c_out, y, (hipStream_t)stream);
         if (r != 1) return r;
     }
     a.x = x; a.bank = bank; a.y = y;
