@@ -100,7 +100,14 @@ template <> struct Pair<bf16_t> {
     static __device__ __forceinline__ void ld(const bf16_t* p, size_t i, float& a, float& b) {
         const uint32_t v = *reinterpret_cast<const uint32_t*>(p + i); a = __uint_as_float(v << 16); b = __uint_as_float(v & 0xffff0000u);
     }
-    static __device__ __forceinline__ void st(bf16_t* p, size_t i, float a, float b) { Store<bf16_t>::st(p, i, a); Store<bf16_t>::st(p, i + 1, b); }
+    // one 4-byte store of the two rounded values (round 6: two 2-byte stores before; Store<bf16_t>::st's rounding, NaN stays NaN)
+    static __device__ __forceinline__ uint32_t bits(float x) {
+        uint32_t u = __float_as_uint(x);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40;
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return u >> 16;
+    }
+    static __device__ __forceinline__ void st(bf16_t* p, size_t i, float a, float b) { *reinterpret_cast<uint32_t*>(p + i) = bits(a) | (bits(b) << 16); }
 };
 
 // Slices a training-mode BatchNorm channel is cut into: partial[(c * BN_CHUNKS + chunk) * 2 + {0, 1}] = {sum, sum of squares} of
