@@ -166,10 +166,16 @@ struct ConvBn {
 };
 // BNL (round 5): the layer's input is act(BatchNorm(x)) with x RAW in memory -- normalised on use from the saved statistics (the weight
 // gradient of patch_conv_bn_fwd_k1m_kernel's layer); a lane's NTI input channels are fixed, so their (scale, shift) sit in registers.
+// four consecutive elements as one aligned load: 16 bytes of fp32, 8 bytes of bf16 (widened)
+__device__ __forceinline__ bw_f32x4 quad_ld(const float* __restrict__ p) { return *reinterpret_cast<const bw_f32x4*>(p); }
+__device__ __forceinline__ bw_f32x4 quad_ld(const bf16_t* __restrict__ p) {
+    typedef unsigned q2u __attribute__((ext_vector_type(2)));
+    const q2u v = *reinterpret_cast<const q2u*>(p);
+    return bw_f32x4{__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] << 16), __uint_as_float(v[1] & 0xffff0000u)};
+}
 template <int MT, int NTI, int VEC, typename T, bool BNL = false>
 __global__ __launch_bounds__(256)
 void patch_conv_bwd_weight_k1m_kernel(ConvBwdArgs a, ConvBn bn) {
-    static_assert(VEC != 1 || sizeof(T) == 4, "16-byte loads: fp32 storage only (pairs serve both storage types)");
     __shared__ __attribute__((aligned(16))) float red[4][MT * NTI][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kg = lane >> 4;
@@ -216,9 +222,9 @@ void patch_conv_bwd_weight_k1m_kernel(ConvBwdArgs a, ConvBn bn) {
             const int l = min(16 * s + 4 * kg, npix - 4), u = div_by_inv(l, a.inv_pw), v = l - u * a.pw;   // pw % 4 == 0: the lane's 4 pixels are one row segment (clamped: chunks past the end are fetched, never used)
             const size_t off = (size_t)u * a.W + v;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const bw_f32x4*>((const float*)dyp[mt] + off);
+            for (int mt = 0; mt < MT; ++mt) av[mt] = quad_ld(dyp[mt] + off);        // 16 bytes (fp32) / 8 bytes (bf16: round 6 -- pairs before)
 #pragma unroll
-            for (int nt = 0; nt < NTI; ++nt) bv[nt] = *reinterpret_cast<const bw_f32x4*>((const float*)xp[nt] + off);
+            for (int nt = 0; nt < NTI; ++nt) bv[nt] = quad_ld(xp[nt] + off);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1230,13 +1236,14 @@ int hs::try_fast_bwd_w(int dtype, const void* x, const void* dy, int batch, int 
         return launch_status();
     }
     if (k != 1 || groups != 1 || a.ph * a.pw < 16) return 1;
-    const bool vec = dtype == HS_DTYPE_F32 && (a.pw & 3) == 0 && ((a.ph * a.pw) & 15) == 0 && (W & 3) == 0 &&
-                     ((((size_t)x) | ((size_t)dy)) & 15) == 0;
+    const bool vec = (a.pw & 3) == 0 && ((a.ph * a.pw) & 15) == 0 && (W & 3) == 0 &&
+                     ((((size_t)x) | ((size_t)dy)) & (dtype == HS_DTYPE_F32 ? 15 : 7)) == 0;           // four elements per load, either storage type
     const int mt = (c_out + 15) / 16, nt = (c_in + 15) / 16;
     const dim3 grid((unsigned)(batch * fh * fw));
     const bool pairs = !vec && (a.pw & 1) == 0 && (W & 1) == 0 && ((((size_t)x) | ((size_t)dy)) & 7) == 0;       // either storage type
 #define HS_BW(MTV, NTV) if (mt == MTV && nt == NTV) { \
-        if (vec) hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 1, float>), grid, dim3(256), 0, stream, a, ConvBn{}); \
+        if (vec) HS_T2(dtype, hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 1, float>), grid, dim3(256), 0, stream, a, ConvBn{}), \
+                              hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 1, bf16_t>), grid, dim3(256), 0, stream, a, ConvBn{})); \
         else if (pairs) HS_T2(dtype, hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 2, float>), grid, dim3(256), 0, stream, a, ConvBn{}), \
                                      hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 2, bf16_t>), grid, dim3(256), 0, stream, a, ConvBn{})); \
         else HS_T2(dtype, hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 0, float>), grid, dim3(256), 0, stream, a, ConvBn{}), \
@@ -1526,12 +1533,13 @@ extern "C" int hs_patch_conv_bn_bwd_w(int32_t dtype, const void* x, const void* 
     const int mt = (c_out + 15) / 16, nt = (c_in + 15) / 16;
     if (a.ph * a.pw < 16 || mt > 2 || nt > 4) return HS_ERR_UNSUPPORTED;
     ConvBn bn{nullptr, gamma, beta, const_cast<float*>(save_mean), const_cast<float*>(save_invstd), nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, act};
-    const bool vec = dtype == HS_DTYPE_F32 && (a.pw & 3) == 0 && ((a.ph * a.pw) & 15) == 0 && (W & 3) == 0 && ((((size_t)x) | ((size_t)dy)) & 15) == 0;
+    const bool vec = (a.pw & 3) == 0 && ((a.ph * a.pw) & 15) == 0 && (W & 3) == 0 && ((((size_t)x) | ((size_t)dy)) & (dtype == HS_DTYPE_F32 ? 15 : 7)) == 0;
     const bool pairs = !vec && (a.pw & 1) == 0 && (W & 1) == 0 && ((((size_t)x) | ((size_t)dy)) & 7) == 0;
     const dim3 grid((unsigned)(batch * fh * fw));
     hipStream_t s = (hipStream_t)stream;
 #define HS_BWB(MTV, NTV) if (mt == MTV && nt == NTV) { \
-        if (vec) hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 1, float, true>), grid, dim3(256), 0, s, a, bn); \
+        if (vec) HS_T2(dtype, hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 1, float, true>), grid, dim3(256), 0, s, a, bn), \
+                              hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 1, bf16_t, true>), grid, dim3(256), 0, s, a, bn)); \
         else if (pairs) HS_T2(dtype, hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 2, float, true>), grid, dim3(256), 0, s, a, bn), \
                                      hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 2, bf16_t, true>), grid, dim3(256), 0, s, a, bn)); \
         else HS_T2(dtype, hipLaunchKernelGGL((patch_conv_bwd_weight_k1m_kernel<MTV, NTV, 0, float, true>), grid, dim3(256), 0, s, a, bn), \
