@@ -438,6 +438,82 @@ __device__ __forceinline__ void bn_block_sum2(float& s0, float& s1, float (*red)
     s1 = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
 }
 
+__device__ __forceinline__ float bn_act(float z, int act) { return act == HS_ACT_RELU ? fmaxf(z, 0.f) : (act == HS_ACT_RELU6 ? fminf(fmaxf(z, 0.f), 6.f) : z); }
+__device__ __forceinline__ float bn_act_grad(float z, int act) {
+    return act == HS_ACT_RELU ? (z > 0.f ? 1.f : 0.f) : (act == HS_ACT_RELU6 ? ((z > 0.f && z < 6.f) ? 1.f : 0.f) : 1.f);
+}
+
+// ---- bf16 storage, PAIR mode (round 6): a lane takes two adjacent elements per step (one 4-byte load / store) -- the one-element walk moves 2 bytes per
+// lane and instruction and did not get faster with the bytes bf16 saves (bn_bwd_apply 16.2 us against fp32's 22.7 for half the bytes).  Needs an even
+// HW >= 256 (pairs stay inside an image; at most two image boundaries per step -- the 18 x 18 tiles of the patch-major tile tensor are 324); slices are cut in pairs (a slice's share of the channel differs from the
+// one-element walk's: only the association of the 32 slice sums changes).  fp32 keeps the one-element walk: its sums stay bit-identical to round 5's.
+__device__ __forceinline__ bool bn_pairs_ok(const BnArgs& a) { return (a.HW & 1) == 0 && a.HW >= 256; }
+__device__ __forceinline__ void bn_slice2(const BnArgs& a, int chunk, int& lo2, int& hi2) {        // in pairs
+    const int n2 = (a.B * a.HW) >> 1, per2 = (n2 + BN_CHUNKS - 1) / BN_CHUNKS;
+    lo2 = min(chunk * per2, n2); hi2 = min(lo2 + per2, n2);
+}
+struct BnWalk2 {
+    int e2, b, p;                                                     // pair index in the channel; its first element's image and position
+    __device__ __forceinline__ BnWalk2(const BnArgs& a, int lo2) { e2 = lo2 + (int)threadIdx.x; const int e = 2 * e2; b = e / a.HW; p = e - b * a.HW; }
+    __device__ __forceinline__ size_t at(const BnArgs& a, int c) const { return ((size_t)b * a.C + c) * a.HW + p; }
+    __device__ __forceinline__ void next(const BnArgs& a) {           // 512 elements on: at most two image boundaries (HW >= 256), taken as selects
+        e2 += 256; p += 512;
+        bool wrap = p >= a.HW; p -= wrap ? a.HW : 0; b += wrap ? 1 : 0;
+        wrap = p >= a.HW; p -= wrap ? a.HW : 0; b += wrap ? 1 : 0;
+    }
+};
+__device__ __forceinline__ void bn_unpack2(uint32_t r, float& v0, float& v1) { v0 = __uint_as_float(r << 16); v1 = __uint_as_float(r & 0xffff0000u); }
+// KIND 0: forward statistics (s, q about `k0` = shift); 1: forward apply (y = act(x k0 + ms)); 2: backward statistics; 3: backward apply
+template <int KIND>
+__device__ __forceinline__ void bn_pair_walk(const BnArgs& a, const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, bf16_t* __restrict__ out, int c,
+                                             int chunk, float mean, float invstd, float g, float bb, float k0, float ms, float mq, float& s, float& q) {
+    int lo2, hi2;
+    bn_slice2(a, chunk, lo2, hi2);
+    const size_t at0 = (size_t)c * a.HW;
+    for (BnWalk2 w(a, lo2); w.e2 < hi2;) {
+        uint32_t vx[BN_BATCH], vd[BN_BATCH];
+        size_t at[BN_BATCH];
+        const int e0 = w.e2;
+#pragma unroll
+        for (int u = 0; u < BN_BATCH; ++u) {
+            at[u] = w.e2 < hi2 ? w.at(a, c) : at0;
+            vx[u] = *reinterpret_cast<const uint32_t*>(x + at[u]);
+            if (KIND >= 2) vd[u] = *reinterpret_cast<const uint32_t*>(dy + at[u]);
+            w.next(a);
+        }
+#pragma unroll
+        for (int u = 0; u < BN_BATCH; ++u)
+            if (e0 + 256 * u < hi2) {
+                float xv[2], dv[2] = {0.f, 0.f}, o[2];
+                bn_unpack2(vx[u], xv[0], xv[1]);
+                if (KIND >= 2) bn_unpack2(vd[u], dv[0], dv[1]);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (KIND == 0) { const float d = xv[h] - k0; s += d; q = fmaf(d, d, q); }
+                    else if (KIND == 1) o[h] = bn_act(fmaf(xv[h], k0, ms), a.act);
+                    else {
+                        const float xh = (xv[h] - mean) * invstd;
+                        const float d = dv[h] * bn_act_grad(fmaf(xh, g, bb), a.act);
+                        if (KIND == 3) o[h] = k0 * (d - ms - xh * mq);
+                        else { s += d; q = fmaf(d, xh, q); }
+                    }
+                }
+                if (KIND == 1 || KIND == 3) Pair<bf16_t>::st(out, at[u], o[0], o[1]);
+            }
+    }
+}
+template <int KIND, typename T>
+__device__ __forceinline__ bool bn_try_pairs(const BnArgs& a, const T* x, const T* dy, T* out, int c, int chunk, float mean, float invstd, float g, float bb,
+                                             float k0, float ms, float mq, float& s, float& q) {
+    if constexpr (sizeof(T) == 2) {
+        if (bn_pairs_ok(a) && ((((size_t)x) | ((size_t)dy) | ((size_t)out)) & 3) == 0) {        // (4-byte aligned tensors: every pair is)
+            bn_pair_walk<KIND>(a, x, dy, out, c, chunk, mean, invstd, g, bb, k0, ms, mq, s, q);
+            return true;
+        }
+    }
+    return false;
+}
+
 template <typename T, bool BIG>
 __device__ __forceinline__ void bn_stats_walk(const BnArgs& a, const T* __restrict__ x, int c, int lo, int hi, float shift, float& s, float& q) {
     for (BnWalk w(a, lo); w.e < hi;) {
@@ -462,16 +538,13 @@ void bn_stats_kernel(BnArgs a, const T* __restrict__ x, float* __restrict__ part
     int lo, hi;
     bn_slice(a, chunk, lo, hi);
     float s = 0.f, q = 0.f;
-    if (a.HW >= 256) bn_stats_walk<T, true>(a, x, c, lo, hi, shift, s, q);
+    if (bn_try_pairs<0, T>(a, x, (const T*)nullptr, (T*)nullptr, c, chunk, 0.f, 0.f, 0.f, 0.f, shift, 0.f, 0.f, s, q)) {}
+    else if (a.HW >= 256) bn_stats_walk<T, true>(a, x, c, lo, hi, shift, s, q);
     else bn_stats_walk<T, false>(a, x, c, lo, hi, shift, s, q);
     bn_block_sum2(s, q, red);
     if (threadIdx.x == 0) { partial[((size_t)c * BN_CHUNKS + chunk) * 2] = s; partial[((size_t)c * BN_CHUNKS + chunk) * 2 + 1] = q; }
 }
 
-__device__ __forceinline__ float bn_act(float z, int act) { return act == HS_ACT_RELU ? fmaxf(z, 0.f) : (act == HS_ACT_RELU6 ? fminf(fmaxf(z, 0.f), 6.f) : z); }
-__device__ __forceinline__ float bn_act_grad(float z, int act) {
-    return act == HS_ACT_RELU ? (z > 0.f ? 1.f : 0.f) : (act == HS_ACT_RELU6 ? ((z > 0.f && z < 6.f) ? 1.f : 0.f) : 1.f);
-}
 
 template <typename T, bool BIG>
 __device__ __forceinline__ void bn_apply_walk(const BnArgs& a, const T* __restrict__ x, T* __restrict__ y, int c, int lo, int hi, float g, float bb) {
@@ -511,7 +584,9 @@ void bn_apply_kernel(BnArgs a, const T* __restrict__ x, const float* __restrict_
     const float g = gamma ? gamma[c] * invstd : invstd, bb = (beta ? beta[c] : 0.f) - mean * g;
     int lo, hi;
     bn_slice(a, chunk, lo, hi);
-    if (a.HW >= 256) bn_apply_walk<T, true>(a, x, y, c, lo, hi, g, bb);
+    float z0 = 0.f, z1 = 0.f;
+    if (bn_try_pairs<1, T>(a, x, (const T*)nullptr, y, c, chunk, 0.f, 0.f, 0.f, 0.f, g, bb, 0.f, z0, z1)) {}
+    else if (a.HW >= 256) bn_apply_walk<T, true>(a, x, y, c, lo, hi, g, bb);
     else bn_apply_walk<T, false>(a, x, y, c, lo, hi, g, bb);
 }
 
@@ -553,7 +628,8 @@ void bn_bwd_stats_kernel(BnArgs a, const T* __restrict__ x, const T* __restrict_
     int lo, hi;
     bn_slice(a, chunk, lo, hi);
     float s = 0.f, q = 0.f;
-    if (a.HW >= 256) bn_bwd_walk<T, true, false>(a, x, dy, (T*)nullptr, c, lo, hi, mean, invstd, g, bb, 0.f, 0.f, 0.f, s, q);
+    if (bn_try_pairs<2, T>(a, x, dy, (T*)nullptr, c, chunk, mean, invstd, g, bb, 0.f, 0.f, 0.f, s, q)) {}
+    else if (a.HW >= 256) bn_bwd_walk<T, true, false>(a, x, dy, (T*)nullptr, c, lo, hi, mean, invstd, g, bb, 0.f, 0.f, 0.f, s, q);
     else bn_bwd_walk<T, false, false>(a, x, dy, (T*)nullptr, c, lo, hi, mean, invstd, g, bb, 0.f, 0.f, 0.f, s, q);
     bn_block_sum2(s, q, red);
     if (threadIdx.x == 0) { partial[((size_t)c * BN_CHUNKS + chunk) * 2] = s; partial[((size_t)c * BN_CHUNKS + chunk) * 2 + 1] = q; }
@@ -575,7 +651,8 @@ void bn_bwd_apply_kernel(BnArgs a, const T* __restrict__ x, const T* __restrict_
     int lo, hi;
     bn_slice(a, chunk, lo, hi);
     float u0 = 0.f, u1 = 0.f;
-    if (a.HW >= 256) bn_bwd_walk<T, true, true>(a, x, dy, dx, c, lo, hi, mean, invstd, g, bb, k0, ms, mq, u0, u1);
+    if (bn_try_pairs<3, T>(a, x, dy, dx, c, chunk, mean, invstd, g, bb, k0, ms, mq, u0, u1)) {}
+    else if (a.HW >= 256) bn_bwd_walk<T, true, true>(a, x, dy, dx, c, lo, hi, mean, invstd, g, bb, k0, ms, mq, u0, u1);
     else bn_bwd_walk<T, false, true>(a, x, dy, dx, c, lo, hi, mean, invstd, g, bb, k0, ms, mq, u0, u1);
 }
 
@@ -598,7 +675,8 @@ void bn_bwd_apply_np_kernel(BnArgs a, const T* __restrict__ x, const T* __restri
     int lo, hi;
     bn_slice(a, chunk, lo, hi);
     float u0 = 0.f, u1 = 0.f;
-    if (a.HW >= 256) bn_bwd_walk<T, true, true>(a, x, dy, dx, c, lo, hi, mean, invstd, g, bb, k0, ms, mq, u0, u1);
+    if (bn_try_pairs<3, T>(a, x, dy, dx, c, chunk, mean, invstd, g, bb, k0, ms, mq, u0, u1)) {}
+    else if (a.HW >= 256) bn_bwd_walk<T, true, true>(a, x, dy, dx, c, lo, hi, mean, invstd, g, bb, k0, ms, mq, u0, u1);
     else bn_bwd_walk<T, false, true>(a, x, dy, dx, c, lo, hi, mean, invstd, g, bb, k0, ms, mq, u0, u1);
 }
 
