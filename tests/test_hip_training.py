@@ -425,6 +425,34 @@ def test_fused_training_batchnorm_vs_stock(dev, shape, act):
     assert int(bn1.num_batches_tracked) == int(bn0.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize('act', [None, 'relu6'])
+@pytest.mark.parametrize('shape', [(2, 6, 200, 160), (2, 4, 96, 86), (648, 5, 18, 18), (1, 3, 300, 211), (2, 5, 129, 133)])
+def test_fused_training_batchnorm_bf16_storage_vs_the_fp32_kernels(dev, shape, act):
+    """hs_bn_act_train_fwd / _bwd on bf16 storage (round 6: a lane takes PAIRS of elements where the plane is even and >= 256 -- the first three
+    shapes, the third the patch-major tile tensor's 18 x 18 planes with two image boundaries per step -- and single elements otherwise) against the
+    same kernels on the widened input: the output within one bf16 rounding of the fp32 result, gradients and statistics at bf16's resolution."""
+    import copy
+    from hyperseg_amd import autograd as HA
+    g = torch.Generator().manual_seed(shape[0] + shape[2])
+    bn0 = torch.nn.BatchNorm2d(shape[1], momentum=0.1).to(dev).train()
+    with torch.no_grad():
+        bn0.weight.copy_(torch.rand(shape[1], generator=g) + 0.5)
+        bn0.bias.copy_(torch.randn(shape[1], generator=g) * 0.5)
+    bn1 = copy.deepcopy(bn0)
+    layer = None if act is None else torch.nn.ReLU6()
+    x = (torch.randn(shape, generator=g) * 2 + torch.randn(1, shape[1], 1, 1, generator=g)).to(dev).bfloat16()
+    r = torch.randn(shape, generator=g).to(dev)
+    xa, xb = x.float().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = HA.bn_act(bn0, layer, xa), HA.bn_act(bn1, layer, xb)
+    assert yb.dtype == torch.bfloat16
+    (ya * r).sum().backward()
+    (yb.float() * r).sum().backward()
+    assert rel_err(yb.detach().float().cpu(), ya.detach().cpu()) < 8e-3                 # one bf16 rounding of values up to the tensor's scale
+    assert rel_l2(xb.grad.float().cpu(), xa.grad.cpu()) < 2e-2
+    assert rel_l2(bn1.weight.grad.cpu(), bn0.weight.grad.cpu()) < 2e-2 and rel_l2(bn1.bias.grad.cpu(), bn0.bias.grad.cpu()) < 2e-2
+    assert torch.allclose(bn1.running_mean, bn0.running_mean, rtol=1e-5, atol=1e-6) and torch.allclose(bn1.running_var, bn0.running_var, rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('case', [dict(b=2, cs=4, cp=16, hw=(36, 24), up=True, coords=True), dict(b=1, cs=28, cp=64, hw=(18, 18), up=True, coords=True),
                                   dict(b=2, cs=5, cp=3, hw=(10, 14), up=False, coords=True), dict(b=2, cs=6, cp=0, hw=(9, 8), up=False, coords=True),
